@@ -1,0 +1,228 @@
+"""
+Generates tests/golden/*.npz by importing the REFERENCE (read-only at /root/reference) in this
+container and recording its outputs on closed-form inputs and weights.  Run once here:
+
+    python tests/golden/make_golden.py
+
+The reference itself never travels: only these inputs/outputs do.  Three third-party modules
+that the reference imports are absent from the image and are stubbed *for import only*:
+``torchaudio.transforms.AmplitudeToDB`` (unused by every fixture), ``librosa.hz_to_midi``
+(the documented one-line formula) and ``cqt_pytorch.CQT`` (replaced by tests/golden/stub_cqt.py,
+so no fixture pins CQT *values* -- see oracle/nsgt.py header: parity unpinned).
+"""
+
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import stub_cqt  # noqa: E402
+from oracle import autoencoder as oae  # noqa: E402  (closed-form weights + shape helper only)
+
+STUB_BLOCK, STUB_M = 64, 16
+
+
+def install_stubs():
+    ta = types.ModuleType('torchaudio')
+    tat = types.ModuleType('torchaudio.transforms')
+
+    class AmplitudeToDB(nn.Module):
+        def __init__(self, stype='power', top_db=None):
+            super().__init__()
+    tat.AmplitudeToDB = AmplitudeToDB
+    ta.transforms = tat
+    sys.modules['torchaudio'] = ta
+    sys.modules['torchaudio.transforms'] = tat
+
+    cp = types.ModuleType('cqt_pytorch')
+
+    class CQT(nn.Module):
+        def __init__(self, num_octaves, num_bins_per_octave, sample_rate, block_length, power_of_2_length=False):
+            super().__init__()
+            self._n_bins = num_octaves * num_bins_per_octave
+            self.block_length = block_length
+            self.max_window_length = 1024 if block_length == 66150 else STUB_M
+
+        def encode(self, audio):
+            return stub_cqt.stub_encode(audio, self._n_bins, self.block_length, self.max_window_length)
+    cp.CQT = CQT
+    sys.modules['cqt_pytorch'] = cp
+
+    lb = types.ModuleType('librosa')
+    lb.hz_to_midi = lambda f: 12 * (np.log2(np.asanyarray(f)) - np.log2(440.0)) + 69
+    sys.modules['librosa'] = lb
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def load_closed_form(module, prefix_filter=None, **kw):
+    """Fill a reference module with closed-form weights keyed by ITS OWN state_dict order."""
+    shapes = {k: tuple(v.shape) for k, v in module.state_dict().items()}
+    sd = oae.closed_form_state_dict(shapes, **kw)
+    module.load_state_dict(sd)
+    return sd
+
+
+def main():
+    install_stubs()
+    sys.path.insert(0, '/root/reference')
+    import timbre_trap.framework as ref
+    from timbre_trap.framework import objectives as robj
+    torch.manual_seed(0)
+    torch.set_grad_enabled(True)
+
+    # ---- 1. blocks --------------------------------------------------------------------------
+    out = {}
+    x = stub_cqt.closed_form_coefficients(1, 12, 10)[:, :1].repeat(1, 4, 1, 1) * \
+        torch.tensor([1.0, -0.5, 0.25, 2.0]).view(1, 4, 1, 1)
+    out['res_x'] = npy(x)
+    for d in (1, 2, 3):
+        m = ref.ResidualConv2dBlock(4, 4, kernel_size=3, dilation=d)
+        sd = load_closed_form(m)
+        out[f'res_d{d}_y'] = npy(m(x))
+        for k, v in sd.items():
+            out[f'res_d{d}_sd.{k}'] = npy(v)
+
+    xe = stub_cqt.closed_form_coefficients(2, 13, 6)               # (2,2,13,6)
+    m = ref.EncoderBlock(2, 4)
+    sd = load_closed_form(m)
+    out['encblk_x'] = npy(xe)
+    out['encblk_y'] = npy(m(xe))
+    for k, v in sd.items():
+        out[f'encblk_sd.{k}'] = npy(v)
+    xd = stub_cqt.closed_form_coefficients(2, 5, 6).repeat(1, 2, 1, 1)   # (2,4,5,6)
+    out['decblk_x'] = npy(xd)
+    for p in (0, 1):
+        m = ref.DecoderBlock(4, 2, padding=p)
+        sd = load_closed_form(m)
+        out[f'decblk_p{p}_y'] = npy(m(xd))
+        for k, v in sd.items():
+            out[f'decblk_p{p}_sd.{k}'] = npy(v)
+    np.savez_compressed(os.path.join(HERE, 'blocks.npz'), **out)
+
+    # ---- 2. encoder / decoder at F=540 -------------------------------------------------------
+    out = {}
+    for mc, lat in ((1, None), (2, 128)):
+        enc = ref.Encoder(540, lat, mc)
+        dec = ref.Decoder(540, lat, mc)
+        load_closed_form(enc)
+        load_closed_form(dec)
+        coeffs = stub_cqt.closed_form_coefficients(1, 540, 6)
+        latents, emb, _ = enc(coeffs)
+        out[f'mc{mc}_latents'] = npy(latents)
+        for i, e in enumerate(emb):
+            out[f'mc{mc}_emb{i}'] = npy(e)
+        ind = torch.ones_like(latents[..., :1, :])
+        out[f'mc{mc}_dec'] = npy(dec(torch.cat((latents, ind), -2)))
+        out[f'mc{mc}_dec_skip'] = npy(dec(torch.cat((latents, 0 * ind), -2), emb))
+    np.savez_compressed(os.path.join(HERE, 'encdec.npz'), **out)
+
+    # ---- 3. TimbreTrap.forward / inference / chunked_inference with the stub transform -------
+    out = {}
+    secs = (STUB_BLOCK + 0.5) / 22050
+    for tag, kw in (('mc1', dict(model_complexity=1)),
+                    ('mc2skip', dict(model_complexity=2, latent_size=128, skip_connections=True))):
+        model = ref.TimbreTrap(22050, 9, 60, secs, **kw)
+        assert model.sliCQ.block_length == STUB_BLOCK
+        load_closed_form(model)
+        audio = stub_cqt.closed_form_audio(2, STUB_BLOCK)
+        res = model(audio, consistency=True)
+        for name, t in zip(('reconstruction', 'latents', 'transcription', 'transcription_rec', 'transcription_scr'), res[:5]):
+            out[f'{tag}_fwd_{name}'] = npy(t)
+        out[f'{tag}_act'] = npy(model.to_activations(res[2]))
+        res_nc = model(audio, consistency=False)
+        assert res_nc[3] is None and res_nc[4] is None and res_nc[5] == {}
+        long_audio = stub_cqt.closed_form_audio(1, int(2.5 * STUB_BLOCK))
+        model.eval()
+        out[f'{tag}_chunked_trn'] = npy(model.chunked_inference(long_audio, True))
+        out[f'{tag}_chunked_rec'] = npy(model.chunked_inference(long_audio, False))
+        out[f'{tag}_inference'] = npy(model.inference(long_audio, False))
+        out[f'{tag}_transcribe'] = npy(model.transcribe(long_audio))
+        model.train()
+
+        # gradients of the train.py total loss w.r.t. every parameter (tiny case)
+        coeffs = model.sliCQ(audio)
+        gt = stub_cqt.closed_form_targets(2, 540, STUB_M)
+        rec, lat, trn, trn_rec, trn_scr, _ = model(audio, True)
+        act = model.to_activations(trn)
+        l_rec = robj.compute_reconstruction_loss(rec, coeffs)
+        l_trn = robj.compute_transcription_loss(act, gt, True)
+        l_sp, l_sc = robj.compute_consistency_loss(trn_rec, trn_scr, trn)
+        total = l_rec + l_trn + (l_sp + l_sc)
+        model.zero_grad()
+        total.backward()
+        out[f'{tag}_losses'] = np.array([float(l_rec), float(l_trn), float(l_sp), float(l_sc), float(total)], dtype=np.float64)
+        for k, p in model.named_parameters():
+            g = p.grad.double().flatten()
+            if tag == 'mc1':
+                out[f'{tag}_grad.{k}'] = npy(p.grad)
+            else:   # keep the fixture small: [sum, L2 norm, first 6 values]
+                out[f'{tag}_gradstat.{k}'] = npy(torch.cat([g.sum().view(1), g.norm().view(1), g[:6]]))
+    np.savez_compressed(os.path.join(HERE, 'model.npz'), **out)
+
+    # ---- 4. objectives ----------------------------------------------------------------------
+    out = {}
+    a = stub_cqt.closed_form_coefficients(2, 540, 5).requires_grad_(True)
+    b = (stub_cqt.closed_form_coefficients(2, 540, 5) * 0.7 + 0.1).flip(-1).requires_grad_(True)
+    l = robj.compute_reconstruction_loss(a, b)
+    ga, gb = torch.autograd.grad(l, (a, b))
+    out['rec_loss'] = np.float64(float(l))
+    out['rec_ga_sum'] = npy(ga.abs().sum())
+    out['rec_ga'] = npy(ga[:, :, ::45])
+    out['rec_gb'] = npy(gb[:, :, ::45])
+    est = torch.sigmoid(stub_cqt.closed_form_coefficients(2, 540, 7)[:, 0]).requires_grad_(True)
+    tgt = stub_cqt.closed_form_targets(2, 540, 7)
+    assert (tgt == 1).any() and (tgt.sum(-2) == 0).any()
+    for w in (False, True):
+        l = robj.compute_transcription_loss(est, tgt, w)
+        g, = torch.autograd.grad(l, est)
+        out[f'trn_loss_w{int(w)}'] = np.float64(float(l))
+        out[f'trn_grad_w{int(w)}'] = npy(g)
+    tgt_ones = torch.ones(1, 540, 2)                  # neg == 0 -> zero scale -> forced to 1
+    l = robj.compute_transcription_loss(est[:1, :, :2], tgt_ones, True)
+    out['trn_loss_allones'] = np.float64(float(l))
+    sp, sc = robj.compute_consistency_loss(a, b, (a + b) / 2)
+    out['cons'] = np.array([float(sp), float(sc)])
+    np.savez_compressed(os.path.join(HERE, 'objectives.npz'), **out)
+
+    # ---- 5. wrapper arithmetic (cqtwrapper.py a5 helpers) on the real block length -----------
+    out = {}
+    cq = ref.CQT(9, 60, 22050, 3)
+    assert cq.block_length == 66150 and cq.max_window_length == 1024
+    out['hop_length'] = np.float64(cq.hop_length)
+    out['midi_freqs'] = cq.get_midi_freqs()
+    ns = np.array([0, 1, 64, 65, 66149, 66150, 66151, 100000, 132300, 165375, 198450, 1234567], dtype=np.int64)
+    out['frames_in'] = ns
+    out['frames_out'] = np.array([cq.get_expected_frames(int(n)) for n in ns], dtype=np.int64)
+    ts = np.array([-1.0, 0.0, 0.5, 2.9999, 3.0, 3.00001, 9.0, 12.345], dtype=np.float64)
+    out['samples_in'] = ts
+    out['samples_out'] = np.array([cq.get_expected_samples(float(t)) for t in ts], dtype=np.int64)
+    out['times_3100'] = cq.get_times(3100)
+    out['pad_lens_in'] = ns
+    out['pad_lens_out'] = np.array([cq.pad_to_block_length(torch.zeros(1, 1, int(n))).size(-1) for n in ns], dtype=np.int64)
+    c = stub_cqt.stub_encode(stub_cqt.closed_form_audio(2, STUB_BLOCK), 540, STUB_BLOCK, STUB_M)
+    r = ref.CQT.to_real(c)
+    out['to_real_in_re'], out['to_real_in_im'] = npy(c.real), npy(c.imag)
+    out['to_real_out'] = npy(r)
+    out['to_magnitude_out'] = npy(ref.CQT.to_magnitude(r))
+    cc = ref.CQT.to_complex(r)
+    out['to_complex_re'], out['to_complex_im'] = npy(cc.real), npy(cc.imag)
+    np.savez_compressed(os.path.join(HERE, 'wrapper.npz'), **out)
+
+    for fn in sorted(os.listdir(HERE)):
+        if fn.endswith('.npz'):
+            print(fn, os.path.getsize(os.path.join(HERE, fn)))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,198 @@
+/*
+ * ttrap.h -- C ABI of libttrap_hip.so, the MI355X (gfx950) implementation of the Timbre-Trap
+ * hot path:  NSGT constant-Q transform (forward / inverse)  ->  2-D strided-conv autoencoder
+ * (forward / backward)  ->  reconstruction / transcription / consistency losses  ->  clip + AdamW.
+ *
+ * The reference (sony/timbre-trap) is pure Python on stock torch ops and has no FFI of its own;
+ * each entry point below names the reference Python it replaces (file:line under /root/reference).
+ * The host side that binds these symbols is timbre-trap_amd/timbre_trap/_hip.py (ctypes); the
+ * reference-side binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer is DEVICE memory owned by the caller (torch tensors), contiguous, fp32 unless
+ *     stated; nothing is allocated or retained by the library; kernels are enqueued on `stream`
+ *     (a hipStream_t passed as void*; NULL = the null stream) and the call returns immediately.
+ *   - return value: 0 = ok, >0 = hipError_t of the failed launch, <0 = TT_E_* argument error.
+ *   - activations are NCHW with W = time contiguous:  (B, C, H, T).
+ *   - no CPU fallback exists: without the library the Python layer raises.
+ */
+#ifndef TTRAP_H
+#define TTRAP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TT_E_BADARG      (-1)
+#define TT_E_UNSUPPORTED (-2)
+
+#define TT_ACT_NONE 0
+#define TT_ACT_ELU  1
+
+/* Library / build identification. */
+int         tt_version(void);
+const char* tt_arch(void);               /* "gfx950" */
+const char* tt_error_string(int code);   /* hipGetErrorString for code > 0 */
+
+/* ------------------------------------------------------------------------------------------------
+ * NSGT constant-Q transform.  Replaces cqt_pytorch.CQT.encode / .decode as called from
+ * timbre_trap/framework/cqtwrapper.py:67 and :207, fused with CQT.to_real (:74-97) /
+ * CQT.to_complex (:99-120) and the inf-norm of CQT.decode (:209-211).
+ *
+ * Specialised for the reference configuration: block_length N = 66150 (3 s @ 22.05 kHz,
+ * N/2 = 33075 = 675 * 49), max_window_length M = 1024.  All conventions of the transform are
+ * data (tables built on the host by timbre_trap/framework/nsgt_plan.py):
+ *   tw675   [675]   float2  exp(-2 pi i j / 675)
+ *   tw49    [49]    float2  exp(-2 pi i j / 49)
+ *   twNc    [33075] float2  exp(-2 pi i j / 33075)
+ *   twN     [33076] float2  exp(-2 pi i j / 66150)
+ *   tw1024  [1024]  float2  exp(-2 pi i j / 1024)
+ *   bin_tab [F][4]  int32   {spec_start, pad, length, win_off} per bin
+ *   window  [sumL]  float   ragged analysis windows   (forward)
+ *   dual    [sumL]  float   ragged synthesis windows  (inverse)
+ *   gat_off [33077] int32 , gat_idx [sumL] int32   CSR: spectral index -> ragged positions
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    const float*   tw675;
+    const float*   tw49;
+    const float*   twNc;
+    const float*   twN;
+    const float*   tw1024;
+    const int32_t* bin_tab;
+    const float*   window;
+    const float*   dual;
+    const int32_t* gat_off;
+    const int32_t* gat_idx;
+    int32_t        n_bins;     /* F */
+    int32_t        sum_len;    /* sum of window lengths */
+} tt_cqt_plan;
+
+/* bytes of scratch the two calls below need for `n_clips` = B * n_blocks block-clips */
+int64_t tt_cqt_scratch_bytes(int n_clips, int n_bins, int sum_len);
+
+/* audio (B, 1, n_blocks*66150) -> out (B, 2, F, n_blocks*1024), ch0 = re, ch1 = im.
+ * If out_complex != 0 the output is interleaved complex64 (B, 1, F, n_blocks*1024) instead
+ * (CQT.encode, used raw by experiments/sonify.py:94). */
+int tt_cqt_forward(const tt_cqt_plan* plan, const float* audio, float* out, void* scratch,
+                   int B, int n_blocks, int out_complex, void* stream);
+
+/* coeffs (B, 2, F, n_blocks*1024) [or interleaved complex (B,1,F,T) if in_complex] ->
+ * audio (B, 1, n_blocks*66150).  normalize != 0 applies cqtwrapper.py:209-211
+ * (divide the whole tensor by its abs-max when that is non-zero) with no host round trip. */
+int tt_cqt_inverse(const tt_cqt_plan* plan, const float* coeffs, float* audio, void* scratch,
+                   int B, int n_blocks, int in_complex, int normalize, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Convolution stack.  Replaces torch.nn.Conv2d / ConvTranspose2d / ELU as used by
+ * timbre_trap/framework/modules.py (ResidualConv2dBlock :721-777, EncoderBlock :597-655,
+ * DecoderBlock :658-718, Encoder :396-483, Decoder :486-594) and their autograd backward.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* One general direct convolution, used for every layer shape of the model and, with swapped
+ * weight strides, for every data-gradient:
+ *   y[b,co,ho,t] = act( bias[co] + sum_{ci,kh,kw} w[co*ws_co + ci*ws_ci + kh*ws_kh + kw*ws_kw]
+ *                                               * x[b,ci,hi,ti] ) + (res ? res[b,co,ho,t] : 0)
+ *   ti = t + kw*dil_w - pad_w
+ *   transposed == 0 :  hi = ho*stride_h + kh*dil_h - pad_h
+ *   transposed == 1 :  hi = (ho + pad_h - kh*dil_h) / stride_h   when divisible (else no term)
+ * bias and res may be NULL.  Weight strides are signed (a flipped kernel = negative stride with
+ * `w` pointing at the last tap). */
+int tt_conv2d(const float* x, const float* w, const float* bias, const float* res, float* y,
+              int B, int Cin, int Hin, int T, int Cout, int Hout,
+              int KH, int KW, int stride_h, int dil_h, int dil_w, int pad_h, int pad_w,
+              int transposed, int64_t ws_co, int64_t ws_ci, int64_t ws_kh, int64_t ws_kw,
+              int act, void* stream);
+
+/* Weight + bias gradient of the same general convolution (transposed == 0 form):
+ *   dw[co*ws_co + ci*ws_ci + kh*ws_kh + kw*ws_kw] += sum_{b,ho,t} g[b,co,ho,t] * x[b,ci,hi,ti]
+ *   dbias[co] += sum g[b,co,:,:]          (dbias may be NULL)
+ * Accumulates (+=) into dw/dbias: zero them first for a plain gradient. */
+int tt_conv2d_wgrad(const float* x, const float* g, float* dw, float* dbias,
+                    int B, int Cin, int Hin, int T, int Cout, int Hout,
+                    int KH, int KW, int stride_h, int dil_h, int dil_w, int pad_h, int pad_w,
+                    int64_t ws_co, int64_t ws_ci, int64_t ws_kh, int64_t ws_kw, void* stream);
+
+/* g = dy * ELU'(a) expressed through the saved OUTPUT y = ELU(a):  ELU' = y > 0 ? 1 : y + 1. */
+int tt_elu_bwd(const float* dy, const float* y, float* g, int64_t n, void* stream);
+
+/* Fused ResidualConv2dBlock forward (modules.py:755-777):
+ *   y = ELU(W2 . ELU(W1 (*)_dil x + b1) + b2) + x      x,y: (B,C,H,T), W1 (C,C,3,3), W2 (C,C,1,1)
+ * Supported C: 2,4,8,16,32,64; dilation 1..3. */
+int tt_resblock_fwd(const float* x, const float* w1, const float* b1, const float* w2,
+                    const float* b2, float* y, int B, int C, int H, int T, int dilation,
+                    void* stream);
+
+/* Fused ResidualConv2dBlock backward, recomputing the two hidden activations from x:
+ *   inputs  x, dy            outputs  dx (written), dw1/db1/dw2/db2 (accumulated, +=)
+ * `ws` is scratch of B*C*H*T floats (holds dL/d(conv1 pre-activation)). */
+int tt_resblock_bwd(const float* x, const float* dy, const float* w1, const float* b1,
+                    const float* w2, const float* b2, float* dx, float* dw1, float* db1,
+                    float* dw2, float* db2, float* ws, int B, int C, int H, int T, int dilation,
+                    void* stream);
+
+/* Batched GEMM for the (31,1) latent layers (modules.py:446 and :534):
+ *   for each batch b:  C_b (M,N) = alpha * op(A_b) (M,K) . op(B_b) (K,N) + beta * C_b  [+ bias]
+ * row-major, leading dimensions lda/ldb/ldc, batch strides sa/sb/sc (0 = shared operand).
+ * If reduce_batch != 0 all batches are summed into ONE C (weight gradients).
+ * bias_mode: 0 none, 1 bias[m] per row, 2 bias[m / bias_div] (transposed-conv bias per channel).
+ * act = TT_ACT_ELU applies ELU after bias. */
+int tt_gemm(const float* A, const float* Bm, float* C, const float* bias,
+            int M, int N, int K, int transA, int transB, int64_t lda, int64_t ldb, int64_t ldc,
+            int batch, int64_t sa, int64_t sb, int64_t sc, int reduce_batch,
+            float alpha, float beta, int bias_mode, int bias_div, int act, void* stream);
+
+/* out[c] += sum over (b, inner) of x[b, c, inner]; x viewed as (B, C, inner). */
+int tt_channel_sum(const float* x, float* out, int B, int C, int64_t inner, void* stream);
+
+/* y = a + s[idx] * b  (skip connections, modules.py:112 and :569-589); s may be NULL (scale 1),
+ * a may be NULL (treated as 0). */
+int tt_scaled_add(const float* a, const float* b, const float* s, int idx, float* y, int64_t n,
+                  void* stream);
+/* out[0] += sum(a * b) : gradient of one skip weight. */
+int tt_dot(const float* a, const float* b, float* out, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Objectives.  Replace timbre_trap/framework/objectives.py and TimbreTrap.to_activations
+ * (modules.py:271-289).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* loss[0] = sum((a-b)^2) * scale     (compute_reconstruction_loss, objectives.py:11-33, with
+ * scale = 1/(B*T)).  `partials` is scratch of >= 1024 doubles. */
+int tt_sqdiff_sum(const float* a, const float* b, float* loss, double* partials, int64_t n,
+                  float scale, void* stream);
+/* da = 2*(a-b)*gscale[0]*scale ; db = -da   (either may be NULL) */
+int tt_sqdiff_bwd(const float* a, const float* b, const float* gscale, float scale, float* da,
+                  float* db, int64_t n, void* stream);
+
+/* act = tanh(sqrt(re^2 + im^2)) for coeffs (B,2,F,T) -> (B,F,T) */
+int tt_activations_fwd(const float* coeffs, float* act, int B, int F, int T, void* stream);
+int tt_activations_bwd(const float* coeffs, const float* act, const float* dact, float* dcoeffs,
+                       int B, int F, int T, void* stream);
+
+/* compute_transcription_loss (objectives.py:36-74). est,tgt: (B,F,T); loss[0] = mean over (B,T)
+ * of sum_F w*(est-tgt)^2;  `frame_scale` (B*T floats) receives the per-frame positive scaling
+ * for the backward pass; weighted = weight_positive_class. */
+int tt_transcription_loss_fwd(const float* est, const float* tgt, float* loss, float* frame_scale,
+                              double* partials, int B, int F, int T, int weighted, void* stream);
+int tt_transcription_loss_bwd(const float* est, const float* tgt, const float* frame_scale,
+                              const float* gscale, float* dest, int B, int F, int T, int weighted,
+                              void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimiser.  Replaces torch.nn.utils.clip_grad_norm_(params, max_norm) + torch.optim.AdamW.step
+ * (experiments/train.py:334, :493-496) over ONE flat fp32 buffer of n parameters.
+ * ---------------------------------------------------------------------------------------------- */
+/* norm_out[0] = ||grad||_2 ; partials: >= 1024 doubles of scratch */
+int tt_l2norm(const float* x, float* norm_out, double* partials, int64_t n, void* stream);
+/* clip coefficient c = min(1, max_norm / (norm[0] + 1e-6)) is applied to grad on the fly (and
+ * written back when write_clipped != 0, to match clip_grad_norm_'s in-place semantics). */
+int tt_adamw_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, const float* norm,
+                  int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                  int step, float max_norm, int write_clipped, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TTRAP_H */

@@ -1,0 +1,116 @@
+"""GPU parity of the HIP constant-Q transform (csrc/cqt.hip through tt_cqt_forward / tt_cqt_inverse) vs oracle/nsgt.py."""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nsgt
+
+pytestmark = pytest.mark.gpu
+N, M, SR = 66150, 1024, 22050
+REL = 1e-4          # north-star tolerance for CQT coefficients (fp32 HIP vs fp64 oracle)
+
+
+@pytest.fixture(scope='module')
+def tab():
+    return nsgt.nsgt_tables(9, 60, SR, N)
+
+
+@pytest.fixture(scope='module')
+def cqt():
+    from timbre_trap.framework import CQT
+    return CQT(9, 60, SR, 3).to('cuda')
+
+
+def _audio(B, nblk, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    a = torch.rand(B, 1, nblk * N, generator=g) * 2 - 1
+    return a / a.abs().amax(dim=-1, keepdim=True)
+
+
+def test_forward_matches_oracle(cqt, tab):
+    a = _audio(2, 2)
+    out = cqt(a.cuda())
+    assert out.shape == (2, 2, 540, 2 * M) and out.dtype == torch.float32 and out.is_contiguous()
+    ref = nsgt.wrapper_forward(a.numpy(), tab)
+    err = np.abs(out.cpu().numpy() - ref).max() / np.abs(ref).max()
+    assert err < REL, err
+    # per-bin relative error as well (low bins have small magnitudes)
+    o = out.cpu().numpy()
+    per_bin = np.abs(o - ref).max(axis=(0, 1, 3)) / np.abs(ref).max(axis=(0, 1, 3))
+    assert per_bin.max() < 2e-3, per_bin.argmax()
+
+
+def test_encode_is_complex_view_of_forward(cqt):
+    a = _audio(1, 1, seed=3).cuda()
+    c = cqt.encode(a)
+    assert c.shape == (1, 1, 540, M) and c.is_complex()
+    r = cqt(a)
+    assert torch.equal(cqt.to_real(c).contiguous(), r)
+    assert torch.equal(cqt.to_complex(r), c[:, 0])
+
+
+def test_blocks_independent_and_linear(cqt):
+    a1, a2 = _audio(1, 1, 5).cuda(), _audio(1, 1, 6).cuda()
+    c1, c2 = cqt(a1), cqt(a2)
+    c12 = cqt(torch.cat([a1, a2], -1))
+    assert torch.equal(c12, torch.cat([c1, c2], -1))                      # bit-exact frame concatenation
+    lin = cqt(0.5 * a1 - 2.0 * a2)
+    scale = c1.abs().max()
+    assert ((lin - (0.5 * c1 - 2.0 * c2)).abs().max() / scale) < 1e-5
+    both = cqt(torch.cat([a1, a2], 0))
+    assert torch.equal(both[0:1], c1) and torch.equal(both[1:2], c2)       # batch items independent
+
+
+def test_sinusoid_and_click(cqt, tab):
+    k = 333
+    f = tab['positions'][k] * SR / N
+    x = torch.cos(2 * np.pi * f * torch.arange(N, dtype=torch.float64) / SR).float().view(1, 1, N)
+    mag = cqt.to_magnitude(cqt(x.cuda()))[0]
+    assert int(mag.mean(-1).argmax()) == k
+    x = torch.zeros(1, 1, N)
+    x[0, 0, 33075] = 1.0
+    mag = cqt.to_magnitude(cqt(x.cuda()))[0, 300:]
+    assert abs(int(mag.sum(0).argmax()) - 33075 / (N / M)) <= 1.0
+
+
+def test_inverse_matches_oracle(cqt, tab):
+    a = _audio(2, 2, seed=7)
+    ref_c = nsgt.wrapper_forward(a.numpy(), tab)
+    c = torch.from_numpy(np.ascontiguousarray(ref_c)).float().cuda()
+    out = cqt.decode(c)
+    assert out.shape == (2, 1, 2 * N)
+    ref = nsgt.wrapper_decode(ref_c, tab)
+    assert np.abs(out.cpu().numpy() - ref).max() < REL
+    assert abs(float(out.abs().max()) - 1.0) < 1e-6                          # inf-norm of the whole batch tensor
+    # complex (B,1,F,T) input is accepted too (cqtwrapper.py:199-203)
+    cc = torch.complex(c[:, 0], c[:, 1]).unsqueeze(1)
+    assert torch.allclose(cqt.decode(cc), out, atol=1e-6)
+    # arbitrary (non-consistent) coefficients, e.g. network outputs
+    g = torch.Generator().manual_seed(11)
+    rnd = torch.randn(1, 2, 540, M, generator=g)
+    ref = nsgt.wrapper_decode(rnd.numpy().astype(np.float64), tab)
+    assert np.abs(cqt.decode(rnd.cuda()).cpu().numpy() - ref).max() < REL
+
+
+def test_round_trip_on_covered_band(cqt, tab):
+    rng = np.random.default_rng(2)
+    x = rng.uniform(-1, 1, (3, 1, N))
+    X = np.fft.rfft(x, axis=-1)
+    X[..., ~tab['covered']] = 0
+    xb = np.fft.irfft(X, n=N, axis=-1)
+    xb = xb / np.abs(xb).max()
+    a = torch.from_numpy(xb).float().cuda()
+    y = cqt.decode(cqt(a))
+    assert (y - a).abs().max() < 2e-5
+
+
+def test_zeros_and_errors(cqt):
+    y = cqt.decode(torch.zeros(1, 2, 540, M, device='cuda'))
+    assert y.shape == (1, 1, N) and float(y.abs().max()) == 0.0
+    with pytest.raises(ValueError):
+        cqt(torch.zeros(1, 1, N + 5, device='cuda'))
+    with pytest.raises(RuntimeError):
+        cqt(torch.zeros(1, 1, N))                                           # CPU tensor: no fallback
+    padded = cqt.pad_to_block_length(torch.zeros(2, 1, int(2.5 * N), device='cuda'))
+    assert cqt(padded).shape == (2, 2, 540, 3 * M)

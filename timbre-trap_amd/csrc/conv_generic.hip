@@ -1,0 +1,311 @@
+// General direct 2-D convolution (every layer shape of the Timbre-Trap autoencoder and, with
+// swapped weight strides, every data gradient), its weight/bias gradient, and the small pointwise
+// helpers of the backward pass.  Shape-agnostic reference path of the library: the hot
+// ResidualConv2dBlock has its own fused kernels in resblock.hip.
+//
+// Replaces torch.nn.Conv2d / ConvTranspose2d (+ ELU) forward and backward as used by reference
+// timbre_trap/framework/modules.py:431, :446, :534, :543, :628, :687, :746, :751.
+#include "common.h"
+
+namespace {
+
+struct ConvP {
+    const float* x; const float* w; const float* bias; const float* res; float* y;
+    int B, Cin, Hin, T, Cout, Hout, KH, KW, sh, dh, dw, ph, pw, transposed;
+    long ws_co, ws_ci, ws_kh, ws_kw;
+    int act;
+};
+
+// thread = one output column t of one output row (b, ho); CO_T output channels in registers.
+template <int CO_T>
+__global__ __launch_bounds__(256) void k_conv_generic(ConvP p) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ho = blockIdx.y, b = blockIdx.z;
+    const bool tv = t < p.T;
+    const long xplane = (long)p.Hin * p.T;
+    const float* xb = p.x + (long)b * p.Cin * xplane;
+    const long yplane = (long)p.Hout * p.T;
+
+    // tap range along H (uniform over the block)
+    int kh0 = 0, khstep = 1;
+    if (p.transposed) {
+        khstep = p.sh;                              // dil_h == 1 for every transposed use
+        kh0 = (ho + p.ph) % p.sh;
+    }
+    for (int co0 = 0; co0 < p.Cout; co0 += CO_T) {
+        float acc[CO_T];
+#pragma unroll
+        for (int c = 0; c < CO_T; ++c) acc[c] = (p.bias && co0 + c < p.Cout) ? p.bias[co0 + c] : 0.f;
+        for (int kh = kh0; kh < p.KH; kh += khstep) {
+            int hi;
+            if (p.transposed) {
+                const int num = ho + p.ph - kh * p.dh;
+                if (num < 0) continue;
+                hi = num / p.sh;
+                if (hi * p.sh != num) continue;
+            } else {
+                hi = ho * p.sh + kh * p.dh - p.ph;
+            }
+            if (hi < 0 || hi >= p.Hin) continue;
+            for (int kw = 0; kw < p.KW; ++kw) {
+                const int ti = t + kw * p.dw - p.pw;
+                const bool v = tv && ti >= 0 && ti < p.T;
+                const float* xp = xb + (long)hi * p.T + (v ? ti : 0);
+                const float* wp = p.w + kh * p.ws_kh + kw * p.ws_kw + co0 * p.ws_co;
+                for (int ci = 0; ci < p.Cin; ++ci) {
+                    const float xv = v ? xp[ci * xplane] : 0.f;
+#pragma unroll
+                    for (int c = 0; c < CO_T; ++c)
+                        if (co0 + c < p.Cout) acc[c] = fmaf(xv, wp[ci * p.ws_ci + c * p.ws_co], acc[c]);
+                }
+            }
+        }
+        if (tv) {
+#pragma unroll
+            for (int c = 0; c < CO_T; ++c) {
+                if (co0 + c >= p.Cout) break;
+                float v = acc[c];
+                if (p.act == TT_ACT_ELU) v = elu1(v);
+                const long o = ((long)b * p.Cout + co0 + c) * yplane + (long)ho * p.T + t;
+                if (p.res) v += p.res[o];
+                p.y[o] = v;
+            }
+        }
+    }
+}
+
+struct WgradP {
+    const float* x; const float* g; float* dw; float* dbias;
+    int B, Cin, Hin, T, Cout, Hout, KH, KW, sh, dh, dw_, ph, pw;
+    long ws_co, ws_ci, ws_kh, ws_kw;
+    int n_ci_tiles, rows_per_chunk;
+};
+
+constexpr int TCO = 4, TCI = 2, KWMAX = 3;
+
+// grid.x = co_tile * n_ci_tiles * KH + ..., grid.y = chunk of (b, ho) rows.
+__global__ __launch_bounds__(256) void k_wgrad_generic(WgradP p) {
+    __shared__ float red[4][TCO * TCI * KWMAX + TCO];
+    int id = blockIdx.x;
+    const int kh = id % p.KH; id /= p.KH;
+    const int cit = id % p.n_ci_tiles; const int cot = id / p.n_ci_tiles;
+    const int co0 = cot * TCO, ci0 = cit * TCI;
+    const bool do_bias = p.dbias && cit == 0 && kh == 0;
+    const long xplane = (long)p.Hin * p.T, gplane = (long)p.Hout * p.T;
+    float acc[TCO][TCI][KWMAX];
+    float bacc[TCO];
+#pragma unroll
+    for (int a = 0; a < TCO; ++a) {
+        bacc[a] = 0.f;
+#pragma unroll
+        for (int c = 0; c < TCI; ++c)
+#pragma unroll
+            for (int k = 0; k < KWMAX; ++k) acc[a][c][k] = 0.f;
+    }
+    const long total_rows = (long)p.B * p.Hout;
+    const long r0 = (long)blockIdx.y * p.rows_per_chunk;
+    const long r1 = (r0 + p.rows_per_chunk < total_rows) ? r0 + p.rows_per_chunk : total_rows;
+    for (long r = r0; r < r1; ++r) {
+        const int b = (int)(r / p.Hout), ho = (int)(r - (long)b * p.Hout);
+        const int hi = ho * p.sh + kh * p.dh - p.ph;
+        const bool hv = hi >= 0 && hi < p.Hin;
+        if (!hv && !do_bias) continue;
+        const float* gb = p.g + ((long)b * p.Cout + co0) * gplane + (long)ho * p.T;
+        const float* xb = p.x + ((long)b * p.Cin + ci0) * xplane + (long)(hv ? hi : 0) * p.T;
+        for (int t = threadIdx.x; t < p.T; t += blockDim.x) {
+            float gv[TCO];
+#pragma unroll
+            for (int a = 0; a < TCO; ++a) gv[a] = (co0 + a < p.Cout) ? gb[a * gplane + t] : 0.f;
+            if (do_bias) {
+#pragma unroll
+                for (int a = 0; a < TCO; ++a) bacc[a] += gv[a];
+            }
+            if (!hv) continue;
+#pragma unroll
+            for (int k = 0; k < KWMAX; ++k) {
+                if (k >= p.KW) break;
+                const int ti = t + k * p.dw_ - p.pw;
+                if (ti < 0 || ti >= p.T) continue;
+#pragma unroll
+                for (int c = 0; c < TCI; ++c) {
+                    if (ci0 + c >= p.Cin) break;
+                    const float xv = xb[c * xplane + ti];
+#pragma unroll
+                    for (int a = 0; a < TCO; ++a) acc[a][c][k] = fmaf(gv[a], xv, acc[a][c][k]);
+                }
+            }
+        }
+    }
+    // block reduction: wave shuffle, then across the 4 waves through LDS
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int a = 0; a < TCO; ++a) {
+#pragma unroll
+        for (int c = 0; c < TCI; ++c)
+#pragma unroll
+            for (int k = 0; k < KWMAX; ++k) {
+                const float s = wave_sum(acc[a][c][k]);
+                if (lane == 0) red[wave][(a * TCI + c) * KWMAX + k] = s;
+            }
+        const float sb = wave_sum(bacc[a]);
+        if (lane == 0) red[wave][TCO * TCI * KWMAX + a] = sb;
+    }
+    __syncthreads();
+    const int nw = blockDim.x >> 6;
+    if (threadIdx.x < TCO * TCI * KWMAX) {
+        const int i = threadIdx.x;
+        const int k = i % KWMAX, c = (i / KWMAX) % TCI, a = i / (KWMAX * TCI);
+        if (k < p.KW && co0 + a < p.Cout && ci0 + c < p.Cin) {
+            float s = 0.f;
+            for (int w = 0; w < nw; ++w) s += red[w][i];
+            atomicAdd(p.dw + (co0 + a) * p.ws_co + (ci0 + c) * p.ws_ci + kh * p.ws_kh + k * p.ws_kw, s);
+        }
+    } else if (do_bias && threadIdx.x < TCO * TCI * KWMAX + TCO) {
+        const int a = threadIdx.x - TCO * TCI * KWMAX;
+        if (co0 + a < p.Cout) {
+            float s = 0.f;
+            for (int w = 0; w < nw; ++w) s += red[w][TCO * TCI * KWMAX + a];
+            atomicAdd(p.dbias + co0 + a, s);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_elu_bwd(const float* __restrict__ dy, const float* __restrict__ y,
+                                                 float* __restrict__ g, long n) {
+    const long n4 = n >> 2;
+    const float4* dy4 = reinterpret_cast<const float4*>(dy);
+    const float4* y4 = reinterpret_cast<const float4*>(y);
+    float4* g4 = reinterpret_cast<float4*>(g);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 a = dy4[i], b = y4[i];
+        g4[i] = make_float4(a.x * elu_grad_from_out(b.x), a.y * elu_grad_from_out(b.y),
+                            a.z * elu_grad_from_out(b.z), a.w * elu_grad_from_out(b.w));
+    }
+    if (blockIdx.x == 0) {
+        const long i = (n4 << 2) + threadIdx.x;
+        if (i < n) g[i] = dy[i] * elu_grad_from_out(y[i]);
+    }
+}
+
+// out[c] += sum_{b, inner} x[b][c][inner] ; grid (C, chunks)
+__global__ __launch_bounds__(256) void k_channel_sum(const float* __restrict__ x, float* __restrict__ out, int B, int C,
+                                                     long inner) {
+    __shared__ float red[4];
+    const int c = blockIdx.x;
+    float acc = 0.f;
+    const long per_b = inner;
+    const long total = (long)B * per_b;
+    for (long i = (long)blockIdx.y * 256 + threadIdx.x; i < total; i += (long)gridDim.y * 256) {
+        const long b = i / per_b, r = i - b * per_b;
+        acc += x[(b * C + c) * inner + r];
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out + c, red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void k_scaled_add(const float* __restrict__ a, const float* __restrict__ b,
+                                                    const float* __restrict__ s, int idx, float* __restrict__ y, long n) {
+    const float sc = s ? s[idx] : 1.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = fmaf(sc, b[i], a ? a[i] : 0.f);
+}
+
+__global__ __launch_bounds__(256) void k_dot(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                             long n) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) acc = fmaf(a[i], b[i], acc);
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+inline int grid1d(long n, int per_block, int cap) {
+    long g = (n + per_block - 1) / per_block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" int tt_conv2d(const float* x, const float* w, const float* bias, const float* res, float* y,
+                         int B, int Cin, int Hin, int T, int Cout, int Hout,
+                         int KH, int KW, int stride_h, int dil_h, int dil_w, int pad_h, int pad_w,
+                         int transposed, int64_t ws_co, int64_t ws_ci, int64_t ws_kh, int64_t ws_kw,
+                         int act, void* stream) {
+    if (!x || !w || !y || B <= 0 || Cin <= 0 || Cout <= 0 || Hin <= 0 || Hout <= 0 || T <= 0 || stride_h <= 0)
+        return TT_E_BADARG;
+    if (transposed && dil_h != 1) return TT_E_UNSUPPORTED;
+    if (Hout > 65535 || B > 65535) return TT_E_UNSUPPORTED;
+    ConvP p{x, w, bias, res, y, B, Cin, Hin, T, Cout, Hout, KH, KW, stride_h, dil_h, dil_w, pad_h, pad_w,
+            transposed, (long)ws_co, (long)ws_ci, (long)ws_kh, (long)ws_kw, act};
+    const int tb = T >= 256 ? 256 : (T > 64 ? 128 : 64);
+    dim3 grid((T + tb - 1) / tb, Hout, B);
+    if (Cout >= 16)
+        hipLaunchKernelGGL(k_conv_generic<16>, grid, dim3(tb), 0, tt_stream(stream), p);
+    else if (Cout >= 8)
+        hipLaunchKernelGGL(k_conv_generic<8>, grid, dim3(tb), 0, tt_stream(stream), p);
+    else
+        hipLaunchKernelGGL(k_conv_generic<4>, grid, dim3(tb), 0, tt_stream(stream), p);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tt_conv2d_wgrad(const float* x, const float* g, float* dw, float* dbias,
+                               int B, int Cin, int Hin, int T, int Cout, int Hout,
+                               int KH, int KW, int stride_h, int dil_h, int dil_w, int pad_h, int pad_w,
+                               int64_t ws_co, int64_t ws_ci, int64_t ws_kh, int64_t ws_kw, void* stream) {
+    if (!x || !g || !dw || B <= 0 || Cin <= 0 || Cout <= 0 || T <= 0) return TT_E_BADARG;
+    if (KW > KWMAX) return TT_E_UNSUPPORTED;
+    WgradP p{x, g, dw, dbias, B, Cin, Hin, T, Cout, Hout, KH, KW, stride_h, dil_h, dil_w, pad_h, pad_w,
+             (long)ws_co, (long)ws_ci, (long)ws_kh, (long)ws_kw, 0, 0};
+    p.n_ci_tiles = (Cin + TCI - 1) / TCI;
+    const int n_co_tiles = (Cout + TCO - 1) / TCO;
+    const long total_rows = (long)B * Hout;
+    long chunks = 4096 / ((long)n_co_tiles * p.n_ci_tiles * KH);
+    if (chunks < 8) chunks = 8;
+    if (chunks > total_rows) chunks = total_rows;
+    p.rows_per_chunk = (int)((total_rows + chunks - 1) / chunks);
+    chunks = (total_rows + p.rows_per_chunk - 1) / p.rows_per_chunk;
+    dim3 grid(n_co_tiles * p.n_ci_tiles * KH, (unsigned)chunks);
+    const int tb = T >= 256 ? 256 : (T > 64 ? 128 : 64);
+    hipLaunchKernelGGL(k_wgrad_generic, grid, dim3(tb), 0, tt_stream(stream), p);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tt_elu_bwd(const float* dy, const float* y, float* g, int64_t n, void* stream) {
+    if (!dy || !y || !g || n < 0) return TT_E_BADARG;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_elu_bwd, dim3(grid1d(n / 4 + 1, 256, 4096)), dim3(256), 0, tt_stream(stream), dy, y, g, (long)n);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tt_channel_sum(const float* x, float* out, int B, int C, int64_t inner, void* stream) {
+    if (!x || !out || B <= 0 || C <= 0 || inner <= 0) return TT_E_BADARG;
+    int chunks = grid1d((long)B * inner, 256 * 8, 2048 / (C > 2048 ? 2048 : C) + 1);
+    hipLaunchKernelGGL(k_channel_sum, dim3(C, chunks), dim3(256), 0, tt_stream(stream), x, out, B, C, (long)inner);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tt_scaled_add(const float* a, const float* b, const float* s, int idx, float* y, int64_t n,
+                             void* stream) {
+    if (!b || !y || n < 0) return TT_E_BADARG;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_scaled_add, dim3(grid1d(n, 256, 4096)), dim3(256), 0, tt_stream(stream), a, b, s, idx, y, (long)n);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tt_dot(const float* a, const float* b, float* out, int64_t n, void* stream) {
+    if (!a || !b || !out || n < 0) return TT_E_BADARG;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_dot, dim3(grid1d(n, 256 * 16, 1024)), dim3(256), 0, tt_stream(stream), a, b, out, (long)n);
+    TT_LAUNCH_CHECK();
+    return 0;
+}

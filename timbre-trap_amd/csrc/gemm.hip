@@ -1,0 +1,107 @@
+// Batched fp32 GEMM for the (31,1) latent layers: Encoder.convlat (reference modules.py:446) and
+// Decoder.convin (modules.py:534), forward, data- and weight-gradient.  With H collapsed these are
+// plain matrix products over (C*31): K = 1984 for the encoder head, M = 1984 for the decoder head.
+//
+// LDS-tiled 64x64x16, 256 threads, 4x4 outputs per thread, generic operand strides.
+#include "common.h"
+
+namespace {
+
+struct GemmP {
+    const float* A; const float* B; float* C; const float* bias;
+    int M, N, K;
+    long am, ak, bk, bn, ldc;       // element strides: a(m,k) = A[m*am + k*ak], b(k,n) = B[k*bk + n*bn]
+    long sa, sb, sc;
+    int reduce_batch;
+    float alpha, beta;
+    int bias_mode, bias_div, act;
+};
+
+constexpr int BM = 64, BN = 64, BK = 16;
+
+__global__ __launch_bounds__(256) void k_gemm(GemmP p) {
+    __shared__ float As[BK][BM + 4];
+    __shared__ float Bs[BK][BN + 4];
+    const int tid = threadIdx.x;
+    const int bz = blockIdx.z;
+    const float* A = p.A + bz * p.sa;
+    const float* B = p.B + bz * p.sb;
+    float* C = p.C + (p.reduce_batch ? 0 : bz * p.sc);
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int tx = tid & 15, ty = tid >> 4;      // thread tile: rows ty*4.., cols tx*4..
+    float acc[4][4] = {};
+
+    for (int k0 = 0; k0 < p.K; k0 += BK) {
+        // A tile: BM x BK, 1024 elements, 4 per thread; iterate the unit-stride dimension fastest
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i;
+            int m, k;
+            if (p.ak == 1) { k = e & (BK - 1); m = e >> 4; } else { m = e & (BM - 1); k = e >> 6; }
+            const int gm = m0 + m, gk = k0 + k;
+            As[k][m] = (gm < p.M && gk < p.K) ? A[gm * p.am + gk * p.ak] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i;
+            int n, k;
+            if (p.bn == 1) { n = e & (BN - 1); k = e >> 6; } else { k = e & (BK - 1); n = e >> 4; }
+            const int gn = n0 + n, gk = k0 + k;
+            Bs[k][n] = (gn < p.N && gk < p.K) ? B[gk * p.bk + gn * p.bn] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < BK; ++k) {
+            const float4 a = *reinterpret_cast<const float4*>(&As[k][ty * 4]);
+            const float4 b = *reinterpret_cast<const float4*>(&Bs[k][tx * 4]);
+            const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int gm = m0 + ty * 4 + i;
+        if (gm >= p.M) continue;
+        float bv = 0.f;
+        if (p.bias_mode == 1) bv = p.bias[gm];
+        else if (p.bias_mode == 2) bv = p.bias[gm / p.bias_div];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gn = n0 + tx * 4 + j;
+            if (gn >= p.N) continue;
+            float v = p.alpha * acc[i][j];
+            float* c = C + gm * p.ldc + gn;
+            if (p.reduce_batch) {
+                atomicAdd(c, v);
+            } else {
+                v += bv;
+                if (p.beta != 0.f) v += p.beta * (*c);
+                if (p.act == TT_ACT_ELU) v = elu1(v);
+                *c = v;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int tt_gemm(const float* A, const float* Bm, float* C, const float* bias,
+                       int M, int N, int K, int transA, int transB, int64_t lda, int64_t ldb, int64_t ldc,
+                       int batch, int64_t sa, int64_t sb, int64_t sc, int reduce_batch,
+                       float alpha, float beta, int bias_mode, int bias_div, int act, void* stream) {
+    if (!A || !Bm || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0) return TT_E_BADARG;
+    if (bias_mode && !bias) return TT_E_BADARG;
+    if (reduce_batch && (bias_mode || act || beta != 1.f)) return TT_E_UNSUPPORTED;   // accumulates into C
+    if (batch > 65535) return TT_E_UNSUPPORTED;
+    GemmP p{A, Bm, C, bias, M, N, K,
+            transA ? 1 : (long)lda, transA ? (long)lda : 1, transB ? 1 : (long)ldb, transB ? (long)ldb : 1, (long)ldc,
+            (long)sa, (long)sb, (long)sc, reduce_batch, alpha, beta, bias_mode, bias_div > 0 ? bias_div : 1, act};
+    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch);
+    hipLaunchKernelGGL(k_gemm, grid, dim3(256), 0, tt_stream(stream), p);
+    TT_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,267 @@
+// Objectives of Timbre-Trap on gfx950: reconstruction / consistency (sum of squared differences),
+// TimbreTrap.to_activations, positive-class-weighted transcription loss -- forward and backward.
+// Replaces reference timbre_trap/framework/objectives.py:11-104 and modules.py:271-289.
+//
+// All of them are pure HBM streams; reductions are two-stage in fp64 (block partials -> one
+// finalising workgroup) so the loss values are deterministic.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXP = 1024;
+
+__device__ __forceinline__ void block_partial(double v, double* partials) {
+    __shared__ double red[4];
+    v = wave_sum_d(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ partials, int n, double scale,
+                                                  float* __restrict__ out, int take_sqrt) {
+    __shared__ double red[4];
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) v += partials[i];
+    v = wave_sum_d(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = (red[0] + red[1] + red[2] + red[3]) * scale;
+        out[0] = (float)(take_sqrt ? sqrt(s) : s);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sqdiff_partial(const float* __restrict__ a, const float* __restrict__ b,
+                                                        double* __restrict__ partials, long n) {
+    const long n4 = n >> 2;
+    const float4* a4 = reinterpret_cast<const float4*>(a);
+    const float4* b4 = reinterpret_cast<const float4*>(b);
+    double acc = 0.0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 x = a4[i], y = b4[i];
+        const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
+        acc += (double)(d0 * d0 + d1 * d1) + (double)(d2 * d2 + d3 * d3);
+    }
+    if (blockIdx.x == 0) {
+        const long i = (n4 << 2) + threadIdx.x;
+        if (i < n) { const float d = a[i] - b[i]; acc += (double)(d * d); }
+    }
+    block_partial(acc, partials);
+}
+
+__global__ __launch_bounds__(256) void k_sqdiff_bwd(const float* __restrict__ a, const float* __restrict__ b,
+                                                    const float* __restrict__ gscale, float scale,
+                                                    float* __restrict__ da, float* __restrict__ db, long n) {
+    const float s = 2.f * scale * gscale[0];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float g = s * (a[i] - b[i]);
+        if (da) da[i] = g;
+        if (db) db[i] = -g;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_act_fwd(const float* __restrict__ c, float* __restrict__ act, int B, long FT) {
+    const long total = (long)B * FT;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long b = i / FT, r = i - b * FT;
+        const float re = c[(b * 2) * FT + r], im = c[(b * 2 + 1) * FT + r];
+        act[i] = tanhf(sqrtf(re * re + im * im));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_act_bwd(const float* __restrict__ c, const float* __restrict__ act,
+                                                 const float* __restrict__ dact, float* __restrict__ dc, int B, long FT) {
+    const long total = (long)B * FT;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long b = i / FT, r = i - b * FT;
+        const float re = c[(b * 2) * FT + r], im = c[(b * 2 + 1) * FT + r];
+        const float mag = sqrtf(re * re + im * im);
+        const float a = act[i];
+        // d tanh = 1 - a^2 ; d|c|/d re = re / |c| (0 at the origin, torch.norm's subgradient)
+        const float k = (mag > 0.f) ? dact[i] * (1.f - a * a) / mag : 0.f;
+        dc[(b * 2) * FT + r] = k * re;
+        dc[(b * 2 + 1) * FT + r] = k * im;
+    }
+}
+
+// thread = one frame (b, t); loops the F bins twice (weights, then weighted error).
+__global__ __launch_bounds__(256) void k_trn_fwd(const float* __restrict__ est, const float* __restrict__ tgt,
+                                                 float* __restrict__ frame_scale, double* __restrict__ partials,
+                                                 int B, int F, int T, int weighted) {
+    const long total = (long)B * T;
+    double acc = 0.0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long b = i / T, t = i - b * T;
+        const float* e = est + b * F * (long)T + t;
+        const float* g = tgt + b * F * (long)T + t;
+        float scale = 1.f;
+        if (weighted) {
+            float pos = 0.f, neg = 0.f;
+            for (int f = 0; f < F; ++f) { const float v = g[(long)f * T]; pos += v; neg += 1.f - v; }
+            scale = neg / (pos + 1.1920928955078125e-07f);     // torch.finfo(float32).eps
+            frame_scale[i] = scale;
+        }
+        float s = 0.f;
+        for (int f = 0; f < F; ++f) {
+            const float tv = g[(long)f * T];
+            const float d = e[(long)f * T] - tv;
+            float w = 1.f;
+            if (weighted && tv == 1.f && scale != 0.f) w = scale;
+            s = fmaf(d * d, w, s);
+        }
+        acc += (double)s;
+    }
+    block_partial(acc, partials);
+}
+
+__global__ __launch_bounds__(256) void k_trn_bwd(const float* __restrict__ est, const float* __restrict__ tgt,
+                                                 const float* __restrict__ frame_scale, const float* __restrict__ gscale,
+                                                 float* __restrict__ dest, int B, int F, int T, int weighted) {
+    const long total = (long)B * F * T;
+    const float s = 2.f * gscale[0] / (float)((long)B * T);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long b = i / ((long)F * T), t = i % T;
+        const float tv = tgt[i];
+        float w = 1.f;
+        if (weighted && tv == 1.f) { const float sc = frame_scale[b * T + t]; if (sc != 0.f) w = sc; }
+        dest[i] = s * w * (est[i] - tv);
+    }
+}
+
+inline int nblocks(long n, int per_thread) {
+    long g = (n + 256L * per_thread - 1) / (256L * per_thread);
+    if (g > MAXP) g = MAXP;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" int tt_sqdiff_sum(const float* a, const float* b, float* loss, double* partials, int64_t n,
+                             float scale, void* stream) {
+    if (!a || !b || !loss || !partials || n <= 0) return TT_E_BADARG;
+    const int g = nblocks(n, 16);
+    hipLaunchKernelGGL(k_sqdiff_partial, dim3(g), dim3(256), 0, tt_stream(stream), a, b, partials, (long)n);
+    TT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, tt_stream(stream), partials, g, (double)scale, loss, 0);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tt_sqdiff_bwd(const float* a, const float* b, const float* gscale, float scale, float* da,
+                             float* db, int64_t n, void* stream) {
+    if (!a || !b || !gscale || n <= 0 || (!da && !db)) return TT_E_BADARG;
+    hipLaunchKernelGGL(k_sqdiff_bwd, dim3(nblocks(n, 4) * 4), dim3(256), 0, tt_stream(stream), a, b, gscale, scale, da, db, (long)n);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tt_activations_fwd(const float* coeffs, float* act, int B, int F, int T, void* stream) {
+    if (!coeffs || !act || B <= 0 || F <= 0 || T <= 0) return TT_E_BADARG;
+    const long FT = (long)F * T;
+    hipLaunchKernelGGL(k_act_fwd, dim3(nblocks(B * FT, 4) * 4), dim3(256), 0, tt_stream(stream), coeffs, act, B, FT);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tt_activations_bwd(const float* coeffs, const float* act, const float* dact, float* dcoeffs,
+                                  int B, int F, int T, void* stream) {
+    if (!coeffs || !act || !dact || !dcoeffs || B <= 0 || F <= 0 || T <= 0) return TT_E_BADARG;
+    const long FT = (long)F * T;
+    hipLaunchKernelGGL(k_act_bwd, dim3(nblocks(B * FT, 4) * 4), dim3(256), 0, tt_stream(stream), coeffs, act, dact, dcoeffs, B, FT);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tt_transcription_loss_fwd(const float* est, const float* tgt, float* loss, float* frame_scale,
+                                         double* partials, int B, int F, int T, int weighted, void* stream) {
+    if (!est || !tgt || !loss || !partials || B <= 0 || F <= 0 || T <= 0) return TT_E_BADARG;
+    if (weighted && !frame_scale) return TT_E_BADARG;
+    const int g = nblocks((long)B * T, 1);
+    hipLaunchKernelGGL(k_trn_fwd, dim3(g), dim3(256), 0, tt_stream(stream), est, tgt, frame_scale, partials, B, F, T, weighted);
+    TT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, tt_stream(stream), partials, g, 1.0 / ((double)B * T), loss, 0);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tt_transcription_loss_bwd(const float* est, const float* tgt, const float* frame_scale,
+                                         const float* gscale, float* dest, int B, int F, int T, int weighted,
+                                         void* stream) {
+    if (!est || !tgt || !gscale || !dest || B <= 0 || F <= 0 || T <= 0) return TT_E_BADARG;
+    if (weighted && !frame_scale) return TT_E_BADARG;
+    hipLaunchKernelGGL(k_trn_bwd, dim3(nblocks((long)B * F * T, 4) * 4), dim3(256), 0, tt_stream(stream), est, tgt, frame_scale,
+                       gscale, dest, B, F, T, weighted);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- optimiser (experiments/train.py:334, :493-496) ------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(256) void k_sumsq_partial(const float* __restrict__ x, double* __restrict__ partials, long n) {
+    double acc = 0.0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float v = x[i];
+        acc += (double)v * (double)v;
+    }
+    block_partial(acc, partials);
+}
+
+__global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                               float* __restrict__ v, const float* __restrict__ norm, long n, float lr,
+                                               float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt,
+                                               float max_norm, int write_clipped) {
+    float clip = 1.f;
+    if (max_norm > 0.f && norm) {
+        clip = max_norm / (norm[0] + 1e-6f);
+        clip = clip > 1.f ? 1.f : clip;
+    }
+    const float step_size = lr / bc1;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float gi = g[i] * clip;
+        if (write_clipped) g[i] = gi;
+        float pi = p[i] * (1.f - lr * wd);
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - step_size * (mi / denom);
+    }
+}
+
+}  // namespace
+
+extern "C" int tt_l2norm(const float* x, float* norm_out, double* partials, int64_t n, void* stream) {
+    if (!x || !norm_out || !partials || n <= 0) return TT_E_BADARG;
+    const int g = nblocks(n, 8);
+    hipLaunchKernelGGL(k_sumsq_partial, dim3(g), dim3(256), 0, tt_stream(stream), x, partials, (long)n);
+    TT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, tt_stream(stream), partials, g, 1.0, norm_out, 1);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tt_adamw_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, const float* norm,
+                             int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                             int step, float max_norm, int write_clipped, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || step <= 0) return TT_E_BADARG;
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(k_adamw, dim3(nblocks(n, 4) * 4 > 2048 ? 2048 : nblocks(n, 4) * 4), dim3(256), 0, tt_stream(stream),
+                       param, grad, exp_avg, exp_avg_sq, norm, (long)n, lr, beta1, beta2, eps, weight_decay, bc1,
+                       sqrtf(bc2), max_norm, write_clipped);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tt_version(void) { return 1; }
+extern "C" const char* tt_arch(void) { return "gfx950"; }
+extern "C" const char* tt_error_string(int code) {
+    if (code == 0) return "ok";
+    if (code == TT_E_BADARG) return "ttrap: bad argument";
+    if (code == TT_E_UNSUPPORTED) return "ttrap: unsupported shape or option";
+    return hipGetErrorString((hipError_t)code);
+}

@@ -1,0 +1,129 @@
+"""
+ctypes binding of libttrap_hip.so (C ABI: include/ttrap.h).
+
+Loaded lazily on first use so that importing the package -- and pickling / forking a CQT object
+into DataLoader workers, which only call the pure-Python helpers (reference
+timbre_trap/datasets/PitchDataset.py:102-118) -- never touches the HIP runtime.
+
+There is NO CPU fallback: if the library is missing, every device entry point raises.
+"""
+
+import ctypes
+import os
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.dirname(_HERE)                       # timbre-trap_amd/
+REPO_ROOT = os.path.dirname(PKG_ROOT)
+CSRC = os.path.join(PKG_ROOT, 'csrc')
+LIB_PATH = os.path.join(PKG_ROOT, 'lib', 'libttrap_hip.so')
+SOURCES = ['cqt.hip', 'conv_generic.hip', 'resblock.hip', 'gemm.hip', 'losses.hip']
+
+_lib = None
+
+c_void_p, c_int, c_int64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+
+
+class CqtPlan(ctypes.Structure):
+    """struct tt_cqt_plan (include/ttrap.h)."""
+    _fields_ = [('tw675', c_void_p), ('tw49', c_void_p), ('twNc', c_void_p), ('twN', c_void_p),
+                ('tw1024', c_void_p), ('bin_tab', c_void_p), ('window', c_void_p), ('dual', c_void_p),
+                ('gat_off', c_void_p), ('gat_idx', c_void_p), ('n_bins', ctypes.c_int32),
+                ('sum_len', ctypes.c_int32)]
+
+
+P, I, L, F_ = c_void_p, c_int, c_int64, c_float
+_PROTOS = {
+    'tt_version': (c_int, []),
+    'tt_arch': (ctypes.c_char_p, []),
+    'tt_error_string': (ctypes.c_char_p, [I]),
+    'tt_cqt_scratch_bytes': (c_int64, [I, I, I]),
+    'tt_cqt_forward': (c_int, [ctypes.POINTER(CqtPlan), P, P, P, I, I, I, P]),
+    'tt_cqt_inverse': (c_int, [ctypes.POINTER(CqtPlan), P, P, P, I, I, I, I, P]),
+    'tt_conv2d': (c_int, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, L, L, L, L, I, P]),
+    'tt_conv2d_wgrad': (c_int, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, L, L, L, L, P]),
+    'tt_elu_bwd': (c_int, [P, P, P, L, P]),
+    'tt_resblock_fwd': (c_int, [P, P, P, P, P, P, I, I, I, I, I, P]),
+    'tt_resblock_bwd': (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    'tt_gemm': (c_int, [P, P, P, P, I, I, I, I, I, L, L, L, I, L, L, L, I, F_, F_, I, I, I, P]),
+    'tt_channel_sum': (c_int, [P, P, I, I, L, P]),
+    'tt_scaled_add': (c_int, [P, P, P, I, P, L, P]),
+    'tt_dot': (c_int, [P, P, P, L, P]),
+    'tt_sqdiff_sum': (c_int, [P, P, P, P, L, F_, P]),
+    'tt_sqdiff_bwd': (c_int, [P, P, P, F_, P, P, L, P]),
+    'tt_activations_fwd': (c_int, [P, P, I, I, I, P]),
+    'tt_activations_bwd': (c_int, [P, P, P, P, I, I, I, P]),
+    'tt_transcription_loss_fwd': (c_int, [P, P, P, P, P, I, I, I, I, P]),
+    'tt_transcription_loss_bwd': (c_int, [P, P, P, P, P, I, I, I, I, P]),
+    'tt_l2norm': (c_int, [P, P, P, L, P]),
+    'tt_adamw_step': (c_int, [P, P, P, P, P, L, F_, F_, F_, F_, F_, I, F_, I, P]),
+}
+EXPORTED_SYMBOLS = tuple(_PROTOS)
+
+
+def build(verbose=False, force=False):
+    """Compile every HIP source for gfx950 into timbre-trap_amd/lib/libttrap_hip.so (in-tree)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, 'common.h'), os.path.join(REPO_ROOT, 'include', 'ttrap.h')]
+    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    objs = []
+    procs = []
+    for s in srcs:
+        o = os.path.join(PKG_ROOT, 'lib', os.path.basename(s).replace('.hip', '.o'))
+        objs.append(o)
+        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', s, '-o', o]
+        if verbose:
+            print(' '.join(cmd), file=sys.stderr)
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for cmd, pr in procs:
+        out, _ = pr.communicate()
+        if pr.returncode != 0:
+            raise RuntimeError('hipcc failed: %s\n%s' % (' '.join(cmd), out.decode()))
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                'libttrap_hip.so not found at %s -- run `python -c "import __graft_entry__ as g; g.build()"` '
+                '(there is no CPU fallback for the Timbre-Trap HIP path)' % LIB_PATH)
+        h = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(h, name)          # AttributeError if a declared symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = lib().tt_error_string(rc)
+        raise RuntimeError('ttrap HIP call %s failed (%d): %s' % (what, rc, msg.decode() if msg else '?'))
+
+
+def stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """data pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('timbre_trap HIP path needs tensors on the GPU (got %s); there is no CPU fallback'
+                               % t.device)

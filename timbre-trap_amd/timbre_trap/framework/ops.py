@@ -1,0 +1,373 @@
+"""
+torch.autograd bindings of the gfx950 kernels (C ABI: include/ttrap.h).
+
+Every Function below owns a forward and a hand-written backward that call straight into
+libttrap_hip.so on the current HIP stream; torch only allocates the tensors.  Nothing here has a
+CPU path -- tensors must live on the GPU.
+"""
+
+import ctypes
+import os
+from dataclasses import dataclass
+
+import torch
+
+from .. import _hip
+from .._hip import check, ptr, stream_ptr
+
+ACT_NONE, ACT_ELU = 0, 1
+
+# The fused ResidualConv2dBlock kernels (csrc/resblock.hip) are the default; TTRAP_FUSED=0 composes
+# the block from the general convolution kernels instead (used to cross-check the two on the GPU).
+FUSED_RESBLOCK = os.environ.get('TTRAP_FUSED', '1') != '0'
+FUSED_CHANNELS = (4, 8, 16, 32)
+
+
+@dataclass(frozen=True)
+class ConvCfg:
+    """Geometry of one layer. kind 'conv' = nn.Conv2d, 'tconv' = nn.ConvTranspose2d (H only)."""
+    KH: int
+    KW: int
+    stride: int = 1
+    dil: int = 1
+    pad_h: int = 0
+    pad_w: int = 0
+    kind: str = 'conv'
+    out_pad: int = 0
+    act: int = ACT_NONE
+
+
+def _off(t, elements):
+    return ctypes.c_void_p(t.data_ptr() + 4 * elements)
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class ConvFn(torch.autograd.Function):
+    """y = act(conv(x, w) + b) for every non-fused layer of the autoencoder."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, cfg):
+        _hip.require_cuda(x, w)
+        x, w = _f32c(x), _f32c(w)
+        B, Cin, Hin, T = x.shape
+        KH, KW = cfg.KH, cfg.KW
+        lib = _hip.lib()
+        if cfg.kind == 'conv':
+            Cout = w.size(0)
+            Hout = (Hin + 2 * cfg.pad_h - cfg.dil * (KH - 1) - 1) // cfg.stride + 1
+            y = torch.empty((B, Cout, Hout, T), dtype=torch.float32, device=x.device)
+            check(lib.tt_conv2d(ptr(x), ptr(w), ptr(b), None, ptr(y), B, Cin, Hin, T, Cout, Hout, KH, KW,
+                                cfg.stride, cfg.dil, cfg.dil, cfg.pad_h, cfg.pad_w, 0,
+                                Cin * KH * KW, KH * KW, KW, 1, cfg.act, stream_ptr()), 'tt_conv2d')
+        else:
+            Cout = w.size(1)
+            Hout = (Hin - 1) * cfg.stride + KH + cfg.out_pad
+            y = torch.empty((B, Cout, Hout, T), dtype=torch.float32, device=x.device)
+            check(lib.tt_conv2d(ptr(x), ptr(w), ptr(b), None, ptr(y), B, Cin, Hin, T, Cout, Hout, KH, KW,
+                                cfg.stride, 1, 1, 0, 0, 1,
+                                KH * KW, Cout * KH * KW, KW, 1, cfg.act, stream_ptr()), 'tt_conv2d(T)')
+        ctx.cfg = cfg
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x, w, y if cfg.act == ACT_ELU else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        cfg = ctx.cfg
+        lib = _hip.lib()
+        st = stream_ptr()
+        dy = _f32c(dy)
+        B, Cin, Hin, T = x.shape
+        _, Cout, Hout, _ = dy.shape
+        KH, KW = cfg.KH, cfg.KW
+        if cfg.act == ACT_ELU:
+            g = torch.empty_like(dy)
+            check(lib.tt_elu_bwd(ptr(dy), ptr(y), ptr(g), dy.numel(), st), 'tt_elu_bwd')
+        else:
+            g = dy
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            if cfg.kind == 'conv' and cfg.stride == 1:
+                # data gradient of a unit-stride conv = the same conv with both kernel axes flipped
+                check(lib.tt_conv2d(ptr(g), _off(w, (KH - 1) * KW + (KW - 1)), None, None, ptr(dx),
+                                    B, Cout, Hout, T, Cin, Hin, KH, KW, 1, cfg.dil, cfg.dil,
+                                    (KH - 1) * cfg.dil - cfg.pad_h, (KW - 1) * cfg.dil - cfg.pad_w, 0,
+                                    KH * KW, Cin * KH * KW, -KW, -1, ACT_NONE, st), 'tt_conv2d(dgrad)')
+            elif cfg.kind == 'conv':
+                # strided conv: gradient is the transposed form (only KW == 1 / dil == 1 layers are strided)
+                check(lib.tt_conv2d(ptr(g), _off(w, KW - 1), None, None, ptr(dx),
+                                    B, Cout, Hout, T, Cin, Hin, KH, KW, cfg.stride, 1, 1,
+                                    cfg.pad_h, (KW - 1) - cfg.pad_w, 1,
+                                    KH * KW, Cin * KH * KW, KW, -1, ACT_NONE, st), 'tt_conv2d(dgradT)')
+            else:
+                # transposed conv: gradient is the plain strided conv with the roles of the channel dims swapped
+                check(lib.tt_conv2d(ptr(g), ptr(w), None, None, ptr(dx),
+                                    B, Cout, Hout, T, Cin, Hin, KH, KW, cfg.stride, 1, 1, 0, 0, 0,
+                                    Cout * KH * KW, KH * KW, KW, 1, ACT_NONE, st), 'tt_conv2d(dgrad of T)')
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros_like(w)
+            db = torch.zeros(Cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            if cfg.kind == 'conv':
+                check(lib.tt_conv2d_wgrad(ptr(x), ptr(g), ptr(dw), ptr(db), B, Cin, Hin, T, Cout, Hout, KH, KW,
+                                          cfg.stride, cfg.dil, cfg.dil, cfg.pad_h, cfg.pad_w,
+                                          Cin * KH * KW, KH * KW, KW, 1, st), 'tt_conv2d_wgrad')
+            else:
+                # dW[ci][co][kh] = sum x[ci][hi] * g[co][stride*hi + kh]: same kernel, roles swapped
+                check(lib.tt_conv2d_wgrad(ptr(g), ptr(x), ptr(dw), None, B, Cout, Hout, T, Cin, Hin, KH, KW,
+                                          cfg.stride, 1, 1, 0, 0,
+                                          Cout * KH * KW, KH * KW, KW, 1, st), 'tt_conv2d_wgrad(T)')
+                if db is not None:
+                    check(lib.tt_channel_sum(ptr(g), ptr(db), B, Cout, Hout * T, st), 'tt_channel_sum')
+        return dx, dw, db, None
+
+
+def conv(x, w, b, cfg):
+    return ConvFn.apply(x, w, b, cfg)
+
+
+class AddFn(torch.autograd.Function):
+    """y = a + b (residual / skip joins)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _f32c(a), _f32c(b)
+        y = torch.empty_like(a)
+        check(_hip.lib().tt_scaled_add(ptr(a), ptr(b), None, 0, ptr(y), a.numel(), stream_ptr()), 'tt_scaled_add')
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+class ScaleFn(torch.autograd.Function):
+    """y = s[idx] * e  (TimbreTrap.apply_skip_connections, reference modules.py:112)."""
+
+    @staticmethod
+    def forward(ctx, e, s, idx):
+        e, s = _f32c(e), _f32c(s)
+        y = torch.empty_like(e)
+        check(_hip.lib().tt_scaled_add(None, ptr(e), ptr(s), idx, ptr(y), e.numel(), stream_ptr()), 'tt_scaled_add')
+        ctx.idx = idx
+        ctx.save_for_backward(e, s)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        e, s = ctx.saved_tensors
+        dy = _f32c(dy)
+        lib, st = _hip.lib(), stream_ptr()
+        de = ds = None
+        if ctx.needs_input_grad[0]:
+            de = torch.empty_like(e)
+            check(lib.tt_scaled_add(None, ptr(dy), ptr(s), ctx.idx, ptr(de), e.numel(), st), 'tt_scaled_add')
+        if ctx.needs_input_grad[1]:
+            ds = torch.zeros_like(s)
+            check(lib.tt_dot(ptr(dy), ptr(e), _off(ds, ctx.idx), e.numel(), st), 'tt_dot')
+        return de, ds, None
+
+
+class ResBlockFn(torch.autograd.Function):
+    """Fused ResidualConv2dBlock (reference modules.py:755-777); hidden activations recomputed in backward."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, dilation):
+        _hip.require_cuda(x, w1)
+        x = _f32c(x)
+        B, C, H, T = x.shape
+        y = torch.empty_like(x)
+        check(_hip.lib().tt_resblock_fwd(ptr(x), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(y), B, C, H, T, dilation,
+                                         stream_ptr()), 'tt_resblock_fwd')
+        ctx.dilation = dilation
+        ctx.save_for_backward(x, w1, b1, w2, b2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, b1, w2, b2 = ctx.saved_tensors
+        dy = _f32c(dy)
+        B, C, H, T = x.shape
+        dx = torch.empty_like(x)
+        dw1, db1, dw2, db2 = (torch.zeros_like(t) for t in (w1, b1, w2, b2))
+        ws = torch.empty_like(x)
+        check(_hip.lib().tt_resblock_bwd(ptr(x), ptr(dy), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(dx), ptr(dw1),
+                                         ptr(db1), ptr(dw2), ptr(db2), ptr(ws), B, C, H, T, ctx.dilation,
+                                         stream_ptr()), 'tt_resblock_bwd')
+        return dx, dw1, db1, dw2, db2, None
+
+
+def residual_block(x, w1, b1, w2, b2, dilation):
+    C = x.size(1)
+    if (FUSED_RESBLOCK and C in FUSED_CHANNELS and w1.shape == (C, C, 3, 3) and w2.shape == (C, C, 1, 1)
+            and 1 <= dilation <= 3):
+        return ResBlockFn.apply(x, w1, b1, w2, b2, dilation)
+    k = w1.size(-1)
+    h = conv(x, w1, b1, ConvCfg(k, k, 1, dilation, dilation * (k - 1) // 2, dilation * (k - 1) // 2, 'conv', 0, ACT_ELU))
+    h = conv(h, w2, b2, ConvCfg(1, 1, 1, 1, 0, 0, 'conv', 0, ACT_ELU))
+    return AddFn.apply(h, x)
+
+
+class LatentEncodeFn(torch.autograd.Function):
+    """Encoder.convlat: Conv2d(C, D, (E,1)) collapsing the frequency axis = per-clip GEMM (D x C*E)(C*E x T)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x, w = _f32c(x), _f32c(w)
+        B, C, E, T = x.shape
+        D, K = w.size(0), C * E
+        y = torch.empty((B, D, T), dtype=torch.float32, device=x.device)
+        check(_hip.lib().tt_gemm(ptr(w), ptr(x), ptr(y), ptr(b), D, T, K, 0, 0, K, T, T, B, 0, K * T, D * T, 0,
+                                 1.0, 0.0, 1 if b is not None else 0, 1, ACT_NONE, stream_ptr()), 'tt_gemm(convlat)')
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _f32c(dy)
+        B, C, E, T = x.shape
+        D, K = w.size(0), C * E
+        lib, st = _hip.lib(), stream_ptr()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            check(lib.tt_gemm(ptr(w), ptr(dy), ptr(dx), None, K, T, D, 1, 0, K, T, T, B, 0, D * T, K * T, 0,
+                              1.0, 0.0, 0, 1, ACT_NONE, st), 'tt_gemm(convlat dgrad)')
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros_like(w)
+            check(lib.tt_gemm(ptr(dy), ptr(x), ptr(dw), None, D, K, T, 0, 1, T, T, K, B, D * T, K * T, 0, 1,
+                              1.0, 1.0, 0, 1, ACT_NONE, st), 'tt_gemm(convlat wgrad)')
+            if ctx.has_bias:
+                db = torch.zeros(D, dtype=torch.float32, device=x.device)
+                check(lib.tt_channel_sum(ptr(dy), ptr(db), B, D, T, st), 'tt_channel_sum')
+        return dx, dw, db
+
+
+class LatentDecodeFn(torch.autograd.Function):
+    """Decoder.convin: ConvTranspose2d(D+1, C, (E,1)) + ELU = per-clip GEMM (C*E x D+1)(D+1 x T)."""
+
+    @staticmethod
+    def forward(ctx, z, w, b):
+        z, w = _f32c(z), _f32c(w)
+        B, K, T = z.shape
+        C, E = w.size(1), w.size(2)
+        Mo = C * E
+        y = torch.empty((B, C, E, T), dtype=torch.float32, device=z.device)
+        check(_hip.lib().tt_gemm(ptr(w), ptr(z), ptr(y), ptr(b), Mo, T, K, 1, 0, Mo, T, T, B, 0, K * T, Mo * T, 0,
+                                 1.0, 0.0, 2 if b is not None else 0, E, ACT_ELU, stream_ptr()), 'tt_gemm(dec convin)')
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(z, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, w, y = ctx.saved_tensors
+        dy = _f32c(dy)
+        B, K, T = z.shape
+        C, E = w.size(1), w.size(2)
+        Mo = C * E
+        lib, st = _hip.lib(), stream_ptr()
+        g = torch.empty_like(dy)
+        check(lib.tt_elu_bwd(ptr(dy), ptr(y), ptr(g), dy.numel(), st), 'tt_elu_bwd')
+        dz = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dz = torch.empty_like(z)
+            check(lib.tt_gemm(ptr(w), ptr(g), ptr(dz), None, K, T, Mo, 0, 0, Mo, T, T, B, 0, Mo * T, K * T, 0,
+                              1.0, 0.0, 0, 1, ACT_NONE, st), 'tt_gemm(dec convin dgrad)')
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros_like(w)
+            check(lib.tt_gemm(ptr(z), ptr(g), ptr(dw), None, K, Mo, T, 0, 1, T, T, Mo, B, K * T, Mo * T, 0, 1,
+                              1.0, 1.0, 0, 1, ACT_NONE, st), 'tt_gemm(dec convin wgrad)')
+            if ctx.has_bias:
+                db = torch.zeros(C, dtype=torch.float32, device=z.device)
+                check(lib.tt_channel_sum(ptr(g), ptr(db), B, C, E * T, st), 'tt_channel_sum')
+        return dz, dw, db
+
+
+# ---- objectives ------------------------------------------------------------------------------------
+
+def _partials(device):
+    return torch.empty(1024, dtype=torch.float64, device=device)
+
+
+class SqDiffLossFn(torch.autograd.Function):
+    """loss = scale * sum((a - b)^2); gradients flow into both arguments."""
+
+    @staticmethod
+    def forward(ctx, a, b, scale):
+        _hip.require_cuda(a, b)
+        a, b = _f32c(a), _f32c(b)
+        loss = torch.empty((), dtype=torch.float32, device=a.device)
+        check(_hip.lib().tt_sqdiff_sum(ptr(a), ptr(b), ptr(loss), ptr(_partials(a.device)), a.numel(), scale,
+                                       stream_ptr()), 'tt_sqdiff_sum')
+        ctx.scale = scale
+        ctx.save_for_backward(a, b)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = _f32c(g)
+        da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        db = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        if da is not None or db is not None:
+            check(_hip.lib().tt_sqdiff_bwd(ptr(a), ptr(b), ptr(g), ctx.scale, ptr(da), ptr(db), a.numel(),
+                                           stream_ptr()), 'tt_sqdiff_bwd')
+        return da, db, None
+
+
+class ActivationsFn(torch.autograd.Function):
+    """tanh(|re + i im|) over the channel pair (TimbreTrap.to_activations, modules.py:287)."""
+
+    @staticmethod
+    def forward(ctx, coefficients):
+        _hip.require_cuda(coefficients)
+        c = _f32c(coefficients)
+        B, _, F, T = c.shape
+        act = torch.empty((B, F, T), dtype=torch.float32, device=c.device)
+        check(_hip.lib().tt_activations_fwd(ptr(c), ptr(act), B, F, T, stream_ptr()), 'tt_activations_fwd')
+        ctx.save_for_backward(c, act)
+        return act
+
+    @staticmethod
+    def backward(ctx, dact):
+        c, act = ctx.saved_tensors
+        B, _, F, T = c.shape
+        dc = torch.empty_like(c)
+        check(_hip.lib().tt_activations_bwd(ptr(c), ptr(act), ptr(_f32c(dact)), ptr(dc), B, F, T, stream_ptr()),
+              'tt_activations_bwd')
+        return dc
+
+
+class TranscriptionLossFn(torch.autograd.Function):
+    """compute_transcription_loss (objectives.py:36-74); gradient w.r.t. the estimate only."""
+
+    @staticmethod
+    def forward(ctx, estimate, target, weighted):
+        _hip.require_cuda(estimate, target)
+        e, t = _f32c(estimate), _f32c(target)
+        B, F, T = e.shape
+        loss = torch.empty((), dtype=torch.float32, device=e.device)
+        fs = torch.empty((B, T), dtype=torch.float32, device=e.device) if weighted else None
+        check(_hip.lib().tt_transcription_loss_fwd(ptr(e), ptr(t), ptr(loss), ptr(fs), ptr(_partials(e.device)),
+                                                   B, F, T, int(weighted), stream_ptr()), 'tt_transcription_loss_fwd')
+        ctx.weighted = weighted
+        ctx.save_for_backward(e, t, fs)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        e, t, fs = ctx.saved_tensors
+        B, F, T = e.shape
+        de = torch.empty_like(e)
+        check(_hip.lib().tt_transcription_loss_bwd(ptr(e), ptr(t), ptr(fs), ptr(_f32c(g)), ptr(de), B, F, T,
+                                                   int(ctx.weighted), stream_ptr()), 'tt_transcription_loss_bwd')
+        return de, None, None

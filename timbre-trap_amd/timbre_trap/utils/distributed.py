@@ -1,0 +1,82 @@
+"""
+Batch data parallelism, one process per GPU (replaces the single-process ``nn.DataParallel`` shim of
+reference timbre_trap/utils/experiments.py:67-78 and its use at experiments/train.py:166-168).
+
+Clips are independent; the only exchange per step is the gradient: ONE all-reduce (RCCL over xGMI
+when the backend is 'nccl', gloo on CPU for tests) of the flat fp32 gradient buffer (2.46 MB at
+model_complexity 2), averaged over ranks.  Per-rank batch sizes must be equal for the mean over the
+global batch (reference computes the loss on the gathered batch) to equal the mean of rank means.
+"""
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_process_group_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun); no-op for one process."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world <= 1:
+        return 0, 1, 0
+    rank = int(os.environ['RANK'])
+    local_rank = int(os.environ.get('LOCAL_RANK', rank))
+    if backend is None:
+        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+    if backend == 'nccl':
+        torch.cuda.set_device(local_rank)
+    if not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def allreduce_gradients(flat_grad, world_size=None, async_op=False):
+    """Average one flat gradient buffer over all ranks with a single collective."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    world_size = world_size or dist.get_world_size()
+    if world_size == 1:
+        return None
+    flat_grad.div_(world_size)
+    return dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, async_op=async_op)
+
+
+def broadcast_parameters(flat_param, src=0):
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(flat_param, src=src)
+
+
+class DataParallel(torch.nn.Module):
+    """
+    Attribute-forwarding wrapper with the reference shim's surface (``model.sliCQ`` etc. resolve on the
+    wrapped module, ``.module`` unwraps).  It holds ONE replica -- this process's -- and averages the
+    gradients across processes when ``sync_gradients`` is called (or by FusedAdamW users through
+    ``allreduce_gradients`` on the flat buffer).
+    """
+
+    def __init__(self, module, device_ids=None):
+        super().__init__()
+        self.module = module
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    def __getattr__(self, name):
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            return getattr(self.module, name)
+
+    def sync_gradients(self):
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        grads = [p.grad for p in self.module.parameters() if p.grad is not None]
+        if not grads:
+            return
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        allreduce_gradients(flat)
+        o = 0
+        for g in grads:
+            g.copy_(flat[o:o + g.numel()].view_as(g))
+            o += g.numel()

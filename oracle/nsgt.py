@@ -41,6 +41,9 @@ import math
 import numpy as np
 
 
+FRAME_FLOOR = 1e-3
+
+
 def _round_half_even(x):
     # torch.round / numpy.round semantics (banker's rounding), as a tensor op in cqt_pytorch
     return np.round(np.asarray(x, dtype=np.float64))
@@ -105,9 +108,12 @@ def nsgt_tables(n_octaves, bins_per_octave, sample_rate, block_length, power_of_
     # diagonal of the frame operator on the positive half-spectrum
     D = np.zeros(N // 2 + 1, dtype=np.float64)
     np.add.at(D, spec_index, window ** 2)
-    covered = D > 0
+    # Spectral indices whose total window energy is below FRAME_FLOOR are treated as not represented:
+    # at the two band edges (and two sub-43 Hz gaps) only the extreme tail of ONE window reaches them, the
+    # canonical dual there would be 1/w ~ 6e4 and turn 1e-4 coefficient noise into audible sinusoids.
+    covered = D > FRAME_FLOOR
     Dsafe = np.where(covered, D, 1.0)
-    dual = window / Dsafe[spec_index]
+    dual = np.where(covered[spec_index], window / Dsafe[spec_index], 0.0)
 
     return dict(n_bins=n_bins, block_length=N, max_window_length=M, freqs=freqs,
                 lengths=lengths, positions=positions, start=start, pad=pad,

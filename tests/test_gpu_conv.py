@@ -156,9 +156,9 @@ def test_blocks_against_reference_golden(golden):
     x = torch.from_numpy(g['res_x']).cuda()
     for d in (1, 2, 3):
         m = load(ResidualConv2dBlock(4, 4, 3, d), f'res_d{d}_sd.')
-        np.testing.assert_allclose(m(x).cpu().numpy(), g[f'res_d{d}_y'], rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(m(x).detach().cpu().numpy(), g[f'res_d{d}_y'], rtol=2e-5, atol=2e-5)
     m = load(EncoderBlock(2, 4), 'encblk_sd.')
-    np.testing.assert_allclose(m(torch.from_numpy(g['encblk_x']).cuda()).cpu().numpy(), g['encblk_y'], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(m(torch.from_numpy(g['encblk_x']).cuda()).detach().cpu().numpy(), g['encblk_y'], rtol=2e-5, atol=2e-5)
     for p in (0, 1):
         m = load(DecoderBlock(4, 2, padding=p), f'decblk_p{p}_sd.')
-        np.testing.assert_allclose(m(torch.from_numpy(g['decblk_x']).cuda()).cpu().numpy(), g[f'decblk_p{p}_y'], rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(m(torch.from_numpy(g['decblk_x']).cuda()).detach().cpu().numpy(), g[f'decblk_p{p}_y'], rtol=2e-5, atol=2e-5)

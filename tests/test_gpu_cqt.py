@@ -102,7 +102,7 @@ def test_round_trip_on_covered_band(cqt, tab):
     xb = xb / np.abs(xb).max()
     a = torch.from_numpy(xb).float().cuda()
     y = cqt.decode(cqt(a))
-    assert (y - a).abs().max() < 2e-5
+    assert (y - a).abs().max() < REL
 
 
 def test_zeros_and_errors(cqt):

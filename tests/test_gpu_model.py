@@ -42,12 +42,12 @@ def test_encoder_decoder_golden(golden):
         coeffs = stub_cqt.closed_form_coefficients(1, 540, 6).cuda()
         latents, emb, losses = enc(coeffs)
         assert losses == {}
-        np.testing.assert_allclose(latents.cpu().numpy(), g[f'mc{mc}_latents'], **LOGIT_TOL)
+        np.testing.assert_allclose(latents.detach().cpu().numpy(), g[f'mc{mc}_latents'], **LOGIT_TOL)
         for i, e in enumerate(emb):
-            np.testing.assert_allclose(e.cpu().numpy(), g[f'mc{mc}_emb{i}'], **LOGIT_TOL)
+            np.testing.assert_allclose(e.detach().cpu().numpy(), g[f'mc{mc}_emb{i}'], **LOGIT_TOL)
         ind = torch.ones_like(latents[..., :1, :])
-        np.testing.assert_allclose(dec(torch.cat((latents, ind), -2)).cpu().numpy(), g[f'mc{mc}_dec'], **LOGIT_TOL)
-        np.testing.assert_allclose(dec(torch.cat((latents, 0 * ind), -2), emb).cpu().numpy(), g[f'mc{mc}_dec_skip'], **LOGIT_TOL)
+        np.testing.assert_allclose(dec(torch.cat((latents, ind), -2)).detach().cpu().numpy(), g[f'mc{mc}_dec'], **LOGIT_TOL)
+        np.testing.assert_allclose(dec(torch.cat((latents, 0 * ind), -2), emb).detach().cpu().numpy(), g[f'mc{mc}_dec_skip'], **LOGIT_TOL)
 
 
 @pytest.mark.parametrize('tag', ['mc1', 'mc2skip'])
@@ -151,7 +151,12 @@ def test_chunked_inference_transcribe_reconstruct():
     assert act.shape == (1, 540, 2 * M) and float(act.min()) >= 0 and float(act.max()) < 1
     rec = model.reconstruct(audio.cuda())
     assert rec.shape == (1, 1, 2 * N) and abs(float(rec.abs().max()) - 1.0) < 1e-5
-    want = nsgt.wrapper_decode(oae.chunked_inference(audio, sd, cqt_fwd, N, M, False).numpy().astype(np.float64), tab)
+    # reconstruct == decode(chunked_inference): check the decode on the SAME coefficients (a random-weight network
+    # emits time-smooth coefficients that the synthesis windows mostly reject, so the audio is the small remainder
+    # of a large cancellation and 1e-4 coefficient differences between two implementations do not stay 1e-4)
+    coeffs = model.chunked_inference(audio.cuda(), False)
+    assert torch.equal(model.sliCQ.decode(coeffs), rec)
+    want = nsgt.wrapper_decode(coeffs.cpu().numpy().astype(np.float64), tab)
     assert np.abs(rec.cpu().numpy() - want).max() < 1e-3
     full = model.inference(audio.cuda(), True)
     assert full.shape == (1, 2, 540, 2 * M)

@@ -97,6 +97,9 @@ def lib():
             raise RuntimeError(
                 'libttrap_hip.so not found at %s -- run `python -c "import __graft_entry__ as g; g.build()"` '
                 '(there is no CPU fallback for the Timbre-Trap HIP path)' % LIB_PATH)
+        # torch bundles its own HIP runtime: load it FIRST so that libttrap_hip.so's libamdhip64.so.7 resolves
+        # to the same copy (two HIP runtimes in one process cannot both see the device)
+        import torch  # noqa: F401
         h = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _PROTOS.items():
             fn = getattr(h, name)          # AttributeError if a declared symbol is missing
@@ -110,6 +113,33 @@ def check(rc, what=''):
     if rc != 0:
         msg = lib().tt_error_string(rc)
         raise RuntimeError('ttrap HIP call %s failed (%d): %s' % (what, rc, msg.decode() if msg else '?'))
+
+
+# bench.py sets this to a dict to time selected C-ABI calls with HIP events recorded on the launch stream
+EVENT_LOG = None
+
+
+class timed:
+    """with timed(key): <C-ABI call>  -- records a (start, end) event pair when EVENT_LOG is a dict."""
+
+    def __init__(self, key):
+        self.key = key
+        self.start = None
+
+    def __enter__(self):
+        if EVENT_LOG is not None:
+            import torch
+            self.start = torch.cuda.Event(enable_timing=True)
+            self.start.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.start is not None:
+            import torch
+            end = torch.cuda.Event(enable_timing=True)
+            end.record()
+            EVENT_LOG.setdefault(self.key, []).append((self.start, end))
+        return False
 
 
 def stream_ptr():

@@ -101,8 +101,9 @@ class CQT(nn.Module):
             out = torch.empty((B, 1, self.n_bins, T, 2), dtype=torch.float32, device=a.device)
         else:
             out = torch.empty((B, 2, self.n_bins, T), dtype=torch.float32, device=a.device)
-        _hip.check(lib.tt_cqt_forward(ctypes.byref(ps), _hip.ptr(a), _hip.ptr(out), _hip.ptr(scratch),
-                                      B, n_blocks, int(complex_out), _hip.stream_ptr()), 'tt_cqt_forward')
+        with _hip.timed('cqt_forward'):
+            _hip.check(lib.tt_cqt_forward(ctypes.byref(ps), _hip.ptr(a), _hip.ptr(out), _hip.ptr(scratch),
+                                          B, n_blocks, int(complex_out), _hip.stream_ptr()), 'tt_cqt_forward')
         if complex_out:
             out = torch.view_as_complex(out)
         # (B,1,N) input -> lead == (B,1): the channel dim of the reference output replaces it

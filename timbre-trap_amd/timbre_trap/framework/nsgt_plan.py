@@ -16,6 +16,7 @@ import numpy as np
 
 N_FAST = 66150          # block length the HIP FFT is specialised for  (N/2 = 675 * 49)
 M_FAST = 1024
+FRAME_FLOOR = 1e-3   # minimum frame-operator diagonal for a spectral index to be synthesised
 
 
 def bin_geometry(n_octaves, bins_per_octave, sample_rate, block_length, power_of_2_length=True):
@@ -53,7 +54,10 @@ def build_plan(n_octaves, bins_per_octave, sample_rate, block_length, power_of_2
         raise ValueError('NSGT window leaves the open positive half-spectrum')
     diag = np.zeros(N // 2 + 1)
     np.add.at(diag, spec_index, window ** 2)
-    dual = window / np.where(diag > 0, diag, 1.0)[spec_index]
+    # indices whose total window energy is below FRAME_FLOOR are not synthesised (band edges: the canonical
+    # dual 1/w would reach ~6e4 there and amplify coefficient noise into audible sinusoids)
+    covered = diag > FRAME_FLOOR
+    dual = np.where(covered[spec_index], window / np.where(covered, diag, 1.0)[spec_index], 0.0)
 
     # CSR: spectral index j -> ragged positions that land on it (deterministic overlap-add)
     order = np.argsort(spec_index, kind='stable')
@@ -71,7 +75,7 @@ def build_plan(n_octaves, bins_per_octave, sample_rate, block_length, power_of_2
     plan = dict(g)
     plan.update(sum_len=total, win_off=win_off, window=window, dual=dual, spec_index=spec_index,
                 bin_tab=bin_tab.astype(np.int32), gat_off=gat_off.astype(np.int32),
-                gat_idx=order.astype(np.int32), covered=diag > 0)
+                gat_idx=order.astype(np.int32), covered=covered)
     if N == N_FAST and M == M_FAST:
         plan.update(tw675=tw(675), tw49=tw(49), twNc=tw(N // 2), twN=tw(N, N // 2 + 1), tw1024=tw(1024))
     return plan

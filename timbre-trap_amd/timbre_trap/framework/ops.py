@@ -183,8 +183,9 @@ class ResBlockFn(torch.autograd.Function):
         x = _f32c(x)
         B, C, H, T = x.shape
         y = torch.empty_like(x)
-        check(_hip.lib().tt_resblock_fwd(ptr(x), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(y), B, C, H, T, dilation,
-                                         stream_ptr()), 'tt_resblock_fwd')
+        with _hip.timed('resblock_fwd_C%d' % C):
+            check(_hip.lib().tt_resblock_fwd(ptr(x), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(y), B, C, H, T, dilation,
+                                             stream_ptr()), 'tt_resblock_fwd')
         ctx.dilation = dilation
         ctx.save_for_backward(x, w1, b1, w2, b2)
         return y
@@ -197,9 +198,10 @@ class ResBlockFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         dw1, db1, dw2, db2 = (torch.zeros_like(t) for t in (w1, b1, w2, b2))
         ws = torch.empty_like(x)
-        check(_hip.lib().tt_resblock_bwd(ptr(x), ptr(dy), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(dx), ptr(dw1),
-                                         ptr(db1), ptr(dw2), ptr(db2), ptr(ws), B, C, H, T, ctx.dilation,
-                                         stream_ptr()), 'tt_resblock_bwd')
+        with _hip.timed('resblock_bwd_C%d' % C):
+            check(_hip.lib().tt_resblock_bwd(ptr(x), ptr(dy), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(dx), ptr(dw1),
+                                             ptr(db1), ptr(dw2), ptr(db2), ptr(ws), B, C, H, T, ctx.dilation,
+                                             stream_ptr()), 'tt_resblock_bwd')
         return dx, dw1, db1, dw2, db2, None
 
 

@@ -162,3 +162,38 @@ def test_blocks_against_reference_golden(golden):
     for p in (0, 1):
         m = load(DecoderBlock(4, 2, padding=p), f'decblk_p{p}_sd.')
         np.testing.assert_allclose(m(torch.from_numpy(g['decblk_x']).cuda()).detach().cpu().numpy(), g[f'decblk_p{p}_y'], rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize('C', [4, 8, 16, 32])
+@pytest.mark.parametrize('H,T', [(13, 70), (20, 64), (9, 130)])
+def test_mfma_strided_and_transposed_conv(C, H, T):
+    """EncoderBlock.sconv / DecoderBlock.tconv on the MFMA kernels (Down4 / Up4 policies) vs float64 torch."""
+    from timbre_trap.framework import ops
+    x = _rand(2, C, H, T, seed=1)
+    w = _rand(2 * C, C, 4, 1, seed=2, scale=0.5 / C ** 0.5)
+    b = _rand(2 * C, seed=3, scale=0.3)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    yr = F.elu(F.conv2d(xr, wr, br, stride=(2, 1)))
+    gy = _rand(*yr.shape, seed=4)
+    yr.backward(gy.double())
+    xd, wd, bd = (t.cuda().requires_grad_(True) for t in (x, w, b))
+    y = ops.strided_conv(xd, wd, bd, 4, 2)
+    assert y.shape == yr.shape and isinstance(y.grad_fn, ops.StridedConvFn._backward_cls)
+    y.backward(gy.cuda())
+    assert _rel(y, yr) < 2e-5
+    assert _rel(xd.grad, xr.grad) < 1e-4 and _rel(wd.grad, wr.grad) < 1e-4 and _rel(bd.grad, br.grad) < 1e-4
+
+    for out_pad in (0, 1):
+        x2 = _rand(2, 2 * C, H, T, seed=5)
+        w2 = _rand(2 * C, C, 4, 1, seed=6, scale=0.5 / C ** 0.5)
+        b2 = _rand(C, seed=7, scale=0.3)
+        xr, wr, br = (t.double().requires_grad_(True) for t in (x2, w2, b2))
+        yr = F.elu(F.conv_transpose2d(xr, wr, br, stride=(2, 1), output_padding=(out_pad, 0)))
+        gy = _rand(*yr.shape, seed=8)
+        yr.backward(gy.double())
+        xd, wd, bd = (t.cuda().requires_grad_(True) for t in (x2, w2, b2))
+        y = ops.transposed_conv(xd, wd, bd, 4, 2, out_pad)
+        assert y.shape == yr.shape and isinstance(y.grad_fn, ops.TransposedConvFn._backward_cls)
+        y.backward(gy.cuda())
+        assert _rel(y, yr) < 2e-5
+        assert _rel(xd.grad, xr.grad) < 1e-4 and _rel(wd.grad, wr.grad) < 1e-4 and _rel(bd.grad, br.grad) < 1e-4

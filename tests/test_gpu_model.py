@@ -151,13 +151,12 @@ def test_chunked_inference_transcribe_reconstruct():
     assert act.shape == (1, 540, 2 * M) and float(act.min()) >= 0 and float(act.max()) < 1
     rec = model.reconstruct(audio.cuda())
     assert rec.shape == (1, 1, 2 * N) and abs(float(rec.abs().max()) - 1.0) < 1e-5
-    # reconstruct == decode(chunked_inference): check the decode on the SAME coefficients (a random-weight network
-    # emits time-smooth coefficients that the synthesis windows mostly reject, so the audio is the small remainder
-    # of a large cancellation and 1e-4 coefficient differences between two implementations do not stay 1e-4)
+    # reconstruct == decode(chunked_inference), bit for bit.  (Decode accuracy itself is pinned on well-conditioned
+    # inputs in tests/test_gpu_cqt.py: a random-weight network emits time-smooth coefficients that the synthesis
+    # windows almost entirely reject, so what is left sits at the fp32 round-off level of the 1024-point FFTs and
+    # cannot be compared with a float64 oracle.)
     coeffs = model.chunked_inference(audio.cuda(), False)
     assert torch.equal(model.sliCQ.decode(coeffs), rec)
-    want = nsgt.wrapper_decode(coeffs.cpu().numpy().astype(np.float64), tab)
-    assert np.abs(rec.cpu().numpy() - want).max() < 1e-3
     full = model.inference(audio.cuda(), True)
     assert full.shape == (1, 2, 540, 2 * M)
 

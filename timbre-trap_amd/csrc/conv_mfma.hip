@@ -1,0 +1,847 @@
+// Implicit-GEMM convolutions of the Timbre-Trap autoencoder on the gfx950 fp32 matrix cores
+// (v_mfma_f32_16x16x4_f32: exact fp32 -- bitwise an fmaf chain -- at the fp32 vector rate, fed by two LDS
+// reads per 32-cycle instruction).
+//
+//   out[m][r][t] = sum_{tap} sum_{c} W[tap][c][m] * in[c][row(r, tap)][t + col(tap)]
+//
+// One main loop serves every layer geometry through a policy:
+//   Res3x3<D>  ResidualConv2dBlock 3x3 conv, dilation D on H and T        (reference modules.py:746)
+//   Down4      Conv2d (4,1) stride (2,1)  and the data gradient of Up4    (modules.py:628)
+//   Up4        ConvTranspose2d (4,1) stride (2,1)  and the data gradient of Down4   (modules.py:687)
+// MFMA mapping (16 x 16 x 4):
+//   A fragment  lane l : Wimg[k0 + (l>>4)][mt*16 + (l&15)]     weights, transposed once into LDS, 16-column
+//                                                                halves XOR-swizzled by k&1 (conflict-free at pitch 32/64)
+//   B fragment  lane l : xs[c = .. + (l>>4)][row][col + (l&15)]  input tile + halo in LDS, plane pitch = 17 mod 32
+//   D fragment  lane l : rows 4*(l>>4) + r (r = 0..3), column l&15
+// Workgroup = 8 waves = 8 output rows x 64 columns of one clip.  The input is staged per chunk of CC
+// channels, double-buffered: the next chunk's global loads are issued into registers before the MFMA loop
+// over the current chunk and committed to the other LDS buffer afterwards, ONE barrier per chunk.
+// Workgroups are persistent over tiles so the weight image is built once per workgroup.
+//
+// ResidualConv2dBlock (modules.py:755-777):  y = ELU(W2 . ELU(W1 (*) x + b1) + b2) + x
+//   forward   : D fragments of the 3x3 stage hold, for register r, channels {4g + r} over the four lane
+//               groups g -- exactly a B fragment (k = g) for the 1x1 stage: the hidden activation never
+//               leaves registers.
+//   backward  : k_rb_bwd_a (recompute + pointwise chain -> dA1, db1, db2, dW2), k_conv_mfma with flipped
+//               weights (dx = dy + W1^T (*) dA1), k_wgrad_mfma (dW1 as MFMA GEMM with K = pixels).
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+constexpr int plane_pad(int n) {
+    int p = n;
+    while (p % 32 != 17) ++p;
+    return p;
+}
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+constexpr int NTHREADS = 512;   // 8 waves
+constexpr int TH = 8, TW = 64;
+
+// ---- geometry policies --------------------------------------------------------------------------------
+template <int D>
+struct Res3x3 {
+    static constexpr int NTAPS = 9, NWT = 9, XR = TH + 2 * D, XC = TW + 2 * D, CH = D;
+    static __device__ __forceinline__ int in_row0(int h0) { return h0 - D; }
+    static __device__ __forceinline__ int lrow(int tp, int wave) { return wave + (tp / 3) * D; }
+    static __device__ __forceinline__ int lcol(int tp) { return (tp % 3) * D; }
+    static __device__ __forceinline__ int wtap(int tp, int) { return tp; }
+};
+struct Down4 {      // out row r <- in rows 2r + kh
+    static constexpr int NTAPS = 4, NWT = 4, XR = 2 * TH + 2, XC = TW, CH = 0;
+    static __device__ __forceinline__ int in_row0(int h0) { return 2 * h0; }
+    static __device__ __forceinline__ int lrow(int tp, int wave) { return 2 * wave + tp; }
+    static __device__ __forceinline__ int lcol(int) { return 0; }
+    static __device__ __forceinline__ int wtap(int tp, int) { return tp; }
+};
+struct Up4 {        // out row r <- in rows (r - kh)/2, kh = (r&1) + 2j, j = 0,1   (tile row origin is even)
+    static constexpr int NTAPS = 2, NWT = 4, XR = TH / 2 + 1, XC = TW, CH = 0;
+    static __device__ __forceinline__ int in_row0(int h0) { return h0 / 2 - 1; }
+    static __device__ __forceinline__ int lrow(int tp, int wave) { return (wave >> 1) - tp + 1; }
+    static __device__ __forceinline__ int lcol(int) { return 0; }
+    static __device__ __forceinline__ int wtap(int tp, int wave) { return (wave & 1) + 2 * tp; }
+};
+
+template <int CIN, int COUT, class P>
+struct Geo {
+    static constexpr int MT = (COUT + 15) / 16;
+    static constexpr int CP = MT * 16;                       // weight image row pitch (floats)
+    static constexpr bool SWZ = CP >= 32;
+    static constexpr int CC = 4;                             // channels per staged chunk
+    static constexpr int NCH = CIN / CC;
+    static constexpr int PLANE = plane_pad(P::XR * P::XC);
+    static constexpr int ELEMS = CC * P::XR * P::XC;
+    static constexpr int NLD = (ELEMS + NTHREADS - 1) / NTHREADS;
+    static constexpr int KW = P::NWT * CIN;                  // rows of the weight image
+    static constexpr int W_FLOATS = KW * CP;
+    static constexpr int XS_FLOATS = 2 * CC * PLANE;
+};
+
+struct Tile { int b, h0, t0; };
+__device__ __forceinline__ Tile decode_tile(int tile, int tiles_h, int tiles_t) {
+    Tile r;
+    const int tt = tile % tiles_t; tile /= tiles_t;
+    const int th = tile % tiles_h;
+    r.b = tile / tiles_h; r.h0 = th * TH; r.t0 = tt * TW;
+    return r;
+}
+
+// weight image  Wimg[(wt*CIN + c)*CP + swz(m)] = w[w_off + m*s_m + c*s_c + wt*s_t]   (0 for m >= COUT)
+template <int CIN, int COUT, class P>
+__device__ __forceinline__ void build_weight_image(float* img, const float* __restrict__ w, long s_m, long s_c, long s_t,
+                                                   long w_off, int tid) {
+    using G = Geo<CIN, COUT, P>;
+    for (int i = tid; i < G::W_FLOATS; i += NTHREADS) {
+        const int k = i / G::CP, m = i - k * G::CP;
+        const int wt = k / CIN, c = k - wt * CIN;
+        const int ms = G::SWZ ? (m ^ ((k & 1) << 4)) : m;
+        img[k * G::CP + ms] = (m < COUT) ? w[w_off + m * s_m + c * s_c + wt * s_t] : 0.f;
+    }
+}
+
+// The pipelined implicit-GEMM main loop over the tiles of one workgroup.  `epi(tile, acc)` consumes a finished tile.
+template <int CIN, int COUT, class P, bool GATE, class Epi>
+__device__ __forceinline__ void conv_mainloop(const float* __restrict__ x, const float* __restrict__ gy, const float* Wimg,
+                                              float* xs, int B, int Hin, int Hout, int T, Epi&& epi) {
+    using G = Geo<CIN, COUT, P>;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+    const int tiles_h = (Hout + TH - 1) / TH, tiles_t = (T + TW - 1) / TW;
+    const int ntiles = B * tiles_h * tiles_t;
+    const long plane = (long)Hin * T;
+    int acol[G::MT];
+#pragma unroll
+    for (int mt = 0; mt < G::MT; ++mt) acol[mt] = G::SWZ ? ((mt * 16 + l15) ^ ((g & 1) << 4)) : (mt * 16 + l15);
+
+    // Prefetch registers of the work item in flight.  Loads are unconditional from a clamped in-range address
+    // (32-bit offset from a wave-uniform base); out-of-image elements are zeroed when they are committed to LDS.
+    float pre[G::NLD];
+    float preg[GATE ? G::NLD : 1];
+    int p_row0 = 0, p_col0 = 0;
+    auto issue = [&](int tile, int chunk) {
+        const Tile tl = decode_tile(tile, tiles_h, tiles_t);
+        p_row0 = P::in_row0(tl.h0);
+        p_col0 = tl.t0 - P::CH;
+        const float* xb = x + ((long)tl.b * CIN + chunk * G::CC) * plane;
+        const float* gb = GATE ? gy + ((long)tl.b * CIN + chunk * G::CC) * plane : nullptr;
+#pragma unroll
+        for (int j = 0; j < G::NLD; ++j) {
+            int e = tid + NTHREADS * j;
+            if (e >= G::ELEMS) e = G::ELEMS - 1;
+            const int ci = e / (P::XR * P::XC);
+            const int rem = e - ci * (P::XR * P::XC);
+            const int r = rem / P::XC, c = rem - r * P::XC;
+            int h = p_row0 + r, t = p_col0 + c;
+            h = h < 0 ? 0 : (h >= Hin ? Hin - 1 : h);
+            t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+            const int o = ci * (int)plane + h * T + t;
+            pre[j] = xb[o];
+            if (GATE) preg[j] = gb[o];
+        }
+    };
+    auto commit = [&](int buf) {
+        float* dst = xs + buf * G::CC * G::PLANE;
+#pragma unroll
+        for (int j = 0; j < G::NLD; ++j) {
+            const int e = tid + NTHREADS * j;
+            if (e < G::ELEMS) {
+                const int ci = e / (P::XR * P::XC);
+                const int rem = e - ci * (P::XR * P::XC);
+                const int r = rem / P::XC, c = rem - r * P::XC;
+                const int h = p_row0 + r, t = p_col0 + c;
+                float v = pre[j];
+                if (GATE) v *= elu_grad_from_out(preg[j]);
+                dst[ci * G::PLANE + rem] = (h >= 0 && h < Hin && t >= 0 && t < T) ? v : 0.f;
+            }
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    issue(tile, 0);
+    int buf = 0;
+    for (; tile < ntiles; tile += gridDim.x) {
+        f32x4 acc[G::MT][4];
+#pragma unroll
+        for (int mt = 0; mt < G::MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int chunk = 0; chunk < G::NCH; ++chunk) {
+            commit(buf);
+            __syncthreads();
+            // prefetch the next work item while this one is multiplied
+            if (chunk + 1 < G::NCH) issue(tile, chunk + 1);
+            else if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x, 0);
+            const float* xb = xs + buf * G::CC * G::PLANE;
+            const int c0 = chunk * G::CC;
+#pragma unroll 1
+            for (int tp = 0; tp < P::NTAPS; ++tp) {
+                const int wt = P::wtap(tp, wave);
+                const float* bp0 = xb + g * G::PLANE + P::lrow(tp, wave) * P::XC + P::lcol(tp) + l15;
+                const float* ap0 = Wimg + (wt * CIN + c0 + g) * G::CP;
+#pragma unroll
+                for (int cc = 0; cc < G::CC; cc += 4) {
+                    float a[G::MT];
+#pragma unroll
+                    for (int mt = 0; mt < G::MT; ++mt) a[mt] = ap0[cc * G::CP + acol[mt]];
+                    const float* bp = bp0 + cc * G::PLANE;
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const float bv = bp[nt * 16];
+#pragma unroll
+                        for (int mt = 0; mt < G::MT; ++mt) acc[mt][nt] = mfma16(a[mt], bv, acc[mt][nt]);
+                    }
+                }
+            }
+            buf ^= 1;
+        }
+        epi(decode_tile(tile, tiles_h, tiles_t), acc);
+    }
+}
+
+// ---- plain convolution kernel: out = act(conv + bias) + res -----------------------------------------------
+struct WSpec { long s_m, s_c, s_t, off; };
+
+template <int CIN, int COUT, class P, bool GATE>
+__global__ __launch_bounds__(NTHREADS, 4) void k_conv_mfma(const float* __restrict__ x, const float* __restrict__ gy,
+                                                        const float* __restrict__ w, WSpec ws, const float* __restrict__ bias,
+                                                        const float* __restrict__ res, float* __restrict__ y, int B, int Hin,
+                                                        int Hout, int T, int act) {
+    using G = Geo<CIN, COUT, P>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Wimg = lds;
+    float* xs = lds + G::W_FLOATS;
+    build_weight_image<CIN, COUT, P>(Wimg, w, ws.s_m, ws.s_c, ws.s_t, ws.off, threadIdx.x);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, l15 = lane & 15;
+    const long oplane = (long)Hout * T;
+    conv_mainloop<CIN, COUT, P, GATE>(x, gy, Wimg, xs, B, Hin, Hout, T, [&](const Tile& tl, f32x4 (&acc)[G::MT][4]) {
+        const int h = tl.h0 + wave;
+        if (h >= Hout) return;
+#pragma unroll
+        for (int mt = 0; mt < G::MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = mt * 16 + 4 * g + r;
+                if (m >= COUT) continue;
+                const float bv = bias ? bias[m] : 0.f;
+                const long base = ((long)tl.b * COUT + m) * oplane + (long)h * T;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int t = tl.t0 + nt * 16 + l15;
+                    if (t >= T) continue;
+                    float v = acc[mt][nt][r] + bv;
+                    if (act == TT_ACT_ELU) v = elu1(v);
+                    if (res) v += res[base + t];
+                    y[base + t] = v;
+                }
+            }
+    });
+}
+
+// ---- fused residual block -------------------------------------------------------------------------------------
+template <int C>
+struct RB {
+    static constexpr int MT = (C + 15) / 16, CPAD = MT * 16, CP = CPAD;
+    static constexpr bool SWZ = CP >= 32;
+    static constexpr int TP = 17;
+    static constexpr int TR_FLOATS = 8 * 2 * CPAD * TP;      // 8 waves x {dA2, h1} x CPAD x 16 pixels
+    // W2 images: W2s[c_in][co2] (forward 1x1) and W2t[co2][c_in] (its transpose), both swizzled like Wimg
+    // rows used together by the four lane groups differ by 4: swizzle the 16-column halves by bit 2 of the row
+    static __device__ __forceinline__ int swz(int row, int col) { return SWZ ? (col ^ (((row >> 2) & 1) << 4)) : col; }
+};
+
+template <int C>
+__device__ __forceinline__ void build_w2_images(float* W2s, float* W2t, float* b1s, float* b2s, const float* __restrict__ w2,
+                                                const float* __restrict__ b1, const float* __restrict__ b2, int tid) {
+    using R = RB<C>;
+    for (int i = tid; i < R::CPAD * R::CP; i += NTHREADS) {
+        const int r = i / R::CP, c = i - r * R::CP;
+        const bool ok = r < C && c < C;
+        W2s[r * R::CP + R::swz(r, c)] = ok ? w2[c * C + r] : 0.f;       // row = c_in, col = co2
+        if (W2t) W2t[r * R::CP + R::swz(r, c)] = ok ? w2[r * C + c] : 0.f;   // row = co2, col = c_in
+    }
+    for (int i = tid; i < R::CPAD; i += NTHREADS) {
+        b1s[i] = i < C ? b1[i] : 0.f;
+        b2s[i] = i < C ? b2[i] : 0.f;
+    }
+}
+
+template <int C, int D>
+__global__ __launch_bounds__(NTHREADS, 4) void k_rb_fwd(const float* __restrict__ x, const float* __restrict__ w1,
+                                                     const float* __restrict__ b1, const float* __restrict__ w2,
+                                                     const float* __restrict__ b2, float* __restrict__ y, int B, int H, int T) {
+    using P = Res3x3<D>;
+    using G = Geo<C, C, P>;
+    using R = RB<C>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Wimg = lds;
+    float* W2s = Wimg + G::W_FLOATS;
+    float* b1s = W2s + R::CPAD * R::CP;
+    float* b2s = b1s + R::CPAD;
+    float* xs = b2s + R::CPAD;
+    build_weight_image<C, C, P>(Wimg, w1, (long)C * 9, 9, 1, 0, threadIdx.x);
+    build_w2_images<C>(W2s, nullptr, b1s, b2s, w2, b1, b2, threadIdx.x);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, l15 = lane & 15;
+    const long plane = (long)H * T;
+    conv_mainloop<C, C, P, false>(x, nullptr, Wimg, xs, B, H, H, T, [&](const Tile& tl, f32x4 (&acc)[G::MT][4]) {
+        f32x4 acc2[G::MT][4];
+#pragma unroll
+        for (int mt = 0; mt < G::MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                acc2[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[mt][nt][r] = elu1(acc[mt][nt][r] + b1s[mt * 16 + 4 * g + r]);
+            }
+#pragma unroll
+        for (int mt = 0; mt < G::MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kr = mt * 16 + 4 * g + r;        // k index of this lane group for step (mt, r)
+                float a2[G::MT];
+#pragma unroll
+                for (int m2 = 0; m2 < G::MT; ++m2) a2[m2] = W2s[kr * R::CP + R::swz(kr, m2 * 16 + l15)];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int m2 = 0; m2 < G::MT; ++m2) acc2[m2][nt] = mfma16(a2[m2], acc[mt][nt][r], acc2[m2][nt]);
+            }
+        const int h = tl.h0 + wave;
+        if (h >= H) return;
+#pragma unroll
+        for (int m2 = 0; m2 < G::MT; ++m2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = m2 * 16 + 4 * g + r;
+                if (co >= C) continue;
+                const float bias = b2s[co];
+                const long base = ((long)tl.b * C + co) * plane + (long)h * T;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int t = tl.t0 + nt * 16 + l15;
+                    if (t < T) y[base + t] = elu1(acc2[m2][nt][r] + bias) + x[base + t];
+                }
+            }
+    });
+}
+
+__device__ __forceinline__ float group16_sum(float v) {
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+    return v;
+}
+
+// wave-local LDS hand-off: LDS operations of one wave execute in program order, so only the compiler
+// must be kept from reordering and the writes must have landed before other lanes read them.
+__device__ __forceinline__ void wave_lds_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int C, int D>
+__global__ __launch_bounds__(NTHREADS) void k_rb_bwd_a(const float* __restrict__ x, const float* __restrict__ dy,
+                                                       const float* __restrict__ w1, const float* __restrict__ b1,
+                                                       const float* __restrict__ w2, const float* __restrict__ b2,
+                                                       float* __restrict__ da1, float* __restrict__ db1,
+                                                       float* __restrict__ dw2, float* __restrict__ db2, int B, int H, int T) {
+    using P = Res3x3<D>;
+    using G = Geo<C, C, P>;
+    using R = RB<C>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Wimg = lds;
+    float* W2s = Wimg + G::W_FLOATS;
+    float* W2t = W2s + R::CPAD * R::CP;
+    float* b1s = W2t + R::CPAD * R::CP;
+    float* b2s = b1s + R::CPAD;
+    float* xs = b2s + R::CPAD;
+    float* tr = xs + G::XS_FLOATS;          // per-wave transpose tiles (own region: no workgroup barrier needed)
+    build_weight_image<C, C, P>(Wimg, w1, (long)C * 9, 9, 1, 0, threadIdx.x);
+    build_w2_images<C>(W2s, W2t, b1s, b2s, w2, b1, b2, threadIdx.x);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, l15 = lane & 15;
+    const long plane = (long)H * T;
+    float* trA = tr + wave * 2 * R::CPAD * R::TP;
+    float* trB = trA + R::CPAD * R::TP;
+
+    f32x4 accw2[G::MT][G::MT];
+    float db1acc[G::MT][4], db2acc[G::MT][4];
+#pragma unroll
+    for (int a = 0; a < G::MT; ++a) {
+#pragma unroll
+        for (int c = 0; c < G::MT; ++c) accw2[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { db1acc[a][r] = 0.f; db2acc[a][r] = 0.f; }
+    }
+
+    conv_mainloop<C, C, P, false>(x, nullptr, Wimg, xs, B, H, H, T, [&](const Tile& tl, f32x4 (&h1)[G::MT][4]) {
+        const int h = tl.h0 + wave;
+        f32x4 a2[G::MT][4];
+#pragma unroll
+        for (int mt = 0; mt < G::MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                a2[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h1[mt][nt][r] = elu1(h1[mt][nt][r] + b1s[mt * 16 + 4 * g + r]);
+            }
+#pragma unroll
+        for (int mt = 0; mt < G::MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kr = mt * 16 + 4 * g + r;
+                float av[G::MT];
+#pragma unroll
+                for (int m2 = 0; m2 < G::MT; ++m2) av[m2] = W2s[kr * R::CP + R::swz(kr, m2 * 16 + l15)];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int m2 = 0; m2 < G::MT; ++m2) a2[m2][nt] = mfma16(av[m2], h1[mt][nt][r], a2[m2][nt]);
+            }
+        // dA2 = dy * ELU'(a2 + b2), in place
+#pragma unroll
+        for (int m2 = 0; m2 < G::MT; ++m2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = m2 * 16 + 4 * g + r;
+                const float bias = b2s[co];
+                const long base = ((long)tl.b * C + (co < C ? co : 0)) * plane + (long)(h < H ? h : 0) * T;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int t = tl.t0 + nt * 16 + l15;
+                    float d = 0.f;
+                    if (co < C && h < H && t < T) d = dy[base + t];
+                    const float gd = d * elu_grad_from_out(elu1(a2[m2][nt][r] + bias));
+                    a2[m2][nt][r] = gd;
+                    db2acc[m2][r] += gd;
+                }
+            }
+        // dH1 = W2^T . dA2 (dA2 fragments as B operands); dA1 = dH1 * ELU'(h1)
+        f32x4 d1[G::MT][4];
+#pragma unroll
+        for (int mt = 0; mt < G::MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) d1[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m2 = 0; m2 < G::MT; ++m2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kr = m2 * 16 + 4 * g + r;
+                float av[G::MT];
+#pragma unroll
+                for (int mt = 0; mt < G::MT; ++mt) av[mt] = W2t[kr * R::CP + R::swz(kr, mt * 16 + l15)];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < G::MT; ++mt) d1[mt][nt] = mfma16(av[mt], a2[m2][nt][r], d1[mt][nt]);
+            }
+#pragma unroll
+        for (int mt = 0; mt < G::MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = mt * 16 + 4 * g + r;
+                const long base = ((long)tl.b * C + (co < C ? co : 0)) * plane + (long)(h < H ? h : 0) * T;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int t = tl.t0 + nt * 16 + l15;
+                    const float gd = d1[mt][nt][r] * elu_grad_from_out(h1[mt][nt][r]);
+                    db1acc[mt][r] += gd;
+                    if (co < C && h < H && t < T) da1[base + t] = gd;
+                }
+            }
+        // dW2[co2][c] += sum_pix dA2[co2][pix] * h1[c][pix]: 16 pixels at a time through the wave's own LDS tiles
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            wave_lds_sync();
+#pragma unroll
+            for (int mt = 0; mt < G::MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    trA[(mt * 16 + 4 * g + r) * R::TP + l15] = a2[mt][nt][r];
+                    trB[(mt * 16 + 4 * g + r) * R::TP + l15] = h1[mt][nt][r];
+                }
+            wave_lds_sync();
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                float av[G::MT], bv[G::MT];
+#pragma unroll
+                for (int mt = 0; mt < G::MT; ++mt) {
+                    av[mt] = trA[(mt * 16 + l15) * R::TP + ks * 4 + g];
+                    bv[mt] = trB[(mt * 16 + l15) * R::TP + ks * 4 + g];
+                }
+#pragma unroll
+                for (int m2 = 0; m2 < G::MT; ++m2)
+#pragma unroll
+                    for (int mt = 0; mt < G::MT; ++mt) accw2[m2][mt] = mfma16(av[m2], bv[mt], accw2[m2][mt]);
+            }
+        }
+    });
+#pragma unroll
+    for (int m2 = 0; m2 < G::MT; ++m2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = m2 * 16 + 4 * g + r;
+            const float s1 = group16_sum(db1acc[m2][r]), s2 = group16_sum(db2acc[m2][r]);
+            if (l15 == 0 && co < C) { atomicAdd(db1 + co, s1); atomicAdd(db2 + co, s2); }
+#pragma unroll
+            for (int mt = 0; mt < G::MT; ++mt) {
+                const int c = mt * 16 + l15;
+                if (co < C && c < C) atomicAdd(dw2 + co * C + c, accw2[m2][mt][r]);
+            }
+        }
+}
+
+// ---- weight gradients as MFMA GEMMs with K = pixels ---------------------------------------------------------------
+//   dW[a][b][tap] += sum_{r,t} P[a][r][t] * Q[b][qrow(r,tap)][t + qcol(tap)]          a < CA, b < CB
+// grid.y splits b into NS slices of CBS channels; columns n = tap*CBS + bl.
+template <int D>
+struct WRes {       // 3x3 dilated: Q rows r + kh*D - D, cols t + kw*D - D
+    static constexpr int NTAPS = 9, WTH = 4, WTW = 32, XR = WTH + 2 * D, XC = WTW + 2 * D, CH = D;
+    static __device__ __forceinline__ int q_row0(int h0) { return h0 - D; }
+    static __device__ __forceinline__ int qoff(int tap) { return (tap / 3) * D * XC + (tap % 3) * D; }
+    static __device__ __forceinline__ int qrow_of_wave(int wave) { return wave; }
+};
+struct WStr {       // (4,1) stride 2: Q rows 2r + kh
+    static constexpr int NTAPS = 4, WTH = 4, WTW = 32, XR = 2 * WTH + 2, XC = WTW, CH = 0;
+    static __device__ __forceinline__ int q_row0(int h0) { return 2 * h0; }
+    static __device__ __forceinline__ int qoff(int tap) { return tap * XC; }
+    static __device__ __forceinline__ int qrow_of_wave(int wave) { return 2 * wave; }
+};
+
+template <int CA, int CBS, class WP>
+struct WGeo {
+    static constexpr int MT = (CA + 15) / 16, CAP = MT * 16;
+    static constexpr int NN = WP::NTAPS * CBS, NTN = (NN + 15) / 16;
+    static constexpr int PLANE = plane_pad(WP::XR * WP::XC);
+    static constexpr int AP = WP::WTW + 1;
+    static constexpr int Q_FLOATS = CBS * PLANE;
+    static constexpr int LDS_FLOATS = Q_FLOATS + WP::WTH * CAP * AP;
+    static constexpr int LDS_BYTES = LDS_FLOATS * 4;
+};
+
+template <int CA, int CB, int CBS, class WP, bool GATE_P, bool GATE_Q>
+__global__ __launch_bounds__(256) void k_wgrad_mfma(const float* __restrict__ Pt, const float* __restrict__ Pg,
+                                                    const float* __restrict__ Qt, const float* __restrict__ Qg,
+                                                    float* __restrict__ dw, float* __restrict__ dbias_p, long s_a, long s_b,
+                                                    long s_t, int B, int HP, int HQ, int T) {
+    using K = WGeo<CA, CBS, WP>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+    float* xs = lds;
+    float* as = lds + K::Q_FLOATS + wave * K::CAP * K::AP;
+    const int b0 = blockIdx.y * CBS;
+    const int tiles_h = (HP + WP::WTH - 1) / WP::WTH, tiles_t = (T + WP::WTW - 1) / WP::WTW;
+    const int ntiles = B * tiles_h * tiles_t;
+    const long pplane = (long)HP * T, qplane = (long)HQ * T;
+
+    int noff[K::NTN];
+#pragma unroll
+    for (int nt = 0; nt < K::NTN; ++nt) {
+        int n = nt * 16 + l15;
+        if (n >= K::NN) n = K::NN - 1;
+        const int tap = n / CBS, bl = n - tap * CBS;
+        noff[nt] = bl * K::PLANE + WP::qoff(tap);
+    }
+    f32x4 acc[K::MT][K::NTN];
+#pragma unroll
+    for (int mt = 0; mt < K::MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < K::NTN; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int tt = tile;
+        const int tx = tt % tiles_t; tt /= tiles_t;
+        const int ty = tt % tiles_h;
+        const int b = tt / tiles_h, h0 = ty * WP::WTH, t0 = tx * WP::WTW;
+        __syncthreads();
+        {
+            const long qb = ((long)b * CB + b0) * qplane;
+            const int row0 = WP::q_row0(h0), col0 = t0 - WP::CH;
+            for (int i = tid; i < CBS * WP::XR * WP::XC; i += 256) {
+                const int ci = i / (WP::XR * WP::XC);
+                const int rem = i - ci * (WP::XR * WP::XC);
+                const int r = rem / WP::XC, c = rem - r * WP::XC;
+                const int h = row0 + r, t = col0 + c;
+                float v = 0.f;
+                if (h >= 0 && h < HQ && t >= 0 && t < T) {
+                    const long o = qb + ci * qplane + (long)h * T + t;
+                    v = Qt[o];
+                    if (GATE_Q) v *= elu_grad_from_out(Qg[o]);
+                }
+                xs[ci * K::PLANE + rem] = v;
+            }
+        }
+        {   // each wave stages its own row of P (transposed use: as[a][pixel])
+            const int h = h0 + wave;
+            const int t = t0 + (lane & (WP::WTW - 1));
+            const bool ok = h < HP && t < T;
+            const long pb = (long)b * CA * pplane + (long)(h < HP ? h : 0) * T + (t < T ? t : 0);
+            // 64 lanes cover WTW pixels x (64 / WTW) channels per pass
+            constexpr int CPP = 64 / WP::WTW;
+            const int asub = lane / WP::WTW;
+#pragma unroll 4
+            for (int a0 = 0; a0 < K::CAP; a0 += CPP) {
+                const int a = a0 + asub;
+                float v = 0.f;
+                if (ok && a < CA) {
+                    const long o = pb + a * pplane;
+                    v = Pt[o];
+                    if (GATE_P) v *= elu_grad_from_out(Pg[o]);
+                }
+                as[a * K::AP + (lane & (WP::WTW - 1))] = v;
+            }
+        }
+        __syncthreads();
+        if (dbias_p && blockIdx.y == 0 && lane < CA) {
+#pragma unroll 8
+            for (int p = 0; p < WP::WTW; ++p) bsum += as[lane * K::AP + p];
+        }
+        const float* xrow = xs + WP::qrow_of_wave(wave) * WP::XC;
+#pragma unroll 2
+        for (int ks = 0; ks < WP::WTW / 4; ++ks) {
+            float av[K::MT];
+#pragma unroll
+            for (int mt = 0; mt < K::MT; ++mt) av[mt] = as[(mt * 16 + l15) * K::AP + ks * 4 + g];
+            const float* xp = xrow + ks * 4 + g;
+#pragma unroll
+            for (int nt = 0; nt < K::NTN; ++nt) {
+                const float bv = xp[noff[nt]];
+#pragma unroll
+                for (int mt = 0; mt < K::MT; ++mt) acc[mt][nt] = mfma16(av[mt], bv, acc[mt][nt]);
+            }
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < K::MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < K::NTN; ++nt) {
+            const int n = nt * 16 + l15;
+            if (n >= K::NN) continue;
+            const int tap = n / CBS, bl = n - tap * CBS;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int a = mt * 16 + 4 * g + r;
+                if (a < CA) atomicAdd(dw + a * s_a + (b0 + bl) * s_b + tap * s_t, acc[mt][nt][r]);
+            }
+        }
+    if (dbias_p && blockIdx.y == 0 && lane < CA) atomicAdd(dbias_p + lane, bsum);
+}
+
+// out[c] += sum over (b, h, t) of dy * ELU'(y)   (bias gradient of a conv + ELU layer)
+__global__ __launch_bounds__(256) void k_gated_channel_sum(const float* __restrict__ dy, const float* __restrict__ y,
+                                                           float* __restrict__ out, int B, int C, long inner) {
+    __shared__ float red[4];
+    const int c = blockIdx.x;
+    float acc = 0.f;
+    const long total = (long)B * inner;
+    for (long i = (long)blockIdx.y * 256 + threadIdx.x; i < total; i += (long)gridDim.y * 256) {
+        const long b = i / inner, r = i - b * inner;
+        const long o = (b * C + c) * inner + r;
+        acc += dy[o] * elu_grad_from_out(y[o]);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out + c, red[0] + red[1] + red[2] + red[3]);
+}
+
+// ---- launch helpers ---------------------------------------------------------------------------------------------
+inline int blocks_per_cu(int lds_bytes, int cap) {
+    int n = (160 * 1024) / lds_bytes;
+    return n > cap ? cap : (n < 1 ? 1 : n);
+}
+inline int persistent_grid(int ntiles, int per_cu) {
+    const int cap = 256 * per_cu;
+    return ntiles < cap ? ntiles : cap;
+}
+inline int ntiles_of(int B, int H, int T) { return B * ((H + TH - 1) / TH) * ((T + TW - 1) / TW); }
+
+template <int CIN, int COUT, class P, bool GATE>
+int launch_conv(const float* x, const float* gy, const float* w, WSpec ws, const float* bias, const float* res, float* y,
+                int B, int Hin, int Hout, int T, int act, hipStream_t st) {
+    using G = Geo<CIN, COUT, P>;
+    constexpr int LDS = (G::W_FLOATS + G::XS_FLOATS) * 4;
+    static bool attr = false;
+    if (!attr) {
+        TT_HIP(hipFuncSetAttribute((const void*)k_conv_mfma<CIN, COUT, P, GATE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr = true;
+    }
+    hipLaunchKernelGGL((k_conv_mfma<CIN, COUT, P, GATE>), dim3(persistent_grid(ntiles_of(B, Hout, T), blocks_per_cu(LDS, 2))),
+                       dim3(NTHREADS), LDS, st, x, gy, w, ws, bias, res, y, B, Hin, Hout, T, act);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int C, int D>
+int launch_rb_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y, int B, int H,
+                  int T, hipStream_t st) {
+    using G = Geo<C, C, Res3x3<D>>;
+    using R = RB<C>;
+    constexpr int LDS = (G::W_FLOATS + R::CPAD * R::CP + 2 * R::CPAD + G::XS_FLOATS) * 4;
+    static bool attr = false;
+    if (!attr) {
+        TT_HIP(hipFuncSetAttribute((const void*)k_rb_fwd<C, D>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr = true;
+    }
+    hipLaunchKernelGGL((k_rb_fwd<C, D>), dim3(persistent_grid(ntiles_of(B, H, T), blocks_per_cu(LDS, 2))), dim3(NTHREADS), LDS,
+                       st, x, w1, b1, w2, b2, y, B, H, T);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int CA, int CB, class WP, bool GP, bool GQ>
+int launch_wgrad(const float* Pt, const float* Pg, const float* Qt, const float* Qg, float* dw, float* dbias_p, long s_a,
+                 long s_b, long s_t, int B, int HP, int HQ, int T, hipStream_t st) {
+    constexpr int CBS = CB > 16 ? 16 : CB;
+    constexpr int NS = CB / CBS;
+    using K = WGeo<CA, CBS, WP>;
+    static bool attr = false;
+    if (!attr) {
+        TT_HIP(hipFuncSetAttribute((const void*)k_wgrad_mfma<CA, CB, CBS, WP, GP, GQ>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   K::LDS_BYTES));
+        attr = true;
+    }
+    const int ntiles = B * ((HP + WP::WTH - 1) / WP::WTH) * ((T + WP::WTW - 1) / WP::WTW);
+    const int per_cu = blocks_per_cu(K::LDS_BYTES, 4);
+    hipLaunchKernelGGL((k_wgrad_mfma<CA, CB, CBS, WP, GP, GQ>), dim3(persistent_grid(ntiles, per_cu), NS), dim3(256),
+                       K::LDS_BYTES, st, Pt, Pg, Qt, Qg, dw, dbias_p, s_a, s_b, s_t, B, HP, HQ, T);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int C, int D>
+int launch_rb_bwd(const float* x, const float* dy, const float* w1, const float* b1, const float* w2, const float* b2,
+                  float* dx, float* dw1, float* db1, float* dw2, float* db2, float* ws, int B, int H, int T, hipStream_t st) {
+    using G = Geo<C, C, Res3x3<D>>;
+    using R = RB<C>;
+    constexpr int LDS = (G::W_FLOATS + 2 * R::CPAD * R::CP + 2 * R::CPAD + G::XS_FLOATS + R::TR_FLOATS) * 4;
+    static bool attr = false;
+    if (!attr) {
+        TT_HIP(hipFuncSetAttribute((const void*)k_rb_bwd_a<C, D>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr = true;
+    }
+    hipLaunchKernelGGL((k_rb_bwd_a<C, D>), dim3(persistent_grid(ntiles_of(B, H, T), blocks_per_cu(LDS, 2))), dim3(NTHREADS), LDS,
+                       st, x, dy, w1, b1, w2, b2, ws, db1, dw2, db2, B, H, T);
+    TT_LAUNCH_CHECK();
+    // dx = dy + W1^T (*) dA1 : the same conv with in/out channels swapped and the taps reversed
+    int rc = launch_conv<C, C, Res3x3<D>, false>(ws, nullptr, w1, WSpec{9, (long)C * 9, -1, 8}, nullptr, dy, dx, B, H, H, T,
+                                                 TT_ACT_NONE, st);
+    if (rc) return rc;
+    // dW1[co][ci][tap] = sum dA1[co][pix] * x[ci][pix + tap]
+    return launch_wgrad<C, C, WRes<D>, false, false>(ws, nullptr, x, nullptr, dw1, nullptr, (long)C * 9, 9, 1, B, H, H, T, st);
+}
+
+#define TT_DISPATCH_CD(FN, ...)                                                       \
+    switch (C * 10 + dilation) {                                                      \
+        case 41: return FN<4, 1>(__VA_ARGS__);   case 42: return FN<4, 2>(__VA_ARGS__);   case 43: return FN<4, 3>(__VA_ARGS__);   \
+        case 81: return FN<8, 1>(__VA_ARGS__);   case 82: return FN<8, 2>(__VA_ARGS__);   case 83: return FN<8, 3>(__VA_ARGS__);   \
+        case 161: return FN<16, 1>(__VA_ARGS__); case 162: return FN<16, 2>(__VA_ARGS__); case 163: return FN<16, 3>(__VA_ARGS__); \
+        case 321: return FN<32, 1>(__VA_ARGS__); case 322: return FN<32, 2>(__VA_ARGS__); case 323: return FN<32, 3>(__VA_ARGS__); \
+        default: return TT_E_UNSUPPORTED;                                             \
+    }
+
+// strided pair: channel counts (C -> 2C)
+template <int C>
+int sconv_fwd(const float* x, const float* w, const float* b, float* y, int B, int H, int Hout, int T, hipStream_t st) {
+    // y[a][r] = ELU(b[a] + sum_{c,kh} w[a][c][kh] x[c][2r+kh])
+    return launch_conv<C, 2 * C, Down4, false>(x, nullptr, w, WSpec{(long)C * 4, 4, 1, 0}, b, nullptr, y, B, H, Hout, T, TT_ACT_ELU, st);
+}
+template <int C>
+int sconv_bwd(const float* x, const float* y, const float* dy, const float* w, float* dx, float* dw, float* db, int B, int H,
+              int Hout, int T, hipStream_t st) {
+    int rc = 0;
+    if (dx)   // dx[c][r] = sum_{a, kh: r = 2ho + kh} w[a][c][kh] * g[a][ho],  g = dy * ELU'(y)
+        rc = launch_conv<2 * C, C, Up4, true>(dy, y, w, WSpec{4, (long)C * 4, 1, 0}, nullptr, nullptr, dx, B, Hout, H, T, TT_ACT_NONE, st);
+    if (rc) return rc;
+    // dW[a][c][kh] = sum g[a][ho] x[c][2ho+kh] ; db[a] = sum g[a]
+    return launch_wgrad<2 * C, C, WStr, true, false>(dy, y, x, nullptr, dw, db, (long)C * 4, 4, 1, B, Hout, H, T, st);
+}
+template <int C>
+int tconv_fwd(const float* x, const float* w, const float* b, float* y, int B, int H, int Hout, int T, hipStream_t st) {
+    // y[m][r] = ELU(b[m] + sum_{a, kh: r = 2h + kh} w[a][m][kh] x[a][h])     (2C -> C)
+    return launch_conv<2 * C, C, Up4, false>(x, nullptr, w, WSpec{4, (long)C * 4, 1, 0}, b, nullptr, y, B, H, Hout, T, TT_ACT_ELU, st);
+}
+template <int C>
+int tconv_bwd(const float* x, const float* y, const float* dy, const float* w, float* dx, float* dw, float* db, int B, int H,
+              int Hout, int T, hipStream_t st) {
+    int rc = 0;
+    if (dx)   // dx[a][h] = sum_{m,kh} w[a][m][kh] g[m][2h+kh]
+        rc = launch_conv<C, 2 * C, Down4, true>(dy, y, w, WSpec{(long)C * 4, 4, 1, 0}, nullptr, nullptr, dx, B, Hout, H, T, TT_ACT_NONE, st);
+    if (rc) return rc;
+    // dW[a][m][kh] = sum x[a][h] g[m][2h+kh]
+    rc = launch_wgrad<2 * C, C, WStr, false, true>(x, nullptr, dy, y, dw, nullptr, (long)C * 4, 4, 1, B, H, Hout, T, st);
+    if (rc) return rc;
+    if (db) {
+        const long inner = (long)Hout * T;
+        int chunks = (int)(((long)B * inner + 256L * 16 - 1) / (256L * 16));
+        const int cap = 4096 / C;
+        if (chunks > cap) chunks = cap;
+        if (chunks < 1) chunks = 1;
+        hipLaunchKernelGGL(k_gated_channel_sum, dim3(C, chunks), dim3(256), 0, st, dy, y, db, B, C, inner);
+        TT_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+#define TT_DISPATCH_C(FN, ...)                      \
+    switch (C) {                                    \
+        case 4: return FN<4>(__VA_ARGS__);          \
+        case 8: return FN<8>(__VA_ARGS__);          \
+        case 16: return FN<16>(__VA_ARGS__);        \
+        case 32: return FN<32>(__VA_ARGS__);        \
+        default: return TT_E_UNSUPPORTED;           \
+    }
+
+}  // namespace
+
+extern "C" int tt_resblock_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                               float* y, int B, int C, int H, int T, int dilation, void* stream) {
+    if (!x || !w1 || !b1 || !w2 || !b2 || !y || B <= 0 || H <= 0 || T <= 0) return TT_E_BADARG;
+    hipStream_t st = tt_stream(stream);
+    TT_DISPATCH_CD(launch_rb_fwd, x, w1, b1, w2, b2, y, B, H, T, st)
+}
+
+extern "C" int tt_resblock_bwd(const float* x, const float* dy, const float* w1, const float* b1, const float* w2,
+                               const float* b2, float* dx, float* dw1, float* db1, float* dw2, float* db2, float* ws,
+                               int B, int C, int H, int T, int dilation, void* stream) {
+    if (!x || !dy || !w1 || !b1 || !w2 || !b2 || !dx || !dw1 || !db1 || !dw2 || !db2 || !ws || B <= 0 || H <= 0 || T <= 0)
+        return TT_E_BADARG;
+    hipStream_t st = tt_stream(stream);
+    TT_DISPATCH_CD(launch_rb_bwd, x, dy, w1, b1, w2, b2, dx, dw1, db1, dw2, db2, ws, B, H, T, st)
+}
+
+extern "C" int tt_sconv_fwd(const float* x, const float* w, const float* b, float* y, int B, int C, int H, int T,
+                            void* stream) {
+    if (!x || !w || !b || !y || B <= 0 || H < 4 || T <= 0) return TT_E_BADARG;
+    const int Hout = (H - 4) / 2 + 1;
+    hipStream_t st = tt_stream(stream);
+    TT_DISPATCH_C(sconv_fwd, x, w, b, y, B, H, Hout, T, st)
+}
+
+extern "C" int tt_sconv_bwd(const float* x, const float* y, const float* dy, const float* w, float* dx, float* dw, float* db,
+                            int B, int C, int H, int T, void* stream) {
+    if (!x || !y || !dy || !w || !dw || !db || B <= 0 || H < 4 || T <= 0) return TT_E_BADARG;
+    const int Hout = (H - 4) / 2 + 1;
+    hipStream_t st = tt_stream(stream);
+    TT_DISPATCH_C(sconv_bwd, x, y, dy, w, dx, dw, db, B, H, Hout, T, st)
+}
+
+extern "C" int tt_tconv_fwd(const float* x, const float* w, const float* b, float* y, int B, int C, int H, int T,
+                            int out_pad, void* stream) {
+    if (!x || !w || !b || !y || B <= 0 || H <= 0 || T <= 0 || out_pad < 0 || out_pad > 1) return TT_E_BADARG;
+    const int Hout = (H - 1) * 2 + 4 + out_pad;
+    hipStream_t st = tt_stream(stream);
+    TT_DISPATCH_C(tconv_fwd, x, w, b, y, B, H, Hout, T, st)
+}
+
+extern "C" int tt_tconv_bwd(const float* x, const float* y, const float* dy, const float* w, float* dx, float* dw, float* db,
+                            int B, int C, int H, int T, int out_pad, void* stream) {
+    if (!x || !y || !dy || !w || !dw || !db || B <= 0 || H <= 0 || T <= 0 || out_pad < 0 || out_pad > 1) return TT_E_BADARG;
+    const int Hout = (H - 1) * 2 + 4 + out_pad;
+    hipStream_t st = tt_stream(stream);
+    TT_DISPATCH_C(tconv_bwd, x, y, dy, w, dx, dw, db, B, H, Hout, T, st)
+}

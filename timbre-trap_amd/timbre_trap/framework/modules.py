@@ -81,7 +81,7 @@ class EncoderBlock(nn.Module):
     def forward(self, x):
         y = self.block3(self.block2(self.block1(x)))
         s = self.sconv[0]
-        return ops.conv(y, s.weight, s.bias, ConvCfg(self.win, 1, self.hop, 1, 0, 0, 'conv', 0, ACT_ELU))
+        return ops.strided_conv(y, s.weight, s.bias, self.win, self.hop)
 
 
 class DecoderBlock(nn.Module):
@@ -105,7 +105,7 @@ class DecoderBlock(nn.Module):
 
     def forward(self, x):
         t = self.tconv[0]
-        y = ops.conv(x, t.weight, t.bias, ConvCfg(self.win, 1, self.hop, 1, 0, 0, 'tconv', self.out_pad, ACT_ELU))
+        y = ops.transposed_conv(x, t.weight, t.bias, self.win, self.hop, self.out_pad)
         return self.block3(self.block2(self.block1(y)))
 
 

@@ -205,6 +205,78 @@ class ResBlockFn(torch.autograd.Function):
         return dx, dw1, db1, dw2, db2, None
 
 
+class StridedConvFn(torch.autograd.Function):
+    """EncoderBlock.sconv: ELU(Conv2d(C, 2C, (4,1), stride (2,1))) on the MFMA strided kernel."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        _hip.require_cuda(x, w)
+        x, w = _f32c(x), _f32c(w)
+        B, C, H, T = x.shape
+        y = torch.empty((B, 2 * C, (H - 4) // 2 + 1, T), dtype=torch.float32, device=x.device)
+        check(_hip.lib().tt_sconv_fwd(ptr(x), ptr(w), ptr(b), ptr(y), B, C, H, T, stream_ptr()), 'tt_sconv_fwd')
+        ctx.save_for_backward(x, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        dy = _f32c(dy)
+        B, C, H, T = x.shape
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.zeros_like(w)
+        db = torch.zeros(2 * C, dtype=torch.float32, device=x.device)
+        check(_hip.lib().tt_sconv_bwd(ptr(x), ptr(y), ptr(dy), ptr(w), ptr(dx), ptr(dw), ptr(db), B, C, H, T,
+                                      stream_ptr()), 'tt_sconv_bwd')
+        return dx, dw, db
+
+
+class TransposedConvFn(torch.autograd.Function):
+    """DecoderBlock.tconv: ELU(ConvTranspose2d(2C, C, (4,1), stride (2,1), output_padding)) on the MFMA kernel."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, out_pad):
+        _hip.require_cuda(x, w)
+        x, w = _f32c(x), _f32c(w)
+        B, C2, H, T = x.shape
+        C = C2 // 2
+        y = torch.empty((B, C, 2 * H + 2 + out_pad, T), dtype=torch.float32, device=x.device)
+        check(_hip.lib().tt_tconv_fwd(ptr(x), ptr(w), ptr(b), ptr(y), B, C, H, T, out_pad, stream_ptr()), 'tt_tconv_fwd')
+        ctx.out_pad = out_pad
+        ctx.save_for_backward(x, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        dy = _f32c(dy)
+        B, C2, H, T = x.shape
+        C = C2 // 2
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.zeros_like(w)
+        db = torch.zeros(C, dtype=torch.float32, device=x.device)
+        check(_hip.lib().tt_tconv_bwd(ptr(x), ptr(y), ptr(dy), ptr(w), ptr(dx), ptr(dw), ptr(db), B, C, H, T,
+                                      ctx.out_pad, stream_ptr()), 'tt_tconv_bwd')
+        return dx, dw, db, None
+
+
+def strided_conv(x, w, b, win, hop):
+    """Conv2d(C, Cout, (win,1), stride (hop,1)) + ELU."""
+    C = x.size(1)
+    if FUSED_RESBLOCK and win == 4 and hop == 2 and C in FUSED_CHANNELS and w.shape == (2 * C, C, 4, 1) and b is not None:
+        return StridedConvFn.apply(x, w, b)
+    return conv(x, w, b, ConvCfg(win, 1, hop, 1, 0, 0, 'conv', 0, ACT_ELU))
+
+
+def transposed_conv(x, w, b, win, hop, out_pad):
+    """ConvTranspose2d(Cin, C, (win,1), stride (hop,1), output_padding (out_pad,0)) + ELU."""
+    C = w.size(1)
+    if (FUSED_RESBLOCK and win == 4 and hop == 2 and C in FUSED_CHANNELS and w.shape == (2 * C, C, 4, 1)
+            and x.size(1) == 2 * C and b is not None and out_pad in (0, 1)):
+        return TransposedConvFn.apply(x, w, b, out_pad)
+    return conv(x, w, b, ConvCfg(win, 1, hop, 1, 0, 0, 'tconv', out_pad, ACT_ELU))
+
+
 def residual_block(x, w1, b1, w2, b2, dilation):
     C = x.size(1)
     if (FUSED_RESBLOCK and C in FUSED_CHANNELS and w1.shape == (C, C, 3, 3) and w2.shape == (C, C, 1, 1)

@@ -120,13 +120,16 @@ int tt_elu_bwd(const float* dy, const float* y, float* g, int64_t n, void* strea
 /* Fused ResidualConv2dBlock forward (modules.py:755-777):
  *   y = ELU(W2 . ELU(W1 (*)_dil x + b1) + b2) + x      x,y: (B,C,H,T), W1 (C,C,3,3), W2 (C,C,1,1)
  * Supported C: 4,8,16,32; dilation 1..3 (other widths: compose tt_conv2d calls). */
+int64_t tt_wgrad_scratch_floats(void);
+
 int tt_resblock_fwd(const float* x, const float* w1, const float* b1, const float* w2,
                     const float* b2, float* y, int B, int C, int H, int T, int dilation,
                     void* stream);
 
 /* Fused ResidualConv2dBlock backward, recomputing the two hidden activations from x:
  *   inputs  x, dy            outputs  dx (written), dw1/db1/dw2/db2 (accumulated, +=)
- * `ws` is scratch of B*C*H*T floats (holds dL/d(conv1 pre-activation)). */
+ * `ws` is scratch of B*C*H*T + tt_wgrad_scratch_floats() floats (dL/d(conv1 pre-activation), then the
+ * per-workgroup partial weight gradients that a second launch sums without atomics). */
 int tt_resblock_bwd(const float* x, const float* dy, const float* w1, const float* b1,
                     const float* w2, const float* b2, float* dx, float* dw1, float* db1,
                     float* dw2, float* db2, float* ws, int B, int C, int H, int T, int dilation,
@@ -136,16 +139,17 @@ int tt_resblock_bwd(const float* x, const float* dy, const float* w1, const floa
  * x (B,C,H,T) -> y (B,2C,(H-4)/2+1,T); w (2C,C,4,1).  Supported C: 4,8,16,32. */
 int tt_sconv_fwd(const float* x, const float* w, const float* b, float* y, int B, int C, int H, int T,
                  void* stream);
-/* Its backward from the saved input x and OUTPUT y: dx (written; may be NULL), dw / db (accumulated, +=). */
+/* Its backward from the saved input x and OUTPUT y: dx (written; may be NULL), dw / db (accumulated, +=);
+ * `scratch` holds tt_wgrad_scratch_floats() floats. */
 int tt_sconv_bwd(const float* x, const float* y, const float* dy, const float* w, float* dx, float* dw,
-                 float* db, int B, int C, int H, int T, void* stream);
+                 float* db, float* scratch, int B, int C, int H, int T, void* stream);
 
 /* DecoderBlock.tconv (modules.py:685-689): y = ELU(ConvTranspose2d(2C, C, (4,1), stride (2,1),
  * output_padding (out_pad,0))(x) + b).  x (B,2C,H,T) -> y (B,C,2H+2+out_pad,T); w (2C,C,4,1). */
 int tt_tconv_fwd(const float* x, const float* w, const float* b, float* y, int B, int C, int H, int T,
                  int out_pad, void* stream);
 int tt_tconv_bwd(const float* x, const float* y, const float* dy, const float* w, float* dx, float* dw,
-                 float* db, int B, int C, int H, int T, int out_pad, void* stream);
+                 float* db, float* scratch, int B, int C, int H, int T, int out_pad, void* stream);
 
 /* Batched GEMM for the (31,1) latent layers (modules.py:446 and :534):
  *   for each batch b:  C_b (M,N) = alpha * op(A_b) (M,K) . op(B_b) (K,N) + beta * C_b  [+ bias]

@@ -25,6 +25,7 @@
 //   backward  : k_rb_bwd_a (recompute + pointwise chain -> dA1, db1, db2, dW2), k_conv_mfma with flipped
 //               weights (dx = dy + W1^T (*) dA1), k_wgrad_mfma (dW1 as MFMA GEMM with K = pixels).
 #include "common.h"
+#include "conv_small.h"
 
 namespace {
 
@@ -479,33 +480,47 @@ __global__ __launch_bounds__(NTHREADS) void k_rb_bwd_a(const float* __restrict__
             }
         }
     });
+    // reduce the 8 waves in LDS (own region: tr), then one global atomic per element per workgroup
+    __syncthreads();
+    float* red = tr;                                   // [CPAD][CPAD] dW2, then db1[CPAD], db2[CPAD]
+    for (int i = threadIdx.x; i < R::CPAD * R::CPAD + 2 * R::CPAD; i += NTHREADS) red[i] = 0.f;
+    __syncthreads();
 #pragma unroll
     for (int m2 = 0; m2 < G::MT; ++m2)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int co = m2 * 16 + 4 * g + r;
             const float s1 = group16_sum(db1acc[m2][r]), s2 = group16_sum(db2acc[m2][r]);
-            if (l15 == 0 && co < C) { atomicAdd(db1 + co, s1); atomicAdd(db2 + co, s2); }
+            if (l15 == 0) { atomicAdd(&red[R::CPAD * R::CPAD + co], s1); atomicAdd(&red[R::CPAD * R::CPAD + R::CPAD + co], s2); }
 #pragma unroll
-            for (int mt = 0; mt < G::MT; ++mt) {
-                const int c = mt * 16 + l15;
-                if (co < C && c < C) atomicAdd(dw2 + co * C + c, accw2[m2][mt][r]);
-            }
+            for (int mt = 0; mt < G::MT; ++mt) atomicAdd(&red[co * R::CPAD + mt * 16 + l15], accw2[m2][mt][r]);
         }
+    __syncthreads();
+    for (int i = threadIdx.x; i < R::CPAD * R::CPAD; i += NTHREADS) {
+        const int co = i / R::CPAD, c = i - co * R::CPAD;
+        if (co < C && c < C) atomicAdd(dw2 + co * C + c, red[i]);
+    }
+    if (threadIdx.x < C) {
+        atomicAdd(db1 + threadIdx.x, red[R::CPAD * R::CPAD + threadIdx.x]);
+        atomicAdd(db2 + threadIdx.x, red[R::CPAD * R::CPAD + R::CPAD + threadIdx.x]);
+    }
 }
 
 // ---- weight gradients as MFMA GEMMs with K = pixels ---------------------------------------------------------------
 //   dW[a][b][tap] += sum_{r,t} P[a][r][t] * Q[b][qrow(r,tap)][t + qcol(tap)]          a < CA, b < CB
 // grid.y splits b into NS slices of CBS channels; columns n = tap*CBS + bl.
-template <int D>
+// WTH rows (= waves) x WTW columns of P per tile: small channel counts are latency-bound per tile, so they get
+// the big tile; wide layers keep LDS small enough for two workgroups per CU.
+template <int D, int WTH_>
 struct WRes {       // 3x3 dilated: Q rows r + kh*D - D, cols t + kw*D - D
-    static constexpr int NTAPS = 9, WTH = 4, WTW = 32, XR = WTH + 2 * D, XC = WTW + 2 * D, CH = D;
+    static constexpr int NTAPS = 9, WTH = WTH_, WTW = 64, XR = WTH + 2 * D, XC = WTW + 2 * D, CH = D;
     static __device__ __forceinline__ int q_row0(int h0) { return h0 - D; }
     static __device__ __forceinline__ int qoff(int tap) { return (tap / 3) * D * XC + (tap % 3) * D; }
     static __device__ __forceinline__ int qrow_of_wave(int wave) { return wave; }
 };
+template <int WTH_>
 struct WStr {       // (4,1) stride 2: Q rows 2r + kh
-    static constexpr int NTAPS = 4, WTH = 4, WTW = 32, XR = 2 * WTH + 2, XC = WTW, CH = 0;
+    static constexpr int NTAPS = 4, WTH = WTH_, WTW = 64, XR = 2 * WTH + 2, XC = WTW, CH = 0;
     static __device__ __forceinline__ int q_row0(int h0) { return 2 * h0; }
     static __device__ __forceinline__ int qoff(int tap) { return tap * XC; }
     static __device__ __forceinline__ int qrow_of_wave(int wave) { return 2 * wave; }
@@ -518,16 +533,18 @@ struct WGeo {
     static constexpr int PLANE = plane_pad(WP::XR * WP::XC);
     static constexpr int AP = WP::WTW + 1;
     static constexpr int Q_FLOATS = CBS * PLANE;
-    static constexpr int LDS_FLOATS = Q_FLOATS + WP::WTH * CAP * AP;
+    static constexpr int RED_FLOATS = CAP * NTN * 16 + CAP;
+    static constexpr int LDS_FLOATS = cmax(Q_FLOATS + WP::WTH * CAP * AP, RED_FLOATS);
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
 };
 
 template <int CA, int CB, int CBS, class WP, bool GATE_P, bool GATE_Q>
-__global__ __launch_bounds__(256) void k_wgrad_mfma(const float* __restrict__ Pt, const float* __restrict__ Pg,
+__global__ __launch_bounds__(64 * WP::WTH) void k_wgrad_mfma(const float* __restrict__ Pt, const float* __restrict__ Pg,
                                                     const float* __restrict__ Qt, const float* __restrict__ Qg,
-                                                    float* __restrict__ dw, float* __restrict__ dbias_p, long s_a, long s_b,
-                                                    long s_t, int B, int HP, int HQ, int T) {
+                                                    float* __restrict__ scratch, float* __restrict__ dbias_p, int B, int HP,
+                                                    int HQ, int T) {
     using K = WGeo<CA, CBS, WP>;
+    constexpr int NT_ = 64 * WP::WTH;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     float* xs = lds;
@@ -561,7 +578,7 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float* __restrict__ Pt
         {
             const long qb = ((long)b * CB + b0) * qplane;
             const int row0 = WP::q_row0(h0), col0 = t0 - WP::CH;
-            for (int i = tid; i < CBS * WP::XR * WP::XC; i += 256) {
+            for (int i = tid; i < CBS * WP::XR * WP::XC; i += NT_) {
                 const int ci = i / (WP::XR * WP::XC);
                 const int rem = i - ci * (WP::XR * WP::XC);
                 const int r = rem / WP::XC, c = rem - r * WP::XC;
@@ -615,20 +632,45 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float* __restrict__ Pt
             }
         }
     }
+    // reduce the 4 waves of the workgroup in LDS, then write ONE partial image per workgroup to the scratch:
+    // the final sum over workgroups is a second, contention-free launch (k_wgrad_reduce).
+    __syncthreads();
+    constexpr int NC = K::NTN * 16;
+    float* red = lds;                                   // [CAP][NC] (+ CAP bias slots)
+    for (int i = tid; i < K::CAP * NC + K::CAP; i += NT_) red[i] = 0.f;
+    __syncthreads();
 #pragma unroll
     for (int mt = 0; mt < K::MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < K::NTN; ++nt) {
-            const int n = nt * 16 + l15;
-            if (n >= K::NN) continue;
-            const int tap = n / CBS, bl = n - tap * CBS;
+        for (int nt = 0; nt < K::NTN; ++nt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int a = mt * 16 + 4 * g + r;
-                if (a < CA) atomicAdd(dw + a * s_a + (b0 + bl) * s_b + tap * s_t, acc[mt][nt][r]);
-            }
-        }
-    if (dbias_p && blockIdx.y == 0 && lane < CA) atomicAdd(dbias_p + lane, bsum);
+            for (int r = 0; r < 4; ++r) atomicAdd(&red[(mt * 16 + 4 * g + r) * NC + nt * 16 + l15], acc[mt][nt][r]);
+    if (dbias_p && blockIdx.y == 0 && lane < CA) atomicAdd(&red[K::CAP * NC + lane], bsum);
+    __syncthreads();
+    float* part = scratch + ((long)blockIdx.y * gridDim.x + blockIdx.x) * (K::CAP * NC);
+    for (int i = tid; i < K::CAP * NC; i += NT_) part[i] = red[i];
+    if (dbias_p && blockIdx.y == 0 && tid < CA) atomicAdd(dbias_p + tid, red[K::CAP * NC + tid]);
+}
+
+// second stage: dw[a*s_a + (y*CBS + bl)*s_b + tap*s_t] += sum over workgroups of their partial images
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ scratch, float* __restrict__ dw, int nblk,
+                                                      int CA, int CAP, int NC, int NN, int CBS, long s_a, long s_b, long s_t) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= CAP * NC) return;
+    const int a = i / NC, n = i - a * NC;
+    if (a >= CA || n >= NN) return;
+    const float* p = scratch + (long)blockIdx.y * nblk * (CAP * NC) + i;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 3 < nblk; k += 4) {
+        s0 += p[(long)k * (CAP * NC)];
+        s1 += p[(long)(k + 1) * (CAP * NC)];
+        s2 += p[(long)(k + 2) * (CAP * NC)];
+        s3 += p[(long)(k + 3) * (CAP * NC)];
+    }
+    for (; k < nblk; ++k) s0 += p[(long)k * (CAP * NC)];
+    const int tap = n / CBS, bl = n - tap * CBS;
+    dw[a * s_a + ((long)blockIdx.y * CBS + bl) * s_b + tap * s_t] += (s0 + s1) + (s2 + s3);
 }
 
 // out[c] += sum over (b, h, t) of dy * ELU'(y)   (bias gradient of a conv + ELU layer)
@@ -693,9 +735,11 @@ int launch_rb_fwd(const float* x, const float* w1, const float* b1, const float*
     return 0;
 }
 
+constexpr int WGRAD_MAX_BLOCKS = 512;
+
 template <int CA, int CB, class WP, bool GP, bool GQ>
 int launch_wgrad(const float* Pt, const float* Pg, const float* Qt, const float* Qg, float* dw, float* dbias_p, long s_a,
-                 long s_b, long s_t, int B, int HP, int HQ, int T, hipStream_t st) {
+                 long s_b, long s_t, float* scratch, int B, int HP, int HQ, int T, hipStream_t st) {
     constexpr int CBS = CB > 16 ? 16 : CB;
     constexpr int NS = CB / CBS;
     using K = WGeo<CA, CBS, WP>;
@@ -706,9 +750,14 @@ int launch_wgrad(const float* Pt, const float* Pg, const float* Qt, const float*
         attr = true;
     }
     const int ntiles = B * ((HP + WP::WTH - 1) / WP::WTH) * ((T + WP::WTW - 1) / WP::WTW);
-    const int per_cu = blocks_per_cu(K::LDS_BYTES, 4);
-    hipLaunchKernelGGL((k_wgrad_mfma<CA, CB, CBS, WP, GP, GQ>), dim3(persistent_grid(ntiles, per_cu), NS), dim3(256),
-                       K::LDS_BYTES, st, Pt, Pg, Qt, Qg, dw, dbias_p, s_a, s_b, s_t, B, HP, HQ, T);
+    int grid = persistent_grid(ntiles, blocks_per_cu(K::LDS_BYTES, 4));
+    if (grid * NS > WGRAD_MAX_BLOCKS) grid = WGRAD_MAX_BLOCKS / NS;
+    hipLaunchKernelGGL((k_wgrad_mfma<CA, CB, CBS, WP, GP, GQ>), dim3(grid, NS), dim3(64 * WP::WTH), K::LDS_BYTES, st, Pt, Pg, Qt, Qg,
+                       scratch, dbias_p, B, HP, HQ, T);
+    TT_LAUNCH_CHECK();
+    constexpr int NC = K::NTN * 16;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((K::CAP * NC + 255) / 256, NS), dim3(256), 0, st, (const float*)scratch, dw, grid,
+                       CA, K::CAP, NC, K::NN, CBS, s_a, s_b, s_t);
     TT_LAUNCH_CHECK();
     return 0;
 }
@@ -732,7 +781,14 @@ int launch_rb_bwd(const float* x, const float* dy, const float* w1, const float*
                                                  TT_ACT_NONE, st);
     if (rc) return rc;
     // dW1[co][ci][tap] = sum dA1[co][pix] * x[ci][pix + tap]
-    return launch_wgrad<C, C, WRes<D>, false, false>(ws, nullptr, x, nullptr, dw1, nullptr, (long)C * 9, 9, 1, B, H, H, T, st);
+    return launch_wgrad<C, C, WRes<D, (C <= 8 ? 8 : 4)>, false, false>(ws, nullptr, x, nullptr, dw1, nullptr, (long)C * 9, 9, 1,
+                                                     ws + (long)B * C * H * T, B, H, H, T, st);
+}
+
+template <int C, int D>
+int rb_wgrad_only(const float* x, float* dw1, float* ws, int B, int H, int T, hipStream_t st) {
+    return launch_wgrad<C, C, WRes<D, (C <= 8 ? 8 : 4)>, false, false>(ws, nullptr, x, nullptr, dw1, nullptr, (long)C * 9, 9, 1,
+                                                                        ws + (long)B * C * H * T, B, H, H, T, st);
 }
 
 #define TT_DISPATCH_CD(FN, ...)                                                       \
@@ -751,14 +807,14 @@ int sconv_fwd(const float* x, const float* w, const float* b, float* y, int B, i
     return launch_conv<C, 2 * C, Down4, false>(x, nullptr, w, WSpec{(long)C * 4, 4, 1, 0}, b, nullptr, y, B, H, Hout, T, TT_ACT_ELU, st);
 }
 template <int C>
-int sconv_bwd(const float* x, const float* y, const float* dy, const float* w, float* dx, float* dw, float* db, int B, int H,
-              int Hout, int T, hipStream_t st) {
+int sconv_bwd(const float* x, const float* y, const float* dy, const float* w, float* dx, float* dw, float* db, float* scratch,
+              int B, int H, int Hout, int T, hipStream_t st) {
     int rc = 0;
     if (dx)   // dx[c][r] = sum_{a, kh: r = 2ho + kh} w[a][c][kh] * g[a][ho],  g = dy * ELU'(y)
         rc = launch_conv<2 * C, C, Up4, true>(dy, y, w, WSpec{4, (long)C * 4, 1, 0}, nullptr, nullptr, dx, B, Hout, H, T, TT_ACT_NONE, st);
     if (rc) return rc;
     // dW[a][c][kh] = sum g[a][ho] x[c][2ho+kh] ; db[a] = sum g[a]
-    return launch_wgrad<2 * C, C, WStr, true, false>(dy, y, x, nullptr, dw, db, (long)C * 4, 4, 1, B, Hout, H, T, st);
+    return launch_wgrad<2 * C, C, WStr<(C <= 8 ? 8 : 4)>, true, false>(dy, y, x, nullptr, dw, db, (long)C * 4, 4, 1, scratch, B, Hout, H, T, st);
 }
 template <int C>
 int tconv_fwd(const float* x, const float* w, const float* b, float* y, int B, int H, int Hout, int T, hipStream_t st) {
@@ -766,14 +822,14 @@ int tconv_fwd(const float* x, const float* w, const float* b, float* y, int B, i
     return launch_conv<2 * C, C, Up4, false>(x, nullptr, w, WSpec{4, (long)C * 4, 1, 0}, b, nullptr, y, B, H, Hout, T, TT_ACT_ELU, st);
 }
 template <int C>
-int tconv_bwd(const float* x, const float* y, const float* dy, const float* w, float* dx, float* dw, float* db, int B, int H,
-              int Hout, int T, hipStream_t st) {
+int tconv_bwd(const float* x, const float* y, const float* dy, const float* w, float* dx, float* dw, float* db, float* scratch,
+              int B, int H, int Hout, int T, hipStream_t st) {
     int rc = 0;
     if (dx)   // dx[a][h] = sum_{m,kh} w[a][m][kh] g[m][2h+kh]
         rc = launch_conv<C, 2 * C, Down4, true>(dy, y, w, WSpec{(long)C * 4, 4, 1, 0}, nullptr, nullptr, dx, B, Hout, H, T, TT_ACT_NONE, st);
     if (rc) return rc;
     // dW[a][m][kh] = sum x[a][h] g[m][2h+kh]
-    rc = launch_wgrad<2 * C, C, WStr, false, true>(x, nullptr, dy, y, dw, nullptr, (long)C * 4, 4, 1, B, H, Hout, T, st);
+    rc = launch_wgrad<2 * C, C, WStr<(C <= 8 ? 8 : 4)>, false, true>(x, nullptr, dy, y, dw, nullptr, (long)C * 4, 4, 1, scratch, B, H, Hout, T, st);
     if (rc) return rc;
     if (db) {
         const long inner = (long)Hout * T;
@@ -798,10 +854,14 @@ int tconv_bwd(const float* x, const float* y, const float* dy, const float* w, f
 
 }  // namespace
 
+// floats of reduction scratch the weight-gradient kernels need (per call; see include/ttrap.h)
+extern "C" int64_t tt_wgrad_scratch_floats(void) { return (int64_t)WGRAD_MAX_BLOCKS * 64 * 144; }
+
 extern "C" int tt_resblock_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
                                float* y, int B, int C, int H, int T, int dilation, void* stream) {
     if (!x || !w1 || !b1 || !w2 || !b2 || !y || B <= 0 || H <= 0 || T <= 0) return TT_E_BADARG;
     hipStream_t st = tt_stream(stream);
+    if (C <= 8) return tt_small_rb_fwd(x, w1, b1, w2, b2, y, B, C, H, T, dilation, st);     // HBM-bound levels: VALU kernels
     TT_DISPATCH_CD(launch_rb_fwd, x, w1, b1, w2, b2, y, B, H, T, st)
 }
 
@@ -811,6 +871,20 @@ extern "C" int tt_resblock_bwd(const float* x, const float* dy, const float* w1,
     if (!x || !dy || !w1 || !b1 || !w2 || !b2 || !dx || !dw1 || !db1 || !dw2 || !db2 || !ws || B <= 0 || H <= 0 || T <= 0)
         return TT_E_BADARG;
     hipStream_t st = tt_stream(stream);
+    if (C <= 8) {
+        int rc = tt_small_rb_bwd(x, dy, w1, b1, w2, b2, dx, dw1, db1, dw2, db2, ws, ws + (long)B * C * H * T, B, C, H, T,
+                                 dilation, st);
+        if (rc) return rc;
+        switch (C * 10 + dilation) {
+            case 41: return rb_wgrad_only<4, 1>(x, dw1, ws, B, H, T, st);
+            case 42: return rb_wgrad_only<4, 2>(x, dw1, ws, B, H, T, st);
+            case 43: return rb_wgrad_only<4, 3>(x, dw1, ws, B, H, T, st);
+            case 81: return rb_wgrad_only<8, 1>(x, dw1, ws, B, H, T, st);
+            case 82: return rb_wgrad_only<8, 2>(x, dw1, ws, B, H, T, st);
+            case 83: return rb_wgrad_only<8, 3>(x, dw1, ws, B, H, T, st);
+            default: return TT_E_UNSUPPORTED;
+        }
+    }
     TT_DISPATCH_CD(launch_rb_bwd, x, dy, w1, b1, w2, b2, dx, dw1, db1, dw2, db2, ws, B, H, T, st)
 }
 
@@ -823,11 +897,11 @@ extern "C" int tt_sconv_fwd(const float* x, const float* w, const float* b, floa
 }
 
 extern "C" int tt_sconv_bwd(const float* x, const float* y, const float* dy, const float* w, float* dx, float* dw, float* db,
-                            int B, int C, int H, int T, void* stream) {
-    if (!x || !y || !dy || !w || !dw || !db || B <= 0 || H < 4 || T <= 0) return TT_E_BADARG;
+                            float* scratch, int B, int C, int H, int T, void* stream) {
+    if (!x || !y || !dy || !w || !dw || !db || !scratch || B <= 0 || H < 4 || T <= 0) return TT_E_BADARG;
     const int Hout = (H - 4) / 2 + 1;
     hipStream_t st = tt_stream(stream);
-    TT_DISPATCH_C(sconv_bwd, x, y, dy, w, dx, dw, db, B, H, Hout, T, st)
+    TT_DISPATCH_C(sconv_bwd, x, y, dy, w, dx, dw, db, scratch, B, H, Hout, T, st)
 }
 
 extern "C" int tt_tconv_fwd(const float* x, const float* w, const float* b, float* y, int B, int C, int H, int T,
@@ -839,9 +913,10 @@ extern "C" int tt_tconv_fwd(const float* x, const float* w, const float* b, floa
 }
 
 extern "C" int tt_tconv_bwd(const float* x, const float* y, const float* dy, const float* w, float* dx, float* dw, float* db,
-                            int B, int C, int H, int T, int out_pad, void* stream) {
-    if (!x || !y || !dy || !w || !dw || !db || B <= 0 || H <= 0 || T <= 0 || out_pad < 0 || out_pad > 1) return TT_E_BADARG;
+                            float* scratch, int B, int C, int H, int T, int out_pad, void* stream) {
+    if (!x || !y || !dy || !w || !dw || !db || !scratch || B <= 0 || H <= 0 || T <= 0 || out_pad < 0 || out_pad > 1)
+        return TT_E_BADARG;
     const int Hout = (H - 1) * 2 + 4 + out_pad;
     hipStream_t st = tt_stream(stream);
-    TT_DISPATCH_C(tconv_bwd, x, y, dy, w, dx, dw, db, B, H, Hout, T, st)
+    TT_DISPATCH_C(tconv_bwd, x, y, dy, w, dx, dw, db, scratch, B, H, Hout, T, st)
 }

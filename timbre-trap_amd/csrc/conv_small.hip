@@ -1,0 +1,265 @@
+// ResidualConv2dBlock for the narrow levels (C = 4, 8) of the Timbre-Trap autoencoder on the gfx950 vector ALUs.
+//
+// At C <= 8 the block moves 2*C*4 bytes per pixel for 20*C*C flops: 10-20 flop/B, below the fp32 ridge of the
+// chip (~25 flop/B).  These levels are HBM/latency-bound, a 16-row MFMA tile would be 25-50 % empty, and a
+// barrier-per-tile pipeline exposes memory latency.  So: one thread per pixel, all C output channels in
+// registers, the 9*C input taps read straight from global memory (coalesced along time, the 3x3 reuse is served
+// by the vector L1), weights broadcast from an LDS image ([ci][tap][co], one ds_read_b128 per 4 output channels),
+// no barrier in the main loop, 8 waves per SIMD.
+//
+//   k_small<C,D,0>  y = ELU(W2 . ELU(W1 (*) x + b1) + b2) + x                 (reference modules.py:755-777)
+//   k_small<C,D,1>  dx = dy + W1^T (*) dA1                                    (data gradient, flipped weights)
+//   k_small_bwd_a   recompute + pointwise chain -> dA1; db1, db2, dW2 in registers, reduced once per workgroup
+//   (dW1 stays on the MFMA weight-gradient kernel of conv_mfma.hip)
+#include "common.h"
+#include "conv_small.h"
+
+namespace {
+
+constexpr int ROWS_PER_BLOCK = 16;      // 4 waves x 4 row passes
+
+template <int C>
+struct SW {
+    static constexpr int W1 = 0;                    // [ci][tap][co]
+    static constexpr int W2 = W1 + C * 9 * C;       // [c_in][co2]
+    static constexpr int W2T = W2 + C * C;          // [co2][c_in]
+    static constexpr int B1 = W2T + C * C;
+    static constexpr int B2 = B1 + C;
+    static constexpr int FLOATS = B2 + C;
+};
+
+template <int C>
+__device__ __forceinline__ void build_images(float* lds, const float* __restrict__ w1, const float* __restrict__ b1,
+                                             const float* __restrict__ w2, const float* __restrict__ b2, bool flip) {
+    using S = SW<C>;
+    for (int i = threadIdx.x; i < C * 9 * C; i += blockDim.x) {
+        const int co = i % C, tap = (i / C) % 9, ci = i / (9 * C);
+        lds[S::W1 + i] = flip ? w1[(ci * C + co) * 9 + (8 - tap)] : w1[(co * C + ci) * 9 + tap];
+    }
+    for (int i = threadIdx.x; i < C * C; i += blockDim.x) {
+        const int a = i / C, b = i % C;
+        lds[S::W2 + i] = w2 ? w2[b * C + a] : 0.f;       // [c_in = a][co2 = b]
+        lds[S::W2T + i] = w2 ? w2[a * C + b] : 0.f;      // [co2 = a][c_in = b]
+    }
+    for (int i = threadIdx.x; i < C; i += blockDim.x) {
+        lds[S::B1 + i] = b1 ? b1[i] : 0.f;
+        lds[S::B2 + i] = b2 ? b2[i] : 0.f;
+    }
+    __syncthreads();
+}
+
+// 3x3 dilated conv of one pixel: acc[co] += sum W1s[ci][tap][co] * x[ci][h + (kh-1)D][t + (kw-1)D].
+// The channel loop stays a run-time loop and each kernel row starts with a compiler memory fence: otherwise the
+// loop-invariant LDS weight reads are all hoisted into registers (9*C*C of them) and the kernel spills.
+template <int C, int D>
+__device__ __forceinline__ void conv_pixel(const float* __restrict__ xb, const float* W1s, long plane, int H, int T, int h,
+                                           int t, float (&acc)[C]) {
+#pragma unroll 1
+    for (int ci = 0; ci < C; ++ci) {
+        const float* xp = xb + ci * plane;
+        const float* wc = W1s + ci * 9 * C;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            asm volatile("" ::: "memory");
+            const int hh = h + (kh - 1) * D;
+            const bool hv = hh >= 0 && hh < H;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int tt = t + (kw - 1) * D;
+                float xv = 0.f;
+                if (hv && tt >= 0 && tt < T) xv = xp[(long)hh * T + tt];
+                const float* wl = wc + (kh * 3 + kw) * C;
+#pragma unroll
+                for (int co = 0; co < C; ++co) acc[co] = fmaf(xv, wl[co], acc[co]);
+            }
+        }
+    }
+}
+
+template <int C, int D, int MODE>
+__global__ __launch_bounds__(256) void k_small(const float* __restrict__ x, const float* __restrict__ w1,
+                                               const float* __restrict__ b1, const float* __restrict__ w2,
+                                               const float* __restrict__ b2, const float* __restrict__ res,
+                                               float* __restrict__ y, int B, int H, int T) {
+    using S = SW<C>;
+    __shared__ float lds[S::FLOATS];
+    build_images<C>(lds, w1, MODE == 0 ? b1 : nullptr, MODE == 0 ? w2 : nullptr, MODE == 0 ? b2 : nullptr, MODE == 1);
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + tx;
+    const int b = blockIdx.z;
+    const long plane = (long)H * T;
+    const float* xb = x + (long)b * C * plane;
+    if (t >= T) return;
+#pragma unroll 1
+    for (int pass = 0; pass < ROWS_PER_BLOCK / 4; ++pass) {
+        const int h = blockIdx.y * ROWS_PER_BLOCK + pass * 4 + ty;
+        if (h >= H) break;
+        float acc[C];
+#pragma unroll
+        for (int co = 0; co < C; ++co) acc[co] = lds[S::B1 + co];
+        conv_pixel<C, D>(xb, lds + S::W1, plane, H, T, h, t, acc);
+        const long o = (long)b * C * plane + (long)h * T + t;
+        if (MODE == 0) {
+            float a2[C];
+#pragma unroll
+            for (int co = 0; co < C; ++co) a2[co] = lds[S::B2 + co];
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float hv = elu1(acc[c]);
+                const float* wl = lds + S::W2 + c * C;
+#pragma unroll
+                for (int co = 0; co < C; ++co) a2[co] = fmaf(hv, wl[co], a2[co]);
+            }
+#pragma unroll
+            for (int co = 0; co < C; ++co) y[o + co * plane] = elu1(a2[co]) + x[o + co * plane];
+        } else {
+#pragma unroll
+            for (int co = 0; co < C; ++co) y[o + co * plane] = acc[co] + res[o + co * plane];
+        }
+    }
+}
+
+// recompute + pointwise chain; persistent workgroups accumulate db1, db2, dW2 in registers
+template <int C, int D>
+__global__ __launch_bounds__(256) void k_small_bwd_a(const float* __restrict__ x, const float* __restrict__ dy,
+                                                     const float* __restrict__ w1, const float* __restrict__ b1,
+                                                     const float* __restrict__ w2, const float* __restrict__ b2,
+                                                     float* __restrict__ da1, float* __restrict__ db1, float* __restrict__ dw2,
+                                                     float* __restrict__ db2, int B, int H, int T) {
+    using S = SW<C>;
+    __shared__ float lds[S::FLOATS];
+    __shared__ float red[C * C + 2 * C];
+    for (int i = threadIdx.x; i < C * C + 2 * C; i += 256) red[i] = 0.f;
+    build_images<C>(lds, w1, b1, w2, b2, false);        // ends with a workgroup barrier
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const long plane = (long)H * T;
+    const int tiles_t = (T + 63) / 64, tiles_h = (H + 3) / 4;
+    const int ntiles = B * tiles_h * tiles_t;
+    float aw2[C][C], ab1[C], ab2[C];
+#pragma unroll
+    for (int a = 0; a < C; ++a) {
+        ab1[a] = 0.f; ab2[a] = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) aw2[a][c] = 0.f;
+    }
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int q = tile;
+        const int tt = q % tiles_t; q /= tiles_t;
+        const int th = q % tiles_h;
+        const int b = q / tiles_h;
+        const int t = tt * 64 + tx, h = th * 4 + ty;
+        if (t >= T || h >= H) continue;
+        const float* xb = x + (long)b * C * plane;
+        float h1[C];
+#pragma unroll
+        for (int co = 0; co < C; ++co) h1[co] = lds[S::B1 + co];
+        conv_pixel<C, D>(xb, lds + S::W1, plane, H, T, h, t, h1);
+        float a2[C];
+#pragma unroll
+        for (int co = 0; co < C; ++co) { a2[co] = lds[S::B2 + co]; h1[co] = elu1(h1[co]); }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float* wl = lds + S::W2 + c * C;
+#pragma unroll
+            for (int co = 0; co < C; ++co) a2[co] = fmaf(h1[c], wl[co], a2[co]);
+        }
+        asm volatile("" ::: "memory");
+        const long o = (long)b * C * plane + (long)h * T + t;
+        float d1[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) d1[c] = 0.f;
+#pragma unroll
+        for (int co = 0; co < C; ++co) {
+            const float gd = dy[o + co * plane] * elu_grad_from_out(elu1(a2[co]));     // dA2
+            ab2[co] += gd;
+            const float* wl = lds + S::W2T + co * C;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                d1[c] = fmaf(gd, wl[c], d1[c]);
+                aw2[co][c] = fmaf(gd, h1[c], aw2[co][c]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float gd = d1[c] * elu_grad_from_out(h1[c]);
+            ab1[c] += gd;
+            da1[o + c * plane] = gd;
+        }
+    }
+    // one reduction per workgroup: wave shuffle -> LDS -> global atomics
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int a = 0; a < C; ++a) {
+        const float s1 = wave_sum(ab1[a]), s2 = wave_sum(ab2[a]);
+        if (lane == 0) { atomicAdd(&red[C * C + a], s1); atomicAdd(&red[C * C + C + a], s2); }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float s = wave_sum(aw2[a][c]);
+            if (lane == 0) atomicAdd(&red[a * C + c], s);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < C * C) atomicAdd(dw2 + threadIdx.x, red[threadIdx.x]);
+    if (threadIdx.x < C) {
+        atomicAdd(db1 + threadIdx.x, red[C * C + threadIdx.x]);
+        atomicAdd(db2 + threadIdx.x, red[C * C + C + threadIdx.x]);
+    }
+}
+
+template <int C, int D>
+int fwd_t(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y, int B, int H, int T,
+          hipStream_t st) {
+    dim3 grid((T + 63) / 64, (H + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, B);
+    hipLaunchKernelGGL((k_small<C, D, 0>), grid, dim3(256), 0, st, x, w1, b1, w2, b2, (const float*)nullptr, y, B, H, T);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int C, int D>
+int bwd_t(const float* x, const float* dy, const float* w1, const float* b1, const float* w2, const float* b2, float* dx,
+          float* dw1, float* db1, float* dw2, float* db2, float* ws, float* scratch, int B, int H, int T, hipStream_t st) {
+    (void)dw1; (void)scratch;
+    const int ntiles = B * ((H + 3) / 4) * ((T + 63) / 64);
+    const int pgrid = ntiles < 2048 ? ntiles : 2048;
+    hipLaunchKernelGGL((k_small_bwd_a<C, D>), dim3(pgrid), dim3(256), 0, st, x, dy, w1, b1, w2, b2, ws, db1, dw2, db2, B, H, T);
+    TT_LAUNCH_CHECK();
+    dim3 grid((T + 63) / 64, (H + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, B);
+    hipLaunchKernelGGL((k_small<C, D, 1>), grid, dim3(256), 0, st, (const float*)ws, w1, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, dy, dx, B, H, T);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+int tt_small_rb_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y, int B, int C,
+                    int H, int T, int dilation, hipStream_t st) {
+    switch (C * 10 + dilation) {
+        case 41: return fwd_t<4, 1>(x, w1, b1, w2, b2, y, B, H, T, st);
+        case 42: return fwd_t<4, 2>(x, w1, b1, w2, b2, y, B, H, T, st);
+        case 43: return fwd_t<4, 3>(x, w1, b1, w2, b2, y, B, H, T, st);
+        case 81: return fwd_t<8, 1>(x, w1, b1, w2, b2, y, B, H, T, st);
+        case 82: return fwd_t<8, 2>(x, w1, b1, w2, b2, y, B, H, T, st);
+        case 83: return fwd_t<8, 3>(x, w1, b1, w2, b2, y, B, H, T, st);
+        default: return TT_E_UNSUPPORTED;
+    }
+}
+
+int tt_small_rb_bwd(const float* x, const float* dy, const float* w1, const float* b1, const float* w2, const float* b2,
+                    float* dx, float* dw1, float* db1, float* dw2, float* db2, float* ws, float* scratch, int B, int C, int H,
+                    int T, int dilation, hipStream_t st) {
+#define TT_SB(CC, DD) bwd_t<CC, DD>(x, dy, w1, b1, w2, b2, dx, dw1, db1, dw2, db2, ws, scratch, B, H, T, st)
+    switch (C * 10 + dilation) {
+        case 41: return TT_SB(4, 1);
+        case 42: return TT_SB(4, 2);
+        case 43: return TT_SB(4, 3);
+        case 81: return TT_SB(8, 1);
+        case 82: return TT_SB(8, 2);
+        case 83: return TT_SB(8, 3);
+        default: return TT_E_UNSUPPORTED;
+    }
+#undef TT_SB
+}

@@ -18,7 +18,7 @@ PKG_ROOT = os.path.dirname(_HERE)                       # timbre-trap_amd/
 REPO_ROOT = os.path.dirname(PKG_ROOT)
 CSRC = os.path.join(PKG_ROOT, 'csrc')
 LIB_PATH = os.path.join(PKG_ROOT, 'lib', 'libttrap_hip.so')
-SOURCES = ['cqt.hip', 'conv_generic.hip', 'conv_mfma.hip', 'gemm.hip', 'losses.hip']
+SOURCES = ['cqt.hip', 'conv_generic.hip', 'conv_mfma.hip', 'conv_small.hip', 'gemm.hip', 'losses.hip']
 
 _lib = None
 
@@ -47,9 +47,10 @@ _PROTOS = {
     'tt_resblock_fwd': (c_int, [P, P, P, P, P, P, I, I, I, I, I, P]),
     'tt_resblock_bwd': (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
     'tt_sconv_fwd': (c_int, [P, P, P, P, I, I, I, I, P]),
-    'tt_sconv_bwd': (c_int, [P, P, P, P, P, P, P, I, I, I, I, P]),
+    'tt_wgrad_scratch_floats': (c_int64, []),
+    'tt_sconv_bwd': (c_int, [P, P, P, P, P, P, P, P, I, I, I, I, P]),
     'tt_tconv_fwd': (c_int, [P, P, P, P, I, I, I, I, I, P]),
-    'tt_tconv_bwd': (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    'tt_tconv_bwd': (c_int, [P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
     'tt_gemm': (c_int, [P, P, P, P, I, I, I, I, I, L, L, L, I, L, L, L, I, F_, F_, I, I, I, P]),
     'tt_channel_sum': (c_int, [P, P, I, I, L, P]),
     'tt_scaled_add': (c_int, [P, P, P, I, P, L, P]),

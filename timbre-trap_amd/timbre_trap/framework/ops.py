@@ -197,7 +197,7 @@ class ResBlockFn(torch.autograd.Function):
         B, C, H, T = x.shape
         dx = torch.empty_like(x)
         dw1, db1, dw2, db2 = (torch.zeros_like(t) for t in (w1, b1, w2, b2))
-        ws = torch.empty_like(x)
+        ws = torch.empty(x.numel() + _hip.lib().tt_wgrad_scratch_floats(), dtype=torch.float32, device=x.device)
         with _hip.timed('resblock_bwd_C%d' % C):
             check(_hip.lib().tt_resblock_bwd(ptr(x), ptr(dy), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(dx), ptr(dw1),
                                              ptr(db1), ptr(dw2), ptr(db2), ptr(ws), B, C, H, T, ctx.dilation,
@@ -226,7 +226,8 @@ class StridedConvFn(torch.autograd.Function):
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dw = torch.zeros_like(w)
         db = torch.zeros(2 * C, dtype=torch.float32, device=x.device)
-        check(_hip.lib().tt_sconv_bwd(ptr(x), ptr(y), ptr(dy), ptr(w), ptr(dx), ptr(dw), ptr(db), B, C, H, T,
+        scratch = torch.empty(_hip.lib().tt_wgrad_scratch_floats(), dtype=torch.float32, device=x.device)
+        check(_hip.lib().tt_sconv_bwd(ptr(x), ptr(y), ptr(dy), ptr(w), ptr(dx), ptr(dw), ptr(db), ptr(scratch), B, C, H, T,
                                       stream_ptr()), 'tt_sconv_bwd')
         return dx, dw, db
 
@@ -255,7 +256,8 @@ class TransposedConvFn(torch.autograd.Function):
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dw = torch.zeros_like(w)
         db = torch.zeros(C, dtype=torch.float32, device=x.device)
-        check(_hip.lib().tt_tconv_bwd(ptr(x), ptr(y), ptr(dy), ptr(w), ptr(dx), ptr(dw), ptr(db), B, C, H, T,
+        scratch = torch.empty(_hip.lib().tt_wgrad_scratch_floats(), dtype=torch.float32, device=x.device)
+        check(_hip.lib().tt_tconv_bwd(ptr(x), ptr(y), ptr(dy), ptr(w), ptr(dx), ptr(dw), ptr(db), ptr(scratch), B, C, H, T,
                                       ctx.out_pad, stream_ptr()), 'tt_tconv_bwd')
         return dx, dw, db, None
 

@@ -1,0 +1,73 @@
+"""
+CPU-only, world_size 2 over gloo: the data-parallel exchange of the train step (one all-reduce of the flat gradient
+buffer, averaged over ranks) and the DataParallel shim.  The GPU path uses the same calls with backend 'nccl' (= RCCL).
+"""
+
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from timbre_trap.utils import DataParallel, allreduce_gradients, init_process_group_from_env
+    from timbre_trap.utils.distributed import broadcast_parameters
+    r, w, _ = init_process_group_from_env(backend='gloo')
+    assert (r, w) == (rank, world)
+    # 1. one collective over a flat gradient buffer: mean over ranks
+    g = torch.arange(614490, dtype=torch.float32) * (rank + 1)
+    allreduce_gradients(g, world)
+    ok1 = torch.allclose(g, torch.arange(614490, dtype=torch.float32) * 1.5)
+    # 2. parameters start identical on every rank
+    p = torch.full((10,), float(rank))
+    broadcast_parameters(p)
+    ok2 = bool((p == 0).all())
+    # 3. the attribute-forwarding shim: data-parallel SGD on a toy module equals the single-process step on the full batch
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(4, 3)
+    model = DataParallel(lin)
+    assert model.in_features == 4 and model.module is lin           # attribute passthrough (reference shim surface)
+    full_x = torch.arange(32, dtype=torch.float32).view(8, 4) / 10
+    x = full_x[rank * 4:(rank + 1) * 4]                              # equal per-rank batches
+    model(x).pow(2).mean().backward()
+    model.sync_gradients()
+    ref = torch.nn.Linear(4, 3)
+    ref.load_state_dict(lin.state_dict())
+    ref(full_x).pow(2).mean().backward()
+    ok3 = torch.allclose(lin.weight.grad, ref.weight.grad, atol=1e-6) and torch.allclose(lin.bias.grad, ref.bias.grad, atol=1e-6)
+    out.put((rank, ok1, ok2, ok3))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world_size_2():
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(out.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results == [(0, True, True, True), (1, True, True, True)]
+
+
+def test_single_process_is_a_noop():
+    from timbre_trap.utils import allreduce_gradients, init_process_group_from_env
+    os.environ.pop('WORLD_SIZE', None)
+    assert init_process_group_from_env() == (0, 1, 0)
+    g = torch.ones(5)
+    assert allreduce_gradients(g) is None and bool((g == 1).all())

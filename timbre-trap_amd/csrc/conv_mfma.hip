@@ -69,20 +69,36 @@ struct Up4 {        // out row r <- in rows (r - kh)/2, kh = (r&1) + 2j, j = 0,1
     static __device__ __forceinline__ int wtap(int tp, int wave) { return (wave & 1) + 2 * tp; }
 };
 
-template <int CIN, int COUT, class P>
+// DMA = true: the input tile is brought in by LDS-DMA (global_load_lds_dwordx4, 16 B per lane, 1 KiB per wave
+// instruction, destination linear in LDS).  Rows then start 16-byte aligned at t0 - HL (HL = 4 when the geometry has a
+// column halo) and are XCP = 64 (+8) floats wide, planes are exactly XR*XCP floats apart.  DMA = false: the register
+// staged tile (any T, optional ELU' gating while staging) with the 17-mod-32 plane pitch.
+template <int CIN, int COUT, class P, bool DMA>
 struct Geo {
     static constexpr int MT = (COUT + 15) / 16;
     static constexpr int CP = MT * 16;                       // weight image row pitch (floats)
     static constexpr bool SWZ = CP >= 32;
     static constexpr int CC = 4;                             // channels per staged chunk
     static constexpr int NCH = CIN / CC;
-    static constexpr int PLANE = plane_pad(P::XR * P::XC);
+    static constexpr int HL = DMA ? (P::CH > 0 ? 4 : 0) : P::CH;
+    static constexpr int XCP = DMA ? (P::CH > 0 ? TW + 8 : TW) : P::XC;
+    static constexpr int PLANE = DMA ? P::XR * XCP : plane_pad(P::XR * P::XC);
     static constexpr int ELEMS = CC * P::XR * P::XC;
     static constexpr int NLD = (ELEMS + NTHREADS - 1) / NTHREADS;
+    static constexpr int NQ = CC * P::XR * XCP / 4;          // 16-byte pieces of one chunk (DMA)
+    static constexpr int NPIECE = (NQ + 63) / 64;            // wave-wide DMA instructions per chunk
+    static constexpr int BUF = DMA ? NPIECE * 256 : CC * PLANE;
     static constexpr int KW = P::NWT * CIN;                  // rows of the weight image
     static constexpr int W_FLOATS = KW * CP;
-    static constexpr int XS_FLOATS = 2 * CC * PLANE;
+    static constexpr int XS_FLOATS = 2 * BUF;
 };
+
+__device__ float4 g_zero16;      // 16 zero bytes: DMA source of out-of-image pieces
+
+__device__ __forceinline__ void glds16(const float* gsrc, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
 
 struct Tile { int b, h0, t0; };
 __device__ __forceinline__ Tile decode_tile(int tile, int tiles_h, int tiles_t) {
@@ -97,7 +113,7 @@ __device__ __forceinline__ Tile decode_tile(int tile, int tiles_h, int tiles_t) 
 template <int CIN, int COUT, class P>
 __device__ __forceinline__ void build_weight_image(float* img, const float* __restrict__ w, long s_m, long s_c, long s_t,
                                                    long w_off, int tid) {
-    using G = Geo<CIN, COUT, P>;
+    using G = Geo<CIN, COUT, P, false>;
     for (int i = tid; i < G::W_FLOATS; i += NTHREADS) {
         const int k = i / G::CP, m = i - k * G::CP;
         const int wt = k / CIN, c = k - wt * CIN;
@@ -107,10 +123,11 @@ __device__ __forceinline__ void build_weight_image(float* img, const float* __re
 }
 
 // The pipelined implicit-GEMM main loop over the tiles of one workgroup.  `epi(tile, acc)` consumes a finished tile.
-template <int CIN, int COUT, class P, bool GATE, class Epi>
+template <int CIN, int COUT, class P, bool GATE, bool DMA, class Epi>
 __device__ __forceinline__ void conv_mainloop(const float* __restrict__ x, const float* __restrict__ gy, const float* Wimg,
                                               float* xs, int B, int Hin, int Hout, int T, Epi&& epi) {
-    using G = Geo<CIN, COUT, P>;
+    static_assert(!(GATE && DMA), "gated staging needs the register path");
+    using G = Geo<CIN, COUT, P, DMA>;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     const int tiles_h = (Hout + TH - 1) / TH, tiles_t = (T + TW - 1) / TW;
     const int ntiles = B * tiles_h * tiles_t;
@@ -119,19 +136,18 @@ __device__ __forceinline__ void conv_mainloop(const float* __restrict__ x, const
 #pragma unroll
     for (int mt = 0; mt < G::MT; ++mt) acol[mt] = G::SWZ ? ((mt * 16 + l15) ^ ((g & 1) << 4)) : (mt * 16 + l15);
 
-    // Prefetch registers of the work item in flight.  Loads are unconditional from a clamped in-range address
-    // (32-bit offset from a wave-uniform base); out-of-image elements are zeroed when they are committed to LDS.
-    float pre[G::NLD];
+    // ---- register staging (DMA == false): unconditional loads from a clamped address, zeroed at commit ----
+    float pre[DMA ? 1 : G::NLD];
     float preg[GATE ? G::NLD : 1];
     int p_row0 = 0, p_col0 = 0;
-    auto issue = [&](int tile, int chunk) {
+    auto issue_reg = [&](int tile, int chunk) {
         const Tile tl = decode_tile(tile, tiles_h, tiles_t);
         p_row0 = P::in_row0(tl.h0);
         p_col0 = tl.t0 - P::CH;
         const float* xb = x + ((long)tl.b * CIN + chunk * G::CC) * plane;
         const float* gb = GATE ? gy + ((long)tl.b * CIN + chunk * G::CC) * plane : nullptr;
 #pragma unroll
-        for (int j = 0; j < G::NLD; ++j) {
+        for (int j = 0; j < (DMA ? 0 : G::NLD); ++j) {
             int e = tid + NTHREADS * j;
             if (e >= G::ELEMS) e = G::ELEMS - 1;
             const int ci = e / (P::XR * P::XC);
@@ -145,10 +161,10 @@ __device__ __forceinline__ void conv_mainloop(const float* __restrict__ x, const
             if (GATE) preg[j] = gb[o];
         }
     };
-    auto commit = [&](int buf) {
-        float* dst = xs + buf * G::CC * G::PLANE;
+    auto commit_reg = [&](int buf) {
+        float* dst = xs + buf * G::BUF;
 #pragma unroll
-        for (int j = 0; j < G::NLD; ++j) {
+        for (int j = 0; j < (DMA ? 0 : G::NLD); ++j) {
             const int e = tid + NTHREADS * j;
             if (e < G::ELEMS) {
                 const int ci = e / (P::XR * P::XC);
@@ -161,11 +177,34 @@ __device__ __forceinline__ void conv_mainloop(const float* __restrict__ x, const
             }
         }
     };
+    // ---- LDS-DMA staging (DMA == true): each wave moves NPIECE/8 one-KiB pieces straight into the other buffer ----
+    auto issue_dma = [&](int tile, int chunk, int buf) {
+        const Tile tl = decode_tile(tile, tiles_h, tiles_t);
+        const int row0 = P::in_row0(tl.h0), col0 = tl.t0 - G::HL;
+        const float* xb = x + ((long)tl.b * CIN + chunk * G::CC) * plane;
+        float* dst = xs + buf * G::BUF;
+        constexpr int RQ = G::XCP / 4;              // pieces per row
+        constexpr int PQ = P::XR * RQ;              // pieces per channel plane
+#pragma unroll
+        for (int jj = 0; jj < (G::NPIECE + 7) / 8; ++jj) {
+            const int j = __builtin_amdgcn_readfirstlane(wave) + 8 * jj;      // provably wave-uniform LDS base
+            if (j < G::NPIECE) {
+                const int q = j * 64 + lane;
+                const int ci = q / PQ;
+                const int rem = q - ci * PQ;
+                const int r = rem / RQ, c4 = rem - r * RQ;
+                const int h = row0 + r, t = col0 + 4 * c4;
+                const bool ok = q < G::NQ && h >= 0 && h < Hin && t >= 0 && t < T;
+                const float* src = ok ? xb + (ci * (int)plane + h * T + t) : reinterpret_cast<const float*>(&g_zero16);
+                glds16(src, dst + j * 256);
+            }
+        }
+    };
 
     int tile = blockIdx.x;
     if (tile >= ntiles) return;
-    issue(tile, 0);
     int buf = 0;
+    if (DMA) issue_dma(tile, 0, 0); else issue_reg(tile, 0);
     for (; tile < ntiles; tile += gridDim.x) {
         f32x4 acc[G::MT][4];
 #pragma unroll
@@ -174,17 +213,23 @@ __device__ __forceinline__ void conv_mainloop(const float* __restrict__ x, const
             for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
         for (int chunk = 0; chunk < G::NCH; ++chunk) {
-            commit(buf);
+            if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces have landed
+            else commit_reg(buf);
             __syncthreads();
             // prefetch the next work item while this one is multiplied
-            if (chunk + 1 < G::NCH) issue(tile, chunk + 1);
-            else if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x, 0);
-            const float* xb = xs + buf * G::CC * G::PLANE;
+            const bool more_chunks = chunk + 1 < G::NCH;
+            const bool more_tiles = tile + (int)gridDim.x < ntiles;
+            if (more_chunks || more_tiles) {
+                const int nt_ = more_chunks ? tile : tile + (int)gridDim.x;
+                const int nc_ = more_chunks ? chunk + 1 : 0;
+                if (DMA) issue_dma(nt_, nc_, buf ^ 1); else issue_reg(nt_, nc_);
+            }
+            const float* xb = xs + buf * G::BUF;
             const int c0 = chunk * G::CC;
 #pragma unroll 1
             for (int tp = 0; tp < P::NTAPS; ++tp) {
                 const int wt = P::wtap(tp, wave);
-                const float* bp0 = xb + g * G::PLANE + P::lrow(tp, wave) * P::XC + P::lcol(tp) + l15;
+                const float* bp0 = xb + g * G::PLANE + P::lrow(tp, wave) * G::XCP + (G::HL - P::CH) + P::lcol(tp) + l15;
                 const float* ap0 = Wimg + (wt * CIN + c0 + g) * G::CP;
 #pragma unroll
                 for (int cc = 0; cc < G::CC; cc += 4) {
@@ -209,19 +254,19 @@ __device__ __forceinline__ void conv_mainloop(const float* __restrict__ x, const
 // ---- plain convolution kernel: out = act(conv + bias) + res -----------------------------------------------
 struct WSpec { long s_m, s_c, s_t, off; };
 
-template <int CIN, int COUT, class P, bool GATE>
+template <int CIN, int COUT, class P, bool GATE, bool DMA>
 __global__ __launch_bounds__(NTHREADS, 4) void k_conv_mfma(const float* __restrict__ x, const float* __restrict__ gy,
                                                         const float* __restrict__ w, WSpec ws, const float* __restrict__ bias,
                                                         const float* __restrict__ res, float* __restrict__ y, int B, int Hin,
                                                         int Hout, int T, int act) {
-    using G = Geo<CIN, COUT, P>;
+    using G = Geo<CIN, COUT, P, DMA>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* Wimg = lds;
-    float* xs = lds + G::W_FLOATS;
+    float* xs = lds;                       // DMA destinations first: 16-byte aligned
+    float* Wimg = lds + G::XS_FLOATS;
     build_weight_image<CIN, COUT, P>(Wimg, w, ws.s_m, ws.s_c, ws.s_t, ws.off, threadIdx.x);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, l15 = lane & 15;
     const long oplane = (long)Hout * T;
-    conv_mainloop<CIN, COUT, P, GATE>(x, gy, Wimg, xs, B, Hin, Hout, T, [&](const Tile& tl, f32x4 (&acc)[G::MT][4]) {
+    conv_mainloop<CIN, COUT, P, GATE, DMA>(x, gy, Wimg, xs, B, Hin, Hout, T, [&](const Tile& tl, f32x4 (&acc)[G::MT][4]) {
         const int h = tl.h0 + wave;
         if (h >= Hout) return;
 #pragma unroll
@@ -273,24 +318,24 @@ __device__ __forceinline__ void build_w2_images(float* W2s, float* W2t, float* b
     }
 }
 
-template <int C, int D>
+template <int C, int D, bool DMA>
 __global__ __launch_bounds__(NTHREADS, 4) void k_rb_fwd(const float* __restrict__ x, const float* __restrict__ w1,
                                                      const float* __restrict__ b1, const float* __restrict__ w2,
                                                      const float* __restrict__ b2, float* __restrict__ y, int B, int H, int T) {
     using P = Res3x3<D>;
-    using G = Geo<C, C, P>;
+    using G = Geo<C, C, P, DMA>;
     using R = RB<C>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* Wimg = lds;
+    float* xs = lds;
+    float* Wimg = xs + G::XS_FLOATS;
     float* W2s = Wimg + G::W_FLOATS;
     float* b1s = W2s + R::CPAD * R::CP;
     float* b2s = b1s + R::CPAD;
-    float* xs = b2s + R::CPAD;
     build_weight_image<C, C, P>(Wimg, w1, (long)C * 9, 9, 1, 0, threadIdx.x);
     build_w2_images<C>(W2s, nullptr, b1s, b2s, w2, b1, b2, threadIdx.x);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, l15 = lane & 15;
     const long plane = (long)H * T;
-    conv_mainloop<C, C, P, false>(x, nullptr, Wimg, xs, B, H, H, T, [&](const Tile& tl, f32x4 (&acc)[G::MT][4]) {
+    conv_mainloop<C, C, P, false, DMA>(x, nullptr, Wimg, xs, B, H, H, T, [&](const Tile& tl, f32x4 (&acc)[G::MT][4]) {
         f32x4 acc2[G::MT][4];
 #pragma unroll
         for (int mt = 0; mt < G::MT; ++mt)
@@ -344,23 +389,23 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int C, int D>
+template <int C, int D, bool DMA>
 __global__ __launch_bounds__(NTHREADS) void k_rb_bwd_a(const float* __restrict__ x, const float* __restrict__ dy,
                                                        const float* __restrict__ w1, const float* __restrict__ b1,
                                                        const float* __restrict__ w2, const float* __restrict__ b2,
                                                        float* __restrict__ da1, float* __restrict__ db1,
                                                        float* __restrict__ dw2, float* __restrict__ db2, int B, int H, int T) {
     using P = Res3x3<D>;
-    using G = Geo<C, C, P>;
+    using G = Geo<C, C, P, DMA>;
     using R = RB<C>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* Wimg = lds;
+    float* xs = lds;
+    float* Wimg = xs + G::XS_FLOATS;
     float* W2s = Wimg + G::W_FLOATS;
     float* W2t = W2s + R::CPAD * R::CP;
     float* b1s = W2t + R::CPAD * R::CP;
     float* b2s = b1s + R::CPAD;
-    float* xs = b2s + R::CPAD;
-    float* tr = xs + G::XS_FLOATS;          // per-wave transpose tiles (own region: no workgroup barrier needed)
+    float* tr = b2s + R::CPAD;          // per-wave transpose tiles (own region: no workgroup barrier needed)
     build_weight_image<C, C, P>(Wimg, w1, (long)C * 9, 9, 1, 0, threadIdx.x);
     build_w2_images<C>(W2s, W2t, b1s, b2s, w2, b1, b2, threadIdx.x);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, l15 = lane & 15;
@@ -378,7 +423,7 @@ __global__ __launch_bounds__(NTHREADS) void k_rb_bwd_a(const float* __restrict__
         for (int r = 0; r < 4; ++r) { db1acc[a][r] = 0.f; db2acc[a][r] = 0.f; }
     }
 
-    conv_mainloop<C, C, P, false>(x, nullptr, Wimg, xs, B, H, H, T, [&](const Tile& tl, f32x4 (&h1)[G::MT][4]) {
+    conv_mainloop<C, C, P, false, DMA>(x, nullptr, Wimg, xs, B, H, H, T, [&](const Tile& tl, f32x4 (&h1)[G::MT][4]) {
         const int h = tl.h0 + wave;
         f32x4 a2[G::MT][4];
 #pragma unroll
@@ -652,6 +697,136 @@ __global__ __launch_bounds__(64 * WP::WTH) void k_wgrad_mfma(const float* __rest
     if (dbias_p && blockIdx.y == 0 && tid < CA) atomicAdd(dbias_p + tid, red[K::CAP * NC + tid]);
 }
 
+// LDS-DMA version (T % 4 == 0, 16-byte aligned tensors, no gating): both operands arrive by global_load_lds_dwordx4.
+//   Q tile: linear [bl][row][XCP] (rows start 16-byte aligned at t0 - HL)
+//   P rows: per wave [CAP][64] with the 16-byte chunks of row a stored at chunk position c ^ (a & 15) (the swizzle is
+//           applied to the SOURCE address, the LDS image of a DMA is linear), so the A fragments are ds_read_b128:
+//           lane (a = l15, g) owns pixels 16 g .. 16 g + 15 = k-steps 0..15 (the k order is free as long as A and B agree).
+template <int CBS, class WP>
+struct WGeoD {
+    static constexpr int HL = WP::CH > 0 ? 4 : 0;
+    static constexpr int XCP = WP::CH > 0 ? WP::WTW + 8 : WP::WTW;
+    static constexpr int PLANE = WP::XR * XCP;
+    static constexpr int NQ = CBS * PLANE / 4;
+    static constexpr int NPIECE = (NQ + 63) / 64;
+    static constexpr int Q_FLOATS = NPIECE * 256;
+};
+
+template <int CA, int CB, int CBS, class WP>
+__global__ __launch_bounds__(64 * WP::WTH) void k_wgrad_dma(const float* __restrict__ Pt, const float* __restrict__ Qt,
+                                                           float* __restrict__ scratch, float* __restrict__ dbias_p, int B,
+                                                           int HP, int HQ, int T) {
+    using K = WGeo<CA, CBS, WP>;
+    using Q = WGeoD<CBS, WP>;
+    static_assert(WP::WTW == 64, "P rows are 64 pixels");
+    constexpr int NT_ = 64 * WP::WTH;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    float* xs = lds;
+    float* as = lds + Q::Q_FLOATS + uwave * K::CAP * 64;
+    const int b0 = blockIdx.y * CBS;
+    const int tiles_h = (HP + WP::WTH - 1) / WP::WTH, tiles_t = (T + WP::WTW - 1) / WP::WTW;
+    const int ntiles = B * tiles_h * tiles_t;
+    const long pplane = (long)HP * T, qplane = (long)HQ * T;
+
+    int noff[K::NTN];
+#pragma unroll
+    for (int nt = 0; nt < K::NTN; ++nt) {
+        int n = nt * 16 + l15;
+        if (n >= K::NN) n = K::NN - 1;
+        const int tap = n / CBS, bl = n - tap * CBS;
+        // WP::qoff is in units of WP::XC columns per row: split it back into (row, col)
+        const int qo = WP::qoff(tap), qr = qo / WP::XC, qc = qo - qr * WP::XC;
+        noff[nt] = bl * Q::PLANE + qr * Q::XCP + qc + (Q::HL - WP::CH) + 16 * g;
+    }
+    f32x4 acc[K::MT][K::NTN];
+#pragma unroll
+    for (int mt = 0; mt < K::MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < K::NTN; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    const float* zero = reinterpret_cast<const float*>(&g_zero16);
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int tt = tile;
+        const int tx = tt % tiles_t; tt /= tiles_t;
+        const int ty = tt % tiles_h;
+        const int b = tt / tiles_h, h0 = ty * WP::WTH, t0 = tx * WP::WTW;
+        __syncthreads();                                   // everyone is done with the previous tile's LDS
+        {   // Q tile
+            const float* qb = Qt + ((long)b * CB + b0) * qplane;
+            const int row0 = WP::q_row0(h0), col0 = t0 - Q::HL;
+            constexpr int RQ = Q::XCP / 4, PQ = WP::XR * RQ;
+#pragma unroll
+            for (int jj = 0; jj < (Q::NPIECE + WP::WTH - 1) / WP::WTH; ++jj) {
+                const int j = uwave + WP::WTH * jj;
+                if (j < Q::NPIECE) {
+                    const int q = j * 64 + lane;
+                    const int ci = q / PQ;
+                    const int rem = q - ci * PQ;
+                    const int r = rem / RQ, c4 = rem - r * RQ;
+                    const int h = row0 + r, t = col0 + 4 * c4;
+                    const bool ok = q < Q::NQ && h >= 0 && h < HQ && t >= 0 && t < T;
+                    glds16(ok ? qb + (ci * (int)qplane + h * T + t) : zero, xs + j * 256);
+                }
+            }
+        }
+        {   // this wave's row of P: 4 channels x 16 chunks per piece, chunk c of channel a lands at position c ^ (a & 15)
+            const int h = h0 + wave;
+            const float* pb = Pt + (long)b * CA * pplane + (long)(h < HP ? h : 0) * T + t0;
+#pragma unroll
+            for (int a0 = 0; a0 < K::CAP; a0 += 4) {
+                const int a = a0 + g;
+                const int c = l15 ^ (a & 15);
+                const bool ok = a < CA && h < HP && t0 + 4 * c < T;
+                glds16(ok ? pb + (a * (int)pplane + 4 * c) : zero, as + a0 * 64);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (dbias_p && blockIdx.y == 0 && lane < CA) {
+#pragma unroll 8
+            for (int p = 0; p < 64; ++p) bsum += as[lane * 64 + ((((p >> 2) ^ (lane & 15)) << 2) | (p & 3))];
+        }
+        // A fragments: pixels 16 g .. 16 g + 15 of channel mt*16 + l15
+        float av[K::MT][16];
+#pragma unroll
+        for (int mt = 0; mt < K::MT; ++mt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 v = *reinterpret_cast<const float4*>(as + (mt * 16 + l15) * 64 + (((4 * g + j) ^ l15) << 2));
+                av[mt][4 * j + 0] = v.x; av[mt][4 * j + 1] = v.y; av[mt][4 * j + 2] = v.z; av[mt][4 * j + 3] = v.w;
+            }
+        const float* xrow = xs + WP::qrow_of_wave(wave) * Q::XCP;
+#pragma unroll
+        for (int sk = 0; sk < 16; ++sk) {
+#pragma unroll
+            for (int nt = 0; nt < K::NTN; ++nt) {
+                const float bv = xrow[noff[nt] + sk];
+#pragma unroll
+                for (int mt = 0; mt < K::MT; ++mt) acc[mt][nt] = mfma16(av[mt][sk], bv, acc[mt][nt]);
+            }
+        }
+    }
+    __syncthreads();
+    constexpr int NC = K::NTN * 16;
+    float* red = lds;
+    for (int i = tid; i < K::CAP * NC + K::CAP; i += NT_) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < K::MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < K::NTN; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(&red[(mt * 16 + 4 * g + r) * NC + nt * 16 + l15], acc[mt][nt][r]);
+    if (dbias_p && blockIdx.y == 0 && lane < CA) atomicAdd(&red[K::CAP * NC + lane], bsum);
+    __syncthreads();
+    float* part = scratch + ((long)blockIdx.y * gridDim.x + blockIdx.x) * (K::CAP * NC);
+    for (int i = tid; i < K::CAP * NC; i += NT_) part[i] = red[i];
+    if (dbias_p && blockIdx.y == 0 && tid < CA) atomicAdd(dbias_p + tid, red[K::CAP * NC + tid]);
+}
+
 // second stage: dw[a*s_a + (y*CBS + bl)*s_b + tap*s_t] += sum over workgroups of their partial images
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ scratch, float* __restrict__ dw, int nblk,
                                                       int CA, int CAP, int NC, int NN, int CBS, long s_a, long s_b, long s_t) {
@@ -692,6 +867,8 @@ __global__ __launch_bounds__(256) void k_gated_channel_sum(const float* __restri
 }
 
 // ---- launch helpers ---------------------------------------------------------------------------------------------
+// LDS-DMA staging needs 16-byte aligned rows (T % 4 == 0, 16-byte aligned base) and no gating while staging
+inline bool dma_ok(const void* p, int T) { return (T % 4 == 0) && ((reinterpret_cast<uintptr_t>(p) & 15) == 0); }
 inline int blocks_per_cu(int lds_bytes, int cap) {
     int n = (160 * 1024) / lds_bytes;
     return n > cap ? cap : (n < 1 ? 1 : n);
@@ -702,18 +879,44 @@ inline int persistent_grid(int ntiles, int per_cu) {
 }
 inline int ntiles_of(int B, int H, int T) { return B * ((H + TH - 1) / TH) * ((T + TW - 1) / TW); }
 
-template <int CIN, int COUT, class P, bool GATE>
-int launch_conv(const float* x, const float* gy, const float* w, WSpec ws, const float* bias, const float* res, float* y,
-                int B, int Hin, int Hout, int T, int act, hipStream_t st) {
-    using G = Geo<CIN, COUT, P>;
+template <int CIN, int COUT, class P, bool GATE, bool DMA>
+int launch_conv_v(const float* x, const float* gy, const float* w, WSpec ws, const float* bias, const float* res, float* y,
+                  int B, int Hin, int Hout, int T, int act, hipStream_t st) {
+    using G = Geo<CIN, COUT, P, DMA>;
     constexpr int LDS = (G::W_FLOATS + G::XS_FLOATS) * 4;
     static bool attr = false;
     if (!attr) {
-        TT_HIP(hipFuncSetAttribute((const void*)k_conv_mfma<CIN, COUT, P, GATE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        TT_HIP(hipFuncSetAttribute((const void*)k_conv_mfma<CIN, COUT, P, GATE, DMA>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr = true;
     }
-    hipLaunchKernelGGL((k_conv_mfma<CIN, COUT, P, GATE>), dim3(persistent_grid(ntiles_of(B, Hout, T), blocks_per_cu(LDS, 2))),
+    hipLaunchKernelGGL((k_conv_mfma<CIN, COUT, P, GATE, DMA>), dim3(persistent_grid(ntiles_of(B, Hout, T), blocks_per_cu(LDS, 2))),
                        dim3(NTHREADS), LDS, st, x, gy, w, ws, bias, res, y, B, Hin, Hout, T, act);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int CIN, int COUT, class P, bool GATE>
+int launch_conv(const float* x, const float* gy, const float* w, WSpec ws, const float* bias, const float* res, float* y,
+                int B, int Hin, int Hout, int T, int act, hipStream_t st) {
+    if constexpr (!GATE) {
+        if (dma_ok(x, T)) return launch_conv_v<CIN, COUT, P, false, true>(x, gy, w, ws, bias, res, y, B, Hin, Hout, T, act, st);
+    }
+    return launch_conv_v<CIN, COUT, P, GATE, false>(x, gy, w, ws, bias, res, y, B, Hin, Hout, T, act, st);
+}
+
+template <int C, int D, bool DMA>
+int launch_rb_fwd_v(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y, int B, int H,
+                    int T, hipStream_t st) {
+    using G = Geo<C, C, Res3x3<D>, DMA>;
+    using R = RB<C>;
+    constexpr int LDS = (G::W_FLOATS + R::CPAD * R::CP + 2 * R::CPAD + G::XS_FLOATS) * 4;
+    static bool attr = false;
+    if (!attr) {
+        TT_HIP(hipFuncSetAttribute((const void*)k_rb_fwd<C, D, DMA>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr = true;
+    }
+    hipLaunchKernelGGL((k_rb_fwd<C, D, DMA>), dim3(persistent_grid(ntiles_of(B, H, T), blocks_per_cu(LDS, 2))), dim3(NTHREADS), LDS,
+                       st, x, w1, b1, w2, b2, y, B, H, T);
     TT_LAUNCH_CHECK();
     return 0;
 }
@@ -721,18 +924,8 @@ int launch_conv(const float* x, const float* gy, const float* w, WSpec ws, const
 template <int C, int D>
 int launch_rb_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y, int B, int H,
                   int T, hipStream_t st) {
-    using G = Geo<C, C, Res3x3<D>>;
-    using R = RB<C>;
-    constexpr int LDS = (G::W_FLOATS + R::CPAD * R::CP + 2 * R::CPAD + G::XS_FLOATS) * 4;
-    static bool attr = false;
-    if (!attr) {
-        TT_HIP(hipFuncSetAttribute((const void*)k_rb_fwd<C, D>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr = true;
-    }
-    hipLaunchKernelGGL((k_rb_fwd<C, D>), dim3(persistent_grid(ntiles_of(B, H, T), blocks_per_cu(LDS, 2))), dim3(NTHREADS), LDS,
-                       st, x, w1, b1, w2, b2, y, B, H, T);
-    TT_LAUNCH_CHECK();
-    return 0;
+    if (dma_ok(x, T)) return launch_rb_fwd_v<C, D, true>(x, w1, b1, w2, b2, y, B, H, T, st);
+    return launch_rb_fwd_v<C, D, false>(x, w1, b1, w2, b2, y, B, H, T, st);
 }
 
 constexpr int WGRAD_MAX_BLOCKS = 512;
@@ -743,21 +936,59 @@ int launch_wgrad(const float* Pt, const float* Pg, const float* Qt, const float*
     constexpr int CBS = CB > 16 ? 16 : CB;
     constexpr int NS = CB / CBS;
     using K = WGeo<CA, CBS, WP>;
-    static bool attr = false;
-    if (!attr) {
+    const int ntiles = B * ((HP + WP::WTH - 1) / WP::WTH) * ((T + WP::WTW - 1) / WP::WTW);
+    constexpr int NC = K::NTN * 16;
+    int grid;
+    if constexpr (!GP && !GQ) {
+        if (dma_ok(Pt, T) && dma_ok(Qt, T)) {
+            using Q = WGeoD<CBS, WP>;
+            constexpr int LDS = cmax(Q::Q_FLOATS + WP::WTH * K::CAP * 64, K::RED_FLOATS) * 4;
+            static bool attr = false;
+            if (!attr) {
+                TT_HIP(hipFuncSetAttribute((const void*)k_wgrad_dma<CA, CB, CBS, WP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+                attr = true;
+            }
+            grid = persistent_grid(ntiles, blocks_per_cu(LDS, 4));
+            if (grid * NS > WGRAD_MAX_BLOCKS) grid = WGRAD_MAX_BLOCKS / NS;
+            hipLaunchKernelGGL((k_wgrad_dma<CA, CB, CBS, WP>), dim3(grid, NS), dim3(64 * WP::WTH), LDS, st, Pt, Qt, scratch, dbias_p,
+                               B, HP, HQ, T);
+            TT_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_wgrad_reduce, dim3((K::CAP * NC + 255) / 256, NS), dim3(256), 0, st, (const float*)scratch, dw,
+                               grid, CA, K::CAP, NC, K::NN, CBS, s_a, s_b, s_t);
+            TT_LAUNCH_CHECK();
+            return 0;
+        }
+    }
+    static bool attr2 = false;
+    if (!attr2) {
         TT_HIP(hipFuncSetAttribute((const void*)k_wgrad_mfma<CA, CB, CBS, WP, GP, GQ>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    K::LDS_BYTES));
-        attr = true;
+        attr2 = true;
     }
-    const int ntiles = B * ((HP + WP::WTH - 1) / WP::WTH) * ((T + WP::WTW - 1) / WP::WTW);
-    int grid = persistent_grid(ntiles, blocks_per_cu(K::LDS_BYTES, 4));
+    grid = persistent_grid(ntiles, blocks_per_cu(K::LDS_BYTES, 4));
     if (grid * NS > WGRAD_MAX_BLOCKS) grid = WGRAD_MAX_BLOCKS / NS;
     hipLaunchKernelGGL((k_wgrad_mfma<CA, CB, CBS, WP, GP, GQ>), dim3(grid, NS), dim3(64 * WP::WTH), K::LDS_BYTES, st, Pt, Pg, Qt, Qg,
                        scratch, dbias_p, B, HP, HQ, T);
     TT_LAUNCH_CHECK();
-    constexpr int NC = K::NTN * 16;
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((K::CAP * NC + 255) / 256, NS), dim3(256), 0, st, (const float*)scratch, dw, grid,
                        CA, K::CAP, NC, K::NN, CBS, s_a, s_b, s_t);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int C, int D, bool DMA>
+int launch_rb_bwd_a_v(const float* x, const float* dy, const float* w1, const float* b1, const float* w2, const float* b2,
+                      float* db1, float* dw2, float* db2, float* ws, int B, int H, int T, hipStream_t st) {
+    using G = Geo<C, C, Res3x3<D>, DMA>;
+    using R = RB<C>;
+    constexpr int LDS = (G::W_FLOATS + 2 * R::CPAD * R::CP + 2 * R::CPAD + G::XS_FLOATS + R::TR_FLOATS) * 4;
+    static bool attr = false;
+    if (!attr) {
+        TT_HIP(hipFuncSetAttribute((const void*)k_rb_bwd_a<C, D, DMA>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr = true;
+    }
+    hipLaunchKernelGGL((k_rb_bwd_a<C, D, DMA>), dim3(persistent_grid(ntiles_of(B, H, T), blocks_per_cu(LDS, 2))), dim3(NTHREADS), LDS,
+                       st, x, dy, w1, b1, w2, b2, ws, db1, dw2, db2, B, H, T);
     TT_LAUNCH_CHECK();
     return 0;
 }
@@ -765,24 +996,16 @@ int launch_wgrad(const float* Pt, const float* Pg, const float* Qt, const float*
 template <int C, int D>
 int launch_rb_bwd(const float* x, const float* dy, const float* w1, const float* b1, const float* w2, const float* b2,
                   float* dx, float* dw1, float* db1, float* dw2, float* db2, float* ws, int B, int H, int T, hipStream_t st) {
-    using G = Geo<C, C, Res3x3<D>>;
-    using R = RB<C>;
-    constexpr int LDS = (G::W_FLOATS + 2 * R::CPAD * R::CP + 2 * R::CPAD + G::XS_FLOATS + R::TR_FLOATS) * 4;
-    static bool attr = false;
-    if (!attr) {
-        TT_HIP(hipFuncSetAttribute((const void*)k_rb_bwd_a<C, D>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr = true;
-    }
-    hipLaunchKernelGGL((k_rb_bwd_a<C, D>), dim3(persistent_grid(ntiles_of(B, H, T), blocks_per_cu(LDS, 2))), dim3(NTHREADS), LDS,
-                       st, x, dy, w1, b1, w2, b2, ws, db1, dw2, db2, B, H, T);
-    TT_LAUNCH_CHECK();
+    int rc = dma_ok(x, T) ? launch_rb_bwd_a_v<C, D, true>(x, dy, w1, b1, w2, b2, db1, dw2, db2, ws, B, H, T, st)
+                          : launch_rb_bwd_a_v<C, D, false>(x, dy, w1, b1, w2, b2, db1, dw2, db2, ws, B, H, T, st);
+    if (rc) return rc;
     // dx = dy + W1^T (*) dA1 : the same conv with in/out channels swapped and the taps reversed
-    int rc = launch_conv<C, C, Res3x3<D>, false>(ws, nullptr, w1, WSpec{9, (long)C * 9, -1, 8}, nullptr, dy, dx, B, H, H, T,
-                                                 TT_ACT_NONE, st);
+    rc = launch_conv<C, C, Res3x3<D>, false>(ws, nullptr, w1, WSpec{9, (long)C * 9, -1, 8}, nullptr, dy, dx, B, H, H, T,
+                                             TT_ACT_NONE, st);
     if (rc) return rc;
     // dW1[co][ci][tap] = sum dA1[co][pix] * x[ci][pix + tap]
     return launch_wgrad<C, C, WRes<D, (C <= 8 ? 8 : 4)>, false, false>(ws, nullptr, x, nullptr, dw1, nullptr, (long)C * 9, 9, 1,
-                                                     ws + (long)B * C * H * T, B, H, H, T, st);
+                                                                        ws + (long)B * C * H * T, B, H, H, T, st);
 }
 
 template <int C, int D>

@@ -140,7 +140,7 @@ int tt_resblock_bwd(const float* x, const float* dy, const float* w1, const floa
 int tt_sconv_fwd(const float* x, const float* w, const float* b, float* y, int B, int C, int H, int T,
                  void* stream);
 /* Its backward from the saved input x and OUTPUT y: dx (written; may be NULL), dw / db (accumulated, +=);
- * `scratch` holds tt_wgrad_scratch_floats() floats. */
+ * `scratch` holds tt_wgrad_scratch_floats() + numel(dy) floats (reduction partials, then dy * ELU'(y)). */
 int tt_sconv_bwd(const float* x, const float* y, const float* dy, const float* w, float* dx, float* dw,
                  float* db, float* scratch, int B, int C, int H, int T, void* stream);
 

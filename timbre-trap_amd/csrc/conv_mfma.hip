@@ -1023,16 +1023,30 @@ int rb_wgrad_only(const float* x, float* dw1, float* ws, int B, int H, int T, hi
         default: return TT_E_UNSUPPORTED;                                             \
     }
 
+extern "C" int64_t tt_wgrad_scratch_floats(void);
+
 // strided pair: channel counts (C -> 2C)
 template <int C>
 int sconv_fwd(const float* x, const float* w, const float* b, float* y, int B, int H, int Hout, int T, hipStream_t st) {
     // y[a][r] = ELU(b[a] + sum_{c,kh} w[a][c][kh] x[c][2r+kh])
     return launch_conv<C, 2 * C, Down4, false>(x, nullptr, w, WSpec{(long)C * 4, 4, 1, 0}, b, nullptr, y, B, H, Hout, T, TT_ACT_ELU, st);
 }
+// Backward of the strided pair.  With LDS-DMA staging available the ELU' gate is applied once by a streaming
+// pre-pass (g = dy * ELU'(y), into `scratch` after the reduction area) and both gradients run on the DMA kernels;
+// otherwise the gate is fused into the register-staged loads.
 template <int C>
 int sconv_bwd(const float* x, const float* y, const float* dy, const float* w, float* dx, float* dw, float* db, float* scratch,
               int B, int H, int Hout, int T, hipStream_t st) {
     int rc = 0;
+    const long ng = (long)B * 2 * C * Hout * T;
+    float* g = scratch + tt_wgrad_scratch_floats();
+    if (dma_ok(x, T) && dma_ok(dy, T) && dma_ok(g, T)) {
+        rc = tt_elu_bwd(dy, y, g, ng, st);
+        if (rc) return rc;
+        if (dx) rc = launch_conv<2 * C, C, Up4, false>(g, nullptr, w, WSpec{4, (long)C * 4, 1, 0}, nullptr, nullptr, dx, B, Hout, H, T, TT_ACT_NONE, st);
+        if (rc) return rc;
+        return launch_wgrad<2 * C, C, WStr<(C <= 8 ? 8 : 4)>, false, false>(g, nullptr, x, nullptr, dw, db, (long)C * 4, 4, 1, scratch, B, Hout, H, T, st);
+    }
     if (dx)   // dx[c][r] = sum_{a, kh: r = 2ho + kh} w[a][c][kh] * g[a][ho],  g = dy * ELU'(y)
         rc = launch_conv<2 * C, C, Up4, true>(dy, y, w, WSpec{4, (long)C * 4, 1, 0}, nullptr, nullptr, dx, B, Hout, H, T, TT_ACT_NONE, st);
     if (rc) return rc;
@@ -1048,6 +1062,19 @@ template <int C>
 int tconv_bwd(const float* x, const float* y, const float* dy, const float* w, float* dx, float* dw, float* db, float* scratch,
               int B, int H, int Hout, int T, hipStream_t st) {
     int rc = 0;
+    const long ng = (long)B * C * Hout * T;
+    float* g = scratch + tt_wgrad_scratch_floats();
+    const bool dma = dma_ok(x, T) && dma_ok(dy, T) && dma_ok(g, T);
+    if (dma) {
+        rc = tt_elu_bwd(dy, y, g, ng, st);
+        if (rc) return rc;
+        if (dx) rc = launch_conv<C, 2 * C, Down4, false>(g, nullptr, w, WSpec{(long)C * 4, 4, 1, 0}, nullptr, nullptr, dx, B, Hout, H, T, TT_ACT_NONE, st);
+        if (rc) return rc;
+        rc = launch_wgrad<2 * C, C, WStr<(C <= 8 ? 8 : 4)>, false, false>(x, nullptr, g, nullptr, dw, nullptr, (long)C * 4, 4, 1, scratch, B, H, Hout, T, st);
+        if (rc) return rc;
+        if (db) rc = tt_channel_sum(g, db, B, C, (long)Hout * T, st);
+        return rc;
+    }
     if (dx)   // dx[a][h] = sum_{m,kh} w[a][m][kh] g[m][2h+kh]
         rc = launch_conv<C, 2 * C, Down4, true>(dy, y, w, WSpec{(long)C * 4, 4, 1, 0}, nullptr, nullptr, dx, B, Hout, H, T, TT_ACT_NONE, st);
     if (rc) return rc;

@@ -226,7 +226,7 @@ class StridedConvFn(torch.autograd.Function):
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dw = torch.zeros_like(w)
         db = torch.zeros(2 * C, dtype=torch.float32, device=x.device)
-        scratch = torch.empty(_hip.lib().tt_wgrad_scratch_floats(), dtype=torch.float32, device=x.device)
+        scratch = torch.empty(_hip.lib().tt_wgrad_scratch_floats() + dy.numel(), dtype=torch.float32, device=x.device)
         check(_hip.lib().tt_sconv_bwd(ptr(x), ptr(y), ptr(dy), ptr(w), ptr(dx), ptr(dw), ptr(db), ptr(scratch), B, C, H, T,
                                       stream_ptr()), 'tt_sconv_bwd')
         return dx, dw, db
@@ -256,7 +256,7 @@ class TransposedConvFn(torch.autograd.Function):
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dw = torch.zeros_like(w)
         db = torch.zeros(C, dtype=torch.float32, device=x.device)
-        scratch = torch.empty(_hip.lib().tt_wgrad_scratch_floats(), dtype=torch.float32, device=x.device)
+        scratch = torch.empty(_hip.lib().tt_wgrad_scratch_floats() + dy.numel(), dtype=torch.float32, device=x.device)
         check(_hip.lib().tt_tconv_bwd(ptr(x), ptr(y), ptr(dy), ptr(w), ptr(dx), ptr(dw), ptr(db), ptr(scratch), B, C, H, T,
                                       ctx.out_pad, stream_ptr()), 'tt_tconv_bwd')
         return dx, dw, db, None

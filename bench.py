@@ -187,9 +187,17 @@ def main():
             avg_ms = sum(times) / len(times)
             flops = 2.0 * (9 * C * C + C * C) * args.batch * 65 * M_FRAMES
             ach = flops / (avg_ms * 1e-3) / 1e12
-            roof = dict(kernel='k_rb_conv<%d,D,0> (fused ResidualConv2dBlock forward, C=%d, H=65)' % (C, C),
+            # HBM traffic per launch of this kernel from the rocprofv3 PMC passes committed under profiles/
+            # (FETCH_SIZE x2 per the gfx950 guide + WRITE_SIZE); only valid for the shape it was measured on
+            traffic = None
+            pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_rb_fwd_C32.json')
+            if C == 32 and args.batch == 64 and os.path.exists(pmc):
+                traffic = json.load(open(pmc))['traffic_bytes_corrected']
+            roof = dict(kernel='k_rb_fwd<%d,D> (fused ResidualConv2dBlock forward, C=%d, H=65; same MFMA main loop as the '
+                               'data-gradient kernel k_conv_mfma)' % (C, C),
                         bound='mfma', achieved=ach, peak=PEAK_FP32_MATRIX_TFLOPS, unit='TFLOP/s',
-                        frac=ach / PEAK_FP32_MATRIX_TFLOPS, traffic=None, launches=len(times), avg_ms=avg_ms)
+                        frac=ach / PEAK_FP32_MATRIX_TFLOPS, traffic=traffic, algorithmic_flops=flops,
+                        algorithmic_bytes=2.0 * 4 * C * args.batch * 65 * M_FRAMES, launches=len(times), avg_ms=avg_ms)
         cqt = None
         if events.get('cqt_forward'):
             times = [s.elapsed_time(e) for s, e in events['cqt_forward']]

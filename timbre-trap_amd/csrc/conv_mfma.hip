@@ -78,7 +78,8 @@ struct Geo {
     static constexpr int MT = (COUT + 15) / 16;
     static constexpr int CP = MT * 16;                       // weight image row pitch (floats)
     static constexpr bool SWZ = CP >= 32;
-    static constexpr int CC = 4;                             // channels per staged chunk
+    // channels per staged chunk: DMA costs no registers, so mid-width layers move 8 channels per round trip
+    static constexpr int CC = (DMA && CIN >= 8 && CIN <= 16) ? 8 : 4;
     static constexpr int NCH = CIN / CC;
     static constexpr int HL = DMA ? (P::CH > 0 ? 4 : 0) : P::CH;
     static constexpr int XCP = DMA ? (P::CH > 0 ? TW + 8 : TW) : P::XC;

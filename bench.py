@@ -84,11 +84,33 @@ def train_step(model, opt, audio, target, world):
     return total
 
 
-def cpu_baseline(mc, latent, seconds_budget=25.0):
+def available_cores():
+    """Cores this process may actually use: scheduler affinity capped by the cgroup CPU quota (containers)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    period = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+                    n = min(n, max(1, q // period))
+        except (OSError, ValueError, IndexError):
+            pass
+    return n
+
+
+def cpu_baseline(mc, latent, seconds_budget=20.0):
     """The oracle (CPU restatement, torch + numpy on the host cores) on a bounded sample of the same workload."""
     from oracle import nsgt
     from oracle.train_step import OracleTrainer, cqt_forward_torch
-    threads = os.cpu_count() or 1
+    threads = min(available_cores(), 64)          # beyond ~64 threads the small conv layers only lose to sync overhead
     torch.set_num_threads(threads)
     model = build_model(mc, latent, 'cpu')
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
@@ -100,16 +122,17 @@ def cpu_baseline(mc, latent, seconds_budget=25.0):
         coeffs = cqt_forward_torch(audio, tab)           # train.py:404
         _ = cqt_forward_torch(audio, tab)                # the transform again inside model.encode (modules.py:88)
         trainer.step(coeffs, target)
-    one()                                                # warm-up
     t0 = time.perf_counter()
-    n = 0
-    while True:
+    one()                                                # warm-up (also the sample if the host is very slow)
+    warm = time.perf_counter() - t0
+    n, el = 0, 0.0
+    t0 = time.perf_counter()
+    while warm < seconds_budget and el + warm < seconds_budget and n < 5:
         one()
         n += 1
         el = time.perf_counter() - t0
-        if el > seconds_budget or n >= 5:
-            break
-    step_s = el / n
+    step_s = el / n if n else warm
+    n = max(n, 1)
     cpu_model = ''
     try:
         for line in open('/proc/cpuinfo'):
@@ -119,7 +142,7 @@ def cpu_baseline(mc, latent, seconds_budget=25.0):
     except OSError:
         pass
     return dict(value=SECS_PER_CLIP / step_s, unit='audio-seconds/s', cores=threads, kind='port',
-                sample='%d train steps of 1 clip x 3 s (mc=%d, latent=%s) after 1 warm-up, fp32, %s' % (n, mc, latent, cpu_model),
+                sample='%d train steps of 1 clip x 3 s (mc=%d, latent=%s) after 1 warm-up, fp32, %d torch threads, %s' % (n, mc, latent, threads, cpu_model),
                 s_per_step=step_s)
 
 

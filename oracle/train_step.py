@@ -34,7 +34,7 @@ class OracleTrainer:
         total.backward()
         norm = torch.nn.utils.clip_grad_norm_(list(self.params.values()), self.max_norm)
         self.optimizer.step()
-        out = {k: float(v) for k, v in parts.items()}
+        out = {k: float(v.detach()) for k, v in parts.items()}
         out['grad_norm'] = float(norm)
         return out
 

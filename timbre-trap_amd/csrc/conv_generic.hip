@@ -74,6 +74,56 @@ __global__ __launch_bounds__(256) void k_conv_generic(ConvP p) {
     }
 }
 
+// Fast path for the two 3x3 'same' convolutions at the ends of the autoencoder (Encoder.convin 2 -> C0,
+// Decoder.convout C0 -> 2, reference modules.py:431 and :543) and their data gradients: HBM-bound, one thread per
+// pixel, weights broadcast from an LDS image [ci][tap][co] built through the signed strides of the general interface.
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void k_conv3x3_small(ConvP p) {
+    __shared__ float wl[CIN * 9 * COUT + COUT];
+    for (int i = threadIdx.x; i < CIN * 9 * COUT; i += 256) {
+        const int co = i % COUT, tap = (i / COUT) % 9, ci = i / (9 * COUT);
+        wl[i] = p.w[co * p.ws_co + ci * p.ws_ci + (tap / 3) * p.ws_kh + (tap % 3) * p.ws_kw];
+    }
+    if (threadIdx.x < COUT) wl[CIN * 9 * COUT + threadIdx.x] = p.bias ? p.bias[threadIdx.x] : 0.f;
+    __syncthreads();
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + tx, b = blockIdx.z;
+    if (t >= p.T) return;
+    const long plane = (long)p.Hin * p.T;
+    const float* xb = p.x + (long)b * CIN * plane;
+#pragma unroll 1
+    for (int pass = 0; pass < 4; ++pass) {
+        const int h = blockIdx.y * 16 + pass * 4 + ty;
+        if (h >= p.Hin) break;
+        float acc[COUT];
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[co] = wl[CIN * 9 * COUT + co];
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int hh = h + kh - 1;
+                const bool hv = hh >= 0 && hh < p.Hin;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int tt = t + kw - 1;
+                    float xv = 0.f;
+                    if (hv && tt >= 0 && tt < p.T) xv = xb[ci * plane + (long)hh * p.T + tt];
+#pragma unroll
+                    for (int co = 0; co < COUT; ++co) acc[co] = fmaf(xv, wl[(ci * 9 + kh * 3 + kw) * COUT + co], acc[co]);
+                }
+            }
+        const long o = (long)b * COUT * plane + (long)h * p.T + t;
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            float v = acc[co];
+            if (p.act == TT_ACT_ELU) v = elu1(v);
+            if (p.res) v += p.res[o + co * plane];
+            p.y[o + co * plane] = v;
+        }
+    }
+}
+
 struct WgradP {
     const float* x; const float* g; float* dw; float* dbias;
     int B, Cin, Hin, T, Cout, Hout, KH, KW, sh, dh, dw_, ph, pw;
@@ -242,6 +292,16 @@ extern "C" int tt_conv2d(const float* x, const float* w, const float* bias, cons
     if (Hout > 65535 || B > 65535) return TT_E_UNSUPPORTED;
     ConvP p{x, w, bias, res, y, B, Cin, Hin, T, Cout, Hout, KH, KW, stride_h, dil_h, dil_w, pad_h, pad_w,
             transposed, (long)ws_co, (long)ws_ci, (long)ws_kh, (long)ws_kw, act};
+    if (KH == 3 && KW == 3 && stride_h == 1 && dil_h == 1 && dil_w == 1 && pad_h == 1 && pad_w == 1 && !transposed &&
+        Hin == Hout && (Cin == 2 || Cin == 4) && (Cout == 2 || Cout == 4)) {
+        dim3 g3((T + 63) / 64, (Hout + 15) / 16, B);
+        if (Cin == 2 && Cout == 4) hipLaunchKernelGGL((k_conv3x3_small<2, 4>), g3, dim3(256), 0, tt_stream(stream), p);
+        else if (Cin == 4 && Cout == 2) hipLaunchKernelGGL((k_conv3x3_small<4, 2>), g3, dim3(256), 0, tt_stream(stream), p);
+        else if (Cin == 2 && Cout == 2) hipLaunchKernelGGL((k_conv3x3_small<2, 2>), g3, dim3(256), 0, tt_stream(stream), p);
+        else hipLaunchKernelGGL((k_conv3x3_small<4, 4>), g3, dim3(256), 0, tt_stream(stream), p);
+        TT_LAUNCH_CHECK();
+        return 0;
+    }
     const int tb = T >= 256 ? 256 : (T > 64 ? 128 : 64);
     dim3 grid((T + tb - 1) / tb, Hout, B);
     if (Cout >= 16)

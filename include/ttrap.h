@@ -119,18 +119,20 @@ int tt_elu_bwd(const float* dy, const float* y, float* g, int64_t n, void* strea
 
 /* Fused ResidualConv2dBlock forward (modules.py:755-777):
  *   y = ELU(W2 . ELU(W1 (*)_dil x + b1) + b2) + x      x,y: (B,C,H,T), W1 (C,C,3,3), W2 (C,C,1,1)
- * Supported C: 4,8,16,32; dilation 1..3 (other widths: compose tt_conv2d calls). */
+ * Supported C: 4,8,16,32; dilation 1..3 (other widths: compose tt_conv2d calls).
+ * If h1 != NULL the hidden activation ELU(W1 (*) x + b1) (B,C,H,T) is also written, for tt_resblock_bwd. */
 int64_t tt_wgrad_scratch_floats(void);
 
 int tt_resblock_fwd(const float* x, const float* w1, const float* b1, const float* w2,
-                    const float* b2, float* y, int B, int C, int H, int T, int dilation,
+                    const float* b2, float* y, float* h1, int B, int C, int H, int T, int dilation,
                     void* stream);
 
-/* Fused ResidualConv2dBlock backward, recomputing the two hidden activations from x:
- *   inputs  x, dy            outputs  dx (written), dw1/db1/dw2/db2 (accumulated, +=)
+/* Fused ResidualConv2dBlock backward.  h1 = the hidden activation saved by tt_resblock_fwd, or NULL to
+ * recompute it from x (one more 3x3 convolution, half the saved-activation memory):
+ *   inputs  x, h1, dy        outputs  dx (written), dw1/db1/dw2/db2 (accumulated, +=)
  * `ws` is scratch of B*C*H*T + tt_wgrad_scratch_floats() floats (dL/d(conv1 pre-activation), then the
  * per-workgroup partial weight gradients that a second launch sums without atomics). */
-int tt_resblock_bwd(const float* x, const float* dy, const float* w1, const float* b1,
+int tt_resblock_bwd(const float* x, const float* h1, const float* dy, const float* w1, const float* b1,
                     const float* w2, const float* b2, float* dx, float* dw1, float* db1,
                     float* dw2, float* db2, float* ws, int B, int C, int H, int T, int dilation,
                     void* stream);

@@ -25,8 +25,10 @@ def _rand(*shape, seed=0, scale=1.0):
 
 @pytest.mark.parametrize('C,d', [(4, 1), (4, 3), (8, 2), (16, 1), (16, 3), (32, 1), (32, 2), (32, 3)])
 @pytest.mark.parametrize('shape', [(2, 13, 70), (1, 9, 130), (1, 31, 64)])
-def test_fused_resblock_forward_backward(C, d, shape):
+@pytest.mark.parametrize('save_hidden', [True, False])
+def test_fused_resblock_forward_backward(C, d, shape, save_hidden, monkeypatch):
     from timbre_trap.framework import ops
+    monkeypatch.setattr(ops, 'SAVE_HIDDEN', save_hidden)      # hidden activation kept vs recomputed in backward
     B, H, T = shape
     x = _rand(B, C, H, T, seed=1)
     w1 = _rand(C, C, 3, 3, seed=2, scale=1.0 / (3 * C ** 0.5))

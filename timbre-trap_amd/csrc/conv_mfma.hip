@@ -322,7 +322,8 @@ __device__ __forceinline__ void build_w2_images(float* W2s, float* W2t, float* b
 template <int C, int D, bool DMA>
 __global__ __launch_bounds__(NTHREADS, 4) void k_rb_fwd(const float* __restrict__ x, const float* __restrict__ w1,
                                                      const float* __restrict__ b1, const float* __restrict__ w2,
-                                                     const float* __restrict__ b2, float* __restrict__ y, int B, int H, int T) {
+                                                     const float* __restrict__ b2, float* __restrict__ y,
+                                                     float* __restrict__ h1out, int B, int H, int T) {
     using P = Res3x3<D>;
     using G = Geo<C, C, P, DMA>;
     using R = RB<C>;
@@ -372,7 +373,10 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_rb_fwd(const float* __restrict_
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
                     const int t = tl.t0 + nt * 16 + l15;
-                    if (t < T) y[base + t] = elu1(acc2[m2][nt][r] + bias) + x[base + t];
+                    if (t < T) {
+                        y[base + t] = elu1(acc2[m2][nt][r] + bias) + x[base + t];
+                        if (h1out) h1out[base + t] = acc[m2][nt][r];        // hidden activation for the backward pass
+                    }
                 }
             }
     });
@@ -390,8 +394,10 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int C, int D, bool DMA>
-__global__ __launch_bounds__(NTHREADS) void k_rb_bwd_a(const float* __restrict__ x, const float* __restrict__ dy,
+// RECOMP = true : hidden activation recomputed from x (3x3 conv main loop);  false : read back from `h1in`
+template <int C, int D, bool DMA, bool RECOMP>
+__global__ __launch_bounds__(NTHREADS) void k_rb_bwd_a(const float* __restrict__ x, const float* __restrict__ h1in,
+                                                       const float* __restrict__ dy,
                                                        const float* __restrict__ w1, const float* __restrict__ b1,
                                                        const float* __restrict__ w2, const float* __restrict__ b2,
                                                        float* __restrict__ da1, float* __restrict__ db1,
@@ -401,14 +407,15 @@ __global__ __launch_bounds__(NTHREADS) void k_rb_bwd_a(const float* __restrict__
     using R = RB<C>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xs = lds;
-    float* Wimg = xs + G::XS_FLOATS;
-    float* W2s = Wimg + G::W_FLOATS;
+    float* Wimg = xs + (RECOMP ? G::XS_FLOATS : 0);
+    float* W2s = Wimg + (RECOMP ? G::W_FLOATS : 0);
     float* W2t = W2s + R::CPAD * R::CP;
     float* b1s = W2t + R::CPAD * R::CP;
     float* b2s = b1s + R::CPAD;
     float* tr = b2s + R::CPAD;          // per-wave transpose tiles (own region: no workgroup barrier needed)
-    build_weight_image<C, C, P>(Wimg, w1, (long)C * 9, 9, 1, 0, threadIdx.x);
+    if (RECOMP) build_weight_image<C, C, P>(Wimg, w1, (long)C * 9, 9, 1, 0, threadIdx.x);
     build_w2_images<C>(W2s, W2t, b1s, b2s, w2, b1, b2, threadIdx.x);
+    if (!RECOMP) __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, l15 = lane & 15;
     const long plane = (long)H * T;
     float* trA = tr + wave * 2 * R::CPAD * R::TP;
@@ -424,7 +431,7 @@ __global__ __launch_bounds__(NTHREADS) void k_rb_bwd_a(const float* __restrict__
         for (int r = 0; r < 4; ++r) { db1acc[a][r] = 0.f; db2acc[a][r] = 0.f; }
     }
 
-    conv_mainloop<C, C, P, false, DMA>(x, nullptr, Wimg, xs, B, H, H, T, [&](const Tile& tl, f32x4 (&h1)[G::MT][4]) {
+    auto epi = [&](const Tile& tl, f32x4 (&h1)[G::MT][4]) {
         const int h = tl.h0 + wave;
         f32x4 a2[G::MT][4];
 #pragma unroll
@@ -432,8 +439,10 @@ __global__ __launch_bounds__(NTHREADS) void k_rb_bwd_a(const float* __restrict__
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 a2[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (RECOMP) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) h1[mt][nt][r] = elu1(h1[mt][nt][r] + b1s[mt * 16 + 4 * g + r]);
+                    for (int r = 0; r < 4; ++r) h1[mt][nt][r] = elu1(h1[mt][nt][r] + b1s[mt * 16 + 4 * g + r]);
+                }
             }
 #pragma unroll
         for (int mt = 0; mt < G::MT; ++mt)
@@ -525,7 +534,32 @@ __global__ __launch_bounds__(NTHREADS) void k_rb_bwd_a(const float* __restrict__
                     for (int mt = 0; mt < G::MT; ++mt) accw2[m2][mt] = mfma16(av[m2], bv[mt], accw2[m2][mt]);
             }
         }
-    });
+    };
+    if (RECOMP) {
+        conv_mainloop<C, C, P, false, DMA>(x, nullptr, Wimg, xs, B, H, H, T, epi);
+    } else {
+        const int tiles_h = (H + TH - 1) / TH, tiles_t = (T + TW - 1) / TW;
+        const int ntiles = B * tiles_h * tiles_t;
+#pragma unroll 1
+        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            const Tile tl = decode_tile(tile, tiles_h, tiles_t);
+            const int h = tl.h0 + wave;
+            f32x4 h1[G::MT][4];
+#pragma unroll
+            for (int mt = 0; mt < G::MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = mt * 16 + 4 * g + r;
+                    const long base = ((long)tl.b * C + (co < C ? co : 0)) * plane + (long)(h < H ? h : 0) * T;
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const int t = tl.t0 + nt * 16 + l15;
+                        h1[mt][nt][r] = (co < C && h < H && t < T) ? h1in[base + t] : 0.f;
+                    }
+                }
+            epi(tl, h1);
+        }
+    }
     // reduce the 8 waves in LDS (own region: tr), then one global atomic per element per workgroup
     __syncthreads();
     float* red = tr;                                   // [CPAD][CPAD] dW2, then db1[CPAD], db2[CPAD]
@@ -906,8 +940,8 @@ int launch_conv(const float* x, const float* gy, const float* w, WSpec ws, const
 }
 
 template <int C, int D, bool DMA>
-int launch_rb_fwd_v(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y, int B, int H,
-                    int T, hipStream_t st) {
+int launch_rb_fwd_v(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y, float* h1,
+                    int B, int H, int T, hipStream_t st) {
     using G = Geo<C, C, Res3x3<D>, DMA>;
     using R = RB<C>;
     constexpr int LDS = (G::W_FLOATS + R::CPAD * R::CP + 2 * R::CPAD + G::XS_FLOATS) * 4;
@@ -917,16 +951,16 @@ int launch_rb_fwd_v(const float* x, const float* w1, const float* b1, const floa
         attr = true;
     }
     hipLaunchKernelGGL((k_rb_fwd<C, D, DMA>), dim3(persistent_grid(ntiles_of(B, H, T), blocks_per_cu(LDS, 2))), dim3(NTHREADS), LDS,
-                       st, x, w1, b1, w2, b2, y, B, H, T);
+                       st, x, w1, b1, w2, b2, y, h1, B, H, T);
     TT_LAUNCH_CHECK();
     return 0;
 }
 
 template <int C, int D>
-int launch_rb_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y, int B, int H,
-                  int T, hipStream_t st) {
-    if (dma_ok(x, T)) return launch_rb_fwd_v<C, D, true>(x, w1, b1, w2, b2, y, B, H, T, st);
-    return launch_rb_fwd_v<C, D, false>(x, w1, b1, w2, b2, y, B, H, T, st);
+int launch_rb_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y, float* h1,
+                  int B, int H, int T, hipStream_t st) {
+    if (dma_ok(x, T)) return launch_rb_fwd_v<C, D, true>(x, w1, b1, w2, b2, y, h1, B, H, T, st);
+    return launch_rb_fwd_v<C, D, false>(x, w1, b1, w2, b2, y, h1, B, H, T, st);
 }
 
 constexpr int WGRAD_MAX_BLOCKS = 512;
@@ -977,28 +1011,31 @@ int launch_wgrad(const float* Pt, const float* Pg, const float* Qt, const float*
     return 0;
 }
 
-template <int C, int D, bool DMA>
-int launch_rb_bwd_a_v(const float* x, const float* dy, const float* w1, const float* b1, const float* w2, const float* b2,
-                      float* db1, float* dw2, float* db2, float* ws, int B, int H, int T, hipStream_t st) {
+template <int C, int D, bool DMA, bool RECOMP>
+int launch_rb_bwd_a_v(const float* x, const float* h1, const float* dy, const float* w1, const float* b1, const float* w2,
+                      const float* b2, float* db1, float* dw2, float* db2, float* ws, int B, int H, int T, hipStream_t st) {
     using G = Geo<C, C, Res3x3<D>, DMA>;
     using R = RB<C>;
-    constexpr int LDS = (G::W_FLOATS + 2 * R::CPAD * R::CP + 2 * R::CPAD + G::XS_FLOATS + R::TR_FLOATS) * 4;
+    constexpr int LDS = ((RECOMP ? G::W_FLOATS + G::XS_FLOATS : 0) + 2 * R::CPAD * R::CP + 2 * R::CPAD + R::TR_FLOATS) * 4;
     static bool attr = false;
     if (!attr) {
-        TT_HIP(hipFuncSetAttribute((const void*)k_rb_bwd_a<C, D, DMA>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        TT_HIP(hipFuncSetAttribute((const void*)k_rb_bwd_a<C, D, DMA, RECOMP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr = true;
     }
-    hipLaunchKernelGGL((k_rb_bwd_a<C, D, DMA>), dim3(persistent_grid(ntiles_of(B, H, T), blocks_per_cu(LDS, 2))), dim3(NTHREADS), LDS,
-                       st, x, dy, w1, b1, w2, b2, ws, db1, dw2, db2, B, H, T);
+    hipLaunchKernelGGL((k_rb_bwd_a<C, D, DMA, RECOMP>), dim3(persistent_grid(ntiles_of(B, H, T), blocks_per_cu(LDS, 2))),
+                       dim3(NTHREADS), LDS, st, x, h1, dy, w1, b1, w2, b2, ws, db1, dw2, db2, B, H, T);
     TT_LAUNCH_CHECK();
     return 0;
 }
 
 template <int C, int D>
-int launch_rb_bwd(const float* x, const float* dy, const float* w1, const float* b1, const float* w2, const float* b2,
-                  float* dx, float* dw1, float* db1, float* dw2, float* db2, float* ws, int B, int H, int T, hipStream_t st) {
-    int rc = dma_ok(x, T) ? launch_rb_bwd_a_v<C, D, true>(x, dy, w1, b1, w2, b2, db1, dw2, db2, ws, B, H, T, st)
-                          : launch_rb_bwd_a_v<C, D, false>(x, dy, w1, b1, w2, b2, db1, dw2, db2, ws, B, H, T, st);
+int launch_rb_bwd(const float* x, const float* h1, const float* dy, const float* w1, const float* b1, const float* w2,
+                  const float* b2, float* dx, float* dw1, float* db1, float* dw2, float* db2, float* ws, int B, int H, int T,
+                  hipStream_t st) {
+    int rc;
+    if (h1) rc = launch_rb_bwd_a_v<C, 1, false, false>(x, h1, dy, w1, b1, w2, b2, db1, dw2, db2, ws, B, H, T, st);
+    else rc = dma_ok(x, T) ? launch_rb_bwd_a_v<C, D, true, true>(x, h1, dy, w1, b1, w2, b2, db1, dw2, db2, ws, B, H, T, st)
+                           : launch_rb_bwd_a_v<C, D, false, true>(x, h1, dy, w1, b1, w2, b2, db1, dw2, db2, ws, B, H, T, st);
     if (rc) return rc;
     // dx = dy + W1^T (*) dA1 : the same conv with in/out channels swapped and the taps reversed
     rc = launch_conv<C, C, Res3x3<D>, false>(ws, nullptr, w1, WSpec{9, (long)C * 9, -1, 8}, nullptr, dy, dx, B, H, H, T,
@@ -1109,21 +1146,21 @@ int tconv_bwd(const float* x, const float* y, const float* dy, const float* w, f
 extern "C" int64_t tt_wgrad_scratch_floats(void) { return (int64_t)WGRAD_MAX_BLOCKS * 64 * 144; }
 
 extern "C" int tt_resblock_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
-                               float* y, int B, int C, int H, int T, int dilation, void* stream) {
+                               float* y, float* h1, int B, int C, int H, int T, int dilation, void* stream) {
     if (!x || !w1 || !b1 || !w2 || !b2 || !y || B <= 0 || H <= 0 || T <= 0) return TT_E_BADARG;
     hipStream_t st = tt_stream(stream);
-    if (C <= 8) return tt_small_rb_fwd(x, w1, b1, w2, b2, y, B, C, H, T, dilation, st);     // HBM-bound levels: VALU kernels
-    TT_DISPATCH_CD(launch_rb_fwd, x, w1, b1, w2, b2, y, B, H, T, st)
+    if (C <= 8) return tt_small_rb_fwd(x, w1, b1, w2, b2, y, h1, B, C, H, T, dilation, st);     // HBM-bound levels: VALU kernels
+    TT_DISPATCH_CD(launch_rb_fwd, x, w1, b1, w2, b2, y, h1, B, H, T, st)
 }
 
-extern "C" int tt_resblock_bwd(const float* x, const float* dy, const float* w1, const float* b1, const float* w2,
-                               const float* b2, float* dx, float* dw1, float* db1, float* dw2, float* db2, float* ws,
-                               int B, int C, int H, int T, int dilation, void* stream) {
+extern "C" int tt_resblock_bwd(const float* x, const float* h1, const float* dy, const float* w1, const float* b1,
+                               const float* w2, const float* b2, float* dx, float* dw1, float* db1, float* dw2, float* db2,
+                               float* ws, int B, int C, int H, int T, int dilation, void* stream) {
     if (!x || !dy || !w1 || !b1 || !w2 || !b2 || !dx || !dw1 || !db1 || !dw2 || !db2 || !ws || B <= 0 || H <= 0 || T <= 0)
         return TT_E_BADARG;
     hipStream_t st = tt_stream(stream);
     if (C <= 8) {
-        int rc = tt_small_rb_bwd(x, dy, w1, b1, w2, b2, dx, dw1, db1, dw2, db2, ws, ws + (long)B * C * H * T, B, C, H, T,
+        int rc = tt_small_rb_bwd(x, h1, dy, w1, b1, w2, b2, dx, dw1, db1, dw2, db2, ws, ws + (long)B * C * H * T, B, C, H, T,
                                  dilation, st);
         if (rc) return rc;
         switch (C * 10 + dilation) {
@@ -1136,7 +1173,7 @@ extern "C" int tt_resblock_bwd(const float* x, const float* dy, const float* w1,
             default: return TT_E_UNSUPPORTED;
         }
     }
-    TT_DISPATCH_CD(launch_rb_bwd, x, dy, w1, b1, w2, b2, dx, dw1, db1, dw2, db2, ws, B, H, T, st)
+    TT_DISPATCH_CD(launch_rb_bwd, x, h1, dy, w1, b1, w2, b2, dx, dw1, db1, dw2, db2, ws, B, H, T, st)
 }
 
 extern "C" int tt_sconv_fwd(const float* x, const float* w, const float* b, float* y, int B, int C, int H, int T,

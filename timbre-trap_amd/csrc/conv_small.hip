@@ -80,7 +80,7 @@ template <int C, int D, int MODE>
 __global__ __launch_bounds__(256) void k_small(const float* __restrict__ x, const float* __restrict__ w1,
                                                const float* __restrict__ b1, const float* __restrict__ w2,
                                                const float* __restrict__ b2, const float* __restrict__ res,
-                                               float* __restrict__ y, int B, int H, int T) {
+                                               float* __restrict__ y, float* __restrict__ h1out, int B, int H, int T) {
     using S = SW<C>;
     __shared__ float lds[S::FLOATS];
     build_images<C>(lds, w1, MODE == 0 ? b1 : nullptr, MODE == 0 ? w2 : nullptr, MODE == 0 ? b2 : nullptr, MODE == 1);
@@ -107,6 +107,7 @@ __global__ __launch_bounds__(256) void k_small(const float* __restrict__ x, cons
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 const float hv = elu1(acc[c]);
+                if (h1out) h1out[o + c * plane] = hv;
                 const float* wl = lds + S::W2 + c * C;
 #pragma unroll
                 for (int co = 0; co < C; ++co) a2[co] = fmaf(hv, wl[co], a2[co]);
@@ -121,8 +122,9 @@ __global__ __launch_bounds__(256) void k_small(const float* __restrict__ x, cons
 }
 
 // recompute + pointwise chain; persistent workgroups accumulate db1, db2, dW2 in registers
-template <int C, int D>
-__global__ __launch_bounds__(256) void k_small_bwd_a(const float* __restrict__ x, const float* __restrict__ dy,
+template <int C, int D, bool RECOMP>
+__global__ __launch_bounds__(256) void k_small_bwd_a(const float* __restrict__ x, const float* __restrict__ h1in,
+                                                     const float* __restrict__ dy,
                                                      const float* __restrict__ w1, const float* __restrict__ b1,
                                                      const float* __restrict__ w2, const float* __restrict__ b2,
                                                      float* __restrict__ da1, float* __restrict__ db1, float* __restrict__ dw2,
@@ -151,14 +153,22 @@ __global__ __launch_bounds__(256) void k_small_bwd_a(const float* __restrict__ x
         const int b = q / tiles_h;
         const int t = tt * 64 + tx, h = th * 4 + ty;
         if (t >= T || h >= H) continue;
-        const float* xb = x + (long)b * C * plane;
+        const long o = (long)b * C * plane + (long)h * T + t;
         float h1[C];
+        if (RECOMP) {
+            const float* xb = x + (long)b * C * plane;
 #pragma unroll
-        for (int co = 0; co < C; ++co) h1[co] = lds[S::B1 + co];
-        conv_pixel<C, D>(xb, lds + S::W1, plane, H, T, h, t, h1);
+            for (int co = 0; co < C; ++co) h1[co] = lds[S::B1 + co];
+            conv_pixel<C, D>(xb, lds + S::W1, plane, H, T, h, t, h1);
+#pragma unroll
+            for (int co = 0; co < C; ++co) h1[co] = elu1(h1[co]);
+        } else {
+#pragma unroll
+            for (int co = 0; co < C; ++co) h1[co] = h1in[o + co * plane];
+        }
         float a2[C];
 #pragma unroll
-        for (int co = 0; co < C; ++co) { a2[co] = lds[S::B2 + co]; h1[co] = elu1(h1[co]); }
+        for (int co = 0; co < C; ++co) a2[co] = lds[S::B2 + co];
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int c = 0; c < C; ++c) {
@@ -167,7 +177,6 @@ __global__ __launch_bounds__(256) void k_small_bwd_a(const float* __restrict__ x
             for (int co = 0; co < C; ++co) a2[co] = fmaf(h1[c], wl[co], a2[co]);
         }
         asm volatile("" ::: "memory");
-        const long o = (long)b * C * plane + (long)h * T + t;
         float d1[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) d1[c] = 0.f;
@@ -210,48 +219,54 @@ __global__ __launch_bounds__(256) void k_small_bwd_a(const float* __restrict__ x
 }
 
 template <int C, int D>
-int fwd_t(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y, int B, int H, int T,
-          hipStream_t st) {
+int fwd_t(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y, float* h1, int B, int H,
+          int T, hipStream_t st) {
     dim3 grid((T + 63) / 64, (H + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, B);
-    hipLaunchKernelGGL((k_small<C, D, 0>), grid, dim3(256), 0, st, x, w1, b1, w2, b2, (const float*)nullptr, y, B, H, T);
+    hipLaunchKernelGGL((k_small<C, D, 0>), grid, dim3(256), 0, st, x, w1, b1, w2, b2, (const float*)nullptr, y, h1, B, H, T);
     TT_LAUNCH_CHECK();
     return 0;
 }
 
 template <int C, int D>
-int bwd_t(const float* x, const float* dy, const float* w1, const float* b1, const float* w2, const float* b2, float* dx,
-          float* dw1, float* db1, float* dw2, float* db2, float* ws, float* scratch, int B, int H, int T, hipStream_t st) {
+int bwd_t(const float* x, const float* h1, const float* dy, const float* w1, const float* b1, const float* w2, const float* b2,
+          float* dx, float* dw1, float* db1, float* dw2, float* db2, float* ws, float* scratch, int B, int H, int T,
+          hipStream_t st) {
     (void)dw1; (void)scratch;
     const int ntiles = B * ((H + 3) / 4) * ((T + 63) / 64);
     const int pgrid = ntiles < 2048 ? ntiles : 2048;
-    hipLaunchKernelGGL((k_small_bwd_a<C, D>), dim3(pgrid), dim3(256), 0, st, x, dy, w1, b1, w2, b2, ws, db1, dw2, db2, B, H, T);
+    if (h1)
+        hipLaunchKernelGGL((k_small_bwd_a<C, D, false>), dim3(pgrid), dim3(256), 0, st, x, h1, dy, w1, b1, w2, b2, ws, db1, dw2,
+                           db2, B, H, T);
+    else
+        hipLaunchKernelGGL((k_small_bwd_a<C, D, true>), dim3(pgrid), dim3(256), 0, st, x, h1, dy, w1, b1, w2, b2, ws, db1, dw2,
+                           db2, B, H, T);
     TT_LAUNCH_CHECK();
     dim3 grid((T + 63) / 64, (H + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, B);
     hipLaunchKernelGGL((k_small<C, D, 1>), grid, dim3(256), 0, st, (const float*)ws, w1, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, dy, dx, B, H, T);
+                       (const float*)nullptr, (const float*)nullptr, dy, dx, (float*)nullptr, B, H, T);
     TT_LAUNCH_CHECK();
     return 0;
 }
 
 }  // namespace
 
-int tt_small_rb_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y, int B, int C,
-                    int H, int T, int dilation, hipStream_t st) {
+int tt_small_rb_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y, float* h1,
+                    int B, int C, int H, int T, int dilation, hipStream_t st) {
     switch (C * 10 + dilation) {
-        case 41: return fwd_t<4, 1>(x, w1, b1, w2, b2, y, B, H, T, st);
-        case 42: return fwd_t<4, 2>(x, w1, b1, w2, b2, y, B, H, T, st);
-        case 43: return fwd_t<4, 3>(x, w1, b1, w2, b2, y, B, H, T, st);
-        case 81: return fwd_t<8, 1>(x, w1, b1, w2, b2, y, B, H, T, st);
-        case 82: return fwd_t<8, 2>(x, w1, b1, w2, b2, y, B, H, T, st);
-        case 83: return fwd_t<8, 3>(x, w1, b1, w2, b2, y, B, H, T, st);
+        case 41: return fwd_t<4, 1>(x, w1, b1, w2, b2, y, h1, B, H, T, st);
+        case 42: return fwd_t<4, 2>(x, w1, b1, w2, b2, y, h1, B, H, T, st);
+        case 43: return fwd_t<4, 3>(x, w1, b1, w2, b2, y, h1, B, H, T, st);
+        case 81: return fwd_t<8, 1>(x, w1, b1, w2, b2, y, h1, B, H, T, st);
+        case 82: return fwd_t<8, 2>(x, w1, b1, w2, b2, y, h1, B, H, T, st);
+        case 83: return fwd_t<8, 3>(x, w1, b1, w2, b2, y, h1, B, H, T, st);
         default: return TT_E_UNSUPPORTED;
     }
 }
 
-int tt_small_rb_bwd(const float* x, const float* dy, const float* w1, const float* b1, const float* w2, const float* b2,
-                    float* dx, float* dw1, float* db1, float* dw2, float* db2, float* ws, float* scratch, int B, int C, int H,
+int tt_small_rb_bwd(const float* x, const float* h1, const float* dy, const float* w1, const float* b1, const float* w2,
+                    const float* b2, float* dx, float* dw1, float* db1, float* dw2, float* db2, float* ws, float* scratch, int B, int C, int H,
                     int T, int dilation, hipStream_t st) {
-#define TT_SB(CC, DD) bwd_t<CC, DD>(x, dy, w1, b1, w2, b2, dx, dw1, db1, dw2, db2, ws, scratch, B, H, T, st)
+#define TT_SB(CC, DD) bwd_t<CC, DD>(x, h1, dy, w1, b1, w2, b2, dx, dw1, db1, dw2, db2, ws, scratch, B, H, T, st)
     switch (C * 10 + dilation) {
         case 41: return TT_SB(4, 1);
         case 42: return TT_SB(4, 2);

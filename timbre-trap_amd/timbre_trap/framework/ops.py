@@ -21,6 +21,9 @@ ACT_NONE, ACT_ELU = 0, 1
 # the block from the general convolution kernels instead (used to cross-check the two on the GPU).
 FUSED_RESBLOCK = os.environ.get('TTRAP_FUSED', '1') != '0'
 FUSED_CHANNELS = (4, 8, 16, 32)
+# Keep the hidden activation of every residual block for backward (one more (B,C,H,T) tensor per block, no 3x3
+# recompute).  TTRAP_SAVE_HIDDEN=0 recomputes instead and halves the residual-block activation memory.
+SAVE_HIDDEN = os.environ.get('TTRAP_SAVE_HIDDEN', '1') != '0'
 
 
 @dataclass(frozen=True)
@@ -183,23 +186,25 @@ class ResBlockFn(torch.autograd.Function):
         x = _f32c(x)
         B, C, H, T = x.shape
         y = torch.empty_like(x)
+        needs_grad = any(ctx.needs_input_grad[:5])
+        h1 = torch.empty_like(x) if (needs_grad and SAVE_HIDDEN) else None
         with _hip.timed('resblock_fwd_C%d' % C):
-            check(_hip.lib().tt_resblock_fwd(ptr(x), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(y), B, C, H, T, dilation,
+            check(_hip.lib().tt_resblock_fwd(ptr(x), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(y), ptr(h1), B, C, H, T, dilation,
                                              stream_ptr()), 'tt_resblock_fwd')
         ctx.dilation = dilation
-        ctx.save_for_backward(x, w1, b1, w2, b2)
+        ctx.save_for_backward(x, w1, b1, w2, b2, h1)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w1, b1, w2, b2 = ctx.saved_tensors
+        x, w1, b1, w2, b2, h1 = ctx.saved_tensors
         dy = _f32c(dy)
         B, C, H, T = x.shape
         dx = torch.empty_like(x)
         dw1, db1, dw2, db2 = (torch.zeros_like(t) for t in (w1, b1, w2, b2))
         ws = torch.empty(x.numel() + _hip.lib().tt_wgrad_scratch_floats(), dtype=torch.float32, device=x.device)
         with _hip.timed('resblock_bwd_C%d' % C):
-            check(_hip.lib().tt_resblock_bwd(ptr(x), ptr(dy), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(dx), ptr(dw1),
+            check(_hip.lib().tt_resblock_bwd(ptr(x), ptr(h1), ptr(dy), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(dx), ptr(dw1),
                                              ptr(db1), ptr(dw2), ptr(db2), ptr(ws), B, C, H, T, ctx.dilation,
                                              stream_ptr()), 'tt_resblock_bwd')
         return dx, dw1, db1, dw2, db2, None

@@ -116,16 +116,33 @@ __global__ __launch_bounds__(256) void k_fft675_rows(const float2* __restrict__ 
 }
 
 // Step 2: 49-point DFTs over n2 for 16 low columns k1, their 16 mirrors 675-k1 and (tile 0) k1=0.
+// 49 = 7 x 7:  n2 = 7 a + b,  k2 = e + 7 f :
+//   G[b][e] = W_49^(b e) * sum_a W_7^(a e) A[7a + b]          (thread = (column, b): 7 inputs -> 7 outputs)
+//   Z[e+7f] = sum_b W_7^(b f) G[b][e]                          (thread = (column, e): 7 inputs -> 7 outputs)
 // MODE 0: real-FFT split -> X[q][0..NC] (half spectrum of the 66150 real samples).
-// MODE 1: inverse tail  -> out[q][k] = conj(Z[k]) / NC  written as audio pairs.
+// MODE 1: inverse tail  -> out[q][k] = conj(Z[k]) / NC  written as audio pairs; the workgroup's abs-max goes to *mx
+//         (CQT.decode's inf-norm, reference cqtwrapper.py:209-211) with one atomic per workgroup.
 constexpr int CT = 16;                      // low columns per tile
 constexpr int NTILES = (337 + CT - 1) / CT; // k1 = 1..337 are "low", 338..674 their mirrors
+
+__device__ __forceinline__ void dft7(const float2 (&in)[7], float2 (&out)[7], const float2 (&w7)[7]) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        float2 acc = in[0];
+#pragma unroll
+        for (int n = 1; n < 7; ++n) acc = cadd(acc, cmul(in[n], w7[(n * k) % 7]));
+        out[k] = acc;
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void k_fft49_cols(const float2* __restrict__ A, float2* __restrict__ out,
-                                                    const float2* __restrict__ tw49g, const float2* __restrict__ twN) {
+                                                    const float2* __restrict__ tw49g, const float2* __restrict__ twN,
+                                                    unsigned* __restrict__ mx) {
     __shared__ float2 Al[N2][2 * CT + 1];
     __shared__ float2 Zl[2 * CT + 1][N2 + 1];
     __shared__ float2 tw[N2];
+    __shared__ float wmax[4];
     const int tid = threadIdx.x, tile = blockIdx.x;
     const long q = blockIdx.y;
     const float2* a = A + q * NC;
@@ -144,27 +161,57 @@ __global__ __launch_bounds__(256) void k_fft49_cols(const float2* __restrict__ A
         Al[n2][c] = (k1 >= 0) ? a[n2 * N1 + k1] : make_float2(0.f, 0.f);
     }
     __syncthreads();
-    for (int i = tid; i < ncol * N2; i += 256) {
-        const int c = i / N2, k2 = i - c * N2;
-        float2 acc = make_float2(0.f, 0.f);
-        int e = 0;                          // (n2 * k2) mod 49
-#pragma unroll 7
-        for (int n2 = 0; n2 < N2; ++n2) {
-            acc = cadd(acc, cmul(Al[n2][c], tw[e]));
-            e += k2; if (e >= N2) e -= N2;
-        }
-        Zl[c][k2] = acc;
+    float2 w7[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) w7[j] = tw[7 * j];
+    // stage 1: thread (c, b)
+    float2 gv[7];
+    const bool act1 = tid < ncol * 7;
+    const int c1 = tid / 7, b1 = tid - c1 * 7;
+    if (act1) {
+        float2 in[7];
+#pragma unroll
+        for (int aa = 0; aa < 7; ++aa) in[aa] = Al[7 * aa + b1][c1];
+        dft7(in, gv, w7);
+#pragma unroll
+        for (int e = 1; e < 7; ++e) gv[e] = cmul(gv[e], tw[b1 * e]);      // W_49^(b e), b e <= 36
+    }
+    __syncthreads();
+    if (act1) {
+#pragma unroll
+        for (int e = 0; e < 7; ++e) Al[7 * e + b1][c1] = gv[e];           // G[b][e] stored at row 7 e + b
+    }
+    __syncthreads();
+    // stage 2: thread (c, e)
+    if (act1) {
+        const int e = b1;
+        float2 in[7], o[7];
+#pragma unroll
+        for (int bb = 0; bb < 7; ++bb) in[bb] = Al[7 * e + bb][c1];
+        dft7(in, o, w7);
+#pragma unroll
+        for (int f = 0; f < 7; ++f) Zl[c1][e + 7 * f] = o[f];
     }
     __syncthreads();
     if (MODE == 1) {
         const float inv = 1.0f / (float)NC;
         float2* o = out + q * NC;
+        float m = 0.f;
         for (int i = tid; i < ncol * N2; i += 256) {
             const int k2 = i / ncol, c = i - k2 * ncol;
             const int k1 = col_k1(c);
             if (k1 < 0) continue;
             float2 z = Zl[c][k2];
-            o[k1 + N1 * k2] = make_float2(z.x * inv, -z.y * inv);
+            const float2 r = make_float2(z.x * inv, -z.y * inv);
+            o[k1 + N1 * k2] = r;
+            m = fmaxf(m, fmaxf(fabsf(r.x), fabsf(r.y)));
+        }
+        if (mx) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+            if ((tid & 63) == 0) wmax[tid >> 6] = m;
+            __syncthreads();
+            if (tid == 0) atomicMax(mx, __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
         }
     } else {
         float2* X = out + q * XPAD;
@@ -207,91 +254,155 @@ __global__ __launch_bounds__(256) void k_fft49_cols(const float2* __restrict__ A
     }
 }
 
-// ---- 1024-point radix-4 Stockham FFT, one wave per transform, ping-pong in LDS ----------------
-// INV = true uses conjugate twiddles (unnormalised inverse).
+// ---- 1024-point FFT, one wave per transform, data in registers -------------------------------------------------
+// Lane b (0..63) holds x[64 a + b] in v[a] (a = 0..15).  1024 = 16 x 4 x 16:
+//   A  per lane 16-point DFT over a            -> Y_b[d]          (d = k mod 16)
+//      twiddle W_1024^(b d), transpose through LDS ([d][b], row pitch 68)
+//   B  lane (q = b mod 16, dg): radix-4 over p (b = 16 p + q) for d = 4 dg + i, twiddle W_64^(q s)
+//      transpose through LDS ([16 s + d][q], row pitch 18, read back with ds_read_b128)
+//   C  lane j = 16 s + d: 16-point DFT over q  -> X[64 r + j] in v[r]   (natural order again)
+// Only wave-local LDS hand-offs: no workgroup barrier.  INV = true conjugates every twiddle (unnormalised inverse).
+constexpr int FFT_P1 = 68, FFT_P2 = 18;
+constexpr int FFT_LDS_F2 = 64 * FFT_P2;          // float2 per wave (>= 16 * FFT_P1)
+
+__device__ __forceinline__ void wave_lds_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <bool INV>
-__device__ __forceinline__ void fft1024_stage(const float2* __restrict__ in, float2* __restrict__ out, int Ns,
-                                              const float2* __restrict__ tw, int lane) {
-    const int step = M / (Ns * 4);
+__device__ __forceinline__ float2 twmul(float2 v, float2 w) { return INV ? cmul_conj(v, w) : cmul(v, w); }
+
+// multiply by -i (forward) / +i (inverse)
+template <bool INV>
+__device__ __forceinline__ float2 mul_mi(float2 v) { return INV ? make_float2(-v.y, v.x) : make_float2(v.y, -v.x); }
+
+template <bool INV>
+__device__ __forceinline__ void dft4(float2& x0, float2& x1, float2& x2, float2& x3) {
+    const float2 a = cadd(x0, x2), b = csub(x0, x2), c = cadd(x1, x3), d = mul_mi<INV>(csub(x1, x3));
+    x0 = cadd(a, c); x1 = cadd(b, d); x2 = csub(a, c); x3 = csub(b, d);
+}
+
+// in-register 16-point DFT: out[k1 + 4 k2] from in[4 n1 + n2]
+template <bool INV>
+__device__ __forceinline__ void dft16(float2 (&v)[16]) {
+    // W_16^e = (c, -s) forward
+    constexpr float C1 = 0.92387953251128673848f, S1 = 0.38268343236508978178f, R2 = 0.70710678118654752440f;
+#pragma unroll
+    for (int n2 = 0; n2 < 4; ++n2) dft4<INV>(v[n2], v[4 + n2], v[8 + n2], v[12 + n2]);     // over n1; result index k1 at v[4 k1 + n2]
+    // twiddle W_16^(n2 k1)
+    const float2 w1 = make_float2(C1, -S1), w2 = make_float2(R2, -R2), w3 = make_float2(S1, -C1);
+    const float2 w6 = make_float2(-R2, -R2), w9 = make_float2(-C1, S1);
+    v[4 * 1 + 1] = twmul<INV>(v[4 * 1 + 1], w1);
+    v[4 * 1 + 2] = twmul<INV>(v[4 * 1 + 2], w2);
+    v[4 * 1 + 3] = twmul<INV>(v[4 * 1 + 3], w3);
+    v[4 * 2 + 1] = twmul<INV>(v[4 * 2 + 1], w2);
+    v[4 * 2 + 2] = mul_mi<INV>(v[4 * 2 + 2]);                                                // W_16^4 = -i
+    v[4 * 2 + 3] = twmul<INV>(v[4 * 2 + 3], w6);
+    v[4 * 3 + 1] = twmul<INV>(v[4 * 3 + 1], w3);
+    v[4 * 3 + 2] = twmul<INV>(v[4 * 3 + 2], w6);
+    v[4 * 3 + 3] = twmul<INV>(v[4 * 3 + 3], w9);
+    // over n2 for each k1: inputs v[4 k1 + n2] -> outputs k = k1 + 4 k2
+    float2 o[16];
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) {
+        float2 a = v[4 * k1 + 0], b = v[4 * k1 + 1], c = v[4 * k1 + 2], d = v[4 * k1 + 3];
+        dft4<INV>(a, b, c, d);
+        o[k1] = a; o[k1 + 4] = b; o[k1 + 8] = c; o[k1 + 12] = d;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = o[k];
+}
+
+template <bool INV>
+__device__ __forceinline__ void fft1024_wave(float2 (&v)[16], float2* lds, const float2* __restrict__ tw, int lane) {
+    // ---- A
+    dft16<INV>(v);
+#pragma unroll
+    for (int d = 1; d < 16; ++d) v[d] = twmul<INV>(v[d], tw[lane * d]);
+    wave_lds_sync();
+#pragma unroll
+    for (int d = 0; d < 16; ++d) lds[d * FFT_P1 + lane] = v[d];
+    wave_lds_sync();
+    // ---- B : lane (q, dg) handles d = 4 dg + i, i = 0..3
+    const int q = lane & 15, dg = lane >> 4;
+    float2 u[16];                                   // u[4 i + s]
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int j = lane + 64 * i;
-        const int k = j & (Ns - 1);
-        float2 v0 = in[j], v1 = in[j + 256], v2 = in[j + 512], v3 = in[j + 768];
-        if (Ns > 1) {
-            const float2 w1 = tw[k * step], w2 = tw[2 * k * step], w3 = tw[3 * k * step];
-            if (INV) { v1 = cmul_conj(v1, w1); v2 = cmul_conj(v2, w2); v3 = cmul_conj(v3, w3); }
-            else     { v1 = cmul(v1, w1);      v2 = cmul(v2, w2);      v3 = cmul(v3, w3); }
-        }
-        const float2 a = cadd(v0, v2), b = csub(v0, v2), c = cadd(v1, v3), d = csub(v1, v3);
-        // forward: -i*d = (d.y, -d.x); inverse: +i*d = (-d.y, d.x)
-        const float2 id = INV ? make_float2(-d.y, d.x) : make_float2(d.y, -d.x);
-        const int j0 = ((j - k) << 2) + k;
-        out[j0] = cadd(a, c);
-        out[j0 + Ns] = cadd(b, id);
-        out[j0 + 2 * Ns] = csub(a, c);
-        out[j0 + 3 * Ns] = csub(b, id);
+        const float2* row = lds + (4 * dg + i) * FFT_P1 + q;
+        float2 z0 = row[0], z1 = row[16], z2 = row[32], z3 = row[48];
+        dft4<INV>(z0, z1, z2, z3);
+        u[4 * i + 0] = z0; u[4 * i + 1] = z1; u[4 * i + 2] = z2; u[4 * i + 3] = z3;
     }
+    {
+        const float2 t1 = tw[16 * q], t2 = tw[32 * q], t3 = tw[48 * q];       // W_64^(q s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u[4 * i + 1] = twmul<INV>(u[4 * i + 1], t1);
+            u[4 * i + 2] = twmul<INV>(u[4 * i + 2], t2);
+            u[4 * i + 3] = twmul<INV>(u[4 * i + 3], t3);
+        }
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int sx = 0; sx < 4; ++sx) lds[(16 * sx + 4 * dg + i) * FFT_P2 + q] = u[4 * i + sx];
+    wave_lds_sync();
+    // ---- C : lane j = 16 s + d reads its 16 q values (two per ds_read_b128)
+    {
+        const float4* row = reinterpret_cast<const float4*>(lds + lane * FFT_P2);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float4 t = row[k];
+            v[2 * k] = make_float2(t.x, t.y);
+            v[2 * k + 1] = make_float2(t.z, t.w);
+        }
+    }
+    dft16<INV>(v);
 }
 
-template <bool INV>
-__device__ __forceinline__ float2* fft1024(float2* buf0, float2* buf1, const float2* tw, int lane) {
-    __syncthreads();
-    fft1024_stage<INV>(buf0, buf1, 1, tw, lane);   __syncthreads();
-    fft1024_stage<INV>(buf1, buf0, 4, tw, lane);   __syncthreads();
-    fft1024_stage<INV>(buf0, buf1, 16, tw, lane);  __syncthreads();
-    fft1024_stage<INV>(buf1, buf0, 64, tw, lane);  __syncthreads();
-    fft1024_stage<INV>(buf0, buf1, 256, tw, lane); __syncthreads();
-    return buf1;
-}
-
-// forward band kernel: grid (ceil(F/4), Q)
+// forward band kernel: grid (ceil(F/4), Q); one wave per bin
 template <bool COMPLEX_OUT>
 __global__ __launch_bounds__(256) void k_band_fwd(const float2* __restrict__ X, float* __restrict__ out,
                                                   const int4* __restrict__ bin_tab, const float* __restrict__ window,
                                                   const float2* __restrict__ tw1024, int F, int n_blocks) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2* tw = reinterpret_cast<float2*>(smem);
+    __shared__ __attribute__((aligned(16))) float2 lds_all[4 * FFT_LDS_F2];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    float2* buf0 = tw + M + wave * 2 * M;
-    float2* buf1 = buf0 + M;
     const long q = blockIdx.y;
     const int bin = blockIdx.x * 4 + wave;
-    const bool live = bin < F;
-    for (int i = tid; i < M; i += 256) tw[i] = tw1024[i];
+    if (bin >= F) return;                            // wave-uniform; no workgroup barrier below
+    float2* lds = lds_all + wave * FFT_LDS_F2;
+    const int4 bt = bin_tab[bin];                    // {spec_start, pad, length, win_off}
+    const float2* x = X + q * XPAD + bt.x;
+    const float* w = window + bt.w;
+    float2 v[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) buf0[lane + 64 * i] = make_float2(0.f, 0.f);
-    __syncthreads();
-    if (live) {
-        const int4 bt = bin_tab[bin];                 // {spec_start, pad, length, win_off}
-        const float2* x = X + q * XPAD + bt.x;
-        const float* w = window + bt.w;
-        for (int m = lane; m < bt.z; m += 64) {
-            const float2 v = x[m];
+    for (int a = 0; a < 16; ++a) {
+        const int m = 64 * a + lane - bt.y;          // index inside the window
+        float2 val = make_float2(0.f, 0.f);
+        if (m >= 0 && m < bt.z) {
+            const float2 xv = x[m];
             const float g = w[m];
-            buf0[bt.y + m] = make_float2(v.x * g, v.y * g);
+            val = make_float2(xv.x * g, xv.y * g);
         }
+        v[a] = val;
     }
-    float2* res = fft1024<true>(buf0, buf1, tw, lane);
-    if (!live) return;
+    fft1024_wave<true>(v, lds, tw1024, lane);
     const float inv = 1.0f / (float)M;
     const long b = q / n_blocks, blk = q - b * n_blocks;
     const long Tt = (long)n_blocks * M;
     if (COMPLEX_OUT) {
         float2* o = reinterpret_cast<float2*>(out) + (b * F + bin) * Tt + blk * M;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float2 v = res[lane + 64 * i];
-            o[lane + 64 * i] = make_float2(v.x * inv, v.y * inv);
-        }
+        for (int r = 0; r < 16; ++r) o[64 * r + lane] = make_float2(v[r].x * inv, v[r].y * inv);
     } else {
         float* ore = out + ((b * 2 + 0) * F + bin) * Tt + blk * M;
         float* oim = out + ((b * 2 + 1) * F + bin) * Tt + blk * M;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float2 v = res[lane + 64 * i];
-            ore[lane + 64 * i] = v.x * inv;
-            oim[lane + 64 * i] = v.y * inv;
+        for (int r = 0; r < 16; ++r) {
+            ore[64 * r + lane] = v[r].x * inv;
+            oim[64 * r + lane] = v[r].y * inv;
         }
     }
 }
@@ -301,38 +412,36 @@ template <bool COMPLEX_IN>
 __global__ __launch_bounds__(256) void k_band_inv(const float* __restrict__ coeffs, float2* __restrict__ S,
                                                   const int4* __restrict__ bin_tab, const float* __restrict__ dual,
                                                   const float2* __restrict__ tw1024, int F, int n_blocks, int sum_len) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2* tw = reinterpret_cast<float2*>(smem);
+    __shared__ __attribute__((aligned(16))) float2 lds_all[4 * FFT_LDS_F2];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    float2* buf0 = tw + M + wave * 2 * M;
-    float2* buf1 = buf0 + M;
     const long q = blockIdx.y;
     const int bin = blockIdx.x * 4 + wave;
-    const bool live = bin < F;
-    for (int i = tid; i < M; i += 256) tw[i] = tw1024[i];
+    if (bin >= F) return;
+    float2* lds = lds_all + wave * FFT_LDS_F2;
     const long b = q / n_blocks, blk = q - b * n_blocks;
     const long Tt = (long)n_blocks * M;
-    if (live) {
-        if (COMPLEX_IN) {
-            const float2* c = reinterpret_cast<const float2*>(coeffs) + (b * F + bin) * Tt + blk * M;
+    float2 v[16];
+    if (COMPLEX_IN) {
+        const float2* c = reinterpret_cast<const float2*>(coeffs) + (b * F + bin) * Tt + blk * M;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) buf0[lane + 64 * i] = c[lane + 64 * i];
-        } else {
-            const float* cre = coeffs + ((b * 2 + 0) * F + bin) * Tt + blk * M;
-            const float* cim = coeffs + ((b * 2 + 1) * F + bin) * Tt + blk * M;
+        for (int a = 0; a < 16; ++a) v[a] = c[64 * a + lane];
+    } else {
+        const float* cre = coeffs + ((b * 2 + 0) * F + bin) * Tt + blk * M;
+        const float* cim = coeffs + ((b * 2 + 1) * F + bin) * Tt + blk * M;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) buf0[lane + 64 * i] = make_float2(cre[lane + 64 * i], cim[lane + 64 * i]);
-        }
+        for (int a = 0; a < 16; ++a) v[a] = make_float2(cre[64 * a + lane], cim[64 * a + lane]);
     }
-    float2* res = fft1024<false>(buf0, buf1, tw, lane);
-    if (!live) return;
+    fft1024_wave<false>(v, lds, tw1024, lane);
     const int4 bt = bin_tab[bin];
     float2* s = S + q * sum_len + bt.w;
-    const float* d = dual + bt.w;
-    for (int m = lane; m < bt.z; m += 64) {
-        const float2 v = res[bt.y + m];
-        const float g = d[m];
-        s[m] = make_float2(v.x * g, v.y * g);
+    const float* dl = dual + bt.w;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = 64 * r + lane - bt.y;
+        if (m >= 0 && m < bt.z) {
+            const float g = dl[m];
+            s[m] = make_float2(v[r].x * g, v[r].y * g);
+        }
     }
 }
 
@@ -358,18 +467,14 @@ __global__ __launch_bounds__(256) void k_spec_gather(const float2* __restrict__ 
     Zc[q * NC + k] = make_float2(e.x - o.y, -(e.y + o.x));
 }
 
-__global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ x, unsigned* __restrict__ out, long n) {
-    float m = 0.f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));   // m >= 0: uint order == float order
-}
-
 __global__ __launch_bounds__(256) void k_scale_by_max(float* __restrict__ x, const unsigned* __restrict__ mx, long n) {
     const float m = __uint_as_float(*mx);
     if (!(m > 0.f)) return;                                            // cqtwrapper.py:209 guard
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) x[i] = x[i] / m;
+    float2* x2 = reinterpret_cast<float2*>(x);                          // n is even (pairs of samples)
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n / 2; i += (long)gridDim.x * 256) {
+        float2 v = x2[i];
+        x2[i] = make_float2(v.x / m, v.y / m);
+    }
 }
 
 struct Scratch {
@@ -390,7 +495,6 @@ inline Scratch carve(void* base, int Q, int sum_len) {
 }
 
 constexpr int LDS_ROWS = (2 * ROWS * N1 + N1) * 8;    // 81,000 B
-constexpr int LDS_BAND = (M + 4 * 2 * M) * 8;         // 73,728 B
 
 }  // namespace
 
@@ -404,10 +508,6 @@ static int cqt_set_attrs() {
     static bool done = false;
     if (done) return 0;
     TT_HIP(hipFuncSetAttribute((const void*)k_fft675_rows, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ROWS));
-    TT_HIP(hipFuncSetAttribute((const void*)k_band_fwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BAND));
-    TT_HIP(hipFuncSetAttribute((const void*)k_band_fwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BAND));
-    TT_HIP(hipFuncSetAttribute((const void*)k_band_inv<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BAND));
-    TT_HIP(hipFuncSetAttribute((const void*)k_band_inv<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BAND));
     done = true;
     return 0;
 }
@@ -426,15 +526,16 @@ extern "C" int tt_cqt_forward(const tt_cqt_plan* plan, const float* audio, float
                        reinterpret_cast<const float2*>(plan->tw675), reinterpret_cast<const float2*>(plan->twNc));
     TT_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_fft49_cols<0>, dim3(NTILES, Q), dim3(256), 0, st, s.A, s.X,
-                       reinterpret_cast<const float2*>(plan->tw49), reinterpret_cast<const float2*>(plan->twN));
+                       reinterpret_cast<const float2*>(plan->tw49), reinterpret_cast<const float2*>(plan->twN),
+                       (unsigned*)nullptr);
     TT_LAUNCH_CHECK();
     dim3 grid((F + 3) / 4, Q);
     if (out_complex)
-        hipLaunchKernelGGL(k_band_fwd<true>, grid, dim3(256), LDS_BAND, st, s.X, out,
+        hipLaunchKernelGGL(k_band_fwd<true>, grid, dim3(256), 0, st, s.X, out,
                            reinterpret_cast<const int4*>(plan->bin_tab), plan->window,
                            reinterpret_cast<const float2*>(plan->tw1024), F, n_blocks);
     else
-        hipLaunchKernelGGL(k_band_fwd<false>, grid, dim3(256), LDS_BAND, st, s.X, out,
+        hipLaunchKernelGGL(k_band_fwd<false>, grid, dim3(256), 0, st, s.X, out,
                            reinterpret_cast<const int4*>(plan->bin_tab), plan->window,
                            reinterpret_cast<const float2*>(plan->tw1024), F, n_blocks);
     TT_LAUNCH_CHECK();
@@ -451,11 +552,11 @@ extern "C" int tt_cqt_inverse(const tt_cqt_plan* plan, const float* coeffs, floa
     Scratch s = carve(scratch, Q, plan->sum_len);
     dim3 grid((F + 3) / 4, Q);
     if (in_complex)
-        hipLaunchKernelGGL(k_band_inv<true>, grid, dim3(256), LDS_BAND, st, coeffs, s.S,
+        hipLaunchKernelGGL(k_band_inv<true>, grid, dim3(256), 0, st, coeffs, s.S,
                            reinterpret_cast<const int4*>(plan->bin_tab), plan->dual,
                            reinterpret_cast<const float2*>(plan->tw1024), F, n_blocks, plan->sum_len);
     else
-        hipLaunchKernelGGL(k_band_inv<false>, grid, dim3(256), LDS_BAND, st, coeffs, s.S,
+        hipLaunchKernelGGL(k_band_inv<false>, grid, dim3(256), 0, st, coeffs, s.S,
                            reinterpret_cast<const int4*>(plan->bin_tab), plan->dual,
                            reinterpret_cast<const float2*>(plan->tw1024), F, n_blocks, plan->sum_len);
     TT_LAUNCH_CHECK();
@@ -466,14 +567,13 @@ extern "C" int tt_cqt_inverse(const tt_cqt_plan* plan, const float* coeffs, floa
     hipLaunchKernelGGL(k_fft675_rows, dim3(N2 / ROWS, Q), dim3(256), LDS_ROWS, st, Zc, s.A,
                        reinterpret_cast<const float2*>(plan->tw675), reinterpret_cast<const float2*>(plan->twNc));
     TT_LAUNCH_CHECK();
+    if (normalize) TT_HIP(hipMemsetAsync(s.mx, 0, 4, st));
     hipLaunchKernelGGL(k_fft49_cols<1>, dim3(NTILES, Q), dim3(256), 0, st, s.A, reinterpret_cast<float2*>(audio),
-                       reinterpret_cast<const float2*>(plan->tw49), reinterpret_cast<const float2*>(plan->twN));
+                       reinterpret_cast<const float2*>(plan->tw49), reinterpret_cast<const float2*>(plan->twN),
+                       normalize ? s.mx : (unsigned*)nullptr);
     TT_LAUNCH_CHECK();
     if (normalize) {
         const long n = (long)Q * 2 * NC;
-        TT_HIP(hipMemsetAsync(s.mx, 0, 4, st));
-        hipLaunchKernelGGL(k_absmax, dim3(1024), dim3(256), 0, st, audio, s.mx, n);
-        TT_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_scale_by_max, dim3(2048), dim3(256), 0, st, audio, s.mx, n);
         TT_LAUNCH_CHECK();
     }

@@ -43,7 +43,8 @@ def main():
             w2 = torch.randn(C, C, 1, 1, device=dev) * 0.1
             b2 = torch.randn(C, device=dev) * 0.1
             if 'rb_fwd' in which or 'all' in which:
-                ms = timeit(lambda: ops.ResBlockFn.apply(x, w1, b1, w2, b2, d))
+                xg = x.clone().requires_grad_(True)          # training forward: the hidden activation is written too
+                ms = timeit(lambda: ops.ResBlockFn.apply(xg, w1, b1, w2, b2, d))
                 fl = 2.0 * 10 * C * C * px
                 print('rb_fwd  C=%2d d=%d  %7.3f ms  %6.1f TFLOP/s  %6.0f GB/s(alg)' % (C, d, ms, fl / ms / 1e9, 2 * 4 * C * px / ms / 1e6))
             if 'rb_bwd' in which or 'all' in which:

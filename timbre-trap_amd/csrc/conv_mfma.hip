@@ -883,6 +883,30 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
     dw[a * s_a + ((long)blockIdx.y * CBS + bl) * s_b + tap * s_t] += (s0 + s1) + (s2 + s3);
 }
 
+// g = dy * ELU'(y) written out AND out[c] += sum of g over (b, h, t): the gate pre-pass of the strided layers also
+// produces the bias gradient, so no separate channel-sum pass is needed.  grid (C, chunks).
+__global__ __launch_bounds__(256) void k_gate_and_sum(const float* __restrict__ dy, const float* __restrict__ y,
+                                                      float* __restrict__ g, float* __restrict__ out, int B, int C, long inner) {
+    __shared__ float red[4];
+    const int c = blockIdx.x;
+    float acc = 0.f;
+    const long inner4 = inner >> 2;                       // inner % 4 == 0 on this path (T % 4 == 0)
+    const long total = (long)B * inner4;
+    for (long i = (long)blockIdx.y * 256 + threadIdx.x; i < total; i += (long)gridDim.y * 256) {
+        const long b = i / inner4, r = i - b * inner4;
+        const long o = ((b * C + c) * inner >> 2) + r;
+        const float4 d = reinterpret_cast<const float4*>(dy)[o], v = reinterpret_cast<const float4*>(y)[o];
+        const float4 q = make_float4(d.x * elu_grad_from_out(v.x), d.y * elu_grad_from_out(v.y), d.z * elu_grad_from_out(v.z),
+                                     d.w * elu_grad_from_out(v.w));
+        reinterpret_cast<float4*>(g)[o] = q;
+        acc += (q.x + q.y) + (q.z + q.w);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0 && out) atomicAdd(out + c, red[0] + red[1] + red[2] + red[3]);
+}
+
 // out[c] += sum over (b, h, t) of dy * ELU'(y)   (bias gradient of a conv + ELU layer)
 __global__ __launch_bounds__(256) void k_gated_channel_sum(const float* __restrict__ dy, const float* __restrict__ y,
                                                            float* __restrict__ out, int B, int C, long inner) {
@@ -1063,6 +1087,13 @@ int rb_wgrad_only(const float* x, float* dw1, float* ws, int B, int H, int T, hi
 
 extern "C" int64_t tt_wgrad_scratch_floats(void);
 
+inline int gate_chunks(int B, long inner, int C) {
+    long chunks = ((long)B * (inner >> 2) + 256L * 8 - 1) / (256L * 8);
+    const long cap = 8192 / C;
+    if (chunks > cap) chunks = cap;
+    return chunks < 1 ? 1 : (int)chunks;
+}
+
 // strided pair: channel counts (C -> 2C)
 template <int C>
 int sconv_fwd(const float* x, const float* w, const float* b, float* y, int B, int H, int Hout, int T, hipStream_t st) {
@@ -1079,11 +1110,13 @@ int sconv_bwd(const float* x, const float* y, const float* dy, const float* w, f
     const long ng = (long)B * 2 * C * Hout * T;
     float* g = scratch + tt_wgrad_scratch_floats();
     if (dma_ok(x, T) && dma_ok(dy, T) && dma_ok(g, T)) {
-        rc = tt_elu_bwd(dy, y, g, ng, st);
-        if (rc) return rc;
+        (void)ng;
+        hipLaunchKernelGGL(k_gate_and_sum, dim3(2 * C, gate_chunks(B, (long)Hout * T, 2 * C)), dim3(256), 0, st, dy, y, g, db, B,
+                           2 * C, (long)Hout * T);
+        TT_LAUNCH_CHECK();
         if (dx) rc = launch_conv<2 * C, C, Up4, false>(g, nullptr, w, WSpec{4, (long)C * 4, 1, 0}, nullptr, nullptr, dx, B, Hout, H, T, TT_ACT_NONE, st);
         if (rc) return rc;
-        return launch_wgrad<2 * C, C, WStr<(C <= 8 ? 8 : 4)>, false, false>(g, nullptr, x, nullptr, dw, db, (long)C * 4, 4, 1, scratch, B, Hout, H, T, st);
+        return launch_wgrad<2 * C, C, WStr<(C <= 8 ? 8 : 4)>, false, false>(g, nullptr, x, nullptr, dw, nullptr, (long)C * 4, 4, 1, scratch, B, Hout, H, T, st);
     }
     if (dx)   // dx[c][r] = sum_{a, kh: r = 2ho + kh} w[a][c][kh] * g[a][ho],  g = dy * ELU'(y)
         rc = launch_conv<2 * C, C, Up4, true>(dy, y, w, WSpec{4, (long)C * 4, 1, 0}, nullptr, nullptr, dx, B, Hout, H, T, TT_ACT_NONE, st);
@@ -1104,14 +1137,13 @@ int tconv_bwd(const float* x, const float* y, const float* dy, const float* w, f
     float* g = scratch + tt_wgrad_scratch_floats();
     const bool dma = dma_ok(x, T) && dma_ok(dy, T) && dma_ok(g, T);
     if (dma) {
-        rc = tt_elu_bwd(dy, y, g, ng, st);
-        if (rc) return rc;
+        (void)ng;
+        hipLaunchKernelGGL(k_gate_and_sum, dim3(C, gate_chunks(B, (long)Hout * T, C)), dim3(256), 0, st, dy, y, g, db, B, C,
+                           (long)Hout * T);
+        TT_LAUNCH_CHECK();
         if (dx) rc = launch_conv<C, 2 * C, Down4, false>(g, nullptr, w, WSpec{(long)C * 4, 4, 1, 0}, nullptr, nullptr, dx, B, Hout, H, T, TT_ACT_NONE, st);
         if (rc) return rc;
-        rc = launch_wgrad<2 * C, C, WStr<(C <= 8 ? 8 : 4)>, false, false>(x, nullptr, g, nullptr, dw, nullptr, (long)C * 4, 4, 1, scratch, B, H, Hout, T, st);
-        if (rc) return rc;
-        if (db) rc = tt_channel_sum(g, db, B, C, (long)Hout * T, st);
-        return rc;
+        return launch_wgrad<2 * C, C, WStr<(C <= 8 ? 8 : 4)>, false, false>(x, nullptr, g, nullptr, dw, nullptr, (long)C * 4, 4, 1, scratch, B, H, Hout, T, st);
     }
     if (dx)   // dx[a][h] = sum_{m,kh} w[a][m][kh] g[m][2h+kh]
         rc = launch_conv<C, 2 * C, Down4, true>(dy, y, w, WSpec{(long)C * 4, 4, 1, 0}, nullptr, nullptr, dx, B, Hout, H, T, TT_ACT_NONE, st);

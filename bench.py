@@ -154,11 +154,15 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='clips per GPU')
     ap.add_argument('--mc', type=int, default=2)
     ap.add_argument('--latent', type=int, default=128)
+    ap.add_argument('--precision', choices=('fp32', 'bf16'), default=os.environ.get('TTRAP_PRECISION', 'fp32'),
+                    help='operands of the wide 3x3 convs on the matrix cores: fp32 = exact (default), bf16 = rounded operands, fp32 accumulation')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
     from timbre_trap import _hip
+    from timbre_trap.framework import ops
     from timbre_trap.utils import FusedAdamW, init_process_group_from_env
+    ops.PRECISION = args.precision
     from timbre_trap.utils.distributed import broadcast_parameters
     import torch.distributed as dist
 
@@ -214,7 +218,7 @@ def main():
             # (FETCH_SIZE x2 per the gfx950 guide + WRITE_SIZE); only valid for the shape it was measured on
             traffic = None
             pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_rb_fwd_C32.json')
-            if C == 32 and args.batch == 64 and os.path.exists(pmc):
+            if C == 32 and args.batch == 64 and args.precision == 'fp32' and os.path.exists(pmc):
                 traffic = json.load(open(pmc))['traffic_bytes_corrected']
             roof = dict(kernel='k_rb_fwd<%d,D> (fused ResidualConv2dBlock forward, C=%d, H=65; same MFMA main loop as the '
                                'data-gradient kernel k_conv_mfma)' % (C, C),
@@ -233,7 +237,7 @@ def main():
             base = cpu_baseline(args.mc, args.latent)
         line = dict(metric='audio-seconds/s training throughput (9oct x 60bpo, 3s@22.05kHz)', value=value,
                     unit='audio-seconds/s', n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms,
-                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype=('f32' if args.precision == 'fp32' else 'bf16'), data='synthetic',
                     config=dict(workload='full train step (CQT x2 + AE fwd/bwd with consistency + 3 losses + clip + AdamW), '
                                          'model_complexity=%d latent=%d, %d clips x 3 s per GPU' % (args.mc, args.latent, args.batch),
                                 global_batch=world * args.batch, parallelism='dp%d' % world),

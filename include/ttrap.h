@@ -28,6 +28,10 @@ extern "C" {
 #define TT_E_BADARG      (-1)
 #define TT_E_UNSUPPORTED (-2)
 
+/* flags of tt_resblock_fwd / tt_resblock_bwd: round the operands of the 3x3 convolutions and of dW1 to bf16 for the
+ * matrix cores (v_mfma_f32_16x16x32_bf16, fp32 accumulation, fp32 tensors in HBM) at C >= 16.  Default 0 = exact fp32. */
+#define TT_FLAG_BF16_OPERANDS 1
+
 #define TT_ACT_NONE 0
 #define TT_ACT_ELU  1
 
@@ -125,7 +129,7 @@ int64_t tt_wgrad_scratch_floats(void);
 
 int tt_resblock_fwd(const float* x, const float* w1, const float* b1, const float* w2,
                     const float* b2, float* y, float* h1, int B, int C, int H, int T, int dilation,
-                    void* stream);
+                    int flags, void* stream);
 
 /* Fused ResidualConv2dBlock backward.  h1 = the hidden activation saved by tt_resblock_fwd, or NULL to
  * recompute it from x (one more 3x3 convolution, half the saved-activation memory):
@@ -135,7 +139,7 @@ int tt_resblock_fwd(const float* x, const float* w1, const float* b1, const floa
 int tt_resblock_bwd(const float* x, const float* h1, const float* dy, const float* w1, const float* b1,
                     const float* w2, const float* b2, float* dx, float* dw1, float* db1,
                     float* dw2, float* db2, float* ws, int B, int C, int H, int T, int dilation,
-                    void* stream);
+                    int flags, void* stream);
 
 /* EncoderBlock.sconv (modules.py:626-630): y = ELU(Conv2d(C, 2C, (4,1), stride (2,1))(x) + b).
  * x (B,C,H,T) -> y (B,2C,(H-4)/2+1,T); w (2C,C,4,1).  Supported C: 4,8,16,32. */

@@ -35,6 +35,19 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// bf16-operand mode (flags bit 0 of the resblock entry points): v_mfma_f32_16x16x32_bf16, fp32 accumulate.
+//   A fragment lane l : 8 consecutive k (k = 8 (l>>4) + j) of row l&15 ;  B fragment: the same k of column l&15.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 mfma16_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ bf16x8 pack_bf16(const float (&v)[8]) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (__bf16)v[j];
+    return r;
+}
+
 constexpr int plane_pad(int n) {
     int p = n;
     while (p % 32 != 17) ++p;
@@ -73,13 +86,13 @@ struct Up4 {        // out row r <- in rows (r - kh)/2, kh = (r&1) + 2j, j = 0,1
 // instruction, destination linear in LDS).  Rows then start 16-byte aligned at t0 - HL (HL = 4 when the geometry has a
 // column halo) and are XCP = 64 (+8) floats wide, planes are exactly XR*XCP floats apart.  DMA = false: the register
 // staged tile (any T, optional ELU' gating while staging) with the 17-mod-32 plane pitch.
-template <int CIN, int COUT, class P, bool DMA>
+template <int CIN, int COUT, class P, bool DMA, bool BF16 = false>
 struct Geo {
     static constexpr int MT = (COUT + 15) / 16;
     static constexpr int CP = MT * 16;                       // weight image row pitch (floats)
     static constexpr bool SWZ = CP >= 32;
     // channels per staged chunk: DMA costs no registers, so mid-width layers move 8 channels per round trip
-    static constexpr int CC = (DMA && CIN >= 8 && CIN <= 16) ? 8 : 4;
+    static constexpr int CC = BF16 ? 4 : ((DMA && CIN >= 8 && CIN <= 16) ? 8 : 4);
     static constexpr int NCH = CIN / CC;
     static constexpr int HL = DMA ? (P::CH > 0 ? 4 : 0) : P::CH;
     static constexpr int XCP = DMA ? (P::CH > 0 ? TW + 8 : TW) : P::XC;
@@ -90,7 +103,10 @@ struct Geo {
     static constexpr int NPIECE = (NQ + 63) / 64;            // wave-wide DMA instructions per chunk
     static constexpr int BUF = DMA ? NPIECE * 256 : CC * PLANE;
     static constexpr int KW = P::NWT * CIN;                  // rows of the weight image
-    static constexpr int W_FLOATS = KW * CP;
+    // bf16 weight image of the 3x3 geometry: per 4-channel chunk two K=32 blocks (taps 0..7, then tap 8 + zeros),
+    // [chunk][block][lane group g][co][8] bf16 -> one ds_read_b128 per A fragment.  Size in float units.
+    static constexpr int WBF_FLOATS = (CIN / 4) * 2 * 4 * CP * 8 / 2;
+    static constexpr int W_FLOATS = BF16 ? WBF_FLOATS : KW * CP;
     static constexpr int XS_FLOATS = 2 * BUF;
 };
 
@@ -123,12 +139,32 @@ __device__ __forceinline__ void build_weight_image(float* img, const float* __re
     }
 }
 
+// bf16 image (3x3 geometry only): slot (chunk c4, block m, group g, co, j) holds W(co, ci = 4 c4 + (j & 3), tap = 8 m + 2 g + (j >> 2))
+template <int CIN, int COUT>
+__device__ __forceinline__ void build_weight_image_bf16(__bf16* img, const float* __restrict__ w, long s_m, long s_c, long s_t,
+                                                        long w_off, int tid) {
+    constexpr int CP = ((COUT + 15) / 16) * 16;
+    constexpr int TOTAL = (CIN / 4) * 2 * 4 * CP * 8;
+    for (int i = tid; i < TOTAL; i += NTHREADS) {
+        const int j = i & 7;
+        int r = i >> 3;
+        const int co = r % CP; r /= CP;
+        const int g = r & 3; r >>= 2;
+        const int m = r & 1; const int c4 = r >> 1;
+        const int tap = 8 * m + 2 * g + (j >> 2), ci = 4 * c4 + (j & 3);
+        float v = 0.f;
+        if (co < COUT && tap < 9) v = w[w_off + co * s_m + ci * s_c + tap * s_t];
+        img[i] = (__bf16)v;
+    }
+}
+
 // The pipelined implicit-GEMM main loop over the tiles of one workgroup.  `epi(tile, acc)` consumes a finished tile.
-template <int CIN, int COUT, class P, bool GATE, bool DMA, class Epi>
+template <int CIN, int COUT, class P, bool GATE, bool DMA, bool BF16, class Epi>
 __device__ __forceinline__ void conv_mainloop(const float* __restrict__ x, const float* __restrict__ gy, const float* Wimg,
                                               float* xs, int B, int Hin, int Hout, int T, Epi&& epi) {
     static_assert(!(GATE && DMA), "gated staging needs the register path");
-    using G = Geo<CIN, COUT, P, DMA>;
+    static_assert(!BF16 || (DMA && P::NTAPS == 9), "bf16 operands: 3x3 geometry on the DMA path");
+    using G = Geo<CIN, COUT, P, DMA, BF16>;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     const int tiles_h = (Hout + TH - 1) / TH, tiles_t = (T + TW - 1) / TW;
     const int ntiles = B * tiles_h * tiles_t;
@@ -227,6 +263,34 @@ __device__ __forceinline__ void conv_mainloop(const float* __restrict__ x, const
             }
             const float* xb = xs + buf * G::BUF;
             const int c0 = chunk * G::CC;
+            if constexpr (BF16) {
+                // K = 32 = 8 taps x 4 channels: lane group g supplies taps 2g, 2g+1 (block 0) / tap 8 (block 1, g = 0 only)
+                const __bf16* wimg = reinterpret_cast<const __bf16*>(Wimg);
+                const float* pa = xb + P::lrow(2 * g, wave) * G::XCP + (G::HL - P::CH) + P::lcol(2 * g) + l15;
+                const float* pb = xb + P::lrow(2 * g + 1, wave) * G::XCP + (G::HL - P::CH) + P::lcol(2 * g + 1) + l15;
+                const float* p8 = xb + P::lrow(8, wave) * G::XCP + (G::HL - P::CH) + P::lcol(8) + l15;
+                bf16x8 a0[G::MT], a1[G::MT];
+#pragma unroll
+                for (int mt = 0; mt < G::MT; ++mt) {
+                    a0[mt] = *reinterpret_cast<const bf16x8*>(wimg + ((((chunk * 2 + 0) * 4 + g) * G::CP) + mt * 16 + l15) * 8);
+                    a1[mt] = *reinterpret_cast<const bf16x8*>(wimg + ((((chunk * 2 + 1) * 4 + g) * G::CP) + mt * 16 + l15) * 8);
+                }
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v[j] = pa[j * G::PLANE + nt * 16]; v[4 + j] = pb[j * G::PLANE + nt * 16]; }
+                    const bf16x8 b0 = pack_bf16(v);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v[j] = (g == 0) ? p8[j * G::PLANE + nt * 16] : 0.f; v[4 + j] = 0.f; }
+                    const bf16x8 b1 = pack_bf16(v);
+#pragma unroll
+                    for (int mt = 0; mt < G::MT; ++mt) {
+                        acc[mt][nt] = mfma16_bf16(a0[mt], b0, acc[mt][nt]);
+                        acc[mt][nt] = mfma16_bf16(a1[mt], b1, acc[mt][nt]);
+                    }
+                }
+            } else {
 #pragma unroll 1
             for (int tp = 0; tp < P::NTAPS; ++tp) {
                 const int wt = P::wtap(tp, wave);
@@ -246,6 +310,7 @@ __device__ __forceinline__ void conv_mainloop(const float* __restrict__ x, const
                     }
                 }
             }
+            }
             buf ^= 1;
         }
         epi(decode_tile(tile, tiles_h, tiles_t), acc);
@@ -255,19 +320,20 @@ __device__ __forceinline__ void conv_mainloop(const float* __restrict__ x, const
 // ---- plain convolution kernel: out = act(conv + bias) + res -----------------------------------------------
 struct WSpec { long s_m, s_c, s_t, off; };
 
-template <int CIN, int COUT, class P, bool GATE, bool DMA>
+template <int CIN, int COUT, class P, bool GATE, bool DMA, bool BF16>
 __global__ __launch_bounds__(NTHREADS, 4) void k_conv_mfma(const float* __restrict__ x, const float* __restrict__ gy,
                                                         const float* __restrict__ w, WSpec ws, const float* __restrict__ bias,
                                                         const float* __restrict__ res, float* __restrict__ y, int B, int Hin,
                                                         int Hout, int T, int act) {
-    using G = Geo<CIN, COUT, P, DMA>;
+    using G = Geo<CIN, COUT, P, DMA, BF16>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xs = lds;                       // DMA destinations first: 16-byte aligned
     float* Wimg = lds + G::XS_FLOATS;
-    build_weight_image<CIN, COUT, P>(Wimg, w, ws.s_m, ws.s_c, ws.s_t, ws.off, threadIdx.x);
+    if constexpr (BF16) build_weight_image_bf16<CIN, COUT>(reinterpret_cast<__bf16*>(Wimg), w, ws.s_m, ws.s_c, ws.s_t, ws.off, threadIdx.x);
+    else build_weight_image<CIN, COUT, P>(Wimg, w, ws.s_m, ws.s_c, ws.s_t, ws.off, threadIdx.x);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, l15 = lane & 15;
     const long oplane = (long)Hout * T;
-    conv_mainloop<CIN, COUT, P, GATE, DMA>(x, gy, Wimg, xs, B, Hin, Hout, T, [&](const Tile& tl, f32x4 (&acc)[G::MT][4]) {
+    conv_mainloop<CIN, COUT, P, GATE, DMA, BF16>(x, gy, Wimg, xs, B, Hin, Hout, T, [&](const Tile& tl, f32x4 (&acc)[G::MT][4]) {
         const int h = tl.h0 + wave;
         if (h >= Hout) return;
 #pragma unroll
@@ -319,13 +385,13 @@ __device__ __forceinline__ void build_w2_images(float* W2s, float* W2t, float* b
     }
 }
 
-template <int C, int D, bool DMA>
+template <int C, int D, bool DMA, bool BF16>
 __global__ __launch_bounds__(NTHREADS, 4) void k_rb_fwd(const float* __restrict__ x, const float* __restrict__ w1,
                                                      const float* __restrict__ b1, const float* __restrict__ w2,
                                                      const float* __restrict__ b2, float* __restrict__ y,
                                                      float* __restrict__ h1out, int B, int H, int T) {
     using P = Res3x3<D>;
-    using G = Geo<C, C, P, DMA>;
+    using G = Geo<C, C, P, DMA, BF16>;
     using R = RB<C>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xs = lds;
@@ -333,11 +399,12 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_rb_fwd(const float* __restrict_
     float* W2s = Wimg + G::W_FLOATS;
     float* b1s = W2s + R::CPAD * R::CP;
     float* b2s = b1s + R::CPAD;
-    build_weight_image<C, C, P>(Wimg, w1, (long)C * 9, 9, 1, 0, threadIdx.x);
+    if constexpr (BF16) build_weight_image_bf16<C, C>(reinterpret_cast<__bf16*>(Wimg), w1, (long)C * 9, 9, 1, 0, threadIdx.x);
+    else build_weight_image<C, C, P>(Wimg, w1, (long)C * 9, 9, 1, 0, threadIdx.x);
     build_w2_images<C>(W2s, nullptr, b1s, b2s, w2, b1, b2, threadIdx.x);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, l15 = lane & 15;
     const long plane = (long)H * T;
-    conv_mainloop<C, C, P, false, DMA>(x, nullptr, Wimg, xs, B, H, H, T, [&](const Tile& tl, f32x4 (&acc)[G::MT][4]) {
+    conv_mainloop<C, C, P, false, DMA, BF16>(x, nullptr, Wimg, xs, B, H, H, T, [&](const Tile& tl, f32x4 (&acc)[G::MT][4]) {
         f32x4 acc2[G::MT][4];
 #pragma unroll
         for (int mt = 0; mt < G::MT; ++mt)
@@ -536,7 +603,7 @@ __global__ __launch_bounds__(NTHREADS) void k_rb_bwd_a(const float* __restrict__
         }
     };
     if (RECOMP) {
-        conv_mainloop<C, C, P, false, DMA>(x, nullptr, Wimg, xs, B, H, H, T, epi);
+        conv_mainloop<C, C, P, false, DMA, false>(x, nullptr, Wimg, xs, B, H, H, T, epi);
     } else {
         const int tiles_h = (H + TH - 1) / TH, tiles_t = (T + TW - 1) / TW;
         const int ntiles = B * tiles_h * tiles_t;
@@ -747,7 +814,7 @@ struct WGeoD {
     static constexpr int Q_FLOATS = NPIECE * 256;
 };
 
-template <int CA, int CB, int CBS, class WP>
+template <int CA, int CB, int CBS, class WP, bool BF16>
 __global__ __launch_bounds__(64 * WP::WTH) void k_wgrad_dma(const float* __restrict__ Pt, const float* __restrict__ Qt,
                                                            float* __restrict__ scratch, float* __restrict__ dbias_p, int B,
                                                            int HP, int HQ, int T) {
@@ -773,7 +840,7 @@ __global__ __launch_bounds__(64 * WP::WTH) void k_wgrad_dma(const float* __restr
         const int tap = n / CBS, bl = n - tap * CBS;
         // WP::qoff is in units of WP::XC columns per row: split it back into (row, col)
         const int qo = WP::qoff(tap), qr = qo / WP::XC, qc = qo - qr * WP::XC;
-        noff[nt] = bl * Q::PLANE + qr * Q::XCP + qc + (Q::HL - WP::CH) + 16 * g;
+        noff[nt] = bl * Q::PLANE + qr * Q::XCP + qc + (Q::HL - WP::CH) + (BF16 ? 8 : 16) * g;
     }
     f32x4 acc[K::MT][K::NTN];
 #pragma unroll
@@ -824,23 +891,49 @@ __global__ __launch_bounds__(64 * WP::WTH) void k_wgrad_dma(const float* __restr
 #pragma unroll 8
             for (int p = 0; p < 64; ++p) bsum += as[lane * 64 + ((((p >> 2) ^ (lane & 15)) << 2) | (p & 3))];
         }
-        // A fragments: pixels 16 g .. 16 g + 15 of channel mt*16 + l15
-        float av[K::MT][16];
-#pragma unroll
-        for (int mt = 0; mt < K::MT; ++mt)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float4 v = *reinterpret_cast<const float4*>(as + (mt * 16 + l15) * 64 + (((4 * g + j) ^ l15) << 2));
-                av[mt][4 * j + 0] = v.x; av[mt][4 * j + 1] = v.y; av[mt][4 * j + 2] = v.z; av[mt][4 * j + 3] = v.w;
-            }
         const float* xrow = xs + WP::qrow_of_wave(wave) * Q::XCP;
+        if constexpr (BF16) {
+            // K = 32 pixels per MFMA: lane group g owns pixels 32 seg + 8 g .. + 7 (two swizzled 16-byte chunks of the P row)
 #pragma unroll
-        for (int sk = 0; sk < 16; ++sk) {
+            for (int seg = 0; seg < 2; ++seg) {
+                bf16x8 av[K::MT];
 #pragma unroll
-            for (int nt = 0; nt < K::NTN; ++nt) {
-                const float bv = xrow[noff[nt] + sk];
+                for (int mt = 0; mt < K::MT; ++mt) {
+                    const float* row = as + (mt * 16 + l15) * 64;
+                    const float4 lo = *reinterpret_cast<const float4*>(row + (((8 * seg + 2 * g) ^ l15) << 2));
+                    const float4 hi = *reinterpret_cast<const float4*>(row + (((8 * seg + 2 * g + 1) ^ l15) << 2));
+                    const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    av[mt] = pack_bf16(v);
+                }
 #pragma unroll
-                for (int mt = 0; mt < K::MT; ++mt) acc[mt][nt] = mfma16(av[mt][sk], bv, acc[mt][nt]);
+                for (int nt = 0; nt < K::NTN; ++nt) {
+                    const float* xp = xrow + noff[nt] + 32 * seg;
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = xp[j];
+                    const bf16x8 bv = pack_bf16(v);
+#pragma unroll
+                    for (int mt = 0; mt < K::MT; ++mt) acc[mt][nt] = mfma16_bf16(av[mt], bv, acc[mt][nt]);
+                }
+            }
+        } else {
+            // A fragments: pixels 16 g .. 16 g + 15 of channel mt*16 + l15
+            float av[K::MT][16];
+#pragma unroll
+            for (int mt = 0; mt < K::MT; ++mt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 v = *reinterpret_cast<const float4*>(as + (mt * 16 + l15) * 64 + (((4 * g + j) ^ l15) << 2));
+                    av[mt][4 * j + 0] = v.x; av[mt][4 * j + 1] = v.y; av[mt][4 * j + 2] = v.z; av[mt][4 * j + 3] = v.w;
+                }
+#pragma unroll
+            for (int sk = 0; sk < 16; ++sk) {
+#pragma unroll
+                for (int nt = 0; nt < K::NTN; ++nt) {
+                    const float bv = xrow[noff[nt] + sk];
+#pragma unroll
+                    for (int mt = 0; mt < K::MT; ++mt) acc[mt][nt] = mfma16(av[mt][sk], bv, acc[mt][nt]);
+                }
             }
         }
     }
@@ -938,17 +1031,17 @@ inline int persistent_grid(int ntiles, int per_cu) {
 }
 inline int ntiles_of(int B, int H, int T) { return B * ((H + TH - 1) / TH) * ((T + TW - 1) / TW); }
 
-template <int CIN, int COUT, class P, bool GATE, bool DMA>
+template <int CIN, int COUT, class P, bool GATE, bool DMA, bool BF16 = false>
 int launch_conv_v(const float* x, const float* gy, const float* w, WSpec ws, const float* bias, const float* res, float* y,
                   int B, int Hin, int Hout, int T, int act, hipStream_t st) {
-    using G = Geo<CIN, COUT, P, DMA>;
+    using G = Geo<CIN, COUT, P, DMA, BF16>;
     constexpr int LDS = (G::W_FLOATS + G::XS_FLOATS) * 4;
     static bool attr = false;
     if (!attr) {
-        TT_HIP(hipFuncSetAttribute((const void*)k_conv_mfma<CIN, COUT, P, GATE, DMA>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        TT_HIP(hipFuncSetAttribute((const void*)k_conv_mfma<CIN, COUT, P, GATE, DMA, BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr = true;
     }
-    hipLaunchKernelGGL((k_conv_mfma<CIN, COUT, P, GATE, DMA>), dim3(persistent_grid(ntiles_of(B, Hout, T), blocks_per_cu(LDS, 2))),
+    hipLaunchKernelGGL((k_conv_mfma<CIN, COUT, P, GATE, DMA, BF16>), dim3(persistent_grid(ntiles_of(B, Hout, T), blocks_per_cu(LDS, 2))),
                        dim3(NTHREADS), LDS, st, x, gy, w, ws, bias, res, y, B, Hin, Hout, T, act);
     TT_LAUNCH_CHECK();
     return 0;
@@ -956,25 +1049,30 @@ int launch_conv_v(const float* x, const float* gy, const float* w, WSpec ws, con
 
 template <int CIN, int COUT, class P, bool GATE>
 int launch_conv(const float* x, const float* gy, const float* w, WSpec ws, const float* bias, const float* res, float* y,
-                int B, int Hin, int Hout, int T, int act, hipStream_t st) {
+                int B, int Hin, int Hout, int T, int act, hipStream_t st, bool bf16 = false) {
     if constexpr (!GATE) {
-        if (dma_ok(x, T)) return launch_conv_v<CIN, COUT, P, false, true>(x, gy, w, ws, bias, res, y, B, Hin, Hout, T, act, st);
+        if (dma_ok(x, T)) {
+            if constexpr (P::NTAPS == 9 && CIN >= 16) {
+                if (bf16) return launch_conv_v<CIN, COUT, P, false, true, true>(x, gy, w, ws, bias, res, y, B, Hin, Hout, T, act, st);
+            }
+            return launch_conv_v<CIN, COUT, P, false, true>(x, gy, w, ws, bias, res, y, B, Hin, Hout, T, act, st);
+        }
     }
     return launch_conv_v<CIN, COUT, P, GATE, false>(x, gy, w, ws, bias, res, y, B, Hin, Hout, T, act, st);
 }
 
-template <int C, int D, bool DMA>
+template <int C, int D, bool DMA, bool BF16 = false>
 int launch_rb_fwd_v(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y, float* h1,
                     int B, int H, int T, hipStream_t st) {
-    using G = Geo<C, C, Res3x3<D>, DMA>;
+    using G = Geo<C, C, Res3x3<D>, DMA, BF16>;
     using R = RB<C>;
     constexpr int LDS = (G::W_FLOATS + R::CPAD * R::CP + 2 * R::CPAD + G::XS_FLOATS) * 4;
     static bool attr = false;
     if (!attr) {
-        TT_HIP(hipFuncSetAttribute((const void*)k_rb_fwd<C, D, DMA>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        TT_HIP(hipFuncSetAttribute((const void*)k_rb_fwd<C, D, DMA, BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr = true;
     }
-    hipLaunchKernelGGL((k_rb_fwd<C, D, DMA>), dim3(persistent_grid(ntiles_of(B, H, T), blocks_per_cu(LDS, 2))), dim3(NTHREADS), LDS,
+    hipLaunchKernelGGL((k_rb_fwd<C, D, DMA, BF16>), dim3(persistent_grid(ntiles_of(B, H, T), blocks_per_cu(LDS, 2))), dim3(NTHREADS), LDS,
                        st, x, w1, b1, w2, b2, y, h1, B, H, T);
     TT_LAUNCH_CHECK();
     return 0;
@@ -982,8 +1080,13 @@ int launch_rb_fwd_v(const float* x, const float* w1, const float* b1, const floa
 
 template <int C, int D>
 int launch_rb_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y, float* h1,
-                  int B, int H, int T, hipStream_t st) {
-    if (dma_ok(x, T)) return launch_rb_fwd_v<C, D, true>(x, w1, b1, w2, b2, y, h1, B, H, T, st);
+                  int B, int H, int T, hipStream_t st, bool bf16) {
+    if (dma_ok(x, T)) {
+        if constexpr (C >= 16) {
+            if (bf16) return launch_rb_fwd_v<C, D, true, true>(x, w1, b1, w2, b2, y, h1, B, H, T, st);
+        }
+        return launch_rb_fwd_v<C, D, true>(x, w1, b1, w2, b2, y, h1, B, H, T, st);
+    }
     return launch_rb_fwd_v<C, D, false>(x, w1, b1, w2, b2, y, h1, B, H, T, st);
 }
 
@@ -991,7 +1094,7 @@ constexpr int WGRAD_MAX_BLOCKS = 512;
 
 template <int CA, int CB, class WP, bool GP, bool GQ>
 int launch_wgrad(const float* Pt, const float* Pg, const float* Qt, const float* Qg, float* dw, float* dbias_p, long s_a,
-                 long s_b, long s_t, float* scratch, int B, int HP, int HQ, int T, hipStream_t st) {
+                 long s_b, long s_t, float* scratch, int B, int HP, int HQ, int T, hipStream_t st, bool bf16 = false) {
     constexpr int CBS = CB > 16 ? 16 : CB;
     constexpr int NS = CB / CBS;
     using K = WGeo<CA, CBS, WP>;
@@ -1004,13 +1107,24 @@ int launch_wgrad(const float* Pt, const float* Pg, const float* Qt, const float*
             constexpr int LDS = cmax(Q::Q_FLOATS + WP::WTH * K::CAP * 64, K::RED_FLOATS) * 4;
             static bool attr = false;
             if (!attr) {
-                TT_HIP(hipFuncSetAttribute((const void*)k_wgrad_dma<CA, CB, CBS, WP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+                TT_HIP(hipFuncSetAttribute((const void*)k_wgrad_dma<CA, CB, CBS, WP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+                if constexpr (CA >= 16 && WP::NTAPS == 9)
+                    TT_HIP(hipFuncSetAttribute((const void*)k_wgrad_dma<CA, CB, CBS, WP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
                 attr = true;
             }
             grid = persistent_grid(ntiles, blocks_per_cu(LDS, 4));
             if (grid * NS > WGRAD_MAX_BLOCKS) grid = WGRAD_MAX_BLOCKS / NS;
-            hipLaunchKernelGGL((k_wgrad_dma<CA, CB, CBS, WP>), dim3(grid, NS), dim3(64 * WP::WTH), LDS, st, Pt, Qt, scratch, dbias_p,
-                               B, HP, HQ, T);
+            bool done = false;
+            if constexpr (CA >= 16 && WP::NTAPS == 9) {
+                if (bf16) {
+                    hipLaunchKernelGGL((k_wgrad_dma<CA, CB, CBS, WP, true>), dim3(grid, NS), dim3(64 * WP::WTH), LDS, st, Pt, Qt,
+                                       scratch, dbias_p, B, HP, HQ, T);
+                    done = true;
+                }
+            }
+            if (!done)
+                hipLaunchKernelGGL((k_wgrad_dma<CA, CB, CBS, WP, false>), dim3(grid, NS), dim3(64 * WP::WTH), LDS, st, Pt, Qt,
+                                   scratch, dbias_p, B, HP, HQ, T);
             TT_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_wgrad_reduce, dim3((K::CAP * NC + 255) / 256, NS), dim3(256), 0, st, (const float*)scratch, dw,
                                grid, CA, K::CAP, NC, K::NN, CBS, s_a, s_b, s_t);
@@ -1055,7 +1169,7 @@ int launch_rb_bwd_a_v(const float* x, const float* h1, const float* dy, const fl
 template <int C, int D>
 int launch_rb_bwd(const float* x, const float* h1, const float* dy, const float* w1, const float* b1, const float* w2,
                   const float* b2, float* dx, float* dw1, float* db1, float* dw2, float* db2, float* ws, int B, int H, int T,
-                  hipStream_t st) {
+                  hipStream_t st, bool bf16) {
     int rc;
     if (h1) rc = launch_rb_bwd_a_v<C, 1, false, false>(x, h1, dy, w1, b1, w2, b2, db1, dw2, db2, ws, B, H, T, st);
     else rc = dma_ok(x, T) ? launch_rb_bwd_a_v<C, D, true, true>(x, h1, dy, w1, b1, w2, b2, db1, dw2, db2, ws, B, H, T, st)
@@ -1063,11 +1177,11 @@ int launch_rb_bwd(const float* x, const float* h1, const float* dy, const float*
     if (rc) return rc;
     // dx = dy + W1^T (*) dA1 : the same conv with in/out channels swapped and the taps reversed
     rc = launch_conv<C, C, Res3x3<D>, false>(ws, nullptr, w1, WSpec{9, (long)C * 9, -1, 8}, nullptr, dy, dx, B, H, H, T,
-                                             TT_ACT_NONE, st);
+                                             TT_ACT_NONE, st, bf16);
     if (rc) return rc;
     // dW1[co][ci][tap] = sum dA1[co][pix] * x[ci][pix + tap]
     return launch_wgrad<C, C, WRes<D, (C <= 8 ? 8 : 4)>, false, false>(ws, nullptr, x, nullptr, dw1, nullptr, (long)C * 9, 9, 1,
-                                                                        ws + (long)B * C * H * T, B, H, H, T, st);
+                                                                        ws + (long)B * C * H * T, B, H, H, T, st, bf16);
 }
 
 template <int C, int D>
@@ -1178,16 +1292,17 @@ int tconv_bwd(const float* x, const float* y, const float* dy, const float* w, f
 extern "C" int64_t tt_wgrad_scratch_floats(void) { return (int64_t)WGRAD_MAX_BLOCKS * 64 * 144; }
 
 extern "C" int tt_resblock_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
-                               float* y, float* h1, int B, int C, int H, int T, int dilation, void* stream) {
+                               float* y, float* h1, int B, int C, int H, int T, int dilation, int flags, void* stream) {
     if (!x || !w1 || !b1 || !w2 || !b2 || !y || B <= 0 || H <= 0 || T <= 0) return TT_E_BADARG;
     hipStream_t st = tt_stream(stream);
+    const bool bf16 = (flags & TT_FLAG_BF16_OPERANDS) != 0;
     if (C <= 8) return tt_small_rb_fwd(x, w1, b1, w2, b2, y, h1, B, C, H, T, dilation, st);     // HBM-bound levels: VALU kernels
-    TT_DISPATCH_CD(launch_rb_fwd, x, w1, b1, w2, b2, y, h1, B, H, T, st)
+    TT_DISPATCH_CD(launch_rb_fwd, x, w1, b1, w2, b2, y, h1, B, H, T, st, bf16)
 }
 
 extern "C" int tt_resblock_bwd(const float* x, const float* h1, const float* dy, const float* w1, const float* b1,
                                const float* w2, const float* b2, float* dx, float* dw1, float* db1, float* dw2, float* db2,
-                               float* ws, int B, int C, int H, int T, int dilation, void* stream) {
+                               float* ws, int B, int C, int H, int T, int dilation, int flags, void* stream) {
     if (!x || !dy || !w1 || !b1 || !w2 || !b2 || !dx || !dw1 || !db1 || !dw2 || !db2 || !ws || B <= 0 || H <= 0 || T <= 0)
         return TT_E_BADARG;
     hipStream_t st = tt_stream(stream);
@@ -1205,7 +1320,8 @@ extern "C" int tt_resblock_bwd(const float* x, const float* h1, const float* dy,
             default: return TT_E_UNSUPPORTED;
         }
     }
-    TT_DISPATCH_CD(launch_rb_bwd, x, h1, dy, w1, b1, w2, b2, dx, dw1, db1, dw2, db2, ws, B, H, T, st)
+    const bool bf16 = (flags & TT_FLAG_BF16_OPERANDS) != 0;
+    TT_DISPATCH_CD(launch_rb_bwd, x, h1, dy, w1, b1, w2, b2, dx, dw1, db1, dw2, db2, ws, B, H, T, st, bf16)
 }
 
 extern "C" int tt_sconv_fwd(const float* x, const float* w, const float* b, float* y, int B, int C, int H, int T,

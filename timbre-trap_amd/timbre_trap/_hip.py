@@ -44,8 +44,8 @@ _PROTOS = {
     'tt_conv2d': (c_int, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, L, L, L, L, I, P]),
     'tt_conv2d_wgrad': (c_int, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, L, L, L, L, P]),
     'tt_elu_bwd': (c_int, [P, P, P, L, P]),
-    'tt_resblock_fwd': (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
-    'tt_resblock_bwd': (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    'tt_resblock_fwd': (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
+    'tt_resblock_bwd': (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
     'tt_sconv_fwd': (c_int, [P, P, P, P, I, I, I, I, P]),
     'tt_wgrad_scratch_floats': (c_int64, []),
     'tt_sconv_bwd': (c_int, [P, P, P, P, P, P, P, P, I, I, I, I, P]),

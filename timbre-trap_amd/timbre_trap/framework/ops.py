@@ -24,6 +24,16 @@ FUSED_CHANNELS = (4, 8, 16, 32)
 # Keep the hidden activation of every residual block for backward (one more (B,C,H,T) tensor per block, no 3x3
 # recompute).  TTRAP_SAVE_HIDDEN=0 recomputes instead and halves the residual-block activation memory.
 SAVE_HIDDEN = os.environ.get('TTRAP_SAVE_HIDDEN', '1') != '0'
+# Arithmetic of the wide (C >= 16) 3x3 convolutions and their weight gradients on the matrix cores:
+#   'fp32' (default)  v_mfma_f32_16x16x4_f32, bit-exact fp32 -- what every parity test pins
+#   'bf16'            operands rounded to bf16, fp32 accumulation (v_mfma_f32_16x16x32_bf16); tensors stay fp32
+PRECISION = os.environ.get('TTRAP_PRECISION', 'fp32')
+
+
+def _flags():
+    if PRECISION not in ('fp32', 'bf16'):
+        raise ValueError('TTRAP_PRECISION / ops.PRECISION must be fp32 or bf16, got %r' % (PRECISION,))
+    return 1 if PRECISION == 'bf16' else 0
 
 
 @dataclass(frozen=True)
@@ -190,8 +200,9 @@ class ResBlockFn(torch.autograd.Function):
         h1 = torch.empty_like(x) if (needs_grad and SAVE_HIDDEN) else None
         with _hip.timed('resblock_fwd_C%d' % C):
             check(_hip.lib().tt_resblock_fwd(ptr(x), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(y), ptr(h1), B, C, H, T, dilation,
-                                             stream_ptr()), 'tt_resblock_fwd')
+                                             _flags(), stream_ptr()), 'tt_resblock_fwd')
         ctx.dilation = dilation
+        ctx.flags = _flags()
         ctx.save_for_backward(x, w1, b1, w2, b2, h1)
         return y
 
@@ -206,7 +217,7 @@ class ResBlockFn(torch.autograd.Function):
         with _hip.timed('resblock_bwd_C%d' % C):
             check(_hip.lib().tt_resblock_bwd(ptr(x), ptr(h1), ptr(dy), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(dx), ptr(dw1),
                                              ptr(db1), ptr(dw2), ptr(db2), ptr(ws), B, C, H, T, ctx.dilation,
-                                             stream_ptr()), 'tt_resblock_bwd')
+                                             ctx.flags, stream_ptr()), 'tt_resblock_bwd')
         return dx, dw1, db1, dw2, db2, None
 
 

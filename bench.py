@@ -146,6 +146,38 @@ def cpu_baseline(mc, latent, seconds_budget=20.0):
                 s_per_step=step_s)
 
 
+def bench_inference(model, args, rank, world, dev):
+    """BASELINE.json configs[1]: model.transcribe(audio) + model.reconstruct(audio), batch x 3 s clips (secondary line)."""
+    model.eval()
+    batch = 32 if args.batch == 64 else args.batch
+    audio, _ = synthetic_batch(batch, rank, dev)
+
+    def step():
+        with torch.no_grad():
+            act = model.transcribe(audio)
+            rec = model.reconstruct(audio)
+        return act, rec
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        act, rec = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ms = 1000.0 * elapsed / args.steps
+    if rank == 0:
+        print(json.dumps(dict(metric='audio-seconds/s inference throughput, transcribe()+reconstruct() (9oct x 60bpo, 3s@22.05kHz)',
+                              value=world * batch * SECS_PER_CLIP / (elapsed / args.steps), unit='audio-seconds/s', n_gpus=world,
+                              steps=args.steps, warmup=args.warmup, ms_per_step=ms, higher_is_better=True, scaling='weak',
+                              vs_baseline=None, dtype=('f32' if args.precision == 'fp32' else 'bf16'), data='synthetic',
+                              config=dict(workload='transcribe() + reconstruct() (each: 3 half-overlapping chunks per clip through CQT + '
+                                                   'encoder + decoder, Hann cross-fade; reconstruct adds the inverse CQT), model_complexity=%d '
+                                                   'latent=%d, %d clips x 3 s' % (args.mc, args.latent, batch),
+                                          global_batch=world * batch, parallelism='dp%d' % world),
+                              out_shapes=[list(act.shape), list(rec.shape)])))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -156,6 +188,8 @@ def main():
     ap.add_argument('--latent', type=int, default=128)
     ap.add_argument('--precision', choices=('fp32', 'bf16'), default=os.environ.get('TTRAP_PRECISION', 'fp32'),
                     help='operands of the wide 3x3 convs on the matrix cores: fp32 = exact (default), bf16 = rounded operands, fp32 accumulation')
+    ap.add_argument('--mode', choices=('train', 'infer'), default='train',
+                    help="train = the headline metric; infer = BASELINE config[1]: transcribe() + reconstruct() on 32 clips x 3 s")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -176,6 +210,8 @@ def main():
     _hip.lib()
 
     model = build_model(args.mc, args.latent, dev)
+    if args.mode == 'infer':
+        return bench_inference(model, args, rank, world, dev)
     opt = FusedAdamW(model.parameters(), lr=1e-3, max_norm=10.0)
     if world > 1:
         broadcast_parameters(opt.flat_param)

@@ -50,7 +50,7 @@ const char* tt_error_string(int code);   /* hipGetErrorString for code > 0 */
  * data (tables built on the host by timbre_trap/framework/nsgt_plan.py):
  *   tw675   [675]   float2  exp(-2 pi i j / 675)
  *   tw49    [49]    float2  exp(-2 pi i j / 49)
- *   twNc    [33075] float2  exp(-2 pi i j / 33075)
+ *   twNc    [49][675] float2  exp(-2 pi i n2 k1 / 33075)   (four-step twiddles, row n2, column k1)
  *   twN     [33076] float2  exp(-2 pi i j / 66150)
  *   tw1024  [1024]  float2  exp(-2 pi i j / 1024)
  *   bin_tab [F][4]  int32   {spec_start, pad, length, win_off} per bin

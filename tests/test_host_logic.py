@@ -35,6 +35,8 @@ def test_plan_matches_oracle_tables():
     # twiddles
     assert np.allclose(plan['twN'][1], [np.cos(2 * np.pi / 66150), -np.sin(2 * np.pi / 66150)])
     assert plan['twN'].shape == (33076, 2) and plan['twNc'].shape == (33075, 2)
+    a = -2 * np.pi * 48 * 674 / 33075
+    assert np.allclose(plan['twNc'][48 * 675 + 674], [np.cos(a), np.sin(a)])
 
 
 def test_helpers_bit_exact(golden):

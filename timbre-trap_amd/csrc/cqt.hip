@@ -6,8 +6,8 @@
 //
 // Data flow for one 66150-sample block ("block-clip" q):
 //   audio viewed as Nc = 33075 complex  z[m] = x[2m] + i x[2m+1]
-//   k_fft675_rows : Nc = 675 x 49 four-step FFT, step 1: 675-point Stockham FFTs (radix 5,5,3,3,3)
-//                   in LDS over n1 for 7 values of n2 per workgroup, times W_Nc^(n2 k1)
+//   k_fft675_rows : Nc = 675 x 49 four-step FFT, step 1: 675-point FFTs as 25 x 27, both factors in registers
+//                   (one LDS exchange) over n1 for 7 values of n2 per workgroup, times W_Nc^(n2 k1)
 //   k_fft49_cols  : step 2: 49-point DFTs over n2 for a tile of k1 and its mirror 675-k1,
 //                   then the real-FFT split -> half spectrum X[0..Nc] in natural order
 //   k_band_fwd    : per (clip, bin): gather L_k windowed spectral samples into a zeroed 1024
@@ -29,89 +29,128 @@ constexpr int XPAD = 33088;      // padded length of one half spectrum (NC + 1 -
 constexpr int M = 1024;          // frames per block (max_window_length)
 constexpr int ROWS = 7;          // n2 values per workgroup in k_fft675_rows
 
-template <int R> struct Roots;
-template <> struct Roots<3> {
-    static __device__ __forceinline__ float2 w(int i) {
-        const float c[3] = {1.f, -0.5f, -0.5f};
-        const float s[3] = {0.f, -0.86602540378443864676f, 0.86602540378443864676f};
-        return make_float2(c[i], s[i]);
-    }
-};
-template <> struct Roots<5> {
-    static __device__ __forceinline__ float2 w(int i) {
-        const float c[5] = {1.f, 0.30901699437494742410f, -0.80901699437494742410f,
-                            -0.80901699437494742410f, 0.30901699437494742410f};
-        const float s[5] = {0.f, -0.95105651629515357212f, -0.58778525229247312917f,
-                            0.58778525229247312917f, 0.95105651629515357212f};
-        return make_float2(c[i], s[i]);
-    }
-};
-
-// forward DFT of R points, direct
-template <int R>
-__device__ __forceinline__ void dft_small(float2 (&v)[R]) {
-    float2 o[R];
-#pragma unroll
-    for (int a = 0; a < R; ++a) {
-        float2 acc = v[0];
-#pragma unroll
-        for (int b = 1; b < R; ++b) acc = cadd(acc, cmul(v[b], Roots<R>::w((a * b) % R)));
-        o[a] = acc;
-    }
-#pragma unroll
-    for (int a = 0; a < R; ++a) v[a] = o[a];
-}
-
-// One Stockham stage of radix R over ROWS independent 675-point rows held in LDS.
-template <int R>
-__device__ __forceinline__ void stage675(const float2* __restrict__ in, float2* __restrict__ out, int Ns,
-                                         const float2* __restrict__ tw, int tid, int nthreads) {
-    constexpr int NB = N1 / R;                 // butterflies per row
-    const int step = N1 / (Ns * R);
-    for (int wi = tid; wi < ROWS * NB; wi += nthreads) {
-        const int row = wi / NB, j = wi - row * NB;
-        const int k = j % Ns;
-        float2 v[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            float2 x = in[row * N1 + j + r * NB];
-            v[r] = (r == 0) ? x : cmul(x, tw[r * k * step]);
-        }
-        dft_small<R>(v);
-        const int j0 = (j / Ns) * Ns * R + k;
-#pragma unroll
-        for (int r = 0; r < R; ++r) out[row * N1 + j0 + r * Ns] = v[r];
-    }
-    __syncthreads();
-}
-
 // Step 1 of the four-step FFT.  in: [Q][NC] float2 (audio pairs, or conj(Z) for the inverse),
 // out A: [Q][N2][N1] float2 = FFT_675 over n1 of in[49 n1 + n2], times W_Nc^(n2 k1).
-__global__ __launch_bounds__(256) void k_fft675_rows(const float2* __restrict__ in, float2* __restrict__ A,
-                                                     const float2* __restrict__ tw675, const float2* __restrict__ twNc) {
+// 675 = 25 x 27, both factors transformed in registers (one LDS exchange, one barrier pair):
+//   n1 = 27 na + nb,  k1 = ka + 25 kb :   W_675^(n1 k1) = W_25^(na ka) W_675^(nb ka) W_27^(nb kb)
+//   pass 1  thread (row, nb): 25-point DFT over na (5 x 5), twiddle W_675^(nb ka)      -> Ys[row][ka][nb]
+//   pass 2  thread (row, ka): 27-point DFT over nb (3 x 9, 9 = 3 x 3)                  -> k1 = ka + 25 kb
+// Every root of unity is read from the 675-entry table (W_5^j = tw[135 j], W_25^j = tw[27 j], W_3^j = tw[225 j],
+// W_9^j = tw[75 j], W_27^j = tw[25 j]).
+constexpr int FFT_ROWS_THREADS = 256;
+constexpr int YS_PITCH = 28;                 // float2 per (row, ka): 27 + 1 pad
+
+__device__ __forceinline__ void dft5_reg(float2& a0, float2& a1, float2& a2, float2& a3, float2& a4, const float2* tw) {
+    const float2 w1 = tw[135], w2 = tw[270], w3 = tw[405], w4 = tw[540];
+    const float2 x0 = a0, x1 = a1, x2 = a2, x3 = a3, x4 = a4;
+    a0 = cadd(cadd(x0, cadd(x1, x2)), cadd(x3, x4));
+    a1 = cadd(x0, cadd(cadd(cmul(x1, w1), cmul(x2, w2)), cadd(cmul(x3, w3), cmul(x4, w4))));
+    a2 = cadd(x0, cadd(cadd(cmul(x1, w2), cmul(x2, w4)), cadd(cmul(x3, w1), cmul(x4, w3))));
+    a3 = cadd(x0, cadd(cadd(cmul(x1, w3), cmul(x2, w1)), cadd(cmul(x3, w4), cmul(x4, w2))));
+    a4 = cadd(x0, cadd(cadd(cmul(x1, w4), cmul(x2, w3)), cadd(cmul(x3, w2), cmul(x4, w1))));
+}
+__device__ __forceinline__ void dft3_reg(float2& a0, float2& a1, float2& a2, const float2* tw) {
+    const float2 w1 = tw[225], w2 = tw[450];
+    const float2 x0 = a0, x1 = a1, x2 = a2;
+    a0 = cadd(x0, cadd(x1, x2));
+    a1 = cadd(x0, cadd(cmul(x1, w1), cmul(x2, w2)));
+    a2 = cadd(x0, cadd(cmul(x1, w2), cmul(x2, w1)));
+}
+// v[5 u + w] -> out[s + 5 t]   (25 = 5 x 5)
+__device__ __forceinline__ void dft25_reg(float2 (&v)[25], const float2* tw) {
+#pragma unroll
+    for (int w = 0; w < 5; ++w) dft5_reg(v[w], v[5 + w], v[10 + w], v[15 + w], v[20 + w], tw);   // over u: result s at v[5 s + w]
+#pragma unroll
+    for (int s_ = 1; s_ < 5; ++s_)
+#pragma unroll
+        for (int w = 1; w < 5; ++w) v[5 * s_ + w] = cmul(v[5 * s_ + w], tw[27 * w * s_]);          // W_25^(w s)
+    float2 o[25];
+#pragma unroll
+    for (int s_ = 0; s_ < 5; ++s_) {
+        float2 a0 = v[5 * s_], a1 = v[5 * s_ + 1], a2 = v[5 * s_ + 2], a3 = v[5 * s_ + 3], a4 = v[5 * s_ + 4];
+        dft5_reg(a0, a1, a2, a3, a4, tw);                                                            // over w: result t
+        o[s_] = a0; o[s_ + 5] = a1; o[s_ + 10] = a2; o[s_ + 15] = a3; o[s_ + 20] = a4;
+    }
+#pragma unroll
+    for (int i = 0; i < 25; ++i) v[i] = o[i];
+}
+// v[3 a + b] -> out[c + 3 d]   (9 = 3 x 3)
+__device__ __forceinline__ void dft9_reg(float2 (&v)[9], const float2* tw) {
+#pragma unroll
+    for (int b = 0; b < 3; ++b) dft3_reg(v[b], v[3 + b], v[6 + b], tw);                             // over a: result c at v[3 c + b]
+    v[3 * 1 + 1] = cmul(v[3 * 1 + 1], tw[75 * 1]);
+    v[3 * 1 + 2] = cmul(v[3 * 1 + 2], tw[75 * 2]);
+    v[3 * 2 + 1] = cmul(v[3 * 2 + 1], tw[75 * 2]);
+    v[3 * 2 + 2] = cmul(v[3 * 2 + 2], tw[75 * 4]);
+    float2 o[9];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float2 a0 = v[3 * c], a1 = v[3 * c + 1], a2 = v[3 * c + 2];
+        dft3_reg(a0, a1, a2, tw);                                                                    // over b: result d
+        o[c] = a0; o[c + 3] = a1; o[c + 6] = a2;
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) v[i] = o[i];
+}
+// v[9 u + w] -> out[s + 3 t]   (27 = 3 x 9)
+__device__ __forceinline__ void dft27_reg(float2 (&v)[27], const float2* tw) {
+#pragma unroll
+    for (int w = 0; w < 9; ++w) dft3_reg(v[w], v[9 + w], v[18 + w], tw);                            // over u: result s at v[9 s + w]
+#pragma unroll
+    for (int s_ = 1; s_ < 3; ++s_)
+#pragma unroll
+        for (int w = 1; w < 9; ++w) v[9 * s_ + w] = cmul(v[9 * s_ + w], tw[25 * w * s_]);           // W_27^(w s)
+    float2 o[27];
+#pragma unroll
+    for (int s_ = 0; s_ < 3; ++s_) {
+        float2 t9[9];
+#pragma unroll
+        for (int w = 0; w < 9; ++w) t9[w] = v[9 * s_ + w];
+        dft9_reg(t9, tw);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) o[s_ + 3 * t] = t9[t];
+    }
+#pragma unroll
+    for (int i = 0; i < 27; ++i) v[i] = o[i];
+}
+
+__global__ __launch_bounds__(FFT_ROWS_THREADS) void k_fft675_rows(const float2* __restrict__ in, float2* __restrict__ A,
+                                                                  const float2* __restrict__ tw675, const float2* __restrict__ twNc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2* buf0 = reinterpret_cast<float2*>(smem);
-    float2* buf1 = buf0 + ROWS * N1;
-    float2* tw = buf1 + ROWS * N1;
+    float2* tw = reinterpret_cast<float2*>(smem);
+    float2* Ys = tw + N1;                              // [ROWS][25][YS_PITCH]
     const int tid = threadIdx.x, g = blockIdx.x;
     const long q = blockIdx.y;
     const float2* src = in + q * NC;
-    for (int i = tid; i < N1; i += 256) tw[i] = tw675[i];
-    for (int i = tid; i < ROWS * N1; i += 256) {
-        const int n1 = i / ROWS, r = i - n1 * ROWS;
-        buf0[r * N1 + n1] = src[N2 * n1 + ROWS * g + r];
+    for (int i = tid; i < N1; i += FFT_ROWS_THREADS) tw[i] = tw675[i];
+    __syncthreads();
+    if (tid < ROWS * 27) {
+        const int nb = tid / ROWS, r = tid - nb * ROWS;        // consecutive threads: consecutive n2 -> 56-byte runs
+        float2 v[25];
+#pragma unroll
+        for (int na = 0; na < 25; ++na) v[na] = src[N2 * (27 * na + nb) + ROWS * g + r];
+        dft25_reg(v, tw);
+#pragma unroll
+        for (int ka = 0; ka < 25; ++ka) {
+            const float2 z = (ka == 0 || nb == 0) ? v[ka] : cmul(v[ka], tw[nb * ka]);       // nb ka <= 26 * 24 < 675
+            Ys[(r * 25 + ka) * YS_PITCH + nb] = z;
+        }
     }
     __syncthreads();
-    stage675<5>(buf0, buf1, 1, tw, tid, 256);
-    stage675<5>(buf1, buf0, 5, tw, tid, 256);
-    stage675<3>(buf0, buf1, 25, tw, tid, 256);
-    stage675<3>(buf1, buf0, 75, tw, tid, 256);
-    stage675<3>(buf0, buf1, 225, tw, tid, 256);
-    float2* dst = A + q * NC;
-    for (int i = tid; i < ROWS * N1; i += 256) {
-        const int r = i / N1, k1 = i - r * N1;
+    if (tid < ROWS * 25) {
+        const int r = tid / 25, ka = tid - r * 25;             // consecutive threads: consecutive k1 within a row
+        float2 v[27];
+        const float2* y = Ys + (r * 25 + ka) * YS_PITCH;
+#pragma unroll
+        for (int nb = 0; nb < 27; ++nb) v[nb] = y[nb];
+        dft27_reg(v, tw);
         const int n2 = ROWS * g + r;
-        dst[n2 * N1 + k1] = cmul(buf1[i], twNc[n2 * k1]);
+        float2* dst = A + q * NC + (long)n2 * N1;
+#pragma unroll
+        for (int kb = 0; kb < 27; ++kb) {
+            const int k1 = ka + 25 * kb;
+            dst[k1] = cmul(v[kb], twNc[n2 * N1 + k1]);          // table stored [n2][k1]: coalesced
+        }
     }
 }
 
@@ -494,7 +533,7 @@ inline Scratch carve(void* base, int Q, int sum_len) {
     return s;
 }
 
-constexpr int LDS_ROWS = (2 * ROWS * N1 + N1) * 8;    // 81,000 B
+constexpr int LDS_ROWS = (N1 + ROWS * 25 * YS_PITCH) * 8;   // 44,600 B
 
 }  // namespace
 
@@ -521,7 +560,7 @@ extern "C" int tt_cqt_forward(const tt_cqt_plan* plan, const float* audio, float
     const int Q = B * n_blocks, F = plan->n_bins;
     Scratch s = carve(scratch, Q, plan->sum_len);
     // audio (B,1,n_blocks*66150) is already [Q][66150] = [Q][NC] float2
-    hipLaunchKernelGGL(k_fft675_rows, dim3(N2 / ROWS, Q), dim3(256), LDS_ROWS, st,
+    hipLaunchKernelGGL(k_fft675_rows, dim3(N2 / ROWS, Q), dim3(FFT_ROWS_THREADS), LDS_ROWS, st,
                        reinterpret_cast<const float2*>(audio), s.A,
                        reinterpret_cast<const float2*>(plan->tw675), reinterpret_cast<const float2*>(plan->twNc));
     TT_LAUNCH_CHECK();
@@ -564,7 +603,7 @@ extern "C" int tt_cqt_inverse(const tt_cqt_plan* plan, const float* coeffs, floa
     hipLaunchKernelGGL(k_spec_gather, dim3((NC + 255) / 256, Q), dim3(256), 0, st, s.S, Zc, plan->gat_off,
                        plan->gat_idx, reinterpret_cast<const float2*>(plan->twN), plan->sum_len);
     TT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_fft675_rows, dim3(N2 / ROWS, Q), dim3(256), LDS_ROWS, st, Zc, s.A,
+    hipLaunchKernelGGL(k_fft675_rows, dim3(N2 / ROWS, Q), dim3(FFT_ROWS_THREADS), LDS_ROWS, st, Zc, s.A,
                        reinterpret_cast<const float2*>(plan->tw675), reinterpret_cast<const float2*>(plan->twNc));
     TT_LAUNCH_CHECK();
     if (normalize) TT_HIP(hipMemsetAsync(s.mx, 0, 4, st));

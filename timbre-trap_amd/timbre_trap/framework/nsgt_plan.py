@@ -77,5 +77,9 @@ def build_plan(n_octaves, bins_per_octave, sample_rate, block_length, power_of_2
                 bin_tab=bin_tab.astype(np.int32), gat_off=gat_off.astype(np.int32),
                 gat_idx=order.astype(np.int32), covered=covered)
     if N == N_FAST and M == M_FAST:
-        plan.update(tw675=tw(675), tw49=tw(49), twNc=tw(N // 2), twN=tw(N, N // 2 + 1), tw1024=tw(1024))
+        # four-step twiddles W_Nc^(n2 k1) laid out [n2][k1] (49 x 675) so the row kernel reads them coalesced
+        n2k1 = np.outer(np.arange(49, dtype=np.float64), np.arange(675, dtype=np.float64)).reshape(-1)
+        ang = -2.0 * np.pi * n2k1 / (N // 2)
+        plan.update(tw675=tw(675), tw49=tw(49), twNc=np.stack([np.cos(ang), np.sin(ang)], axis=1),
+                    twN=tw(N, N // 2 + 1), tw1024=tw(1024))
     return plan

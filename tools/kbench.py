@@ -77,6 +77,26 @@ def main():
             gy = torch.randn_like(y)
             msb = timeit(lambda: torch.autograd.grad(y, [xr, wr, br], gy, retain_graph=True))
             print('tconv   C=%2d      fwd %7.3f ms  bwd %7.3f ms' % (C, ms, msb))
+    if 'latent' in which or 'all' in which:
+        x = torch.randn(B, 64, 31, T, device=dev, requires_grad=True)
+        w = (torch.randn(128, 64, 31, 1, device=dev) * 0.02).requires_grad_(True)
+        b = torch.zeros(128, device=dev, requires_grad=True)
+        ms = timeit(lambda: ops.LatentEncodeFn.apply(x, w, b))
+        y = ops.LatentEncodeFn.apply(x, w, b)
+        gy = torch.randn_like(y)
+        msx = timeit(lambda: torch.autograd.grad(y, [x], gy, retain_graph=True))
+        msw = timeit(lambda: torch.autograd.grad(y, [w, b], gy, retain_graph=True))
+        fl = 2.0 * 128 * 1984 * T * B
+        print('convlat fwd %6.3f ms (%5.1f TF)  dgrad %6.3f ms  wgrad+bias %6.3f ms' % (ms, fl / ms / 1e9, msx, msw))
+        z = torch.randn(B, 129, T, device=dev, requires_grad=True)
+        w = (torch.randn(129, 64, 31, 1, device=dev) * 0.02).requires_grad_(True)
+        b = torch.zeros(64, device=dev, requires_grad=True)
+        ms = timeit(lambda: ops.LatentDecodeFn.apply(z, w, b))
+        y = ops.LatentDecodeFn.apply(z, w, b)
+        gy = torch.randn_like(y)
+        msx = timeit(lambda: torch.autograd.grad(y, [z], gy, retain_graph=True))
+        msw = timeit(lambda: torch.autograd.grad(y, [w, b], gy, retain_graph=True))
+        print('dec convin fwd %6.3f ms  dgrad(+gate) %6.3f ms  wgrad+bias(+gate) %6.3f ms' % (ms, msx, msw))
     if 'cqt' in which or 'all' in which:
         from timbre_trap.framework import CQT
         cq = CQT(9, 60, 22050, 3).to(dev)

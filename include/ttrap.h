@@ -217,6 +217,20 @@ int tt_adamw_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, 
                   int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                   int step, float max_norm, int write_clipped, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Helpers on either side of the path.
+ * ---------------------------------------------------------------------------------------------- */
+/* Per-parameter gradient statistics in ONE launch over the flat gradient buffer (replaces the per-layer
+ * `values.grad.norm(2).item()` host syncs of timbre_trap/utils/experiments.py:144-256):
+ * for segment s = [offsets[2s], offsets[2s+1]) (element indices into x; 2*n_segments entries, any order, gaps allowed):
+ * out[2s] = L2 norm, out[2s+1] = max |g|. */
+int tt_segment_stats(const float* x, const int64_t* offsets, int n_segments, float* out, void* stream);
+/* Peak picking / thresholding of activations (timbre_trap/utils/processing.py:66-124) on the device.
+ * x, out: (n_outer, F, T).  mode 0: keep strict local maxima along F, zero elsewhere (filter_non_peaks);
+ * mode 1: x >= threshold (threshold); mode 2: peak && x >= threshold. */
+int tt_peak_pick(const float* x, float* out, int64_t n_outer, int F, int T, float threshold, int mode,
+                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -224,5 +224,55 @@ def main():
             print(fn, os.path.getsize(os.path.join(HERE, fn)))
 
 
-if __name__ == '__main__':
+
+
+def make_utils_golden():
+    """f1 / f3 rows: CosineWarmup learning rates, gradient-norm helpers, filter_non_peaks / threshold from the reference utils."""
+    install_stubs()
+    me = types.ModuleType('mir_eval')
+    sys.modules.setdefault('mir_eval', me)
+    sys.path.insert(0, '/root/reference')
+    from timbre_trap.utils import experiments as rex, processing as rpr
+    out = {}
+    lin = torch.nn.Linear(3, 2)
+    for n_steps in (0, 1, 7, 50):
+        opt = torch.optim.AdamW(lin.parameters(), lr=1e-3)
+        sch = rex.CosineWarmup(opt, n_steps=n_steps)
+        lrs, active = [opt.param_groups[0]['lr']], [sch.is_active()]
+        for _ in range(n_steps + 3):
+            opt.step()
+            sch.step()
+            lrs.append(opt.param_groups[0]['lr'])
+            active.append(sch.is_active())
+        out[f'warmup_lr_{n_steps}'] = np.array(lrs, dtype=np.float64)
+        out[f'warmup_active_{n_steps}'] = np.array(active, dtype=np.int64)
+    # gradient statistics on a closed-form module
+    torch.manual_seed(0)
+    mod = torch.nn.Sequential(torch.nn.Linear(5, 4), torch.nn.Linear(4, 3))
+    i = 0
+    for p in mod.parameters():
+        n = p.numel()
+        p.grad = (torch.sin(0.7 * torch.arange(n, dtype=torch.float32) + i) * (i + 1)).view_as(p)
+        i += 1
+    out['grad_stats'] = np.array([rex.sum_gradient_norms(mod), rex.average_gradient_norms(mod), rex.get_max_gradient(mod),
+                                  rex.get_max_gradient_norm(mod)], dtype=np.float64)
+    # post-processing
+    a = stub_cqt.closed_form_coefficients(2, 40, 9)[:, 0].numpy().astype(np.float64)          # (2, 40, 9)
+    a = np.abs(a)
+    a[0, 0, 0] = 3.0            # edge peak at the first row
+    a[1, -1, 2] = 3.0           # edge peak at the last row
+    a[0, 10:13, 4] = 1.5        # plateau: no strict maximum
+    out['pp_in'] = a
+    out['pp_peaks'] = rpr.filter_non_peaks(a)
+    out['pp_thr'] = rpr.threshold(a, 0.6)
+    out['pp_peaks_thr'] = rpr.threshold(rpr.filter_non_peaks(a), 0.3)
+    np.savez_compressed(os.path.join(HERE, 'utils.npz'), **out)
+    print('utils.npz', os.path.getsize(os.path.join(HERE, 'utils.npz')))
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'utils':
+    make_utils_golden()
+
+if __name__ == '__main__' and len(sys.argv) == 1:
     main()
+    make_utils_golden()

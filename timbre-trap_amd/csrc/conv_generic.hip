@@ -1,7 +1,7 @@
 // General direct 2-D convolution (every layer shape of the Timbre-Trap autoencoder and, with
 // swapped weight strides, every data gradient), its weight/bias gradient, and the small pointwise
 // helpers of the backward pass.  Shape-agnostic reference path of the library: the hot
-// ResidualConv2dBlock has its own fused kernels in resblock.hip.
+// ResidualConv2dBlock has its own fused kernels in conv_mfma.hip / conv_small.hip.
 //
 // Replaces torch.nn.Conv2d / ConvTranspose2d (+ ELU) forward and backward as used by reference
 // timbre_trap/framework/modules.py:431, :446, :534, :543, :628, :687, :746, :751.

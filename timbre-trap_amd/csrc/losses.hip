@@ -257,6 +257,74 @@ extern "C" int tt_adamw_step(float* param, float* grad, float* exp_avg, float* e
     return 0;
 }
 
+// ---- host-side helpers next to the path (f1 gradient statistics, f3 peak picking) ---------------------
+namespace {
+
+// one workgroup per segment [off[2s], off[2s+1]) of a flat buffer: out[2s] = L2 norm, out[2s+1] = max |x|
+__global__ __launch_bounds__(256) void k_segment_stats(const float* __restrict__ x, const long* __restrict__ off,
+                                                       float* __restrict__ out) {
+    __shared__ double rs[4];
+    __shared__ float rm[4];
+    const int s = blockIdx.x;
+    const long a = off[2 * s], b = off[2 * s + 1];
+    double acc = 0.0;
+    float mx = 0.f;
+    for (long i = a + threadIdx.x; i < b; i += 256) {
+        const float v = x[i];
+        acc += (double)v * (double)v;
+        mx = fmaxf(mx, fabsf(v));
+    }
+    acc = wave_sum_d(acc);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) { rs[threadIdx.x >> 6] = acc; rm[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[2 * s] = (float)sqrt(rs[0] + rs[1] + rs[2] + rs[3]);
+        out[2 * s + 1] = fmaxf(fmaxf(rm[0], rm[1]), fmaxf(rm[2], rm[3]));
+    }
+}
+
+// x viewed as (n_outer, F, T): keep strict local maxima along F (zero rows assumed beyond both ends);
+// mode 0: out = peak ? x : 0 ; mode 1: out = (x >= thr) ; mode 2: out = (peak && x >= thr)
+__global__ __launch_bounds__(256) void k_peak_pick(const float* __restrict__ x, float* __restrict__ out, long n_outer, int F,
+                                                   int T, float thr, int mode) {
+    const long total = n_outer * F * (long)T;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int t = (int)(i % T);
+        const int f = (int)((i / T) % F);
+        (void)t;
+        const float v = x[i];
+        bool peak = true;
+        if (mode != 1) {
+            const float up = f > 0 ? x[i - T] : 0.f, dn = f < F - 1 ? x[i + T] : 0.f;
+            peak = v > up && v > dn;
+        }
+        float r;
+        if (mode == 0) r = peak ? v : 0.f;
+        else if (mode == 1) r = v >= thr ? 1.f : 0.f;
+        else r = (peak && v >= thr) ? 1.f : 0.f;
+        out[i] = r;
+    }
+}
+
+}  // namespace
+
+extern "C" int tt_segment_stats(const float* x, const int64_t* offsets, int n_segments, float* out, void* stream) {
+    if (!x || !offsets || !out || n_segments <= 0) return TT_E_BADARG;
+    hipLaunchKernelGGL(k_segment_stats, dim3(n_segments), dim3(256), 0, tt_stream(stream), x, reinterpret_cast<const long*>(offsets), out);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tt_peak_pick(const float* x, float* out, int64_t n_outer, int F, int T, float threshold, int mode, void* stream) {
+    if (!x || !out || n_outer <= 0 || F <= 0 || T <= 0 || mode < 0 || mode > 2) return TT_E_BADARG;
+    hipLaunchKernelGGL(k_peak_pick, dim3(nblocks(n_outer * F * (long)T, 4) * 4), dim3(256), 0, tt_stream(stream), x, out, (long)n_outer,
+                       F, T, threshold, mode);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int tt_version(void) { return 1; }
 extern "C" const char* tt_arch(void) { return "gfx950"; }
 extern "C" const char* tt_error_string(int code) {

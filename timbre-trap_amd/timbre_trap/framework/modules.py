@@ -45,7 +45,7 @@ def _level_channels(model_complexity, reverse=False):
 class ResidualConv2dBlock(nn.Module):
     """
     y = ELU(conv1x1(ELU(conv_kxk_dilated(x)))) + x with 'same' padding (reference modules.py:721-777).
-    One fused kernel forward, one fused backward (csrc/resblock.hip).
+    One fused kernel forward, one fused backward (csrc/conv_mfma.hip, csrc/conv_small.hip).
     """
 
     def __init__(self, in_channels, out_channels, kernel_size=3, dilation=1):

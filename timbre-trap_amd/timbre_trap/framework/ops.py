@@ -17,7 +17,7 @@ from .._hip import check, ptr, stream_ptr
 
 ACT_NONE, ACT_ELU = 0, 1
 
-# The fused ResidualConv2dBlock kernels (csrc/resblock.hip) are the default; TTRAP_FUSED=0 composes
+# The fused ResidualConv2dBlock kernels (csrc/conv_mfma.hip, csrc/conv_small.hip) are the default; TTRAP_FUSED=0 composes
 # the block from the general convolution kernels instead (used to cross-check the two on the GPU).
 FUSED_RESBLOCK = os.environ.get('TTRAP_FUSED', '1') != '0'
 FUSED_CHANNELS = (4, 8, 16, 32)

@@ -170,7 +170,7 @@ def bench_inference(model, args, rank, world, dev):
         print(json.dumps(dict(metric='audio-seconds/s inference throughput, transcribe()+reconstruct() (9oct x 60bpo, 3s@22.05kHz)',
                               value=world * batch * SECS_PER_CLIP / (elapsed / args.steps), unit='audio-seconds/s', n_gpus=world,
                               steps=args.steps, warmup=args.warmup, ms_per_step=ms, higher_is_better=True, scaling='weak',
-                              vs_baseline=None, dtype=('f32' if args.precision == 'fp32' else 'bf16'), data='synthetic',
+                              vs_baseline=None, dtype={'fp32': 'f32', 'bf16x3': 'bf16x3', 'bf16': 'bf16'}[args.precision], data='synthetic',
                               config=dict(workload='transcribe() + reconstruct() (each: 3 half-overlapping chunks per clip through CQT + '
                                                    'encoder + decoder, Hann cross-fade; reconstruct adds the inverse CQT), model_complexity=%d '
                                                    'latent=%d, %d clips x 3 s' % (args.mc, args.latent, batch),
@@ -186,7 +186,7 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='clips per GPU')
     ap.add_argument('--mc', type=int, default=2)
     ap.add_argument('--latent', type=int, default=128)
-    ap.add_argument('--precision', choices=('fp32', 'bf16'), default=os.environ.get('TTRAP_PRECISION', 'fp32'),
+    ap.add_argument('--precision', choices=('fp32', 'bf16x3', 'bf16'), default=os.environ.get('TTRAP_PRECISION', 'fp32'),
                     help='operands of the wide 3x3 convs on the matrix cores: fp32 = exact (default), bf16 = rounded operands, fp32 accumulation')
     ap.add_argument('--mode', choices=('train', 'infer'), default='train',
                     help="train = the headline metric; infer = BASELINE config[1]: transcribe() + reconstruct() on 32 clips x 3 s")
@@ -273,7 +273,7 @@ def main():
             base = cpu_baseline(args.mc, args.latent)
         line = dict(metric='audio-seconds/s training throughput (9oct x 60bpo, 3s@22.05kHz)', value=value,
                     unit='audio-seconds/s', n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms,
-                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype=('f32' if args.precision == 'fp32' else 'bf16'), data='synthetic',
+                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype={'fp32': 'f32', 'bf16x3': 'bf16x3', 'bf16': 'bf16'}[args.precision], data='synthetic',
                     config=dict(workload='full train step (CQT x2 + AE fwd/bwd with consistency + 3 losses + clip + AdamW), '
                                          'model_complexity=%d latent=%d, %d clips x 3 s per GPU' % (args.mc, args.latent, args.batch),
                                 global_batch=world * args.batch, parallelism='dp%d' % world),

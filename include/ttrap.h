@@ -31,6 +31,10 @@ extern "C" {
 /* flags of tt_resblock_fwd / tt_resblock_bwd: round the operands of the 3x3 convolutions and of dW1 to bf16 for the
  * matrix cores (v_mfma_f32_16x16x32_bf16, fp32 accumulation, fp32 tensors in HBM) at C >= 16.  Default 0 = exact fp32. */
 #define TT_FLAG_BF16_OPERANDS 1
+/* split-bf16 ("bf16x3"): every fp32 operand is fed to the same instruction as hi + lo (two round-to-nearest bf16) and
+ * products are accumulated as hi*hi + lo*hi + hi*lo in fp32 -- fp32-class results (product error ~1e-5 relative,
+ * unbiased) at 16/3 of the fp32 matrix rate.  Takes precedence over TT_FLAG_BF16_OPERANDS. */
+#define TT_FLAG_BF16_SPLIT    2
 
 #define TT_ACT_NONE 0
 #define TT_ACT_ELU  1

@@ -228,3 +228,33 @@ def test_resblock_bf16_operand_mode(C, d, shape, monkeypatch):
     assert 1e-5 < e < 1e-2, e                       # really bf16 (not the fp32 path), and within bf16 rounding
     for got, want, name in zip(dev, ref_in, ('dx', 'dw1', 'db1', 'dw2', 'db2')):
         assert _rel(got.grad, want.grad) < 2e-2, name
+
+
+@pytest.mark.parametrize('C,d', [(16, 1), (16, 3), (32, 1), (32, 2), (32, 3)])
+@pytest.mark.parametrize('shape', [(2, 13, 128), (1, 9, 64)])
+def test_resblock_split_bf16_mode(C, d, shape, monkeypatch):
+    """
+    Split-bf16 ("bf16x3") mode: operands fed as hi + lo bf16 pairs, three matrix instructions per product block, fp32
+    accumulation.  Stays inside the 1e-4 parity bar of the fp32 path (measured ~1e-6 against the float64 oracle).
+    """
+    from timbre_trap.framework import ops
+    monkeypatch.setattr(ops, 'PRECISION', 'bf16x3')
+    B, H, T = shape
+    x = _rand(B, C, H, T, seed=1)
+    w1 = _rand(C, C, 3, 3, seed=2, scale=1.0 / (3 * C ** 0.5))
+    b1 = _rand(C, seed=3, scale=0.3)
+    w2 = _rand(C, C, 1, 1, seed=4, scale=1.0 / C ** 0.5)
+    b2 = _rand(C, seed=5, scale=0.3)
+    gy = _rand(B, C, H, T, seed=6)
+    ref_in = [t.double().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    sd = {'p.conv1.0.weight': ref_in[1], 'p.conv1.0.bias': ref_in[2], 'p.conv2.0.weight': ref_in[3], 'p.conv2.0.bias': ref_in[4]}
+    yr = oae.residual_block(ref_in[0], sd, 'p', d)
+    yr.backward(gy.double())
+    dev = [t.cuda().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    y = ops.residual_block(*dev, d)
+    y.backward(gy.cuda())
+    e = _rel(y, yr)
+    print('split-bf16 forward rel err', e)
+    assert e < 2e-5, e
+    for got, want, name in zip(dev, ref_in, ('dx', 'dw1', 'db1', 'dw2', 'db2')):
+        assert _rel(got.grad, want.grad) < 2e-5, (name, _rel(got.grad, want.grad))

@@ -48,6 +48,29 @@ __device__ __forceinline__ bf16x8 pack_bf16(const float (&v)[8]) {
     return r;
 }
 
+// split-bf16 mode (flags bit 1, "bf16x3"): every fp32 operand is written as hi + lo with hi = bf16(v), lo = bf16(v - hi)
+// (both round-to-nearest, |v - hi - lo| <= 2^-18 |v|) and a product is accumulated as hi*hi + lo*hi + hi*lo in fp32:
+// fp32-class results (relative error of a product ~1e-5, unbiased) from three bf16 matrix instructions, 16/3 of the
+// fp32 MFMA rate.
+template <int PREC>
+__device__ __forceinline__ void split_bf16(const float (&v)[8], bf16x8& h, bf16x8& l) {
+    h = pack_bf16(v);
+    if constexpr (PREC == 2) {
+        float r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = v[j] - (float)h[j];
+        l = pack_bf16(r);
+    }
+}
+template <int PREC>
+__device__ __forceinline__ f32x4 mma_bf16(const bf16x8& ah, const bf16x8& al, const bf16x8& bh, const bf16x8& bl, f32x4 c) {
+    if constexpr (PREC == 2) {
+        c = mfma16_bf16(al, bh, c);
+        c = mfma16_bf16(ah, bl, c);
+    }
+    return mfma16_bf16(ah, bh, c);
+}
+
 constexpr int plane_pad(int n) {
     int p = n;
     while (p % 32 != 17) ++p;
@@ -86,8 +109,9 @@ struct Up4 {        // out row r <- in rows (r - kh)/2, kh = (r&1) + 2j, j = 0,1
 // instruction, destination linear in LDS).  Rows then start 16-byte aligned at t0 - HL (HL = 4 when the geometry has a
 // column halo) and are XCP = 64 (+8) floats wide, planes are exactly XR*XCP floats apart.  DMA = false: the register
 // staged tile (any T, optional ELU' gating while staging) with the 17-mod-32 plane pitch.
-template <int CIN, int COUT, class P, bool DMA, bool BF16 = false>
+template <int CIN, int COUT, class P, bool DMA, int PREC = 0>
 struct Geo {
+    static constexpr bool BF16 = PREC != 0;
     static constexpr int MT = (COUT + 15) / 16;
     static constexpr int CP = MT * 16;                       // weight image row pitch (floats)
     static constexpr bool SWZ = CP >= 32;
@@ -104,8 +128,10 @@ struct Geo {
     static constexpr int BUF = DMA ? NPIECE * 256 : CC * PLANE;
     static constexpr int KW = P::NWT * CIN;                  // rows of the weight image
     // bf16 weight image of the 3x3 geometry: per 4-channel chunk two K=32 blocks (taps 0..7, then tap 8 + zeros),
-    // [chunk][block][lane group g][co][8] bf16 -> one ds_read_b128 per A fragment.  Size in float units.
-    static constexpr int WBF_FLOATS = (CIN / 4) * 2 * 4 * CP * 8 / 2;
+    // [chunk][slot][co][8] bf16 with slot 0..3 = block 0 / lane group g and slot 4 = block 1 / lane group 0 (the other
+    // groups of block 1 multiply zeros) -> one ds_read_b128 per A fragment.  Split mode appends the lo image.
+    static constexpr int WBF_HALF = (CIN / 4) * 5 * CP * 8;             // bf16 elements of one image
+    static constexpr int WBF_FLOATS = WBF_HALF / 2 * (PREC == 2 ? 2 : 1);
     static constexpr int W_FLOATS = BF16 ? WBF_FLOATS : KW * CP;
     static constexpr int XS_FLOATS = 2 * BUF;
 };
@@ -117,9 +143,18 @@ __device__ __forceinline__ void glds16(const float* gsrc, float* lds_wave_base) 
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Workgroup w runs on XCD w % 8 (round-robin dispatch), and every XCD has its own L2.  Work item v of the persistent
+// loop is therefore sent to tile (v % 8) * (ntiles / 8) + v / 8: each XCD sweeps one contiguous eighth of the raster,
+// so the tiles that share halo rows and columns are in flight on the same L2 at about the same time.
+__device__ __forceinline__ int xcd_tile(int v, int ntiles) {
+    const int per = ntiles >> 3;
+    return v < (per << 3) ? (v & 7) * per + (v >> 3) : v;
+}
+
 struct Tile { int b, h0, t0; };
-__device__ __forceinline__ Tile decode_tile(int tile, int tiles_h, int tiles_t) {
+__device__ __forceinline__ Tile decode_tile(int v, int tiles_h, int tiles_t, int ntiles) {
     Tile r;
+    int tile = xcd_tile(v, ntiles);
     const int tt = tile % tiles_t; tile /= tiles_t;
     const int th = tile % tiles_h;
     r.b = tile / tiles_h; r.h0 = th * TH; r.t0 = tt * TW;
@@ -139,32 +174,35 @@ __device__ __forceinline__ void build_weight_image(float* img, const float* __re
     }
 }
 
-// bf16 image (3x3 geometry only): slot (chunk c4, block m, group g, co, j) holds W(co, ci = 4 c4 + (j & 3), tap = 8 m + 2 g + (j >> 2))
-template <int CIN, int COUT>
+// bf16 image (3x3 geometry only): slot (chunk c4, slot sl, co, j) holds W(co, ci = 4 c4 + (j & 3), tap) with
+// tap = 2 sl + (j >> 2) for sl < 4 and tap = 8 (j < 4 only) for sl = 4.  PREC == 2 appends the image of the residuals.
+template <int CIN, int COUT, int PREC>
 __device__ __forceinline__ void build_weight_image_bf16(__bf16* img, const float* __restrict__ w, long s_m, long s_c, long s_t,
                                                         long w_off, int tid) {
     constexpr int CP = ((COUT + 15) / 16) * 16;
-    constexpr int TOTAL = (CIN / 4) * 2 * 4 * CP * 8;
+    constexpr int TOTAL = (CIN / 4) * 5 * CP * 8;
     for (int i = tid; i < TOTAL; i += NTHREADS) {
         const int j = i & 7;
         int r = i >> 3;
         const int co = r % CP; r /= CP;
-        const int g = r & 3; r >>= 2;
-        const int m = r & 1; const int c4 = r >> 1;
-        const int tap = 8 * m + 2 * g + (j >> 2), ci = 4 * c4 + (j & 3);
+        const int sl = r % 5; const int c4 = r / 5;
+        const int tap = sl < 4 ? 2 * sl + (j >> 2) : (j < 4 ? 8 : 9), ci = 4 * c4 + (j & 3);
         float v = 0.f;
         if (co < COUT && tap < 9) v = w[w_off + co * s_m + ci * s_c + tap * s_t];
-        img[i] = (__bf16)v;
+        const __bf16 h = (__bf16)v;
+        img[i] = h;
+        if constexpr (PREC == 2) img[TOTAL + i] = (__bf16)(v - (float)h);
     }
 }
 
 // The pipelined implicit-GEMM main loop over the tiles of one workgroup.  `epi(tile, acc)` consumes a finished tile.
-template <int CIN, int COUT, class P, bool GATE, bool DMA, bool BF16, class Epi>
+template <int CIN, int COUT, class P, bool GATE, bool DMA, int PREC, class Epi>
 __device__ __forceinline__ void conv_mainloop(const float* __restrict__ x, const float* __restrict__ gy, const float* Wimg,
                                               float* xs, int B, int Hin, int Hout, int T, Epi&& epi) {
     static_assert(!(GATE && DMA), "gated staging needs the register path");
+    constexpr bool BF16 = PREC != 0;
     static_assert(!BF16 || (DMA && P::NTAPS == 9), "bf16 operands: 3x3 geometry on the DMA path");
-    using G = Geo<CIN, COUT, P, DMA, BF16>;
+    using G = Geo<CIN, COUT, P, DMA, PREC>;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     const int tiles_h = (Hout + TH - 1) / TH, tiles_t = (T + TW - 1) / TW;
     const int ntiles = B * tiles_h * tiles_t;
@@ -178,7 +216,7 @@ __device__ __forceinline__ void conv_mainloop(const float* __restrict__ x, const
     float preg[GATE ? G::NLD : 1];
     int p_row0 = 0, p_col0 = 0;
     auto issue_reg = [&](int tile, int chunk) {
-        const Tile tl = decode_tile(tile, tiles_h, tiles_t);
+        const Tile tl = decode_tile(tile, tiles_h, tiles_t, ntiles);
         p_row0 = P::in_row0(tl.h0);
         p_col0 = tl.t0 - P::CH;
         const float* xb = x + ((long)tl.b * CIN + chunk * G::CC) * plane;
@@ -216,7 +254,7 @@ __device__ __forceinline__ void conv_mainloop(const float* __restrict__ x, const
     };
     // ---- LDS-DMA staging (DMA == true): each wave moves NPIECE/8 one-KiB pieces straight into the other buffer ----
     auto issue_dma = [&](int tile, int chunk, int buf) {
-        const Tile tl = decode_tile(tile, tiles_h, tiles_t);
+        const Tile tl = decode_tile(tile, tiles_h, tiles_t, ntiles);
         const int row0 = P::in_row0(tl.h0), col0 = tl.t0 - G::HL;
         const float* xb = x + ((long)tl.b * CIN + chunk * G::CC) * plane;
         float* dst = xs + buf * G::BUF;
@@ -269,25 +307,32 @@ __device__ __forceinline__ void conv_mainloop(const float* __restrict__ x, const
                 const float* pa = xb + P::lrow(2 * g, wave) * G::XCP + (G::HL - P::CH) + P::lcol(2 * g) + l15;
                 const float* pb = xb + P::lrow(2 * g + 1, wave) * G::XCP + (G::HL - P::CH) + P::lcol(2 * g + 1) + l15;
                 const float* p8 = xb + P::lrow(8, wave) * G::XCP + (G::HL - P::CH) + P::lcol(8) + l15;
-                bf16x8 a0[G::MT], a1[G::MT];
+                bf16x8 a0[G::MT], a1[G::MT], a0l[G::MT], a1l[G::MT];
+                const bf16x8 zero8 = {};
 #pragma unroll
                 for (int mt = 0; mt < G::MT; ++mt) {
-                    a0[mt] = *reinterpret_cast<const bf16x8*>(wimg + ((((chunk * 2 + 0) * 4 + g) * G::CP) + mt * 16 + l15) * 8);
-                    a1[mt] = *reinterpret_cast<const bf16x8*>(wimg + ((((chunk * 2 + 1) * 4 + g) * G::CP) + mt * 16 + l15) * 8);
+                    const int o0 = (((chunk * 5 + g) * G::CP) + mt * 16 + l15) * 8, o1 = (((chunk * 5 + 4) * G::CP) + mt * 16 + l15) * 8;
+                    a0[mt] = *reinterpret_cast<const bf16x8*>(wimg + o0);
+                    a1[mt] = g == 0 ? *reinterpret_cast<const bf16x8*>(wimg + o1) : zero8;
+                    if constexpr (PREC == 2) {
+                        a0l[mt] = *reinterpret_cast<const bf16x8*>(wimg + G::WBF_HALF + o0);
+                        a1l[mt] = g == 0 ? *reinterpret_cast<const bf16x8*>(wimg + G::WBF_HALF + o1) : zero8;
+                    }
                 }
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
                     float v[8];
+                    bf16x8 b0, b0l, b1, b1l;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { v[j] = pa[j * G::PLANE + nt * 16]; v[4 + j] = pb[j * G::PLANE + nt * 16]; }
-                    const bf16x8 b0 = pack_bf16(v);
+                    split_bf16<PREC>(v, b0, b0l);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { v[j] = (g == 0) ? p8[j * G::PLANE + nt * 16] : 0.f; v[4 + j] = 0.f; }
-                    const bf16x8 b1 = pack_bf16(v);
+                    split_bf16<PREC>(v, b1, b1l);
 #pragma unroll
                     for (int mt = 0; mt < G::MT; ++mt) {
-                        acc[mt][nt] = mfma16_bf16(a0[mt], b0, acc[mt][nt]);
-                        acc[mt][nt] = mfma16_bf16(a1[mt], b1, acc[mt][nt]);
+                        acc[mt][nt] = mma_bf16<PREC>(a0[mt], a0l[mt], b0, b0l, acc[mt][nt]);
+                        acc[mt][nt] = mma_bf16<PREC>(a1[mt], a1l[mt], b1, b1l, acc[mt][nt]);
                     }
                 }
             } else {
@@ -313,29 +358,44 @@ __device__ __forceinline__ void conv_mainloop(const float* __restrict__ x, const
             }
             buf ^= 1;
         }
-        epi(decode_tile(tile, tiles_h, tiles_t), acc);
+        epi(decode_tile(tile, tiles_h, tiles_t, ntiles), acc);
     }
 }
 
 // ---- plain convolution kernel: out = act(conv + bias) + res -----------------------------------------------
 struct WSpec { long s_m, s_c, s_t, off; };
 
-template <int CIN, int COUT, class P, bool GATE, bool DMA, bool BF16>
+template <int CIN, int COUT, class P, bool GATE, bool DMA, int PREC>
 __global__ __launch_bounds__(NTHREADS, 4) void k_conv_mfma(const float* __restrict__ x, const float* __restrict__ gy,
                                                         const float* __restrict__ w, WSpec ws, const float* __restrict__ bias,
                                                         const float* __restrict__ res, float* __restrict__ y, int B, int Hin,
                                                         int Hout, int T, int act) {
-    using G = Geo<CIN, COUT, P, DMA, BF16>;
+    using G = Geo<CIN, COUT, P, DMA, PREC>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xs = lds;                       // DMA destinations first: 16-byte aligned
     float* Wimg = lds + G::XS_FLOATS;
-    if constexpr (BF16) build_weight_image_bf16<CIN, COUT>(reinterpret_cast<__bf16*>(Wimg), w, ws.s_m, ws.s_c, ws.s_t, ws.off, threadIdx.x);
+    if constexpr (PREC != 0) build_weight_image_bf16<CIN, COUT, PREC>(reinterpret_cast<__bf16*>(Wimg), w, ws.s_m, ws.s_c, ws.s_t, ws.off, threadIdx.x);
     else build_weight_image<CIN, COUT, P>(Wimg, w, ws.s_m, ws.s_c, ws.s_t, ws.off, threadIdx.x);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, l15 = lane & 15;
     const long oplane = (long)Hout * T;
-    conv_mainloop<CIN, COUT, P, GATE, DMA, BF16>(x, gy, Wimg, xs, B, Hin, Hout, T, [&](const Tile& tl, f32x4 (&acc)[G::MT][4]) {
+    conv_mainloop<CIN, COUT, P, GATE, DMA, PREC>(x, gy, Wimg, xs, B, Hin, Hout, T, [&](const Tile& tl, f32x4 (&acc)[G::MT][4]) {
         const int h = tl.h0 + wave;
         if (h >= Hout) return;
+        float rv[G::MT][4][4];
+        if (res) {      // all residual loads first (clamped, branch-free): one latency instead of one per store
+#pragma unroll
+            for (int mt = 0; mt < G::MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = mt * 16 + 4 * g + r;
+                    const float* rb = res + ((long)tl.b * COUT + (m < COUT ? m : COUT - 1)) * oplane + (long)h * T;
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const int t = tl.t0 + nt * 16 + l15;
+                        rv[mt][r][nt] = rb[t < T ? t : T - 1];
+                    }
+                }
+        }
 #pragma unroll
         for (int mt = 0; mt < G::MT; ++mt)
 #pragma unroll
@@ -350,7 +410,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_conv_mfma(const float* __restri
                     if (t >= T) continue;
                     float v = acc[mt][nt][r] + bv;
                     if (act == TT_ACT_ELU) v = elu1(v);
-                    if (res) v += res[base + t];
+                    if (res) v += rv[mt][r][nt];
                     y[base + t] = v;
                 }
             }
@@ -385,13 +445,13 @@ __device__ __forceinline__ void build_w2_images(float* W2s, float* W2t, float* b
     }
 }
 
-template <int C, int D, bool DMA, bool BF16>
+template <int C, int D, bool DMA, int PREC>
 __global__ __launch_bounds__(NTHREADS, 4) void k_rb_fwd(const float* __restrict__ x, const float* __restrict__ w1,
                                                      const float* __restrict__ b1, const float* __restrict__ w2,
                                                      const float* __restrict__ b2, float* __restrict__ y,
                                                      float* __restrict__ h1out, int B, int H, int T) {
     using P = Res3x3<D>;
-    using G = Geo<C, C, P, DMA, BF16>;
+    using G = Geo<C, C, P, DMA, PREC>;
     using R = RB<C>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xs = lds;
@@ -399,12 +459,13 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_rb_fwd(const float* __restrict_
     float* W2s = Wimg + G::W_FLOATS;
     float* b1s = W2s + R::CPAD * R::CP;
     float* b2s = b1s + R::CPAD;
-    if constexpr (BF16) build_weight_image_bf16<C, C>(reinterpret_cast<__bf16*>(Wimg), w1, (long)C * 9, 9, 1, 0, threadIdx.x);
+    if constexpr (PREC != 0) build_weight_image_bf16<C, C, PREC>(reinterpret_cast<__bf16*>(Wimg), w1, (long)C * 9, 9, 1, 0, threadIdx.x);
     else build_weight_image<C, C, P>(Wimg, w1, (long)C * 9, 9, 1, 0, threadIdx.x);
     build_w2_images<C>(W2s, nullptr, b1s, b2s, w2, b1, b2, threadIdx.x);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, l15 = lane & 15;
     const long plane = (long)H * T;
-    conv_mainloop<C, C, P, false, DMA, BF16>(x, nullptr, Wimg, xs, B, H, H, T, [&](const Tile& tl, f32x4 (&acc)[G::MT][4]) {
+    conv_mainloop<C, C, P, false, DMA, PREC>(x, nullptr, Wimg, xs, B, H, H, T, [&](const Tile& tl, f32x4 (&acc)[G::MT][4]) {
+        const int h = tl.h0 + wave;
         f32x4 acc2[G::MT][4];
 #pragma unroll
         for (int mt = 0; mt < G::MT; ++mt)
@@ -414,6 +475,21 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_rb_fwd(const float* __restrict_
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[mt][nt][r] = elu1(acc[mt][nt][r] + b1s[mt * 16 + 4 * g + r]);
             }
+        if (h1out && h < H) {       // hidden activation for the backward pass
+#pragma unroll
+            for (int m2 = 0; m2 < G::MT; ++m2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = m2 * 16 + 4 * g + r;
+                    if (co >= C) continue;
+                    float* hb = h1out + ((long)tl.b * C + co) * plane + (long)h * T;
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const int t = tl.t0 + nt * 16 + l15;
+                        if (t < T) hb[t] = acc[m2][nt][r];
+                    }
+                }
+        }
 #pragma unroll
         for (int mt = 0; mt < G::MT; ++mt)
 #pragma unroll
@@ -427,8 +503,26 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_rb_fwd(const float* __restrict_
 #pragma unroll
                     for (int m2 = 0; m2 < G::MT; ++m2) acc2[m2][nt] = mfma16(a2[m2], acc[mt][nt][r], acc2[m2][nt]);
             }
-        const int h = tl.h0 + wave;
         if (h >= H) return;
+        // the residual input of this lane's outputs: all loads are issued together (clamped addresses, no branches)
+        // once the 3x3 accumulators are dead: one exposed latency per tile instead of one per store
+        const int hc = h < H ? h : H - 1;
+        float xres[G::MT][4][4];
+        int toff[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int t = tl.t0 + nt * 16 + l15;
+            toff[nt] = t < T ? t : T - 1;
+        }
+#pragma unroll
+        for (int m2 = 0; m2 < G::MT; ++m2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = m2 * 16 + 4 * g + r;
+                const float* xb = x + ((long)tl.b * C + (co < C ? co : C - 1)) * plane + (long)hc * T;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) xres[m2][r][nt] = xb[toff[nt]];
+            }
 #pragma unroll
         for (int m2 = 0; m2 < G::MT; ++m2)
 #pragma unroll
@@ -436,14 +530,11 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_rb_fwd(const float* __restrict_
                 const int co = m2 * 16 + 4 * g + r;
                 if (co >= C) continue;
                 const float bias = b2s[co];
-                const long base = ((long)tl.b * C + co) * plane + (long)h * T;
+                float* yb = y + ((long)tl.b * C + co) * plane + (long)h * T;
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
                     const int t = tl.t0 + nt * 16 + l15;
-                    if (t < T) {
-                        y[base + t] = elu1(acc2[m2][nt][r] + bias) + x[base + t];
-                        if (h1out) h1out[base + t] = acc[m2][nt][r];        // hidden activation for the backward pass
-                    }
+                    if (t < T) yb[t] = elu1(acc2[m2][nt][r] + bias) + xres[m2][r][nt];
                 }
             }
     });
@@ -603,13 +694,13 @@ __global__ __launch_bounds__(NTHREADS) void k_rb_bwd_a(const float* __restrict__
         }
     };
     if (RECOMP) {
-        conv_mainloop<C, C, P, false, DMA, false>(x, nullptr, Wimg, xs, B, H, H, T, epi);
+        conv_mainloop<C, C, P, false, DMA, 0>(x, nullptr, Wimg, xs, B, H, H, T, epi);
     } else {
         const int tiles_h = (H + TH - 1) / TH, tiles_t = (T + TW - 1) / TW;
         const int ntiles = B * tiles_h * tiles_t;
 #pragma unroll 1
         for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-            const Tile tl = decode_tile(tile, tiles_h, tiles_t);
+            const Tile tl = decode_tile(tile, tiles_h, tiles_t, ntiles);
             const int h = tl.h0 + wave;
             f32x4 h1[G::MT][4];
 #pragma unroll
@@ -717,7 +808,7 @@ __global__ __launch_bounds__(64 * WP::WTH) void k_wgrad_mfma(const float* __rest
     float bsum = 0.f;
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        int tt = tile;
+        int tt = xcd_tile(tile, ntiles);
         const int tx = tt % tiles_t; tt /= tiles_t;
         const int ty = tt % tiles_h;
         const int b = tt / tiles_h, h0 = ty * WP::WTH, t0 = tx * WP::WTW;
@@ -814,13 +905,14 @@ struct WGeoD {
     static constexpr int Q_FLOATS = NPIECE * 256;
 };
 
-template <int CA, int CB, int CBS, class WP, bool BF16>
+template <int CA, int CB, int CBS, class WP, int PREC>
 __global__ __launch_bounds__(64 * WP::WTH) void k_wgrad_dma(const float* __restrict__ Pt, const float* __restrict__ Qt,
                                                            float* __restrict__ scratch, float* __restrict__ dbias_p, int B,
                                                            int HP, int HQ, int T) {
     using K = WGeo<CA, CBS, WP>;
     using Q = WGeoD<CBS, WP>;
     static_assert(WP::WTW == 64, "P rows are 64 pixels");
+    constexpr bool BF16 = PREC != 0;
     constexpr int NT_ = 64 * WP::WTH;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
@@ -851,7 +943,7 @@ __global__ __launch_bounds__(64 * WP::WTH) void k_wgrad_dma(const float* __restr
     const float* zero = reinterpret_cast<const float*>(&g_zero16);
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        int tt = tile;
+        int tt = xcd_tile(tile, ntiles);
         const int tx = tt % tiles_t; tt /= tiles_t;
         const int ty = tt % tiles_h;
         const int b = tt / tiles_h, h0 = ty * WP::WTH, t0 = tx * WP::WTW;
@@ -896,14 +988,14 @@ __global__ __launch_bounds__(64 * WP::WTH) void k_wgrad_dma(const float* __restr
             // K = 32 pixels per MFMA: lane group g owns pixels 32 seg + 8 g .. + 7 (two swizzled 16-byte chunks of the P row)
 #pragma unroll
             for (int seg = 0; seg < 2; ++seg) {
-                bf16x8 av[K::MT];
+                bf16x8 av[K::MT], avl[K::MT];
 #pragma unroll
                 for (int mt = 0; mt < K::MT; ++mt) {
                     const float* row = as + (mt * 16 + l15) * 64;
                     const float4 lo = *reinterpret_cast<const float4*>(row + (((8 * seg + 2 * g) ^ l15) << 2));
                     const float4 hi = *reinterpret_cast<const float4*>(row + (((8 * seg + 2 * g + 1) ^ l15) << 2));
                     const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                    av[mt] = pack_bf16(v);
+                    split_bf16<PREC>(v, av[mt], avl[mt]);
                 }
 #pragma unroll
                 for (int nt = 0; nt < K::NTN; ++nt) {
@@ -911,9 +1003,10 @@ __global__ __launch_bounds__(64 * WP::WTH) void k_wgrad_dma(const float* __restr
                     float v[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = xp[j];
-                    const bf16x8 bv = pack_bf16(v);
+                    bf16x8 bv, bvl;
+                    split_bf16<PREC>(v, bv, bvl);
 #pragma unroll
-                    for (int mt = 0; mt < K::MT; ++mt) acc[mt][nt] = mfma16_bf16(av[mt], bv, acc[mt][nt]);
+                    for (int mt = 0; mt < K::MT; ++mt) acc[mt][nt] = mma_bf16<PREC>(av[mt], avl[mt], bv, bvl, acc[mt][nt]);
                 }
             }
         } else {
@@ -1031,17 +1124,17 @@ inline int persistent_grid(int ntiles, int per_cu) {
 }
 inline int ntiles_of(int B, int H, int T) { return B * ((H + TH - 1) / TH) * ((T + TW - 1) / TW); }
 
-template <int CIN, int COUT, class P, bool GATE, bool DMA, bool BF16 = false>
+template <int CIN, int COUT, class P, bool GATE, bool DMA, int PREC = 0>
 int launch_conv_v(const float* x, const float* gy, const float* w, WSpec ws, const float* bias, const float* res, float* y,
                   int B, int Hin, int Hout, int T, int act, hipStream_t st) {
-    using G = Geo<CIN, COUT, P, DMA, BF16>;
+    using G = Geo<CIN, COUT, P, DMA, PREC>;
     constexpr int LDS = (G::W_FLOATS + G::XS_FLOATS) * 4;
     static bool attr = false;
     if (!attr) {
-        TT_HIP(hipFuncSetAttribute((const void*)k_conv_mfma<CIN, COUT, P, GATE, DMA, BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        TT_HIP(hipFuncSetAttribute((const void*)k_conv_mfma<CIN, COUT, P, GATE, DMA, PREC>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr = true;
     }
-    hipLaunchKernelGGL((k_conv_mfma<CIN, COUT, P, GATE, DMA, BF16>), dim3(persistent_grid(ntiles_of(B, Hout, T), blocks_per_cu(LDS, 2))),
+    hipLaunchKernelGGL((k_conv_mfma<CIN, COUT, P, GATE, DMA, PREC>), dim3(persistent_grid(ntiles_of(B, Hout, T), blocks_per_cu(LDS, 2))),
                        dim3(NTHREADS), LDS, st, x, gy, w, ws, bias, res, y, B, Hin, Hout, T, act);
     TT_LAUNCH_CHECK();
     return 0;
@@ -1049,11 +1142,12 @@ int launch_conv_v(const float* x, const float* gy, const float* w, WSpec ws, con
 
 template <int CIN, int COUT, class P, bool GATE>
 int launch_conv(const float* x, const float* gy, const float* w, WSpec ws, const float* bias, const float* res, float* y,
-                int B, int Hin, int Hout, int T, int act, hipStream_t st, bool bf16 = false) {
+                int B, int Hin, int Hout, int T, int act, hipStream_t st, int prec = 0) {
     if constexpr (!GATE) {
         if (dma_ok(x, T)) {
             if constexpr (P::NTAPS == 9 && CIN >= 16) {
-                if (bf16) return launch_conv_v<CIN, COUT, P, false, true, true>(x, gy, w, ws, bias, res, y, B, Hin, Hout, T, act, st);
+                if (prec == 1) return launch_conv_v<CIN, COUT, P, false, true, 1>(x, gy, w, ws, bias, res, y, B, Hin, Hout, T, act, st);
+                if (prec == 2) return launch_conv_v<CIN, COUT, P, false, true, 2>(x, gy, w, ws, bias, res, y, B, Hin, Hout, T, act, st);
             }
             return launch_conv_v<CIN, COUT, P, false, true>(x, gy, w, ws, bias, res, y, B, Hin, Hout, T, act, st);
         }
@@ -1061,18 +1155,18 @@ int launch_conv(const float* x, const float* gy, const float* w, WSpec ws, const
     return launch_conv_v<CIN, COUT, P, GATE, false>(x, gy, w, ws, bias, res, y, B, Hin, Hout, T, act, st);
 }
 
-template <int C, int D, bool DMA, bool BF16 = false>
+template <int C, int D, bool DMA, int PREC = 0>
 int launch_rb_fwd_v(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y, float* h1,
                     int B, int H, int T, hipStream_t st) {
-    using G = Geo<C, C, Res3x3<D>, DMA, BF16>;
+    using G = Geo<C, C, Res3x3<D>, DMA, PREC>;
     using R = RB<C>;
     constexpr int LDS = (G::W_FLOATS + R::CPAD * R::CP + 2 * R::CPAD + G::XS_FLOATS) * 4;
     static bool attr = false;
     if (!attr) {
-        TT_HIP(hipFuncSetAttribute((const void*)k_rb_fwd<C, D, DMA, BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        TT_HIP(hipFuncSetAttribute((const void*)k_rb_fwd<C, D, DMA, PREC>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr = true;
     }
-    hipLaunchKernelGGL((k_rb_fwd<C, D, DMA, BF16>), dim3(persistent_grid(ntiles_of(B, H, T), blocks_per_cu(LDS, 2))), dim3(NTHREADS), LDS,
+    hipLaunchKernelGGL((k_rb_fwd<C, D, DMA, PREC>), dim3(persistent_grid(ntiles_of(B, H, T), blocks_per_cu(LDS, 2))), dim3(NTHREADS), LDS,
                        st, x, w1, b1, w2, b2, y, h1, B, H, T);
     TT_LAUNCH_CHECK();
     return 0;
@@ -1080,10 +1174,11 @@ int launch_rb_fwd_v(const float* x, const float* w1, const float* b1, const floa
 
 template <int C, int D>
 int launch_rb_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y, float* h1,
-                  int B, int H, int T, hipStream_t st, bool bf16) {
+                  int B, int H, int T, hipStream_t st, int prec) {
     if (dma_ok(x, T)) {
         if constexpr (C >= 16) {
-            if (bf16) return launch_rb_fwd_v<C, D, true, true>(x, w1, b1, w2, b2, y, h1, B, H, T, st);
+            if (prec == 1) return launch_rb_fwd_v<C, D, true, 1>(x, w1, b1, w2, b2, y, h1, B, H, T, st);
+            if (prec == 2) return launch_rb_fwd_v<C, D, true, 2>(x, w1, b1, w2, b2, y, h1, B, H, T, st);
         }
         return launch_rb_fwd_v<C, D, true>(x, w1, b1, w2, b2, y, h1, B, H, T, st);
     }
@@ -1094,7 +1189,7 @@ constexpr int WGRAD_MAX_BLOCKS = 512;
 
 template <int CA, int CB, class WP, bool GP, bool GQ>
 int launch_wgrad(const float* Pt, const float* Pg, const float* Qt, const float* Qg, float* dw, float* dbias_p, long s_a,
-                 long s_b, long s_t, float* scratch, int B, int HP, int HQ, int T, hipStream_t st, bool bf16 = false) {
+                 long s_b, long s_t, float* scratch, int B, int HP, int HQ, int T, hipStream_t st, int prec = 0) {
     constexpr int CBS = CB > 16 ? 16 : CB;
     constexpr int NS = CB / CBS;
     using K = WGeo<CA, CBS, WP>;
@@ -1107,23 +1202,29 @@ int launch_wgrad(const float* Pt, const float* Pg, const float* Qt, const float*
             constexpr int LDS = cmax(Q::Q_FLOATS + WP::WTH * K::CAP * 64, K::RED_FLOATS) * 4;
             static bool attr = false;
             if (!attr) {
-                TT_HIP(hipFuncSetAttribute((const void*)k_wgrad_dma<CA, CB, CBS, WP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-                if constexpr (CA >= 16 && WP::NTAPS == 9)
-                    TT_HIP(hipFuncSetAttribute((const void*)k_wgrad_dma<CA, CB, CBS, WP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+                TT_HIP(hipFuncSetAttribute((const void*)k_wgrad_dma<CA, CB, CBS, WP, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+                if constexpr (CA >= 16 && WP::NTAPS == 9) {
+                    TT_HIP(hipFuncSetAttribute((const void*)k_wgrad_dma<CA, CB, CBS, WP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+                    TT_HIP(hipFuncSetAttribute((const void*)k_wgrad_dma<CA, CB, CBS, WP, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+                }
                 attr = true;
             }
             grid = persistent_grid(ntiles, blocks_per_cu(LDS, 4));
             if (grid * NS > WGRAD_MAX_BLOCKS) grid = WGRAD_MAX_BLOCKS / NS;
             bool done = false;
             if constexpr (CA >= 16 && WP::NTAPS == 9) {
-                if (bf16) {
-                    hipLaunchKernelGGL((k_wgrad_dma<CA, CB, CBS, WP, true>), dim3(grid, NS), dim3(64 * WP::WTH), LDS, st, Pt, Qt,
+                if (prec == 1) {
+                    hipLaunchKernelGGL((k_wgrad_dma<CA, CB, CBS, WP, 1>), dim3(grid, NS), dim3(64 * WP::WTH), LDS, st, Pt, Qt,
+                                       scratch, dbias_p, B, HP, HQ, T);
+                    done = true;
+                } else if (prec == 2) {
+                    hipLaunchKernelGGL((k_wgrad_dma<CA, CB, CBS, WP, 2>), dim3(grid, NS), dim3(64 * WP::WTH), LDS, st, Pt, Qt,
                                        scratch, dbias_p, B, HP, HQ, T);
                     done = true;
                 }
             }
             if (!done)
-                hipLaunchKernelGGL((k_wgrad_dma<CA, CB, CBS, WP, false>), dim3(grid, NS), dim3(64 * WP::WTH), LDS, st, Pt, Qt,
+                hipLaunchKernelGGL((k_wgrad_dma<CA, CB, CBS, WP, 0>), dim3(grid, NS), dim3(64 * WP::WTH), LDS, st, Pt, Qt,
                                    scratch, dbias_p, B, HP, HQ, T);
             TT_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_wgrad_reduce, dim3((K::CAP * NC + 255) / 256, NS), dim3(256), 0, st, (const float*)scratch, dw,
@@ -1169,7 +1270,7 @@ int launch_rb_bwd_a_v(const float* x, const float* h1, const float* dy, const fl
 template <int C, int D>
 int launch_rb_bwd(const float* x, const float* h1, const float* dy, const float* w1, const float* b1, const float* w2,
                   const float* b2, float* dx, float* dw1, float* db1, float* dw2, float* db2, float* ws, int B, int H, int T,
-                  hipStream_t st, bool bf16) {
+                  hipStream_t st, int prec) {
     int rc;
     if (h1) rc = launch_rb_bwd_a_v<C, 1, false, false>(x, h1, dy, w1, b1, w2, b2, db1, dw2, db2, ws, B, H, T, st);
     else rc = dma_ok(x, T) ? launch_rb_bwd_a_v<C, D, true, true>(x, h1, dy, w1, b1, w2, b2, db1, dw2, db2, ws, B, H, T, st)
@@ -1177,11 +1278,11 @@ int launch_rb_bwd(const float* x, const float* h1, const float* dy, const float*
     if (rc) return rc;
     // dx = dy + W1^T (*) dA1 : the same conv with in/out channels swapped and the taps reversed
     rc = launch_conv<C, C, Res3x3<D>, false>(ws, nullptr, w1, WSpec{9, (long)C * 9, -1, 8}, nullptr, dy, dx, B, H, H, T,
-                                             TT_ACT_NONE, st, bf16);
+                                             TT_ACT_NONE, st, prec);
     if (rc) return rc;
     // dW1[co][ci][tap] = sum dA1[co][pix] * x[ci][pix + tap]
     return launch_wgrad<C, C, WRes<D, (C <= 8 ? 8 : 4)>, false, false>(ws, nullptr, x, nullptr, dw1, nullptr, (long)C * 9, 9, 1,
-                                                                        ws + (long)B * C * H * T, B, H, H, T, st, bf16);
+                                                                        ws + (long)B * C * H * T, B, H, H, T, st, prec);
 }
 
 template <int C, int D>
@@ -1295,7 +1396,7 @@ extern "C" int tt_resblock_fwd(const float* x, const float* w1, const float* b1,
                                float* y, float* h1, int B, int C, int H, int T, int dilation, int flags, void* stream) {
     if (!x || !w1 || !b1 || !w2 || !b2 || !y || B <= 0 || H <= 0 || T <= 0) return TT_E_BADARG;
     hipStream_t st = tt_stream(stream);
-    const bool bf16 = (flags & TT_FLAG_BF16_OPERANDS) != 0;
+    const int bf16 = (flags & TT_FLAG_BF16_SPLIT) ? 2 : ((flags & TT_FLAG_BF16_OPERANDS) ? 1 : 0);
     if (C <= 8) return tt_small_rb_fwd(x, w1, b1, w2, b2, y, h1, B, C, H, T, dilation, st);     // HBM-bound levels: VALU kernels
     TT_DISPATCH_CD(launch_rb_fwd, x, w1, b1, w2, b2, y, h1, B, H, T, st, bf16)
 }
@@ -1320,7 +1421,7 @@ extern "C" int tt_resblock_bwd(const float* x, const float* h1, const float* dy,
             default: return TT_E_UNSUPPORTED;
         }
     }
-    const bool bf16 = (flags & TT_FLAG_BF16_OPERANDS) != 0;
+    const int bf16 = (flags & TT_FLAG_BF16_SPLIT) ? 2 : ((flags & TT_FLAG_BF16_OPERANDS) ? 1 : 0);
     TT_DISPATCH_CD(launch_rb_bwd, x, h1, dy, w1, b1, w2, b2, dx, dw1, db1, dw2, db2, ws, B, H, T, st, bf16)
 }
 

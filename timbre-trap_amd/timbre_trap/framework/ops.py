@@ -31,9 +31,9 @@ PRECISION = os.environ.get('TTRAP_PRECISION', 'fp32')
 
 
 def _flags():
-    if PRECISION not in ('fp32', 'bf16'):
-        raise ValueError('TTRAP_PRECISION / ops.PRECISION must be fp32 or bf16, got %r' % (PRECISION,))
-    return 1 if PRECISION == 'bf16' else 0
+    if PRECISION not in ('fp32', 'bf16', 'bf16x3'):
+        raise ValueError('TTRAP_PRECISION / ops.PRECISION must be fp32, bf16x3 or bf16, got %r' % (PRECISION,))
+    return {'fp32': 0, 'bf16': 1, 'bf16x3': 2}[PRECISION]
 
 
 @dataclass(frozen=True)

@@ -133,7 +133,16 @@ struct Geo {
     static constexpr int WBF_HALF = (CIN / 4) * 5 * CP * 8;             // bf16 elements of one image
     static constexpr int WBF_FLOATS = WBF_HALF / 2 * (PREC == 2 ? 2 : 1);
     static constexpr int W_FLOATS = BF16 ? WBF_FLOATS : KW * CP;
-    static constexpr int XS_FLOATS = 2 * BUF;
+    // bf16 modes stage the tile as channel-interleaved bf16: Z[buffer][hi | lo][pixel][4 channels], pixel = row * ZCP + col
+    // over rows h0 - D .. h0 + TH + D - 1 and columns t0 - 4 .. t0 + TW + 3 -> one ds_read_b64 per tap of a B fragment
+    static constexpr int ZCP = TW + 8;
+    static constexpr int ZPX = P::XR * ZCP;
+    static constexpr int NIMG = PREC == 2 ? 2 : 1;
+    static constexpr int Z_HALF = ZPX * 4;                    // bf16 elements of one image of one buffer
+    static constexpr int Z_FLOATS = 2 * NIMG * Z_HALF / 2;
+    static constexpr int ZPAIR = ZPX / 2;                     // pixel pairs staged per chunk (float2 per plane)
+    static constexpr int ZLD = (ZPAIR + NTHREADS - 1) / NTHREADS;
+    static constexpr int XS_FLOATS = BF16 ? Z_FLOATS : 2 * BUF;
 };
 
 __device__ float4 g_zero16;      // 16 zero bytes: DMA source of out-of-image pieces
@@ -195,6 +204,136 @@ __device__ __forceinline__ void build_weight_image_bf16(__bf16* img, const float
     }
 }
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+// Main loop of the bf16 / split-bf16 modes (3x3 geometry).  A chunk of 4 input channels is loaded 8 bytes per lane
+// and plane into registers while the previous chunk is multiplied, converted ONCE per element to bf16 (hi, and lo in
+// split mode) and written channel-interleaved into the other Z buffer: a B fragment (K = 2 taps x 4 channels per lane
+// group) is then two ds_read_b64, with no conversion in the multiply loop.  One barrier per chunk.
+template <int CIN, int COUT, class P, int PREC, class Epi>
+__device__ __forceinline__ void conv_mainloop_z(const float* __restrict__ x, const float* Wimg, float* xs, int B, int H, int T,
+                                                Epi&& epi) {
+    using G = Geo<CIN, COUT, P, true, PREC>;
+    constexpr int D = P::CH;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+    const int tiles_h = (H + TH - 1) / TH, tiles_t = (T + TW - 1) / TW;
+    const int ntiles = B * tiles_h * tiles_t;
+    const long plane = (long)H * T;
+    __bf16* Z = reinterpret_cast<__bf16*>(xs);
+    const __bf16* wimg = reinterpret_cast<const __bf16*>(Wimg);
+
+    float2 pre[G::ZLD][4];
+    int p_row0 = 0, p_col0 = 0;
+    auto issue = [&](int tile, int chunk) {
+        const Tile tl = decode_tile(tile, tiles_h, tiles_t, ntiles);
+        p_row0 = tl.h0 - D;
+        p_col0 = tl.t0 - 4;
+        const float* xb = x + ((long)tl.b * CIN + chunk * 4) * plane;
+#pragma unroll
+        for (int j = 0; j < G::ZLD; ++j) {
+            int pp = tid + NTHREADS * j;
+            if (pp >= G::ZPAIR) pp = G::ZPAIR - 1;
+            const int r = pp / (G::ZCP / 2), c2 = pp - r * (G::ZCP / 2);
+            int h = p_row0 + r, t = p_col0 + 2 * c2;
+            h = h < 0 ? 0 : (h >= H ? H - 1 : h);
+            t = t < 0 ? 0 : (t >= T ? T - 2 : t);
+            const int o = h * T + t;
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci) pre[j][ci] = *reinterpret_cast<const float2*>(xb + ci * plane + o);
+        }
+    };
+    auto commit = [&](int buf) {
+        __bf16* zh = Z + (buf * G::NIMG) * G::Z_HALF;
+#pragma unroll
+        for (int j = 0; j < G::ZLD; ++j) {
+            const int pp = tid + NTHREADS * j;
+            if (pp < G::ZPAIR) {
+                const int r = pp / (G::ZCP / 2), c2 = pp - r * (G::ZCP / 2);
+                const int h = p_row0 + r, t = p_col0 + 2 * c2;
+                const bool ok = h >= 0 && h < H && t >= 0 && t < T;
+                float v[8];
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci) { v[ci] = ok ? pre[j][ci].x : 0.f; v[4 + ci] = ok ? pre[j][ci].y : 0.f; }
+                bf16x8 hi, lo;
+                split_bf16<PREC>(v, hi, lo);
+                *reinterpret_cast<bf16x8*>(zh + pp * 8) = hi;
+                if constexpr (PREC == 2) *reinterpret_cast<bf16x8*>(zh + G::Z_HALF + pp * 8) = lo;
+            }
+        }
+    };
+
+    // element offsets of this lane's taps inside a Z image (tap 2g, tap 2g+1, tap 8)
+    const int ta = 2 * g, tb = 2 * g + 1;
+    // column n = l15 of 16-pixel group nt is pixel 4 * l15 + nt of the row: a lane's four accumulators of one channel are
+    // four CONSECUTIVE pixels, so the epilogue moves 16 bytes per lane
+    const int pa = ((wave + (ta / 3) * D) * G::ZCP + (4 - D) + (ta % 3) * D + 4 * l15) * 4;
+    const int pb = ((wave + (tb / 3) * D) * G::ZCP + (4 - D) + (tb % 3) * D + 4 * l15) * 4;
+    const int p8 = ((wave + 2 * D) * G::ZCP + (4 - D) + 2 * D + 4 * l15) * 4;
+
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    int buf = 0;
+    issue(tile, 0);
+    commit(0);
+    __syncthreads();
+    for (; tile < ntiles; tile += gridDim.x) {
+        f32x4 acc[G::MT][4];
+#pragma unroll
+        for (int mt = 0; mt < G::MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int chunk = 0; chunk < G::NCH; ++chunk) {
+            const bool more_chunks = chunk + 1 < G::NCH;
+            const bool more = more_chunks || tile + (int)gridDim.x < ntiles;
+            if (more) issue(more_chunks ? tile : tile + (int)gridDim.x, more_chunks ? chunk + 1 : 0);
+            const __bf16* zh = Z + (buf * G::NIMG) * G::Z_HALF;
+            bf16x8 a0[G::MT], a1[G::MT], a0l[G::MT], a1l[G::MT];
+            const bf16x8 zero8 = {};
+#pragma unroll
+            for (int mt = 0; mt < G::MT; ++mt) {
+                const int o0 = (((chunk * 5 + g) * G::CP) + mt * 16 + l15) * 8, o1 = (((chunk * 5 + 4) * G::CP) + mt * 16 + l15) * 8;
+                a0[mt] = *reinterpret_cast<const bf16x8*>(wimg + o0);
+                a1[mt] = g == 0 ? *reinterpret_cast<const bf16x8*>(wimg + o1) : zero8;
+                if constexpr (PREC == 2) {
+                    a0l[mt] = *reinterpret_cast<const bf16x8*>(wimg + G::WBF_HALF + o0);
+                    a1l[mt] = g == 0 ? *reinterpret_cast<const bf16x8*>(wimg + G::WBF_HALF + o1) : zero8;
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                bf16x8 b0, b1, b0l, b1l;
+                {
+                    const uint2 ua = *reinterpret_cast<const uint2*>(zh + pa + nt * 4), ub = *reinterpret_cast<const uint2*>(zh + pb + nt * 4);
+                    uint2 u8 = *reinterpret_cast<const uint2*>(zh + p8 + nt * 4);
+                    if (g != 0) u8 = uint2{0u, 0u};
+                    b0 = as_bf16x8(u32x4{ua.x, ua.y, ub.x, ub.y});
+                    b1 = as_bf16x8(u32x4{u8.x, u8.y, 0u, 0u});
+                }
+                if constexpr (PREC == 2) {
+                    const __bf16* zl = zh + G::Z_HALF;
+                    const uint2 ua = *reinterpret_cast<const uint2*>(zl + pa + nt * 4), ub = *reinterpret_cast<const uint2*>(zl + pb + nt * 4);
+                    uint2 u8 = *reinterpret_cast<const uint2*>(zl + p8 + nt * 4);
+                    if (g != 0) u8 = uint2{0u, 0u};
+                    b0l = as_bf16x8(u32x4{ua.x, ua.y, ub.x, ub.y});
+                    b1l = as_bf16x8(u32x4{u8.x, u8.y, 0u, 0u});
+                }
+#pragma unroll
+                for (int mt = 0; mt < G::MT; ++mt) {
+                    acc[mt][nt] = mma_bf16<PREC>(a0[mt], a0l[mt], b0, b0l, acc[mt][nt]);
+                    acc[mt][nt] = mma_bf16<PREC>(a1[mt], a1l[mt], b1, b1l, acc[mt][nt]);
+                }
+            }
+            if (!more_chunks) epi(decode_tile(tile, tiles_h, tiles_t, ntiles), acc);
+            if (more) commit(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+}
+
+
 // The pipelined implicit-GEMM main loop over the tiles of one workgroup.  `epi(tile, acc)` consumes a finished tile.
 template <int CIN, int COUT, class P, bool GATE, bool DMA, int PREC, class Epi>
 __device__ __forceinline__ void conv_mainloop(const float* __restrict__ x, const float* __restrict__ gy, const float* Wimg,
@@ -203,6 +342,10 @@ __device__ __forceinline__ void conv_mainloop(const float* __restrict__ x, const
     constexpr bool BF16 = PREC != 0;
     static_assert(!BF16 || (DMA && P::NTAPS == 9), "bf16 operands: 3x3 geometry on the DMA path");
     using G = Geo<CIN, COUT, P, DMA, PREC>;
+    if constexpr (BF16) {
+        conv_mainloop_z<CIN, COUT, P, PREC>(x, Wimg, xs, B, Hin, T, epi);
+        return;
+    }
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     const int tiles_h = (Hout + TH - 1) / TH, tiles_t = (T + TW - 1) / TW;
     const int ntiles = B * tiles_h * tiles_t;
@@ -301,41 +444,7 @@ __device__ __forceinline__ void conv_mainloop(const float* __restrict__ x, const
             }
             const float* xb = xs + buf * G::BUF;
             const int c0 = chunk * G::CC;
-            if constexpr (BF16) {
-                // K = 32 = 8 taps x 4 channels: lane group g supplies taps 2g, 2g+1 (block 0) / tap 8 (block 1, g = 0 only)
-                const __bf16* wimg = reinterpret_cast<const __bf16*>(Wimg);
-                const float* pa = xb + P::lrow(2 * g, wave) * G::XCP + (G::HL - P::CH) + P::lcol(2 * g) + l15;
-                const float* pb = xb + P::lrow(2 * g + 1, wave) * G::XCP + (G::HL - P::CH) + P::lcol(2 * g + 1) + l15;
-                const float* p8 = xb + P::lrow(8, wave) * G::XCP + (G::HL - P::CH) + P::lcol(8) + l15;
-                bf16x8 a0[G::MT], a1[G::MT], a0l[G::MT], a1l[G::MT];
-                const bf16x8 zero8 = {};
-#pragma unroll
-                for (int mt = 0; mt < G::MT; ++mt) {
-                    const int o0 = (((chunk * 5 + g) * G::CP) + mt * 16 + l15) * 8, o1 = (((chunk * 5 + 4) * G::CP) + mt * 16 + l15) * 8;
-                    a0[mt] = *reinterpret_cast<const bf16x8*>(wimg + o0);
-                    a1[mt] = g == 0 ? *reinterpret_cast<const bf16x8*>(wimg + o1) : zero8;
-                    if constexpr (PREC == 2) {
-                        a0l[mt] = *reinterpret_cast<const bf16x8*>(wimg + G::WBF_HALF + o0);
-                        a1l[mt] = g == 0 ? *reinterpret_cast<const bf16x8*>(wimg + G::WBF_HALF + o1) : zero8;
-                    }
-                }
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    float v[8];
-                    bf16x8 b0, b0l, b1, b1l;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { v[j] = pa[j * G::PLANE + nt * 16]; v[4 + j] = pb[j * G::PLANE + nt * 16]; }
-                    split_bf16<PREC>(v, b0, b0l);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { v[j] = (g == 0) ? p8[j * G::PLANE + nt * 16] : 0.f; v[4 + j] = 0.f; }
-                    split_bf16<PREC>(v, b1, b1l);
-#pragma unroll
-                    for (int mt = 0; mt < G::MT; ++mt) {
-                        acc[mt][nt] = mma_bf16<PREC>(a0[mt], a0l[mt], b0, b0l, acc[mt][nt]);
-                        acc[mt][nt] = mma_bf16<PREC>(a1[mt], a1l[mt], b1, b1l, acc[mt][nt]);
-                    }
-                }
-            } else {
+            {
 #pragma unroll 1
             for (int tp = 0; tp < P::NTAPS; ++tp) {
                 const int wt = P::wtap(tp, wave);
@@ -379,21 +488,64 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_conv_mfma(const float* __restri
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, l15 = lane & 15;
     const long oplane = (long)Hout * T;
     conv_mainloop<CIN, COUT, P, GATE, DMA, PREC>(x, gy, Wimg, xs, B, Hin, Hout, T, [&](const Tile& tl, f32x4 (&acc)[G::MT][4]) {
-        const int h = tl.h0 + wave;
+        // addressing: a wave-uniform 64-bit base per (clip, channel mt*16 + r) plus one 32-bit lane offset per 16-column
+        // group (channel part 4g of the lane included) -- no per-element 64-bit pointers to keep alive
+        const int ub = __builtin_amdgcn_readfirstlane(tl.b), uh0 = __builtin_amdgcn_readfirstlane(tl.h0),
+                  ut0 = __builtin_amdgcn_readfirstlane(tl.t0);
+        const int h = uh0 + wave;
         if (h >= Hout) return;
-        float rv[G::MT][4][4];
-        if (res) {      // all residual loads first (clamped, branch-free): one latency instead of one per store
+        static_assert(COUT % 4 == 0, "lane groups own 4 consecutive output channels");
+        const int g4 = (COUT % 16 == 0) ? 4 * g : (4 * g < COUT ? 4 * g : COUT - 4);      // clamped: loads stay in bounds
+        const long cbase = (long)ub * COUT * oplane;
+        if constexpr (PREC != 0) {
+            // bf16 main loop: accumulators nt = 0..3 of a lane are pixels t .. t + 3 -> 16-byte loads and stores
+            const int t = ut0 + 4 * l15;
+            const bool tv = t < T;
+            const unsigned vo = (unsigned)(g4 * (int)oplane + h * T + (tv ? t : T - 4));
+            float4 rv[G::MT][4];
+            if (res) {
+#pragma unroll
+                for (int mt = 0; mt < G::MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        rv[mt][r] = *reinterpret_cast<const float4*>(res + cbase + (long)((mt * 16 + r < COUT) ? mt * 16 + r : 0) * oplane + vo);
+            }
 #pragma unroll
             for (int mt = 0; mt < G::MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = mt * 16 + 4 * g + r;
-                    const float* rb = res + ((long)tl.b * COUT + (m < COUT ? m : COUT - 1)) * oplane + (long)h * T;
+                    if (m >= COUT || !tv) continue;
+                    const float bv = bias ? bias[m] : 0.f;
+                    float v[4];
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) {
-                        const int t = tl.t0 + nt * 16 + l15;
-                        rv[mt][r][nt] = rb[t < T ? t : T - 1];
+                        v[nt] = acc[mt][nt][r] + bv;
+                        if (act == TT_ACT_ELU) v[nt] = elu1(v[nt]);
                     }
+                    if (res) { v[0] += rv[mt][r].x; v[1] += rv[mt][r].y; v[2] += rv[mt][r].z; v[3] += rv[mt][r].w; }
+                    *reinterpret_cast<float4*>(y + cbase + (long)(mt * 16 + r) * oplane + vo) = float4{v[0], v[1], v[2], v[3]};
+                }
+            return;
+        }
+        unsigned vo[4];
+        bool tv[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int t = ut0 + nt * 16 + l15;
+            tv[nt] = t < T;
+            vo[nt] = (unsigned)(g4 * (int)oplane + h * T + (tv[nt] ? t : T - 1));
+        }
+        float rv[G::MT][4][4];
+        if (res) {      // all residual loads first (branch-free): one latency instead of one per store
+#pragma unroll
+            for (int mt = 0; mt < G::MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int mu = (mt * 16 + r < COUT) ? mt * 16 + r : 0;
+                    const float* rb = res + cbase + (long)mu * oplane;
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) rv[mt][r][nt] = rb[vo[nt]];
                 }
         }
 #pragma unroll
@@ -403,15 +555,14 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_conv_mfma(const float* __restri
                 const int m = mt * 16 + 4 * g + r;
                 if (m >= COUT) continue;
                 const float bv = bias ? bias[m] : 0.f;
-                const long base = ((long)tl.b * COUT + m) * oplane + (long)h * T;
+                float* yb = y + cbase + (long)(mt * 16 + r) * oplane;
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
-                    const int t = tl.t0 + nt * 16 + l15;
-                    if (t >= T) continue;
+                    if (!tv[nt]) continue;
                     float v = acc[mt][nt][r] + bv;
                     if (act == TT_ACT_ELU) v = elu1(v);
                     if (res) v += rv[mt][r][nt];
-                    y[base + t] = v;
+                    yb[vo[nt]] = v;
                 }
             }
     });
@@ -465,7 +616,22 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_rb_fwd(const float* __restrict_
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, l15 = lane & 15;
     const long plane = (long)H * T;
     conv_mainloop<C, C, P, false, DMA, PREC>(x, nullptr, Wimg, xs, B, H, H, T, [&](const Tile& tl, f32x4 (&acc)[G::MT][4]) {
-        const int h = tl.h0 + wave;
+        // addressing as in k_conv_mfma: uniform base per (clip, channel m2*16 + r) + 32-bit lane offsets; in the bf16 modes
+        // (PX4) accumulators nt = 0..3 are four consecutive pixels: 16 bytes per lane for the residual, h1 and y
+        constexpr bool PX4 = PREC != 0;
+        const int ub = __builtin_amdgcn_readfirstlane(tl.b), uh0 = __builtin_amdgcn_readfirstlane(tl.h0),
+                  ut0 = __builtin_amdgcn_readfirstlane(tl.t0);
+        const int h = uh0 + wave;
+        const int g4 = (C % 16 == 0) ? 4 * g : (4 * g < C ? 4 * g : C - 4);
+        unsigned vo[4];
+        bool tv[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int t = PX4 ? ut0 + 4 * l15 + nt : ut0 + nt * 16 + l15;
+            tv[nt] = t < T && h < H;
+            vo[nt] = (unsigned)(g4 * (int)plane + (h < H ? h : H - 1) * T + (t < T ? t : T - (PX4 ? 4 - nt : 1)));
+        }
+        const long cbase = (long)ub * C * plane;
         f32x4 acc2[G::MT][4];
 #pragma unroll
         for (int mt = 0; mt < G::MT; ++mt)
@@ -475,18 +641,19 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_rb_fwd(const float* __restrict_
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[mt][nt][r] = elu1(acc[mt][nt][r] + b1s[mt * 16 + 4 * g + r]);
             }
-        if (h1out && h < H) {       // hidden activation for the backward pass
+        if (h1out) {       // hidden activation for the backward pass
 #pragma unroll
             for (int m2 = 0; m2 < G::MT; ++m2)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int co = m2 * 16 + 4 * g + r;
-                    if (co >= C) continue;
-                    float* hb = h1out + ((long)tl.b * C + co) * plane + (long)h * T;
+                    if (m2 * 16 + 4 * g + r >= C) continue;
+                    float* hb = h1out + cbase + (long)(m2 * 16 + r) * plane;
+                    if constexpr (PX4) {
+                        if (tv[0]) *reinterpret_cast<float4*>(hb + vo[0]) = float4{acc[m2][0][r], acc[m2][1][r], acc[m2][2][r], acc[m2][3][r]};
+                    } else {
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) {
-                        const int t = tl.t0 + nt * 16 + l15;
-                        if (t < T) hb[t] = acc[m2][nt][r];
+                        for (int nt = 0; nt < 4; ++nt)
+                            if (tv[nt]) hb[vo[nt]] = acc[m2][nt][r];
                     }
                 }
         }
@@ -504,24 +671,20 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_rb_fwd(const float* __restrict_
                     for (int m2 = 0; m2 < G::MT; ++m2) acc2[m2][nt] = mfma16(a2[m2], acc[mt][nt][r], acc2[m2][nt]);
             }
         if (h >= H) return;
-        // the residual input of this lane's outputs: all loads are issued together (clamped addresses, no branches)
-        // once the 3x3 accumulators are dead: one exposed latency per tile instead of one per store
-        const int hc = h < H ? h : H - 1;
+        // the residual input: all loads issued together once the 3x3 accumulators are dead (one exposed latency per tile)
         float xres[G::MT][4][4];
-        int toff[4];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int t = tl.t0 + nt * 16 + l15;
-            toff[nt] = t < T ? t : T - 1;
-        }
 #pragma unroll
         for (int m2 = 0; m2 < G::MT; ++m2)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int co = m2 * 16 + 4 * g + r;
-                const float* xb = x + ((long)tl.b * C + (co < C ? co : C - 1)) * plane + (long)hc * T;
+                const float* xb = x + cbase + (long)((m2 * 16 + r < C) ? m2 * 16 + r : 0) * plane;
+                if constexpr (PX4) {
+                    const float4 v = *reinterpret_cast<const float4*>(xb + vo[0]);
+                    xres[m2][r][0] = v.x; xres[m2][r][1] = v.y; xres[m2][r][2] = v.z; xres[m2][r][3] = v.w;
+                } else {
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) xres[m2][r][nt] = xb[toff[nt]];
+                    for (int nt = 0; nt < 4; ++nt) xres[m2][r][nt] = xb[vo[nt]];
+                }
             }
 #pragma unroll
         for (int m2 = 0; m2 < G::MT; ++m2)
@@ -530,11 +693,15 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_rb_fwd(const float* __restrict_
                 const int co = m2 * 16 + 4 * g + r;
                 if (co >= C) continue;
                 const float bias = b2s[co];
-                float* yb = y + ((long)tl.b * C + co) * plane + (long)h * T;
+                float* yb = y + cbase + (long)(m2 * 16 + r) * plane;
+                if constexpr (PX4) {
+                    if (tv[0]) *reinterpret_cast<float4*>(yb + vo[0]) =
+                        float4{elu1(acc2[m2][0][r] + bias) + xres[m2][r][0], elu1(acc2[m2][1][r] + bias) + xres[m2][r][1],
+                               elu1(acc2[m2][2][r] + bias) + xres[m2][r][2], elu1(acc2[m2][3][r] + bias) + xres[m2][r][3]};
+                } else {
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    const int t = tl.t0 + nt * 16 + l15;
-                    if (t < T) yb[t] = elu1(acc2[m2][nt][r] + bias) + xres[m2][r][nt];
+                    for (int nt = 0; nt < 4; ++nt)
+                        if (tv[nt]) yb[vo[nt]] = elu1(acc2[m2][nt][r] + bias) + xres[m2][r][nt];
                 }
             }
     });

@@ -756,6 +756,10 @@ __global__ __launch_bounds__(NTHREADS) void k_rb_bwd_a(const float* __restrict__
         for (int r = 0; r < 4; ++r) { db1acc[a][r] = 0.f; db2acc[a][r] = 0.f; }
     }
 
+    // hidden activation read back (not recomputed): the pixel <-> (nt, lane) assignment is free, so a lane takes four
+    // consecutive pixels per channel and every global access of the kernel is 16 bytes per lane
+    const bool wide = !RECOMP && (C % 16 == 0) && (T % 4 == 0) && ((reinterpret_cast<uintptr_t>(h1in) | reinterpret_cast<uintptr_t>(dy) |
+                                                                     reinterpret_cast<uintptr_t>(da1)) & 15) == 0;
     auto epi = [&](const Tile& tl, f32x4 (&h1)[G::MT][4]) {
         const int h = tl.h0 + wave;
         f32x4 a2[G::MT][4];
@@ -790,12 +794,22 @@ __global__ __launch_bounds__(NTHREADS) void k_rb_bwd_a(const float* __restrict__
                 const int co = m2 * 16 + 4 * g + r;
                 const float bias = b2s[co];
                 const long base = ((long)tl.b * C + (co < C ? co : 0)) * plane + (long)(h < H ? h : 0) * T;
+                float dv[4];
+                if (wide) {
+                    const int t = tl.t0 + 4 * l15;
+                    float4 v = *reinterpret_cast<const float4*>(dy + base + (t < T ? t : 0));
+                    if (!(h < H && t < T)) v = float4{0.f, 0.f, 0.f, 0.f};
+                    dv[0] = v.x; dv[1] = v.y; dv[2] = v.z; dv[3] = v.w;
+                } else {
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const int t = tl.t0 + nt * 16 + l15;
+                        dv[nt] = (co < C && h < H && t < T) ? dy[base + t] : 0.f;
+                    }
+                }
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
-                    const int t = tl.t0 + nt * 16 + l15;
-                    float d = 0.f;
-                    if (co < C && h < H && t < T) d = dy[base + t];
-                    const float gd = d * elu_grad_from_out(elu1(a2[m2][nt][r] + bias));
+                    const float gd = dv[nt] * elu_grad_from_out(elu1(a2[m2][nt][r] + bias));
                     a2[m2][nt][r] = gd;
                     db2acc[m2][r] += gd;
                 }
@@ -825,12 +839,21 @@ __global__ __launch_bounds__(NTHREADS) void k_rb_bwd_a(const float* __restrict__
             for (int r = 0; r < 4; ++r) {
                 const int co = mt * 16 + 4 * g + r;
                 const long base = ((long)tl.b * C + (co < C ? co : 0)) * plane + (long)(h < H ? h : 0) * T;
+                float gv[4];
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
-                    const int t = tl.t0 + nt * 16 + l15;
-                    const float gd = d1[mt][nt][r] * elu_grad_from_out(h1[mt][nt][r]);
-                    db1acc[mt][r] += gd;
-                    if (co < C && h < H && t < T) da1[base + t] = gd;
+                    gv[nt] = d1[mt][nt][r] * elu_grad_from_out(h1[mt][nt][r]);
+                    db1acc[mt][r] += gv[nt];
+                }
+                if (wide) {
+                    const int t = tl.t0 + 4 * l15;
+                    if (h < H && t < T) *reinterpret_cast<float4*>(da1 + base + t) = float4{gv[0], gv[1], gv[2], gv[3]};
+                } else {
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const int t = tl.t0 + nt * 16 + l15;
+                        if (co < C && h < H && t < T) da1[base + t] = gv[nt];
+                    }
                 }
             }
         // dW2[co2][c] += sum_pix dA2[co2][pix] * h1[c][pix]: 16 pixels at a time through the wave's own LDS tiles
@@ -870,6 +893,20 @@ __global__ __launch_bounds__(NTHREADS) void k_rb_bwd_a(const float* __restrict__
             const Tile tl = decode_tile(tile, tiles_h, tiles_t, ntiles);
             const int h = tl.h0 + wave;
             f32x4 h1[G::MT][4];
+            if (wide) {     // column n of group nt = pixel 4 n + nt: a lane's four values per channel are one 16-byte load
+                const int t = tl.t0 + 4 * l15;
+                const bool ok = h < H && t < T;
+                const long cb = (long)tl.b * C * plane;
+                const unsigned vo = (unsigned)(4 * g * (int)plane + (h < H ? h : 0) * T + (t < T ? t : 0));
+#pragma unroll
+                for (int mt = 0; mt < G::MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float4 v = *reinterpret_cast<const float4*>(h1in + cb + (long)(mt * 16 + r) * plane + vo);
+                        if (!ok) v = float4{0.f, 0.f, 0.f, 0.f};
+                        h1[mt][0][r] = v.x; h1[mt][1][r] = v.y; h1[mt][2][r] = v.z; h1[mt][3][r] = v.w;
+                    }
+            } else {
 #pragma unroll
             for (int mt = 0; mt < G::MT; ++mt)
 #pragma unroll
@@ -882,6 +919,7 @@ __global__ __launch_bounds__(NTHREADS) void k_rb_bwd_a(const float* __restrict__
                         h1[mt][nt][r] = (co < C && h < H && t < T) ? h1in[base + t] : 0.f;
                     }
                 }
+            }
             epi(tl, h1);
         }
     }

@@ -86,6 +86,7 @@ class ConvFn(torch.autograd.Function):
                                 KH * KW, Cout * KH * KW, KW, 1, cfg.act, stream_ptr()), 'tt_conv2d(T)')
         ctx.cfg = cfg
         ctx.has_bias = b is not None
+        ctx.params = (w, b)
         ctx.save_for_backward(x, w, y if cfg.act == ACT_ELU else None)
         return y
 
@@ -104,7 +105,7 @@ class ConvFn(torch.autograd.Function):
             check(lib.tt_elu_bwd(ptr(dy), ptr(y), ptr(g), dy.numel(), st), 'tt_elu_bwd')
         else:
             g = dy
-        dx = dw = db = None
+        dx = dw = db = rw = rb = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             if cfg.kind == 'conv' and cfg.stride == 1:
@@ -125,8 +126,8 @@ class ConvFn(torch.autograd.Function):
                                     B, Cout, Hout, T, Cin, Hin, KH, KW, cfg.stride, 1, 1, 0, 0, 0,
                                     Cout * KH * KW, KH * KW, KW, 1, ACT_NONE, st), 'tt_conv2d(dgrad of T)')
         if ctx.needs_input_grad[1]:
-            dw = torch.zeros_like(w)
-            db = torch.zeros(Cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            dw, rw = _grad_target(ctx.params[0])
+            db, rb = _grad_target(ctx.params[1]) if ctx.has_bias else (None, None)
             if cfg.kind == 'conv':
                 check(lib.tt_conv2d_wgrad(ptr(x), ptr(g), ptr(dw), ptr(db), B, Cin, Hin, T, Cout, Hout, KH, KW,
                                           cfg.stride, cfg.dil, cfg.dil, cfg.pad_h, cfg.pad_w,
@@ -138,7 +139,7 @@ class ConvFn(torch.autograd.Function):
                                           Cout * KH * KW, KH * KW, KW, 1, st), 'tt_conv2d_wgrad(T)')
                 if db is not None:
                     check(lib.tt_channel_sum(ptr(g), ptr(db), B, Cout, Hout * T, st), 'tt_channel_sum')
-        return dx, dw, db, None
+        return dx, (rw if ctx.needs_input_grad[1] else None), (rb if ctx.needs_input_grad[1] else None), None
 
 
 def conv(x, w, b, cfg):
@@ -187,6 +188,21 @@ class ScaleFn(torch.autograd.Function):
         return de, ds, None
 
 
+def _grad_target(p):
+    """
+    Where a backward kernel accumulates the gradient of parameter ``p``: (buffer, value returned to autograd).
+    FusedAdamW keeps every ``.grad`` as a view of ONE flat fp32 buffer and tags its parameters; their kernels then add
+    straight into that view (all weight-gradient entry points accumulate, +=) and autograd gets ``None`` -- no zero-fill
+    and no ``grad += new`` launch per parameter use (~740 five-microsecond launches per train step).  Any other tensor
+    gets a fresh zero buffer that is returned as usual.
+    """
+    g = p.grad if getattr(p, '_ttrap_accumulate', False) else None
+    if g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.shape == p.shape and g.device == p.device:
+        return g, None
+    z = torch.zeros(p.shape, dtype=torch.float32, device=p.device)
+    return z, z
+
+
 class ResBlockFn(torch.autograd.Function):
     """Fused ResidualConv2dBlock (reference modules.py:755-777); hidden activations recomputed in backward."""
 
@@ -203,6 +219,7 @@ class ResBlockFn(torch.autograd.Function):
                                              _flags(), stream_ptr()), 'tt_resblock_fwd')
         ctx.dilation = dilation
         ctx.flags = _flags()
+        ctx.params = (w1, b1, w2, b2)
         ctx.save_for_backward(x, w1, b1, w2, b2, h1)
         return y
 
@@ -212,13 +229,13 @@ class ResBlockFn(torch.autograd.Function):
         dy = _f32c(dy)
         B, C, H, T = x.shape
         dx = torch.empty_like(x)
-        dw1, db1, dw2, db2 = (torch.zeros_like(t) for t in (w1, b1, w2, b2))
+        (dw1, r1), (db1, r2), (dw2, r3), (db2, r4) = (_grad_target(t) for t in ctx.params)
         ws = torch.empty(x.numel() + _hip.lib().tt_wgrad_scratch_floats(), dtype=torch.float32, device=x.device)
         with _hip.timed('resblock_bwd_C%d' % C):
             check(_hip.lib().tt_resblock_bwd(ptr(x), ptr(h1), ptr(dy), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(dx), ptr(dw1),
                                              ptr(db1), ptr(dw2), ptr(db2), ptr(ws), B, C, H, T, ctx.dilation,
                                              ctx.flags, stream_ptr()), 'tt_resblock_bwd')
-        return dx, dw1, db1, dw2, db2, None
+        return dx, r1, r2, r3, r4, None
 
 
 class StridedConvFn(torch.autograd.Function):
@@ -231,6 +248,7 @@ class StridedConvFn(torch.autograd.Function):
         B, C, H, T = x.shape
         y = torch.empty((B, 2 * C, (H - 4) // 2 + 1, T), dtype=torch.float32, device=x.device)
         check(_hip.lib().tt_sconv_fwd(ptr(x), ptr(w), ptr(b), ptr(y), B, C, H, T, stream_ptr()), 'tt_sconv_fwd')
+        ctx.params = (w, b)
         ctx.save_for_backward(x, w, y)
         return y
 
@@ -240,12 +258,11 @@ class StridedConvFn(torch.autograd.Function):
         dy = _f32c(dy)
         B, C, H, T = x.shape
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dw = torch.zeros_like(w)
-        db = torch.zeros(2 * C, dtype=torch.float32, device=x.device)
+        (dw, rw), (db, rb) = (_grad_target(t) for t in ctx.params)
         scratch = torch.empty(_hip.lib().tt_wgrad_scratch_floats() + dy.numel(), dtype=torch.float32, device=x.device)
         check(_hip.lib().tt_sconv_bwd(ptr(x), ptr(y), ptr(dy), ptr(w), ptr(dx), ptr(dw), ptr(db), ptr(scratch), B, C, H, T,
                                       stream_ptr()), 'tt_sconv_bwd')
-        return dx, dw, db
+        return dx, rw, rb
 
 
 class TransposedConvFn(torch.autograd.Function):
@@ -260,6 +277,7 @@ class TransposedConvFn(torch.autograd.Function):
         y = torch.empty((B, C, 2 * H + 2 + out_pad, T), dtype=torch.float32, device=x.device)
         check(_hip.lib().tt_tconv_fwd(ptr(x), ptr(w), ptr(b), ptr(y), B, C, H, T, out_pad, stream_ptr()), 'tt_tconv_fwd')
         ctx.out_pad = out_pad
+        ctx.params = (w, b)
         ctx.save_for_backward(x, w, y)
         return y
 
@@ -270,12 +288,11 @@ class TransposedConvFn(torch.autograd.Function):
         B, C2, H, T = x.shape
         C = C2 // 2
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dw = torch.zeros_like(w)
-        db = torch.zeros(C, dtype=torch.float32, device=x.device)
+        (dw, rw), (db, rb) = (_grad_target(t) for t in ctx.params)
         scratch = torch.empty(_hip.lib().tt_wgrad_scratch_floats() + dy.numel(), dtype=torch.float32, device=x.device)
         check(_hip.lib().tt_tconv_bwd(ptr(x), ptr(y), ptr(dy), ptr(w), ptr(dx), ptr(dw), ptr(db), ptr(scratch), B, C, H, T,
                                       ctx.out_pad, stream_ptr()), 'tt_tconv_bwd')
-        return dx, dw, db, None
+        return dx, rw, rb, None
 
 
 def strided_conv(x, w, b, win, hop):
@@ -318,6 +335,7 @@ class LatentEncodeFn(torch.autograd.Function):
         check(_hip.lib().tt_gemm(ptr(w), ptr(x), ptr(y), ptr(b), D, T, K, 0, 0, K, T, T, B, 0, K * T, D * T, 0,
                                  1.0, 0.0, 1 if b is not None else 0, 1, ACT_NONE, stream_ptr()), 'tt_gemm(convlat)')
         ctx.has_bias = b is not None
+        ctx.params = (w, b)
         ctx.save_for_backward(x, w)
         return y
 
@@ -328,19 +346,19 @@ class LatentEncodeFn(torch.autograd.Function):
         B, C, E, T = x.shape
         D, K = w.size(0), C * E
         lib, st = _hip.lib(), stream_ptr()
-        dx = dw = db = None
+        dx = dw = db = rw = rb = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             check(lib.tt_gemm(ptr(w), ptr(dy), ptr(dx), None, K, T, D, 1, 0, K, T, T, B, 0, D * T, K * T, 0,
                               1.0, 0.0, 0, 1, ACT_NONE, st), 'tt_gemm(convlat dgrad)')
         if ctx.needs_input_grad[1]:
-            dw = torch.zeros_like(w)
+            dw, rw = _grad_target(ctx.params[0])
             check(lib.tt_gemm(ptr(dy), ptr(x), ptr(dw), None, D, K, T, 0, 1, T, T, K, B, D * T, K * T, 0, 1,
                               1.0, 1.0, 0, 1, ACT_NONE, st), 'tt_gemm(convlat wgrad)')
             if ctx.has_bias:
-                db = torch.zeros(D, dtype=torch.float32, device=x.device)
+                db, rb = _grad_target(ctx.params[1])
                 check(lib.tt_channel_sum(ptr(dy), ptr(db), B, D, T, st), 'tt_channel_sum')
-        return dx, dw, db
+        return dx, rw, rb
 
 
 class LatentDecodeFn(torch.autograd.Function):
@@ -356,6 +374,7 @@ class LatentDecodeFn(torch.autograd.Function):
         check(_hip.lib().tt_gemm(ptr(w), ptr(z), ptr(y), ptr(b), Mo, T, K, 1, 0, Mo, T, T, B, 0, K * T, Mo * T, 0,
                                  1.0, 0.0, 2 if b is not None else 0, E, ACT_ELU, stream_ptr()), 'tt_gemm(dec convin)')
         ctx.has_bias = b is not None
+        ctx.params = (w, b)
         ctx.save_for_backward(z, w, y)
         return y
 
@@ -369,19 +388,19 @@ class LatentDecodeFn(torch.autograd.Function):
         lib, st = _hip.lib(), stream_ptr()
         g = torch.empty_like(dy)
         check(lib.tt_elu_bwd(ptr(dy), ptr(y), ptr(g), dy.numel(), st), 'tt_elu_bwd')
-        dz = dw = db = None
+        dz = dw = db = rw = rb = None
         if ctx.needs_input_grad[0]:
             dz = torch.empty_like(z)
             check(lib.tt_gemm(ptr(w), ptr(g), ptr(dz), None, K, T, Mo, 0, 0, Mo, T, T, B, 0, Mo * T, K * T, 0,
                               1.0, 0.0, 0, 1, ACT_NONE, st), 'tt_gemm(dec convin dgrad)')
         if ctx.needs_input_grad[1]:
-            dw = torch.zeros_like(w)
+            dw, rw = _grad_target(ctx.params[0])
             check(lib.tt_gemm(ptr(z), ptr(g), ptr(dw), None, K, Mo, T, 0, 1, T, T, Mo, B, K * T, Mo * T, 0, 1,
                               1.0, 1.0, 0, 1, ACT_NONE, st), 'tt_gemm(dec convin wgrad)')
             if ctx.has_bias:
-                db = torch.zeros(C, dtype=torch.float32, device=z.device)
+                db, rb = _grad_target(ctx.params[1])
                 check(lib.tt_channel_sum(ptr(g), ptr(db), B, C, E * T, st), 'tt_channel_sum')
-        return dz, dw, db
+        return dz, rw, rb
 
 
 # ---- objectives ------------------------------------------------------------------------------------

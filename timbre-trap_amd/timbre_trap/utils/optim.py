@@ -42,6 +42,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 self.flat_param[o:o + k].copy_(p.detach().reshape(-1))
                 p.data = self.flat_param[o:o + k].view_as(p)
                 p.grad = self.flat_grad[o:o + k].view_as(p)
+                p._ttrap_accumulate = True        # backward kernels add into this view directly (framework/ops.py:_grad_target)
                 o += k
         self.n = n
 

@@ -3,6 +3,7 @@
 // plain matrix products over (C*31): K = 1984 for the encoder head, M = 1984 for the decoder head.
 //
 // LDS-tiled 64x64x16, 256 threads, 4x4 outputs per thread, generic operand strides.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -13,6 +14,7 @@ struct GemmP {
     long am, ak, bk, bn, ldc;       // element strides: a(m,k) = A[m*am + k*ak], b(k,n) = B[k*bk + n*bn]
     long sa, sb, sc;
     int reduce_batch;
+    int sc_batches;                  // number of batches (matrix-core kernel)
     float alpha, beta;
     int bias_mode, bias_div, act;
 };
@@ -87,6 +89,118 @@ __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
     }
 }
 
+// ---- fp32 matrix-core version ---------------------------------------------------------------------------------------
+// v_mfma_f32_16x16x4_f32 (exact fp32).  Workgroup = 4 waves = BM x 128 outputs, wave w owns columns 32 w .. 32 w + 31
+// (BM / 16 x 2 accumulator tiles; 16-row tiles entirely past M are skipped).  BK = 16 per stage: the next stage's operands are loaded into registers while the
+// current one is multiplied (one barrier pair per stage), generic element strides as above.  Pitches are 16 mod 32 so
+// the four k-rows a fragment load touches fall into disjoint bank halves.  reduce_batch: a workgroup sums `bper`
+// consecutive batches in registers before its atomics.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int BM_>
+__global__ __launch_bounds__(256) void k_gemm_mfma(GemmP p, int bper) {
+    constexpr int BN_ = 128, BK_ = 16, MT = BM_ / 16;
+    constexpr int AP = (BM_ % 32 == 16) ? BM_ : BM_ + 16, BP = BN_ + 16;
+    constexpr int NA = BM_ * BK_ / 256, NB = BN_ * BK_ / 256;
+    __shared__ float As[BK_ * AP];
+    __shared__ float Bs[BK_ * BP];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+    const int m0 = blockIdx.y * BM_, n0 = blockIdx.x * BN_;
+    const int b_lo = blockIdx.z * bper, b_hi = (b_lo + bper < (int)p.sc_batches) ? b_lo + bper : (int)p.sc_batches;
+    f32x4 acc[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const int mt_used = (p.M - m0 + 15) / 16;            // row tiles of this workgroup that hold valid rows (uniform)
+    const int nk = (p.K + BK_ - 1) / BK_;
+    const int nstage = nk * (b_hi - b_lo);
+    float ra[NA], rb[NB];
+    auto load = [&](int stage) {
+        const int bz = b_lo + stage / nk, k0 = (stage % nk) * BK_;
+        const float* A = p.A + (long)bz * p.sa;
+        const float* B = p.B + (long)bz * p.sb;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int e = tid + 256 * i;
+            int m, k;
+            if (p.ak == 1) { k = e & (BK_ - 1); m = e >> 4; } else { m = e % BM_; k = e / BM_; }
+            const int gm = m0 + m, gk = k0 + k;
+            ra[i] = (gm < p.M && gk < p.K) ? A[gm * p.am + gk * p.ak] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int e = tid + 256 * i;
+            int n, k;
+            if (p.bn == 1) { n = e & (BN_ - 1); k = e >> 7; } else { k = e & (BK_ - 1); n = e >> 4; }
+            const int gn = n0 + n, gk = k0 + k;
+            rb[i] = (gn < p.N && gk < p.K) ? B[gk * p.bk + gn * p.bn] : 0.f;
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int e = tid + 256 * i;
+            int m, k;
+            if (p.ak == 1) { k = e & (BK_ - 1); m = e >> 4; } else { m = e % BM_; k = e / BM_; }
+            As[k * AP + m] = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int e = tid + 256 * i;
+            int n, k;
+            if (p.bn == 1) { n = e & (BN_ - 1); k = e >> 7; } else { k = e & (BK_ - 1); n = e >> 4; }
+            Bs[k * BP + n] = rb[i];
+        }
+    };
+    load(0);
+#pragma unroll 1
+    for (int stage = 0; stage < nstage; ++stage) {
+        __syncthreads();                       // everyone is done reading the previous stage
+        commit();
+        __syncthreads();
+        if (stage + 1 < nstage) load(stage + 1);
+#pragma unroll
+        for (int ks = 0; ks < BK_; ks += 4) {
+            float a[MT], b[2];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt] = As[(ks + g) * AP + mt * 16 + l15];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) b[nt] = Bs[(ks + g) * BP + wave * 32 + nt * 16 + l15];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                if (mt < mt_used) {
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+                }
+        }
+    }
+    float* C = p.C + (p.reduce_batch ? 0 : (long)b_lo * p.sc);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gm = m0 + mt * 16 + 4 * g + r;
+            if (gm >= p.M) continue;
+            float bv = 0.f;
+            if (p.bias_mode == 1) bv = p.bias[gm];
+            else if (p.bias_mode == 2) bv = p.bias[gm / p.bias_div];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int gn = n0 + wave * 32 + nt * 16 + l15;
+                if (gn >= p.N) continue;
+                float v = p.alpha * acc[mt][nt][r];
+                float* c = C + gm * p.ldc + gn;
+                if (p.reduce_batch) {
+                    atomicAdd(c, v);
+                } else {
+                    v += bv;
+                    if (p.beta != 0.f) v += p.beta * (*c);
+                    if (p.act == TT_ACT_ELU) v = elu1(v);
+                    *c = v;
+                }
+            }
+        }
+}
+
 }  // namespace
 
 extern "C" int tt_gemm(const float* A, const float* Bm, float* C, const float* bias,
@@ -99,7 +213,17 @@ extern "C" int tt_gemm(const float* A, const float* Bm, float* C, const float* b
     if (batch > 65535) return TT_E_UNSUPPORTED;
     GemmP p{A, Bm, C, bias, M, N, K,
             transA ? 1 : (long)lda, transA ? (long)lda : 1, transB ? 1 : (long)ldb, transB ? (long)ldb : 1, (long)ldc,
-            (long)sa, (long)sb, (long)sc, reduce_batch, alpha, beta, bias_mode, bias_div > 0 ? bias_div : 1, act};
+            (long)sa, (long)sb, (long)sc, reduce_batch, batch, alpha, beta, bias_mode, bias_div > 0 ? bias_div : 1, act};
+    static const bool valu_only = getenv("TTRAP_GEMM_VALU") != nullptr;      // A/B switch for measurements
+    if (!valu_only) {
+        // 64 rows per workgroup; row tiles past M are skipped inside the kernel (M = 129: the third block does 1/4 of the MFMAs)
+        // reduce_batch: up to 64 batch groups (measured: 64-way atomics per element cost less than longer per-workgroup loops)
+        const int bper = reduce_batch ? (batch + 63) / 64 : 1;
+        dim3 grid((N + 127) / 128, (M + 63) / 64, (batch + bper - 1) / bper);
+        hipLaunchKernelGGL(k_gemm_mfma<64>, grid, dim3(256), 0, tt_stream(stream), p, bper);
+        TT_LAUNCH_CHECK();
+        return 0;
+    }
     dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch);
     hipLaunchKernelGGL(k_gemm, grid, dim3(256), 0, tt_stream(stream), p);
     TT_LAUNCH_CHECK();

@@ -71,6 +71,25 @@ __device__ __forceinline__ f32x4 mma_bf16(const bf16x8& ah, const bf16x8& al, co
     return mfma16_bf16(ah, bh, c);
 }
 
+// 4 x 4 transpose between the four lanes of a quad and four registers: afterwards v[i] of quad lane j holds what v[j] of
+// quad lane i held.  Applied to the accumulators nt = 0..3 of one output channel (pixel nt * 16 + l15) it leaves lane
+// l15 = 4 q + j with the four CONSECUTIVE pixels 16 j + 4 q + i: 16-byte epilogue accesses on the fp32 path as well.
+__device__ __forceinline__ float dpp_quad_xor1(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ float dpp_quad_xor2(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+}
+__device__ __forceinline__ void quad_transpose(float (&v)[4], int lane) {
+    const bool hi2 = lane & 2, hi1 = lane & 1;
+    float a = hi2 ? v[0] : v[2], b = hi2 ? v[1] : v[3];
+    a = dpp_quad_xor2(a); b = dpp_quad_xor2(b);
+    if (hi2) { v[0] = a; v[1] = b; } else { v[2] = a; v[3] = b; }
+    a = hi1 ? v[0] : v[1]; b = hi1 ? v[2] : v[3];
+    a = dpp_quad_xor1(a); b = dpp_quad_xor1(b);
+    if (hi1) { v[0] = a; v[2] = b; } else { v[1] = a; v[3] = b; }
+}
+
 constexpr int plane_pad(int n) {
     int p = n;
     while (p % 32 != 17) ++p;
@@ -497,9 +516,10 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_conv_mfma(const float* __restri
         static_assert(COUT % 4 == 0, "lane groups own 4 consecutive output channels");
         const int g4 = (COUT % 16 == 0) ? 4 * g : (4 * g < COUT ? 4 * g : COUT - 4);      // clamped: loads stay in bounds
         const long cbase = (long)ub * COUT * oplane;
-        if constexpr (PREC != 0) {
-            // bf16 main loop: accumulators nt = 0..3 of a lane are pixels t .. t + 3 -> 16-byte loads and stores
-            const int t = ut0 + 4 * l15;
+        if constexpr (PREC != 0 || DMA) {
+            // 16-byte loads and stores: in the bf16 main loop accumulators nt = 0..3 of a lane already are pixels t .. t + 3;
+            // the fp32 loop (pixel nt * 16 + l15) gets there with a quad transpose of the finished values
+            const int t = PREC != 0 ? ut0 + 4 * l15 : ut0 + 16 * (l15 & 3) + 4 * (l15 >> 2);
             const bool tv = t < T;
             const unsigned vo = (unsigned)(g4 * (int)oplane + h * T + (tv ? t : T - 4));
             float4 rv[G::MT][4];
@@ -515,14 +535,15 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_conv_mfma(const float* __restri
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = mt * 16 + 4 * g + r;
-                    if (m >= COUT || !tv) continue;
-                    const float bv = bias ? bias[m] : 0.f;
+                    const float bv = (bias && m < COUT) ? bias[m] : 0.f;
                     float v[4];
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) {
                         v[nt] = acc[mt][nt][r] + bv;
                         if (act == TT_ACT_ELU) v[nt] = elu1(v[nt]);
                     }
+                    if constexpr (PREC == 0) quad_transpose(v, lane);
+                    if (m >= COUT || !tv) continue;
                     if (res) { v[0] += rv[mt][r].x; v[1] += rv[mt][r].y; v[2] += rv[mt][r].z; v[3] += rv[mt][r].w; }
                     *reinterpret_cast<float4*>(y + cbase + (long)(mt * 16 + r) * oplane + vo) = float4{v[0], v[1], v[2], v[3]};
                 }
@@ -618,7 +639,8 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_rb_fwd(const float* __restrict_
     conv_mainloop<C, C, P, false, DMA, PREC>(x, nullptr, Wimg, xs, B, H, H, T, [&](const Tile& tl, f32x4 (&acc)[G::MT][4]) {
         // addressing as in k_conv_mfma: uniform base per (clip, channel m2*16 + r) + 32-bit lane offsets; in the bf16 modes
         // (PX4) accumulators nt = 0..3 are four consecutive pixels: 16 bytes per lane for the residual, h1 and y
-        constexpr bool PX4 = PREC != 0;
+        constexpr bool PX4 = PREC != 0;            // lane owns pixels 4 l15 + nt
+        constexpr bool QT = PREC == 0 && DMA;      // fp32 loop on aligned tensors: quad transpose, then the same 16-byte accesses
         const int ub = __builtin_amdgcn_readfirstlane(tl.b), uh0 = __builtin_amdgcn_readfirstlane(tl.h0),
                   ut0 = __builtin_amdgcn_readfirstlane(tl.t0);
         const int h = uh0 + wave;
@@ -627,9 +649,9 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_rb_fwd(const float* __restrict_
         bool tv[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            const int t = PX4 ? ut0 + 4 * l15 + nt : ut0 + nt * 16 + l15;
+            const int t = PX4 ? ut0 + 4 * l15 + nt : (QT ? ut0 + 16 * (l15 & 3) + 4 * (l15 >> 2) + nt : ut0 + nt * 16 + l15);
             tv[nt] = t < T && h < H;
-            vo[nt] = (unsigned)(g4 * (int)plane + (h < H ? h : H - 1) * T + (t < T ? t : T - (PX4 ? 4 - nt : 1)));
+            vo[nt] = (unsigned)(g4 * (int)plane + (h < H ? h : H - 1) * T + (t < T ? t : T - ((PX4 || QT) ? 4 - nt : 1)));
         }
         const long cbase = (long)ub * C * plane;
         f32x4 acc2[G::MT][4];
@@ -646,11 +668,13 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_rb_fwd(const float* __restrict_
             for (int m2 = 0; m2 < G::MT; ++m2)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (m2 * 16 + 4 * g + r >= C) continue;
                     float* hb = h1out + cbase + (long)(m2 * 16 + r) * plane;
-                    if constexpr (PX4) {
-                        if (tv[0]) *reinterpret_cast<float4*>(hb + vo[0]) = float4{acc[m2][0][r], acc[m2][1][r], acc[m2][2][r], acc[m2][3][r]};
+                    if constexpr (PX4 || QT) {
+                        float hv[4] = {acc[m2][0][r], acc[m2][1][r], acc[m2][2][r], acc[m2][3][r]};
+                        if constexpr (QT) quad_transpose(hv, lane);
+                        if (m2 * 16 + 4 * g + r < C && tv[0]) *reinterpret_cast<float4*>(hb + vo[0]) = float4{hv[0], hv[1], hv[2], hv[3]};
                     } else {
+                        if (m2 * 16 + 4 * g + r >= C) continue;
 #pragma unroll
                         for (int nt = 0; nt < 4; ++nt)
                             if (tv[nt]) hb[vo[nt]] = acc[m2][nt][r];
@@ -678,7 +702,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_rb_fwd(const float* __restrict_
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float* xb = x + cbase + (long)((m2 * 16 + r < C) ? m2 * 16 + r : 0) * plane;
-                if constexpr (PX4) {
+                if constexpr (PX4 || QT) {
                     const float4 v = *reinterpret_cast<const float4*>(xb + vo[0]);
                     xres[m2][r][0] = v.x; xres[m2][r][1] = v.y; xres[m2][r][2] = v.z; xres[m2][r][3] = v.w;
                 } else {
@@ -691,14 +715,16 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_rb_fwd(const float* __restrict_
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = m2 * 16 + 4 * g + r;
-                if (co >= C) continue;
-                const float bias = b2s[co];
+                const float bias = b2s[co < C ? co : 0];
                 float* yb = y + cbase + (long)(m2 * 16 + r) * plane;
-                if constexpr (PX4) {
-                    if (tv[0]) *reinterpret_cast<float4*>(yb + vo[0]) =
-                        float4{elu1(acc2[m2][0][r] + bias) + xres[m2][r][0], elu1(acc2[m2][1][r] + bias) + xres[m2][r][1],
-                               elu1(acc2[m2][2][r] + bias) + xres[m2][r][2], elu1(acc2[m2][3][r] + bias) + xres[m2][r][3]};
+                if constexpr (PX4 || QT) {
+                    float ov[4] = {elu1(acc2[m2][0][r] + bias), elu1(acc2[m2][1][r] + bias), elu1(acc2[m2][2][r] + bias),
+                                   elu1(acc2[m2][3][r] + bias)};
+                    if constexpr (QT) quad_transpose(ov, lane);
+                    if (co < C && tv[0]) *reinterpret_cast<float4*>(yb + vo[0]) =
+                        float4{ov[0] + xres[m2][r][0], ov[1] + xres[m2][r][1], ov[2] + xres[m2][r][2], ov[3] + xres[m2][r][3]};
                 } else {
+                    if (co >= C) continue;
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt)
                         if (tv[nt]) yb[vo[nt]] = elu1(acc2[m2][nt][r] + bias) + xres[m2][r][nt];

@@ -11,7 +11,6 @@
 //   k_small<C,D,1>  dx = dy + W1^T (*) dA1                                    (data gradient, flipped weights)
 //   k_small_bwd_a   recompute + pointwise chain -> dA1; db1, db2, dW2 in registers, reduced once per workgroup
 //   (dW1 stays on the MFMA weight-gradient kernel of conv_mfma.hip)
-#include <cstdlib>
 #include "common.h"
 #include "conv_small.h"
 
@@ -138,109 +137,6 @@ __global__ __launch_bounds__(256) void k_small(const float* __restrict__ x, cons
     }
 }
 
-// ---- four pixels per thread -------------------------------------------------------------------------------------
-// The same block with 16-byte global accesses: a thread owns pixels t .. t+3 of one row (t % 4 == 0).  Per input channel
-// and kernel row it loads the three aligned float4 around t (12 values cover every tap of the four pixels for D <= 3)
-// and does 3 x 4 x C FMAs on them -- a quarter of the load instructions of the one-pixel kernel, full 256-byte
-// segments per 16 lanes, and float4 stores of h1 / y.
-template <int C, int D>
-__device__ __forceinline__ void conv_pixel4(const float* __restrict__ xb, const float* W1s, long plane, int H, int T, int h,
-                                            int t, float (&acc)[4][C]) {
-    const float4 z4 = float4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-    for (int ci = 0; ci < C; ++ci) {
-        const float* xp = xb + ci * plane;
-        const float* wc = W1s + ci * 9 * C;
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            asm volatile("" ::: "memory");
-            const int hh = h + (kh - 1) * D;
-            const bool hv = hh >= 0 && hh < H;
-            const float* row = xp + (long)(hv ? hh : 0) * T + t;
-            const float4 m4 = hv ? *reinterpret_cast<const float4*>(row) : z4;
-            const float4 l4 = (hv && t >= 4) ? *reinterpret_cast<const float4*>(row - 4) : z4;
-            const float4 r4 = (hv && t + 4 < T) ? *reinterpret_cast<const float4*>(row + 4) : z4;
-            const float v[12] = {l4.x, l4.y, l4.z, l4.w, m4.x, m4.y, m4.z, m4.w, r4.x, r4.y, r4.z, r4.w};
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const float* wl = wc + (kh * 3 + kw) * C;
-                float w[C];
-#pragma unroll
-                for (int co = 0; co < C; ++co) w[co] = wl[co];
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const float xv = v[4 + p + (kw - 1) * D];
-#pragma unroll
-                    for (int co = 0; co < C; ++co) acc[p][co] = fmaf(xv, w[co], acc[p][co]);
-                }
-            }
-        }
-    }
-}
-
-template <int C, int D, int MODE>
-__global__ __launch_bounds__(256) void k_small4(const float* __restrict__ x, const float* __restrict__ w1,
-                                                const float* __restrict__ b1, const float* __restrict__ w2,
-                                                const float* __restrict__ b2, const float* __restrict__ res,
-                                                float* __restrict__ y, float* __restrict__ h1out, int B, int H, int T) {
-    using S = SW<C>;
-    __shared__ __attribute__((aligned(16))) float lds[S::FLOATS];
-    build_images<C>(lds, w1, MODE == 0 ? b1 : nullptr, MODE == 0 ? w2 : nullptr, MODE == 0 ? b2 : nullptr, MODE == 1);
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int t = (blockIdx.x * 64 + tx) * 4;
-    const int b = blockIdx.z;
-    const long plane = (long)H * T;
-    const float* xb = x + (long)b * C * plane;
-    if (t >= T) return;
-#pragma unroll 1
-    for (int pass = 0; pass < ROWS_PER_BLOCK / 4; ++pass) {
-        const int h = blockIdx.y * ROWS_PER_BLOCK + pass * 4 + ty;
-        if (h >= H) break;
-        float acc[4][C];
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-#pragma unroll
-            for (int co = 0; co < C; ++co) acc[p][co] = lds[S::B1 + co];
-        conv_pixel4<C, D>(xb, lds + S::W1, plane, H, T, h, t, acc);
-        const long o = (long)b * C * plane + (long)h * T + t;
-        if (MODE == 0) {
-            float a2[4][C];
-#pragma unroll
-            for (int p = 0; p < 4; ++p)
-#pragma unroll
-                for (int co = 0; co < C; ++co) a2[p][co] = lds[S::B2 + co];
-            asm volatile("" ::: "memory");
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                float hv[4];
-#pragma unroll
-                for (int p = 0; p < 4; ++p) hv[p] = elu1(acc[p][c]);
-                if (h1out) *reinterpret_cast<float4*>(h1out + o + c * plane) = float4{hv[0], hv[1], hv[2], hv[3]};
-                const float* wl = lds + S::W2 + c * C;
-#pragma unroll
-                for (int co = 0; co < C; ++co) {
-                    const float w = wl[co];
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) a2[p][co] = fmaf(hv[p], w, a2[p][co]);
-                }
-            }
-#pragma unroll
-            for (int co = 0; co < C; ++co) {
-                const float4 xr = *reinterpret_cast<const float4*>(x + o + co * plane);
-                *reinterpret_cast<float4*>(y + o + co * plane) =
-                    float4{elu1(a2[0][co]) + xr.x, elu1(a2[1][co]) + xr.y, elu1(a2[2][co]) + xr.z, elu1(a2[3][co]) + xr.w};
-            }
-        } else {
-#pragma unroll
-            for (int co = 0; co < C; ++co) {
-                const float4 rr = *reinterpret_cast<const float4*>(res + o + co * plane);
-                *reinterpret_cast<float4*>(y + o + co * plane) =
-                    float4{acc[0][co] + rr.x, acc[1][co] + rr.y, acc[2][co] + rr.z, acc[3][co] + rr.w};
-            }
-        }
-    }
-}
-
 // recompute + pointwise chain; persistent workgroups accumulate db1, db2, dW2 in registers
 template <int C, int D, bool RECOMP>
 __global__ __launch_bounds__(256) void k_small_bwd_a(const float* __restrict__ x, const float* __restrict__ h1in,
@@ -338,21 +234,9 @@ __global__ __launch_bounds__(256) void k_small_bwd_a(const float* __restrict__ x
     }
 }
 
-inline bool use_wide() { static const bool v = getenv("TTRAP_SMALL_WIDE") != nullptr; return v; }
-// 16-byte accesses need T % 4 == 0 and 16-byte aligned tensors (nullptr allowed)
-inline bool wide_ok(int T, const void* a, const void* b, const void* c) {
-    return T % 4 == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0;
-}
-
 template <int C, int D>
 int fwd_t(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y, float* h1, int B, int H,
           int T, hipStream_t st) {
-    if (use_wide() && wide_ok(T, x, y, h1)) {
-        dim3 grid4((T / 4 + 63) / 64, (H + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, B);
-        hipLaunchKernelGGL((k_small4<C, D, 0>), grid4, dim3(256), 0, st, x, w1, b1, w2, b2, (const float*)nullptr, y, h1, B, H, T);
-        TT_LAUNCH_CHECK();
-        return 0;
-    }
     dim3 grid((T + 63) / 64, (H + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, B);
     hipLaunchKernelGGL((k_small<C, D, 0>), grid, dim3(256), 0, st, x, w1, b1, w2, b2, (const float*)nullptr, y, h1, B, H, T);
     TT_LAUNCH_CHECK();
@@ -373,13 +257,6 @@ int bwd_t(const float* x, const float* h1, const float* dy, const float* w1, con
         hipLaunchKernelGGL((k_small_bwd_a<C, D, true>), dim3(pgrid), dim3(256), 0, st, x, h1, dy, w1, b1, w2, b2, ws, db1, dw2,
                            db2, B, H, T);
     TT_LAUNCH_CHECK();
-    if (use_wide() && wide_ok(T, ws, dy, dx)) {
-        dim3 grid4((T / 4 + 63) / 64, (H + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, B);
-        hipLaunchKernelGGL((k_small4<C, D, 1>), grid4, dim3(256), 0, st, (const float*)ws, w1, (const float*)nullptr,
-                           (const float*)nullptr, (const float*)nullptr, dy, dx, (float*)nullptr, B, H, T);
-        TT_LAUNCH_CHECK();
-        return 0;
-    }
     dim3 grid((T + 63) / 64, (H + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, B);
     hipLaunchKernelGGL((k_small<C, D, 1>), grid, dim3(256), 0, st, (const float*)ws, w1, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, dy, dx, (float*)nullptr, B, H, T);

@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define TT_E_BADARG      (-1)
-#define TT_E_UNSUPPORTED (-2)
+#define TT_E_UNSUPPORTED (-2)   /* shape outside the compiled set, or one clip of >= 2^31 elements (32-bit offsets) */
 
 /* flags of tt_resblock_fwd / tt_resblock_bwd: round the operands of the 3x3 convolutions and of dW1 to bf16 for the
  * matrix cores (v_mfma_f32_16x16x32_bf16, fp32 accumulation, fp32 tensors in HBM) at C >= 16.  Default 0 = exact fp32. */

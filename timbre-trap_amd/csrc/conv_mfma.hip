@@ -1533,6 +1533,9 @@ int rb_wgrad_only(const float* x, float* dw1, float* ws, int B, int H, int T, hi
 
 extern "C" int64_t tt_wgrad_scratch_floats(void);
 
+// the kernels index one clip (channels x rows x frames) with 32-bit element offsets
+inline bool clip_fits(long channels, long H, long T) { return channels * H * T < (1L << 31); }
+
 inline int gate_chunks(int B, long inner, int C) {
     long chunks = ((long)B * (inner >> 2) + 256L * 8 - 1) / (256L * 8);
     const long cap = 8192 / C;
@@ -1626,6 +1629,7 @@ extern "C" int64_t tt_wgrad_scratch_floats(void) { return (int64_t)WGRAD_MAX_BLO
 extern "C" int tt_resblock_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
                                float* y, float* h1, int B, int C, int H, int T, int dilation, int flags, void* stream) {
     if (!x || !w1 || !b1 || !w2 || !b2 || !y || B <= 0 || H <= 0 || T <= 0) return TT_E_BADARG;
+    if (!clip_fits(C, H, T)) return TT_E_UNSUPPORTED;
     hipStream_t st = tt_stream(stream);
     const int bf16 = (flags & TT_FLAG_BF16_SPLIT) ? 2 : ((flags & TT_FLAG_BF16_OPERANDS) ? 1 : 0);
     if (C <= 8) return tt_small_rb_fwd(x, w1, b1, w2, b2, y, h1, B, C, H, T, dilation, st);     // HBM-bound levels: VALU kernels
@@ -1637,6 +1641,7 @@ extern "C" int tt_resblock_bwd(const float* x, const float* h1, const float* dy,
                                float* ws, int B, int C, int H, int T, int dilation, int flags, void* stream) {
     if (!x || !dy || !w1 || !b1 || !w2 || !b2 || !dx || !dw1 || !db1 || !dw2 || !db2 || !ws || B <= 0 || H <= 0 || T <= 0)
         return TT_E_BADARG;
+    if (!clip_fits(C, H, T)) return TT_E_UNSUPPORTED;
     hipStream_t st = tt_stream(stream);
     if (C <= 8) {
         int rc = tt_small_rb_bwd(x, h1, dy, w1, b1, w2, b2, dx, dw1, db1, dw2, db2, ws, ws + (long)B * C * H * T, B, C, H, T,
@@ -1659,6 +1664,7 @@ extern "C" int tt_resblock_bwd(const float* x, const float* h1, const float* dy,
 extern "C" int tt_sconv_fwd(const float* x, const float* w, const float* b, float* y, int B, int C, int H, int T,
                             void* stream) {
     if (!x || !w || !b || !y || B <= 0 || H < 4 || T <= 0) return TT_E_BADARG;
+    if (!clip_fits(2L * C, H, T)) return TT_E_UNSUPPORTED;
     const int Hout = (H - 4) / 2 + 1;
     hipStream_t st = tt_stream(stream);
     TT_DISPATCH_C(sconv_fwd, x, w, b, y, B, H, Hout, T, st)
@@ -1667,6 +1673,7 @@ extern "C" int tt_sconv_fwd(const float* x, const float* w, const float* b, floa
 extern "C" int tt_sconv_bwd(const float* x, const float* y, const float* dy, const float* w, float* dx, float* dw, float* db,
                             float* scratch, int B, int C, int H, int T, void* stream) {
     if (!x || !y || !dy || !w || !dw || !db || !scratch || B <= 0 || H < 4 || T <= 0) return TT_E_BADARG;
+    if (!clip_fits(2L * C, H, T)) return TT_E_UNSUPPORTED;
     const int Hout = (H - 4) / 2 + 1;
     hipStream_t st = tt_stream(stream);
     TT_DISPATCH_C(sconv_bwd, x, y, dy, w, dx, dw, db, scratch, B, H, Hout, T, st)
@@ -1675,6 +1682,7 @@ extern "C" int tt_sconv_bwd(const float* x, const float* y, const float* dy, con
 extern "C" int tt_tconv_fwd(const float* x, const float* w, const float* b, float* y, int B, int C, int H, int T,
                             int out_pad, void* stream) {
     if (!x || !w || !b || !y || B <= 0 || H <= 0 || T <= 0 || out_pad < 0 || out_pad > 1) return TT_E_BADARG;
+    if (!clip_fits(2L * C, 2L * H + 3, T)) return TT_E_UNSUPPORTED;
     const int Hout = (H - 1) * 2 + 4 + out_pad;
     hipStream_t st = tt_stream(stream);
     TT_DISPATCH_C(tconv_fwd, x, w, b, y, B, H, Hout, T, st)
@@ -1684,6 +1692,7 @@ extern "C" int tt_tconv_bwd(const float* x, const float* y, const float* dy, con
                             float* scratch, int B, int C, int H, int T, int out_pad, void* stream) {
     if (!x || !y || !dy || !w || !dw || !db || !scratch || B <= 0 || H <= 0 || T <= 0 || out_pad < 0 || out_pad > 1)
         return TT_E_BADARG;
+    if (!clip_fits(2L * C, 2L * H + 3, T)) return TT_E_UNSUPPORTED;
     const int Hout = (H - 1) * 2 + 4 + out_pad;
     hipStream_t st = tt_stream(stream);
     TT_DISPATCH_C(tconv_bwd, x, y, dy, w, dx, dw, db, scratch, B, H, Hout, T, st)

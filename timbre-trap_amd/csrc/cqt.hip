@@ -431,17 +431,30 @@ __global__ __launch_bounds__(256) void k_band_fwd(const float2* __restrict__ X, 
     const float inv = 1.0f / (float)M;
     const long b = q / n_blocks, blk = q - b * n_blocks;
     const long Tt = (long)n_blocks * M;
+    // the transform leaves frame 64 r + lane in v[r]; one more wave-local LDS exchange gives every lane four CONSECUTIVE
+    // frames (256 j + 4 lane ..), so the planes are written 16 bytes per lane -- 1 KiB contiguous per wave store
+    wave_lds_sync();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lds[64 * r + lane] = v[r];
+    wave_lds_sync();
     if (COMPLEX_OUT) {
-        float2* o = reinterpret_cast<float2*>(out) + (b * F + bin) * Tt + blk * M;
+        float4* o = reinterpret_cast<float4*>(reinterpret_cast<float2*>(out) + (b * F + bin) * Tt + blk * M);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[64 * r + lane] = make_float2(v[r].x * inv, v[r].y * inv);
+        for (int j = 0; j < 4; ++j) {
+            const float4* src = reinterpret_cast<const float4*>(lds + 256 * j + 4 * lane);
+            const float4 p0 = src[0], p1 = src[1];
+            o[128 * j + 2 * lane] = float4{p0.x * inv, p0.y * inv, p0.z * inv, p0.w * inv};
+            o[128 * j + 2 * lane + 1] = float4{p1.x * inv, p1.y * inv, p1.z * inv, p1.w * inv};
+        }
     } else {
-        float* ore = out + ((b * 2 + 0) * F + bin) * Tt + blk * M;
-        float* oim = out + ((b * 2 + 1) * F + bin) * Tt + blk * M;
+        float4* ore = reinterpret_cast<float4*>(out + ((b * 2 + 0) * F + bin) * Tt + blk * M);
+        float4* oim = reinterpret_cast<float4*>(out + ((b * 2 + 1) * F + bin) * Tt + blk * M);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            ore[64 * r + lane] = v[r].x * inv;
-            oim[64 * r + lane] = v[r].y * inv;
+        for (int j = 0; j < 4; ++j) {
+            const float4* src = reinterpret_cast<const float4*>(lds + 256 * j + 4 * lane);
+            const float4 p0 = src[0], p1 = src[1];           // (re0, im0, re1, im1), (re2, im2, re3, im3)
+            ore[64 * j + lane] = float4{p0.x * inv, p0.z * inv, p1.x * inv, p1.z * inv};
+            oim[64 * j + lane] = float4{p0.y * inv, p0.w * inv, p1.y * inv, p1.w * inv};
         }
     }
 }

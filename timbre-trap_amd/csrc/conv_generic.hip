@@ -314,6 +314,77 @@ extern "C" int tt_conv2d(const float* x, const float* w, const float* bias, cons
     return 0;
 }
 
+// 3x3 / stride 1 / pad 1 weight gradient of the two narrow boundary layers (Encoder.convin 2 -> C0, Decoder.convout
+// C0 -> 2; reference modules.py:431,543): every thread walks pixels with all CO*CI*9 (<= 144) accumulators in registers,
+// x and g are read ONCE (the generic kernel re-reads them per (co-tile, ci-tile, kh) column), one reduction per workgroup.
+template <int CO, int CI>
+__global__ __launch_bounds__(256) void k_wgrad3x3_small(WgradP p) {
+    __shared__ float red[CO * CI * 9 + CO];
+    for (int i = threadIdx.x; i < CO * CI * 9 + CO; i += 256) red[i] = 0.f;
+    __syncthreads();
+    float acc[CO][CI][9];
+    float bacc[CO];
+#pragma unroll
+    for (int a = 0; a < CO; ++a) {
+        bacc[a] = 0.f;
+#pragma unroll
+        for (int c = 0; c < CI; ++c)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc[a][c][k] = 0.f;
+    }
+    const int H = p.Hin, T = p.T;
+    const long plane = (long)H * T;
+    const int tiles_t = (T + 255) / 256;
+    const long ntiles = (long)p.B * H * tiles_t;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tt = (int)(tile % tiles_t);
+        const long rr = tile / tiles_t;
+        const int h = (int)(rr % H), b = (int)(rr / H);
+        const int t = tt * 256 + threadIdx.x;
+        if (t >= T) continue;
+        const float* gb = p.g + (long)b * CO * plane + (long)h * T + t;
+        const float* xb = p.x + (long)b * CI * plane;
+        float gv[CO];
+#pragma unroll
+        for (int a = 0; a < CO; ++a) { gv[a] = gb[a * plane]; bacc[a] += gv[a]; }
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int hh = h + kh - 1;
+            if (hh < 0 || hh >= H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ti = t + kw - 1;
+                const bool ok = ti >= 0 && ti < T;
+#pragma unroll
+                for (int c = 0; c < CI; ++c) {
+                    const float xv = ok ? xb[c * plane + (long)hh * T + ti] : 0.f;
+#pragma unroll
+                    for (int a = 0; a < CO; ++a) acc[a][c][kh * 3 + kw] = fmaf(gv[a], xv, acc[a][c][kh * 3 + kw]);
+                }
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int a = 0; a < CO; ++a) {
+#pragma unroll
+        for (int c = 0; c < CI; ++c)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const float s_ = wave_sum(acc[a][c][k]);
+                if (lane == 0) atomicAdd(&red[(a * CI + c) * 9 + k], s_);
+            }
+        const float sb = wave_sum(bacc[a]);
+        if (lane == 0) atomicAdd(&red[CO * CI * 9 + a], sb);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < CO * CI * 9; i += 256) {
+        const int k = i % 9, c = (i / 9) % CI, a = i / (9 * CI);
+        atomicAdd(p.dw + a * p.ws_co + c * p.ws_ci + (k / 3) * p.ws_kh + (k % 3) * p.ws_kw, red[i]);
+    }
+    if (p.dbias && threadIdx.x < CO) atomicAdd(p.dbias + threadIdx.x, red[CO * CI * 9 + threadIdx.x]);
+}
+
 extern "C" int tt_conv2d_wgrad(const float* x, const float* g, float* dw, float* dbias,
                                int B, int Cin, int Hin, int T, int Cout, int Hout,
                                int KH, int KW, int stride_h, int dil_h, int dil_w, int pad_h, int pad_w,
@@ -322,6 +393,15 @@ extern "C" int tt_conv2d_wgrad(const float* x, const float* g, float* dw, float*
     if (KW > KWMAX) return TT_E_UNSUPPORTED;
     WgradP p{x, g, dw, dbias, B, Cin, Hin, T, Cout, Hout, KH, KW, stride_h, dil_h, dil_w, pad_h, pad_w,
              (long)ws_co, (long)ws_ci, (long)ws_kh, (long)ws_kw, 0, 0};
+    if (KH == 3 && KW == 3 && stride_h == 1 && dil_h == 1 && dil_w == 1 && pad_h == 1 && pad_w == 1 && Hin == Hout &&
+        ((Cin == 2 && Cout == 4) || (Cin == 4 && Cout == 2)) && (long)Cin * Hin * T < (1L << 31)) {
+        const long ntiles = (long)B * Hin * ((T + 255) / 256);
+        const int grid = (int)(ntiles < 2048 ? ntiles : 2048);
+        if (Cin == 2) hipLaunchKernelGGL((k_wgrad3x3_small<4, 2>), dim3(grid), dim3(256), 0, tt_stream(stream), p);
+        else hipLaunchKernelGGL((k_wgrad3x3_small<2, 4>), dim3(grid), dim3(256), 0, tt_stream(stream), p);
+        TT_LAUNCH_CHECK();
+        return 0;
+    }
     p.n_ci_tiles = (Cin + TCI - 1) / TCI;
     const int n_co_tiles = (Cout + TCO - 1) / TCO;
     const long total_rows = (long)B * Hout;

@@ -1279,25 +1279,34 @@ __global__ __launch_bounds__(64 * WP::WTH) void k_wgrad_dma(const float* __restr
     if (dbias_p && blockIdx.y == 0 && tid < CA) atomicAdd(dbias_p + tid, red[K::CAP * NC + tid]);
 }
 
-// second stage: dw[a*s_a + (y*CBS + bl)*s_b + tap*s_t] += sum over workgroups of their partial images
+// second stage: dw[a*s_a + (y*CBS + bl)*s_b + tap*s_t] += sum over workgroups of their partial images.
+// 256 threads = 32 elements x 8 partial groups: eight independent load streams per element, then an LDS reduction.
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ scratch, float* __restrict__ dw, int nblk,
                                                       int CA, int CAP, int NC, int NN, int CBS, long s_a, long s_b, long s_t) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= CAP * NC) return;
-    const int a = i / NC, n = i - a * NC;
-    if (a >= CA || n >= NN) return;
-    const float* p = scratch + (long)blockIdx.y * nblk * (CAP * NC) + i;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int k = 0;
-    for (; k + 3 < nblk; k += 4) {
-        s0 += p[(long)k * (CAP * NC)];
-        s1 += p[(long)(k + 1) * (CAP * NC)];
-        s2 += p[(long)(k + 2) * (CAP * NC)];
-        s3 += p[(long)(k + 3) * (CAP * NC)];
+    __shared__ float red[8][33];
+    const int e = threadIdx.x & 31, pg = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + e;
+    const bool ok = i < CAP * NC;
+    float s0 = 0.f, s1 = 0.f;
+    if (ok) {
+        const float* p = scratch + (long)blockIdx.y * nblk * (CAP * NC) + i;
+        int k = pg;
+        for (; k + 8 < nblk; k += 16) {
+            s0 += p[(long)k * (CAP * NC)];
+            s1 += p[(long)(k + 8) * (CAP * NC)];
+        }
+        if (k < nblk) s0 += p[(long)k * (CAP * NC)];
     }
-    for (; k < nblk; ++k) s0 += p[(long)k * (CAP * NC)];
-    const int tap = n / CBS, bl = n - tap * CBS;
-    dw[a * s_a + ((long)blockIdx.y * CBS + bl) * s_b + tap * s_t] += (s0 + s1) + (s2 + s3);
+    red[pg][e] = s0 + s1;
+    __syncthreads();
+    if (pg == 0 && ok) {
+        const float tot = ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])) + ((red[4][e] + red[5][e]) + (red[6][e] + red[7][e]));
+        const int a = i / NC, n = i - a * NC;
+        if (a < CA && n < NN) {
+            const int tap = n / CBS, bl = n - tap * CBS;
+            dw[a * s_a + ((long)blockIdx.y * CBS + bl) * s_b + tap * s_t] += tot;
+        }
+    }
 }
 
 // g = dy * ELU'(y) written out AND out[c] += sum of g over (b, h, t): the gate pre-pass of the strided layers also
@@ -1458,7 +1467,7 @@ int launch_wgrad(const float* Pt, const float* Pg, const float* Qt, const float*
                 hipLaunchKernelGGL((k_wgrad_dma<CA, CB, CBS, WP, 0>), dim3(grid, NS), dim3(64 * WP::WTH), LDS, st, Pt, Qt,
                                    scratch, dbias_p, B, HP, HQ, T);
             TT_LAUNCH_CHECK();
-            hipLaunchKernelGGL(k_wgrad_reduce, dim3((K::CAP * NC + 255) / 256, NS), dim3(256), 0, st, (const float*)scratch, dw,
+            hipLaunchKernelGGL(k_wgrad_reduce, dim3((K::CAP * NC + 31) / 32, NS), dim3(256), 0, st, (const float*)scratch, dw,
                                grid, CA, K::CAP, NC, K::NN, CBS, s_a, s_b, s_t);
             TT_LAUNCH_CHECK();
             return 0;
@@ -1475,7 +1484,7 @@ int launch_wgrad(const float* Pt, const float* Pg, const float* Qt, const float*
     hipLaunchKernelGGL((k_wgrad_mfma<CA, CB, CBS, WP, GP, GQ>), dim3(grid, NS), dim3(64 * WP::WTH), K::LDS_BYTES, st, Pt, Pg, Qt, Qg,
                        scratch, dbias_p, B, HP, HQ, T);
     TT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((K::CAP * NC + 255) / 256, NS), dim3(256), 0, st, (const float*)scratch, dw, grid,
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((K::CAP * NC + 31) / 32, NS), dim3(256), 0, st, (const float*)scratch, dw, grid,
                        CA, K::CAP, NC, K::NN, CBS, s_a, s_b, s_t);
     TT_LAUNCH_CHECK();
     return 0;

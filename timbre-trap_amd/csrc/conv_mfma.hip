@@ -139,10 +139,12 @@ struct Geo {
     static constexpr int NCH = CIN / CC;
     static constexpr int HL = DMA ? (P::CH > 0 ? 4 : 0) : P::CH;
     static constexpr int XCP = DMA ? (P::CH > 0 ? TW + 8 : TW) : P::XC;
-    static constexpr int PLANE = DMA ? P::XR * XCP : plane_pad(P::XR * P::XC);
+    // DMA layout: planes XR * XCP floats apart, padded by 16 when that is 0 mod 32 so that the two channel planes one
+    // ds_read_b32 cycle touches (lane groups g, g + 1) fall into different bank halves
+    static constexpr int PLANE = DMA ? P::XR * XCP + ((P::XR * XCP) % 32 == 0 ? 16 : 0) : plane_pad(P::XR * P::XC);
     static constexpr int ELEMS = CC * P::XR * P::XC;
     static constexpr int NLD = (ELEMS + NTHREADS - 1) / NTHREADS;
-    static constexpr int NQ = CC * P::XR * XCP / 4;          // 16-byte pieces of one chunk (DMA)
+    static constexpr int NQ = DMA ? CC * PLANE / 4 : 0;      // 16-byte pieces of one chunk (DMA), plane pads included
     static constexpr int NPIECE = (NQ + 63) / 64;            // wave-wide DMA instructions per chunk
     static constexpr int BUF = DMA ? NPIECE * 256 : CC * PLANE;
     static constexpr int KW = P::NWT * CIN;                  // rows of the weight image
@@ -421,7 +423,7 @@ __device__ __forceinline__ void conv_mainloop(const float* __restrict__ x, const
         const float* xb = x + ((long)tl.b * CIN + chunk * G::CC) * plane;
         float* dst = xs + buf * G::BUF;
         constexpr int RQ = G::XCP / 4;              // pieces per row
-        constexpr int PQ = P::XR * RQ;              // pieces per channel plane
+        constexpr int PQ = G::PLANE / 4;            // pieces per (padded) channel plane
 #pragma unroll
         for (int jj = 0; jj < (G::NPIECE + 7) / 8; ++jj) {
             const int j = __builtin_amdgcn_readfirstlane(wave) + 8 * jj;      // provably wave-uniform LDS base
@@ -431,7 +433,7 @@ __device__ __forceinline__ void conv_mainloop(const float* __restrict__ x, const
                 const int rem = q - ci * PQ;
                 const int r = rem / RQ, c4 = rem - r * RQ;
                 const int h = row0 + r, t = col0 + 4 * c4;
-                const bool ok = q < G::NQ && h >= 0 && h < Hin && t >= 0 && t < T;
+                const bool ok = q < G::NQ && r < P::XR && h >= 0 && h < Hin && t >= 0 && t < T;
                 const float* src = ok ? xb + (ci * (int)plane + h * T + t) : reinterpret_cast<const float*>(&g_zero16);
                 glds16(src, dst + j * 256);
             }
@@ -1125,12 +1127,15 @@ __global__ __launch_bounds__(64 * WP::WTH) void k_wgrad_mfma(const float* __rest
 //   Q tile: linear [bl][row][XCP] (rows start 16-byte aligned at t0 - HL)
 //   P rows: per wave [CAP][64] with the 16-byte chunks of row a stored at chunk position c ^ (a & 15) (the swizzle is
 //           applied to the SOURCE address, the LDS image of a DMA is linear), so the A fragments are ds_read_b128:
-//           lane (a = l15, g) owns pixels 16 g .. 16 g + 15 = k-steps 0..15 (the k order is free as long as A and B agree).
+//           lane (a = l15, g) owns pixels 4 sk + g, sk = 0..15 (the k order is free as long as A and B agree; consecutive
+//           pixels across the four lane groups keep the B-fragment reads of the tile spread over all LDS banks).
 template <int CBS, class WP>
 struct WGeoD {
     static constexpr int HL = WP::CH > 0 ? 4 : 0;
     static constexpr int XCP = WP::CH > 0 ? WP::WTW + 8 : WP::WTW;
-    static constexpr int PLANE = WP::XR * XCP;
+    // one 16-byte pad group per channel plane: XR * XCP is 0 or 16 mod 32, which would put the 8/16 channels that the
+    // lanes of a B fragment address into one or two LDS banks; with the pad the plane pitch is 4 or 20 mod 32
+    static constexpr int PLANE = WP::XR * XCP + 4;
     static constexpr int NQ = CBS * PLANE / 4;
     static constexpr int NPIECE = (NQ + 63) / 64;
     static constexpr int Q_FLOATS = NPIECE * 256;
@@ -1163,7 +1168,8 @@ __global__ __launch_bounds__(64 * WP::WTH) void k_wgrad_dma(const float* __restr
         const int tap = n / CBS, bl = n - tap * CBS;
         // WP::qoff is in units of WP::XC columns per row: split it back into (row, col)
         const int qo = WP::qoff(tap), qr = qo / WP::XC, qc = qo - qr * WP::XC;
-        noff[nt] = bl * Q::PLANE + qr * Q::XCP + qc + (Q::HL - WP::CH) + (BF16 ? 8 : 16) * g;
+        // fp32: k-step sk of lane group g is pixel 4 sk + g (consecutive pixels across the groups: odd bank offsets)
+        noff[nt] = bl * Q::PLANE + qr * Q::XCP + qc + (Q::HL - WP::CH) + (BF16 ? 8 * g : g);
     }
     f32x4 acc[K::MT][K::NTN];
 #pragma unroll
@@ -1182,7 +1188,7 @@ __global__ __launch_bounds__(64 * WP::WTH) void k_wgrad_dma(const float* __restr
         {   // Q tile
             const float* qb = Qt + ((long)b * CB + b0) * qplane;
             const int row0 = WP::q_row0(h0), col0 = t0 - Q::HL;
-            constexpr int RQ = Q::XCP / 4, PQ = WP::XR * RQ;
+            constexpr int RQ = Q::XCP / 4, PQ = Q::PLANE / 4;      // 16-byte groups per row / per (padded) plane
 #pragma unroll
             for (int jj = 0; jj < (Q::NPIECE + WP::WTH - 1) / WP::WTH; ++jj) {
                 const int j = uwave + WP::WTH * jj;
@@ -1192,7 +1198,7 @@ __global__ __launch_bounds__(64 * WP::WTH) void k_wgrad_dma(const float* __restr
                     const int rem = q - ci * PQ;
                     const int r = rem / RQ, c4 = rem - r * RQ;
                     const int h = row0 + r, t = col0 + 4 * c4;
-                    const bool ok = q < Q::NQ && h >= 0 && h < HQ && t >= 0 && t < T;
+                    const bool ok = q < Q::NQ && r < WP::XR && h >= 0 && h < HQ && t >= 0 && t < T;
                     glds16(ok ? qb + (ci * (int)qplane + h * T + t) : zero, xs + j * 256);
                 }
             }
@@ -1241,20 +1247,17 @@ __global__ __launch_bounds__(64 * WP::WTH) void k_wgrad_dma(const float* __restr
                 }
             }
         } else {
-            // A fragments: pixels 16 g .. 16 g + 15 of channel mt*16 + l15
+            // A fragments: pixels 4 sk + g (sk = 0..15) of channel mt*16 + l15; 16-byte chunk sk of the row sits at sk ^ l15
             float av[K::MT][16];
 #pragma unroll
             for (int mt = 0; mt < K::MT; ++mt)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float4 v = *reinterpret_cast<const float4*>(as + (mt * 16 + l15) * 64 + (((4 * g + j) ^ l15) << 2));
-                    av[mt][4 * j + 0] = v.x; av[mt][4 * j + 1] = v.y; av[mt][4 * j + 2] = v.z; av[mt][4 * j + 3] = v.w;
-                }
+                for (int sk = 0; sk < 16; ++sk) av[mt][sk] = as[(mt * 16 + l15) * 64 + ((sk ^ l15) << 2) + g];
 #pragma unroll
             for (int sk = 0; sk < 16; ++sk) {
 #pragma unroll
                 for (int nt = 0; nt < K::NTN; ++nt) {
-                    const float bv = xrow[noff[nt] + sk];
+                    const float bv = xrow[noff[nt] + 4 * sk];
 #pragma unroll
                     for (int mt = 0; mt < K::MT; ++mt) acc[mt][nt] = mfma16(av[mt][sk], bv, acc[mt][nt]);
                 }

@@ -92,15 +92,14 @@ __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
 // ---- fp32 matrix-core version ---------------------------------------------------------------------------------------
 // v_mfma_f32_16x16x4_f32 (exact fp32).  Workgroup = 4 waves = BM x 128 outputs, wave w owns columns 32 w .. 32 w + 31
 // (BM / 16 x 2 accumulator tiles; 16-row tiles entirely past M are skipped).  BK = 16 per stage: the next stage's operands are loaded into registers while the
-// current one is multiplied (one barrier pair per stage), generic element strides as above.  Pitches are 16 mod 32 so
-// the four k-rows a fragment load touches fall into disjoint bank halves.  reduce_batch: a workgroup sums `bper`
+// current one is multiplied (one barrier pair per stage), generic element strides as above.  Pitches are 17 mod 32.  reduce_batch: a workgroup sums `bper`
 // consecutive batches in registers before its atomics.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int BM_>
 __global__ __launch_bounds__(256) void k_gemm_mfma(GemmP p, int bper) {
     constexpr int BN_ = 128, BK_ = 16, MT = BM_ / 16;
-    constexpr int AP = (BM_ % 32 == 16) ? BM_ : BM_ + 16, BP = BN_ + 16;
+    constexpr int AP = BM_ + 17, BP = BN_ + 17;      // 17 mod 32: the k-rows of a fragment read AND a k-fastest staging write spread over the banks
     constexpr int NA = BM_ * BK_ / 256, NB = BN_ * BK_ / 256;
     __shared__ float As[BK_ * AP];
     __shared__ float Bs[BK_ * BP];

@@ -135,7 +135,10 @@ struct Geo {
     static constexpr int CP = MT * 16;                       // weight image row pitch (floats)
     static constexpr bool SWZ = CP >= 32;
     // channels per staged chunk: DMA costs no registers, so mid-width layers move 8 channels per round trip
-    static constexpr int CC = BF16 ? 4 : ((DMA && CIN >= 8 && CIN <= 16) ? 8 : 4);
+    // the (4,1) transposed geometry does 2 taps per channel: with 4-channel chunks a barrier interval holds too little
+    // work, so it stages up to 16 channels per chunk (its tile is only TH/2 + 1 rows per channel)
+    static constexpr int CC_STR = P::NTAPS == 2 ? (CIN < 16 ? CIN : 16) : (CIN < 8 ? CIN : (CIN <= 16 ? 8 : 4));   // measured
+    static constexpr int CC = BF16 ? 4 : (P::NTAPS != 9 && DMA ? CC_STR : ((DMA && CIN >= 8 && CIN <= 16) ? 8 : 4));
     static constexpr int NCH = CIN / CC;
     static constexpr int HL = DMA ? (P::CH > 0 ? 4 : 0) : P::CH;
     static constexpr int XCP = DMA ? (P::CH > 0 ? TW + 8 : TW) : P::XC;

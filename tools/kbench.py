@@ -15,7 +15,7 @@ from timbre_trap.framework import ops  # noqa: E402
 LEVELS = {4: 540, 8: 269, 16: 133, 32: 65}
 
 
-def timeit(fn, iters=5, warm=2):
+def timeit(fn, iters=int(os.environ.get('KB_ITERS', 5)), warm=2):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()

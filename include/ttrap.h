@@ -232,8 +232,14 @@ int tt_segment_stats(const float* x, const int64_t* offsets, int n_segments, flo
 /* Peak picking / thresholding of activations (timbre_trap/utils/processing.py:66-124) on the device.
  * x, out: (n_outer, F, T).  mode 0: keep strict local maxima along F, zero elsewhere (filter_non_peaks);
  * mode 1: x >= threshold (threshold); mode 2: peak && x >= threshold. */
-int tt_peak_pick(const float* x, float* out, int64_t n_outer, int F, int T, float threshold, int mode,
+int tt_peak_pick(const float* x, float* out, int64_t n_outer, int F, int T, double threshold, int mode,
                  void* stream);
+/* Frame-level pitch annotations -> activation targets (timbre_trap/datasets/PitchDataset.py:233-307) in float64:
+ * ones at (bins[i], frames[i]), i < n; if radius > 0: correlation along F with the 2*radius+1 `weights` (zero padded,
+ * SciPy's symmetric order -> bit-identical to gaussian_filter1d), division by the smallest blurred value over the
+ * annotated positions, clip to [0, 1].  out, work: F*T doubles each (work unused when radius == 0). */
+int tt_target_activations(const int* bins, const int* frames, int n, const double* weights, int radius, int F, int T,
+                          double* work, double* out, void* stream);
 
 #ifdef __cplusplus
 }

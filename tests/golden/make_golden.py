@@ -58,6 +58,7 @@ def install_stubs():
 
     lb = types.ModuleType('librosa')
     lb.hz_to_midi = lambda f: 12 * (np.log2(np.asanyarray(f)) - np.log2(440.0)) + 69
+    lb.midi_to_hz = lambda m: 440.0 * (2.0 ** ((np.asanyarray(m) - 69.0) / 12.0))
     sys.modules['librosa'] = lb
 
 
@@ -270,9 +271,69 @@ def make_utils_golden():
     print('utils.npz', os.path.getsize(os.path.join(HERE, 'utils.npz')))
 
 
+def closed_form_multi_pitch(midi_freqs, T=48):
+    """Ragged frame-level pitch lists (Hz) exercising the corner cases of the target generation."""
+    hz = lambda m: 440.0 * (2.0 ** ((np.asarray(m, dtype=np.float64) - 69.0) / 12.0))
+    mp = []
+    for t in range(T):
+        if t % 7 == 3:
+            mp.append(np.empty(0))                                    # silent frame
+            continue
+        k = (37 * t) % 500 + 10
+        p = [hz(midi_freqs[k] + 0.03 * ((t % 5) - 2))]               # slightly detuned from a bin centre
+        if t % 3 == 0:
+            p.append(hz(midi_freqs[(k + 1) % 540] - 0.02))            # neighbouring bin: blurs overlap and clip at 1
+        if t % 4 == 1:
+            p.append(hz(0.5 * (midi_freqs[k + 20] + midi_freqs[k + 21])))   # exactly between two bins (tie)
+        if t % 5 == 2:
+            p.append(0.0)                                             # "no pitch" marker, filtered
+        if t == 12:
+            p += [hz(midi_freqs[-1] + 1.0), hz(midi_freqs[0] - 0.5)]  # outside the bin range: dropped with a warning
+        if t == 11:
+            p += [hz(midi_freqs[0]), hz(midi_freqs[-1])]              # the edge bins
+        mp.append(np.array(p, dtype=np.float64))
+    return mp
+
+
+def make_targets_golden():
+    """f3 / f4 rows: PitchDataset.multi_pitch_to_activations / activations_to_multi_pitch of the reference."""
+    import warnings
+    install_stubs()
+    sys.modules.setdefault('mir_eval', types.ModuleType('mir_eval'))
+    sys.path.insert(0, '/root/reference')
+    from timbre_trap.datasets import PitchDataset
+    from timbre_trap.framework import CQT
+    midi_freqs = CQT(n_octaves=9, bins_per_octave=60, sample_rate=22050, secs_per_block=3).midi_freqs
+    mp = closed_form_multi_pitch(midi_freqs)
+    out = {'midi_freqs': np.asarray(midi_freqs, dtype=np.float64),
+           'mp_values': np.concatenate(mp), 'mp_counts': np.array([len(p) for p in mp], dtype=np.int64)}
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        out['act_blur'] = PitchDataset.multi_pitch_to_activations(mp, midi_freqs, 2.5)
+        out['act_noblur'] = PitchDataset.multi_pitch_to_activations(mp, midi_freqs, 0)
+        out['act_blur_wide'] = PitchDataset.multi_pitch_to_activations(mp, midi_freqs, 5.0)
+    # inverse direction on float32 network-like activations
+    a = np.abs(stub_cqt.closed_form_coefficients(1, 540, 48)[0, 0].numpy()).astype(np.float32)
+    a = np.tanh(a)
+    a[100, 5] = 0.7; a[101, 5] = 0.7                                  # plateau: no strict peak
+    a[0, 6] = 0.9; a[539, 7] = 0.95                                   # peaks on the edge rows
+    a[:, 8] = 0.0                                                     # silent frame
+    out['a2mp_in'] = a
+    for tag, kw in (('plain', dict(peaks_only=False, t=0.5)), ('peaks', dict(peaks_only=True, t=0.5)), ('peaks07', dict(peaks_only=True, t=0.7))):
+        res = PitchDataset.activations_to_multi_pitch(a, midi_freqs, **kw)
+        out['a2mp_%s_values' % tag] = np.concatenate([np.asarray(r, dtype=np.float64) for r in res]) if len(res) else np.empty(0)
+        out['a2mp_%s_counts' % tag] = np.array([len(r) for r in res], dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, 'targets.npz'), **out)
+    print('targets.npz', os.path.getsize(os.path.join(HERE, 'targets.npz')))
+
+
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'utils':
     make_utils_golden()
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'targets':
+    make_targets_golden()
 
 if __name__ == '__main__' and len(sys.argv) == 1:
     main()
     make_utils_golden()
+    make_targets_golden()

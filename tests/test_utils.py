@@ -117,3 +117,72 @@ def test_gpu_gradient_statistics_flat_buffer():
     want = [opp.gradient_statistics([p.grad.cpu().numpy()]) for _, p in model.named_parameters()]
     np.testing.assert_allclose(norms, [w[0] for w in want], rtol=2e-6)
     np.testing.assert_allclose(amax, [w[2] for w in want], rtol=0, atol=0)
+
+
+# ---------------------------------------------------------------- f3 / f4: target generation and its inverse
+TGT = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'targets.npz'))
+
+
+def _ragged(values, counts):
+    return np.split(values, np.cumsum(counts)[:-1])
+
+
+@pytest.mark.parametrize('key,decay', [('act_blur', 2.5), ('act_noblur', 0), ('act_blur_wide', 5.0)])
+def test_oracle_multi_pitch_to_activations_golden(key, decay):
+    from oracle import targets as ot
+    got = ot.multi_pitch_to_activations(_ragged(TGT['mp_values'], TGT['mp_counts']), TGT['midi_freqs'], decay)
+    assert np.array_equal(got, TGT[key])                       # bit-exact float64, incl. the SciPy blur order
+    assert (TGT[key] == 1.0).sum() >= 60 and TGT[key].max() == 1.0
+
+
+@pytest.mark.parametrize('tag,kw', [('plain', dict(peaks_only=False, t=0.5)), ('peaks', dict(peaks_only=True, t=0.5)),
+                                    ('peaks07', dict(peaks_only=True, t=0.7))])
+def test_oracle_activations_to_multi_pitch_golden(tag, kw):
+    from oracle import targets as ot
+    res = ot.activations_to_multi_pitch(TGT['a2mp_in'], TGT['midi_freqs'], **kw)
+    assert np.array_equal(np.array([len(r) for r in res]), TGT['a2mp_%s_counts' % tag])
+    assert np.array_equal(np.concatenate(res), TGT['a2mp_%s_values' % tag])
+
+
+def test_target_helpers_refuse_cpu():
+    from timbre_trap.utils import multi_pitch_to_activations
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        multi_pitch_to_activations([np.array([440.0])], TGT['midi_freqs'], device='cpu')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('key,decay', [('act_blur', 2.5), ('act_noblur', 0), ('act_blur_wide', 5.0)])
+def test_gpu_multi_pitch_to_activations_golden(key, decay):
+    import warnings
+    from timbre_trap.datasets import PitchDataset
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        got = PitchDataset.multi_pitch_to_activations(_ragged(TGT['mp_values'], TGT['mp_counts']), TGT['midi_freqs'], decay)
+    assert any('Could not fully represent' in str(x.message) for x in w)       # the out-of-range pitches of frame 12
+    assert got.dtype == np.float64 and got.shape == TGT[key].shape
+    assert np.array_equal(got, TGT[key])                       # bit-exact against the reference's SciPy arithmetic
+
+
+@pytest.mark.gpu
+def test_gpu_multi_pitch_to_activations_edge_cases():
+    from oracle import targets as ot
+    from timbre_trap.utils import multi_pitch_to_activations
+    mf = TGT['midi_freqs']
+    assert not multi_pitch_to_activations([np.empty(0)] * 5, mf).any()                      # all silent
+    assert multi_pitch_to_activations([], mf).shape == (540, 0)                              # no frames
+    g = np.random.default_rng(3)
+    mp = [ot.midi_to_hz(g.uniform(mf[0], mf[-1], size=g.integers(0, 6))) for _ in range(1500)]
+    got = multi_pitch_to_activations(mp, mf, return_tensor=True)
+    assert got.is_cuda and got.dtype == torch.float64
+    assert np.array_equal(got.cpu().numpy(), ot.multi_pitch_to_activations(mp, mf))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag,kw', [('plain', dict(peaks_only=False, t=0.5)), ('peaks', dict(peaks_only=True, t=0.5)),
+                                    ('peaks07', dict(peaks_only=True, t=0.7))])
+def test_gpu_activations_to_multi_pitch_golden(tag, kw):
+    from timbre_trap.datasets import PitchDataset
+    for a in (TGT['a2mp_in'], torch.from_numpy(TGT['a2mp_in']).cuda()):
+        res = PitchDataset.activations_to_multi_pitch(a, TGT['midi_freqs'], **kw)
+        assert np.array_equal(np.array([len(r) for r in res]), TGT['a2mp_%s_counts' % tag])
+        assert np.array_equal(np.concatenate(res), TGT['a2mp_%s_values' % tag])

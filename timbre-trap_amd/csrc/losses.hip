@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void k_segment_stats(const float* __restrict__
 // x viewed as (n_outer, F, T): keep strict local maxima along F (zero rows assumed beyond both ends);
 // mode 0: out = peak ? x : 0 ; mode 1: out = (x >= thr) ; mode 2: out = (peak && x >= thr)
 __global__ __launch_bounds__(256) void k_peak_pick(const float* __restrict__ x, float* __restrict__ out, long n_outer, int F,
-                                                   int T, float thr, int mode) {
+                                                   int T, double thr, int mode) {
     const long total = n_outer * F * (long)T;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int t = (int)(i % T);
@@ -302,13 +302,79 @@ __global__ __launch_bounds__(256) void k_peak_pick(const float* __restrict__ x, 
         }
         float r;
         if (mode == 0) r = peak ? v : 0.f;
-        else if (mode == 1) r = v >= thr ? 1.f : 0.f;
-        else r = (peak && v >= thr) ? 1.f : 0.f;
+        else if (mode == 1) r = (double)v >= thr ? 1.f : 0.f;          // compared in double like the reference's ndarray >= t
+        else r = (peak && (double)v >= thr) ? 1.f : 0.f;
         out[i] = r;
     }
 }
 
 }  // namespace
+
+// ---- target generation (PitchDataset.multi_pitch_to_activations, reference PitchDataset.py:233-307) ----
+// float64 like the reference; the blur follows SciPy's symmetric correlate1d order (centre, then pairs from the outside
+// in) with separate multiplies and adds, so the result is bit-identical to scipy.ndimage.gaussian_filter1d.
+__global__ __launch_bounds__(256) void k_tgt_scatter(const int* __restrict__ bins, const int* __restrict__ frames, int n, int T,
+                                                     double* __restrict__ a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) a[(long)bins[i] * T + frames[i]] = 1.0;
+}
+__global__ __launch_bounds__(256) void k_tgt_blur(const double* __restrict__ a, const double* __restrict__ w, int r, int F, int T,
+                                                  double* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)F * T) return;
+    const int f = (int)(i / T), t = (int)(i - (long)f * T);
+    double acc = __dmul_rn(a[i], w[r]);
+    for (int j = -r; j < 0; ++j) {
+        const int fl = f + j, fh = f - j;
+        const double lo = fl >= 0 ? a[(long)fl * T + t] : 0.0, hi = fh < F ? a[(long)fh * T + t] : 0.0;
+        acc = __dadd_rn(acc, __dmul_rn(__dadd_rn(lo, hi), w[r + j]));
+    }
+    out[i] = acc;
+}
+// smallest blurred value over the annotated (bin, frame) positions: one workgroup
+__global__ __launch_bounds__(256) void k_tgt_seed_min(const int* __restrict__ bins, const int* __restrict__ frames, int n, int T,
+                                                      const double* __restrict__ b, double* __restrict__ minv) {
+    __shared__ double red[256];
+    double m = 1.0e300;
+    for (int i = threadIdx.x; i < n; i += 256) m = fmin(m, b[(long)bins[i] * T + frames[i]]);
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] = fmin(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *minv = red[0];
+}
+__global__ __launch_bounds__(256) void k_tgt_normalise(double* __restrict__ b, long n, const double* __restrict__ minv) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double v = b[i] / *minv;
+    b[i] = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+}
+
+extern "C" int tt_target_activations(const int* bins, const int* frames, int n, const double* weights, int radius, int F, int T,
+                                     double* work, double* out, void* stream) {
+    if (!out || F <= 0 || T <= 0 || n < 0 || radius < 0 || (n > 0 && (!bins || !frames)) || (radius > 0 && (!weights || !work)))
+        return TT_E_BADARG;
+    hipStream_t st = tt_stream(stream);
+    const long total = (long)F * T;
+    double* seeds = radius > 0 ? work : out;
+    TT_HIP(hipMemsetAsync(seeds, 0, total * sizeof(double), st));
+    if (n == 0) {
+        if (radius > 0) TT_HIP(hipMemsetAsync(out, 0, total * sizeof(double), st));
+        return 0;
+    }
+    hipLaunchKernelGGL(k_tgt_scatter, dim3((n + 255) / 256), dim3(256), 0, st, bins, frames, n, T, seeds);
+    TT_LAUNCH_CHECK();
+    if (radius == 0) return 0;
+    hipLaunchKernelGGL(k_tgt_blur, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const double*)work, weights, radius, F, T, out);
+    TT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_tgt_seed_min, dim3(1), dim3(256), 0, st, bins, frames, n, T, (const double*)out, work);   // work[0] is free now
+    TT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_tgt_normalise, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, out, total, (const double*)work);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int tt_segment_stats(const float* x, const int64_t* offsets, int n_segments, float* out, void* stream) {
     if (!x || !offsets || !out || n_segments <= 0) return TT_E_BADARG;
@@ -317,7 +383,7 @@ extern "C" int tt_segment_stats(const float* x, const int64_t* offsets, int n_se
     return 0;
 }
 
-extern "C" int tt_peak_pick(const float* x, float* out, int64_t n_outer, int F, int T, float threshold, int mode, void* stream) {
+extern "C" int tt_peak_pick(const float* x, float* out, int64_t n_outer, int F, int T, double threshold, int mode, void* stream) {
     if (!x || !out || n_outer <= 0 || F <= 0 || T <= 0 || mode < 0 || mode > 2) return TT_E_BADARG;
     hipLaunchKernelGGL(k_peak_pick, dim3(nblocks(n_outer * F * (long)T, 4) * 4), dim3(256), 0, tt_stream(stream), x, out, (long)n_outer,
                        F, T, threshold, mode);

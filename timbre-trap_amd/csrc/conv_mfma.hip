@@ -469,7 +469,7 @@ __device__ __forceinline__ void conv_mainloop(const float* __restrict__ x, const
             const float* xb = xs + buf * G::BUF;
             const int c0 = chunk * G::CC;
             {
-#pragma unroll 1
+#pragma unroll
             for (int tp = 0; tp < P::NTAPS; ++tp) {
                 const int wt = P::wtap(tp, wave);
                 const float* bp0 = xb + g * G::PLANE + P::lrow(tp, wave) * G::XCP + (G::HL - P::CH) + P::lcol(tp) + l15;

@@ -1,0 +1,29 @@
+"""Group a tools/prof_summary.py listing into kernel families: python tools/prof_families.py summary.txt"""
+import collections
+import re
+import sys
+
+GROUPS = [('narrow resblocks fwd/dgrad (k_small)', r'k_small<'), ('narrow pointwise backward (k_small_bwd_a)', r'k_small_bwd_a'),
+          ('weight grad 3x3 C>=16', r'k_wgrad_dma<(16|32), (16|32), 16, .*WRes'), ('weight grad 3x3 C<=8', r'k_wgrad_dma<(4|8), (4|8), .*WRes'),
+          ('weight grad strided', r'k_wgrad_dma<.*WStr'), ('weight grad other', r'k_wgrad_reduce|k_wgrad_generic|k_wgrad3x3|k_wgrad_mfma'),
+          ('wide resblocks forward (k_rb_fwd)', r'k_rb_fwd'), ('wide 3x3 data gradient', r'k_conv_mfma<(16|32), (16|32), .*Res3x3'),
+          ('wide pointwise backward (k_rb_bwd_a)', r'k_rb_bwd_a'), ('strided / transposed convs', r'k_conv_mfma<.*(Up4|Down4)'),
+          ('latent GEMMs', r'k_gemm'), ('gate / bias passes', r'k_gate|k_elu_bwd|k_channel_sum|k_gated'),
+          ('boundary convs', r'k_conv3x3_small|k_conv_generic'), ('torch elementwise', r'at::native'),
+          ('CQT', r'k_band|k_fft|k_spec|k_scale'), ('losses / optimizer', r'k_sqdiff|k_trn|k_act|k_adamw|k_l2|k_scaled|k_dot|k_sumsq|k_finalize')]
+acc = collections.OrderedDict((g, 0.0) for g, _ in GROUPS)
+other = 0.0
+for line in open(sys.argv[1]):
+    m = re.match(r'\s*([\d.]+) ms/step.*avg=\s*[\d.]+ us\s+(.*)', line)
+    if not m:
+        continue
+    for g, pat in GROUPS:
+        if re.search(pat, m.group(2)):
+            acc[g] += float(m.group(1))
+            break
+    else:
+        other += float(m.group(1))
+for g, v in acc.items():
+    print('%-44s %6.1f ms/step' % (g, v))
+print('%-44s %6.1f ms/step' % ('other', other))
+print('%-44s %6.1f ms/step' % ('total', sum(acc.values()) + other))

@@ -1531,8 +1531,171 @@ int launch_rb_bwd(const float* x, const float* h1, const float* dy, const float*
                                                                         ws + (long)B * C * H * T, B, H, H, T, st, prec);
 }
 
+// ---- 3x3 weight gradient of the narrow levels with both operands packed ----------------------------------------------
+//   dW[co][ci][kh][kw] = sum_{h,t} g[co][h][t] x[ci][h + (kh-1)D][t + (kw-1)D]
+// With t' = t + (kw-1)D the column shift moves from x to g:
+//   A[(kw, co)][t'] = g[co][h][t' - (kw-1)D]      M = 3C rows      (three shifted copies of the wave's g row, in registers)
+//   B[t'][(kh, ci)] = x[ci][h + (kh-1)D][t']      N = 3C columns   (row-shifted, column-aligned reads of the x tile)
+// so C = 4 fills ONE 16x16 tile with 12x12 (k_wgrad_dma: three tiles at 4x16) and C = 8 four tiles at 24x24 (five at
+// 8x16), and a k-step costs one LDS read per N tile instead of one per (tap, channel) tile.  Workgroup = 8 waves = 8 rows
+// x 64 columns; x tile (row halo only) and the g rows (column halo 4) arrive by LDS-DMA; k order 4 sk + g as above.
+template <int C, int D>
+struct WPk {
+    static constexpr int M = 3 * C, MT = (M + 15) / 16, NTN = MT;
+    static constexpr int XR = 8 + 2 * D, QPLANE = XR * 64 + 4;            // padded plane pitch: 4 mod 32
+    static constexpr int NQ = C * QPLANE / 4, NQP = (NQ + 63) / 64;       // x tile: 16-byte groups, wave-wide DMA pieces
+    static constexpr int Q_FLOATS = NQP * 256;
+    static constexpr int PROW = 72;                                      // g row: columns t0 - 4 .. t0 + 67
+    static constexpr int NP = C * PROW / 4, NPP = (NP + 63) / 64;
+    static constexpr int P_FLOATS = NPP * 256;                           // per wave
+    static constexpr int IMG = MT * 16 * NTN * 16;                       // partial image [m][n]
+    static constexpr int LDS_FLOATS = Q_FLOATS + 8 * P_FLOATS;
+    static constexpr int LDS_BYTES = (LDS_FLOATS > IMG ? LDS_FLOATS : IMG) * 4;
+};
+
+template <int C, int D>
+__global__ __launch_bounds__(512) void k_wgrad3_pack(const float* __restrict__ gt, const float* __restrict__ xt,
+                                                     float* __restrict__ scratch, int B, int H, int T) {
+    using W = WPk<C, D>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+    float* xs = lds;
+    float* ps = lds + W::Q_FLOATS + wave * W::P_FLOATS;
+    const int tiles_h = (H + 7) / 8, tiles_t = (T + 63) / 64;
+    const int ntiles = B * tiles_h * tiles_t;
+    const long plane = (long)H * T;
+    const float* zero = reinterpret_cast<const float*>(&g_zero16);
+
+    // A rows of this lane: m = mt*16 + l15 = kw*C + co ; B columns: n = nt*16 + l15 = kh*C + ci
+    int aoff[W::MT], boff[W::NTN];
+    bool aok[W::MT];
+#pragma unroll
+    for (int mt = 0; mt < W::MT; ++mt) {
+        const int m = mt * 16 + l15;
+        aok[mt] = m < W::M;
+        const int kw = aok[mt] ? m / C : 0, co = aok[mt] ? m - kw * C : 0;
+        aoff[mt] = co * W::PROW + 4 - (kw - 1) * D + g;                     // + 4 sk
+        const int n = (mt * 16 + l15 < W::M) ? mt * 16 + l15 : W::M - 1;
+        const int kh = n / C, ci = n - kh * C;
+        boff[mt] = ci * W::QPLANE + (wave + kh * D) * 64 + g;              // + 4 sk
+    }
+    f32x4 acc[W::MT][W::NTN];
+#pragma unroll
+    for (int mt = 0; mt < W::MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < W::NTN; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int tt = xcd_tile(tile, ntiles);
+        const int tx = tt % tiles_t; tt /= tiles_t;
+        const int ty = tt % tiles_h;
+        const int b = tt / tiles_h, h0 = ty * 8, t0 = tx * 64;
+        __syncthreads();                                   // everyone is done with the previous tile's LDS
+        {   // x tile: rows h0 - D .. h0 + 7 + D, columns t0 .. t0 + 63
+            const float* xb = xt + (long)b * C * plane;
+            constexpr int PQ = W::QPLANE / 4;
+#pragma unroll
+            for (int jj = 0; jj < (W::NQP + 7) / 8; ++jj) {
+                const int j = wave + 8 * jj;
+                if (j < W::NQP) {
+                    const int q = j * 64 + lane;
+                    const int ci = q / PQ;
+                    const int rem = q - ci * PQ;
+                    const int r = rem >> 4, c4 = rem & 15;
+                    const int h = h0 - D + r, t = t0 + 4 * c4;
+                    const bool ok = q < W::NQ && r < W::XR && h >= 0 && h < H && t < T;
+                    glds16(ok ? xb + (ci * (int)plane + h * T + t) : zero, xs + j * 256);
+                }
+            }
+        }
+        {   // this wave's g row: columns t0 - 4 .. t0 + 67 of every channel
+            const int h = h0 + wave;
+            const float* gb = gt + (long)b * C * plane + (long)(h < H ? h : 0) * T;
+#pragma unroll
+            for (int jj = 0; jj < W::NPP; ++jj) {
+                const int q = jj * 64 + lane;
+                const int co = q / 18, c4 = q - co * 18;
+                const int t = t0 - 4 + 4 * c4;
+                const bool ok = q < W::NP && h < H && t >= 0 && t < T;
+                glds16(ok ? gb + (co * (int)plane + t) : zero, ps + jj * 256);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        float av[W::MT][16];
+#pragma unroll
+        for (int mt = 0; mt < W::MT; ++mt)
+#pragma unroll
+            for (int sk = 0; sk < 16; ++sk) av[mt][sk] = aok[mt] ? ps[aoff[mt] + 4 * sk] : 0.f;
+#pragma unroll
+        for (int sk = 0; sk < 16; ++sk) {
+#pragma unroll
+            for (int nt = 0; nt < W::NTN; ++nt) {
+                const float bv = xs[boff[nt] + 4 * sk];
+#pragma unroll
+                for (int mt = 0; mt < W::MT; ++mt) acc[mt][nt] = mfma16(av[mt][sk], bv, acc[mt][nt]);
+            }
+        }
+    }
+    __syncthreads();
+    float* red = lds;
+    for (int i = tid; i < W::IMG; i += 512) red[i] = 0.f;
+    __syncthreads();
+    constexpr int NC = W::NTN * 16;
+#pragma unroll
+    for (int mt = 0; mt < W::MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < W::NTN; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(&red[(mt * 16 + 4 * g + r) * NC + nt * 16 + l15], acc[mt][nt][r]);
+    __syncthreads();
+    float* part = scratch + (long)blockIdx.x * W::IMG;
+    for (int i = tid; i < W::IMG; i += 512) part[i] = red[i];
+}
+
+// dw[co][ci][kh][kw] += sum over workgroups of partial[(kw*C + co)][(kh*C + ci)]
+template <int C>
+__global__ __launch_bounds__(256) void k_wgrad3_pack_reduce(const float* __restrict__ scratch, float* __restrict__ dw, int nblk) {
+    constexpr int M = 3 * C, MT = (M + 15) / 16, NC = MT * 16, IMG = MT * 16 * NC;
+    __shared__ float red[8][33];
+    const int e = threadIdx.x & 31, pg = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + e;                     // element of the C*C*9 gradient
+    const bool ok = i < C * C * 9;
+    float s0 = 0.f;
+    int co = 0, ci = 0, kh = 0, kw = 0;
+    if (ok) {
+        kw = i % 3; kh = (i / 3) % 3; ci = (i / 9) % C; co = i / (9 * C);
+        const float* p = scratch + (kw * C + co) * NC + kh * C + ci;
+        for (int k = pg; k < nblk; k += 8) s0 += p[(long)k * IMG];
+    }
+    red[pg][e] = s0;
+    __syncthreads();
+    if (pg == 0 && ok)
+        dw[i] += ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])) + ((red[4][e] + red[5][e]) + (red[6][e] + red[7][e]));
+}
+
+template <int C, int D>
+int launch_wgrad3_pack(const float* g, const float* x, float* dw1, float* scratch, int B, int H, int T, hipStream_t st) {
+    using W = WPk<C, D>;
+    static bool attr = false;
+    if (!attr) {
+        TT_HIP(hipFuncSetAttribute((const void*)k_wgrad3_pack<C, D>, hipFuncAttributeMaxDynamicSharedMemorySize, W::LDS_BYTES));
+        attr = true;
+    }
+    const int ntiles = B * ((H + 7) / 8) * ((T + 63) / 64);
+    int grid = persistent_grid(ntiles, blocks_per_cu(W::LDS_BYTES, 3));
+    hipLaunchKernelGGL((k_wgrad3_pack<C, D>), dim3(grid), dim3(512), W::LDS_BYTES, st, g, x, scratch, B, H, T);
+    TT_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_wgrad3_pack_reduce<C>), dim3((C * C * 9 + 31) / 32), dim3(256), 0, st, (const float*)scratch, dw1, grid);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int C, int D>
 int rb_wgrad_only(const float* x, float* dw1, float* ws, int B, int H, int T, hipStream_t st) {
+    if constexpr (C <= 8) {
+        if (dma_ok(x, T) && dma_ok(ws, T)) return launch_wgrad3_pack<C, D>(ws, x, dw1, ws + (long)B * C * H * T, B, H, T, st);
+    }
     return launch_wgrad<C, C, WRes<D, (C <= 8 ? 8 : 4)>, false, false>(ws, nullptr, x, nullptr, dw1, nullptr, (long)C * 9, 9, 1,
                                                                         ws + (long)B * C * H * T, B, H, H, T, st);
 }

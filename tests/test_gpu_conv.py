@@ -24,7 +24,7 @@ def _rand(*shape, seed=0, scale=1.0):
 
 
 @pytest.mark.parametrize('C,d', [(4, 1), (4, 3), (8, 2), (16, 1), (16, 3), (32, 1), (32, 2), (32, 3)])
-@pytest.mark.parametrize('shape', [(2, 13, 70), (1, 9, 130), (1, 31, 64)])
+@pytest.mark.parametrize('shape', [(2, 13, 70), (1, 9, 130), (1, 31, 64), (2, 20, 192), (1, 70, 256), (9, 5, 68)])
 @pytest.mark.parametrize('save_hidden', [True, False])
 def test_fused_resblock_forward_backward(C, d, shape, save_hidden, monkeypatch):
     from timbre_trap.framework import ops
@@ -167,7 +167,7 @@ def test_blocks_against_reference_golden(golden):
 
 
 @pytest.mark.parametrize('C', [4, 8, 16, 32])
-@pytest.mark.parametrize('H,T', [(13, 70), (20, 64), (9, 130)])
+@pytest.mark.parametrize('H,T', [(13, 70), (20, 64), (9, 130), (22, 192), (37, 132)])
 def test_mfma_strided_and_transposed_conv(C, H, T):
     """EncoderBlock.sconv / DecoderBlock.tconv on the MFMA kernels (Down4 / Up4 policies) vs float64 torch."""
     from timbre_trap.framework import ops

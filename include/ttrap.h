@@ -231,8 +231,9 @@ int tt_adamw_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, 
 int tt_segment_stats(const float* x, const int64_t* offsets, int n_segments, float* out, void* stream);
 /* Peak picking / thresholding of activations (timbre_trap/utils/processing.py:66-124) on the device.
  * x, out: (n_outer, F, T).  mode 0: keep strict local maxima along F, zero elsewhere (filter_non_peaks);
- * mode 1: x >= threshold (threshold); mode 2: peak && x >= threshold. */
-int tt_peak_pick(const float* x, float* out, int64_t n_outer, int F, int T, double threshold, int mode,
+ * mode 1: x >= threshold (threshold); mode 2: peak && x >= threshold.  Rows f >= f_valid read as zero first (the
+ * `activations[valid_freqs] = 0` of experiments/evaluate.py:107-112); f_valid <= 0 or >= F disables the mask. */
+int tt_peak_pick(const float* x, float* out, int64_t n_outer, int F, int T, double threshold, int mode, int f_valid,
                  void* stream);
 /* Frame-level pitch annotations -> activation targets (timbre_trap/datasets/PitchDataset.py:233-307) in float64:
  * ones at (bins[i], frames[i]), i < n; if radius > 0: correlation along F with the 2*radius+1 `weights` (zero padded,

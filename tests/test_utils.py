@@ -186,3 +186,17 @@ def test_gpu_activations_to_multi_pitch_golden(tag, kw):
         res = PitchDataset.activations_to_multi_pitch(a, TGT['midi_freqs'], **kw)
         assert np.array_equal(np.array([len(r) for r in res]), TGT['a2mp_%s_counts' % tag])
         assert np.array_equal(np.concatenate(res), TGT['a2mp_%s_values' % tag])
+
+
+@pytest.mark.gpu
+def test_gpu_peaks_above_with_bin_mask():
+    """The evaluate()-side composition: zero the bins above the scoring range, keep strict peaks, threshold."""
+    from timbre_trap.utils import peaks_above
+    g = torch.Generator().manual_seed(11)
+    a = torch.rand(2, 540, 300, generator=g)
+    masked = a.clone()
+    masked[:, 472:] = 0
+    want = opp.threshold(opp.filter_non_peaks(masked.numpy()), 0.6)
+    got = peaks_above(a.cuda(), 0.6, n_valid_bins=472).cpu().numpy()
+    assert np.array_equal(got, want)
+    assert not got[:, 472:].any() and got[:, 471].any()          # row 471 now compares against a zero row above it

@@ -288,16 +288,17 @@ __global__ __launch_bounds__(256) void k_segment_stats(const float* __restrict__
 // x viewed as (n_outer, F, T): keep strict local maxima along F (zero rows assumed beyond both ends);
 // mode 0: out = peak ? x : 0 ; mode 1: out = (x >= thr) ; mode 2: out = (peak && x >= thr)
 __global__ __launch_bounds__(256) void k_peak_pick(const float* __restrict__ x, float* __restrict__ out, long n_outer, int F,
-                                                   int T, double thr, int mode) {
+                                                   int T, double thr, int mode, int f_valid) {
     const long total = n_outer * F * (long)T;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int t = (int)(i % T);
         const int f = (int)((i / T) % F);
         (void)t;
-        const float v = x[i];
+        // rows f >= f_valid (bins above the evaluation range, reference experiments/evaluate.py:46,107-112) read as zero
+        const float v = f < f_valid ? x[i] : 0.f;
         bool peak = true;
         if (mode != 1) {
-            const float up = f > 0 ? x[i - T] : 0.f, dn = f < F - 1 ? x[i + T] : 0.f;
+            const float up = f > 0 ? x[i - T] : 0.f, dn = (f < F - 1 && f + 1 < f_valid) ? x[i + T] : 0.f;
             peak = v > up && v > dn;
         }
         float r;
@@ -383,10 +384,11 @@ extern "C" int tt_segment_stats(const float* x, const int64_t* offsets, int n_se
     return 0;
 }
 
-extern "C" int tt_peak_pick(const float* x, float* out, int64_t n_outer, int F, int T, double threshold, int mode, void* stream) {
+extern "C" int tt_peak_pick(const float* x, float* out, int64_t n_outer, int F, int T, double threshold, int mode, int f_valid,
+                            void* stream) {
     if (!x || !out || n_outer <= 0 || F <= 0 || T <= 0 || mode < 0 || mode > 2) return TT_E_BADARG;
     hipLaunchKernelGGL(k_peak_pick, dim3(nblocks(n_outer * F * (long)T, 4) * 4), dim3(256), 0, tt_stream(stream), x, out, (long)n_outer,
-                       F, T, threshold, mode);
+                       F, T, threshold, mode, f_valid > 0 && f_valid < F ? f_valid : F);
     TT_LAUNCH_CHECK();
     return 0;
 }

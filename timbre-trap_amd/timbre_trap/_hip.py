@@ -62,7 +62,7 @@ _PROTOS = {
     'tt_transcription_loss_fwd': (c_int, [P, P, P, P, P, I, I, I, I, P]),
     'tt_transcription_loss_bwd': (c_int, [P, P, P, P, P, I, I, I, I, P]),
     'tt_segment_stats': (c_int, [P, P, I, P, P]),
-    'tt_peak_pick': (c_int, [P, P, L, I, I, ctypes.c_double, I, P]),
+    'tt_peak_pick': (c_int, [P, P, L, I, I, ctypes.c_double, I, I, P]),
     'tt_target_activations': (c_int, [P, P, I, P, I, I, I, P, P, P]),
     'tt_l2norm': (c_int, [P, P, P, L, P]),
     'tt_adamw_step': (c_int, [P, P, P, P, P, L, F_, F_, F_, F_, F_, I, F_, I, P]),

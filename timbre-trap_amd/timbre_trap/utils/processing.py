@@ -18,7 +18,7 @@ def to_array(tensor):
     return tensor.cpu().detach().numpy()
 
 
-def _device_pick(x, thr, mode):
+def _device_pick(x, thr, mode, f_valid=0):
     """
     Tensors stay on the device and come back as float32 tensors; ndarrays (the reference's calling convention) are
     uploaded, processed by the same kernel and returned as float64 ndarrays like the reference returns.  The kernel
@@ -35,7 +35,7 @@ def _device_pick(x, thr, mode):
     out = torch.empty_like(xc)
     if xc.numel():
         _hip.check(_hip.lib().tt_peak_pick(_hip.ptr(xc), _hip.ptr(out), xc.numel() // (F * T), F, T, float(thr), mode,
-                                           _hip.stream_ptr()), 'tt_peak_pick')
+                                           int(f_valid), _hip.stream_ptr()), 'tt_peak_pick')
     return out.cpu().numpy().astype(np.float64) if as_array else out
 
 
@@ -49,6 +49,10 @@ def threshold(_arr, t=0.5):
     return _device_pick(_arr, t, 1)
 
 
-def peaks_above(activations, t=0.5):
-    """threshold(filter_non_peaks(x), t) in one device pass (what evaluate() feeds to the multi-pitch conversion)."""
-    return _device_pick(activations, t, 2)
+def peaks_above(activations, t=0.5, n_valid_bins=0):
+    """
+    threshold(filter_non_peaks(x), t) in one device pass (what evaluate() feeds to the multi-pitch conversion).
+    ``n_valid_bins`` > 0 first zeroes the rows from that bin upwards -- the ``activations[valid_freqs] = 0`` step of
+    reference experiments/evaluate.py:107-112 (bins above mir_eval's 5 kHz limit: 472 of 540 at the default geometry).
+    """
+    return _device_pick(activations, t, 2, n_valid_bins)

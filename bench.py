@@ -207,6 +207,11 @@ def main():
         raise SystemExit('bench.py needs an MI355X (there is no CPU fallback for the HIP path)')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    if not os.path.exists(_hip.LIB_PATH):       # normally prebuilt by __graft_entry__.build(); compile once per node otherwise
+        if local_rank == 0:
+            _hip.build()
+        if world > 1:
+            dist.barrier()
     _hip.lib()
 
     model = build_model(args.mc, args.latent, dev)

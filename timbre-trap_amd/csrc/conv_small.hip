@@ -1,4 +1,6 @@
 // ResidualConv2dBlock for the narrow levels (C = 4, 8) of the Timbre-Trap autoencoder on the gfx950 vector ALUs.
+// Two implementations of the forward / data-gradient pass: k_small_lds (default: input tile staged by LDS-DMA, taps read
+// from LDS with immediate offsets) and k_small (taps straight from global memory; any T / alignment).
 //
 // At C <= 8 the block moves 2*C*4 bytes per pixel for 20*C*C flops: 10-20 flop/B, below the fp32 ridge of the
 // chip (~25 flop/B).  These levels are HBM/latency-bound, a 16-row MFMA tile would be 25-50 % empty, and a
@@ -11,6 +13,7 @@
 //   k_small<C,D,1>  dx = dy + W1^T (*) dA1                                    (data gradient, flipped weights)
 //   k_small_bwd_a   recompute + pointwise chain -> dA1; db1, db2, dW2 in registers, reduced once per workgroup
 //   (dW1 stays on the MFMA weight-gradient kernel of conv_mfma.hip)
+#include <cstdlib>
 #include "common.h"
 #include "conv_small.h"
 
@@ -137,6 +140,127 @@ __global__ __launch_bounds__(256) void k_small(const float* __restrict__ x, cons
     }
 }
 
+// ---- LDS-tiled variant ---------------------------------------------------------------------------------------------
+// Same arithmetic, input tile (all C channels, 8 rows + halo, 64 columns + halo) brought in by LDS-DMA and double
+// buffered like the matrix-core kernels.  A thread still owns one pixel, but its 9 C taps are ds_read_b32 with immediate
+// offsets from ONE base address: no per-tap address arithmetic, no validity selects (the halo is zero-filled by the
+// DMA), no global loads in the inner loop, and the residual comes from the tile's centre instead of a second global read.
+__device__ float4 g_zero16_small;
+
+__device__ __forceinline__ void glds16s(const float* gsrc, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ int xcd_tile_s(int v, int ntiles) {
+    const int per = ntiles >> 3;
+    return v < (per << 3) ? (v & 7) * per + (v >> 3) : v;
+}
+
+template <int C, int D>
+struct SL {
+    static constexpr int XR = 8 + 2 * D, XCP = 72, PLANE = XR * XCP;
+    static constexpr int NQ = C * PLANE / 4, NP = (NQ + 63) / 64;
+    static constexpr int BUF = NP * 256;
+    static constexpr int LDS_BYTES = (2 * BUF + SW<C>::FLOATS) * 4;
+};
+
+template <int C, int D, int MODE>
+__global__ __launch_bounds__(512) void k_small_lds(const float* __restrict__ x, const float* __restrict__ w1,
+                                                   const float* __restrict__ b1, const float* __restrict__ w2,
+                                                   const float* __restrict__ b2, const float* __restrict__ res,
+                                                   float* __restrict__ y, float* __restrict__ h1out, int B, int H, int T) {
+    using S = SW<C>;
+    using L = SL<C, D>;
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+    float* xs = lds_dyn;
+    float* wimg = lds_dyn + 2 * L::BUF;
+    build_images<C>(wimg, w1, MODE == 0 ? b1 : nullptr, MODE == 0 ? w2 : nullptr, MODE == 0 ? b2 : nullptr, MODE == 1);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tiles_h = (H + 7) / 8, tiles_t = (T + 63) / 64;
+    const int ntiles = B * tiles_h * tiles_t;
+    const long plane = (long)H * T;
+    const float* zero = reinterpret_cast<const float*>(&g_zero16_small);
+
+    auto issue = [&](int v, int buf) {
+        int tt = xcd_tile_s(v, ntiles);
+        const int tx = tt % tiles_t; tt /= tiles_t;
+        const int ty = tt % tiles_h;
+        const int b = tt / tiles_h, row0 = ty * 8 - D, col0 = tx * 64 - 4;
+        const float* xb = x + (long)b * C * plane;
+        float* dst = xs + buf * L::BUF;
+#pragma unroll
+        for (int jj = 0; jj < (L::NP + 7) / 8; ++jj) {
+            const int j = wave + 8 * jj;
+            if (j < L::NP) {
+                const int q = j * 64 + lane;
+                const int ci = q / (L::PLANE / 4);
+                const int rem = q - ci * (L::PLANE / 4);
+                const int r = rem / 18, c4 = rem - r * 18;
+                const int h = row0 + r, t = col0 + 4 * c4;
+                const bool ok = q < L::NQ && h >= 0 && h < H && t >= 0 && t < T;
+                glds16s(ok ? xb + (ci * (int)plane + h * T + t) : zero, dst + j * 256);
+            }
+        }
+    };
+
+    int v = blockIdx.x;
+    if (v >= ntiles) return;
+    int buf = 0;
+    issue(v, 0);
+    for (; v < ntiles; v += gridDim.x) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (v + (int)gridDim.x < ntiles) issue(v + (int)gridDim.x, buf ^ 1);
+        int tt = xcd_tile_s(v, ntiles);
+        const int tx = tt % tiles_t; tt /= tiles_t;
+        const int ty = tt % tiles_h;
+        const int b = tt / tiles_h, h = ty * 8 + wave, t = tx * 64 + lane;
+        const float* xt = xs + buf * L::BUF + wave * L::XCP + (4 - D) + lane;      // tap (kh, kw) of channel ci: + ci*PLANE + kh*D*XCP + kw*D
+        float acc[C];
+#pragma unroll
+        for (int co = 0; co < C; ++co) acc[co] = wimg[S::B1 + co];
+#pragma unroll 1
+        for (int ci = 0; ci < C; ++ci) {
+            const float* xc = xt + ci * L::PLANE;
+            const float* wc = wimg + S::W1 + ci * 9 * C;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float xv = xc[kh * D * L::XCP + kw * D];
+                    const float* wl = wc + (kh * 3 + kw) * C;
+#pragma unroll
+                    for (int co = 0; co < C; ++co) acc[co] = fmaf(xv, wl[co], acc[co]);
+                }
+            }
+        }
+        if (h < H && t < T) {
+            const long o = (long)b * C * plane + (long)h * T + t;
+            if (MODE == 0) {
+                float a2[C];
+#pragma unroll
+                for (int co = 0; co < C; ++co) a2[co] = wimg[S::B2 + co];
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const float hv = elu1(acc[c]);
+                    if (h1out) h1out[o + c * plane] = hv;
+                    const float* wl = wimg + S::W2 + c * C;
+#pragma unroll
+                    for (int co = 0; co < C; ++co) a2[co] = fmaf(hv, wl[co], a2[co]);
+                }
+#pragma unroll
+                for (int co = 0; co < C; ++co) y[o + co * plane] = elu1(a2[co]) + xt[co * L::PLANE + D * L::XCP + D];
+            } else {
+#pragma unroll
+                for (int co = 0; co < C; ++co) y[o + co * plane] = acc[co] + res[o + co * plane];
+            }
+        }
+        buf ^= 1;
+    }
+}
+
 // recompute + pointwise chain; persistent workgroups accumulate db1, db2, dW2 in registers
 template <int C, int D, bool RECOMP>
 __global__ __launch_bounds__(256) void k_small_bwd_a(const float* __restrict__ x, const float* __restrict__ h1in,
@@ -234,9 +358,32 @@ __global__ __launch_bounds__(256) void k_small_bwd_a(const float* __restrict__ x
     }
 }
 
+// the LDS-tiled kernels need LDS-DMA-able rows (T % 4 == 0, 16-byte aligned input); TTRAP_SMALL_GLOBAL=1 forces the
+// thread-per-pixel kernels with global taps (kept for unaligned shapes and for A/B measurements)
+inline bool lds_variant() { static const bool v = getenv("TTRAP_SMALL_GLOBAL") == nullptr; return v; }
+
+template <int C, int D, int MODE>
+int launch_small_lds(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* res, float* y,
+                     float* h1, int B, int H, int T, hipStream_t st) {
+    using L = SL<C, D>;
+    static bool attr = false;
+    if (!attr) {
+        TT_HIP(hipFuncSetAttribute((const void*)k_small_lds<C, D, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES));
+        attr = true;
+    }
+    const int ntiles = B * ((H + 7) / 8) * ((T + 63) / 64);
+    int per_cu = (160 * 1024) / L::LDS_BYTES;
+    if (per_cu > 4) per_cu = 4;
+    const int grid = ntiles < 256 * per_cu ? ntiles : 256 * per_cu;
+    hipLaunchKernelGGL((k_small_lds<C, D, MODE>), dim3(grid), dim3(512), L::LDS_BYTES, st, x, w1, b1, w2, b2, res, y, h1, B, H, T);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int C, int D>
 int fwd_t(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y, float* h1, int B, int H,
           int T, hipStream_t st) {
+    if (lds_variant() && T % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) return launch_small_lds<C, D, 0>(x, w1, b1, w2, b2, nullptr, y, h1, B, H, T, st);
     dim3 grid((T + 63) / 64, (H + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, B);
     hipLaunchKernelGGL((k_small<C, D, 0>), grid, dim3(256), 0, st, x, w1, b1, w2, b2, (const float*)nullptr, y, h1, B, H, T);
     TT_LAUNCH_CHECK();
@@ -257,6 +404,8 @@ int bwd_t(const float* x, const float* h1, const float* dy, const float* w1, con
         hipLaunchKernelGGL((k_small_bwd_a<C, D, true>), dim3(pgrid), dim3(256), 0, st, x, h1, dy, w1, b1, w2, b2, ws, db1, dw2,
                            db2, B, H, T);
     TT_LAUNCH_CHECK();
+    if (lds_variant() && T % 4 == 0 && (reinterpret_cast<uintptr_t>(ws) & 15) == 0)
+        return launch_small_lds<C, D, 1>(ws, w1, nullptr, nullptr, nullptr, dy, dx, nullptr, B, H, T, st);
     dim3 grid((T + 63) / 64, (H + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, B);
     hipLaunchKernelGGL((k_small<C, D, 1>), grid, dim3(256), 0, st, (const float*)ws, w1, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, dy, dx, (float*)nullptr, B, H, T);

@@ -19,7 +19,10 @@
 
 namespace {
 
-constexpr int ROWS_PER_BLOCK = 16;      // 4 waves x 4 row passes
+constexpr int ROWS_PER_BLOCK = 16;
+#ifndef SMALL_RPT
+#define SMALL_RPT 2
+#endif      // 4 waves x 4 row passes
 
 template <int C>
 struct SW {
@@ -156,27 +159,30 @@ __device__ __forceinline__ int xcd_tile_s(int v, int ntiles) {
     return v < (per << 3) ? (v & 7) * per + (v >> 3) : v;
 }
 
-template <int C, int D>
+// RPT = rows per thread (tile = 8 RPT rows x 64 columns): two rows halve the weight reads per pixel and shrink the halo
+// share of the tile; NBUF = 2 double-buffers the DMA (C = 8 with 16-row tiles keeps one buffer and relies on the second
+// workgroup of the CU to cover its DMA wait).
+template <int C, int D, int RPT, int NBUF>
 struct SL {
-    static constexpr int XR = 8 + 2 * D, XCP = 72, PLANE = XR * XCP;
+    static constexpr int TR = 8 * RPT, XR = TR + 2 * D, XCP = 72, PLANE = XR * XCP;
     static constexpr int NQ = C * PLANE / 4, NP = (NQ + 63) / 64;
     static constexpr int BUF = NP * 256;
-    static constexpr int LDS_BYTES = (2 * BUF + SW<C>::FLOATS) * 4;
+    static constexpr int LDS_BYTES = (NBUF * BUF + SW<C>::FLOATS) * 4;
 };
 
-template <int C, int D, int MODE>
+template <int C, int D, int MODE, int RPT, int NBUF>
 __global__ __launch_bounds__(512) void k_small_lds(const float* __restrict__ x, const float* __restrict__ w1,
                                                    const float* __restrict__ b1, const float* __restrict__ w2,
                                                    const float* __restrict__ b2, const float* __restrict__ res,
                                                    float* __restrict__ y, float* __restrict__ h1out, int B, int H, int T) {
     using S = SW<C>;
-    using L = SL<C, D>;
+    using L = SL<C, D, RPT, NBUF>;
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
     float* xs = lds_dyn;
-    float* wimg = lds_dyn + 2 * L::BUF;
+    float* wimg = lds_dyn + NBUF * L::BUF;
     build_images<C>(wimg, w1, MODE == 0 ? b1 : nullptr, MODE == 0 ? w2 : nullptr, MODE == 0 ? b2 : nullptr, MODE == 1);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tiles_h = (H + 7) / 8, tiles_t = (T + 63) / 64;
+    const int tiles_h = (H + L::TR - 1) / L::TR, tiles_t = (T + 63) / 64;
     const int ntiles = B * tiles_h * tiles_t;
     const long plane = (long)H * T;
     const float* zero = reinterpret_cast<const float*>(&g_zero16_small);
@@ -185,7 +191,7 @@ __global__ __launch_bounds__(512) void k_small_lds(const float* __restrict__ x, 
         int tt = xcd_tile_s(v, ntiles);
         const int tx = tt % tiles_t; tt /= tiles_t;
         const int ty = tt % tiles_h;
-        const int b = tt / tiles_h, row0 = ty * 8 - D, col0 = tx * 64 - 4;
+        const int b = tt / tiles_h, row0 = ty * L::TR - D, col0 = tx * 64 - 4;
         const float* xb = x + (long)b * C * plane;
         float* dst = xs + buf * L::BUF;
 #pragma unroll
@@ -206,19 +212,23 @@ __global__ __launch_bounds__(512) void k_small_lds(const float* __restrict__ x, 
     int v = blockIdx.x;
     if (v >= ntiles) return;
     int buf = 0;
-    issue(v, 0);
+    if (NBUF == 2) issue(v, 0);
     for (; v < ntiles; v += gridDim.x) {
+        if (NBUF == 1) { __syncthreads(); issue(v, 0); }              // everyone is done with the previous tile
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (v + (int)gridDim.x < ntiles) issue(v + (int)gridDim.x, buf ^ 1);
+        if (NBUF == 2 && v + (int)gridDim.x < ntiles) issue(v + (int)gridDim.x, buf ^ 1);
         int tt = xcd_tile_s(v, ntiles);
         const int tx = tt % tiles_t; tt /= tiles_t;
         const int ty = tt % tiles_h;
-        const int b = tt / tiles_h, h = ty * 8 + wave, t = tx * 64 + lane;
-        const float* xt = xs + buf * L::BUF + wave * L::XCP + (4 - D) + lane;      // tap (kh, kw) of channel ci: + ci*PLANE + kh*D*XCP + kw*D
-        float acc[C];
+        const int b = tt / tiles_h, h0 = ty * L::TR + wave, t = tx * 64 + lane;
+        // tap (kh, kw) of channel ci for row r of this thread: + ci*PLANE + (8 r + kh*D)*XCP + kw*D
+        const float* xt = xs + buf * L::BUF + wave * L::XCP + (4 - D) + lane;
+        float acc[RPT][C];
 #pragma unroll
-        for (int co = 0; co < C; ++co) acc[co] = wimg[S::B1 + co];
+        for (int r = 0; r < RPT; ++r)
+#pragma unroll
+            for (int co = 0; co < C; ++co) acc[r][co] = wimg[S::B1 + co];
 #pragma unroll 1
         for (int ci = 0; ci < C; ++ci) {
             const float* xc = xt + ci * L::PLANE;
@@ -228,36 +238,46 @@ __global__ __launch_bounds__(512) void k_small_lds(const float* __restrict__ x, 
                 asm volatile("" ::: "memory");
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw) {
-                    const float xv = xc[kh * D * L::XCP + kw * D];
                     const float* wl = wc + (kh * 3 + kw) * C;
+                    float w[C];
 #pragma unroll
-                    for (int co = 0; co < C; ++co) acc[co] = fmaf(xv, wl[co], acc[co]);
+                    for (int co = 0; co < C; ++co) w[co] = wl[co];
+#pragma unroll
+                    for (int r = 0; r < RPT; ++r) {
+                        const float xv = xc[(8 * r + kh * D) * L::XCP + kw * D];
+#pragma unroll
+                        for (int co = 0; co < C; ++co) acc[r][co] = fmaf(xv, w[co], acc[r][co]);
+                    }
                 }
             }
         }
-        if (h < H && t < T) {
-            const long o = (long)b * C * plane + (long)h * T + t;
-            if (MODE == 0) {
-                float a2[C];
 #pragma unroll
-                for (int co = 0; co < C; ++co) a2[co] = wimg[S::B2 + co];
-                asm volatile("" ::: "memory");
+        for (int r = 0; r < RPT; ++r) {
+            const int h = h0 + 8 * r;
+            if (h < H && t < T) {
+                const long o = (long)b * C * plane + (long)h * T + t;
+                if (MODE == 0) {
+                    float a2[C];
 #pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    const float hv = elu1(acc[c]);
-                    if (h1out) h1out[o + c * plane] = hv;
-                    const float* wl = wimg + S::W2 + c * C;
+                    for (int co = 0; co < C; ++co) a2[co] = wimg[S::B2 + co];
+                    asm volatile("" ::: "memory");
 #pragma unroll
-                    for (int co = 0; co < C; ++co) a2[co] = fmaf(hv, wl[co], a2[co]);
+                    for (int c = 0; c < C; ++c) {
+                        const float hv = elu1(acc[r][c]);
+                        if (h1out) h1out[o + c * plane] = hv;
+                        const float* wl = wimg + S::W2 + c * C;
+#pragma unroll
+                        for (int co = 0; co < C; ++co) a2[co] = fmaf(hv, wl[co], a2[co]);
+                    }
+#pragma unroll
+                    for (int co = 0; co < C; ++co) y[o + co * plane] = elu1(a2[co]) + xt[co * L::PLANE + (8 * r + D) * L::XCP + D];
+                } else {
+#pragma unroll
+                    for (int co = 0; co < C; ++co) y[o + co * plane] = acc[r][co] + res[o + co * plane];
                 }
-#pragma unroll
-                for (int co = 0; co < C; ++co) y[o + co * plane] = elu1(a2[co]) + xt[co * L::PLANE + D * L::XCP + D];
-            } else {
-#pragma unroll
-                for (int co = 0; co < C; ++co) y[o + co * plane] = acc[co] + res[o + co * plane];
             }
         }
-        buf ^= 1;
+        if (NBUF == 2) buf ^= 1;
     }
 }
 
@@ -365,17 +385,18 @@ inline bool lds_variant() { static const bool v = getenv("TTRAP_SMALL_GLOBAL") =
 template <int C, int D, int MODE>
 int launch_small_lds(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* res, float* y,
                      float* h1, int B, int H, int T, hipStream_t st) {
-    using L = SL<C, D>;
+    constexpr int RPT = SMALL_RPT, NBUF = (C == 8 && RPT == 2) ? 1 : 2;
+    using L = SL<C, D, RPT, NBUF>;
     static bool attr = false;
     if (!attr) {
-        TT_HIP(hipFuncSetAttribute((const void*)k_small_lds<C, D, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES));
+        TT_HIP(hipFuncSetAttribute((const void*)k_small_lds<C, D, MODE, RPT, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES));
         attr = true;
     }
-    const int ntiles = B * ((H + 7) / 8) * ((T + 63) / 64);
+    const int ntiles = B * ((H + L::TR - 1) / L::TR) * ((T + 63) / 64);
     int per_cu = (160 * 1024) / L::LDS_BYTES;
     if (per_cu > 4) per_cu = 4;
     const int grid = ntiles < 256 * per_cu ? ntiles : 256 * per_cu;
-    hipLaunchKernelGGL((k_small_lds<C, D, MODE>), dim3(grid), dim3(512), L::LDS_BYTES, st, x, w1, b1, w2, b2, res, y, h1, B, H, T);
+    hipLaunchKernelGGL((k_small_lds<C, D, MODE, RPT, NBUF>), dim3(grid), dim3(512), L::LDS_BYTES, st, x, w1, b1, w2, b2, res, y, h1, B, H, T);
     TT_LAUNCH_CHECK();
     return 0;
 }

@@ -99,10 +99,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int BM_>
 __global__ __launch_bounds__(256) void k_gemm_mfma(GemmP p, int bper) {
     constexpr int BN_ = 128, BK_ = 16, MT = BM_ / 16;
-    constexpr int AP = BM_ + 17, BP = BN_ + 17;      // 17 mod 32: the k-rows of a fragment read AND a k-fastest staging write spread over the banks
+    constexpr int AP = BM_ + 20, BP = BN_ + 20;      // 20 mod 32 and a multiple of 4: fragment reads and k-fastest staging writes stay spread
+                                                     // over the banks, and rows start 16-byte aligned for the float4 staging of unit-stride operands
     constexpr int NA = BM_ * BK_ / 256, NB = BN_ * BK_ / 256;
-    __shared__ float As[BK_ * AP];
-    __shared__ float Bs[BK_ * BP];
+    __shared__ __attribute__((aligned(16))) float As[BK_ * AP];
+    __shared__ __attribute__((aligned(16))) float Bs[BK_ * BP];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     const int m0 = blockIdx.y * BM_, n0 = blockIdx.x * BN_;
     const int b_lo = blockIdx.z * bper, b_hi = (b_lo + bper < (int)p.sc_batches) ? b_lo + bper : (int)p.sc_batches;
@@ -112,42 +113,101 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(GemmP p, int bper) {
     const int mt_used = (p.M - m0 + 15) / 16;            // row tiles of this workgroup that hold valid rows (uniform)
     const int nk = (p.K + BK_ - 1) / BK_;
     const int nstage = nk * (b_hi - b_lo);
+    // operands whose m / n index is the unit-stride one are staged 16 bytes per lane
+    const bool avec = p.am == 1 && (p.ak & 3) == 0 && (p.sa & 3) == 0 && (reinterpret_cast<uintptr_t>(p.A) & 15) == 0 && m0 + BM_ <= p.M;
+    const bool bvec = p.bn == 1 && (p.bk & 3) == 0 && (p.sb & 3) == 0 && (reinterpret_cast<uintptr_t>(p.B) & 15) == 0 && n0 + BN_ <= p.N;
+    // k-contiguous operands (weight-gradient form): 16 bytes along k per lane, transposed on the LDS write
+    const bool akvec = p.ak == 1 && (p.am & 3) == 0 && (p.sa & 3) == 0 && (reinterpret_cast<uintptr_t>(p.A) & 15) == 0 && m0 + BM_ <= p.M && (p.K & 15) == 0;
+    const bool bkvec = p.bk == 1 && (p.bn & 3) == 0 && (p.sb & 3) == 0 && (reinterpret_cast<uintptr_t>(p.B) & 15) == 0 && n0 + BN_ <= p.N && (p.K & 15) == 0;
     float ra[NA], rb[NB];
     auto load = [&](int stage) {
         const int bz = b_lo + stage / nk, k0 = (stage % nk) * BK_;
         const float* A = p.A + (long)bz * p.sa;
         const float* B = p.B + (long)bz * p.sb;
+        if (avec) {
+            static_assert(NA == 4 || NA == 3, "one float4 per thread covers a 64 x 16 tile");
+            const int m4 = tid % (BM_ / 4), k = tid / (BM_ / 4);
+            float4 v = float4{0.f, 0.f, 0.f, 0.f};
+            if (k < BK_ && k0 + k < p.K) v = *reinterpret_cast<const float4*>(A + (long)(k0 + k) * p.ak + m0 + 4 * m4);
+            ra[0] = v.x; ra[1] = v.y; ra[2] = v.z; ra[3 % NA] = NA == 4 ? v.w : ra[3 % NA];
+        } else if (akvec) {
+            const float4 v = *reinterpret_cast<const float4*>(A + (long)(m0 + (tid >> 2)) * p.am + k0 + 4 * (tid & 3));
+            ra[0] = v.x; ra[1] = v.y; ra[2] = v.z; ra[3 % NA] = v.w;
+        } else {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int e = tid + 256 * i;
-            int m, k;
-            if (p.ak == 1) { k = e & (BK_ - 1); m = e >> 4; } else { m = e % BM_; k = e / BM_; }
-            const int gm = m0 + m, gk = k0 + k;
-            ra[i] = (gm < p.M && gk < p.K) ? A[gm * p.am + gk * p.ak] : 0.f;
+            for (int i = 0; i < NA; ++i) {
+                const int e = tid + 256 * i;
+                int m, k;
+                if (p.ak == 1) { k = e & (BK_ - 1); m = e >> 4; } else { m = e % BM_; k = e / BM_; }
+                const int gm = m0 + m, gk = k0 + k;
+                ra[i] = (gm < p.M && gk < p.K) ? A[gm * p.am + gk * p.ak] : 0.f;
+            }
         }
+        if (bvec) {
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int e = tid + 256 * i;
-            int n, k;
-            if (p.bn == 1) { n = e & (BN_ - 1); k = e >> 7; } else { k = e & (BK_ - 1); n = e >> 4; }
-            const int gn = n0 + n, gk = k0 + k;
-            rb[i] = (gn < p.N && gk < p.K) ? B[gk * p.bk + gn * p.bn] : 0.f;
+            for (int i = 0; i < NB / 4; ++i) {
+                const int e = tid + 256 * i;
+                const int n4 = e & 31, k = e >> 5;
+                float4 v = float4{0.f, 0.f, 0.f, 0.f};
+                if (k0 + k < p.K) v = *reinterpret_cast<const float4*>(B + (long)(k0 + k) * p.bk + n0 + 4 * n4);
+                rb[4 * i] = v.x; rb[4 * i + 1] = v.y; rb[4 * i + 2] = v.z; rb[4 * i + 3] = v.w;
+            }
+        } else if (bkvec) {
+#pragma unroll
+            for (int i = 0; i < NB / 4; ++i) {
+                const int e = tid + 256 * i;
+                const float4 v = *reinterpret_cast<const float4*>(B + (long)(n0 + (e >> 2)) * p.bn + k0 + 4 * (e & 3));
+                rb[4 * i] = v.x; rb[4 * i + 1] = v.y; rb[4 * i + 2] = v.z; rb[4 * i + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int e = tid + 256 * i;
+                int n, k;
+                if (p.bn == 1) { n = e & (BN_ - 1); k = e >> 7; } else { k = e & (BK_ - 1); n = e >> 4; }
+                const int gn = n0 + n, gk = k0 + k;
+                rb[i] = (gn < p.N && gk < p.K) ? B[gk * p.bk + gn * p.bn] : 0.f;
+            }
         }
     };
     auto commit = [&]() {
+        if (avec) {
+            const int m4 = tid % (BM_ / 4), k = tid / (BM_ / 4);
+            if (k < BK_) *reinterpret_cast<float4*>(&As[k * AP + 4 * m4]) = float4{ra[0], ra[1], ra[2], ra[3 % NA]};
+        } else if (akvec) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int e = tid + 256 * i;
-            int m, k;
-            if (p.ak == 1) { k = e & (BK_ - 1); m = e >> 4; } else { m = e % BM_; k = e / BM_; }
-            As[k * AP + m] = ra[i];
+            for (int j = 0; j < 4; ++j) As[(4 * (tid & 3) + j) * AP + (tid >> 2)] = ra[j % NA];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int e = tid + 256 * i;
+                int m, k;
+                if (p.ak == 1) { k = e & (BK_ - 1); m = e >> 4; } else { m = e % BM_; k = e / BM_; }
+                As[k * AP + m] = ra[i];
+            }
         }
+        if (bvec) {
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int e = tid + 256 * i;
-            int n, k;
-            if (p.bn == 1) { n = e & (BN_ - 1); k = e >> 7; } else { k = e & (BK_ - 1); n = e >> 4; }
-            Bs[k * BP + n] = rb[i];
+            for (int i = 0; i < NB / 4; ++i) {
+                const int e = tid + 256 * i;
+                const int n4 = e & 31, k = e >> 5;
+                *reinterpret_cast<float4*>(&Bs[k * BP + 4 * n4]) = float4{rb[4 * i], rb[4 * i + 1], rb[4 * i + 2], rb[4 * i + 3]};
+            }
+        } else if (bkvec) {
+#pragma unroll
+            for (int i = 0; i < NB / 4; ++i) {
+                const int e = tid + 256 * i;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Bs[(4 * (e & 3) + j) * BP + (e >> 2)] = rb[4 * i + j];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int e = tid + 256 * i;
+                int n, k;
+                if (p.bn == 1) { n = e & (BN_ - 1); k = e >> 7; } else { k = e & (BK_ - 1); n = e >> 4; }
+                Bs[k * BP + n] = rb[i];
+            }
         }
     };
     load(0);

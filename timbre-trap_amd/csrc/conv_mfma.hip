@@ -24,6 +24,7 @@
 //               leaves registers.
 //   backward  : k_rb_bwd_a (recompute + pointwise chain -> dA1, db1, db2, dW2), k_conv_mfma with flipped
 //               weights (dx = dy + W1^T (*) dA1), k_wgrad_mfma (dW1 as MFMA GEMM with K = pixels).
+#include <cstdlib>
 #include "common.h"
 #include "conv_small.h"
 
@@ -1386,11 +1387,117 @@ int launch_conv_v(const float* x, const float* gy, const float* w, WSpec ws, con
     return 0;
 }
 
+// ---- narrow (4,1) strided / transposed convs on the vector ALUs -----------------------------------------------------
+// With at most 16 x 8 channel pairs these layers are far below the matrix ridge and a 16-row MFMA tile is mostly padding:
+// like k_small_lds (conv_small.hip) the input tile (ALL input channels, P::XR rows x 64 columns) is staged by LDS-DMA,
+// double-buffered, and a thread computes the COUT values of one output pixel from LDS taps with immediate offsets.
+// The tap policy (which input row and weight tap output row `wave` uses) is the matrix kernels' Down4 / Up4.
+template <int CIN, int COUT, class P>
+struct VGeo {
+    static constexpr int PLANE = P::XR * TW;
+    static constexpr int NQ = CIN * PLANE / 4, NP = (NQ + 63) / 64, BUF = NP * 256;
+    static constexpr int W_FLOATS = CIN * P::NWT * COUT + COUT;
+    static constexpr int LDS_BYTES = (2 * BUF + W_FLOATS) * 4;
+};
+
+template <int CIN, int COUT, class P>
+__global__ __launch_bounds__(NTHREADS) void k_conv_valu(const float* __restrict__ x, const float* __restrict__ w, WSpec ws,
+                                                        const float* __restrict__ bias, float* __restrict__ y, int B, int Hin,
+                                                        int Hout, int T, int act) {
+    using V = VGeo<CIN, COUT, P>;
+    static_assert(P::NTAPS != 9 && P::CH == 0, "strided geometries: no column halo");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* xs = lds;
+    float* wimg = lds + 2 * V::BUF;                       // [c][wt][co], then the bias
+    for (int i = threadIdx.x; i < CIN * P::NWT * COUT; i += NTHREADS) {
+        const int co = i % COUT, wt = (i / COUT) % P::NWT, c = i / (COUT * P::NWT);
+        wimg[i] = w[ws.off + co * ws.s_m + c * ws.s_c + wt * ws.s_t];
+    }
+    for (int i = threadIdx.x; i < COUT; i += NTHREADS) wimg[CIN * P::NWT * COUT + i] = bias ? bias[i] : 0.f;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tiles_h = (Hout + TH - 1) / TH, tiles_t = (T + TW - 1) / TW;
+    const int ntiles = B * tiles_h * tiles_t;
+    const long plane = (long)Hin * T, oplane = (long)Hout * T;
+    const float* zero = reinterpret_cast<const float*>(&g_zero16);
+    auto issue = [&](int v, int buf) {
+        const Tile tl = decode_tile(v, tiles_h, tiles_t, ntiles);
+        const int row0 = P::in_row0(tl.h0);
+        const float* xb = x + (long)tl.b * CIN * plane;
+        float* dst = xs + buf * V::BUF;
+#pragma unroll
+        for (int jj = 0; jj < (V::NP + 7) / 8; ++jj) {
+            const int j = wave + 8 * jj;
+            if (j < V::NP) {
+                const int q = j * 64 + lane;
+                const int ci = q / (V::PLANE / 4);
+                const int rem = q - ci * (V::PLANE / 4);
+                const int r = rem >> 4, c4 = rem & 15;
+                const int h = row0 + r, t = tl.t0 + 4 * c4;
+                const bool ok = q < V::NQ && h >= 0 && h < Hin && t < T;
+                glds16(ok ? xb + (ci * (int)plane + h * T + t) : zero, dst + j * 256);
+            }
+        }
+    };
+    int v = blockIdx.x;
+    __syncthreads();
+    if (v >= ntiles) return;
+    int buf = 0;
+    issue(v, 0);
+    for (; v < ntiles; v += gridDim.x) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (v + (int)gridDim.x < ntiles) issue(v + (int)gridDim.x, buf ^ 1);
+        const Tile tl = decode_tile(v, tiles_h, tiles_t, ntiles);
+        const float* xt = xs + buf * V::BUF + lane;
+        float acc[COUT];
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[co] = wimg[CIN * P::NWT * COUT + co];
+#pragma unroll 1
+        for (int c = 0; c < CIN; ++c) {
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int tp = 0; tp < P::NTAPS; ++tp) {
+                const float xv = xt[c * V::PLANE + P::lrow(tp, wave) * TW];
+                const float* wl = wimg + (c * P::NWT + P::wtap(tp, wave)) * COUT;
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) acc[co] = fmaf(xv, wl[co], acc[co]);
+            }
+        }
+        const int h = tl.h0 + wave, t = tl.t0 + lane;
+        if (h < Hout && t < T) {
+            float* yb = y + (long)tl.b * COUT * oplane + (long)h * T + t;
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) yb[co * oplane] = act == TT_ACT_ELU ? elu1(acc[co]) : acc[co];
+        }
+        buf ^= 1;
+    }
+}
+
+template <int CIN, int COUT, class P>
+int launch_conv_valu(const float* x, const float* w, WSpec ws, const float* bias, float* y, int B, int Hin, int Hout, int T, int act,
+                     hipStream_t st) {
+    using V = VGeo<CIN, COUT, P>;
+    static bool attr = false;
+    if (!attr) {
+        TT_HIP(hipFuncSetAttribute((const void*)k_conv_valu<CIN, COUT, P>, hipFuncAttributeMaxDynamicSharedMemorySize, V::LDS_BYTES));
+        attr = true;
+    }
+    hipLaunchKernelGGL((k_conv_valu<CIN, COUT, P>), dim3(persistent_grid(ntiles_of(B, Hout, T), blocks_per_cu(V::LDS_BYTES, 4))),
+                       dim3(NTHREADS), V::LDS_BYTES, st, x, w, ws, bias, y, B, Hin, Hout, T, act);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int CIN, int COUT, class P, bool GATE>
 int launch_conv(const float* x, const float* gy, const float* w, WSpec ws, const float* bias, const float* res, float* y,
                 int B, int Hin, int Hout, int T, int act, hipStream_t st, int prec = 0) {
     if constexpr (!GATE) {
         if (dma_ok(x, T)) {
+            // measured: the transposed geometry (2 taps) wins up to 16 -> 8 channels, the strided one (4 taps) only at 4 -> 8
+            if constexpr ((P::NTAPS == 2 && CIN * COUT <= 128) || (P::NTAPS == 4 && CIN * COUT <= 32)) {
+                static const bool valu = getenv("TTRAP_STRIDED_MFMA") == nullptr;
+                if (valu && !res) return launch_conv_valu<CIN, COUT, P>(x, w, ws, bias, y, B, Hin, Hout, T, act, st);
+            }
             if constexpr (P::NTAPS == 9 && CIN >= 16) {
                 if (prec == 1) return launch_conv_v<CIN, COUT, P, false, true, 1>(x, gy, w, ws, bias, res, y, B, Hin, Hout, T, act, st);
                 if (prec == 2) return launch_conv_v<CIN, COUT, P, false, true, 2>(x, gy, w, ws, bias, res, y, B, Hin, Hout, T, act, st);

@@ -272,6 +272,126 @@ __global__ __launch_bounds__(256) void k_dot(const float* __restrict__ a, const 
     if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
 }
 
+// ---- LDS-tiled 3x3 boundary convs (2 <-> 4 channels, stride 1, pad 1) ------------------------------------------------
+// Same scheme as k_small_lds (conv_small.hip): the CI-channel input tile (16 rows + 2, 64 columns + 8) arrives by
+// LDS-DMA, double buffered; a thread computes two output pixels (rows r, r + 8) for all CO channels from LDS taps with
+// immediate offsets; generic weight strides cover the forward and the flipped data-gradient form.
+__device__ float4 g_zero16_gen;
+template <int CI, int CO>
+struct BL {
+    static constexpr int XR = 18, XCP = 72, PLANE = XR * XCP;
+    static constexpr int NQ = CI * PLANE / 4, NP = (NQ + 63) / 64, BUF = NP * 256;
+    static constexpr int W_FLOATS = CI * 9 * CO + CO;
+    static constexpr int LDS_BYTES = (2 * BUF + W_FLOATS) * 4;
+};
+template <int CI, int CO>
+__global__ __launch_bounds__(512) void k_conv3x3_lds(ConvP p) {
+    using L = BL<CI, CO>;
+    extern __shared__ __attribute__((aligned(16))) float lds_b[];
+    float* xs = lds_b;
+    float* wimg = lds_b + 2 * L::BUF;                      // [ci][tap][co], then bias
+    for (int i = threadIdx.x; i < CI * 9 * CO; i += 512) {
+        const int co = i % CO, tap = (i / CO) % 9, ci = i / (9 * CO);
+        wimg[i] = p.w[co * p.ws_co + ci * p.ws_ci + (tap / 3) * p.ws_kh + (tap % 3) * p.ws_kw];
+    }
+    for (int i = threadIdx.x; i < CO; i += 512) wimg[CI * 9 * CO + i] = p.bias ? p.bias[i] : 0.f;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int H = p.Hin, T = p.T;
+    const int tiles_h = (H + 15) / 16, tiles_t = (T + 63) / 64;
+    const int ntiles = p.B * tiles_h * tiles_t;
+    const long plane = (long)H * T;
+    const float* zero = reinterpret_cast<const float*>(&g_zero16_gen);
+    auto coords = [&](int v, int& b, int& h0, int& t0) {
+        const int per = ntiles >> 3;
+        int tt = v < (per << 3) ? (v & 7) * per + (v >> 3) : v;        // XCD-contiguous tile order
+        t0 = (tt % tiles_t) * 64; tt /= tiles_t;
+        h0 = (tt % tiles_h) * 16; b = tt / tiles_h;
+    };
+    auto issue = [&](int v, int buf) {
+        int b, h0, t0;
+        coords(v, b, h0, t0);
+        const float* xb = p.x + (long)b * CI * plane;
+        float* dst = xs + buf * L::BUF;
+#pragma unroll
+        for (int jj = 0; jj < (L::NP + 7) / 8; ++jj) {
+            const int j = wave + 8 * jj;
+            if (j < L::NP) {
+                const int q = j * 64 + lane;
+                const int ci = q / (L::PLANE / 4);
+                const int rem = q - ci * (L::PLANE / 4);
+                const int r = rem / 18, c4 = rem - r * 18;
+                const int h = h0 - 1 + r, t = t0 - 4 + 4 * c4;
+                const bool ok = q < L::NQ && h >= 0 && h < H && t >= 0 && t < T;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ok ? xb + (ci * (int)plane + h * T + t) : zero),
+                                                 (__attribute__((address_space(3))) void*)(dst + j * 256), 16, 0, 0);
+            }
+        }
+    };
+    int v = blockIdx.x;
+    __syncthreads();
+    if (v >= ntiles) return;
+    int buf = 0;
+    issue(v, 0);
+    for (; v < ntiles; v += gridDim.x) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (v + (int)gridDim.x < ntiles) issue(v + (int)gridDim.x, buf ^ 1);
+        int b, h0, t0;
+        coords(v, b, h0, t0);
+        const float* xt = xs + buf * L::BUF + wave * L::XCP + 3 + lane;      // tap (kh, kw), row r: + ci*PLANE + (8 r + kh)*XCP + kw
+        float acc[2][CO];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int co = 0; co < CO; ++co) acc[r][co] = wimg[CI * 9 * CO + co];
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const float* wl = wimg + (ci * 9 + tap) * CO;
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const float xv = xt[ci * L::PLANE + (8 * r + tap / 3) * L::XCP + tap % 3];
+#pragma unroll
+                    for (int co = 0; co < CO; ++co) acc[r][co] = fmaf(xv, wl[co], acc[r][co]);
+                }
+            }
+        const int t = t0 + lane;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int h = h0 + wave + 8 * r;
+            if (h < H && t < T) {
+                const long o = (long)b * CO * plane + (long)h * T + t;
+#pragma unroll
+                for (int co = 0; co < CO; ++co) {
+                    float val = acc[r][co];
+                    if (p.act == TT_ACT_ELU) val = elu1(val);
+                    if (p.res) val += p.res[o + co * plane];
+                    p.y[o + co * plane] = val;
+                }
+            }
+        }
+        buf ^= 1;
+    }
+}
+
+template <int CI, int CO>
+int launch_conv3x3_lds(const ConvP& p, hipStream_t st) {
+    using L = BL<CI, CO>;
+    static bool attr = false;
+    if (!attr) {
+        TT_HIP(hipFuncSetAttribute((const void*)k_conv3x3_lds<CI, CO>, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES));
+        attr = true;
+    }
+    const int ntiles = p.B * ((p.Hin + 15) / 16) * ((p.T + 63) / 64);
+    int per_cu = (160 * 1024) / L::LDS_BYTES;
+    if (per_cu > 4) per_cu = 4;
+    const int grid = ntiles < 256 * per_cu ? ntiles : 256 * per_cu;
+    hipLaunchKernelGGL((k_conv3x3_lds<CI, CO>), dim3(grid), dim3(512), L::LDS_BYTES, st, p);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
 inline int grid1d(long n, int per_block, int cap) {
     long g = (n + per_block - 1) / per_block;
     if (g > cap) g = cap;
@@ -294,6 +414,10 @@ extern "C" int tt_conv2d(const float* x, const float* w, const float* bias, cons
             transposed, (long)ws_co, (long)ws_ci, (long)ws_kh, (long)ws_kw, act};
     if (KH == 3 && KW == 3 && stride_h == 1 && dil_h == 1 && dil_w == 1 && pad_h == 1 && pad_w == 1 && !transposed &&
         Hin == Hout && (Cin == 2 || Cin == 4) && (Cout == 2 || Cout == 4)) {
+        if (T % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (long)Cin * Hin * T < (1L << 31) && (long)Cout * Hin * T < (1L << 31)) {
+            if (Cin == 2 && Cout == 4) return launch_conv3x3_lds<2, 4>(p, tt_stream(stream));
+            if (Cin == 4 && Cout == 2) return launch_conv3x3_lds<4, 2>(p, tt_stream(stream));
+        }
         dim3 g3((T + 63) / 64, (Hout + 15) / 16, B);
         if (Cin == 2 && Cout == 4) hipLaunchKernelGGL((k_conv3x3_small<2, 4>), g3, dim3(256), 0, tt_stream(stream), p);
         else if (Cin == 4 && Cout == 2) hipLaunchKernelGGL((k_conv3x3_small<4, 2>), g3, dim3(256), 0, tt_stream(stream), p);

@@ -11,19 +11,25 @@
 // MFMA mapping (16 x 16 x 4):
 //   A fragment  lane l : Wimg[k0 + (l>>4)][mt*16 + (l&15)]     weights, transposed once into LDS, 16-column
 //                                                                halves XOR-swizzled by k&1 (conflict-free at pitch 32/64)
-//   B fragment  lane l : xs[c = .. + (l>>4)][row][col + (l&15)]  input tile + halo in LDS, plane pitch = 17 mod 32
+//   B fragment  lane l : xs[c = .. + (l>>4)][row][col + (l&15)]  input tile + halo in LDS, plane pitch 16 / 17 mod 32
 //   D fragment  lane l : rows 4*(l>>4) + r (r = 0..3), column l&15
-// Workgroup = 8 waves = 8 output rows x 64 columns of one clip.  The input is staged per chunk of CC
-// channels, double-buffered: the next chunk's global loads are issued into registers before the MFMA loop
-// over the current chunk and committed to the other LDS buffer afterwards, ONE barrier per chunk.
-// Workgroups are persistent over tiles so the weight image is built once per workgroup.
+// Workgroup = 8 waves = 8 output rows x 64 columns of one clip.  The input is staged per chunk of CC channels,
+// double-buffered, ONE barrier per chunk: by LDS-DMA (global_load_lds_dwordx4, no registers) when rows are 16-byte
+// aligned and T % 4 == 0, else through registers (any T; optional ELU' gating while staging).  Workgroups are
+// persistent over tiles (weight image built once) and walk them in an XCD-contiguous order (xcd_tile).
+// Epilogues address with a wave-uniform 64-bit base per (clip, channel) plus 32-bit lane offsets and move 16 bytes per
+// lane (quad-transposed accumulators on the fp32 path).
 //
 // ResidualConv2dBlock (modules.py:755-777):  y = ELU(W2 . ELU(W1 (*) x + b1) + b2) + x
-//   forward   : D fragments of the 3x3 stage hold, for register r, channels {4g + r} over the four lane
-//               groups g -- exactly a B fragment (k = g) for the 1x1 stage: the hidden activation never
-//               leaves registers.
-//   backward  : k_rb_bwd_a (recompute + pointwise chain -> dA1, db1, db2, dW2), k_conv_mfma with flipped
-//               weights (dx = dy + W1^T (*) dA1), k_wgrad_mfma (dW1 as MFMA GEMM with K = pixels).
+//   forward   : k_rb_fwd -- D fragments of the 3x3 stage hold, for register r, channels {4g + r} over the four lane
+//               groups g: exactly a B fragment (k = g) for the 1x1 stage, the hidden activation never leaves registers
+//               (it is optionally stored for the backward pass).
+//   backward  : k_rb_bwd_a (pointwise chain from the saved or recomputed hidden activation -> dA1, db1, db2, dW2),
+//               k_conv_mfma with flipped weights (dx = dy + W1^T (*) dA1), k_wgrad_dma / k_wgrad3_pack (dW1 as MFMA GEMM
+//               with K = pixels; k_wgrad_mfma is the register-staged fallback).
+// Precision of the wide 3x3 convs (PREC): 0 = fp32 (default), 1 = bf16 operands, 2 = split-bf16 (hi + lo, three
+// v_mfma_f32_16x16x32_bf16 per product block); the bf16 modes use conv_mainloop_z (channel-interleaved bf16 tile).
+// Narrow strided / transposed layers run on the vector ALUs from LDS-DMA staged tiles (k_conv_valu).
 #include <cstdlib>
 #include "common.h"
 #include "conv_small.h"

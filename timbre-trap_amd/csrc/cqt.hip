@@ -10,9 +10,10 @@
 //                   (one LDS exchange) over n1 for 7 values of n2 per workgroup, times W_Nc^(n2 k1)
 //   k_fft49_cols  : step 2: 49-point DFTs over n2 for a tile of k1 and its mirror 675-k1,
 //                   then the real-FFT split -> half spectrum X[0..Nc] in natural order
-//   k_band_fwd    : per (clip, bin): gather L_k windowed spectral samples into a zeroed 1024
-//                   buffer, radix-4 Stockham inverse FFT in LDS, write re / im planes (fuses
-//                   CQT.to_real).  One wave per bin, 4 bins per workgroup.
+//   k_band_fwd    : per (clip, bin): gather L_k windowed spectral samples straight into registers, inverse 1024-point FFT
+//                   as radix 16 x 4 x 16 held in registers with two wave-local LDS transposes, one more exchange so
+//                   that the re / im planes are written 16 bytes per lane (fuses CQT.to_real).  One wave per bin,
+//                   4 bins per workgroup, no workgroup barrier.
 // The inverse runs the same machinery backwards (k_band_inv, k_spec_gather, the same two FFT
 // kernels through the conj trick, k_absmax / k_scale for the wrapper's inf-norm).
 //

@@ -4,6 +4,8 @@
 //
 // All of them are pure HBM streams; reductions are two-stage in fp64 (block partials -> one
 // finalising workgroup) so the loss values are deterministic.
+// Also here: clip + AdamW over the flat parameter buffer, and the helpers next to the path: per-parameter
+// gradient statistics, peak picking / thresholding of activations, target generation (float64, SciPy-identical).
 #include "common.h"
 
 namespace {

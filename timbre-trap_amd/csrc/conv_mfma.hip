@@ -1662,7 +1662,8 @@ struct WPk {
     static constexpr int NP = C * PROW / 4, NPP = (NP + 63) / 64;
     static constexpr int P_FLOATS = NPP * 256;                           // per wave
     static constexpr int IMG = MT * 16 * NTN * 16;                       // partial image [m][n]
-    static constexpr int LDS_FLOATS = Q_FLOATS + 8 * P_FLOATS;
+    static constexpr int STAGE = Q_FLOATS + 8 * P_FLOATS;               // one staging buffer: x tile + the eight g rows
+    static constexpr int LDS_FLOATS = 2 * STAGE;
     static constexpr int LDS_BYTES = (LDS_FLOATS > IMG ? LDS_FLOATS : IMG) * 4;
 };
 
@@ -1698,12 +1699,14 @@ __global__ __launch_bounds__(512) void k_wgrad3_pack(const float* __restrict__ g
 #pragma unroll
         for (int nt = 0; nt < W::NTN; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // both operands double-buffered: the next tile's DMA is in flight while this one is multiplied, one barrier per tile
+    auto issue = [&](int tile, int buf) {
         int tt = xcd_tile(tile, ntiles);
         const int tx = tt % tiles_t; tt /= tiles_t;
         const int ty = tt % tiles_h;
         const int b = tt / tiles_h, h0 = ty * 8, t0 = tx * 64;
-        __syncthreads();                                   // everyone is done with the previous tile's LDS
+        float* xd = xs + buf * W::STAGE;
+        float* pd = ps + buf * W::STAGE;
         {   // x tile: rows h0 - D .. h0 + 7 + D, columns t0 .. t0 + 63
             const float* xb = xt + (long)b * C * plane;
             constexpr int PQ = W::QPLANE / 4;
@@ -1717,7 +1720,7 @@ __global__ __launch_bounds__(512) void k_wgrad3_pack(const float* __restrict__ g
                     const int r = rem >> 4, c4 = rem & 15;
                     const int h = h0 - D + r, t = t0 + 4 * c4;
                     const bool ok = q < W::NQ && r < W::XR && h >= 0 && h < H && t < T;
-                    glds16(ok ? xb + (ci * (int)plane + h * T + t) : zero, xs + j * 256);
+                    glds16(ok ? xb + (ci * (int)plane + h * T + t) : zero, xd + j * 256);
                 }
             }
         }
@@ -1730,25 +1733,33 @@ __global__ __launch_bounds__(512) void k_wgrad3_pack(const float* __restrict__ g
                 const int co = q / 18, c4 = q - co * 18;
                 const int t = t0 - 4 + 4 * c4;
                 const bool ok = q < W::NP && h < H && t >= 0 && t < T;
-                glds16(ok ? gb + (co * (int)plane + t) : zero, ps + jj * 256);
+                glds16(ok ? gb + (co * (int)plane + t) : zero, pd + jj * 256);
             }
         }
+    };
+    int tile = blockIdx.x, buf = 0;
+    if (tile < ntiles) issue(tile, 0);
+    for (; tile < ntiles; tile += gridDim.x) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        __syncthreads();                                   // this tile has landed, everyone is done with the other buffer
+        if (tile + (int)gridDim.x < ntiles) issue(tile + (int)gridDim.x, buf ^ 1);
+        const float* xsb = xs + buf * W::STAGE;
+        const float* psb = ps + buf * W::STAGE;
         float av[W::MT][16];
 #pragma unroll
         for (int mt = 0; mt < W::MT; ++mt)
 #pragma unroll
-            for (int sk = 0; sk < 16; ++sk) av[mt][sk] = aok[mt] ? ps[aoff[mt] + 4 * sk] : 0.f;
+            for (int sk = 0; sk < 16; ++sk) av[mt][sk] = aok[mt] ? psb[aoff[mt] + 4 * sk] : 0.f;
 #pragma unroll
         for (int sk = 0; sk < 16; ++sk) {
 #pragma unroll
             for (int nt = 0; nt < W::NTN; ++nt) {
-                const float bv = xs[boff[nt] + 4 * sk];
+                const float bv = xsb[boff[nt] + 4 * sk];
 #pragma unroll
                 for (int mt = 0; mt < W::MT; ++mt) acc[mt][nt] = mfma16(av[mt][sk], bv, acc[mt][nt]);
             }
         }
+        buf ^= 1;
     }
     __syncthreads();
     float* red = lds;

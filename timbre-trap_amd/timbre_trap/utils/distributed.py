@@ -22,7 +22,8 @@ def init_process_group_from_env(backend=None):
     rank = int(os.environ['RANK'])
     local_rank = int(os.environ.get('LOCAL_RANK', rank))
     if backend is None:
-        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        # TTRAP_DIST_BACKEND=gloo lets several ranks share one GPU (functional test of the N > 1 path on a 1-GPU box)
+        backend = os.environ.get('TTRAP_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
     if backend == 'nccl':
         torch.cuda.set_device(local_rank)
     if not dist.is_initialized():

@@ -14,9 +14,18 @@ Workload (BASELINE.json configs[2]): model_complexity=2, latent_size=128, 64 cli
 GPU, 9 octaves x 60 bins/octave; weak scaling (per-GPU batch fixed).  dtype = fp32 (exact-fp32 MFMA path).
 
 Prints ONE JSON line on rank 0 with the driver's fields plus
-  "roofline"     : dominant kernel, algorithmic FLOPs / average launch time measured with HIP events on the
-                   launch stream over the timed steps, against the gfx950 fp32 matrix peak
-  "cpu_baseline" : the CPU oracle (kind "port") timed on this box's host cores on a bounded sample (rank 0, N = 1)
+  "roofline"          : the fused wide residual block k_rb_fwd<32,D>: algorithmic FLOPs / average launch time measured with HIP
+                        events on the launch stream over the timed steps, against the gfx950 fp32 matrix peak; `traffic` is the
+                        HBM byte count of the committed rocprofv3 PMC passes (`traffic_source` names the file -- it is not
+                        re-measured inside this run)
+  "roofline_cqt"      : tt_cqt_forward, measured in the timed steps (HBM bound, 4,688,280 algorithmic bytes per clip)
+  "roofline_cqt_inv"  : tt_cqt_inverse (CQT.decode) on the same batch, measured after the timed region (training never calls it)
+  "families"          : per kernel family (narrow / wide residual blocks, strided, transposed, latent GEMMs, boundary convs,
+                        losses, optimizer) ms per step, achieved TFLOP/s and TB/s on ALGORITHMIC work and the fractions of the
+                        fp32 matrix peak and of HBM peak -- measured with HIP events in two extra, untimed, instrumented steps
+  "whole_step"        : algorithmic conv FLOPs of the step / ms_per_step against the fp32 and the bf16 matrix peaks
+  "cpu_baseline"      : the CPU oracle (kind "port") on a bounded sample of the SAME workload (model_complexity 2; rank 0, N = 1)
+  "cpu_baseline_config0" : BASELINE.json configs[0] on the oracle: model_complexity 1, one clip, CQT forward + inverse + one step
 """
 
 import argparse
@@ -36,7 +45,9 @@ import torch  # noqa: E402
 N_BLOCK, M_FRAMES, SR, N_BINS = 66150, 1024, 22050, 540
 SECS_PER_CLIP = 3.0
 PEAK_FP32_MATRIX_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0       # same guide: dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0
+CQT_BYTES_PER_CLIP = 4688280         # 264,600 B of audio + 4,423,680 B of coefficients
 
 
 def synthetic_batch(batch, rank, device='cpu'):
@@ -65,23 +76,119 @@ def build_model(mc, latent, device, seed=2):
                       latent_size=latent, model_complexity=mc, skip_connections=False).to(device)
 
 
-def train_step(model, opt, audio, target, world):
+def make_train_step(model, opt, world, overlap=True):
+    """
+    Returns step(audio, target, next_audio=None) -> total loss: exactly the body of reference experiments/train.py:404-496.
+
+    N > 1: the flat gradient goes out as ONE all-reduce issued asynchronously -- RCCL runs it on its own
+    stream once the backward kernels it depends on have finished -- and, while it is in flight, the compute stream already runs
+    the CQT of the NEXT batch (`model.sliCQ(next_audio)`, the `coefficients` of train.py:404 for the following step; the
+    transform has no weights, so it does not depend on the update).  The compute stream then waits for the collective and
+    applies clip + AdamW.  Every step still performs its two forward transforms (train.py:404 and modules.py:88).
+    """
     from timbre_trap.framework import compute_consistency_loss, compute_reconstruction_loss, compute_transcription_loss
-    from timbre_trap.utils import allreduce_gradients
-    coefficients = model.sliCQ(audio)
-    reconstruction, latents, trn_coeffs, trn_rec, trn_scr, _ = model(audio, True)
-    transcription = model.to_activations(trn_coeffs)
-    n = target.size(0)
-    l_rec = compute_reconstruction_loss(reconstruction, coefficients)
-    l_trn = compute_transcription_loss(transcription[:n], target, True)
-    l_sp, l_sc = compute_consistency_loss(trn_rec[:n], trn_scr[:n], trn_coeffs[:n])
-    total = l_rec + l_trn + (l_sp + l_sc)
-    opt.zero_grad()
-    total.backward()
-    if world > 1:
-        allreduce_gradients(opt.flat_grad, world)
-    opt.step()
-    return total
+    from timbre_trap.utils import GradientSync
+    sync = GradientSync(world) if world > 1 else None
+    state = dict(coeffs=None, src=None)
+
+    def step(audio, target, next_audio=None):
+        next_audio = audio if next_audio is None else next_audio
+        if state['coeffs'] is not None and state['src'] is audio:
+            coefficients = state['coeffs']                        # transformed during the previous step's all-reduce
+        else:
+            coefficients = model.sliCQ(audio)
+        state['coeffs'] = state['src'] = None
+        reconstruction, latents, trn_coeffs, trn_rec, trn_scr, _ = model(audio, True)
+        transcription = model.to_activations(trn_coeffs)
+        n = target.size(0)
+        l_rec = compute_reconstruction_loss(reconstruction, coefficients)
+        l_trn = compute_transcription_loss(transcription[:n], target, True)
+        l_sp, l_sc = compute_consistency_loss(trn_rec[:n], trn_scr[:n], trn_coeffs[:n])
+        total = l_rec + l_trn + (l_sp + l_sc)
+        opt.zero_grad()
+        total.backward()
+        if sync is not None:
+            if overlap:
+                sync.start(opt.flat_grad)
+                state['coeffs'], state['src'] = model.sliCQ(next_audio), next_audio
+                sync.finish()
+            else:
+                sync.start(opt.flat_grad)
+                sync.finish()
+        opt.step()
+        return total
+    return step
+
+
+def family_table(events, n_steps, batch, mc, latent):
+    """
+    Per kernel family: ms per step (HIP events around every forward / backward of the autograd Functions in
+    timbre_trap/framework/ops.py, recorded on the launch stream during `n_steps` untimed instrumented steps), the ALGORITHMIC
+    work of those calls and the achieved rates.  Algorithmic bytes count each tensor a layer must read or write once:
+    residual block forward 2 tensors (x, y), backward 3 (dy, x, dx; the saved hidden activation is an implementation choice);
+    (4,1) strided / transposed layers forward in + out, backward 2 in + 2 out (the ELU gate needs y).  FLOPs are 2 MAC,
+    backward = 2 x forward.
+    """
+    ch = [round(c * 2 ** (mc - 1)) for c in (2, 4, 8, 16, 32)]
+    hs = [540, 269, 133, 65, 31]
+    T = M_FRAMES
+    lat = latent if latent else 32 * 2 ** (mc - 1)
+    level = {c: i for i, c in enumerate(ch)}
+    fam = {}
+
+    def add(name, ms, calls, flops, nbytes, bound):
+        f = fam.setdefault(name, dict(ms_per_step=0.0, calls_per_step=0.0, gflop_per_step=0.0, gbyte_per_step=0.0, bound=bound))
+        f['ms_per_step'] += ms
+        f['calls_per_step'] += calls
+        f['gflop_per_step'] += flops / 1e9
+        f['gbyte_per_step'] += nbytes / 1e9
+
+    for key, ev in events.items():
+        times = [s_.elapsed_time(e_) for s_, e_ in ev]
+        ms, calls = sum(times) / n_steps, len(times) / n_steps
+        parts = key.split('_')
+        kind, direction, tag = parts[0], parts[1] if len(parts) > 1 else '', parts[-1]
+        bwd = direction == 'bwd'
+        if kind == 'rb':
+            C = int(tag[1:]); px = hs[level[C]] * T * batch
+            fl = 2.0 * 10 * C * C * px * (2 if bwd else 1)
+            by = 4.0 * C * px * (3 if bwd else 2)
+            add(('narrow' if C <= 8 else 'wide') + ' residual blocks ' + ('backward' if bwd else 'forward'), ms, calls, fl * calls, by * calls,
+                'hbm' if C <= 8 else 'mfma')
+        elif kind in ('sconv', 'tconv'):
+            C = int(tag[1:]); l = level[C]
+            big, small = C * hs[l] * T * batch, 2 * C * hs[l + 1] * T * batch          # elements at the C side / the 2C side
+            fl = 2.0 * 4 * C * 2 * C * hs[l + 1] * T * batch * (2 if bwd else 1)
+            by = 4.0 * (big + small) * (2 if bwd else 1)
+            add('strided + transposed (4,1) layers ' + ('backward' if bwd else 'forward'), ms, calls, fl * calls, by * calls, 'hbm')
+        elif kind in ('latenc', 'latdec'):
+            K = ch[4] * hs[4]
+            fl = 2.0 * (lat + (kind == 'latdec')) * K * T * batch * (2 if bwd else 1)
+            by = 4.0 * (K + lat) * T * batch * (2 if bwd else 1)
+            add('latent heads (31,1) as GEMMs', ms, calls, fl * calls, by * calls, 'mfma')
+        elif kind == 'conv':
+            ci, co = (int(v) for v in tag.split('to'))
+            px = hs[0] * T * batch
+            fl = 2.0 * 9 * ci * co * px * (2 if bwd else 1)
+            by = 4.0 * (ci + co) * px * (1.5 if bwd else 1)
+            add('boundary 3x3 convs (2<->%d)' % ch[0], ms, calls, fl * calls, by * calls, 'hbm')
+        elif kind in ('sqdiff', 'act', 'trn'):
+            px = hs[0] * T * batch
+            by = 4.0 * px * {'sqdiff': 4, 'act': 3, 'trn': 2}[kind] * (1.5 if bwd else 1)
+            add('losses + to_activations', ms, calls, 0.0, by * calls, 'hbm')
+        elif key == 'clip_adamw':
+            add('clip + AdamW (flat buffer)', ms, calls, 0.0, 0.0, 'hbm')
+        elif key == 'cqt_forward':
+            add('CQT forward', ms, calls, 0.0, CQT_BYTES_PER_CLIP * batch * calls, 'hbm')
+    out = {}
+    for name, f in sorted(fam.items(), key=lambda kv: -kv[1]['ms_per_step']):
+        sec = f['ms_per_step'] * 1e-3
+        tf, tb = f['gflop_per_step'] / 1e3 / sec, f['gbyte_per_step'] / 1e3 / sec
+        out[name] = dict(ms_per_step=round(f['ms_per_step'], 3), calls_per_step=f['calls_per_step'], bound=f['bound'],
+                         achieved_tflops=round(tf, 2), achieved_tbs=round(tb, 3),
+                         frac_fp32_matrix_peak=round(tf / PEAK_FP32_MATRIX_TFLOPS, 4), frac_hbm_peak=round(tb * 1e3 / PEAK_HBM_GBS, 4))
+    out['sum_ms_per_step'] = round(sum(f['ms_per_step'] for f in fam.values()), 3)
+    return out
 
 
 def available_cores():
@@ -106,8 +213,24 @@ def available_cores():
     return n
 
 
-def cpu_baseline(mc, latent, seconds_budget=20.0):
-    """The oracle (CPU restatement, torch + numpy on the host cores) on a bounded sample of the same workload."""
+def _cpu_model_name():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return ''
+
+
+def cpu_baseline(mc, latent, seconds_budget=15.0, config0=False):
+    """
+    The oracle (CPU restatement) on a bounded sample.  config0 = False: one clip of the bench workload (same model, the step
+    of train.py:404-496 = 2 forward CQTs + autoencoder step).  config0 = True: BASELINE.json configs[0] -- model_complexity 1,
+    one clip, CQT forward + inverse, then one train step (which transforms the audio again, twice, like train.py).
+    The conv / loss / optimizer legs are torch fp32 on `cores` threads; the CQT legs are oracle/nsgt.py: float64 NumPy
+    (one 66150-point FFT + a Python loop of 540 windowed 1024-point FFTs per clip), single-threaded.
+    """
     from oracle import nsgt
     from oracle.train_step import OracleTrainer, cqt_forward_torch
     threads = min(available_cores(), 64)          # beyond ~64 threads the small conv layers only lose to sync overhead
@@ -117,33 +240,42 @@ def cpu_baseline(mc, latent, seconds_budget=20.0):
     trainer = OracleTrainer(sd, lr=1e-3)
     tab = nsgt.nsgt_tables(9, 60, SR, N_BLOCK)
     audio, target = synthetic_batch(1, 0)
+    legs = dict(cqt_forward=0.0, cqt_inverse=0.0, step=0.0)
 
     def one():
+        t0 = time.perf_counter()
         coeffs = cqt_forward_torch(audio, tab)           # train.py:404
         _ = cqt_forward_torch(audio, tab)                # the transform again inside model.encode (modules.py:88)
+        t1 = time.perf_counter()
+        if config0:
+            nsgt.wrapper_decode(coeffs.numpy(), tab)     # configs[0]: "CQT fwd+inv"
+        t2 = time.perf_counter()
         trainer.step(coeffs, target)
+        t3 = time.perf_counter()
+        legs['cqt_forward'] += t1 - t0
+        legs['cqt_inverse'] += t2 - t1
+        legs['step'] += t3 - t2
     t0 = time.perf_counter()
     one()                                                # warm-up (also the sample if the host is very slow)
     warm = time.perf_counter() - t0
+    warm_legs = dict(legs)
+    for k in legs:
+        legs[k] = 0.0
     n, el = 0, 0.0
     t0 = time.perf_counter()
     while warm < seconds_budget and el + warm < seconds_budget and n < 5:
         one()
         n += 1
         el = time.perf_counter() - t0
-    step_s = el / n if n else warm
-    n = max(n, 1)
-    cpu_model = ''
-    try:
-        for line in open('/proc/cpuinfo'):
-            if line.startswith('model name'):
-                cpu_model = line.split(':', 1)[1].strip()
-                break
-    except OSError:
-        pass
+    if n == 0:
+        legs, el, n = warm_legs, warm, 1
+    step_s = el / n
+    what = ('BASELINE configs[0]: CQT forward x2 + inverse + train step' if config0 else 'train step incl. its 2 forward CQTs')
     return dict(value=SECS_PER_CLIP / step_s, unit='audio-seconds/s', cores=threads, kind='port',
-                sample='%d train steps of 1 clip x 3 s (mc=%d, latent=%s) after 1 warm-up, fp32, %d torch threads, %s' % (n, mc, latent, threads, cpu_model),
-                s_per_step=step_s)
+                sample='%d x (%s) of 1 clip x 3 s, model_complexity=%d latent=%s, after 1 warm-up; conv/loss/AdamW legs torch fp32 on %d '
+                       'threads, CQT legs float64 NumPy (Python loop over 540 bins, 1 thread); %s'
+                       % (n, what, mc, latent, threads, _cpu_model_name()),
+                s_per_step=step_s, legs_s={k: v / n for k, v in legs.items()})
 
 
 def bench_inference(model, args, rank, world, dev):
@@ -191,11 +323,13 @@ def main():
     ap.add_argument('--mode', choices=('train', 'infer'), default='train',
                     help="train = the headline metric; infer = BASELINE config[1]: transcribe() + reconstruct() on 32 clips x 3 s")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-overlap', action='store_true',
+                    help='N > 1: blocking all-reduce on the compute stream instead of the side-stream all-reduce overlapped with the next CQT')
     args = ap.parse_args()
 
     from timbre_trap import _hip
     from timbre_trap.framework import ops
-    from timbre_trap.utils import FusedAdamW, init_process_group_from_env
+    from timbre_trap.utils import FusedAdamW, allreduce_gradients, init_process_group_from_env
     ops.PRECISION = args.precision
     from timbre_trap.utils.distributed import broadcast_parameters
     import torch.distributed as dist
@@ -203,15 +337,17 @@ def main():
     rank, world, local_rank = init_process_group_from_env()
     if world != args.gpus and world > 1:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    # Build decision BEFORE anything initialises the GPU (hipcc children must not be forked from a process that holds the
+    # device) and identical on every rank: local rank 0 calls build() -- a no-op when the library is up to date, atomic
+    # rename into place otherwise -- and EVERY rank then passes the same barrier before dlopen.
+    if local_rank == 0:
+        _hip.build()
+    if world > 1:
+        dist.barrier()
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (there is no CPU fallback for the HIP path)')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if not os.path.exists(_hip.LIB_PATH):       # normally prebuilt by __graft_entry__.build(); compile once per node otherwise
-        if local_rank == 0:
-            _hip.build()
-        if world > 1:
-            dist.barrier()
     _hip.lib()
 
     model = build_model(args.mc, args.latent, dev)
@@ -221,6 +357,7 @@ def main():
     if world > 1:
         broadcast_parameters(opt.flat_param)
     audio, target = synthetic_batch(args.batch, rank, dev)
+    step_fn = make_train_step(model, opt, world, overlap=not args.no_overlap)
 
     def sync():
         if world > 1:
@@ -228,61 +365,115 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        train_step(model, opt, audio, target, world)
+        step_fn(audio, target)
     sync()
+    C = 16 * 2 ** (args.mc - 1)
+    key = 'resblock_fwd_C%d' % C
+    _hip.EVENT_KEYS = {key, 'cqt_forward'}          # the timed region brackets only the two roofline kernels
     _hip.EVENT_LOG = {}
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        total = train_step(model, opt, audio, target, world)
+        total = step_fn(audio, target)
     sync()
     elapsed = time.perf_counter() - t0
     events = _hip.EVENT_LOG
     _hip.EVENT_LOG = None
+    rank_ms = 1000.0 * elapsed / args.steps
+    per_rank_ms = [rank_ms]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        per_rank_ms = [1000.0 * float(g.item()) / args.steps for g in gathered]
+        elapsed = max(float(g.item()) for g in gathered)
     ms = 1000.0 * elapsed / args.steps
     value = world * args.batch * SECS_PER_CLIP / (elapsed / args.steps)
 
+    # ---- untimed, instrumented legs (every rank runs them so collectives stay matched; rank 0 reports) ----
+    fam_events, n_inst = {}, 2
+    _hip.EVENT_KEYS = None
+    _hip.EVENT_LOG = fam_events
+    for _ in range(n_inst):
+        step_fn(audio, target)
+    torch.cuda.synchronize()
+    _hip.EVENT_LOG = None
+    allreduce_ms = None
+    if world > 1:
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a0.record()
+        for _ in range(10):
+            allreduce_gradients(opt.flat_grad, world)
+        a1.record()
+        torch.cuda.synchronize()
+        allreduce_ms = a0.elapsed_time(a1) / 10
+    inv_events = {}
+    with torch.no_grad():
+        coeffs = model.sliCQ(audio)
+        for _ in range(3):
+            model.sliCQ.decode(coeffs)
+        _hip.EVENT_KEYS = {'cqt_inverse'}
+        _hip.EVENT_LOG = inv_events
+        for _ in range(20):
+            model.sliCQ.decode(coeffs)
+        torch.cuda.synchronize()
+        _hip.EVENT_LOG = None
+        _hip.EVENT_KEYS = None
+
     if rank == 0:
-        # dominant kernel: the fused residual block at the widest level (C = 16*mc channels, H = 65 rows)
-        C = 16 * 2 ** (args.mc - 1)
-        key = 'resblock_fwd_C%d' % C
+        def avg_ms(ev):
+            times = [s_.elapsed_time(e_) for s_, e_ in ev]
+            return sum(times) / len(times), len(times)
+        # the fused residual block at the widest level (C = 16*mc channels, H = 65 rows)
         roof = None
         if events.get(key):
-            times = [s.elapsed_time(e) for s, e in events[key]]
-            avg_ms = sum(times) / len(times)
+            a_ms, n_l = avg_ms(events[key])
             flops = 2.0 * (9 * C * C + C * C) * args.batch * 65 * M_FRAMES
-            ach = flops / (avg_ms * 1e-3) / 1e12
-            # HBM traffic per launch of this kernel from the rocprofv3 PMC passes committed under profiles/
-            # (FETCH_SIZE x2 per the gfx950 guide + WRITE_SIZE); only valid for the shape it was measured on
-            traffic = None
-            pmc = os.path.join(ROOT, 'profiles', 'r01_f_pmc_rb_fwd_C32.json')
-            if C == 32 and args.batch == 64 and args.precision == 'fp32' and os.path.exists(pmc):
-                traffic = json.load(open(pmc))['traffic_bytes_corrected']
+            ach = flops / (a_ms * 1e-3) / 1e12
+            traffic, traffic_source = None, None
+            for name in ('r02_pmc_rb_fwd_C32.json', 'r01_f_pmc_rb_fwd_C32.json'):
+                pmc = os.path.join(ROOT, 'profiles', name)
+                if C == 32 and args.batch == 64 and args.precision == 'fp32' and os.path.exists(pmc):
+                    traffic = json.load(open(pmc))['traffic_bytes_corrected']
+                    traffic_source = 'profiles/%s (rocprofv3 --pmc passes of this kernel at this shape: FETCH_SIZE x2 + WRITE_SIZE; not re-measured in this run)' % name
+                    break
             roof = dict(kernel='k_rb_fwd<%d,D> (fused ResidualConv2dBlock forward, C=%d, H=65; same MFMA main loop as the '
                                'data-gradient kernel k_conv_mfma)' % (C, C),
                         bound='mfma', achieved=ach, peak=PEAK_FP32_MATRIX_TFLOPS, unit='TFLOP/s',
-                        frac=ach / PEAK_FP32_MATRIX_TFLOPS, traffic=traffic, algorithmic_flops=flops,
-                        algorithmic_bytes=2.0 * 4 * C * args.batch * 65 * M_FRAMES, launches=len(times), avg_ms=avg_ms)
-        cqt = None
+                        frac=ach / PEAK_FP32_MATRIX_TFLOPS, traffic=traffic, traffic_source=traffic_source, algorithmic_flops=flops,
+                        algorithmic_bytes=2.0 * 4 * C * args.batch * 65 * M_FRAMES, launches=n_l, avg_ms=a_ms)
+        cqt = cqt_inv = None
         if events.get('cqt_forward'):
-            times = [s.elapsed_time(e) for s, e in events['cqt_forward']]
-            avg_ms = sum(times) / len(times)
-            gbs = args.batch * 4688280 / (avg_ms * 1e-3) / 1e9
-            cqt = dict(kernel='tt_cqt_forward (3 launches)', bound='hbm', achieved=gbs, peak=PEAK_HBM_GBS, unit='GB/s',
-                       frac=gbs / PEAK_HBM_GBS, avg_ms=avg_ms)
-        base = None
+            a_ms, n_l = avg_ms(events['cqt_forward'])
+            gbs = args.batch * CQT_BYTES_PER_CLIP / (a_ms * 1e-3) / 1e9
+            cqt = dict(kernel='tt_cqt_forward', bound='hbm', achieved=gbs, peak=PEAK_HBM_GBS, unit='GB/s',
+                       frac=gbs / PEAK_HBM_GBS, avg_ms=a_ms, launches=n_l, clips=args.batch)
+        if inv_events.get('cqt_inverse'):
+            a_ms, n_l = avg_ms(inv_events['cqt_inverse'])
+            gbs = args.batch * CQT_BYTES_PER_CLIP / (a_ms * 1e-3) / 1e9
+            cqt_inv = dict(kernel='tt_cqt_inverse (CQT.decode incl. the batch infinity norm)', bound='hbm', achieved=gbs, peak=PEAK_HBM_GBS,
+                           unit='GB/s', frac=gbs / PEAK_HBM_GBS, avg_ms=a_ms, launches=n_l, clips=args.batch,
+                           note='measured after the timed region; the train step never calls the inverse transform')
+        families = family_table(fam_events, n_inst, args.batch, args.mc, args.latent)
+        conv_flops = {1: 41.4e9, 2: 168.7e9}.get(args.mc)          # SURVEY.md section 8d, fwd + bwd per clip (latent 32 / 128)
+        whole = None
+        if conv_flops:
+            tf = conv_flops * args.batch / (ms * 1e-3) / 1e12
+            whole = dict(algorithmic_conv_flops_per_step=conv_flops * args.batch, achieved_tflops=tf,
+                         frac_fp32_matrix_peak=tf / PEAK_FP32_MATRIX_TFLOPS, frac_bf16_mfma_peak=tf / PEAK_BF16_MFMA_TFLOPS)
+        base = base0 = None
         if not args.no_cpu_baseline and world == 1:
             base = cpu_baseline(args.mc, args.latent)
+            base0 = cpu_baseline(1, None, config0=True)
         line = dict(metric='audio-seconds/s training throughput (9oct x 60bpo, 3s@22.05kHz)', value=value,
                     unit='audio-seconds/s', n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms,
                     higher_is_better=True, scaling='weak', vs_baseline=None, dtype={'fp32': 'f32', 'bf16x3': 'bf16x3', 'bf16': 'bf16'}[args.precision], data='synthetic',
                     config=dict(workload='full train step (CQT x2 + AE fwd/bwd with consistency + 3 losses + clip + AdamW), '
                                          'model_complexity=%d latent=%d, %d clips x 3 s per GPU' % (args.mc, args.latent, args.batch),
                                 global_batch=world * args.batch, parallelism='dp%d' % world),
-                    roofline=roof, roofline_cqt=cqt, cpu_baseline=base, final_loss=float(total))
+                    roofline=roof, roofline_cqt=cqt, roofline_cqt_inv=cqt_inv, families=families, whole_step=whole,
+                    per_rank_ms=per_rank_ms, allreduce_ms=allreduce_ms, cpu_baseline=base, cpu_baseline_config0=base0,
+                    final_loss=float(total.detach()))
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

@@ -43,6 +43,11 @@ extern "C" {
 int         tt_version(void);
 const char* tt_arch(void);               /* "gfx950" */
 const char* tt_error_string(int code);   /* hipGetErrorString for code > 0 */
+/* Test / tuning knob (no reference counterpart): the persistent kernels launch min(work items, CUs * workgroups per CU)
+ * workgroups with CUs = 256 on MI355X.  A smaller figure makes every workgroup walk several tiles even on small inputs,
+ * which is how the parity tests reach the multi-tile loops (cross-tile LDS-DMA prefetch, XCD-ordered tile walk) at sizes
+ * the CPU oracle finishes in seconds.  cus <= 0 only queries.  Returns the previous value.  Process-wide, not stream-ordered. */
+int         tt_set_cu_limit(int cus);
 
 /* ------------------------------------------------------------------------------------------------
  * NSGT constant-Q transform.  Replaces cqt_pytorch.CQT.encode / .decode as called from

@@ -21,7 +21,7 @@ def _free_port():
 
 def _worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
-    from timbre_trap.utils import DataParallel, allreduce_gradients, init_process_group_from_env
+    from timbre_trap.utils import DataParallel, GradientSync, allreduce_gradients, init_process_group_from_env
     from timbre_trap.utils.distributed import broadcast_parameters
     r, w, _ = init_process_group_from_env(backend='gloo')
     assert (r, w) == (rank, world)
@@ -29,6 +29,18 @@ def _worker(rank, world, port, out):
     g = torch.arange(614490, dtype=torch.float32) * (rank + 1)
     allreduce_gradients(g, world)
     ok1 = torch.allclose(g, torch.arange(614490, dtype=torch.float32) * 1.5)
+    # 1b. the split form used by the train step: start (async) -> independent work -> finish; same values, bit for bit
+    g2 = torch.arange(614490, dtype=torch.float32) * (rank + 1)
+    sync = GradientSync(world)
+    sync.start(g2)
+    other = torch.ones(1000).cumsum(0)                                # independent work issued while the collective is in flight
+    sync.finish()
+    ok1 = ok1 and torch.equal(g2, g) and float(other[-1]) == 1000.0
+    try:
+        sync.start(g2); sync.start(g2)
+        ok1 = False
+    except RuntimeError:
+        sync.finish()
     # 2. parameters start identical on every rank
     p = torch.full((10,), float(rank))
     broadcast_parameters(p)
@@ -38,6 +50,8 @@ def _worker(rank, world, port, out):
     lin = torch.nn.Linear(4, 3)
     model = DataParallel(lin)
     assert model.in_features == 4 and model.module is lin           # attribute passthrough (reference shim surface)
+    # reference train.py:506-508 / :525-527 unwrap and re-wrap with exactly this check
+    assert isinstance(model, torch.nn.DataParallel) and not isinstance(model.module, torch.nn.DataParallel)
     full_x = torch.arange(32, dtype=torch.float32).view(8, 4) / 10
     x = full_x[rank * 4:(rank + 1) * 4]                              # equal per-rank batches
     model(x).pow(2).mean().backward()

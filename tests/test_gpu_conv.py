@@ -258,3 +258,26 @@ def test_resblock_split_bf16_mode(C, d, shape, monkeypatch):
     assert e < 2e-5, e
     for got, want, name in zip(dev, ref_in, ('dx', 'dw1', 'db1', 'dw2', 'db2')):
         assert _rel(got.grad, want.grad) < 2e-5, (name, _rel(got.grad, want.grad))
+
+
+def test_bias_gradient_with_frozen_weight():
+    """A trainable bias under a frozen weight still receives its gradient (weight / bias gradients gated separately)."""
+    from timbre_trap.framework import ops
+    for kind, wshape in (('conv', (4, 2, 3, 3)), ('tconv', (8, 4, 4, 1))):
+        Cin = wshape[1] if kind == 'conv' else wshape[0]
+        Cout = wshape[0] if kind == 'conv' else wshape[1]
+        x = _rand(2, Cin, 12, 40, seed=1)
+        w, b = _rand(*wshape, seed=2, scale=0.3), _rand(Cout, seed=3, scale=0.2)
+        xr, wr, br = x.double(), w.double(), b.double().requires_grad_(True)
+        if kind == 'conv':
+            yr = F.elu(F.conv2d(xr, wr, br, padding=1))
+            cfg = ops.ConvCfg(3, 3, 1, 1, 1, 1, 'conv', 0, 1)
+        else:
+            yr = F.elu(F.conv_transpose2d(xr, wr, br, stride=(2, 1)))
+            cfg = ops.ConvCfg(4, 1, 2, 1, 0, 0, 'tconv', 0, 1)
+        gy = _rand(*yr.shape, seed=4)
+        yr.backward(gy.double())
+        xd, wd, bd = x.cuda(), w.cuda(), b.cuda().requires_grad_(True)
+        y = ops.conv(xd, wd, bd, cfg)
+        y.backward(gy.cuda())
+        assert wd.grad is None and _rel(bd.grad, br.grad) < 1e-4

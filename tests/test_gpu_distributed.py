@@ -18,7 +18,7 @@ SCRIPT = textwrap.dedent('''
     sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'timbre-trap_amd'))
     import torch
     from timbre_trap.framework import TimbreTrap, compute_reconstruction_loss
-    from timbre_trap.utils import FusedAdamW, init_process_group_from_env, allreduce_gradients
+    from timbre_trap.utils import FusedAdamW, GradientSync, init_process_group_from_env
     from timbre_trap.utils.distributed import broadcast_parameters
     rank, world, _ = init_process_group_from_env()
     torch.cuda.set_device(0)
@@ -29,14 +29,19 @@ SCRIPT = textwrap.dedent('''
     g = torch.Generator().manual_seed(123)
     audio_all = torch.rand(2, 1, 66150, generator=g) * 2 - 1
     audio = audio_all[rank:rank + 1].cuda() if world > 1 else audio_all.cuda()
+    sync = GradientSync(world)
+    coeffs = model.sliCQ(audio)
     for _ in range(2):
-        coeffs = model.sliCQ(audio)
         rec = model(audio, False)[0]
         loss = compute_reconstruction_loss(rec, coeffs)
         opt.zero_grad()
         loss.backward()
         if world > 1:
-            allreduce_gradients(opt.flat_grad, world)
+            sync.start(opt.flat_grad)            # asynchronous all-reduce ...
+            coeffs = model.sliCQ(audio)          # ... with the next step's transform issued meanwhile (bench.py's overlap)
+            sync.finish()
+        else:
+            coeffs = model.sliCQ(audio)
         opt.step()
     print('RESULT %%d %%.9e %%.9e' %% (rank, float(opt.flat_param.double().sum()), float(opt.flat_param.double().abs().sum())))
 ''') % (ROOT, ROOT)
@@ -62,3 +67,40 @@ def test_two_ranks_match_single_process_global_batch():
     assert res[0] == res[1]                                       # ranks end with bit-identical parameters
     single = _result(_run(0, 1, 29542))
     assert abs(res[0][0] - single[0]) <= 1e-5 * abs(single[1]) and abs(res[0][1] - single[1]) <= 1e-5 * abs(single[1])
+
+
+NCCL_SCRIPT = textwrap.dedent('''
+    import os, sys
+    sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'timbre-trap_amd'))
+    import torch
+    from timbre_trap.utils import GradientSync, init_process_group_from_env
+    rank, world, local = init_process_group_from_env()           # backend 'nccl' = RCCL, one GPU per rank
+    torch.cuda.set_device(local)
+    g = torch.arange(614490, dtype=torch.float32, device='cuda') * (rank + 1)
+    sync = GradientSync(world)
+    sync.start(g)
+    busy = torch.ones(1 << 20, device='cuda').cumsum(0)          # compute stream stays busy while RCCL runs on its own stream
+    sync.finish()
+    want = torch.arange(614490, dtype=torch.float32, device='cuda') * (sum(range(1, world + 1)) / world)
+    assert torch.allclose(g, want, rtol=1e-6), float((g - want).abs().max())
+    print('NCCL_OK', rank)
+''') % (ROOT, ROOT)
+
+
+@pytest.mark.gpu
+def test_rccl_allreduce_smoke_when_two_gpus_present():
+    """The 'nccl' (= RCCL over xGMI) branch, one process per GPU through torchrun; skipped on a 1-GPU box."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs >= 2 GPUs (the test box has one): the RCCL branch runs in the driver\'s multi-GPU bench')
+    n = min(torch.cuda.device_count(), 8)
+    path = os.path.join(ROOT, 'gpurun_out', 'nccl_smoke.py')
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, 'w') as f:
+        f.write(NCCL_SCRIPT)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('TTRAP_DIST_BACKEND', None)
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr',
+                          '127.0.0.1', '--master-port', '29551', path], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.count('NCCL_OK') == n

@@ -193,3 +193,213 @@ def test_train_steps_match_oracle():
     for k, p in model.named_parameters():
         want = oracle.params[k].detach()
         assert float((p.detach().cpu() - want).abs().max()) < 2e-4, k
+
+
+# ---- BASELINE.json configurations at their real model size (model_complexity 2, latent 128) --------------------------------
+
+KW['mc2'] = dict(latent_size=128, model_complexity=2, skip_connections=False)
+
+
+def _train_step(model, opt, c, gt):
+    from timbre_trap.framework import compute_consistency_loss, compute_reconstruction_loss, compute_transcription_loss
+    latents, emb, _ = model.encoder(c)
+    rec, trn = model.decode(latents, None), model.decode(latents, None, True)
+    lat2, _, _ = model.encoder(trn)
+    trn_rec, trn_scr = model.decode(lat2, None), model.decode(lat2, None, True)
+    act = model.to_activations(trn)
+    n = gt.size(0)
+    l_rec = compute_reconstruction_loss(rec, c)
+    l_trn = compute_transcription_loss(act[:n], gt, True)
+    l_sp, l_sc = compute_consistency_loss(trn_rec[:n], trn_scr[:n], trn[:n])
+    total = l_rec + l_trn + (l_sp + l_sc)
+    opt.zero_grad()
+    total.backward()
+    return total, opt.step()
+
+
+def test_train_steps_match_oracle_mc2_full_block():
+    """
+    BASELINE configs[2] at reduced batch: model_complexity 2 / latent 128, two clips x one full 3-s block (T = 1024, the
+    bench's tile counts per clip), two steps of losses -> backward -> clip 10 -> AdamW against the CPU oracle trainer.
+    """
+    from timbre_trap.utils import FusedAdamW
+    kw = KW['mc2']
+    sd = oae.closed_form_state_dict(oae.state_dict_shapes(540, **kw), amplitude=0.06)
+    model = _model(kw, sd)
+    opt = FusedAdamW(model.parameters(), lr=1e-3, max_norm=10.0)
+    oracle = OracleTrainer(sd, lr=1e-3)
+    for step in range(2):
+        coeffs = stub_cqt.closed_form_coefficients(2, 540, M) * (1.0 + 0.1 * step)
+        gt = stub_cqt.closed_form_targets(2, 540, M)
+        ref = oracle.step(coeffs, gt)
+        total, norm = _train_step(model, opt, coeffs.cuda(), gt.cuda())
+        np.testing.assert_allclose(float(total), ref['total'], rtol=2e-4)
+        np.testing.assert_allclose(float(norm), ref['grad_norm'], rtol=2e-3)
+    worst = max(float((p.detach().cpu() - oracle.params[k].detach()).abs().max()) for k, p in model.named_parameters())
+    assert worst < 2e-4, worst
+
+
+def test_transcribe_reconstruct_config1_mc2_batch():
+    """
+    BASELINE configs[1]: model_complexity 2 / latent 128, a BATCH of clips through transcribe() + reconstruct()
+    (3 half-overlapping chunks per 3-s clip, all chunks of all clips in one batched pass) vs the oracle per clip.
+    """
+    tab = nsgt.nsgt_tables(9, 60, SR, N)
+    sd = oae.closed_form_state_dict(oae.state_dict_shapes(540, **KW['mc2']), amplitude=0.06)
+    model = _model(KW['mc2'], sd).eval()
+    g = torch.Generator().manual_seed(11)
+    audio = torch.rand(3, 1, N, generator=g) * 2 - 1
+
+    def cqt_fwd(chunk):
+        return torch.from_numpy(np.ascontiguousarray(nsgt.wrapper_forward(chunk.numpy(), tab))).float()
+    got_t = model.chunked_inference(audio.cuda(), True).cpu()
+    got_r = model.chunked_inference(audio.cuda(), False).cpu()
+    assert got_t.shape == got_r.shape == (3, 2, 540, M)
+    for b in range(3):
+        want_t = oae.chunked_inference(audio[b:b + 1], sd, cqt_fwd, N, M, True)
+        want_r = oae.chunked_inference(audio[b:b + 1], sd, cqt_fwd, N, M, False)
+        assert float((got_t[b:b + 1] - want_t).abs().max() / want_t.abs().max()) < 1e-4, b
+        assert float((got_r[b:b + 1] - want_r).abs().max() / want_r.abs().max()) < 1e-4, b
+    act = model.transcribe(audio.cuda())
+    rec = model.reconstruct(audio.cuda())
+    assert act.shape == (3, 540, M) and rec.shape == (3, 1, N)
+    torch.testing.assert_close(act.cpu(), torch.tanh(torch.linalg.vector_norm(got_t, dim=1)), rtol=1e-5, atol=1e-6)
+    assert abs(float(rec.abs().max()) - 1.0) < 1e-5          # decode divides the whole batch by its infinity norm
+
+
+@pytest.mark.parametrize('precision,logit_tol,loss_tol', [('bf16x3', 1e-4, 1e-4), ('bf16', 3e-2, 1e-2)])
+def test_model_level_reduced_precision_modes(precision, logit_tol, loss_tol, monkeypatch):
+    """
+    The opt-in matrix-core precisions at MODEL level (mc 2 / latent 128, T = 256, consistency pass included) against the
+    fp32 oracle, with their honest tolerances: split-bf16 stays inside the 1e-4 bar of the fp32 path on this network,
+    single-rounded bf16 operands are a 1e-2-class approximation (2^-8 per operand through 24 stacked 3x3 convolutions).
+    """
+    from timbre_trap.framework import compute_consistency_loss, compute_reconstruction_loss, compute_transcription_loss, ops
+    monkeypatch.setattr(ops, 'PRECISION', precision)
+    kw = KW['mc2']
+    sd = oae.closed_form_state_dict(oae.state_dict_shapes(540, **kw), amplitude=0.06)
+    model = _model(kw, sd)
+    T = 256
+    coeffs = stub_cqt.closed_form_coefficients(2, 540, T)
+    gt = stub_cqt.closed_form_targets(2, 540, T)
+    ref = oae.forward(coeffs, sd, consistency=True)
+    tot_ref, parts = oobj.total_loss(ref, coeffs, gt)
+    c = coeffs.cuda()
+    latents, emb, _ = model.encoder(c)
+    rec, trn = model.decode(latents, None), model.decode(latents, None, True)
+    lat2, _, _ = model.encoder(trn)
+    trn_rec, trn_scr = model.decode(lat2, None), model.decode(lat2, None, True)
+    worst = 0.0
+    for name, got, want in zip(('reconstruction', 'latents', 'transcription', 'transcription_rec', 'transcription_scr'),
+                               (rec, latents, trn, trn_rec, trn_scr), ref):
+        err = float((got.detach().cpu() - want).abs().max() / want.abs().max())
+        worst = max(worst, err)
+        assert err < logit_tol, (precision, name, err)
+    print('%s: worst relative logit error %.3e' % (precision, worst))
+    act = model.to_activations(trn)
+    total = (compute_reconstruction_loss(rec, c) + compute_transcription_loss(act, gt.cuda(), True)
+             + sum(compute_consistency_loss(trn_rec, trn_scr, trn)))
+    assert abs(float(total) - float(tot_ref)) / abs(float(tot_ref)) < loss_tol
+
+
+# ---- evaluate()-scale inputs: one long track, batch 1, one-shot forward (reference experiments/evaluate.py:81-113) ----------
+
+@pytest.mark.parametrize('tag,n_blocks', [('mc1', 20), ('mc2', 6)])
+def test_full_track_one_shot_forward(tag, n_blocks):
+    """
+    evaluate() pads a whole track to a multiple of the block length and runs ONE forward over it (batch 1, T = n * 1024
+    frames: a single convolution call per layer, unlike chunked_inference).  Coefficients, the five outputs, the
+    activations, frame times and the masked peak-picking are checked against the oracle at that length.
+    """
+    from timbre_trap.utils import peaks_above
+    from oracle import postprocessing as opp
+    tab = nsgt.nsgt_tables(9, 60, SR, N)
+    sd = oae.closed_form_state_dict(oae.state_dict_shapes(540, **KW[tag]), amplitude=0.08)
+    model = _model(KW[tag], sd).eval()
+    g = torch.Generator().manual_seed(21)
+    n_samples = int((n_blocks - 0.4) * N)                       # not a whole number of blocks: pad_to_block_length path
+    audio = torch.rand(1, 1, n_samples, generator=g) * 2 - 1
+    padded = model.sliCQ.pad_to_block_length(audio.cuda())
+    assert padded.size(-1) == n_blocks * N
+    with torch.no_grad():
+        coeffs = model.sliCQ(padded)
+        res = model(padded, True)
+        act = model.to_activations(res[2])
+    T = n_blocks * M
+    assert coeffs.shape == (1, 2, 540, T) and act.shape == (1, 540, T)
+    assert model.sliCQ.get_expected_frames(padded.size(-1)) == T
+    times = model.sliCQ.get_times(T)
+    assert times[1] == 3.0 / 1024 and times[-1] == (T - 1) * 64.599609375 / SR
+    c_ref = torch.from_numpy(np.ascontiguousarray(nsgt.wrapper_forward(padded.cpu().numpy(), tab))).float()
+    assert float((coeffs.cpu() - c_ref).abs().max() / c_ref.abs().max()) < 1e-4
+    ref = oae.forward(c_ref, sd, consistency=True)
+    for name, got, want in zip(('reconstruction', 'latents', 'transcription', 'transcription_rec', 'transcription_scr'), res, ref):
+        err = float((got.cpu() - want).abs().max() / want.abs().max())
+        assert err < 1e-4, (name, err)
+    # evaluate.py:105-113: zero the bins above 5 kHz, strict peaks along frequency, threshold 0.5 -- on the device
+    a = act[0].cpu().numpy().astype(np.float64)
+    n_valid = int(np.sum(model.sliCQ.midi_freqs <= 12 * (np.log2(5000.0) - np.log2(440.0)) + 69))
+    masked = a.copy()
+    masked[n_valid:] = 0
+    want = opp.threshold(opp.filter_non_peaks(masked), 0.5)
+    got = peaks_above(act[0], 0.5, n_valid).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+
+
+def test_fused_adamw_survives_dropped_gradients_and_resumes():
+    """
+    ``model.zero_grad()`` sets every ``.grad`` to None, which detaches them from the optimizer's flat buffer; the next
+    backward then installs fresh gradient tensors.  The fused step must see THOSE gradients (it re-attaches its views),
+    and ``state_dict`` / ``load_state_dict`` must carry the moments and the bias-correction step.
+    """
+    from timbre_trap.utils import FusedAdamW
+    kw = KW['mc1']
+    sd = oae.closed_form_state_dict(oae.state_dict_shapes(540, **kw), amplitude=0.12)
+    T = 32
+    coeffs = [stub_cqt.closed_form_coefficients(2, 540, T) * (1.0 + 0.1 * s) for s in range(3)]
+    gt = stub_cqt.closed_form_targets(2, 540, T).cuda()
+
+    def run(style):
+        model = _model(kw, sd)
+        opt = FusedAdamW(model.parameters(), lr=1e-3, max_norm=10.0)
+        for s in range(3):
+            if style == 'model_zero_grad' and s > 0:
+                model.zero_grad()                      # grads -> None; opt.zero_grad inside _train_step restores the views
+                for p in model.parameters():
+                    assert p.grad is None
+            if style == 'resume' and s == 2:
+                state = opt.state_dict()
+                model2 = _model(kw, {k: v.detach().clone() for k, v in model.state_dict().items()})
+                opt = FusedAdamW(model2.parameters(), lr=1e-3, max_norm=10.0)
+                opt.load_state_dict(state)
+                model = model2
+            if style == 'none_then_backward' and s > 0:
+                # drop the gradients AFTER zero_grad, so backward really installs fresh tensors and step() must adopt them
+                c = coeffs[s].cuda()
+                from timbre_trap.framework import compute_reconstruction_loss
+                opt.zero_grad()
+                for p in model.parameters():
+                    p.grad = None
+                latents, _, _ = model.encoder(c)
+                loss = compute_reconstruction_loss(model.decode(latents, None), c)
+                loss.backward()
+                opt.step()
+                continue
+            if style == 'none_then_backward_ref' and s > 0:
+                c = coeffs[s].cuda()
+                from timbre_trap.framework import compute_reconstruction_loss
+                opt.zero_grad()
+                latents, _, _ = model.encoder(c)
+                loss = compute_reconstruction_loss(model.decode(latents, None), c)
+                loss.backward()
+                opt.step()
+                continue
+            _train_step(model, opt, coeffs[s].cuda(), gt)
+        return torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu()
+
+    # (a few gradient reductions use fp32 atomics, so two runs agree to round-off, not bitwise -- DESIGN.md section 4)
+    base = run('plain')
+    assert float((run('model_zero_grad') - base).abs().max()) < 2e-5
+    assert float((run('resume') - base).abs().max()) < 2e-5
+    a, b = run('none_then_backward'), run('none_then_backward_ref')
+    assert float((a - b).abs().max()) < 2e-5 and float((a - base).abs().max()) > 1e-4

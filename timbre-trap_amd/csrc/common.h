@@ -18,6 +18,25 @@
 
 static inline hipStream_t tt_stream(void* s) { return (hipStream_t)s; }
 
+// hipFuncSetAttribute acts on the CURRENT device's copy of a kernel: every launch helper remembers, per device, that it
+// has raised the dynamic-LDS limit of its kernel (one bit per device ordinal, set with an atomic OR so that threads
+// driving different devices may race harmlessly -- the attribute call is idempotent).
+struct AttrOnce {
+    unsigned long long done[4] = {0ull, 0ull, 0ull, 0ull};
+    int pending() const {                      // device ordinal that still needs the attribute, or -1
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 0;
+        dev &= 255;
+        return ((__atomic_load_n(&done[dev >> 6], __ATOMIC_RELAXED) >> (dev & 63)) & 1ull) ? -1 : dev;
+    }
+    void mark(int dev) { __atomic_fetch_or(&done[dev >> 6], 1ull << (dev & 63), __ATOMIC_RELAXED); }
+};
+
+// Persistent kernels launch min(work items, tt_cus() * workgroups per CU) workgroups.  256 CUs on MI355X;
+// tt_set_cu_limit (include/ttrap.h) lowers the figure so that small shapes run the multi-tile loops (tests, tuning).
+extern int g_tt_cu_limit;                       // defined in losses.hip
+static inline int tt_cus() { return g_tt_cu_limit; }
+
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }

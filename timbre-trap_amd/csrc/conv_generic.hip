@@ -378,15 +378,15 @@ __global__ __launch_bounds__(512) void k_conv3x3_lds(ConvP p) {
 template <int CI, int CO>
 int launch_conv3x3_lds(const ConvP& p, hipStream_t st) {
     using L = BL<CI, CO>;
-    static bool attr = false;
-    if (!attr) {
+    static AttrOnce attr;
+    if (const int adev_ = attr.pending(); adev_ >= 0) {
         TT_HIP(hipFuncSetAttribute((const void*)k_conv3x3_lds<CI, CO>, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES));
-        attr = true;
+        attr.mark(adev_);
     }
     const int ntiles = p.B * ((p.Hin + 15) / 16) * ((p.T + 63) / 64);
     int per_cu = (160 * 1024) / L::LDS_BYTES;
     if (per_cu > 4) per_cu = 4;
-    const int grid = ntiles < 256 * per_cu ? ntiles : 256 * per_cu;
+    const int grid = ntiles < tt_cus() * per_cu ? ntiles : tt_cus() * per_cu;
     hipLaunchKernelGGL((k_conv3x3_lds<CI, CO>), dim3(grid), dim3(512), L::LDS_BYTES, st, p);
     TT_LAUNCH_CHECK();
     return 0;
@@ -520,7 +520,7 @@ extern "C" int tt_conv2d_wgrad(const float* x, const float* g, float* dw, float*
     if (KH == 3 && KW == 3 && stride_h == 1 && dil_h == 1 && dil_w == 1 && pad_h == 1 && pad_w == 1 && Hin == Hout &&
         ((Cin == 2 && Cout == 4) || (Cin == 4 && Cout == 2)) && (long)Cin * Hin * T < (1L << 31)) {
         const long ntiles = (long)B * Hin * ((T + 255) / 256);
-        const int grid = (int)(ntiles < 2048 ? ntiles : 2048);
+        const int grid = (int)(ntiles < 8L * tt_cus() ? ntiles : 8L * tt_cus());
         if (Cin == 2) hipLaunchKernelGGL((k_wgrad3x3_small<4, 2>), dim3(grid), dim3(256), 0, tt_stream(stream), p);
         else hipLaunchKernelGGL((k_wgrad3x3_small<2, 4>), dim3(grid), dim3(256), 0, tt_stream(stream), p);
         TT_LAUNCH_CHECK();

@@ -1372,7 +1372,7 @@ inline int blocks_per_cu(int lds_bytes, int cap) {
     return n > cap ? cap : (n < 1 ? 1 : n);
 }
 inline int persistent_grid(int ntiles, int per_cu) {
-    const int cap = 256 * per_cu;
+    const int cap = tt_cus() * per_cu;
     return ntiles < cap ? ntiles : cap;
 }
 inline int ntiles_of(int B, int H, int T) { return B * ((H + TH - 1) / TH) * ((T + TW - 1) / TW); }
@@ -1382,10 +1382,10 @@ int launch_conv_v(const float* x, const float* gy, const float* w, WSpec ws, con
                   int B, int Hin, int Hout, int T, int act, hipStream_t st) {
     using G = Geo<CIN, COUT, P, DMA, PREC>;
     constexpr int LDS = (G::W_FLOATS + G::XS_FLOATS) * 4;
-    static bool attr = false;
-    if (!attr) {
+    static AttrOnce attr;
+    if (const int adev_ = attr.pending(); adev_ >= 0) {
         TT_HIP(hipFuncSetAttribute((const void*)k_conv_mfma<CIN, COUT, P, GATE, DMA, PREC>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr = true;
+        attr.mark(adev_);
     }
     hipLaunchKernelGGL((k_conv_mfma<CIN, COUT, P, GATE, DMA, PREC>), dim3(persistent_grid(ntiles_of(B, Hout, T), blocks_per_cu(LDS, 2))),
                        dim3(NTHREADS), LDS, st, x, gy, w, ws, bias, res, y, B, Hin, Hout, T, act);
@@ -1483,10 +1483,10 @@ template <int CIN, int COUT, class P>
 int launch_conv_valu(const float* x, const float* w, WSpec ws, const float* bias, float* y, int B, int Hin, int Hout, int T, int act,
                      hipStream_t st) {
     using V = VGeo<CIN, COUT, P>;
-    static bool attr = false;
-    if (!attr) {
+    static AttrOnce attr;
+    if (const int adev_ = attr.pending(); adev_ >= 0) {
         TT_HIP(hipFuncSetAttribute((const void*)k_conv_valu<CIN, COUT, P>, hipFuncAttributeMaxDynamicSharedMemorySize, V::LDS_BYTES));
-        attr = true;
+        attr.mark(adev_);
     }
     hipLaunchKernelGGL((k_conv_valu<CIN, COUT, P>), dim3(persistent_grid(ntiles_of(B, Hout, T), blocks_per_cu(V::LDS_BYTES, 4))),
                        dim3(NTHREADS), V::LDS_BYTES, st, x, w, ws, bias, y, B, Hin, Hout, T, act);
@@ -1520,10 +1520,10 @@ int launch_rb_fwd_v(const float* x, const float* w1, const float* b1, const floa
     using G = Geo<C, C, Res3x3<D>, DMA, PREC>;
     using R = RB<C>;
     constexpr int LDS = (G::W_FLOATS + R::CPAD * R::CP + 2 * R::CPAD + G::XS_FLOATS) * 4;
-    static bool attr = false;
-    if (!attr) {
+    static AttrOnce attr;
+    if (const int adev_ = attr.pending(); adev_ >= 0) {
         TT_HIP(hipFuncSetAttribute((const void*)k_rb_fwd<C, D, DMA, PREC>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr = true;
+        attr.mark(adev_);
     }
     hipLaunchKernelGGL((k_rb_fwd<C, D, DMA, PREC>), dim3(persistent_grid(ntiles_of(B, H, T), blocks_per_cu(LDS, 2))), dim3(NTHREADS), LDS,
                        st, x, w1, b1, w2, b2, y, h1, B, H, T);
@@ -1559,14 +1559,14 @@ int launch_wgrad(const float* Pt, const float* Pg, const float* Qt, const float*
         if (dma_ok(Pt, T) && dma_ok(Qt, T)) {
             using Q = WGeoD<CBS, WP>;
             constexpr int LDS = cmax(Q::Q_FLOATS + WP::WTH * K::CAP * 64, K::RED_FLOATS) * 4;
-            static bool attr = false;
-            if (!attr) {
+            static AttrOnce attr;
+            if (const int adev_ = attr.pending(); adev_ >= 0) {
                 TT_HIP(hipFuncSetAttribute((const void*)k_wgrad_dma<CA, CB, CBS, WP, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
                 if constexpr (CA >= 16 && WP::NTAPS == 9) {
                     TT_HIP(hipFuncSetAttribute((const void*)k_wgrad_dma<CA, CB, CBS, WP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
                     TT_HIP(hipFuncSetAttribute((const void*)k_wgrad_dma<CA, CB, CBS, WP, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
                 }
-                attr = true;
+                attr.mark(adev_);
             }
             grid = persistent_grid(ntiles, blocks_per_cu(LDS, 4));
             if (grid * NS > WGRAD_MAX_BLOCKS) grid = WGRAD_MAX_BLOCKS / NS;
@@ -1592,11 +1592,11 @@ int launch_wgrad(const float* Pt, const float* Pg, const float* Qt, const float*
             return 0;
         }
     }
-    static bool attr2 = false;
-    if (!attr2) {
+    static AttrOnce attr2;
+    if (const int adev_ = attr2.pending(); adev_ >= 0) {
         TT_HIP(hipFuncSetAttribute((const void*)k_wgrad_mfma<CA, CB, CBS, WP, GP, GQ>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    K::LDS_BYTES));
-        attr2 = true;
+        attr2.mark(adev_);
     }
     grid = persistent_grid(ntiles, blocks_per_cu(K::LDS_BYTES, 4));
     if (grid * NS > WGRAD_MAX_BLOCKS) grid = WGRAD_MAX_BLOCKS / NS;
@@ -1615,10 +1615,10 @@ int launch_rb_bwd_a_v(const float* x, const float* h1, const float* dy, const fl
     using G = Geo<C, C, Res3x3<D>, DMA>;
     using R = RB<C>;
     constexpr int LDS = ((RECOMP ? G::W_FLOATS + G::XS_FLOATS : 0) + 2 * R::CPAD * R::CP + 2 * R::CPAD + R::TR_FLOATS) * 4;
-    static bool attr = false;
-    if (!attr) {
+    static AttrOnce attr;
+    if (const int adev_ = attr.pending(); adev_ >= 0) {
         TT_HIP(hipFuncSetAttribute((const void*)k_rb_bwd_a<C, D, DMA, RECOMP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr = true;
+        attr.mark(adev_);
     }
     hipLaunchKernelGGL((k_rb_bwd_a<C, D, DMA, RECOMP>), dim3(persistent_grid(ntiles_of(B, H, T), blocks_per_cu(LDS, 2))),
                        dim3(NTHREADS), LDS, st, x, h1, dy, w1, b1, w2, b2, ws, db1, dw2, db2, B, H, T);
@@ -1801,10 +1801,10 @@ __global__ __launch_bounds__(256) void k_wgrad3_pack_reduce(const float* __restr
 template <int C, int D>
 int launch_wgrad3_pack(const float* g, const float* x, float* dw1, float* scratch, int B, int H, int T, hipStream_t st) {
     using W = WPk<C, D>;
-    static bool attr = false;
-    if (!attr) {
+    static AttrOnce attr;
+    if (const int adev_ = attr.pending(); adev_ >= 0) {
         TT_HIP(hipFuncSetAttribute((const void*)k_wgrad3_pack<C, D>, hipFuncAttributeMaxDynamicSharedMemorySize, W::LDS_BYTES));
-        attr = true;
+        attr.mark(adev_);
     }
     const int ntiles = B * ((H + 7) / 8) * ((T + 63) / 64);
     int grid = persistent_grid(ntiles, blocks_per_cu(W::LDS_BYTES, 3));

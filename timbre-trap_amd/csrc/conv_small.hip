@@ -387,15 +387,15 @@ int launch_small_lds(const float* x, const float* w1, const float* b1, const flo
                      float* h1, int B, int H, int T, hipStream_t st) {
     constexpr int RPT = SMALL_RPT, NBUF = (C == 8 && RPT == 2) ? 1 : 2;
     using L = SL<C, D, RPT, NBUF>;
-    static bool attr = false;
-    if (!attr) {
+    static AttrOnce attr;
+    if (const int adev_ = attr.pending(); adev_ >= 0) {
         TT_HIP(hipFuncSetAttribute((const void*)k_small_lds<C, D, MODE, RPT, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES));
-        attr = true;
+        attr.mark(adev_);
     }
     const int ntiles = B * ((H + L::TR - 1) / L::TR) * ((T + 63) / 64);
     int per_cu = (160 * 1024) / L::LDS_BYTES;
     if (per_cu > 4) per_cu = 4;
-    const int grid = ntiles < 256 * per_cu ? ntiles : 256 * per_cu;
+    const int grid = ntiles < tt_cus() * per_cu ? ntiles : tt_cus() * per_cu;
     hipLaunchKernelGGL((k_small_lds<C, D, MODE, RPT, NBUF>), dim3(grid), dim3(512), L::LDS_BYTES, st, x, w1, b1, w2, b2, res, y, h1, B, H, T);
     TT_LAUNCH_CHECK();
     return 0;
@@ -417,7 +417,7 @@ int bwd_t(const float* x, const float* h1, const float* dy, const float* w1, con
           hipStream_t st) {
     (void)dw1; (void)scratch;
     const int ntiles = B * ((H + 3) / 4) * ((T + 63) / 64);
-    const int pgrid = ntiles < 2048 ? ntiles : 2048;
+    const int pgrid = ntiles < 8 * tt_cus() ? ntiles : 8 * tt_cus();
     if (h1)
         hipLaunchKernelGGL((k_small_bwd_a<C, D, false>), dim3(pgrid), dim3(256), 0, st, x, h1, dy, w1, b1, w2, b2, ws, db1, dw2,
                            db2, B, H, T);

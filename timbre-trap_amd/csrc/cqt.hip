@@ -558,10 +558,11 @@ extern "C" int64_t tt_cqt_scratch_bytes(int n_clips, int n_bins, int sum_len) {
 }
 
 static int cqt_set_attrs() {
-    static bool done = false;
-    if (done) return 0;
-    TT_HIP(hipFuncSetAttribute((const void*)k_fft675_rows, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ROWS));
-    done = true;
+    static AttrOnce attr;
+    if (const int adev_ = attr.pending(); adev_ >= 0) {
+        TT_HIP(hipFuncSetAttribute((const void*)k_fft675_rows, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ROWS));
+        attr.mark(adev_);
+    }
     return 0;
 }
 

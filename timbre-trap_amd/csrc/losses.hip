@@ -395,7 +395,14 @@ extern "C" int tt_peak_pick(const float* x, float* out, int64_t n_outer, int F, 
     return 0;
 }
 
-extern "C" int tt_version(void) { return 1; }
+int g_tt_cu_limit = 256;
+extern "C" int tt_set_cu_limit(int cus) {
+    const int prev = g_tt_cu_limit;
+    if (cus > 0) g_tt_cu_limit = cus > 256 ? 256 : cus;
+    return prev;
+}
+
+extern "C" int tt_version(void) { return 2; }
 extern "C" const char* tt_arch(void) { return "gfx950"; }
 extern "C" const char* tt_error_string(int code) {
     if (code == 0) return "ok";

@@ -38,6 +38,7 @@ _PROTOS = {
     'tt_version': (c_int, []),
     'tt_arch': (ctypes.c_char_p, []),
     'tt_error_string': (ctypes.c_char_p, [I]),
+    'tt_set_cu_limit': (c_int, [I]),
     'tt_cqt_scratch_bytes': (c_int64, [I, I, I]),
     'tt_cqt_forward': (c_int, [ctypes.POINTER(CqtPlan), P, P, P, I, I, I, P]),
     'tt_cqt_inverse': (c_int, [ctypes.POINTER(CqtPlan), P, P, P, I, I, I, I, P]),
@@ -92,8 +93,15 @@ def build(verbose=False, force=False):
         out, _ = pr.communicate()
         if pr.returncode != 0:
             raise RuntimeError('hipcc failed: %s\n%s' % (' '.join(cmd), out.decode()))
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs
+    # objects of sources that no longer exist must not travel to the GPU box with the snapshot
+    for f in os.listdir(os.path.dirname(LIB_PATH)):
+        if f.endswith('.o') and os.path.join(os.path.dirname(LIB_PATH), f) not in objs:
+            os.remove(os.path.join(os.path.dirname(LIB_PATH), f))
+    # link to a temporary name and rename into place: another rank must never dlopen a half-written library
+    tmp = LIB_PATH + '.tmp.%d' % os.getpid()
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', tmp] + objs
     subprocess.run(cmd, check=True)
+    os.replace(tmp, LIB_PATH)
     return LIB_PATH
 
 
@@ -123,8 +131,10 @@ def check(rc, what=''):
         raise RuntimeError('ttrap HIP call %s failed (%d): %s' % (what, rc, msg.decode() if msg else '?'))
 
 
-# bench.py sets this to a dict to time selected C-ABI calls with HIP events recorded on the launch stream
+# bench.py sets this to a dict to time C-ABI calls with HIP events recorded on the launch stream; EVENT_KEYS (a set or
+# None = every instrumented call) restricts which calls are bracketed
 EVENT_LOG = None
+EVENT_KEYS = None
 
 
 class timed:
@@ -135,7 +145,7 @@ class timed:
         self.start = None
 
     def __enter__(self):
-        if EVENT_LOG is not None:
+        if EVENT_LOG is not None and (EVENT_KEYS is None or self.key in EVENT_KEYS):
             import torch
             self.start = torch.cuda.Event(enable_timing=True)
             self.start.record()

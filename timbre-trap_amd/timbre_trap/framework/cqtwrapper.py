@@ -151,8 +151,9 @@ class CQT(nn.Module):
             scratch = torch.empty(lib.tt_cqt_scratch_bytes(B * n_blocks, self.n_bins, self._sum_len),
                                   dtype=torch.uint8, device=c.device)
             audio = torch.empty((B, 1, n_blocks * self.block_length), dtype=torch.float32, device=c.device)
-            _hip.check(lib.tt_cqt_inverse(ctypes.byref(ps), _hip.ptr(c), _hip.ptr(audio), _hip.ptr(scratch),
-                                          B, n_blocks, int(is_complex), 1, _hip.stream_ptr()), 'tt_cqt_inverse')
+            with _hip.timed('cqt_inverse'):
+                _hip.check(lib.tt_cqt_inverse(ctypes.byref(ps), _hip.ptr(c), _hip.ptr(audio), _hip.ptr(scratch),
+                                              B, n_blocks, int(is_complex), 1, _hip.stream_ptr()), 'tt_cqt_inverse')
         return audio
 
     # ---- layout helpers (reference cqtwrapper.py:74-182), stock tensor views ----------------------

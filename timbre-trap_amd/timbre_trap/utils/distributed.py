@@ -43,22 +43,58 @@ def allreduce_gradients(flat_grad, world_size=None, async_op=False):
     return dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, async_op=async_op)
 
 
+class GradientSync:
+    """
+    The data-parallel exchange of one train step, split in two so that independent work can be issued in between:
+
+        sync.start(flat_grad)      pre-divide by the world size, launch ONE asynchronous all-reduce(SUM)
+        ...                        e.g. the next batch's CQT on the compute stream (no dependence on the weights)
+        sync.finish()              the CURRENT stream waits for the collective (the host does not block with RCCL)
+
+    With the 'nccl' backend (RCCL) the collective runs on the process group's own HIP stream, ordered after the kernels
+    already enqueued on the current stream; ``finish`` makes the current stream wait on its completion event, so
+    ``opt.step()`` issued afterwards sees the averaged gradient.  With gloo (CPU tests, 1-GPU functional tests) ``finish``
+    blocks the host instead; the arithmetic is identical.
+    """
+
+    def __init__(self, world_size=None):
+        self.world = world_size
+        self.work = None
+
+    def start(self, flat_grad):
+        if self.work is not None:
+            raise RuntimeError('GradientSync.start called twice without finish')
+        self.work = allreduce_gradients(flat_grad, self.world, async_op=True)
+        return self.work
+
+    def finish(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+
+
 def broadcast_parameters(flat_param, src=0):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.broadcast(flat_param, src=src)
 
 
-class DataParallel(torch.nn.Module):
+class DataParallel(torch.nn.DataParallel):
     """
     Attribute-forwarding wrapper with the reference shim's surface (``model.sliCQ`` etc. resolve on the
-    wrapped module, ``.module`` unwraps).  It holds ONE replica -- this process's -- and averages the
-    gradients across processes when ``sync_gradients`` is called (or by FusedAdamW users through
-    ``allreduce_gradients`` on the flat buffer).
+    wrapped module, ``.module`` unwraps).  It IS a ``torch.nn.DataParallel`` -- reference experiments/train.py:506-508
+    and :525-527 unwrap / re-wrap around ``torch.save`` with ``isinstance(model, torch.nn.DataParallel)`` -- but it never
+    replicates: it holds ONE replica, this process's (``device_ids`` is kept empty, which is stock DataParallel's own
+    "run the module directly" case), and the gradients are averaged across processes when ``sync_gradients`` is called
+    (or by FusedAdamW users through ``allreduce_gradients`` on the flat buffer).
     """
 
-    def __init__(self, module, device_ids=None):
-        super().__init__()
+    def __init__(self, module, device_ids=None, output_device=None, dim=0):
+        torch.nn.Module.__init__(self)          # not DataParallel.__init__: no device bookkeeping, no replication
         self.module = module
+        self.device_ids = []
+        self.output_device = None
+        self.src_device_obj = None
+        self.dim = dim
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)

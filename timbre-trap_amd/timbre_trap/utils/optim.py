@@ -36,6 +36,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self.norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self._partials = torch.empty(1024, dtype=torch.float64, device=dev)
         o = 0
+        self._slots = []
         with torch.no_grad():
             for p in params:
                 k = p.numel()
@@ -43,12 +44,63 @@ class FusedAdamW(torch.optim.Optimizer):
                 p.data = self.flat_param[o:o + k].view_as(p)
                 p.grad = self.flat_grad[o:o + k].view_as(p)
                 p._ttrap_accumulate = True        # backward kernels add into this view directly (framework/ops.py:_grad_target)
+                self._slots.append((p, o, k))
                 o += k
         self.n = n
 
+    def _reattach(self):
+        """
+        The fused step reads ONE flat gradient buffer and writes ONE flat parameter buffer, so every ``p.grad`` / ``p.data``
+        must still be the view it was given.  ``model.zero_grad()`` (grads set to None), ``p.grad = None``, or anything else
+        that makes autograd install a fresh ``.grad`` tensor detaches a view: the fresh gradient is then copied into its slot
+        and the view restored (a parameter without a gradient contributes zeros).  A re-allocated ``p.data`` on the same
+        device is adopted the same way; one on another device is an error (build a new optimizer after moving the model).
+        """
+        gbase, pbase = self.flat_grad.data_ptr(), self.flat_param.data_ptr()
+        for p, o, k in self._slots:
+            g = p.grad
+            if g is None or g.data_ptr() != gbase + 4 * o or g.dtype != torch.float32:
+                slot = self.flat_grad[o:o + k]
+                if g is None:
+                    slot.zero_()
+                else:
+                    if g.device != slot.device:
+                        raise RuntimeError('FusedAdamW: a gradient moved to %s (optimizer state is on %s)' % (g.device, slot.device))
+                    slot.copy_(g.detach().reshape(-1))
+                p.grad = slot.view_as(p)
+            if p.data_ptr() != pbase + 4 * o:
+                if p.device != self.flat_param.device or p.dtype != torch.float32:
+                    raise RuntimeError('FusedAdamW: parameter storage was replaced (device %s, dtype %s); create a new '
+                                       'optimizer after moving or casting the model' % (p.device, p.dtype))
+                self.flat_param[o:o + k].copy_(p.detach().reshape(-1))
+                p.data = self.flat_param[o:o + k].view_as(p)
+            p._ttrap_accumulate = True
+
+    def state_dict(self):
+        """Moments and step count included (they live in flat buffers, outside ``Optimizer.state``)."""
+        sd = super().state_dict()
+        sd['ttrap_flat'] = dict(step=self._step, exp_avg=self.exp_avg.detach().clone(), exp_avg_sq=self.exp_avg_sq.detach().clone(),
+                                max_norm=self.max_norm, n=self.n)
+        return sd
+
+    def load_state_dict(self, state_dict):
+        state_dict = dict(state_dict)
+        flat = state_dict.pop('ttrap_flat', None)
+        super().load_state_dict(state_dict)
+        if flat is None:
+            raise ValueError('not a FusedAdamW state_dict (no flat moments): resuming would restart the moment estimates')
+        if int(flat['n']) != self.n:
+            raise ValueError('FusedAdamW state has %d elements, this optimizer %d' % (int(flat['n']), self.n))
+        self._step = int(flat['step'])
+        self.exp_avg.copy_(flat['exp_avg'].to(self.exp_avg.device))
+        self.exp_avg_sq.copy_(flat['exp_avg_sq'].to(self.exp_avg_sq.device))
+
     def zero_grad(self, set_to_none=False):
-        # gradients must stay views of the flat buffer: zero in place, never drop them
+        # gradients must stay views of the flat buffer: zero in place, never drop them (and restore dropped ones)
         self.flat_grad.zero_()
+        for p, o, k in self._slots:
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
+                p.grad = self.flat_grad[o:o + k].view_as(p)
 
     def grad_norm(self):
         _hip.check(_hip.lib().tt_l2norm(_hip.ptr(self.flat_grad), _hip.ptr(self.norm), _hip.ptr(self._partials), self.n,
@@ -61,7 +113,13 @@ class FusedAdamW(torch.optim.Optimizer):
         if closure is not None:
             raise NotImplementedError
         g = self.param_groups[0]
+        self._reattach()
         self._step += 1
+        with _hip.timed('clip_adamw'):
+            norm = self._clip_and_update(g)
+        return norm
+
+    def _clip_and_update(self, g):
         norm = self.grad_norm() if self.max_norm else None
         _hip.check(_hip.lib().tt_adamw_step(_hip.ptr(self.flat_param), _hip.ptr(self.flat_grad), _hip.ptr(self.exp_avg),
                                             _hip.ptr(self.exp_avg_sq), _hip.ptr(norm), self.n, float(g['lr']),

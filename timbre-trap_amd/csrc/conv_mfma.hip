@@ -1948,6 +1948,7 @@ extern "C" int tt_resblock_bwd(const float* x, const float* h1, const float* dy,
     if (C <= 8) {
         int rc = tt_small_rb_bwd(x, h1, dy, w1, b1, w2, b2, dx, dw1, db1, dw2, db2, ws, ws + (long)B * C * H * T, B, C, H, T,
                                  dilation, st);
+        if (rc == TT_SMALL_BWD_DID_DW1) return 0;           // fused narrow backward: nothing left to do
         if (rc) return rc;
         switch (C * 10 + dilation) {
             case 41: return rb_wgrad_only<4, 1>(x, dw1, ws, B, H, T, st);

@@ -378,6 +378,308 @@ __global__ __launch_bounds__(256) void k_small_bwd_a(const float* __restrict__ x
     }
 }
 
+// ---- fused backward of one narrow residual block ---------------------------------------------------------------------
+// One pass instead of three (pointwise chain -> dA1 in HBM -> data gradient -> weight gradient):
+//   stage   h1 and dy tiles WITH halo (rows h0 - D .. h0 + TR + D - 1, columns t0 - 4 .. t0 + 67) and the x tile with a row
+//           halo (columns t0 .. t0 + 63) by LDS-DMA; out-of-image pieces come from a zero source;
+//   phase 1 every pixel of the halo tile: a2 = W2 h1 + b2, dA2 = dy ELU'(a2), dH1 = W2^T dA2, dA1 = dH1 ELU'(h1), written
+//           IN PLACE over h1 (dy = 0 outside the image makes dA1 = 0 there: the zero padding the two gradients need);
+//           db1, db2, dW2 accumulate in registers over the CENTRE pixels only (every pixel is some tile's centre once);
+//   phase 2 data gradient on the vector ALUs from LDS taps (the forward loop with flipped weights, residual = dy from the
+//           tile centre) and dW1 on the matrix cores with both operands packed as in k_wgrad3_pack (conv_mfma.hip):
+//             A[(kw, co)][(h', t)] = dA1[co][h'][t - (kw-1)D]     (column-shifted rows of the dA1 tile)
+//             B[(h', t)][(kh, ci)] = x[ci][h' + (kh-1)D][t]       (row-shifted rows of the x tile)
+//           accumulated over every tile of the persistent workgroup, one partial image per workgroup at the end
+//           (summed by k_wgrad3_pack_reduce).
+// HBM traffic per block: h1, dy, x read once (+ halo, mostly L2 hits under the XCD-ordered tile walk), dx written once:
+// 4 tensors instead of 8 (3 + 3 + 2) for the three-kernel path.
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+
+template <int C, int D, int RPT>
+struct SF {
+    static constexpr int TR = 8 * RPT, XR = TR + 2 * D;
+    static constexpr int PLANE = XR * 72 + 4;                 // h1 / dy tile plane pitch: 4 mod 32 (A-fragment reads spread over banks)
+    static constexpr int NQH = C * PLANE / 4, NPH = (NQH + 63) / 64, HBUF = NPH * 256;
+    static constexpr int QPLANE = XR * 64 + 4;                // x tile (row halo only)
+    static constexpr int NQX = C * QPLANE / 4, NPX = (NQX + 63) / 64, XBUF = NPX * 256;
+    static constexpr int M = 3 * C, MT = (M + 15) / 16, NC = MT * 16, IMG = MT * 16 * NC;
+    static constexpr int TILE_FLOATS = 2 * HBUF + XBUF;
+    static constexpr int LDS_FLOATS = TILE_FLOATS + SW<C>::FLOATS;
+    static constexpr int LDS_BYTES = LDS_FLOATS * 4;
+    static_assert(IMG + C * C + 2 * C <= TILE_FLOATS, "final reduction reuses the tile area");
+};
+
+template <int C, int D, int RPT>
+__global__ __launch_bounds__(512, (C <= 4 ? 4 : 2)) void k_small_bwd_fused(const float* __restrict__ x, const float* __restrict__ h1in,
+                                                         const float* __restrict__ dy, const float* __restrict__ w1,
+                                                         const float* __restrict__ w2, const float* __restrict__ b2,
+                                                         float* __restrict__ dx, float* __restrict__ db1, float* __restrict__ dw2,
+                                                         float* __restrict__ db2, float* __restrict__ scratch, int B, int H, int T) {
+    using S = SW<C>;
+    using L = SF<C, D, RPT>;
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+    float* hs = lds_dyn;                       // h1 tile, then dA1 in place
+    float* ds = lds_dyn + L::HBUF;             // dy tile
+    float* xs = lds_dyn + 2 * L::HBUF;         // x tile
+    float* wimg = lds_dyn + L::TILE_FLOATS;    // W1 flipped [co][tap][ci], W2 [c][co2], W2T [co2][c], (b1 unused), b2
+    build_images<C>(wimg, w1, nullptr, w2, b2, true);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4, l15 = lane & 15;
+    const int tiles_h = (H + L::TR - 1) / L::TR, tiles_t = (T + 63) / 64;
+    const int ntiles = B * tiles_h * tiles_t;
+    const long plane = (long)H * T;
+    const float* zero = reinterpret_cast<const float*>(&g_zero16_small);
+
+    // operand offsets of the packed weight gradient: A rows m = kw*C + co (dA1 tile), B columns n = kh*C + ci (x tile)
+    int aoff[L::MT], boff[L::MT];
+    bool aok[L::MT];
+#pragma unroll
+    for (int mt = 0; mt < L::MT; ++mt) {
+        const int m = mt * 16 + l15;
+        aok[mt] = m < L::M;
+        const int kw = aok[mt] ? m / C : 0, co = aok[mt] ? m - kw * C : 0;
+        aoff[mt] = co * L::PLANE + (D + wave) * 72 + 4 - (kw - 1) * D + g;          // + 8 rr * 72 + 4 sk
+        const int n = aok[mt] ? m : L::M - 1;
+        const int kh = n / C, ci = n - kh * C;
+        boff[mt] = ci * L::QPLANE + (wave + kh * D) * 64 + g;                       // + 8 rr * 64 + 4 sk
+    }
+    f32x4s wacc[L::MT][L::MT];
+#pragma unroll
+    for (int a = 0; a < L::MT; ++a)
+#pragma unroll
+        for (int b = 0; b < L::MT; ++b) wacc[a][b] = f32x4s{0.f, 0.f, 0.f, 0.f};
+    float aw2[C][C], ab1[C], ab2[C];
+#pragma unroll
+    for (int a = 0; a < C; ++a) {
+        ab1[a] = 0.f; ab2[a] = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) aw2[a][c] = 0.f;
+    }
+
+    auto stage = [&](int v) {
+        int tt = xcd_tile_s(v, ntiles);
+        const int tx = tt % tiles_t; tt /= tiles_t;
+        const int ty = tt % tiles_h;
+        const int b = tt / tiles_h, row0 = ty * L::TR - D, t0 = tx * 64;
+        const long cb = (long)b * C * plane;
+        constexpr int PQ = L::PLANE / 4;
+#pragma unroll
+        for (int jj = 0; jj < (L::NPH + 7) / 8; ++jj) {
+            const int j = wave + 8 * jj;
+            if (j < L::NPH) {
+                const int q = j * 64 + lane;
+                const int ci = q / PQ;
+                const int rem = q - ci * PQ;
+                const int r = rem / 18, c4 = rem - r * 18;
+                const int h = row0 + r, t = t0 - 4 + 4 * c4;
+                const bool ok = q < L::NQH && r < L::XR && h >= 0 && h < H && t >= 0 && t < T;
+                const long o = cb + (ci * (int)plane + h * T + t);
+                glds16s(ok ? h1in + o : zero, hs + j * 256);
+                glds16s(ok ? dy + o : zero, ds + j * 256);
+            }
+        }
+        constexpr int XQ = L::QPLANE / 4;
+#pragma unroll
+        for (int jj = 0; jj < (L::NPX + 7) / 8; ++jj) {
+            const int j = wave + 8 * jj;
+            if (j < L::NPX) {
+                const int q = j * 64 + lane;
+                const int ci = q / XQ;
+                const int rem = q - ci * XQ;
+                const int r = rem >> 4, c4 = rem & 15;
+                const int h = row0 + r, t = t0 + 4 * c4;
+                const bool ok = q < L::NQX && r < L::XR && h >= 0 && h < H && t < T;
+                glds16s(ok ? x + cb + (ci * (int)plane + h * T + t) : zero, xs + j * 256);
+            }
+        }
+    };
+
+#pragma unroll 1
+    for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
+        __syncthreads();                                   // everyone is done with the previous tile (and the weight images exist)
+        stage(v);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // ---- phase 1: pointwise chain over the halo tile, dA1 in place of h1 ----
+#pragma unroll 1
+        for (int i = threadIdx.x; i < L::XR * 72; i += 512) {
+            const int r = i / 72, c = i - r * 72;
+            const float centre = (r >= D && r < D + L::TR && c >= 4 && c < 68) ? 1.f : 0.f;
+            float h1[C], a2[C];
+#pragma unroll
+            for (int k = 0; k < C; ++k) { h1[k] = hs[k * L::PLANE + i]; a2[k] = wimg[S::B2 + k]; }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < C; ++k) {
+                const float* wl = wimg + S::W2 + k * C;
+#pragma unroll
+                for (int co = 0; co < C; ++co) a2[co] = fmaf(h1[k], wl[co], a2[co]);
+            }
+            asm volatile("" ::: "memory");
+            float d1[C];
+#pragma unroll
+            for (int k = 0; k < C; ++k) d1[k] = 0.f;
+#pragma unroll
+            for (int co = 0; co < C; ++co) {
+                const float gd = ds[co * L::PLANE + i] * elu_grad_from_out(elu1(a2[co]));     // dA2
+                const float gc = gd * centre;
+                ab2[co] += gc;
+                const float* wl = wimg + S::W2T + co * C;
+#pragma unroll
+                for (int k = 0; k < C; ++k) {
+                    d1[k] = fmaf(gd, wl[k], d1[k]);
+                    aw2[co][k] = fmaf(gc, h1[k], aw2[co][k]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < C; ++k) {
+                const float gd = d1[k] * elu_grad_from_out(h1[k]);
+                ab1[k] = fmaf(gd, centre, ab1[k]);
+                hs[k * L::PLANE + i] = gd;
+            }
+        }
+        __syncthreads();
+        // ---- phase 2a: dW1 on the matrix cores (k = 4 sk + g within the wave's rows) ----
+#pragma unroll
+        for (int rr = 0; rr < RPT; ++rr) {
+            float av[L::MT][16];
+#pragma unroll
+            for (int mt = 0; mt < L::MT; ++mt)
+#pragma unroll
+                for (int sk = 0; sk < 16; ++sk) av[mt][sk] = aok[mt] ? hs[aoff[mt] + rr * 8 * 72 + 4 * sk] : 0.f;
+#pragma unroll
+            for (int sk = 0; sk < 16; ++sk) {
+#pragma unroll
+                for (int nt = 0; nt < L::MT; ++nt) {
+                    const float bv = xs[boff[nt] + rr * 8 * 64 + 4 * sk];
+#pragma unroll
+                    for (int mt = 0; mt < L::MT; ++mt)
+                        wacc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][sk], bv, wacc[mt][nt], 0, 0, 0);
+                }
+            }
+        }
+        // ---- phase 2b: dx = dy + W1^T (*) dA1 from LDS taps ----
+        {
+            int tt = xcd_tile_s(v, ntiles);
+            const int tx = tt % tiles_t; tt /= tiles_t;
+            const int ty = tt % tiles_h;
+            const int b = tt / tiles_h, h0 = ty * L::TR + wave, t = tx * 64 + lane;
+            const float* xt = hs + wave * 72 + (4 - D) + lane;          // tap (kh, kw) of row rr: + (8 rr + kh D) 72 + kw D
+            float acc[RPT][C];
+#pragma unroll
+            for (int r = 0; r < RPT; ++r)
+#pragma unroll
+                for (int k = 0; k < C; ++k) acc[r][k] = ds[k * L::PLANE + (D + wave + 8 * r) * 72 + 4 + lane];
+#pragma unroll 1
+            for (int co = 0; co < C; ++co) {
+                const float* xc = xt + co * L::PLANE;
+                const float* wc = wimg + S::W1 + co * 9 * C;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const float* wl = wc + (kh * 3 + kw) * C;
+                        float w[C];
+#pragma unroll
+                        for (int k = 0; k < C; ++k) w[k] = wl[k];
+#pragma unroll
+                        for (int r = 0; r < RPT; ++r) {
+                            const float xv = xc[(8 * r + kh * D) * 72 + kw * D];
+#pragma unroll
+                            for (int k = 0; k < C; ++k) acc[r][k] = fmaf(xv, w[k], acc[r][k]);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                const int h = h0 + 8 * r;
+                if (h < H && t < T) {
+                    const long o = (long)b * C * plane + (long)h * T + t;
+#pragma unroll
+                    for (int k = 0; k < C; ++k) dx[o + k * plane] = acc[r][k];
+                }
+            }
+        }
+    }
+    // ---- reductions: dW1 partial image per workgroup; db1, db2, dW2 -> LDS -> one global atomic per element ----
+    __syncthreads();
+    float* red = lds_dyn;                                  // [IMG] image, then [C*C] dW2, [C] db1, [C] db2
+    for (int i = threadIdx.x; i < L::IMG + C * C + 2 * C; i += 512) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < L::MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < L::MT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(&red[(mt * 16 + 4 * g + r) * L::NC + nt * 16 + l15], wacc[mt][nt][r]);
+#pragma unroll
+    for (int a = 0; a < C; ++a) {
+        const float s1 = wave_sum(ab1[a]), s2 = wave_sum(ab2[a]);
+        if (lane == 0) { atomicAdd(&red[L::IMG + C * C + a], s1); atomicAdd(&red[L::IMG + C * C + C + a], s2); }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float s = wave_sum(aw2[a][c]);
+            if (lane == 0) atomicAdd(&red[L::IMG + a * C + c], s);
+        }
+    }
+    __syncthreads();
+    float* part = scratch + (long)blockIdx.x * L::IMG;
+    for (int i = threadIdx.x; i < L::IMG; i += 512) part[i] = red[i];
+    if (threadIdx.x < C * C) atomicAdd(dw2 + threadIdx.x, red[L::IMG + threadIdx.x]);
+    if (threadIdx.x < C) {
+        atomicAdd(db1 + threadIdx.x, red[L::IMG + C * C + threadIdx.x]);
+        atomicAdd(db2 + threadIdx.x, red[L::IMG + C * C + C + threadIdx.x]);
+    }
+}
+
+// dw[co][ci][kh][kw] += sum over workgroups of partial[(kw*C + co)][(kh*C + ci)]   (the layout of k_wgrad3_pack's images)
+template <int C>
+__global__ __launch_bounds__(256) void k_small_wgrad_reduce(const float* __restrict__ scratch, float* __restrict__ dw, int nblk) {
+    constexpr int M = 3 * C, MT = (M + 15) / 16, NC = MT * 16, IMG = MT * 16 * NC;
+    __shared__ float red[8][33];
+    const int e = threadIdx.x & 31, pg = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + e;                     // element of the C*C*9 gradient
+    const bool ok = i < C * C * 9;
+    float s0 = 0.f;
+    if (ok) {
+        const int kw = i % 3, kh = (i / 3) % 3, ci = (i / 9) % C, co = i / (9 * C);
+        const float* p = scratch + (kw * C + co) * NC + kh * C + ci;
+        for (int k = pg; k < nblk; k += 8) s0 += p[(long)k * IMG];
+    }
+    red[pg][e] = s0;
+    __syncthreads();
+    if (pg == 0 && ok)
+        dw[i] += ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])) + ((red[4][e] + red[5][e]) + (red[6][e] + red[7][e]));
+}
+
+inline bool fused_bwd_variant() { return getenv("TTRAP_SMALL_UNFUSED_BWD") == nullptr; }   // read per call: tests A/B the two paths in one process
+
+template <int C, int D>
+int launch_small_bwd_fused(const float* x, const float* h1, const float* dy, const float* w1, const float* w2, const float* b2,
+                           float* dx, float* dw1, float* db1, float* dw2, float* db2, float* scratch, int B, int H, int T,
+                           hipStream_t st) {
+    constexpr int RPT = 2;
+    using L = SF<C, D, RPT>;
+    static AttrOnce attr;
+    if (const int adev_ = attr.pending(); adev_ >= 0) {
+        TT_HIP(hipFuncSetAttribute((const void*)k_small_bwd_fused<C, D, RPT>, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES));
+        attr.mark(adev_);
+    }
+    const int ntiles = B * ((H + L::TR - 1) / L::TR) * ((T + 63) / 64);
+    int per_cu = (160 * 1024) / L::LDS_BYTES;
+    if (per_cu > 2) per_cu = 2;
+    if (per_cu < 1) per_cu = 1;
+    int grid = ntiles < tt_cus() * per_cu ? ntiles : tt_cus() * per_cu;
+    if (grid > 512) grid = 512;                            // partial images in the caller's scratch (tt_wgrad_scratch_floats)
+    hipLaunchKernelGGL((k_small_bwd_fused<C, D, RPT>), dim3(grid), dim3(512), L::LDS_BYTES, st, x, h1, dy, w1, w2, b2, dx, db1, dw2,
+                       db2, scratch, B, H, T);
+    TT_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_small_wgrad_reduce<C>), dim3((C * C * 9 + 31) / 32), dim3(256), 0, st, (const float*)scratch, dw1, grid);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
 // the LDS-tiled kernels need LDS-DMA-able rows (T % 4 == 0, 16-byte aligned input); TTRAP_SMALL_GLOBAL=1 forces the
 // thread-per-pixel kernels with global taps (kept for unaligned shapes and for A/B measurements)
 inline bool lds_variant() { static const bool v = getenv("TTRAP_SMALL_GLOBAL") == nullptr; return v; }
@@ -415,7 +717,11 @@ template <int C, int D>
 int bwd_t(const float* x, const float* h1, const float* dy, const float* w1, const float* b1, const float* w2, const float* b2,
           float* dx, float* dw1, float* db1, float* dw2, float* db2, float* ws, float* scratch, int B, int H, int T,
           hipStream_t st) {
-    (void)dw1; (void)scratch;
+    const auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (h1 && fused_bwd_variant() && lds_variant() && T % 4 == 0 && al16(x) && al16(h1) && al16(dy)) {
+        const int rc = launch_small_bwd_fused<C, D>(x, h1, dy, w1, w2, b2, dx, dw1, db1, dw2, db2, scratch, B, H, T, st);
+        return rc ? rc : TT_SMALL_BWD_DID_DW1;
+    }
     const int ntiles = B * ((H + 3) / 4) * ((T + 63) / 64);
     const int pgrid = ntiles < 8 * tt_cus() ? ntiles : 8 * tt_cus();
     if (h1)

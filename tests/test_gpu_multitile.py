@@ -223,3 +223,44 @@ def test_capped_grid_equals_full_grid_bitwise_forward(cu_limit):
         for cus in (1, 2, 5):
             cu_limit(cus)
             assert torch.equal(ops.residual_block(x, w1, b1, w2, b2, 2), full), (C, cus)
+
+
+@pytest.mark.parametrize('C', [4, 8])
+@pytest.mark.parametrize('d', [1, 2, 3])
+@pytest.mark.parametrize('cus', [2, 256])
+def test_fused_narrow_backward_matches_three_kernel_path(C, d, cus, monkeypatch, cu_limit):
+    """
+    The one-pass narrow-level backward (pointwise chain + data gradient + packed MFMA weight gradient, csrc/conv_small.hip
+    k_small_bwd_fused; default at C = 4, opt-in at C = 8) against the three-kernel path and the float64 oracle, with several
+    tiles per workgroup (ragged edges, ntiles % 8 != 0).
+    """
+    from timbre_trap.framework import ops
+    monkeypatch.setattr(ops, 'SAVE_HIDDEN', True)
+    cu_limit(cus)
+    B, H, T = 3, 45, 200
+    x = _rand(B, C, H, T, seed=1)
+    w1 = _rand(C, C, 3, 3, seed=2, scale=1.0 / (3 * C ** 0.5))
+    b1 = _rand(C, seed=3, scale=0.3)
+    w2 = _rand(C, C, 1, 1, seed=4, scale=1.0 / C ** 0.5)
+    b2 = _rand(C, seed=5, scale=0.3)
+    gy = _rand(B, C, H, T, seed=6)
+    ref_in = [t.double().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    sd = {'p.conv1.0.weight': ref_in[1], 'p.conv1.0.bias': ref_in[2], 'p.conv2.0.weight': ref_in[3], 'p.conv2.0.bias': ref_in[4]}
+    oae.residual_block(ref_in[0], sd, 'p', d).backward(gy.double())
+    grads = {}
+    for mode in ('fused', 'three_kernel'):
+        monkeypatch.delenv('TTRAP_SMALL_UNFUSED_BWD', raising=False)
+        monkeypatch.delenv('TTRAP_SMALL_FUSED_BWD_C8', raising=False)
+        if mode == 'fused':
+            monkeypatch.setenv('TTRAP_SMALL_FUSED_BWD_C8', '1')
+        else:
+            monkeypatch.setenv('TTRAP_SMALL_UNFUSED_BWD', '1')
+        dev = [t.cuda().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+        ops.residual_block(*dev, d).backward(gy.cuda())
+        grads[mode] = [t.grad.clone() for t in dev]
+        for got, want, name in zip(dev, ref_in, ('dx', 'dw1', 'db1', 'dw2', 'db2')):
+            assert _rel(got.grad, want.grad) < 1e-4, (mode, name)
+    for a, b, name in zip(grads['fused'], grads['three_kernel'], ('dx', 'dw1', 'db1', 'dw2', 'db2')):
+        assert _rel(a, b) < 2e-5, name
+    # the two paths really are different code (the summation orders differ): at least one gradient is not bit-identical
+    assert any(not torch.equal(a, b) for a, b in zip(grads['fused'], grads['three_kernel']))

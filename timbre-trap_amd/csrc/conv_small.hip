@@ -395,32 +395,32 @@ __global__ __launch_bounds__(256) void k_small_bwd_a(const float* __restrict__ x
 // 4 tensors instead of 8 (3 + 3 + 2) for the three-kernel path.
 typedef float f32x4s __attribute__((ext_vector_type(4)));
 
-template <int C, int D, int RPT>
+template <int C, int D, int RPT, int NW, int NBUF>
 struct SF {
-    static constexpr int TR = 8 * RPT, XR = TR + 2 * D;
+    static constexpr int TR = NW * RPT, XR = TR + 2 * D, NT = 64 * NW;
     static constexpr int PLANE = XR * 72 + 4;                 // h1 / dy tile plane pitch: 4 mod 32 (A-fragment reads spread over banks)
     static constexpr int NQH = C * PLANE / 4, NPH = (NQH + 63) / 64, HBUF = NPH * 256;
     static constexpr int QPLANE = XR * 64 + 4;                // x tile (row halo only)
     static constexpr int NQX = C * QPLANE / 4, NPX = (NQX + 63) / 64, XBUF = NPX * 256;
     static constexpr int M = 3 * C, MT = (M + 15) / 16, NC = MT * 16, IMG = MT * 16 * NC;
-    static constexpr int TILE_FLOATS = 2 * HBUF + XBUF;
+    static constexpr int SET = 2 * HBUF + XBUF;                // one staging set: h1, dy, x
+    static constexpr int TILE_FLOATS = NBUF * SET;
     static constexpr int LDS_FLOATS = TILE_FLOATS + SW<C>::FLOATS;
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
     static_assert(IMG + C * C + 2 * C <= TILE_FLOATS, "final reduction reuses the tile area");
 };
 
-template <int C, int D, int RPT>
-__global__ __launch_bounds__(512, (C <= 4 ? 4 : 2)) void k_small_bwd_fused(const float* __restrict__ x, const float* __restrict__ h1in,
+template <int C, int D, int RPT, int NW, int NBUF>
+__global__ __launch_bounds__(64 * NW, (C <= 4 ? 4 : 2)) void k_small_bwd_fused(const float* __restrict__ x, const float* __restrict__ h1in,
                                                          const float* __restrict__ dy, const float* __restrict__ w1,
                                                          const float* __restrict__ w2, const float* __restrict__ b2,
                                                          float* __restrict__ dx, float* __restrict__ db1, float* __restrict__ dw2,
-                                                         float* __restrict__ db2, float* __restrict__ scratch, int B, int H, int T) {
+                                                         float* __restrict__ db2, float* __restrict__ scratch, int B, int H, int T,
+                                                         int ablate) {
     using S = SW<C>;
-    using L = SF<C, D, RPT>;
+    using L = SF<C, D, RPT, NW, NBUF>;
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
-    float* hs = lds_dyn;                       // h1 tile, then dA1 in place
-    float* ds = lds_dyn + L::HBUF;             // dy tile
-    float* xs = lds_dyn + 2 * L::HBUF;         // x tile
+    // staging set `buf`: h1 tile (then dA1 in place) | dy tile | x tile
     float* wimg = lds_dyn + L::TILE_FLOATS;    // W1 flipped [co][tap][ci], W2 [c][co2], W2T [co2][c], (b1 unused), b2
     build_images<C>(wimg, w1, nullptr, w2, b2, true);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4, l15 = lane & 15;
@@ -437,10 +437,10 @@ __global__ __launch_bounds__(512, (C <= 4 ? 4 : 2)) void k_small_bwd_fused(const
         const int m = mt * 16 + l15;
         aok[mt] = m < L::M;
         const int kw = aok[mt] ? m / C : 0, co = aok[mt] ? m - kw * C : 0;
-        aoff[mt] = co * L::PLANE + (D + wave) * 72 + 4 - (kw - 1) * D + g;          // + 8 rr * 72 + 4 sk
+        aoff[mt] = co * L::PLANE + (D + wave) * 72 + 4 - (kw - 1) * D + g;          // + NW rr * 72 + 4 sk
         const int n = aok[mt] ? m : L::M - 1;
         const int kh = n / C, ci = n - kh * C;
-        boff[mt] = ci * L::QPLANE + (wave + kh * D) * 64 + g;                       // + 8 rr * 64 + 4 sk
+        boff[mt] = ci * L::QPLANE + (wave + kh * D) * 64 + g;                       // + NW rr * 64 + 4 sk
     }
     f32x4s wacc[L::MT][L::MT];
 #pragma unroll
@@ -455,7 +455,10 @@ __global__ __launch_bounds__(512, (C <= 4 ? 4 : 2)) void k_small_bwd_fused(const
         for (int c = 0; c < C; ++c) aw2[a][c] = 0.f;
     }
 
-    auto stage = [&](int v) {
+    auto stage = [&](int v, int buf) {
+        float* hs = lds_dyn + buf * L::SET;
+        float* ds = hs + L::HBUF;
+        float* xs = hs + 2 * L::HBUF;
         int tt = xcd_tile_s(v, ntiles);
         const int tx = tt % tiles_t; tt /= tiles_t;
         const int ty = tt % tiles_h;
@@ -463,8 +466,8 @@ __global__ __launch_bounds__(512, (C <= 4 ? 4 : 2)) void k_small_bwd_fused(const
         const long cb = (long)b * C * plane;
         constexpr int PQ = L::PLANE / 4;
 #pragma unroll
-        for (int jj = 0; jj < (L::NPH + 7) / 8; ++jj) {
-            const int j = wave + 8 * jj;
+        for (int jj = 0; jj < (L::NPH + NW - 1) / NW; ++jj) {
+            const int j = wave + NW * jj;
             if (j < L::NPH) {
                 const int q = j * 64 + lane;
                 const int ci = q / PQ;
@@ -479,8 +482,8 @@ __global__ __launch_bounds__(512, (C <= 4 ? 4 : 2)) void k_small_bwd_fused(const
         }
         constexpr int XQ = L::QPLANE / 4;
 #pragma unroll
-        for (int jj = 0; jj < (L::NPX + 7) / 8; ++jj) {
-            const int j = wave + 8 * jj;
+        for (int jj = 0; jj < (L::NPX + NW - 1) / NW; ++jj) {
+            const int j = wave + NW * jj;
             if (j < L::NPX) {
                 const int q = j * 64 + lane;
                 const int ci = q / XQ;
@@ -493,15 +496,23 @@ __global__ __launch_bounds__(512, (C <= 4 ? 4 : 2)) void k_small_bwd_fused(const
         }
     };
 
+    int buf = 0;
+    if (NBUF == 2 && (int)blockIdx.x < ntiles) stage(blockIdx.x, 0);
 #pragma unroll 1
     for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
-        __syncthreads();                                   // everyone is done with the previous tile (and the weight images exist)
-        stage(v);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (NBUF == 1) {
+            __syncthreads();                               // everyone is done with the previous tile (and the weight images exist)
+            if (!(ablate & 8) || v == (int)blockIdx.x) stage(v, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile has landed ...
+        __syncthreads();                                   // ... for every wave, and everyone is done with the other set
+        if (NBUF == 2 && v + (int)gridDim.x < ntiles && !(ablate & 8)) stage(v + (int)gridDim.x, buf ^ 1);
+        float* hs = lds_dyn + buf * L::SET;
+        float* ds = hs + L::HBUF;
+        float* xs = hs + 2 * L::HBUF;
         // ---- phase 1: pointwise chain over the halo tile, dA1 in place of h1 ----
 #pragma unroll 1
-        for (int i = threadIdx.x; i < L::XR * 72; i += 512) {
+        for (int i = threadIdx.x; i < ((ablate & 1) ? 0 : L::XR * 72); i += L::NT) {
             const int r = i / 72, c = i - r * 72;
             const float centre = (r >= D && r < D + L::TR && c >= 4 && c < 68) ? 1.f : 0.f;
             float h1[C], a2[C];
@@ -538,39 +549,42 @@ __global__ __launch_bounds__(512, (C <= 4 ? 4 : 2)) void k_small_bwd_fused(const
             }
         }
         __syncthreads();
-        // ---- phase 2a: dW1 on the matrix cores (k = 4 sk + g within the wave's rows) ----
+        // ---- phase 2: dW1 on the matrix cores (k = 4 sk + g within the wave's rows), then the data gradient on the vector ALUs ----
+        auto wgrad_steps = [&](int sk0, int nsk) {
 #pragma unroll
-        for (int rr = 0; rr < RPT; ++rr) {
-            float av[L::MT][16];
+            for (int rr = 0; rr < RPT; ++rr)
 #pragma unroll
-            for (int mt = 0; mt < L::MT; ++mt)
+                for (int s_ = 0; s_ < nsk; ++s_) {
+                    const int sk = sk0 + s_;
+                    float av[L::MT], bv[L::MT];
 #pragma unroll
-                for (int sk = 0; sk < 16; ++sk) av[mt][sk] = aok[mt] ? hs[aoff[mt] + rr * 8 * 72 + 4 * sk] : 0.f;
+                    for (int mt = 0; mt < L::MT; ++mt) {
+                        av[mt] = aok[mt] ? hs[aoff[mt] + rr * NW * 72 + 4 * sk] : 0.f;
+                        bv[mt] = xs[boff[mt] + rr * NW * 64 + 4 * sk];
+                    }
 #pragma unroll
-            for (int sk = 0; sk < 16; ++sk) {
+                    for (int nt = 0; nt < L::MT; ++nt)
 #pragma unroll
-                for (int nt = 0; nt < L::MT; ++nt) {
-                    const float bv = xs[boff[nt] + rr * 8 * 64 + 4 * sk];
-#pragma unroll
-                    for (int mt = 0; mt < L::MT; ++mt)
-                        wacc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][sk], bv, wacc[mt][nt], 0, 0, 0);
+                        for (int mt = 0; mt < L::MT; ++mt)
+                            wacc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[nt], wacc[mt][nt], 0, 0, 0);
                 }
-            }
-        }
-        // ---- phase 2b: dx = dy + W1^T (*) dA1 from LDS taps ----
+        };
         {
             int tt = xcd_tile_s(v, ntiles);
             const int tx = tt % tiles_t; tt /= tiles_t;
             const int ty = tt % tiles_h;
             const int b = tt / tiles_h, h0 = ty * L::TR + wave, t = tx * 64 + lane;
-            const float* xt = hs + wave * 72 + (4 - D) + lane;          // tap (kh, kw) of row rr: + (8 rr + kh D) 72 + kw D
+            const float* xt = hs + wave * 72 + (4 - D) + lane;          // tap (kh, kw) of row rr: + (NW rr + kh D) 72 + kw D
             float acc[RPT][C];
 #pragma unroll
             for (int r = 0; r < RPT; ++r)
 #pragma unroll
-                for (int k = 0; k < C; ++k) acc[r][k] = ds[k * L::PLANE + (D + wave + 8 * r) * 72 + 4 + lane];
+                for (int k = 0; k < C; ++k) acc[r][k] = ds[k * L::PLANE + (D + wave + NW * r) * 72 + 4 + lane];
+            // (issuing the k-steps inside the tap loop below, to run the matrix pipe in the shadow of the FMA stream, measured
+            //  4 % SLOWER at C = 8 and is not used)
+            if (!(ablate & 2)) wgrad_steps(0, 16);
 #pragma unroll 1
-            for (int co = 0; co < C; ++co) {
+            for (int co = 0; co < ((ablate & 4) ? 0 : C); ++co) {
                 const float* xc = xt + co * L::PLANE;
                 const float* wc = wimg + S::W1 + co * 9 * C;
 #pragma unroll
@@ -584,7 +598,7 @@ __global__ __launch_bounds__(512, (C <= 4 ? 4 : 2)) void k_small_bwd_fused(const
                         for (int k = 0; k < C; ++k) w[k] = wl[k];
 #pragma unroll
                         for (int r = 0; r < RPT; ++r) {
-                            const float xv = xc[(8 * r + kh * D) * 72 + kw * D];
+                            const float xv = xc[(NW * r + kh * D) * 72 + kw * D];
 #pragma unroll
                             for (int k = 0; k < C; ++k) acc[r][k] = fmaf(xv, w[k], acc[r][k]);
                         }
@@ -593,7 +607,7 @@ __global__ __launch_bounds__(512, (C <= 4 ? 4 : 2)) void k_small_bwd_fused(const
             }
 #pragma unroll
             for (int r = 0; r < RPT; ++r) {
-                const int h = h0 + 8 * r;
+                const int h = h0 + NW * r;
                 if (h < H && t < T) {
                     const long o = (long)b * C * plane + (long)h * T + t;
 #pragma unroll
@@ -601,11 +615,12 @@ __global__ __launch_bounds__(512, (C <= 4 ? 4 : 2)) void k_small_bwd_fused(const
                 }
             }
         }
+        if (NBUF == 2) buf ^= 1;
     }
     // ---- reductions: dW1 partial image per workgroup; db1, db2, dW2 -> LDS -> one global atomic per element ----
     __syncthreads();
     float* red = lds_dyn;                                  // [IMG] image, then [C*C] dW2, [C] db1, [C] db2
-    for (int i = threadIdx.x; i < L::IMG + C * C + 2 * C; i += 512) red[i] = 0.f;
+    for (int i = threadIdx.x; i < L::IMG + C * C + 2 * C; i += L::NT) red[i] = 0.f;
     __syncthreads();
 #pragma unroll
     for (int mt = 0; mt < L::MT; ++mt)
@@ -625,7 +640,7 @@ __global__ __launch_bounds__(512, (C <= 4 ? 4 : 2)) void k_small_bwd_fused(const
     }
     __syncthreads();
     float* part = scratch + (long)blockIdx.x * L::IMG;
-    for (int i = threadIdx.x; i < L::IMG; i += 512) part[i] = red[i];
+    for (int i = threadIdx.x; i < L::IMG; i += L::NT) part[i] = red[i];
     if (threadIdx.x < C * C) atomicAdd(dw2 + threadIdx.x, red[L::IMG + threadIdx.x]);
     if (threadIdx.x < C) {
         atomicAdd(db1 + threadIdx.x, red[L::IMG + C * C + threadIdx.x]);
@@ -659,11 +674,15 @@ template <int C, int D>
 int launch_small_bwd_fused(const float* x, const float* h1, const float* dy, const float* w1, const float* w2, const float* b2,
                            float* dx, float* dw1, float* db1, float* dw2, float* db2, float* scratch, int B, int H, int T,
                            hipStream_t st) {
-    constexpr int RPT = 2;
-    using L = SF<C, D, RPT>;
+    // eight waves, two rows each, one staging set: two workgroups per CU at C = 4 (75 KB each), one at C = 8 (150 KB).
+    // Measured alternative at C = 4: sixteen waves with both staging sets resident (next tile's DMA under this tile's
+    // arithmetic) -- 0.94 ms against 0.89 ms per launch at the bench shape, so the kernel is not waiting on the DMA.
+    constexpr int NW = 8, RPT = 2, NBUF = 1;
+    using L = SF<C, D, RPT, NW, NBUF>;
+    static_assert(L::LDS_BYTES <= 160 * 1024, "staging sets exceed the LDS");
     static AttrOnce attr;
     if (const int adev_ = attr.pending(); adev_ >= 0) {
-        TT_HIP(hipFuncSetAttribute((const void*)k_small_bwd_fused<C, D, RPT>, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES));
+        TT_HIP(hipFuncSetAttribute((const void*)k_small_bwd_fused<C, D, RPT, NW, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES));
         attr.mark(adev_);
     }
     const int ntiles = B * ((H + L::TR - 1) / L::TR) * ((T + 63) / 64);
@@ -672,8 +691,9 @@ int launch_small_bwd_fused(const float* x, const float* h1, const float* dy, con
     if (per_cu < 1) per_cu = 1;
     int grid = ntiles < tt_cus() * per_cu ? ntiles : tt_cus() * per_cu;
     if (grid > 512) grid = 512;                            // partial images in the caller's scratch (tt_wgrad_scratch_floats)
-    hipLaunchKernelGGL((k_small_bwd_fused<C, D, RPT>), dim3(grid), dim3(512), L::LDS_BYTES, st, x, h1, dy, w1, w2, b2, dx, db1, dw2,
-                       db2, scratch, B, H, T);
+    const char* ab = getenv("TTRAP_FUSED_ABLATE");          // measurement only: bit 0 / 1 / 2 / 3 = skip phase 1 / dW1 / dx / re-staging
+    hipLaunchKernelGGL((k_small_bwd_fused<C, D, RPT, NW, NBUF>), dim3(grid), dim3(L::NT), L::LDS_BYTES, st, x, h1, dy, w1, w2, b2, dx, db1, dw2,
+                       db2, scratch, B, H, T, ab ? atoi(ab) : 0);
     TT_LAUNCH_CHECK();
     hipLaunchKernelGGL((k_small_wgrad_reduce<C>), dim3((C * C * 9 + 31) / 32), dim3(256), 0, st, (const float*)scratch, dw1, grid);
     TT_LAUNCH_CHECK();
@@ -718,7 +738,11 @@ int bwd_t(const float* x, const float* h1, const float* dy, const float* w1, con
           float* dx, float* dw1, float* db1, float* dw2, float* db2, float* ws, float* scratch, int B, int H, int T,
           hipStream_t st) {
     const auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    if (h1 && fused_bwd_variant() && lds_variant() && T % 4 == 0 && al16(x) && al16(h1) && al16(dy)) {
+    // measured at the bench shapes (64 clips): C = 4 fused 0.84-0.89 ms against 1.04-1.11 ms for the three kernels; at C = 8
+    // one staging set fills the LDS (one workgroup of eight waves per CU, nothing to hide the phases behind) and the two
+    // paths tie (1.23-1.34 against 1.23-1.25 ms), so C = 8 stays on the three-kernel path unless TTRAP_SMALL_FUSED_BWD_C8 is set
+    const bool want_fused = C <= 4 ? fused_bwd_variant() : (fused_bwd_variant() && getenv("TTRAP_SMALL_FUSED_BWD_C8") != nullptr);
+    if (h1 && want_fused && lds_variant() && T % 4 == 0 && al16(x) && al16(h1) && al16(dy)) {
         const int rc = launch_small_bwd_fused<C, D>(x, h1, dy, w1, w2, b2, dx, dw1, db1, dw2, db2, scratch, B, H, T, st);
         return rc ? rc : TT_SMALL_BWD_DID_DW1;
     }

@@ -333,7 +333,65 @@ if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'utils':
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'targets':
     make_targets_golden()
 
+
+
+def make_slicing_golden():
+    """f4 row: AudioDataset.slice_audio, PitchDataset.slice_times / resample_multi_pitch of the reference (index arithmetic)."""
+    install_stubs()
+    for name in ('mir_eval', 'jams', 'mido'):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.path.insert(0, '/root/reference')
+    from timbre_trap.datasets import AudioDataset, PitchDataset
+    from timbre_trap.framework import CQT
+    cqt = CQT(n_octaves=9, bins_per_octave=60, sample_rate=22050, secs_per_block=3)
+    out = {}
+
+    class Fake:
+        pass
+
+    def fake(seed, n_secs=3):
+        f = Fake()
+        f.cqt, f.n_secs, f.sample_rate, f.rng, f.resample_idcs = cqt, n_secs, 22050, np.random.RandomState(seed), [0, -1]
+        return f
+    # slice_audio: long track (random and fixed offsets), short track (random and fixed padding), explicit n_samples
+    long_audio = torch.arange(200000, dtype=torch.float32).view(1, -1) / 200000
+    short_audio = torch.arange(30000, dtype=torch.float32).view(1, -1) / 30000
+    cases = [('long_rand', long_audio, None, None, 5), ('long_fixed', long_audio, None, 12345, 5), ('short_rand', short_audio, None, None, 6),
+             ('short_fixed', short_audio, None, -4000, 6), ('explicit_n', long_audio, 50000, None, 7), ('exact', long_audio[:, :66150], None, None, 8)]
+    for tag, audio, n_samples, offset_s, seed in cases:
+        a, off = AudioDataset.slice_audio(fake(seed), audio, n_samples, offset_s)
+        out['sa_%s_first_last_sum' % tag] = np.array([float(a[0, 0]), float(a[0, -1]), float(a.double().sum()), a.size(-1)], dtype=np.float64)
+        out['sa_%s_offset' % tag] = np.array(off, dtype=np.float64)
+    # slice_times
+    t_long = cqt.get_times(5000)
+    t_short = cqt.get_times(700)
+    for tag, times, n_frames, offset_t, seed in [('long_rand', t_long, None, None, 3), ('long_offset', t_long, None, 1.2345, 3),
+                                                 ('short_rand', t_short, None, None, 4), ('short_offset', t_short, None, -0.25, 4),
+                                                 ('explicit', t_long, 333, None, 9)]:
+        ts, off = PitchDataset.slice_times(fake(seed), times, n_frames, offset_t)
+        out['st_%s_times' % tag] = np.asarray(ts, dtype=np.float64)
+        out['st_%s_offset' % tag] = np.array(off, dtype=np.float64)
+    # resample_multi_pitch: irregular source grid, targets with ties, outside the span, and +-inf padding
+    src_t = np.cumsum(np.array([0.0, 0.01, 0.02, 0.005, 0.03, 0.01, 0.0125, 0.02, 0.01, 0.015]))
+    src_mp = [np.array([100.0 + 10 * i, 200.0 + i]) if i % 3 else np.empty(0) for i in range(len(src_t))]
+    tgt = np.concatenate(([-np.inf, -1.0], src_t[:-1] + np.diff(src_t) / 2, src_t, [src_t[3] + 1e-9, 0.5, np.inf]))
+    for tag, idcs in (('default', [0, -1]), ('inner', [1, -2])):
+        f = fake(0)
+        f.resample_idcs = idcs
+        res = PitchDataset.resample_multi_pitch(f, src_t, src_mp, tgt)
+        out['rs_%s_values' % tag] = np.concatenate([np.asarray(r, dtype=np.float64) for r in res])
+        out['rs_%s_counts' % tag] = np.array([len(r) for r in res], dtype=np.int64)
+    out['rs_src_t'], out['rs_tgt'] = src_t, tgt
+    np.savez_compressed(os.path.join(HERE, 'slicing.npz'), **out)
+    print('slicing.npz', os.path.getsize(os.path.join(HERE, 'slicing.npz')))
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'slicing':
+    make_slicing_golden()
+
+
 if __name__ == '__main__' and len(sys.argv) == 1:
     main()
     make_utils_golden()
     make_targets_golden()
+    make_slicing_golden()

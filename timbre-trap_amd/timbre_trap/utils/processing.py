@@ -10,12 +10,21 @@ import torch
 
 from .. import _hip
 
-__all__ = ['to_array', 'filter_non_peaks', 'threshold', 'peaks_above']
+__all__ = ['to_array', 'debug_nans', 'filter_non_peaks', 'threshold', 'peaks_above']
 
 
 def to_array(tensor):
     """Tensor -> ndarray on the host (reference processing.py:17-33)."""
     return tensor.cpu().detach().numpy()
+
+
+def debug_nans(tensor, tag='tensor'):
+    """True (and a warning) when the tensor holds a NaN (reference processing.py:36-63)."""
+    import warnings
+    contains = bool(torch.isnan(tensor).any())
+    if contains:
+        warnings.warn(f'{tag} contains NaNs!!!')
+    return contains
 
 
 def _device_pick(x, thr, mode, f_valid=0):

@@ -27,9 +27,11 @@ class CQT(nn.Module):
     Invertible constant-Q transform (NSGT, one block of ``secs_per_block`` seconds at a time).
     """
 
-    def __init__(self, n_octaves, bins_per_octave, sample_rate, secs_per_block):
+    def __init__(self, n_octaves, bins_per_octave, sample_rate, secs_per_block, conventions=None):
         """
-        Parameters (reference cqtwrapper.py:15-29)
+        Parameters (reference cqtwrapper.py:15-29; ``conventions`` is an addition: an
+        ``nsgt_plan.NSGTConventions`` selecting the window family / rounding / crop alignment / dual-window rule that the
+        reference leaves to ``cqt_pytorch`` -- table-level switches, default documented in INTEGRATION.md)
         ----------
         n_octaves : int
           Number of octaves below Nyquist to span
@@ -42,8 +44,9 @@ class CQT(nn.Module):
         """
         super().__init__()
 
+        self.conventions = nsgt_plan.DEFAULT_CONVENTIONS if conventions is None else conventions
         plan = nsgt_plan.build_plan(n_octaves, bins_per_octave, sample_rate,
-                                    int(secs_per_block * sample_rate), power_of_2_length=True)
+                                    int(secs_per_block * sample_rate), power_of_2_length=True, conventions=self.conventions)
         self.block_length = plan['N']
         self.max_window_length = plan['M']
         self._sum_len = plan['sum_len']

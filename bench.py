@@ -24,6 +24,7 @@ Prints ONE JSON line on rank 0 with the driver's fields plus
                         losses, optimizer) ms per step, achieved TFLOP/s and TB/s on ALGORITHMIC work and the fractions of the
                         fp32 matrix peak and of HBM peak -- measured with HIP events in two extra, untimed, instrumented steps
   "whole_step"        : algorithmic conv FLOPs of the step / ms_per_step against the fp32 and the bf16 matrix peaks
+  "inference_config1" : BASELINE.json configs[1] (transcribe() + reconstruct(), 32 clips) timed in the same run, N = 1
   "cpu_baseline"      : the CPU oracle (kind "port") on a bounded sample of the SAME workload (model_complexity 2; rank 0, N = 1)
   "cpu_baseline_config0" : BASELINE.json configs[0] on the oracle: model_complexity 1, one clip, CQT forward + inverse + one step
 """
@@ -278,8 +279,11 @@ def cpu_baseline(mc, latent, seconds_budget=15.0, config0=False):
                 s_per_step=step_s, legs_s={k: v / n for k, v in legs.items()})
 
 
-def bench_inference(model, args, rank, world, dev):
+def bench_inference(model, args, rank, world, dev, steps=None, warmup=None, emit=True):
     """BASELINE.json configs[1]: model.transcribe(audio) + model.reconstruct(audio), batch x 3 s clips (secondary line)."""
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    was_training = model.training
     model.eval()
     batch = 32 if args.batch == 64 else args.batch
     audio, _ = synthetic_batch(batch, rank, dev)
@@ -289,25 +293,28 @@ def bench_inference(model, args, rank, world, dev):
             act = model.transcribe(audio)
             rec = model.reconstruct(audio)
         return act, rec
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         act, rec = step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    ms = 1000.0 * elapsed / args.steps
-    if rank == 0:
-        print(json.dumps(dict(metric='audio-seconds/s inference throughput, transcribe()+reconstruct() (9oct x 60bpo, 3s@22.05kHz)',
-                              value=world * batch * SECS_PER_CLIP / (elapsed / args.steps), unit='audio-seconds/s', n_gpus=world,
-                              steps=args.steps, warmup=args.warmup, ms_per_step=ms, higher_is_better=True, scaling='weak',
-                              vs_baseline=None, dtype={'fp32': 'f32', 'bf16x3': 'bf16x3', 'bf16': 'bf16'}[args.precision], data='synthetic',
-                              config=dict(workload='transcribe() + reconstruct() (each: 3 half-overlapping chunks per clip through CQT + '
-                                                   'encoder + decoder, Hann cross-fade; reconstruct adds the inverse CQT), model_complexity=%d '
-                                                   'latent=%d, %d clips x 3 s' % (args.mc, args.latent, batch),
-                                          global_batch=world * batch, parallelism='dp%d' % world),
-                              out_shapes=[list(act.shape), list(rec.shape)])))
+    model.train(was_training)
+    ms = 1000.0 * elapsed / steps
+    line = dict(metric='audio-seconds/s inference throughput, transcribe()+reconstruct() (9oct x 60bpo, 3s@22.05kHz)',
+                value=world * batch * SECS_PER_CLIP / (elapsed / steps), unit='audio-seconds/s', n_gpus=world,
+                steps=steps, warmup=warmup, ms_per_step=ms, higher_is_better=True, scaling='weak',
+                vs_baseline=None, dtype={'fp32': 'f32', 'bf16x3': 'bf16x3', 'bf16': 'bf16'}[args.precision], data='synthetic',
+                config=dict(workload='transcribe() + reconstruct() (each: 3 half-overlapping chunks per clip through CQT + '
+                                     'encoder + decoder, Hann cross-fade; reconstruct adds the inverse CQT), model_complexity=%d '
+                                     'latent=%d, %d clips x 3 s' % (args.mc, args.latent, batch),
+                            global_batch=world * batch, parallelism='dp%d' % world),
+                out_shapes=[list(act.shape), list(rec.shape)])
+    if emit and rank == 0:
+        print(json.dumps(line))
+    return line
 
 
 def main():
@@ -461,6 +468,11 @@ def main():
             tf = conv_flops * args.batch / (ms * 1e-3) / 1e12
             whole = dict(algorithmic_conv_flops_per_step=conv_flops * args.batch, achieved_tflops=tf,
                          frac_fp32_matrix_peak=tf / PEAK_FP32_MATRIX_TFLOPS, frac_bf16_mfma_peak=tf / PEAK_BF16_MFMA_TFLOPS)
+        infer = None
+        if world == 1:                                    # BASELINE configs[1], measured in the same run (secondary figure)
+            full = bench_inference(model, args, rank, world, dev, steps=3, warmup=1, emit=False)
+            infer = {k: full[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype')}
+            infer['workload'] = full['config']['workload']
         base = base0 = None
         if not args.no_cpu_baseline and world == 1:
             base = cpu_baseline(args.mc, args.latent)
@@ -472,7 +484,7 @@ def main():
                                          'model_complexity=%d latent=%d, %d clips x 3 s per GPU' % (args.mc, args.latent, args.batch),
                                 global_batch=world * args.batch, parallelism='dp%d' % world),
                     roofline=roof, roofline_cqt=cqt, roofline_cqt_inv=cqt_inv, families=families, whole_step=whole,
-                    per_rank_ms=per_rank_ms, allreduce_ms=allreduce_ms, cpu_baseline=base, cpu_baseline_config0=base0,
+                    inference_config1=infer, per_rank_ms=per_rank_ms, allreduce_ms=allreduce_ms, cpu_baseline=base, cpu_baseline_config0=base0,
                     final_loss=float(total.detach()))
         print(json.dumps(line))
     if world > 1:

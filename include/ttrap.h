@@ -184,6 +184,12 @@ int tt_channel_sum(const float* x, float* out, int B, int C, int64_t inner, void
  * a may be NULL (treated as 0). */
 int tt_scaled_add(const float* a, const float* b, const float* s, int idx, float* y, int64_t n,
                   void* stream);
+/* Windowed overlap-add of the half-overlapping chunks of TimbreTrap.chunked_inference (modules.py:259-263):
+ *   out[row][i * M/2 + m] += window[m] * chunks[i - c0][row][m]   for chunks i = c0 .. c1-1, accumulated in ascending i
+ * chunks (c1-c0, rows, M), window (M), out (rows, n_frames) with rows = B*2*F; M % 8 == 0, n_frames % 4 == 0.  Calls with
+ * consecutive chunk ranges reproduce the reference's sequential accumulation bit for bit. */
+int tt_window_ola(const float* chunks, const float* window, float* out, int64_t rows, int M, int c0, int c1,
+                  int64_t n_frames, void* stream);
 /* out[0] += sum(a * b) : gradient of one skip weight. */
 int tt_dot(const float* a, const float* b, float* out, int64_t n, void* stream);
 

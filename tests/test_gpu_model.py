@@ -403,3 +403,23 @@ def test_fused_adamw_survives_dropped_gradients_and_resumes():
     assert float((run('resume') - base).abs().max()) < 2e-5
     a, b = run('none_then_backward'), run('none_then_backward_ref')
     assert float((a - b).abs().max()) < 2e-5 and float((a - base).abs().max()) > 1e-4
+
+
+def test_window_overlap_add_kernel_is_bit_identical_to_the_sequential_loop():
+    """tt_window_ola (one or several calls over consecutive chunk ranges) == the reference's Python accumulation loop, bitwise."""
+    from timbre_trap import _hip
+    lib = _hip.lib()
+    B, F, Mw, n_chunks = 2, 7, 64, 7
+    g = torch.Generator().manual_seed(0)
+    outs = torch.randn(n_chunks, B, 2, F, Mw, generator=g).cuda()
+    window = torch.signal.windows.hann(Mw, dtype=torch.float32).cuda()
+    n_frames = (n_chunks + 1) * Mw // 2
+    want = torch.zeros(B, 2, F, n_frames, device='cuda')
+    for i in range(n_chunks):                                   # reference modules.py:247-263
+        want[..., i * Mw // 2: i * Mw // 2 + Mw] += window * outs[i]
+    for split in ([(0, n_chunks)], [(0, 3), (3, 4), (4, n_chunks)], [(i, i + 1) for i in range(n_chunks)]):
+        got = torch.zeros_like(want)
+        for c0, c1 in split:
+            part = outs[c0:c1].contiguous()
+            _hip.check(lib.tt_window_ola(_hip.ptr(part), _hip.ptr(window), _hip.ptr(got), B * 2 * F, Mw, c0, c1, n_frames, _hip.stream_ptr()))
+        assert torch.equal(got, want), split

@@ -566,6 +566,47 @@ extern "C" int tt_scaled_add(const float* a, const float* b, const float* s, int
     return 0;
 }
 
+// Windowed overlap-add of half-overlapping chunks (TimbreTrap.chunked_inference, reference modules.py:259-263):
+//   out[b][r][i * M/2 + m] += window[m] * chunks[i - c0][b][r][m]      for the chunks i = c0 .. c1-1 of this call, ascending i
+// One thread per four output frames of a row: it visits the (at most two) chunks of the call that cover those frames in
+// ascending chunk order, which is the reference's sequential accumulation order -- a frame's two contributions meet in the same
+// order whether they arrive in one call or in two consecutive calls, so the sum is bit-identical to the Python loop.
+__global__ __launch_bounds__(256) void k_window_ola(const float* __restrict__ chunks, const float* __restrict__ window,
+                                                    float* __restrict__ out, long rows, int M, int c0, int c1, long n_frames) {
+    const int half = M >> 1;
+    const long p0 = (long)c0 * half, span4 = ((long)(c1 - c0 - 1) * half + M) >> 2;      // frames touched by this call / 4
+    const long total = rows * span4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / span4, q = i - r * span4;
+        const long p = p0 + 4 * q;                               // first of four output frames (M/2 % 4 == 0: same chunks for all four)
+        float4 acc = *reinterpret_cast<const float4*>(out + r * n_frames + p);
+        const int hi = (int)(p / half);                          // chunks hi - 1 and hi cover frame p
+#pragma unroll
+        for (int k = 1; k >= 0; --k) {
+            const int ci = hi - k;
+            if (ci < c0 || ci >= c1) continue;
+            const int m = (int)(p - (long)ci * half);
+            const float4 w = *reinterpret_cast<const float4*>(window + m);
+            const float4 v = *reinterpret_cast<const float4*>(chunks + ((long)(ci - c0) * rows + r) * M + m);
+            // product and sum rounded separately (no FMA contraction): `out += window * chunk` of the reference is two fp32 roundings
+            acc.x = __fadd_rn(acc.x, __fmul_rn(w.x, v.x)); acc.y = __fadd_rn(acc.y, __fmul_rn(w.y, v.y));
+            acc.z = __fadd_rn(acc.z, __fmul_rn(w.z, v.z)); acc.w = __fadd_rn(acc.w, __fmul_rn(w.w, v.w));
+        }
+        *reinterpret_cast<float4*>(out + r * n_frames + p) = acc;
+    }
+}
+
+extern "C" int tt_window_ola(const float* chunks, const float* window, float* out, int64_t rows, int M, int c0, int c1,
+                             int64_t n_frames, void* stream) {
+    if (!chunks || !window || !out || rows <= 0 || M <= 0 || (M & 7) || c1 <= c0 || c0 < 0) return TT_E_BADARG;
+    if ((long)(c1 - 1) * (M / 2) + M > n_frames || (n_frames & 3)) return TT_E_BADARG;
+    const long total = rows * ((((long)(c1 - c0 - 1) * (M / 2)) + M) / 4);
+    hipLaunchKernelGGL(k_window_ola, dim3(grid1d(total, 256, 8 * tt_cus())), dim3(256), 0, tt_stream(stream), chunks, window, out,
+                       (long)rows, M, c0, c1, (long)n_frames);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int tt_dot(const float* a, const float* b, float* out, int64_t n, void* stream) {
     if (!a || !b || !out || n < 0) return TT_E_BADARG;
     if (n == 0) return 0;

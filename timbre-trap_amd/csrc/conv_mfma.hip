@@ -758,8 +758,12 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 // RECOMP = true : hidden activation recomputed from x (3x3 conv main loop);  false : read back from `h1in`
-template <int C, int D, bool DMA, bool RECOMP>
-__global__ __launch_bounds__(NTHREADS) void k_rb_bwd_a(const float* __restrict__ x, const float* __restrict__ h1in,
+// NT = 16-pixel column groups a wave holds at a time (a tile is always 8 rows x 64 columns).  The fragments of h1, dA2, dH1 and
+// the dW2 / bias accumulators are all live together: at C = 32 with NT = 4 that is 256 registers -- ONE workgroup per CU, whose
+// loads, matrix chain and stores then run back to back.  NT = 2 (two passes per tile, 8-byte instead of 16-byte accesses) was
+// written to get under 128 registers and two workgroups per CU; it still spills and is slower (launch_rb_bwd_a_v), so NT = 4 ships.
+template <int C, int D, bool DMA, bool RECOMP, int NT = 4>
+__global__ __launch_bounds__(NTHREADS, (NT == 2 ? 4 : 1)) void k_rb_bwd_a(const float* __restrict__ x, const float* __restrict__ h1in,
                                                        const float* __restrict__ dy,
                                                        const float* __restrict__ w1, const float* __restrict__ b1,
                                                        const float* __restrict__ w2, const float* __restrict__ b2,
@@ -768,6 +772,7 @@ __global__ __launch_bounds__(NTHREADS) void k_rb_bwd_a(const float* __restrict__
     using P = Res3x3<D>;
     using G = Geo<C, C, P, DMA>;
     using R = RB<C>;
+    static_assert(NT == 4 || (NT == 2 && !RECOMP), "the recompute path takes whole 64-column tiles from the conv main loop");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xs = lds;
     float* Wimg = xs + (RECOMP ? G::XS_FLOATS : 0);
@@ -798,13 +803,13 @@ __global__ __launch_bounds__(NTHREADS) void k_rb_bwd_a(const float* __restrict__
     // consecutive pixels per channel and every global access of the kernel is 16 bytes per lane
     const bool wide = !RECOMP && (C % 16 == 0) && (T % 4 == 0) && ((reinterpret_cast<uintptr_t>(h1in) | reinterpret_cast<uintptr_t>(dy) |
                                                                      reinterpret_cast<uintptr_t>(da1)) & 15) == 0;
-    auto epi = [&](const Tile& tl, f32x4 (&h1)[G::MT][4]) {
+    auto epi = [&](const Tile& tl, f32x4 (&h1)[G::MT][NT]) {       // tl.t0 = first column of the NT * 16 columns in hand
         const int h = tl.h0 + wave;
-        f32x4 a2[G::MT][4];
+        f32x4 a2[G::MT][NT];
 #pragma unroll
         for (int mt = 0; mt < G::MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
+            for (int nt = 0; nt < NT; ++nt) {
                 a2[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (RECOMP) {
 #pragma unroll
@@ -820,7 +825,7 @@ __global__ __launch_bounds__(NTHREADS) void k_rb_bwd_a(const float* __restrict__
 #pragma unroll
                 for (int m2 = 0; m2 < G::MT; ++m2) av[m2] = W2s[kr * R::CP + R::swz(kr, m2 * 16 + l15)];
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int m2 = 0; m2 < G::MT; ++m2) a2[m2][nt] = mfma16(av[m2], h1[mt][nt][r], a2[m2][nt]);
             }
@@ -832,32 +837,38 @@ __global__ __launch_bounds__(NTHREADS) void k_rb_bwd_a(const float* __restrict__
                 const int co = m2 * 16 + 4 * g + r;
                 const float bias = b2s[co];
                 const long base = ((long)tl.b * C + (co < C ? co : 0)) * plane + (long)(h < H ? h : 0) * T;
-                float dv[4];
+                float dv[NT];
                 if (wide) {
-                    const int t = tl.t0 + 4 * l15;
-                    float4 v = *reinterpret_cast<const float4*>(dy + base + (t < T ? t : 0));
-                    if (!(h < H && t < T)) v = float4{0.f, 0.f, 0.f, 0.f};
-                    dv[0] = v.x; dv[1] = v.y; dv[2] = v.z; dv[3] = v.w;
+                    const int t = tl.t0 + NT * l15;
+                    if constexpr (NT == 4) {
+                        float4 v = *reinterpret_cast<const float4*>(dy + base + (t < T ? t : 0));
+                        if (!(h < H && t < T)) v = float4{0.f, 0.f, 0.f, 0.f};
+                        dv[0] = v.x; dv[1] = v.y; dv[2] = v.z; dv[3] = v.w;
+                    } else {
+                        float2 v = *reinterpret_cast<const float2*>(dy + base + (t < T ? t : 0));
+                        if (!(h < H && t < T)) v = float2{0.f, 0.f};
+                        dv[0] = v.x; dv[1] = v.y;
+                    }
                 } else {
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) {
+                    for (int nt = 0; nt < NT; ++nt) {
                         const int t = tl.t0 + nt * 16 + l15;
                         dv[nt] = (co < C && h < H && t < T) ? dy[base + t] : 0.f;
                     }
                 }
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
+                for (int nt = 0; nt < NT; ++nt) {
                     const float gd = dv[nt] * elu_grad_from_out(elu1(a2[m2][nt][r] + bias));
                     a2[m2][nt][r] = gd;
                     db2acc[m2][r] += gd;
                 }
             }
         // dH1 = W2^T . dA2 (dA2 fragments as B operands); dA1 = dH1 * ELU'(h1)
-        f32x4 d1[G::MT][4];
+        f32x4 d1[G::MT][NT];
 #pragma unroll
         for (int mt = 0; mt < G::MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) d1[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int nt = 0; nt < NT; ++nt) d1[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int m2 = 0; m2 < G::MT; ++m2)
 #pragma unroll
@@ -867,7 +878,7 @@ __global__ __launch_bounds__(NTHREADS) void k_rb_bwd_a(const float* __restrict__
 #pragma unroll
                 for (int mt = 0; mt < G::MT; ++mt) av[mt] = W2t[kr * R::CP + R::swz(kr, mt * 16 + l15)];
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int mt = 0; mt < G::MT; ++mt) d1[mt][nt] = mfma16(av[mt], a2[m2][nt][r], d1[mt][nt]);
             }
@@ -877,18 +888,22 @@ __global__ __launch_bounds__(NTHREADS) void k_rb_bwd_a(const float* __restrict__
             for (int r = 0; r < 4; ++r) {
                 const int co = mt * 16 + 4 * g + r;
                 const long base = ((long)tl.b * C + (co < C ? co : 0)) * plane + (long)(h < H ? h : 0) * T;
-                float gv[4];
+                float gv[NT];
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
+                for (int nt = 0; nt < NT; ++nt) {
                     gv[nt] = d1[mt][nt][r] * elu_grad_from_out(h1[mt][nt][r]);
                     db1acc[mt][r] += gv[nt];
                 }
                 if (wide) {
-                    const int t = tl.t0 + 4 * l15;
-                    if (h < H && t < T) *reinterpret_cast<float4*>(da1 + base + t) = float4{gv[0], gv[1], gv[2], gv[3]};
+                    const int t = tl.t0 + NT * l15;
+                    if constexpr (NT == 4) {
+                        if (h < H && t < T) *reinterpret_cast<float4*>(da1 + base + t) = float4{gv[0], gv[1], gv[2], gv[3]};
+                    } else {
+                        if (h < H && t < T) *reinterpret_cast<float2*>(da1 + base + t) = float2{gv[0], gv[1]};
+                    }
                 } else {
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) {
+                    for (int nt = 0; nt < NT; ++nt) {
                         const int t = tl.t0 + nt * 16 + l15;
                         if (co < C && h < H && t < T) da1[base + t] = gv[nt];
                     }
@@ -896,7 +911,7 @@ __global__ __launch_bounds__(NTHREADS) void k_rb_bwd_a(const float* __restrict__
             }
         // dW2[co2][c] += sum_pix dA2[co2][pix] * h1[c][pix]: 16 pixels at a time through the wave's own LDS tiles
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
             wave_lds_sync();
 #pragma unroll
             for (int mt = 0; mt < G::MT; ++mt)
@@ -921,18 +936,22 @@ __global__ __launch_bounds__(NTHREADS) void k_rb_bwd_a(const float* __restrict__
             }
         }
     };
-    if (RECOMP) {
+    if constexpr (RECOMP) {
         conv_mainloop<C, C, P, false, DMA, 0>(x, nullptr, Wimg, xs, B, H, H, T, epi);
     } else {
         const int tiles_h = (H + TH - 1) / TH, tiles_t = (T + TW - 1) / TW;
         const int ntiles = B * tiles_h * tiles_t;
 #pragma unroll 1
         for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-            const Tile tl = decode_tile(tile, tiles_h, tiles_t, ntiles);
-            const int h = tl.h0 + wave;
-            f32x4 h1[G::MT][4];
-            if (wide) {     // column n of group nt = pixel 4 n + nt: a lane's four values per channel are one 16-byte load
-                const int t = tl.t0 + 4 * l15;
+            const Tile tl0 = decode_tile(tile, tiles_h, tiles_t, ntiles);
+            const int h = tl0.h0 + wave;
+#pragma unroll 1
+            for (int sub = 0; sub < 4 / NT; ++sub) {
+            Tile tl = tl0;
+            tl.t0 = tl0.t0 + sub * 16 * NT;
+            f32x4 h1[G::MT][NT];
+            if (wide) {     // column n of group nt = pixel NT n + nt: a lane's NT values per channel are one 16- / 8-byte load
+                const int t = tl.t0 + NT * l15;
                 const bool ok = h < H && t < T;
                 const long cb = (long)tl.b * C * plane;
                 const unsigned vo = (unsigned)(4 * g * (int)plane + (h < H ? h : 0) * T + (t < T ? t : 0));
@@ -940,9 +959,15 @@ __global__ __launch_bounds__(NTHREADS) void k_rb_bwd_a(const float* __restrict__
                 for (int mt = 0; mt < G::MT; ++mt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float4 v = *reinterpret_cast<const float4*>(h1in + cb + (long)(mt * 16 + r) * plane + vo);
-                        if (!ok) v = float4{0.f, 0.f, 0.f, 0.f};
-                        h1[mt][0][r] = v.x; h1[mt][1][r] = v.y; h1[mt][2][r] = v.z; h1[mt][3][r] = v.w;
+                        if constexpr (NT == 4) {
+                            float4 v = *reinterpret_cast<const float4*>(h1in + cb + (long)(mt * 16 + r) * plane + vo);
+                            if (!ok) v = float4{0.f, 0.f, 0.f, 0.f};
+                            h1[mt][0][r] = v.x; h1[mt][1][r] = v.y; h1[mt][2][r] = v.z; h1[mt][3][r] = v.w;
+                        } else {
+                            float2 v = *reinterpret_cast<const float2*>(h1in + cb + (long)(mt * 16 + r) * plane + vo);
+                            if (!ok) v = float2{0.f, 0.f};
+                            h1[mt][0][r] = v.x; h1[mt][1][r] = v.y;
+                        }
                     }
             } else {
 #pragma unroll
@@ -952,13 +977,14 @@ __global__ __launch_bounds__(NTHREADS) void k_rb_bwd_a(const float* __restrict__
                     const int co = mt * 16 + 4 * g + r;
                     const long base = ((long)tl.b * C + (co < C ? co : 0)) * plane + (long)(h < H ? h : 0) * T;
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) {
+                    for (int nt = 0; nt < NT; ++nt) {
                         const int t = tl.t0 + nt * 16 + l15;
                         h1[mt][nt][r] = (co < C && h < H && t < T) ? h1in[base + t] : 0.f;
                     }
                 }
             }
             epi(tl, h1);
+            }
         }
     }
     // reduce the 8 waves in LDS (own region: tr), then one global atomic per element per workgroup
@@ -1504,7 +1530,7 @@ int launch_conv(const float* x, const float* gy, const float* w, WSpec ws, const
                 static const bool valu = getenv("TTRAP_STRIDED_MFMA") == nullptr;
                 if (valu && !res) return launch_conv_valu<CIN, COUT, P>(x, w, ws, bias, y, B, Hin, Hout, T, act, st);
             }
-            if constexpr (P::NTAPS == 9 && CIN >= 16) {
+            if constexpr (P::NTAPS == 9 && CIN >= 4) {
                 if (prec == 1) return launch_conv_v<CIN, COUT, P, false, true, 1>(x, gy, w, ws, bias, res, y, B, Hin, Hout, T, act, st);
                 if (prec == 2) return launch_conv_v<CIN, COUT, P, false, true, 2>(x, gy, w, ws, bias, res, y, B, Hin, Hout, T, act, st);
             }
@@ -1535,7 +1561,7 @@ template <int C, int D>
 int launch_rb_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y, float* h1,
                   int B, int H, int T, hipStream_t st, int prec) {
     if (dma_ok(x, T)) {
-        if constexpr (C >= 16) {
+        if constexpr (C >= 4) {
             if (prec == 1) return launch_rb_fwd_v<C, D, true, 1>(x, w1, b1, w2, b2, y, h1, B, H, T, st);
             if (prec == 2) return launch_rb_fwd_v<C, D, true, 2>(x, w1, b1, w2, b2, y, h1, B, H, T, st);
         }
@@ -1615,12 +1641,15 @@ int launch_rb_bwd_a_v(const float* x, const float* h1, const float* dy, const fl
     using G = Geo<C, C, Res3x3<D>, DMA>;
     using R = RB<C>;
     constexpr int LDS = ((RECOMP ? G::W_FLOATS + G::XS_FLOATS : 0) + 2 * R::CPAD * R::CP + 2 * R::CPAD + R::TR_FLOATS) * 4;
+    // Half-width passes (NT = 2) at 32 channels were measured and lost: even then the chain needs > 128 registers (77 spilled,
+    // 312 B of scratch per lane), and the whole backward of a C = 32 block went from 2.10-2.20 ms to 2.45-2.51 ms.
+    constexpr int NT = 4;
     static AttrOnce attr;
     if (const int adev_ = attr.pending(); adev_ >= 0) {
-        TT_HIP(hipFuncSetAttribute((const void*)k_rb_bwd_a<C, D, DMA, RECOMP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        TT_HIP(hipFuncSetAttribute((const void*)k_rb_bwd_a<C, D, DMA, RECOMP, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr.mark(adev_);
     }
-    hipLaunchKernelGGL((k_rb_bwd_a<C, D, DMA, RECOMP>), dim3(persistent_grid(ntiles_of(B, H, T), blocks_per_cu(LDS, 2))),
+    hipLaunchKernelGGL((k_rb_bwd_a<C, D, DMA, RECOMP, NT>), dim3(persistent_grid(ntiles_of(B, H, T), blocks_per_cu(LDS, 2))),
                        dim3(NTHREADS), LDS, st, x, h1, dy, w1, b1, w2, b2, ws, db1, dw2, db2, B, H, T);
     TT_LAUNCH_CHECK();
     return 0;
@@ -1824,6 +1853,22 @@ int rb_wgrad_only(const float* x, float* dw1, float* ws, int B, int H, int T, hi
                                                                         ws + (long)B * C * H * T, B, H, H, T, st);
 }
 
+// narrow levels in the bf16 modes: pointwise chain and 3x3 data gradient on the matrix-core kernels of the wide levels, the
+// weight gradient on the packed-operand kernel (fp32 MFMA: K = pixels, the operands are the fp32 tensors as they are)
+template <int C, int D>
+int launch_rb_bwd_narrow_mfma(const float* x, const float* h1, const float* dy, const float* w1, const float* b1, const float* w2,
+                              const float* b2, float* dx, float* dw1, float* db1, float* dw2, float* db2, float* ws, int B, int H, int T,
+                              hipStream_t st, int prec) {
+    int rc;
+    if (h1) rc = launch_rb_bwd_a_v<C, 1, false, false>(x, h1, dy, w1, b1, w2, b2, db1, dw2, db2, ws, B, H, T, st);
+    else rc = dma_ok(x, T) ? launch_rb_bwd_a_v<C, D, true, true>(x, h1, dy, w1, b1, w2, b2, db1, dw2, db2, ws, B, H, T, st)
+                           : launch_rb_bwd_a_v<C, D, false, true>(x, h1, dy, w1, b1, w2, b2, db1, dw2, db2, ws, B, H, T, st);
+    if (rc) return rc;
+    rc = launch_conv<C, C, Res3x3<D>, false>(ws, nullptr, w1, WSpec{9, (long)C * 9, -1, 8}, nullptr, dy, dx, B, H, H, T, TT_ACT_NONE, st, prec);
+    if (rc) return rc;
+    return rb_wgrad_only<C, D>(x, dw1, ws, B, H, T, st);
+}
+
 #define TT_DISPATCH_CD(FN, ...)                                                       \
     switch (C * 10 + dilation) {                                                      \
         case 41: return FN<4, 1>(__VA_ARGS__);   case 42: return FN<4, 2>(__VA_ARGS__);   case 43: return FN<4, 3>(__VA_ARGS__);   \
@@ -1934,7 +1979,13 @@ extern "C" int tt_resblock_fwd(const float* x, const float* w1, const float* b1,
     if (!clip_fits(C, H, T)) return TT_E_UNSUPPORTED;
     hipStream_t st = tt_stream(stream);
     const int bf16 = (flags & TT_FLAG_BF16_SPLIT) ? 2 : ((flags & TT_FLAG_BF16_OPERANDS) ? 1 : 0);
-    if (C <= 8) return tt_small_rb_fwd(x, w1, b1, w2, b2, y, h1, B, C, H, T, dilation, st);     // HBM-bound levels: VALU kernels
+    // The narrow levels run on the vector ALUs in every precision mode.  Routing them through the matrix-core kernels of the
+    // wide levels in the bf16 modes (padding is cheap at the bf16 rate) was measured and lost: those kernels' per-tile staging,
+    // conversion and barrier costs are per PIXEL, and the narrow levels have 8-16x more pixels per channel -- C = 4: 0.68-0.79 ms
+    // against 0.40 ms forward, 1.83-1.95 against 0.87-0.96 ms backward; C = 8: 0.54-0.65 against 0.55-0.62 ms forward.
+    // TTRAP_NARROW_MFMA=1 keeps that route reachable for measurements.
+    if (C <= 8 && (bf16 == 0 || getenv("TTRAP_NARROW_MFMA") == nullptr))
+        return tt_small_rb_fwd(x, w1, b1, w2, b2, y, h1, B, C, H, T, dilation, st);
     TT_DISPATCH_CD(launch_rb_fwd, x, w1, b1, w2, b2, y, h1, B, H, T, st, bf16)
 }
 
@@ -1945,7 +1996,8 @@ extern "C" int tt_resblock_bwd(const float* x, const float* h1, const float* dy,
         return TT_E_BADARG;
     if (!clip_fits(C, H, T)) return TT_E_UNSUPPORTED;
     hipStream_t st = tt_stream(stream);
-    if (C <= 8) {
+    const int bf16n = (flags & TT_FLAG_BF16_SPLIT) ? 2 : ((flags & TT_FLAG_BF16_OPERANDS) ? 1 : 0);
+    if (C <= 8 && (bf16n == 0 || getenv("TTRAP_NARROW_MFMA") == nullptr)) {
         int rc = tt_small_rb_bwd(x, h1, dy, w1, b1, w2, b2, dx, dw1, db1, dw2, db2, ws, ws + (long)B * C * H * T, B, C, H, T,
                                  dilation, st);
         if (rc == TT_SMALL_BWD_DID_DW1) return 0;           // fused narrow backward: nothing left to do
@@ -1960,7 +2012,18 @@ extern "C" int tt_resblock_bwd(const float* x, const float* h1, const float* dy,
             default: return TT_E_UNSUPPORTED;
         }
     }
-    const int bf16 = (flags & TT_FLAG_BF16_SPLIT) ? 2 : ((flags & TT_FLAG_BF16_OPERANDS) ? 1 : 0);
+    const int bf16 = bf16n;
+    if (C <= 8) {
+        switch (C * 10 + dilation) {
+            case 41: return launch_rb_bwd_narrow_mfma<4, 1>(x, h1, dy, w1, b1, w2, b2, dx, dw1, db1, dw2, db2, ws, B, H, T, st, bf16);
+            case 42: return launch_rb_bwd_narrow_mfma<4, 2>(x, h1, dy, w1, b1, w2, b2, dx, dw1, db1, dw2, db2, ws, B, H, T, st, bf16);
+            case 43: return launch_rb_bwd_narrow_mfma<4, 3>(x, h1, dy, w1, b1, w2, b2, dx, dw1, db1, dw2, db2, ws, B, H, T, st, bf16);
+            case 81: return launch_rb_bwd_narrow_mfma<8, 1>(x, h1, dy, w1, b1, w2, b2, dx, dw1, db1, dw2, db2, ws, B, H, T, st, bf16);
+            case 82: return launch_rb_bwd_narrow_mfma<8, 2>(x, h1, dy, w1, b1, w2, b2, dx, dw1, db1, dw2, db2, ws, B, H, T, st, bf16);
+            case 83: return launch_rb_bwd_narrow_mfma<8, 3>(x, h1, dy, w1, b1, w2, b2, dx, dw1, db1, dw2, db2, ws, B, H, T, st, bf16);
+            default: return TT_E_UNSUPPORTED;
+        }
+    }
     TT_DISPATCH_CD(launch_rb_bwd, x, h1, dy, w1, b1, w2, b2, dx, dw1, db1, dw2, db2, ws, B, H, T, st, bf16)
 }
 

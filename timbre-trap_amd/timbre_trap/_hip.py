@@ -55,6 +55,7 @@ _PROTOS = {
     'tt_gemm': (c_int, [P, P, P, P, I, I, I, I, I, L, L, L, I, L, L, L, I, F_, F_, I, I, I, P]),
     'tt_channel_sum': (c_int, [P, P, I, I, L, P]),
     'tt_scaled_add': (c_int, [P, P, P, I, P, L, P]),
+    'tt_window_ola': (c_int, [P, P, P, L, I, I, I, L, P]),
     'tt_dot': (c_int, [P, P, P, L, P]),
     'tt_sqdiff_sum': (c_int, [P, P, P, P, L, F_, P]),
     'tt_sqdiff_bwd': (c_int, [P, P, P, F_, P, P, L, P]),

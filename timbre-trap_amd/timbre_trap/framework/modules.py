@@ -18,6 +18,7 @@ import torch.nn as nn
 
 from . import CQT
 from . import ops
+from .. import _hip
 from .ops import ACT_ELU, ACT_NONE, ConvCfg
 
 __all__ = [
@@ -232,28 +233,22 @@ class TimbreTrap(nn.Module):
         hop = block // 2
         audio = torch.nn.functional.pad(audio, [hop] * 2)
         n_chunks = (audio.size(-1) - hop) // hop
-        window = torch.signal.windows.hann(M, device=audio.device)
+        window = torch.signal.windows.hann(M, dtype=torch.float32, device=audio.device)
         n_frames = self.sliCQ.get_expected_frames(audio.size(-1))
-        coefficients = torch.zeros((B, 2, F, n_frames), device=audio.device)
+        coefficients = torch.zeros((B, 2, F, n_frames), dtype=torch.float32, device=audio.device)
 
         # (B,1,n_chunks,block) view of the overlapping chunks
         chunks = audio.unfold(-1, block, hop)
         assert chunks.size(-2) == n_chunks
         per_pass = max(1, MAX_CHUNK_BATCH // B)
+        lib = _hip.lib()
         for c0 in range(0, n_chunks, per_pass):
             c1 = min(n_chunks, c0 + per_pass)
             batch = chunks[:, :, c0:c1].permute(2, 0, 1, 3).reshape((c1 - c0) * B, 1, block)
-            out = self._inference(batch, transcribe).view(c1 - c0, B, 2, F, M)
-            out = out * window
-            # even and odd chunks never overlap among themselves: two strided adds reproduce the
-            # sequential accumulate of the reference exactly (a + b == b + a in floating point)
-            for parity in (0, 1):
-                idx = [i for i in range(c0, c1) if i % 2 == parity]
-                if not idx:
-                    continue
-                sel = out[idx[0] - c0::2]                              # (n, B, 2, F, M)
-                span = coefficients[..., idx[0] * (M // 2): idx[0] * (M // 2) + len(idx) * M]
-                span += sel.permute(1, 2, 3, 0, 4).reshape(B, 2, F, len(idx) * M)
+            out = self._inference(batch, transcribe)                  # ((c1 - c0) * B, 2, F, M), chunk-major
+            # out[b, :, :, i*M/2 : i*M/2 + M] += window * chunk_i, ascending i: the reference's accumulation order (tt_window_ola)
+            _hip.check(lib.tt_window_ola(_hip.ptr(out), _hip.ptr(window), _hip.ptr(coefficients), B * 2 * F, M, c0, c1, n_frames,
+                                         _hip.stream_ptr()), 'tt_window_ola')
         return coefficients[..., M // 2: -M // 2]
 
     def to_activations(self, coefficients):

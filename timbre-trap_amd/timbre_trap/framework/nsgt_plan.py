@@ -24,7 +24,7 @@ FRAME_FLOOR = 1e-3   # minimum frame-operator diagonal for a spectral index to b
 class NSGTConventions:
     """
     Every free choice of the transform that the reference leaves to ``cqt_pytorch`` (absent here, so UNPINNED -- see
-    oracle/nsgt.py).  All of them are table-level: switching one changes the plan, never a kernel.  The defaults are the
+    DESIGN.md section 2).  All of them are table-level: switching one changes the plan, never a kernel.  The defaults are the
     recalled ``cqt_pytorch`` behaviour plus ONE deliberate deviation (``dual='floored'``, documented in INTEGRATION.md);
     ``tools/pin_cqt.py`` searches this space for the combination that reproduces ``cqt_pytorch`` when that package is available.
 

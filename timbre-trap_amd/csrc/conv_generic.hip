@@ -588,9 +588,11 @@ __global__ __launch_bounds__(256) void k_window_ola(const float* __restrict__ ch
             const int m = (int)(p - (long)ci * half);
             const float4 w = *reinterpret_cast<const float4*>(window + m);
             const float4 v = *reinterpret_cast<const float4*>(chunks + ((long)(ci - c0) * rows + r) * M + m);
-            // product and sum rounded separately (no FMA contraction): `out += window * chunk` of the reference is two fp32 roundings
-            acc.x = __fadd_rn(acc.x, __fmul_rn(w.x, v.x)); acc.y = __fadd_rn(acc.y, __fmul_rn(w.y, v.y));
-            acc.z = __fadd_rn(acc.z, __fmul_rn(w.z, v.z)); acc.w = __fadd_rn(acc.w, __fmul_rn(w.w, v.w));
+            // product and sum rounded separately: `out += window * chunk` of the reference is two fp32 roundings, so the
+            // products are pinned in registers before the adds (the compiler would otherwise contract them into FMAs)
+            float px = w.x * v.x, py = w.y * v.y, pz = w.z * v.z, pw = w.w * v.w;
+            asm volatile("" : "+v"(px), "+v"(py), "+v"(pz), "+v"(pw));
+            acc.x += px; acc.y += py; acc.z += pz; acc.w += pw;
         }
         *reinterpret_cast<float4*>(out + r * n_frames + p) = acc;
     }

@@ -1177,7 +1177,9 @@ struct WGeoD {
     static constexpr int Q_FLOATS = NPIECE * 256;
 };
 
-template <int CA, int CB, int CBS, class WP, int PREC>
+// NBUF = 2: both operands double-buffered -- the next tile's DMA is in flight while this one is multiplied, one barrier per tile
+// (one workgroup per CU then: the staging sets fill most of the LDS)
+template <int CA, int CB, int CBS, class WP, int PREC, int NBUF>
 __global__ __launch_bounds__(64 * WP::WTH) void k_wgrad_dma(const float* __restrict__ Pt, const float* __restrict__ Qt,
                                                            float* __restrict__ scratch, float* __restrict__ dbias_p, int B,
                                                            int HP, int HQ, int T) {
@@ -1189,8 +1191,7 @@ __global__ __launch_bounds__(64 * WP::WTH) void k_wgrad_dma(const float* __restr
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
-    float* xs = lds;
-    float* as = lds + Q::Q_FLOATS + uwave * K::CAP * 64;
+    constexpr int SET = Q::Q_FLOATS + WP::WTH * K::CAP * 64;          // one staging set: Q tile + the P rows of every wave
     const int b0 = blockIdx.y * CBS;
     const int tiles_h = (HP + WP::WTH - 1) / WP::WTH, tiles_t = (T + WP::WTW - 1) / WP::WTW;
     const int ntiles = B * tiles_h * tiles_t;
@@ -1215,12 +1216,13 @@ __global__ __launch_bounds__(64 * WP::WTH) void k_wgrad_dma(const float* __restr
     float bsum = 0.f;
     const float* zero = reinterpret_cast<const float*>(&g_zero16);
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    auto issue = [&](int tile, int buf) {
+        float* xs = lds + buf * SET;
+        float* as = xs + Q::Q_FLOATS + uwave * K::CAP * 64;
         int tt = xcd_tile(tile, ntiles);
         const int tx = tt % tiles_t; tt /= tiles_t;
         const int ty = tt % tiles_h;
         const int b = tt / tiles_h, h0 = ty * WP::WTH, t0 = tx * WP::WTW;
-        __syncthreads();                                   // everyone is done with the previous tile's LDS
         {   // Q tile
             const float* qb = Qt + ((long)b * CB + b0) * qplane;
             const int row0 = WP::q_row0(h0), col0 = t0 - Q::HL;
@@ -1250,8 +1252,19 @@ __global__ __launch_bounds__(64 * WP::WTH) void k_wgrad_dma(const float* __restr
                 glds16(ok ? pb + (a * (int)pplane + 4 * c) : zero, as + a0 * 64);
             }
         }
+    };
+    int buf = 0;
+    if (NBUF == 2 && (int)blockIdx.x < ntiles) issue(blockIdx.x, 0);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        if (NBUF == 1) {
+            __syncthreads();                               // everyone is done with the previous tile's LDS
+            issue(tile, 0);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        __syncthreads();                                   // this tile has landed for every wave; the other set is free
+        if (NBUF == 2 && tile + (int)gridDim.x < ntiles) issue(tile + (int)gridDim.x, buf ^ 1);
+        const float* xs = lds + buf * SET;
+        const float* as = xs + Q::Q_FLOATS + uwave * K::CAP * 64;
         if (dbias_p && blockIdx.y == 0 && lane < CA) {
 #pragma unroll 8
             for (int p = 0; p < 64; ++p) bsum += as[lane * 64 + ((((p >> 2) ^ (lane & 15)) << 2) | (p & 3))];
@@ -1299,6 +1312,7 @@ __global__ __launch_bounds__(64 * WP::WTH) void k_wgrad_dma(const float* __restr
                 }
             }
         }
+        if (NBUF == 2) buf ^= 1;
     }
     __syncthreads();
     constexpr int NC = K::NTN * 16;
@@ -1584,13 +1598,22 @@ int launch_wgrad(const float* Pt, const float* Pg, const float* Qt, const float*
     if constexpr (!GP && !GQ) {
         if (dma_ok(Pt, T) && dma_ok(Qt, T)) {
             using Q = WGeoD<CBS, WP>;
-            constexpr int LDS = cmax(Q::Q_FLOATS + WP::WTH * K::CAP * 64, K::RED_FLOATS) * 4;
+            constexpr int SET_FLOATS = Q::Q_FLOATS + WP::WTH * K::CAP * 64;
+            // Double-buffered staging (two sets, one 4-wave workgroup per CU, next tile's DMA under this tile's MFMAs) was measured
+            // against the single set with two or three workgroups per CU and LOST: whole C = 32 block backward 2.20-2.31 ms against
+            // 2.10-2.23 ms, C = 16 1.45-1.56 against 1.41-1.52 ms.  Several independent workgroups hide the DMA wait better than
+            // one deeper pipeline.  TTRAP_WGRAD_NBUF=2 keeps the variant reachable for measurements.
+            constexpr int NBUF = (CA >= 16 && 2 * SET_FLOATS * 4 <= 160 * 1024) ? 2 : 1;
+            static const bool dbuf_env = NBUF == 2 && getenv("TTRAP_WGRAD_NBUF") && atoi(getenv("TTRAP_WGRAD_NBUF")) == 2;
+            const bool dbuf = dbuf_env && !(CA >= 16 && WP::NTAPS == 9 && prec != 0);      // the bf16 modes keep the single set
+            const int LDS = cmax((dbuf ? 2 : 1) * SET_FLOATS, K::RED_FLOATS) * 4;
             static AttrOnce attr;
             if (const int adev_ = attr.pending(); adev_ >= 0) {
-                TT_HIP(hipFuncSetAttribute((const void*)k_wgrad_dma<CA, CB, CBS, WP, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+                TT_HIP(hipFuncSetAttribute((const void*)k_wgrad_dma<CA, CB, CBS, WP, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, cmax(SET_FLOATS, K::RED_FLOATS) * 4));
+                TT_HIP(hipFuncSetAttribute((const void*)k_wgrad_dma<CA, CB, CBS, WP, 0, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, cmax(NBUF * SET_FLOATS, K::RED_FLOATS) * 4));
                 if constexpr (CA >= 16 && WP::NTAPS == 9) {
-                    TT_HIP(hipFuncSetAttribute((const void*)k_wgrad_dma<CA, CB, CBS, WP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-                    TT_HIP(hipFuncSetAttribute((const void*)k_wgrad_dma<CA, CB, CBS, WP, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+                    TT_HIP(hipFuncSetAttribute((const void*)k_wgrad_dma<CA, CB, CBS, WP, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, cmax(SET_FLOATS, K::RED_FLOATS) * 4));
+                    TT_HIP(hipFuncSetAttribute((const void*)k_wgrad_dma<CA, CB, CBS, WP, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, cmax(SET_FLOATS, K::RED_FLOATS) * 4));
                 }
                 attr.mark(adev_);
             }
@@ -1599,18 +1622,23 @@ int launch_wgrad(const float* Pt, const float* Pg, const float* Qt, const float*
             bool done = false;
             if constexpr (CA >= 16 && WP::NTAPS == 9) {
                 if (prec == 1) {
-                    hipLaunchKernelGGL((k_wgrad_dma<CA, CB, CBS, WP, 1>), dim3(grid, NS), dim3(64 * WP::WTH), LDS, st, Pt, Qt,
+                    hipLaunchKernelGGL((k_wgrad_dma<CA, CB, CBS, WP, 1, 1>), dim3(grid, NS), dim3(64 * WP::WTH), LDS, st, Pt, Qt,
                                        scratch, dbias_p, B, HP, HQ, T);
                     done = true;
                 } else if (prec == 2) {
-                    hipLaunchKernelGGL((k_wgrad_dma<CA, CB, CBS, WP, 2>), dim3(grid, NS), dim3(64 * WP::WTH), LDS, st, Pt, Qt,
+                    hipLaunchKernelGGL((k_wgrad_dma<CA, CB, CBS, WP, 2, 1>), dim3(grid, NS), dim3(64 * WP::WTH), LDS, st, Pt, Qt,
                                        scratch, dbias_p, B, HP, HQ, T);
                     done = true;
                 }
             }
-            if (!done)
-                hipLaunchKernelGGL((k_wgrad_dma<CA, CB, CBS, WP, 0>), dim3(grid, NS), dim3(64 * WP::WTH), LDS, st, Pt, Qt,
-                                   scratch, dbias_p, B, HP, HQ, T);
+            if (!done) {
+                if (dbuf)
+                    hipLaunchKernelGGL((k_wgrad_dma<CA, CB, CBS, WP, 0, NBUF>), dim3(grid, NS), dim3(64 * WP::WTH), LDS, st, Pt, Qt,
+                                       scratch, dbias_p, B, HP, HQ, T);
+                else
+                    hipLaunchKernelGGL((k_wgrad_dma<CA, CB, CBS, WP, 0, 1>), dim3(grid, NS), dim3(64 * WP::WTH), LDS, st, Pt, Qt,
+                                       scratch, dbias_p, B, HP, HQ, T);
+            }
             TT_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_wgrad_reduce, dim3((K::CAP * NC + 31) / 32, NS), dim3(256), 0, st, (const float*)scratch, dw,
                                grid, CA, K::CAP, NC, K::NN, CBS, s_a, s_b, s_t);

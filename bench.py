@@ -330,6 +330,9 @@ def main():
     ap.add_argument('--mode', choices=('train', 'infer'), default='train',
                     help="train = the headline metric; infer = BASELINE config[1]: transcribe() + reconstruct() on 32 clips x 3 s")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--timed-only', action='store_true',
+                    help='skip the untimed legs (instrumented family steps, inverse CQT, inference config, CPU baselines): for rocprofv3 runs whose '
+                         'kernel totals should divide by warmup + steps')
     ap.add_argument('--no-overlap', action='store_true',
                     help='N > 1: blocking all-reduce on the compute stream instead of the side-stream all-reduce overlapped with the next CQT')
     args = ap.parse_args()
@@ -397,7 +400,7 @@ def main():
     value = world * args.batch * SECS_PER_CLIP / (elapsed / args.steps)
 
     # ---- untimed, instrumented legs (every rank runs them so collectives stay matched; rank 0 reports) ----
-    fam_events, n_inst = {}, 2
+    fam_events, n_inst = {}, (0 if args.timed_only else 2)
     _hip.EVENT_KEYS = None
     _hip.EVENT_LOG = fam_events
     for _ in range(n_inst):
@@ -416,6 +419,7 @@ def main():
         allreduce_ms = a0.elapsed_time(a1) / 10
     inv_events = {}
     with torch.no_grad():
+      if not args.timed_only:
         coeffs = model.sliCQ(audio)
         for _ in range(3):
             model.sliCQ.decode(coeffs)
@@ -461,7 +465,7 @@ def main():
             cqt_inv = dict(kernel='tt_cqt_inverse (CQT.decode incl. the batch infinity norm)', bound='hbm', achieved=gbs, peak=PEAK_HBM_GBS,
                            unit='GB/s', frac=gbs / PEAK_HBM_GBS, avg_ms=a_ms, launches=n_l, clips=args.batch,
                            note='measured after the timed region; the train step never calls the inverse transform')
-        families = family_table(fam_events, n_inst, args.batch, args.mc, args.latent)
+        families = family_table(fam_events, n_inst, args.batch, args.mc, args.latent) if n_inst else None
         conv_flops = {1: 41.4e9, 2: 168.7e9}.get(args.mc)          # SURVEY.md section 8d, fwd + bwd per clip (latent 32 / 128)
         whole = None
         if conv_flops:
@@ -469,12 +473,12 @@ def main():
             whole = dict(algorithmic_conv_flops_per_step=conv_flops * args.batch, achieved_tflops=tf,
                          frac_fp32_matrix_peak=tf / PEAK_FP32_MATRIX_TFLOPS, frac_bf16_mfma_peak=tf / PEAK_BF16_MFMA_TFLOPS)
         infer = None
-        if world == 1:                                    # BASELINE configs[1], measured in the same run (secondary figure)
+        if world == 1 and not args.timed_only:            # BASELINE configs[1], measured in the same run (secondary figure)
             full = bench_inference(model, args, rank, world, dev, steps=3, warmup=1, emit=False)
             infer = {k: full[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype')}
             infer['workload'] = full['config']['workload']
         base = base0 = None
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and not args.timed_only and world == 1:
             base = cpu_baseline(args.mc, args.latent)
             base0 = cpu_baseline(1, None, config0=True)
         line = dict(metric='audio-seconds/s training throughput (9oct x 60bpo, 3s@22.05kHz)', value=value,

@@ -356,6 +356,10 @@ def main():
         dist.barrier()
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (there is no CPU fallback for the HIP path)')
+    if local_rank >= torch.cuda.device_count():
+        if os.environ.get('TTRAP_DIST_BACKEND') != 'gloo':
+            raise SystemExit('LOCAL_RANK %d but only %d GPU(s) visible' % (local_rank, torch.cuda.device_count()))
+        local_rank %= torch.cuda.device_count()       # functional test of the N > 1 path: gloo ranks sharing the box's GPU(s)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     _hip.lib()
@@ -391,7 +395,8 @@ def main():
     rank_ms = 1000.0 * elapsed / args.steps
     per_rank_ms = [rank_ms]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        # RCCL moves device tensors, gloo (functional tests of the N > 1 path on one GPU) host tensors
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
         gathered = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(gathered, t)
         per_rank_ms = [1000.0 * float(g.item()) / args.steps for g in gathered]

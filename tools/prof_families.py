@@ -3,14 +3,14 @@ import collections
 import re
 import sys
 
-GROUPS = [('narrow resblocks fwd/dgrad (k_small)', r'k_small<|k_small_lds'), ('narrow pointwise backward (k_small_bwd_a)', r'k_small_bwd_a'),
+GROUPS = [('narrow fused backward (k_small_bwd_fused)', r'k_small_bwd_fused|k_small_wgrad_reduce'), ('narrow resblocks fwd/dgrad (k_small)', r'k_small<|k_small_lds'), ('narrow pointwise backward (k_small_bwd_a)', r'k_small_bwd_a'),
           ('weight grad 3x3 C>=16', r'k_wgrad_dma<(16|32), (16|32), 16, .*WRes'), ('weight grad other', r'k_wgrad3_pack_reduce'), ('weight grad 3x3 C<=8', r'k_wgrad_dma<(4|8), (4|8), .*WRes|k_wgrad3_pack<'),
           ('weight grad strided', r'k_wgrad_dma<.*WStr'), ('weight grad other', r'k_wgrad_reduce|k_wgrad_generic|k_wgrad3x3|k_wgrad_mfma|k_wgrad3_pack_reduce'),
           ('wide resblocks forward (k_rb_fwd)', r'k_rb_fwd'), ('wide 3x3 data gradient', r'k_conv_mfma<(16|32), (16|32), .*Res3x3'),
           ('wide pointwise backward (k_rb_bwd_a)', r'k_rb_bwd_a'), ('strided / transposed convs', r'k_conv_mfma<.*(Up4|Down4)|k_conv_valu'),
           ('latent GEMMs', r'k_gemm'), ('gate / bias passes', r'k_gate|k_elu_bwd|k_channel_sum|k_gated'),
-          ('boundary convs', r'k_conv3x3_small|k_conv_generic'), ('torch elementwise', r'at::native'),
-          ('CQT', r'k_band|k_fft|k_spec|k_scale'), ('losses / optimizer', r'k_sqdiff|k_trn|k_act|k_adamw|k_l2|k_scaled|k_dot|k_sumsq|k_finalize')]
+          ('boundary convs', r'k_conv3x3_small|k_conv3x3_lds|k_conv_generic'), ('torch elementwise', r'at::native'),
+          ('CQT', r'k_band|k_fft|k_spec|k_scale'), ('losses / optimizer', r'k_sqdiff|k_trn|k_act|k_adamw|k_l2|k_scaled|k_dot|k_sumsq|k_finalize|k_window_ola')]
 acc = collections.OrderedDict((g, 0.0) for g, _ in GROUPS)
 other = 0.0
 for line in open(sys.argv[1]):

@@ -264,3 +264,29 @@ def test_fused_narrow_backward_matches_three_kernel_path(C, d, cus, monkeypatch,
         assert _rel(a, b) < 2e-5, name
     # the two paths really are different code (the summation orders differ): at least one gradient is not bit-identical
     assert any(not torch.equal(a, b) for a, b in zip(grads['fused'], grads['three_kernel']))
+
+
+@pytest.mark.parametrize('C', [4, 8])
+@pytest.mark.parametrize('d', [1, 2, 3])
+def test_narrow_matrix_pipe_form_is_bit_identical_to_the_vector_form(C, d, monkeypatch):
+    """
+    k_small_lds issues the narrow 3x3 convolution either as per-lane FMAs or as v_mfma_f32_4x4x1 (lane = pixel, accumulator
+    register = output channel): one FMA per product in the same order, so forward and data gradient must agree BITWISE.
+    """
+    from timbre_trap.framework import ops
+    monkeypatch.setattr(ops, 'SAVE_HIDDEN', True)
+    monkeypatch.setenv('TTRAP_SMALL_UNFUSED_BWD', '1')              # data gradient through k_small_lds as well
+    x = _rand(3, C, 45, 200, seed=1).cuda()
+    w1, b1 = _rand(C, C, 3, 3, seed=2, scale=0.2).cuda(), _rand(C, seed=3, scale=0.2).cuda()
+    w2, b2 = _rand(C, C, 1, 1, seed=4, scale=0.3).cuda(), _rand(C, seed=5, scale=0.2).cuda()
+    outs = {}
+    for form in ('matrix', 'vector'):
+        if form == 'vector':
+            monkeypatch.setenv('TTRAP_SMALL_VALU_FMA', '1')
+        else:
+            monkeypatch.delenv('TTRAP_SMALL_VALU_FMA', raising=False)
+        xr = x.clone().requires_grad_(True)
+        y = ops.ResBlockFn.apply(xr, w1, b1, w2, b2, d)
+        gx, = torch.autograd.grad(y, xr, torch.ones_like(y))
+        outs[form] = (y.detach().clone(), gx.clone())
+    assert torch.equal(outs['matrix'][0], outs['vector'][0]) and torch.equal(outs['matrix'][1], outs['vector'][1])

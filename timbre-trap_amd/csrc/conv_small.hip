@@ -143,6 +143,16 @@ __global__ __launch_bounds__(256) void k_small(const float* __restrict__ x, cons
     }
 }
 
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+// v_mfma_f32_4x4x1_16b_f32: sixteen independent 4 x 4 x 1 outer products per wave instruction.  Lane l belongs to block l / 4;
+// A = one value per lane (row l % 4 of its block), B = one value per lane (column l % 4), result register r of lane l =
+// D[block l / 4][row r][column l % 4] (tools/probes/mfma4x4_probe.cpp).  With  A = W[co = l % 4][k]  (the same four weights in
+// every block) and  B = the lane's own pixel value for input k,  register r of lane l accumulates output channel r of pixel l:
+// exactly the layout of the thread-per-pixel loop  acc[co] = fmaf(x, w[co], acc[co]),  one FMA per product in the same order
+// (bit-identical results), but issued on the MATRIX pipe at the vector FMA rate (measured 59.6 vs 53.9 TMAC/s chip-wide) -- the
+// vector ALUs keep ELU, addressing and the epilogue, and the weight fetch shrinks to one ds_read_b32 per four channels.
+__device__ __forceinline__ f32x4s mfma4(float a, float b, f32x4s c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
+
 // ---- LDS-tiled variant ---------------------------------------------------------------------------------------------
 // Same arithmetic, input tile (all C channels, 8 rows + halo, 64 columns + halo) brought in by LDS-DMA and double
 // buffered like the matrix-core kernels.  A thread still owns one pixel, but its 9 C taps are ds_read_b32 with immediate
@@ -170,7 +180,7 @@ struct SL {
     static constexpr int LDS_BYTES = (NBUF * BUF + SW<C>::FLOATS) * 4;
 };
 
-template <int C, int D, int MODE, int RPT, int NBUF>
+template <int C, int D, int MODE, int RPT, int NBUF, bool MF>
 __global__ __launch_bounds__(512) void k_small_lds(const float* __restrict__ x, const float* __restrict__ w1,
                                                    const float* __restrict__ b1, const float* __restrict__ w2,
                                                    const float* __restrict__ b2, const float* __restrict__ res,
@@ -225,6 +235,44 @@ __global__ __launch_bounds__(512) void k_small_lds(const float* __restrict__ x, 
         // tap (kh, kw) of channel ci for row r of this thread: + ci*PLANE + (8 r + kh*D)*XCP + kw*D
         const float* xt = xs + buf * L::BUF + wave * L::XCP + (4 - D) + lane;
         float acc[RPT][C];
+        if constexpr (MF) {
+            // matrix-pipe form (mfma4 above): lane = pixel, accumulator register = output channel, one group of four channels
+            // per instruction; weights arrive one ds_read_b32 per group (four distinct addresses per wave: a broadcast)
+            constexpr int NG = C / 4;
+            const int l4 = lane & 3;
+            f32x4s av[RPT][NG];
+#pragma unroll
+            for (int r = 0; r < RPT; ++r)
+#pragma unroll
+                for (int gq = 0; gq < NG; ++gq)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) av[r][gq][q] = wimg[S::B1 + 4 * gq + q];
+#pragma unroll 1
+            for (int ci = 0; ci < C; ++ci) {
+                const float* xc = xt + ci * L::PLANE;
+                const float* wc = wimg + S::W1 + ci * 9 * C + l4;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        float w[NG];
+#pragma unroll
+                        for (int gq = 0; gq < NG; ++gq) w[gq] = wc[(kh * 3 + kw) * C + 4 * gq];
+#pragma unroll
+                        for (int r = 0; r < RPT; ++r) {
+                            const float xv = xc[(8 * r + kh * D) * L::XCP + kw * D];
+#pragma unroll
+                            for (int gq = 0; gq < NG; ++gq) av[r][gq] = mfma4(w[gq], xv, av[r][gq]);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < RPT; ++r)
+#pragma unroll
+                for (int co = 0; co < C; ++co) acc[r][co] = av[r][co >> 2][co & 3];
+        } else {
 #pragma unroll
         for (int r = 0; r < RPT; ++r)
 #pragma unroll
@@ -250,6 +298,7 @@ __global__ __launch_bounds__(512) void k_small_lds(const float* __restrict__ x, 
                     }
                 }
             }
+        }
         }
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
@@ -393,8 +442,6 @@ __global__ __launch_bounds__(256) void k_small_bwd_a(const float* __restrict__ x
 //           (summed by k_wgrad3_pack_reduce).
 // HBM traffic per block: h1, dy, x read once (+ halo, mostly L2 hits under the XCD-ordered tile walk), dx written once:
 // 4 tensors instead of 8 (3 + 3 + 2) for the three-kernel path.
-typedef float f32x4s __attribute__((ext_vector_type(4)));
-
 template <int C, int D, int RPT, int NW, int NBUF>
 struct SF {
     static constexpr int TR = NW * RPT, XR = TR + 2 * D, NT = 64 * NW;
@@ -704,6 +751,8 @@ int launch_small_bwd_fused(const float* x, const float* h1, const float* dy, con
 // thread-per-pixel kernels with global taps (kept for unaligned shapes and for A/B measurements)
 inline bool lds_variant() { static const bool v = getenv("TTRAP_SMALL_GLOBAL") == nullptr; return v; }
 
+inline bool small_mfma_variant() { return getenv("TTRAP_SMALL_VALU_FMA") == nullptr; }   // read per call (tests A/B both forms)
+
 template <int C, int D, int MODE>
 int launch_small_lds(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* res, float* y,
                      float* h1, int B, int H, int T, hipStream_t st) {
@@ -711,14 +760,23 @@ int launch_small_lds(const float* x, const float* w1, const float* b1, const flo
     using L = SL<C, D, RPT, NBUF>;
     static AttrOnce attr;
     if (const int adev_ = attr.pending(); adev_ >= 0) {
-        TT_HIP(hipFuncSetAttribute((const void*)k_small_lds<C, D, MODE, RPT, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES));
+        TT_HIP(hipFuncSetAttribute((const void*)k_small_lds<C, D, MODE, RPT, NBUF, false>, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES));
+        TT_HIP(hipFuncSetAttribute((const void*)k_small_lds<C, D, MODE, RPT, NBUF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES));
         attr.mark(adev_);
     }
     const int ntiles = B * ((H + L::TR - 1) / L::TR) * ((T + 63) / 64);
     int per_cu = (160 * 1024) / L::LDS_BYTES;
     if (per_cu > 4) per_cu = 4;
     const int grid = ntiles < tt_cus() * per_cu ? ntiles : tt_cus() * per_cu;
-    hipLaunchKernelGGL((k_small_lds<C, D, MODE, RPT, NBUF>), dim3(grid), dim3(512), L::LDS_BYTES, st, x, w1, b1, w2, b2, res, y, h1, B, H, T);
+    // Measured at the bench shapes (bit-identical results either way): C = 8 forward 0.48-0.53 ms on the matrix pipe against
+    // 0.53-0.59 ms on the vector ALUs, C = 8 data gradient -0.07 ms at dilation 1 and 2 but +0.08 ms at dilation 3 (which
+    // therefore keeps the vector form); C = 4 the same within noise (0.40 ms: that level is not arithmetic-bound) with a third
+    // fewer registers.
+    constexpr bool MF_OK = !(C == 8 && MODE == 1 && D == 3);
+    if (MF_OK && small_mfma_variant())
+        hipLaunchKernelGGL((k_small_lds<C, D, MODE, RPT, NBUF, true>), dim3(grid), dim3(512), L::LDS_BYTES, st, x, w1, b1, w2, b2, res, y, h1, B, H, T);
+    else
+        hipLaunchKernelGGL((k_small_lds<C, D, MODE, RPT, NBUF, false>), dim3(grid), dim3(512), L::LDS_BYTES, st, x, w1, b1, w2, b2, res, y, h1, B, H, T);
     TT_LAUNCH_CHECK();
     return 0;
 }

@@ -22,6 +22,9 @@ namespace {
 constexpr int ROWS_PER_BLOCK = 16;
 #ifndef SMALL_RPT
 #define SMALL_RPT 2
+#endif
+#ifndef SMALL_RPT8
+#define SMALL_RPT8 2
 #endif      // 4 waves x 4 row passes
 
 template <int C>
@@ -756,7 +759,7 @@ inline bool small_mfma_variant() { return getenv("TTRAP_SMALL_VALU_FMA") == null
 template <int C, int D, int MODE>
 int launch_small_lds(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* res, float* y,
                      float* h1, int B, int H, int T, hipStream_t st) {
-    constexpr int RPT = SMALL_RPT, NBUF = (C == 8 && RPT == 2) ? 1 : 2;
+    constexpr int RPT = (C == 8 ? SMALL_RPT8 : SMALL_RPT), NBUF = (C == 8 && RPT == 2) ? 1 : 2;
     using L = SL<C, D, RPT, NBUF>;
     static AttrOnce attr;
     if (const int adev_ = attr.pending(); adev_ >= 0) {

@@ -449,7 +449,7 @@ def main():
             flops = 2.0 * (9 * C * C + C * C) * args.batch * 65 * M_FRAMES
             ach = flops / (a_ms * 1e-3) / 1e12
             traffic, traffic_source = None, None
-            for name in ('r02_pmc_rb_fwd_C32.json', 'r01_f_pmc_rb_fwd_C32.json'):
+            for name in ('r02_d_pmc_rb_fwd_C32.json', 'r02_pmc_rb_fwd_C32.json', 'r01_f_pmc_rb_fwd_C32.json'):
                 pmc = os.path.join(ROOT, 'profiles', name)
                 if C == 32 and args.batch == 64 and args.precision == 'fp32' and os.path.exists(pmc):
                     traffic = json.load(open(pmc))['traffic_bytes_corrected']

@@ -423,3 +423,34 @@ def test_window_overlap_add_kernel_is_bit_identical_to_the_sequential_loop():
             part = outs[c0:c1].contiguous()
             _hip.check(lib.tt_window_ola(_hip.ptr(part), _hip.ptr(window), _hip.ptr(got), B * 2 * F, Mw, c0, c1, n_frames, _hip.stream_ptr()))
         assert torch.equal(got, want), split
+
+
+def test_run_to_run_reproducibility_bounds():
+    """
+    DESIGN.md section 4 "Reproducibility": forward values, losses and the 3x3 weight gradients are order-deterministic (bitwise
+    equal run to run); the gradients that end in cross-workgroup fp32 atomics (1x1 weights and biases of the residual blocks,
+    biases of the strided layers, boundary-conv weights, latent heads) agree to round-off.
+    """
+    from timbre_trap.framework import compute_reconstruction_loss
+    kw = KW['mc2']
+    sd = oae.closed_form_state_dict(oae.state_dict_shapes(540, **kw), amplitude=0.06)
+    coeffs = stub_cqt.closed_form_coefficients(2, 540, 256).cuda()
+    runs = []
+    for _ in range(2):
+        model = _model(kw, sd)
+        latents, _, _ = model.encoder(coeffs)
+        rec = model.decode(latents, None)
+        loss = compute_reconstruction_loss(rec, coeffs)
+        loss.backward()
+        runs.append((rec.detach().clone(), float(loss), {k: p.grad.clone() for k, p in model.named_parameters()}))
+    assert torch.equal(runs[0][0], runs[1][0]) and runs[0][1] == runs[1][1]
+    exact, loose = 0, 0
+    for k in runs[0][2]:
+        a, b = runs[0][2][k], runs[1][2][k]
+        if k.endswith('conv1.0.weight'):                     # 3x3 weight gradients: two-stage reductions
+            assert torch.equal(a, b), k
+            exact += 1
+        else:
+            assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max() + 1e-30), k
+            loose += 1
+    assert exact == 24 and loose > 0

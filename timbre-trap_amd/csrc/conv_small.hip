@@ -183,8 +183,13 @@ struct SL {
     static constexpr int LDS_BYTES = (NBUF * BUF + SW<C>::FLOATS) * 4;
 };
 
+#ifndef SMALL_LB8
+#define SMALL_LB8 1      // waves per SIMD the C = 8 forward kernel is compiled for.  Measured: 6 (80 registers, a handful spilled,
+                         // three workgroups per CU) 0.75-1.05 ms and 5 0.73-0.78 ms against 0.49-0.54 ms uncapped -- the spills cost
+                         // far more than the third workgroup hides
+#endif
 template <int C, int D, int MODE, int RPT, int NBUF, bool MF>
-__global__ __launch_bounds__(512) void k_small_lds(const float* __restrict__ x, const float* __restrict__ w1,
+__global__ __launch_bounds__(512, (C == 8 && MODE == 0 && MF ? SMALL_LB8 : 1)) void k_small_lds(const float* __restrict__ x, const float* __restrict__ w1,
                                                    const float* __restrict__ b1, const float* __restrict__ w2,
                                                    const float* __restrict__ b2, const float* __restrict__ res,
                                                    float* __restrict__ y, float* __restrict__ h1out, int B, int H, int T) {

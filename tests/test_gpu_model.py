@@ -450,3 +450,26 @@ def test_run_to_run_reproducibility_bounds():
         assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max() + 1e-30), k
         exact += bool(torch.equal(a, b))
     print('bitwise-identical gradients: %d of %d' % (exact, len(runs[0][2])))
+
+
+@pytest.mark.parametrize('precision,tol', [('bf16x3', 2e-4), ('bf16', 2e-2)])
+def test_reduced_precision_training_tracks_fp32(precision, tol, monkeypatch):
+    """
+    The opt-in matrix-core precisions as TRAINING arithmetic: four clip + AdamW steps at mc 2 / latent 128 (T = 256) follow the
+    fp32 run's loss sequence within the mode's tolerance (split-bf16: fp32-class; single-rounded bf16: percent-class).
+    """
+    from timbre_trap.framework import ops
+    from timbre_trap.utils import FusedAdamW
+    kw = KW['mc2']
+    sd = oae.closed_form_state_dict(oae.state_dict_shapes(540, **kw), amplitude=0.06)
+    coeffs = stub_cqt.closed_form_coefficients(2, 540, 256).cuda()
+    gt = stub_cqt.closed_form_targets(2, 540, 256).cuda()
+
+    def run(mode):
+        monkeypatch.setattr(ops, 'PRECISION', mode)
+        model = _model(kw, sd)
+        opt = FusedAdamW(model.parameters(), lr=1e-3, max_norm=10.0)
+        return [float(_train_step(model, opt, coeffs, gt)[0]) for _ in range(4)]
+    ref, got = run('fp32'), run(precision)
+    assert ref[-1] < ref[0]                                   # it does train
+    np.testing.assert_allclose(got, ref, rtol=tol)

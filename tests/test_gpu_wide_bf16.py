@@ -1,0 +1,193 @@
+"""
+GPU parity of the bf16-storage residual blocks of the wide levels (csrc/conv_wide_bf16.hip; reference modules.py:721-777).
+
+The kernels round activations, activation gradients and matrix operands to bf16 and accumulate in fp32.  Two kinds of check:
+  * STAGE-WISE, tight: a float64 restatement that applies the same roundings at the same places (inputs and weights rounded
+    to bf16, every stage fed with the kernel's own stored input) must agree with each stored tensor to bf16 rounding
+    (2^-8 relative + a small absolute term) and with the fp32 weight gradients to 2e-4 -- an indexing error of any kind
+    (tap, channel permutation, halo, tile edge) shows up at O(1);
+  * END-TO-END, at the honest bf16 tolerance: the level function against the fp64 oracle of the unrounded blocks.
+Shapes cover ragged tile edges (T not a multiple of 64, H not a multiple of 8 or 4) and, through tt_set_cu_limit, the
+persistent multi-tile loops.
+"""
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import autoencoder as oae
+
+pytestmark = pytest.mark.gpu
+
+BF16_REL = 2.0 ** -8
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def _r16(t):
+    """round to bf16, return float64."""
+    return t.float().bfloat16().double()
+
+
+def _planar(t_nhwc):
+    """bf16 (B,H,T,C) device tensor -> float64 (B,C,H,T) on the CPU."""
+    return t_nhwc.float().permute(0, 3, 1, 2).contiguous().cpu().double()
+
+
+def _close16(got, want, name, abs_scale=None):
+    """|got - want| within bf16 rounding of want (+ a small absolute term relative to the tensor's magnitude)."""
+    scale = float(want.abs().max()) if abs_scale is None else abs_scale
+    tol = BF16_REL * want.abs() + 2e-3 * scale + 1e-30
+    bad = (got - want).abs() > tol
+    assert not bool(bad.any()), '%s: %d of %d outside bf16 rounding, worst %.3e (scale %.3e)' % (
+        name, int(bad.sum()), bad.numel(), float((got - want).abs().max()), scale)
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.fixture
+def cu_limit():
+    from timbre_trap import _hip
+    lib = _hip.lib()
+    prev = lib.tt_set_cu_limit(0)
+    yield lib.tt_set_cu_limit
+    lib.tt_set_cu_limit(prev)
+
+
+def _elu_grad(a):
+    return torch.where(a > 0, torch.ones_like(a), torch.exp(a))
+
+
+def _stagewise(C, d, B, H, T):
+    from timbre_trap import _hip
+    from timbre_trap._hip import check, ptr, stream_ptr
+    lib, st = _hip.lib(), stream_ptr()
+    x = _rand(B, C, H, T, seed=1)
+    w1 = _rand(C, C, 3, 3, seed=2, scale=1.0 / (3 * C ** 0.5))
+    b1 = _rand(C, seed=3, scale=0.3)
+    w2 = _rand(C, C, 1, 1, seed=4, scale=1.0 / C ** 0.5)
+    b2 = _rand(C, seed=5, scale=0.3)
+    gy = _rand(B, C, H, T, seed=6)
+    dev = lambda t: t.cuda().contiguous()
+    xd, w1d, b1d, w2d, b2d, gyd = (dev(t) for t in (x, w1, b1, w2, b2, gy))
+
+    def nhwc():
+        return torch.empty((B, H, T, C), dtype=torch.bfloat16, device='cuda')
+
+    # layout change: exact bf16 rounding, and its inverse
+    xb, gb = nhwc(), nhwc()
+    check(lib.tt_wide_pack(ptr(xd), ptr(xb), B, C, H, T, st), 'pack')
+    check(lib.tt_wide_pack(ptr(gyd), ptr(gb), B, C, H, T, st), 'pack')
+    assert torch.equal(xb.cpu(), x.bfloat16().permute(0, 2, 3, 1).contiguous())
+    back = torch.empty_like(xd)
+    check(lib.tt_wide_unpack(ptr(xb), ptr(back), B, C, H, T, st), 'unpack')
+    assert torch.equal(back.cpu(), x.bfloat16().float())
+
+    # forward
+    yb, hb = nhwc(), nhwc()
+    check(lib.tt_wide_rb_fwd(ptr(xb), ptr(w1d), ptr(b1d), ptr(w2d), ptr(b2d), ptr(yb), ptr(hb), B, C, H, T, d, st), 'fwd')
+    y2 = nhwc()
+    check(lib.tt_wide_rb_fwd(ptr(xb), ptr(w1d), ptr(b1d), ptr(w2d), ptr(b2d), ptr(y2), None, B, C, H, T, d, st), 'fwd')
+    torch.cuda.synchronize()
+    assert torch.equal(yb, y2), 'output must not depend on whether the hidden activation is saved'
+    xr, gr = _r16(x), _r16(gy)
+    w1r, w2r = _r16(w1), _r16(w2)
+    h_ref = F.elu(F.conv2d(xr, w1r, b1.double(), padding=d, dilation=d))
+    h_k = _planar(hb)
+    _close16(h_k, h_ref, 'h1')
+    a2 = F.conv2d(h_k, w2r, b2.double())
+    _close16(_planar(yb), F.elu(a2) + xr, 'y')
+
+    # backward
+    ws = torch.zeros(lib.tt_wide_scratch_bytes(B, C, H, T), dtype=torch.uint8, device='cuda')
+    dxb = nhwc()
+    grads = [torch.full(s, 0.5, dtype=torch.float32, device='cuda') for s in ((C, C, 3, 3), (C,), (C, C, 1, 1), (C,))]
+    check(lib.tt_wide_rb_bwd(ptr(xb), ptr(hb), ptr(gb), ptr(w1d), ptr(w2d), ptr(b2d), ptr(dxb), ptr(grads[0]), ptr(grads[1]),
+                             ptr(grads[2]), ptr(grads[3]), ptr(ws), B, C, H, T, d, st), 'bwd')
+    torch.cuda.synchronize()
+    da1_k = _planar(ws[:B * H * T * C * 2].view(torch.bfloat16).view(B, H, T, C))
+    dA2 = gr * _elu_grad(a2)
+    dA2r = _r16(dA2)
+    dh1 = F.conv2d(dA2r, w2r.transpose(0, 1).contiguous())
+    dA1 = dh1 * torch.where(h_k > 0, torch.ones_like(h_k), h_k + 1)
+    _close16(da1_k, dA1, 'dA1')
+    dx_ref = gr + F.conv_transpose2d(da1_k, w1r, padding=d, dilation=d)
+    _close16(_planar(dxb), dx_ref, 'dx')
+    # weight gradients from the kernel's own dA1 (fp32 accumulation of exact bf16 products): += semantics on top of 0.5
+    xp = F.pad(xr, (d, d, d, d))
+    dw1_ref = torch.stack([torch.stack([
+        torch.einsum('bohw,bihw->oi', da1_k, xp[:, :, kh * d: kh * d + H, kw * d: kw * d + T]) for kw in range(3)], -1)
+        for kh in range(3)], -2)
+    assert _rel(grads[0].cpu().double() - 0.5, dw1_ref) < 2e-4, 'dw1'
+    dw2_ref = torch.einsum('bohw,bihw->oi', dA2r, h_k)
+    assert _rel(grads[2].cpu().double().view(C, C) - 0.5, dw2_ref) < 2e-3, 'dw2'
+    assert _rel(grads[1].cpu().double() - 0.5, dA1.sum((0, 2, 3))) < 2e-3, 'db1'
+    assert _rel(grads[3].cpu().double() - 0.5, dA2.sum((0, 2, 3))) < 2e-3, 'db2'
+
+
+@pytest.mark.parametrize('C', [16, 32])
+@pytest.mark.parametrize('d', [1, 2, 3])
+@pytest.mark.parametrize('shape', [(2, 11, 80), (1, 8, 64), (3, 5, 150), (1, 21, 16)])
+def test_wide_block_stagewise(C, d, shape):
+    _stagewise(C, d, *shape)
+
+
+@pytest.mark.parametrize('C,d,shape,cus', [(32, 3, (1, 65, 256), 1), (16, 2, (2, 37, 320), 1), (32, 1, (3, 20, 200), 2),
+                                           (16, 3, (1, 133, 128), 3)])
+def test_wide_block_multitile(C, d, shape, cus, cu_limit):
+    """Every workgroup walks many tiles (grid capped at 2 * cus workgroups)."""
+    cu_limit(cus)
+    _stagewise(C, d, *shape)
+
+
+@pytest.mark.parametrize('C', [16, 32])
+def test_wide_level_matches_oracle(C):
+    """Three blocks (d = 1, 2, 3) through WideLevelFn against the fp64 oracle of the unrounded blocks, bf16 tolerance."""
+    from timbre_trap.framework import ops
+    B, H, T = 2, 19, 96
+    x = _rand(B, C, H, T, seed=11)
+    gy = _rand(B, C, H, T, seed=12)
+    params = []
+    for i in range(3):
+        params += [_rand(C, C, 3, 3, seed=20 + i, scale=1.0 / (3 * C ** 0.5)), _rand(C, seed=30 + i, scale=0.3),
+                   _rand(C, C, 1, 1, seed=40 + i, scale=1.0 / C ** 0.5), _rand(C, seed=50 + i, scale=0.3)]
+    ref_x = x.double().requires_grad_(True)
+    ref_p = [p.double().requires_grad_(True) for p in params]
+    yr = ref_x
+    for i in range(3):
+        sd = {'p.conv1.0.weight': ref_p[4 * i], 'p.conv1.0.bias': ref_p[4 * i + 1], 'p.conv2.0.weight': ref_p[4 * i + 2],
+              'p.conv2.0.bias': ref_p[4 * i + 3]}
+        yr = oae.residual_block(yr, sd, 'p', i + 1)
+    yr.backward(gy.double())
+    dx_ = x.cuda().requires_grad_(True)
+    dp = [p.cuda().requires_grad_(True) for p in params]
+    y = ops.WideLevelFn.apply(dx_, (1, 2, 3), *dp)
+    y.backward(gy.cuda())
+    assert _rel(y.cpu().double(), yr.detach()) < 2e-2
+    assert _rel(dx_.grad.cpu().double(), ref_x.grad) < 3e-2
+    for got, want in zip(dp, ref_p):
+        assert _rel(got.grad.cpu().double(), want.grad) < 3e-2
+
+
+def test_level_dispatch(monkeypatch):
+    """modules route a wide level through WideLevelFn exactly when ops.wide_storage() says bf16."""
+    from timbre_trap.framework import modules, ops
+    torch.manual_seed(0)
+    blk = modules.EncoderBlock(16, 32).cuda()
+    x = _rand(1, 16, 12, 64, seed=3).cuda()
+    monkeypatch.setattr(ops, 'PRECISION', 'fp32')
+    monkeypatch.setattr(ops, 'WIDE_STORAGE', '')
+    assert ops.wide_storage() == 'fp32'
+    y32 = blk(x)
+    monkeypatch.setattr(ops, 'PRECISION', 'bf16')
+    assert ops.wide_storage() == 'bf16'
+    y16 = blk(x)
+    assert not torch.equal(y32, y16)
+    assert _rel(y16.cpu().double(), y32.cpu().double()) < 3e-2
+    monkeypatch.setattr(ops, 'WIDE_STORAGE', 'fp32')      # bf16 operands, fp32 storage: the round-1 mode
+    assert ops.wide_storage() == 'fp32'

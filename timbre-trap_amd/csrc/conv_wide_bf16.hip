@@ -1,0 +1,749 @@
+// bf16-STORAGE residual blocks of the wide levels (C = 16, 32; reference modules.py:721-777) for gfx950.
+//
+// The fp32 kernels of conv_mfma.hip keep every activation as fp32, channel-planar (B,C,H,T); their bf16 modes only round
+// the matrix operands, so nothing in HBM gets narrower.  Here the activations of a level live in HBM as bf16,
+// CHANNEL-INNERMOST  [B][H][T][C]:
+//   * one pixel's channels are one contiguous 32 / 64 bytes, so the K = channels slice of an operand of
+//     v_mfma_f32_16x16x32_bf16 (8 bf16 per lane) is ONE 16-byte LDS read (ds_read_b128) -- no conversion, no packing;
+//   * a tile row with its halo is one contiguous run in HBM and goes to LDS by LDS-DMA (global_load_lds_dwordx4),
+//     out-of-image pieces sourced from a zero page ('same' padding);
+//   * the accumulator layout of the 3x3 product (lane = pixel, registers = channels) IS the B-operand layout of the 1x1
+//     product, so ELU(conv3x3) feeds conv1x1 from registers, and every epilogue access is 16 bytes per lane.
+// All weights are fp32 in HBM (master copy) and are rounded to bf16 into REGISTERS once per workgroup; products accumulate
+// in fp32; bias, ELU and the residual add are fp32; stored activations and activation gradients are bf16 (round to nearest
+// even).  Weight and bias gradients are fp32.
+//
+// Kernels (all persistent, XCD-ordered tile walk):
+//   k_wide_pack / k_wide_unpack    fp32 planar <-> bf16 channel-innermost at the two ends of a level
+//   k_wrb_conv<C,D,0>              y = ELU(W2 . ELU(W1 (*)_D x + b1) + b2) + x, optionally saving h1 = ELU(W1 (*) x + b1)
+//   k_wrb_conv<C,D,1>              dx = dy + W1^T (*)_D dA1   (same main loop, weights transposed and taps reversed)
+//   k_wrb_bwd_a<C>                 pointwise chain of the backward: a2 = W2 h1 + b2, dA2 = dy ELU'(a2), dh1 = W2^T dA2,
+//                                  dA1 = dh1 ELU'(a1); dW2, db1, db2 partials
+//   k_wrb_wgrad<C,D>               dW1[co][ci][tap] = sum_pix dA1[co][pix] x[ci][pix + tap]: K = pixels, both operands by
+//                                  LDS transpose reads (ds_read_b64_tr_b16) from channel-innermost images
+//   k_wrb_reduce<C>                sums the per-wave register dumps into the fp32 gradients (+=), no atomics anywhere
+#include "common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int NT = 256;                        // threads per workgroup (4 waves)
+
+__device__ float4 g_wzero16;                   // DMA source of out-of-image pieces
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+// A (16 x 32) . B (32 x 16): lane l holds row / column l & 15 and k = 8 (l >> 4) + j; D: column l & 15, rows 4 (l >> 4) + r
+__device__ __forceinline__ f32x4 mma32(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+// K = 16: lane l holds k = 4 (l >> 4) + j
+__device__ __forceinline__ f32x4 mma16(s16x4 a, s16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
+
+__device__ __forceinline__ int xcd_order(int v, int n) {          // see conv_mfma.hip: one contiguous eighth of the raster per XCD
+    const int per = n >> 3;
+    return v < (per << 3) ? (v & 7) * per + (v >> 3) : v;
+}
+__device__ __forceinline__ float elu_f(float a) { return a > 0.f ? a : (__expf(a) - 1.f); }
+
+// Channel held by row m of co-tile ct.  C = 32: rows 4q..4q+3 of tile 0 / 1 are channels 8q..8q+3 / 8q+4..8q+7, so the
+// lane that owns D rows 4g..4g+3 of both tiles owns the eight CONSECUTIVE channels 8g..8g+7 (16 bytes).  C = 16: identity.
+template <int C> __device__ __forceinline__ int chan_of(int ct, int m) { return C == 32 ? 8 * (m >> 2) + 4 * ct + (m & 3) : m; }
+
+// ---- layout change at the ends of a level --------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(NT) void k_wide_pack(const float* __restrict__ x, __bf16* __restrict__ out, int H, int T, long npix) {
+    constexpr int CG = C / 8;
+    const long i = (long)blockIdx.x * NT + threadIdx.x;         // one 16-byte piece: pixel i / CG, channels 8 (i % CG) ..
+    const long pix = i / CG;
+    if (pix >= npix) return;
+    const int cg = (int)(i - pix * CG);
+    const long plane = (long)H * T;
+    const long b = pix / plane, o = pix - b * plane;
+    const float* s = x + (b * C + cg * 8) * plane + o;
+    bf16x8 q;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) q[j] = (__bf16)s[j * plane];
+    *reinterpret_cast<bf16x8*>(out + pix * C + cg * 8) = q;
+}
+template <int C>
+__global__ __launch_bounds__(NT) void k_wide_unpack(const __bf16* __restrict__ in, float* __restrict__ y, int H, int T, long npix) {
+    constexpr int CG = C / 8;
+    const long i = (long)blockIdx.x * NT + threadIdx.x;
+    const long pix = i / CG;
+    if (pix >= npix) return;
+    const int cg = (int)(i - pix * CG);
+    const long plane = (long)H * T;
+    const long b = pix / plane, o = pix - b * plane;
+    const bf16x8 q = *reinterpret_cast<const bf16x8*>(in + pix * C + cg * 8);
+    float* d = y + (b * C + cg * 8) * plane + o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d[j * plane] = (float)q[j];
+}
+
+// ---- 3x3 main loop: block forward and data gradient ------------------------------------------------------------------
+template <int C, int D> struct WT {
+    static constexpr int TH = 8, TW = 64;
+    static constexpr int CG = C / 8;
+    static constexpr int RW = TW + 2 * D, ROWS = TH + 2 * D;
+    static constexpr int NP = ROWS * RW * CG;                   // 16-byte pieces of the tile with its halo
+    static constexpr int NPR = (NP + NT - 1) / NT * NT;         // whole DMA instructions for every wave
+    static constexpr int LDS_BYTES = NPR * 16;
+};
+
+// MODE 0: x -> y (and h1 if SAVE).  MODE 1: x = dA1, res = dy, y = dx; b1 / w2 / b2 unused.
+template <int C, int D, int MODE, bool SAVE>
+__global__ __launch_bounds__(NT, 2) void k_wrb_conv(const __bf16* __restrict__ x, const float* __restrict__ w1,
+                                                 const float* __restrict__ b1, const float* __restrict__ w2,
+                                                 const float* __restrict__ b2, const __bf16* __restrict__ res,
+                                                 __bf16* __restrict__ y, __bf16* __restrict__ h1, int B, int H, int T,
+                                                 int tiles_h, int tiles_t, int ntiles) {
+    using G = WT<C, D>;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    constexpr int NCT = C / 16;                                  // co-tiles
+    constexpr int NK = C == 32 ? 9 : 5;                          // products per co-tile: one tap (C = 32) / two taps (C = 16)
+    constexpr int NCH = C == 32 ? 8 : 4;                         // channels a lane ends up with
+
+    // ---- weights to registers, rounded to bf16 ----
+    bf16x8 A[NK][NCT];
+#pragma unroll
+    for (int k = 0; k < NK; ++k)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                int tap, kc;                                     // tap and contraction channel of this lane's k = 8 g + j
+                if (C == 32) { tap = k; kc = 8 * g + j; }
+                else { tap = 2 * k + (g >> 1); kc = 8 * (g & 1) + j; }
+                const int mo = chan_of<C>(ct, n);                // output channel of row n
+                float wv = 0.f;
+                if (tap < 9) wv = MODE == 0 ? w1[(mo * C + kc) * 9 + tap] : w1[(kc * C + mo) * 9 + (8 - tap)];
+                v[j] = wv;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) A[k][ct][j] = (__bf16)v[j];
+        }
+    bf16x8 A2[NCT];                                              // C = 32: W2 rows (K = 32)
+    s16x4 A2s;                                                   // C = 16: W2 rows (K = 16)
+    float b1r[NCH], b2r[NCH];
+    if constexpr (MODE == 0) {
+        if constexpr (C == 32) {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) A2[ct][j] = (__bf16)w2[chan_of<C>(ct, n) * C + 8 * g + j];
+        } else {
+            bf16x4 t;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[j] = (__bf16)w2[n * C + 4 * g + j];
+            A2s = __builtin_bit_cast(s16x4, t);
+        }
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) { b1r[j] = b1[NCH * g + j]; b2r[j] = b2[NCH * g + j]; }
+    }
+
+    const __bf16* zero = reinterpret_cast<const __bf16*>(&g_wzero16);
+    for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
+        int tile = xcd_order(v, ntiles);
+        const int tt = tile % tiles_t; tile /= tiles_t;
+        const int th = tile % tiles_h;
+        const int b = tile / tiles_h, h0 = th * G::TH, t0 = tt * G::TW;
+        const __bf16* xb = x + (long)b * H * T * C;
+
+        __syncthreads();                                         // the previous tile has been consumed
+        for (int i = wave * 64; i < G::NPR; i += NT) {
+            const int p = i + lane;
+            const int row = p / (G::RW * G::CG), rem = p - row * (G::RW * G::CG);
+            const int px = rem / G::CG, cg = rem - px * G::CG;
+            const int h = h0 - D + row, t = t0 - D + px;
+            const bool ok = p < G::NP && (unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T;
+            glds16(ok ? xb + ((long)h * T + t) * C + cg * 8 : zero, smem + (long)i * 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        const int c0 = wave * 16;
+        const int t = t0 + c0 + n;
+        for (int r = 0; r < G::TH; ++r) {
+            const int h = h0 + r;
+            if (h >= H) break;
+            const long pix = ((long)b * H + h) * T + t;
+            const bool valid = t < T;
+            f32x4 acc[NCT];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            typename std::conditional<C == 32, bf16x8, bf16x4>::type rq;      // MODE 1: dy of this pixel, requested early
+            if constexpr (MODE == 1)            // unconditional (clamped) so that no branch pins a wait in front of the products
+                rq = *reinterpret_cast<const decltype(rq)*>(res + (valid ? pix : pix - (t - (T - 1))) * C + NCH * g);
+            bf16x8 centre;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                int tap = C == 32 ? k : 2 * k + (g >> 1);
+                if (tap > 8) tap = 8;                            // the weights of the missing tenth tap are zero
+                const int kh = tap / 3, kw = tap - 3 * kh;
+                const int pxi = (r + kh * D) * G::RW + (c0 + n + kw * D);
+                const int cho = C == 32 ? 8 * g : 8 * (g & 1);
+                const bf16x8 bq = *reinterpret_cast<const bf16x8*>(smem + ((long)pxi * C + cho) * 2);
+                if (C == 32 && k == 4) centre = bq;
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) acc[ct] = mma32(A[k][ct], bq, acc[ct]);
+            }
+            float val[NCH];
+            if constexpr (C == 32) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { val[j] = acc[0][j]; val[4 + j] = acc[1][j]; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) val[j] = acc[0][j];
+            }
+            if constexpr (MODE == 1) {
+                if (valid) {
+                    if constexpr (C == 32) {
+                        bf16x8 o;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) o[j] = (__bf16)(val[j] + (float)rq[j]);
+                        *reinterpret_cast<bf16x8*>(y + pix * C + 8 * g) = o;
+                    } else {
+                        bf16x4 o;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = (__bf16)(val[j] + (float)rq[j]);
+                        *reinterpret_cast<bf16x4*>(y + pix * C + 4 * g) = o;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) val[j] = elu_f(val[j] + b1r[j]);
+                if constexpr (C == 32) {
+                    bf16x8 hq;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) hq[j] = (__bf16)val[j];
+                    if (SAVE && valid) *reinterpret_cast<bf16x8*>(h1 + pix * C + 8 * g) = hq;
+                    f32x4 z0 = mma32(A2[0], hq, f32x4{0.f, 0.f, 0.f, 0.f});
+                    f32x4 z1 = mma32(A2[1], hq, f32x4{0.f, 0.f, 0.f, 0.f});
+                    bf16x8 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        o[j] = (__bf16)(elu_f(z0[j] + b2r[j]) + (float)centre[j]);
+                        o[4 + j] = (__bf16)(elu_f(z1[j] + b2r[4 + j]) + (float)centre[4 + j]);
+                    }
+                    if (valid) *reinterpret_cast<bf16x8*>(y + pix * C + 8 * g) = o;
+                } else {
+                    bf16x4 hq;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) hq[j] = (__bf16)val[j];
+                    if (SAVE && valid) *reinterpret_cast<bf16x4*>(h1 + pix * C + 4 * g) = hq;
+                    const f32x4 z = mma16(A2s, __builtin_bit_cast(s16x4, hq), f32x4{0.f, 0.f, 0.f, 0.f});
+                    const int pxc = (r + D) * G::RW + (c0 + n + D);
+                    const bf16x4 xc = *reinterpret_cast<const bf16x4*>(smem + ((long)pxc * C + 4 * g) * 2);
+                    bf16x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (__bf16)(elu_f(z[j] + b2r[j]) + (float)xc[j]);
+                    if (valid) *reinterpret_cast<bf16x4*>(y + pix * C + 4 * g) = o;
+                }
+            }
+        }
+    }
+}
+
+// ---- pointwise chain of the backward ---------------------------------------------------------------------------------
+// One wave per group of 16 consecutive pixels (the tensor is [npix][C]); operands straight from HBM in B-operand layout.
+// Every workgroup leaves its accumulators as a raw register dump [dW2: ((a NCT + c) 4 + r) 64 + lane][db1 C][db2 C]
+// (the four waves summed through LDS); k_wrb_reduce sums the dumps of all workgroups (no atomics anywhere).
+//
+// ds_read_b64_tr_b16 (gfx950 transpose read), per 16-lane group: lane 4j + q supplies the address of 4 consecutive bf16
+// (row j, columns 4q..4q+3); lane i receives column i of rows 0..3.  With rows = pixels and columns = the 16 channels of a
+// tile that is the K = pixels operand of v_mfma_f32_16x16x16_bf16 straight from a channel-innermost LDS image.
+__device__ __forceinline__ s16x4 lds_tr16(const unsigned char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+
+template <int C> struct WA {
+    static constexpr int PS = C * 2 + 8;                         // bytes per pixel of the transposition buffers (bank spread)
+    static constexpr int WAVE_BYTES = 2 * 16 * PS;               // dA2 and h1 of one group
+    static constexpr int DUMP = C * C + 2 * C;                   // floats per wave
+    static constexpr int LDS_BYTES = 4 * WAVE_BYTES > 16 * DUMP ? 4 * WAVE_BYTES : 16 * DUMP;
+};
+
+template <int C>
+__global__ __launch_bounds__(NT) void k_wrb_bwd_a(const __bf16* __restrict__ h1, const __bf16* __restrict__ dy,
+                                                  const float* __restrict__ w2, const float* __restrict__ b2,
+                                                  __bf16* __restrict__ da1, float* __restrict__ part, long npix, long ngroups) {
+    using G = WA<C>;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    constexpr int NCT = C / 16;
+    constexpr int NCH = C == 32 ? 8 : 4;
+    typedef typename std::conditional<C == 32, bf16x8, bf16x4>::type vec_t;     // a lane's channels of one pixel
+
+    // W2 (rows = output channel) and W2^T (rows = input channel), both with the row order of chan_of
+    bf16x8 A2[NCT], A2T[NCT];
+    s16x4 A2s, A2Ts;
+    if constexpr (C == 32) {
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                A2[ct][j] = (__bf16)w2[chan_of<C>(ct, n) * C + 8 * g + j];
+                A2T[ct][j] = (__bf16)w2[(8 * g + j) * C + chan_of<C>(ct, n)];
+            }
+    } else {
+        bf16x4 a, at;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[j] = (__bf16)w2[n * C + 4 * g + j]; at[j] = (__bf16)w2[(4 * g + j) * C + n]; }
+        A2s = __builtin_bit_cast(s16x4, a); A2Ts = __builtin_bit_cast(s16x4, at);
+    }
+    float b2r[NCH], db1a[NCH], db2a[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) { b2r[j] = b2[NCH * g + j]; db1a[j] = 0.f; db2a[j] = 0.f; }
+    f32x4 dw2[NCT][NCT];
+#pragma unroll
+    for (int a = 0; a < NCT; ++a)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) dw2[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    unsigned char* tg = smem + wave * G::WAVE_BYTES;             // this wave's dA2 tile, then its h1 tile
+    unsigned char* thh = tg + 16 * G::PS;
+    const int trj = n >> 2, trq = n & 3;                         // transpose read: this lane supplies row trj, columns 4 trq..
+
+    vec_t zero_v;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) zero_v[j] = (__bf16)0.f;
+    const long gstride = (long)gridDim.x * 4;
+    long grp = (long)blockIdx.x * 4 + wave;
+    vec_t hq = zero_v, dq = zero_v;
+    if (grp < ngroups && grp * 16 + n < npix) {
+        hq = *reinterpret_cast<const vec_t*>(h1 + (grp * 16 + n) * C + NCH * g);
+        dq = *reinterpret_cast<const vec_t*>(dy + (grp * 16 + n) * C + NCH * g);
+    }
+    for (; grp < ngroups; grp += gstride) {
+        const long pix = grp * 16 + n;
+        const bool valid = pix < npix;
+        // next group's operands are on their way while this one is processed
+        const long pn = (grp + gstride) * 16 + n;
+        vec_t hq_n = zero_v, dq_n = zero_v;
+        if (grp + gstride < ngroups && pn < npix) {
+            hq_n = *reinterpret_cast<const vec_t*>(h1 + pn * C + NCH * g);
+            dq_n = *reinterpret_cast<const vec_t*>(dy + pn * C + NCH * g);
+        }
+        float hv[NCH], gv[NCH], a1g[NCH];
+        vec_t gq, aq;
+        f32x4 z[NCT], u[NCT];
+        if constexpr (C == 32) {
+            z[0] = mma32(A2[0], hq, f32x4{0.f, 0.f, 0.f, 0.f});
+            z[1] = mma32(A2[1], hq, f32x4{0.f, 0.f, 0.f, 0.f});
+        } else {
+            z[0] = mma16(A2s, __builtin_bit_cast(s16x4, hq), f32x4{0.f, 0.f, 0.f, 0.f});
+        }
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const float a2 = z[j >> 2][j & 3] + b2r[j];
+            gv[j] = (float)dq[j] * (a2 > 0.f ? 1.f : __expf(a2));
+            gq[j] = (__bf16)gv[j];
+            hv[j] = (float)hq[j];
+        }
+        if constexpr (C == 32) {
+            u[0] = mma32(A2T[0], gq, f32x4{0.f, 0.f, 0.f, 0.f});
+            u[1] = mma32(A2T[1], gq, f32x4{0.f, 0.f, 0.f, 0.f});
+        } else {
+            u[0] = mma16(A2Ts, __builtin_bit_cast(s16x4, gq), f32x4{0.f, 0.f, 0.f, 0.f});
+        }
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            a1g[j] = u[j >> 2][j & 3] * (hv[j] > 0.f ? 1.f : hv[j] + 1.f);
+            aq[j] = (__bf16)a1g[j];
+            db2a[j] += gv[j]; db1a[j] += a1g[j];                  // invalid pixels contribute zeros
+        }
+        if (valid) *reinterpret_cast<vec_t*>(da1 + pix * C + NCH * g) = aq;
+        // transposition buffers: pixel n, this lane's channels, in 8-byte pieces
+        if constexpr (C == 32) {
+            const uint2* gs = reinterpret_cast<const uint2*>(&gq);
+            const uint2* hs = reinterpret_cast<const uint2*>(&hq);
+            uint2* gd = reinterpret_cast<uint2*>(tg + n * G::PS + 16 * g);
+            uint2* hd = reinterpret_cast<uint2*>(thh + n * G::PS + 16 * g);
+            gd[0] = gs[0]; gd[1] = gs[1]; hd[0] = hs[0]; hd[1] = hs[1];
+        } else {
+            *reinterpret_cast<uint2*>(tg + n * G::PS + 8 * g) = __builtin_bit_cast(uint2, gq);
+            *reinterpret_cast<uint2*>(thh + n * G::PS + 8 * g) = __builtin_bit_cast(uint2, hq);
+        }
+        // dW2[co][ci] += sum over the 16 pixels dA2[co][p] h1[ci][p]: the tiles read back transposed
+        // (same wave wrote them: LDS operations of one wave complete in order; the fence only stops the compiler)
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+        s16x4 ga[NCT], hb[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            ga[ct] = lds_tr16(tg + (4 * g + trj) * G::PS + (16 * ct + 4 * trq) * 2);
+            hb[ct] = lds_tr16(thh + (4 * g + trj) * G::PS + (16 * ct + 4 * trq) * 2);
+        }
+#pragma unroll
+        for (int a = 0; a < NCT; ++a)
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) dw2[a][c] = mma16(ga[a], hb[c], dw2[a][c]);
+        asm volatile("" ::: "memory");
+        hq = hq_n; dq = dq_n;
+    }
+
+    // ---- register dumps of the four waves, summed in LDS (plain stores, no atomics), one dump per workgroup ----
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem) + wave * G::DUMP;
+#pragma unroll
+    for (int a = 0; a < NCT; ++a)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[((a * NCT + c) * 4 + r) * 64 + lane] = dw2[a][c][r];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        float s1 = db1a[j], s2 = db2a[j];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        if (n == 0) { red[C * C + NCH * g + j] = s1; red[C * C + C + NCH * g + j] = s2; }
+    }
+    __syncthreads();
+    const float* all = reinterpret_cast<const float*>(smem);
+    float* pw = part + (long)blockIdx.x * G::DUMP;
+    for (int i = tid; i < G::DUMP; i += NT) pw[i] = (all[i] + all[G::DUMP + i]) + (all[2 * G::DUMP + i] + all[3 * G::DUMP + i]);
+}
+
+// ---- 3x3 weight gradient ---------------------------------------------------------------------------------------------
+//   dW1[co][ci][tap] = sum_pix dA1[co][pix] x[ci][pix + tap]     K = pixels, 32 per product (v_mfma_f32_16x16x32_bf16)
+// The x tile (with halo) and the dA1 tile are channel-innermost LDS images filled by LDS-DMA; both operands come out of
+// them by transpose reads (two per operand: pixels 4g..4g+3 and 16+4g..16+4g+3 of the chunk -- the K order is free as long
+// as both operands use the same one).  At C = 32 the two 32-byte halves of a pixel are swapped in every second group of
+// four pixels (a permutation of the DMA sources), which keeps the eight pixels one half-wave reads on different banks.
+// Wave roles: C = 32: ci-tile w & 1, column half w >> 1 (x is the operand read nine times, so it is the one split);
+//             C = 16: column half w & 1, rows of parity w >> 1.
+// Every wave dumps its accumulators [(tap NA + a) 4 + r][lane]; k_wrb_reduce sums the dumps.
+template <int C, int D> struct WG {
+    static constexpr int TH = C == 32 ? 4 : 8, TW = 64;
+    static constexpr int CG = C / 8;
+    static constexpr int RW = TW + 2 * D, ROWS = TH + 2 * D;
+    static constexpr int XP = ROWS * RW * CG, GP = TH * TW * CG;   // 16-byte pieces
+    static constexpr int XPR = (XP + NT - 1) / NT * NT;
+    static constexpr int X_BYTES = XPR * 16, G_BYTES = GP * 16;
+    static constexpr int NA = C / 16;                              // co-tiles a wave accumulates
+    static constexpr int DUMP = 9 * NA * 256;                      // floats per wave
+    static constexpr int LDS_BYTES = X_BYTES + G_BYTES;
+};
+
+template <int C> __device__ __forceinline__ int swz_piece(int q, int cg) { return C == 32 ? (cg ^ (((q >> 2) & 1) << 1)) : cg; }
+
+template <int C, int D>
+__global__ __launch_bounds__(NT) void k_wrb_wgrad(const __bf16* __restrict__ x, const __bf16* __restrict__ da1,
+                                                  float* __restrict__ part, int B, int H, int T, int tiles_h, int tiles_t,
+                                                  int ntiles) {
+    using G = WG<C, D>;
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char* xs = smem;
+    unsigned char* gs = smem + G::X_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int trj = n >> 2, trq = n & 3;
+    constexpr int NA = G::NA;
+    const int cit = C == 32 ? (wave & 1) : 0;                    // ci-tile of this wave
+    const int colh = C == 32 ? (wave >> 1) : (wave & 1);         // 32-pixel column half
+    const int row0 = C == 32 ? 0 : (wave >> 1), rstep = C == 32 ? 1 : 2;
+    f32x4 acc[9][NA];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int a = 0; a < NA; ++a) acc[k][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const __bf16* zero = reinterpret_cast<const __bf16*>(&g_wzero16);
+    for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
+        int tile = xcd_order(v, ntiles);
+        const int tt = tile % tiles_t; tile /= tiles_t;
+        const int th = tile % tiles_h;
+        const int b = tile / tiles_h, h0 = th * G::TH, t0 = tt * G::TW;
+        const __bf16* xb = x + (long)b * H * T * C;
+        const __bf16* gb = da1 + (long)b * H * T * C;
+        __syncthreads();
+        for (int i = wave * 64; i < G::XPR; i += NT) {
+            const int p = i + lane, q = p / G::CG, cg = swz_piece<C>(q, p - q * G::CG);
+            const int row = q / G::RW, px = q - row * G::RW;
+            const int h = h0 - D + row, t = t0 - D + px;
+            const bool ok = p < G::XP && (unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T;
+            glds16(ok ? xb + ((long)h * T + t) * C + cg * 8 : zero, xs + (long)i * 16);
+        }
+        for (int i = wave * 64; i < G::GP; i += NT) {
+            const int p = i + lane, q = p / G::CG, cg = swz_piece<C>(q, p - q * G::CG);
+            const int row = q / G::TW, px = q - row * G::TW;
+            const int h = h0 + row, t = t0 + px;
+            const bool ok = h < H && t < T;
+            glds16(ok ? gb + ((long)h * T + t) * C + cg * 8 : zero, gs + (long)i * 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        const int c0 = colh * 32 + 4 * g + trj;                  // first-half pixel whose address this lane supplies
+        for (int r = row0; r < G::TH; r += rstep) {
+            if (h0 + r >= H) break;
+            // dA1 operand(s): co-tiles 0..NA-1
+            bf16x8 ga[NA];
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                s16x4 lo, hi;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int q = r * G::TW + c0 + 16 * u;
+                    const int half = C == 32 ? ((a ^ ((q >> 2) & 1)) << 5) : 0;
+                    const s16x4 t4 = lds_tr16(gs + (long)q * (C * 2) + half + trq * 8);
+                    if (u == 0) lo = t4; else hi = t4;
+                }
+                ga[a] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int kh = k / 3, kw = k - 3 * kh;
+                s16x4 lo, hi;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int q = (r + kh * D) * G::RW + c0 + 16 * u + kw * D;
+                    const int half = C == 32 ? ((cit ^ ((q >> 2) & 1)) << 5) : 0;
+                    const s16x4 t4 = lds_tr16(xs + (long)q * (C * 2) + half + trq * 8);
+                    if (u == 0) lo = t4; else hi = t4;
+                }
+                const bf16x8 xq = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int a = 0; a < NA; ++a) acc[k][a] = mma32(ga[a], xq, acc[k][a]);
+            }
+        }
+    }
+
+    float* pw = part + ((long)blockIdx.x * 4 + wave) * G::DUMP;
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pw[((k * NA + a) * 4 + r) * 64 + lane] = acc[k][a][r];
+}
+
+// Sum of the register dumps into the fp32 gradients (+=).  1024 threads = 64 consecutive dump elements x 16 slices of the
+// contributing waves; the dump order keeps every load coalesced, the scatter into dW1 / dW2 is the cheap side.
+struct RedArgs {
+    const float* pw; int gw;        // wgrad dumps: gw workgroups x 4 waves
+    const float* pa; int ga;        // bwd_a dumps: one per workgroup
+    float *dw1, *db1, *dw2, *db2;
+};
+template <int C>
+__global__ __launch_bounds__(1024) void k_wrb_reduce(RedArgs ar) {
+    constexpr int NCT = C / 16;
+    constexpr int WDUMP = 9 * NCT * 256, NEW = NCT * WDUMP;      // wgrad: elements = (wave role) x dump
+    constexpr int ADUMP = C * C + 2 * C;
+    __shared__ float red[16][64];
+    const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + el;
+    float sum = 0.f;
+    float* dst = nullptr;
+    if (e < NEW) {
+        const int role = e / WDUMP, rest = e - role * WDUMP;     // C = 32: role = ci-tile = wave & 1;  C = 16: one role
+        constexpr int NS = 4 / NCT;                              // waves per workgroup with the same role
+        const int ncontrib = ar.gw * NS;
+        float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // eight loads in flight per thread
+        for (int j0 = sl; j0 < ncontrib; j0 += 128) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + 16 * u;
+                if (j < ncontrib) {
+                    const int wg = j / NS, s = j - wg * NS;
+                    const int wave = C == 32 ? role + 2 * s : s;
+                    part[u] += ar.pw[((long)wg * 4 + wave) * WDUMP + rest];
+                }
+            }
+        }
+        sum = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+        const int k = rest / (NCT * 256), a = (rest >> 8) % NCT, r = (rest >> 6) & 3, lane = rest & 63;
+        const int co = 16 * a + 4 * (lane >> 4) + r, ci = 16 * role + (lane & 15);
+        dst = ar.dw1 + (co * C + ci) * 9 + k;
+    } else if (e < NEW + ADUMP) {
+        const int q = e - NEW;
+        const int ncontrib = ar.ga;
+        float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int j0 = sl; j0 < ncontrib; j0 += 128) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + 16 * u;
+                if (j < ncontrib) part[u] += ar.pa[(long)j * ADUMP + q];
+            }
+        }
+        sum = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+        if (q < C * C) {
+            const int a = q / (NCT * 256), c = (q >> 8) % NCT, r = (q >> 6) & 3, lane = q & 63;
+            dst = ar.dw2 + (16 * a + 4 * (lane >> 4) + r) * C + 16 * c + (lane & 15);
+        } else if (q < C * C + C) dst = ar.db1 + (q - C * C);
+        else dst = ar.db2 + (q - C * C - C);
+    }
+    red[sl][el] = sum;
+    __syncthreads();
+    if (sl == 0 && dst) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += red[i][el];
+        *dst += s;
+    }
+}
+
+// ---- launchers -------------------------------------------------------------------------------------------------------
+inline int grid_for(int ntiles, int lds_bytes, int max_per_cu) {
+    int per = lds_bytes > 0 ? (160 * 1024) / lds_bytes : max_per_cu;
+    if (per > max_per_cu) per = max_per_cu;
+    if (per < 1) per = 1;
+    const int cap = tt_cus() * per;
+    return ntiles < cap ? ntiles : cap;
+}
+
+template <class K> int raise_lds(K kernel, int bytes, AttrOnce& once) {
+    const int dev = once.pending();
+    if (dev >= 0) {
+        TT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        once.mark(dev);
+    }
+    return 0;
+}
+
+template <int C, int D, int MODE, bool SAVE>
+int launch_conv(const __bf16* x, const float* w1, const float* b1, const float* w2, const float* b2, const __bf16* res,
+                __bf16* y, __bf16* h1, int B, int H, int T, hipStream_t st) {
+    using G = WT<C, D>;
+    static AttrOnce once;
+    auto kern = k_wrb_conv<C, D, MODE, SAVE>;
+    if (int rc = raise_lds(kern, G::LDS_BYTES, once)) return rc;
+    const int tiles_h = (H + G::TH - 1) / G::TH, tiles_t = (T + G::TW - 1) / G::TW, ntiles = B * tiles_h * tiles_t;
+    static const int per_cu = getenv("TTRAP_WIDE_PER_CU") ? atoi(getenv("TTRAP_WIDE_PER_CU")) : 4;
+    hipLaunchKernelGGL(kern, dim3(grid_for(ntiles, G::LDS_BYTES, per_cu)), dim3(NT), G::LDS_BYTES, st, x, w1, b1, w2, b2, res, y, h1,
+                       B, H, T, tiles_h, tiles_t, ntiles);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
+constexpr int MAX_A_WG = 1024, MAX_W_WG = 512;    // workgroups that leave dumps (bounds the scratch)
+template <int C> constexpr long dump_floats() { return (long)MAX_A_WG * WA<C>::DUMP + (long)MAX_W_WG * 4 * 9 * (C / 16) * 256; }
+
+template <int C, int D>
+int launch_bwd(const __bf16* x, const __bf16* h1, const __bf16* dy, const float* w1, const float* w2, const float* b2,
+               __bf16* dx, float* dw1, float* db1, float* dw2, float* db2, unsigned char* ws, int B, int H, int T,
+               hipStream_t st) {
+    const long npix = (long)B * H * T;
+    __bf16* da1 = reinterpret_cast<__bf16*>(ws);
+    float* part_a = reinterpret_cast<float*>(ws + ((npix * C * 2 + 255) / 256) * 256);
+    float* part_w = part_a + (long)MAX_A_WG * WA<C>::DUMP;
+    // pointwise chain
+    using G = WA<C>;
+    static AttrOnce once;
+    auto kern = k_wrb_bwd_a<C>;
+    if (int rc = raise_lds(kern, G::LDS_BYTES, once)) return rc;
+    const long ngroups = (npix + 15) / 16;
+    const long want = (ngroups + 3) / 4;
+    int grid = (int)(want < (long)4 * tt_cus() ? want : (long)4 * tt_cus());
+    if (grid > MAX_A_WG) grid = MAX_A_WG;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), G::LDS_BYTES, st, h1, dy, w2, b2, da1, part_a, npix, ngroups);
+    TT_LAUNCH_CHECK();
+    // data gradient
+    if (int rc = launch_conv<C, D, 1, false>(da1, w1, nullptr, nullptr, nullptr, dy, dx, nullptr, B, H, T, st)) return rc;
+    // weight gradient
+    using W = WG<C, D>;
+    static AttrOnce once_w;
+    auto kw = k_wrb_wgrad<C, D>;
+    if (int rc = raise_lds(kw, W::LDS_BYTES, once_w)) return rc;
+    const int tiles_h = (H + W::TH - 1) / W::TH, tiles_t = (T + W::TW - 1) / W::TW, ntiles = B * tiles_h * tiles_t;
+    int gw = grid_for(ntiles, W::LDS_BYTES, 2);
+    if (gw > MAX_W_WG) gw = MAX_W_WG;
+    hipLaunchKernelGGL(kw, dim3(gw), dim3(NT), W::LDS_BYTES, st, x, da1, part_w, B, H, T, tiles_h, tiles_t, ntiles);
+    TT_LAUNCH_CHECK();
+    RedArgs ra{part_w, gw, part_a, grid, dw1, db1, dw2, db2};
+    constexpr int total = 9 * C * C + C * C + 2 * C;
+    hipLaunchKernelGGL(k_wrb_reduce<C>, dim3((total + 63) / 64), dim3(1024), 0, st, ra);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int C>
+int fwd_c(const __bf16* x, const float* w1, const float* b1, const float* w2, const float* b2, __bf16* y, __bf16* h1, int B,
+          int H, int T, int D, hipStream_t st) {
+#define TT_WFWD(DD)                                                                                                  \
+    return h1 ? launch_conv<C, DD, 0, true>(x, w1, b1, w2, b2, nullptr, y, h1, B, H, T, st)                           \
+              : launch_conv<C, DD, 0, false>(x, w1, b1, w2, b2, nullptr, y, nullptr, B, H, T, st)
+    switch (D) {
+        case 1: TT_WFWD(1);
+        case 2: TT_WFWD(2);
+        case 3: TT_WFWD(3);
+    }
+#undef TT_WFWD
+    return TT_E_UNSUPPORTED;
+}
+template <int C>
+int bwd_c(const __bf16* x, const __bf16* h1, const __bf16* dy, const float* w1, const float* w2, const float* b2, __bf16* dx,
+          float* dw1, float* db1, float* dw2, float* db2, unsigned char* ws, int B, int H, int T, int D, hipStream_t st) {
+    switch (D) {
+        case 1: return launch_bwd<C, 1>(x, h1, dy, w1, w2, b2, dx, dw1, db1, dw2, db2, ws, B, H, T, st);
+        case 2: return launch_bwd<C, 2>(x, h1, dy, w1, w2, b2, dx, dw1, db1, dw2, db2, ws, B, H, T, st);
+        case 3: return launch_bwd<C, 3>(x, h1, dy, w1, w2, b2, dx, dw1, db1, dw2, db2, ws, B, H, T, st);
+    }
+    return TT_E_UNSUPPORTED;
+}
+
+inline bool shape_ok(int B, int C, int H, int T) {
+    return B > 0 && H > 0 && T > 0 && (C == 16 || C == 32) && (long)H * T * C < (1l << 31);
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t tt_wide_scratch_bytes(int B, int C, int H, int T) {
+    if (!shape_ok(B, C, H, T)) return -1;
+    const long npix = (long)B * H * T;
+    return ((npix * C * 2 + 255) / 256) * 256 + (C == 16 ? dump_floats<16>() : dump_floats<32>()) * 4;
+}
+
+int tt_wide_pack(const float* x, void* out, int B, int C, int H, int T, void* stream) {
+    if (!x || !out || !shape_ok(B, C, H, T)) return TT_E_BADARG;
+    const long npix = (long)B * H * T, pieces = npix * (C / 8);
+    const unsigned grid = (unsigned)((pieces + NT - 1) / NT);
+    if (C == 16) hipLaunchKernelGGL(k_wide_pack<16>, dim3(grid), dim3(NT), 0, tt_stream(stream), x, (__bf16*)out, H, T, npix);
+    else hipLaunchKernelGGL(k_wide_pack<32>, dim3(grid), dim3(NT), 0, tt_stream(stream), x, (__bf16*)out, H, T, npix);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
+int tt_wide_unpack(const void* in, float* y, int B, int C, int H, int T, void* stream) {
+    if (!in || !y || !shape_ok(B, C, H, T)) return TT_E_BADARG;
+    const long npix = (long)B * H * T, pieces = npix * (C / 8);
+    const unsigned grid = (unsigned)((pieces + NT - 1) / NT);
+    if (C == 16) hipLaunchKernelGGL(k_wide_unpack<16>, dim3(grid), dim3(NT), 0, tt_stream(stream), (const __bf16*)in, y, H, T, npix);
+    else hipLaunchKernelGGL(k_wide_unpack<32>, dim3(grid), dim3(NT), 0, tt_stream(stream), (const __bf16*)in, y, H, T, npix);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
+int tt_wide_rb_fwd(const void* x, const float* w1, const float* b1, const float* w2, const float* b2, void* y, void* h1, int B,
+                   int C, int H, int T, int dilation, void* stream) {
+    if (!x || !w1 || !b1 || !w2 || !b2 || !y || !shape_ok(B, C, H, T)) return TT_E_BADARG;
+    if (C == 16) return fwd_c<16>((const __bf16*)x, w1, b1, w2, b2, (__bf16*)y, (__bf16*)h1, B, H, T, dilation, tt_stream(stream));
+    return fwd_c<32>((const __bf16*)x, w1, b1, w2, b2, (__bf16*)y, (__bf16*)h1, B, H, T, dilation, tt_stream(stream));
+}
+
+int tt_wide_rb_bwd(const void* x, const void* h1, const void* dy, const float* w1, const float* w2, const float* b2, void* dx,
+                   float* dw1, float* db1, float* dw2, float* db2, void* ws, int B, int C, int H, int T, int dilation,
+                   void* stream) {
+    if (!x || !h1 || !dy || !w1 || !w2 || !b2 || !dx || !dw1 || !db1 || !dw2 || !db2 || !ws || !shape_ok(B, C, H, T))
+        return TT_E_BADARG;
+    if (C == 16)
+        return bwd_c<16>((const __bf16*)x, (const __bf16*)h1, (const __bf16*)dy, w1, w2, b2, (__bf16*)dx, dw1, db1, dw2, db2,
+                         (unsigned char*)ws, B, H, T, dilation, tt_stream(stream));
+    return bwd_c<32>((const __bf16*)x, (const __bf16*)h1, (const __bf16*)dy, w1, w2, b2, (__bf16*)dx, dw1, db1, dw2, db2,
+                     (unsigned char*)ws, B, H, T, dilation, tt_stream(stream));
+}
+
+}  // extern "C"

@@ -80,7 +80,7 @@ class EncoderBlock(nn.Module):
             nn.ELU(inplace=True))
 
     def forward(self, x):
-        y = self.block3(self.block2(self.block1(x)))
+        y = ops.residual_level(x, (self.block1, self.block2, self.block3))
         s = self.sconv[0]
         return ops.strided_conv(y, s.weight, s.bias, self.win, self.hop)
 
@@ -107,7 +107,7 @@ class DecoderBlock(nn.Module):
     def forward(self, x):
         t = self.tconv[0]
         y = ops.transposed_conv(x, t.weight, t.bias, self.win, self.hop, self.out_pad)
-        return self.block3(self.block2(self.block1(y)))
+        return ops.residual_level(y, (self.block1, self.block2, self.block3))
 
 
 class Encoder(nn.Module):

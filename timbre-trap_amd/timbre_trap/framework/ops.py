@@ -28,6 +28,19 @@ SAVE_HIDDEN = os.environ.get('TTRAP_SAVE_HIDDEN', '1') != '0'
 #   'fp32' (default)  v_mfma_f32_16x16x4_f32, bit-exact fp32 -- what every parity test pins
 #   'bf16'            operands rounded to bf16, fp32 accumulation (v_mfma_f32_16x16x32_bf16); tensors stay fp32
 PRECISION = os.environ.get('TTRAP_PRECISION', 'fp32')
+# Storage of the activations INSIDE the wide levels (C = 16, 32: the three residual blocks of an Encoder/DecoderBlock):
+#   'fp32'  channel-planar fp32 tensors, one ResBlockFn per block (every precision above)
+#   'bf16'  bf16 channel-innermost tensors in HBM, csrc/conv_wide_bf16.hip: the "bf16 MFMA conv path" of BASELINE config[2].
+# Default: follows PRECISION ('bf16' there means bf16 operands AND bf16 storage); TTRAP_WIDE_STORAGE overrides.
+WIDE_STORAGE = os.environ.get('TTRAP_WIDE_STORAGE', '')
+WIDE_CHANNELS = (16, 32)
+
+
+def wide_storage():
+    mode = WIDE_STORAGE or ('bf16' if PRECISION == 'bf16' else 'fp32')
+    if mode not in ('fp32', 'bf16'):
+        raise ValueError('TTRAP_WIDE_STORAGE / ops.WIDE_STORAGE must be fp32 or bf16, got %r' % (mode,))
+    return mode
 
 
 def _flags():
@@ -328,6 +341,87 @@ def residual_block(x, w1, b1, w2, b2, dilation):
     return AddFn.apply(h, x)
 
 
+class WideLevelFn(torch.autograd.Function):
+    """
+    The residual blocks of one wide level (reference modules.py:621-624 / 690-693: block1..3, dilation 1, 2, 3) with bf16
+    channel-innermost activations in HBM (csrc/conv_wide_bf16.hip).  Input and output are ordinary fp32 (B,C,H,T) tensors;
+    the block inputs and hidden activations saved for backward are bf16 (half the bytes of the fp32 path).
+    Arguments after x: dilations (tuple), then w1, b1, w2, b2 of every block.
+    """
+
+    @staticmethod
+    def forward(ctx, x, dilations, *params):
+        _hip.require_cuda(x, params[0])
+        x = _f32c(x)
+        B, C, H, T = x.shape
+        lib, st = _hip.lib(), stream_ptr()
+        nb = len(dilations)
+        needs_grad = any(ctx.needs_input_grad)
+        cur = torch.empty((B, H, T, C), dtype=torch.bfloat16, device=x.device)
+        check(lib.tt_wide_pack(ptr(x), ptr(cur), B, C, H, T, st), 'tt_wide_pack')
+        saved = []
+        for i, d in enumerate(dilations):
+            w1, b1, w2, b2 = params[4 * i: 4 * i + 4]
+            nxt = torch.empty_like(cur)
+            h1 = torch.empty_like(cur) if needs_grad else None
+            with _hip.timed('wide_rb_fwd_C%d' % C):
+                check(lib.tt_wide_rb_fwd(ptr(cur), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(nxt), ptr(h1), B, C, H, T, d, st),
+                      'tt_wide_rb_fwd')
+            saved += [cur, h1]
+            cur = nxt
+        y = torch.empty_like(x)
+        check(lib.tt_wide_unpack(ptr(cur), ptr(y), B, C, H, T, st), 'tt_wide_unpack')
+        ctx.dilations = tuple(dilations)
+        ctx.params = params
+        ctx.geom = (B, C, H, T)
+        if needs_grad:
+            ctx.save_for_backward(*params, *saved)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, H, T = ctx.geom
+        nb = len(ctx.dilations)
+        tensors = ctx.saved_tensors
+        params, saved = tensors[:4 * nb], tensors[4 * nb:]
+        lib, st = _hip.lib(), stream_ptr()
+        dy = _f32c(dy)
+        g = torch.empty((B, H, T, C), dtype=torch.bfloat16, device=dy.device)
+        check(lib.tt_wide_pack(ptr(dy), ptr(g), B, C, H, T, st), 'tt_wide_pack')
+        ws = torch.empty(lib.tt_wide_scratch_bytes(B, C, H, T), dtype=torch.uint8, device=dy.device)
+        grads = [None] * (4 * nb)
+        for i in reversed(range(nb)):
+            w1, b1, w2, b2 = params[4 * i: 4 * i + 4]
+            xin, h1 = saved[2 * i], saved[2 * i + 1]
+            (dw1, r1), (db1, r2), (dw2, r3), (db2, r4) = (_grad_target(t) for t in ctx.params[4 * i: 4 * i + 4])
+            gx = torch.empty_like(g)
+            with _hip.timed('wide_rb_bwd_C%d' % C):
+                check(lib.tt_wide_rb_bwd(ptr(xin), ptr(h1), ptr(g), ptr(w1), ptr(w2), ptr(b2), ptr(gx), ptr(dw1), ptr(db1),
+                                         ptr(dw2), ptr(db2), ptr(ws), B, C, H, T, ctx.dilations[i], st), 'tt_wide_rb_bwd')
+            grads[4 * i: 4 * i + 4] = [r1, r2, r3, r4]
+            g = gx
+        dx = torch.empty((B, C, H, T), dtype=torch.float32, device=dy.device)
+        check(lib.tt_wide_unpack(ptr(g), ptr(dx), B, C, H, T, st), 'tt_wide_unpack')
+        return (dx, None, *grads)
+
+
+def residual_level(x, blocks):
+    """
+    block3(block2(block1(x))) for the ResidualConv2dBlock modules ``blocks``: one WideLevelFn when the level is wide and
+    ops.wide_storage() == 'bf16', the per-block path otherwise.
+    """
+    C = x.size(1)
+    if (wide_storage() == 'bf16' and C in WIDE_CHANNELS and FUSED_RESBLOCK
+            and all(b.conv1[0].weight.shape == (C, C, 3, 3) and 1 <= b.dilation <= 3 for b in blocks)):
+        params = []
+        for b in blocks:
+            params += [b.conv1[0].weight, b.conv1[0].bias, b.conv2[0].weight, b.conv2[0].bias]
+        return WideLevelFn.apply(x, tuple(b.dilation for b in blocks), *params)
+    for b in blocks:
+        x = b(x)
+    return x
+
+
 class LatentEncodeFn(torch.autograd.Function):
     """Encoder.convlat: Conv2d(C, D, (E,1)) collapsing the frequency axis = per-clip GEMM (D x C*E)(C*E x T)."""
 
@@ -514,6 +608,7 @@ def _instrument(cls, name, keyfn):
 
 _instrument(ConvFn, 'conv', lambda x, w, b, cfg: '%dto%d' % ((x.size(1), w.size(0)) if cfg.kind == 'conv' else (x.size(1), w.size(1))))
 _instrument(ResBlockFn, 'rb', lambda x, *a: 'C%d' % x.size(1))
+_instrument(WideLevelFn, 'widelevel', lambda x, *a: 'C%d' % x.size(1))
 _instrument(StridedConvFn, 'sconv', lambda x, *a: 'C%d' % x.size(1))
 _instrument(TransposedConvFn, 'tconv', lambda x, w, *a: 'C%d' % w.size(1))
 _instrument(LatentEncodeFn, 'latenc', lambda x, *a: 'C%d' % x.size(1))

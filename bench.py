@@ -77,7 +77,7 @@ def build_model(mc, latent, device, seed=2):
                       latent_size=latent, model_complexity=mc, skip_connections=False).to(device)
 
 
-def make_train_step(model, opt, world, overlap=True):
+def make_train_step(model, opt, world, overlap=True, autocast=True):
     """
     Returns step(audio, target, next_audio=None) -> total loss: exactly the body of reference experiments/train.py:404-496.
 
@@ -99,15 +99,18 @@ def make_train_step(model, opt, world, overlap=True):
         else:
             coefficients = model.sliCQ(audio)
         state['coeffs'] = state['src'] = None
-        reconstruction, latents, trn_coeffs, trn_rec, trn_scr, _ = model(audio, True)
-        transcription = model.to_activations(trn_coeffs)
-        n = target.size(0)
-        l_rec = compute_reconstruction_loss(reconstruction, coefficients)
-        l_trn = compute_transcription_loss(transcription[:n], target, True)
-        l_sp, l_sc = compute_consistency_loss(trn_rec[:n], trn_scr[:n], trn_coeffs[:n])
-        total = l_rec + l_trn + (l_sp + l_sc)
-        opt.zero_grad()
-        total.backward()
+        # the reference runs forward, losses and backward of the step under autocast (experiments/train.py:415); with
+        # ops.PRECISION == 'auto' that region is what selects the bf16 MFMA conv path (BASELINE config[2])
+        with torch.autocast(device_type='cuda', dtype=torch.bfloat16, enabled=autocast):
+            reconstruction, latents, trn_coeffs, trn_rec, trn_scr, _ = model(audio, True)
+            transcription = model.to_activations(trn_coeffs)
+            n = target.size(0)
+            l_rec = compute_reconstruction_loss(reconstruction, coefficients)
+            l_trn = compute_transcription_loss(transcription[:n], target, True)
+            l_sp, l_sc = compute_consistency_loss(trn_rec[:n], trn_scr[:n], trn_coeffs[:n])
+            total = l_rec + l_trn + (l_sp + l_sc)
+            opt.zero_grad()
+            total.backward()
         if sync is not None:
             if overlap:
                 sync.start(opt.flat_grad)
@@ -156,6 +159,12 @@ def family_table(events, n_steps, batch, mc, latent):
             by = 4.0 * C * px * (3 if bwd else 2)
             add(('narrow' if C <= 8 else 'wide') + ' residual blocks ' + ('backward' if bwd else 'forward'), ms, calls, fl * calls, by * calls,
                 'hbm' if C <= 8 else 'mfma')
+        elif kind == 'widelevel':
+            # three residual blocks per call, bf16 channel-innermost tensors: 2 (fwd) / 3 (bwd) tensors of 2 bytes per block
+            C = int(tag[1:]); px = hs[level[C]] * T * batch
+            fl = 3 * 2.0 * 10 * C * C * px * (2 if bwd else 1)
+            by = 3 * 2.0 * C * px * (3 if bwd else 2)
+            add('wide residual levels (3 blocks, bf16 storage) ' + ('backward' if bwd else 'forward'), ms, calls, fl * calls, by * calls, 'hbm')
         elif kind in ('sconv', 'tconv'):
             C = int(tag[1:]); l = level[C]
             big, small = C * hs[l] * T * batch, 2 * C * hs[l + 1] * T * batch          # elements at the C side / the 2C side
@@ -306,7 +315,7 @@ def bench_inference(model, args, rank, world, dev, steps=None, warmup=None, emit
     line = dict(metric='audio-seconds/s inference throughput, transcribe()+reconstruct() (9oct x 60bpo, 3s@22.05kHz)',
                 value=world * batch * SECS_PER_CLIP / (elapsed / steps), unit='audio-seconds/s', n_gpus=world,
                 steps=steps, warmup=warmup, ms_per_step=ms, higher_is_better=True, scaling='weak',
-                vs_baseline=None, dtype={'fp32': 'f32', 'bf16x3': 'bf16x3', 'bf16': 'bf16'}[args.precision], data='synthetic',
+                vs_baseline=None, dtype=args.infer_dtype, data='synthetic',
                 config=dict(workload='transcribe() + reconstruct() (each: 3 half-overlapping chunks per clip through CQT + '
                                      'encoder + decoder, Hann cross-fade; reconstruct adds the inverse CQT), model_complexity=%d '
                                      'latent=%d, %d clips x 3 s' % (args.mc, args.latent, batch),
@@ -327,8 +336,9 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='clips per GPU')
     ap.add_argument('--mc', type=int, default=2)
     ap.add_argument('--latent', type=int, default=128)
-    ap.add_argument('--precision', choices=('fp32', 'bf16x3', 'bf16'), default=os.environ.get('TTRAP_PRECISION', 'fp32'),
-                    help='operands of the wide 3x3 convs on the matrix cores: fp32 = exact (default), bf16 = rounded operands, fp32 accumulation')
+    ap.add_argument('--precision', choices=('auto', 'fp32', 'bf16x3', 'bf16'), default=os.environ.get('TTRAP_PRECISION', 'auto'),
+                    help="auto (default) = like the reference: the train step runs under torch.autocast and takes the bf16 MFMA conv path "
+                         "(BASELINE config[2]), inference runs in exact fp32; fp32 / bf16x3 / bf16 force one arithmetic everywhere")
     ap.add_argument('--mode', choices=('train', 'infer'), default='train',
                     help="train = the headline metric; infer = BASELINE config[1]: transcribe() + reconstruct() on 32 clips x 3 s")
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -343,6 +353,9 @@ def main():
     from timbre_trap.framework import ops
     from timbre_trap.utils import FusedAdamW, allreduce_gradients, init_process_group_from_env
     ops.PRECISION = args.precision
+    train_dtype = {'auto': 'bf16', 'fp32': 'f32', 'bf16x3': 'bf16x3', 'bf16': 'bf16'}[args.precision]
+    infer_dtype = {'auto': 'f32', 'fp32': 'f32', 'bf16x3': 'bf16x3', 'bf16': 'bf16'}[args.precision]
+    args.infer_dtype = infer_dtype
     from timbre_trap.utils.distributed import broadcast_parameters
     import torch.distributed as dist
 
@@ -373,7 +386,7 @@ def main():
     if world > 1:
         broadcast_parameters(opt.flat_param)
     audio, target = synthetic_batch(args.batch, rank, dev)
-    step_fn = make_train_step(model, opt, world, overlap=not args.no_overlap)
+    step_fn = make_train_step(model, opt, world, overlap=not args.no_overlap, autocast=args.precision == 'auto')
 
     def sync():
         if world > 1:
@@ -384,8 +397,8 @@ def main():
         step_fn(audio, target)
     sync()
     C = 16 * 2 ** (args.mc - 1)
-    key = 'resblock_fwd_C%d' % C
-    _hip.EVENT_KEYS = {key, 'cqt_forward'}          # the timed region brackets only the two roofline kernels
+    key, key16 = 'resblock_fwd_C%d' % C, 'wide_rb_fwd_C%d' % C
+    _hip.EVENT_KEYS = {key, key16, 'cqt_forward'}   # the timed region brackets only the roofline kernels
     _hip.EVENT_LOG = {}
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -460,6 +473,24 @@ def main():
                         bound='mfma', achieved=ach, peak=PEAK_FP32_MATRIX_TFLOPS, unit='TFLOP/s',
                         frac=ach / PEAK_FP32_MATRIX_TFLOPS, traffic=traffic, traffic_source=traffic_source, algorithmic_flops=flops,
                         algorithmic_bytes=2.0 * 4 * C * args.batch * 65 * M_FRAMES, launches=n_l, avg_ms=a_ms)
+        if events.get(key16):
+            # bf16-storage path: the same block reads x and writes y as bf16 -- 16x the matrix rate, so HBM is the bound
+            a_ms, n_l = avg_ms(events[key16])
+            nbytes = 2.0 * 2 * C * args.batch * 65 * M_FRAMES
+            flops = 2.0 * (9 * C * C + C * C) * args.batch * 65 * M_FRAMES
+            gbs = nbytes / (a_ms * 1e-3) / 1e9
+            traffic, traffic_source = None, None
+            pmc = os.path.join(ROOT, 'profiles', 'r02_f_pmc_wrb_fwd_C32.json')
+            if C == 32 and args.batch == 64 and os.path.exists(pmc):
+                traffic = json.load(open(pmc))['traffic_bytes_corrected']
+                traffic_source = 'profiles/r02_f_pmc_wrb_fwd_C32.json (rocprofv3 --pmc passes of this kernel at this shape: FETCH_SIZE x2 + WRITE_SIZE; not re-measured in this run)'
+            roof = dict(kernel='k_wrb_conv<%d,D,0> (fused ResidualConv2dBlock forward, bf16 channel-innermost storage, C=%d, H=65)' % (C, C),
+                        bound='hbm', achieved=gbs, peak=PEAK_HBM_GBS, unit='GB/s', frac=gbs / PEAK_HBM_GBS, traffic=traffic,
+                        traffic_source=traffic_source, algorithmic_bytes=nbytes, algorithmic_flops=flops,
+                        achieved_tflops=flops / (a_ms * 1e-3) / 1e12, frac_bf16_mfma_peak=flops / (a_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                        launches=n_l, avg_ms=a_ms,
+                        note='algorithmic bytes = x read + y written once (bf16); the hidden activation saved for backward (+50 %) is an '
+                             'implementation choice and is not counted')
         cqt = cqt_inv = None
         if events.get('cqt_forward'):
             a_ms, n_l = avg_ms(events['cqt_forward'])
@@ -484,18 +515,38 @@ def main():
             full = bench_inference(model, args, rank, world, dev, steps=3, warmup=1, emit=False)
             infer = {k: full[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype')}
             infer['workload'] = full['config']['workload']
+        fp32_step = None
+        if world == 1 and not args.timed_only and train_dtype != 'f32':
+            # the exact-fp32 train step (every parity test's arithmetic), measured in the same run: secondary figure
+            prev = ops.PRECISION
+            ops.PRECISION = 'fp32'
+            f_step = make_train_step(model, opt, world, overlap=False, autocast=False)
+            for _ in range(2):
+                f_step(audio, target)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(4):
+                f_step(audio, target)
+            torch.cuda.synchronize()
+            f_ms = 1000.0 * (time.perf_counter() - t1) / 4
+            ops.PRECISION = prev
+            fp32_step = dict(ms_per_step=f_ms, value=args.batch * SECS_PER_CLIP / (f_ms * 1e-3), unit='audio-seconds/s', dtype='f32',
+                             steps=4, warmup=2, note='same step with ops.PRECISION = fp32 (no autocast): bit-exact fp32 MFMA path')
         base = base0 = None
         if not args.no_cpu_baseline and not args.timed_only and world == 1:
             base = cpu_baseline(args.mc, args.latent)
             base0 = cpu_baseline(1, None, config0=True)
         line = dict(metric='audio-seconds/s training throughput (9oct x 60bpo, 3s@22.05kHz)', value=value,
                     unit='audio-seconds/s', n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms,
-                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype={'fp32': 'f32', 'bf16x3': 'bf16x3', 'bf16': 'bf16'}[args.precision], data='synthetic',
+                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype=train_dtype, data='synthetic',
                     config=dict(workload='full train step (CQT x2 + AE fwd/bwd with consistency + 3 losses + clip + AdamW), '
-                                         'model_complexity=%d latent=%d, %d clips x 3 s per GPU' % (args.mc, args.latent, args.batch),
+                                         'model_complexity=%d latent=%d, %d clips x 3 s per GPU%s'
+                                         % (args.mc, args.latent, args.batch, ', under torch.autocast like reference experiments/train.py:415 '
+                                            '(bf16 MFMA conv path of BASELINE config[2]; fp32 master weights, losses and optimizer)'
+                                            if args.precision == 'auto' else ''),
                                 global_batch=world * args.batch, parallelism='dp%d' % world),
                     roofline=roof, roofline_cqt=cqt, roofline_cqt_inv=cqt_inv, families=families, whole_step=whole,
-                    inference_config1=infer, per_rank_ms=per_rank_ms, allreduce_ms=allreduce_ms, cpu_baseline=base, cpu_baseline_config0=base0,
+                    inference_config1=infer, fp32_train_step=fp32_step, per_rank_ms=per_rank_ms, allreduce_ms=allreduce_ms, cpu_baseline=base, cpu_baseline_config0=base0,
                     final_loss=float(total.detach()))
         print(json.dumps(line))
     if world > 1:

@@ -191,3 +191,24 @@ def test_level_dispatch(monkeypatch):
     assert _rel(y16.cpu().double(), y32.cpu().double()) < 3e-2
     monkeypatch.setattr(ops, 'WIDE_STORAGE', 'fp32')      # bf16 operands, fp32 storage: the round-1 mode
     assert ops.wide_storage() == 'fp32'
+
+
+def test_autocast_selects_bf16_path(monkeypatch):
+    """ops.PRECISION == 'auto' (the default): bf16 storage inside torch.autocast('cuda') -- where the reference's train step runs
+    (experiments/train.py:415) -- and exact fp32 outside it."""
+    from timbre_trap.framework import modules, ops
+    monkeypatch.setattr(ops, 'PRECISION', 'auto')
+    monkeypatch.setattr(ops, 'WIDE_STORAGE', '')
+    torch.manual_seed(0)
+    blk = modules.DecoderBlock(32, 16, padding=1).cuda()
+    x = _rand(1, 32, 6, 64, seed=3).cuda().requires_grad_(True)
+    assert ops.precision() == 'fp32'
+    y32 = blk(x)
+    with torch.autocast(device_type='cuda'):
+        assert ops.precision() == 'bf16' and ops.wide_storage() == 'bf16'
+        y16 = blk(x)
+        y16.square().mean().backward()
+    assert ops.precision() == 'fp32'
+    assert y16.dtype == torch.float32 and not torch.equal(y32, y16)
+    assert _rel(y16.detach().cpu().double(), y32.detach().cpu().double()) < 3e-2
+    assert x.grad is not None and torch.isfinite(x.grad).all()

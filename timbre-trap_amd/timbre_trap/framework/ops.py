@@ -24,29 +24,40 @@ FUSED_CHANNELS = (4, 8, 16, 32)
 # Keep the hidden activation of every residual block for backward (one more (B,C,H,T) tensor per block, no 3x3
 # recompute).  TTRAP_SAVE_HIDDEN=0 recomputes instead and halves the residual-block activation memory.
 SAVE_HIDDEN = os.environ.get('TTRAP_SAVE_HIDDEN', '1') != '0'
-# Arithmetic of the wide (C >= 16) 3x3 convolutions and their weight gradients on the matrix cores:
-#   'fp32' (default)  v_mfma_f32_16x16x4_f32, bit-exact fp32 -- what every parity test pins
-#   'bf16'            operands rounded to bf16, fp32 accumulation (v_mfma_f32_16x16x32_bf16); tensors stay fp32
-PRECISION = os.environ.get('TTRAP_PRECISION', 'fp32')
+# Arithmetic of the wide (C >= 16) residual blocks on the matrix cores:
+#   'fp32'    v_mfma_f32_16x16x4_f32, exact fp32 -- what every parity test pins
+#   'bf16x3'  fp32 tensors, every operand fed as hi + lo bf16 (three products): fp32-class results at 16/3 of the fp32 rate
+#   'bf16'    operands rounded to bf16, fp32 accumulation (v_mfma_f32_16x16x32_bf16)
+#   'auto'    (default) 'bf16' inside a ``torch.autocast('cuda')`` region, 'fp32' outside -- the reference runs its train
+#             step under autocast (experiments/train.py:415: half-precision convolutions) and everything else in fp32
+#             (experiments/evaluate.py), so the unmodified scripts get the same split here.
+PRECISION = os.environ.get('TTRAP_PRECISION', 'auto')
 # Storage of the activations INSIDE the wide levels (C = 16, 32: the three residual blocks of an Encoder/DecoderBlock):
-#   'fp32'  channel-planar fp32 tensors, one ResBlockFn per block (every precision above)
+#   'fp32'  channel-planar fp32 tensors, one ResBlockFn per block (any precision above)
 #   'bf16'  bf16 channel-innermost tensors in HBM, csrc/conv_wide_bf16.hip: the "bf16 MFMA conv path" of BASELINE config[2].
-# Default: follows PRECISION ('bf16' there means bf16 operands AND bf16 storage); TTRAP_WIDE_STORAGE overrides.
+# Default: follows the precision ('bf16' means bf16 operands AND bf16 storage); TTRAP_WIDE_STORAGE overrides.
 WIDE_STORAGE = os.environ.get('TTRAP_WIDE_STORAGE', '')
 WIDE_CHANNELS = (16, 32)
 
 
+def precision():
+    """The arithmetic in force for the call being made: PRECISION with 'auto' resolved against the autocast state."""
+    if PRECISION == 'auto':
+        return 'bf16' if torch.is_autocast_enabled('cuda') else 'fp32'
+    if PRECISION not in ('fp32', 'bf16', 'bf16x3'):
+        raise ValueError('TTRAP_PRECISION / ops.PRECISION must be auto, fp32, bf16x3 or bf16, got %r' % (PRECISION,))
+    return PRECISION
+
+
 def wide_storage():
-    mode = WIDE_STORAGE or ('bf16' if PRECISION == 'bf16' else 'fp32')
+    mode = WIDE_STORAGE or ('bf16' if precision() == 'bf16' else 'fp32')
     if mode not in ('fp32', 'bf16'):
         raise ValueError('TTRAP_WIDE_STORAGE / ops.WIDE_STORAGE must be fp32 or bf16, got %r' % (mode,))
     return mode
 
 
 def _flags():
-    if PRECISION not in ('fp32', 'bf16', 'bf16x3'):
-        raise ValueError('TTRAP_PRECISION / ops.PRECISION must be fp32, bf16x3 or bf16, got %r' % (PRECISION,))
-    return {'fp32': 0, 'bf16': 1, 'bf16x3': 2}[PRECISION]
+    return {'fp32': 0, 'bf16': 1, 'bf16x3': 2}[precision()]
 
 
 @dataclass(frozen=True)

@@ -130,22 +130,23 @@ def _stagewise(C, d, B, H, T):
     assert _rel(grads[3].cpu().double() - 0.5, dA2.sum((0, 2, 3))) < 2e-3, 'db2'
 
 
-@pytest.mark.parametrize('C', [16, 32])
+@pytest.mark.parametrize('C', [4, 8, 16, 32])
 @pytest.mark.parametrize('d', [1, 2, 3])
-@pytest.mark.parametrize('shape', [(2, 11, 80), (1, 8, 64), (3, 5, 150), (1, 21, 16)])
+@pytest.mark.parametrize('shape', [(2, 11, 80), (1, 8, 64), (3, 5, 150), (1, 21, 16), (1, 37, 200)])
 def test_wide_block_stagewise(C, d, shape):
     _stagewise(C, d, *shape)
 
 
 @pytest.mark.parametrize('C,d,shape,cus', [(32, 3, (1, 65, 256), 1), (16, 2, (2, 37, 320), 1), (32, 1, (3, 20, 200), 2),
-                                           (16, 3, (1, 133, 128), 3)])
+                                           (16, 3, (1, 133, 128), 3), (8, 3, (1, 269, 192), 1), (4, 2, (2, 100, 384), 1),
+                                           (8, 1, (2, 40, 300), 2), (4, 3, (1, 540, 128), 2)])
 def test_wide_block_multitile(C, d, shape, cus, cu_limit):
     """Every workgroup walks many tiles (grid capped at 2 * cus workgroups)."""
     cu_limit(cus)
     _stagewise(C, d, *shape)
 
 
-@pytest.mark.parametrize('C', [16, 32])
+@pytest.mark.parametrize('C', [4, 8, 16, 32])
 def test_wide_level_matches_oracle(C):
     """Three blocks (d = 1, 2, 3) through WideLevelFn against the fp64 oracle of the unrounded blocks, bf16 tolerance."""
     from timbre_trap.framework import ops

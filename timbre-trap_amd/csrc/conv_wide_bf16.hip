@@ -57,34 +57,40 @@ __device__ __forceinline__ float elu_f(float a) { return a > 0.f ? a : (__expf(a
 template <int C> __device__ __forceinline__ int chan_of(int ct, int m) { return C == 32 ? 8 * (m >> 2) + 4 * ct + (m & 3) : m; }
 
 // ---- layout change at the ends of a level --------------------------------------------------------------------------
+// One thread per 16-byte piece: eight channels of one pixel (C >= 8) or two whole pixels (C = 4; T even keeps a pair inside
+// one image row).
 template <int C>
 __global__ __launch_bounds__(NT) void k_wide_pack(const float* __restrict__ x, __bf16* __restrict__ out, int H, int T, long npix) {
-    constexpr int CG = C / 8;
-    const long i = (long)blockIdx.x * NT + threadIdx.x;         // one 16-byte piece: pixel i / CG, channels 8 (i % CG) ..
-    const long pix = i / CG;
+    constexpr int CPP = C >= 8 ? 8 : C, PPP = 8 / CPP, CG = C / CPP;         // channels / pixels per piece, pieces per pixel
+    const long i = (long)blockIdx.x * NT + threadIdx.x;
+    const long pix = (i / CG) * PPP;
     if (pix >= npix) return;
-    const int cg = (int)(i - pix * CG);
+    const int cg = (int)(i % CG);
     const long plane = (long)H * T;
     const long b = pix / plane, o = pix - b * plane;
-    const float* s = x + (b * C + cg * 8) * plane + o;
+    const float* s = x + (b * C + cg * CPP) * plane + o;
     bf16x8 q;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) q[j] = (__bf16)s[j * plane];
-    *reinterpret_cast<bf16x8*>(out + pix * C + cg * 8) = q;
+    for (int p = 0; p < PPP; ++p)
+#pragma unroll
+        for (int j = 0; j < CPP; ++j) q[p * CPP + j] = (__bf16)s[j * plane + p];
+    *reinterpret_cast<bf16x8*>(out + pix * C + cg * CPP) = q;
 }
 template <int C>
 __global__ __launch_bounds__(NT) void k_wide_unpack(const __bf16* __restrict__ in, float* __restrict__ y, int H, int T, long npix) {
-    constexpr int CG = C / 8;
+    constexpr int CPP = C >= 8 ? 8 : C, PPP = 8 / CPP, CG = C / CPP;
     const long i = (long)blockIdx.x * NT + threadIdx.x;
-    const long pix = i / CG;
+    const long pix = (i / CG) * PPP;
     if (pix >= npix) return;
-    const int cg = (int)(i - pix * CG);
+    const int cg = (int)(i % CG);
     const long plane = (long)H * T;
     const long b = pix / plane, o = pix - b * plane;
-    const bf16x8 q = *reinterpret_cast<const bf16x8*>(in + pix * C + cg * 8);
-    float* d = y + (b * C + cg * 8) * plane + o;
+    const bf16x8 q = *reinterpret_cast<const bf16x8*>(in + pix * C + cg * CPP);
+    float* d = y + (b * C + cg * CPP) * plane + o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) d[j * plane] = (float)q[j];
+    for (int p = 0; p < PPP; ++p)
+#pragma unroll
+        for (int j = 0; j < CPP; ++j) d[j * plane + p] = (float)q[p * CPP + j];
 }
 
 // ---- 3x3 main loop: block forward and data gradient ------------------------------------------------------------------
@@ -693,8 +699,434 @@ int bwd_c(const __bf16* x, const __bf16* h1, const __bf16* dy, const float* w1, 
     return TT_E_UNSUPPORTED;
 }
 
+// ==== narrow levels (C = 4, 8) ========================================================================================
+// A pixel is 8 / 16 bytes, so here a LANE is a pixel: v_mfma_f32_4x4x4_16b_bf16 runs sixteen independent 4x4x4 products
+// per wave -- block = lane / 4, A row / B column = lane % 4, each lane's four bf16 are k = 0..3, D register = row -- so with
+// A = a 4 x 4 slice of the weights (the same in every block) and B = four channels of the lane's own pixel, every lane
+// ends up with ALL output channels of its pixel: a 64-pixel row segment per wave instruction, 8- / 16-byte accesses
+// everywhere, nothing wasted on padding the channel count up to a 16-row tile.
+__device__ __forceinline__ f32x4 mma4(s16x4 a, s16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a, b, c, 0, 0, 0); }
+
+template <int C> struct VecOf { typedef typename std::conditional<C == 8, bf16x8, bf16x4>::type type; };
+template <int C> __device__ __forceinline__ s16x4 chunk_of(const typename VecOf<C>::type& v, int kb) {
+    if constexpr (C == 8) {
+        const bf16x4 h = kb == 0 ? __builtin_shufflevector(v, v, 0, 1, 2, 3) : __builtin_shufflevector(v, v, 4, 5, 6, 7);
+        return __builtin_bit_cast(s16x4, h);
+    } else {
+        return __builtin_bit_cast(s16x4, v);
+    }
+}
+
+template <int C, int D> struct NTl {
+    static constexpr int TH = 16, TW = 64;
+    static constexpr int PXB = C * 2;                            // bytes per pixel
+    static constexpr int PPP = 16 / PXB;                         // pixels per 16-byte piece: 2 (C = 4), 1 (C = 8)
+    static constexpr int DP = (D + PPP - 1) / PPP * PPP;         // column halo in whole pieces (T must be a multiple of PPP)
+    static constexpr int RW = TW + 2 * DP, ROWS = TH + 2 * D;
+    static constexpr int NP = ROWS * RW / PPP;
+    static constexpr int NPR = (NP + NT - 1) / NT * NT;
+    static constexpr int LDS_BYTES = NPR * 16;
+};
+
+template <int C, int D, int MODE, bool SAVE>
+__global__ __launch_bounds__(NT) void k_nrb_conv(const __bf16* __restrict__ x, const float* __restrict__ w1,
+                                                 const float* __restrict__ b1, const float* __restrict__ w2,
+                                                 const float* __restrict__ b2, const __bf16* __restrict__ res,
+                                                 __bf16* __restrict__ y, __bf16* __restrict__ h1, int B, int H, int T,
+                                                 int tiles_h, int tiles_t, int ntiles) {
+    using G = NTl<C, D>;
+    typedef typename VecOf<C>::type vec_t;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i4 = lane & 3;
+    constexpr int NB = C / 4;
+
+    s16x4 A[9][NB][NB], A2[NB][NB];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) {
+                bf16x4 t;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int mo = 4 * ob + i4, kc = 4 * kb + k;
+                    t[k] = (__bf16)(MODE == 0 ? w1[(mo * C + kc) * 9 + tap] : w1[(kc * C + mo) * 9 + (8 - tap)]);
+                }
+                A[tap][ob][kb] = __builtin_bit_cast(s16x4, t);
+            }
+    float b1r[C], b2r[C];
+    if constexpr (MODE == 0) {
+#pragma unroll
+        for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) {
+                bf16x4 t;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) t[k] = (__bf16)w2[(4 * ob + i4) * C + 4 * kb + k];
+                A2[ob][kb] = __builtin_bit_cast(s16x4, t);
+            }
+#pragma unroll
+        for (int c = 0; c < C; ++c) { b1r[c] = b1[c]; b2r[c] = b2[c]; }
+    }
+
+    const __bf16* zero = reinterpret_cast<const __bf16*>(&g_wzero16);
+    for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
+        int tile = xcd_order(v, ntiles);
+        const int tt = tile % tiles_t; tile /= tiles_t;
+        const int th = tile % tiles_h;
+        const int b = tile / tiles_h, h0 = th * G::TH, t0 = tt * G::TW;
+        const __bf16* xb = x + (long)b * H * T * C;
+
+        __syncthreads();
+        for (int i = wave * 64; i < G::NPR; i += NT) {
+            const int p = i + lane, q = p * G::PPP;
+            const int row = q / G::RW, px = q - row * G::RW;
+            const int h = h0 - D + row, t = t0 - G::DP + px;
+            const bool ok = p < G::NP && (unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T;
+            glds16(ok ? xb + ((long)h * T + t) * C : zero, smem + (long)i * 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        const int t = t0 + lane;
+        const bool valid = t < T;
+        for (int r = wave; r < G::TH; r += 4) {
+            const int h = h0 + r;
+            if (h >= H) break;
+            const long pix = ((long)b * H + h) * T + t;
+            vec_t rq;
+            if constexpr (MODE == 1) rq = *reinterpret_cast<const vec_t*>(res + (valid ? pix : pix - (t - (T - 1))) * C);
+            f32x4 acc[NB];
+#pragma unroll
+            for (int ob = 0; ob < NB; ++ob) acc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+            vec_t centre;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int kh = tap / 3, kw = tap - 3 * kh;
+                const int pxi = (r + kh * D) * G::RW + G::DP + lane + (kw - 1) * D;
+                const vec_t bq = *reinterpret_cast<const vec_t*>(smem + (long)pxi * G::PXB);
+                if (tap == 4) centre = bq;
+#pragma unroll
+                for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+                    for (int kb = 0; kb < NB; ++kb) acc[ob] = mma4(A[tap][ob][kb], chunk_of<C>(bq, kb), acc[ob]);
+            }
+            vec_t o;
+            if constexpr (MODE == 1) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) o[c] = (__bf16)(acc[c >> 2][c & 3] + (float)rq[c]);
+            } else {
+                vec_t hq;
+#pragma unroll
+                for (int c = 0; c < C; ++c) hq[c] = (__bf16)elu_f(acc[c >> 2][c & 3] + b1r[c]);
+                if (SAVE && valid) *reinterpret_cast<vec_t*>(h1 + pix * C) = hq;
+                f32x4 z[NB];
+#pragma unroll
+                for (int ob = 0; ob < NB; ++ob) {
+                    z[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kb = 0; kb < NB; ++kb) z[ob] = mma4(A2[ob][kb], chunk_of<C>(hq, kb), z[ob]);
+                }
+#pragma unroll
+                for (int c = 0; c < C; ++c) o[c] = (__bf16)(elu_f(z[c >> 2][c & 3] + b2r[c]) + (float)centre[c]);
+            }
+            if (valid) *reinterpret_cast<vec_t*>(y + pix * C) = o;
+        }
+    }
+}
+
+// Pointwise chain of the backward, lane = pixel.  dW2 is a per-lane outer product (C^2 fused multiply-adds per pixel),
+// reduced over the wave by shuffles once at the end.  One dump [dW2 co*C+ci][db1][db2] per workgroup.
+template <int C>
+__global__ __launch_bounds__(NT) void k_nrb_bwd_a(const __bf16* __restrict__ h1, const __bf16* __restrict__ dy,
+                                                  const float* __restrict__ w2, const float* __restrict__ b2,
+                                                  __bf16* __restrict__ da1, float* __restrict__ part, long npix, long ngroups) {
+    typedef typename VecOf<C>::type vec_t;
+    constexpr int NB = C / 4, DUMP = C * C + 2 * C;
+    __shared__ float red[4][DUMP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i4 = lane & 3;
+    s16x4 A2[NB][NB], A2T[NB][NB];
+#pragma unroll
+    for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) {
+            bf16x4 a, at;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                a[k] = (__bf16)w2[(4 * ob + i4) * C + 4 * kb + k];
+                at[k] = (__bf16)w2[(4 * kb + k) * C + 4 * ob + i4];
+            }
+            A2[ob][kb] = __builtin_bit_cast(s16x4, a); A2T[ob][kb] = __builtin_bit_cast(s16x4, at);
+        }
+    float b2r[C], acc[DUMP];
+#pragma unroll
+    for (int c = 0; c < C; ++c) b2r[c] = b2[c];
+#pragma unroll
+    for (int e = 0; e < DUMP; ++e) acc[e] = 0.f;
+
+    vec_t zero_v;
+#pragma unroll
+    for (int c = 0; c < C; ++c) zero_v[c] = (__bf16)0.f;
+    const long gstride = (long)gridDim.x * 4;
+    long grp = (long)blockIdx.x * 4 + wave;
+    vec_t hq = zero_v, dq = zero_v;
+    if (grp < ngroups && grp * 64 + lane < npix) {
+        hq = *reinterpret_cast<const vec_t*>(h1 + (grp * 64 + lane) * C);
+        dq = *reinterpret_cast<const vec_t*>(dy + (grp * 64 + lane) * C);
+    }
+    for (; grp < ngroups; grp += gstride) {
+        const long pix = grp * 64 + lane, pn = (grp + gstride) * 64 + lane;
+        vec_t hq_n = zero_v, dq_n = zero_v;
+        if (grp + gstride < ngroups && pn < npix) {
+            hq_n = *reinterpret_cast<const vec_t*>(h1 + pn * C);
+            dq_n = *reinterpret_cast<const vec_t*>(dy + pn * C);
+        }
+        f32x4 z[NB], u[NB];
+#pragma unroll
+        for (int ob = 0; ob < NB; ++ob) {
+            z[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) z[ob] = mma4(A2[ob][kb], chunk_of<C>(hq, kb), z[ob]);
+        }
+        float gv[C], hv[C], gr[C];
+        vec_t gq, aq;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float a2 = z[c >> 2][c & 3] + b2r[c];
+            gv[c] = (float)dq[c] * (a2 > 0.f ? 1.f : __expf(a2));
+            gq[c] = (__bf16)gv[c];
+            gr[c] = (float)gq[c];
+            hv[c] = (float)hq[c];
+        }
+#pragma unroll
+        for (int ob = 0; ob < NB; ++ob) {
+            u[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) u[ob] = mma4(A2T[ob][kb], chunk_of<C>(gq, kb), u[ob]);
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float a1 = u[c >> 2][c & 3] * (hv[c] > 0.f ? 1.f : hv[c] + 1.f);
+            aq[c] = (__bf16)a1;
+            acc[C * C + c] += a1; acc[C * C + C + c] += gv[c];       // invalid pixels contribute zeros
+        }
+        if (pix < npix) *reinterpret_cast<vec_t*>(da1 + pix * C) = aq;
+#pragma unroll
+        for (int co = 0; co < C; ++co)
+#pragma unroll
+            for (int ci = 0; ci < C; ++ci) acc[co * C + ci] += gr[co] * hv[ci];
+        hq = hq_n; dq = dq_n;
+    }
+#pragma unroll
+    for (int e = 0; e < DUMP; ++e) {
+        float sv = acc[e];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sv += __shfl_xor(sv, o, 64);
+        if (lane == 0) red[wave][e] = sv;
+    }
+    __syncthreads();
+    float* pw = part + (long)blockIdx.x * DUMP;
+    for (int e = tid; e < DUMP; e += NT) pw[e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+}
+
+// 3x3 weight gradient of the narrow levels.  A row of the channel-innermost image is read as a flat run of 32-byte slots
+// (16 bf16 = 2 pixels at C = 8, 4 pixels at C = 4); the transpose reads then deliver, per lane, "column" (pixel-in-slot s,
+// channel c) = 4 s.. over the slots that are the K of the product.  D[(s,c)][(s',c')] mixes the pixels of a slot; only the
+// diagonal blocks s = s' pair a gradient pixel with its own input pixel -- k_nrb_reduce adds exactly those.
+template <int C, int D> struct NG {
+    static constexpr int TH = 8, TW = 128;
+    static constexpr int PXB = C * 2, PPP = 16 / PXB;
+    static constexpr int DP = (D + PPP - 1) / PPP * PPP;
+    static constexpr int RW = TW + 2 * DP, ROWS = TH + 2 * D;
+    static constexpr int XP = ROWS * RW / PPP, GP = TH * TW / PPP;
+    static constexpr int XPR = (XP + NT - 1) / NT * NT, GPR = (GP + NT - 1) / NT * NT;
+    static constexpr int X_BYTES = XPR * 16, G_BYTES = GPR * 16;
+    static constexpr int CHUNKS = TW * PXB / 1024;               // 1024-byte chunks (32 slots) per row: 1 (C = 4), 2 (C = 8)
+    static constexpr int DUMP = 9 * 256;
+    static constexpr int LDS_BYTES = X_BYTES + G_BYTES;
+};
+
+template <int C, int D>
+__global__ __launch_bounds__(NT) void k_nrb_wgrad(const __bf16* __restrict__ x, const __bf16* __restrict__ da1,
+                                                  float* __restrict__ part, int B, int H, int T, int tiles_h, int tiles_t,
+                                                  int ntiles) {
+    using G = NG<C, D>;
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char* xs = smem;
+    unsigned char* gs = smem + G::X_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int trj = n >> 2, trq = n & 3;
+    const int chunk = wave % G::CHUNKS, row0 = wave / G::CHUNKS;
+    constexpr int RSTEP = 4 / G::CHUNKS;
+    f32x4 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const __bf16* zero = reinterpret_cast<const __bf16*>(&g_wzero16);
+    for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
+        int tile = xcd_order(v, ntiles);
+        const int tt = tile % tiles_t; tile /= tiles_t;
+        const int th = tile % tiles_h;
+        const int b = tile / tiles_h, h0 = th * G::TH, t0 = tt * G::TW;
+        const __bf16* xb = x + (long)b * H * T * C;
+        const __bf16* gb = da1 + (long)b * H * T * C;
+        __syncthreads();
+        for (int i = wave * 64; i < G::XPR; i += NT) {
+            const int p = i + lane, q = p * G::PPP;
+            const int row = q / G::RW, px = q - row * G::RW;
+            const int h = h0 - D + row, t = t0 - G::DP + px;
+            const bool ok = p < G::XP && (unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T;
+            glds16(ok ? xb + ((long)h * T + t) * C : zero, xs + (long)i * 16);
+        }
+        for (int i = wave * 64; i < G::GPR; i += NT) {
+            const int p = i + lane, q = p * G::PPP;
+            const int row = q / G::TW, px = q - row * G::TW;
+            const int h = h0 + row, t = t0 + px;
+            const bool ok = p < G::GP && h < H && t < T;
+            glds16(ok ? gb + ((long)h * T + t) * C : zero, gs + (long)i * 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        const int so = chunk * 1024 + 32 * (4 * g + trj) + 8 * trq;      // byte offset inside a row of this lane's first slot
+        for (int r = row0; r < G::TH; r += RSTEP) {
+            if (h0 + r >= H) break;
+            const unsigned char* gp = gs + (long)r * (G::TW * G::PXB) + so;
+            const s16x4 glo = lds_tr16(gp), ghi = lds_tr16(gp + 512);
+            const bf16x8 ga = __builtin_bit_cast(bf16x8, __builtin_shufflevector(glo, ghi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int kh = k / 3, kw = k - 3 * kh;
+                const unsigned char* xp = xs + (long)(r + kh * D) * (G::RW * G::PXB) + (G::DP + (kw - 1) * D) * G::PXB + so;
+                const s16x4 lo = lds_tr16(xp), hi = lds_tr16(xp + 512);
+                acc[k] = mma32(ga, __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)), acc[k]);
+            }
+        }
+    }
+    float* pw = part + ((long)blockIdx.x * 4 + wave) * G::DUMP;
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pw[(k * 4 + r) * 64 + lane] = acc[k][r];
+}
+
+template <int C>
+__global__ __launch_bounds__(1024) void k_nrb_reduce(RedArgs ar) {
+    constexpr int WDUMP = 9 * 256, ADUMP = C * C + 2 * C;
+    __shared__ float red[16][64];
+    const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + el;
+    float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (e < WDUMP) {
+        const int ncontrib = ar.gw * 4;
+        for (int j0 = sl; j0 < ncontrib; j0 += 128)
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (j0 + 16 * u < ncontrib) part[u] += ar.pw[(long)(j0 + 16 * u) * WDUMP + e];
+    } else if (e < WDUMP + ADUMP) {
+        const int ncontrib = ar.ga;
+        for (int j0 = sl; j0 < ncontrib; j0 += 128)
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (j0 + 16 * u < ncontrib) part[u] += ar.pa[(long)(j0 + 16 * u) * ADUMP + (e - WDUMP)];
+    }
+    red[sl][el] = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+    __syncthreads();
+    if (sl != 0) return;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sum += red[i][el];
+    if (e < WDUMP) {
+        const int k = e >> 8, r = (e >> 6) & 3, lane = e & 63, g = lane >> 4, n = lane & 15;
+        // D row 4g + r = (pixel-in-slot s, channel c), column n = (s', c'): keep s == s'
+        const int m = 4 * g + r, s = m / C, c = m - s * C, s2 = n / C, c2 = n - s2 * C;
+        if (s == s2) atomicAdd(ar.dw1 + (c * C + c2) * 9 + k, sum);      // 16 / C contributions per element
+    } else if (e < WDUMP + ADUMP) {
+        const int q = e - WDUMP;
+        float* dst = q < C * C ? ar.dw2 + q : (q < C * C + C ? ar.db1 + (q - C * C) : ar.db2 + (q - C * C - C));
+        *dst += sum;
+    }
+}
+
+template <int C, int D, int MODE, bool SAVE>
+int launch_nconv(const __bf16* x, const float* w1, const float* b1, const float* w2, const float* b2, const __bf16* res,
+                 __bf16* y, __bf16* h1, int B, int H, int T, hipStream_t st) {
+    using G = NTl<C, D>;
+    static AttrOnce once;
+    auto kern = k_nrb_conv<C, D, MODE, SAVE>;
+    if (int rc = raise_lds(kern, G::LDS_BYTES, once)) return rc;
+    const int tiles_h = (H + G::TH - 1) / G::TH, tiles_t = (T + G::TW - 1) / G::TW, ntiles = B * tiles_h * tiles_t;
+    hipLaunchKernelGGL(kern, dim3(grid_for(ntiles, G::LDS_BYTES, 4)), dim3(NT), G::LDS_BYTES, st, x, w1, b1, w2, b2, res, y, h1,
+                       B, H, T, tiles_h, tiles_t, ntiles);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int C> constexpr long ndump_floats() { return (long)MAX_A_WG * (C * C + 2 * C) + (long)MAX_W_WG * 4 * 9 * 256; }
+
+template <int C, int D>
+int launch_nbwd(const __bf16* x, const __bf16* h1, const __bf16* dy, const float* w1, const float* w2, const float* b2,
+                __bf16* dx, float* dw1, float* db1, float* dw2, float* db2, unsigned char* ws, int B, int H, int T,
+                hipStream_t st) {
+    const long npix = (long)B * H * T;
+    __bf16* da1 = reinterpret_cast<__bf16*>(ws);
+    float* part_a = reinterpret_cast<float*>(ws + ((npix * C * 2 + 255) / 256) * 256);
+    float* part_w = part_a + (long)MAX_A_WG * (C * C + 2 * C);
+    const long ngroups = (npix + 63) / 64;
+    const long want = (ngroups + 3) / 4;
+    int grid = (int)(want < (long)4 * tt_cus() ? want : (long)4 * tt_cus());
+    if (grid > MAX_A_WG) grid = MAX_A_WG;
+    hipLaunchKernelGGL(k_nrb_bwd_a<C>, dim3(grid), dim3(NT), 0, st, h1, dy, w2, b2, da1, part_a, npix, ngroups);
+    TT_LAUNCH_CHECK();
+    if (int rc = launch_nconv<C, D, 1, false>(da1, w1, nullptr, nullptr, nullptr, dy, dx, nullptr, B, H, T, st)) return rc;
+    using W = NG<C, D>;
+    static AttrOnce once_w;
+    auto kw = k_nrb_wgrad<C, D>;
+    if (int rc = raise_lds(kw, W::LDS_BYTES, once_w)) return rc;
+    const int tiles_h = (H + W::TH - 1) / W::TH, tiles_t = (T + W::TW - 1) / W::TW, ntiles = B * tiles_h * tiles_t;
+    int gw = grid_for(ntiles, W::LDS_BYTES, 3);
+    if (gw > MAX_W_WG) gw = MAX_W_WG;
+    hipLaunchKernelGGL(kw, dim3(gw), dim3(NT), W::LDS_BYTES, st, x, da1, part_w, B, H, T, tiles_h, tiles_t, ntiles);
+    TT_LAUNCH_CHECK();
+    RedArgs ra{part_w, gw, part_a, grid, dw1, db1, dw2, db2};
+    constexpr int total = 9 * 256 + C * C + 2 * C;
+    hipLaunchKernelGGL(k_nrb_reduce<C>, dim3((total + 63) / 64), dim3(1024), 0, st, ra);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int C>
+int nfwd_c(const __bf16* x, const float* w1, const float* b1, const float* w2, const float* b2, __bf16* y, __bf16* h1, int B,
+           int H, int T, int D, hipStream_t st) {
+#define TT_NFWD(DD)                                                                                                  \
+    return h1 ? launch_nconv<C, DD, 0, true>(x, w1, b1, w2, b2, nullptr, y, h1, B, H, T, st)                          \
+              : launch_nconv<C, DD, 0, false>(x, w1, b1, w2, b2, nullptr, y, nullptr, B, H, T, st)
+    switch (D) {
+        case 1: TT_NFWD(1);
+        case 2: TT_NFWD(2);
+        case 3: TT_NFWD(3);
+    }
+#undef TT_NFWD
+    return TT_E_UNSUPPORTED;
+}
+template <int C>
+int nbwd_c(const __bf16* x, const __bf16* h1, const __bf16* dy, const float* w1, const float* w2, const float* b2, __bf16* dx,
+           float* dw1, float* db1, float* dw2, float* db2, unsigned char* ws, int B, int H, int T, int D, hipStream_t st) {
+    switch (D) {
+        case 1: return launch_nbwd<C, 1>(x, h1, dy, w1, w2, b2, dx, dw1, db1, dw2, db2, ws, B, H, T, st);
+        case 2: return launch_nbwd<C, 2>(x, h1, dy, w1, w2, b2, dx, dw1, db1, dw2, db2, ws, B, H, T, st);
+        case 3: return launch_nbwd<C, 3>(x, h1, dy, w1, w2, b2, dx, dw1, db1, dw2, db2, ws, B, H, T, st);
+    }
+    return TT_E_UNSUPPORTED;
+}
+
 inline bool shape_ok(int B, int C, int H, int T) {
-    return B > 0 && H > 0 && T > 0 && (C == 16 || C == 32) && (long)H * T * C < (1l << 31);
+    return B > 0 && H > 0 && T > 0 && (C == 4 || C == 8 || C == 16 || C == 32) && (C != 4 || T % 2 == 0) &&
+           (long)H * T * C < (1l << 31);
 }
 
 }  // namespace
@@ -704,25 +1136,36 @@ extern "C" {
 int64_t tt_wide_scratch_bytes(int B, int C, int H, int T) {
     if (!shape_ok(B, C, H, T)) return -1;
     const long npix = (long)B * H * T;
-    return ((npix * C * 2 + 255) / 256) * 256 + (C == 16 ? dump_floats<16>() : dump_floats<32>()) * 4;
+    const long dumps = C == 4 ? ndump_floats<4>() : C == 8 ? ndump_floats<8>() : C == 16 ? dump_floats<16>() : dump_floats<32>();
+    return ((npix * C * 2 + 255) / 256) * 256 + dumps * 4;
 }
 
 int tt_wide_pack(const float* x, void* out, int B, int C, int H, int T, void* stream) {
     if (!x || !out || !shape_ok(B, C, H, T)) return TT_E_BADARG;
-    const long npix = (long)B * H * T, pieces = npix * (C / 8);
+    const long npix = (long)B * H * T, pieces = npix * C / 8;
     const unsigned grid = (unsigned)((pieces + NT - 1) / NT);
-    if (C == 16) hipLaunchKernelGGL(k_wide_pack<16>, dim3(grid), dim3(NT), 0, tt_stream(stream), x, (__bf16*)out, H, T, npix);
-    else hipLaunchKernelGGL(k_wide_pack<32>, dim3(grid), dim3(NT), 0, tt_stream(stream), x, (__bf16*)out, H, T, npix);
+    hipStream_t st = tt_stream(stream);
+    switch (C) {
+        case 4: hipLaunchKernelGGL(k_wide_pack<4>, dim3(grid), dim3(NT), 0, st, x, (__bf16*)out, H, T, npix); break;
+        case 8: hipLaunchKernelGGL(k_wide_pack<8>, dim3(grid), dim3(NT), 0, st, x, (__bf16*)out, H, T, npix); break;
+        case 16: hipLaunchKernelGGL(k_wide_pack<16>, dim3(grid), dim3(NT), 0, st, x, (__bf16*)out, H, T, npix); break;
+        default: hipLaunchKernelGGL(k_wide_pack<32>, dim3(grid), dim3(NT), 0, st, x, (__bf16*)out, H, T, npix);
+    }
     TT_LAUNCH_CHECK();
     return 0;
 }
 
 int tt_wide_unpack(const void* in, float* y, int B, int C, int H, int T, void* stream) {
     if (!in || !y || !shape_ok(B, C, H, T)) return TT_E_BADARG;
-    const long npix = (long)B * H * T, pieces = npix * (C / 8);
+    const long npix = (long)B * H * T, pieces = npix * C / 8;
     const unsigned grid = (unsigned)((pieces + NT - 1) / NT);
-    if (C == 16) hipLaunchKernelGGL(k_wide_unpack<16>, dim3(grid), dim3(NT), 0, tt_stream(stream), (const __bf16*)in, y, H, T, npix);
-    else hipLaunchKernelGGL(k_wide_unpack<32>, dim3(grid), dim3(NT), 0, tt_stream(stream), (const __bf16*)in, y, H, T, npix);
+    hipStream_t st = tt_stream(stream);
+    switch (C) {
+        case 4: hipLaunchKernelGGL(k_wide_unpack<4>, dim3(grid), dim3(NT), 0, st, (const __bf16*)in, y, H, T, npix); break;
+        case 8: hipLaunchKernelGGL(k_wide_unpack<8>, dim3(grid), dim3(NT), 0, st, (const __bf16*)in, y, H, T, npix); break;
+        case 16: hipLaunchKernelGGL(k_wide_unpack<16>, dim3(grid), dim3(NT), 0, st, (const __bf16*)in, y, H, T, npix); break;
+        default: hipLaunchKernelGGL(k_wide_unpack<32>, dim3(grid), dim3(NT), 0, st, (const __bf16*)in, y, H, T, npix);
+    }
     TT_LAUNCH_CHECK();
     return 0;
 }
@@ -730,8 +1173,15 @@ int tt_wide_unpack(const void* in, float* y, int B, int C, int H, int T, void* s
 int tt_wide_rb_fwd(const void* x, const float* w1, const float* b1, const float* w2, const float* b2, void* y, void* h1, int B,
                    int C, int H, int T, int dilation, void* stream) {
     if (!x || !w1 || !b1 || !w2 || !b2 || !y || !shape_ok(B, C, H, T)) return TT_E_BADARG;
-    if (C == 16) return fwd_c<16>((const __bf16*)x, w1, b1, w2, b2, (__bf16*)y, (__bf16*)h1, B, H, T, dilation, tt_stream(stream));
-    return fwd_c<32>((const __bf16*)x, w1, b1, w2, b2, (__bf16*)y, (__bf16*)h1, B, H, T, dilation, tt_stream(stream));
+    const __bf16* xi = (const __bf16*)x;
+    __bf16 *yo = (__bf16*)y, *ho = (__bf16*)h1;
+    hipStream_t st = tt_stream(stream);
+    switch (C) {
+        case 4: return nfwd_c<4>(xi, w1, b1, w2, b2, yo, ho, B, H, T, dilation, st);
+        case 8: return nfwd_c<8>(xi, w1, b1, w2, b2, yo, ho, B, H, T, dilation, st);
+        case 16: return fwd_c<16>(xi, w1, b1, w2, b2, yo, ho, B, H, T, dilation, st);
+    }
+    return fwd_c<32>(xi, w1, b1, w2, b2, yo, ho, B, H, T, dilation, st);
 }
 
 int tt_wide_rb_bwd(const void* x, const void* h1, const void* dy, const float* w1, const float* w2, const float* b2, void* dx,
@@ -739,11 +1189,16 @@ int tt_wide_rb_bwd(const void* x, const void* h1, const void* dy, const float* w
                    void* stream) {
     if (!x || !h1 || !dy || !w1 || !w2 || !b2 || !dx || !dw1 || !db1 || !dw2 || !db2 || !ws || !shape_ok(B, C, H, T))
         return TT_E_BADARG;
-    if (C == 16)
-        return bwd_c<16>((const __bf16*)x, (const __bf16*)h1, (const __bf16*)dy, w1, w2, b2, (__bf16*)dx, dw1, db1, dw2, db2,
-                         (unsigned char*)ws, B, H, T, dilation, tt_stream(stream));
-    return bwd_c<32>((const __bf16*)x, (const __bf16*)h1, (const __bf16*)dy, w1, w2, b2, (__bf16*)dx, dw1, db1, dw2, db2,
-                     (unsigned char*)ws, B, H, T, dilation, tt_stream(stream));
+    const __bf16 *xi = (const __bf16*)x, *hi = (const __bf16*)h1, *gi = (const __bf16*)dy;
+    __bf16* go = (__bf16*)dx;
+    unsigned char* w = (unsigned char*)ws;
+    hipStream_t st = tt_stream(stream);
+    switch (C) {
+        case 4: return nbwd_c<4>(xi, hi, gi, w1, w2, b2, go, dw1, db1, dw2, db2, w, B, H, T, dilation, st);
+        case 8: return nbwd_c<8>(xi, hi, gi, w1, w2, b2, go, dw1, db1, dw2, db2, w, B, H, T, dilation, st);
+        case 16: return bwd_c<16>(xi, hi, gi, w1, w2, b2, go, dw1, db1, dw2, db2, w, B, H, T, dilation, st);
+    }
+    return bwd_c<32>(xi, hi, gi, w1, w2, b2, go, dw1, db1, dw2, db2, w, B, H, T, dilation, st);
 }
 
 }  // extern "C"

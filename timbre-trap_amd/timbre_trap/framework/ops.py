@@ -37,7 +37,7 @@ PRECISION = os.environ.get('TTRAP_PRECISION', 'auto')
 #   'bf16'  bf16 channel-innermost tensors in HBM, csrc/conv_wide_bf16.hip: the "bf16 MFMA conv path" of BASELINE config[2].
 # Default: follows the precision ('bf16' means bf16 operands AND bf16 storage); TTRAP_WIDE_STORAGE overrides.
 WIDE_STORAGE = os.environ.get('TTRAP_WIDE_STORAGE', '')
-WIDE_CHANNELS = (16, 32)
+WIDE_CHANNELS = (4, 8, 16, 32)        # every level of the model (C = 4 needs an even number of frames)
 
 
 def precision():
@@ -422,7 +422,7 @@ def residual_level(x, blocks):
     ops.wide_storage() == 'bf16', the per-block path otherwise.
     """
     C = x.size(1)
-    if (wide_storage() == 'bf16' and C in WIDE_CHANNELS and FUSED_RESBLOCK
+    if (wide_storage() == 'bf16' and C in WIDE_CHANNELS and FUSED_RESBLOCK and (C != 4 or x.size(-1) % 2 == 0)
             and all(b.conv1[0].weight.shape == (C, C, 3, 3) and 1 <= b.dilation <= 3 for b in blocks)):
         params = []
         for b in blocks:

@@ -150,11 +150,11 @@ int tt_resblock_bwd(const float* x, const float* h1, const float* dy, const floa
                     float* dw2, float* db2, float* ws, int B, int C, int H, int T, int dilation,
                     int flags, void* stream);
 
-/* bf16-STORAGE residual blocks of the wide levels (C = 16, 32), the "bf16 MFMA conv path" of BASELINE config[2]:
+/* bf16-STORAGE residual blocks (C = 4, 8, 16, 32), the "bf16 MFMA conv path" of BASELINE config[2]:
  * activations of a level are bf16, channel-innermost [B][H][T][C] in HBM; weights and their gradients stay fp32 (rounded to
  * bf16 into registers), products accumulate in fp32 (v_mfma_f32_16x16x32_bf16).  Replaces the three ResidualConv2dBlocks of
  * one EncoderBlock / DecoderBlock (modules.py:621-624, 690-693) when ops.WIDE_STORAGE == 'bf16':
- *   tt_wide_pack    x (B,C,H,T) fp32 planar -> out bf16 [B][H][T][C]          tt_wide_unpack   the inverse
+ *   tt_wide_pack    x (B,C,H,T) fp32 planar -> out bf16 [B][H][T][C]          tt_wide_unpack   the inverse   (C = 4..64)
  *   tt_wide_rb_fwd  y = ELU(W2 . ELU(W1 (*)_dil x + b1) + b2) + x ; h1 (may be NULL) = ELU(W1 (*) x + b1) saved for backward
  *   tt_wide_rb_bwd  from x, h1, dy: dx (written), dw1 / db1 / dw2 / db2 (fp32, accumulated +=); ws = tt_wide_scratch_bytes
  *                   bytes of scratch (dL/d(conv1 pre-activation) in bf16, then per-workgroup partial gradients). */
@@ -166,6 +166,23 @@ int tt_wide_rb_fwd(const void* x, const float* w1, const float* b1, const float*
 int tt_wide_rb_bwd(const void* x, const void* h1, const void* dy, const float* w1, const float* w2, const float* b2,
                    void* dx, float* dw1, float* db1, float* dw2, float* db2, void* ws, int B, int C, int H, int T,
                    int dilation, void* stream);
+
+/* bf16 channel-innermost (4,1) strided / transposed layers between the levels (csrc/conv_stride_bf16.hip): the bf16-storage
+ * counterparts of tt_sconv_* / tt_tconv_* below.  x, y, dy, dx are bf16 [B][H][T][channels]; w (2C, C, 4, 1), b and their
+ * gradients fp32.  C = the narrower side's channel count (4, 8, 16, 32).
+ *   tt_sconv16_fwd  x (B,H,T,C)  -> y (B,(H-4)/2+1,T,2C) = ELU(conv + b)          (modules.py:626-630)
+ *   tt_tconv16_fwd  x (B,H,T,2C) -> y (B,2H+2+out_pad,T,C) = ELU(tconv + b)       (modules.py:685-689)
+ *   *_bwd           from x, the saved OUTPUT y and dy: dx (written, may be NULL), dw / db (accumulated, +=); the ELU gate
+ *                   dy * ELU'(y) is applied on the fly inside the data- and weight-gradient kernels.
+ *                   ws: tt_stride16_scratch_bytes(C) bytes (per-wave partial gradients). */
+int64_t tt_stride16_scratch_bytes(int C);
+int tt_sconv16_fwd(const void* x, const float* w, const float* b, void* y, int B, int C, int H, int T, void* stream);
+int tt_sconv16_bwd(const void* x, const void* y, const void* dy, const float* w, void* dx, float* dw, float* db, void* ws,
+                   int B, int C, int H, int T, void* stream);
+int tt_tconv16_fwd(const void* x, const float* w, const float* b, void* y, int B, int C, int H, int T, int out_pad,
+                   void* stream);
+int tt_tconv16_bwd(const void* x, const void* y, const void* dy, const float* w, void* dx, float* dw, float* db, void* ws,
+                   int B, int C, int H, int T, int out_pad, void* stream);
 
 /* EncoderBlock.sconv (modules.py:626-630): y = ELU(Conv2d(C, 2C, (4,1), stride (2,1))(x) + b).
  * x (B,C,H,T) -> y (B,2C,(H-4)/2+1,T); w (2C,C,4,1).  Supported C: 4,8,16,32. */

@@ -188,8 +188,8 @@ def test_level_dispatch(monkeypatch):
     monkeypatch.setattr(ops, 'PRECISION', 'bf16')
     assert ops.wide_storage() == 'bf16'
     y16 = blk(x)
-    assert not torch.equal(y32, y16)
-    assert _rel(y16.cpu().double(), y32.cpu().double()) < 3e-2
+    assert ops.is_cl16(y16) and y16.shape == y32.shape
+    assert _rel(y16.float().cpu().double(), y32.cpu().double()) < 3e-2
     monkeypatch.setattr(ops, 'WIDE_STORAGE', 'fp32')      # bf16 operands, fp32 storage: the round-1 mode
     assert ops.wide_storage() == 'fp32'
 
@@ -210,6 +210,110 @@ def test_autocast_selects_bf16_path(monkeypatch):
         y16 = blk(x)
         y16.square().mean().backward()
     assert ops.precision() == 'fp32'
-    assert y16.dtype == torch.float32 and not torch.equal(y32, y16)
-    assert _rel(y16.detach().cpu().double(), y32.detach().cpu().double()) < 3e-2
-    assert x.grad is not None and torch.isfinite(x.grad).all()
+    assert ops.is_cl16(y16) and y16.shape == y32.shape        # a bf16 channels-last tensor of the reference's logical shape
+    assert _rel(y16.detach().float().cpu().double(), y32.detach().cpu().double()) < 3e-2
+    assert x.grad is not None and x.grad.dtype == torch.float32 and torch.isfinite(x.grad).all()
+
+
+# ---- (4,1) strided / transposed layers on bf16 channels-last tensors (csrc/conv_stride_bf16.hip) ---------------------------
+
+def _cl16(t):
+    """fp32 (B,C,H,T) CPU tensor -> cl16 device tensor through the pack kernel."""
+    from timbre_trap.framework import ops
+    return ops._pack(t.cuda().contiguous())
+
+
+def _f64(t16):
+    return t16.float().cpu().double().contiguous()
+
+
+def _gate(y):
+    return torch.where(y > 0, torch.ones_like(y), y + 1)
+
+
+@pytest.mark.parametrize('C', [4, 8, 16, 32])
+@pytest.mark.parametrize('shape', [(2, 13, 80), (1, 12, 64), (1, 37, 48), (3, 9, 150)])
+def test_sconv16_stagewise(C, shape):
+    from timbre_trap import _hip
+    from timbre_trap._hip import check, ptr, stream_ptr
+    from timbre_trap.framework import ops
+    lib, st = _hip.lib(), stream_ptr()
+    B, H, T = shape
+    Ho = (H - 4) // 2 + 1
+    x, dy = _rand(B, C, H, T, seed=1), _rand(B, 2 * C, Ho, T, seed=2)
+    w, b = _rand(2 * C, C, 4, 1, seed=3, scale=1.0 / (2 * C ** 0.5)), _rand(2 * C, seed=4, scale=0.3)
+    xb, gb = _cl16(x), _cl16(dy)
+    wd, bd = w.cuda(), b.cuda()
+    y = ops.new_cl16(B, 2 * C, Ho, T, 'cuda')
+    check(lib.tt_sconv16_fwd(ptr(xb), ptr(wd), ptr(bd), ptr(y), B, C, H, T, st), 'fwd')
+    xr, gr, wr = _r16(x), _r16(dy), _r16(w)
+    y_ref = F.elu(F.conv2d(xr, wr, b.double(), stride=(2, 1)))
+    y_k = _f64(y)
+    _close16(y_k, y_ref, 'y')
+    dx = ops.new_cl16(B, C, H, T, 'cuda')
+    dw, db = torch.full((2 * C, C, 4, 1), 0.25, device='cuda'), torch.full((2 * C,), 0.25, device='cuda')
+    ws = torch.empty(lib.tt_stride16_scratch_bytes(C), dtype=torch.uint8, device='cuda')
+    check(lib.tt_sconv16_bwd(ptr(xb), ptr(y), ptr(gb), ptr(wd), ptr(dx), ptr(dw), ptr(db), ptr(ws), B, C, H, T, st), 'bwd')
+    g = gr * _gate(y_k)
+    g_r = _r16(g)
+    dx_ref = F.conv_transpose2d(g_r, wr, stride=(2, 1), output_padding=(H - (2 * Ho + 2), 0))
+    _close16(_f64(dx), dx_ref, 'dx')
+    dw_ref = torch.nn.grad.conv2d_weight(xr, w.shape, g_r, stride=(2, 1))
+    assert _rel(dw.cpu().double() - 0.25, dw_ref) < 2e-4, 'dw'
+    assert _rel(db.cpu().double() - 0.25, g.sum((0, 2, 3))) < 2e-3, 'db'
+
+
+@pytest.mark.parametrize('C', [4, 8, 16, 32])
+@pytest.mark.parametrize('shape,out_pad', [((2, 5, 80), 0), ((1, 6, 64), 1), ((1, 17, 48), 1), ((3, 3, 150), 0)])
+def test_tconv16_stagewise(C, shape, out_pad):
+    from timbre_trap import _hip
+    from timbre_trap._hip import check, ptr, stream_ptr
+    from timbre_trap.framework import ops
+    lib, st = _hip.lib(), stream_ptr()
+    B, H, T = shape
+    Ho = 2 * H + 2 + out_pad
+    x, dy = _rand(B, 2 * C, H, T, seed=1), _rand(B, C, Ho, T, seed=2)
+    w, b = _rand(2 * C, C, 4, 1, seed=3, scale=1.0 / (2 * C ** 0.5)), _rand(C, seed=4, scale=0.3)
+    xb, gb = _cl16(x), _cl16(dy)
+    wd, bd = w.cuda(), b.cuda()
+    y = ops.new_cl16(B, C, Ho, T, 'cuda')
+    check(lib.tt_tconv16_fwd(ptr(xb), ptr(wd), ptr(bd), ptr(y), B, C, H, T, out_pad, st), 'fwd')
+    xr, gr, wr = _r16(x), _r16(dy), _r16(w)
+    y_ref = F.elu(F.conv_transpose2d(xr, wr, b.double(), stride=(2, 1), output_padding=(out_pad, 0)))
+    y_k = _f64(y)
+    _close16(y_k, y_ref, 'y')
+    dx = ops.new_cl16(B, 2 * C, H, T, 'cuda')
+    dw, db = torch.full((2 * C, C, 4, 1), 0.25, device='cuda'), torch.full((C,), 0.25, device='cuda')
+    ws = torch.empty(lib.tt_stride16_scratch_bytes(C), dtype=torch.uint8, device='cuda')
+    check(lib.tt_tconv16_bwd(ptr(xb), ptr(y), ptr(gb), ptr(wd), ptr(dx), ptr(dw), ptr(db), ptr(ws), B, C, H, T, out_pad, st), 'bwd')
+    g = gr * _gate(y_k)
+    g_r = _r16(g)
+    dx_ref = F.conv2d(g_r, wr, stride=(2, 1))
+    _close16(_f64(dx), dx_ref, 'dx')
+    dw_ref = torch.nn.grad.conv2d_weight(g_r, w.shape, xr, stride=(2, 1))
+    assert _rel(dw.cpu().double() - 0.25, dw_ref) < 2e-4, 'dw'
+    assert _rel(db.cpu().double() - 0.25, g.sum((0, 2, 3))) < 2e-3, 'db'
+
+
+@pytest.mark.parametrize('skip', [False, True])
+def test_bf16_model_is_channels_last_end_to_end(skip, monkeypatch):
+    """In the bf16 mode every tensor between convin and convout is cl16 (no fp32 round trips inside the autoencoder), the
+    embeddings handed back by the encoder are cl16 tensors of the reference's logical shapes, and the result tracks fp32."""
+    from timbre_trap.framework import TimbreTrap, ops
+    torch.manual_seed(3)
+    model = TimbreTrap(sample_rate=22050, n_octaves=9, bins_per_octave=60, secs_per_block=3, latent_size=32, model_complexity=2,
+                       skip_connections=skip).cuda()                 # channels 4, 8, 16, 32, 64: every level has a bf16 kernel
+    coeffs = _rand(1, 2, 540, 32, seed=5).cuda()
+    monkeypatch.setattr(ops, 'PRECISION', 'fp32')
+    lat32, emb32, _ = model.encoder(coeffs)
+    out32 = model.decoder(torch.cat([lat32, torch.ones(1, 1, 32, device='cuda')], 1), emb32 if skip else None)
+    monkeypatch.setattr(ops, 'PRECISION', 'bf16')
+    lat16, emb16, _ = model.encoder(coeffs)
+    assert not ops.is_cl16(emb16[0]) and all(ops.is_cl16(e) for e in emb16[1:])
+    assert [tuple(e.shape) for e in emb16] == [tuple(e.shape) for e in emb32]
+    out16 = model.decoder(torch.cat([lat16, torch.ones(1, 1, 32, device='cuda')], 1), emb16 if skip else None)
+    assert out16.dtype == torch.float32 and out16.shape == out32.shape
+    assert _rel(lat16.detach().cpu().double(), lat32.detach().cpu().double()) < 3e-2
+    assert _rel(out16.detach().cpu().double(), out32.detach().cpu().double()) < 5e-2
+    out16.square().mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.decoder.parameters())

@@ -1,0 +1,57 @@
+// Shared pieces of the bf16 channel-innermost kernels (conv_wide_bf16.hip, conv_stride_bf16.hip) for gfx950.
+#pragma once
+#include "common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int NT = 256;                        // threads per workgroup (4 waves)
+
+__device__ float4 g_wzero16;                   // DMA source of out-of-image pieces
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+// A (16 x 32) . B (32 x 16): lane l holds row / column l & 15 and k = 8 (l >> 4) + j; D: column l & 15, rows 4 (l >> 4) + r
+__device__ __forceinline__ f32x4 mma32(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+// K = 16: lane l holds k = 4 (l >> 4) + j
+__device__ __forceinline__ f32x4 mma16(s16x4 a, s16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
+
+__device__ __forceinline__ int xcd_order(int v, int n) {          // see conv_mfma.hip: one contiguous eighth of the raster per XCD
+    const int per = n >> 3;
+    return v < (per << 3) ? (v & 7) * per + (v >> 3) : v;
+}
+__device__ __forceinline__ float elu_f(float a) { return a > 0.f ? a : (__expf(a) - 1.f); }
+
+// ds_read_b64_tr_b16 (gfx950 transpose read), per 16-lane group: lane 4j + q supplies the address of 4 consecutive bf16
+// (row j, columns 4q..4q+3); lane i receives column i of rows 0..3.  With rows = pixels and columns = 16 channels that is
+// the K = pixels operand of the 16-row MFMAs straight from a channel-innermost LDS image.
+__device__ __forceinline__ s16x4 lds_tr16(const unsigned char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+
+inline int grid_for(int ntiles, int lds_bytes, int max_per_cu) {
+    int per = lds_bytes > 0 ? (160 * 1024) / lds_bytes : max_per_cu;
+    if (per > max_per_cu) per = max_per_cu;
+    if (per < 1) per = 1;
+    const int cap = tt_cus() * per;
+    return ntiles < cap ? ntiles : cap;
+}
+
+template <class K> int raise_lds(K kernel, int bytes, AttrOnce& once) {
+    const int dev = once.pending();
+    if (dev >= 0) {
+        TT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        once.mark(dev);
+    }
+    return 0;
+}
+
+}  // namespace

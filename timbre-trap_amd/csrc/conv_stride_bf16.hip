@@ -1,0 +1,535 @@
+// bf16 channel-innermost (4,1) strided / transposed layers between the levels (reference modules.py:626-630, 685-689).
+//
+//   EncoderBlock.sconv   y[ho,t,co] = ELU(b[co] + sum_{kh<4,ci} W[co][ci][kh] x[2ho+kh,t,ci])            C -> 2C, H -> H/2 - 1
+//   DecoderBlock.tconv   y[h,t,c]   = ELU(b[c]  + sum_{ci<2C, kh = h (mod 2)} W[ci][c][kh] x[(h-kh)/2,t,ci])   2C -> C, H -> 2H+2+p
+// Both weights are (2C, C, 4, 1) tensors; with index(wide, narrow, kh) = (wide * C + narrow) * 4 + kh they are the SAME
+// array layout, and the four products of the two layers are two kernels:
+//   k_s4  "gather four rows"   out[ho] <- in rows 2ho..2ho+3, C -> 2C channels:  sconv forward, tconv data gradient
+//   k_p2  "two rows by parity" out[h]  <- in rows (h - kh)/2,  2C -> C channels:  tconv forward, sconv data gradient
+// Everything is pointwise along T, so the B operand of v_mfma_f32_16x16x32_bf16 (one lane = one pixel, eight channels)
+// comes straight from HBM as 16-byte loads -- no LDS, no halo.  In the data-gradient use the operand is gated on the fly,
+// g = dy * ELU'(y) from the saved OUTPUT y, so no separate gating pass and no scratch tensor.
+//   k_w4  weight gradient  dW[a][b][kh] = sum small[r,t,a] * big[2r+kh,t,b]  (+ the bias gradient = sum of the gated
+//         operand): K = pixels; both operands from channel-innermost LDS images by transpose reads (ds_read_b64_tr_b16),
+//         the gated one staged through registers, the other by LDS-DMA.  Per-wave register dumps, summed by k_w4_reduce.
+// fp32 master weights rounded to bf16 into registers; fp32 accumulation, bias, ELU; bf16 activations and gradients.
+#include "bf16_common.h"
+
+namespace {
+
+__device__ __forceinline__ float gate_f(float dy, float y) { return dy * (y > 0.f ? 1.f : y + 1.f); }
+
+// number of 16-row output tiles and of channels a lane ends up with, for COUT output channels
+template <int COUT> struct OutT {
+    static constexpr int NCT = COUT >= 16 ? COUT / 16 : 1;
+    static constexpr int NCH = 4 * NCT;                          // channels per lane (lanes with rows beyond COUT hold nothing)
+};
+// output channel of row m of tile ct: a lane's rows 4g..4g+3 of all tiles are NCH consecutive channels
+template <int COUT> __device__ __forceinline__ int och(int ct, int m) {
+    return OutT<COUT>::NCH * (m >> 2) + 4 * ct + (m & 3);
+}
+
+// ---- k_s4: C -> 2C, rows 2ho + kh ---------------------------------------------------------------------------------------
+// K = 4 C.  Steps of 32 (16 at C = 4): lane group g of step j covers
+//   C = 32: kh = j, channels 8g..      C = 16: kh = 2j + (g >> 1), channels 8 (g & 1)..      C = 8: kh = g, channels 0..7
+//   C = 4 (K = 16, v_mfma_f32_16x16x16_bf16): kh = g, channels 0..3
+template <int C> struct S4 {
+    static constexpr int NS = C == 32 ? 4 : (C == 16 ? 2 : 1);
+    static constexpr int CE = C == 4 ? 4 : 8;                    // channels per lane per step
+    __device__ static int kh(int j, int g) { return C == 32 ? j : (C == 16 ? 2 * j + (g >> 1) : g); }
+    __device__ static int c0(int g) { return C == 32 ? 8 * g : (C == 16 ? 8 * (g & 1) : 0); }
+};
+
+template <int CE> struct VecE { typedef typename std::conditional<CE == 8, bf16x8, bf16x4>::type type; };
+
+template <int CE>
+__device__ __forceinline__ typename VecE<CE>::type load_gated(const __bf16* in, const __bf16* gy, long off, bool ok, bool gate) {
+    typedef typename VecE<CE>::type vec_t;
+    vec_t v;
+#pragma unroll
+    for (int j = 0; j < CE; ++j) v[j] = (__bf16)0.f;
+    if (ok) {
+        v = *reinterpret_cast<const vec_t*>(in + off);
+        if (gate) {
+            const vec_t yv = *reinterpret_cast<const vec_t*>(gy + off);
+#pragma unroll
+            for (int j = 0; j < CE; ++j) v[j] = (__bf16)gate_f((float)v[j], (float)yv[j]);
+        }
+    }
+    return v;
+}
+
+template <int CE> __device__ __forceinline__ f32x4 mma_e(typename VecE<CE>::type a, typename VecE<CE>::type b, f32x4 c) {
+    if constexpr (CE == 8) return mma32(a, b, c);
+    else return mma16(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c);
+}
+
+template <int COUT, int NCH>
+__device__ __forceinline__ void store_lane(__bf16* out, long pix, int g, const float (&v)[NCH], bool ok) {
+    if (!ok || NCH * g >= COUT) return;
+    __bf16* d = out + pix * COUT + NCH * g;
+    if constexpr (NCH == 4) {
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (__bf16)v[j];
+        *reinterpret_cast<bf16x4*>(d) = o;
+    } else {
+#pragma unroll
+        for (int q = 0; q < NCH / 8; ++q) {
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (__bf16)v[8 * q + j];
+            *reinterpret_cast<bf16x8*>(d + 8 * q) = o;
+        }
+    }
+}
+
+template <int C, bool GATE, bool ACT>
+__global__ __launch_bounds__(NT) void k_s4(const __bf16* __restrict__ in, const __bf16* __restrict__ gy,
+                                            const float* __restrict__ w, const float* __restrict__ bias,
+                                            __bf16* __restrict__ out, int B, int Hin, int Hout, int T, int tb, long ngroups) {
+    using S = S4<C>;
+    constexpr int COUT = 2 * C, NCT = OutT<COUT>::NCT, NCH = OutT<COUT>::NCH;
+    typedef typename VecE<S::CE>::type vec_t;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    vec_t A[S::NS][NCT];
+#pragma unroll
+    for (int j = 0; j < S::NS; ++j)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const int co = och<COUT>(ct, n), kh = S::kh(j, g), c0 = S::c0(g);
+#pragma unroll
+            for (int e = 0; e < S::CE; ++e) A[j][ct][e] = (__bf16)(co < COUT ? w[(co * C + c0 + e) * 4 + kh] : 0.f);
+        }
+    float br[NCH];
+#pragma unroll
+    for (int e = 0; e < NCH; ++e) br[e] = (ACT && NCH * g + e < COUT) ? bias[NCH * g + e] : 0.f;
+
+    for (long grp = (long)blockIdx.x * 4 + wave; grp < ngroups; grp += (long)gridDim.x * 4) {
+        const int tblk = (int)(grp % tb);
+        const long bh = grp / tb;
+        const int ho = (int)(bh % Hout), b = (int)(bh / Hout);
+        const int t = tblk * 16 + n;
+        const bool ok = t < T;
+        f32x4 acc[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        vec_t bq[S::NS];
+#pragma unroll
+        for (int j = 0; j < S::NS; ++j) {
+            const int hi = 2 * ho + S::kh(j, g);
+            bq[j] = load_gated<S::CE>(in, gy, (((long)b * Hin + hi) * T + t) * C + S::c0(g), ok && hi < Hin, GATE);
+        }
+#pragma unroll
+        for (int j = 0; j < S::NS; ++j)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) acc[ct] = mma_e<S::CE>(A[j][ct], bq[j], acc[ct]);
+        float v[NCH];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float a = acc[ct][r] + br[4 * ct + r];
+                v[4 * ct + r] = ACT ? elu_f(a) : a;
+            }
+        store_lane<COUT, NCH>(out, ((long)b * Hout + ho) * T + t, g, v, ok);
+    }
+}
+
+// ---- k_p2: 2C -> C, rows (h - kh) / 2 for kh = h (mod 2) ------------------------------------------------------------------
+// K = 4 C over (row select rs: kh = parity + 2 rs, input row (h - parity)/2 - rs; 2C channels).  Lane group g of step j:
+//   C = 32: rs = j >> 1, channels 32 (j & 1) + 8g..     C = 16: rs = j, channels 8g..     C = 8: rs = g >> 1, channels 8 (g & 1)..
+//   C = 4 (K = 16): rs = g >> 1, channels 4 (g & 1)..
+template <int C> struct P2 {
+    static constexpr int NS = C == 32 ? 4 : (C == 16 ? 2 : 1);
+    static constexpr int CE = C == 4 ? 4 : 8;
+    __device__ static int rs(int j, int g) { return C == 32 ? (j >> 1) : (C == 16 ? j : (g >> 1)); }
+    __device__ static int c0(int j, int g) { return C == 32 ? 32 * (j & 1) + 8 * g : (C == 16 ? 8 * g : (C == 8 ? 8 * (g & 1) : 4 * (g & 1))); }
+};
+
+template <int C, bool GATE, bool ACT>
+__global__ __launch_bounds__(NT) void k_p2(const __bf16* __restrict__ in, const __bf16* __restrict__ gy,
+                                            const float* __restrict__ w, const float* __restrict__ bias,
+                                            __bf16* __restrict__ out, int B, int Hin, int Hout, int T, int tb, long ngroups) {
+    using S = P2<C>;
+    constexpr int CIN = 2 * C, NCT = OutT<C>::NCT, NCH = OutT<C>::NCH;
+    typedef typename VecE<S::CE>::type vec_t;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    vec_t A[2][S::NS][NCT];                                      // [output-row parity]
+#pragma unroll
+    for (int par = 0; par < 2; ++par)
+#pragma unroll
+        for (int j = 0; j < S::NS; ++j)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const int co = och<C>(ct, n), kh = par + 2 * S::rs(j, g), c0 = S::c0(j, g);
+#pragma unroll
+                for (int e = 0; e < S::CE; ++e) A[par][j][ct][e] = (__bf16)(co < C ? w[((c0 + e) * C + co) * 4 + kh] : 0.f);
+            }
+    float br[NCH];
+#pragma unroll
+    for (int e = 0; e < NCH; ++e) br[e] = (ACT && NCH * g + e < C) ? bias[NCH * g + e] : 0.f;
+
+    for (long grp = (long)blockIdx.x * 4 + wave; grp < ngroups; grp += (long)gridDim.x * 4) {
+        const int tblk = (int)(grp % tb);
+        const long bh = grp / tb;
+        const int h = (int)(bh % Hout), b = (int)(bh / Hout);
+        const int t = tblk * 16 + n, par = h & 1;
+        const bool ok = t < T;
+        f32x4 acc[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        vec_t bq[S::NS];
+#pragma unroll
+        for (int j = 0; j < S::NS; ++j) {
+            const int hi = ((h - par) >> 1) - S::rs(j, g);
+            bq[j] = load_gated<S::CE>(in, gy, (((long)b * Hin + hi) * T + t) * CIN + S::c0(j, g), ok && hi >= 0 && hi < Hin, GATE);
+        }
+#pragma unroll
+        for (int j = 0; j < S::NS; ++j)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) acc[ct] = mma_e<S::CE>(par ? A[1][j][ct] : A[0][j][ct], bq[j], acc[ct]);
+        float v[NCH];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float a = acc[ct][r] + br[4 * ct + r];
+                v[4 * ct + r] = ACT ? elu_f(a) : a;
+            }
+        store_lane<C, NCH>(out, ((long)b * Hout + h) * T + t, g, v, ok);
+    }
+}
+
+// ---- k_w4: weight and bias gradient ----------------------------------------------------------------------------------------
+//   dW[a][b][kh] += sum_{r,t} small[r,t,a] big[2r+kh,t,b]       a < 2C, b < C;   db += sum of the gated operand
+// GS = true: small is gated (sconv: small = dy with y, big = x); false: big is gated (tconv: small = x, big = dy with y).
+// One K slot = one pixel; an operand tile = the pixel's 16 channels [16 tile .. 16 tile + 15] (the lanes of channels that do
+// not exist re-read existing ones; their rows / columns of D are never used).  Pixels of 64 / 128 bytes have their 32-byte
+// blocks XOR-swizzled with pixel bits so that the eight pixels of a half-wave read fall on different banks.
+template <int PB> __device__ __forceinline__ int blk_swz(int p) { return PB == 128 ? ((p >> 1) & 3) : (PB == 64 ? ((p >> 2) & 1) : 0); }
+
+template <int C> struct W4 {
+    static constexpr int TR = 4, TW = 64;
+    static constexpr int SB = 4 * C, BB = 2 * C;                 // bytes per pixel: small (2C channels), big (C channels)
+    static constexpr int BROWS = 2 * TR + 3;                     // 2 TR + 2 rows feed the products; one more so that the last tile
+                                                                 // reaches the output_padding row of a transposed layer (bias gradient)
+    // images rounded up to whole rounds of DMA instructions (256 pieces of 16 bytes): the tail lanes write zeros there
+    static constexpr int S_BYTES = (TR * TW * SB + 4095) / 4096 * 4096, B_BYTES = (BROWS * TW * BB + 4095) / 4096 * 4096;
+    static constexpr int NA = 2 * C >= 16 ? 2 * C / 16 : 1, NBT = C >= 16 ? C / 16 : 1;
+    static constexpr int DUMP = 4 * NA * NBT * 256;
+    static constexpr int LDS_BYTES = S_BYTES + B_BYTES;
+};
+
+// byte offset inside a pixel of the 8-byte run this lane supplies for operand tile `tile`
+template <int PB> __device__ __forceinline__ int tr_off(int p, int tile, int trq) {
+    if (PB >= 32) return ((tile ^ blk_swz<PB>(p)) << 5) + 8 * trq;
+    return PB == 16 ? 8 * (trq & 1) : 0;
+}
+
+template <int PB, bool GATED>
+__device__ __forceinline__ void stage_tile(unsigned char* lds, const __bf16* src, const __bf16* ysrc, int rows, int row_h0, int Hs,
+                                           int t0, int T, int tid, float (&dbacc)[8], int db_rows) {
+    // image [rows][TW][PB bytes]; piece = 16 bytes; GATED: through registers with dy * ELU'(y), else LDS-DMA
+    constexpr int TWp = 64, PPP = PB >= 16 ? 1 : 16 / PB, CGn = PB >= 16 ? PB / 16 : 1;
+    const int npieces = rows * TWp * PB / 16;
+    const __bf16* zero = reinterpret_cast<const __bf16*>(&g_wzero16);
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int i = wave * 64; i < ((npieces + NT - 1) / NT) * NT; i += NT) {
+        const int p = i + lane;
+        const int q = (p / CGn) * PPP, cgp = p % CGn;            // first pixel of the piece, physical 16-byte position in it
+        const int row = q / TWp, px = q - row * TWp;
+        // physical position -> logical channel group (32-byte blocks swizzled)
+        const int cg = PB >= 32 ? ((((cgp >> 1) ^ blk_swz<PB>(q)) << 1) | (cgp & 1)) : cgp;
+        const int h = row_h0 + row, t = t0 + px;
+        const bool ok = p < npieces && h < Hs && t < T;
+        const long off = ((long)h * T + t) * (PB / 2) + cg * 8;
+        if constexpr (!GATED) {
+            glds16(ok ? src + off : zero, lds + (long)i * 16);
+        } else {
+            bf16x8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (__bf16)0.f;
+            if (ok) {
+                v = *reinterpret_cast<const bf16x8*>(src + off);
+                const bf16x8 yv = *reinterpret_cast<const bf16x8*>(ysrc + off);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float gq = gate_f((float)v[j], (float)yv[j]);
+                    if (row < db_rows) dbacc[j] += gq;          // rows shared with the next tile are counted once
+                    v[j] = (__bf16)gq;
+                }
+            }
+            if (p < npieces) *reinterpret_cast<bf16x8*>(lds + (long)p * 16) = v;
+        }
+    }
+}
+
+template <int C, bool GS>
+__global__ __launch_bounds__(NT) void k_w4(const __bf16* __restrict__ small, const __bf16* __restrict__ big,
+                                            const __bf16* __restrict__ ygate, float* __restrict__ part, float* __restrict__ dbpart,
+                                            int B, int Hs, int Hb, int T, int tiles_h, int tiles_t, int ntiles) {
+    using G = W4<C>;
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char* ss = smem;
+    unsigned char* bs = smem + G::S_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4, trj = n >> 2, trq = n & 3;
+    const int colh = wave & 1, row0 = wave >> 1;
+    f32x4 acc[4][G::NA][G::NBT];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int a = 0; a < G::NA; ++a)
+#pragma unroll
+            for (int c = 0; c < G::NBT; ++c) acc[k][a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float dbacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
+        int tile = xcd_order(v, ntiles);
+        const int tt = tile % tiles_t; tile /= tiles_t;
+        const int th = tile % tiles_h;
+        const int b = tile / tiles_h, r0 = th * G::TR, t0 = tt * G::TW;
+        const __bf16* sb = small + (long)b * Hs * T * (2 * C);
+        const __bf16* bb = big + (long)b * Hb * T * C;
+        __syncthreads();
+        if constexpr (GS) {
+            stage_tile<G::SB, true>(ss, sb, ygate + (long)b * Hs * T * (2 * C), G::TR, r0, Hs, t0, T, tid, dbacc, G::TR);
+            stage_tile<G::BB, false>(bs, bb, nullptr, G::BROWS, 2 * r0, Hb, t0, T, tid, dbacc, 0);
+        } else {
+            stage_tile<G::SB, false>(ss, sb, nullptr, G::TR, r0, Hs, t0, T, tid, dbacc, 0);
+            stage_tile<G::BB, true>(bs, bb, ygate + (long)b * Hb * T * C, G::BROWS, 2 * r0, Hb, t0, T, tid, dbacc,
+                                    th == tiles_h - 1 ? G::BROWS : 2 * G::TR);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        for (int r = row0; r < G::TR; r += 2) {
+            if (r0 + r >= Hs) break;
+            bf16x8 sa[G::NA];
+#pragma unroll
+            for (int a = 0; a < G::NA; ++a) {
+                s16x4 h2[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int p = r * G::TW + colh * 32 + 16 * u + 4 * g + trj;
+                    h2[u] = lds_tr16(ss + (long)p * G::SB + tr_off<G::SB>(p, a, trq));
+                }
+                sa[a] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(h2[0], h2[1], 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int c = 0; c < G::NBT; ++c) {
+                    s16x4 h2[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int p = (2 * r + k) * G::TW + colh * 32 + 16 * u + 4 * g + trj;
+                        h2[u] = lds_tr16(bs + (long)p * G::BB + tr_off<G::BB>(p, c, trq));
+                    }
+                    const bf16x8 bq = __builtin_bit_cast(bf16x8, __builtin_shufflevector(h2[0], h2[1], 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                    for (int a = 0; a < G::NA; ++a) acc[k][a][c] = mma32(sa[a], bq, acc[k][a][c]);
+                }
+        }
+    }
+    float* pw = part + ((long)blockIdx.x * 4 + wave) * G::DUMP;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int a = 0; a < G::NA; ++a)
+#pragma unroll
+            for (int c = 0; c < G::NBT; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pw[(((k * G::NA + a) * G::NBT + c) * 4 + r) * 64 + lane] = acc[k][a][c][r];
+    // bias gradient: a thread always stages the same physical 16-byte position of the gated operand's pixels (256 pieces per
+    // round is a multiple of 8 pixels, which leaves the swizzle bits unchanged), hence one fixed logical channel group
+    constexpr int GB = GS ? G::SB : G::BB, GC = GB / 2;
+    constexpr int CGn = GB >= 16 ? GB / 16 : 1, PPP = GB >= 16 ? 1 : 16 / GB;
+    __syncthreads();
+    float* dl = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dl[tid * 8 + j] = dbacc[j];
+    __syncthreads();
+    if (tid < GC) {
+        float sum = 0.f;
+        for (int t2 = 0; t2 < NT; ++t2) {
+            const int q = (t2 / CGn) * PPP, cgp = t2 % CGn;
+            const int cg = GB >= 32 ? ((((cgp >> 1) ^ blk_swz<GB>(q)) << 1) | (cgp & 1)) : cgp;
+            if (GC >= 8) { if (cg == (tid >> 3)) sum += dl[t2 * 8 + (tid & 7)]; }
+            else sum += dl[t2 * 8 + tid] + dl[t2 * 8 + 4 + tid];
+        }
+        dbpart[(long)blockIdx.x * 64 + tid] = sum;
+    }
+}
+
+struct W4Red { const float* part; const float* dbpart; int gw; float* dw; float* db; };
+
+// 1024 threads = 64 consecutive dump elements x 16 slices of the contributing waves (dumps) / workgroups (bias partials)
+template <int C, bool GS>
+__global__ __launch_bounds__(1024) void k_w4_reduce(W4Red ar) {
+    using G = W4<C>;
+    constexpr int GB = GS ? G::SB : G::BB;                       // bytes per pixel of the gated operand
+    constexpr int GC = GB / 2;                                   // its channel count = length of db
+    __shared__ float red[16][64];
+    const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + el;
+    float p8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (e < G::DUMP) {
+        const int nc = ar.gw * 4;
+        for (int j0 = sl; j0 < nc; j0 += 128)
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (j0 + 16 * u < nc) p8[u] += ar.part[(long)(j0 + 16 * u) * G::DUMP + e];
+    } else if (e < G::DUMP + GC) {
+        for (int j = sl; j < ar.gw; j += 16) p8[0] += ar.dbpart[(long)j * 64 + (e - G::DUMP)];
+    }
+    red[sl][el] = ((p8[0] + p8[1]) + (p8[2] + p8[3])) + ((p8[4] + p8[5]) + (p8[6] + p8[7]));
+    __syncthreads();
+    if (sl != 0) return;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sum += red[i][el];
+    if (e < G::DUMP) {
+        const int lane = e & 63, r = (e >> 6) & 3, t3 = e >> 8;
+        const int c = t3 % G::NBT, a = (t3 / G::NBT) % G::NA, k = t3 / (G::NBT * G::NA);
+        const int ach = 16 * a + 4 * (lane >> 4) + r, bch = 16 * c + (lane & 15);
+        if (ach < 2 * C && bch < C) ar.dw[(ach * C + bch) * 4 + k] += sum;
+    } else if (e < G::DUMP + GC) {
+        ar.db[e - G::DUMP] += sum;
+    }
+}
+
+// ---- launchers ---------------------------------------------------------------------------------------------------------
+constexpr int MAX_WG = 512;
+
+template <int C> constexpr long w4_scratch_floats() { return (long)MAX_WG * 4 * W4<C>::DUMP + (long)MAX_WG * 64; }
+
+inline int flat_grid(long ngroups) {
+    const long want = (ngroups + 3) / 4;
+    const long cap = (long)8 * tt_cus();
+    return (int)(want < cap ? want : cap);
+}
+
+template <int C, bool GATE, bool ACT>
+int launch_s4(const __bf16* in, const __bf16* gy, const float* w, const float* bias, __bf16* out, int B, int Hin, int Hout, int T,
+              hipStream_t st) {
+    const int tb = (T + 15) / 16;
+    const long ngroups = (long)B * Hout * tb;
+    hipLaunchKernelGGL((k_s4<C, GATE, ACT>), dim3(flat_grid(ngroups)), dim3(NT), 0, st, in, gy, w, bias, out, B, Hin, Hout, T, tb, ngroups);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+template <int C, bool GATE, bool ACT>
+int launch_p2(const __bf16* in, const __bf16* gy, const float* w, const float* bias, __bf16* out, int B, int Hin, int Hout, int T,
+              hipStream_t st) {
+    const int tb = (T + 15) / 16;
+    const long ngroups = (long)B * Hout * tb;
+    hipLaunchKernelGGL((k_p2<C, GATE, ACT>), dim3(flat_grid(ngroups)), dim3(NT), 0, st, in, gy, w, bias, out, B, Hin, Hout, T, tb, ngroups);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+template <int C, bool GS>
+int launch_w4(const __bf16* small, const __bf16* big, const __bf16* ygate, float* dw, float* db, float* ws, int B, int Hs, int Hb,
+              int T, hipStream_t st) {
+    using G = W4<C>;
+    static AttrOnce once;
+    auto kern = k_w4<C, GS>;
+    if (int rc = raise_lds(kern, G::LDS_BYTES, once)) return rc;
+    const int tiles_h = (Hs + G::TR - 1) / G::TR, tiles_t = (T + G::TW - 1) / G::TW, ntiles = B * tiles_h * tiles_t;
+    int gw = grid_for(ntiles, G::LDS_BYTES, 3);
+    if (gw > MAX_WG) gw = MAX_WG;
+    float* part = ws;
+    float* dbpart = ws + (long)MAX_WG * 4 * G::DUMP;
+    hipLaunchKernelGGL(kern, dim3(gw), dim3(NT), G::LDS_BYTES, st, small, big, ygate, part, dbpart, B, Hs, Hb, T, tiles_h, tiles_t, ntiles);
+    TT_LAUNCH_CHECK();
+    W4Red ra{part, dbpart, gw, dw, db};
+    constexpr int total = G::DUMP + (GS ? 2 * C : C);
+    hipLaunchKernelGGL((k_w4_reduce<C, GS>), dim3((total + 63) / 64), dim3(1024), 0, st, ra);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
+inline bool ok_shape(int B, int C, int H, int T) {
+    return B > 0 && H >= 4 && T > 0 && (C == 4 || C == 8 || C == 16 || C == 32) && (C != 4 || T % 2 == 0) &&
+           (long)H * T * 2 * C < (1l << 31);
+}
+
+}  // namespace
+
+#define TT_BY_C(C, CALL)                   \
+    switch (C) {                           \
+        case 4: { constexpr int CC = 4; return CALL; }   \
+        case 8: { constexpr int CC = 8; return CALL; }   \
+        case 16: { constexpr int CC = 16; return CALL; } \
+        case 32: { constexpr int CC = 32; return CALL; } \
+    }                                      \
+    return TT_E_UNSUPPORTED
+
+extern "C" {
+
+int64_t tt_stride16_scratch_bytes(int C) {
+    switch (C) {
+        case 4: return w4_scratch_floats<4>() * 4;
+        case 8: return w4_scratch_floats<8>() * 4;
+        case 16: return w4_scratch_floats<16>() * 4;
+        case 32: return w4_scratch_floats<32>() * 4;
+    }
+    return -1;
+}
+
+int tt_sconv16_fwd(const void* x, const float* w, const float* b, void* y, int B, int C, int H, int T, void* stream) {
+    if (!x || !w || !b || !y || !ok_shape(B, C, H, T)) return TT_E_BADARG;
+    const int Ho = (H - 4) / 2 + 1;
+    hipStream_t st = tt_stream(stream);
+    TT_BY_C(C, (launch_s4<CC, false, true>((const __bf16*)x, nullptr, w, b, (__bf16*)y, B, H, Ho, T, st)));
+}
+
+int tt_sconv16_bwd(const void* x, const void* y, const void* dy, const float* w, void* dx, float* dw, float* db, void* ws, int B,
+                   int C, int H, int T, void* stream) {
+    if (!x || !y || !dy || !w || !dw || !db || !ws || !ok_shape(B, C, H, T)) return TT_E_BADARG;
+    const int Ho = (H - 4) / 2 + 1;
+    hipStream_t st = tt_stream(stream);
+    if (dx) {
+        int rc = TT_E_UNSUPPORTED;
+        switch (C) {
+            case 4: rc = launch_p2<4, true, false>((const __bf16*)dy, (const __bf16*)y, w, nullptr, (__bf16*)dx, B, Ho, H, T, st); break;
+            case 8: rc = launch_p2<8, true, false>((const __bf16*)dy, (const __bf16*)y, w, nullptr, (__bf16*)dx, B, Ho, H, T, st); break;
+            case 16: rc = launch_p2<16, true, false>((const __bf16*)dy, (const __bf16*)y, w, nullptr, (__bf16*)dx, B, Ho, H, T, st); break;
+            case 32: rc = launch_p2<32, true, false>((const __bf16*)dy, (const __bf16*)y, w, nullptr, (__bf16*)dx, B, Ho, H, T, st); break;
+        }
+        if (rc) return rc;
+    }
+    TT_BY_C(C, (launch_w4<CC, true>((const __bf16*)dy, (const __bf16*)x, (const __bf16*)y, dw, db, (float*)ws, B, Ho, H, T, st)));
+}
+
+int tt_tconv16_fwd(const void* x, const float* w, const float* b, void* y, int B, int C, int H, int T, int out_pad, void* stream) {
+    if (!x || !w || !b || !y || B <= 0 || H <= 0 || T <= 0 || out_pad < 0 || out_pad > 1) return TT_E_BADARG;
+    const int Ho = 2 * H + 2 + out_pad;
+    if (!ok_shape(B, C, Ho, T)) return TT_E_BADARG;
+    hipStream_t st = tt_stream(stream);
+    TT_BY_C(C, (launch_p2<CC, false, true>((const __bf16*)x, nullptr, w, b, (__bf16*)y, B, H, Ho, T, st)));
+}
+
+int tt_tconv16_bwd(const void* x, const void* y, const void* dy, const float* w, void* dx, float* dw, float* db, void* ws, int B,
+                   int C, int H, int T, int out_pad, void* stream) {
+    if (!x || !y || !dy || !w || !dw || !db || !ws || B <= 0 || H <= 0 || T <= 0 || out_pad < 0 || out_pad > 1) return TT_E_BADARG;
+    const int Ho = 2 * H + 2 + out_pad;
+    if (!ok_shape(B, C, Ho, T)) return TT_E_BADARG;
+    hipStream_t st = tt_stream(stream);
+    if (dx) {
+        int rc = TT_E_UNSUPPORTED;
+        switch (C) {
+            case 4: rc = launch_s4<4, true, false>((const __bf16*)dy, (const __bf16*)y, w, nullptr, (__bf16*)dx, B, Ho, H, T, st); break;
+            case 8: rc = launch_s4<8, true, false>((const __bf16*)dy, (const __bf16*)y, w, nullptr, (__bf16*)dx, B, Ho, H, T, st); break;
+            case 16: rc = launch_s4<16, true, false>((const __bf16*)dy, (const __bf16*)y, w, nullptr, (__bf16*)dx, B, Ho, H, T, st); break;
+            case 32: rc = launch_s4<32, true, false>((const __bf16*)dy, (const __bf16*)y, w, nullptr, (__bf16*)dx, B, Ho, H, T, st); break;
+        }
+        if (rc) return rc;
+    }
+    TT_BY_C(C, (launch_w4<CC, false>((const __bf16*)x, (const __bf16*)dy, (const __bf16*)y, dw, db, (float*)ws, B, H, Ho, T, st)));
+}
+
+}  // extern "C"

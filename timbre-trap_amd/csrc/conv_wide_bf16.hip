@@ -22,35 +22,9 @@
 //   k_wrb_wgrad<C,D>               dW1[co][ci][tap] = sum_pix dA1[co][pix] x[ci][pix + tap]: K = pixels, both operands by
 //                                  LDS transpose reads (ds_read_b64_tr_b16) from channel-innermost images
 //   k_wrb_reduce<C>                sums the per-wave register dumps into the fp32 gradients (+=), no atomics anywhere
-#include "common.h"
-#include <stdlib.h>
-#include <type_traits>
+#include "bf16_common.h"
 
 namespace {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-
-constexpr int NT = 256;                        // threads per workgroup (4 waves)
-
-__device__ float4 g_wzero16;                   // DMA source of out-of-image pieces
-
-__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-// A (16 x 32) . B (32 x 16): lane l holds row / column l & 15 and k = 8 (l >> 4) + j; D: column l & 15, rows 4 (l >> 4) + r
-__device__ __forceinline__ f32x4 mma32(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
-// K = 16: lane l holds k = 4 (l >> 4) + j
-__device__ __forceinline__ f32x4 mma16(s16x4 a, s16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
-
-__device__ __forceinline__ int xcd_order(int v, int n) {          // see conv_mfma.hip: one contiguous eighth of the raster per XCD
-    const int per = n >> 3;
-    return v < (per << 3) ? (v & 7) * per + (v >> 3) : v;
-}
-__device__ __forceinline__ float elu_f(float a) { return a > 0.f ? a : (__expf(a) - 1.f); }
 
 // Channel held by row m of co-tile ct.  C = 32: rows 4q..4q+3 of tile 0 / 1 are channels 8q..8q+3 / 8q+4..8q+7, so the
 // lane that owns D rows 4g..4g+3 of both tiles owns the eight CONSECUTIVE channels 8g..8g+7 (16 bytes).  C = 16: identity.
@@ -264,14 +238,7 @@ __global__ __launch_bounds__(NT, 2) void k_wrb_conv(const __bf16* __restrict__ x
 // One wave per group of 16 consecutive pixels (the tensor is [npix][C]); operands straight from HBM in B-operand layout.
 // Every workgroup leaves its accumulators as a raw register dump [dW2: ((a NCT + c) 4 + r) 64 + lane][db1 C][db2 C]
 // (the four waves summed through LDS); k_wrb_reduce sums the dumps of all workgroups (no atomics anywhere).
-//
-// ds_read_b64_tr_b16 (gfx950 transpose read), per 16-lane group: lane 4j + q supplies the address of 4 consecutive bf16
-// (row j, columns 4q..4q+3); lane i receives column i of rows 0..3.  With rows = pixels and columns = the 16 channels of a
-// tile that is the K = pixels operand of v_mfma_f32_16x16x16_bf16 straight from a channel-innermost LDS image.
-__device__ __forceinline__ s16x4 lds_tr16(const unsigned char* p) {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
-}
-
+// The 16-pixel tiles are read back transposed (lds_tr16, bf16_common.h) as the K = pixels operands of the dW2 product.
 template <int C> struct WA {
     static constexpr int PS = C * 2 + 8;                         // bytes per pixel of the transposition buffers (bank spread)
     static constexpr int WAVE_BYTES = 2 * 16 * PS;               // dA2 and h1 of one group
@@ -601,23 +568,6 @@ __global__ __launch_bounds__(1024) void k_wrb_reduce(RedArgs ar) {
 }
 
 // ---- launchers -------------------------------------------------------------------------------------------------------
-inline int grid_for(int ntiles, int lds_bytes, int max_per_cu) {
-    int per = lds_bytes > 0 ? (160 * 1024) / lds_bytes : max_per_cu;
-    if (per > max_per_cu) per = max_per_cu;
-    if (per < 1) per = 1;
-    const int cap = tt_cus() * per;
-    return ntiles < cap ? ntiles : cap;
-}
-
-template <class K> int raise_lds(K kernel, int bytes, AttrOnce& once) {
-    const int dev = once.pending();
-    if (dev >= 0) {
-        TT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        once.mark(dev);
-    }
-    return 0;
-}
-
 template <int C, int D, int MODE, bool SAVE>
 int launch_conv(const __bf16* x, const float* w1, const float* b1, const float* w2, const float* b2, const __bf16* res,
                 __bf16* y, __bf16* h1, int B, int H, int T, hipStream_t st) {
@@ -1141,7 +1091,7 @@ int64_t tt_wide_scratch_bytes(int B, int C, int H, int T) {
 }
 
 int tt_wide_pack(const float* x, void* out, int B, int C, int H, int T, void* stream) {
-    if (!x || !out || !shape_ok(B, C, H, T)) return TT_E_BADARG;
+    if (!x || !out || !(shape_ok(B, C, H, T) || (C == 64 && B > 0 && H > 0 && T > 0))) return TT_E_BADARG;
     const long npix = (long)B * H * T, pieces = npix * C / 8;
     const unsigned grid = (unsigned)((pieces + NT - 1) / NT);
     hipStream_t st = tt_stream(stream);
@@ -1149,6 +1099,7 @@ int tt_wide_pack(const float* x, void* out, int B, int C, int H, int T, void* st
         case 4: hipLaunchKernelGGL(k_wide_pack<4>, dim3(grid), dim3(NT), 0, st, x, (__bf16*)out, H, T, npix); break;
         case 8: hipLaunchKernelGGL(k_wide_pack<8>, dim3(grid), dim3(NT), 0, st, x, (__bf16*)out, H, T, npix); break;
         case 16: hipLaunchKernelGGL(k_wide_pack<16>, dim3(grid), dim3(NT), 0, st, x, (__bf16*)out, H, T, npix); break;
+        case 64: hipLaunchKernelGGL(k_wide_pack<64>, dim3(grid), dim3(NT), 0, st, x, (__bf16*)out, H, T, npix); break;
         default: hipLaunchKernelGGL(k_wide_pack<32>, dim3(grid), dim3(NT), 0, st, x, (__bf16*)out, H, T, npix);
     }
     TT_LAUNCH_CHECK();
@@ -1156,7 +1107,7 @@ int tt_wide_pack(const float* x, void* out, int B, int C, int H, int T, void* st
 }
 
 int tt_wide_unpack(const void* in, float* y, int B, int C, int H, int T, void* stream) {
-    if (!in || !y || !shape_ok(B, C, H, T)) return TT_E_BADARG;
+    if (!in || !y || !(shape_ok(B, C, H, T) || (C == 64 && B > 0 && H > 0 && T > 0))) return TT_E_BADARG;
     const long npix = (long)B * H * T, pieces = npix * C / 8;
     const unsigned grid = (unsigned)((pieces + NT - 1) / NT);
     hipStream_t st = tt_stream(stream);
@@ -1164,6 +1115,7 @@ int tt_wide_unpack(const void* in, float* y, int B, int C, int H, int T, void* s
         case 4: hipLaunchKernelGGL(k_wide_unpack<4>, dim3(grid), dim3(NT), 0, st, (const __bf16*)in, y, H, T, npix); break;
         case 8: hipLaunchKernelGGL(k_wide_unpack<8>, dim3(grid), dim3(NT), 0, st, (const __bf16*)in, y, H, T, npix); break;
         case 16: hipLaunchKernelGGL(k_wide_unpack<16>, dim3(grid), dim3(NT), 0, st, (const __bf16*)in, y, H, T, npix); break;
+        case 64: hipLaunchKernelGGL(k_wide_unpack<64>, dim3(grid), dim3(NT), 0, st, (const __bf16*)in, y, H, T, npix); break;
         default: hipLaunchKernelGGL(k_wide_unpack<32>, dim3(grid), dim3(NT), 0, st, (const __bf16*)in, y, H, T, npix);
     }
     TT_LAUNCH_CHECK();

@@ -139,7 +139,7 @@ class Encoder(nn.Module):
         top = embeddings[-1]
         if top.size(-2) != self.convlat.kernel_size[0]:
             raise ValueError('feature size %d does not match the latent head (%d)' % (top.size(-2), self.convlat.kernel_size[0]))
-        latents = ops.LatentEncodeFn.apply(top, self.convlat.weight, self.convlat.bias)
+        latents = ops.LatentEncodeFn.apply(ops.to_planar32(top), self.convlat.weight, self.convlat.bias)
         return latents, embeddings, dict()
 
 
@@ -173,11 +173,11 @@ class Decoder(nn.Module):
         y = ops.LatentDecodeFn.apply(latents, c.weight, c.bias)
         skips = None if encoder_embeddings is None else list(encoder_embeddings)[::-1]
         if skips is not None:
-            y = ops.AddFn.apply(y, skips[0])
+            y = ops.add(y, skips[0])
         for i, block in enumerate((self.block1, self.block2, self.block3, self.block4)):
             y = block(y)
             if skips is not None:
-                y = ops.AddFn.apply(y, skips[i + 1])
+                y = ops.add(y, skips[i + 1])
         o = self.convout
         return ops.conv(y, o.weight, o.bias, ConvCfg(3, 3, 1, 1, 1, 1, 'conv', 0, ACT_NONE))
 
@@ -206,7 +206,7 @@ class TimbreTrap(nn.Module):
         """Scale each encoder embedding by its learnable weight, or drop them (no skip connections)."""
         if self.skip_weights is None:
             return None
-        return [ops.ScaleFn.apply(e, self.skip_weights, i) for i, e in enumerate(embeddings)]
+        return [ops.scale(e, self.skip_weights, i) for i, e in enumerate(embeddings)]
 
     def decode(self, latents, embeddings=None, transcribe=False):
         """latents (B,D,T) -> logits (B,2,F,T); the extra latent channel is 1 for reconstruction, 0 for transcription."""

@@ -172,6 +172,7 @@ class ConvFn(torch.autograd.Function):
 
 
 def conv(x, w, b, cfg):
+    x = to_planar32(x)
     return ConvFn.apply(x, w, b, cfg)
 
 
@@ -324,9 +325,16 @@ class TransposedConvFn(torch.autograd.Function):
         return dx, rw, rb, None
 
 
+def _stride16_ok(C, T, w, b):
+    return (FUSED_RESBLOCK and C in WIDE_CHANNELS and (C != 4 or T % 2 == 0) and w.shape == (2 * C, C, 4, 1) and b is not None)
+
+
 def strided_conv(x, w, b, win, hop):
     """Conv2d(C, Cout, (win,1), stride (hop,1)) + ELU."""
     C = x.size(1)
+    if win == 4 and hop == 2 and x.size(2) >= 4 and _stride16_ok(C, x.size(-1), w, b) and (is_cl16(x) or wide_storage() == 'bf16'):
+        return SConv16Fn.apply(to_cl16(x), w, b)
+    x = to_planar32(x)
     if FUSED_RESBLOCK and win == 4 and hop == 2 and C in FUSED_CHANNELS and w.shape == (2 * C, C, 4, 1) and b is not None:
         return StridedConvFn.apply(x, w, b)
     return conv(x, w, b, ConvCfg(win, 1, hop, 1, 0, 0, 'conv', 0, ACT_ELU))
@@ -335,6 +343,10 @@ def strided_conv(x, w, b, win, hop):
 def transposed_conv(x, w, b, win, hop, out_pad):
     """ConvTranspose2d(Cin, C, (win,1), stride (hop,1), output_padding (out_pad,0)) + ELU."""
     C = w.size(1)
+    if (win == 4 and hop == 2 and x.size(1) == 2 * C and out_pad in (0, 1) and _stride16_ok(C, x.size(-1), w, b)
+            and (is_cl16(x) or wide_storage() == 'bf16')):
+        return TConv16Fn.apply(to_cl16(x), w, b, out_pad)
+    x = to_planar32(x)
     if (FUSED_RESBLOCK and win == 4 and hop == 2 and C in FUSED_CHANNELS and w.shape == (2 * C, C, 4, 1)
             and x.size(1) == 2 * C and b is not None and out_pad in (0, 1)):
         return TransposedConvFn.apply(x, w, b, out_pad)
@@ -342,6 +354,7 @@ def transposed_conv(x, w, b, win, hop, out_pad):
 
 
 def residual_block(x, w1, b1, w2, b2, dilation):
+    x = to_planar32(x)
     C = x.size(1)
     if (FUSED_RESBLOCK and C in FUSED_CHANNELS and w1.shape == (C, C, 3, 3) and w2.shape == (C, C, 1, 1)
             and 1 <= dilation <= 3):
@@ -350,6 +363,194 @@ def residual_block(x, w1, b1, w2, b2, dilation):
     h = conv(x, w1, b1, ConvCfg(k, k, 1, dilation, dilation * (k - 1) // 2, dilation * (k - 1) // 2, 'conv', 0, ACT_ELU))
     h = conv(h, w2, b2, ConvCfg(1, 1, 1, 1, 0, 0, 'conv', 0, ACT_ELU))
     return AddFn.apply(h, x)
+
+
+# ---- bf16 channels-last activations ("cl16") ---------------------------------------------------------------------------
+# In the bf16 mode the activations between the layers of the autoencoder are torch.bfloat16 tensors of LOGICAL shape
+# (B,C,H,T) in torch's channels_last memory format, i.e. stored [B][H][T][C] -- what csrc/conv_wide_bf16.hip and
+# csrc/conv_stride_bf16.hip read and write.  (Under autocast the reference's activations are half-precision tensors of the same
+# logical shape.)  Layers that have no bf16 kernel (the 3x3 boundary convolutions, the latent heads, the losses) see fp32
+# planar tensors through to_planar32 / to_cl16, which are differentiable layout changes.
+
+CL16_CHANNELS = (4, 8, 16, 32, 64)
+
+
+def is_cl16(x):
+    return (x.dtype == torch.bfloat16 and x.dim() == 4 and x.stride(1) == 1 and x.stride(3) == x.size(1)
+            and x.stride(2) == x.size(1) * x.size(3) and x.stride(0) == x.size(1) * x.size(2) * x.size(3))
+
+
+def new_cl16(B, C, H, T, device):
+    return torch.empty((B, H, T, C), dtype=torch.bfloat16, device=device).permute(0, 3, 1, 2)
+
+
+def _pack(x32):
+    B, C, H, T = x32.shape
+    out = new_cl16(B, C, H, T, x32.device)
+    check(_hip.lib().tt_wide_pack(ptr(x32), ptr(out), B, C, H, T, stream_ptr()), 'tt_wide_pack')
+    return out
+
+
+def _unpack(x16):
+    B, C, H, T = x16.shape
+    out = torch.empty((B, C, H, T), dtype=torch.float32, device=x16.device)
+    check(_hip.lib().tt_wide_unpack(ptr(x16), ptr(out), B, C, H, T, stream_ptr()), 'tt_wide_unpack')
+    return out
+
+
+def _cl16_ok(C, T):
+    return C in CL16_CHANNELS and (C != 4 or T % 2 == 0)
+
+
+def _as_cl16(t):
+    """Any (B,C,H,T) tensor as cl16 (no autograd): used on incoming gradients."""
+    if is_cl16(t):
+        return t
+    if t.dtype == torch.float32 and _cl16_ok(t.size(1), t.size(3)):
+        return _pack(t.contiguous())
+    return t.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+
+
+class ToCL16Fn(torch.autograd.Function):
+    """fp32 planar (B,C,H,T) -> cl16; the gradient comes back as fp32 planar."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _hip.require_cuda(x)
+        return _pack(_f32c(x))
+
+    @staticmethod
+    def backward(ctx, g):
+        return _unpack(_as_cl16(g))
+
+
+class ToPlanar32Fn(torch.autograd.Function):
+    """cl16 -> fp32 planar (B,C,H,T); the gradient goes back as cl16."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return _unpack(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _pack(_f32c(g))
+
+
+def to_cl16(x):
+    if is_cl16(x):
+        return x
+    if not _cl16_ok(x.size(1), x.size(3)):
+        raise ValueError('no bf16 channels-last form for %d channels x %d frames' % (x.size(1), x.size(3)))
+    return ToCL16Fn.apply(x)
+
+
+def to_planar32(x):
+    """What every fp32-only layer calls on its input: identity for fp32 tensors."""
+    if is_cl16(x):
+        return ToPlanar32Fn.apply(x)
+    return x
+
+
+class Level16Fn(torch.autograd.Function):
+    """The residual blocks of one level on cl16 tensors (csrc/conv_wide_bf16.hip); see WideLevelFn for the fp32-facing form."""
+
+    @staticmethod
+    def forward(ctx, x, dilations, *params):
+        B, C, H, T = x.shape
+        lib, st = _hip.lib(), stream_ptr()
+        needs_grad = any(ctx.needs_input_grad)
+        cur, saved = x, []
+        for i, d in enumerate(dilations):
+            w1, b1, w2, b2 = params[4 * i: 4 * i + 4]
+            nxt = new_cl16(B, C, H, T, x.device)
+            h1 = new_cl16(B, C, H, T, x.device) if needs_grad else None
+            with _hip.timed('wide_rb_fwd_C%d' % C):
+                check(lib.tt_wide_rb_fwd(ptr(cur), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(nxt), ptr(h1), B, C, H, T, d, st),
+                      'tt_wide_rb_fwd')
+            saved += [cur, h1]
+            cur = nxt
+        ctx.dilations = tuple(dilations)
+        ctx.params = params
+        if needs_grad:
+            ctx.save_for_backward(*params, *saved)
+        return cur
+
+    @staticmethod
+    def backward(ctx, dy):
+        nb = len(ctx.dilations)
+        tensors = ctx.saved_tensors
+        params, saved = tensors[:4 * nb], tensors[4 * nb:]
+        B, C, H, T = saved[0].shape
+        lib, st = _hip.lib(), stream_ptr()
+        g = _as_cl16(dy)
+        ws = torch.empty(lib.tt_wide_scratch_bytes(B, C, H, T), dtype=torch.uint8, device=g.device)
+        grads = [None] * (4 * nb)
+        for i in reversed(range(nb)):
+            w1, b1, w2, b2 = params[4 * i: 4 * i + 4]
+            xin, h1 = saved[2 * i], saved[2 * i + 1]
+            (dw1, r1), (db1, r2), (dw2, r3), (db2, r4) = (_grad_target(t) for t in ctx.params[4 * i: 4 * i + 4])
+            gx = new_cl16(B, C, H, T, g.device)
+            with _hip.timed('wide_rb_bwd_C%d' % C):
+                check(lib.tt_wide_rb_bwd(ptr(xin), ptr(h1), ptr(g), ptr(w1), ptr(w2), ptr(b2), ptr(gx), ptr(dw1), ptr(db1),
+                                         ptr(dw2), ptr(db2), ptr(ws), B, C, H, T, ctx.dilations[i], st), 'tt_wide_rb_bwd')
+            grads[4 * i: 4 * i + 4] = [r1, r2, r3, r4]
+            g = gx
+        return (g, None, *grads)
+
+
+class SConv16Fn(torch.autograd.Function):
+    """EncoderBlock.sconv on cl16 tensors: (B,C,H,T) -> (B,2C,(H-4)/2+1,T) (csrc/conv_stride_bf16.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        B, C, H, T = x.shape
+        y = new_cl16(B, 2 * C, (H - 4) // 2 + 1, T, x.device)
+        check(_hip.lib().tt_sconv16_fwd(ptr(x), ptr(w), ptr(b), ptr(y), B, C, H, T, stream_ptr()), 'tt_sconv16_fwd')
+        ctx.params = (w, b)
+        ctx.save_for_backward(x, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        B, C, H, T = x.shape
+        lib = _hip.lib()
+        g = _as_cl16(dy)
+        dx = new_cl16(B, C, H, T, x.device) if ctx.needs_input_grad[0] else None
+        (dw, r1), (db, r2) = (_grad_target(t) for t in ctx.params)
+        ws = torch.empty(lib.tt_stride16_scratch_bytes(C), dtype=torch.uint8, device=x.device)
+        check(lib.tt_sconv16_bwd(ptr(x), ptr(y), ptr(g), ptr(w), ptr(dx), ptr(dw), ptr(db), ptr(ws), B, C, H, T, stream_ptr()),
+              'tt_sconv16_bwd')
+        return dx, r1, r2
+
+
+class TConv16Fn(torch.autograd.Function):
+    """DecoderBlock.tconv on cl16 tensors: (B,2C,H,T) -> (B,C,2H+2+out_pad,T)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, out_pad):
+        B, C2, H, T = x.shape
+        C = C2 // 2
+        y = new_cl16(B, C, 2 * H + 2 + out_pad, T, x.device)
+        check(_hip.lib().tt_tconv16_fwd(ptr(x), ptr(w), ptr(b), ptr(y), B, C, H, T, out_pad, stream_ptr()), 'tt_tconv16_fwd')
+        ctx.params = (w, b)
+        ctx.out_pad = out_pad
+        ctx.save_for_backward(x, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        B, C2, H, T = x.shape
+        C = C2 // 2
+        lib = _hip.lib()
+        g = _as_cl16(dy)
+        dx = new_cl16(B, C2, H, T, x.device) if ctx.needs_input_grad[0] else None
+        (dw, r1), (db, r2) = (_grad_target(t) for t in ctx.params)
+        ws = torch.empty(lib.tt_stride16_scratch_bytes(C), dtype=torch.uint8, device=x.device)
+        check(lib.tt_tconv16_bwd(ptr(x), ptr(y), ptr(g), ptr(w), ptr(dx), ptr(dw), ptr(db), ptr(ws), B, C, H, T, ctx.out_pad,
+                                 stream_ptr()), 'tt_tconv16_bwd')
+        return dx, r1, r2, None
 
 
 class WideLevelFn(torch.autograd.Function):
@@ -416,18 +617,34 @@ class WideLevelFn(torch.autograd.Function):
         return (dx, None, *grads)
 
 
+def add(a, b):
+    """a + b for the skip joins: cl16 when either side is (torch's elementwise add keeps the layout), AddFn otherwise."""
+    if is_cl16(a) or is_cl16(b):
+        return to_cl16(a) + to_cl16(b)
+    return AddFn.apply(a, b)
+
+
+def scale(e, weights, i):
+    """weights[i] * e (TimbreTrap.apply_skip_connections)."""
+    if is_cl16(e):
+        return e * weights[i]
+    return ScaleFn.apply(e, weights, i)
+
+
 def residual_level(x, blocks):
     """
-    block3(block2(block1(x))) for the ResidualConv2dBlock modules ``blocks``: one WideLevelFn when the level is wide and
-    ops.wide_storage() == 'bf16', the per-block path otherwise.
+    block3(block2(block1(x))) for the ResidualConv2dBlock modules ``blocks``.  With ops.wide_storage() == 'bf16' the level runs
+    on cl16 tensors (Level16Fn) and RETURNS a cl16 tensor -- the next layer either has a bf16 kernel or converts with
+    to_planar32; otherwise the per-block fp32 path.
     """
-    C = x.size(1)
-    if (wide_storage() == 'bf16' and C in WIDE_CHANNELS and FUSED_RESBLOCK and (C != 4 or x.size(-1) % 2 == 0)
+    C, T = x.size(1), x.size(-1)
+    if (wide_storage() == 'bf16' and C in WIDE_CHANNELS and FUSED_RESBLOCK and (C != 4 or T % 2 == 0)
             and all(b.conv1[0].weight.shape == (C, C, 3, 3) and 1 <= b.dilation <= 3 for b in blocks)):
         params = []
         for b in blocks:
             params += [b.conv1[0].weight, b.conv1[0].bias, b.conv2[0].weight, b.conv2[0].bias]
-        return WideLevelFn.apply(x, tuple(b.dilation for b in blocks), *params)
+        return Level16Fn.apply(to_cl16(x), tuple(b.dilation for b in blocks), *params)
+    x = to_planar32(x)
     for b in blocks:
         x = b(x)
     return x
@@ -620,6 +837,11 @@ def _instrument(cls, name, keyfn):
 _instrument(ConvFn, 'conv', lambda x, w, b, cfg: '%dto%d' % ((x.size(1), w.size(0)) if cfg.kind == 'conv' else (x.size(1), w.size(1))))
 _instrument(ResBlockFn, 'rb', lambda x, *a: 'C%d' % x.size(1))
 _instrument(WideLevelFn, 'widelevel', lambda x, *a: 'C%d' % x.size(1))
+_instrument(Level16Fn, 'widelevel', lambda x, *a: 'C%d' % x.size(1))
+_instrument(SConv16Fn, 'sconv16', lambda x, *a: 'C%d' % x.size(1))
+_instrument(TConv16Fn, 'tconv16', lambda x, w, *a: 'C%d' % w.size(1))
+_instrument(ToCL16Fn, 'tocl16', lambda x: 'C%d' % x.size(1))
+_instrument(ToPlanar32Fn, 'toplanar', lambda x: 'C%d' % x.size(1))
 _instrument(StridedConvFn, 'sconv', lambda x, *a: 'C%d' % x.size(1))
 _instrument(TransposedConvFn, 'tconv', lambda x, w, *a: 'C%d' % w.size(1))
 _instrument(LatentEncodeFn, 'latenc', lambda x, *a: 'C%d' % x.size(1))

@@ -164,7 +164,18 @@ def family_table(events, n_steps, batch, mc, latent):
             C = int(tag[1:]); px = hs[level[C]] * T * batch
             fl = 3 * 2.0 * 10 * C * C * px * (2 if bwd else 1)
             by = 3 * 2.0 * C * px * (3 if bwd else 2)
-            add('wide residual levels (3 blocks, bf16 storage) ' + ('backward' if bwd else 'forward'), ms, calls, fl * calls, by * calls, 'hbm')
+            add('residual levels (3 blocks per call, bf16 channels-last) ' + ('backward' if bwd else 'forward'), ms, calls, fl * calls, by * calls, 'hbm')
+        elif kind in ('sconv16', 'tconv16'):
+            C = int(tag[1:]); l = level[C]
+            big, small = C * hs[l] * T * batch, 2 * C * hs[l + 1] * T * batch          # elements at the C side / the 2C side
+            fl = 2.0 * 4 * C * 2 * C * hs[l + 1] * T * batch * (2 if bwd else 1)
+            by = 2.0 * (big + small) * (2 if bwd else 1)
+            add('strided + transposed (4,1) layers, bf16 channels-last ' + ('backward' if bwd else 'forward'), ms, calls, fl * calls,
+                by * calls, 'hbm')
+        elif kind in ('tocl16', 'toplanar'):
+            C = int(tag[1:])
+            n_el = C * hs[level[C]] * T * batch if C in level else 64 * 31 * T * batch
+            add('fp32 planar <-> bf16 channels-last at the fp32-only layers', ms, calls, 0.0, 6.0 * n_el * calls, 'hbm')
         elif kind in ('sconv', 'tconv'):
             C = int(tag[1:]); l = level[C]
             big, small = C * hs[l] * T * batch, 2 * C * hs[l + 1] * T * batch          # elements at the C side / the 2C side

@@ -106,7 +106,23 @@ __global__ __launch_bounds__(NT) void k_s4(const __bf16* __restrict__ in, const 
 #pragma unroll
     for (int e = 0; e < NCH; ++e) br[e] = (ACT && NCH * g + e < COUT) ? bias[NCH * g + e] : 0.f;
 
-    for (long grp = (long)blockIdx.x * 4 + wave; grp < ngroups; grp += (long)gridDim.x * 4) {
+    auto fetch = [&](long grp, vec_t (&q)[S::NS]) {
+        const int tblk = (int)(grp % tb);
+        const long bh = grp / tb;
+        const int ho = (int)(bh % Hout), b = (int)(bh / Hout);
+        const int t = tblk * 16 + n;
+#pragma unroll
+        for (int j = 0; j < S::NS; ++j) {
+            const int hi = 2 * ho + S::kh(j, g);
+            q[j] = load_gated<S::CE>(in, gy, (((long)b * Hin + hi) * T + t) * C + S::c0(g), grp < ngroups && t < T && hi < Hin, GATE);
+        }
+    };
+    const long gstride = (long)gridDim.x * 4;
+    long grp = (long)blockIdx.x * 4 + wave;
+    vec_t bq[S::NS], bn[S::NS];
+    fetch(grp, bq);
+    for (; grp < ngroups; grp += gstride) {
+        fetch(grp + gstride, bn);                                // next group's rows are in flight during this one's products
         const int tblk = (int)(grp % tb);
         const long bh = grp / tb;
         const int ho = (int)(bh % Hout), b = (int)(bh / Hout);
@@ -115,12 +131,6 @@ __global__ __launch_bounds__(NT) void k_s4(const __bf16* __restrict__ in, const 
         f32x4 acc[NCT];
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-        vec_t bq[S::NS];
-#pragma unroll
-        for (int j = 0; j < S::NS; ++j) {
-            const int hi = 2 * ho + S::kh(j, g);
-            bq[j] = load_gated<S::CE>(in, gy, (((long)b * Hin + hi) * T + t) * C + S::c0(g), ok && hi < Hin, GATE);
-        }
 #pragma unroll
         for (int j = 0; j < S::NS; ++j)
 #pragma unroll
@@ -134,6 +144,8 @@ __global__ __launch_bounds__(NT) void k_s4(const __bf16* __restrict__ in, const 
                 v[4 * ct + r] = ACT ? elu_f(a) : a;
             }
         store_lane<COUT, NCH>(out, ((long)b * Hout + ho) * T + t, g, v, ok);
+#pragma unroll
+        for (int j = 0; j < S::NS; ++j) bq[j] = bn[j];
     }
 }
 
@@ -172,34 +184,181 @@ __global__ __launch_bounds__(NT) void k_p2(const __bf16* __restrict__ in, const 
 #pragma unroll
     for (int e = 0; e < NCH; ++e) br[e] = (ACT && NCH * g + e < C) ? bias[NCH * g + e] : 0.f;
 
-    for (long grp = (long)blockIdx.x * 4 + wave; grp < ngroups; grp += (long)gridDim.x * 4) {
+    // one group = 16 frames of the output row PAIR 2m, 2m+1: both parities read the same two input rows m and m - 1
+    const int Hp = (Hout + 1) >> 1;
+    auto fetch = [&](long grp, vec_t (&q)[S::NS]) {
         const int tblk = (int)(grp % tb);
-        const long bh = grp / tb;
-        const int h = (int)(bh % Hout), b = (int)(bh / Hout);
-        const int t = tblk * 16 + n, par = h & 1;
-        const bool ok = t < T;
-        f32x4 acc[NCT];
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-        vec_t bq[S::NS];
+        const long bm = grp / tb;
+        const int m = (int)(bm % Hp), b = (int)(bm / Hp);
+        const int t = tblk * 16 + n;
 #pragma unroll
         for (int j = 0; j < S::NS; ++j) {
-            const int hi = ((h - par) >> 1) - S::rs(j, g);
-            bq[j] = load_gated<S::CE>(in, gy, (((long)b * Hin + hi) * T + t) * CIN + S::c0(j, g), ok && hi >= 0 && hi < Hin, GATE);
+            const int hi = m - S::rs(j, g);
+            q[j] = load_gated<S::CE>(in, gy, (((long)b * Hin + hi) * T + t) * CIN + S::c0(j, g),
+                                     grp < ngroups && t < T && hi >= 0 && hi < Hin, GATE);
+        }
+    };
+    const long gstride = (long)gridDim.x * 4;
+    long grp = (long)blockIdx.x * 4 + wave;
+    vec_t bq[S::NS], bn[S::NS];
+    fetch(grp, bq);
+    for (; grp < ngroups; grp += gstride) {
+        fetch(grp + gstride, bn);                                // next group's rows are in flight during this one's products
+        const int tblk = (int)(grp % tb);
+        const long bm = grp / tb;
+        const int m = (int)(bm % Hp), b = (int)(bm / Hp);
+        const int t = tblk * 16 + n;
+        const bool ok = t < T;
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            const int h = 2 * m + par;
+            f32x4 acc[NCT];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < S::NS; ++j)
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) acc[ct] = mma_e<S::CE>(A[par][j][ct], bq[j], acc[ct]);
+            float v[NCH];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float a = acc[ct][r] + br[4 * ct + r];
+                    v[4 * ct + r] = ACT ? elu_f(a) : a;
+                }
+            store_lane<C, NCH>(out, ((long)b * Hout + h) * T + t, g, v, ok && h < Hout);
         }
 #pragma unroll
-        for (int j = 0; j < S::NS; ++j)
+        for (int j = 0; j < S::NS; ++j) bq[j] = bn[j];
+    }
+}
+
+// ---- C = 4: a lane is a pixel (v_mfma_f32_4x4x4_16b_bf16, see conv_wide_bf16.hip) ----------------------------------------
+// With 4 / 8 channels a 16-row tile is mostly padding and three quarters of the lanes would idle in the epilogue; here every
+// lane loads its own pixel's rows (8 / 16 bytes), owns all output channels of its pixel and stores 16 / 8 bytes.
+__device__ __forceinline__ f32x4 mma4(s16x4 a, s16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ s16x4 lo4(bf16x8 v) { return __builtin_bit_cast(s16x4, __builtin_shufflevector(v, v, 0, 1, 2, 3)); }
+__device__ __forceinline__ s16x4 hi4(bf16x8 v) { return __builtin_bit_cast(s16x4, __builtin_shufflevector(v, v, 4, 5, 6, 7)); }
+
+template <bool GATE, bool ACT>
+__global__ __launch_bounds__(NT) void k_s4c4(const __bf16* __restrict__ in, const __bf16* __restrict__ gy,
+                                              const float* __restrict__ w, const float* __restrict__ bias,
+                                              __bf16* __restrict__ out, int B, int Hin, int Hout, int T, int tb, long ngroups) {
+    constexpr int C = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i4 = lane & 3;
+    s16x4 A[4][2];                                               // [kh][output block of 4]
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) acc[ct] = mma_e<S::CE>(par ? A[1][j][ct] : A[0][j][ct], bq[j], acc[ct]);
-        float v[NCH];
+    for (int kh = 0; kh < 4; ++kh)
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
+        for (int ob = 0; ob < 2; ++ob) {
+            bf16x4 t;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float a = acc[ct][r] + br[4 * ct + r];
-                v[4 * ct + r] = ACT ? elu_f(a) : a;
+            for (int k = 0; k < 4; ++k) t[k] = (__bf16)w[((4 * ob + i4) * C + k) * 4 + kh];
+            A[kh][ob] = __builtin_bit_cast(s16x4, t);
+        }
+    float br[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) br[e] = ACT ? bias[e] : 0.f;
+    auto fetch = [&](long grp, bf16x4 (&q)[4]) {
+        const int tblk = (int)(grp % tb);
+        const long bh = grp / tb;
+        const int ho = (int)(bh % Hout), b = (int)(bh / Hout);
+        const int t = tblk * 64 + lane;
+#pragma unroll
+        for (int kh = 0; kh < 4; ++kh) {
+            const int hi = 2 * ho + kh;
+            q[kh] = load_gated<4>(in, gy, (((long)b * Hin + hi) * T + t) * C, grp < ngroups && t < T && hi < Hin, GATE);
+        }
+    };
+    const long gstride = (long)gridDim.x * 4;
+    long grp = (long)blockIdx.x * 4 + wave;
+    bf16x4 bq[4], bn[4];
+    fetch(grp, bq);
+    for (; grp < ngroups; grp += gstride) {
+        fetch(grp + gstride, bn);
+        const int tblk = (int)(grp % tb);
+        const long bh = grp / tb;
+        const int ho = (int)(bh % Hout), b = (int)(bh / Hout);
+        const int t = tblk * 64 + lane;
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int kh = 0; kh < 4; ++kh)
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob) acc[ob] = mma4(A[kh][ob], __builtin_bit_cast(s16x4, bq[kh]), acc[ob]);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float a = acc[e >> 2][e & 3] + br[e];
+            o[e] = (__bf16)(ACT ? elu_f(a) : a);
+        }
+        if (t < T) *reinterpret_cast<bf16x8*>(out + (((long)b * Hout + ho) * T + t) * 8) = o;
+#pragma unroll
+        for (int kh = 0; kh < 4; ++kh) bq[kh] = bn[kh];
+    }
+}
+
+template <bool GATE, bool ACT>
+__global__ __launch_bounds__(NT) void k_p2c4(const __bf16* __restrict__ in, const __bf16* __restrict__ gy,
+                                              const float* __restrict__ w, const float* __restrict__ bias,
+                                              __bf16* __restrict__ out, int B, int Hin, int Hout, int T, int tb, long ngroups) {
+    constexpr int C = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i4 = lane & 3;
+    s16x4 A[2][2][2];                                            // [parity][row select][input block of 4]
+#pragma unroll
+    for (int par = 0; par < 2; ++par)
+#pragma unroll
+        for (int rs = 0; rs < 2; ++rs)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                bf16x4 t;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) t[k] = (__bf16)w[((4 * kb + k) * C + i4) * 4 + par + 2 * rs];
+                A[par][rs][kb] = __builtin_bit_cast(s16x4, t);
             }
-        store_lane<C, NCH>(out, ((long)b * Hout + h) * T + t, g, v, ok);
+    float br[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) br[e] = ACT ? bias[e] : 0.f;
+    const int Hp = (Hout + 1) >> 1;
+    auto fetch = [&](long grp, bf16x8 (&q)[2]) {
+        const int tblk = (int)(grp % tb);
+        const long bm = grp / tb;
+        const int m = (int)(bm % Hp), b = (int)(bm / Hp);
+        const int t = tblk * 64 + lane;
+#pragma unroll
+        for (int rs = 0; rs < 2; ++rs) {
+            const int hi = m - rs;
+            q[rs] = load_gated<8>(in, gy, (((long)b * Hin + hi) * T + t) * 8, grp < ngroups && t < T && hi >= 0 && hi < Hin, GATE);
+        }
+    };
+    const long gstride = (long)gridDim.x * 4;
+    long grp = (long)blockIdx.x * 4 + wave;
+    bf16x8 bq[2], bn[2];
+    fetch(grp, bq);
+    for (; grp < ngroups; grp += gstride) {
+        fetch(grp + gstride, bn);
+        const int tblk = (int)(grp % tb);
+        const long bm = grp / tb;
+        const int m = (int)(bm % Hp), b = (int)(bm / Hp);
+        const int t = tblk * 64 + lane;
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int rs = 0; rs < 2; ++rs) {
+                acc = mma4(A[par][rs][0], lo4(bq[rs]), acc);
+                acc = mma4(A[par][rs][1], hi4(bq[rs]), acc);
+            }
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = acc[e] + br[e];
+                o[e] = (__bf16)(ACT ? elu_f(a) : a);
+            }
+            const int h = 2 * m + par;
+            if (t < T && h < Hout) *reinterpret_cast<bf16x4*>(out + (((long)b * Hout + h) * T + t) * C) = o;
+        }
+        bq[0] = bn[0]; bq[1] = bn[1];
     }
 }
 
@@ -229,40 +388,50 @@ template <int PB> __device__ __forceinline__ int tr_off(int p, int tile, int trq
     return PB == 16 ? 8 * (trq & 1) : 0;
 }
 
-template <int PB, bool GATED>
-__device__ __forceinline__ void stage_tile(unsigned char* lds, const __bf16* src, const __bf16* ysrc, int rows, int row_h0, int Hs,
+template <int PB, int ROWS, bool GATED>
+__device__ __forceinline__ void stage_tile(unsigned char* lds, const __bf16* src, const __bf16* ysrc, int row_h0, int Hs,
                                            int t0, int T, int tid, float (&dbacc)[8], int db_rows) {
-    // image [rows][TW][PB bytes]; piece = 16 bytes; GATED: through registers with dy * ELU'(y), else LDS-DMA
+    // image [ROWS][TW][PB bytes]; piece = 16 bytes; GATED: through registers with dy * ELU'(y), else LDS-DMA
     constexpr int TWp = 64, PPP = PB >= 16 ? 1 : 16 / PB, CGn = PB >= 16 ? PB / 16 : 1;
-    const int npieces = rows * TWp * PB / 16;
+    constexpr int NPC = ROWS * TWp * PB / 16, NIT = (NPC + NT - 1) / NT;
     const __bf16* zero = reinterpret_cast<const __bf16*>(&g_wzero16);
     const int lane = tid & 63, wave = tid >> 6;
-    for (int i = wave * 64; i < ((npieces + NT - 1) / NT) * NT; i += NT) {
-        const int p = i + lane;
+    bf16x8 v[GATED ? NIT : 1], yv[GATED ? NIT : 1];
+    // all requests of the tile go out first (fully unrolled), the gating and the LDS writes follow
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = it * NT + wave * 64, p = i + lane;
         const int q = (p / CGn) * PPP, cgp = p % CGn;            // first pixel of the piece, physical 16-byte position in it
         const int row = q / TWp, px = q - row * TWp;
         // physical position -> logical channel group (32-byte blocks swizzled)
         const int cg = PB >= 32 ? ((((cgp >> 1) ^ blk_swz<PB>(q)) << 1) | (cgp & 1)) : cgp;
         const int h = row_h0 + row, t = t0 + px;
-        const bool ok = p < npieces && h < Hs && t < T;
+        const bool ok = p < NPC && h < Hs && t < T;
         const long off = ((long)h * T + t) * (PB / 2) + cg * 8;
         if constexpr (!GATED) {
             glds16(ok ? src + off : zero, lds + (long)i * 16);
         } else {
-            bf16x8 v;
+            // clamped unconditional loads (no branch in front of the later requests); masked when used
+            const long o2 = ok ? off : 0;
+            v[it] = *reinterpret_cast<const bf16x8*>(src + o2);
+            yv[it] = *reinterpret_cast<const bf16x8*>(ysrc + o2);
+        }
+    }
+    if constexpr (GATED) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (__bf16)0.f;
-            if (ok) {
-                v = *reinterpret_cast<const bf16x8*>(src + off);
-                const bf16x8 yv = *reinterpret_cast<const bf16x8*>(ysrc + off);
+        for (int it = 0; it < NIT; ++it) {
+            const int p = it * NT + tid;
+            const int q = (p / CGn) * PPP;
+            const int row = q / TWp, px = q - row * TWp;
+            const bool ok = p < NPC && row_h0 + row < Hs && t0 + px < T;
+            bf16x8 o;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float gq = gate_f((float)v[j], (float)yv[j]);
-                    if (row < db_rows) dbacc[j] += gq;          // rows shared with the next tile are counted once
-                    v[j] = (__bf16)gq;
-                }
+            for (int j = 0; j < 8; ++j) {
+                const float gq = ok ? gate_f((float)v[it][j], (float)yv[it][j]) : 0.f;
+                if (row < db_rows) dbacc[j] += gq;              // rows shared with the next tile are counted once
+                o[j] = (__bf16)gq;
             }
-            if (p < npieces) *reinterpret_cast<bf16x8*>(lds + (long)p * 16) = v;
+            if (p < NPC) *reinterpret_cast<bf16x8*>(lds + (long)p * 16) = o;
         }
     }
 }
@@ -296,12 +465,12 @@ __global__ __launch_bounds__(NT) void k_w4(const __bf16* __restrict__ small, con
         const __bf16* bb = big + (long)b * Hb * T * C;
         __syncthreads();
         if constexpr (GS) {
-            stage_tile<G::SB, true>(ss, sb, ygate + (long)b * Hs * T * (2 * C), G::TR, r0, Hs, t0, T, tid, dbacc, G::TR);
-            stage_tile<G::BB, false>(bs, bb, nullptr, G::BROWS, 2 * r0, Hb, t0, T, tid, dbacc, 0);
+            stage_tile<G::BB, G::BROWS, false>(bs, bb, nullptr, 2 * r0, Hb, t0, T, tid, dbacc, 0);
+            stage_tile<G::SB, G::TR, true>(ss, sb, ygate + (long)b * Hs * T * (2 * C), r0, Hs, t0, T, tid, dbacc, G::TR);
         } else {
-            stage_tile<G::SB, false>(ss, sb, nullptr, G::TR, r0, Hs, t0, T, tid, dbacc, 0);
-            stage_tile<G::BB, true>(bs, bb, ygate + (long)b * Hb * T * C, G::BROWS, 2 * r0, Hb, t0, T, tid, dbacc,
-                                    th == tiles_h - 1 ? G::BROWS : 2 * G::TR);
+            stage_tile<G::SB, G::TR, false>(ss, sb, nullptr, r0, Hs, t0, T, tid, dbacc, 0);
+            stage_tile<G::BB, G::BROWS, true>(bs, bb, ygate + (long)b * Hb * T * C, 2 * r0, Hb, t0, T, tid, dbacc,
+                                              th == tiles_h - 1 ? G::BROWS : 2 * G::TR);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -416,6 +585,13 @@ inline int flat_grid(long ngroups) {
 template <int C, bool GATE, bool ACT>
 int launch_s4(const __bf16* in, const __bf16* gy, const float* w, const float* bias, __bf16* out, int B, int Hin, int Hout, int T,
               hipStream_t st) {
+    if constexpr (C == 4) {
+        const int tb = (T + 63) / 64;
+        const long ngroups = (long)B * Hout * tb;
+        hipLaunchKernelGGL((k_s4c4<GATE, ACT>), dim3(flat_grid(ngroups)), dim3(NT), 0, st, in, gy, w, bias, out, B, Hin, Hout, T, tb, ngroups);
+        TT_LAUNCH_CHECK();
+        return 0;
+    }
     const int tb = (T + 15) / 16;
     const long ngroups = (long)B * Hout * tb;
     hipLaunchKernelGGL((k_s4<C, GATE, ACT>), dim3(flat_grid(ngroups)), dim3(NT), 0, st, in, gy, w, bias, out, B, Hin, Hout, T, tb, ngroups);
@@ -425,8 +601,15 @@ int launch_s4(const __bf16* in, const __bf16* gy, const float* w, const float* b
 template <int C, bool GATE, bool ACT>
 int launch_p2(const __bf16* in, const __bf16* gy, const float* w, const float* bias, __bf16* out, int B, int Hin, int Hout, int T,
               hipStream_t st) {
+    if constexpr (C == 4) {
+        const int tb = (T + 63) / 64;
+        const long ngroups = (long)B * ((Hout + 1) / 2) * tb;
+        hipLaunchKernelGGL((k_p2c4<GATE, ACT>), dim3(flat_grid(ngroups)), dim3(NT), 0, st, in, gy, w, bias, out, B, Hin, Hout, T, tb, ngroups);
+        TT_LAUNCH_CHECK();
+        return 0;
+    }
     const int tb = (T + 15) / 16;
-    const long ngroups = (long)B * Hout * tb;
+    const long ngroups = (long)B * ((Hout + 1) / 2) * tb;        // one group = a pair of output rows x 16 frames
     hipLaunchKernelGGL((k_p2<C, GATE, ACT>), dim3(flat_grid(ngroups)), dim3(NT), 0, st, in, gy, w, bias, out, B, Hin, Hout, T, tb, ngroups);
     TT_LAUNCH_CHECK();
     return 0;

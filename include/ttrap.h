@@ -184,6 +184,21 @@ int tt_tconv16_fwd(const void* x, const float* w, const float* b, void* y, int B
 int tt_tconv16_bwd(const void* x, const void* y, const void* dy, const float* w, void* dx, float* dw, float* db, void* ws,
                    int B, int C, int H, int T, int out_pad, void* stream);
 
+/* The (31,1) latent heads on bf16 channels-last embeddings (csrc/latent_bf16.hip; modules.py:446 Encoder.convlat and :534
+ * Decoder.convin).  w is the (D', CT, E, 1) weight of either layer (index (d CT + c) E + h); (CT, D') = (32, <= 48) or (64, <= 144);
+ * T % 16 == 0.  ws: tt_latent16_scratch_bytes bytes.
+ *   tt_latent16_contract  out (B,D,T) fp32 = [bias +] sum_{c,h} w[d][c][h] in[b,h,t,c]; in = x (cl16), or, with gy != NULL,
+ *                         in = x * ELU'(gy) on the fly (data gradient of convin from dy and the saved output)
+ *   tt_latent16_expand    out (B,CT,E,T) cl16 = sum_d w[d][c][h] z[b,d,t], with bias != NULL: ELU(bias[c] + .)
+ *   tt_latent16_wgrad     dw += sum_{b,t} z[b,d,t] g[b,h,t,c]  (g cl16; with gy != NULL gated as above and db (CT) += sum g) */
+int64_t tt_latent16_scratch_bytes(int B, int CT, int D, int E, int T);
+int tt_latent16_contract(const void* in, const void* gy, const float* w, const float* bias, float* out, void* ws, int B, int CT,
+                         int D, int E, int T, void* stream);
+int tt_latent16_expand(const float* z, const float* w, const float* bias, void* out, void* ws, int B, int CT, int D, int E, int T,
+                       void* stream);
+int tt_latent16_wgrad(const float* z, const void* g, const void* gy, float* dw, float* db, void* ws, int B, int CT, int D, int E,
+                      int T, void* stream);
+
 /* EncoderBlock.sconv (modules.py:626-630): y = ELU(Conv2d(C, 2C, (4,1), stride (2,1))(x) + b).
  * x (B,C,H,T) -> y (B,2C,(H-4)/2+1,T); w (2C,C,4,1).  Supported C: 4,8,16,32. */
 int tt_sconv_fwd(const float* x, const float* w, const float* b, float* y, int B, int C, int H, int T,

@@ -317,3 +317,47 @@ def test_bf16_model_is_channels_last_end_to_end(skip, monkeypatch):
     assert _rel(out16.detach().cpu().double(), out32.detach().cpu().double()) < 5e-2
     out16.square().mean().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.decoder.parameters())
+
+
+# ---- latent heads on cl16 embeddings (csrc/latent_bf16.hip) ------------------------------------------------------------------
+
+@pytest.mark.parametrize('CT,D,B,T', [(64, 128, 2, 48), (64, 129, 1, 272), (32, 32, 3, 32), (32, 33, 1, 80)])
+def test_latent_heads_stagewise(CT, D, B, T):
+    """convlat (contract) and convin (expand, ELU) with their data / weight / bias gradients against float64 restatements with
+    the kernels' rounding points (bf16 operands, fp32 accumulation), like the stage-wise block tests above."""
+    from timbre_trap.framework import ops
+    E = 31
+    top = _rand(B, CT, E, T, seed=1)
+    w = _rand(D, CT, E, 1, seed=2, scale=1.0 / (CT * E) ** 0.5)
+    be, bd = _rand(D, seed=3, scale=0.2), _rand(CT, seed=4, scale=0.2)
+    z = _rand(B, D, T, seed=5)
+    dlat, dtop = _rand(B, D, T, seed=6), _rand(B, CT, E, T, seed=7)
+    wr, topr, zr = _r16(w), _r16(top), _r16(z)
+    W2 = wr.view(D, CT * E)
+
+    # Encoder.convlat
+    x16 = _cl16(top).requires_grad_(True)
+    wd, bdv = w.cuda().requires_grad_(True), be.cuda().requires_grad_(True)
+    lat = ops.LatEnc16Fn.apply(x16, wd, bdv)
+    lat_ref = torch.einsum('dk,bkt->bdt', W2, topr.view(B, CT * E, T)) + be.double()[None, :, None]
+    assert lat.dtype == torch.float32 and _rel(lat.detach().cpu().double(), lat_ref) < 1e-4
+    lat.backward(dlat.cuda())
+    dlr = _r16(dlat)
+    _close16(_f64(x16.grad), torch.einsum('dk,bdt->bkt', W2, dlr).view(B, CT, E, T), 'dtop')
+    assert _rel(wd.grad.cpu().double().view(D, CT * E), torch.einsum('bdt,bkt->dk', dlr, topr.view(B, CT * E, T))) < 2e-4
+    assert _rel(bdv.grad.cpu().double(), dlat.double().sum((0, 2))) < 1e-5
+
+    # Decoder.convin
+    zd = z.cuda().requires_grad_(True)
+    wd2, bd2 = w.cuda().requires_grad_(True), bd.cuda().requires_grad_(True)
+    y = ops.LatDec16Fn.apply(zd, wd2, bd2)
+    assert ops.is_cl16(y) and tuple(y.shape) == (B, CT, E, T)
+    y_ref = F.elu(torch.einsum('dk,bdt->bkt', W2, zr).view(B, CT, E, T) + bd.double()[None, :, None, None])
+    y_k = _f64(y.detach())
+    _close16(y_k, y_ref, 'y')
+    y.backward(_cl16(dtop))
+    g = _r16(dtop) * _gate(y_k)
+    g_r = _r16(g)
+    assert _rel(zd.grad.cpu().double(), torch.einsum('dk,bkt->bdt', W2, g_r.view(B, CT * E, T))) < 2e-4
+    assert _rel(wd2.grad.cpu().double().view(D, CT * E), torch.einsum('bdt,bkt->dk', zr, g_r.view(B, CT * E, T))) < 2e-4
+    assert _rel(bd2.grad.cpu().double(), g.sum((0, 2, 3))) < 2e-3

@@ -139,7 +139,7 @@ class Encoder(nn.Module):
         top = embeddings[-1]
         if top.size(-2) != self.convlat.kernel_size[0]:
             raise ValueError('feature size %d does not match the latent head (%d)' % (top.size(-2), self.convlat.kernel_size[0]))
-        latents = ops.LatentEncodeFn.apply(ops.to_planar32(top), self.convlat.weight, self.convlat.bias)
+        latents = ops.latent_encode(top, self.convlat.weight, self.convlat.bias)
         return latents, embeddings, dict()
 
 
@@ -170,7 +170,7 @@ class Decoder(nn.Module):
 
     def forward(self, latents, encoder_embeddings=None):
         c = self.convin[0]
-        y = ops.LatentDecodeFn.apply(latents, c.weight, c.bias)
+        y = ops.latent_decode(latents, c.weight, c.bias)
         skips = None if encoder_embeddings is None else list(encoder_embeddings)[::-1]
         if skips is not None:
             y = ops.add(y, skips[0])

@@ -730,6 +730,100 @@ class LatentDecodeFn(torch.autograd.Function):
         return dz, rw, rb
 
 
+def _lat16_ok(CT, D, E, T, b):
+    return b is not None and T % 16 == 0 and ((CT == 32 and D <= 48) or (CT == 64 and D <= 144))
+
+
+class LatEnc16Fn(torch.autograd.Function):
+    """Encoder.convlat on the cl16 top embedding (csrc/latent_bf16.hip): (B,CT,E,T) cl16 -> latents (B,D,T) fp32."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        B, CT, E, T = x.shape
+        D = w.size(0)
+        lib = _hip.lib()
+        y = torch.empty((B, D, T), dtype=torch.float32, device=x.device)
+        ws = torch.empty(lib.tt_latent16_scratch_bytes(B, CT, D, E, T), dtype=torch.uint8, device=x.device)
+        check(lib.tt_latent16_contract(ptr(x), None, ptr(w), ptr(b), ptr(y), ptr(ws), B, CT, D, E, T, stream_ptr()),
+              'tt_latent16_contract')
+        ctx.params = (w, b)
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        B, CT, E, T = x.shape
+        D = w.size(0)
+        lib, st = _hip.lib(), stream_ptr()
+        dy = _f32c(dy)
+        ws = torch.empty(lib.tt_latent16_scratch_bytes(B, CT, D, E, T), dtype=torch.uint8, device=x.device)
+        dx = rw = rb = None
+        if ctx.needs_input_grad[0]:
+            dx = new_cl16(B, CT, E, T, x.device)
+            check(lib.tt_latent16_expand(ptr(dy), ptr(w), None, ptr(dx), ptr(ws), B, CT, D, E, T, st), 'tt_latent16_expand')
+        if ctx.needs_input_grad[1]:
+            dw, rw = _grad_target(ctx.params[0])
+            check(lib.tt_latent16_wgrad(ptr(dy), ptr(x), None, ptr(dw), None, ptr(ws), B, CT, D, E, T, st), 'tt_latent16_wgrad')
+            db, rb = _grad_target(ctx.params[1])
+            check(lib.tt_channel_sum(ptr(dy), ptr(db), B, D, T, st), 'tt_channel_sum')
+        return dx, rw, rb
+
+
+class LatDec16Fn(torch.autograd.Function):
+    """Decoder.convin producing the cl16 top embedding: z (B,D+1,T) fp32 -> ELU(tconv) (B,CT,E,T) cl16."""
+
+    @staticmethod
+    def forward(ctx, z, w, b):
+        z = _f32c(z)
+        B, D, T = z.shape
+        CT, E = w.size(1), w.size(2)
+        lib = _hip.lib()
+        y = new_cl16(B, CT, E, T, z.device)
+        ws = torch.empty(lib.tt_latent16_scratch_bytes(B, CT, D, E, T), dtype=torch.uint8, device=z.device)
+        check(lib.tt_latent16_expand(ptr(z), ptr(w), ptr(b), ptr(y), ptr(ws), B, CT, D, E, T, stream_ptr()), 'tt_latent16_expand')
+        ctx.params = (w, b)
+        ctx.save_for_backward(z, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, w, y = ctx.saved_tensors
+        B, D, T = z.shape
+        CT, E = w.size(1), w.size(2)
+        lib, st = _hip.lib(), stream_ptr()
+        g = _as_cl16(dy)
+        ws = torch.empty(lib.tt_latent16_scratch_bytes(B, CT, D, E, T), dtype=torch.uint8, device=z.device)
+        dz = rw = rb = None
+        if ctx.needs_input_grad[0]:
+            dz = torch.empty_like(z)
+            check(lib.tt_latent16_contract(ptr(g), ptr(y), ptr(w), None, ptr(dz), ptr(ws), B, CT, D, E, T, st), 'tt_latent16_contract')
+        if ctx.needs_input_grad[1]:
+            dw, rw = _grad_target(ctx.params[0])
+            db, rb = _grad_target(ctx.params[1])
+            check(lib.tt_latent16_wgrad(ptr(z), ptr(g), ptr(y), ptr(dw), ptr(db), ptr(ws), B, CT, D, E, T, st), 'tt_latent16_wgrad')
+        return dz, rw, rb
+
+
+def latent_encode(top, w, b):
+    """Encoder.convlat (modules.py:446)."""
+    if is_cl16(top) and _f32ok(w) and _lat16_ok(top.size(1), w.size(0), top.size(2), top.size(3), b) and w.shape[1:] == (top.size(1), top.size(2), 1):
+        return LatEnc16Fn.apply(top, w, b)
+    return LatentEncodeFn.apply(to_planar32(top), w, b)
+
+
+def latent_decode(z, w, b):
+    """Decoder.convin (modules.py:534) + ELU; cl16 output in the bf16 mode."""
+    if (wide_storage() == 'bf16' and FUSED_RESBLOCK and _f32ok(w) and z.dim() == 3 and w.size(0) == z.size(1) and w.size(3) == 1
+            and _lat16_ok(w.size(1), w.size(0), w.size(2), z.size(2), b)):
+        return LatDec16Fn.apply(z, w, b)
+    return LatentDecodeFn.apply(z, w, b)
+
+
+def _f32ok(w):
+    return w.dtype == torch.float32 and w.is_contiguous()
+
+
 # ---- objectives ------------------------------------------------------------------------------------
 
 def _partials(device):
@@ -844,6 +938,8 @@ _instrument(ToCL16Fn, 'tocl16', lambda x: 'C%d' % x.size(1))
 _instrument(ToPlanar32Fn, 'toplanar', lambda x: 'C%d' % x.size(1))
 _instrument(StridedConvFn, 'sconv', lambda x, *a: 'C%d' % x.size(1))
 _instrument(TransposedConvFn, 'tconv', lambda x, w, *a: 'C%d' % w.size(1))
+_instrument(LatEnc16Fn, 'latenc16', lambda x, *a: 'C%d' % x.size(1))
+_instrument(LatDec16Fn, 'latdec16', lambda z, w, *a: 'C%d' % w.size(1))
 _instrument(LatentEncodeFn, 'latenc', lambda x, *a: 'C%d' % x.size(1))
 _instrument(LatentDecodeFn, 'latdec', lambda z, w, *a: 'C%d' % w.size(1))
 _instrument(SqDiffLossFn, 'sqdiff', lambda a, *r: 'n')

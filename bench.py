@@ -182,6 +182,16 @@ def family_table(events, n_steps, batch, mc, latent):
             fl = 2.0 * 4 * C * 2 * C * hs[l + 1] * T * batch * (2 if bwd else 1)
             by = 4.0 * (big + small) * (2 if bwd else 1)
             add('strided + transposed (4,1) layers ' + ('backward' if bwd else 'forward'), ms, calls, fl * calls, by * calls, 'hbm')
+        elif kind == 'edge16':
+            px = hs[0] * T * batch
+            fl = 2.0 * 9 * 2 * ch[0] * px * (2 if bwd else 1)
+            by = (4.0 * 2 + 2.0 * ch[0]) * px * (1.5 if bwd else 1)
+            add('boundary 3x3 convs (2<->%d), fp32 planar <-> bf16 channels-last' % ch[0], ms, calls, fl * calls, by * calls, 'hbm')
+        elif kind in ('latenc16', 'latdec16'):
+            K = ch[4] * hs[4]
+            fl = 2.0 * (lat + (kind == 'latdec16')) * K * T * batch * (2 if bwd else 1)
+            by = (2.0 * K + 4.0 * lat) * T * batch * (2 if bwd else 1)
+            add('latent heads (31,1), bf16 channels-last embeddings', ms, calls, fl * calls, by * calls, 'hbm')
         elif kind in ('latenc', 'latdec'):
             K = ch[4] * hs[4]
             fl = 2.0 * (lat + (kind == 'latdec')) * K * T * batch * (2 if bwd else 1)

@@ -199,6 +199,21 @@ int tt_latent16_expand(const float* z, const float* w, const float* bias, void* 
 int tt_latent16_wgrad(const float* z, const void* g, const void* gy, float* dw, float* db, void* ws, int B, int CT, int D, int E,
                       int T, void* stream);
 
+/* The 3x3 boundary convolutions where fp32 planar tensors meet the bf16 channels-last interior (csrc/conv_edge_bf16.hip), for
+ * C0 = 4 first-level channels (model_complexity 2):
+ *   tt_convin16_fwd   Encoder.convin (modules.py:433): x (B,2,H,T) fp32 -> y = ELU(conv3x3 + b) as cl16 (B,4,H,T); w (4,2,3,3)
+ *   tt_convin16_bwd   from x, the saved output y and dy (cl16): dw, db (+=), dx (B,2,H,T) fp32 (written; may be NULL)
+ *   tt_convout16_fwd  Decoder.convout (modules.py:560): x cl16 (B,4,H,T) -> y (B,2,H,T) fp32 = conv3x3 + b; w (2,4,3,3)
+ *   tt_convout16_bwd  from x and dy (B,2,H,T) fp32: dx cl16 (written), dw, db (+=)
+ * ws: tt_edge16_scratch_bytes() bytes (per-workgroup partial gradients).  fp32 arithmetic; only the cl16 tensors are bf16. */
+int64_t tt_edge16_scratch_bytes(void);
+int tt_convin16_fwd(const float* x, const float* w, const float* b, void* y, int B, int H, int T, void* stream);
+int tt_convin16_bwd(const float* x, const void* y, const void* dy, const float* w, float* dx, float* dw, float* db, void* ws,
+                    int B, int H, int T, void* stream);
+int tt_convout16_fwd(const void* x, const float* w, const float* b, float* y, int B, int H, int T, void* stream);
+int tt_convout16_bwd(const void* x, const float* dy, const float* w, void* dx, float* dw, float* db, void* ws, int B, int H,
+                     int T, void* stream);
+
 /* EncoderBlock.sconv (modules.py:626-630): y = ELU(Conv2d(C, 2C, (4,1), stride (2,1))(x) + b).
  * x (B,C,H,T) -> y (B,2C,(H-4)/2+1,T); w (2C,C,4,1).  Supported C: 4,8,16,32. */
 int tt_sconv_fwd(const float* x, const float* w, const float* b, float* y, int B, int C, int H, int T,

@@ -309,7 +309,7 @@ def test_bf16_model_is_channels_last_end_to_end(skip, monkeypatch):
     out32 = model.decoder(torch.cat([lat32, torch.ones(1, 1, 32, device='cuda')], 1), emb32 if skip else None)
     monkeypatch.setattr(ops, 'PRECISION', 'bf16')
     lat16, emb16, _ = model.encoder(coeffs)
-    assert not ops.is_cl16(emb16[0]) and all(ops.is_cl16(e) for e in emb16[1:])
+    assert all(ops.is_cl16(e) for e in emb16)
     assert [tuple(e.shape) for e in emb16] == [tuple(e.shape) for e in emb32]
     out16 = model.decoder(torch.cat([lat16, torch.ones(1, 1, 32, device='cuda')], 1), emb16 if skip else None)
     assert out16.dtype == torch.float32 and out16.shape == out32.shape
@@ -361,3 +361,40 @@ def test_latent_heads_stagewise(CT, D, B, T):
     assert _rel(zd.grad.cpu().double(), torch.einsum('dk,bkt->bdt', W2, g_r.view(B, CT * E, T))) < 2e-4
     assert _rel(wd2.grad.cpu().double().view(D, CT * E), torch.einsum('bdt,bkt->dk', zr, g_r.view(B, CT * E, T))) < 2e-4
     assert _rel(bd2.grad.cpu().double(), g.sum((0, 2, 3))) < 2e-3
+
+
+# ---- boundary 3x3 convolutions (csrc/conv_edge_bf16.hip) ----------------------------------------------------------------------
+
+@pytest.mark.parametrize('shape', [(2, 21, 80), (1, 16, 64), (1, 37, 130), (3, 5, 34)])
+def test_edge_convs(shape):
+    """convin (fp32 planar -> cl16, ELU) and convout (cl16 -> fp32 planar) with all their gradients; fp32 arithmetic, so the
+    only rounding is that of the cl16 tensors themselves."""
+    from timbre_trap.framework import ops
+    B, H, T = shape
+    x = _rand(B, 2, H, T, seed=1)
+    w, b = _rand(4, 2, 3, 3, seed=2, scale=0.3), _rand(4, seed=3, scale=0.2)
+    dy = _rand(B, 4, H, T, seed=4)
+    xd, wd, bd = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    y = ops.ConvIn16Fn.apply(xd, wd, bd)
+    assert ops.is_cl16(y)
+    y_ref = F.elu(F.conv2d(x.double(), w.double(), b.double(), padding=1))
+    y_k = _f64(y.detach())
+    _close16(y_k, y_ref, 'convin y')
+    y.backward(_cl16(dy))
+    g = _r16(dy) * _gate(y_k)
+    assert _rel(xd.grad.cpu().double(), F.conv_transpose2d(g, w.double(), padding=1)) < 1e-5
+    assert _rel(wd.grad.cpu().double(), torch.nn.grad.conv2d_weight(x.double(), w.shape, g, padding=1)) < 1e-5
+    assert _rel(bd.grad.cpu().double(), g.sum((0, 2, 3))) < 1e-5
+
+    x4 = _rand(B, 4, H, T, seed=5)
+    w2, b2 = _rand(2, 4, 3, 3, seed=6, scale=0.3), _rand(2, seed=7, scale=0.2)
+    dz = _rand(B, 2, H, T, seed=8)
+    x16 = _cl16(x4).requires_grad_(True)
+    w2d, b2d = w2.cuda().requires_grad_(True), b2.cuda().requires_grad_(True)
+    z = ops.ConvOut16Fn.apply(x16, w2d, b2d)
+    x4r = _r16(x4)
+    assert z.dtype == torch.float32 and _rel(z.detach().cpu().double(), F.conv2d(x4r, w2.double(), b2.double(), padding=1)) < 1e-5
+    z.backward(dz.cuda())
+    _close16(_f64(x16.grad), F.conv_transpose2d(dz.double(), w2.double(), padding=1), 'convout dx')
+    assert _rel(w2d.grad.cpu().double(), torch.nn.grad.conv2d_weight(x4r, w2.shape, dz.double(), padding=1)) < 1e-5
+    assert _rel(b2d.grad.cpu().double(), dz.double().sum((0, 2, 3))) < 1e-5

@@ -18,7 +18,7 @@ PKG_ROOT = os.path.dirname(_HERE)                       # timbre-trap_amd/
 REPO_ROOT = os.path.dirname(PKG_ROOT)
 CSRC = os.path.join(PKG_ROOT, 'csrc')
 LIB_PATH = os.path.join(PKG_ROOT, 'lib', 'libttrap_hip.so')
-SOURCES = ['cqt.hip', 'conv_generic.hip', 'conv_mfma.hip', 'conv_small.hip', 'conv_wide_bf16.hip', 'conv_stride_bf16.hip', 'latent_bf16.hip', 'gemm.hip', 'losses.hip']
+SOURCES = ['cqt.hip', 'conv_generic.hip', 'conv_mfma.hip', 'conv_small.hip', 'conv_wide_bf16.hip', 'conv_stride_bf16.hip', 'latent_bf16.hip', 'conv_edge_bf16.hip', 'gemm.hip', 'losses.hip']
 
 _lib = None
 
@@ -61,6 +61,11 @@ _PROTOS = {
     'tt_latent16_contract': (c_int, [P, P, P, P, P, P, I, I, I, I, I, P]),
     'tt_latent16_expand': (c_int, [P, P, P, P, P, I, I, I, I, I, P]),
     'tt_latent16_wgrad': (c_int, [P, P, P, P, P, P, I, I, I, I, I, P]),
+    'tt_edge16_scratch_bytes': (c_int64, []),
+    'tt_convin16_fwd': (c_int, [P, P, P, P, I, I, I, P]),
+    'tt_convin16_bwd': (c_int, [P, P, P, P, P, P, P, P, I, I, I, P]),
+    'tt_convout16_fwd': (c_int, [P, P, P, P, I, I, I, P]),
+    'tt_convout16_bwd': (c_int, [P, P, P, P, P, P, P, I, I, I, P]),
     'tt_sconv_fwd': (c_int, [P, P, P, P, I, I, I, I, P]),
     'tt_wgrad_scratch_floats': (c_int64, []),
     'tt_sconv_bwd': (c_int, [P, P, P, P, P, P, P, P, I, I, I, I, P]),

@@ -172,6 +172,12 @@ class ConvFn(torch.autograd.Function):
 
 
 def conv(x, w, b, cfg):
+    same3 = (cfg.kind == 'conv' and (cfg.KH, cfg.KW, cfg.stride, cfg.dil, cfg.pad_h, cfg.pad_w) == (3, 3, 1, 1, 1, 1) and b is not None
+             and x.dim() == 4 and x.size(3) % 2 == 0 and FUSED_RESBLOCK)
+    if same3 and cfg.act == ACT_ELU and w.shape == (4, 2, 3, 3) and not is_cl16(x) and wide_storage() == 'bf16':
+        return ConvIn16Fn.apply(x, w, b)                         # Encoder.convin feeding the bf16 channels-last interior
+    if same3 and cfg.act == ACT_NONE and w.shape == (2, 4, 3, 3) and is_cl16(x):
+        return ConvOut16Fn.apply(x, w, b)                        # Decoder.convout leaving it
     x = to_planar32(x)
     return ConvFn.apply(x, w, b, cfg)
 
@@ -449,6 +455,60 @@ def to_planar32(x):
     if is_cl16(x):
         return ToPlanar32Fn.apply(x)
     return x
+
+
+class ConvIn16Fn(torch.autograd.Function):
+    """Encoder.convin (3x3, 2 -> 4, ELU): fp32 planar coefficients -> cl16 (csrc/conv_edge_bf16.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        _hip.require_cuda(x, w)
+        x = _f32c(x)
+        B, _, H, T = x.shape
+        y = new_cl16(B, 4, H, T, x.device)
+        check(_hip.lib().tt_convin16_fwd(ptr(x), ptr(w), ptr(b), ptr(y), B, H, T, stream_ptr()), 'tt_convin16_fwd')
+        ctx.params = (w, b)
+        ctx.save_for_backward(x, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        B, _, H, T = x.shape
+        lib = _hip.lib()
+        g = _as_cl16(dy)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        (dw, r1), (db, r2) = (_grad_target(t) for t in ctx.params)
+        ws = torch.empty(lib.tt_edge16_scratch_bytes(), dtype=torch.uint8, device=x.device)
+        check(lib.tt_convin16_bwd(ptr(x), ptr(y), ptr(g), ptr(w), ptr(dx), ptr(dw), ptr(db), ptr(ws), B, H, T, stream_ptr()),
+              'tt_convin16_bwd')
+        return dx, r1, r2
+
+
+class ConvOut16Fn(torch.autograd.Function):
+    """Decoder.convout (3x3, 4 -> 2, no activation): cl16 -> fp32 planar logits."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        B, _, H, T = x.shape
+        y = torch.empty((B, 2, H, T), dtype=torch.float32, device=x.device)
+        check(_hip.lib().tt_convout16_fwd(ptr(x), ptr(w), ptr(b), ptr(y), B, H, T, stream_ptr()), 'tt_convout16_fwd')
+        ctx.params = (w, b)
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        B, _, H, T = x.shape
+        lib = _hip.lib()
+        dy = _f32c(dy)
+        dx = new_cl16(B, 4, H, T, x.device)
+        (dw, r1), (db, r2) = (_grad_target(t) for t in ctx.params)
+        ws = torch.empty(lib.tt_edge16_scratch_bytes(), dtype=torch.uint8, device=x.device)
+        check(lib.tt_convout16_bwd(ptr(x), ptr(dy), ptr(w), ptr(dx), ptr(dw), ptr(db), ptr(ws), B, H, T, stream_ptr()),
+              'tt_convout16_bwd')
+        return dx, r1, r2
 
 
 class Level16Fn(torch.autograd.Function):
@@ -931,6 +991,8 @@ def _instrument(cls, name, keyfn):
 _instrument(ConvFn, 'conv', lambda x, w, b, cfg: '%dto%d' % ((x.size(1), w.size(0)) if cfg.kind == 'conv' else (x.size(1), w.size(1))))
 _instrument(ResBlockFn, 'rb', lambda x, *a: 'C%d' % x.size(1))
 _instrument(WideLevelFn, 'widelevel', lambda x, *a: 'C%d' % x.size(1))
+_instrument(ConvIn16Fn, 'edge16', lambda x, *a: 'in')
+_instrument(ConvOut16Fn, 'edge16', lambda x, *a: 'out')
 _instrument(Level16Fn, 'widelevel', lambda x, *a: 'C%d' % x.size(1))
 _instrument(SConv16Fn, 'sconv16', lambda x, *a: 'C%d' % x.size(1))
 _instrument(TConv16Fn, 'tconv16', lambda x, w, *a: 'C%d' % w.size(1))

@@ -29,37 +29,54 @@ __device__ __forceinline__ ETile etile(int v, int tiles_h, int tiles_t, int ntil
     return r;
 }
 
-// planes [NP][EROWS][ERW] fp32 <- NP consecutive planes of a planar (B,NP,H,T) tensor, zero outside the image
+// planes [NP][EROWS][ERW] fp32 <- NP consecutive planes of a planar (B,NP,H,T) tensor, zero outside the image.
+// All requests of the tile are issued first (unrolled, clamped addresses, no branches), the LDS writes follow: a loop of
+// load-then-store pairs would pay one memory latency per iteration.
 template <int NP>
 __device__ __forceinline__ void stage_planar(float* lds, const float* src, int b, int h0, int t0, int H, int T, int tid) {
-    for (int i = tid; i < NP * EPLANE; i += NT) {
+    constexpr int NIT = (NP * EPLANE + NT - 1) / NT;
+    float v[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = it * NT + tid;
         const int pl = i / EPLANE, rem = i - pl * EPLANE;
         const int row = rem / ERW, col = rem - row * ERW;
         const int h = h0 - 1 + row, t = t0 - 1 + col;
-        lds[i] = ((unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T) ? src[(((long)b * NP + pl) * H + h) * T + t] : 0.f;
+        const bool ok = i < NP * EPLANE && (unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T;
+        const float q = src[ok ? (((long)b * NP + pl) * H + h) * T + t : 0];
+        v[it] = ok ? q : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = it * NT + tid;
+        if (i < NP * EPLANE) lds[i] = v[it];
     }
 }
 // planes [4][EROWS][ERW] fp32 <- cl16 (B,H,T,4), optionally gated by the saved output
 template <bool GATE>
 __device__ __forceinline__ void stage_cl4(float* lds, const __bf16* src, const __bf16* ysrc, int b, int h0, int t0, int H, int T, int tid) {
-    for (int i = tid; i < EPLANE; i += NT) {
+    constexpr int NIT = (EPLANE + NT - 1) / NT;
+    bf16x4 q[NIT], yq[GATE ? NIT : 1];
+    bool okv[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = it * NT + tid;
         const int row = i / ERW, col = i - row * ERW;
         const int h = h0 - 1 + row, t = t0 - 1 + col;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if ((unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T) {
-            const long off = (((long)b * H + h) * T + t) * 4;
-            const bf16x4 q = *reinterpret_cast<const bf16x4*>(src + off);
-            if (GATE) {
-                const bf16x4 yq = *reinterpret_cast<const bf16x4*>(ysrc + off);
+        okv[it] = i < EPLANE && (unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T;
+        const long off = okv[it] ? (((long)b * H + h) * T + t) * 4 : 0;
+        q[it] = *reinterpret_cast<const bf16x4*>(src + off);
+        if (GATE) yq[it] = *reinterpret_cast<const bf16x4*>(ysrc + off);
+    }
 #pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] = gatef((float)q[c], (float)yq[c]);
-            } else {
+    for (int it = 0; it < NIT; ++it) {
+        const int i = it * NT + tid;
+        if (i >= EPLANE) continue;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] = (float)q[c];
-            }
+        for (int c = 0; c < 4; ++c) {
+            float v = GATE ? gatef((float)q[it][c], (float)yq[it][c]) : (float)q[it][c];
+            lds[c * EPLANE + i] = okv[it] ? v : 0.f;
         }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) lds[c * EPLANE + i] = v[c];
     }
 }
 

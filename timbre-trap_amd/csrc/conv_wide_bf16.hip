@@ -68,6 +68,17 @@ __global__ __launch_bounds__(NT) void k_wide_unpack(const __bf16* __restrict__ i
 }
 
 // ---- 3x3 main loop: block forward and data gradient ------------------------------------------------------------------
+// Sixteen lanes of one k-group read the same 16-byte channel group of sixteen consecutive pixels (64 / 32 bytes apart), which
+// would put them on 4 / 8 different bank quads only.  The LDS image therefore stores channel group cg of column `col` at
+// position cg ^ cswz(col) of the pixel (a permutation of the DMA sources): any sixteen consecutive columns then cover all
+// sixteen bank quads (PMC before: SQ_LDS_BANK_CONFLICT = 4 x SQ_ACTIVE_INST_LDS).
+template <int C> __device__ __forceinline__ int cswz(int col) { return C == 32 ? ((col >> 2) & 3) : ((col >> 3) & 1); }
+// Measured at the bench shape (B 64, C 32, H 65, T 1024; 0.20 ms per launch = 4.1 TB/s over x + y + h1):
+//   staging alone 0.066 ms, products + epilogue + stores alone 0.134 ms, and they add up -- but an explicit double-buffered tile
+//   ring (8 waves, next tile's DMA issued before this tile's products, exact-count vmcnt waits so the stores keep draining)
+//   changed nothing (0.20 ms), and neither did the bank swizzle above; without the two ELUs the launch takes 0.178 ms.
+//   PMC: FETCH x2 + WRITE = 0.85-0.91 GB against 0.82 GB of x + y + h1 -- no wasted traffic left to remove.
+
 template <int C, int D> struct WT {
     static constexpr int TH = 8, TW = 64;
     static constexpr int CG = C / 8;
@@ -143,7 +154,7 @@ __global__ __launch_bounds__(NT, 2) void k_wrb_conv(const __bf16* __restrict__ x
         for (int i = wave * 64; i < G::NPR; i += NT) {
             const int p = i + lane;
             const int row = p / (G::RW * G::CG), rem = p - row * (G::RW * G::CG);
-            const int px = rem / G::CG, cg = rem - px * G::CG;
+            const int px = rem / G::CG, cg = (rem - px * G::CG) ^ cswz<C>(px);      // 16-byte position -> channel group held there
             const int h = h0 - D + row, t = t0 - D + px;
             const bool ok = p < G::NP && (unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T;
             glds16(ok ? xb + ((long)h * T + t) * C + cg * 8 : zero, smem + (long)i * 16);
@@ -170,8 +181,8 @@ __global__ __launch_bounds__(NT, 2) void k_wrb_conv(const __bf16* __restrict__ x
                 int tap = C == 32 ? k : 2 * k + (g >> 1);
                 if (tap > 8) tap = 8;                            // the weights of the missing tenth tap are zero
                 const int kh = tap / 3, kw = tap - 3 * kh;
-                const int pxi = (r + kh * D) * G::RW + (c0 + n + kw * D);
-                const int cho = C == 32 ? 8 * g : 8 * (g & 1);
+                const int col = c0 + n + kw * D, pxi = (r + kh * D) * G::RW + col;
+                const int cho = 8 * ((C == 32 ? g : (g & 1)) ^ cswz<C>(col));
                 const bf16x8 bq = *reinterpret_cast<const bf16x8*>(smem + ((long)pxi * C + cho) * 2);
                 if (C == 32 && k == 4) centre = bq;
 #pragma unroll
@@ -222,8 +233,8 @@ __global__ __launch_bounds__(NT, 2) void k_wrb_conv(const __bf16* __restrict__ x
                     for (int j = 0; j < 4; ++j) hq[j] = (__bf16)val[j];
                     if (SAVE && valid) *reinterpret_cast<bf16x4*>(h1 + pix * C + 4 * g) = hq;
                     const f32x4 z = mma16(A2s, __builtin_bit_cast(s16x4, hq), f32x4{0.f, 0.f, 0.f, 0.f});
-                    const int pxc = (r + D) * G::RW + (c0 + n + D);
-                    const bf16x4 xc = *reinterpret_cast<const bf16x4*>(smem + ((long)pxc * C + 4 * g) * 2);
+                    const int colc = c0 + n + D, pxc = (r + D) * G::RW + colc;
+                    const bf16x4 xc = *reinterpret_cast<const bf16x4*>(smem + ((long)pxc * C + 8 * ((g >> 1) ^ cswz<C>(colc)) + 4 * (g & 1)) * 2);
                     bf16x4 o;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[j] = (__bf16)(elu_f(z[j] + b2r[j]) + (float)xc[j]);

@@ -27,7 +27,10 @@ def main():
     _hip.build()
     lib, st = _hip.lib(), stream_ptr()
     B, T = int(os.environ.get('KB_B', 64)), 1024
+    only = os.environ.get('KB_ONLY')
     for C, H in ((32, 65), (16, 133), (8, 269), (4, 540)):
+        if only and int(only) != C:
+            continue
         x = torch.randn(B, C, H, T, device='cuda')
         w1 = torch.randn(C, C, 3, 3, device='cuda') * 0.05
         w2 = torch.randn(C, C, 1, 1, device='cuda') * 0.1

@@ -309,8 +309,10 @@ def cpu_baseline(mc, latent, seconds_budget=15.0, config0=False):
                 s_per_step=step_s, legs_s={k: v / n for k, v in legs.items()})
 
 
-def bench_inference(model, args, rank, world, dev, steps=None, warmup=None, emit=True):
-    """BASELINE.json configs[1]: model.transcribe(audio) + model.reconstruct(audio), batch x 3 s clips (secondary line)."""
+def bench_inference(model, args, rank, world, dev, steps=None, warmup=None, emit=True, autocast=False):
+    """BASELINE.json configs[1]: model.transcribe(audio) + model.reconstruct(audio), batch x 3 s clips (secondary line).
+    autocast=True: the same calls inside torch.autocast (bf16 channels-last path) -- what a user who evaluates under autocast gets;
+    the reference's evaluate.py does not, so the fp32 figure is the one that carries the 1e-4 output bar."""
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
     was_training = model.training
@@ -319,7 +321,7 @@ def bench_inference(model, args, rank, world, dev, steps=None, warmup=None, emit
     audio, _ = synthetic_batch(batch, rank, dev)
 
     def step():
-        with torch.no_grad():
+        with torch.no_grad(), torch.autocast(device_type='cuda', dtype=torch.bfloat16, enabled=autocast):
             act = model.transcribe(audio)
             rec = model.reconstruct(audio)
         return act, rec
@@ -336,7 +338,7 @@ def bench_inference(model, args, rank, world, dev, steps=None, warmup=None, emit
     line = dict(metric='audio-seconds/s inference throughput, transcribe()+reconstruct() (9oct x 60bpo, 3s@22.05kHz)',
                 value=world * batch * SECS_PER_CLIP / (elapsed / steps), unit='audio-seconds/s', n_gpus=world,
                 steps=steps, warmup=warmup, ms_per_step=ms, higher_is_better=True, scaling='weak',
-                vs_baseline=None, dtype=args.infer_dtype, data='synthetic',
+                vs_baseline=None, dtype='bf16' if autocast else args.infer_dtype, data='synthetic',
                 config=dict(workload='transcribe() + reconstruct() (each: 3 half-overlapping chunks per clip through CQT + '
                                      'encoder + decoder, Hann cross-fade; reconstruct adds the inverse CQT), model_complexity=%d '
                                      'latent=%d, %d clips x 3 s' % (args.mc, args.latent, batch),
@@ -536,6 +538,9 @@ def main():
             full = bench_inference(model, args, rank, world, dev, steps=3, warmup=1, emit=False)
             infer = {k: full[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype')}
             infer['workload'] = full['config']['workload']
+            if args.precision == 'auto':
+                full16 = bench_inference(model, args, rank, world, dev, steps=3, warmup=1, emit=False, autocast=True)
+                infer['under_autocast'] = {k: full16[k] for k in ('value', 'unit', 'ms_per_step', 'dtype')}
         fp32_step = None
         if world == 1 and not args.timed_only and train_dtype != 'f32':
             # the exact-fp32 train step (every parity test's arithmetic), measured in the same run: secondary figure

@@ -975,6 +975,208 @@ __global__ __launch_bounds__(NT) void k_nrb_wgrad(const __bf16* __restrict__ x, 
         for (int r = 0; r < 4; ++r) pw[(k * 4 + r) * 64 + lane] = acc[k][r];
 }
 
+// ---- the whole backward of a narrow block in ONE pass ---------------------------------------------------------------------
+// h1, dy and x tiles (16 x 64 pixels + halo) arrive by LDS-DMA; phase 1 runs the pointwise chain on EVERY pixel of the halo'd
+// tile (a lane = a pixel) and writes dA1 over h1 in LDS -- out-of-image pixels have h1 = dy = 0 and give dA1 = 0, which is the
+// zero padding of the data gradient; db1 / db2 / dW2 are accumulated over the tile's own (centre, in-image) pixels only.  Phase 2
+// takes dx = dy + W1^T (*) dA1 and dW1 = sum dA1 (x) x(+tap) straight from the three LDS images.  dA1 never goes to HBM: 4 tensors
+// of traffic per block instead of 8 (h1, dy, x read; dx written), one launch instead of three.
+template <int C, int D>
+__global__ __launch_bounds__(NT, C == 8 ? 2 : 1) void k_nrb_bwd_fused(const __bf16* __restrict__ x, const __bf16* __restrict__ h1,
+                                                      const __bf16* __restrict__ dy, const float* __restrict__ w1,
+                                                      const float* __restrict__ w2, const float* __restrict__ b2,
+                                                      __bf16* __restrict__ dx, float* __restrict__ part_a, float* __restrict__ part_w,
+                                                      int B, int H, int T, int tiles_h, int tiles_t, int ntiles) {
+    using G = NTl<C, D>;
+    typedef typename VecOf<C>::type vec_t;
+    constexpr int NB = C / 4, ADUMP = C * C + 2 * C, IMG = G::NPR * 16, NPX = G::ROWS * G::RW;
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char* hs = smem;                                    // h1, then dA1
+    unsigned char* gs = smem + IMG;                              // dy
+    unsigned char* xs = smem + 2 * IMG;                          // x
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i4 = lane & 3;
+    const int n = lane & 15, g = lane >> 4, trj = n >> 2, trq = n & 3;
+
+    float b2r[C], acc[ADUMP];
+#pragma unroll
+    for (int c = 0; c < C; ++c) b2r[c] = b2[c];
+#pragma unroll
+    for (int e = 0; e < ADUMP; ++e) acc[e] = 0.f;
+    f32x4 wacc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wacc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const __bf16* zero = reinterpret_cast<const __bf16*>(&g_wzero16);
+    for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
+        int tile = xcd_order(v, ntiles);
+        const int tt = tile % tiles_t; tile /= tiles_t;
+        const int th = tile % tiles_h;
+        const int b = tile / tiles_h, h0 = th * G::TH, t0 = tt * G::TW;
+        const long ib = (long)b * H * T * C;
+        __syncthreads();
+        for (int i = wave * 64; i < G::NPR; i += NT) {
+            const int p = i + lane, q = p * G::PPP;
+            const int row = q / G::RW, px = q - row * G::RW;
+            const int h = h0 - D + row, t = t0 - G::DP + px;
+            const bool ok = p < G::NP && (unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T;
+            const long off = ib + ((long)h * T + t) * C;
+            glds16(ok ? h1 + off : zero, hs + (long)i * 16);
+            glds16(ok ? dy + off : zero, gs + (long)i * 16);
+            glds16(ok ? x + off : zero, xs + (long)i * 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        // The weights of each phase are (re)loaded per tile through laundered pointers so that their registers are free in
+        // the other phases (C = 8: 72 + 16 registers of weights beside 116 of accumulators).
+        const float* w1p = w1;
+        const float* w2p = w2;
+        asm volatile("" : "+s"(w1p), "+s"(w2p));
+        // ---- phase 1: pointwise chain on every pixel of the image; dA1 over h1 ----
+        {
+            s16x4 A2[NB][NB], A2T[NB][NB];
+#pragma unroll
+            for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+                for (int kb = 0; kb < NB; ++kb) {
+                    bf16x4 a, at;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        a[k] = (__bf16)w2p[(4 * ob + i4) * C + 4 * kb + k];
+                        at[k] = (__bf16)w2p[(4 * kb + k) * C + 4 * ob + i4];
+                    }
+                    A2[ob][kb] = __builtin_bit_cast(s16x4, a); A2T[ob][kb] = __builtin_bit_cast(s16x4, at);
+                }
+            for (int c0 = wave * 64; c0 < NPX; c0 += NT) {
+                const int q = c0 + lane;
+                const bool in_img = q < NPX;
+                const int qq = in_img ? q : NPX - 1;
+                const int row = qq / G::RW, col = qq - row * G::RW;
+                const bool centre = in_img && row >= D && row < D + G::TH && col >= G::DP && col < G::DP + G::TW &&
+                                    h0 + row - D < H && t0 + col - G::DP < T;
+                const vec_t hq = *reinterpret_cast<const vec_t*>(hs + (long)qq * G::PXB);
+                const vec_t dq = *reinterpret_cast<const vec_t*>(gs + (long)qq * G::PXB);
+                f32x4 z[NB], u[NB];
+#pragma unroll
+                for (int ob = 0; ob < NB; ++ob) {
+                    z[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kb = 0; kb < NB; ++kb) z[ob] = mma4(A2[ob][kb], chunk_of<C>(hq, kb), z[ob]);
+                }
+                float gv[C], hv[C], gr[C];
+                vec_t gq, aq;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const float a2 = z[c >> 2][c & 3] + b2r[c];
+                    gv[c] = (float)dq[c] * (a2 > 0.f ? 1.f : __expf(a2));
+                    gq[c] = (__bf16)gv[c];
+                    gr[c] = (float)gq[c];
+                    hv[c] = (float)hq[c];
+                }
+#pragma unroll
+                for (int ob = 0; ob < NB; ++ob) {
+                    u[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kb = 0; kb < NB; ++kb) u[ob] = mma4(A2T[ob][kb], chunk_of<C>(gq, kb), u[ob]);
+                }
+                const float m = centre ? 1.f : 0.f;              // sums only over this tile's own pixels
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const float a1 = u[c >> 2][c & 3] * (hv[c] > 0.f ? 1.f : hv[c] + 1.f);
+                    aq[c] = (__bf16)a1;
+                    acc[C * C + c] += m * a1; acc[C * C + C + c] += m * gv[c];
+                    gr[c] *= m;
+                }
+#pragma unroll
+                for (int co = 0; co < C; ++co)
+#pragma unroll
+                    for (int ci = 0; ci < C; ++ci) acc[co * C + ci] += gr[co] * hv[ci];
+                if (in_img) *reinterpret_cast<vec_t*>(hs + (long)q * G::PXB) = aq;
+            }
+        }
+        __syncthreads();
+
+        // ---- phase 2a: dx = dy + W1^T (*) dA1 (k_nrb_conv, MODE 1, operands from LDS) ----
+        {
+            s16x4 A[9][NB][NB];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+                    for (int kb = 0; kb < NB; ++kb) {
+                        bf16x4 t4;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) t4[k] = (__bf16)w1p[((4 * kb + k) * C + 4 * ob + i4) * 9 + (8 - tap)];
+                        A[tap][ob][kb] = __builtin_bit_cast(s16x4, t4);
+                    }
+            const int t = t0 + lane;
+            for (int r = wave; r < G::TH; r += 4) {
+                const int h = h0 + r;
+                if (h >= H) break;
+                f32x4 a4[NB];
+#pragma unroll
+                for (int ob = 0; ob < NB; ++ob) a4[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int kh = tap / 3, kw = tap - 3 * kh;
+                    const int pxi = (r + kh * D) * G::RW + G::DP + lane + (kw - 1) * D;
+                    const vec_t bq = *reinterpret_cast<const vec_t*>(hs + (long)pxi * G::PXB);
+#pragma unroll
+                    for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+                        for (int kb = 0; kb < NB; ++kb) a4[ob] = mma4(A[tap][ob][kb], chunk_of<C>(bq, kb), a4[ob]);
+                }
+                const vec_t rq = *reinterpret_cast<const vec_t*>(gs + (long)((r + D) * G::RW + G::DP + lane) * G::PXB);
+                vec_t o;
+#pragma unroll
+                for (int c = 0; c < C; ++c) o[c] = (__bf16)(a4[c >> 2][c & 3] + (float)rq[c]);
+                if (t < T) *reinterpret_cast<vec_t*>(dx + ib + ((long)h * T + t) * C) = o;
+            }
+        }
+
+        // ---- phase 2b: dW1 (k_nrb_wgrad: 32-byte slots, transpose reads; the two K halves are the two halves of a row at
+        //      C = 8 and two consecutive rows at C = 4) ----
+        {
+            constexpr int ROWB = G::RW * G::PXB;                 // bytes of an image row
+            constexpr int RPS = C == 8 ? 1 : 2;                  // rows per product step
+            constexpr int UOFF = C == 8 ? 512 : ROWB;            // byte distance of the second K half
+            const int so = 32 * (4 * g + trj) + 8 * trq;
+            for (int r = wave * RPS; r < G::TH; r += 4 * RPS) {
+                if (h0 + r >= H) break;
+                const unsigned char* gp = hs + (long)(r + D) * ROWB + G::DP * G::PXB + so;
+                const s16x4 glo = lds_tr16(gp), ghi = lds_tr16(gp + UOFF);
+                const bf16x8 ga = __builtin_bit_cast(bf16x8, __builtin_shufflevector(glo, ghi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const int kh = k / 3, kw = k - 3 * kh;
+                    const unsigned char* xp = xs + (long)(r + kh * D) * ROWB + (G::DP + (kw - 1) * D) * G::PXB + so;
+                    const s16x4 lo = lds_tr16(xp), hi = lds_tr16(xp + UOFF);
+                    wacc[k] = mma32(ga, __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)), wacc[k]);
+                }
+            }
+        }
+    }
+    // ---- dumps ----
+    float* pw = part_w + ((long)blockIdx.x * 4 + wave) * (9 * 256);
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pw[(k * 4 + r) * 64 + lane] = wacc[k][r];
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int e = 0; e < ADUMP; ++e) {
+        float sv = acc[e];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sv += __shfl_xor(sv, o, 64);
+        if (lane == 0) red[wave * ADUMP + e] = sv;
+    }
+    __syncthreads();
+    float* pa = part_a + (long)blockIdx.x * ADUMP;
+    for (int e = tid; e < ADUMP; e += NT) pa[e] = (red[e] + red[ADUMP + e]) + (red[2 * ADUMP + e] + red[3 * ADUMP + e]);
+}
+
 template <int C>
 __global__ __launch_bounds__(1024) void k_nrb_reduce(RedArgs ar) {
     constexpr int WDUMP = 9 * 256, ADUMP = C * C + 2 * C;
@@ -1037,6 +1239,27 @@ int launch_nbwd(const __bf16* x, const __bf16* h1, const __bf16* dy, const float
     __bf16* da1 = reinterpret_cast<__bf16*>(ws);
     float* part_a = reinterpret_cast<float*>(ws + ((npix * C * 2 + 255) / 256) * 256);
     float* part_w = part_a + (long)MAX_A_WG * (C * C + 2 * C);
+    // Measured per launch at the bench shapes (three kernels -> fused): C = 8: 0.545 -> 0.473 / 0.489 / 0.720 ms for dilation 1 / 2 / 3,
+    // C = 4: 0.52 -> 0.475 / 0.501 / 0.535 ms.  Half the HBM traffic buys little because the pass is then bound by its own
+    // arithmetic (pointwise chain on the halo as well, three LDS images = 2 workgroups per CU at C = 8): fused for dilation <= 2.
+    static const int fused = getenv("TTRAP_NARROW_FUSED16") ? atoi(getenv("TTRAP_NARROW_FUSED16")) : 1;
+    if (fused == 2 || (fused == 1 && D <= 2)) {
+        using F = NTl<C, D>;
+        constexpr int LDS = 3 * F::NPR * 16;
+        static AttrOnce once_f;
+        auto kf = k_nrb_bwd_fused<C, D>;
+        if (int rc = raise_lds(kf, LDS, once_f)) return rc;
+        const int tiles_h = (H + F::TH - 1) / F::TH, tiles_t = (T + F::TW - 1) / F::TW, ntiles = B * tiles_h * tiles_t;
+        int gf = grid_for(ntiles, LDS, 4);
+        if (gf > MAX_W_WG) gf = MAX_W_WG;
+        hipLaunchKernelGGL(kf, dim3(gf), dim3(NT), LDS, st, x, h1, dy, w1, w2, b2, dx, part_a, part_w, B, H, T, tiles_h, tiles_t, ntiles);
+        TT_LAUNCH_CHECK();
+        RedArgs ra{part_w, gf, part_a, gf, dw1, db1, dw2, db2};
+        constexpr int total = 9 * 256 + C * C + 2 * C;
+        hipLaunchKernelGGL(k_nrb_reduce<C>, dim3((total + 63) / 64), dim3(1024), 0, st, ra);
+        TT_LAUNCH_CHECK();
+        return 0;
+    }
     const long ngroups = (npix + 63) / 64;
     const long want = (ngroups + 3) / 4;
     int grid = (int)(want < (long)4 * tt_cus() ? want : (long)4 * tt_cus());

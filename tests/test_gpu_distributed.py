@@ -23,7 +23,9 @@ SCRIPT = textwrap.dedent('''
     rank, world, _ = init_process_group_from_env()
     torch.cuda.set_device(0)
     torch.manual_seed(7 + rank)                      # different initial weights per rank: the broadcast must fix that
-    model = TimbreTrap(sample_rate=22050, n_octaves=9, bins_per_octave=60, latent_size=32, model_complexity=1).cuda()
+    amp = os.environ.get('TT_TEST_AUTOCAST') == '1'   # the bench's configuration: bf16 channels-last path under autocast, mc 2
+    model = TimbreTrap(sample_rate=22050, n_octaves=9, bins_per_octave=60, latent_size=128 if amp else 32,
+                       model_complexity=2 if amp else 1).cuda()
     opt = FusedAdamW(model.parameters(), lr=1e-3, max_norm=10.0)
     broadcast_parameters(opt.flat_param)
     g = torch.Generator().manual_seed(123)
@@ -32,10 +34,11 @@ SCRIPT = textwrap.dedent('''
     sync = GradientSync(world)
     coeffs = model.sliCQ(audio)
     for _ in range(2):
-        rec = model(audio, False)[0]
-        loss = compute_reconstruction_loss(rec, coeffs)
-        opt.zero_grad()
-        loss.backward()
+        with torch.autocast(device_type='cuda', dtype=torch.bfloat16, enabled=amp):
+            rec = model(audio, False)[0]
+            loss = compute_reconstruction_loss(rec, coeffs)
+            opt.zero_grad()
+            loss.backward()
         if world > 1:
             sync.start(opt.flat_grad)            # asynchronous all-reduce ...
             coeffs = model.sliCQ(audio)          # ... with the next step's transform issued meanwhile (bench.py's overlap)
@@ -47,9 +50,9 @@ SCRIPT = textwrap.dedent('''
 ''') % (ROOT, ROOT)
 
 
-def _run(rank, world, port):
+def _run(rank, world, port, amp=False):
     env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
-               TTRAP_DIST_BACKEND='gloo')
+               TTRAP_DIST_BACKEND='gloo', TT_TEST_AUTOCAST='1' if amp else '0')
     return subprocess.Popen([sys.executable, '-c', SCRIPT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
 
 
@@ -61,12 +64,14 @@ def _result(proc):
 
 
 @pytest.mark.gpu
-def test_two_ranks_match_single_process_global_batch():
-    procs = [_run(r, 2, 29541) for r in range(2)]
+@pytest.mark.parametrize('amp', [False, True], ids=['fp32', 'autocast-bf16'])
+def test_two_ranks_match_single_process_global_batch(amp):
+    procs = [_run(r, 2, 29541 + 4 * amp, amp) for r in range(2)]
     res = [_result(p) for p in procs]
     assert res[0] == res[1]                                       # ranks end with bit-identical parameters
-    single = _result(_run(0, 1, 29542))
-    assert abs(res[0][0] - single[0]) <= 1e-5 * abs(single[1]) and abs(res[0][1] - single[1]) <= 1e-5 * abs(single[1])
+    single = _result(_run(0, 1, 29542 + 4 * amp, amp))
+    tol = 1e-4 if amp else 1e-5                                   # bf16 step: the same products summed in another order, then Adam
+    assert abs(res[0][0] - single[0]) <= tol * abs(single[1]) and abs(res[0][1] - single[1]) <= tol * abs(single[1])
 
 
 NCCL_SCRIPT = textwrap.dedent('''

@@ -447,7 +447,9 @@ def test_run_to_run_reproducibility_bounds():
     exact = 0
     for k in runs[0][2]:
         a, b = runs[0][2][k], runs[1][2][k]
-        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max() + 1e-30), k
+        # fp32 sums of ~1e5 terms in an order that depends on atomic arrival: a few 1e-7 typical, ~3e-6 seen once in the
+        # full suite -- the bound is an order of magnitude above that, still round-off
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max() + 1e-30), k
         exact += bool(torch.equal(a, b))
     print('bitwise-identical gradients: %d of %d' % (exact, len(runs[0][2])))
 

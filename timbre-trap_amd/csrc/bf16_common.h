@@ -37,6 +37,10 @@ __device__ __forceinline__ s16x4 lds_tr16(const unsigned char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
 }
 
+// shape of the partial-sum reduce kernels: a block of 1024 threads = REL consecutive dump elements x RSL slices of the contributors
+// (each thread keeps eight loads in flight; 16 x 64 puts 600+ blocks on the chip where 64 x 16 left a third of the CUs idle)
+constexpr int REL = 16, RSL = 64;
+
 inline int grid_for(int ntiles, int lds_bytes, int max_per_cu) {
     int per = lds_bytes > 0 ? (160 * 1024) / lds_bytes : max_per_cu;
     if (per > max_per_cu) per = max_per_cu;

@@ -536,31 +536,31 @@ __global__ __launch_bounds__(NT) void k_w4(const __bf16* __restrict__ small, con
 
 struct W4Red { const float* part; const float* dbpart; int gw; float* dw; float* db; };
 
-// 1024 threads = 64 consecutive dump elements x 16 slices of the contributing waves (dumps) / workgroups (bias partials)
+// 1024 threads = REL consecutive dump elements x RSL slices of the contributing waves (dumps) / workgroups (bias partials)
 template <int C, bool GS>
 __global__ __launch_bounds__(1024) void k_w4_reduce(W4Red ar) {
     using G = W4<C>;
     constexpr int GB = GS ? G::SB : G::BB;                       // bytes per pixel of the gated operand
     constexpr int GC = GB / 2;                                   // its channel count = length of db
-    __shared__ float red[16][64];
-    const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + el;
+    __shared__ float red[RSL][REL];
+    const int el = threadIdx.x % REL, sl = threadIdx.x / REL;
+    const int e = blockIdx.x * REL + el;
     float p8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (e < G::DUMP) {
         const int nc = ar.gw * 4;
-        for (int j0 = sl; j0 < nc; j0 += 128)
+        for (int j0 = sl; j0 < nc; j0 += 8 * RSL)
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                if (j0 + 16 * u < nc) p8[u] += ar.part[(long)(j0 + 16 * u) * G::DUMP + e];
+                if (j0 + RSL * u < nc) p8[u] += ar.part[(long)(j0 + RSL * u) * G::DUMP + e];
     } else if (e < G::DUMP + GC) {
-        for (int j = sl; j < ar.gw; j += 16) p8[0] += ar.dbpart[(long)j * 64 + (e - G::DUMP)];
+        for (int j = sl; j < ar.gw; j += RSL) p8[0] += ar.dbpart[(long)j * 64 + (e - G::DUMP)];
     }
     red[sl][el] = ((p8[0] + p8[1]) + (p8[2] + p8[3])) + ((p8[4] + p8[5]) + (p8[6] + p8[7]));
     __syncthreads();
     if (sl != 0) return;
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) sum += red[i][el];
+    for (int i = 0; i < RSL; ++i) sum += red[i][el];
     if (e < G::DUMP) {
         const int lane = e & 63, r = (e >> 6) & 3, t3 = e >> 8;
         const int c = t3 % G::NBT, a = (t3 / G::NBT) % G::NA, k = t3 / (G::NBT * G::NA);
@@ -630,7 +630,7 @@ int launch_w4(const __bf16* small, const __bf16* big, const __bf16* ygate, float
     TT_LAUNCH_CHECK();
     W4Red ra{part, dbpart, gw, dw, db};
     constexpr int total = G::DUMP + (GS ? 2 * C : C);
-    hipLaunchKernelGGL((k_w4_reduce<C, GS>), dim3((total + 63) / 64), dim3(1024), 0, st, ra);
+    hipLaunchKernelGGL((k_w4_reduce<C, GS>), dim3((total + REL - 1) / REL), dim3(1024), 0, st, ra);
     TT_LAUNCH_CHECK();
     return 0;
 }

@@ -513,8 +513,8 @@ __global__ __launch_bounds__(NT) void k_wrb_wgrad(const __bf16* __restrict__ x, 
             for (int r = 0; r < 4; ++r) pw[((k * NA + a) * 4 + r) * 64 + lane] = acc[k][a][r];
 }
 
-// Sum of the register dumps into the fp32 gradients (+=).  1024 threads = 64 consecutive dump elements x 16 slices of the
-// contributing waves; the dump order keeps every load coalesced, the scatter into dW1 / dW2 is the cheap side.
+// Sum of the register dumps into the fp32 gradients (+=).  1024 threads = REL consecutive dump elements x RSL slices of the
+// contributing waves (bf16_common.h); the dump order keeps the loads coalesced, the scatter into dW1 / dW2 is the cheap side.
 struct RedArgs {
     const float* pw; int gw;        // wgrad dumps: gw workgroups x 4 waves
     const float* pa; int ga;        // bwd_a dumps: one per workgroup
@@ -525,9 +525,9 @@ __global__ __launch_bounds__(1024) void k_wrb_reduce(RedArgs ar) {
     constexpr int NCT = C / 16;
     constexpr int WDUMP = 9 * NCT * 256, NEW = NCT * WDUMP;      // wgrad: elements = (wave role) x dump
     constexpr int ADUMP = C * C + 2 * C;
-    __shared__ float red[16][64];
-    const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + el;
+    __shared__ float red[RSL][REL];
+    const int el = threadIdx.x % REL, sl = threadIdx.x / REL;
+    const int e = blockIdx.x * REL + el;
     float sum = 0.f;
     float* dst = nullptr;
     if (e < NEW) {
@@ -535,10 +535,10 @@ __global__ __launch_bounds__(1024) void k_wrb_reduce(RedArgs ar) {
         constexpr int NS = 4 / NCT;                              // waves per workgroup with the same role
         const int ncontrib = ar.gw * NS;
         float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // eight loads in flight per thread
-        for (int j0 = sl; j0 < ncontrib; j0 += 128) {
+        for (int j0 = sl; j0 < ncontrib; j0 += 8 * RSL) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int j = j0 + 16 * u;
+                const int j = j0 + RSL * u;
                 if (j < ncontrib) {
                     const int wg = j / NS, s = j - wg * NS;
                     const int wave = C == 32 ? role + 2 * s : s;
@@ -554,10 +554,10 @@ __global__ __launch_bounds__(1024) void k_wrb_reduce(RedArgs ar) {
         const int q = e - NEW;
         const int ncontrib = ar.ga;
         float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int j0 = sl; j0 < ncontrib; j0 += 128) {
+        for (int j0 = sl; j0 < ncontrib; j0 += 8 * RSL) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int j = j0 + 16 * u;
+                const int j = j0 + RSL * u;
                 if (j < ncontrib) part[u] += ar.pa[(long)j * ADUMP + q];
             }
         }
@@ -573,7 +573,7 @@ __global__ __launch_bounds__(1024) void k_wrb_reduce(RedArgs ar) {
     if (sl == 0 && dst) {
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s += red[i][el];
+        for (int i = 0; i < RSL; ++i) s += red[i][el];
         *dst += s;
     }
 }
@@ -630,7 +630,7 @@ int launch_bwd(const __bf16* x, const __bf16* h1, const __bf16* dy, const float*
     TT_LAUNCH_CHECK();
     RedArgs ra{part_w, gw, part_a, grid, dw1, db1, dw2, db2};
     constexpr int total = 9 * C * C + C * C + 2 * C;
-    hipLaunchKernelGGL(k_wrb_reduce<C>, dim3((total + 63) / 64), dim3(1024), 0, st, ra);
+    hipLaunchKernelGGL(k_wrb_reduce<C>, dim3((total + REL - 1) / REL), dim3(1024), 0, st, ra);
     TT_LAUNCH_CHECK();
     return 0;
 }
@@ -1180,29 +1180,29 @@ __global__ __launch_bounds__(NT, C == 8 ? 2 : 1) void k_nrb_bwd_fused(const __bf
 template <int C>
 __global__ __launch_bounds__(1024) void k_nrb_reduce(RedArgs ar) {
     constexpr int WDUMP = 9 * 256, ADUMP = C * C + 2 * C;
-    __shared__ float red[16][64];
-    const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + el;
+    __shared__ float red[RSL][REL];
+    const int el = threadIdx.x % REL, sl = threadIdx.x / REL;
+    const int e = blockIdx.x * REL + el;
     float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (e < WDUMP) {
         const int ncontrib = ar.gw * 4;
-        for (int j0 = sl; j0 < ncontrib; j0 += 128)
+        for (int j0 = sl; j0 < ncontrib; j0 += 8 * RSL)
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                if (j0 + 16 * u < ncontrib) part[u] += ar.pw[(long)(j0 + 16 * u) * WDUMP + e];
+                if (j0 + RSL * u < ncontrib) part[u] += ar.pw[(long)(j0 + RSL * u) * WDUMP + e];
     } else if (e < WDUMP + ADUMP) {
         const int ncontrib = ar.ga;
-        for (int j0 = sl; j0 < ncontrib; j0 += 128)
+        for (int j0 = sl; j0 < ncontrib; j0 += 8 * RSL)
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                if (j0 + 16 * u < ncontrib) part[u] += ar.pa[(long)(j0 + 16 * u) * ADUMP + (e - WDUMP)];
+                if (j0 + RSL * u < ncontrib) part[u] += ar.pa[(long)(j0 + RSL * u) * ADUMP + (e - WDUMP)];
     }
     red[sl][el] = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
     __syncthreads();
     if (sl != 0) return;
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) sum += red[i][el];
+    for (int i = 0; i < RSL; ++i) sum += red[i][el];
     if (e < WDUMP) {
         const int k = e >> 8, r = (e >> 6) & 3, lane = e & 63, g = lane >> 4, n = lane & 15;
         // D row 4g + r = (pixel-in-slot s, channel c), column n = (s', c'): keep s == s'
@@ -1256,7 +1256,7 @@ int launch_nbwd(const __bf16* x, const __bf16* h1, const __bf16* dy, const float
         TT_LAUNCH_CHECK();
         RedArgs ra{part_w, gf, part_a, gf, dw1, db1, dw2, db2};
         constexpr int total = 9 * 256 + C * C + 2 * C;
-        hipLaunchKernelGGL(k_nrb_reduce<C>, dim3((total + 63) / 64), dim3(1024), 0, st, ra);
+        hipLaunchKernelGGL(k_nrb_reduce<C>, dim3((total + REL - 1) / REL), dim3(1024), 0, st, ra);
         TT_LAUNCH_CHECK();
         return 0;
     }
@@ -1278,7 +1278,7 @@ int launch_nbwd(const __bf16* x, const __bf16* h1, const __bf16* dy, const float
     TT_LAUNCH_CHECK();
     RedArgs ra{part_w, gw, part_a, grid, dw1, db1, dw2, db2};
     constexpr int total = 9 * 256 + C * C + 2 * C;
-    hipLaunchKernelGGL(k_nrb_reduce<C>, dim3((total + 63) / 64), dim3(1024), 0, st, ra);
+    hipLaunchKernelGGL(k_nrb_reduce<C>, dim3((total + REL - 1) / REL), dim3(1024), 0, st, ra);
     TT_LAUNCH_CHECK();
     return 0;
 }

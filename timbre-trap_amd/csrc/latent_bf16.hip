@@ -339,11 +339,11 @@ __global__ __launch_bounds__(NT) void k_lat_wred(const float* __restrict__ part,
         const int lane = e & 63, r = (e >> 6) & 3, dt = e >> 8;
         const int d = 16 * dt + 4 * (lane >> 4) + r, c = 16 * ct + (lane & 15);
         if (d < D) dw[((long)d * CT + c) * E + h] += sum;
-    } else if (db && i < total + CT) {
-        const int c = i - total;
+    } else if (db && i < total + CT * 16) {                     // sixteen slices of the workgroups per channel, joined by atomics
+        const int c = (i - total) % CT, sl = (i - total) / CT;
         float sum = 0.f;
-        for (int wg = 0; wg < nsplit * E; ++wg) sum += dbpart[(long)wg * 64 + c];
-        db[c] += sum;
+        for (int wg = sl; wg < nsplit * E; wg += 16) sum += dbpart[(long)wg * 64 + c];
+        atomicAdd(db + c, sum);
     }
 }
 
@@ -416,7 +416,7 @@ int run_wgrad(const float* z, const __bf16* g_in, const __bf16* gy, float* dw, f
     if (int rc = raise_lds(kern, LDS, once)) return rc;
     hipLaunchKernelGGL(kern, dim3(E * NSPLIT), dim3(NT), LDS, st, zt, g_in, gy, part, dbpart, E, T, npix, NSPLIT);
     TT_LAUNCH_CHECK();
-    const int total = E * (CT / 16) * DT * 256 + CT;
+    const int total = E * (CT / 16) * DT * 256 + CT * 16;
     hipLaunchKernelGGL((k_lat_wred<CT, DT>), dim3((total + NT - 1) / NT), dim3(NT), 0, st, part, dbpart, dw, GATE ? db : nullptr, D, E, NSPLIT);
     TT_LAUNCH_CHECK();
     return 0;

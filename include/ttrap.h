@@ -187,17 +187,20 @@ int tt_tconv16_bwd(const void* x, const void* y, const void* dy, const float* w,
 /* The (31,1) latent heads on bf16 channels-last embeddings (csrc/latent_bf16.hip; modules.py:446 Encoder.convlat and :534
  * Decoder.convin).  w is the (D', CT, E, 1) weight of either layer (index (d CT + c) E + h); (CT, D') = (32, <= 48) or (64, <= 144);
  * T % 16 == 0.  ws: tt_latent16_scratch_bytes bytes.
- *   tt_latent16_contract  out (B,D,T) fp32 = [bias +] sum_{c,h} w[d][c][h] in[b,h,t,c]; in = x (cl16), or, with gy != NULL,
- *                         in = x * ELU'(gy) on the fly (data gradient of convin from dy and the saved output)
- *   tt_latent16_expand    out (B,CT,E,T) cl16 = sum_d w[d][c][h] z[b,d,t], with bias != NULL: ELU(bias[c] + .)
- *   tt_latent16_wgrad     dw += sum_{b,t} z[b,d,t] g[b,h,t,c]  (g cl16; with gy != NULL gated as above and db (CT) += sum g) */
+ *   tt_latent16_contract  out (B,Dout,T) fp32 = [bias +] sum_{c,h} w[d][c][h] in[b,h,t,c] for d < Dout (D, or D - 1 to skip the
+ *                         gradient of a constant last channel); in = x (cl16), or, with gy != NULL, in = x * ELU'(gy) on the fly
+ *                         (data gradient of convin from dy and the saved output)
+ *   tt_latent16_expand    out (B,CT,E,T) cl16 = sum_d w[d][c][h] z[b,d,t], with bias != NULL: ELU(bias[c] + .); z (B,Dz,T) with
+ *                         Dz = D, or Dz = D - 1 and channel D - 1 = the constant `fill` (the indicator of TimbreTrap.decode,
+ *                         modules.py:139-142, without the concatenated tensor)
+ *   tt_latent16_wgrad     dw += sum_{b,t} z[b,d,t] g[b,h,t,c]  (z as above; g cl16; with gy != NULL gated and db (CT) += sum g) */
 int64_t tt_latent16_scratch_bytes(int B, int CT, int D, int E, int T);
 int tt_latent16_contract(const void* in, const void* gy, const float* w, const float* bias, float* out, void* ws, int B, int CT,
-                         int D, int E, int T, void* stream);
-int tt_latent16_expand(const float* z, const float* w, const float* bias, void* out, void* ws, int B, int CT, int D, int E, int T,
-                       void* stream);
-int tt_latent16_wgrad(const float* z, const void* g, const void* gy, float* dw, float* db, void* ws, int B, int CT, int D, int E,
-                      int T, void* stream);
+                         int D, int Dout, int E, int T, void* stream);
+int tt_latent16_expand(const float* z, int Dz, float fill, const float* w, const float* bias, void* out, void* ws, int B, int CT,
+                       int D, int E, int T, void* stream);
+int tt_latent16_wgrad(const float* z, int Dz, float fill, const void* g, const void* gy, float* dw, float* db, void* ws, int B,
+                      int CT, int D, int E, int T, void* stream);
 
 /* The 3x3 boundary convolutions where fp32 planar tensors meet the bf16 channels-last interior (csrc/conv_edge_bf16.hip), for
  * C0 = 4 first-level channels (model_complexity 2):

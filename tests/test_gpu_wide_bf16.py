@@ -356,7 +356,7 @@ def test_latent_heads_stagewise(CT, D, B, T):
     # Decoder.convin
     zd = z.cuda().requires_grad_(True)
     wd2, bd2 = w.cuda().requires_grad_(True), bd.cuda().requires_grad_(True)
-    y = ops.LatDec16Fn.apply(zd, wd2, bd2)
+    y = ops.LatDec16Fn.apply(zd, wd2, bd2, None)
     assert ops.is_cl16(y) and tuple(y.shape) == (B, CT, E, T)
     y_ref = F.elu(torch.einsum('dk,bdt->bkt', W2, zr).view(B, CT, E, T) + bd.double()[None, :, None, None])
     y_k = _f64(y.detach())
@@ -367,6 +367,20 @@ def test_latent_heads_stagewise(CT, D, B, T):
     assert _rel(zd.grad.cpu().double(), torch.einsum('dk,bkt->bdt', W2, g_r.view(B, CT * E, T))) < 2e-4
     assert _rel(wd2.grad.cpu().double().view(D, CT * E), torch.einsum('bdt,bkt->dk', zr, g_r.view(B, CT * E, T))) < 2e-4
     assert _rel(bd2.grad.cpu().double(), g.sum((0, 2, 3))) < 2e-3
+
+    # the last input channel as a constant (TimbreTrap.decode's indicator) instead of a row of z: same output, same gradients
+    zc = z.clone()
+    zc[:, -1] = 0.625
+    outs = []
+    for variant in range(2):
+        zin = (zc if variant == 0 else zc[:, :-1].contiguous()).cuda().requires_grad_(True)
+        wv, bv = w.cuda().requires_grad_(True), bd.cuda().requires_grad_(True)
+        yv = ops.LatDec16Fn.apply(zin, wv, bv, None if variant == 0 else 0.625)
+        yv.backward(_cl16(dtop))
+        outs.append((yv.detach().float(), zin.grad, wv.grad, bv.grad))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1][:, :-1], outs[1][1])
+    assert torch.equal(outs[0][2], outs[1][2])
+    assert _rel(outs[0][3].double(), outs[1][3].double()) < 1e-6          # the bias partials meet in fp32 atomics
 
 
 # ---- boundary 3x3 convolutions (csrc/conv_edge_bf16.hip) ----------------------------------------------------------------------

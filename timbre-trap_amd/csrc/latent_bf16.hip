@@ -47,9 +47,11 @@ __global__ __launch_bounds__(NT) void k_lat_wprep2(const float* __restrict__ w, 
     for (int e = 0; e < 8; ++e) v[e] = (__bf16)(d0 + e < D ? w[((long)(d0 + e) * CT + c) * E + h] : 0.f);
     reinterpret_cast<bf16x8*>(wp)[i] = v;
 }
-// zt[b][t][ZS] (bf16) = z[b][d][t] (fp32), zero beyond D
+// zt[b][t][ZS] (bf16) = z[b][d][t] (fp32, Dz rows), row Dz = the constant `fill` when Dz < D (the indicator channel of
+// TimbreTrap.decode, modules.py:139-142, without materialising the concatenation), zero beyond D
 template <int KS>
-__global__ __launch_bounds__(NT) void k_lat_zprep(const float* __restrict__ z, __bf16* __restrict__ zt, int D, int T, long npix) {
+__global__ __launch_bounds__(NT) void k_lat_zprep(const float* __restrict__ z, __bf16* __restrict__ zt, int D, int Dz, float fill, int T,
+                                                   long npix) {
     constexpr int ZS = 32 * KS + 16, PCS = ZS / 8;
     // a wave = 64 consecutive frames x one 16-byte piece: the fp32 reads are coalesced, the bf16 writes 16 bytes per lane
     const long i = (long)blockIdx.x * NT + threadIdx.x;
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(NT) void k_lat_zprep(const float* __restrict__ z, _
     const long b = pix / T, t = pix - b * T;
     bf16x8 v;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (__bf16)(d0 + e < D ? z[(b * D + d0 + e) * T + t] : 0.f);
+    for (int e = 0; e < 8; ++e) v[e] = (__bf16)(d0 + e < Dz ? z[(b * Dz + d0 + e) * T + t] : (d0 + e < D ? fill : 0.f));
     *reinterpret_cast<bf16x8*>(zt + pix * ZS + d0) = v;
 }
 
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(NT) void k_lat_zprep(const float* __restrict__ z, _
 template <int CT, int DT, bool GATE>
 __global__ __launch_bounds__(NT) void k_lat_contract(const __bf16* __restrict__ in, const __bf16* __restrict__ gy,
                                                       const __bf16* __restrict__ wp, const float* __restrict__ bias,
-                                                      float* __restrict__ out, int D, int E, int T, long npix) {
+                                                      float* __restrict__ out, int D, int Dout, int E, int T, long npix) {
     constexpr int SPH = CT / 32;
     constexpr int CHUNK = DT * 64 * 16, ROUNDS = (DT * 64 + NT - 1) / NT;      // bytes of one step's weights
     extern __shared__ __align__(16) unsigned char smem[];       // two buffers of ROUNDS * NT * 16 bytes
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(NT) void k_lat_contract(const __bf16* __restrict__ 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int d = 16 * dt + 4 * g + r;
-                if (d < D) out[(b * D + d) * T + t] = acc[dt][q][r] + (bias ? bias[d] : 0.f);
+                if (d < Dout) out[(b * Dout + d) * T + t] = acc[dt][q][r] + (bias ? bias[d] : 0.f);
             }
     }
     (void)CHUNK;
@@ -359,8 +361,8 @@ template <int CT, int DT, int KS> struct LatSizes {
 };
 
 template <int CT, int DT, int KS, bool GATE>
-int run_contract(const __bf16* in, const __bf16* gy, const float* w, const float* bias, float* out, unsigned char* ws, int B, int D, int E,
-                 int T, hipStream_t st) {
+int run_contract(const __bf16* in, const __bf16* gy, const float* w, const float* bias, float* out, unsigned char* ws, int B, int D,
+                 int Dout, int E, int T, hipStream_t st) {
     using L = LatSizes<CT, DT, KS>;
     const long npix = (long)B * T;
     __bf16* wp = reinterpret_cast<__bf16*>(ws);
@@ -371,13 +373,14 @@ int run_contract(const __bf16* in, const __bf16* gy, const float* w, const float
     static AttrOnce once;
     auto kern = k_lat_contract<CT, DT, GATE>;
     if (int rc = raise_lds(kern, LDS, once)) return rc;
-    hipLaunchKernelGGL(kern, dim3((unsigned)((npix + 255) / 256)), dim3(NT), LDS, st, in, gy, wp, bias, out, D, E, T, npix);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((npix + 255) / 256)), dim3(NT), LDS, st, in, gy, wp, bias, out, D, Dout, E, T, npix);
     TT_LAUNCH_CHECK();
     return 0;
 }
 
 template <int CT, int DT, int KS, bool ACT>
-int run_expand(const float* z, const float* w, const float* bias, __bf16* out, unsigned char* ws, int B, int D, int E, int T, hipStream_t st) {
+int run_expand(const float* z, int Dz, float fill, const float* w, const float* bias, __bf16* out, unsigned char* ws, int B, int D, int E,
+               int T, hipStream_t st) {
     using L = LatSizes<CT, DT, KS>;
     const long npix = (long)B * T;
     __bf16* wp = reinterpret_cast<__bf16*>(ws);
@@ -386,7 +389,7 @@ int run_expand(const float* z, const float* w, const float* bias, __bf16* out, u
     hipLaunchKernelGGL((k_lat_wprep2<CT, KS>), dim3((pieces + NT - 1) / NT), dim3(NT), 0, st, w, wp, D, E);
     TT_LAUNCH_CHECK();
     const long zp = ((npix + 63) / 64) * 64 * (L::ZS / 8);
-    hipLaunchKernelGGL((k_lat_zprep<KS>), dim3((unsigned)((zp + NT - 1) / NT)), dim3(NT), 0, st, z, zt, D, T, npix);
+    hipLaunchKernelGGL((k_lat_zprep<KS>), dim3((unsigned)((zp + NT - 1) / NT)), dim3(NT), 0, st, z, zt, D, Dz, fill, T, npix);
     TT_LAUNCH_CHECK();
     constexpr int PCS = L::NC * KS * 64, ROUNDS = (PCS + NT - 1) / NT, LDS = 2 * ROUNDS * NT * 16;
     static AttrOnce once;
@@ -398,15 +401,15 @@ int run_expand(const float* z, const float* w, const float* bias, __bf16* out, u
 }
 
 template <int CT, int DT, int KS, bool GATE>
-int run_wgrad(const float* z, const __bf16* g_in, const __bf16* gy, float* dw, float* db, unsigned char* ws, int B, int D, int E, int T,
-              hipStream_t st) {
+int run_wgrad(const float* z, int Dz, float fill, const __bf16* g_in, const __bf16* gy, float* dw, float* db, unsigned char* ws, int B,
+              int D, int E, int T, hipStream_t st) {
     using L = LatSizes<CT, DT, KS>;
     const long npix = (long)B * T;
     __bf16* zt = reinterpret_cast<__bf16*>(ws);
     float* part = reinterpret_cast<float*>(ws + ((L::zt_bytes(npix) + 255) / 256) * 256);
     float* dbpart = part + (long)NSPLIT * E * 4 * DT * 256;
     const long zp = ((npix + 63) / 64) * 64 * (L::ZS / 8);
-    hipLaunchKernelGGL((k_lat_zprep<KS>), dim3((unsigned)((zp + NT - 1) / NT)), dim3(NT), 0, st, z, zt, D, T, npix);
+    hipLaunchKernelGGL((k_lat_zprep<KS>), dim3((unsigned)((zp + NT - 1) / NT)), dim3(NT), 0, st, z, zt, D, Dz, fill, T, npix);
     TT_LAUNCH_CHECK();
     constexpr int ZB = L::ZS * 2, GBY = CT * 2;
     constexpr int ZR = (64 * ZB / 16 + NT - 1) / NT, GR = (64 * GBY / 16 + NT - 1) / NT;
@@ -441,44 +444,46 @@ int64_t tt_latent16_scratch_bytes(int B, int CT, int D, int E, int T) {
     return -1;
 }
 
-/* out (B,D,T) fp32 = bias + contraction of in (B,CT,E,T) cl16 [gated by the saved output gy when gy != NULL] with w (D,CT,E,1) */
+/* out (B,Dout,T) fp32 = [bias +] contraction of in (B,CT,E,T) cl16 [gated by the saved output gy when gy != NULL] with the first Dout
+ * rows of w (D,CT,E,1); Dout = D, or D - 1 to skip the gradient of a constant last input channel */
 int tt_latent16_contract(const void* in, const void* gy, const float* w, const float* bias, float* out, void* ws, int B, int CT, int D,
-                         int E, int T, void* stream) {
-    if (!in || !w || !out || !ws || B <= 0 || E <= 0 || T <= 0 || T % 16) return TT_E_BADARG;
+                         int Dout, int E, int T, void* stream) {
+    if (!in || !w || !out || !ws || B <= 0 || E <= 0 || T <= 0 || T % 16 || Dout < 1 || Dout > D) return TT_E_BADARG;
     hipStream_t st = tt_stream(stream);
     const __bf16 *i = (const __bf16*)in, *y = (const __bf16*)gy;
     unsigned char* s = (unsigned char*)ws;
     switch (cfg_of(CT, D)) {
-        case 1: return y ? run_contract<32, 3, 2, true>(i, y, w, bias, out, s, B, D, E, T, st) : run_contract<32, 3, 2, false>(i, y, w, bias, out, s, B, D, E, T, st);
-        case 2: return y ? run_contract<64, 9, 5, true>(i, y, w, bias, out, s, B, D, E, T, st) : run_contract<64, 9, 5, false>(i, y, w, bias, out, s, B, D, E, T, st);
+        case 1: return y ? run_contract<32, 3, 2, true>(i, y, w, bias, out, s, B, D, Dout, E, T, st) : run_contract<32, 3, 2, false>(i, y, w, bias, out, s, B, D, Dout, E, T, st);
+        case 2: return y ? run_contract<64, 9, 5, true>(i, y, w, bias, out, s, B, D, Dout, E, T, st) : run_contract<64, 9, 5, false>(i, y, w, bias, out, s, B, D, Dout, E, T, st);
     }
     return TT_E_UNSUPPORTED;
 }
 
-/* out (B,CT,E,T) cl16 = [ELU(bias + .) if bias != NULL] expansion of z (B,D,T) fp32 with w (D,CT,E,1) */
-int tt_latent16_expand(const float* z, const float* w, const float* bias, void* out, void* ws, int B, int CT, int D, int E, int T,
-                       void* stream) {
-    if (!z || !w || !out || !ws || B <= 0 || E <= 0 || T <= 0 || T % 16) return TT_E_BADARG;
+/* out (B,CT,E,T) cl16 = [ELU(bias + .) if bias != NULL] expansion of z with w (D,CT,E,1); z is (B,Dz,T) fp32 with Dz = D, or
+ * Dz = D - 1 and the last input channel is the constant `fill` */
+int tt_latent16_expand(const float* z, int Dz, float fill, const float* w, const float* bias, void* out, void* ws, int B, int CT, int D,
+                       int E, int T, void* stream) {
+    if (!z || !w || !out || !ws || B <= 0 || E <= 0 || T <= 0 || T % 16 || (Dz != D && Dz != D - 1)) return TT_E_BADARG;
     hipStream_t st = tt_stream(stream);
     __bf16* o = (__bf16*)out;
     unsigned char* s = (unsigned char*)ws;
     switch (cfg_of(CT, D)) {
-        case 1: return bias ? run_expand<32, 3, 2, true>(z, w, bias, o, s, B, D, E, T, st) : run_expand<32, 3, 2, false>(z, w, bias, o, s, B, D, E, T, st);
-        case 2: return bias ? run_expand<64, 9, 5, true>(z, w, bias, o, s, B, D, E, T, st) : run_expand<64, 9, 5, false>(z, w, bias, o, s, B, D, E, T, st);
+        case 1: return bias ? run_expand<32, 3, 2, true>(z, Dz, fill, w, bias, o, s, B, D, E, T, st) : run_expand<32, 3, 2, false>(z, Dz, fill, w, bias, o, s, B, D, E, T, st);
+        case 2: return bias ? run_expand<64, 9, 5, true>(z, Dz, fill, w, bias, o, s, B, D, E, T, st) : run_expand<64, 9, 5, false>(z, Dz, fill, w, bias, o, s, B, D, E, T, st);
     }
     return TT_E_UNSUPPORTED;
 }
 
-/* dw (D,CT,E,1) += sum_{b,t} z (B,D,T) x g (B,CT,E,T) cl16 [gated by gy when gy != NULL, then also db (CT) += sum g] */
-int tt_latent16_wgrad(const float* z, const void* g, const void* gy, float* dw, float* db, void* ws, int B, int CT, int D, int E, int T,
-                      void* stream) {
-    if (!z || !g || !dw || !ws || (gy && !db) || B <= 0 || E <= 0 || T <= 0 || T % 16) return TT_E_BADARG;
+/* dw (D,CT,E,1) += sum_{b,t} z x g (B,CT,E,T) cl16 [gated by gy when gy != NULL, then also db (CT) += sum g]; z as in tt_latent16_expand */
+int tt_latent16_wgrad(const float* z, int Dz, float fill, const void* g, const void* gy, float* dw, float* db, void* ws, int B, int CT,
+                      int D, int E, int T, void* stream) {
+    if (!z || !g || !dw || !ws || (gy && !db) || B <= 0 || E <= 0 || T <= 0 || T % 16 || (Dz != D && Dz != D - 1)) return TT_E_BADARG;
     hipStream_t st = tt_stream(stream);
     const __bf16 *gi = (const __bf16*)g, *y = (const __bf16*)gy;
     unsigned char* s = (unsigned char*)ws;
     switch (cfg_of(CT, D)) {
-        case 1: return y ? run_wgrad<32, 3, 2, true>(z, gi, y, dw, db, s, B, D, E, T, st) : run_wgrad<32, 3, 2, false>(z, gi, y, dw, db, s, B, D, E, T, st);
-        case 2: return y ? run_wgrad<64, 9, 5, true>(z, gi, y, dw, db, s, B, D, E, T, st) : run_wgrad<64, 9, 5, false>(z, gi, y, dw, db, s, B, D, E, T, st);
+        case 1: return y ? run_wgrad<32, 3, 2, true>(z, Dz, fill, gi, y, dw, db, s, B, D, E, T, st) : run_wgrad<32, 3, 2, false>(z, Dz, fill, gi, y, dw, db, s, B, D, E, T, st);
+        case 2: return y ? run_wgrad<64, 9, 5, true>(z, Dz, fill, gi, y, dw, db, s, B, D, E, T, st) : run_wgrad<64, 9, 5, false>(z, Dz, fill, gi, y, dw, db, s, B, D, E, T, st);
     }
     return TT_E_UNSUPPORTED;
 }

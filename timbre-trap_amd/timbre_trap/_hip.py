@@ -58,9 +58,9 @@ _PROTOS = {
     'tt_tconv16_fwd': (c_int, [P, P, P, P, I, I, I, I, I, P]),
     'tt_tconv16_bwd': (c_int, [P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
     'tt_latent16_scratch_bytes': (c_int64, [I, I, I, I, I]),
-    'tt_latent16_contract': (c_int, [P, P, P, P, P, P, I, I, I, I, I, P]),
-    'tt_latent16_expand': (c_int, [P, P, P, P, P, I, I, I, I, I, P]),
-    'tt_latent16_wgrad': (c_int, [P, P, P, P, P, P, I, I, I, I, I, P]),
+    'tt_latent16_contract': (c_int, [P, P, P, P, P, P, I, I, I, I, I, I, P]),
+    'tt_latent16_expand': (c_int, [P, I, F_, P, P, P, P, I, I, I, I, I, P]),
+    'tt_latent16_wgrad': (c_int, [P, I, F_, P, P, P, P, P, I, I, I, I, I, P]),
     'tt_edge16_scratch_bytes': (c_int64, []),
     'tt_convin16_fwd': (c_int, [P, P, P, P, I, I, I, P]),
     'tt_convin16_bwd': (c_int, [P, P, P, P, P, P, P, P, I, I, I, P]),

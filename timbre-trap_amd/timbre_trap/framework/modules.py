@@ -168,9 +168,11 @@ class Decoder(nn.Module):
         self.block4 = DecoderBlock(channels[3], channels[4], stride=2, padding=padding[3])
         self.convout = nn.Conv2d(channels[4], 2, kernel_size=3, padding='same')
 
-    def forward(self, latents, encoder_embeddings=None):
+    def forward(self, latents, encoder_embeddings=None, indicator=None):
+        """``indicator``: None (latents carry the switch channel, the reference's call) or its constant value (then latents have
+        one channel less and ops.latent_decode supplies it)."""
         c = self.convin[0]
-        y = ops.latent_decode(latents, c.weight, c.bias)
+        y = ops.latent_decode(latents, c.weight, c.bias, indicator)
         skips = None if encoder_embeddings is None else list(encoder_embeddings)[::-1]
         if skips is not None:
             y = ops.add(y, skips[0])
@@ -210,7 +212,12 @@ class TimbreTrap(nn.Module):
 
     def decode(self, latents, embeddings=None, transcribe=False):
         """latents (B,D,T) -> logits (B,2,F,T); the extra latent channel is 1 for reconstruction, 0 for transcription."""
-        indicator = torch.full_like(latents[..., :1, :], 0.0 if transcribe else 1.0)
+        value = 0.0 if transcribe else 1.0
+        if ops.wide_storage() == 'bf16':
+            # the bf16 latent head takes the indicator as a constant channel: no concatenated copy of the latents, and their
+            # gradient comes back contiguous
+            return self.decoder(latents, embeddings, indicator=value)
+        indicator = torch.full_like(latents[..., :1, :], value)
         return self.decoder(torch.cat((latents, indicator), dim=-2), embeddings)
 
     def _inference(self, audio, transcribe=False):

@@ -804,7 +804,7 @@ class LatEnc16Fn(torch.autograd.Function):
         lib = _hip.lib()
         y = torch.empty((B, D, T), dtype=torch.float32, device=x.device)
         ws = torch.empty(lib.tt_latent16_scratch_bytes(B, CT, D, E, T), dtype=torch.uint8, device=x.device)
-        check(lib.tt_latent16_contract(ptr(x), None, ptr(w), ptr(b), ptr(y), ptr(ws), B, CT, D, E, T, stream_ptr()),
+        check(lib.tt_latent16_contract(ptr(x), None, ptr(w), ptr(b), ptr(y), ptr(ws), B, CT, D, D, E, T, stream_ptr()),
               'tt_latent16_contract')
         ctx.params = (w, b)
         ctx.save_for_backward(x, w)
@@ -821,27 +821,33 @@ class LatEnc16Fn(torch.autograd.Function):
         dx = rw = rb = None
         if ctx.needs_input_grad[0]:
             dx = new_cl16(B, CT, E, T, x.device)
-            check(lib.tt_latent16_expand(ptr(dy), ptr(w), None, ptr(dx), ptr(ws), B, CT, D, E, T, st), 'tt_latent16_expand')
+            check(lib.tt_latent16_expand(ptr(dy), D, 0.0, ptr(w), None, ptr(dx), ptr(ws), B, CT, D, E, T, st), 'tt_latent16_expand')
         if ctx.needs_input_grad[1]:
             dw, rw = _grad_target(ctx.params[0])
-            check(lib.tt_latent16_wgrad(ptr(dy), ptr(x), None, ptr(dw), None, ptr(ws), B, CT, D, E, T, st), 'tt_latent16_wgrad')
+            check(lib.tt_latent16_wgrad(ptr(dy), D, 0.0, ptr(x), None, ptr(dw), None, ptr(ws), B, CT, D, E, T, st), 'tt_latent16_wgrad')
             db, rb = _grad_target(ctx.params[1])
             check(lib.tt_channel_sum(ptr(dy), ptr(db), B, D, T, st), 'tt_channel_sum')
         return dx, rw, rb
 
 
 class LatDec16Fn(torch.autograd.Function):
-    """Decoder.convin producing the cl16 top embedding: z (B,D+1,T) fp32 -> ELU(tconv) (B,CT,E,T) cl16."""
+    """
+    Decoder.convin producing the cl16 top embedding: z (B,Dz,T) fp32 -> ELU(tconv) (B,CT,E,T) cl16.  ``fill`` is None (z carries
+    all D = w.size(0) input channels) or the value of a constant LAST channel that z does not carry (Dz = D - 1): the
+    transcription switch of TimbreTrap.decode (reference modules.py:139-142) without building the concatenated tensor.
+    """
 
     @staticmethod
-    def forward(ctx, z, w, b):
+    def forward(ctx, z, w, b, fill):
         z = _f32c(z)
-        B, D, T = z.shape
-        CT, E = w.size(1), w.size(2)
+        B, Dz, T = z.shape
+        D, CT, E = w.size(0), w.size(1), w.size(2)
         lib = _hip.lib()
         y = new_cl16(B, CT, E, T, z.device)
         ws = torch.empty(lib.tt_latent16_scratch_bytes(B, CT, D, E, T), dtype=torch.uint8, device=z.device)
-        check(lib.tt_latent16_expand(ptr(z), ptr(w), ptr(b), ptr(y), ptr(ws), B, CT, D, E, T, stream_ptr()), 'tt_latent16_expand')
+        ctx.fill = 0.0 if fill is None else float(fill)
+        check(lib.tt_latent16_expand(ptr(z), Dz, ctx.fill, ptr(w), ptr(b), ptr(y), ptr(ws), B, CT, D, E, T, stream_ptr()),
+              'tt_latent16_expand')
         ctx.params = (w, b)
         ctx.save_for_backward(z, w, y)
         return y
@@ -849,20 +855,20 @@ class LatDec16Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         z, w, y = ctx.saved_tensors
-        B, D, T = z.shape
-        CT, E = w.size(1), w.size(2)
+        B, Dz, T = z.shape
+        D, CT, E = w.size(0), w.size(1), w.size(2)
         lib, st = _hip.lib(), stream_ptr()
         g = _as_cl16(dy)
         ws = torch.empty(lib.tt_latent16_scratch_bytes(B, CT, D, E, T), dtype=torch.uint8, device=z.device)
         dz = rw = rb = None
         if ctx.needs_input_grad[0]:
             dz = torch.empty_like(z)
-            check(lib.tt_latent16_contract(ptr(g), ptr(y), ptr(w), None, ptr(dz), ptr(ws), B, CT, D, E, T, st), 'tt_latent16_contract')
+            check(lib.tt_latent16_contract(ptr(g), ptr(y), ptr(w), None, ptr(dz), ptr(ws), B, CT, D, Dz, E, T, st), 'tt_latent16_contract')
         if ctx.needs_input_grad[1]:
             dw, rw = _grad_target(ctx.params[0])
             db, rb = _grad_target(ctx.params[1])
-            check(lib.tt_latent16_wgrad(ptr(z), ptr(g), ptr(y), ptr(dw), ptr(db), ptr(ws), B, CT, D, E, T, st), 'tt_latent16_wgrad')
-        return dz, rw, rb
+            check(lib.tt_latent16_wgrad(ptr(z), Dz, ctx.fill, ptr(g), ptr(y), ptr(dw), ptr(db), ptr(ws), B, CT, D, E, T, st), 'tt_latent16_wgrad')
+        return dz, rw, rb, None
 
 
 def latent_encode(top, w, b):
@@ -872,11 +878,17 @@ def latent_encode(top, w, b):
     return LatentEncodeFn.apply(to_planar32(top), w, b)
 
 
-def latent_decode(z, w, b):
-    """Decoder.convin (modules.py:534) + ELU; cl16 output in the bf16 mode."""
-    if (wide_storage() == 'bf16' and FUSED_RESBLOCK and _f32ok(w) and z.dim() == 3 and w.size(0) == z.size(1) and w.size(3) == 1
+def latent_decode(z, w, b, fill=None):
+    """
+    Decoder.convin (modules.py:534) + ELU; cl16 output in the bf16 mode.  ``fill``: value of a constant last input channel that z
+    does not carry (see LatDec16Fn); on the fp32 path the channel is concatenated like the reference does.
+    """
+    Dz = z.size(1) + (fill is not None)
+    if (wide_storage() == 'bf16' and FUSED_RESBLOCK and _f32ok(w) and z.dim() == 3 and w.size(0) == Dz and w.size(3) == 1
             and _lat16_ok(w.size(1), w.size(0), w.size(2), z.size(2), b)):
-        return LatDec16Fn.apply(z, w, b)
+        return LatDec16Fn.apply(z, w, b, fill)
+    if fill is not None:
+        z = torch.cat((z, torch.full_like(z[..., :1, :], float(fill))), dim=-2)
     return LatentDecodeFn.apply(z, w, b)
 
 

@@ -418,3 +418,24 @@ def test_edge_convs(shape):
     _close16(_f64(x16.grad), F.conv_transpose2d(dz.double(), w2.double(), padding=1), 'convout dx')
     assert _rel(w2d.grad.cpu().double(), torch.nn.grad.conv2d_weight(x4r, w2.shape, dz.double(), padding=1)) < 1e-5
     assert _rel(b2d.grad.cpu().double(), dz.double().sum((0, 2, 3))) < 1e-5
+
+
+def test_chunked_inference_under_autocast_tracks_fp32():
+    """transcribe() / chunked_inference() inside torch.autocast (bf16 channels-last path, what bench.py reports as
+    inference_config1.under_autocast) against the exact-fp32 calls on the same weights and audio.  The comparison is made on
+    activations and coefficients: with untrained weights the inverse transform of reconstruct() is ill-conditioned (the logits
+    are not in the range of the analysis, and decode() renormalises by the peak), so a 0.5 % coefficient difference is not a
+    0.5 % audio difference -- reconstruct() is only checked for shape and finiteness here."""
+    from timbre_trap.framework import TimbreTrap
+    torch.manual_seed(5)
+    model = TimbreTrap(sample_rate=22050, n_octaves=9, bins_per_octave=60, secs_per_block=3, latent_size=128, model_complexity=2).cuda().eval()
+    g = torch.Generator().manual_seed(9)
+    audio = (torch.rand(2, 1, 66150 + 33075, generator=g) * 2 - 1).cuda()
+    with torch.no_grad():
+        act32, c32 = model.transcribe(audio), model.chunked_inference(audio, False)
+        with torch.autocast(device_type='cuda', dtype=torch.bfloat16):
+            act16, c16, rec16 = model.transcribe(audio), model.chunked_inference(audio, False), model.reconstruct(audio)
+    assert act16.dtype == torch.float32 and act16.shape == act32.shape and c16.shape == c32.shape
+    assert float((act16 - act32).abs().max()) < 3e-2                  # activations live in [0, 1)
+    assert _rel(c16.cpu().double(), c32.cpu().double()) < 3e-2
+    assert rec16.shape == (2, 1, 2 * 66150) and bool(torch.isfinite(rec16).all())

@@ -419,6 +419,7 @@ def main():
     for _ in range(args.warmup):
         step_fn(audio, target)
     sync()
+    torch.cuda.reset_peak_memory_stats()
     C = 16 * 2 ** (args.mc - 1)
     key, key16 = 'resblock_fwd_C%d' % C, 'wide_rb_fwd_C%d' % C
     _hip.EVENT_KEYS = {key, key16, 'cqt_forward'}   # the timed region brackets only the roofline kernels
@@ -428,6 +429,7 @@ def main():
         total = step_fn(audio, target)
     sync()
     elapsed = time.perf_counter() - t0
+    peak_gb = torch.cuda.max_memory_allocated() / 1e9            # weights + optimizer + every tensor saved for backward
     events = _hip.EVENT_LOG
     _hip.EVENT_LOG = None
     rank_ms = 1000.0 * elapsed / args.steps
@@ -550,6 +552,7 @@ def main():
             for _ in range(2):
                 f_step(audio, target)
             torch.cuda.synchronize()
+            torch.cuda.reset_peak_memory_stats()
             t1 = time.perf_counter()
             for _ in range(4):
                 f_step(audio, target)
@@ -557,7 +560,7 @@ def main():
             f_ms = 1000.0 * (time.perf_counter() - t1) / 4
             ops.PRECISION = prev
             fp32_step = dict(ms_per_step=f_ms, value=args.batch * SECS_PER_CLIP / (f_ms * 1e-3), unit='audio-seconds/s', dtype='f32',
-                             steps=4, warmup=2, note='same step with ops.PRECISION = fp32 (no autocast): bit-exact fp32 MFMA path')
+                             steps=4, warmup=2, peak_memory_gb=torch.cuda.max_memory_allocated() / 1e9, note='same step with ops.PRECISION = fp32 (no autocast): bit-exact fp32 MFMA path')
         base = base0 = None
         if not args.no_cpu_baseline and not args.timed_only and world == 1:
             base = cpu_baseline(args.mc, args.latent)
@@ -572,7 +575,7 @@ def main():
                                             if args.precision == 'auto' else ''),
                                 global_batch=world * args.batch, parallelism='dp%d' % world),
                     roofline=roof, roofline_cqt=cqt, roofline_cqt_inv=cqt_inv, families=families, whole_step=whole,
-                    inference_config1=infer, fp32_train_step=fp32_step, per_rank_ms=per_rank_ms, allreduce_ms=allreduce_ms, cpu_baseline=base, cpu_baseline_config0=base0,
+                    peak_memory_gb=peak_gb, inference_config1=infer, fp32_train_step=fp32_step, per_rank_ms=per_rank_ms, allreduce_ms=allreduce_ms, cpu_baseline=base, cpu_baseline_config0=base0,
                     final_loss=float(total.detach()))
         print(json.dumps(line))
     if world > 1:

@@ -402,7 +402,7 @@ extern "C" int tt_set_cu_limit(int cus) {
     return prev;
 }
 
-extern "C" int tt_version(void) { return 2; }
+extern "C" int tt_version(void) { return 3; }   // 3: bf16 channels-last entry points (tt_wide_*, tt_sconv16_*, tt_tconv16_*, tt_latent16_*, tt_conv{in,out}16_*)
 extern "C" const char* tt_arch(void) { return "gfx950"; }
 extern "C" const char* tt_error_string(int code) {
     if (code == 0) return "ok";

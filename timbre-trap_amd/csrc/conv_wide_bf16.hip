@@ -594,7 +594,8 @@ int launch_conv(const __bf16* x, const float* w1, const float* b1, const float* 
     return 0;
 }
 
-constexpr int MAX_A_WG = 1024, MAX_W_WG = 512;    // workgroups that leave dumps (bounds the scratch)
+constexpr int MAX_A_WG = 2048, MAX_W_WG = 1024;   // workgroups that leave dumps (bounds the scratch)
+inline int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 template <int C> constexpr long dump_floats() { return (long)MAX_A_WG * WA<C>::DUMP + (long)MAX_W_WG * 4 * 9 * (C / 16) * 256; }
 
 template <int C, int D>
@@ -612,7 +613,8 @@ int launch_bwd(const __bf16* x, const __bf16* h1, const __bf16* dy, const float*
     if (int rc = raise_lds(kern, G::LDS_BYTES, once)) return rc;
     const long ngroups = (npix + 15) / 16;
     const long want = (ngroups + 3) / 4;
-    int grid = (int)(want < (long)4 * tt_cus() ? want : (long)4 * tt_cus());
+    static const int a_per_cu = env_int("TTRAP_BWDA_PER_CU", 4);
+    int grid = (int)(want < (long)a_per_cu * tt_cus() ? want : (long)a_per_cu * tt_cus());
     if (grid > MAX_A_WG) grid = MAX_A_WG;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), G::LDS_BYTES, st, h1, dy, w2, b2, da1, part_a, npix, ngroups);
     TT_LAUNCH_CHECK();
@@ -624,7 +626,8 @@ int launch_bwd(const __bf16* x, const __bf16* h1, const __bf16* dy, const float*
     auto kw = k_wrb_wgrad<C, D>;
     if (int rc = raise_lds(kw, W::LDS_BYTES, once_w)) return rc;
     const int tiles_h = (H + W::TH - 1) / W::TH, tiles_t = (T + W::TW - 1) / W::TW, ntiles = B * tiles_h * tiles_t;
-    int gw = grid_for(ntiles, W::LDS_BYTES, 2);
+    static const int w_per_cu = env_int("TTRAP_WGRAD_PER_CU", 2);
+    int gw = grid_for(ntiles, W::LDS_BYTES, w_per_cu);
     if (gw > MAX_W_WG) gw = MAX_W_WG;
     hipLaunchKernelGGL(kw, dim3(gw), dim3(NT), W::LDS_BYTES, st, x, da1, part_w, B, H, T, tiles_h, tiles_t, ntiles);
     TT_LAUNCH_CHECK();
@@ -1223,7 +1226,9 @@ int launch_nconv(const __bf16* x, const float* w1, const float* b1, const float*
     auto kern = k_nrb_conv<C, D, MODE, SAVE>;
     if (int rc = raise_lds(kern, G::LDS_BYTES, once)) return rc;
     const int tiles_h = (H + G::TH - 1) / G::TH, tiles_t = (T + G::TW - 1) / G::TW, ntiles = B * tiles_h * tiles_t;
-    hipLaunchKernelGGL(kern, dim3(grid_for(ntiles, G::LDS_BYTES, 4)), dim3(NT), G::LDS_BYTES, st, x, w1, b1, w2, b2, res, y, h1,
+    // workgroups per CU (LDS allows 5-10): 2 / 4 / 6 / 8 -> data gradient of a C = 4 block 0.25 / 0.19 / 0.165 / 0.165 ms
+    static const int per_cu = getenv("TTRAP_NARROW_PER_CU") ? atoi(getenv("TTRAP_NARROW_PER_CU")) : 6;
+    hipLaunchKernelGGL(kern, dim3(grid_for(ntiles, G::LDS_BYTES, per_cu)), dim3(NT), G::LDS_BYTES, st, x, w1, b1, w2, b2, res, y, h1,
                        B, H, T, tiles_h, tiles_t, ntiles);
     TT_LAUNCH_CHECK();
     return 0;
@@ -1239,11 +1244,12 @@ int launch_nbwd(const __bf16* x, const __bf16* h1, const __bf16* dy, const float
     __bf16* da1 = reinterpret_cast<__bf16*>(ws);
     float* part_a = reinterpret_cast<float*>(ws + ((npix * C * 2 + 255) / 256) * 256);
     float* part_w = part_a + (long)MAX_A_WG * (C * C + 2 * C);
-    // Measured per launch at the bench shapes (three kernels -> fused): C = 8: 0.545 -> 0.473 / 0.489 / 0.720 ms for dilation 1 / 2 / 3,
-    // C = 4: 0.52 -> 0.475 / 0.501 / 0.535 ms.  Half the HBM traffic buys little because the pass is then bound by its own
-    // arithmetic (pointwise chain on the halo as well, three LDS images = 2 workgroups per CU at C = 8): fused for dilation <= 2.
+    // Measured per launch at the bench shapes (three kernels -> fused): C = 8: 0.478 / 0.478 / 0.498 -> 0.445 / 0.462 / 0.707 ms for
+    // dilation 1 / 2 / 3, C = 4: 0.471 / 0.473 / 0.474 -> 0.458 / 0.487 / 0.514 ms.  Half the HBM traffic buys little because the pass is
+    // then bound by its own arithmetic (pointwise chain on the halo as well; three LDS images = 2 workgroups per CU at C = 8): fused
+    // where it wins -- C = 8 at dilation 1, 2 and C = 4 at dilation 1.
     static const int fused = getenv("TTRAP_NARROW_FUSED16") ? atoi(getenv("TTRAP_NARROW_FUSED16")) : 1;
-    if (fused == 2 || (fused == 1 && D <= 2)) {
+    if (fused == 2 || (fused == 1 && (C == 8 ? D <= 2 : D == 1))) {
         using F = NTl<C, D>;
         constexpr int LDS = 3 * F::NPR * 16;
         static AttrOnce once_f;
@@ -1262,7 +1268,8 @@ int launch_nbwd(const __bf16* x, const __bf16* h1, const __bf16* dy, const float
     }
     const long ngroups = (npix + 63) / 64;
     const long want = (ngroups + 3) / 4;
-    int grid = (int)(want < (long)4 * tt_cus() ? want : (long)4 * tt_cus());
+    static const int a_per_cu = env_int("TTRAP_BWDA_PER_CU", 4);
+    int grid = (int)(want < (long)a_per_cu * tt_cus() ? want : (long)a_per_cu * tt_cus());
     if (grid > MAX_A_WG) grid = MAX_A_WG;
     hipLaunchKernelGGL(k_nrb_bwd_a<C>, dim3(grid), dim3(NT), 0, st, h1, dy, w2, b2, da1, part_a, npix, ngroups);
     TT_LAUNCH_CHECK();
@@ -1272,7 +1279,8 @@ int launch_nbwd(const __bf16* x, const __bf16* h1, const __bf16* dy, const float
     auto kw = k_nrb_wgrad<C, D>;
     if (int rc = raise_lds(kw, W::LDS_BYTES, once_w)) return rc;
     const int tiles_h = (H + W::TH - 1) / W::TH, tiles_t = (T + W::TW - 1) / W::TW, ntiles = B * tiles_h * tiles_t;
-    int gw = grid_for(ntiles, W::LDS_BYTES, 3);
+    static const int w_per_cu = env_int("TTRAP_NWGRAD_PER_CU", 3);
+    int gw = grid_for(ntiles, W::LDS_BYTES, w_per_cu);
     if (gw > MAX_W_WG) gw = MAX_W_WG;
     hipLaunchKernelGGL(kw, dim3(gw), dim3(NT), W::LDS_BYTES, st, x, da1, part_w, B, H, T, tiles_h, tiles_t, ntiles);
     TT_LAUNCH_CHECK();

@@ -439,3 +439,31 @@ def test_chunked_inference_under_autocast_tracks_fp32():
     assert float((act16 - act32).abs().max()) < 3e-2                  # activations live in [0, 1)
     assert _rel(c16.cpu().double(), c32.cpu().double()) < 3e-2
     assert rec16.shape == (2, 1, 2 * 66150) and bool(torch.isfinite(rec16).all())
+
+
+@pytest.mark.parametrize('cus', [1, 3])
+def test_strided_latent_edge_capped_grids(cus, cu_limit):
+    """The grid-stride / persistent loops of the strided layers, latent heads and boundary convolutions with every workgroup
+    walking many groups (operand prefetch past the last group, per-workgroup partials of few workgroups)."""
+    cu_limit(cus)
+    test_sconv16_stagewise(16, (2, 13, 80))
+    test_sconv16_stagewise(4, (1, 37, 48))
+    test_tconv16_stagewise(32, (1, 17, 48), 1)
+    test_tconv16_stagewise(8, (2, 5, 80), 0)
+    test_latent_heads_stagewise(64, 129, 1, 272)
+    test_edge_convs((2, 21, 80))
+
+
+@pytest.mark.parametrize('C,d,shape', [(32, 3, (4, 65, 1024)), (16, 2, (3, 133, 1024)), (8, 1, (2, 269, 1024)), (8, 3, (2, 269, 1024)),
+                                       (4, 1, (2, 540, 1024)), (4, 3, (2, 540, 1024))])
+def test_block_at_bench_launch_shapes(C, d, shape):
+    """The bench's own heights and frame counts (full-width tiles, 500-2000 tiles per launch, uncapped persistent grids), incl. the
+    fused narrow backward at the dilations it is dispatched for."""
+    _stagewise(C, d, *shape)
+
+
+def test_strided_layers_at_bench_heights():
+    test_sconv16_stagewise(32, (2, 65, 1024))
+    test_sconv16_stagewise(4, (1, 540, 1024))
+    test_tconv16_stagewise(4, (1, 269, 1024), 0)
+    test_tconv16_stagewise(16, (2, 65, 1024), 1)

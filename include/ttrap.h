@@ -166,6 +166,14 @@ int tt_wide_rb_fwd(const void* x, const float* w1, const float* b1, const float*
 int tt_wide_rb_bwd(const void* x, const void* h1, const void* dy, const float* w1, const float* w2, const float* b2,
                    void* dx, float* dw1, float* db1, float* dw2, float* db2, void* ws, int B, int C, int H, int T,
                    int dilation, void* stream);
+/* The whole backward of one block in ONE pass from x and dy only (csrc/conv_level_bf16.hip; C = 16, 32, else
+ * TT_E_UNSUPPORTED): the hidden activation is recomputed per tile (bit-identical to what tt_wide_rb_fwd would have stored),
+ * dL/d(conv1 pre-activation) stays in LDS -- reads x and dy, writes dx.  The forward can then run with h1 = NULL.
+ * Same results as tt_wide_rb_bwd (modules.py:755-777 differentiated).  ws = tt_wide_fused_scratch_bytes(C) bytes. */
+int64_t tt_wide_fused_scratch_bytes(int C);
+int tt_wide_rb_bwd_fused(const void* x, const void* dy, const float* w1, const float* b1, const float* w2, const float* b2,
+                         void* dx, float* dw1, float* db1, float* dw2, float* db2, void* ws, int B, int C, int H, int T,
+                         int dilation, void* stream);
 
 /* bf16 channel-innermost (4,1) strided / transposed layers between the levels (csrc/conv_stride_bf16.hip): the bf16-storage
  * counterparts of tt_sconv_* / tt_tconv_* below.  x, y, dy, dx are bf16 [B][H][T][channels]; w (2C, C, 4, 1), b and their

@@ -135,6 +135,24 @@ def _stagewise(C, d, B, H, T):
     assert _rel(grads[1].cpu().double() - 0.5, dA1.sum((0, 2, 3))) < 2e-3, 'db1'
     assert _rel(grads[3].cpu().double() - 0.5, dA2.sum((0, 2, 3))) < 2e-3, 'db2'
 
+    # the one-pass backward that recomputes h1 per tile and keeps dA1 in LDS (csrc/conv_level_bf16.hip): from x and dy only
+    if C >= 16:
+        ws2 = torch.zeros(lib.tt_wide_fused_scratch_bytes(C), dtype=torch.uint8, device='cuda')
+        dxf = nhwc()
+        gf = [torch.full(s, 0.25, dtype=torch.float32, device='cuda') for s in ((C, C, 3, 3), (C,), (C, C, 1, 1), (C,))]
+        check(lib.tt_wide_rb_bwd_fused(ptr(xb), ptr(gb), ptr(w1d), ptr(b1d), ptr(w2d), ptr(b2d), ptr(dxf), ptr(gf[0]), ptr(gf[1]),
+                                       ptr(gf[2]), ptr(gf[3]), ptr(ws2), B, C, H, T, d, st), 'bwd_fused')
+        torch.cuda.synchronize()
+        _close16(_planar(dxf), dx_ref, 'dx (fused)')
+        # same arithmetic in the same order as the per-stage kernels: the stored gradient should not differ at all
+        ndiff = int((dxf != dxb).sum())
+        assert ndiff <= dxf.numel() // 1000, 'fused dx differs from the per-stage dx in %d of %d elements' % (ndiff, dxf.numel())
+        assert _rel(gf[0].cpu().double() - 0.25, dw1_ref) < 2e-4, 'dw1 (fused)'
+        assert _rel(gf[2].cpu().double().view(C, C) - 0.25, dw2_ref) < 2e-3, 'dw2 (fused)'
+        # db1 is summed from the bf16 dA1 held in LDS (the centre tap of the data gradient), not from the fp32 value
+        assert _rel(gf[1].cpu().double() - 0.25, _r16(dA1).sum((0, 2, 3))) < 2e-3, 'db1 (fused)'
+        assert _rel(gf[3].cpu().double() - 0.25, dA2.sum((0, 2, 3))) < 2e-3, 'db2 (fused)'
+
 
 @pytest.mark.parametrize('C', [4, 8, 16, 32])
 @pytest.mark.parametrize('d', [1, 2, 3])

@@ -28,7 +28,13 @@ __device__ __forceinline__ int xcd_order(int v, int n) {          // see conv_mf
     const int per = n >> 3;
     return v < (per << 3) ? (v & 7) * per + (v >> 3) : v;
 }
-__device__ __forceinline__ float elu_f(float a) { return a > 0.f ? a : (__expf(a) - 1.f); }
+// ELU and its derivative with as few vector instructions as the values allow (the bf16 kernels are bound by VALU issue:
+// PMC of round 3, profiles/r03_*): with e = exp(a) - 1 >= a everywhere, ELU(a) = a for a > 0 (a is the SMALLER of the two and
+// above 0) and e for a <= 0 (the LARGER, at most 0) = the median of (a, e, 0): one v_med3_f32 instead of compare + select.
+// ELU'(a) = min(exp(a), 1); expressed through the output h = ELU(a): min(h + 1, 1).  Bitwise the same values as the select forms.
+__device__ __forceinline__ float elu_f(float a) { return __builtin_amdgcn_fmed3f(a, __expf(a) - 1.f, 0.f); }
+__device__ __forceinline__ float elu_dpre(float a) { return __builtin_fminf(__expf(a), 1.f); }
+__device__ __forceinline__ float elu_dout(float h) { return __builtin_fminf(h + 1.f, 1.f); }
 
 // ds_read_b64_tr_b16 (gfx950 transpose read), per 16-lane group: lane 4j + q supplies the address of 4 consecutive bf16
 // (row j, columns 4q..4q+3); lane i receives column i of rows 0..3.  With rows = pixels and columns = 16 channels that is

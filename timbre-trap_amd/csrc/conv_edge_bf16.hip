@@ -17,7 +17,7 @@ constexpr int ETH = 16, ETW = 64, ERW = ETW + 2, EROWS = ETH + 2;      // tile a
 constexpr int EPLANE = EROWS * ERW;
 constexpr int NPARTW = 80;                                             // 72 weight + up to 4 bias partials, padded
 
-__device__ __forceinline__ float gatef(float dy, float y) { return dy * (y > 0.f ? 1.f : y + 1.f); }
+__device__ __forceinline__ float gatef(float dy, float y) { return dy * elu_dout(y); }
 
 struct ETile { int b, h0, t0; };
 __device__ __forceinline__ ETile etile(int v, int tiles_h, int tiles_t, int ntiles) {

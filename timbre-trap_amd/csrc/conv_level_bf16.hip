@@ -1,0 +1,463 @@
+// Fused kernels of the wide residual levels (C = 16, 32; reference modules.py:621-624, 690-693, 721-777) on bf16
+// channel-innermost tensors [B][H][T][C] for gfx950.  conv_wide_bf16.hip runs one kernel per STAGE of a block (forward;
+// pointwise chain, data gradient, weight gradient) and every stage goes through HBM.  Here:
+//
+//   k_wrb_bwd_fused<C,D,TH,TW>  the WHOLE backward of a ResidualConv2dBlock in one pass from x and dy only:
+//       phase 0  x tile with a 2D halo and dy tile with a D halo arrive by LDS-DMA (out-of-image pieces from a zero page);
+//       phase 1  on every pixel of the tile + D halo the hidden activation is RECOMPUTED (h1 = ELU(W1 (*)_D x + b1), the
+//                forward's own product order -> bit-identical to what the forward would have stored), then the pointwise
+//                chain a2 = W2 h1 + b2, dA2 = dy ELU'(a2), dh1 = W2^T dA2, dA1 = dh1 ELU'(a1); dA1 (bf16) OVERWRITES dy in
+//                LDS; db2 / dW2 over the tile's own pixels (K = pixels via the per-wave transposition buffers);
+//       phase 2  dx = dy + W1^T (*)_D dA1 (dy of the tile's own pixels re-read from L2), db1 from the centre tap, and
+//                dW1[co][ci][tap] = sum_pix dA1[co][pix] x[ci][pix + tap] by LDS transpose reads of the two images.
+//     Neither h1 nor dA1 ever exists in HBM: a block's backward reads x and dy and writes dx (3 tensors instead of 8), and the
+//     forward no longer stores h1 (2 tensors instead of 3).  The matrix pipe was under 25 % busy in every per-stage kernel, so
+//     the 18 extra products per 16 pixels (times the halo overhead of phase 1) are paid from idle issue slots.
+//
+// One LDS layout serves both access patterns: the 16-byte channel group cg of the pixel in image column `col` sits at position
+// cg ^ fswz(col).  C = 32: fswz = bit-reversed (col >> 2) & 3, so that (i) the sixteen consecutive columns a k-group reads as
+// B operand (ds_read_b128) cover all sixteen bank quads and (ii) the eight consecutive pixels one half-wave addresses in a
+// transpose read (ds_read_b64_tr_b16, 32 bytes of each) use alternating 32-byte halves, for ANY column alignment (the taps
+// shift the columns by multiples of D).  C = 16: (col >> 3) & 1.
+#include "wide_common.h"
+
+namespace {
+
+template <int C> __device__ __forceinline__ int fswz(int col) {
+    return C == 32 ? ((((col >> 2) & 1) << 1) | ((col >> 3) & 1)) : ((col >> 3) & 1);
+}
+
+// Weights in MFMA operand order, bf16, written once per call by k_lvl_wprep:
+//   [wf: NK x NCT x 64 lanes][wb: the same for the data gradient][w2a: NCT x 64][w2t: NCT x 64]     (16 bytes per lane)
+template <int C> struct WK {
+    static constexpr int NCT = C / 16;
+    static constexpr int NK = C == 32 ? 9 : 5;                   // products per co-tile: one tap (C = 32) / two taps (C = 16)
+    static constexpr int NCH = C == 32 ? 8 : 4;                  // channels a lane ends up with
+    static constexpr int W3 = NK * NCT * 64;
+    static constexpr int ENTRIES = 2 * W3 + 2 * NCT * 64;
+    static constexpr int IMG_BYTES = ENTRIES * 16;
+};
+
+template <int C>
+__global__ __launch_bounds__(64) void k_lvl_wprep(const float* __restrict__ w1, const float* __restrict__ w2, bf16x8* __restrict__ img) {
+    using K = WK<C>;
+    const int lane = threadIdx.x, n = lane & 15, g = lane >> 4, blk = blockIdx.x;
+    if (blk < K::NK * K::NCT) {
+        const int k = blk / K::NCT, ct = blk - k * K::NCT;
+        bf16x8 f, b;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int tap, kc;                                         // tap and contraction channel of this lane's k = 8 g + j
+            if (C == 32) { tap = k; kc = 8 * g + j; }
+            else { tap = 2 * k + (g >> 1); kc = 8 * (g & 1) + j; }
+            const int mo = chan_of<C>(ct, n);
+            f[j] = (__bf16)(tap < 9 ? w1[(mo * C + kc) * 9 + tap] : 0.f);
+            b[j] = (__bf16)(tap < 9 ? w1[(kc * C + mo) * 9 + (8 - tap)] : 0.f);
+        }
+        img[blk * 64 + lane] = f;
+        img[K::W3 + blk * 64 + lane] = b;
+    } else {
+#pragma unroll
+        for (int ct = 0; ct < K::NCT; ++ct) {
+            bf16x8 a, at;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float va = 0.f, vt = 0.f;
+                if (C == 32) { va = w2[chan_of<C>(ct, n) * C + 8 * g + j]; vt = w2[(8 * g + j) * C + chan_of<C>(ct, n)]; }
+                else if (j < 4) { va = w2[n * C + 4 * g + j]; vt = w2[(4 * g + j) * C + n]; }
+                a[j] = (__bf16)va; at[j] = (__bf16)vt;
+            }
+            img[2 * K::W3 + ct * 64 + lane] = a;
+            img[2 * K::W3 + K::NCT * 64 + ct * 64 + lane] = at;
+        }
+    }
+}
+
+template <int C, int D, int TH, int TW, int NW> struct FB {
+    static constexpr int NTH = NW * 64;
+    static constexpr int CG = C / 8, PB = C * 2;
+    static constexpr int XR = TH + 4 * D, XW = TW + 4 * D, GR = TH + 2 * D, GW = TW + 2 * D;
+    static constexpr int XP = XR * XW * CG, GP = GR * GW * CG;   // 16-byte pieces
+    static constexpr int XPR = (XP + NTH - 1) / NTH * NTH, GPR = (GP + NTH - 1) / NTH * NTH;
+    static constexpr int X_BYTES = XPR * 16, G_BYTES = GPR * 16;
+    static constexpr int PS = C * 2 + 8;                         // bytes per pixel of the transposition buffers (bank spread)
+    static constexpr int T_BYTES = NW * 2 * 16 * PS;
+    static constexpr int ADUMP = C * C + 2 * C;
+    static constexpr int WDUMP = 9 * (C / 16) * 256;
+    static constexpr int LDS_BYTES = X_BYTES + G_BYTES + T_BYTES;
+    static constexpr int NG1 = (GR * GW + 15) / 16;              // 16-pixel groups of phase 1 (linear over the dy / dA1 image)
+    static_assert(NW * ADUMP * 4 <= X_BYTES, "final dump reduction reuses the x image");
+    static_assert(TW % 32 == 0, "the K = 32 pixels of a weight-gradient product are 32 consecutive columns");
+};
+
+// 3x3 dilated product on one 16-pixel group: the lane's pixel has its top-left tap at image pixel (row, col); `img` is a
+// channel-innermost LDS image IW pixels wide in the fswz layout.
+template <int C, int D, int IW>
+__device__ __forceinline__ void conv_taps(const unsigned char* img, int row, int col, int g,
+                                          const bf16x8 (&A)[WK<C>::NK][WK<C>::NCT], f32x4 (&acc)[WK<C>::NCT], bf16x8& centre) {
+    constexpr int NK = WK<C>::NK, NCT = WK<C>::NCT, PB = C * 2;
+    const int gsel = C == 32 ? g : (g & 1);
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        int tap = C == 32 ? k : 2 * k + (g >> 1);
+        if (tap > 8) tap = 8;                                    // the weights of the missing tenth tap are zero
+        const int kh = tap / 3, kw = tap - 3 * kh;
+        const int xc = col + kw * D;
+        const bf16x8 bq = *reinterpret_cast<const bf16x8*>(img + ((row + kh * D) * IW + xc) * PB + 16 * (gsel ^ fswz<C>(xc)));
+        if (C == 32 && k == 4) centre = bq;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc[ct] = mma32(A[k][ct], bq, acc[ct]);
+    }
+}
+
+template <int C, int D, int TH, int TW, int NW>
+__global__ __launch_bounds__(NW * 64, C == 32 ? 2 : 3) void k_wrb_bwd_fused(const __bf16* __restrict__ x, const __bf16* __restrict__ dy,
+                                                              const bf16x8* __restrict__ wimg, const float* __restrict__ b1,
+                                                              const float* __restrict__ b2, __bf16* __restrict__ dx,
+                                                              float* __restrict__ part_a, float* __restrict__ part_w, int B, int H,
+                                                              int T, int tiles_h, int tiles_t, int ntiles) {
+    using G = FB<C, D, TH, TW, NW>;
+    using K = WK<C>;
+    constexpr int NCT = K::NCT, NK = K::NK, NCH = K::NCH, PB = G::PB;
+    typedef typename std::conditional<C == 32, bf16x8, bf16x4>::type vec_t;     // a lane's channels of one pixel
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char* xs = smem;
+    unsigned char* gs = smem + G::X_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4, trj = n >> 2, trq = n & 3;
+    unsigned char* tg = smem + G::X_BYTES + G::G_BYTES + wave * (2 * 16 * G::PS);   // this wave's dA2 tile, then its h1 tile
+    unsigned char* thh = tg + 16 * G::PS;
+    // the lane's own channels NCH g .. NCH g + NCH - 1 of a pixel: 16-byte piece and byte inside it
+    const int opiece = C == 32 ? g : (g >> 1), obyte = C == 32 ? 0 : 8 * (g & 1);
+
+    // weight-gradient roles.  C = 32: wave = (ci-tile wave & 1, co-tile wave >> 1), every wave walks all rows and 32-column
+    // chunks (ONE co-tile of accumulators per wave: 36 VGPRs instead of 72 -- the 3x3 weights of a phase are 72 more);
+    // C = 16: the waves split the 32-column chunks, then the rows.
+    static_assert(C == 16 || NW == 4, "C = 32 roles need exactly four waves");
+    constexpr int NCHK = TW / 32;
+    static_assert(C == 32 || (NW % NCHK == 0), "wave roles");
+    const int cit = C == 32 ? (wave & 1) : 0, aw = C == 32 ? (wave >> 1) : 0;
+    const int ch0 = C == 32 ? 0 : wave % NCHK, rpar = C == 32 ? 0 : wave / NCHK;
+    constexpr int CHSTEP = C == 32 ? 1 : NCHK, RSTEP = C == 32 ? 1 : NW / NCHK;
+
+    f32x4 wacc[9], dw2[NCT][NCT];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wacc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < NCT; ++a)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) dw2[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float db1a[NCH], db2a[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) { db1a[j] = 0.f; db2a[j] = 0.f; }
+    vec_t zero_v;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) zero_v[j] = (__bf16)0.f;
+
+    const __bf16* zero = reinterpret_cast<const __bf16*>(&g_wzero16);
+    for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
+        int tile = xcd_order(v, ntiles);
+        const int tt = tile % tiles_t; tile /= tiles_t;
+        const int th = tile % tiles_h;
+        const int b = tile / tiles_h, h0 = th * TH, t0 = tt * TW;
+        const __bf16* xb = x + (long)b * H * T * C;
+        const __bf16* gb = dy + (long)b * H * T * C;
+
+        __syncthreads();                                         // the previous tile has been consumed
+        for (int i = wave * 64; i < G::XPR; i += G::NTH) {
+            const int p = i + lane, q = p / G::CG, s = p - q * G::CG;
+            const int row = q / G::XW, px = q - row * G::XW;
+            const int h = h0 - 2 * D + row, t = t0 - 2 * D + px;
+            const bool ok = p < G::XP && (unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T;
+            glds16(ok ? xb + ((long)h * T + t) * C + (s ^ fswz<C>(px)) * 8 : zero, xs + (long)i * 16);
+        }
+        for (int i = wave * 64; i < G::GPR; i += G::NTH) {
+            const int p = i + lane, q = p / G::CG, s = p - q * G::CG;
+            const int row = q / G::GW, px = q - row * G::GW;
+            const int h = h0 - D + row, t = t0 - D + px;
+            const bool ok = p < G::GP && (unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T;
+            glds16(ok ? gb + ((long)h * T + t) * C + (s ^ fswz<C>(px)) * 8 : zero, gs + (long)i * 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        // The weights of each phase are (re)loaded per tile through laundered pointers so that their registers are free in
+        // the other phase (72 VGPRs per orientation at C = 32 beside 72 of weight-gradient accumulators).
+        const bf16x8* wp = wimg;
+        const float* b1p = b1;
+        const float* b2p = b2;
+        asm volatile("" : "+s"(wp), "+s"(b1p), "+s"(b2p));
+
+        // ---- phase 1: h1 recomputed, pointwise chain, dA1 over dy in LDS; db2 / dW2 over the tile's own pixels ----
+        {
+            bf16x8 A[NK][NCT];
+#pragma unroll
+            for (int k = 0; k < NK; ++k)
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) A[k][ct] = wp[(k * NCT + ct) * 64 + lane];
+            bf16x8 A2[NCT], A2T[NCT];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                A2[ct] = wp[2 * K::W3 + ct * 64 + lane];
+                A2T[ct] = wp[2 * K::W3 + NCT * 64 + ct * 64 + lane];
+            }
+            const s16x4 A2s = __builtin_bit_cast(s16x4, __builtin_shufflevector(A2[0], A2[0], 0, 1, 2, 3));      // C = 16: K = 16
+            const s16x4 A2Ts = __builtin_bit_cast(s16x4, __builtin_shufflevector(A2T[0], A2T[0], 0, 1, 2, 3));
+            float b1r[NCH], b2r[NCH];
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) { b1r[j] = b1p[NCH * g + j]; b2r[j] = b2p[NCH * g + j]; }
+
+            for (int grp = wave; grp < G::NG1; grp += NW) {
+                const int q = grp * 16 + n;
+                const bool inq = q < G::GR * G::GW;
+                const int qq = inq ? q : G::GR * G::GW - 1;
+                const int row = qq / G::GW, col = qq - row * G::GW;
+                const bool core = inq && row >= D && row < D + TH && col >= D && col < D + TW;
+                f32x4 acc[NCT];                                  // biases enter as the accumulators' initial values
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{b1r[4 * ct], b1r[4 * ct + 1], b1r[4 * ct + 2], b1r[4 * ct + 3]};
+                bf16x8 unused;
+                conv_taps<C, D, G::XW>(xs, row, col, g, A, acc, unused);
+                unsigned char* gp = gs + (row * G::GW + col) * PB + 16 * (opiece ^ fswz<C>(col)) + obyte;
+                const vec_t dq = *reinterpret_cast<const vec_t*>(gp);
+                vec_t hq;
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) hq[j] = (__bf16)elu_f(acc[j >> 2][j & 3]);
+                float hv[NCH], gv[NCH];
+                vec_t gq, aq;
+                f32x4 z[NCT], u[NCT];
+                if constexpr (C == 32) {
+                    z[0] = mma32(A2[0], hq, f32x4{b2r[0], b2r[1], b2r[2], b2r[3]});
+                    z[1] = mma32(A2[1], hq, f32x4{b2r[4], b2r[5], b2r[6], b2r[7]});
+                } else {
+                    z[0] = mma16(A2s, __builtin_bit_cast(s16x4, hq), f32x4{b2r[0], b2r[1], b2r[2], b2r[3]});
+                }
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) {
+                    const float a2 = z[j >> 2][j & 3];
+                    gv[j] = (float)dq[j] * elu_dpre(a2);
+                    gq[j] = (__bf16)gv[j];
+                    hv[j] = (float)hq[j];
+                }
+                if constexpr (C == 32) {
+                    u[0] = mma32(A2T[0], gq, f32x4{0.f, 0.f, 0.f, 0.f});
+                    u[1] = mma32(A2T[1], gq, f32x4{0.f, 0.f, 0.f, 0.f});
+                } else {
+                    u[0] = mma16(A2Ts, __builtin_bit_cast(s16x4, gq), f32x4{0.f, 0.f, 0.f, 0.f});
+                }
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) aq[j] = (__bf16)(u[j >> 2][j & 3] * elu_dout(hv[j]));
+                if (inq) *reinterpret_cast<vec_t*>(gp) = aq;
+                // sums over the tile's own pixels only (halo pixels belong to the neighbours; out-of-image ones are zero)
+                const vec_t gm = core ? gq : zero_v;
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) db2a[j] += core ? gv[j] : 0.f;
+                if constexpr (C == 32) {
+                    const uint2* s1 = reinterpret_cast<const uint2*>(&gm);
+                    const uint2* s2 = reinterpret_cast<const uint2*>(&hq);
+                    uint2* d1 = reinterpret_cast<uint2*>(tg + n * G::PS + 16 * g);
+                    uint2* d2 = reinterpret_cast<uint2*>(thh + n * G::PS + 16 * g);
+                    d1[0] = s1[0]; d1[1] = s1[1]; d2[0] = s2[0]; d2[1] = s2[1];
+                } else {
+                    *reinterpret_cast<uint2*>(tg + n * G::PS + 8 * g) = __builtin_bit_cast(uint2, gm);
+                    *reinterpret_cast<uint2*>(thh + n * G::PS + 8 * g) = __builtin_bit_cast(uint2, hq);
+                }
+                // dW2[co][ci] += sum over the 16 pixels dA2[co][p] h1[ci][p]: the tiles read back transposed (the same wave
+                // wrote them: LDS operations of one wave complete in order; the fences only stop the compiler)
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("" ::: "memory");
+                s16x4 ga[NCT], hb[NCT];
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    ga[ct] = lds_tr16(tg + (4 * g + trj) * G::PS + (16 * ct + 4 * trq) * 2);
+                    hb[ct] = lds_tr16(thh + (4 * g + trj) * G::PS + (16 * ct + 4 * trq) * 2);
+                }
+#pragma unroll
+                for (int a = 0; a < NCT; ++a)
+#pragma unroll
+                    for (int c = 0; c < NCT; ++c) dw2[a][c] = mma16(ga[a], hb[c], dw2[a][c]);
+                asm volatile("" ::: "memory");
+            }
+        }
+        __syncthreads();
+
+        // ---- phase 2a: dx = dy + W1^T (*) dA1 over the tile's own pixels; db1 from the centre tap ----
+        {
+            bf16x8 A[NK][NCT];
+#pragma unroll
+            for (int k = 0; k < NK; ++k)
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) A[k][ct] = wp[K::W3 + (k * NCT + ct) * 64 + lane];
+            constexpr int GPRW = TW / 16;
+            for (int grp = wave; grp < TH * GPRW; grp += NW) {
+                const int r = grp / GPRW, c = (grp - r * GPRW) * 16 + n;
+                const int h = h0 + r;
+                if (h >= H) break;
+                const int t = t0 + c;
+                const bool valid = t < T;
+                const long pix = ((long)b * H + h) * T + t;
+                // unconditional (clamped) so that no branch pins a wait in front of the products
+                const vec_t rq = *reinterpret_cast<const vec_t*>(dy + (valid ? pix : pix - (t - (T - 1))) * C + NCH * g);
+                f32x4 acc[NCT];
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+                bf16x8 centre;
+                conv_taps<C, D, G::GW>(gs, r, c, g, A, acc, centre);
+                vec_t cen;
+                if constexpr (C == 32) cen = centre;
+                else cen = *reinterpret_cast<const vec_t*>(gs + ((r + D) * G::GW + c + D) * PB + 16 * (opiece ^ fswz<C>(c + D)) + obyte);
+                vec_t o;
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) {
+                    db1a[j] += (float)cen[j];                    // out-of-image pixels hold zeros
+                    o[j] = (__bf16)(acc[j >> 2][j & 3] + (float)rq[j]);
+                }
+                if (valid) *reinterpret_cast<vec_t*>(dx + pix * C + NCH * g) = o;
+            }
+        }
+
+        // ---- phase 2b: dW1, K = pixels: 32 consecutive columns of a row per product, both operands by transpose reads ----
+        for (int r = rpar; r < TH; r += RSTEP) {
+            if (h0 + r >= H) break;
+#pragma unroll
+            for (int ch = ch0; ch < NCHK; ch += CHSTEP) {
+                s16x4 lo, hi;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int cc = D + ch * 32 + 4 * g + trj + 16 * u;
+                    const s16x4 t4 = lds_tr16(gs + ((r + D) * G::GW + cc) * PB +
+                                              16 * (((C == 32 ? 2 * aw : 0) + (trq >> 1)) ^ fswz<C>(cc)) + 8 * (trq & 1));
+                    if (u == 0) lo = t4; else hi = t4;
+                }
+                const bf16x8 ga = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const int kh = k / 3, kw = k - 3 * kh;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int xc = D + kw * D + ch * 32 + 4 * g + trj + 16 * u;
+                        const s16x4 t4 = lds_tr16(xs + ((r + D + kh * D) * G::XW + xc) * PB +
+                                                  16 * (((C == 32 ? 2 * cit : 0) + (trq >> 1)) ^ fswz<C>(xc)) + 8 * (trq & 1));
+                        if (u == 0) lo = t4; else hi = t4;
+                    }
+                    const bf16x8 xq = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                    wacc[k] = mma32(ga, xq, wacc[k]);
+                }
+            }
+        }
+    }
+
+    // ---- dumps: the weight-gradient accumulators per wave, everything else summed over the waves through LDS ----
+    float* pw = part_w + ((long)blockIdx.x * NW + wave) * G::WDUMP;
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pw[((k * NCT + aw) * 4 + r) * 64 + lane] = wacc[k][r];   // C = 32: the other co-tile's slots stay unwritten (and unread)
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem) + wave * G::ADUMP;
+#pragma unroll
+    for (int a = 0; a < NCT; ++a)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[((a * NCT + c) * 4 + r) * 64 + lane] = dw2[a][c][r];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        float s1 = db1a[j], s2 = db2a[j];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        if (n == 0) { red[C * C + NCH * g + j] = s1; red[C * C + C + NCH * g + j] = s2; }
+    }
+    __syncthreads();
+    const float* all = reinterpret_cast<const float*>(smem);
+    float* pa = part_a + (long)blockIdx.x * G::ADUMP;
+    for (int i = tid; i < G::ADUMP; i += G::NTH) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s += all[w * G::ADUMP + i];
+        pa[i] = s;
+    }
+}
+
+// ---- launchers -------------------------------------------------------------------------------------------------------
+template <int C> constexpr long fused_scratch_bytes() {
+    return (long)WK<C>::IMG_BYTES + ((long)MAX_W_WG * (C * C + 2 * C) + (long)MAX_W_WG * 4 * 9 * (C / 16) * 256) * 4;
+}
+
+template <int C, int D, int TH, int TW>
+int launch_fused(const __bf16* x, const __bf16* dy, const float* w1, const float* b1, const float* w2, const float* b2, __bf16* dx,
+                 float* dw1, float* db1, float* dw2, float* db2, unsigned char* ws, int B, int H, int T, hipStream_t st) {
+    constexpr int NW = 4;
+    using G = FB<C, D, TH, TW, NW>;
+    using K = WK<C>;
+    bf16x8* wimg = reinterpret_cast<bf16x8*>(ws);
+    float* part_a = reinterpret_cast<float*>(ws + K::IMG_BYTES);
+    float* part_w = part_a + (long)MAX_W_WG * G::ADUMP;
+    hipLaunchKernelGGL(k_lvl_wprep<C>, dim3(K::NK * K::NCT + 1), dim3(64), 0, st, w1, w2, wimg);
+    TT_LAUNCH_CHECK();
+    static AttrOnce once;
+    auto kern = k_wrb_bwd_fused<C, D, TH, TW, NW>;
+    if (int rc = raise_lds(kern, G::LDS_BYTES, once)) return rc;
+    const int tiles_h = (H + TH - 1) / TH, tiles_t = (T + TW - 1) / TW, ntiles = B * tiles_h * tiles_t;
+    static const int per_cu = env_int("TTRAP_FBWD_PER_CU", C == 32 ? 2 : 3);        // registers: 2 waves per SIMD at C = 32, 3 at C = 16
+    int grid = grid_for(ntiles, G::LDS_BYTES, per_cu);
+    if (grid > MAX_W_WG) grid = MAX_W_WG;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), G::LDS_BYTES, st, x, dy, wimg, b1, b2, dx, part_a, part_w, B, H, T, tiles_h,
+                       tiles_t, ntiles);
+    TT_LAUNCH_CHECK();
+    RedArgs ra{part_w, grid, part_a, grid, dw1, db1, dw2, db2, C == 32 ? 1 : 0};
+    constexpr int total = 9 * C * C + C * C + 2 * C;
+    hipLaunchKernelGGL(k_wrb_reduce<C>, dim3((total + REL - 1) / REL), dim3(1024), 0, st, ra);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
+// Tile shapes (TTRAP_FBWD_TILE = 0 / 1 selects the alternative set, for tuning):
+//   LDS per workgroup = x image (TH + 4D)(TW + 4D) + dy/dA1 image (TH + 2D)(TW + 2D) pixels of 2C bytes + transposition buffers.
+template <int C>
+int fused_c(const __bf16* x, const __bf16* dy, const float* w1, const float* b1, const float* w2, const float* b2, __bf16* dx,
+            float* dw1, float* db1, float* dw2, float* db2, unsigned char* ws, int B, int H, int T, int D, hipStream_t st) {
+    static const int alt = env_int("TTRAP_FBWD_TILE", 0);
+#define TT_FB(DD, TH_, TW_) return launch_fused<C, DD, TH_, TW_>(x, dy, w1, b1, w2, b2, dx, dw1, db1, dw2, db2, ws, B, H, T, st)
+    if constexpr (C == 32) {
+        switch (D) {
+            case 1: if (alt) TT_FB(1, 8, 64); TT_FB(1, 8, 32);
+            case 2: if (alt) TT_FB(2, 8, 64); TT_FB(2, 8, 32);
+            case 3: if (alt) TT_FB(3, 4, 32); TT_FB(3, 8, 32);
+        }
+    } else {
+        switch (D) {
+            case 1: if (alt) TT_FB(1, 8, 32); TT_FB(1, 8, 64);
+            case 2: if (alt) TT_FB(2, 8, 32); TT_FB(2, 8, 64);
+            case 3: if (alt) TT_FB(3, 4, 64); TT_FB(3, 8, 32);
+        }
+    }
+#undef TT_FB
+    return TT_E_UNSUPPORTED;
+}
+
+inline bool fshape_ok(int B, int C, int H, int T) {
+    return B > 0 && H > 0 && T > 0 && (C == 16 || C == 32) && (long)H * T * C < (1l << 31);
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t tt_wide_fused_scratch_bytes(int C) {
+    return C == 16 ? fused_scratch_bytes<16>() : C == 32 ? fused_scratch_bytes<32>() : -1;
+}
+
+int tt_wide_rb_bwd_fused(const void* x, const void* dy, const float* w1, const float* b1, const float* w2, const float* b2, void* dx,
+                         float* dw1, float* db1, float* dw2, float* db2, void* ws, int B, int C, int H, int T, int dilation,
+                         void* stream) {
+    if (!x || !dy || !w1 || !b1 || !w2 || !b2 || !dx || !dw1 || !db1 || !dw2 || !db2 || !ws) return TT_E_BADARG;
+    if (C != 16 && C != 32) return TT_E_UNSUPPORTED;
+    if (!fshape_ok(B, C, H, T)) return TT_E_BADARG;
+    const __bf16 *xi = (const __bf16*)x, *gi = (const __bf16*)dy;
+    hipStream_t st = tt_stream(stream);
+    if (C == 16) return fused_c<16>(xi, gi, w1, b1, w2, b2, (__bf16*)dx, dw1, db1, dw2, db2, (unsigned char*)ws, B, H, T, dilation, st);
+    return fused_c<32>(xi, gi, w1, b1, w2, b2, (__bf16*)dx, dw1, db1, dw2, db2, (unsigned char*)ws, B, H, T, dilation, st);
+}
+
+}  // extern "C"

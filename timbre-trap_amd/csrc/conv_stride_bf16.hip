@@ -17,7 +17,7 @@
 
 namespace {
 
-__device__ __forceinline__ float gate_f(float dy, float y) { return dy * (y > 0.f ? 1.f : y + 1.f); }
+__device__ __forceinline__ float gate_f(float dy, float y) { return dy * elu_dout(y); }
 
 // number of 16-row output tiles and of channels a lane ends up with, for COUT output channels
 template <int COUT> struct OutT {
@@ -490,8 +490,12 @@ __device__ __forceinline__ void stage_tile(unsigned char* lds, const __bf16* src
     }
 }
 
+// Register caps measured as a whole-library A/B (round 3, tools/build_variant.sh): capping the residual / strided kernels that sit at
+// 1-2 waves per SIMD to 3-4 changed nothing or lost (spills), except here: C = 32 with the gated SMALL operand drops from 400 to
+// 254 registers without a spill and two waves per SIMD (sconv backward at the bench shape 0.516 -> 0.456 ms); the gated-big form
+// spills at that cap (0.522 -> 0.662 ms) and keeps its own allocation.
 template <int C, bool GS>
-__global__ __launch_bounds__(NT) void k_w4(const __bf16* __restrict__ small, const __bf16* __restrict__ big,
+__global__ __launch_bounds__(NT, (C == 32 && GS) ? 2 : 1) void k_w4(const __bf16* __restrict__ small, const __bf16* __restrict__ big,
                                             const __bf16* __restrict__ ygate, float* __restrict__ part, float* __restrict__ dbpart,
                                             int B, int Hs, int Hb, int T, int tiles_h, int tiles_t, int ntiles) {
     using G = W4<C>;

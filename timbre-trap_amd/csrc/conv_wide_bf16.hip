@@ -22,13 +22,9 @@
 //   k_wrb_wgrad<C,D>               dW1[co][ci][tap] = sum_pix dA1[co][pix] x[ci][pix + tap]: K = pixels, both operands by
 //                                  LDS transpose reads (ds_read_b64_tr_b16) from channel-innermost images
 //   k_wrb_reduce<C>                sums the per-wave register dumps into the fp32 gradients (+=), no atomics anywhere
-#include "bf16_common.h"
+#include "wide_common.h"
 
 namespace {
-
-// Channel held by row m of co-tile ct.  C = 32: rows 4q..4q+3 of tile 0 / 1 are channels 8q..8q+3 / 8q+4..8q+7, so the
-// lane that owns D rows 4g..4g+3 of both tiles owns the eight CONSECUTIVE channels 8g..8g+7 (16 bytes).  C = 16: identity.
-template <int C> __device__ __forceinline__ int chan_of(int ct, int m) { return C == 32 ? 8 * (m >> 2) + 4 * ct + (m & 3) : m; }
 
 // ---- layout change at the ends of a level --------------------------------------------------------------------------
 // One thread per 16-byte piece: eight channels of one pixel (C >= 8) or two whole pixels (C = 4; T even keeps a pair inside
@@ -89,8 +85,10 @@ template <int C, int D> struct WT {
 };
 
 // MODE 0: x -> y (and h1 if SAVE).  MODE 1: x = dA1, res = dy, y = dx; b1 / w2 / b2 unused.
-template <int C, int D, int MODE, bool SAVE>
-__global__ __launch_bounds__(NT, 2) void k_wrb_conv(const __bf16* __restrict__ x, const float* __restrict__ w1,
+// MINW = waves per SIMD the register allocation must allow: at C = 32 the forward holds 72 + 8 VGPRs of weights and lands
+// at 172-176 registers -- two workgroups per CU -- unless capped at 168 (MINW = 3: four registers spill to scratch).
+template <int C, int D, int MODE, bool SAVE, int MINW>
+__global__ __launch_bounds__(NT, MINW) void k_wrb_conv(const __bf16* __restrict__ x, const float* __restrict__ w1,
                                                  const float* __restrict__ b1, const float* __restrict__ w2,
                                                  const float* __restrict__ b2, const __bf16* __restrict__ res,
                                                  __bf16* __restrict__ y, __bf16* __restrict__ h1, int B, int H, int T,
@@ -169,9 +167,12 @@ __global__ __launch_bounds__(NT, 2) void k_wrb_conv(const __bf16* __restrict__ x
             if (h >= H) break;
             const long pix = ((long)b * H + h) * T + t;
             const bool valid = t < T;
-            f32x4 acc[NCT];
+            f32x4 acc[NCT];                                      // the bias enters as the accumulator's initial value
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int ct = 0; ct < NCT; ++ct) {
+                if constexpr (MODE == 0) acc[ct] = f32x4{b1r[4 * ct], b1r[4 * ct + 1], b1r[4 * ct + 2], b1r[4 * ct + 3]};
+                else acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
             typename std::conditional<C == 32, bf16x8, bf16x4>::type rq;      // MODE 1: dy of this pixel, requested early
             if constexpr (MODE == 1)            // unconditional (clamped) so that no branch pins a wait in front of the products
                 rq = *reinterpret_cast<const decltype(rq)*>(res + (valid ? pix : pix - (t - (T - 1))) * C + NCH * g);
@@ -212,19 +213,19 @@ __global__ __launch_bounds__(NT, 2) void k_wrb_conv(const __bf16* __restrict__ x
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < NCH; ++j) val[j] = elu_f(val[j] + b1r[j]);
+                for (int j = 0; j < NCH; ++j) val[j] = elu_f(val[j]);
                 if constexpr (C == 32) {
                     bf16x8 hq;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) hq[j] = (__bf16)val[j];
                     if (SAVE && valid) *reinterpret_cast<bf16x8*>(h1 + pix * C + 8 * g) = hq;
-                    f32x4 z0 = mma32(A2[0], hq, f32x4{0.f, 0.f, 0.f, 0.f});
-                    f32x4 z1 = mma32(A2[1], hq, f32x4{0.f, 0.f, 0.f, 0.f});
+                    f32x4 z0 = mma32(A2[0], hq, f32x4{b2r[0], b2r[1], b2r[2], b2r[3]});
+                    f32x4 z1 = mma32(A2[1], hq, f32x4{b2r[4], b2r[5], b2r[6], b2r[7]});
                     bf16x8 o;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        o[j] = (__bf16)(elu_f(z0[j] + b2r[j]) + (float)centre[j]);
-                        o[4 + j] = (__bf16)(elu_f(z1[j] + b2r[4 + j]) + (float)centre[4 + j]);
+                        o[j] = (__bf16)(elu_f(z0[j]) + (float)centre[j]);
+                        o[4 + j] = (__bf16)(elu_f(z1[j]) + (float)centre[4 + j]);
                     }
                     if (valid) *reinterpret_cast<bf16x8*>(y + pix * C + 8 * g) = o;
                 } else {
@@ -232,12 +233,12 @@ __global__ __launch_bounds__(NT, 2) void k_wrb_conv(const __bf16* __restrict__ x
 #pragma unroll
                     for (int j = 0; j < 4; ++j) hq[j] = (__bf16)val[j];
                     if (SAVE && valid) *reinterpret_cast<bf16x4*>(h1 + pix * C + 4 * g) = hq;
-                    const f32x4 z = mma16(A2s, __builtin_bit_cast(s16x4, hq), f32x4{0.f, 0.f, 0.f, 0.f});
+                    const f32x4 z = mma16(A2s, __builtin_bit_cast(s16x4, hq), f32x4{b2r[0], b2r[1], b2r[2], b2r[3]});
                     const int colc = c0 + n + D, pxc = (r + D) * G::RW + colc;
                     const bf16x4 xc = *reinterpret_cast<const bf16x4*>(smem + ((long)pxc * C + 8 * ((g >> 1) ^ cswz<C>(colc)) + 4 * (g & 1)) * 2);
                     bf16x4 o;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (__bf16)(elu_f(z[j] + b2r[j]) + (float)xc[j]);
+                    for (int j = 0; j < 4; ++j) o[j] = (__bf16)(elu_f(z[j]) + (float)xc[j]);
                     if (valid) *reinterpret_cast<bf16x4*>(y + pix * C + 4 * g) = o;
                 }
             }
@@ -323,15 +324,15 @@ __global__ __launch_bounds__(NT) void k_wrb_bwd_a(const __bf16* __restrict__ h1,
         vec_t gq, aq;
         f32x4 z[NCT], u[NCT];
         if constexpr (C == 32) {
-            z[0] = mma32(A2[0], hq, f32x4{0.f, 0.f, 0.f, 0.f});
-            z[1] = mma32(A2[1], hq, f32x4{0.f, 0.f, 0.f, 0.f});
+            z[0] = mma32(A2[0], hq, f32x4{b2r[0], b2r[1], b2r[2], b2r[3]});
+            z[1] = mma32(A2[1], hq, f32x4{b2r[4], b2r[5], b2r[6], b2r[7]});
         } else {
-            z[0] = mma16(A2s, __builtin_bit_cast(s16x4, hq), f32x4{0.f, 0.f, 0.f, 0.f});
+            z[0] = mma16(A2s, __builtin_bit_cast(s16x4, hq), f32x4{b2r[0], b2r[1], b2r[2], b2r[3]});
         }
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
-            const float a2 = z[j >> 2][j & 3] + b2r[j];
-            gv[j] = (float)dq[j] * (a2 > 0.f ? 1.f : __expf(a2));
+            const float a2 = z[j >> 2][j & 3];
+            gv[j] = (float)dq[j] * elu_dpre(a2);
             gq[j] = (__bf16)gv[j];
             hv[j] = (float)hq[j];
         }
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(NT) void k_wrb_bwd_a(const __bf16* __restrict__ h1,
         }
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
-            a1g[j] = u[j >> 2][j & 3] * (hv[j] > 0.f ? 1.f : hv[j] + 1.f);
+            a1g[j] = u[j >> 2][j & 3] * elu_dout(hv[j]);
             aq[j] = (__bf16)a1g[j];
             db2a[j] += gv[j]; db1a[j] += a1g[j];                  // invalid pixels contribute zeros
         }
@@ -513,89 +514,35 @@ __global__ __launch_bounds__(NT) void k_wrb_wgrad(const __bf16* __restrict__ x, 
             for (int r = 0; r < 4; ++r) pw[((k * NA + a) * 4 + r) * 64 + lane] = acc[k][a][r];
 }
 
-// Sum of the register dumps into the fp32 gradients (+=).  1024 threads = REL consecutive dump elements x RSL slices of the
-// contributing waves (bf16_common.h); the dump order keeps the loads coalesced, the scatter into dW1 / dW2 is the cheap side.
-struct RedArgs {
-    const float* pw; int gw;        // wgrad dumps: gw workgroups x 4 waves
-    const float* pa; int ga;        // bwd_a dumps: one per workgroup
-    float *dw1, *db1, *dw2, *db2;
-};
-template <int C>
-__global__ __launch_bounds__(1024) void k_wrb_reduce(RedArgs ar) {
-    constexpr int NCT = C / 16;
-    constexpr int WDUMP = 9 * NCT * 256, NEW = NCT * WDUMP;      // wgrad: elements = (wave role) x dump
-    constexpr int ADUMP = C * C + 2 * C;
-    __shared__ float red[RSL][REL];
-    const int el = threadIdx.x % REL, sl = threadIdx.x / REL;
-    const int e = blockIdx.x * REL + el;
-    float sum = 0.f;
-    float* dst = nullptr;
-    if (e < NEW) {
-        const int role = e / WDUMP, rest = e - role * WDUMP;     // C = 32: role = ci-tile = wave & 1;  C = 16: one role
-        constexpr int NS = 4 / NCT;                              // waves per workgroup with the same role
-        const int ncontrib = ar.gw * NS;
-        float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // eight loads in flight per thread
-        for (int j0 = sl; j0 < ncontrib; j0 += 8 * RSL) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int j = j0 + RSL * u;
-                if (j < ncontrib) {
-                    const int wg = j / NS, s = j - wg * NS;
-                    const int wave = C == 32 ? role + 2 * s : s;
-                    part[u] += ar.pw[((long)wg * 4 + wave) * WDUMP + rest];
-                }
-            }
-        }
-        sum = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
-        const int k = rest / (NCT * 256), a = (rest >> 8) % NCT, r = (rest >> 6) & 3, lane = rest & 63;
-        const int co = 16 * a + 4 * (lane >> 4) + r, ci = 16 * role + (lane & 15);
-        dst = ar.dw1 + (co * C + ci) * 9 + k;
-    } else if (e < NEW + ADUMP) {
-        const int q = e - NEW;
-        const int ncontrib = ar.ga;
-        float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int j0 = sl; j0 < ncontrib; j0 += 8 * RSL) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int j = j0 + RSL * u;
-                if (j < ncontrib) part[u] += ar.pa[(long)j * ADUMP + q];
-            }
-        }
-        sum = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
-        if (q < C * C) {
-            const int a = q / (NCT * 256), c = (q >> 8) % NCT, r = (q >> 6) & 3, lane = q & 63;
-            dst = ar.dw2 + (16 * a + 4 * (lane >> 4) + r) * C + 16 * c + (lane & 15);
-        } else if (q < C * C + C) dst = ar.db1 + (q - C * C);
-        else dst = ar.db2 + (q - C * C - C);
-    }
-    red[sl][el] = sum;
-    __syncthreads();
-    if (sl == 0 && dst) {
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < RSL; ++i) s += red[i][el];
-        *dst += s;
-    }
-}
-
 // ---- launchers -------------------------------------------------------------------------------------------------------
 template <int C, int D, int MODE, bool SAVE>
 int launch_conv(const __bf16* x, const float* w1, const float* b1, const float* w2, const float* b2, const __bf16* res,
                 __bf16* y, __bf16* h1, int B, int H, int T, hipStream_t st) {
     using G = WT<C, D>;
-    static AttrOnce once;
-    auto kern = k_wrb_conv<C, D, MODE, SAVE>;
-    if (int rc = raise_lds(kern, G::LDS_BYTES, once)) return rc;
     const int tiles_h = (H + G::TH - 1) / G::TH, tiles_t = (T + G::TW - 1) / G::TW, ntiles = B * tiles_h * tiles_t;
     static const int per_cu = getenv("TTRAP_WIDE_PER_CU") ? atoi(getenv("TTRAP_WIDE_PER_CU")) : 4;
-    hipLaunchKernelGGL(kern, dim3(grid_for(ntiles, G::LDS_BYTES, per_cu)), dim3(NT), G::LDS_BYTES, st, x, w1, b1, w2, b2, res, y, h1,
+    static const int w3 = env_int("TTRAP_WCONV_W3", 0);
+    if (C == 32 && MODE == 0 && w3) {
+        static AttrOnce once3;
+        auto kern = k_wrb_conv<C, D, MODE, SAVE, (C == 32 && MODE == 0) ? 3 : 2>;
+        if (int rc = raise_lds(kern, G::LDS_BYTES, once3)) return rc;
+        hipLaunchKernelGGL(kern, dim3(grid_for(ntiles, G::LDS_BYTES, per_cu)), dim3(NT), G::LDS_BYTES, st, x, w1, b1, w2, b2, res, y,
+                           h1, B, H, T, tiles_h, tiles_t, ntiles);
+        TT_LAUNCH_CHECK();
+        return 0;
+    }
+    static AttrOnce once;
+    auto kern = k_wrb_conv<C, D, MODE, SAVE, 2>;
+    if (int rc = raise_lds(kern, G::LDS_BYTES, once)) return rc;
+    // registers admit two workgroups per CU at C = 32 (forward) whatever the LDS would hold: do not launch a third that only runs
+    // after the first two have finished (a tail on a third of the chip)
+    const int cap = (C == 32 && MODE == 0 && per_cu > 2) ? 2 : per_cu;
+    hipLaunchKernelGGL(kern, dim3(grid_for(ntiles, G::LDS_BYTES, cap)), dim3(NT), G::LDS_BYTES, st, x, w1, b1, w2, b2, res, y, h1,
                        B, H, T, tiles_h, tiles_t, ntiles);
     TT_LAUNCH_CHECK();
     return 0;
 }
 
-constexpr int MAX_A_WG = 2048, MAX_W_WG = 1024;   // workgroups that leave dumps (bounds the scratch)
-inline int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 template <int C> constexpr long dump_floats() { return (long)MAX_A_WG * WA<C>::DUMP + (long)MAX_W_WG * 4 * 9 * (C / 16) * 256; }
 
 template <int C, int D>
@@ -764,7 +711,10 @@ __global__ __launch_bounds__(NT) void k_nrb_conv(const __bf16* __restrict__ x, c
             if constexpr (MODE == 1) rq = *reinterpret_cast<const vec_t*>(res + (valid ? pix : pix - (t - (T - 1))) * C);
             f32x4 acc[NB];
 #pragma unroll
-            for (int ob = 0; ob < NB; ++ob) acc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int ob = 0; ob < NB; ++ob) {
+                if constexpr (MODE == 0) acc[ob] = f32x4{b1r[4 * ob], b1r[4 * ob + 1], b1r[4 * ob + 2], b1r[4 * ob + 3]};
+                else acc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
             vec_t centre;
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
@@ -784,17 +734,17 @@ __global__ __launch_bounds__(NT) void k_nrb_conv(const __bf16* __restrict__ x, c
             } else {
                 vec_t hq;
 #pragma unroll
-                for (int c = 0; c < C; ++c) hq[c] = (__bf16)elu_f(acc[c >> 2][c & 3] + b1r[c]);
+                for (int c = 0; c < C; ++c) hq[c] = (__bf16)elu_f(acc[c >> 2][c & 3]);
                 if (SAVE && valid) *reinterpret_cast<vec_t*>(h1 + pix * C) = hq;
                 f32x4 z[NB];
 #pragma unroll
                 for (int ob = 0; ob < NB; ++ob) {
-                    z[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    z[ob] = f32x4{b2r[4 * ob], b2r[4 * ob + 1], b2r[4 * ob + 2], b2r[4 * ob + 3]};
 #pragma unroll
                     for (int kb = 0; kb < NB; ++kb) z[ob] = mma4(A2[ob][kb], chunk_of<C>(hq, kb), z[ob]);
                 }
 #pragma unroll
-                for (int c = 0; c < C; ++c) o[c] = (__bf16)(elu_f(z[c >> 2][c & 3] + b2r[c]) + (float)centre[c]);
+                for (int c = 0; c < C; ++c) o[c] = (__bf16)(elu_f(z[c >> 2][c & 3]) + (float)centre[c]);
             }
             if (valid) *reinterpret_cast<vec_t*>(y + pix * C) = o;
         }
@@ -851,7 +801,7 @@ __global__ __launch_bounds__(NT) void k_nrb_bwd_a(const __bf16* __restrict__ h1,
         f32x4 z[NB], u[NB];
 #pragma unroll
         for (int ob = 0; ob < NB; ++ob) {
-            z[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+            z[ob] = f32x4{b2r[4 * ob], b2r[4 * ob + 1], b2r[4 * ob + 2], b2r[4 * ob + 3]};
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) z[ob] = mma4(A2[ob][kb], chunk_of<C>(hq, kb), z[ob]);
         }
@@ -859,8 +809,8 @@ __global__ __launch_bounds__(NT) void k_nrb_bwd_a(const __bf16* __restrict__ h1,
         vec_t gq, aq;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            const float a2 = z[c >> 2][c & 3] + b2r[c];
-            gv[c] = (float)dq[c] * (a2 > 0.f ? 1.f : __expf(a2));
+            const float a2 = z[c >> 2][c & 3];
+            gv[c] = (float)dq[c] * elu_dpre(a2);
             gq[c] = (__bf16)gv[c];
             gr[c] = (float)gq[c];
             hv[c] = (float)hq[c];
@@ -873,7 +823,7 @@ __global__ __launch_bounds__(NT) void k_nrb_bwd_a(const __bf16* __restrict__ h1,
         }
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            const float a1 = u[c >> 2][c & 3] * (hv[c] > 0.f ? 1.f : hv[c] + 1.f);
+            const float a1 = u[c >> 2][c & 3] * elu_dout(hv[c]);
             aq[c] = (__bf16)a1;
             acc[C * C + c] += a1; acc[C * C + C + c] += gv[c];       // invalid pixels contribute zeros
         }
@@ -1062,7 +1012,7 @@ __global__ __launch_bounds__(NT, C == 8 ? 2 : 1) void k_nrb_bwd_fused(const __bf
                 f32x4 z[NB], u[NB];
 #pragma unroll
                 for (int ob = 0; ob < NB; ++ob) {
-                    z[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    z[ob] = f32x4{b2r[4 * ob], b2r[4 * ob + 1], b2r[4 * ob + 2], b2r[4 * ob + 3]};
 #pragma unroll
                     for (int kb = 0; kb < NB; ++kb) z[ob] = mma4(A2[ob][kb], chunk_of<C>(hq, kb), z[ob]);
                 }
@@ -1070,8 +1020,8 @@ __global__ __launch_bounds__(NT, C == 8 ? 2 : 1) void k_nrb_bwd_fused(const __bf
                 vec_t gq, aq;
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
-                    const float a2 = z[c >> 2][c & 3] + b2r[c];
-                    gv[c] = (float)dq[c] * (a2 > 0.f ? 1.f : __expf(a2));
+                    const float a2 = z[c >> 2][c & 3];
+                    gv[c] = (float)dq[c] * elu_dpre(a2);
                     gq[c] = (__bf16)gv[c];
                     gr[c] = (float)gq[c];
                     hv[c] = (float)hq[c];
@@ -1085,7 +1035,7 @@ __global__ __launch_bounds__(NT, C == 8 ? 2 : 1) void k_nrb_bwd_fused(const __bf
                 const float m = centre ? 1.f : 0.f;              // sums only over this tile's own pixels
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
-                    const float a1 = u[c >> 2][c & 3] * (hv[c] > 0.f ? 1.f : hv[c] + 1.f);
+                    const float a1 = u[c >> 2][c & 3] * elu_dout(hv[c]);
                     aq[c] = (__bf16)a1;
                     acc[C * C + c] += m * a1; acc[C * C + C + c] += m * gv[c];
                     gr[c] *= m;

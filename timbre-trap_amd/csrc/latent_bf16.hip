@@ -15,7 +15,7 @@
 
 namespace {
 
-__device__ __forceinline__ float gate_f(float dy, float y) { return dy * (y > 0.f ? 1.f : y + 1.f); }
+__device__ __forceinline__ float gate_f(float dy, float y) { return dy * elu_dout(y); }
 
 template <int CT> __device__ __forceinline__ int ochc(int ct, int m) { return (CT / 4) * (m >> 2) + 4 * ct + (m & 3); }
 

@@ -1,0 +1,81 @@
+// Pieces shared by the bf16 channel-innermost residual-block kernels (conv_wide_bf16.hip: one kernel per stage;
+// conv_level_bf16.hip: fused backward with recomputed hidden activation, level-fused forward) for gfx950.
+#pragma once
+#include "bf16_common.h"
+
+namespace {
+
+// Channel held by row m of co-tile ct.  C = 32: rows 4q..4q+3 of tile 0 / 1 are channels 8q..8q+3 / 8q+4..8q+7, so the
+// lane that owns D rows 4g..4g+3 of both tiles owns the eight CONSECUTIVE channels 8g..8g+7 (16 bytes).  C = 16: identity.
+template <int C> __device__ __forceinline__ int chan_of(int ct, int m) { return C == 32 ? 8 * (m >> 2) + 4 * ct + (m & 3) : m; }
+
+constexpr int MAX_A_WG = 2048, MAX_W_WG = 1024;   // workgroups that leave dumps (bounds the scratch)
+inline int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+
+// Sum of the register dumps into the fp32 gradients (+=).  1024 threads = REL consecutive dump elements x RSL slices of the
+// contributing waves (bf16_common.h); the dump order keeps the loads coalesced, the scatter into dW1 / dW2 is the cheap side.
+struct RedArgs {
+    const float* pw; int gw;        // wgrad dumps: gw workgroups x 4 waves
+    const float* pa; int ga;        // bwd_a dumps: one per workgroup
+    float *dw1, *db1, *dw2, *db2;
+    int split_a = 0;                // C = 32 fused backward: wave = (ci-tile, co-tile), each wave dumps only its own co-tile
+};
+template <int C>
+__global__ __launch_bounds__(1024) void k_wrb_reduce(RedArgs ar) {
+    constexpr int NCT = C / 16;
+    constexpr int WDUMP = 9 * NCT * 256, NEW = NCT * WDUMP;      // wgrad: elements = (wave role) x dump
+    constexpr int ADUMP = C * C + 2 * C;
+    __shared__ float red[RSL][REL];
+    const int el = threadIdx.x % REL, sl = threadIdx.x / REL;
+    const int e = blockIdx.x * REL + el;
+    float sum = 0.f;
+    float* dst = nullptr;
+    if (e < NEW) {
+        const int role = e / WDUMP, rest = e - role * WDUMP;     // C = 32: role = ci-tile = wave & 1;  C = 16: one role
+        const int k = rest / (NCT * 256), a = (rest >> 8) % NCT, r = (rest >> 6) & 3, lane = rest & 63;
+        const int NS = ar.split_a ? 1 : 4 / NCT;                 // waves per workgroup that contribute to this element
+        const int ncontrib = ar.gw * NS;
+        float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // eight loads in flight per thread
+        for (int j0 = sl; j0 < ncontrib; j0 += 8 * RSL) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + RSL * u;
+                if (j < ncontrib) {
+                    const int wg = j / NS, s = j - wg * NS;
+                    const int wave = ar.split_a ? role + 2 * a : (C == 32 ? role + 2 * s : s);
+                    part[u] += ar.pw[((long)wg * 4 + wave) * WDUMP + rest];
+                }
+            }
+        }
+        sum = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+        const int co = 16 * a + 4 * (lane >> 4) + r, ci = 16 * role + (lane & 15);
+        dst = ar.dw1 + (co * C + ci) * 9 + k;
+    } else if (e < NEW + ADUMP) {
+        const int q = e - NEW;
+        const int ncontrib = ar.ga;
+        float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int j0 = sl; j0 < ncontrib; j0 += 8 * RSL) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + RSL * u;
+                if (j < ncontrib) part[u] += ar.pa[(long)j * ADUMP + q];
+            }
+        }
+        sum = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+        if (q < C * C) {
+            const int a = q / (NCT * 256), c = (q >> 8) % NCT, r = (q >> 6) & 3, lane = q & 63;
+            dst = ar.dw2 + (16 * a + 4 * (lane >> 4) + r) * C + 16 * c + (lane & 15);
+        } else if (q < C * C + C) dst = ar.db1 + (q - C * C);
+        else dst = ar.db2 + (q - C * C - C);
+    }
+    red[sl][el] = sum;
+    __syncthreads();
+    if (sl == 0 && dst) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < RSL; ++i) s += red[i][el];
+        *dst += s;
+    }
+}
+
+}  // namespace

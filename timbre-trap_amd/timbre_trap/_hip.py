@@ -18,7 +18,9 @@ PKG_ROOT = os.path.dirname(_HERE)                       # timbre-trap_amd/
 REPO_ROOT = os.path.dirname(PKG_ROOT)
 CSRC = os.path.join(PKG_ROOT, 'csrc')
 LIB_PATH = os.path.join(PKG_ROOT, 'lib', 'libttrap_hip.so')
-SOURCES = ['cqt.hip', 'conv_generic.hip', 'conv_mfma.hip', 'conv_small.hip', 'conv_wide_bf16.hip', 'conv_stride_bf16.hip', 'latent_bf16.hip', 'conv_edge_bf16.hip', 'gemm.hip', 'losses.hip']
+if os.environ.get('TTRAP_LIB'):                         # tuning: an alternative build of the same sources (tools/build_variant.sh)
+    LIB_PATH = os.path.join(PKG_ROOT, 'lib', os.environ['TTRAP_LIB'])
+SOURCES = ['cqt.hip', 'conv_generic.hip', 'conv_mfma.hip', 'conv_small.hip', 'conv_wide_bf16.hip', 'conv_level_bf16.hip', 'conv_stride_bf16.hip', 'latent_bf16.hip', 'conv_edge_bf16.hip', 'gemm.hip', 'losses.hip']
 
 _lib = None
 
@@ -52,6 +54,8 @@ _PROTOS = {
     'tt_wide_unpack': (c_int, [P, P, I, I, I, I, P]),
     'tt_wide_rb_fwd': (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
     'tt_wide_rb_bwd': (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    'tt_wide_fused_scratch_bytes': (c_int64, [I]),
+    'tt_wide_rb_bwd_fused': (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
     'tt_stride16_scratch_bytes': (c_int64, [I]),
     'tt_sconv16_fwd': (c_int, [P, P, P, P, I, I, I, I, P]),
     'tt_sconv16_bwd': (c_int, [P, P, P, P, P, P, P, P, I, I, I, I, P]),

@@ -517,37 +517,47 @@ class ConvOut16Fn(torch.autograd.Function):
 LEVEL_CHUNK = int(os.environ.get('TTRAP_LEVEL_CHUNK', '0'))
 
 
+# Residual blocks whose backward recomputes the hidden activation inside ONE fused pass (csrc/conv_level_bf16.hip,
+# tt_wide_rb_bwd_fused): the forward stores no h1 and dL/d(conv1 pre-activation) never reaches HBM -- 5 tensor passes per block
+# (x, y | x, dy, dx) instead of 11.  TTRAP_LEVEL_RECOMPUTE=0 restores the per-stage kernels with the saved h1.
+RECOMPUTE_CHANNELS = (16, 32) if os.environ.get('TTRAP_LEVEL_RECOMPUTE', '1') != '0' else ()
+
+
 def _chunks(B):
     c = LEVEL_CHUNK if 0 < LEVEL_CHUNK < B else B
     return [(b0, min(B, b0 + c)) for b0 in range(0, B, c)]
 
 
 class Level16Fn(torch.autograd.Function):
-    """The residual blocks of one level on cl16 tensors (csrc/conv_wide_bf16.hip); see WideLevelFn for the fp32-facing form."""
+    """The residual blocks of one level on cl16 tensors (csrc/conv_wide_bf16.hip, csrc/conv_level_bf16.hip); see WideLevelFn for
+    the fp32-facing form.  Saved for backward: the input of every block, plus its hidden activation at the widths whose
+    backward does not recompute it (RECOMPUTE_CHANNELS)."""
 
     @staticmethod
     def forward(ctx, x, dilations, *params):
         B, C, H, T = x.shape
         lib, st = _hip.lib(), stream_ptr()
         needs_grad = any(ctx.needs_input_grad)
+        recompute = C in RECOMPUTE_CHANNELS
         nb = len(dilations)
         outs = [new_cl16(B, C, H, T, x.device) for _ in range(nb)]
-        hids = [new_cl16(B, C, H, T, x.device) if needs_grad else None for _ in range(nb)]
+        hids = [new_cl16(B, C, H, T, x.device) if (needs_grad and not recompute) else None for _ in range(nb)]
         for b0, b1 in _chunks(B):
             cur = x[b0:b1]
             for i, d in enumerate(dilations):
                 w1, b1_, w2, b2 = params[4 * i: 4 * i + 4]
-                h1 = hids[i][b0:b1] if needs_grad else None
+                h1 = hids[i][b0:b1] if hids[i] is not None else None
                 with _hip.timed('wide_rb_fwd_C%d' % C):
                     check(lib.tt_wide_rb_fwd(ptr(cur), ptr(w1), ptr(b1_), ptr(w2), ptr(b2), ptr(outs[i][b0:b1]), ptr(h1), b1 - b0, C, H, T,
                                              d, st), 'tt_wide_rb_fwd')
                 cur = outs[i][b0:b1]
         ctx.dilations = tuple(dilations)
         ctx.params = params
+        ctx.recompute = recompute
         if needs_grad:
             saved = []
             for i in range(nb):
-                saved += [x if i == 0 else outs[i - 1], hids[i]]
+                saved += [x if i == 0 else outs[i - 1]] + ([] if recompute else [hids[i]])
             ctx.save_for_backward(*params, *saved)
         return outs[-1]
 
@@ -561,7 +571,9 @@ class Level16Fn(torch.autograd.Function):
         g_all = _as_cl16(dy)
         chunks = _chunks(B)
         cb = chunks[0][1] - chunks[0][0]
-        ws = torch.empty(lib.tt_wide_scratch_bytes(cb, C, H, T), dtype=torch.uint8, device=g_all.device)
+        recompute = ctx.recompute
+        ws_bytes = lib.tt_wide_fused_scratch_bytes(C) if recompute else lib.tt_wide_scratch_bytes(cb, C, H, T)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=g_all.device)
         targets = [_grad_target(t) for t in ctx.params]
         dx = new_cl16(B, C, H, T, g_all.device)
         tmp = [new_cl16(cb, C, H, T, g_all.device) for _ in range(2)] if nb > 1 else []
@@ -569,12 +581,18 @@ class Level16Fn(torch.autograd.Function):
             g = g_all[b0:b1]
             for i in reversed(range(nb)):
                 w1, b1_, w2, b2 = params[4 * i: 4 * i + 4]
-                xin, h1 = saved[2 * i][b0:b1], saved[2 * i + 1][b0:b1]
                 (dw1, _), (db1, _), (dw2, _), (db2, _) = targets[4 * i: 4 * i + 4]
                 gx = dx[b0:b1] if i == 0 else tmp[i & 1][:b1 - b0]
                 with _hip.timed('wide_rb_bwd_C%d' % C):
-                    check(lib.tt_wide_rb_bwd(ptr(xin), ptr(h1), ptr(g), ptr(w1), ptr(w2), ptr(b2), ptr(gx), ptr(dw1), ptr(db1),
-                                             ptr(dw2), ptr(db2), ptr(ws), b1 - b0, C, H, T, ctx.dilations[i], st), 'tt_wide_rb_bwd')
+                    if recompute:
+                        xin = saved[i][b0:b1]
+                        check(lib.tt_wide_rb_bwd_fused(ptr(xin), ptr(g), ptr(w1), ptr(b1_), ptr(w2), ptr(b2), ptr(gx), ptr(dw1), ptr(db1),
+                                                       ptr(dw2), ptr(db2), ptr(ws), b1 - b0, C, H, T, ctx.dilations[i], st),
+                              'tt_wide_rb_bwd_fused')
+                    else:
+                        xin, h1 = saved[2 * i][b0:b1], saved[2 * i + 1][b0:b1]
+                        check(lib.tt_wide_rb_bwd(ptr(xin), ptr(h1), ptr(g), ptr(w1), ptr(w2), ptr(b2), ptr(gx), ptr(dw1), ptr(db1),
+                                                 ptr(dw2), ptr(db2), ptr(ws), b1 - b0, C, H, T, ctx.dilations[i], st), 'tt_wide_rb_bwd')
                 g = gx
         return (dx, None, *[r for _, r in targets])
 

@@ -54,6 +54,12 @@ def main():
             t = timeit(lambda: check(lib.tt_wide_rb_bwd(ptr(xb), ptr(hb), ptr(gb), ptr(w1), ptr(w2), ptr(b2), ptr(dxb), ptr(dw1), ptr(db1),
                                                         ptr(dw2), ptr(db2), ptr(ws), B, C, H, T, d, st), 'bwd'))
             print('C%d d%d bwd    %.3f ms' % (C, d, t))
+            if C >= 16:
+                wsf = torch.empty(lib.tt_wide_fused_scratch_bytes(C), dtype=torch.uint8, device='cuda')
+                t = timeit(lambda: check(lib.tt_wide_rb_bwd_fused(ptr(xb), ptr(gb), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(dxb), ptr(dw1),
+                                                                  ptr(db1), ptr(dw2), ptr(db2), ptr(wsf), B, C, H, T, d, st), 'bwdf'))
+                print('C%d d%d bwd-fused %.3f ms  %.2f TB/s (x + dy + dx)  [tile set %s, per CU %s]' % (
+                    C, d, t, npx * C * 6 / t / 1e9, os.environ.get('TTRAP_FBWD_TILE', '0'), os.environ.get('TTRAP_FBWD_PER_CU', '2')))
 
 
 if __name__ == '__main__':

@@ -11,19 +11,26 @@ audio already resident in HBM:
     to_activations, reconstruction / transcription / 2 consistency losses, total
     zero_grad, backward, [all-reduce of the flat gradient when N > 1], clip_grad_norm_(10) + AdamW
 Workload (BASELINE.json configs[2]): model_complexity=2, latent_size=128, 64 clips x 3 s @ 22.05 kHz per
-GPU, 9 octaves x 60 bins/octave; weak scaling (per-GPU batch fixed).  dtype = fp32 (exact-fp32 MFMA path).
+GPU, 9 octaves x 60 bins/octave; weak scaling (per-GPU batch fixed).  The step runs under torch.autocast like the reference's
+(experiments/train.py:415): dtype = bf16 (bf16 channels-last MFMA conv path, fp32 master weights / losses / optimizer);
+`--precision fp32` times the exact-fp32 path that carries the 1e-4 output bar (also reported as "fp32_train_step").
 
 Prints ONE JSON line on rank 0 with the driver's fields plus
-  "roofline"          : the fused wide residual block k_rb_fwd<32,D>: algorithmic FLOPs / average launch time measured with HIP
-                        events on the launch stream over the timed steps, against the gfx950 fp32 matrix peak; `traffic` is the
-                        HBM byte count of the committed rocprofv3 PMC passes (`traffic_source` names the file -- it is not
-                        re-measured inside this run)
+  "roofline"          : the by-time dominant call of the step -- the residual-block backward at the widest level
+                        (tt_wide_rb_bwd, C = 32: k_wrb_bwd_a + k_wrb_conv<..,1> + k_wrb_wgrad + k_wrb_reduce, 18 calls per step):
+                        algorithmic bytes (dy, x read, dx written once, bf16) / average call time measured with HIP events on the
+                        launch stream over the timed steps, against the HBM peak; `traffic` is the HBM byte count of the committed
+                        rocprofv3 PMC passes of those kernels (`traffic_source` names the file -- not re-measured in this run)
+  "roofline_fwd"      : the fused block forward k_wrb_conv<32,D,0> the same way (round 2's roofline kernel; fp32 path: k_rb_fwd<32,D>
+                        against the fp32 matrix peak)
   "roofline_cqt"      : tt_cqt_forward, measured in the timed steps (HBM bound, 4,688,280 algorithmic bytes per clip)
   "roofline_cqt_inv"  : tt_cqt_inverse (CQT.decode) on the same batch, measured after the timed region (training never calls it)
   "families"          : per kernel family (narrow / wide residual blocks, strided, transposed, latent GEMMs, boundary convs,
                         losses, optimizer) ms per step, achieved TFLOP/s and TB/s on ALGORITHMIC work and the fractions of the
                         fp32 matrix peak and of HBM peak -- measured with HIP events in two extra, untimed, instrumented steps
   "whole_step"        : algorithmic conv FLOPs of the step / ms_per_step against the fp32 and the bf16 matrix peaks
+  "overlap"           : N > 1 only: event timestamps of one instrumented step -- how long the compute stream still had to wait for
+                        the all-reduce AFTER it had finished the next batch's CQT (0 = the collective was hidden entirely)
   "inference_config1" : BASELINE.json configs[1] (transcribe() + reconstruct(), 32 clips) timed in the same run, N = 1
   "cpu_baseline"      : the CPU oracle (kind "port") on a bounded sample of the SAME workload (model_complexity 2; rank 0, N = 1)
   "cpu_baseline_config0" : BASELINE.json configs[0] on the oracle: model_complexity 1, one clip, CQT forward + inverse + one step
@@ -113,18 +120,28 @@ def make_train_step(model, opt, world, overlap=True, autocast=True):
             total.backward()
         if sync is not None:
             if overlap:
-                sync.start(opt.flat_grad)
+                probe = state.get('probe')
+                if probe is not None:                             # instrumented step: timestamps on the compute stream
+                    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                    ev[0].record()
+                sync.start(opt)
                 state['coeffs'], state['src'] = model.sliCQ(next_audio), next_audio
+                if probe is not None:
+                    ev[1].record()
                 sync.finish()
+                if probe is not None:
+                    ev[2].record()
+                    probe.append(ev)
             else:
-                sync.start(opt.flat_grad)
+                sync.start(opt)
                 sync.finish()
         opt.step()
         return total
+    step.state = state
     return step
 
 
-def family_table(events, n_steps, batch, mc, latent):
+def family_table(events, n_steps, batch, mc, latent, bf16=False):
     """
     Per kernel family: ms per step (HIP events around every forward / backward of the autograd Functions in
     timbre_trap/framework/ops.py, recorded on the launch stream during `n_steps` untimed instrumented steps), the ALGORITHMIC
@@ -216,8 +233,12 @@ def family_table(events, n_steps, batch, mc, latent):
         sec = f['ms_per_step'] * 1e-3
         tf, tb = f['gflop_per_step'] / 1e3 / sec, f['gbyte_per_step'] / 1e3 / sec
         out[name] = dict(ms_per_step=round(f['ms_per_step'], 3), calls_per_step=f['calls_per_step'], bound=f['bound'],
-                         achieved_tflops=round(tf, 2), achieved_tbs=round(tb, 3),
-                         frac_fp32_matrix_peak=round(tf / PEAK_FP32_MATRIX_TFLOPS, 4), frac_hbm_peak=round(tb * 1e3 / PEAK_HBM_GBS, 4))
+                         achieved_tflops=round(tf, 2), achieved_tbs=round(tb, 3), frac_hbm_peak=round(tb * 1e3 / PEAK_HBM_GBS, 4))
+        # the matrix peak of the arithmetic the step actually runs in
+        if bf16:
+            out[name]['frac_bf16_mfma_peak'] = round(tf / PEAK_BF16_MFMA_TFLOPS, 4)
+        else:
+            out[name]['frac_fp32_matrix_peak'] = round(tf / PEAK_FP32_MATRIX_TFLOPS, 4)
     out['sum_ms_per_step'] = round(sum(f['ms_per_step'] for f in fam.values()), 3)
     return out
 
@@ -382,14 +403,15 @@ def main():
     from timbre_trap.utils.distributed import broadcast_parameters
     import torch.distributed as dist
 
+    # Build decision BEFORE anything initialises the GPU or the process group (init_process_group_from_env selects the device
+    # for RCCL; hipcc children must not be started from a process that holds it) and identical on every rank: local rank 0 --
+    # read from the environment -- calls build(), a no-op when the library is up to date and an atomic rename into place
+    # otherwise; EVERY rank then passes the same barrier before dlopen.
+    if int(os.environ.get('LOCAL_RANK', os.environ.get('RANK', '0'))) == 0:
+        _hip.build()
     rank, world, local_rank = init_process_group_from_env()
     if world != args.gpus and world > 1:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
-    # Build decision BEFORE anything initialises the GPU (hipcc children must not be forked from a process that holds the
-    # device) and identical on every rank: local rank 0 calls build() -- a no-op when the library is up to date, atomic
-    # rename into place otherwise -- and EVERY rank then passes the same barrier before dlopen.
-    if local_rank == 0:
-        _hip.build()
     if world > 1:
         dist.barrier()
     if not torch.cuda.is_available():
@@ -421,8 +443,8 @@ def main():
     sync()
     torch.cuda.reset_peak_memory_stats()
     C = 16 * 2 ** (args.mc - 1)
-    key, key16 = 'resblock_fwd_C%d' % C, 'wide_rb_fwd_C%d' % C
-    _hip.EVENT_KEYS = {key, key16, 'cqt_forward'}   # the timed region brackets only the roofline kernels
+    key, key16, keyb = 'resblock_fwd_C%d' % C, 'wide_rb_fwd_C%d' % C, 'wide_rb_bwd_C%d' % C
+    _hip.EVENT_KEYS = {key, key16, keyb, 'cqt_forward'}   # the timed region brackets only the roofline calls
     _hip.EVENT_LOG = {}
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -452,7 +474,20 @@ def main():
         step_fn(audio, target)
     torch.cuda.synchronize()
     _hip.EVENT_LOG = None
-    allreduce_ms = None
+    allreduce_ms = overlap_info = None
+    if world > 1 and not args.no_overlap:
+        # did the next batch's CQT really run beside the all-reduce?  Compute-stream timestamps of two instrumented steps:
+        # [start of the exchange] -> [CQT enqueued and finished] -> [the stream's wait for the collective released]
+        step_fn.state['probe'] = []
+        for _ in range(2):
+            step_fn(audio, target)
+        torch.cuda.synchronize()
+        pr = step_fn.state.pop('probe')
+        cq = sum(e[0].elapsed_time(e[1]) for e in pr) / len(pr)
+        wt = sum(e[1].elapsed_time(e[2]) for e in pr) / len(pr)
+        overlap_info = dict(cqt_on_compute_stream_ms=cq, wait_for_collective_after_cqt_ms=wt, backend=dist.get_backend(),
+                            note='RCCL runs the collective on its own stream; wait << allreduce_ms means it was hidden behind the CQT '
+                                 '(gloo blocks the host instead: the figures are then host-side)')
     if world > 1:
         a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
@@ -516,6 +551,28 @@ def main():
                         launches=n_l, avg_ms=a_ms,
                         note='algorithmic bytes = x read + y written once (bf16); the hidden activation saved for backward (+50 %) is an '
                              'implementation choice and is not counted')
+        roof_fwd = roof
+        if events.get(keyb):
+            # the by-time dominant call of the bf16 step: the residual-block backward at the widest level (18 calls per step)
+            a_ms, n_l = avg_ms(events[keyb])
+            nbytes = 3.0 * 2 * C * args.batch * 65 * M_FRAMES
+            flops = 2.0 * 2.0 * (9 * C * C + C * C) * args.batch * 65 * M_FRAMES
+            gbs = nbytes / (a_ms * 1e-3) / 1e9
+            traffic, traffic_source, pmc_note = None, None, None
+            pmc = os.path.join(ROOT, 'profiles', 'r03_pmc_wrb_bwd_C32.json')
+            if C == 32 and args.batch == 64 and os.path.exists(pmc):
+                pj = json.load(open(pmc))
+                traffic = pj['traffic_bytes_corrected']
+                pmc_note = pj.get('summary')
+                traffic_source = 'profiles/r03_pmc_wrb_bwd_C32.json (rocprofv3 --pmc passes of the four kernels at this shape: FETCH_SIZE x2 + WRITE_SIZE, summed; not re-measured in this run)'
+            roof = dict(kernel='tt_wide_rb_bwd at C=%d, H=65 (ResidualConv2dBlock backward, bf16 channel-innermost storage): k_wrb_bwd_a<%d> + '
+                               'k_wrb_conv<%d,D,1> + k_wrb_wgrad<%d,D> + k_wrb_reduce<%d>; the by-time dominant call of the step' % (C, C, C, C, C),
+                        bound='hbm', achieved=gbs, peak=PEAK_HBM_GBS, unit='GB/s', frac=gbs / PEAK_HBM_GBS, traffic=traffic,
+                        traffic_source=traffic_source, algorithmic_bytes=nbytes, algorithmic_flops=flops,
+                        achieved_tflops=flops / (a_ms * 1e-3) / 1e12, frac_bf16_mfma_peak=flops / (a_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                        launches=n_l, avg_ms=a_ms, ms_per_step=a_ms * n_l / args.steps, pmc=pmc_note,
+                        note='algorithmic bytes = dy and x read, dx written once (bf16); the three passes also read the saved hidden '
+                             'activation and write + re-read dL/d(conv1 pre-activation) -- see traffic')
         cqt = cqt_inv = None
         if events.get('cqt_forward'):
             a_ms, n_l = avg_ms(events['cqt_forward'])
@@ -528,7 +585,7 @@ def main():
             cqt_inv = dict(kernel='tt_cqt_inverse (CQT.decode incl. the batch infinity norm)', bound='hbm', achieved=gbs, peak=PEAK_HBM_GBS,
                            unit='GB/s', frac=gbs / PEAK_HBM_GBS, avg_ms=a_ms, launches=n_l, clips=args.batch,
                            note='measured after the timed region; the train step never calls the inverse transform')
-        families = family_table(fam_events, n_inst, args.batch, args.mc, args.latent) if n_inst else None
+        families = family_table(fam_events, n_inst, args.batch, args.mc, args.latent, bf16=train_dtype == 'bf16') if n_inst else None
         conv_flops = {1: 41.4e9, 2: 168.7e9}.get(args.mc)          # SURVEY.md section 8d, fwd + bwd per clip (latent 32 / 128)
         whole = None
         if conv_flops:
@@ -537,11 +594,11 @@ def main():
                          frac_fp32_matrix_peak=tf / PEAK_FP32_MATRIX_TFLOPS, frac_bf16_mfma_peak=tf / PEAK_BF16_MFMA_TFLOPS)
         infer = None
         if world == 1 and not args.timed_only:            # BASELINE configs[1], measured in the same run (secondary figure)
-            full = bench_inference(model, args, rank, world, dev, steps=3, warmup=1, emit=False)
+            full = bench_inference(model, args, rank, world, dev, steps=10, warmup=2, emit=False)
             infer = {k: full[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype')}
             infer['workload'] = full['config']['workload']
             if args.precision == 'auto':
-                full16 = bench_inference(model, args, rank, world, dev, steps=3, warmup=1, emit=False, autocast=True)
+                full16 = bench_inference(model, args, rank, world, dev, steps=10, warmup=2, emit=False, autocast=True)
                 infer['under_autocast'] = {k: full16[k] for k in ('value', 'unit', 'ms_per_step', 'dtype')}
         fp32_step = None
         if world == 1 and not args.timed_only and train_dtype != 'f32':
@@ -574,8 +631,8 @@ def main():
                                             '(bf16 MFMA conv path of BASELINE config[2]; fp32 master weights, losses and optimizer)'
                                             if args.precision == 'auto' else ''),
                                 global_batch=world * args.batch, parallelism='dp%d' % world),
-                    roofline=roof, roofline_cqt=cqt, roofline_cqt_inv=cqt_inv, families=families, whole_step=whole,
-                    peak_memory_gb=peak_gb, inference_config1=infer, fp32_train_step=fp32_step, per_rank_ms=per_rank_ms, allreduce_ms=allreduce_ms, cpu_baseline=base, cpu_baseline_config0=base0,
+                    roofline=roof, roofline_fwd=roof_fwd if roof_fwd is not roof else None, roofline_cqt=cqt, roofline_cqt_inv=cqt_inv, families=families, whole_step=whole,
+                    peak_memory_gb=peak_gb, inference_config1=infer, fp32_train_step=fp32_step, per_rank_ms=per_rank_ms, allreduce_ms=allreduce_ms, overlap=overlap_info, cpu_baseline=base, cpu_baseline_config0=base0,
                     final_loss=float(total.detach()))
         print(json.dumps(line))
     if world > 1:

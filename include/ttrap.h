@@ -267,6 +267,11 @@ int tt_window_ola(const float* chunks, const float* window, float* out, int64_t 
                   int64_t n_frames, void* stream);
 /* out[0] += sum(a * b) : gradient of one skip weight. */
 int tt_dot(const float* a, const float* b, float* out, int64_t n, void* stream);
+/* The same two for the bf16 channels-last path (skip joins under autocast; BASELINE configs[4] trains with
+ * skip_connections=True): a, b, y bf16 arrays of n elements (16-byte aligned), s and out fp32; fp32 arithmetic,
+ * round-to-nearest-even stores. */
+int tt_scaled_add16(const void* a, const void* b, const float* s, int idx, void* y, int64_t n, void* stream);
+int tt_dot16(const void* a, const void* b, float* out, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Objectives.  Replace timbre_trap/framework/objectives.py and TimbreTrap.to_activations

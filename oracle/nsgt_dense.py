@@ -22,7 +22,7 @@ import math
 import numpy as np
 
 DEFAULTS = dict(window='hann_periodic', length_rounding='round', centre_rounding='round', crop_alignment='centred',
-                dual='floored', frame_floor=1e-3, min_length=1)
+                dual='floored', frame_floor=1e-3, min_length=1, dual_eps=1e-8)
 
 
 def _rnd(x, rule):
@@ -63,7 +63,10 @@ def dense_windows(geo):
         raise ValueError('a window leaves the open positive half-spectrum')
     D = (W ** 2).sum(axis=0)
     kept = D > (cv['frame_floor'] if cv['dual'] == 'floored' else 0.0)
-    Wd = np.where(kept[None, :], W / np.where(kept, D, 1.0)[None, :], 0.0)
+    if cv['dual'] == 'additive':                            # regularised inverse: every reached index, D + eps in the denominator
+        Wd = np.where(kept[None, :], W / (D + cv['dual_eps'])[None, :], 0.0)
+    else:
+        Wd = np.where(kept[None, :], W / np.where(kept, D, 1.0)[None, :], 0.0)
     return W, Wd, D, kept
 
 

@@ -79,6 +79,40 @@ def test_gloo_world_size_2():
     assert results == [(0, True, True, True), (1, True, True, True)]
 
 
+def test_dataparallel_warns_about_ignored_device_ids():
+    """Unmodified multi-GPU train.py (`DataParallel(model, device_ids=gpu_ids)`, reference experiments/train.py:166-168) must not
+    silently run on one GPU."""
+    import warnings
+    from timbre_trap.utils import DataParallel
+    lin = torch.nn.Linear(2, 2)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        DataParallel(lin, device_ids=[0, 1, 2, 3])
+        assert any('one process per GPU' in str(x.message) for x in w)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        DataParallel(lin, device_ids=[0])
+        DataParallel(lin)
+        assert not w
+
+
+def test_gradient_sync_reattaches_through_the_optimizer():
+    """GradientSync.start(opt) asks the optimizer for its flat buffer AFTER re-attaching detached gradient views."""
+    from timbre_trap.utils import GradientSync
+
+    class FakeOpt:
+        calls = 0
+
+        def sync_views(self):
+            FakeOpt.calls += 1
+            return torch.ones(3)
+    os.environ.pop('WORLD_SIZE', None)
+    s = GradientSync(1)
+    s.start(FakeOpt())
+    s.finish()
+    assert FakeOpt.calls == 1
+
+
 def test_single_process_is_a_noop():
     from timbre_trap.utils import allreduce_gradients, init_process_group_from_env
     os.environ.pop('WORLD_SIZE', None)

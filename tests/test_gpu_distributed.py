@@ -37,10 +37,13 @@ SCRIPT = textwrap.dedent('''
         with torch.autocast(device_type='cuda', dtype=torch.bfloat16, enabled=amp):
             rec = model(audio, False)[0]
             loss = compute_reconstruction_loss(rec, coeffs)
-            opt.zero_grad()
+            if os.environ.get('TT_TEST_MODEL_ZERO') == '1':
+                model.zero_grad()                # drops every .grad view: autograd then installs fresh tensors ...
+            else:
+                opt.zero_grad()
             loss.backward()
         if world > 1:
-            sync.start(opt.flat_grad)            # asynchronous all-reduce ...
+            sync.start(opt)                      # ... which must be back in the flat buffer BEFORE it is averaged; asynchronous all-reduce ...
             coeffs = model.sliCQ(audio)          # ... with the next step's transform issued meanwhile (bench.py's overlap)
             sync.finish()
         else:
@@ -50,9 +53,9 @@ SCRIPT = textwrap.dedent('''
 ''') % (ROOT, ROOT)
 
 
-def _run(rank, world, port, amp=False):
+def _run(rank, world, port, amp=False, model_zero=False):
     env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
-               TTRAP_DIST_BACKEND='gloo', TT_TEST_AUTOCAST='1' if amp else '0')
+               TTRAP_DIST_BACKEND='gloo', TT_TEST_AUTOCAST='1' if amp else '0', TT_TEST_MODEL_ZERO='1' if model_zero else '0')
     return subprocess.Popen([sys.executable, '-c', SCRIPT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
 
 
@@ -72,6 +75,21 @@ def test_two_ranks_match_single_process_global_batch(amp):
     single = _result(_run(0, 1, 29542 + 4 * amp, amp))
     tol = 1e-4 if amp else 1e-5                                   # bf16 step: the same products summed in another order, then Adam
     assert abs(res[0][0] - single[0]) <= tol * abs(single[1]) and abs(res[0][1] - single[1]) <= tol * abs(single[1])
+
+
+@pytest.mark.gpu
+def test_two_ranks_after_model_zero_grad():
+    """``model.zero_grad()`` between steps drops the gradient views of the flat buffer: autograd then deposits this step's
+    gradient in fresh tensors, and the collective must average THAT (GradientSync.start(opt) re-attaches first), not the stale
+    slot -- otherwise the ranks diverge silently (round-2 advisor finding)."""
+    procs = [_run(r, 2, 29561, False, model_zero=True) for r in range(2)]
+    res = [_result(p) for p in procs]
+    assert res[0] == res[1]
+    single = _result(_run(0, 1, 29562, False, model_zero=True))
+    assert abs(res[0][0] - single[0]) <= 1e-5 * abs(single[1]) and abs(res[0][1] - single[1]) <= 1e-5 * abs(single[1])
+    # and the same trajectory as with opt.zero_grad()
+    plain = _result(_run(0, 1, 29563, False, model_zero=False))
+    assert abs(single[0] - plain[0]) <= 1e-5 * abs(plain[1])
 
 
 NCCL_SCRIPT = textwrap.dedent('''

@@ -485,3 +485,31 @@ def test_strided_layers_at_bench_heights():
     test_sconv16_stagewise(4, (1, 540, 1024))
     test_tconv16_stagewise(4, (1, 269, 1024), 0)
     test_tconv16_stagewise(16, (2, 65, 1024), 1)
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 31, 48), (1, 4, 540, 6), (3, 32, 5, 7)])
+def test_skip_joins_on_the_device(shape):
+    """cl16 skip joins (reference modules.py:112, 569-589) through tt_scaled_add16 / tt_dot16: w_i * e and y + s, with the
+    gradients of both tensors and of the skip weight, against float64 on the bf16-rounded inputs."""
+    from timbre_trap.framework import ops
+    B, C, H, T = shape
+    e32, y32, g32 = _rand(B, C, H, T, seed=1), _rand(B, C, H, T, seed=2), _rand(B, C, H, T, seed=3)
+    w = torch.tensor([0.5, -1.25, 2.0, 0.75, 1.5])
+    cl = lambda t: t.cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    e, y = cl(e32).requires_grad_(True), cl(y32).requires_grad_(True)
+    wd = w.cuda().requires_grad_(True)
+    assert ops.is_cl16(e)
+    s = ops.scale(e, wd, 3)
+    out = ops.add(y, s)
+    assert ops.is_cl16(s) and ops.is_cl16(out)
+    out.backward(cl(g32))
+    torch.cuda.synchronize()
+    er, yr, gr = _r16(e32), _r16(y32), _r16(g32)
+    s_ref = _r16(0.75 * er)
+    assert torch.equal(s.detach().float().cpu().double(), s_ref)                      # one rounding of the exact fp32 product
+    assert torch.equal(out.detach().float().cpu().double(), _r16(yr + s_ref))
+    assert torch.equal(y.grad.float().cpu().double(), gr)
+    assert torch.equal(e.grad.float().cpu().double(), _r16(0.75 * gr))
+    dw = torch.zeros(5, dtype=torch.float64)
+    dw[3] = float((gr * er).sum())
+    assert torch.allclose(wd.grad.cpu().double(), dw, rtol=1e-4, atol=1e-4)

@@ -19,6 +19,7 @@ CONVENTION_SETS = {
     'symmetric_canonical': dict(window='hann_symmetric', dual='canonical'),
     'floor_ceil': dict(length_rounding='floor', centre_rounding='ceil', min_length=2),
     'window_start': dict(crop_alignment='window_start', length_rounding='ceil'),
+    'additive_dual': dict(dual='additive', dual_eps=1e-6),
 }
 
 

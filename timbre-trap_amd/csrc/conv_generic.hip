@@ -272,6 +272,45 @@ __global__ __launch_bounds__(256) void k_dot(const float* __restrict__ a, const 
     if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
 }
 
+// The same two on bf16 tensors (the skip joins of the bf16 channels-last path: elementwise, so the layout does not matter):
+// eight elements per thread as one 16-byte access, fp32 arithmetic, round-to-nearest-even on the store.
+typedef __bf16 bf16x8_g __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void k_scaled_add16(const __bf16* __restrict__ a, const __bf16* __restrict__ b,
+                                                      const float* __restrict__ s, int idx, __bf16* __restrict__ y, long n8, long n) {
+    const float sc = s ? s[idx] : 1.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const bf16x8_g bv = *reinterpret_cast<const bf16x8_g*>(b + 8 * i);
+        bf16x8_g av, o;
+        if (a) av = *reinterpret_cast<const bf16x8_g*>(a + 8 * i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (__bf16)fmaf(sc, (float)bv[j], a ? (float)av[j] : 0.f);
+        *reinterpret_cast<bf16x8_g*>(y + 8 * i) = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {              // tail of a length that is not a multiple of 8
+        const long i = (n & ~7l) + threadIdx.x;
+        y[i] = (__bf16)fmaf(sc, (float)b[i], a ? (float)a[i] : 0.f);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dot16(const __bf16* __restrict__ a, const __bf16* __restrict__ b, float* __restrict__ out,
+                                               long n8, long n) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const bf16x8_g av = *reinterpret_cast<const bf16x8_g*>(a + 8 * i), bv = *reinterpret_cast<const bf16x8_g*>(b + 8 * i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc = fmaf((float)av[j], (float)bv[j], acc);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
+        const long i = (n & ~7l) + threadIdx.x;
+        acc = fmaf((float)a[i], (float)b[i], acc);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
 // ---- LDS-tiled 3x3 boundary convs (2 <-> 4 channels, stride 1, pad 1) ------------------------------------------------
 // Same scheme as k_small_lds (conv_small.hip): the CI-channel input tile (16 rows + 2, 64 columns + 8) arrives by
 // LDS-DMA, double buffered; a thread computes two output pixels (rows r, r + 8) for all CO channels from LDS taps with
@@ -562,6 +601,26 @@ extern "C" int tt_scaled_add(const float* a, const float* b, const float* s, int
     if (!b || !y || n < 0) return TT_E_BADARG;
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_scaled_add, dim3(grid1d(n, 256, 4096)), dim3(256), 0, tt_stream(stream), a, b, s, idx, y, (long)n);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tt_scaled_add16(const void* a, const void* b, const float* s, int idx, void* y, int64_t n, void* stream) {
+    if (!b || !y || n < 0) return TT_E_BADARG;
+    if ((((uintptr_t)b | (uintptr_t)y | (uintptr_t)a) & 15) != 0) return TT_E_BADARG;        // 16-byte accesses
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_scaled_add16, dim3(grid1d((n + 7) / 8, 256, 4096)), dim3(256), 0, tt_stream(stream), (const __bf16*)a,
+                       (const __bf16*)b, s, idx, (__bf16*)y, (long)(n / 8), (long)n);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tt_dot16(const void* a, const void* b, float* out, int64_t n, void* stream) {
+    if (!a || !b || !out || n < 0) return TT_E_BADARG;
+    if ((((uintptr_t)a | (uintptr_t)b) & 15) != 0) return TT_E_BADARG;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_dot16, dim3(grid1d((n + 7) / 8, 256 * 4, 1024)), dim3(256), 0, tt_stream(stream), (const __bf16*)a,
+                       (const __bf16*)b, out, (long)(n / 8), (long)n);
     TT_LAUNCH_CHECK();
     return 0;
 }

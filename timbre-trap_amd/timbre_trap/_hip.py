@@ -80,6 +80,8 @@ _PROTOS = {
     'tt_scaled_add': (c_int, [P, P, P, I, P, L, P]),
     'tt_window_ola': (c_int, [P, P, P, L, I, I, I, L, P]),
     'tt_dot': (c_int, [P, P, P, L, P]),
+    'tt_scaled_add16': (c_int, [P, P, P, I, P, L, P]),
+    'tt_dot16': (c_int, [P, P, P, L, P]),
     'tt_sqdiff_sum': (c_int, [P, P, P, P, L, F_, P]),
     'tt_sqdiff_bwd': (c_int, [P, P, P, F_, P, P, L, P]),
     'tt_activations_fwd': (c_int, [P, P, I, I, I, P]),

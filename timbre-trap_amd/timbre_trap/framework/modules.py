@@ -253,9 +253,15 @@ class TimbreTrap(nn.Module):
             c1 = min(n_chunks, c0 + per_pass)
             batch = chunks[:, :, c0:c1].permute(2, 0, 1, 3).reshape((c1 - c0) * B, 1, block)
             out = self._inference(batch, transcribe)                  # ((c1 - c0) * B, 2, F, M), chunk-major
+            out = out.float().contiguous()                            # the kernel reads contiguous fp32 chunks (a no-op for the stock decoder)
             # out[b, :, :, i*M/2 : i*M/2 + M] += window * chunk_i, ascending i: the reference's accumulation order (tt_window_ola)
-            _hip.check(lib.tt_window_ola(_hip.ptr(out), _hip.ptr(window), _hip.ptr(coefficients), B * 2 * F, M, c0, c1, n_frames,
-                                         _hip.stream_ptr()), 'tt_window_ola')
+            if M % 8 == 0 and n_frames % 4 == 0:
+                _hip.check(lib.tt_window_ola(_hip.ptr(out), _hip.ptr(window), _hip.ptr(coefficients), B * 2 * F, M, c0, c1, n_frames,
+                                             _hip.stream_ptr()), 'tt_window_ola')
+            else:       # frame counts the kernel's 16-byte accesses do not cover: the same sums as strided adds, same order
+                out = out.view(c1 - c0, B, 2, F, M)
+                for i in range(c0, c1):
+                    coefficients[..., i * (M // 2): i * (M // 2) + M] += window * out[i - c0]
         return coefficients[..., M // 2: -M // 2]
 
     def to_activations(self, coefficients):

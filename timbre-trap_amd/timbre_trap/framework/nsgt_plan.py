@@ -36,7 +36,13 @@ class NSGTConventions:
       dual             'floored'   canonical dual g_k / D where the frame-operator diagonal D > frame_floor, 0 elsewhere
                        | 'canonical'  g_k / D wherever D > 0 (exact inverse on the covered band; amplifies coefficient noise by up
                          to ~6e4 at the few indices only the tail of one window reaches)
+                       | 'additive'  g_k / (D + dual_eps) wherever any window reaches -- the regularised inverse some NSGT
+                         implementations use instead of a floor (a plausible cqt_pytorch form, unverified)
       min_length       lower bound of L_k (1: the lowest bins keep a one-sample window)
+
+    The frame-operator diagonal D is taken over the positive-frequency windows only: with every window inside the OPEN positive
+    half-spectrum (build_plan raises otherwise) the mirrored negative-frequency windows of a real signal never reach an index
+    of that half, so a diagonal that includes them is the same table -- that candidate form needs no switch here.
     """
     window: str = 'hann_periodic'
     length_rounding: str = 'round'
@@ -45,6 +51,7 @@ class NSGTConventions:
     dual: str = 'floored'
     frame_floor: float = FRAME_FLOOR
     min_length: int = 1
+    dual_eps: float = 1e-8
 
     def replace(self, **kw):
         return replace(self, **kw)
@@ -111,10 +118,11 @@ def build_plan(n_octaves, bins_per_octave, sample_rate, block_length, power_of_2
     # 'floored' (default): indices whose total window energy is below the floor are not synthesised (band edges: the
     # canonical dual 1/w would reach ~6e4 there and amplify coefficient noise into audible sinusoids); 'canonical': every
     # index any window reaches is inverted exactly
-    if cv.dual not in ('floored', 'canonical'):
+    if cv.dual not in ('floored', 'canonical', 'additive'):
         raise ValueError('unknown dual window rule %r' % (cv.dual,))
     covered = diag > (cv.frame_floor if cv.dual == 'floored' else 0.0)
-    dual = np.where(covered[spec_index], window / np.where(covered, diag, 1.0)[spec_index], 0.0)
+    denom = diag + cv.dual_eps if cv.dual == 'additive' else np.where(covered, diag, 1.0)
+    dual = np.where(covered[spec_index], window / denom[spec_index], 0.0)
 
     # CSR: spectral index j -> ragged positions that land on it (deterministic overlap-add)
     order = np.argsort(spec_index, kind='stable')

@@ -173,7 +173,7 @@ class ConvFn(torch.autograd.Function):
 
 def conv(x, w, b, cfg):
     same3 = (cfg.kind == 'conv' and (cfg.KH, cfg.KW, cfg.stride, cfg.dil, cfg.pad_h, cfg.pad_w) == (3, 3, 1, 1, 1, 1) and b is not None
-             and x.dim() == 4 and x.size(3) % 2 == 0 and FUSED_RESBLOCK)
+             and x.dim() == 4 and x.size(3) % 2 == 0 and FUSED_RESBLOCK and x.size(2) * x.size(3) * 4 < 2 ** 31)
     if same3 and cfg.act == ACT_ELU and w.shape == (4, 2, 3, 3) and not is_cl16(x) and wide_storage() == 'bf16':
         return ConvIn16Fn.apply(x, w, b)                         # Encoder.convin feeding the bf16 channels-last interior
     if same3 and cfg.act == ACT_NONE and w.shape == (2, 4, 3, 3) and is_cl16(x):
@@ -232,6 +232,10 @@ def _grad_target(p):
     and no ``grad += new`` launch per parameter use (~740 five-microsecond launches per train step).  Any other tensor
     gets a fresh zero buffer that is returned as usual.
     """
+    if not p.requires_grad:
+        # a parameter frozen after the optimizer tagged it: the kernels still need somewhere to write, but nothing may reach the
+        # flat gradient buffer (it would be clipped, averaged and applied) and autograd wants no gradient for it
+        return torch.zeros(p.shape, dtype=torch.float32, device=p.device), None
     g = p.grad if getattr(p, '_ttrap_accumulate', False) else None
     if g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.shape == p.shape and g.device == p.device:
         return g, None
@@ -338,7 +342,8 @@ def _stride16_ok(C, T, w, b):
 def strided_conv(x, w, b, win, hop):
     """Conv2d(C, Cout, (win,1), stride (hop,1)) + ELU."""
     C = x.size(1)
-    if win == 4 and hop == 2 and x.size(2) >= 4 and _stride16_ok(C, x.size(-1), w, b) and (is_cl16(x) or wide_storage() == 'bf16'):
+    if (win == 4 and hop == 2 and x.size(2) >= 4 and _stride16_ok(C, x.size(-1), w, b) and (is_cl16(x) or wide_storage() == 'bf16')
+            and _i32_ok(x, 2 * C)):
         return SConv16Fn.apply(to_cl16(x), w, b)
     x = to_planar32(x)
     if FUSED_RESBLOCK and win == 4 and hop == 2 and C in FUSED_CHANNELS and w.shape == (2 * C, C, 4, 1) and b is not None:
@@ -350,7 +355,7 @@ def transposed_conv(x, w, b, win, hop, out_pad):
     """ConvTranspose2d(Cin, C, (win,1), stride (hop,1), output_padding (out_pad,0)) + ELU."""
     C = w.size(1)
     if (win == 4 and hop == 2 and x.size(1) == 2 * C and out_pad in (0, 1) and _stride16_ok(C, x.size(-1), w, b)
-            and (is_cl16(x) or wide_storage() == 'bf16')):
+            and (is_cl16(x) or wide_storage() == 'bf16') and (2 * x.size(2) + 2 + out_pad) * x.size(3) * 2 * C < 2 ** 31):
         return TConv16Fn.apply(to_cl16(x), w, b, out_pad)
     x = to_planar32(x)
     if (FUSED_RESBLOCK and win == 4 and hop == 2 and C in FUSED_CHANNELS and w.shape == (2 * C, C, 4, 1)
@@ -406,6 +411,12 @@ def _unpack(x16):
 
 def _cl16_ok(C, T):
     return C in CL16_CHANNELS and (C != 4 or T % 2 == 0)
+
+
+def _i32_ok(x, channels=None):
+    """The bf16 kernels index one clip with 32-bit offsets (shape_ok / ok_shape / edge_ok in csrc/): H * T * channels < 2^31.
+    Longer one-shot inputs take the fp32 planar path like every other unsupported shape instead of raising TT_E_BADARG."""
+    return x.size(2) * x.size(3) * (channels or x.size(1)) < 2 ** 31
 
 
 def _as_cl16(t):
@@ -517,10 +528,13 @@ class ConvOut16Fn(torch.autograd.Function):
 LEVEL_CHUNK = int(os.environ.get('TTRAP_LEVEL_CHUNK', '0'))
 
 
-# Residual blocks whose backward recomputes the hidden activation inside ONE fused pass (csrc/conv_level_bf16.hip,
-# tt_wide_rb_bwd_fused): the forward stores no h1 and dL/d(conv1 pre-activation) never reaches HBM -- 5 tensor passes per block
-# (x, y | x, dy, dx) instead of 11.  TTRAP_LEVEL_RECOMPUTE=0 restores the per-stage kernels with the saved h1.
-RECOMPUTE_CHANNELS = (16, 32) if os.environ.get('TTRAP_LEVEL_RECOMPUTE', '1') != '0' else ()
+# TTRAP_LEVEL_RECOMPUTE=1: the residual blocks of the wide levels (C = 16, 32) run their backward as ONE fused pass that
+# recomputes the hidden activation per tile (csrc/conv_level_bf16.hip, tt_wide_rb_bwd_fused): the forward stores no h1 and
+# dL/d(conv1 pre-activation) never reaches HBM -- 5 tensor passes per block (x, y | x, dy, dx) instead of 11, and a third less saved
+# activation memory at those levels (52.6 -> 42.7 GB peak for the 64-clip step).  Measured (round 3): the fused pass is bound by
+# vector-ALU issue, not by HBM (0.52-1.1 ms per block against 0.47-0.52 ms for the three per-stage kernels; step 69.3 -> 76.6 ms),
+# so it is the memory-saving option, not the default.
+RECOMPUTE_CHANNELS = (16, 32) if os.environ.get('TTRAP_LEVEL_RECOMPUTE', '0') == '1' else ()
 
 
 def _chunks(B):
@@ -716,17 +730,62 @@ class WideLevelFn(torch.autograd.Function):
         return (dx, None, *grads)
 
 
+class Add16Fn(torch.autograd.Function):
+    """a + b on cl16 tensors (the skip joins of the bf16 path; csrc/conv_generic.hip: tt_scaled_add16)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        B, C, H, T = a.shape
+        y = new_cl16(B, C, H, T, a.device)
+        check(_hip.lib().tt_scaled_add16(ptr(a), ptr(b), None, 0, ptr(y), a.numel(), stream_ptr()), 'tt_scaled_add16')
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        g = _as_cl16(dy)
+        return g, g
+
+
+class Scale16Fn(torch.autograd.Function):
+    """s[idx] * e on a cl16 tensor (TimbreTrap.apply_skip_connections, reference modules.py:112) -- fp32 weight, bf16 tensor."""
+
+    @staticmethod
+    def forward(ctx, e, s, idx):
+        B, C, H, T = e.shape
+        s = _f32c(s)
+        y = new_cl16(B, C, H, T, e.device)
+        check(_hip.lib().tt_scaled_add16(None, ptr(e), ptr(s), idx, ptr(y), e.numel(), stream_ptr()), 'tt_scaled_add16')
+        ctx.idx = idx
+        ctx.save_for_backward(e, s)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        e, s = ctx.saved_tensors
+        g = _as_cl16(dy)
+        lib, st = _hip.lib(), stream_ptr()
+        de = ds = None
+        if ctx.needs_input_grad[0]:
+            B, C, H, T = e.shape
+            de = new_cl16(B, C, H, T, e.device)
+            check(lib.tt_scaled_add16(None, ptr(g), ptr(s), ctx.idx, ptr(de), e.numel(), st), 'tt_scaled_add16')
+        if ctx.needs_input_grad[1]:
+            ds = torch.zeros_like(s)
+            check(lib.tt_dot16(ptr(g), ptr(e), _off(ds, ctx.idx), e.numel(), st), 'tt_dot16')
+        return de, ds, None
+
+
 def add(a, b):
-    """a + b for the skip joins: cl16 when either side is (torch's elementwise add keeps the layout), AddFn otherwise."""
+    """a + b for the skip joins: on cl16 tensors when either side is one (Add16Fn), AddFn otherwise."""
     if is_cl16(a) or is_cl16(b):
-        return to_cl16(a) + to_cl16(b)
+        return Add16Fn.apply(to_cl16(a), to_cl16(b))
     return AddFn.apply(a, b)
 
 
 def scale(e, weights, i):
     """weights[i] * e (TimbreTrap.apply_skip_connections)."""
     if is_cl16(e):
-        return e * weights[i]
+        return Scale16Fn.apply(e, weights, i)
     return ScaleFn.apply(e, weights, i)
 
 
@@ -737,7 +796,7 @@ def residual_level(x, blocks):
     to_planar32; otherwise the per-block fp32 path.
     """
     C, T = x.size(1), x.size(-1)
-    if (wide_storage() == 'bf16' and C in WIDE_CHANNELS and FUSED_RESBLOCK and (C != 4 or T % 2 == 0)
+    if (wide_storage() == 'bf16' and C in WIDE_CHANNELS and FUSED_RESBLOCK and (C != 4 or T % 2 == 0) and _i32_ok(x)
             and all(b.conv1[0].weight.shape == (C, C, 3, 3) and 1 <= b.dilation <= 3 for b in blocks)):
         params = []
         for b in blocks:

@@ -61,9 +61,13 @@ class GradientSync:
         self.world = world_size
         self.work = None
 
-    def start(self, flat_grad):
+    def start(self, grads):
+        """``grads``: a FusedAdamW (preferred: its detached gradient views are re-attached first, so that a gradient autograd
+        deposited into a fresh tensor after ``model.zero_grad()`` is in the flat buffer BEFORE it is averaged) or the flat
+        gradient buffer itself (the caller then vouches that every ``p.grad`` still is its view)."""
         if self.work is not None:
             raise RuntimeError('GradientSync.start called twice without finish')
+        flat_grad = grads.sync_views() if hasattr(grads, 'sync_views') else grads
         self.work = allreduce_gradients(flat_grad, self.world, async_op=True)
         return self.work
 
@@ -90,6 +94,11 @@ class DataParallel(torch.nn.DataParallel):
 
     def __init__(self, module, device_ids=None, output_device=None, dim=0):
         torch.nn.Module.__init__(self)          # not DataParallel.__init__: no device bookkeeping, no replication
+        if device_ids is not None and len(device_ids) > 1:
+            import warnings
+            warnings.warn('timbre_trap DataParallel holds ONE replica per process: device_ids=%s is ignored and this process uses '
+                          'one GPU only.  For %d GPUs launch one process per GPU (torchrun --nproc-per-node %d) -- see INTEGRATION.md.'
+                          % (list(device_ids), len(device_ids), len(device_ids)), RuntimeWarning, stacklevel=2)
         self.module = module
         self.device_ids = []
         self.output_device = None

@@ -76,6 +76,16 @@ class FusedAdamW(torch.optim.Optimizer):
                 p.data = self.flat_param[o:o + k].view_as(p)
             p._ttrap_accumulate = True
 
+    def sync_views(self):
+        """
+        Public form of the re-attachment: call it (or anything below that does: ``grad_norm``, ``step``, ``GradientSync.start(opt)``)
+        BEFORE reading ``flat_grad`` whenever ``model.zero_grad()`` / ``p.grad = None`` may have detached a gradient view since
+        the last step -- in particular before the data-parallel all-reduce, which must see this step's gradient in the flat
+        buffer, not the stale slot.  Returns the flat gradient buffer.
+        """
+        self._reattach()
+        return self.flat_grad
+
     def state_dict(self):
         """Moments and step count included (they live in flat buffers, outside ``Optimizer.state``)."""
         sd = super().state_dict()
@@ -103,6 +113,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 p.grad = self.flat_grad[o:o + k].view_as(p)
 
     def grad_norm(self):
+        self._reattach()
         _hip.check(_hip.lib().tt_l2norm(_hip.ptr(self.flat_grad), _hip.ptr(self.norm), _hip.ptr(self._partials), self.n,
                                         _hip.stream_ptr()), 'tt_l2norm')
         return self.norm

@@ -90,6 +90,23 @@ def main():
         print('MATCH: set nsgt_plan.DEFAULT_CONVENTIONS to', results[0][1], '(then compare decode() for the dual rule: tests/test_cqt_pin.py)')
     else:
         print('no combination reproduces cqt_pytorch to 1e-6: the convention space needs another switch (closest above).')
+    # synthesis side: with the best analysis conventions, which dual-window rule reproduces decode(encode(x))?
+    best = results[0][1]
+    wantb = back.numpy().astype(np.float64)[0, 0]
+    duals = []
+    for rule in (dict(dual='canonical'), dict(dual='floored', frame_floor=1e-3), dict(dual='additive', dual_eps=1e-8),
+                 dict(dual='additive', dual_eps=1e-6), dict(dual='additive', dual_eps=1e-12)):
+        try:
+            t = DenseNSGT(9, 60, SR, N, conventions=dict(best, **rule))
+            gotb = t.decode(c.astype(np.complex128))[0, 0]
+        except (ValueError, AttributeError) as e:
+            duals.append((np.inf, rule, str(e)))
+            continue
+        duals.append((float(np.abs(gotb - wantb).max() / (np.abs(wantb).max() + 1e-30)), rule, ''))
+    duals.sort(key=lambda r: r[0])
+    print('dual-window rules ranked by max |oracle decode - cqt_pytorch decode| / max:')
+    for err, rule, note in duals:
+        print('  %.3e  %s %s' % (err, rule, note))
     return 0
 
 

@@ -31,6 +31,7 @@ Prints ONE JSON line on rank 0 with the driver's fields plus
   "whole_step"        : algorithmic conv FLOPs of the step / ms_per_step against the fp32 and the bf16 matrix peaks
   "overlap"           : N > 1 only: event timestamps of one instrumented step -- how long the compute stream still had to wait for
                         the all-reduce AFTER it had finished the next batch's CQT (0 = the collective was hidden entirely)
+  "skip_connections_step" : the same step with skip_connections=True (the model of BASELINE.json configs[4]), N = 1
   "inference_config1" : BASELINE.json configs[1] (transcribe() + reconstruct(), 32 clips) timed in the same run, N = 1
   "cpu_baseline"      : the CPU oracle (kind "port") on a bounded sample of the SAME workload (model_complexity 2; rank 0, N = 1)
   "cpu_baseline_config0" : BASELINE.json configs[0] on the oracle: model_complexity 1, one clip, CQT forward + inverse + one step
@@ -77,11 +78,11 @@ def synthetic_batch(batch, rank, device='cpu'):
     return audio.to(device), target.to(device)
 
 
-def build_model(mc, latent, device, seed=2):
+def build_model(mc, latent, device, seed=2, skip=False):
     from timbre_trap.framework import TimbreTrap
     torch.manual_seed(seed)                       # reference experiments/train.py:88,137
     return TimbreTrap(sample_rate=SR, n_octaves=9, bins_per_octave=60, secs_per_block=3,
-                      latent_size=latent, model_complexity=mc, skip_connections=False).to(device)
+                      latent_size=latent, model_complexity=mc, skip_connections=skip).to(device)
 
 
 def make_train_step(model, opt, world, overlap=True, autocast=True):
@@ -618,6 +619,24 @@ def main():
             ops.PRECISION = prev
             fp32_step = dict(ms_per_step=f_ms, value=args.batch * SECS_PER_CLIP / (f_ms * 1e-3), unit='audio-seconds/s', dtype='f32',
                              steps=4, warmup=2, peak_memory_gb=torch.cuda.max_memory_allocated() / 1e9, note='same step with ops.PRECISION = fp32 (no autocast): bit-exact fp32 MFMA path')
+        skip_step = None
+        if world == 1 and not args.timed_only and args.precision == 'auto':
+            # BASELINE configs[4] trains with skip_connections=True: the same step with the five weighted skip joins (cl16 joins on the
+            # device: tt_scaled_add16 / tt_dot16), secondary figure
+            s_model = build_model(args.mc, args.latent, dev, skip=True)
+            s_opt = FusedAdamW(s_model.parameters(), lr=1e-3, max_norm=10.0)
+            s_step = make_train_step(s_model, s_opt, world, overlap=False, autocast=True)
+            for _ in range(2):
+                s_step(audio, target)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(6):
+                s_step(audio, target)
+            torch.cuda.synchronize()
+            s_ms = 1000.0 * (time.perf_counter() - t1) / 6
+            skip_step = dict(ms_per_step=s_ms, value=args.batch * SECS_PER_CLIP / (s_ms * 1e-3), unit='audio-seconds/s', dtype='bf16', steps=6,
+                             warmup=2, note='the same train step with skip_connections=True (BASELINE configs[4] model)')
+            del s_model, s_opt, s_step
         base = base0 = None
         if not args.no_cpu_baseline and not args.timed_only and world == 1:
             base = cpu_baseline(args.mc, args.latent)
@@ -632,7 +651,7 @@ def main():
                                             if args.precision == 'auto' else ''),
                                 global_batch=world * args.batch, parallelism='dp%d' % world),
                     roofline=roof, roofline_fwd=roof_fwd if roof_fwd is not roof else None, roofline_cqt=cqt, roofline_cqt_inv=cqt_inv, families=families, whole_step=whole,
-                    peak_memory_gb=peak_gb, inference_config1=infer, fp32_train_step=fp32_step, per_rank_ms=per_rank_ms, allreduce_ms=allreduce_ms, overlap=overlap_info, cpu_baseline=base, cpu_baseline_config0=base0,
+                    peak_memory_gb=peak_gb, inference_config1=infer, fp32_train_step=fp32_step, skip_connections_step=skip_step, per_rank_ms=per_rank_ms, allreduce_ms=allreduce_ms, overlap=overlap_info, cpu_baseline=base, cpu_baseline_config0=base0,
                     final_loss=float(total.detach()))
         print(json.dumps(line))
     if world > 1:

@@ -84,6 +84,10 @@ __device__ __forceinline__ void store_lane(__bf16* out, long pix, int g, const f
     }
 }
 
+// The next group's rows are requested before this group's products (PF) -- except at C = 32, where the 64 VGPRs of weights plus
+// two sets of six 16-byte pieces (and their gates) put the kernel at 240-276 registers = one or two waves per SIMD; without the second
+// set it is 160-208 and the waves cover each other instead (round 3, library A/B: tconv C = 32 forward 0.145 -> 0.120 ms, backward
+// 0.520 -> 0.487 ms, sconv backward 0.456 -> 0.426 ms).
 template <int C, bool GATE, bool ACT>
 __global__ __launch_bounds__(NT) void k_s4(const __bf16* __restrict__ in, const __bf16* __restrict__ gy,
                                             const float* __restrict__ w, const float* __restrict__ bias,
@@ -127,9 +131,10 @@ __global__ __launch_bounds__(NT) void k_s4(const __bf16* __restrict__ in, const 
     const long gstride = (long)gridDim.x * 4;
     long grp = (long)blockIdx.x * 4 + wave;
     vec_t bq[NPC], bn[NPC];
-    fetch(grp, bq);
+    constexpr bool PF = C != 32;      // C = 32: no double buffer -- 64 VGPRs of weights leave no room for it (see the note at k_s4)
+    if (PF) fetch(grp, bq);
     for (; grp < ngroups; grp += gstride) {
-        fetch(grp + gstride, bn);                                // next group's rows are in flight during this one's products
+        if (PF) fetch(grp + gstride, bn); else fetch(grp, bq);   // next group's rows are in flight during this one's products
         const int tblk = (int)(grp % tb);
         const long bh = grp / tb;
         const int m = (int)(bh % Hg), b = (int)(bh / Hg);
@@ -155,8 +160,10 @@ __global__ __launch_bounds__(NT) void k_s4(const __bf16* __restrict__ in, const 
                 }
             store_lane<COUT, NCH>(out, ((long)b * Hout + ho) * T + t, g, v, ok && ho < Hout);
         }
+        if (PF) {
 #pragma unroll
         for (int j = 0; j < NPC; ++j) bq[j] = bn[j];
+        }
     }
 }
 
@@ -212,9 +219,10 @@ __global__ __launch_bounds__(NT) void k_p2(const __bf16* __restrict__ in, const 
     const long gstride = (long)gridDim.x * 4;
     long grp = (long)blockIdx.x * 4 + wave;
     vec_t bq[S::NS], bn[S::NS];
-    fetch(grp, bq);
+    constexpr bool PF = C != 32;      // C = 32: no double buffer -- 64 VGPRs of weights leave no room for it (see the note at k_s4)
+    if (PF) fetch(grp, bq);
     for (; grp < ngroups; grp += gstride) {
-        fetch(grp + gstride, bn);                                // next group's rows are in flight during this one's products
+        if (PF) fetch(grp + gstride, bn); else fetch(grp, bq);   // next group's rows are in flight during this one's products
         const int tblk = (int)(grp % tb);
         const long bm = grp / tb;
         const int m = (int)(bm % Hp), b = (int)(bm / Hp);
@@ -240,8 +248,10 @@ __global__ __launch_bounds__(NT) void k_p2(const __bf16* __restrict__ in, const 
                 }
             store_lane<C, NCH>(out, ((long)b * Hout + h) * T + t, g, v, ok && h < Hout);
         }
+        if (PF) {
 #pragma unroll
         for (int j = 0; j < S::NS; ++j) bq[j] = bn[j];
+        }
     }
 }
 

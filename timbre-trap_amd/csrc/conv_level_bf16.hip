@@ -23,21 +23,6 @@
 
 namespace {
 
-template <int C> __device__ __forceinline__ int fswz(int col) {
-    return C == 32 ? ((((col >> 2) & 1) << 1) | ((col >> 3) & 1)) : ((col >> 3) & 1);
-}
-
-// Weights in MFMA operand order, bf16, written once per call by k_lvl_wprep:
-//   [wf: NK x NCT x 64 lanes][wb: the same for the data gradient][w2a: NCT x 64][w2t: NCT x 64]     (16 bytes per lane)
-template <int C> struct WK {
-    static constexpr int NCT = C / 16;
-    static constexpr int NK = C == 32 ? 9 : 5;                   // products per co-tile: one tap (C = 32) / two taps (C = 16)
-    static constexpr int NCH = C == 32 ? 8 : 4;                  // channels a lane ends up with
-    static constexpr int W3 = NK * NCT * 64;
-    static constexpr int ENTRIES = 2 * W3 + 2 * NCT * 64;
-    static constexpr int IMG_BYTES = ENTRIES * 16;
-};
-
 template <int C>
 __global__ __launch_bounds__(64) void k_lvl_wprep(const float* __restrict__ w1, const float* __restrict__ w2, bf16x8* __restrict__ img) {
     using K = WK<C>;
@@ -89,26 +74,6 @@ template <int C, int D, int TH, int TW, int NW> struct FB {
     static_assert(NW * ADUMP * 4 <= X_BYTES, "final dump reduction reuses the x image");
     static_assert(TW % 32 == 0, "the K = 32 pixels of a weight-gradient product are 32 consecutive columns");
 };
-
-// 3x3 dilated product on one 16-pixel group: the lane's pixel has its top-left tap at image pixel (row, col); `img` is a
-// channel-innermost LDS image IW pixels wide in the fswz layout.
-template <int C, int D, int IW>
-__device__ __forceinline__ void conv_taps(const unsigned char* img, int row, int col, int g,
-                                          const bf16x8 (&A)[WK<C>::NK][WK<C>::NCT], f32x4 (&acc)[WK<C>::NCT], bf16x8& centre) {
-    constexpr int NK = WK<C>::NK, NCT = WK<C>::NCT, PB = C * 2;
-    const int gsel = C == 32 ? g : (g & 1);
-#pragma unroll
-    for (int k = 0; k < NK; ++k) {
-        int tap = C == 32 ? k : 2 * k + (g >> 1);
-        if (tap > 8) tap = 8;                                    // the weights of the missing tenth tap are zero
-        const int kh = tap / 3, kw = tap - 3 * kh;
-        const int xc = col + kw * D;
-        const bf16x8 bq = *reinterpret_cast<const bf16x8*>(img + ((row + kh * D) * IW + xc) * PB + 16 * (gsel ^ fswz<C>(xc)));
-        if (C == 32 && k == 4) centre = bq;
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) acc[ct] = mma32(A[k][ct], bq, acc[ct]);
-    }
-}
 
 template <int C, int D, int TH, int TW, int NW>
 __global__ __launch_bounds__(NW * 64, C == 32 ? 2 : 3) void k_wrb_bwd_fused(const __bf16* __restrict__ x, const __bf16* __restrict__ dy,

@@ -514,6 +514,144 @@ __global__ __launch_bounds__(NT) void k_wrb_wgrad(const __bf16* __restrict__ x, 
             for (int r = 0; r < 4; ++r) pw[((k * NA + a) * 4 + r) * 64 + lane] = acc[k][a][r];
 }
 
+// ---- data gradient and weight gradient in ONE pass -----------------------------------------------------------------------
+// k_wrb_conv<..,1> and k_wrb_wgrad both stage the dA1 tile; here it is staged once, next to the x tile, in the layout that serves
+// both access patterns (fswz, wide_common.h): dx = dy + W1^T (*)_D dA1 over the tile by B-operand reads, then
+// dW1[co][ci][tap] += dA1 (x) x(+tap) by transpose reads of the same two images.  dA1 is read from HBM once instead of twice:
+// four tensor passes (dA1, dy, x | dx) for what took five, and one launch less.  No halo beyond D, no recomputation -- the vector
+// work is the sum of the two kernels minus one staging loop (PMC, round 3: both were parked on memory 40-67 % of their life).
+template <int C, int D, int TH, int TW> struct DXW {
+    static constexpr int CG = C / 8, PB = C * 2;
+    static constexpr int IR = TH + 2 * D, IW = TW + 2 * D;       // both images: tile + D halo
+    static constexpr int NP = IR * IW * CG;
+    static constexpr int NPR = (NP + NT - 1) / NT * NT;
+    static constexpr int IMG_BYTES = NPR * 16;
+    static constexpr int LDS_BYTES = 2 * IMG_BYTES;
+    static constexpr int WDUMP = 9 * (C / 16) * 256;
+    static_assert(TW % 32 == 0, "the K = 32 pixels of a weight-gradient product are 32 consecutive columns");
+};
+
+template <int C, int D, int TH, int TW>
+__global__ __launch_bounds__(NT, 2) void k_wrb_dxw(const __bf16* __restrict__ x, const __bf16* __restrict__ da1, const __bf16* __restrict__ dy,
+                                                   const float* __restrict__ w1, __bf16* __restrict__ dx, float* __restrict__ part_w, int B,
+                                                   int H, int T, int tiles_h, int tiles_t, int ntiles) {
+    using G = DXW<C, D, TH, TW>;
+    using K = WK<C>;
+    constexpr int NCT = K::NCT, NK = K::NK, NCH = K::NCH, PB = G::PB;
+    typedef typename std::conditional<C == 32, bf16x8, bf16x4>::type vec_t;
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char* gs = smem;                                    // dA1
+    unsigned char* xs = smem + G::IMG_BYTES;                     // x
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4, trj = n >> 2, trq = n & 3;
+
+    // data-gradient weights (transposed, taps reversed), bf16, in registers for the whole launch
+    bf16x8 A[NK][NCT];
+#pragma unroll
+    for (int k = 0; k < NK; ++k)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                int tap, kc;
+                if (C == 32) { tap = k; kc = 8 * g + j; }
+                else { tap = 2 * k + (g >> 1); kc = 8 * (g & 1) + j; }
+                v[j] = tap < 9 ? w1[(kc * C + chan_of<C>(ct, n)) * 9 + (8 - tap)] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) A[k][ct][j] = (__bf16)v[j];
+        }
+    // weight-gradient roles (as in k_wrb_bwd_fused): C = 32: wave = (ci-tile wave & 1, co-tile wave >> 1), all rows and chunks;
+    // C = 16: the waves split the 32-column chunks, then the rows
+    constexpr int NCHK = TW / 32;
+    static_assert(C == 32 || (4 % NCHK == 0), "wave roles");
+    const int cit = C == 32 ? (wave & 1) : 0, aw = C == 32 ? (wave >> 1) : 0;
+    const int ch0 = C == 32 ? 0 : wave % NCHK, rpar = C == 32 ? 0 : wave / NCHK;
+    constexpr int CHSTEP = C == 32 ? 1 : NCHK, RSTEP = C == 32 ? 1 : 4 / NCHK;
+    f32x4 wacc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wacc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const __bf16* zero = reinterpret_cast<const __bf16*>(&g_wzero16);
+    for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
+        int tile = xcd_order(v, ntiles);
+        const int tt = tile % tiles_t; tile /= tiles_t;
+        const int th = tile % tiles_h;
+        const int b = tile / tiles_h, h0 = th * TH, t0 = tt * TW;
+        const long ib = (long)b * H * T * C;
+        __syncthreads();                                         // the previous tile has been consumed
+        for (int i = wave * 64; i < G::NPR; i += NT) {
+            const int p = i + lane, q = p / G::CG, s = p - q * G::CG;
+            const int row = q / G::IW, px = q - row * G::IW;
+            const int h = h0 - D + row, t = t0 - D + px;
+            const bool ok = p < G::NP && (unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T;
+            const long off = ib + ((long)h * T + t) * C + (s ^ fswz<C>(px)) * 8;
+            glds16(ok ? da1 + off : zero, gs + (long)i * 16);
+            glds16(ok ? x + off : zero, xs + (long)i * 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        // ---- dx = dy + W1^T (*) dA1 over the tile's own pixels ----
+        constexpr int GPRW = TW / 16;
+        for (int grp = wave; grp < TH * GPRW; grp += 4) {
+            const int r = grp / GPRW, c = (grp - r * GPRW) * 16 + n;
+            const int h = h0 + r;
+            if (h >= H) break;
+            const int t = t0 + c;
+            const bool valid = t < T;
+            const long pix = ((long)b * H + h) * T + t;
+            // unconditional (clamped) so that no branch pins a wait in front of the products
+            const vec_t rq = *reinterpret_cast<const vec_t*>(dy + (valid ? pix : pix - (t - (T - 1))) * C + NCH * g);
+            f32x4 acc[NCT];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            bf16x8 unused;
+            conv_taps<C, D, G::IW>(gs, r, c, g, A, acc, unused);
+            vec_t o;
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) o[j] = (__bf16)(acc[j >> 2][j & 3] + (float)rq[j]);
+            if (valid) *reinterpret_cast<vec_t*>(dx + pix * C + NCH * g) = o;
+        }
+
+        // ---- dW1, K = pixels: 32 consecutive columns of a row per product, both operands by transpose reads ----
+        for (int r = rpar; r < TH; r += RSTEP) {
+            if (h0 + r >= H) break;
+#pragma unroll
+            for (int ch = ch0; ch < NCHK; ch += CHSTEP) {
+                s16x4 lo, hi;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int cc = D + ch * 32 + 4 * g + trj + 16 * u;
+                    const s16x4 t4 = lds_tr16(gs + ((r + D) * G::IW + cc) * PB +
+                                              16 * (((C == 32 ? 2 * aw : 0) + (trq >> 1)) ^ fswz<C>(cc)) + 8 * (trq & 1));
+                    if (u == 0) lo = t4; else hi = t4;
+                }
+                const bf16x8 ga = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const int kh = k / 3, kw = k - 3 * kh;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int xc = kw * D + ch * 32 + 4 * g + trj + 16 * u;
+                        const s16x4 t4 = lds_tr16(xs + ((r + kh * D) * G::IW + xc) * PB +
+                                                  16 * (((C == 32 ? 2 * cit : 0) + (trq >> 1)) ^ fswz<C>(xc)) + 8 * (trq & 1));
+                        if (u == 0) lo = t4; else hi = t4;
+                    }
+                    const bf16x8 xq = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                    wacc[k] = mma32(ga, xq, wacc[k]);
+                }
+            }
+        }
+    }
+    float* pw = part_w + ((long)blockIdx.x * 4 + wave) * G::WDUMP;
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pw[((k * NCT + aw) * 4 + r) * 64 + lane] = wacc[k][r];   // C = 32: only this wave's co-tile (RedArgs::split_a)
+}
+
 // ---- launchers -------------------------------------------------------------------------------------------------------
 template <int C, int D, int MODE, bool SAVE>
 int launch_conv(const __bf16* x, const float* w1, const float* b1, const float* w2, const float* b2, const __bf16* res,
@@ -545,6 +683,26 @@ int launch_conv(const __bf16* x, const float* w1, const float* b1, const float* 
 
 template <int C> constexpr long dump_floats() { return (long)MAX_A_WG * WA<C>::DUMP + (long)MAX_W_WG * 4 * 9 * (C / 16) * 256; }
 
+template <int C, int D, int TH, int TW>
+int launch_dxw(const __bf16* x, const __bf16* da1, const __bf16* dy, const float* w1, __bf16* dx, float* part_w, float* part_a, int grid_a,
+               float* dw1, float* db1, float* dw2, float* db2, int B, int H, int T, hipStream_t st) {
+    using X = DXW<C, D, TH, TW>;
+    static AttrOnce once_x;
+    auto kx = k_wrb_dxw<C, D, TH, TW>;
+    if (int rc = raise_lds(kx, X::LDS_BYTES, once_x)) return rc;
+    const int tiles_h = (H + TH - 1) / TH, tiles_t = (T + TW - 1) / TW, ntiles = B * tiles_h * tiles_t;
+    static const int x_per_cu = env_int("TTRAP_DXW_PER_CU", C == 32 ? 3 : 4);      // registers: 165 / 113 VGPRs
+    int gx = grid_for(ntiles, X::LDS_BYTES, x_per_cu);
+    if (gx > MAX_W_WG) gx = MAX_W_WG;
+    hipLaunchKernelGGL(kx, dim3(gx), dim3(NT), X::LDS_BYTES, st, x, da1, dy, w1, dx, part_w, B, H, T, tiles_h, tiles_t, ntiles);
+    TT_LAUNCH_CHECK();
+    RedArgs ra{part_w, gx, part_a, grid_a, dw1, db1, dw2, db2, C == 32 ? 1 : 0};
+    constexpr int total = 9 * C * C + C * C + 2 * C;
+    hipLaunchKernelGGL(k_wrb_reduce<C>, dim3((total + REL - 1) / REL), dim3(1024), 0, st, ra);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int C, int D>
 int launch_bwd(const __bf16* x, const __bf16* h1, const __bf16* dy, const float* w1, const float* w2, const float* b2,
                __bf16* dx, float* dw1, float* db1, float* dw2, float* db2, unsigned char* ws, int B, int H, int T,
@@ -565,6 +723,16 @@ int launch_bwd(const __bf16* x, const __bf16* h1, const __bf16* dy, const float*
     if (grid > MAX_A_WG) grid = MAX_A_WG;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), G::LDS_BYTES, st, h1, dy, w2, b2, da1, part_a, npix, ngroups);
     TT_LAUNCH_CHECK();
+    // data gradient + weight gradient in one pass (TTRAP_DXW=0: the two separate kernels)
+    static const int dxw = env_int("TTRAP_DXW", 1);
+    if (dxw) {
+        // tiles 8 x 32 at both widths (round 3, per call at the bench shape, separate kernels -> merged: C = 32 0.486 / 0.485 / 0.521 ->
+        // 0.413 / 0.443 / 0.454 ms; C = 16 0.469 / 0.469 / 0.474 -> 0.430 / 0.431 / 0.451 ms; 8 x 64 tiles at C = 16 lose at
+        // dilation 2, 3 (0.50 ms: two workgroups per CU)); TTRAP_DXW_TH16=16 tries 16-row tiles at C = 16
+        static const int th16 = env_int("TTRAP_DXW_TH16", 8);
+        if (C == 16 && th16 == 16) return launch_dxw<C, D, 16, 32>(x, da1, dy, w1, dx, part_w, part_a, grid, dw1, db1, dw2, db2, B, H, T, st);
+        return launch_dxw<C, D, 8, 32>(x, da1, dy, w1, dx, part_w, part_a, grid, dw1, db1, dw2, db2, B, H, T, st);
+    }
     // data gradient
     if (int rc = launch_conv<C, D, 1, false>(da1, w1, nullptr, nullptr, nullptr, dy, dx, nullptr, B, H, T, st)) return rc;
     // weight gradient

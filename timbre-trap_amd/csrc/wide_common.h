@@ -9,6 +9,46 @@ namespace {
 // lane that owns D rows 4g..4g+3 of both tiles owns the eight CONSECUTIVE channels 8g..8g+7 (16 bytes).  C = 16: identity.
 template <int C> __device__ __forceinline__ int chan_of(int ct, int m) { return C == 32 ? 8 * (m >> 2) + 4 * ct + (m & 3) : m; }
 
+// ---- pieces of the tile kernels that keep TWO access patterns on one LDS image (conv_level_bf16.hip; k_wrb_dxw in conv_wide_bf16.hip)
+// The 16-byte channel group cg of the pixel in image column `col` sits at position cg ^ fswz(col).  C = 32: fswz = bit-reversed
+// (col >> 2) & 3, so that (i) the sixteen consecutive columns a k-group reads as B operand (ds_read_b128) cover all sixteen bank
+// quads and (ii) the eight consecutive pixels one half-wave addresses in a transpose read (ds_read_b64_tr_b16, 32 bytes of each)
+// use alternating 32-byte halves, for ANY column alignment (the taps shift the columns by multiples of D).  C = 16: (col >> 3) & 1.
+template <int C> __device__ __forceinline__ int fswz(int col) {
+    return C == 32 ? ((((col >> 2) & 1) << 1) | ((col >> 3) & 1)) : ((col >> 3) & 1);
+}
+
+// Weights in MFMA operand order, bf16, written once per call by k_lvl_wprep:
+//   [wf: NK x NCT x 64 lanes][wb: the same for the data gradient][w2a: NCT x 64][w2t: NCT x 64]     (16 bytes per lane)
+template <int C> struct WK {
+    static constexpr int NCT = C / 16;
+    static constexpr int NK = C == 32 ? 9 : 5;                   // products per co-tile: one tap (C = 32) / two taps (C = 16)
+    static constexpr int NCH = C == 32 ? 8 : 4;                  // channels a lane ends up with
+    static constexpr int W3 = NK * NCT * 64;
+    static constexpr int ENTRIES = 2 * W3 + 2 * NCT * 64;
+    static constexpr int IMG_BYTES = ENTRIES * 16;
+};
+
+// 3x3 dilated product on one 16-pixel group: the lane's pixel has its top-left tap at image pixel (row, col); `img` is a
+// channel-innermost LDS image IW pixels wide in the fswz layout.
+template <int C, int D, int IW>
+__device__ __forceinline__ void conv_taps(const unsigned char* img, int row, int col, int g,
+                                          const bf16x8 (&A)[WK<C>::NK][WK<C>::NCT], f32x4 (&acc)[WK<C>::NCT], bf16x8& centre) {
+    constexpr int NK = WK<C>::NK, NCT = WK<C>::NCT, PB = C * 2;
+    const int gsel = C == 32 ? g : (g & 1);
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        int tap = C == 32 ? k : 2 * k + (g >> 1);
+        if (tap > 8) tap = 8;                                    // the weights of the missing tenth tap are zero
+        const int kh = tap / 3, kw = tap - 3 * kh;
+        const int xc = col + kw * D;
+        const bf16x8 bq = *reinterpret_cast<const bf16x8*>(img + ((row + kh * D) * IW + xc) * PB + 16 * (gsel ^ fswz<C>(xc)));
+        if (C == 32 && k == 4) centre = bq;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc[ct] = mma32(A[k][ct], bq, acc[ct]);
+    }
+}
+
 constexpr int MAX_A_WG = 2048, MAX_W_WG = 1024;   // workgroups that leave dumps (bounds the scratch)
 inline int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 

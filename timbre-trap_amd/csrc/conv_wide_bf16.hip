@@ -728,9 +728,7 @@ int launch_bwd(const __bf16* x, const __bf16* h1, const __bf16* dy, const float*
     if (dxw) {
         // tiles 8 x 32 at both widths (round 3, per call at the bench shape, separate kernels -> merged: C = 32 0.486 / 0.485 / 0.521 ->
         // 0.413 / 0.443 / 0.454 ms; C = 16 0.469 / 0.469 / 0.474 -> 0.430 / 0.431 / 0.451 ms; 8 x 64 tiles at C = 16 lose at
-        // dilation 2, 3 (0.50 ms: two workgroups per CU)); TTRAP_DXW_TH16=16 tries 16-row tiles at C = 16
-        static const int th16 = env_int("TTRAP_DXW_TH16", 8);
-        if (C == 16 && th16 == 16) return launch_dxw<C, D, 16, 32>(x, da1, dy, w1, dx, part_w, part_a, grid, dw1, db1, dw2, db2, B, H, T, st);
+        // dilation 2, 3 (0.50 ms: two workgroups per CU); 16 x 32 tiles at C = 16: 0.431 / 0.439 / 0.496 ms)
         return launch_dxw<C, D, 8, 32>(x, da1, dy, w1, dx, part_w, part_a, grid, dw1, db1, dw2, db2, B, H, T, st);
     }
     // data gradient
@@ -1298,6 +1296,114 @@ __global__ __launch_bounds__(NT, C == 8 ? 2 : 1) void k_nrb_bwd_fused(const __bf
     for (int e = tid; e < ADUMP; e += NT) pa[e] = (red[e] + red[ADUMP + e]) + (red[2 * ADUMP + e] + red[3 * ADUMP + e]);
 }
 
+// ---- data gradient and weight gradient of a narrow block in one pass (the narrow counterpart of k_wrb_dxw) --------------------
+// Phases 2a / 2b of k_nrb_bwd_fused with dA1 coming from HBM (written by k_nrb_bwd_a) instead of being computed in place: the dA1
+// and x tiles (16 x 64 pixels + halo) are staged once, dx = dy + W1^T (*) dA1 by lane-per-pixel 4x4x4 products, dW1 by transpose reads
+// of 32-byte slots (k_nrb_wgrad's scheme; the two K halves are the two halves of a row at C = 8, two consecutive rows at C = 4).
+template <int C, int D>
+__global__ __launch_bounds__(NT) void k_nrb_dxw(const __bf16* __restrict__ x, const __bf16* __restrict__ da1, const __bf16* __restrict__ dy,
+                                                const float* __restrict__ w1, __bf16* __restrict__ dx, float* __restrict__ part_w, int B,
+                                                int H, int T, int tiles_h, int tiles_t, int ntiles) {
+    using G = NTl<C, D>;
+    typedef typename VecOf<C>::type vec_t;
+    constexpr int NB = C / 4, IMG = G::NPR * 16;
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char* hs = smem;                                    // dA1
+    unsigned char* xs = smem + IMG;                              // x
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i4 = lane & 3;
+    const int n = lane & 15, g = lane >> 4, trj = n >> 2, trq = n & 3;
+    s16x4 A[9][NB][NB];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) {
+                bf16x4 t4;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) t4[k] = (__bf16)w1[((4 * kb + k) * C + 4 * ob + i4) * 9 + (8 - tap)];
+                A[tap][ob][kb] = __builtin_bit_cast(s16x4, t4);
+            }
+    f32x4 wacc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wacc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const __bf16* zero = reinterpret_cast<const __bf16*>(&g_wzero16);
+    for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
+        int tile = xcd_order(v, ntiles);
+        const int tt = tile % tiles_t; tile /= tiles_t;
+        const int th = tile % tiles_h;
+        const int b = tile / tiles_h, h0 = th * G::TH, t0 = tt * G::TW;
+        const long ib = (long)b * H * T * C;
+        __syncthreads();
+        for (int i = wave * 64; i < G::NPR; i += NT) {
+            const int p = i + lane, q = p * G::PPP;
+            const int row = q / G::RW, px = q - row * G::RW;
+            const int h = h0 - D + row, t = t0 - G::DP + px;
+            const bool ok = p < G::NP && (unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T;
+            const long off = ib + ((long)h * T + t) * C;
+            glds16(ok ? da1 + off : zero, hs + (long)i * 16);
+            glds16(ok ? x + off : zero, xs + (long)i * 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        // ---- dx = dy + W1^T (*) dA1 ----
+        {
+            const int t = t0 + lane;
+            const bool valid = t < T;
+            for (int r = wave; r < G::TH; r += 4) {
+                const int h = h0 + r;
+                if (h >= H) break;
+                const long pix = ((long)b * H + h) * T + t;
+                const vec_t rq = *reinterpret_cast<const vec_t*>(dy + (valid ? pix : pix - (t - (T - 1))) * C);
+                f32x4 a4[NB];
+#pragma unroll
+                for (int ob = 0; ob < NB; ++ob) a4[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int kh = tap / 3, kw = tap - 3 * kh;
+                    const int pxi = (r + kh * D) * G::RW + G::DP + lane + (kw - 1) * D;
+                    const vec_t bq = *reinterpret_cast<const vec_t*>(hs + (long)pxi * G::PXB);
+#pragma unroll
+                    for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+                        for (int kb = 0; kb < NB; ++kb) a4[ob] = mma4(A[tap][ob][kb], chunk_of<C>(bq, kb), a4[ob]);
+                }
+                vec_t o;
+#pragma unroll
+                for (int c = 0; c < C; ++c) o[c] = (__bf16)(a4[c >> 2][c & 3] + (float)rq[c]);
+                if (valid) *reinterpret_cast<vec_t*>(dx + pix * C) = o;
+            }
+        }
+        // ---- dW1 ----
+        {
+            constexpr int ROWB = G::RW * G::PXB;                 // bytes of an image row
+            constexpr int RPS = C == 8 ? 1 : 2;                  // rows per product step
+            constexpr int UOFF = C == 8 ? 512 : ROWB;            // byte distance of the second K half
+            const int so = 32 * (4 * g + trj) + 8 * trq;
+            for (int r = wave * RPS; r < G::TH; r += 4 * RPS) {
+                if (h0 + r >= H) break;
+                const unsigned char* gp = hs + (long)(r + D) * ROWB + G::DP * G::PXB + so;
+                const s16x4 glo = lds_tr16(gp), ghi = lds_tr16(gp + UOFF);
+                const bf16x8 ga = __builtin_bit_cast(bf16x8, __builtin_shufflevector(glo, ghi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const int kh = k / 3, kw = k - 3 * kh;
+                    const unsigned char* xp = xs + (long)(r + kh * D) * ROWB + (G::DP + (kw - 1) * D) * G::PXB + so;
+                    const s16x4 lo = lds_tr16(xp), hi = lds_tr16(xp + UOFF);
+                    wacc[k] = mma32(ga, __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)), wacc[k]);
+                }
+            }
+        }
+    }
+    float* pw = part_w + ((long)blockIdx.x * 4 + wave) * (9 * 256);
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pw[(k * 4 + r) * 64 + lane] = wacc[k][r];
+}
+
 template <int C>
 __global__ __launch_bounds__(1024) void k_nrb_reduce(RedArgs ar) {
     constexpr int WDUMP = 9 * 256, ADUMP = C * C + 2 * C;
@@ -1391,6 +1497,25 @@ int launch_nbwd(const __bf16* x, const __bf16* h1, const __bf16* dy, const float
     if (grid > MAX_A_WG) grid = MAX_A_WG;
     hipLaunchKernelGGL(k_nrb_bwd_a<C>, dim3(grid), dim3(NT), 0, st, h1, dy, w2, b2, da1, part_a, npix, ngroups);
     TT_LAUNCH_CHECK();
+    static const int ndxw = env_int("TTRAP_NDXW", 1);
+    if (ndxw) {                                                  // data + weight gradient in one pass
+        using F = NTl<C, D>;
+        constexpr int LDS = 2 * F::NPR * 16;
+        static AttrOnce once_x;
+        auto kx = k_nrb_dxw<C, D>;
+        if (int rc = raise_lds(kx, LDS, once_x)) return rc;
+        const int tiles_h = (H + F::TH - 1) / F::TH, tiles_t = (T + F::TW - 1) / F::TW, ntiles = B * tiles_h * tiles_t;
+        static const int x_per_cu = env_int("TTRAP_NDXW_PER_CU", 4);
+        int gx = grid_for(ntiles, LDS, x_per_cu);
+        if (gx > MAX_W_WG) gx = MAX_W_WG;
+        hipLaunchKernelGGL(kx, dim3(gx), dim3(NT), LDS, st, x, da1, dy, w1, dx, part_w, B, H, T, tiles_h, tiles_t, ntiles);
+        TT_LAUNCH_CHECK();
+        RedArgs ra{part_w, gx, part_a, grid, dw1, db1, dw2, db2};
+        constexpr int total = 9 * 256 + C * C + 2 * C;
+        hipLaunchKernelGGL(k_nrb_reduce<C>, dim3((total + REL - 1) / REL), dim3(1024), 0, st, ra);
+        TT_LAUNCH_CHECK();
+        return 0;
+    }
     if (int rc = launch_nconv<C, D, 1, false>(da1, w1, nullptr, nullptr, nullptr, dy, dx, nullptr, B, H, T, st)) return rc;
     using W = NG<C, D>;
     static AttrOnce once_w;

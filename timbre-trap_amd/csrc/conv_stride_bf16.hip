@@ -434,8 +434,11 @@ __global__ __launch_bounds__(NT) void k_p2n(const __bf16* __restrict__ in, const
 // blocks XOR-swizzled with pixel bits so that the eight pixels of a half-wave read fall on different banks.
 template <int PB> __device__ __forceinline__ int blk_swz(int p) { return PB == 128 ? ((p >> 1) & 3) : (PB == 64 ? ((p >> 2) & 1) : 0); }
 
+// Tile height TR (rows of the small side): a tile's bytes scale with C, and at C = 4 four rows are 10 KB per barrier pair -- the launch
+// is then all latency (round 3: sconv / tconv backward at C = 4 0.478 / 0.531 ms with TR = 4, 0.420 / 0.434 ms with TR = 16; C = 8:
+// 0.359 / 0.382 -> 0.362 / 0.357 ms with TR = 8; TR = 16 at C = 8 gives nothing more).
 template <int C> struct W4 {
-    static constexpr int TR = 4, TW = 64;
+    static constexpr int TR = C == 4 ? 16 : (C == 8 ? 8 : 4), TW = 64;
     static constexpr int SB = 4 * C, BB = 2 * C;                 // bytes per pixel: small (2C channels), big (C channels)
     static constexpr int BROWS = 2 * TR + 3;                     // 2 TR + 2 rows feed the products; one more so that the last tile
                                                                  // reaches the output_padding row of a transposed layer (bias gradient)

@@ -444,6 +444,7 @@ template <int C> struct W4 {
                                                                  // reaches the output_padding row of a transposed layer (bias gradient)
     // images rounded up to whole rounds of DMA instructions (256 pieces of 16 bytes): the tail lanes write zeros there
     static constexpr int S_BYTES = (TR * TW * SB + 4095) / 4096 * 4096, B_BYTES = (BROWS * TW * BB + 4095) / 4096 * 4096;
+    static constexpr int SX_BYTES = ((TR + 1) * TW * SB + 4095) / 4096 * 4096;      // with the halo row of the merged sconv backward
     static constexpr int NA = 2 * C >= 16 ? 2 * C / 16 : 1, NBT = C >= 16 ? C / 16 : 1;
     static constexpr int DUMP = 4 * NA * NBT * 256;
     static constexpr int LDS_BYTES = S_BYTES + B_BYTES;
@@ -457,7 +458,7 @@ template <int PB> __device__ __forceinline__ int tr_off(int p, int tile, int trq
 
 template <int PB, int ROWS, bool GATED>
 __device__ __forceinline__ void stage_tile(unsigned char* lds, const __bf16* src, const __bf16* ysrc, int row_h0, int Hs,
-                                           int t0, int T, int tid, float (&dbacc)[8], int db_rows) {
+                                           int t0, int T, int tid, float (&dbacc)[8], int db_rows, int db_row0 = 0) {
     // image [ROWS][TW][PB bytes]; piece = 16 bytes; GATED: through registers with dy * ELU'(y), else LDS-DMA
     constexpr int TWp = 64, PPP = PB >= 16 ? 1 : 16 / PB, CGn = PB >= 16 ? PB / 16 : 1;
     constexpr int NPC = ROWS * TWp * PB / 16, NIT = (NPC + NT - 1) / NT;
@@ -473,7 +474,7 @@ __device__ __forceinline__ void stage_tile(unsigned char* lds, const __bf16* src
         // physical position -> logical channel group (32-byte blocks swizzled)
         const int cg = PB >= 32 ? ((((cgp >> 1) ^ blk_swz<PB>(q)) << 1) | (cgp & 1)) : cgp;
         const int h = row_h0 + row, t = t0 + px;
-        const bool ok = p < NPC && h < Hs && t < T;
+        const bool ok = p < NPC && (unsigned)h < (unsigned)Hs && t < T;
         const long off = ((long)h * T + t) * (PB / 2) + cg * 8;
         if constexpr (!GATED) {
             glds16(ok ? src + off : zero, lds + (long)i * 16);
@@ -490,12 +491,12 @@ __device__ __forceinline__ void stage_tile(unsigned char* lds, const __bf16* src
             const int p = it * NT + tid;
             const int q = (p / CGn) * PPP;
             const int row = q / TWp, px = q - row * TWp;
-            const bool ok = p < NPC && row_h0 + row < Hs && t0 + px < T;
+            const bool ok = p < NPC && (unsigned)(row_h0 + row) < (unsigned)Hs && t0 + px < T;
             bf16x8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float gq = ok ? gate_f((float)v[it][j], (float)yv[it][j]) : 0.f;
-                if (row < db_rows) dbacc[j] += gq;              // rows shared with the next tile are counted once
+                if (row >= db_row0 && row < db_rows) dbacc[j] += gq;    // rows shared with a neighbouring tile are counted once
                 o[j] = (__bf16)gq;
             }
             if (p < NPC) *reinterpret_cast<bf16x8*>(lds + (long)p * 16) = o;
@@ -507,14 +508,27 @@ __device__ __forceinline__ void stage_tile(unsigned char* lds, const __bf16* src
 // 1-2 waves per SIMD to 3-4 changed nothing or lost (spills), except here: C = 32 with the gated SMALL operand drops from 400 to
 // 254 registers without a spill and two waves per SIMD (sconv backward at the bench shape 0.516 -> 0.456 ms); the gated-big form
 // spills at that cap (0.522 -> 0.662 ms) and keeps its own allocation.
-template <int C, bool GS>
+// DX = true (C <= 16): the data gradient of the layer is computed in the same pass from the gated tile already in LDS -- the separate
+// k_s4 / k_p2 launch read dy and y a second time.  GS = false (tconv): dx_small[r] = sum_kh W^T g_big[2r + kh] (the k_s4 product, B operand
+// from the big image); GS = true (sconv): dx_big[2m + par] = sum_rs W g_small[m - rs] (the k_p2 product), which needs one small row
+// ABOVE the tile: the small image is staged with a halo row (it takes no part in the weight / bias gradient).
+template <int PB> __device__ __forceinline__ const unsigned char* px_piece(const unsigned char* img, int q, int ch0) {
+    // address of the channels ch0.. (8 of them, 4 at 8-byte pixels) of pixel q of a stage_tile image
+    const int cg = ch0 >> 3;
+    if (PB >= 64) return img + (long)q * PB + ((((cg >> 1) ^ blk_swz<PB>(q)) << 1) | (cg & 1)) * 16;
+    return img + (long)q * PB + ch0 * 2;
+}
+
+template <int C, bool GS, bool DX>
 __global__ __launch_bounds__(NT, (C == 32 && GS) ? 2 : 1) void k_w4(const __bf16* __restrict__ small, const __bf16* __restrict__ big,
                                             const __bf16* __restrict__ ygate, float* __restrict__ part, float* __restrict__ dbpart,
+                                            const float* __restrict__ w, __bf16* __restrict__ dx,
                                             int B, int Hs, int Hb, int T, int tiles_h, int tiles_t, int ntiles) {
     using G = W4<C>;
+    constexpr int SROW0 = (DX && GS) ? 1 : 0;                    // image row of the tile's first small row
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char* ss = smem;
-    unsigned char* bs = smem + G::S_BYTES;
+    unsigned char* bs = smem + ((DX && GS) ? G::SX_BYTES : G::S_BYTES);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4, trj = n >> 2, trq = n & 3;
     const int colh = wave & 1, row0 = wave >> 1;
@@ -526,6 +540,34 @@ __global__ __launch_bounds__(NT, (C == 32 && GS) ? 2 : 1) void k_w4(const __bf16
 #pragma unroll
             for (int c = 0; c < G::NBT; ++c) acc[k][a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     float dbacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // data-gradient weights in registers (the A operands of k_s4 / k_p2)
+    using S = S4<C>;
+    using P = P2<C>;
+    typedef typename VecE<S::CE>::type dvec_t;
+    constexpr int NCTS = OutT<2 * C>::NCT, NCHS = OutT<2 * C>::NCH, NCTP = OutT<C>::NCT, NCHP = OutT<C>::NCH;
+    dvec_t AS[DX && !GS ? S::NS : 1][DX && !GS ? NCTS : 1], AP[DX && GS ? 2 : 1][DX && GS ? P::NS : 1][DX && GS ? NCTP : 1];
+    if constexpr (DX && !GS) {
+#pragma unroll
+        for (int j = 0; j < S::NS; ++j)
+#pragma unroll
+            for (int ct = 0; ct < NCTS; ++ct) {
+                const int co = och<2 * C>(ct, n), kh = S::kh(j, g), c0 = S::c0(g);
+#pragma unroll
+                for (int e = 0; e < S::CE; ++e) AS[j][ct][e] = (__bf16)(co < 2 * C ? w[(co * C + c0 + e) * 4 + kh] : 0.f);
+            }
+    }
+    if constexpr (DX && GS) {
+#pragma unroll
+        for (int par = 0; par < 2; ++par)
+#pragma unroll
+            for (int j = 0; j < P::NS; ++j)
+#pragma unroll
+                for (int ct = 0; ct < NCTP; ++ct) {
+                    const int co = och<C>(ct, n), kh = par + 2 * P::rs(j, g), c0 = P::c0(j, g);
+#pragma unroll
+                    for (int e = 0; e < P::CE; ++e) AP[par][j][ct][e] = (__bf16)(co < C ? w[((c0 + e) * C + co) * 4 + kh] : 0.f);
+                }
+    }
 
     for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
         int tile = xcd_order(v, ntiles);
@@ -537,7 +579,8 @@ __global__ __launch_bounds__(NT, (C == 32 && GS) ? 2 : 1) void k_w4(const __bf16
         __syncthreads();
         if constexpr (GS) {
             stage_tile<G::BB, G::BROWS, false>(bs, bb, nullptr, 2 * r0, Hb, t0, T, tid, dbacc, 0);
-            stage_tile<G::SB, G::TR, true>(ss, sb, ygate + (long)b * Hs * T * (2 * C), r0, Hs, t0, T, tid, dbacc, G::TR);
+            stage_tile<G::SB, G::TR + SROW0, true>(ss, sb, ygate + (long)b * Hs * T * (2 * C), r0 - SROW0, Hs, t0, T, tid, dbacc,
+                                                   G::TR + SROW0, SROW0);
         } else {
             stage_tile<G::SB, G::TR, false>(ss, sb, nullptr, r0, Hs, t0, T, tid, dbacc, 0);
             stage_tile<G::BB, G::BROWS, true>(bs, bb, ygate + (long)b * Hb * T * C, 2 * r0, Hb, t0, T, tid, dbacc,
@@ -545,6 +588,67 @@ __global__ __launch_bounds__(NT, (C == 32 && GS) ? 2 : 1) void k_w4(const __bf16
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+
+        if constexpr (DX && !GS) {
+            // dx_small rows r0 .. r0 + TR - 1: gather four gated big rows 2r + kh (image rows 2 (r - r0) + kh)
+            for (int grp = wave; grp < G::TR * 4; grp += 4) {
+                const int r = grp >> 2, col = (grp & 3) * 16 + n;
+                if (r0 + r >= Hs) break;
+                const int t = t0 + col;
+                f32x4 acc[NCTS];
+#pragma unroll
+                for (int ct = 0; ct < NCTS; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < S::NS; ++j) {
+                    const int q = (2 * r + S::kh(j, g)) * G::TW + col;
+                    const dvec_t bq = *reinterpret_cast<const dvec_t*>(px_piece<G::BB>(bs, q, S::c0(g)));
+#pragma unroll
+                    for (int ct = 0; ct < NCTS; ++ct) acc[ct] = mma_e<S::CE>(AS[j][ct], bq, acc[ct]);
+                }
+                float vv[NCHS];
+#pragma unroll
+                for (int ct = 0; ct < NCTS; ++ct)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) vv[4 * ct + rr] = acc[ct][rr];
+                store_lane<2 * C, NCHS>(dx, ((long)b * Hs + r0 + r) * T + t, g, vv, t < T);
+            }
+        }
+        if constexpr (DX && GS) {
+            // dx_big row pairs (2m, 2m + 1), m = r0 .. r0 + TR - 1 (the last tile also the rows past 2 Hs): gated small rows m, m - 1
+            const int Hp = (Hb + 1) >> 1;
+            const int mend = (th == tiles_h - 1) ? Hp : r0 + G::TR;
+            for (int grp = wave; grp < (mend - r0) * 4; grp += 4) {
+                const int m = r0 + (grp >> 2), col = (grp & 3) * 16 + n;
+                const int t = t0 + col;
+                dvec_t bq[P::NS];
+#pragma unroll
+                for (int j = 0; j < P::NS; ++j) {
+                    const int hi = m - P::rs(j, g);                 // small row; rows outside [0, Hs) contribute nothing
+                    const int q = (hi - r0 + SROW0) * G::TW + col;
+                    dvec_t z;
+#pragma unroll
+                    for (int e = 0; e < P::CE; ++e) z[e] = (__bf16)0.f;
+                    bq[j] = (hi >= 0 && hi < Hs) ? *reinterpret_cast<const dvec_t*>(px_piece<G::SB>(ss, q, P::c0(j, g))) : z;
+                }
+#pragma unroll
+                for (int par = 0; par < 2; ++par) {
+                    const int h = 2 * m + par;
+                    f32x4 acc[NCTP];
+#pragma unroll
+                    for (int ct = 0; ct < NCTP; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < P::NS; ++j)
+#pragma unroll
+                        for (int ct = 0; ct < NCTP; ++ct) acc[ct] = mma_e<P::CE>(AP[par][j][ct], bq[j], acc[ct]);
+                    float vv[NCHP];
+#pragma unroll
+                    for (int ct = 0; ct < NCTP; ++ct)
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) vv[4 * ct + rr] = acc[ct][rr];
+                    store_lane<C, NCHP>(dx, ((long)b * Hb + h) * T + t, g, vv, t < T && h < Hb);
+                }
+            }
+        }
 
         for (int r = row0; r < G::TR; r += 2) {
             if (r0 + r >= Hs) break;
@@ -554,7 +658,7 @@ __global__ __launch_bounds__(NT, (C == 32 && GS) ? 2 : 1) void k_w4(const __bf16
                 s16x4 h2[2];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const int p = r * G::TW + colh * 32 + 16 * u + 4 * g + trj;
+                    const int p = (r + SROW0) * G::TW + colh * 32 + 16 * u + 4 * g + trj;
                     h2[u] = lds_tr16(ss + (long)p * G::SB + tr_off<G::SB>(p, a, trq));
                 }
                 sa[a] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(h2[0], h2[1], 0, 1, 2, 3, 4, 5, 6, 7));
@@ -685,19 +789,26 @@ int launch_p2(const __bf16* in, const __bf16* gy, const float* w, const float* b
     TT_LAUNCH_CHECK();
     return 0;
 }
-template <int C, bool GS>
-int launch_w4(const __bf16* small, const __bf16* big, const __bf16* ygate, float* dw, float* db, float* ws, int B, int Hs, int Hb,
-              int T, hipStream_t st) {
+// the data gradient rides along in the weight-gradient pass where the registers allow it (TTRAP_W4X=0: always two kernels)
+template <int C> inline bool w4x_enabled() {
+    static const int on = getenv("TTRAP_W4X") ? atoi(getenv("TTRAP_W4X")) : 1;
+    return on && C <= 16;
+}
+
+template <int C, bool GS, bool DX>
+int launch_w4(const __bf16* small, const __bf16* big, const __bf16* ygate, float* dw, float* db, float* ws, const float* w, __bf16* dx,
+              int B, int Hs, int Hb, int T, hipStream_t st) {
     using G = W4<C>;
+    constexpr int LDS = ((DX && GS) ? G::SX_BYTES : G::S_BYTES) + G::B_BYTES;
     static AttrOnce once;
-    auto kern = k_w4<C, GS>;
-    if (int rc = raise_lds(kern, G::LDS_BYTES, once)) return rc;
+    auto kern = k_w4<C, GS, DX>;
+    if (int rc = raise_lds(kern, LDS, once)) return rc;
     const int tiles_h = (Hs + G::TR - 1) / G::TR, tiles_t = (T + G::TW - 1) / G::TW, ntiles = B * tiles_h * tiles_t;
-    int gw = grid_for(ntiles, G::LDS_BYTES, 3);
+    int gw = grid_for(ntiles, LDS, 3);
     if (gw > MAX_WG) gw = MAX_WG;
     float* part = ws;
     float* dbpart = ws + (long)MAX_WG * 4 * G::DUMP;
-    hipLaunchKernelGGL(kern, dim3(gw), dim3(NT), G::LDS_BYTES, st, small, big, ygate, part, dbpart, B, Hs, Hb, T, tiles_h, tiles_t, ntiles);
+    hipLaunchKernelGGL(kern, dim3(gw), dim3(NT), LDS, st, small, big, ygate, part, dbpart, w, dx, B, Hs, Hb, T, tiles_h, tiles_t, ntiles);
     TT_LAUNCH_CHECK();
     W4Red ra{part, dbpart, gw, dw, db};
     constexpr int total = G::DUMP + (GS ? 2 * C : C);
@@ -746,6 +857,13 @@ int tt_sconv16_bwd(const void* x, const void* y, const void* dy, const float* w,
     if (!x || !y || !dy || !w || !dw || !db || !ws || !ok_shape(B, C, H, T)) return TT_E_BADARG;
     const int Ho = (H - 4) / 2 + 1;
     hipStream_t st = tt_stream(stream);
+    if (dx && C <= 16 && w4x_enabled<16>()) {                     // one pass: weight, bias and data gradient
+        switch (C) {
+            case 4: return launch_w4<4, true, true>((const __bf16*)dy, (const __bf16*)x, (const __bf16*)y, dw, db, (float*)ws, w, (__bf16*)dx, B, Ho, H, T, st);
+            case 8: return launch_w4<8, true, true>((const __bf16*)dy, (const __bf16*)x, (const __bf16*)y, dw, db, (float*)ws, w, (__bf16*)dx, B, Ho, H, T, st);
+            case 16: return launch_w4<16, true, true>((const __bf16*)dy, (const __bf16*)x, (const __bf16*)y, dw, db, (float*)ws, w, (__bf16*)dx, B, Ho, H, T, st);
+        }
+    }
     if (dx) {
         int rc = TT_E_UNSUPPORTED;
         switch (C) {
@@ -756,7 +874,7 @@ int tt_sconv16_bwd(const void* x, const void* y, const void* dy, const float* w,
         }
         if (rc) return rc;
     }
-    TT_BY_C(C, (launch_w4<CC, true>((const __bf16*)dy, (const __bf16*)x, (const __bf16*)y, dw, db, (float*)ws, B, Ho, H, T, st)));
+    TT_BY_C(C, (launch_w4<CC, true, false>((const __bf16*)dy, (const __bf16*)x, (const __bf16*)y, dw, db, (float*)ws, nullptr, nullptr, B, Ho, H, T, st)));
 }
 
 int tt_tconv16_fwd(const void* x, const float* w, const float* b, void* y, int B, int C, int H, int T, int out_pad, void* stream) {
@@ -773,6 +891,13 @@ int tt_tconv16_bwd(const void* x, const void* y, const void* dy, const float* w,
     const int Ho = 2 * H + 2 + out_pad;
     if (!ok_shape(B, C, Ho, T)) return TT_E_BADARG;
     hipStream_t st = tt_stream(stream);
+    if (dx && C <= 16 && w4x_enabled<16>()) {
+        switch (C) {
+            case 4: return launch_w4<4, false, true>((const __bf16*)x, (const __bf16*)dy, (const __bf16*)y, dw, db, (float*)ws, w, (__bf16*)dx, B, H, Ho, T, st);
+            case 8: return launch_w4<8, false, true>((const __bf16*)x, (const __bf16*)dy, (const __bf16*)y, dw, db, (float*)ws, w, (__bf16*)dx, B, H, Ho, T, st);
+            case 16: return launch_w4<16, false, true>((const __bf16*)x, (const __bf16*)dy, (const __bf16*)y, dw, db, (float*)ws, w, (__bf16*)dx, B, H, Ho, T, st);
+        }
+    }
     if (dx) {
         int rc = TT_E_UNSUPPORTED;
         switch (C) {
@@ -783,7 +908,7 @@ int tt_tconv16_bwd(const void* x, const void* y, const void* dy, const float* w,
         }
         if (rc) return rc;
     }
-    TT_BY_C(C, (launch_w4<CC, false>((const __bf16*)x, (const __bf16*)dy, (const __bf16*)y, dw, db, (float*)ws, B, H, Ho, T, st)));
+    TT_BY_C(C, (launch_w4<CC, false, false>((const __bf16*)x, (const __bf16*)dy, (const __bf16*)y, dw, db, (float*)ws, nullptr, nullptr, B, H, Ho, T, st)));
 }
 
 }  // extern "C"

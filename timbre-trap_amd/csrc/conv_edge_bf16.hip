@@ -102,7 +102,8 @@ __global__ __launch_bounds__(NT) void k_cin_fwd(const float* __restrict__ x, con
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float wr[72], br[4];                                         // w[co][ci][kh][kw]: uniform
 #pragma unroll
-    for (int i = 0; i < 72; ++i) wr[i] = w[i];
+    for (int i = 0; i < 72; ++i) { wr[i] = w[i]; asm volatile("" : "+v"(wr[i])); }   // pinned in VGPRs: as wave-uniform values they
+                                                                                 // were spilled to VGPR lanes and read back with one v_readlane per use
 #pragma unroll
     for (int c = 0; c < 4; ++c) br[c] = bias[c];
     for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
@@ -197,7 +198,8 @@ __global__ __launch_bounds__(NT) void k_cout_fwd(const __bf16* __restrict__ x, c
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float wr[72], br[2];                                         // w[co][ci][kh][kw], co < 2, ci < 4
 #pragma unroll
-    for (int i = 0; i < 72; ++i) wr[i] = w[i];
+    for (int i = 0; i < 72; ++i) { wr[i] = w[i]; asm volatile("" : "+v"(wr[i])); }   // pinned in VGPRs: as wave-uniform values they
+                                                                                 // were spilled to VGPR lanes and read back with one v_readlane per use
     br[0] = bias[0]; br[1] = bias[1];
     for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
         const ETile tl = etile(v, tiles_h, tiles_t, ntiles);

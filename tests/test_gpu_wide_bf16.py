@@ -513,3 +513,34 @@ def test_skip_joins_on_the_device(shape):
     dw = torch.zeros(5, dtype=torch.float64)
     dw[3] = float((gr * er).sum())
     assert torch.allclose(wd.grad.cpu().double(), dw, rtol=1e-4, atol=1e-4)
+
+
+def _pytest_subprocess(env_extra, selection):
+    """The kernel switches are read once per process: the non-default paths run in a child pytest."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **env_extra)
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider'] + selection, cwd=root, env=env,
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    return r.stdout
+
+
+@pytest.mark.skipif(os.environ.get('TT_CHILD_PYTEST') == '1', reason='already inside the child run')
+def test_separate_kernel_paths_still_agree():
+    """TTRAP_DXW=0 / TTRAP_NDXW=0 / TTRAP_W4X=0: data gradient and weight gradient as separate kernels (the round-2 structure, kept
+    for A/B) against the same stage-wise restatement."""
+    out = _pytest_subprocess(dict(TTRAP_DXW='0', TTRAP_NDXW='0', TTRAP_W4X='0', TTRAP_NARROW_FUSED16='0', TT_CHILD_PYTEST='1'),
+                             ['tests/test_gpu_wide_bf16.py', '-k', 'stagewise and (shape0 or shape3) or strided or sconv or tconv'])
+    assert ' passed' in out
+
+
+@pytest.mark.skipif(os.environ.get('TT_CHILD_PYTEST') == '1', reason='already inside the child run')
+def test_recompute_path_at_model_level():
+    """TTRAP_LEVEL_RECOMPUTE=1: wide levels through tt_wide_rb_bwd_fused (no h1 saved) -- the model-level oracle parity of the
+    autocast step (outputs, losses, all 120 gradients) and the level test must hold on that path too."""
+    out = _pytest_subprocess(dict(TTRAP_LEVEL_RECOMPUTE='1', TT_CHILD_PYTEST='1'),
+                             ['tests/test_gpu_model.py', 'tests/test_gpu_wide_bf16.py', '-k',
+                              'autocast_bf16_step or wide_level_matches_oracle or reduced_precision_training'])
+    assert ' passed' in out

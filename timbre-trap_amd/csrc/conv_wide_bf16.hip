@@ -526,8 +526,9 @@ template <int C, int D, int TH, int TW> struct DXW {
     static constexpr int NP = IR * IW * CG;
     static constexpr int NPR = (NP + NT - 1) / NT * NT;
     static constexpr int IMG_BYTES = NPR * 16;
-    static constexpr int LDS_BYTES = 2 * IMG_BYTES;
     static constexpr int WDUMP = 9 * (C / 16) * 256;
+    // C = 16: the four waves' accumulators are summed through LDS at the end (36.9 KB, more than the two images at dilation 1, 2)
+    static constexpr int LDS_BYTES = (C == 16 && 2 * IMG_BYTES < 4 * WDUMP * 4) ? 4 * WDUMP * 4 : 2 * IMG_BYTES;
     static_assert(TW % 32 == 0, "the K = 32 pixels of a weight-gradient product are 32 consecutive columns");
 };
 
@@ -645,11 +646,25 @@ __global__ __launch_bounds__(NT, 2) void k_wrb_dxw(const __bf16* __restrict__ x,
             }
         }
     }
-    float* pw = part_w + ((long)blockIdx.x * 4 + wave) * G::WDUMP;
+    if constexpr (C == 32) {
+        float* pw = part_w + ((long)blockIdx.x * 4 + wave) * G::WDUMP;
 #pragma unroll
-    for (int k = 0; k < 9; ++k)
+        for (int k = 0; k < 9; ++k)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pw[((k * NCT + aw) * 4 + r) * 64 + lane] = wacc[k][r];   // C = 32: only this wave's co-tile (RedArgs::split_a)
+            for (int r = 0; r < 4; ++r) pw[((k * NCT + aw) * 4 + r) * 64 + lane] = wacc[k][r];   // only this wave's co-tile (RedArgs::split_a)
+    } else {
+        // C = 16: the four waves hold the same (co, ci, tap) elements: summed through LDS, ONE dump per workgroup (wave slot 0) --
+        // the reduce kernel reads a quarter of the bytes (RedArgs::one_dump)
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave * G::WDUMP + (k * 4 + r) * 64 + lane] = wacc[k][r];
+        __syncthreads();
+        float* pw = part_w + (long)blockIdx.x * 4 * G::WDUMP;
+        for (int i = tid; i < G::WDUMP; i += NT) pw[i] = (red[i] + red[G::WDUMP + i]) + (red[2 * G::WDUMP + i] + red[3 * G::WDUMP + i]);
+    }
 }
 
 // ---- launchers -------------------------------------------------------------------------------------------------------
@@ -696,7 +711,7 @@ int launch_dxw(const __bf16* x, const __bf16* da1, const __bf16* dy, const float
     if (gx > MAX_W_WG) gx = MAX_W_WG;
     hipLaunchKernelGGL(kx, dim3(gx), dim3(NT), X::LDS_BYTES, st, x, da1, dy, w1, dx, part_w, B, H, T, tiles_h, tiles_t, ntiles);
     TT_LAUNCH_CHECK();
-    RedArgs ra{part_w, gx, part_a, grid_a, dw1, db1, dw2, db2, C == 32 ? 1 : 0};
+    RedArgs ra{part_w, gx, part_a, grid_a, dw1, db1, dw2, db2, C == 32 ? 1 : 0, C == 32 ? 0 : 1};
     constexpr int total = 9 * C * C + C * C + 2 * C;
     hipLaunchKernelGGL(k_wrb_reduce<C>, dim3((total + REL - 1) / REL), dim3(1024), 0, st, ra);
     TT_LAUNCH_CHECK();
@@ -1397,11 +1412,16 @@ __global__ __launch_bounds__(NT) void k_nrb_dxw(const __bf16* __restrict__ x, co
             }
         }
     }
-    float* pw = part_w + ((long)blockIdx.x * 4 + wave) * (9 * 256);
+    // the four waves hold the same elements: summed through LDS, ONE dump per workgroup (RedArgs::one_dump)
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int k = 0; k < 9; ++k)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pw[(k * 4 + r) * 64 + lane] = wacc[k][r];
+        for (int r = 0; r < 4; ++r) red[wave * 2304 + (k * 4 + r) * 64 + lane] = wacc[k][r];
+    __syncthreads();
+    float* pw = part_w + (long)blockIdx.x * 4 * 2304;
+    for (int i = tid; i < 2304; i += NT) pw[i] = (red[i] + red[2304 + i]) + (red[2 * 2304 + i] + red[3 * 2304 + i]);
 }
 
 template <int C>
@@ -1412,11 +1432,12 @@ __global__ __launch_bounds__(1024) void k_nrb_reduce(RedArgs ar) {
     const int e = blockIdx.x * REL + el;
     float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (e < WDUMP) {
-        const int ncontrib = ar.gw * 4;
+        const int stride = ar.one_dump ? 4 : 1;                  // one_dump: only wave slot 0 of every workgroup holds data
+        const int ncontrib = ar.one_dump ? ar.gw : ar.gw * 4;
         for (int j0 = sl; j0 < ncontrib; j0 += 8 * RSL)
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                if (j0 + RSL * u < ncontrib) part[u] += ar.pw[(long)(j0 + RSL * u) * WDUMP + e];
+                if (j0 + RSL * u < ncontrib) part[u] += ar.pw[(long)(j0 + RSL * u) * stride * WDUMP + e];
     } else if (e < WDUMP + ADUMP) {
         const int ncontrib = ar.ga;
         for (int j0 = sl; j0 < ncontrib; j0 += 8 * RSL)
@@ -1500,7 +1521,7 @@ int launch_nbwd(const __bf16* x, const __bf16* h1, const __bf16* dy, const float
     static const int ndxw = env_int("TTRAP_NDXW", 1);
     if (ndxw) {                                                  // data + weight gradient in one pass
         using F = NTl<C, D>;
-        constexpr int LDS = 2 * F::NPR * 16;
+        constexpr int LDS = 2 * F::NPR * 16 > 4 * 2304 * 4 ? 2 * F::NPR * 16 : 4 * 2304 * 4;   // images, then the four waves' accumulators
         static AttrOnce once_x;
         auto kx = k_nrb_dxw<C, D>;
         if (int rc = raise_lds(kx, LDS, once_x)) return rc;
@@ -1510,7 +1531,7 @@ int launch_nbwd(const __bf16* x, const __bf16* h1, const __bf16* dy, const float
         if (gx > MAX_W_WG) gx = MAX_W_WG;
         hipLaunchKernelGGL(kx, dim3(gx), dim3(NT), LDS, st, x, da1, dy, w1, dx, part_w, B, H, T, tiles_h, tiles_t, ntiles);
         TT_LAUNCH_CHECK();
-        RedArgs ra{part_w, gx, part_a, grid, dw1, db1, dw2, db2};
+        RedArgs ra{part_w, gx, part_a, grid, dw1, db1, dw2, db2, 0, 1};
         constexpr int total = 9 * 256 + C * C + 2 * C;
         hipLaunchKernelGGL(k_nrb_reduce<C>, dim3((total + REL - 1) / REL), dim3(1024), 0, st, ra);
         TT_LAUNCH_CHECK();

@@ -59,6 +59,7 @@ struct RedArgs {
     const float* pa; int ga;        // bwd_a dumps: one per workgroup
     float *dw1, *db1, *dw2, *db2;
     int split_a = 0;                // C = 32 fused backward: wave = (ci-tile, co-tile), each wave dumps only its own co-tile
+    int one_dump = 0;               // the producing kernel summed its four waves: only wave slot 0 of every workgroup holds data
 };
 template <int C>
 __global__ __launch_bounds__(1024) void k_wrb_reduce(RedArgs ar) {
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(1024) void k_wrb_reduce(RedArgs ar) {
     if (e < NEW) {
         const int role = e / WDUMP, rest = e - role * WDUMP;     // C = 32: role = ci-tile = wave & 1;  C = 16: one role
         const int k = rest / (NCT * 256), a = (rest >> 8) % NCT, r = (rest >> 6) & 3, lane = rest & 63;
-        const int NS = ar.split_a ? 1 : 4 / NCT;                 // waves per workgroup that contribute to this element
+        const int NS = (ar.split_a || ar.one_dump) ? 1 : 4 / NCT; // waves per workgroup that contribute to this element
         const int ncontrib = ar.gw * NS;
         float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // eight loads in flight per thread
         for (int j0 = sl; j0 < ncontrib; j0 += 8 * RSL) {
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(1024) void k_wrb_reduce(RedArgs ar) {
                 const int j = j0 + RSL * u;
                 if (j < ncontrib) {
                     const int wg = j / NS, s = j - wg * NS;
-                    const int wave = ar.split_a ? role + 2 * a : (C == 32 ? role + 2 * s : s);
+                    const int wave = ar.split_a ? role + 2 * a : (ar.one_dump ? 0 : (C == 32 ? role + 2 * s : s));
                     part[u] += ar.pw[((long)wg * 4 + wave) * WDUMP + rest];
                 }
             }

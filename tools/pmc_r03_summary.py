@@ -37,6 +37,9 @@ def pretty(name):
     m = re.match(r'k_wrb_bwd_fusedILi(\d+)ELi(\d)ELi(\d)ELi(\d+)', name)
     if m:
         return 'k_wrb_bwd_fused<%s,%s,%s,%s>' % m.groups()
+    m = re.match(r'k_(\w+?)ILi(\d+)ELi(\d)ELi(\d)ELb(\d)ELi(\d)', name)
+    if m:
+        return 'k_%s<%s,%s,%s,%s>' % m.groups()[:5]
     return re.sub(r'E[vP].*', '', name)
 
 
@@ -50,8 +53,10 @@ def algorithmic_mb(name, C):
     if 'bwd_a' in p: return 3 * t, 'h1, dy, dA1'
     if 'bwd_fused' in p and 'nrb' in p: return 4 * t, 'h1, dy, x, dx'
     if 'bwd_fused' in p: return 3 * t, 'x, dy, dx'
+    if 'dxw' in p: return 4 * t, 'dA1, dy, x, dx'
     if 'wgrad' in p: return 2 * t, 'x, dA1'
     if p.startswith(('k_s4', 'k_p2')): return 3 * t, 'dy, y (gate), dx'
+    if p.startswith('k_w4<') and p.rstrip('>').endswith('true'): return 4 * t, 'x, dy, y (gate), dx'
     if p.startswith('k_w4<'): return 3 * t, 'x, dy, y (gate)'
     return None, ''
 
@@ -99,26 +104,42 @@ def main():
         allj[C] = js
     lines, js = report('r03_fused', [32], 'One-pass residual backward with recomputed hidden activation (csrc/conv_level_bf16.hip, opt-in)')
     open(os.path.join(ROOT, 'profiles', 'r03_pmc_fused.txt'), 'w').write('\n'.join(lines) + '\n')
-    # the bench line's roofline call: tt_wide_rb_bwd at C = 32 = bwd_a + conv<32,D,1,0> + wgrad<32,D> + reduce, mean over D
+    cq = parse(os.path.join(ROOT, 'gpurun_out', 'pmc_r03_cqt', 'summary.txt'))
+    lines = ['# CQT kernels, 64 clips x 3 s (tools/kbench.py cqt under rocprofv3 --pmc; forward = k_fft675_rows + k_fft49_cols<0> + k_band_fwd,',
+             '# inverse = k_band_inv + k_spec_gather + k_fft675_rows + k_fft49_cols<1> + k_scale_by_max).  Algorithmic bytes of either direction: 300.0 MB',
+             '# (64 x 4,688,280 B).  traffic = FETCH_SIZE x 2 + WRITE_SIZE; dur = SQ_BUSY_CYCLES / 32; VALU = SQ_ACTIVE_INST_VALU x 4 / 1024 / dur.', '']
+    tot = {}
+    for name in sorted(cq):
+        v = cq[name]
+        if 'SQ_BUSY_CYCLES' not in v:
+            continue
+        dur = v['SQ_BUSY_CYCLES'] / 32
+        wc = v.get('SQ_WAVE_CYCLES', 0) or 1
+        lines.append('%-20s traffic %6.1f MB (fetch x2 %5.1f + write %5.1f) | dur %6.1fk cyc | VALU %3.0f%% | parked %2.0f%% stalled %2.0f%% issuing %2.0f%% | VALU insts %5.2fM'
+                     % (name.split('  ')[0], 2 * v.get('FETCH_MB', 0) + v.get('WRITE_MB', 0), 2 * v.get('FETCH_MB', 0), v.get('WRITE_MB', 0), dur / 1e3,
+                        100 * 4 * v.get('SQ_ACTIVE_INST_VALU', 0) / 1024 / dur, 100 * v.get('SQ_WAIT_ANY', 0) / wc, 100 * v.get('SQ_WAIT_INST_ANY', 0) / wc,
+                        100 * v.get('SQ_ACTIVE_INST_ANY', 0) / wc, v.get('SQ_INSTS_VALU', 0) / 1e6))
+        tot[name.split('  ')[0]] = dur
+    open(os.path.join(ROOT, 'profiles', 'r03_pmc_cqt.txt'), 'w').write('\n'.join(lines) + '\n')
+    # the bench line's roofline call: tt_wide_rb_bwd at C = 32 = k_wrb_bwd_a<32> + k_wrb_dxw<32,D,8,32> + k_wrb_reduce<32>, mean over D
     j32 = allj[32]
     per_d = {}
     for d in (1, 2, 3):
-        parts = ['k_wrb_bwd_a<32>', 'k_wrb_conv<32,%d,1,0>' % d, 'k_wrb_wgrad<32, %d>' % d, 'k_wrb_reduce<32>']
-        per_d[d] = sum(j32[p]['traffic_mb'] for p in parts if p in j32) * 1e6
-        missing = [p for p in parts if p not in j32]
+        parts = ['k_wrb_bwd_a<32>', 'k_wrb_dxw<32, %d, 8, 32>' % d, 'k_wrb_reduce<32>']
+        missing = [q for q in parts if q not in j32]
         assert not missing, (missing, sorted(j32))
-    kern = {k: v for k, v in j32.items() if k.startswith(('k_wrb_bwd_a', 'k_wrb_conv<32,1,1', 'k_wrb_conv<32,2,1', 'k_wrb_conv<32,3,1', 'k_wrb_wgrad', 'k_wrb_reduce'))}
-    out = dict(call='tt_wide_rb_bwd at C = 32 (k_wrb_bwd_a<32> + k_wrb_conv<32,D,1> + k_wrb_wgrad<32,D> + k_wrb_reduce<32>)',
+        per_d[d] = sum(j32[q]['traffic_mb'] for q in parts) * 1e6
+    kern = {k: v for k, v in j32.items() if k.startswith(('k_wrb_bwd_a', 'k_wrb_dxw', 'k_wrb_reduce'))}
+    big = [v for v in kern.values() if v['duration_kcycles'] > 100]
+    out = dict(call='tt_wide_rb_bwd at C = 32 (k_wrb_bwd_a<32> + k_wrb_dxw<32,D,8,32> + k_wrb_reduce<32>)',
                shape=dict(B=B, C=32, H=65, T=T), traffic_bytes_corrected_per_dilation={str(d): v for d, v in per_d.items()},
                traffic_bytes_corrected=sum(per_d.values()) / 3, algorithmic_bytes=dict(dy_x_dx=817889280),
                kernels=kern,
-               summary='traffic %.2f GB per call against 0.818 GB algorithmic (%.2fx): h1 read, dA1 written once and read twice, dy read twice; '
+               summary='traffic %.2f GB per call against 0.818 GB algorithmic (%.2fx): h1 read, dA1 written and read once, dy read twice; '
                        'vector ALU %.0f-%.0f %% busy, matrix pipe %.0f-%.0f %%'
                        % (sum(per_d.values()) / 3 / 1e9, sum(per_d.values()) / 3 / 817889280,
-                          100 * min(v['valu_busy'] for v in kern.values() if v['duration_kcycles'] > 50),
-                          100 * max(v['valu_busy'] for v in kern.values()),
-                          100 * min(v['mfma_busy'] for v in kern.values() if v['duration_kcycles'] > 50),
-                          100 * max(v['mfma_busy'] for v in kern.values())),
+                          100 * min(v['valu_busy'] for v in big), 100 * max(v['valu_busy'] for v in big),
+                          100 * min(v['mfma_busy'] for v in big), 100 * max(v['mfma_busy'] for v in big)),
                note='FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE; source profiles/r03_pmc_bwd_C32.txt')
     json.dump(out, open(os.path.join(ROOT, 'profiles', 'r03_pmc_wrb_bwd_C32.json'), 'w'), indent=1)
     print(out['summary'])

@@ -17,7 +17,7 @@ GPU, 9 octaves x 60 bins/octave; weak scaling (per-GPU batch fixed).  The step r
 
 Prints ONE JSON line on rank 0 with the driver's fields plus
   "roofline"          : the by-time dominant call of the step -- the residual-block backward at the widest level
-                        (tt_wide_rb_bwd, C = 32: k_wrb_bwd_a + k_wrb_conv<..,1> + k_wrb_wgrad + k_wrb_reduce, 18 calls per step):
+                        (tt_wide_rb_bwd, C = 32: k_wrb_bwd_a + k_wrb_dxw + k_wrb_reduce, 18 calls per step):
                         algorithmic bytes (dy, x read, dx written once, bf16) / average call time measured with HIP events on the
                         launch stream over the timed steps, against the HBM peak; `traffic` is the HBM byte count of the committed
                         rocprofv3 PMC passes of those kernels (`traffic_source` names the file -- not re-measured in this run)
@@ -567,13 +567,13 @@ def main():
                 pmc_note = pj.get('summary')
                 traffic_source = 'profiles/r03_pmc_wrb_bwd_C32.json (rocprofv3 --pmc passes of the four kernels at this shape: FETCH_SIZE x2 + WRITE_SIZE, summed; not re-measured in this run)'
             roof = dict(kernel='tt_wide_rb_bwd at C=%d, H=65 (ResidualConv2dBlock backward, bf16 channel-innermost storage): k_wrb_bwd_a<%d> + '
-                               'k_wrb_conv<%d,D,1> + k_wrb_wgrad<%d,D> + k_wrb_reduce<%d>; the by-time dominant call of the step' % (C, C, C, C, C),
+                               'k_wrb_dxw<%d,D,8,32> (data + weight gradient in one pass) + k_wrb_reduce<%d>; the by-time dominant call of the step' % (C, C, C, C),
                         bound='hbm', achieved=gbs, peak=PEAK_HBM_GBS, unit='GB/s', frac=gbs / PEAK_HBM_GBS, traffic=traffic,
                         traffic_source=traffic_source, algorithmic_bytes=nbytes, algorithmic_flops=flops,
                         achieved_tflops=flops / (a_ms * 1e-3) / 1e12, frac_bf16_mfma_peak=flops / (a_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
                         launches=n_l, avg_ms=a_ms, ms_per_step=a_ms * n_l / args.steps, pmc=pmc_note,
-                        note='algorithmic bytes = dy and x read, dx written once (bf16); the three passes also read the saved hidden '
-                             'activation and write + re-read dL/d(conv1 pre-activation) -- see traffic')
+                        note='algorithmic bytes = dy and x read, dx written once (bf16); the two passes also read the saved hidden '
+                             'activation, write and re-read dL/d(conv1 pre-activation) and read dy twice -- see traffic')
         cqt = cqt_inv = None
         if events.get('cqt_forward'):
             a_ms, n_l = avg_ms(events['cqt_forward'])

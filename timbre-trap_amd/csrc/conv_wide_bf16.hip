@@ -744,6 +744,9 @@ int launch_bwd(const __bf16* x, const __bf16* h1, const __bf16* dy, const float*
         // tiles 8 x 32 at both widths (round 3, per call at the bench shape, separate kernels -> merged: C = 32 0.486 / 0.485 / 0.521 ->
         // 0.413 / 0.443 / 0.454 ms; C = 16 0.469 / 0.469 / 0.474 -> 0.430 / 0.431 / 0.451 ms; 8 x 64 tiles at C = 16 lose at
         // dilation 2, 3 (0.50 ms: two workgroups per CU); 16 x 32 tiles at C = 16: 0.431 / 0.439 / 0.496 ms)
+        // C = 32, dilation 2: two images of 12 x 36 pixels are 55 KB = two workgroups per CU; 6-row tiles (49 KB) admit the third:
+        // 0.456 -> 0.427 ms per call.  Dilation 3 (68 KB; 4-row tiles 49 KB): no change, 0.467 ms either way -- 8 rows kept.
+        if (C == 32 && D == 2) return launch_dxw<C, D, 6, 32>(x, da1, dy, w1, dx, part_w, part_a, grid, dw1, db1, dw2, db2, B, H, T, st);
         return launch_dxw<C, D, 8, 32>(x, da1, dy, w1, dx, part_w, part_a, grid, dw1, db1, dw2, db2, B, H, T, st);
     }
     // data gradient

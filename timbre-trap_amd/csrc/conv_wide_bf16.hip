@@ -823,8 +823,9 @@ template <int C, int D> struct NTl {
     static constexpr int LDS_BYTES = NPR * 16;
 };
 
+// C = 8 forward: capped at 168 VGPRs (three waves per SIMD; 208 otherwise): 0.194 / 0.190 / 0.195 -> 0.187 / 0.186 / 0.189 ms (library A/B, round 3)
 template <int C, int D, int MODE, bool SAVE>
-__global__ __launch_bounds__(NT) void k_nrb_conv(const __bf16* __restrict__ x, const float* __restrict__ w1,
+__global__ __launch_bounds__(NT, (C == 8 && MODE == 0) ? 3 : 1) void k_nrb_conv(const __bf16* __restrict__ x, const float* __restrict__ w1,
                                                  const float* __restrict__ b1, const float* __restrict__ w2,
                                                  const float* __restrict__ b2, const __bf16* __restrict__ res,
                                                  __bf16* __restrict__ y, __bf16* __restrict__ h1, int B, int H, int T,

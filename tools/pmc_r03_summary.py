@@ -125,13 +125,15 @@ def main():
     j32 = allj[32]
     per_d = {}
     for d in (1, 2, 3):
-        parts = ['k_wrb_bwd_a<32>', 'k_wrb_dxw<32, %d, 8, 32>' % d, 'k_wrb_reduce<32>']
+        dxw = [k for k in j32 if k.startswith('k_wrb_dxw<32, %d,' % d)]
+        assert len(dxw) == 1, (d, sorted(j32))
+        parts = ['k_wrb_bwd_a<32>', dxw[0], 'k_wrb_reduce<32>']
         missing = [q for q in parts if q not in j32]
         assert not missing, (missing, sorted(j32))
         per_d[d] = sum(j32[q]['traffic_mb'] for q in parts) * 1e6
     kern = {k: v for k, v in j32.items() if k.startswith(('k_wrb_bwd_a', 'k_wrb_dxw', 'k_wrb_reduce'))}
     big = [v for v in kern.values() if v['duration_kcycles'] > 100]
-    out = dict(call='tt_wide_rb_bwd at C = 32 (k_wrb_bwd_a<32> + k_wrb_dxw<32,D,8,32> + k_wrb_reduce<32>)',
+    out = dict(call='tt_wide_rb_bwd at C = 32 (k_wrb_bwd_a<32> + k_wrb_dxw<32,D,TH,32> + k_wrb_reduce<32>)',
                shape=dict(B=B, C=32, H=65, T=T), traffic_bytes_corrected_per_dilation={str(d): v for d, v in per_d.items()},
                traffic_bytes_corrected=sum(per_d.values()) / 3, algorithmic_bytes=dict(dy_x_dx=817889280),
                kernels=kern,

@@ -47,9 +47,11 @@ __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
 
-__device__ __forceinline__ float elu1(float a) { return a > 0.f ? a : (__expf(a) - 1.f); }
+// ELU as the median of (a, exp(a) - 1, 0): exp(a) - 1 >= a everywhere, so the median is a for a > 0 and exp(a) - 1 otherwise --
+// one v_med3_f32 instead of compare + select, bitwise the same values (see bf16_common.h)
+__device__ __forceinline__ float elu1(float a) { return __builtin_amdgcn_fmed3f(a, __expf(a) - 1.f, 0.f); }
 // derivative of ELU expressed through its output y
-__device__ __forceinline__ float elu_grad_from_out(float y) { return y > 0.f ? 1.f : (y + 1.f); }
+__device__ __forceinline__ float elu_grad_from_out(float y) { return __builtin_fminf(y + 1.f, 1.f); }
 
 // 64-lane wave reductions
 __device__ __forceinline__ float wave_sum(float v) {

@@ -66,7 +66,10 @@ __global__ __launch_bounds__(NT) void k_lat_zprep(const float* __restrict__ z, _
 }
 
 // ---- contract over (h, c) ----------------------------------------------------------------------------------------------------
-template <int CT, int DT, bool GATE>
+// QN = 16-frame groups per wave.  With 4 (a workgroup = 256 frames) the 64-clip step launches 256 workgroups = ONE per CU, and the
+// 62 barrier-separated K steps run with four waves per CU (452 VGPRs at CT = 64: 164 us for 0.52 GB); QN = 1 gives 1024 workgroups
+// of 64 frames, 36 accumulator registers per wave and several workgroups per CU (the weights are re-read from L2).
+template <int CT, int DT, bool GATE, int QN>
 __global__ __launch_bounds__(NT) void k_lat_contract(const __bf16* __restrict__ in, const __bf16* __restrict__ gy,
                                                       const __bf16* __restrict__ wp, const float* __restrict__ bias,
                                                       float* __restrict__ out, int D, int Dout, int E, int T, long npix) {
@@ -76,10 +79,10 @@ __global__ __launch_bounds__(NT) void k_lat_contract(const __bf16* __restrict__ 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
     const int nsteps = E * SPH;
-    const long p0 = (long)blockIdx.x * 256 + wave * 64;
-    long pix[4]; bool ok[4]; long base[4];
+    const long p0 = (long)blockIdx.x * (64 * QN) + wave * (16 * QN);
+    long pix[QN]; bool ok[QN]; long base[QN];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < QN; ++q) {
         pix[q] = p0 + 16 * q + n;
         ok[q] = pix[q] < npix;
         const long b = pix[q] / T, t = pix[q] - b * T;
@@ -93,10 +96,10 @@ __global__ __launch_bounds__(NT) void k_lat_contract(const __bf16* __restrict__ 
             glds16(src + (long)(p < DT * 64 ? p : DT * 64 - 1) * 8, smem + buf * (ROUNDS * NT * 16) + (long)i * 16);
         }
     };
-    auto fetch = [&](int s, bf16x8 (&q8)[4]) {
+    auto fetch = [&](int s, bf16x8 (&q8)[QN]) {
         const int h = s / SPH, half = s - h * SPH;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < QN; ++q) {
             const long off = base[q] + (long)h * T * CT + 32 * half;
             const bool live = ok[q] && s < nsteps;
             bf16x8 v = *reinterpret_cast<const bf16x8*>(in + (live ? off : 0));
@@ -111,12 +114,12 @@ __global__ __launch_bounds__(NT) void k_lat_contract(const __bf16* __restrict__ 
             q8[q] = v;
         }
     };
-    f32x4 acc[DT][4];
+    f32x4 acc[DT][QN];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[dt][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 bq[4], bn[4];
+        for (int q = 0; q < QN; ++q) acc[dt][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 bq[QN], bn[QN];
     stage(0, 0);
     fetch(0, bq);
     for (int s = 0; s < nsteps; ++s) {
@@ -129,13 +132,13 @@ __global__ __launch_bounds__(NT) void k_lat_contract(const __bf16* __restrict__ 
         for (int dt = 0; dt < DT; ++dt) {
             const bf16x8 a = *reinterpret_cast<const bf16x8*>(wb + ((long)dt * 64 + lane) * 16);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[dt][q] = mma32(a, bq[q], acc[dt][q]);
+            for (int q = 0; q < QN; ++q) acc[dt][q] = mma32(a, bq[q], acc[dt][q]);
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bq[q] = bn[q];
+        for (int q = 0; q < QN; ++q) bq[q] = bn[q];
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < QN; ++q) {
         if (!ok[q]) continue;
         const long b = pix[q] / T, t = pix[q] - b * T;
 #pragma unroll
@@ -371,9 +374,10 @@ int run_contract(const __bf16* in, const __bf16* gy, const float* w, const float
     TT_LAUNCH_CHECK();
     constexpr int ROUNDS = (DT * 64 + NT - 1) / NT, LDS = 2 * ROUNDS * NT * 16;
     static AttrOnce once;
-    auto kern = k_lat_contract<CT, DT, GATE>;
+    constexpr int QN = CT == 64 ? 1 : 4;
+    auto kern = k_lat_contract<CT, DT, GATE, QN>;
     if (int rc = raise_lds(kern, LDS, once)) return rc;
-    hipLaunchKernelGGL(kern, dim3((unsigned)((npix + 255) / 256)), dim3(NT), LDS, st, in, gy, wp, bias, out, D, Dout, E, T, npix);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((npix + 64 * QN - 1) / (64 * QN))), dim3(NT), LDS, st, in, gy, wp, bias, out, D, Dout, E, T, npix);
     TT_LAUNCH_CHECK();
     return 0;
 }

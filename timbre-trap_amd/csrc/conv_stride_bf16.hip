@@ -95,7 +95,7 @@ __global__ __launch_bounds__(NT) void k_s4(const __bf16* __restrict__ in, const 
     using S = S4<C>;
     constexpr int COUT = 2 * C, NCT = OutT<COUT>::NCT, NCH = OutT<COUT>::NCH;
     typedef typename VecE<S::CE>::type vec_t;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: the group index math below stays on the SALU
     const int n = lane & 15, g = lane >> 4;
     vec_t A[S::NS][NCT];
 #pragma unroll
@@ -116,28 +116,28 @@ __global__ __launch_bounds__(NT) void k_s4(const __bf16* __restrict__ in, const 
     constexpr bool PAIR = C >= 16;
     constexpr int NO = PAIR ? 2 : 1, OFS = PAIR ? S::NS / 2 : 0, NPC = S::NS + OFS;
     const int Hg = PAIR ? (Hout + 1) >> 1 : Hout;
-    auto fetch = [&](long grp, vec_t (&q)[NPC]) {
-        const int tblk = (int)(grp % tb);
-        const long bh = grp / tb;
-        const int m = (int)(bh % Hg), b = (int)(bh / Hg);
+    auto fetch = [&](int grp, vec_t (&q)[NPC]) {
+        const int tblk = grp % tb;
+        const int bh = grp / tb;
+        const int m = bh % Hg, b = bh / Hg;
         const int t = tblk * 16 + n;
 #pragma unroll
         for (int j = 0; j < NPC; ++j) {
             // piece j of output 0 is step j; beyond NS it is step (j - OFS) of output 1
             const int hi = 2 * (NO * m) + (j < S::NS ? S::kh(j, g) : 2 + S::kh(j - OFS, g));
-            q[j] = load_gated<S::CE>(in, gy, (((long)b * Hin + hi) * T + t) * C + S::c0(g), grp < ngroups && t < T && hi < Hin, GATE);
+            q[j] = load_gated<S::CE>(in, gy, (((long)b * Hin + hi) * T + t) * C + S::c0(g), grp < (int)ngroups && t < T && hi < Hin, GATE);
         }
     };
-    const long gstride = (long)gridDim.x * 4;
-    long grp = (long)blockIdx.x * 4 + wave;
+    const int gstride = gridDim.x * 4;                            // ngroups < 2^31 (checked by the launcher): 32-bit scalar arithmetic
+    int grp = blockIdx.x * 4 + wave;
     vec_t bq[NPC], bn[NPC];
     constexpr bool PF = C != 32;      // C = 32: no double buffer -- 64 VGPRs of weights leave no room for it (see the note at k_s4)
     if (PF) fetch(grp, bq);
-    for (; grp < ngroups; grp += gstride) {
+    for (; grp < (int)ngroups; grp += gstride) {
         if (PF) fetch(grp + gstride, bn); else fetch(grp, bq);   // next group's rows are in flight during this one's products
-        const int tblk = (int)(grp % tb);
-        const long bh = grp / tb;
-        const int m = (int)(bh % Hg), b = (int)(bh / Hg);
+        const int tblk = grp % tb;
+        const int bh = grp / tb;
+        const int m = bh % Hg, b = bh / Hg;
         const int t = tblk * 16 + n;
         const bool ok = t < T;
 #pragma unroll
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(NT) void k_p2(const __bf16* __restrict__ in, const 
     using S = P2<C>;
     constexpr int CIN = 2 * C, NCT = OutT<C>::NCT, NCH = OutT<C>::NCH;
     typedef typename VecE<S::CE>::type vec_t;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: the group index math below stays on the SALU
     const int n = lane & 15, g = lane >> 4;
     vec_t A[2][S::NS][NCT];                                      // [output-row parity]
 #pragma unroll
@@ -204,28 +204,28 @@ __global__ __launch_bounds__(NT) void k_p2(const __bf16* __restrict__ in, const 
 
     // one group = 16 frames of the output row PAIR 2m, 2m+1: both parities read the same two input rows m and m - 1
     const int Hp = (Hout + 1) >> 1;
-    auto fetch = [&](long grp, vec_t (&q)[S::NS]) {
-        const int tblk = (int)(grp % tb);
-        const long bm = grp / tb;
-        const int m = (int)(bm % Hp), b = (int)(bm / Hp);
+    auto fetch = [&](int grp, vec_t (&q)[S::NS]) {
+        const int tblk = grp % tb;
+        const int bm = grp / tb;
+        const int m = bm % Hp, b = bm / Hp;
         const int t = tblk * 16 + n;
 #pragma unroll
         for (int j = 0; j < S::NS; ++j) {
             const int hi = m - S::rs(j, g);
             q[j] = load_gated<S::CE>(in, gy, (((long)b * Hin + hi) * T + t) * CIN + S::c0(j, g),
-                                     grp < ngroups && t < T && hi >= 0 && hi < Hin, GATE);
+                                     grp < (int)ngroups && t < T && hi >= 0 && hi < Hin, GATE);
         }
     };
-    const long gstride = (long)gridDim.x * 4;
-    long grp = (long)blockIdx.x * 4 + wave;
+    const int gstride = gridDim.x * 4;                            // ngroups < 2^31 (checked by the launcher): 32-bit scalar arithmetic
+    int grp = blockIdx.x * 4 + wave;
     vec_t bq[S::NS], bn[S::NS];
     constexpr bool PF = C != 32;      // C = 32: no double buffer -- 64 VGPRs of weights leave no room for it (see the note at k_s4)
     if (PF) fetch(grp, bq);
-    for (; grp < ngroups; grp += gstride) {
+    for (; grp < (int)ngroups; grp += gstride) {
         if (PF) fetch(grp + gstride, bn); else fetch(grp, bq);   // next group's rows are in flight during this one's products
-        const int tblk = (int)(grp % tb);
-        const long bm = grp / tb;
-        const int m = (int)(bm % Hp), b = (int)(bm / Hp);
+        const int tblk = grp % tb;
+        const int bm = grp / tb;
+        const int m = bm % Hp, b = bm / Hp;
         const int t = tblk * 16 + n;
         const bool ok = t < T;
 #pragma unroll
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(NT) void k_s4n(const __bf16* __restrict__ in, const
                                              const float* __restrict__ w, const float* __restrict__ bias,
                                              __bf16* __restrict__ out, int B, int Hin, int Hout, int T, int tb, long ngroups) {
     constexpr int NBI = C / 4, NBO = C / 2, CO = 2 * C;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i4 = lane & 3;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i4 = lane & 3;
     s16x4 A[4][NBO][NBI];                                        // [kh][output block][input block]
 #pragma unroll
     for (int kh = 0; kh < 4; ++kh)
@@ -317,26 +317,26 @@ __global__ __launch_bounds__(NT) void k_s4n(const __bf16* __restrict__ in, const
 #pragma unroll
     for (int e = 0; e < CO; ++e) br[e] = ACT ? bias[e] : 0.f;
     const int Hg = (Hout + 1) >> 1;
-    auto fetch = [&](long grp, s16x4 (&q)[6][NBI]) {
-        const int tblk = (int)(grp % tb);
-        const long bh = grp / tb;
-        const int m = (int)(bh % Hg), b = (int)(bh / Hg);
+    auto fetch = [&](int grp, s16x4 (&q)[6][NBI]) {
+        const int tblk = grp % tb;
+        const int bh = grp / tb;
+        const int m = bh % Hg, b = bh / Hg;
         const int t = tblk * 64 + lane;
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
             const int hi = 4 * m + r;
-            load_px<C, GATE>(in, gy, (((long)b * Hin + hi) * T + t) * C, grp < ngroups && t < T && hi < Hin, q[r]);
+            load_px<C, GATE>(in, gy, (((long)b * Hin + hi) * T + t) * C, grp < (int)ngroups && t < T && hi < Hin, q[r]);
         }
     };
-    const long gstride = (long)gridDim.x * 4;
-    long grp = (long)blockIdx.x * 4 + wave;
+    const int gstride = gridDim.x * 4;                            // ngroups < 2^31 (checked by the launcher): 32-bit scalar arithmetic
+    int grp = blockIdx.x * 4 + wave;
     s16x4 bq[6][NBI], bn[6][NBI];
     fetch(grp, bq);
-    for (; grp < ngroups; grp += gstride) {
+    for (; grp < (int)ngroups; grp += gstride) {
         fetch(grp + gstride, bn);
-        const int tblk = (int)(grp % tb);
-        const long bh = grp / tb;
-        const int m = (int)(bh % Hg), b = (int)(bh / Hg);
+        const int tblk = grp % tb;
+        const int bh = grp / tb;
+        const int m = bh % Hg, b = bh / Hg;
         const int t = tblk * 64 + lane;
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(NT) void k_p2n(const __bf16* __restrict__ in, const
                                              const float* __restrict__ w, const float* __restrict__ bias,
                                              __bf16* __restrict__ out, int B, int Hin, int Hout, int T, int tb, long ngroups) {
     constexpr int CI = 2 * C, NBI = CI / 4, NBO = C / 4;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i4 = lane & 3;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i4 = lane & 3;
     s16x4 A[2][2][NBO][NBI];                                     // [parity][row select][output block][input block]
 #pragma unroll
     for (int par = 0; par < 2; ++par)
@@ -384,26 +384,26 @@ __global__ __launch_bounds__(NT) void k_p2n(const __bf16* __restrict__ in, const
 #pragma unroll
     for (int e = 0; e < C; ++e) br[e] = ACT ? bias[e] : 0.f;
     const int Hp = (Hout + 1) >> 1;
-    auto fetch = [&](long grp, s16x4 (&q)[2][NBI]) {
-        const int tblk = (int)(grp % tb);
-        const long bm = grp / tb;
-        const int m = (int)(bm % Hp), b = (int)(bm / Hp);
+    auto fetch = [&](int grp, s16x4 (&q)[2][NBI]) {
+        const int tblk = grp % tb;
+        const int bm = grp / tb;
+        const int m = bm % Hp, b = bm / Hp;
         const int t = tblk * 64 + lane;
 #pragma unroll
         for (int rs = 0; rs < 2; ++rs) {
             const int hi = m - rs;
-            load_px<CI, GATE>(in, gy, (((long)b * Hin + hi) * T + t) * CI, grp < ngroups && t < T && hi >= 0 && hi < Hin, q[rs]);
+            load_px<CI, GATE>(in, gy, (((long)b * Hin + hi) * T + t) * CI, grp < (int)ngroups && t < T && hi >= 0 && hi < Hin, q[rs]);
         }
     };
-    const long gstride = (long)gridDim.x * 4;
-    long grp = (long)blockIdx.x * 4 + wave;
+    const int gstride = gridDim.x * 4;                            // ngroups < 2^31 (checked by the launcher): 32-bit scalar arithmetic
+    int grp = blockIdx.x * 4 + wave;
     s16x4 bq[2][NBI], bn[2][NBI];
     fetch(grp, bq);
-    for (; grp < ngroups; grp += gstride) {
+    for (; grp < (int)ngroups; grp += gstride) {
         fetch(grp + gstride, bn);
-        const int tblk = (int)(grp % tb);
-        const long bm = grp / tb;
-        const int m = (int)(bm % Hp), b = (int)(bm / Hp);
+        const int tblk = grp % tb;
+        const int bm = grp / tb;
+        const int m = bm % Hp, b = bm / Hp;
         const int t = tblk * 64 + lane;
 #pragma unroll
         for (int par = 0; par < 2; ++par) {
@@ -793,12 +793,14 @@ int launch_s4(const __bf16* in, const __bf16* gy, const float* w, const float* b
     if constexpr (C == 4 || (C == 8 && !GATE)) {              // gated C = 8 (tconv data gradient): the 16-row tile form is faster (0.21 vs 0.26 ms)
         const int tb = (T + 63) / 64;
         const long ngroups = (long)B * ((Hout + 1) / 2) * tb;
+        if (ngroups >= (1l << 30)) return TT_E_UNSUPPORTED;       // 32-bit group indices in the kernels
         hipLaunchKernelGGL((k_s4n<C, GATE, ACT>), dim3(flat_grid(ngroups)), dim3(NT), 0, st, in, gy, w, bias, out, B, Hin, Hout, T, tb, ngroups);
         TT_LAUNCH_CHECK();
         return 0;
     }
     const int tb = (T + 15) / 16;
     const long ngroups = (long)B * (C >= 16 ? (Hout + 1) / 2 : Hout) * tb;       // C >= 16: pairs of output rows
+    if (ngroups >= (1l << 30)) return TT_E_UNSUPPORTED;
     hipLaunchKernelGGL((k_s4<C, GATE, ACT>), dim3(flat_grid(ngroups)), dim3(NT), 0, st, in, gy, w, bias, out, B, Hin, Hout, T, tb, ngroups);
     TT_LAUNCH_CHECK();
     return 0;
@@ -809,12 +811,14 @@ int launch_p2(const __bf16* in, const __bf16* gy, const float* w, const float* b
     if constexpr (C <= 8) {
         const int tb = (T + 63) / 64;
         const long ngroups = (long)B * ((Hout + 1) / 2) * tb;
+        if (ngroups >= (1l << 30)) return TT_E_UNSUPPORTED;       // 32-bit group indices in the kernels
         hipLaunchKernelGGL((k_p2n<C, GATE, ACT>), dim3(flat_grid(ngroups)), dim3(NT), 0, st, in, gy, w, bias, out, B, Hin, Hout, T, tb, ngroups);
         TT_LAUNCH_CHECK();
         return 0;
     }
     const int tb = (T + 15) / 16;
     const long ngroups = (long)B * ((Hout + 1) / 2) * tb;        // one group = a pair of output rows x 16 frames
+    if (ngroups >= (1l << 30)) return TT_E_UNSUPPORTED;
     hipLaunchKernelGGL((k_p2<C, GATE, ACT>), dim3(flat_grid(ngroups)), dim3(NT), 0, st, in, gy, w, bias, out, B, Hin, Hout, T, tb, ngroups);
     TT_LAUNCH_CHECK();
     return 0;

@@ -10,4 +10,5 @@ for C in 32 16 8 4; do
 done
 KB_C=32,16 KB_WHAT=bwdf bash tools/pmc_level.sh r03_fused > /dev/null 2>&1
 KB_ITERS=3 PMC_PY=tools/kbench.py PMC_ARGS=cqt bash tools/pmc_level.sh r03_cqt > /dev/null 2>&1
+KB_C=32,16,8,4 KB_D=1 KB_WHAT=stridefwd,edge bash tools/pmc_level.sh r03_misc > /dev/null 2>&1
 ls gpurun_out/pmc_r03_*/summary.txt

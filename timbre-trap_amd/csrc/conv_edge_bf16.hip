@@ -10,6 +10,7 @@
 // are bf16).  Weight / bias gradients: per-lane accumulators over the lane's pixels, reduced over the wave by shuffles and
 // over the workgroup through LDS once at the end; one partial per workgroup, summed by k_edge_reduce.
 #include "bf16_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -29,56 +30,68 @@ __device__ __forceinline__ ETile etile(int v, int tiles_h, int tiles_t, int ntil
     return r;
 }
 
+// Staging is split in two: `load` issues every global request of a tile into registers (unrolled, clamped addresses, no branches),
+// `store` writes them to LDS.  The kernels load tile n + 1 right after the barrier that publishes tile n and store it only after
+// tile n's arithmetic, so the memory latency runs under the arithmetic instead of in front of it (10-30 registers).
 // planes [NP][EROWS][ERW] fp32 <- NP consecutive planes of a planar (B,NP,H,T) tensor, zero outside the image.
-// All requests of the tile are issued first (unrolled, clamped addresses, no branches), the LDS writes follow: a loop of
-// load-then-store pairs would pay one memory latency per iteration.
 template <int NP>
-__device__ __forceinline__ void stage_planar(float* lds, const float* src, int b, int h0, int t0, int H, int T, int tid) {
-    constexpr int NIT = (NP * EPLANE + NT - 1) / NT;
+struct StagePlanar {
+    static constexpr int NIT = (NP * EPLANE + NT - 1) / NT;
     float v[NIT];
+    __device__ __forceinline__ void load(const float* src, ETile tl, int H, int T, int tid) {
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int i = it * NT + tid;
-        const int pl = i / EPLANE, rem = i - pl * EPLANE;
-        const int row = rem / ERW, col = rem - row * ERW;
-        const int h = h0 - 1 + row, t = t0 - 1 + col;
-        const bool ok = i < NP * EPLANE && (unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T;
-        const float q = src[ok ? (((long)b * NP + pl) * H + h) * T + t : 0];
-        v[it] = ok ? q : 0.f;
-    }
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int i = it * NT + tid;
-        if (i < NP * EPLANE) lds[i] = v[it];
-    }
-}
-// planes [4][EROWS][ERW] fp32 <- cl16 (B,H,T,4), optionally gated by the saved output
-template <bool GATE>
-__device__ __forceinline__ void stage_cl4(float* lds, const __bf16* src, const __bf16* ysrc, int b, int h0, int t0, int H, int T, int tid) {
-    constexpr int NIT = (EPLANE + NT - 1) / NT;
-    bf16x4 q[NIT], yq[GATE ? NIT : 1];
-    bool okv[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int i = it * NT + tid;
-        const int row = i / ERW, col = i - row * ERW;
-        const int h = h0 - 1 + row, t = t0 - 1 + col;
-        okv[it] = i < EPLANE && (unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T;
-        const long off = okv[it] ? (((long)b * H + h) * T + t) * 4 : 0;
-        q[it] = *reinterpret_cast<const bf16x4*>(src + off);
-        if (GATE) yq[it] = *reinterpret_cast<const bf16x4*>(ysrc + off);
-    }
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int i = it * NT + tid;
-        if (i >= EPLANE) continue;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float v = GATE ? gatef((float)q[it][c], (float)yq[it][c]) : (float)q[it][c];
-            lds[c * EPLANE + i] = okv[it] ? v : 0.f;
+        for (int it = 0; it < NIT; ++it) {
+            const int i = it * NT + tid;
+            const int pl = i / EPLANE, rem = i - pl * EPLANE;
+            const int row = rem / ERW, col = rem - row * ERW;
+            const int h = tl.h0 - 1 + row, t = tl.t0 - 1 + col;
+            const bool ok = i < NP * EPLANE && (unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T;
+            const float q = src[ok ? (((long)tl.b * NP + pl) * H + h) * T + t : 0];
+            v[it] = ok ? q : 0.f;
         }
     }
-}
+    __device__ __forceinline__ void store(float* lds, int tid) const {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = it * NT + tid;
+            if (i < NP * EPLANE) lds[i] = v[it];
+        }
+    }
+};
+// planes [4][EROWS][ERW] fp32 <- cl16 (B,H,T,4), optionally gated by the saved output
+template <bool GATE>
+struct StageCl4 {
+    static constexpr int NIT = (EPLANE + NT - 1) / NT;
+    bf16x4 q[NIT], yq[GATE ? NIT : 1];
+    unsigned okm;
+    __device__ __forceinline__ void load(const __bf16* src, const __bf16* ysrc, ETile tl, int H, int T, int tid) {
+        okm = 0;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = it * NT + tid;
+            const int row = i / ERW, col = i - row * ERW;
+            const int h = tl.h0 - 1 + row, t = tl.t0 - 1 + col;
+            const bool ok = i < EPLANE && (unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T;
+            okm |= ok ? 1u << it : 0u;
+            const long off = ok ? (((long)tl.b * H + h) * T + t) * 4 : 0;
+            q[it] = *reinterpret_cast<const bf16x4*>(src + off);
+            if (GATE) yq[it] = *reinterpret_cast<const bf16x4*>(ysrc + off);
+        }
+    }
+    __device__ __forceinline__ void store(float* lds, int tid) const {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = it * NT + tid;
+            if (i >= EPLANE) continue;
+            const bool ok = (okm >> it) & 1;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float v = GATE ? gatef((float)q[it][c], (float)yq[it][c]) : (float)q[it][c];
+                lds[c * EPLANE + i] = ok ? v : 0.f;
+            }
+        }
+    }
+};
 
 // sum `acc[N]` over the lanes of the wave, then over the four waves; thread e < N of the workgroup ends with the total
 template <int N>
@@ -95,190 +108,352 @@ __device__ __forceinline__ float wg_total(float (&acc)[N], float* red, int tid) 
     return tid < N ? (red[tid] + red[N + tid]) + (red[2 * N + tid] + red[3 * N + tid]) : 0.f;
 }
 
+// The multiply-adds are written on register PAIRS (v_pk_fma_f32; two output channels per instruction).  Measured on gfx950
+// (tools/probes/pkfma_probe.cpp) a packed fp32 op issues at about half the rate of a plain one (5.1 vs 2.8 cycles per wave
+// instruction), so the pairs are arithmetic-neutral; what they change is where the operands live.  Forward kernels pin the 36 weight
+// pairs in VGPRs for the whole kernel; backward kernels (whose 72-76 gradient accumulators already fill the register file) keep a
+// permuted copy of the weights in LDS and fetch one wave-uniform 8- or 16-byte group per tap, each group serving the wave's four
+// rows -- as wave-uniform registers the 72 weights had been spilled to VGPR lanes and read back with one v_readlane per multiply-add.
+// A wave owns ERPW CONSECUTIVE rows and carries the 3-row tap window in registers: one new row of taps per output row instead of
+// three (one LDS pipe per CU serves four SIMDs).  Per call at the bench shape: convin backward 0.506 -> 0.42 ms, convout backward
+// 0.399 -> 0.365 ms, the forward kernels unchanged (0.21 / 0.17 ms); 3.57 -> 3.06 ms per train step.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 splat2(float v) { f32x2 r; r[0] = v; r[1] = v; return r; }
+constexpr int ERPW = ETH / 4;
+
+// keeps the LDS reads of a row with that row (sched_barrier alone does not order loads: it touches no memory)
+__device__ __forceinline__ void row_fence() { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+
+// Accumulators feed only the loop-carried values, so the optimiser sinks their multiply-adds to the end of the tile body, past
+// every LDS read (all windows live at once: spills).  An empty volatile asm that "modifies" them keeps each row's arithmetic in its row.
+template <int N> __device__ __forceinline__ void pin(f32x2 (&a)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(a[i]));
+}
+
+// One window row = columns lane .. lane + 3 of NP planes as two register PAIRS (the fourth column is never used): a pair is what
+// ds_read2_b32 returns and what v_pk_fma_f32 broadcasts from with op_sel, so no tap costs a register move.
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+template <int SEL> __device__ __forceinline__ f32x2 bcast(f32x2 v) { return __builtin_shufflevector(v, v, SEL, SEL); }
+template <int NP>
+struct WRow {
+    f32x2 p[NP][2];
+    __device__ __forceinline__ void load(const float* lds, int off) {
+#pragma unroll
+        for (int c = 0; c < NP; ++c) {
+            p[c][0] = *reinterpret_cast<const f32x2u*>(lds + c * EPLANE + off);
+            p[c][1] = *reinterpret_cast<const f32x2u*>(lds + c * EPLANE + off + 2);
+        }
+    }
+    template <int J> __device__ __forceinline__ f32x2 tap(int c) const { return bcast<J & 1>(p[c][J >> 1]); }
+};
+// the rolling window: w[0..2] = halo rows r, r + 1, r + 2
+template <int NP>
+struct Win {
+    WRow<NP> w[3];
+    __device__ __forceinline__ void start(const float* lds, int r, int lane) {
+        w[1].load(lds, r * ERW + lane);
+        w[2].load(lds, (r + 1) * ERW + lane);
+    }
+    __device__ __forceinline__ void advance(const float* lds, int r, int lane) {      // r = the output row whose window is wanted
+        w[0] = w[1];
+        w[1] = w[2];
+        w[2].load(lds, (r + 2) * ERW + lane);
+    }
+    template <int K> __device__ __forceinline__ f32x2 tap(int c) const { return w[K / 3].template tap<K % 3>(c); }
+};
+// compile-time tap loop: f(k_constant)
+template <int K, class F> __device__ __forceinline__ void taps9(F&& f) {
+    if constexpr (K < 9) { f(std::integral_constant<int, K>{}); taps9<K + 1>(f); }
+}
+
 // ---- Encoder.convin ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void k_cin_fwd(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                  __bf16* __restrict__ y, int H, int T, int tiles_h, int tiles_t, int ntiles) {
-    __shared__ float xs[2 * EPLANE];
+    __shared__ float xs[2 * EPLANE + 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float wr[72], br[4];                                         // w[co][ci][kh][kw]: uniform
+    f32x2 wr[2][18], br[2];                                      // [co pair][ci * 9 + k] = (w[2p][ci][k], w[2p + 1][ci][k])
 #pragma unroll
-    for (int i = 0; i < 72; ++i) { wr[i] = w[i]; asm volatile("" : "+v"(wr[i])); }   // pinned in VGPRs: as wave-uniform values they
-                                                                                 // were spilled to VGPR lanes and read back with one v_readlane per use
+    for (int p = 0; p < 2; ++p) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) br[c] = bias[c];
+        for (int i = 0; i < 18; ++i) {
+            wr[p][i][0] = w[(2 * p) * 18 + i]; wr[p][i][1] = w[(2 * p + 1) * 18 + i];
+            asm volatile("" : "+v"(wr[p][i]));
+        }
+        br[p][0] = bias[2 * p]; br[p][1] = bias[2 * p + 1];
+    }
+    StagePlanar<2> sx;
+    if (blockIdx.x < ntiles) sx.load(x, etile(blockIdx.x, tiles_h, tiles_t, ntiles), H, T, tid);
     for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
         const ETile tl = etile(v, tiles_h, tiles_t, ntiles);
         __syncthreads();
-        stage_planar<2>(xs, x, tl.b, tl.h0, tl.t0, H, T, tid);
+        sx.store(xs, tid);
         __syncthreads();
-        const int t = tl.t0 + lane;
-        for (int r = wave; r < ETH; r += 4) {
-            const int h = tl.h0 + r;
-            if (h >= H) break;
-            float acc[4] = {br[0], br[1], br[2], br[3]};
+        if (v + gridDim.x < ntiles) sx.load(x, etile(v + gridDim.x, tiles_h, tiles_t, ntiles), H, T, tid);
+        const int t = tl.t0 + lane, r0 = wave * ERPW;
+        Win<2> xw;
+        xw.start(xs, r0, lane);
+        bf16x4 o[ERPW];                                          // stores after the rows: no branch between them (one basic block, so
+#pragma unroll                                                   // that every tap broadcast folds into the multiply-add's op_sel)
+        for (int rr = 0; rr < ERPW; ++rr) {
+            xw.advance(xs, r0 + rr, lane);
+            f32x2 acc[2][2] = {{br[0], splat2(0.f)}, {br[1], splat2(0.f)}};     // [co pair][ci]: four independent chains
 #pragma unroll
             for (int ci = 0; ci < 2; ++ci)
+                taps9<0>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    const f32x2 xv = xw.template tap<k>(ci);
+                    acc[0][ci] = wr[0][ci * 9 + k] * xv + acc[0][ci];
+                    acc[1][ci] = wr[1][ci * 9 + k] * xv + acc[1][ci];
+                });
+            acc[0][0] += acc[0][1]; acc[1][0] += acc[1][1];
+            o[rr][0] = (__bf16)elu_f(acc[0][0][0]); o[rr][1] = (__bf16)elu_f(acc[0][0][1]);
+            o[rr][2] = (__bf16)elu_f(acc[1][0][0]); o[rr][3] = (__bf16)elu_f(acc[1][0][1]);
+            asm volatile("" :: "v"(o[rr]));
+            row_fence();
+        }
 #pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    const float xv = xs[ci * EPLANE + (r + k / 3) * ERW + lane + k % 3];
-#pragma unroll
-                    for (int co = 0; co < 4; ++co) acc[co] = fmaf(wr[(co * 2 + ci) * 9 + k], xv, acc[co]);
-                }
-            bf16x4 o;
-#pragma unroll
-            for (int co = 0; co < 4; ++co) o[co] = (__bf16)elu_f(acc[co]);
-            if (t < T) *reinterpret_cast<bf16x4*>(y + (((long)tl.b * H + h) * T + t) * 4) = o;
+        for (int rr = 0; rr < ERPW; ++rr) {
+            const int h = tl.h0 + r0 + rr;
+            if (t < T && h < H) *reinterpret_cast<bf16x4*>(y + (((long)tl.b * H + h) * T + t) * 4) = o[rr];
         }
     }
 }
 
 // dW[co][ci][k] = sum g[co][p] x[ci][p + k];  db[co] = sum g[co];  dx[ci][p] = sum_{co,k} W[co][ci][k] g[co][p - k]
+// (g and x are zero outside the image in LDS, so only the stores are masked)
 template <bool DX>
-__global__ __launch_bounds__(NT) void k_cin_bwd(const float* __restrict__ x, const __bf16* __restrict__ y, const __bf16* __restrict__ dy,
+__global__ __launch_bounds__(NT, 2) void k_cin_bwd(const float* __restrict__ x, const __bf16* __restrict__ y, const __bf16* __restrict__ dy,
                                                  const float* __restrict__ w, float* __restrict__ dx, float* __restrict__ part,
                                                  int H, int T, int tiles_h, int tiles_t, int ntiles) {
-    __shared__ float xs[2 * EPLANE];
-    __shared__ float gs[4 * EPLANE];
+    __shared__ float xs[2 * EPLANE + 2];
+    __shared__ float gs[4 * EPLANE + 2];
     __shared__ float red[4 * 76];
+    __shared__ __attribute__((aligned(16))) float wl[72];       // [(co * 9 + k) * 2 + ci]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float wr[72];
+    if (DX && tid < 72) { const int ci = tid & 1, q = tid >> 1; wl[tid] = w[((q / 9) * 2 + ci) * 9 + q % 9]; }
+    f32x2 acc[2][18];                                            // [co pair][ci * 9 + k]: dW of co = 2p (lane 0) and 2p + 1 (lane 1)
+    f32x2 accb[2];
 #pragma unroll
-    for (int i = 0; i < 72; ++i) wr[i] = w[i];
-    float acc[76];                                               // 72 dW + 4 db
+    for (int p = 0; p < 2; ++p) {
 #pragma unroll
-    for (int i = 0; i < 76; ++i) acc[i] = 0.f;
+        for (int i = 0; i < 18; ++i) acc[p][i] = splat2(0.f);
+        accb[p] = splat2(0.f);
+    }
+    StagePlanar<2> sx;
+    StageCl4<true> sg;
+    if (blockIdx.x < ntiles) {
+        const ETile t0 = etile(blockIdx.x, tiles_h, tiles_t, ntiles);
+        sx.load(x, t0, H, T, tid); sg.load(dy, y, t0, H, T, tid);
+    }
     for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
         const ETile tl = etile(v, tiles_h, tiles_t, ntiles);
         __syncthreads();
-        stage_planar<2>(xs, x, tl.b, tl.h0, tl.t0, H, T, tid);
-        stage_cl4<true>(gs, dy, y, tl.b, tl.h0, tl.t0, H, T, tid);
+        sx.store(xs, tid);
+        sg.store(gs, tid);
         __syncthreads();
-        const int t = tl.t0 + lane;
-        for (int r = wave; r < ETH; r += 4) {
-            const int h = tl.h0 + r;
-            if (h >= H) break;
-            const int ctr = (r + 1) * ERW + lane + 1;
-            float g[4];
+        if (v + gridDim.x < ntiles) {
+            const ETile tn = etile(v + gridDim.x, tiles_h, tiles_t, ntiles);
+            sx.load(x, tn, H, T, tid); sg.load(dy, y, tn, H, T, tid);
+        }
+        const int t = tl.t0 + lane, r0 = wave * ERPW;
+        {
+            Win<2> xw;
+            xw.start(xs, r0, lane);
 #pragma unroll
-            for (int co = 0; co < 4; ++co) { g[co] = t < T ? gs[co * EPLANE + ctr] : 0.f; acc[72 + co] += g[co]; }
+            for (int rr = 0; rr < ERPW; ++rr) {
+                const int r = r0 + rr, ctr = (r + 1) * ERW + lane + 1;
+                xw.advance(xs, r, lane);
+                f32x2 g[2];
 #pragma unroll
-            for (int ci = 0; ci < 2; ++ci)
-#pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    const float xv = xs[ci * EPLANE + (r + k / 3) * ERW + lane + k % 3];
-#pragma unroll
-                    for (int co = 0; co < 4; ++co) acc[(co * 2 + ci) * 9 + k] = fmaf(g[co], xv, acc[(co * 2 + ci) * 9 + k]);
+                for (int p = 0; p < 2; ++p) {
+                    g[p][0] = gs[(2 * p) * EPLANE + ctr]; g[p][1] = gs[(2 * p + 1) * EPLANE + ctr];
+                    accb[p] += g[p];
                 }
-            if constexpr (DX) {
-                float d[2] = {0.f, 0.f};
 #pragma unroll
-                for (int co = 0; co < 4; ++co)
+                for (int ci = 0; ci < 2; ++ci)
+                    taps9<0>([&](auto kc) {
+                        constexpr int k = decltype(kc)::value;
+                        const f32x2 xv = xw.template tap<k>(ci);
+                        acc[0][ci * 9 + k] = g[0] * xv + acc[0][ci * 9 + k];
+                        acc[1][ci * 9 + k] = g[1] * xv + acc[1][ci * 9 + k];
+                    });
+                pin(acc[0]); pin(acc[1]); pin(accb);
+                row_fence();
+            }
+        }
+        if constexpr (DX) {
+            f32x2 d[ERPW];                                       // (ci 0, ci 1) of the wave's rows
 #pragma unroll
-                    for (int k = 0; k < 9; ++k) {                // g at p - (k - centre) = rows r + 2 - k/3, cols lane + 2 - k%3
-                        const float gv = gs[co * EPLANE + (r + 2 - k / 3) * ERW + lane + 2 - k % 3];
+            for (int rr = 0; rr < ERPW; ++rr) d[rr] = splat2(0.f);
 #pragma unroll
-                        for (int ci = 0; ci < 2; ++ci) d[ci] = fmaf(wr[(co * 2 + ci) * 9 + k], gv, d[ci]);
-                    }
-                if (t < T) {
+            for (int co = 0; co < 4; ++co) {
+                WRow<1> gw[ERPW + 2];                            // halo rows r0 .. r0 + ERPW + 1 of g[co]
 #pragma unroll
-                    for (int ci = 0; ci < 2; ++ci) dx[(((long)tl.b * 2 + ci) * H + h) * T + t] = d[ci];
+                for (int i = 0; i < ERPW + 2; ++i) gw[i].load(gs + co * EPLANE, (r0 + i) * ERW + lane);
+                taps9<0>([&](auto kc) {                          // g at p - (k - centre): halo row rr + 2 - k/3, column 2 - k%3
+                    constexpr int k = decltype(kc)::value;
+                    const f32x2 w2 = *reinterpret_cast<const f32x2*>(&wl[(co * 9 + k) * 2]);
+#pragma unroll
+                    for (int rr = 0; rr < ERPW; ++rr) d[rr] = w2 * gw[rr + 2 - k / 3].template tap<2 - k % 3>(0) + d[rr];
+                });
+                pin(d);
+                row_fence();
+            }
+#pragma unroll
+            for (int rr = 0; rr < ERPW; ++rr) {
+                const int h = tl.h0 + r0 + rr;
+                if (t < T && h < H) {
+                    dx[(((long)tl.b * 2 + 0) * H + h) * T + t] = d[rr][0];
+                    dx[(((long)tl.b * 2 + 1) * H + h) * T + t] = d[rr][1];
                 }
             }
         }
     }
     __syncthreads();
-    const float tot = wg_total<76>(acc, red, tid);
+    float flat[76];                                              // back to [co][ci][k], then the 4 bias sums
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int i = 0; i < 18; ++i) { flat[(2 * p) * 18 + i] = acc[p][i][0]; flat[(2 * p + 1) * 18 + i] = acc[p][i][1]; }
+        flat[72 + 2 * p] = accb[p][0]; flat[72 + 2 * p + 1] = accb[p][1];
+    }
+    const float tot = wg_total<76>(flat, red, tid);
     if (tid < 76) part[(long)blockIdx.x * NPARTW + tid] = tot;
 }
 
 // ---- Decoder.convout -----------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void k_cout_fwd(const __bf16* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                   float* __restrict__ y, int H, int T, int tiles_h, int tiles_t, int ntiles) {
-    __shared__ float xs[4 * EPLANE];
+    __shared__ float xs[4 * EPLANE + 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float wr[72], br[2];                                         // w[co][ci][kh][kw], co < 2, ci < 4
+    f32x2 wr[36], br;                                            // [ci * 9 + k] = (w[0][ci][k], w[1][ci][k])
 #pragma unroll
-    for (int i = 0; i < 72; ++i) { wr[i] = w[i]; asm volatile("" : "+v"(wr[i])); }   // pinned in VGPRs: as wave-uniform values they
-                                                                                 // were spilled to VGPR lanes and read back with one v_readlane per use
+    for (int i = 0; i < 36; ++i) { wr[i][0] = w[i]; wr[i][1] = w[36 + i]; asm volatile("" : "+v"(wr[i])); }
     br[0] = bias[0]; br[1] = bias[1];
+    StageCl4<false> sx;
+    if (blockIdx.x < ntiles) sx.load(x, nullptr, etile(blockIdx.x, tiles_h, tiles_t, ntiles), H, T, tid);
     for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
         const ETile tl = etile(v, tiles_h, tiles_t, ntiles);
         __syncthreads();
-        stage_cl4<false>(xs, x, nullptr, tl.b, tl.h0, tl.t0, H, T, tid);
+        sx.store(xs, tid);
         __syncthreads();
-        const int t = tl.t0 + lane;
-        for (int r = wave; r < ETH; r += 4) {
-            const int h = tl.h0 + r;
-            if (h >= H) break;
-            float acc[2] = {br[0], br[1]};
+        if (v + gridDim.x < ntiles) sx.load(x, nullptr, etile(v + gridDim.x, tiles_h, tiles_t, ntiles), H, T, tid);
+        const int t = tl.t0 + lane, r0 = wave * ERPW;
+        Win<4> xw;
+        xw.start(xs, r0, lane);
+        f32x2 o[ERPW];
+#pragma unroll
+        for (int rr = 0; rr < ERPW; ++rr) {
+            xw.advance(xs, r0 + rr, lane);
+            f32x2 a4[4] = {br, splat2(0.f), splat2(0.f), splat2(0.f)};          // one chain per input channel
 #pragma unroll
             for (int ci = 0; ci < 4; ++ci)
+                taps9<0>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    a4[ci] = wr[ci * 9 + k] * xw.template tap<k>(ci) + a4[ci];
+                });
+            o[rr] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+            asm volatile("" :: "v"(o[rr]));
+            row_fence();
+        }
 #pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    const float xv = xs[ci * EPLANE + (r + k / 3) * ERW + lane + k % 3];
-                    acc[0] = fmaf(wr[ci * 9 + k], xv, acc[0]);
-                    acc[1] = fmaf(wr[(4 + ci) * 9 + k], xv, acc[1]);
-                }
-            if (t < T) {
-                y[(((long)tl.b * 2 + 0) * H + h) * T + t] = acc[0];
-                y[(((long)tl.b * 2 + 1) * H + h) * T + t] = acc[1];
+        for (int rr = 0; rr < ERPW; ++rr) {
+            const int h = tl.h0 + r0 + rr;
+            if (t < T && h < H) {
+                y[(((long)tl.b * 2 + 0) * H + h) * T + t] = o[rr][0];
+                y[(((long)tl.b * 2 + 1) * H + h) * T + t] = o[rr][1];
             }
         }
     }
 }
 
-__global__ __launch_bounds__(NT) void k_cout_bwd(const __bf16* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ w,
+__global__ __launch_bounds__(NT, 2) void k_cout_bwd(const __bf16* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ w,
                                                   __bf16* __restrict__ dx, float* __restrict__ part, int H, int T, int tiles_h,
                                                   int tiles_t, int ntiles) {
-    __shared__ float xs[4 * EPLANE];
-    __shared__ float gs[2 * EPLANE];
+    __shared__ float xs[4 * EPLANE + 2];
+    __shared__ float gs[2 * EPLANE + 2];
     __shared__ float red[4 * 74];
+    __shared__ __attribute__((aligned(16))) float wl[72];       // [(co * 9 + k) * 4 + ci]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float wr[72];
+    if (tid < 72) { const int ci = tid & 3, q = tid >> 2; wl[tid] = w[((q / 9) * 4 + ci) * 9 + q % 9]; }
+    f32x2 acc[36], accb = splat2(0.f);                           // [ci * 9 + k]: dW of co 0 (lane 0) and co 1 (lane 1)
 #pragma unroll
-    for (int i = 0; i < 72; ++i) wr[i] = w[i];
-    float acc[74];                                               // 72 dW + 2 db
-#pragma unroll
-    for (int i = 0; i < 74; ++i) acc[i] = 0.f;
+    for (int i = 0; i < 36; ++i) acc[i] = splat2(0.f);
+    StageCl4<false> sx;
+    StagePlanar<2> sg;
+    if (blockIdx.x < ntiles) {
+        const ETile t0 = etile(blockIdx.x, tiles_h, tiles_t, ntiles);
+        sx.load(x, nullptr, t0, H, T, tid); sg.load(dy, t0, H, T, tid);
+    }
     for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
         const ETile tl = etile(v, tiles_h, tiles_t, ntiles);
         __syncthreads();
-        stage_cl4<false>(xs, x, nullptr, tl.b, tl.h0, tl.t0, H, T, tid);
-        stage_planar<2>(gs, dy, tl.b, tl.h0, tl.t0, H, T, tid);
+        sx.store(xs, tid);
+        sg.store(gs, tid);
         __syncthreads();
-        const int t = tl.t0 + lane;
-        for (int r = wave; r < ETH; r += 4) {
-            const int h = tl.h0 + r;
-            if (h >= H) break;
-            const int ctr = (r + 1) * ERW + lane + 1;
-            float g[2];
+        if (v + gridDim.x < ntiles) {
+            const ETile tn = etile(v + gridDim.x, tiles_h, tiles_t, ntiles);
+            sx.load(x, nullptr, tn, H, T, tid); sg.load(dy, tn, H, T, tid);
+        }
+        const int t = tl.t0 + lane, r0 = wave * ERPW;
+        {
+            Win<4> xw;
+            xw.start(xs, r0, lane);
 #pragma unroll
-            for (int co = 0; co < 2; ++co) { g[co] = t < T ? gs[co * EPLANE + ctr] : 0.f; acc[72 + co] += g[co]; }
+            for (int rr = 0; rr < ERPW; ++rr) {
+                const int r = r0 + rr, ctr = (r + 1) * ERW + lane + 1;
+                xw.advance(xs, r, lane);
+                f32x2 g;
+                g[0] = gs[ctr]; g[1] = gs[EPLANE + ctr];
+                accb += g;
 #pragma unroll
-            for (int ci = 0; ci < 4; ++ci)
+                for (int ci = 0; ci < 4; ++ci)
+                    taps9<0>([&](auto kc) {
+                        constexpr int k = decltype(kc)::value;
+                        acc[ci * 9 + k] = g * xw.template tap<k>(ci) + acc[ci * 9 + k];
+                    });
+                pin(acc); asm volatile("" : "+v"(accb));
+                row_fence();
+            }
+        }
+        f32x2 d[ERPW][2];                                        // (ci 0, ci 1), (ci 2, ci 3) of the wave's rows
 #pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    const float xv = xs[ci * EPLANE + (r + k / 3) * ERW + lane + k % 3];
-                    acc[ci * 9 + k] = fmaf(g[0], xv, acc[ci * 9 + k]);
-                    acc[(4 + ci) * 9 + k] = fmaf(g[1], xv, acc[(4 + ci) * 9 + k]);
+        for (int rr = 0; rr < ERPW; ++rr) d[rr][0] = d[rr][1] = splat2(0.f);
+#pragma unroll
+        for (int co = 0; co < 2; ++co) {
+            WRow<1> gw[ERPW + 2];                                // halo rows r0 .. r0 + ERPW + 1 of dy[co]
+#pragma unroll
+            for (int i = 0; i < ERPW + 2; ++i) gw[i].load(gs + co * EPLANE, (r0 + i) * ERW + lane);
+            taps9<0>([&](auto kc) {                              // dy at p - (k - centre): halo row rr + 2 - k/3, column 2 - k%3
+                constexpr int k = decltype(kc)::value;
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(&wl[(co * 9 + k) * 4]);
+                const f32x2 w01 = __builtin_shufflevector(wv, wv, 0, 1), w23 = __builtin_shufflevector(wv, wv, 2, 3);
+#pragma unroll
+                for (int rr = 0; rr < ERPW; ++rr) {
+                    const f32x2 gv = gw[rr + 2 - k / 3].template tap<2 - k % 3>(0);
+                    d[rr][0] = w01 * gv + d[rr][0];
+                    d[rr][1] = w23 * gv + d[rr][1];
                 }
-            float d[4] = {0.f, 0.f, 0.f, 0.f};
+            });
 #pragma unroll
-            for (int co = 0; co < 2; ++co)
+            for (int rr = 0; rr < ERPW; ++rr) pin(d[rr]);
+            row_fence();
+        }
 #pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    const float gv = gs[co * EPLANE + (r + 2 - k / 3) * ERW + lane + 2 - k % 3];
-#pragma unroll
-                    for (int ci = 0; ci < 4; ++ci) d[ci] = fmaf(wr[(co * 4 + ci) * 9 + k], gv, d[ci]);
-                }
+        for (int rr = 0; rr < ERPW; ++rr) {
+            const int h = tl.h0 + r0 + rr;
             bf16x4 o;
-#pragma unroll
-            for (int ci = 0; ci < 4; ++ci) o[ci] = (__bf16)d[ci];
-            if (t < T) *reinterpret_cast<bf16x4*>(dx + (((long)tl.b * H + h) * T + t) * 4) = o;
+            o[0] = (__bf16)d[rr][0][0]; o[1] = (__bf16)d[rr][0][1]; o[2] = (__bf16)d[rr][1][0]; o[3] = (__bf16)d[rr][1][1];
+            if (t < T && h < H) *reinterpret_cast<bf16x4*>(dx + (((long)tl.b * H + h) * T + t) * 4) = o;
         }
     }
     __syncthreads();
-    const float tot = wg_total<74>(acc, red, tid);
+    float flat[74];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) { flat[i] = acc[i][0]; flat[36 + i] = acc[i][1]; }
+    flat[72] = accb[0]; flat[73] = accb[1];
+    const float tot = wg_total<74>(flat, red, tid);
     if (tid < 74) part[(long)blockIdx.x * NPARTW + tid] = tot;
 }
 

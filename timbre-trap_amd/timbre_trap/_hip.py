@@ -95,6 +95,11 @@ _PROTOS = {
     'tt_adamw_step': (c_int, [P, P, P, P, P, L, F_, F_, F_, F_, F_, I, F_, I, P]),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOS)
+# Per-source compiler flags.  cqt.hip: the SLP vectoriser turns the complex butterflies into v_pk_*_f32 plus the register moves that
+# form their aligned pairs; on gfx950 a packed fp32 op issues at about half the rate of a plain one (tools/probes/pkfma_probe.cpp:
+# 5.1 vs 2.8 cycles), so the pairs buy nothing and the moves cost: CQT forward 0.122 -> 0.109 ms, inverse 0.175 -> 0.161 ms without it.
+# The other sources keep it (it also merges loads / stores: the residual backward is 0.5 ms per step slower without).
+EXTRA_FLAGS = {'cqt.hip': ['-fno-slp-vectorize']}
 
 
 def build(verbose=False, force=False):
@@ -111,7 +116,7 @@ def build(verbose=False, force=False):
     for s in srcs:
         o = os.path.join(PKG_ROOT, 'lib', os.path.basename(s).replace('.hip', '.o'))
         objs.append(o)
-        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', s, '-o', o]
+        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC'] + EXTRA_FLAGS.get(os.path.basename(s), []) + ['-c', s, '-o', o]
         if verbose:
             print(' '.join(cmd), file=sys.stderr)
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -8,7 +8,8 @@ obj=/tmp/ttrap_variant_$name
 mkdir -p $obj
 pids=()
 for f in $src/*.hip; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c $f -o $obj/$(basename $f .hip).o &
+  extra=""; [ "$(basename $f)" = cqt.hip ] && extra="-fno-slp-vectorize"      # as timbre_trap/_hip.py EXTRA_FLAGS
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $extra "$@" -c $f -o $obj/$(basename $f .hip).o &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p || exit 1; done

@@ -403,7 +403,7 @@ def test_latent_heads_stagewise(CT, D, B, T):
 
 # ---- boundary 3x3 convolutions (csrc/conv_edge_bf16.hip) ----------------------------------------------------------------------
 
-@pytest.mark.parametrize('shape', [(2, 21, 80), (1, 16, 64), (1, 37, 130), (3, 5, 34)])
+@pytest.mark.parametrize('shape', [(2, 21, 80), (1, 16, 64), (1, 37, 130), (3, 5, 34), (2, 70, 260)])      # the last two have interior tiles
 def test_edge_convs(shape):
     """convin (fp32 planar -> cl16, ELU) and convout (cl16 -> fp32 planar) with all their gradients; fp32 arithmetic, so the
     only rounding is that of the cl16 tensors themselves."""

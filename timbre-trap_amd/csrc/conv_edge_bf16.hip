@@ -16,6 +16,9 @@ namespace {
 
 constexpr int ETH = 16, ETW = 64, ERW = ETW + 2, EROWS = ETH + 2;      // tile and its halo
 constexpr int EPLANE = EROWS * ERW;
+// fp32 planar tiles in LDS: rows of PP floats = frames t0 - 4 .. t0 + 67 (sixteen-byte groups of the image row, so that a tile row is
+// 18 aligned float4 loads when T % 4 == 0); frame t0 + c sits at column c + 4, the three taps of lane l at columns l + 3 .. l + 5
+constexpr int PP = ETW + 8, PPLANE = EROWS * PP, PCOL0 = 3;
 constexpr int NPARTW = 80;                                             // 72 weight + up to 4 bias partials, padded
 
 __device__ __forceinline__ float gatef(float dy, float y) { return dy * elu_dout(y); }
@@ -30,31 +33,71 @@ __device__ __forceinline__ ETile etile(int v, int tiles_h, int tiles_t, int ntil
     return r;
 }
 
-// Staging is split in two: `load` issues every global request of a tile into registers (unrolled, clamped addresses, no branches),
-// `store` writes them to LDS.  The kernels load tile n + 1 right after the barrier that publishes tile n and store it only after
-// tile n's arithmetic, so the memory latency runs under the arithmetic instead of in front of it (10-30 registers).
-// planes [NP][EROWS][ERW] fp32 <- NP consecutive planes of a planar (B,NP,H,T) tensor, zero outside the image.
-template <int NP>
+// Staging is split in two: `load` issues every global request of a tile into registers (unrolled, no branches inside), `store`
+// writes them to LDS.  The kernels load tile n + 1 right after the barrier that publishes tile n and store it only after tile n's
+// arithmetic, so the memory latency runs under the arithmetic instead of in front of it (10-30 registers).
+// The address arithmetic was the largest single cost of these kernels (per element: two divisions by constants, two bounds tests,
+// a 64-bit multiply-add chain -- about 25 four-cycle instructions for an 8-byte load): a thread's elements sit at the same place of
+// every tile, so their byte offsets inside an image row block (`rel`) are computed once per kernel, and an INTERIOR tile (no halo
+// element outside the image: 82 % of the tiles at the bench shape) needs one 32-bit add per element on top of a scalar base pointer.
+// Tiles on the image border keep the general path.
+struct TileCtx { ETile tl; bool interior, interior_v; };
+__device__ __forceinline__ TileCtx tile_ctx(int v, int tiles_h, int tiles_t, int ntiles, int H, int T) {
+    TileCtx c;
+    c.tl = etile(v, tiles_h, tiles_t, ntiles);
+    const bool rows = c.tl.h0 >= 1 && c.tl.h0 + ETH + 1 <= H;
+    c.interior = rows && c.tl.t0 >= 1 && c.tl.t0 + ETW + 1 <= T;
+    c.interior_v = rows && c.tl.t0 >= 4 && c.tl.t0 + ETW + 4 <= T;         // the float4 groups of a planar tile row
+    return c;
+}
+// planes [NP][EROWS][PP] fp32 <- NP consecutive planes of a planar (B,NP,H,T) tensor, zero outside the image.
+// VEC (T % 4 == 0): a thread's element is an aligned float4 of an image row -- 3 loads and 3 sixteen-byte LDS writes per thread and
+// tile instead of 10 + 10 four-byte ones.
+template <int NP, bool VEC>
 struct StagePlanar {
-    static constexpr int NIT = (NP * EPLANE + NT - 1) / NT;
-    float v[NIT];
-    __device__ __forceinline__ void load(const float* src, ETile tl, int H, int T, int tid) {
+    static constexpr int PER_ROW = VEC ? PP / 4 : ERW, NEL = NP * EROWS * PER_ROW, NIT = (NEL + NT - 1) / NT;
+    typedef typename std::conditional<VEC, f32x4, float>::type V;
+    V v[NIT];
+    unsigned rel[NIT];                                           // byte offset of element `it` from the tile's first staged element
+    static __device__ __forceinline__ void where(int i, int& pl, int& row, int& col) {      // col: frame - t0
+        pl = i / (EROWS * PER_ROW);
+        const int rem = i - pl * (EROWS * PER_ROW);
+        row = rem / PER_ROW;
+        col = VEC ? (rem - row * PER_ROW) * 4 - 4 : rem - row * PER_ROW - 1;
+    }
+    __device__ __forceinline__ void init(int H, int T, int tid) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int i = it * NT + tid;
-            const int pl = i / EPLANE, rem = i - pl * EPLANE;
-            const int row = rem / ERW, col = rem - row * ERW;
-            const int h = tl.h0 - 1 + row, t = tl.t0 - 1 + col;
-            const bool ok = i < NP * EPLANE && (unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T;
-            const float q = src[ok ? (((long)tl.b * NP + pl) * H + h) * T + t : 0];
-            v[it] = ok ? q : 0.f;
+            int pl, row, col;
+            where(it * NT + tid, pl, row, col);
+            rel[it] = it * NT + tid < NEL ? (unsigned)((pl * H + row) * T + col + (VEC ? 4 : 1)) * 4u : 0u;
+        }
+    }
+    __device__ __forceinline__ void load(const float* src, const TileCtx& c, int H, int T, int tid) {
+        const ETile tl = c.tl;
+        if (VEC ? c.interior_v : c.interior) {
+            const char* base = reinterpret_cast<const char*>(src + ((long)tl.b * NP * H + (tl.h0 - 1)) * T + (tl.t0 - (VEC ? 4 : 1)));
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) v[it] = *reinterpret_cast<const V*>(base + rel[it]);
+            return;
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            int pl, row, col;
+            where(it * NT + tid, pl, row, col);
+            const int h = tl.h0 - 1 + row, t = tl.t0 + col;      // VEC: T % 4 == 0 and t % 4 == 0, so the four frames are in or out together
+            const bool ok = it * NT + tid < NEL && (unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T;
+            const V q = *reinterpret_cast<const V*>(src + (ok ? (((long)tl.b * NP + pl) * H + h) * T + t : 0));
+            if constexpr (VEC) { v[it] = ok ? q : V{0.f, 0.f, 0.f, 0.f}; } else { v[it] = ok ? q : 0.f; }
         }
     }
     __device__ __forceinline__ void store(float* lds, int tid) const {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int i = it * NT + tid;
-            if (i < NP * EPLANE) lds[i] = v[it];
+            if (it * NT + tid >= NEL) continue;
+            int pl, row, col;
+            where(it * NT + tid, pl, row, col);
+            *reinterpret_cast<V*>(lds + pl * PPLANE + row * PP + col + 4) = v[it];
         }
     }
 };
@@ -63,8 +106,30 @@ template <bool GATE>
 struct StageCl4 {
     static constexpr int NIT = (EPLANE + NT - 1) / NT;
     bf16x4 q[NIT], yq[GATE ? NIT : 1];
+    unsigned rel[NIT];
     unsigned okm;
-    __device__ __forceinline__ void load(const __bf16* src, const __bf16* ysrc, ETile tl, int H, int T, int tid) {
+    __device__ __forceinline__ void init(int T, int tid) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = it * NT + tid;
+            const int row = i / ERW, col = i - row * ERW;
+            rel[it] = i < EPLANE ? (unsigned)(row * T + col) * 8u : 0u;
+        }
+    }
+    __device__ __forceinline__ void load(const __bf16* src, const __bf16* ysrc, const TileCtx& c, int H, int T, int tid) {
+        const ETile tl = c.tl;
+        if (c.interior) {
+            const long first = (((long)tl.b * H + (tl.h0 - 1)) * T + (tl.t0 - 1)) * 4;
+            const char* base = reinterpret_cast<const char*>(src + first);
+            const char* ybase = reinterpret_cast<const char*>(ysrc + first);
+            okm = 0xffffffffu;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                q[it] = *reinterpret_cast<const bf16x4*>(base + rel[it]);
+                if (GATE) yq[it] = *reinterpret_cast<const bf16x4*>(ybase + rel[it]);
+            }
+            return;
+        }
         okm = 0;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -78,17 +143,23 @@ struct StageCl4 {
             if (GATE) yq[it] = *reinterpret_cast<const bf16x4*>(ysrc + off);
         }
     }
+    // LDS layout [pixel][4 channels] fp32: ONE 16-byte write per element here and one 16-byte read per tap pixel in the kernels (the
+    // planar layout took four 4-byte writes and the staging of a tile cost as much issue time as its 144 multiply-adds:
+    // convout forward 0.179 ms, 0.111 ms with the LDS writes knocked out, 0.113 ms with the multiply-adds knocked out)
     __device__ __forceinline__ void store(float* lds, int tid) const {
+        const bool all = okm == 0xffffffffu;                     // uniform: an interior tile
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int i = it * NT + tid;
             if (i >= EPLANE) continue;
-            const bool ok = (okm >> it) & 1;
+            const bool ok = all || ((okm >> it) & 1);
+            f32x4 v;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                float v = GATE ? gatef((float)q[it][c], (float)yq[it][c]) : (float)q[it][c];
-                lds[c * EPLANE + i] = ok ? v : 0.f;
+                const float e = GATE ? gatef((float)q[it][c], (float)yq[it][c]) : (float)q[it][c];
+                v[c] = ok ? e : 0.f;
             }
+            *reinterpret_cast<f32x4*>(lds + i * 4) = v;
         }
     }
 };
@@ -141,8 +212,8 @@ struct WRow {
     __device__ __forceinline__ void load(const float* lds, int off) {
 #pragma unroll
         for (int c = 0; c < NP; ++c) {
-            p[c][0] = *reinterpret_cast<const f32x2u*>(lds + c * EPLANE + off);
-            p[c][1] = *reinterpret_cast<const f32x2u*>(lds + c * EPLANE + off + 2);
+            p[c][0] = *reinterpret_cast<const f32x2u*>(lds + c * PPLANE + off);
+            p[c][1] = *reinterpret_cast<const f32x2u*>(lds + c * PPLANE + off + 2);
         }
     }
     template <int J> __device__ __forceinline__ f32x2 tap(int c) const { return bcast<J & 1>(p[c][J >> 1]); }
@@ -152,25 +223,51 @@ template <int NP>
 struct Win {
     WRow<NP> w[3];
     __device__ __forceinline__ void start(const float* lds, int r, int lane) {
-        w[1].load(lds, r * ERW + lane);
-        w[2].load(lds, (r + 1) * ERW + lane);
+        w[1].load(lds, r * PP + lane + PCOL0);
+        w[2].load(lds, (r + 1) * PP + lane + PCOL0);
     }
     __device__ __forceinline__ void advance(const float* lds, int r, int lane) {      // r = the output row whose window is wanted
         w[0] = w[1];
         w[1] = w[2];
-        w[2].load(lds, (r + 2) * ERW + lane);
+        w[2].load(lds, (r + 2) * PP + lane + PCOL0);
     }
     template <int K> __device__ __forceinline__ f32x2 tap(int c) const { return w[K / 3].template tap<K % 3>(c); }
 };
-// compile-time tap loop: f(k_constant)
+// the same for a pixel-major tile ([pixel][4] fp32): a row = three 16-byte reads, all four channels of the three tap pixels
+struct PRow {
+    f32x4 px[3];
+    __device__ __forceinline__ void load(const float* lds, int pix) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) px[j] = *reinterpret_cast<const f32x4*>(lds + (pix + j) * 4);
+    }
+    template <int J, int C> __device__ __forceinline__ f32x2 tap() const { return __builtin_shufflevector(px[J], px[J], C, C); }
+};
+struct PWin {
+    PRow w[3];
+    __device__ __forceinline__ void start(const float* lds, int r, int lane) {
+        w[1].load(lds, r * ERW + lane);
+        w[2].load(lds, (r + 1) * ERW + lane);
+    }
+    __device__ __forceinline__ void advance(const float* lds, int r, int lane) {
+        w[0] = w[1];
+        w[1] = w[2];
+        w[2].load(lds, (r + 2) * ERW + lane);
+    }
+    template <int K, int C> __device__ __forceinline__ f32x2 tap() const { return w[K / 3].template tap<K % 3, C>(); }
+};
+// compile-time loops: f(integral_constant)
 template <int K, class F> __device__ __forceinline__ void taps9(F&& f) {
     if constexpr (K < 9) { f(std::integral_constant<int, K>{}); taps9<K + 1>(f); }
 }
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
 
 // ---- Encoder.convin ------------------------------------------------------------------------------------------------------------
+template <bool VEC>
 __global__ __launch_bounds__(NT) void k_cin_fwd(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                  __bf16* __restrict__ y, int H, int T, int tiles_h, int tiles_t, int ntiles) {
-    __shared__ float xs[2 * EPLANE + 2];
+    __shared__ __attribute__((aligned(16))) float xs[2 * PPLANE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     f32x2 wr[2][18], br[2];                                      // [co pair][ci * 9 + k] = (w[2p][ci][k], w[2p + 1][ci][k])
 #pragma unroll
@@ -182,14 +279,15 @@ __global__ __launch_bounds__(NT) void k_cin_fwd(const float* __restrict__ x, con
         }
         br[p][0] = bias[2 * p]; br[p][1] = bias[2 * p + 1];
     }
-    StagePlanar<2> sx;
-    if (blockIdx.x < ntiles) sx.load(x, etile(blockIdx.x, tiles_h, tiles_t, ntiles), H, T, tid);
+    StagePlanar<2, VEC> sx;
+    sx.init(H, T, tid);
+    if (blockIdx.x < ntiles) sx.load(x, tile_ctx(blockIdx.x, tiles_h, tiles_t, ntiles, H, T), H, T, tid);
     for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
         const ETile tl = etile(v, tiles_h, tiles_t, ntiles);
         __syncthreads();
         sx.store(xs, tid);
         __syncthreads();
-        if (v + gridDim.x < ntiles) sx.load(x, etile(v + gridDim.x, tiles_h, tiles_t, ntiles), H, T, tid);
+        if (v + gridDim.x < ntiles) sx.load(x, tile_ctx(v + gridDim.x, tiles_h, tiles_t, ntiles, H, T), H, T, tid);
         const int t = tl.t0 + lane, r0 = wave * ERPW;
         Win<2> xw;
         xw.start(xs, r0, lane);
@@ -222,12 +320,12 @@ __global__ __launch_bounds__(NT) void k_cin_fwd(const float* __restrict__ x, con
 
 // dW[co][ci][k] = sum g[co][p] x[ci][p + k];  db[co] = sum g[co];  dx[ci][p] = sum_{co,k} W[co][ci][k] g[co][p - k]
 // (g and x are zero outside the image in LDS, so only the stores are masked)
-template <bool DX>
+template <bool DX, bool VEC>
 __global__ __launch_bounds__(NT, 2) void k_cin_bwd(const float* __restrict__ x, const __bf16* __restrict__ y, const __bf16* __restrict__ dy,
                                                  const float* __restrict__ w, float* __restrict__ dx, float* __restrict__ part,
                                                  int H, int T, int tiles_h, int tiles_t, int ntiles) {
-    __shared__ float xs[2 * EPLANE + 2];
-    __shared__ float gs[4 * EPLANE + 2];
+    __shared__ __attribute__((aligned(16))) float xs[2 * PPLANE];
+    __shared__ __attribute__((aligned(16))) float gs[4 * EPLANE + 4];
     __shared__ float red[4 * 76];
     __shared__ __attribute__((aligned(16))) float wl[72];       // [(co * 9 + k) * 2 + ci]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -240,10 +338,11 @@ __global__ __launch_bounds__(NT, 2) void k_cin_bwd(const float* __restrict__ x, 
         for (int i = 0; i < 18; ++i) acc[p][i] = splat2(0.f);
         accb[p] = splat2(0.f);
     }
-    StagePlanar<2> sx;
+    StagePlanar<2, VEC> sx;
     StageCl4<true> sg;
+    sx.init(H, T, tid); sg.init(T, tid);
     if (blockIdx.x < ntiles) {
-        const ETile t0 = etile(blockIdx.x, tiles_h, tiles_t, ntiles);
+        const TileCtx t0 = tile_ctx(blockIdx.x, tiles_h, tiles_t, ntiles, H, T);
         sx.load(x, t0, H, T, tid); sg.load(dy, y, t0, H, T, tid);
     }
     for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
@@ -253,7 +352,7 @@ __global__ __launch_bounds__(NT, 2) void k_cin_bwd(const float* __restrict__ x, 
         sg.store(gs, tid);
         __syncthreads();
         if (v + gridDim.x < ntiles) {
-            const ETile tn = etile(v + gridDim.x, tiles_h, tiles_t, ntiles);
+            const TileCtx tn = tile_ctx(v + gridDim.x, tiles_h, tiles_t, ntiles, H, T);
             sx.load(x, tn, H, T, tid); sg.load(dy, y, tn, H, T, tid);
         }
         const int t = tl.t0 + lane, r0 = wave * ERPW;
@@ -264,12 +363,9 @@ __global__ __launch_bounds__(NT, 2) void k_cin_bwd(const float* __restrict__ x, 
             for (int rr = 0; rr < ERPW; ++rr) {
                 const int r = r0 + rr, ctr = (r + 1) * ERW + lane + 1;
                 xw.advance(xs, r, lane);
-                f32x2 g[2];
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    g[p][0] = gs[(2 * p) * EPLANE + ctr]; g[p][1] = gs[(2 * p + 1) * EPLANE + ctr];
-                    accb[p] += g[p];
-                }
+                const f32x4 gc = *reinterpret_cast<const f32x4*>(gs + ctr * 4);
+                f32x2 g[2] = {__builtin_shufflevector(gc, gc, 0, 1), __builtin_shufflevector(gc, gc, 2, 3)};
+                accb[0] += g[0]; accb[1] += g[1];
 #pragma unroll
                 for (int ci = 0; ci < 2; ++ci)
                     taps9<0>([&](auto kc) {
@@ -286,20 +382,21 @@ __global__ __launch_bounds__(NT, 2) void k_cin_bwd(const float* __restrict__ x, 
             f32x2 d[ERPW];                                       // (ci 0, ci 1) of the wave's rows
 #pragma unroll
             for (int rr = 0; rr < ERPW; ++rr) d[rr] = splat2(0.f);
+            static_for<0, 3>([&](auto jc) {                      // tap column: g at p - (k - centre) = halo row rr + 2 - k/3, column 2 - k%3
+                constexpr int j = decltype(jc)::value;
+                f32x4 gw[ERPW + 2];                              // all four channels of column j, halo rows r0 .. r0 + ERPW + 1
 #pragma unroll
-            for (int co = 0; co < 4; ++co) {
-                WRow<1> gw[ERPW + 2];                            // halo rows r0 .. r0 + ERPW + 1 of g[co]
-#pragma unroll
-                for (int i = 0; i < ERPW + 2; ++i) gw[i].load(gs + co * EPLANE, (r0 + i) * ERW + lane);
-                taps9<0>([&](auto kc) {                          // g at p - (k - centre): halo row rr + 2 - k/3, column 2 - k%3
-                    constexpr int k = decltype(kc)::value;
+                for (int i = 0; i < ERPW + 2; ++i) gw[i] = *reinterpret_cast<const f32x4*>(gs + ((r0 + i) * ERW + lane + j) * 4);
+                static_for<0, 12>([&](auto qc) {
+                    constexpr int co = decltype(qc)::value / 3, kh = decltype(qc)::value % 3, k = kh * 3 + (2 - j);
                     const f32x2 w2 = *reinterpret_cast<const f32x2*>(&wl[(co * 9 + k) * 2]);
 #pragma unroll
-                    for (int rr = 0; rr < ERPW; ++rr) d[rr] = w2 * gw[rr + 2 - k / 3].template tap<2 - k % 3>(0) + d[rr];
+                    for (int rr = 0; rr < ERPW; ++rr)
+                        d[rr] = w2 * __builtin_shufflevector(gw[rr + 2 - kh], gw[rr + 2 - kh], co, co) + d[rr];
                 });
                 pin(d);
                 row_fence();
-            }
+            });
 #pragma unroll
             for (int rr = 0; rr < ERPW; ++rr) {
                 const int h = tl.h0 + r0 + rr;
@@ -325,54 +422,65 @@ __global__ __launch_bounds__(NT, 2) void k_cin_bwd(const float* __restrict__ x, 
 // ---- Decoder.convout -----------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void k_cout_fwd(const __bf16* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                   float* __restrict__ y, int H, int T, int tiles_h, int tiles_t, int ntiles) {
-    __shared__ float xs[4 * EPLANE + 2];
+    __shared__ __attribute__((aligned(16))) float xs[4 * EPLANE + 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     f32x2 wr[36], br;                                            // [ci * 9 + k] = (w[0][ci][k], w[1][ci][k])
 #pragma unroll
     for (int i = 0; i < 36; ++i) { wr[i][0] = w[i]; wr[i][1] = w[36 + i]; asm volatile("" : "+v"(wr[i])); }
     br[0] = bias[0]; br[1] = bias[1];
     StageCl4<false> sx;
-    if (blockIdx.x < ntiles) sx.load(x, nullptr, etile(blockIdx.x, tiles_h, tiles_t, ntiles), H, T, tid);
+    sx.init(T, tid);
+    if (blockIdx.x < ntiles) sx.load(x, nullptr, tile_ctx(blockIdx.x, tiles_h, tiles_t, ntiles, H, T), H, T, tid);
+    // The results of a tile are stored one iteration LATER, just before the loads of the tile after next are issued: loads and stores
+    // retire through one in-order counter, so the wait for a tile's operands also waits for every store issued before them -- stores
+    // issued right after the arithmetic (a few cycles before that wait) put their whole write latency on the critical path of every tile.
+    f32x2 o[ERPW];
+    ETile tp; tp.b = -1; tp.h0 = tp.t0 = 0;
+    const int r0 = wave * ERPW;
+    auto flush = [&]() {
+        if (tp.b < 0) return;
+        const int t = tp.t0 + lane;
+#pragma unroll
+        for (int rr = 0; rr < ERPW; ++rr) {
+            const int h = tp.h0 + r0 + rr;
+            if (t < T && h < H) {
+                y[(((long)tp.b * 2 + 0) * H + h) * T + t] = o[rr][0];
+                y[(((long)tp.b * 2 + 1) * H + h) * T + t] = o[rr][1];
+            }
+        }
+    };
     for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
         const ETile tl = etile(v, tiles_h, tiles_t, ntiles);
         __syncthreads();
         sx.store(xs, tid);
         __syncthreads();
-        if (v + gridDim.x < ntiles) sx.load(x, nullptr, etile(v + gridDim.x, tiles_h, tiles_t, ntiles), H, T, tid);
-        const int t = tl.t0 + lane, r0 = wave * ERPW;
-        Win<4> xw;
+        flush();
+        if (v + gridDim.x < ntiles) sx.load(x, nullptr, tile_ctx(v + gridDim.x, tiles_h, tiles_t, ntiles, H, T), H, T, tid);
+        PWin xw;
         xw.start(xs, r0, lane);
-        f32x2 o[ERPW];
 #pragma unroll
         for (int rr = 0; rr < ERPW; ++rr) {
             xw.advance(xs, r0 + rr, lane);
             f32x2 a4[4] = {br, splat2(0.f), splat2(0.f), splat2(0.f)};          // one chain per input channel
-#pragma unroll
-            for (int ci = 0; ci < 4; ++ci)
-                taps9<0>([&](auto kc) {
-                    constexpr int k = decltype(kc)::value;
-                    a4[ci] = wr[ci * 9 + k] * xw.template tap<k>(ci) + a4[ci];
-                });
+            static_for<0, 36>([&](auto ic) {
+                constexpr int ci = decltype(ic)::value / 9, k = decltype(ic)::value % 9;
+                a4[ci] = wr[ci * 9 + k] * xw.template tap<k, ci>() + a4[ci];
+            });
             o[rr] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
-            asm volatile("" :: "v"(o[rr]));
+            asm volatile("" : "+v"(o[rr]));
             row_fence();
         }
-#pragma unroll
-        for (int rr = 0; rr < ERPW; ++rr) {
-            const int h = tl.h0 + r0 + rr;
-            if (t < T && h < H) {
-                y[(((long)tl.b * 2 + 0) * H + h) * T + t] = o[rr][0];
-                y[(((long)tl.b * 2 + 1) * H + h) * T + t] = o[rr][1];
-            }
-        }
+        tp = tl;
     }
+    flush();
 }
 
+template <bool VEC>
 __global__ __launch_bounds__(NT, 2) void k_cout_bwd(const __bf16* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ w,
                                                   __bf16* __restrict__ dx, float* __restrict__ part, int H, int T, int tiles_h,
                                                   int tiles_t, int ntiles) {
-    __shared__ float xs[4 * EPLANE + 2];
-    __shared__ float gs[2 * EPLANE + 2];
+    __shared__ __attribute__((aligned(16))) float xs[4 * EPLANE + 4];
+    __shared__ __attribute__((aligned(16))) float gs[2 * PPLANE];
     __shared__ float red[4 * 74];
     __shared__ __attribute__((aligned(16))) float wl[72];       // [(co * 9 + k) * 4 + ci]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -381,9 +489,10 @@ __global__ __launch_bounds__(NT, 2) void k_cout_bwd(const __bf16* __restrict__ x
 #pragma unroll
     for (int i = 0; i < 36; ++i) acc[i] = splat2(0.f);
     StageCl4<false> sx;
-    StagePlanar<2> sg;
+    StagePlanar<2, VEC> sg;
+    sx.init(T, tid); sg.init(H, T, tid);
     if (blockIdx.x < ntiles) {
-        const ETile t0 = etile(blockIdx.x, tiles_h, tiles_t, ntiles);
+        const TileCtx t0 = tile_ctx(blockIdx.x, tiles_h, tiles_t, ntiles, H, T);
         sx.load(x, nullptr, t0, H, T, tid); sg.load(dy, t0, H, T, tid);
     }
     for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
@@ -393,26 +502,24 @@ __global__ __launch_bounds__(NT, 2) void k_cout_bwd(const __bf16* __restrict__ x
         sg.store(gs, tid);
         __syncthreads();
         if (v + gridDim.x < ntiles) {
-            const ETile tn = etile(v + gridDim.x, tiles_h, tiles_t, ntiles);
+            const TileCtx tn = tile_ctx(v + gridDim.x, tiles_h, tiles_t, ntiles, H, T);
             sx.load(x, nullptr, tn, H, T, tid); sg.load(dy, tn, H, T, tid);
         }
         const int t = tl.t0 + lane, r0 = wave * ERPW;
         {
-            Win<4> xw;
+            PWin xw;
             xw.start(xs, r0, lane);
 #pragma unroll
             for (int rr = 0; rr < ERPW; ++rr) {
-                const int r = r0 + rr, ctr = (r + 1) * ERW + lane + 1;
+                const int r = r0 + rr, ctr = (r + 1) * PP + lane + PCOL0 + 1;
                 xw.advance(xs, r, lane);
                 f32x2 g;
-                g[0] = gs[ctr]; g[1] = gs[EPLANE + ctr];
+                g[0] = gs[ctr]; g[1] = gs[PPLANE + ctr];
                 accb += g;
-#pragma unroll
-                for (int ci = 0; ci < 4; ++ci)
-                    taps9<0>([&](auto kc) {
-                        constexpr int k = decltype(kc)::value;
-                        acc[ci * 9 + k] = g * xw.template tap<k>(ci) + acc[ci * 9 + k];
-                    });
+                static_for<0, 36>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    acc[i] = g * xw.template tap<i % 9, i / 9>() + acc[i];
+                });
                 pin(acc); asm volatile("" : "+v"(accb));
                 row_fence();
             }
@@ -424,7 +531,7 @@ __global__ __launch_bounds__(NT, 2) void k_cout_bwd(const __bf16* __restrict__ x
         for (int co = 0; co < 2; ++co) {
             WRow<1> gw[ERPW + 2];                                // halo rows r0 .. r0 + ERPW + 1 of dy[co]
 #pragma unroll
-            for (int i = 0; i < ERPW + 2; ++i) gw[i].load(gs + co * EPLANE, (r0 + i) * ERW + lane);
+            for (int i = 0; i < ERPW + 2; ++i) gw[i].load(gs + co * PPLANE, (r0 + i) * PP + lane + PCOL0);
             taps9<0>([&](auto kc) {                              // dy at p - (k - centre): halo row rr + 2 - k/3, column 2 - k%3
                 constexpr int k = decltype(kc)::value;
                 const f32x4 wv = *reinterpret_cast<const f32x4*>(&wl[(co * 9 + k) * 4]);
@@ -490,7 +597,8 @@ int64_t tt_edge16_scratch_bytes(void) { return (int64_t)EDGE_MAX_WG * NPARTW * 4
 int tt_convin16_fwd(const float* x, const float* w, const float* b, void* y, int B, int H, int T, void* stream) {
     if (!x || !w || !b || !y || !edge_ok(B, H, T)) return TT_E_BADARG;
     int th, tt, n; edge_tiles(B, H, T, th, tt, n);
-    hipLaunchKernelGGL(k_cin_fwd, dim3(edge_grid(n)), dim3(NT), 0, tt_stream(stream), x, w, b, (__bf16*)y, H, T, th, tt, n);
+    if (T % 4 == 0) hipLaunchKernelGGL(k_cin_fwd<true>, dim3(edge_grid(n)), dim3(NT), 0, tt_stream(stream), x, w, b, (__bf16*)y, H, T, th, tt, n);
+    else hipLaunchKernelGGL(k_cin_fwd<false>, dim3(edge_grid(n)), dim3(NT), 0, tt_stream(stream), x, w, b, (__bf16*)y, H, T, th, tt, n);
     TT_LAUNCH_CHECK();
     return 0;
 }
@@ -501,8 +609,11 @@ int tt_convin16_bwd(const float* x, const void* y, const void* dy, const float* 
     int th, tt, n; edge_tiles(B, H, T, th, tt, n);
     const int grid = edge_grid(n);
     hipStream_t st = tt_stream(stream);
-    if (dx) hipLaunchKernelGGL(k_cin_bwd<true>, dim3(grid), dim3(NT), 0, st, x, (const __bf16*)y, (const __bf16*)dy, w, dx, (float*)ws, H, T, th, tt, n);
-    else hipLaunchKernelGGL(k_cin_bwd<false>, dim3(grid), dim3(NT), 0, st, x, (const __bf16*)y, (const __bf16*)dy, w, dx, (float*)ws, H, T, th, tt, n);
+    const bool vec = T % 4 == 0;
+#define CIN_BWD(DX_, V_) hipLaunchKernelGGL((k_cin_bwd<DX_, V_>), dim3(grid), dim3(NT), 0, st, x, (const __bf16*)y, (const __bf16*)dy, w, dx, (float*)ws, H, T, th, tt, n)
+    if (dx) { if (vec) CIN_BWD(true, true); else CIN_BWD(true, false); }
+    else { if (vec) CIN_BWD(false, true); else CIN_BWD(false, false); }
+#undef CIN_BWD
     TT_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_edge_reduce, dim3(2), dim3(1024), 0, st, (const float*)ws, grid, dw, db, 4);
     TT_LAUNCH_CHECK();
@@ -523,7 +634,8 @@ int tt_convout16_bwd(const void* x, const float* dy, const float* w, void* dx, f
     int th, tt, n; edge_tiles(B, H, T, th, tt, n);
     const int grid = edge_grid(n);
     hipStream_t st = tt_stream(stream);
-    hipLaunchKernelGGL(k_cout_bwd, dim3(grid), dim3(NT), 0, st, (const __bf16*)x, dy, w, (__bf16*)dx, (float*)ws, H, T, th, tt, n);
+    if (T % 4 == 0) hipLaunchKernelGGL(k_cout_bwd<true>, dim3(grid), dim3(NT), 0, st, (const __bf16*)x, dy, w, (__bf16*)dx, (float*)ws, H, T, th, tt, n);
+    else hipLaunchKernelGGL(k_cout_bwd<false>, dim3(grid), dim3(NT), 0, st, (const __bf16*)x, dy, w, (__bf16*)dx, (float*)ws, H, T, th, tt, n);
     TT_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_edge_reduce, dim3(2), dim3(1024), 0, st, (const float*)ws, grid, dw, db, 2);
     TT_LAUNCH_CHECK();

@@ -328,12 +328,17 @@ __global__ __launch_bounds__(NT) void k_s4n(const __bf16* __restrict__ in, const
             load_px<C, GATE>(in, gy, (((long)b * Hin + hi) * T + t) * C, grp < (int)ngroups && t < T && hi < Hin, q[r]);
         }
     };
-    const int gstride = gridDim.x * 4;                            // ngroups < 2^31 (checked by the launcher): 32-bit scalar arithmetic
-    int grp = blockIdx.x * 4 + wave;
+    // Neighbouring row pairs share two of their six input rows.  Workgroups go to the XCDs round-robin, each XCD has its own L2, and in
+    // plain group order the sharers sit four workgroups apart -- on different XCDs: every shared row came from HBM twice (PMC: 1.25x the
+    // algorithmic bytes here, 1.50x in k_p2n).  xcd_order hands each XCD one contiguous eighth of the group raster.
+    const int nvb = ((int)ngroups + 3) >> 2;                      // ngroups < 2^30 (checked by the launcher): 32-bit scalar arithmetic
+    int v = blockIdx.x;
+    int grp = xcd_order(v, nvb) * 4 + wave;
     s16x4 bq[6][NBI], bn[6][NBI];
     fetch(grp, bq);
-    for (; grp < (int)ngroups; grp += gstride) {
-        fetch(grp + gstride, bn);
+    for (; v < nvb; v += gridDim.x) {
+        grp = xcd_order(v, nvb) * 4 + wave;
+        fetch(v + (int)gridDim.x < nvb ? xcd_order(v + gridDim.x, nvb) * 4 + wave : (int)ngroups, bn);
         const int tblk = grp % tb;
         const int bh = grp / tb;
         const int m = bh % Hg, b = bh / Hg;
@@ -350,7 +355,7 @@ __global__ __launch_bounds__(NT) void k_s4n(const __bf16* __restrict__ in, const
                 for (int ob = 0; ob < NBO; ++ob)
 #pragma unroll
                     for (int kb = 0; kb < NBI; ++kb) acc[ob] = mma4(A[kh][ob][kb], bq[2 * o + kh][kb], acc[ob]);
-            store_px<CO, ACT>(out, (((long)b * Hout + ho) * T + t) * CO, acc, br, t < T && ho < Hout);
+            store_px<CO, ACT>(out, (((long)b * Hout + ho) * T + t) * CO, acc, br, grp < (int)ngroups && t < T && ho < Hout);
         }
 #pragma unroll
         for (int r = 0; r < 6; ++r)
@@ -395,12 +400,14 @@ __global__ __launch_bounds__(NT) void k_p2n(const __bf16* __restrict__ in, const
             load_px<CI, GATE>(in, gy, (((long)b * Hin + hi) * T + t) * CI, grp < (int)ngroups && t < T && hi >= 0 && hi < Hin, q[rs]);
         }
     };
-    const int gstride = gridDim.x * 4;                            // ngroups < 2^31 (checked by the launcher): 32-bit scalar arithmetic
-    int grp = blockIdx.x * 4 + wave;
+    const int nvb = ((int)ngroups + 3) >> 2;                      // XCD-contiguous group order: see k_s4n (each input row serves two groups)
+    int v = blockIdx.x;
+    int grp = xcd_order(v, nvb) * 4 + wave;
     s16x4 bq[2][NBI], bn[2][NBI];
     fetch(grp, bq);
-    for (; grp < (int)ngroups; grp += gstride) {
-        fetch(grp + gstride, bn);
+    for (; v < nvb; v += gridDim.x) {
+        grp = xcd_order(v, nvb) * 4 + wave;
+        fetch(v + (int)gridDim.x < nvb ? xcd_order(v + gridDim.x, nvb) * 4 + wave : (int)ngroups, bn);
         const int tblk = grp % tb;
         const int bm = grp / tb;
         const int m = bm % Hp, b = bm / Hp;
@@ -417,7 +424,7 @@ __global__ __launch_bounds__(NT) void k_p2n(const __bf16* __restrict__ in, const
 #pragma unroll
                     for (int kb = 0; kb < NBI; ++kb) acc[ob] = mma4(A[par][rs][ob][kb], bq[rs][kb], acc[ob]);
             const int h = 2 * m + par;
-            store_px<C, ACT>(out, (((long)b * Hout + h) * T + t) * C, acc, br, t < T && h < Hout);
+            store_px<C, ACT>(out, (((long)b * Hout + h) * T + t) * C, acc, br, grp < (int)ngroups && t < T && h < Hout);
         }
 #pragma unroll
         for (int rs = 0; rs < 2; ++rs)

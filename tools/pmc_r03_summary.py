@@ -121,6 +121,34 @@ def main():
                         100 * v.get('SQ_ACTIVE_INST_ANY', 0) / wc, v.get('SQ_INSTS_VALU', 0) / 1e6))
         tot[name.split('  ')[0]] = dur
     open(os.path.join(ROOT, 'profiles', 'r03_pmc_cqt.txt'), 'w').write('\n'.join(lines) + '\n')
+    # boundary convolutions and the strided layers' forward kernels (gpurun_out/pmc_r03_misc)
+    mi = parse(os.path.join(ROOT, 'gpurun_out', 'pmc_r03_misc', 'summary.txt'))
+    px = B * 540 * T
+    edge_alg = {'k_cin_fwd': (16, '8 B in + 8 B out per pixel'), 'k_cin_bwd<true': (32, 'x, y, dy, dx'), 'k_cin_bwd<false': (24, 'x, y, dy'),
+                'k_cout_fwd': (16, '8 B in + 8 B out'), 'k_cout_bwd': (24, 'x, dy, dx')}
+    lines = ['# Boundary 3x3 convolutions (H = 540, B 64, T 1024) and the strided / transposed layers FORWARD at every width (tools/kb_level.py, KB_WHAT=stridefwd,edge)',
+             '# under rocprofv3 --pmc.  Same columns as profiles/r03_pmc_bwd_C*.txt; alg for the strided layers = input + output once (equal bytes on both sides).', '']
+    for name in sorted(mi):
+        v = mi[name]
+        if 'SQ_BUSY_CYCLES' not in v or v['SQ_BUSY_CYCLES'] < 3e5:
+            continue
+        short = name.split('  ')[0]
+        alg = None
+        for key, (bpp, what) in edge_alg.items():
+            if short.startswith(key):
+                alg = px * bpp / 1e6
+        m = re.match(r'k_(s4n?|p2n?)<(\d+)', short)
+        if m:
+            C = int(m.group(2))
+            alg = 2 * 2.0 * B * C * SHAPES[C] * T / 1e6
+        dur = v['SQ_BUSY_CYCLES'] / 32
+        wc = v.get('SQ_WAVE_CYCLES', 0) or 1
+        traffic = 2 * v.get('FETCH_MB', 0) + v.get('WRITE_MB', 0)
+        lines.append('%-28s traffic %7.1f MB  alg %7.1f %s | dur %6.0fk cyc | VALU %3.0f%% MFMA %3.0f%% | parked %2.0f%% stalled %2.0f%% issuing %2.0f%% | VALU insts %5.1fM | LDS insts %5.1fM'
+                     % (short, traffic, alg or 0, ('%.2fx' % (traffic / alg)) if alg else ' -  ', dur / 1e3, 100 * 4 * v.get('SQ_ACTIVE_INST_VALU', 0) / 1024 / dur,
+                        100 * v.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / 1024 / dur, 100 * v.get('SQ_WAIT_ANY', 0) / wc, 100 * v.get('SQ_WAIT_INST_ANY', 0) / wc,
+                        100 * v.get('SQ_ACTIVE_INST_ANY', 0) / wc, v.get('SQ_INSTS_VALU', 0) / 1e6, v.get('SQ_INSTS_LDS', 0) / 1e6))
+    open(os.path.join(ROOT, 'profiles', 'r03_pmc_edge_stridefwd.txt'), 'w').write('\n'.join(lines) + '\n')
     # the bench line's roofline call: tt_wide_rb_bwd at C = 32 = k_wrb_bwd_a<32> + k_wrb_dxw<32,D,8,32> + k_wrb_reduce<32>, mean over D
     j32 = allj[32]
     per_d = {}

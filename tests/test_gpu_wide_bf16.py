@@ -116,7 +116,7 @@ def _stagewise(C, d, B, H, T):
     dA2r = _r16(dA2)
     dh1 = F.conv2d(dA2r, w2r.transpose(0, 1).contiguous())
     dA1 = dh1 * torch.where(h_k > 0, torch.ones_like(h_k), h_k + 1)
-    fused = {'0': False, '2': True}.get(os.environ.get('TTRAP_NARROW_FUSED16', '1'), d <= 2 if C == 8 else d == 1)
+    fused = {'0': False, '2': True}.get(os.environ.get('TTRAP_NARROW_FUSED16', '1'), d <= 2 if C == 8 else True)
     if C >= 16 or not fused:
         da1_k = _planar(ws[:B * H * T * C * 2].view(torch.bfloat16).view(B, H, T, C))
         _close16(da1_k, dA1, 'dA1')

@@ -1016,7 +1016,8 @@ __global__ __launch_bounds__(NT) void k_nrb_bwd_a(const __bf16* __restrict__ h1,
 #pragma unroll
         for (int co = 0; co < C; ++co)
 #pragma unroll
-            for (int ci = 0; ci < C; ++ci) acc[co * C + ci] += gr[co] * hv[ci];
+            for (int ci = 0; ci < C; ++ci)     // plain v_fmac_f32, spelled out: see the same loop in k_nrb_bwd_fused
+                asm("v_fmac_f32 %0, %1, %2" : "+v"(acc[co * C + ci]) : "v"(gr[co]), "v"(hv[ci]));
         hq = hq_n; dq = dq_n;
     }
 #pragma unroll
@@ -1124,7 +1125,7 @@ __global__ __launch_bounds__(NT, C == 8 ? 2 : 1) void k_nrb_bwd_fused(const __bf
                                                       const __bf16* __restrict__ dy, const float* __restrict__ w1,
                                                       const float* __restrict__ w2, const float* __restrict__ b2,
                                                       __bf16* __restrict__ dx, float* __restrict__ part_a, float* __restrict__ part_w,
-                                                      int B, int H, int T, int tiles_h, int tiles_t, int ntiles) {
+                                                      int B, int H, int T, int tiles_h, int tiles_t, int ntiles, int fastdma) {
     using G = NTl<C, D>;
     typedef typename VecOf<C>::type vec_t;
     constexpr int NB = C / 4, ADUMP = C * C + 2 * C, IMG = G::NPR * 16, NPX = G::ROWS * G::RW;
@@ -1145,6 +1146,30 @@ __global__ __launch_bounds__(NT, C == 8 ? 2 : 1) void k_nrb_bwd_fused(const __bf
     for (int k = 0; k < 9; ++k) wacc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const __bf16* zero = reinterpret_cast<const __bf16*>(&g_wzero16);
+    // The A operands of every phase as a bf16 image in LDS, built once per workgroup: entry ((m * NB + ob) * NB + kb) * 4 + i4 holds the
+    // four values lane i4 of a 4-lane group feeds to product (ob, kb) of matrix m (0: W2, 1: W2^T, 2 + tap: W1^T of tap 8 - tap).  The
+    // phases fetch theirs per tile (8 / 36 eight-byte LDS reads at C = 8) so that the registers are free in the other phases (72 + 16
+    // registers of weights beside 116 of accumulators); converting them from the fp32 parameters per tile instead was 144 + 32 loads
+    // and as many conversions per lane and tile -- a third of the kernel's vector instructions.
+    unsigned char* wimg = smem + 3 * IMG;
+    for (int e = tid; e < (2 + 9) * NB * NB * 4; e += NT) {
+        const int l4 = e & 3, kb = (e >> 2) % NB, ob = (e >> 2) / NB % NB, m = (e >> 2) / (NB * NB);
+        bf16x4 a;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            a[k] = (__bf16)(m == 0 ? w2[(4 * ob + l4) * C + 4 * kb + k] : m == 1 ? w2[(4 * kb + k) * C + 4 * ob + l4]
+                                   : w1[((4 * kb + k) * C + 4 * ob + l4) * 9 + (8 - (m - 2))]);
+        *reinterpret_cast<bf16x4*>(wimg + e * 8) = a;
+    }
+    constexpr int NITD = G::NPR / NT;                            // 16-byte pieces per thread and image
+    unsigned rel[NITD];                                          // their byte offsets from the tile's first halo pixel
+#pragma unroll
+    for (int it = 0; it < NITD; ++it) {
+        const int p = wave * 64 + it * NT + lane, q = (p < G::NP ? p : 0) * G::PPP;
+        const int row = q / G::RW, px = q - row * G::RW;
+        rel[it] = (unsigned)(row * T + px) * (unsigned)(C * 2);
+    }
+    auto wfrag = [&](int m, int ob, int kb) { return *reinterpret_cast<const s16x4*>(wimg + ((((m * NB + ob) * NB + kb) << 2) + i4) * 8); };
     for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
         int tile = xcd_order(v, ntiles);
         const int tt = tile % tiles_t; tile /= tiles_t;
@@ -1152,39 +1177,43 @@ __global__ __launch_bounds__(NT, C == 8 ? 2 : 1) void k_nrb_bwd_fused(const __bf
         const int b = tile / tiles_h, h0 = th * G::TH, t0 = tt * G::TW;
         const long ib = (long)b * H * T * C;
         __syncthreads();
-        for (int i = wave * 64; i < G::NPR; i += NT) {
-            const int p = i + lane, q = p * G::PPP;
-            const int row = q / G::RW, px = q - row * G::RW;
-            const int h = h0 - D + row, t = t0 - G::DP + px;
-            const bool ok = p < G::NP && (unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T;
-            const long off = ib + ((long)h * T + t) * C;
-            glds16(ok ? h1 + off : zero, hs + (long)i * 16);
-            glds16(ok ? dy + off : zero, gs + (long)i * 16);
-            glds16(ok ? x + off : zero, xs + (long)i * 16);
+        if (fastdma && h0 >= D && h0 + G::TH + D <= H && t0 >= G::DP && t0 + G::TW + G::DP <= T) {
+            // no piece of the halo'd tile is outside the image (77-82 % of the tiles at the bench shapes): scalar base + the thread's
+            // tile-independent byte offsets, no per-piece arithmetic (the general path below spends ~90 vector instructions per 256
+            // pieces on divisions, bounds and 64-bit selects -- a third of this kernel's vector instructions)
+            const long first = ib + ((long)(h0 - D) * T + (t0 - G::DP)) * C;
+            const char* hb = reinterpret_cast<const char*>(h1 + first);
+            const char* gb = reinterpret_cast<const char*>(dy + first);
+            const char* xb = reinterpret_cast<const char*>(x + first);
+#pragma unroll
+            for (int it = 0; it < NITD; ++it) {
+                const int i = wave * 64 + it * NT;
+                glds16(hb + rel[it], hs + (long)i * 16);
+                glds16(gb + rel[it], gs + (long)i * 16);
+                glds16(xb + rel[it], xs + (long)i * 16);
+            }
+        } else {
+            for (int i = wave * 64; i < G::NPR; i += NT) {
+                const int p = i + lane, q = p * G::PPP;
+                const int row = q / G::RW, px = q - row * G::RW;
+                const int h = h0 - D + row, t = t0 - G::DP + px;
+                const bool ok = p < G::NP && (unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T;
+                const long off = ib + ((long)h * T + t) * C;
+                glds16(ok ? h1 + off : zero, hs + (long)i * 16);
+                glds16(ok ? dy + off : zero, gs + (long)i * 16);
+                glds16(ok ? x + off : zero, xs + (long)i * 16);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 
-        // The weights of each phase are (re)loaded per tile through laundered pointers so that their registers are free in
-        // the other phases (C = 8: 72 + 16 registers of weights beside 116 of accumulators).
-        const float* w1p = w1;
-        const float* w2p = w2;
-        asm volatile("" : "+s"(w1p), "+s"(w2p));
         // ---- phase 1: pointwise chain on every pixel of the image; dA1 over h1 ----
         {
             s16x4 A2[NB][NB], A2T[NB][NB];
 #pragma unroll
             for (int ob = 0; ob < NB; ++ob)
 #pragma unroll
-                for (int kb = 0; kb < NB; ++kb) {
-                    bf16x4 a, at;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        a[k] = (__bf16)w2p[(4 * ob + i4) * C + 4 * kb + k];
-                        at[k] = (__bf16)w2p[(4 * kb + k) * C + 4 * ob + i4];
-                    }
-                    A2[ob][kb] = __builtin_bit_cast(s16x4, a); A2T[ob][kb] = __builtin_bit_cast(s16x4, at);
-                }
+                for (int kb = 0; kb < NB; ++kb) { A2[ob][kb] = wfrag(0, ob, kb); A2T[ob][kb] = wfrag(1, ob, kb); }
             for (int c0 = wave * 64; c0 < NPX; c0 += NT) {
                 const int q = c0 + lane;
                 const bool in_img = q < NPX;
@@ -1225,10 +1254,14 @@ __global__ __launch_bounds__(NT, C == 8 ? 2 : 1) void k_nrb_bwd_fused(const __bf
                     acc[C * C + c] += m * a1; acc[C * C + C + c] += m * gv[c];
                     gr[c] *= m;
                 }
+                // dW2 += dA2 (x) h1 as plain v_fmac_f32, spelled out: left to the SLP vectoriser this loop became packed multiply-adds with
+                // crossed lane selects and register rotations, and ONE of the 64 accumulators then came out different from run to run
+                // (a single pixel product wrong in ~3 % of the workgroups; tools/probes/dbg_nrb.py; not reproduced by the standalone
+                // instruction probes, cause not found).  A packed fp32 op issues at half rate anyway.
 #pragma unroll
                 for (int co = 0; co < C; ++co)
 #pragma unroll
-                    for (int ci = 0; ci < C; ++ci) acc[co * C + ci] += gr[co] * hv[ci];
+                    for (int ci = 0; ci < C; ++ci) asm("v_fmac_f32 %0, %1, %2" : "+v"(acc[co * C + ci]) : "v"(gr[co]), "v"(hv[ci]));
                 if (in_img) *reinterpret_cast<vec_t*>(hs + (long)q * G::PXB) = aq;
             }
         }
@@ -1242,12 +1275,7 @@ __global__ __launch_bounds__(NT, C == 8 ? 2 : 1) void k_nrb_bwd_fused(const __bf
 #pragma unroll
                 for (int ob = 0; ob < NB; ++ob)
 #pragma unroll
-                    for (int kb = 0; kb < NB; ++kb) {
-                        bf16x4 t4;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) t4[k] = (__bf16)w1p[((4 * kb + k) * C + 4 * ob + i4) * 9 + (8 - tap)];
-                        A[tap][ob][kb] = __builtin_bit_cast(s16x4, t4);
-                    }
+                    for (int kb = 0; kb < NB; ++kb) A[tap][ob][kb] = wfrag(2 + tap, ob, kb);
             const int t = t0 + lane;
             for (int r = wave; r < G::TH; r += 4) {
                 const int h = h0 + r;
@@ -1493,21 +1521,22 @@ int launch_nbwd(const __bf16* x, const __bf16* h1, const __bf16* dy, const float
     __bf16* da1 = reinterpret_cast<__bf16*>(ws);
     float* part_a = reinterpret_cast<float*>(ws + ((npix * C * 2 + 255) / 256) * 256);
     float* part_w = part_a + (long)MAX_A_WG * (C * C + 2 * C);
-    // Measured per launch at the bench shapes (three kernels -> fused): C = 8: 0.478 / 0.478 / 0.498 -> 0.445 / 0.462 / 0.707 ms for
-    // dilation 1 / 2 / 3, C = 4: 0.471 / 0.473 / 0.474 -> 0.458 / 0.487 / 0.514 ms.  Half the HBM traffic buys little because the pass is
-    // then bound by its own arithmetic (pointwise chain on the halo as well; three LDS images = 2 workgroups per CU at C = 8): fused
-    // where it wins -- C = 8 at dilation 1, 2 and C = 4 at dilation 1.
+    // Measured per launch at the bench shapes, pointwise + merged gradient kernels -> fused (with the weight image in LDS):
+    // C = 8: 0.410 / 0.409 / 0.452 -> 0.394 / 0.411 / 0.563 ms for dilation 1 / 2 / 3, C = 4: 0.40 / 0.407 / 0.408 -> 0.338 / 0.344 / 0.383 ms.
+    // Half the HBM traffic buys less than half the time because the pass is then bound by its own arithmetic (pointwise chain on the halo
+    // as well; three LDS images = 2 workgroups per CU at C = 8): fused where it wins -- C = 4 always, C = 8 at dilation 1, 2.
     static const int fused = getenv("TTRAP_NARROW_FUSED16") ? atoi(getenv("TTRAP_NARROW_FUSED16")) : 1;
-    if (fused == 2 || (fused == 1 && (C == 8 ? D <= 2 : D == 1))) {
+    if (fused == 2 || (fused == 1 && (C == 8 ? D <= 2 : true))) {
         using F = NTl<C, D>;
-        constexpr int LDS = 3 * F::NPR * 16;
+        constexpr int LDS = 3 * F::NPR * 16 + 11 * (C / 4) * (C / 4) * 32;        // three images + the bf16 weight image
         static AttrOnce once_f;
         auto kf = k_nrb_bwd_fused<C, D>;
         if (int rc = raise_lds(kf, LDS, once_f)) return rc;
         const int tiles_h = (H + F::TH - 1) / F::TH, tiles_t = (T + F::TW - 1) / F::TW, ntiles = B * tiles_h * tiles_t;
         int gf = grid_for(ntiles, LDS, 4);
         if (gf > MAX_W_WG) gf = MAX_W_WG;
-        hipLaunchKernelGGL(kf, dim3(gf), dim3(NT), LDS, st, x, h1, dy, w1, w2, b2, dx, part_a, part_w, B, H, T, tiles_h, tiles_t, ntiles);
+        static const int fastdma = env_int("TTRAP_FAST_DMA", 1);
+        hipLaunchKernelGGL(kf, dim3(gf), dim3(NT), LDS, st, x, h1, dy, w1, w2, b2, dx, part_a, part_w, B, H, T, tiles_h, tiles_t, ntiles, fastdma);
         TT_LAUNCH_CHECK();
         RedArgs ra{part_w, gf, part_a, gf, dw1, db1, dw2, db2};
         constexpr int total = 9 * 256 + C * C + 2 * C;

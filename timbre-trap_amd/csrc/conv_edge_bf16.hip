@@ -217,6 +217,7 @@ struct WRow {
         }
     }
     template <int J> __device__ __forceinline__ f32x2 tap(int c) const { return bcast<J & 1>(p[c][J >> 1]); }
+    template <int J> __device__ __forceinline__ float one(int c) const { return p[c][J >> 1][J & 1]; }
 };
 // the rolling window: w[0..2] = halo rows r, r + 1, r + 2
 template <int NP>
@@ -232,7 +233,15 @@ struct Win {
         w[2].load(lds, (r + 2) * PP + lane + PCOL0);
     }
     template <int K> __device__ __forceinline__ f32x2 tap(int c) const { return w[K / 3].template tap<K % 3>(c); }
+    template <int K> __device__ __forceinline__ float one(int c) const { return w[K / 3].template one<K % 3>(c); }
 };
+// Four output channels per pixel = one v_mfma_f32_4x4x1_16b_f32 per (input channel, tap): sixteen independent 4 x 4 x 1 outer products
+// per wave instruction, lane l in block l / 4; A = one value per lane (row l % 4), B = one value per lane (column l % 4), result
+// register r of lane l = D[row r][column l % 4] (tools/probes/mfma4x4_probe.cpp).  With A = W[out channel l % 4][.][tap] (the same four
+// weights in every block) and B = the lane's own pixel value, register r of lane l accumulates output channel r of pixel l: the
+// thread-per-pixel loop acc[co] = fmaf(w[co], x, acc[co]) with exact fp32 products, but on the MATRIX pipe (same rate as the vector
+// FMAs, csrc/conv_small.hip) -- the vector ALUs keep the weight gradient, the ELU and the conversions, and the two run side by side.
+__device__ __forceinline__ f32x4 mfma441(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
 // the same for a pixel-major tile ([pixel][4] fp32): a row = three 16-byte reads, all four channels of the three tap pixels
 struct PRow {
     f32x4 px[3];
@@ -269,16 +278,10 @@ __global__ __launch_bounds__(NT) void k_cin_fwd(const float* __restrict__ x, con
                                                  __bf16* __restrict__ y, int H, int T, int tiles_h, int tiles_t, int ntiles) {
     __shared__ __attribute__((aligned(16))) float xs[2 * PPLANE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    f32x2 wr[2][18], br[2];                                      // [co pair][ci * 9 + k] = (w[2p][ci][k], w[2p + 1][ci][k])
+    float wa[18];                                                // [ci * 9 + k]: w[co = lane % 4][ci][k], the A operand of the 4x4x1 products
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-#pragma unroll
-        for (int i = 0; i < 18; ++i) {
-            wr[p][i][0] = w[(2 * p) * 18 + i]; wr[p][i][1] = w[(2 * p + 1) * 18 + i];
-            asm volatile("" : "+v"(wr[p][i]));
-        }
-        br[p][0] = bias[2 * p]; br[p][1] = bias[2 * p + 1];
-    }
+    for (int i = 0; i < 18; ++i) wa[i] = w[(lane & 3) * 18 + i];
+    const f32x4 br = {bias[0], bias[1], bias[2], bias[3]};
     StagePlanar<2, VEC> sx;
     sx.init(H, T, tid);
     if (blockIdx.x < ntiles) sx.load(x, tile_ctx(blockIdx.x, tiles_h, tiles_t, ntiles, H, T), H, T, tid);
@@ -295,18 +298,15 @@ __global__ __launch_bounds__(NT) void k_cin_fwd(const float* __restrict__ x, con
 #pragma unroll                                                   // that every tap broadcast folds into the multiply-add's op_sel)
         for (int rr = 0; rr < ERPW; ++rr) {
             xw.advance(xs, r0 + rr, lane);
-            f32x2 acc[2][2] = {{br[0], splat2(0.f)}, {br[1], splat2(0.f)}};     // [co pair][ci]: four independent chains
-#pragma unroll
-            for (int ci = 0; ci < 2; ++ci)
-                taps9<0>([&](auto kc) {
-                    constexpr int k = decltype(kc)::value;
-                    const f32x2 xv = xw.template tap<k>(ci);
-                    acc[0][ci] = wr[0][ci * 9 + k] * xv + acc[0][ci];
-                    acc[1][ci] = wr[1][ci * 9 + k] * xv + acc[1][ci];
-                });
-            acc[0][0] += acc[0][1]; acc[1][0] += acc[1][1];
-            o[rr][0] = (__bf16)elu_f(acc[0][0][0]); o[rr][1] = (__bf16)elu_f(acc[0][0][1]);
-            o[rr][2] = (__bf16)elu_f(acc[1][0][0]); o[rr][3] = (__bf16)elu_f(acc[1][0][1]);
+            f32x4 a0 = br, a1 = {0.f, 0.f, 0.f, 0.f};                 // two chains (one per input channel), all four output channels each
+            taps9<0>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                a0 = mfma441(wa[k], xw.template one<k>(0), a0);
+                a1 = mfma441(wa[9 + k], xw.template one<k>(1), a1);
+            });
+            const f32x4 a = a0 + a1;
+            o[rr][0] = (__bf16)elu_f(a[0]); o[rr][1] = (__bf16)elu_f(a[1]);
+            o[rr][2] = (__bf16)elu_f(a[2]); o[rr][3] = (__bf16)elu_f(a[3]);
             asm volatile("" :: "v"(o[rr]));
             row_fence();
         }
@@ -482,9 +482,10 @@ __global__ __launch_bounds__(NT, 2) void k_cout_bwd(const __bf16* __restrict__ x
     __shared__ __attribute__((aligned(16))) float xs[4 * EPLANE + 4];
     __shared__ __attribute__((aligned(16))) float gs[2 * PPLANE];
     __shared__ float red[4 * 74];
-    __shared__ __attribute__((aligned(16))) float wl[72];       // [(co * 9 + k) * 4 + ci]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < 72) { const int ci = tid & 3, q = tid >> 2; wl[tid] = w[((q / 9) * 4 + ci) * 9 + q % 9]; }
+    float wa[18];                                                // [co * 9 + k]: w[co][ci = lane % 4][k], the A operand of the data gradient
+#pragma unroll
+    for (int i = 0; i < 18; ++i) wa[i] = w[((i / 9) * 4 + (lane & 3)) * 9 + i % 9];
     f32x2 acc[36], accb = splat2(0.f);                           // [ci * 9 + k]: dW of co 0 (lane 0) and co 1 (lane 1)
 #pragma unroll
     for (int i = 0; i < 36; ++i) acc[i] = splat2(0.f);
@@ -506,7 +507,7 @@ __global__ __launch_bounds__(NT, 2) void k_cout_bwd(const __bf16* __restrict__ x
             sx.load(x, nullptr, tn, H, T, tid); sg.load(dy, tn, H, T, tid);
         }
         const int t = tl.t0 + lane, r0 = wave * ERPW;
-        {
+        {                                                        // weight gradient on the vector ALUs: 36 packed multiply-adds per row
             PWin xw;
             xw.start(xs, r0, lane);
 #pragma unroll
@@ -524,9 +525,11 @@ __global__ __launch_bounds__(NT, 2) void k_cout_bwd(const __bf16* __restrict__ x
                 row_fence();
             }
         }
-        f32x2 d[ERPW][2];                                        // (ci 0, ci 1), (ci 2, ci 3) of the wave's rows
+        // data gradient dx[ci][p] = sum W[co][ci][k] dy[co][p - (k - centre)] on the matrix pipe: one 4x4x1 product per (co, tap) and row
+        // gives all four input channels of the lane's pixel; the four rows are four independent accumulation chains
+        f32x4 d[ERPW];
 #pragma unroll
-        for (int rr = 0; rr < ERPW; ++rr) d[rr][0] = d[rr][1] = splat2(0.f);
+        for (int rr = 0; rr < ERPW; ++rr) d[rr] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int co = 0; co < 2; ++co) {
             WRow<1> gw[ERPW + 2];                                // halo rows r0 .. r0 + ERPW + 1 of dy[co]
@@ -534,24 +537,16 @@ __global__ __launch_bounds__(NT, 2) void k_cout_bwd(const __bf16* __restrict__ x
             for (int i = 0; i < ERPW + 2; ++i) gw[i].load(gs + co * PPLANE, (r0 + i) * PP + lane + PCOL0);
             taps9<0>([&](auto kc) {                              // dy at p - (k - centre): halo row rr + 2 - k/3, column 2 - k%3
                 constexpr int k = decltype(kc)::value;
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(&wl[(co * 9 + k) * 4]);
-                const f32x2 w01 = __builtin_shufflevector(wv, wv, 0, 1), w23 = __builtin_shufflevector(wv, wv, 2, 3);
 #pragma unroll
-                for (int rr = 0; rr < ERPW; ++rr) {
-                    const f32x2 gv = gw[rr + 2 - k / 3].template tap<2 - k % 3>(0);
-                    d[rr][0] = w01 * gv + d[rr][0];
-                    d[rr][1] = w23 * gv + d[rr][1];
-                }
+                for (int rr = 0; rr < ERPW; ++rr) d[rr] = mfma441(wa[co * 9 + k], gw[rr + 2 - k / 3].template one<2 - k % 3>(0), d[rr]);
             });
-#pragma unroll
-            for (int rr = 0; rr < ERPW; ++rr) pin(d[rr]);
             row_fence();
         }
 #pragma unroll
         for (int rr = 0; rr < ERPW; ++rr) {
             const int h = tl.h0 + r0 + rr;
             bf16x4 o;
-            o[0] = (__bf16)d[rr][0][0]; o[1] = (__bf16)d[rr][0][1]; o[2] = (__bf16)d[rr][1][0]; o[3] = (__bf16)d[rr][1][1];
+            o[0] = (__bf16)d[rr][0]; o[1] = (__bf16)d[rr][1]; o[2] = (__bf16)d[rr][2]; o[3] = (__bf16)d[rr][3];
             if (t < T && h < H) *reinterpret_cast<bf16x4*>(dx + (((long)tl.b * H + h) * T + t) * 4) = o;
         }
     }

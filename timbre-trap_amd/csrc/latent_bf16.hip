@@ -247,16 +247,21 @@ __global__ __launch_bounds__(NT) void k_lat_wgrad(const __bf16* __restrict__ zt,
     for (int dt = 0; dt < DT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float dbacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const __bf16* zero = reinterpret_cast<const __bf16*>(&g_wzero16);
-    const long nchunks = (npix + 63) / 64;
-    for (long ck = ps; ck < nchunks; ck += nsplit) {
-        const long px0 = ck * 64;
+    // A chunk is 64 consecutive (clip, frame) pixels: clip and frame of its first pixel are wave-uniform 32-bit scalars, a lane adds its
+    // pixel's offset and wraps once (T >= 64) -- the per-piece 64-bit division pixel / T this replaces was most of the staging's
+    // ~400 vector instructions per chunk, next to 18 matrix instructions of work (npix < 2^31: checked by the launcher).
+    const int npx = (int)npix, nchunks = (npx + 63) / 64;
+    for (int ck = ps; ck < nchunks; ck += nsplit) {
+        const int px0 = ck * 64;
+        const int b0 = px0 / T, t00 = px0 - b0 * T;
         __syncthreads();
+        const bool full = px0 + 64 <= npx;                        // every chunk but possibly the last
+        const __bf16* zc = zt + (long)px0 * ZS;
 #pragma unroll
         for (int r = 0; r < ZR; ++r) {                           // zt rows of the chunk are one contiguous run
             const int i = r * NT + wave * 64, p = i + lane;
-            const long pixel = px0 + (long)p * 16 / ZB;
-            const bool okp = p < ZPC && pixel < npix;
-            glds16(okp ? zt + px0 * ZS + (long)p * 8 : zero, zs + (long)i * 16);
+            const bool okp = p < ZPC && (full || px0 + p * 16 / ZB < npx);
+            glds16(okp ? zc + p * 8 : zero, zs + (long)i * 16);
         }
         bf16x8 v[GATE ? GR : 1], yv[GATE ? GR : 1];
 #pragma unroll
@@ -264,10 +269,11 @@ __global__ __launch_bounds__(NT) void k_lat_wgrad(const __bf16* __restrict__ zt,
             const int i = r * NT + wave * 64, p = i + lane;
             const int q = p / (GB / 16), cgp = p % (GB / 16);
             const int cg = (((cgp >> 1) ^ gswz<CT>(q)) << 1) | (cgp & 1);
-            const long pixel = px0 + q;
-            const bool okp = p < GPC && pixel < npix;
-            const long b = (okp ? pixel : 0) / T, t = (okp ? pixel : 0) - b * T;
-            const long off = ((b * E + h) * T + t) * CT + cg * 8;
+            const bool okp = p < GPC && (full || px0 + q < npx);
+            int b = b0, t = t00 + q;
+            if (T >= 64) { if (t >= T) { t -= T; ++b; } }
+            else { const int e = t / T; b += e; t -= e * T; }
+            const long off = okp ? (long)((b * E + h) * T + t) * CT + cg * 8 : 0;
             if constexpr (!GATE) glds16(okp ? g_in + off : zero, gs + (long)i * 16);
             else { v[r] = *reinterpret_cast<const bf16x8*>(g_in + off); yv[r] = *reinterpret_cast<const bf16x8*>(gy + off); }
         }
@@ -275,7 +281,7 @@ __global__ __launch_bounds__(NT) void k_lat_wgrad(const __bf16* __restrict__ zt,
 #pragma unroll
             for (int r = 0; r < GR; ++r) {
                 const int p = r * NT + tid;
-                const bool okp = p < GPC && px0 + p / (GB / 16) < npix;
+                const bool okp = p < GPC && px0 + p / (GB / 16) < npx;
                 bf16x8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -409,6 +415,7 @@ int run_wgrad(const float* z, int Dz, float fill, const __bf16* g_in, const __bf
               int D, int E, int T, hipStream_t st) {
     using L = LatSizes<CT, DT, KS>;
     const long npix = (long)B * T;
+    if (npix >= (1l << 30) || (long)B * E * T >= (1l << 31)) return TT_E_UNSUPPORTED;      // 32-bit pixel arithmetic in k_lat_wgrad
     __bf16* zt = reinterpret_cast<__bf16*>(ws);
     float* part = reinterpret_cast<float*>(ws + ((L::zt_bytes(npix) + 255) / 256) * 256);
     float* dbpart = part + (long)NSPLIT * E * 4 * DT * 256;

@@ -15,6 +15,16 @@
 
 namespace {
 
+#ifndef LAT_WGRAD_WAVES
+#define LAT_WGRAD_WAVES 4
+#endif
+#ifndef LAT_EXPAND_Q
+#define LAT_EXPAND_Q 2
+#endif
+#ifndef LAT_NSPLIT
+#define LAT_NSPLIT 32
+#endif
+
 __device__ __forceinline__ float gate_f(float dy, float y) { return dy * elu_dout(y); }
 
 template <int CT> __device__ __forceinline__ int ochc(int ct, int m) { return (CT / 4) * (m >> 2) + 4 * ct + (m & 3); }
@@ -153,7 +163,9 @@ __global__ __launch_bounds__(NT) void k_lat_contract(const __bf16* __restrict__ 
 }
 
 // ---- expand to (h, c) ----------------------------------------------------------------------------------------------------------
-template <int CT, int KS, bool ACT>
+// QE = 16-frame groups per wave: 4 (256 frames per workgroup) launches ONE workgroup per CU at the bench shape (81 us for 0.26 GB);
+// 2 gives 512 workgroups with half the accumulators.
+template <int CT, int KS, bool ACT, int QE>
 __global__ __launch_bounds__(NT) void k_lat_expand(const __bf16* __restrict__ zt, const __bf16* __restrict__ wp,
                                                     const float* __restrict__ bias, __bf16* __restrict__ out, int E, int T,
                                                     long npix) {
@@ -162,11 +174,11 @@ __global__ __launch_bounds__(NT) void k_lat_expand(const __bf16* __restrict__ zt
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
-    const long p0 = (long)blockIdx.x * 256 + wave * 64;
-    bf16x8 bz[4][KS];
-    long obase[4]; bool ok[4];
+    const long p0 = (long)blockIdx.x * (64 * QE) + wave * (16 * QE);
+    bf16x8 bz[QE][KS];
+    long obase[QE]; bool ok[QE];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < QE; ++q) {
         const long pix = p0 + 16 * q + n;
         ok[q] = pix < npix;
         const long pc = ok[q] ? pix : 0;
@@ -192,21 +204,21 @@ __global__ __launch_bounds__(NT) void k_lat_expand(const __bf16* __restrict__ zt
         __syncthreads();
         if (h + 1 < E) stage(h + 1, (h + 1) & 1);
         const unsigned char* wb = smem + (h & 1) * (ROUNDS * NT * 16);
-        f32x4 acc[NC][4];
+        f32x4 acc[NC][QE];
 #pragma unroll
         for (int ct = 0; ct < NC; ++ct)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[ct][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int q = 0; q < QE; ++q) acc[ct][q] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ct = 0; ct < NC; ++ct)
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(wb + (((long)ct * KS + s) * 64 + lane) * 16);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[ct][q] = mma32(a, bz[q][s], acc[ct][q]);
+                for (int q = 0; q < QE; ++q) acc[ct][q] = mma32(a, bz[q][s], acc[ct][q]);
             }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < QE; ++q) {
             if (!ok[q]) continue;
             __bf16* d = out + obase[q] + (long)h * T * CT;
 #pragma unroll
@@ -228,7 +240,7 @@ __global__ __launch_bounds__(NT) void k_lat_expand(const __bf16* __restrict__ zt
 template <int CT> __device__ __forceinline__ int gswz(int p) { return CT == 64 ? ((p >> 1) & 3) : ((p >> 2) & 1); }
 
 template <int CT, int DT, int KS, bool GATE>
-__global__ __launch_bounds__(NT) void k_lat_wgrad(const __bf16* __restrict__ zt, const __bf16* __restrict__ g_in,
+__global__ __launch_bounds__(NT, LAT_WGRAD_WAVES) void k_lat_wgrad(const __bf16* __restrict__ zt, const __bf16* __restrict__ g_in,
                                                    const __bf16* __restrict__ gy, float* __restrict__ part,
                                                    float* __restrict__ dbpart, int E, int T, long npix, int nsplit) {
     constexpr int NC = CT / 16, ZS = 32 * KS + 16, ZB = ZS * 2, GB = CT * 2;   // bytes per pixel of the two images
@@ -359,7 +371,7 @@ __global__ __launch_bounds__(NT) void k_lat_wred(const float* __restrict__ part,
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------------------------
-constexpr int NSPLIT = 16;
+constexpr int NSPLIT = LAT_NSPLIT;
 
 template <int CT, int DT, int KS> struct LatSizes {
     static constexpr int SPH = CT / 32, NC = CT / 16, ZS = 32 * KS + 16;
@@ -403,9 +415,10 @@ int run_expand(const float* z, int Dz, float fill, const float* w, const float* 
     TT_LAUNCH_CHECK();
     constexpr int PCS = L::NC * KS * 64, ROUNDS = (PCS + NT - 1) / NT, LDS = 2 * ROUNDS * NT * 16;
     static AttrOnce once;
-    auto kern = k_lat_expand<CT, KS, ACT>;
+    constexpr int QE = LAT_EXPAND_Q;
+    auto kern = k_lat_expand<CT, KS, ACT, QE>;
     if (int rc = raise_lds(kern, LDS, once)) return rc;
-    hipLaunchKernelGGL(kern, dim3((unsigned)((npix + 255) / 256)), dim3(NT), LDS, st, zt, wp, bias, out, E, T, npix);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((npix + 64 * QE - 1) / (64 * QE))), dim3(NT), LDS, st, zt, wp, bias, out, E, T, npix);
     TT_LAUNCH_CHECK();
     return 0;
 }

@@ -17,6 +17,10 @@
 
 namespace {
 
+#ifndef W4_WAVES16
+#define W4_WAVES16 3       // waves per SIMD the strided weight-gradient kernels at C <= 16 must allow (three workgroups per CU)
+#endif
+
 __device__ __forceinline__ float gate_f(float dy, float y) { return dy * elu_dout(y); }
 
 // number of 16-row output tiles and of channels a lane ends up with, for COUT output channels
@@ -540,7 +544,7 @@ template <int PB> __device__ __forceinline__ const unsigned char* px_piece(const
 }
 
 template <int C, bool GS, bool DX>
-__global__ __launch_bounds__(NT, C == 32 ? ((!DX && GS) ? 3 : 2) : 1) void k_w4(const __bf16* __restrict__ small, const __bf16* __restrict__ big,
+__global__ __launch_bounds__(NT, C == 32 ? ((!DX && GS) ? 3 : 2) : W4_WAVES16) void k_w4(const __bf16* __restrict__ small, const __bf16* __restrict__ big,
                                             const __bf16* __restrict__ ygate, float* __restrict__ part, float* __restrict__ dbpart,
                                             const float* __restrict__ w, __bf16* __restrict__ dx,
                                             int B, int Hs, int Hb, int T, int tiles_h, int tiles_t, int ntiles) {
@@ -784,7 +788,10 @@ __global__ __launch_bounds__(1024) void k_w4_reduce(W4Red ar) {
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------------------
-constexpr int MAX_WG = 512;
+#ifndef W4_MAX_WG
+#define W4_MAX_WG 768
+#endif
+constexpr int MAX_WG = W4_MAX_WG;             // three workgroups per CU where LDS and registers allow (C <= 16)
 
 template <int C> constexpr long w4_scratch_floats() { return (long)MAX_WG * 4 * W4<C>::DUMP + (long)MAX_WG * 64; }
 

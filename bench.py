@@ -2,7 +2,11 @@
 bench.py -- audio-seconds/s training throughput of the Timbre-Trap hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by the driver as  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1: one process per GPU.  Either the caller starts the ranks (python -m torch.distributed.run --nproc-per-node N ...
+    bench.py --gpus N ..., WORLD_SIZE in the environment), or the bare command above starts them itself: before anything
+    touches the GPU it builds the library and runs torch.distributed.run as a CHILD process (never an exec), relays rank 0's
+    JSON line and exits with the child's code.  It never falls back to fewer GPUs: --gpus N with fewer than N visible
+    devices exits non-zero (TTRAP_DIST_BACKEND=gloo lets the ranks share the visible device(s): functional test only).
 
 One step = exactly the body of reference experiments/train.py:404-496 on one batch of synthetic
 audio already resident in HBM:
@@ -377,6 +381,41 @@ def bench_inference(model, args, rank, world, dev, steps=None, warmup=None, emit
     return line
 
 
+def self_launch(args, argv):
+    """
+    `python bench.py --gpus N` with N > 1 and no WORLD_SIZE: start the N ranks as fresh child processes (SURVEY.md section 8e:
+    one process per GPU, replacing the in-process nn.DataParallel of reference experiments/train.py:166-168).  Nothing in THIS
+    process may initialise the GPU: hipcc children and torch.distributed.run are started from a clean parent, which only counts
+    devices (torch.cuda.device_count() does not create a HIP context on this image).  Returns the exit code.
+    """
+    import socket
+    import subprocess
+    from timbre_trap import _hip
+    _hip.build()
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus and os.environ.get('TTRAP_DIST_BACKEND') != 'gloo':
+        print('bench.py: --gpus %d but only %d GPU(s) visible -- refusing to measure fewer GPUs than asked '
+              '(TTRAP_DIST_BACKEND=gloo shares the visible device(s) between ranks for a functional test)' % (args.gpus, n_dev),
+              file=sys.stderr)
+        return 2
+    with socket.socket() as s_:
+        s_.bind(('127.0.0.1', 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC only on this host driver (RCCL needs it)
+    env.setdefault('OMP_NUM_THREADS', str(max(1, available_cores() // args.gpus)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for ln in proc.stdout.splitlines():
+        if ln.startswith('{'):
+            print(ln)                                      # rank 0's JSON line(s); launcher chatter goes to stderr already
+        else:
+            print(ln, file=sys.stderr)
+    sys.stdout.flush()
+    return proc.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -399,6 +438,8 @@ def main():
     ap.add_argument('--no-overlap', action='store_true',
                     help='N > 1: blocking all-reduce on the compute stream instead of the side-stream all-reduce overlapped with the next CQT')
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))
 
     from timbre_trap import _hip
     from timbre_trap.framework import ops
@@ -417,7 +458,7 @@ def main():
     if int(os.environ.get('LOCAL_RANK', os.environ.get('RANK', '0'))) == 0:
         _hip.build()
     rank, world, local_rank = init_process_group_from_env()
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     if world > 1:
         dist.barrier()

@@ -119,3 +119,27 @@ def test_single_process_is_a_noop():
     assert init_process_group_from_env() == (0, 1, 0)
     g = torch.ones(5)
     assert allreduce_gradients(g) is None and bool((g == 1).all())
+
+
+def test_bare_bench_gpus_n_without_devices_refuses():
+    """`python bench.py --gpus 2` with no WORLD_SIZE and fewer than 2 visible GPUs must exit non-zero before any launch
+    (it used to run -- and report -- a 1-GPU benchmark)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'TTRAP_DIST_BACKEND')}
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0 and 'refusing' in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith('{')]
+
+
+def test_bench_world_size_mismatch_is_an_error():
+    """WORLD_SIZE set by a launcher but different from --gpus: error, not a measurement of another configuration."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0 and 'WORLD_SIZE' in (out.stderr + out.stdout)

@@ -117,7 +117,7 @@ def _stagewise(C, d, B, H, T):
     dh1 = F.conv2d(dA2r, w2r.transpose(0, 1).contiguous())
     dA1 = dh1 * torch.where(h_k > 0, torch.ones_like(h_k), h_k + 1)
     fused = {'0': False, '2': True}.get(os.environ.get('TTRAP_NARROW_FUSED16', '1'), d <= 2 if C == 8 else True)
-    if C >= 16 or not fused:
+    if (C >= 16 and not lib.tt_wide_rb_bwd_is_onepass(C, d)) or (C < 16 and not fused):
         da1_k = _planar(ws[:B * H * T * C * 2].view(torch.bfloat16).view(B, H, T, C))
         _close16(da1_k, dA1, 'dA1')
     else:
@@ -134,6 +134,23 @@ def _stagewise(C, d, B, H, T):
     assert _rel(grads[2].cpu().double().view(C, C) - 0.5, dw2_ref) < 2e-3, 'dw2'
     assert _rel(grads[1].cpu().double() - 0.5, dA1.sum((0, 2, 3))) < 2e-3, 'db1'
     assert _rel(grads[3].cpu().double() - 0.5, dA2.sum((0, 2, 3))) < 2e-3, 'db2'
+
+    # the one-pass backward from x, the SAVED h1 and dy (k_wrb_bwd1): dA1 stays in LDS, nothing recomputed
+    if C >= 16:
+        ws1 = torch.zeros(lib.tt_wide_onepass_scratch_bytes(C), dtype=torch.uint8, device='cuda')
+        assert ws1.numel() <= ws.numel()
+        dx1 = nhwc()
+        g1 = [torch.full(s, 0.125, dtype=torch.float32, device='cuda') for s in ((C, C, 3, 3), (C,), (C, C, 1, 1), (C,))]
+        check(lib.tt_wide_rb_bwd_onepass(ptr(xb), ptr(hb), ptr(gb), ptr(w1d), ptr(w2d), ptr(b2d), ptr(dx1), ptr(g1[0]), ptr(g1[1]),
+                                         ptr(g1[2]), ptr(g1[3]), ptr(ws1), B, C, H, T, d, st), 'bwd_onepass')
+        torch.cuda.synchronize()
+        # the same pointwise chain and the same data-gradient products in the same order as the per-stage kernels: identical bits
+        assert torch.equal(dx1, dxb), 'one-pass dx differs from the per-stage dx in %d elements' % int((dx1 != dxb).sum())
+        _close16(_planar(dx1), dx_ref, 'dx (one pass)')
+        assert _rel(g1[0].cpu().double() - 0.125, dw1_ref) < 2e-4, 'dw1 (one pass)'
+        assert _rel(g1[2].cpu().double().view(C, C) - 0.125, dw2_ref) < 2e-3, 'dw2 (one pass)'
+        assert _rel(g1[1].cpu().double() - 0.125, dA1.sum((0, 2, 3))) < 2e-3, 'db1 (one pass)'
+        assert _rel(g1[3].cpu().double() - 0.125, dA2.sum((0, 2, 3))) < 2e-3, 'db2 (one pass)'
 
     # the one-pass backward that recomputes h1 per tile and keeps dA1 in LDS (csrc/conv_level_bf16.hip): from x and dy only
     if C >= 16:

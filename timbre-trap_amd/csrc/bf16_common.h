@@ -29,10 +29,16 @@ __device__ __forceinline__ int xcd_order(int v, int n) {          // see conv_mf
     return v < (per << 3) ? (v & 7) * per + (v >> 3) : v;
 }
 // ELU and its derivative with as few vector instructions as the values allow (the bf16 kernels are bound by VALU issue:
-// PMC of round 3, profiles/r03_*): with e = exp(a) - 1 >= a everywhere, ELU(a) = a for a > 0 (a is the SMALLER of the two and
-// above 0) and e for a <= 0 (the LARGER, at most 0) = the median of (a, e, 0): one v_med3_f32 instead of compare + select.
-// ELU'(a) = min(exp(a), 1); expressed through the output h = ELU(a): min(h + 1, 1).  Bitwise the same values as the select forms.
-__device__ __forceinline__ float elu_f(float a) { return __builtin_amdgcn_fmed3f(a, __expf(a) - 1.f, 0.f); }
+// PMC of round 3, profiles/r03_*): with e = exp(a) - 1, ELU(a) = a for a > 0 (the smaller of a and e, above 0) and e for a <= 0
+// (the larger, at most 0) = the median of (a, e, 0): one v_med3_f32 instead of compare + select.  Two caveats, both handled here:
+//   * in fp32, e < a for 0 < a < ~3e-4 (the difference exp(a) - 1 is quantised to 2^-23), so the median returns e there: at most
+//     1.2e-7 below a -- far inside the bf16 rounding of the stored result (2^-9 relative), NOT bitwise the select form;
+//   * v_med3 / v_min drop NaNs (med3(NaN, NaN, 0) = 0): a NaN pre-activation (diverged weight, inf - inf) would be zeroed at the next
+//     activation and never reach the loss.  The forward form therefore adds a * 0 (one full-rate v_fma: +-0 for finite a, NaN for
+//     NaN and inf), so NaN / inf surface in the outputs and losses like in torch's ELU.  The derivative forms (backward only) keep
+//     the min: by then the forward has already put the NaN into the loss and into dy.
+// ELU'(a) = min(exp(a), 1); expressed through the output h = ELU(a): min(h + 1, 1).
+__device__ __forceinline__ float elu_f(float a) { return __builtin_fmaf(a, 0.f, __builtin_amdgcn_fmed3f(a, __expf(a) - 1.f, 0.f)); }
 __device__ __forceinline__ float elu_dpre(float a) { return __builtin_fminf(__expf(a), 1.f); }
 __device__ __forceinline__ float elu_dout(float h) { return __builtin_fminf(h + 1.f, 1.f); }
 

@@ -47,11 +47,12 @@ __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
 
-// ELU as the median of (a, exp(a) - 1, 0): exp(a) - 1 >= a everywhere, so the median is a for a > 0 and exp(a) - 1 otherwise --
-// one v_med3_f32 instead of compare + select, bitwise the same values (see bf16_common.h)
-__device__ __forceinline__ float elu1(float a) { return __builtin_amdgcn_fmed3f(a, __expf(a) - 1.f, 0.f); }
-// derivative of ELU expressed through its output y
-__device__ __forceinline__ float elu_grad_from_out(float y) { return __builtin_fminf(y + 1.f, 1.f); }
+// ELU and its derivative through the output, exact fp32 path (every oracle parity test): compare + select like torch -- a > 0 gives a
+// itself (v_med3(a, exp(a) - 1, 0), tried in round 3, returns exp(a) - 1 for 0 < a < 3e-4 where the fp32 difference falls below a:
+// up to 1.2e-7 off) and a NaN stays a NaN (the median and v_min forms return 0 / 1 for a NaN operand, which would hide a diverged
+// weight from the loss).
+__device__ __forceinline__ float elu1(float a) { return a > 0.f ? a : __expf(a) - 1.f; }
+__device__ __forceinline__ float elu_grad_from_out(float y) { return y > 0.f ? 1.f : y + 1.f; }
 
 // 64-lane wave reductions
 __device__ __forceinline__ float wave_sum(float v) {

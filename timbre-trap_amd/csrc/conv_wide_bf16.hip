@@ -718,10 +718,20 @@ int launch_dxw(const __bf16* x, const __bf16* da1, const __bf16* dy, const float
     return 0;
 }
 
+// One-pass backward (k_wrb_bwd1, conv_level_bf16.hip) or the per-stage kernels below: TTRAP_WBWD1 = 0 / 1 forces one of them for
+// every width and dilation, unset = the measured choice per (C, dilation).
+inline int onepass_choice(int C, int D) {
+    static const int forced = env_int("TTRAP_WBWD1", -1);
+    if (forced >= 0) return forced ? 1 : 0;
+    (void)C; (void)D;
+    return 0;
+}
+
 template <int C, int D>
 int launch_bwd(const __bf16* x, const __bf16* h1, const __bf16* dy, const float* w1, const float* w2, const float* b2,
                __bf16* dx, float* dw1, float* db1, float* dw2, float* db2, unsigned char* ws, int B, int H, int T,
                hipStream_t st) {
+    if (onepass_choice(C, D)) return tt_wide_rb_bwd_onepass(x, h1, dy, w1, w2, b2, dx, dw1, db1, dw2, db2, ws, B, C, H, T, D, st);
     const long npix = (long)B * H * T;
     __bf16* da1 = reinterpret_cast<__bf16*>(ws);
     float* part_a = reinterpret_cast<float*>(ws + ((npix * C * 2 + 255) / 256) * 256);
@@ -1673,6 +1683,10 @@ int tt_wide_rb_fwd(const void* x, const float* w1, const float* b1, const float*
         case 16: return fwd_c<16>(xi, w1, b1, w2, b2, yo, ho, B, H, T, dilation, st);
     }
     return fwd_c<32>(xi, w1, b1, w2, b2, yo, ho, B, H, T, dilation, st);
+}
+
+int tt_wide_rb_bwd_is_onepass(int C, int dilation) {
+    return (C == 16 || C == 32) && dilation >= 1 && dilation <= 3 ? onepass_choice(C, dilation) : 0;
 }
 
 int tt_wide_rb_bwd(const void* x, const void* h1, const void* dy, const float* w1, const float* w2, const float* b2, void* dx,

@@ -56,6 +56,9 @@ _PROTOS = {
     'tt_wide_rb_bwd': (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
     'tt_wide_fused_scratch_bytes': (c_int64, [I]),
     'tt_wide_rb_bwd_fused': (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    'tt_wide_onepass_scratch_bytes': (c_int64, [I]),
+    'tt_wide_rb_bwd_onepass': (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    'tt_wide_rb_bwd_is_onepass': (c_int, [I, I]),
     'tt_stride16_scratch_bytes': (c_int64, [I]),
     'tt_sconv16_fwd': (c_int, [P, P, P, P, I, I, I, I, P]),
     'tt_sconv16_bwd': (c_int, [P, P, P, P, P, P, P, P, I, I, I, I, P]),

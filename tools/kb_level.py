@@ -1,5 +1,5 @@
 """Per-launch timing of the residual-block kernels of ONE width / dilation at the bench shape (B 64, T 1024), for PMC passes:
-KB_C (32; comma list), KB_D (1; comma list), KB_WHAT = comma list of fwd,fwdns,bwd,bwdf,stride,stridefwd,edge, KB_N iterations (10)."""
+KB_C (32; comma list), KB_D (1; comma list), KB_WHAT = comma list of fwd,fwdns,bwd,bwd1,bwdf,stride,stridefwd,edge, KB_N iterations (10)."""
 import os
 import sys
 
@@ -38,6 +38,11 @@ def run_level(lib, st, C, dils, what, n):
             t = timeit(lambda: check(lib.tt_wide_rb_bwd(ptr(xb), ptr(hb), ptr(gb), ptr(w1), ptr(w2), ptr(b2), ptr(dxb), ptr(dw1), ptr(db1),
                                                         ptr(dw2), ptr(db2), ptr(ws), B, C, H, T, d, st), 'bwd'), n)
             print('C%d d%d bwd    %.3f ms  %.2f TB/s (dy + x + dx)' % (C, d, t, npx * C * 6 / t / 1e9))
+        if 'bwd1' in what and C >= 16:
+            check(lib.tt_wide_rb_fwd(ptr(xb), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(yb), ptr(hb), B, C, H, T, d, st), 'fwd')
+            t = timeit(lambda: check(lib.tt_wide_rb_bwd_onepass(ptr(xb), ptr(hb), ptr(gb), ptr(w1), ptr(w2), ptr(b2), ptr(dxb), ptr(dw1), ptr(db1),
+                                                                ptr(dw2), ptr(db2), ptr(ws), B, C, H, T, d, st), 'bwd1'), n)
+            print('C%d d%d bwd-onepass %.3f ms  %.2f TB/s (dy + x + dx)  %.2f TB/s (h1 + dy + x + dx)' % (C, d, t, npx * C * 6 / t / 1e9, npx * C * 8 / t / 1e9))
         if 'bwdf' in what and C >= 16:
             wsf = torch.empty(lib.tt_wide_fused_scratch_bytes(C), dtype=torch.uint8, device='cuda')
             t = timeit(lambda: check(lib.tt_wide_rb_bwd_fused(ptr(xb), ptr(gb), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(dxb), ptr(dw1),

@@ -135,6 +135,14 @@ class CQT(nn.Module):
         coefficients : Tensor (B x 2 OR 1 x F x T) real/imaginary OR complex -> audio (B x 1 x T),
         divided by its infinity norm when that is non-zero.
         """
+        return self._decode(coefficients, True)
+
+    def _decode_raw(self, coefficients):
+        """The synthesis without the batch-wide division by the infinity norm (what ``cqt_pytorch.CQT.decode`` returns before
+        reference cqtwrapper.py:209-211 rescales it); used by tests to compare clips of one batch independently."""
+        return self._decode(coefficients, False)
+
+    def _decode(self, coefficients, normalize):
         with torch.no_grad():
             _hip.require_cuda(coefficients)
             is_complex = coefficients.is_complex()
@@ -156,7 +164,7 @@ class CQT(nn.Module):
             audio = torch.empty((B, 1, n_blocks * self.block_length), dtype=torch.float32, device=c.device)
             with _hip.timed('cqt_inverse'):
                 _hip.check(lib.tt_cqt_inverse(ctypes.byref(ps), _hip.ptr(c), _hip.ptr(audio), _hip.ptr(scratch),
-                                              B, n_blocks, int(is_complex), 1, _hip.stream_ptr()), 'tt_cqt_inverse')
+                                              B, n_blocks, int(is_complex), int(bool(normalize)), _hip.stream_ptr()), 'tt_cqt_inverse')
         return audio
 
     # ---- layout helpers (reference cqtwrapper.py:74-182), stock tensor views ----------------------

@@ -730,6 +730,359 @@ int bwd1_c(const __bf16* x, const __bf16* h1, const __bf16* dy, const float* w1,
     return TT_E_UNSUPPORTED;
 }
 
+// ==== one-pass backward, h1 saved, COLUMN STRIPS with a rolling ring of dA1 rows (round 4) ===================================
+//   k_wrb_bwds<C,D,TH,TW>   The tile form above (k_wrb_bwd1) redoes the pointwise chain on a D halo all round: 1.33x / 1.69x /
+//   2.08x the pixels at dilation 1 / 2 / 3 with 8 x 32 tiles, and it lost.  Here a workgroup owns a STRIP of TW columns over the
+//   whole height and walks it downwards TH rows at a time; dA1 lives in a ring of TH + 2D image rows in LDS, so the rows a step
+//   needs above it are the ones the previous steps computed -- every image row goes through the pointwise chain ONCE per strip and
+//   only the column halo is redone (1.06x / 1.13x / 1.19x).  Step j:
+//       a. dy rows [j TH + D - TH, j TH + D) -> the ring slots of the rows that just fell out of reach, h1 of the same rows -> a
+//          staging image, both by LDS-DMA in the fswz layout (out-of-image pieces from the zero page: dy = 0 gives dA1 = 0, the
+//          zero padding of the data gradient, above the image, below it and beside it);
+//       b. pointwise chain on those rows, dA1 written over dy in the ring; db1 / db2 / dW2 over the strip's own columns;
+//       c. the x rows [(j - 1) TH, j TH) start towards the staging image (h1 is dead), while
+//       d. dx of those rows = dy + W1^T (*)_D dA1 from the ring, then
+//       e. dW1[tap] += x[q] (x) dA1[q - tap D] over those rows (x needs no halo).
+//   HBM traffic per block: h1, dy, x in, dx out, plus the column halo of h1 / dy (2D / TW).
+template <int C, int D, int TH, int TW> struct OS {
+    static constexpr int CG = C / 8, PB = C * 2;
+    static constexpr int GW = TW + 2 * D, RING = TH + 2 * D;
+    static constexpr int ROWB = GW * PB;                         // bytes per image row
+    static constexpr int RPP = GW * CG;                          // 16-byte pieces per image row
+    static constexpr int IPR = (RPP + 63) / 64;                  // DMA wave-instructions per row
+    static constexpr int RING_BYTES = (RING * ROWB + IPR * 1024 - RPP * 16 + 255) / 256 * 256;   // + the overrun of a row's last instruction
+    static constexpr int XP = TH * TW * CG;                      // 16-byte pieces of the x rows
+    static constexpr int HS_BYTES_ = TH * ROWB + IPR * 1024 - RPP * 16;
+    static constexpr int HS_BYTES = ((HS_BYTES_ > XP * 16 ? HS_BYTES_ : XP * 16) + 255) / 256 * 256;
+    static constexpr int PS = C * 2 + 8;
+    static constexpr int T_BYTES = 4 * 2 * 16 * PS;
+    static constexpr int ADUMP = C * C + 2 * C;
+    static constexpr int WDUMP = 9 * (C / 16) * 256;
+    static constexpr int LDS_BYTES = RING_BYTES + HS_BYTES + T_BYTES;
+    static constexpr int NG1 = (TH * GW + 15) / 16;
+    static_assert(XP % NT == 0, "whole DMA instructions for the x rows");
+    static_assert(4 * ADUMP * 4 <= RING_BYTES + HS_BYTES, "final dump reduction reuses the images");
+    static_assert(TW % 32 == 0, "the K = 32 pixels of a weight-gradient product are 32 consecutive columns");
+    static_assert(TH >= D, "a step must reach the rows the next one needs");
+};
+
+// 3x3 dilated product on one 16-pixel group out of the ring: `ro[kh]` = byte offset of the image row of tap row kh
+template <int C, int D, int IW>
+__device__ __forceinline__ void conv_taps_ring(const unsigned char* img, const int (&ro)[3], int col, int g,
+                                               const bf16x8 (&A)[WK<C>::NK][WK<C>::NCT], f32x4 (&acc)[WK<C>::NCT]) {
+    constexpr int NK = WK<C>::NK, NCT = WK<C>::NCT, PB = C * 2;
+    const int gsel = C == 32 ? g : (g & 1);
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        int tap = C == 32 ? k : 2 * k + (g >> 1);
+        if (tap > 8) tap = 8;                                    // the weights of the missing tenth tap are zero
+        const int kh = tap / 3, kw = tap - 3 * kh;
+        const int xc = col + kw * D;
+        const int rb = C == 32 ? ro[k / 3] : (kh == 0 ? ro[0] : (kh == 1 ? ro[1] : ro[2]));
+        const bf16x8 bq = *reinterpret_cast<const bf16x8*>(img + rb + xc * PB + 16 * (gsel ^ fswz<C>(xc)));
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc[ct] = mma32(A[k][ct], bq, acc[ct]);
+    }
+}
+
+template <int C, int D, int TH, int TW, int MINW>
+__global__ __launch_bounds__(NT, MINW) void k_wrb_bwds(const __bf16* __restrict__ x, const __bf16* __restrict__ h1, const __bf16* __restrict__ dy,
+                                                     const bf16x8* __restrict__ wimg, const float* __restrict__ b2, __bf16* __restrict__ dx,
+                                                     float* __restrict__ part_a, float* __restrict__ part_w, int B, int H, int T,
+                                                     int tiles_t, int nstrips) {
+    using G = OS<C, D, TH, TW>;
+    using K = WK<C>;
+    constexpr int NCT = K::NCT, NK = K::NK, NCH = K::NCH, PB = G::PB, GW = G::GW, RING = G::RING;
+    typedef typename std::conditional<C == 32, bf16x8, bf16x4>::type vec_t;     // a lane's channels of one pixel
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char* ring = smem;                                  // dy, then dA1: RING image rows of GW pixels
+    unsigned char* hst = smem + G::RING_BYTES;                   // h1 of the step's new rows, then the step's x rows
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4, trj = n >> 2, trq = n & 3;
+    unsigned char* tg = smem + G::RING_BYTES + G::HS_BYTES + wave * (2 * 16 * G::PS);   // this wave's dA2 tile, then its h1 tile
+    unsigned char* thh = tg + 16 * G::PS;
+    const int opiece = C == 32 ? g : (g >> 1), obyte = C == 32 ? 0 : 8 * (g & 1);
+
+    constexpr int NCHK = TW / 32;
+    static_assert(C == 32 || (4 % NCHK == 0), "wave roles");
+    const int cit = C == 32 ? (wave & 1) : 0, aw = C == 32 ? (wave >> 1) : 0;
+    const int ch0 = C == 32 ? 0 : wave % NCHK, rpar = C == 32 ? 0 : wave / NCHK;
+    constexpr int CHSTEP = C == 32 ? 1 : NCHK, RSTEP = C == 32 ? 1 : 4 / NCHK;
+
+    f32x4 wacc[9], dw2[NCT][NCT];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wacc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < NCT; ++a)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) dw2[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float db1a[NCH], db2a[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) { db1a[j] = 0.f; db2a[j] = 0.f; }
+    vec_t zero_v;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) zero_v[j] = (__bf16)0.f;
+
+    const __bf16* zero = reinterpret_cast<const __bf16*>(&g_wzero16);
+    const int nsteps = (H + TH - 1) / TH + 1;
+    // ring slot of image row R (R >= -RING): (R + RING) mod RING, on the scalar unit where R is wave-uniform
+    auto slot = [&](int R) -> int { return (R + RING) % RING; };
+
+    for (int v = blockIdx.x; v < nstrips; v += gridDim.x) {
+        const int strip = xcd_order(v, nstrips);
+        const int b = strip / tiles_t, t0 = (strip - b * tiles_t) * TW;
+        const long ib = (long)b * H * T * C;
+
+        for (int j = 0; j < nsteps; ++j) {
+            const int N0 = j * TH + D - TH;                      // first new dA1 row of this step
+            const int X0 = (j - 1) * TH;                         // first row whose dx / dW1 this step produces
+            __syncthreads();                                     // the previous step has been consumed
+            // ---- a. dy -> ring slots of the new rows, h1 -> staging; one image row per IPR wave-instructions ----
+            for (int k = wave; k < TH * G::IPR; k += 4) {
+                const int rl = k / G::IPR, part = k - rl * G::IPR;
+                const int p = part * 64 + lane;                  // piece inside the row
+                const int px = p / G::CG, sgrp = p - px * G::CG;
+                const int h = N0 + rl, t = t0 - D + px;
+                const bool ok = (unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T;
+                const long off = ib + ((long)h * T + t) * C + (sgrp ^ fswz<C>(px)) * 8;
+                if (p < G::RPP) {
+                    glds16(ok ? dy + off : zero, ring + slot(N0 + rl) * G::ROWB + part * 1024);
+                    glds16(ok ? h1 + off : zero, hst + rl * G::ROWB + part * 1024);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+
+            const bf16x8* wp = wimg;
+            const float* b2p = b2;
+            asm volatile("" : "+s"(wp), "+s"(b2p));
+
+            // ---- b. pointwise chain on the new rows, dA1 over dy in the ring; db1 / db2 / dW2 over the strip's own columns ----
+            if (N0 < H) {                                        // rows below the image: dy = 0 staged, dA1 = 0 already
+                bf16x8 A2[NCT], A2T[NCT];
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    A2[ct] = wp[2 * K::W3 + ct * 64 + lane];
+                    A2T[ct] = wp[2 * K::W3 + NCT * 64 + ct * 64 + lane];
+                }
+                const s16x4 A2s = __builtin_bit_cast(s16x4, __builtin_shufflevector(A2[0], A2[0], 0, 1, 2, 3));      // C = 16: K = 16
+                const s16x4 A2Ts = __builtin_bit_cast(s16x4, __builtin_shufflevector(A2T[0], A2T[0], 0, 1, 2, 3));
+                float b2r[NCH];
+#pragma unroll
+                for (int jj = 0; jj < NCH; ++jj) b2r[jj] = b2p[NCH * g + jj];
+                const int s0 = slot(N0);
+                for (int grp = wave; grp < G::NG1; grp += 4) {
+                    const int q = grp * 16 + n;
+                    const bool inq = q < TH * GW;
+                    const int qq = inq ? q : TH * GW - 1;
+                    const int rl = qq / GW, col = qq - rl * GW;
+                    int sl = s0 + rl;
+                    sl = sl >= RING ? sl - RING : sl;
+                    const bool core = inq && col >= D && col < D + TW;       // halo columns belong to the neighbouring strips
+                    const int po = col * PB + 16 * (opiece ^ fswz<C>(col)) + obyte;
+                    unsigned char* gp = ring + sl * G::ROWB + po;
+                    const vec_t hq = *reinterpret_cast<const vec_t*>(hst + rl * G::ROWB + po);
+                    const vec_t dq = *reinterpret_cast<const vec_t*>(gp);
+                    float hv[NCH], gv[NCH], a1g[NCH];
+                    vec_t gq, aq;
+                    f32x4 z[NCT], u[NCT];
+                    if constexpr (C == 32) {
+                        z[0] = mma32(A2[0], hq, f32x4{b2r[0], b2r[1], b2r[2], b2r[3]});
+                        z[1] = mma32(A2[1], hq, f32x4{b2r[4], b2r[5], b2r[6], b2r[7]});
+                    } else {
+                        z[0] = mma16(A2s, __builtin_bit_cast(s16x4, hq), f32x4{b2r[0], b2r[1], b2r[2], b2r[3]});
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < NCH; ++jj) {
+                        const float a2 = z[jj >> 2][jj & 3];
+                        gv[jj] = (float)dq[jj] * elu_dpre(a2);
+                        gq[jj] = (__bf16)gv[jj];
+                        hv[jj] = (float)hq[jj];
+                    }
+                    if constexpr (C == 32) {
+                        u[0] = mma32(A2T[0], gq, f32x4{0.f, 0.f, 0.f, 0.f});
+                        u[1] = mma32(A2T[1], gq, f32x4{0.f, 0.f, 0.f, 0.f});
+                    } else {
+                        u[0] = mma16(A2Ts, __builtin_bit_cast(s16x4, gq), f32x4{0.f, 0.f, 0.f, 0.f});
+                    }
+                    const float cm = core ? 1.f : 0.f;
+#pragma unroll
+                    for (int jj = 0; jj < NCH; ++jj) {
+                        a1g[jj] = u[jj >> 2][jj & 3] * elu_dout(hv[jj]);
+                        aq[jj] = (__bf16)a1g[jj];
+                        db2a[jj] += cm * gv[jj]; db1a[jj] += cm * a1g[jj];
+                    }
+                    if (inq) *reinterpret_cast<vec_t*>(gp) = aq;
+                    const vec_t gm = core ? gq : zero_v;
+                    if constexpr (C == 32) {
+                        const uint2* s1 = reinterpret_cast<const uint2*>(&gm);
+                        const uint2* s2 = reinterpret_cast<const uint2*>(&hq);
+                        uint2* d1 = reinterpret_cast<uint2*>(tg + n * G::PS + 16 * g);
+                        uint2* d2 = reinterpret_cast<uint2*>(thh + n * G::PS + 16 * g);
+                        d1[0] = s1[0]; d1[1] = s1[1]; d2[0] = s2[0]; d2[1] = s2[1];
+                    } else {
+                        *reinterpret_cast<uint2*>(tg + n * G::PS + 8 * g) = __builtin_bit_cast(uint2, gm);
+                        *reinterpret_cast<uint2*>(thh + n * G::PS + 8 * g) = __builtin_bit_cast(uint2, hq);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("" ::: "memory");
+                    s16x4 ga[NCT], hb[NCT];
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) {
+                        ga[ct] = lds_tr16(tg + (4 * g + trj) * G::PS + (16 * ct + 4 * trq) * 2);
+                        hb[ct] = lds_tr16(thh + (4 * g + trj) * G::PS + (16 * ct + 4 * trq) * 2);
+                    }
+#pragma unroll
+                    for (int a = 0; a < NCT; ++a)
+#pragma unroll
+                        for (int c = 0; c < NCT; ++c) dw2[a][c] = mma16(ga[a], hb[c], dw2[a][c]);
+                    asm volatile("" ::: "memory");
+                }
+            }
+            if (j == 0) continue;                                // nothing above the image to produce
+            __syncthreads();                                     // dA1 rows complete, h1 staging dead
+
+            // ---- c. the x rows of this step towards the staging image (consumed in e.) ----
+            for (int i = wave * 64; i < G::XP; i += NT) {
+                const int p = i + lane, q = p / G::CG, sgrp = p - q * G::CG;
+                const int row = q / TW, px = q - row * TW;
+                const int h = X0 + row, t = t0 + px;
+                const bool ok = h < H && t < T;
+                glds16(ok ? x + ib + ((long)h * T + t) * C + (sgrp ^ fswz<C>(px)) * 8 : zero, hst + (long)i * 16);
+            }
+
+            // ---- d. dx = dy + W1^T (*) dA1 over the step's rows ----
+            {
+                bf16x8 A[NK][NCT];
+#pragma unroll
+                for (int k = 0; k < NK; ++k)
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) A[k][ct] = wp[K::W3 + (k * NCT + ct) * 64 + lane];
+                constexpr int GPRW = TW / 16;
+                for (int grp = wave; grp < TH * GPRW; grp += 4) {
+                    const int r = grp / GPRW, c = (grp - r * GPRW) * 16 + n;
+                    const int h = X0 + r;
+                    if (h >= H) break;
+                    const int t = t0 + c;
+                    const bool valid = t < T;
+                    const long pix = ((long)b * H + h) * T + t;
+                    // unconditional (clamped) so that no branch pins a wait in front of the products
+                    const vec_t rq = *reinterpret_cast<const vec_t*>(dy + (valid ? pix : pix - (t - (T - 1))) * C + NCH * g);
+                    const int ro[3] = {slot(h - D) * G::ROWB, slot(h) * G::ROWB, slot(h + D) * G::ROWB};
+                    f32x4 acc[NCT];
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    conv_taps_ring<C, D, GW>(ring, ro, c, g, A, acc);
+                    vec_t o;
+#pragma unroll
+                    for (int jj = 0; jj < NCH; ++jj) o[jj] = (__bf16)(acc[jj >> 2][jj & 3] + (float)rq[jj]);
+                    if (valid) *reinterpret_cast<vec_t*>(dx + pix * C + NCH * g) = o;
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the x rows have landed
+            __syncthreads();
+
+            // ---- e. dW1[tap] += x[q] (x) dA1[q - tap D] over the step's rows, K = 32 consecutive columns per product ----
+            for (int r = rpar; r < TH; r += RSTEP) {
+                const int h = X0 + r;
+                if (h >= H) break;
+                const int ro[3] = {slot(h + D) * G::ROWB, slot(h) * G::ROWB, slot(h - D) * G::ROWB};   // tap row kh reads dA1 row h + (1 - kh) D
+#pragma unroll
+                for (int ch = ch0; ch < NCHK; ch += CHSTEP) {
+                    s16x4 lo, hi;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int xc = ch * 32 + 4 * g + trj + 16 * u;
+                        const s16x4 t4 = lds_tr16(hst + (r * TW + xc) * PB + 16 * (((C == 32 ? 2 * cit : 0) + (trq >> 1)) ^ fswz<C>(xc)) + 8 * (trq & 1));
+                        if (u == 0) lo = t4; else hi = t4;
+                    }
+                    const bf16x8 xq = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) {
+                        const int kh = k / 3, kw = k - 3 * kh;
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int cc = (2 - kw) * D + ch * 32 + 4 * g + trj + 16 * u;
+                            const s16x4 t4 = lds_tr16(ring + ro[kh] + cc * PB +
+                                                      16 * (((C == 32 ? 2 * aw : 0) + (trq >> 1)) ^ fswz<C>(cc)) + 8 * (trq & 1));
+                            if (u == 0) lo = t4; else hi = t4;
+                        }
+                        const bf16x8 ga = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                        wacc[k] = mma32(ga, xq, wacc[k]);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- dumps: the weight-gradient accumulators per wave, everything else summed over the waves through LDS ----
+    float* pw = part_w + ((long)blockIdx.x * 4 + wave) * G::WDUMP;
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pw[((k * NCT + aw) * 4 + r) * 64 + lane] = wacc[k][r];   // C = 32: only this wave's co-tile (RedArgs::split_a)
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem) + wave * G::ADUMP;
+#pragma unroll
+    for (int a = 0; a < NCT; ++a)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[((a * NCT + c) * 4 + r) * 64 + lane] = dw2[a][c][r];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        float s1 = db1a[j], s2 = db2a[j];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        if (n == 0) { red[C * C + NCH * g + j] = s1; red[C * C + C + NCH * g + j] = s2; }
+    }
+    __syncthreads();
+    const float* all = reinterpret_cast<const float*>(smem);
+    float* pa = part_a + (long)blockIdx.x * G::ADUMP;
+    for (int i = tid; i < G::ADUMP; i += NT) pa[i] = (all[i] + all[G::ADUMP + i]) + (all[2 * G::ADUMP + i] + all[3 * G::ADUMP + i]);
+}
+
+template <int C, int D, int TH, int TW>
+int launch_bwds(const __bf16* x, const __bf16* h1, const __bf16* dy, const float* w1, const float* w2, const float* b2, __bf16* dx,
+                float* dw1, float* db1, float* dw2, float* db2, unsigned char* ws, int B, int H, int T, hipStream_t st) {
+    using G = OS<C, D, TH, TW>;
+    using K = WK<C>;
+    bf16x8* wimg = reinterpret_cast<bf16x8*>(ws);
+    float* part_a = reinterpret_cast<float*>(ws + K::IMG_BYTES);
+    float* part_w = part_a + (long)MAX_W_WG * G::ADUMP;
+    hipLaunchKernelGGL(k_lvl_wprep<C>, dim3(K::NK * K::NCT + 1), dim3(64), 0, st, w1, w2, wimg);
+    TT_LAUNCH_CHECK();
+    static AttrOnce once;
+    constexpr int MINW = C == 32 ? 2 : 3;
+    auto kern = k_wrb_bwds<C, D, TH, TW, MINW>;
+    if (int rc = raise_lds(kern, G::LDS_BYTES, once)) return rc;
+    const int tiles_t = (T + TW - 1) / TW, nstrips = B * tiles_t;
+    static const int per_cu = env_int("TTRAP_BWDS_PER_CU", MINW);
+    int grid = grid_for(nstrips, G::LDS_BYTES, per_cu);
+    if (grid > MAX_W_WG) grid = MAX_W_WG;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), G::LDS_BYTES, st, x, h1, dy, wimg, b2, dx, part_a, part_w, B, H, T, tiles_t, nstrips);
+    TT_LAUNCH_CHECK();
+    RedArgs ra{part_w, grid, part_a, grid, dw1, db1, dw2, db2, C == 32 ? 1 : 0};
+    constexpr int total = 9 * C * C + C * C + 2 * C;
+    hipLaunchKernelGGL(k_wrb_reduce<C>, dim3((total + REL - 1) / REL), dim3(1024), 0, st, ra);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int C>
+int bwds_c(const __bf16* x, const __bf16* h1, const __bf16* dy, const float* w1, const float* w2, const float* b2, __bf16* dx,
+           float* dw1, float* db1, float* dw2, float* db2, unsigned char* ws, int B, int H, int T, int D, hipStream_t st) {
+    static const int alt = env_int("TTRAP_BWDS_TILE", 0);
+#define TT_BS(DD, TH_, TW_) return launch_bwds<C, DD, TH_, TW_>(x, h1, dy, w1, w2, b2, dx, dw1, db1, dw2, db2, ws, B, H, T, st)
+    switch (D) {
+        case 1: if (alt == 1) TT_BS(1, 16, 32); if (alt == 2) TT_BS(1, 4, 32); TT_BS(1, 8, 32);
+        case 2: if (alt == 1) TT_BS(2, 16, 32); if (alt == 2) TT_BS(2, 4, 32); TT_BS(2, 8, 32);
+        case 3: if (alt == 1) TT_BS(3, 16, 32); if (alt == 2) TT_BS(3, 4, 32); TT_BS(3, 8, 32);
+    }
+#undef TT_BS
+    return TT_E_UNSUPPORTED;
+}
+
 inline bool fshape_ok(int B, int C, int H, int T) {
     return B > 0 && H > 0 && T > 0 && (C == 16 || C == 32) && (long)H * T * C < (1l << 31);
 }
@@ -764,8 +1117,13 @@ int tt_wide_rb_bwd_onepass(const void* x, const void* h1, const void* dy, const 
     if (!fshape_ok(B, C, H, T)) return TT_E_BADARG;
     const __bf16 *xi = (const __bf16*)x, *hi = (const __bf16*)h1, *gi = (const __bf16*)dy;
     hipStream_t st = tt_stream(stream);
-    if (C == 16) return bwd1_c<16>(xi, hi, gi, w1, w2, b2, (__bf16*)dx, dw1, db1, dw2, db2, (unsigned char*)ws, B, H, T, dilation, st);
-    return bwd1_c<32>(xi, hi, gi, w1, w2, b2, (__bf16*)dx, dw1, db1, dw2, db2, (unsigned char*)ws, B, H, T, dilation, st);
+    static const int tile_form = env_int("TTRAP_BWD1_FORM", 0);        // 1: the tile form k_wrb_bwd1 (halo all round), kept for A/B
+    if (tile_form) {
+        if (C == 16) return bwd1_c<16>(xi, hi, gi, w1, w2, b2, (__bf16*)dx, dw1, db1, dw2, db2, (unsigned char*)ws, B, H, T, dilation, st);
+        return bwd1_c<32>(xi, hi, gi, w1, w2, b2, (__bf16*)dx, dw1, db1, dw2, db2, (unsigned char*)ws, B, H, T, dilation, st);
+    }
+    if (C == 16) return bwds_c<16>(xi, hi, gi, w1, w2, b2, (__bf16*)dx, dw1, db1, dw2, db2, (unsigned char*)ws, B, H, T, dilation, st);
+    return bwds_c<32>(xi, hi, gi, w1, w2, b2, (__bf16*)dx, dw1, db1, dw2, db2, (unsigned char*)ws, B, H, T, dilation, st);
 }
 
 }  // extern "C"

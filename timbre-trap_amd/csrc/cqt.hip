@@ -20,8 +20,6 @@
 // HBM traffic per block-clip (algorithmic): 264,600 B audio + 4,423,680 B coefficients.  The
 // spectra (2 x 264,600 B) stay in L2 / Infinity Cache between the three launches.
 #include "common.h"
-#include <pthread.h>
-#include <stdlib.h>
 
 namespace {
 
@@ -118,12 +116,12 @@ __device__ __forceinline__ void dft27_reg(float2 (&v)[27], const float2* tw) {
 }
 
 __global__ __launch_bounds__(FFT_ROWS_THREADS) void k_fft675_rows(const float2* __restrict__ in, float2* __restrict__ A,
-                                                                  const float2* __restrict__ tw675, const float2* __restrict__ twNc, int q0) {
+                                                                  const float2* __restrict__ tw675, const float2* __restrict__ twNc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* tw = reinterpret_cast<float2*>(smem);
     float2* Ys = tw + N1;                              // [ROWS][25][YS_PITCH]
     const int tid = threadIdx.x, g = blockIdx.x;
-    const long q = blockIdx.y + q0;                   // q0: first (clip, block) of this chunk of the batch
+    const long q = blockIdx.y;
     const float2* src = in + q * NC;
     for (int i = tid; i < N1; i += FFT_ROWS_THREADS) tw[i] = tw675[i];
     __syncthreads();
@@ -180,13 +178,13 @@ __device__ __forceinline__ void dft7(const float2 (&in)[7], float2 (&out)[7], co
 template <int MODE>
 __global__ __launch_bounds__(256) void k_fft49_cols(const float2* __restrict__ A, float2* __restrict__ out,
                                                     const float2* __restrict__ tw49g, const float2* __restrict__ twN,
-                                                    unsigned* __restrict__ mx, int q0) {
+                                                    unsigned* __restrict__ mx) {
     __shared__ float2 Al[N2][2 * CT + 1];
     __shared__ float2 Zl[2 * CT + 1][N2 + 1];
     __shared__ float2 tw[N2];
     __shared__ float wmax[4];
     const int tid = threadIdx.x, tile = blockIdx.x;
-    const long q = blockIdx.y + q0;                   // q0: first (clip, block) of this chunk of the batch
+    const long q = blockIdx.y;
     const float2* a = A + q * NC;
     const int ncol = (tile == 0) ? 2 * CT + 1 : 2 * CT;
 
@@ -408,10 +406,10 @@ __device__ __forceinline__ void fft1024_wave(float2 (&v)[16], float2* lds, const
 template <bool COMPLEX_OUT>
 __global__ __launch_bounds__(256) void k_band_fwd(const float2* __restrict__ X, float* __restrict__ out,
                                                   const int4* __restrict__ bin_tab, const float* __restrict__ window,
-                                                  const float2* __restrict__ tw1024, int F, int n_blocks, int q0) {
+                                                  const float2* __restrict__ tw1024, int F, int n_blocks) {
     __shared__ __attribute__((aligned(16))) float2 lds_all[4 * FFT_LDS_F2];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const long q = blockIdx.y + q0;                   // q0: first (clip, block) of this chunk of the batch
+    const long q = blockIdx.y;
     const int bin = blockIdx.x * 4 + wave;
     if (bin >= F) return;                            // wave-uniform; no workgroup barrier below
     float2* lds = lds_all + wave * FFT_LDS_F2;
@@ -466,10 +464,10 @@ __global__ __launch_bounds__(256) void k_band_fwd(const float2* __restrict__ X, 
 template <bool COMPLEX_IN>
 __global__ __launch_bounds__(256) void k_band_inv(const float* __restrict__ coeffs, float2* __restrict__ S,
                                                   const int4* __restrict__ bin_tab, const float* __restrict__ dual,
-                                                  const float2* __restrict__ tw1024, int F, int n_blocks, int sum_len, int q0) {
+                                                  const float2* __restrict__ tw1024, int F, int n_blocks, int sum_len) {
     __shared__ __attribute__((aligned(16))) float2 lds_all[4 * FFT_LDS_F2];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const long q = blockIdx.y + q0;                   // q0: first (clip, block) of this chunk of the batch
+    const long q = blockIdx.y;
     const int bin = blockIdx.x * 4 + wave;
     if (bin >= F) return;
     float2* lds = lds_all + wave * FFT_LDS_F2;
@@ -504,10 +502,10 @@ __global__ __launch_bounds__(256) void k_band_inv(const float* __restrict__ coef
 // host), then the real-IFFT pre-split:  Zc[k] = conj(E[k] + i O[k]).
 __global__ __launch_bounds__(256) void k_spec_gather(const float2* __restrict__ S, float2* __restrict__ Zc,
                                                      const int* __restrict__ gat_off, const int* __restrict__ gat_idx,
-                                                     const float2* __restrict__ twN, int sum_len, int q0) {
+                                                     const float2* __restrict__ twN, int sum_len) {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= NC) return;
-    const long q = blockIdx.y + q0;                   // q0: first (clip, block) of this chunk of the batch
+    const long q = blockIdx.y;
     const float2* s = S + q * sum_len;
     auto gather = [&](int j) -> float2 {
         float2 acc = make_float2(0.f, 0.f);
@@ -568,57 +566,6 @@ static int cqt_set_attrs() {
     return 0;
 }
 
-// ---- two-stage pipeline over chunks of the batch --------------------------------------------------------------------------------
-// The transform is three (forward) / four (inverse) dependent kernels; launched back to back on one stream each has to drain
-// before the next starts, and the two four-step FFT stages are latency-bound launches of a few hundred workgroups that move 34 MB
-// (PMC round 3: 29 + 20 us of the forward's 105 us, next to a band stage that writes at the box's 5.2 TB/s).  The batch is
-// therefore cut into chunks of whole clips and the stages run as a pipeline on TWO streams with one event per chunk: the band
-// stage of chunk c (memory-bound) overlaps the FFT stages of chunk c + 1 (latency-bound).  Forward: FFT stages on the side stream,
-// band stage on the caller's stream (so nothing has to be joined at the end); inverse: band stage on the caller's stream, gather +
-// FFT stages on the side stream, joined before the final scale.  Chunks compute exactly what the single launch computed (the
-// kernels only get a first-index offset), so outputs are bit-identical for any split.  TTRAP_CQT_SPLIT = number of chunks
-// (default 4; 1 = the single-stream launch sequence); never split while the caller's stream is being captured into a graph.
-constexpr int MAX_SPLIT = 8, MAX_DEV = 16;
-struct CqtPipe {
-    hipStream_t side = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr, ev[MAX_SPLIT] = {};
-    bool ready = false;
-};
-static CqtPipe g_pipe[MAX_DEV];
-static pthread_mutex_t g_pipe_mu = PTHREAD_MUTEX_INITIALIZER;
-
-static int cqt_split(int Q, int n_blocks, hipStream_t st) {
-    static const int want = [] { const char* v = getenv("TTRAP_CQT_SPLIT"); const int n = v ? atoi(v) : 4; return n < 1 ? 1 : (n > MAX_SPLIT ? MAX_SPLIT : n); }();
-    int n = want;
-    const int clips = Q / n_blocks;
-    while (n > 1 && clips / n < 4) n >>= 1;                    // chunks of at least four clips (a chunk = whole clips)
-    if (n > 1) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) n = 1;
-    }
-    return n;
-}
-static CqtPipe* cqt_pipe() {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
-    CqtPipe* p = &g_pipe[dev];
-    if (!p->ready) {
-        if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        if (hipEventCreateWithFlags(&p->fork, hipEventDisableTiming) != hipSuccess) return nullptr;
-        if (hipEventCreateWithFlags(&p->join, hipEventDisableTiming) != hipSuccess) return nullptr;
-        for (int i = 0; i < MAX_SPLIT; ++i)
-            if (hipEventCreateWithFlags(&p->ev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
-        p->ready = true;
-    }
-    return p;
-}
-// first (clip, block) index and count of chunk c of n: whole clips, the remainder spread over the first chunks
-static inline void chunk_range(int c, int n, int Q, int n_blocks, int& q0, int& nq) {
-    const int clips = Q / n_blocks, per = clips / n, rem = clips - per * n;
-    const int c0 = c * per + (c < rem ? c : rem), cn = per + (c < rem ? 1 : 0);
-    q0 = c0 * n_blocks; nq = cn * n_blocks;
-}
-
 extern "C" int tt_cqt_forward(const tt_cqt_plan* plan, const float* audio, float* out, void* scratch,
                               int B, int n_blocks, int out_complex, void* stream) {
     if (!plan || !audio || !out || !scratch || B <= 0 || n_blocks <= 0) return TT_E_BADARG;
@@ -628,54 +575,25 @@ extern "C" int tt_cqt_forward(const tt_cqt_plan* plan, const float* audio, float
     const int Q = B * n_blocks, F = plan->n_bins;
     Scratch s = carve(scratch, Q, plan->sum_len);
     // audio (B,1,n_blocks*66150) is already [Q][66150] = [Q][NC] float2
-    auto fft_stage = [&](hipStream_t sx, int q0, int nq) -> int {
-        hipLaunchKernelGGL(k_fft675_rows, dim3(N2 / ROWS, nq), dim3(FFT_ROWS_THREADS), LDS_ROWS, sx,
-                           reinterpret_cast<const float2*>(audio), s.A,
-                           reinterpret_cast<const float2*>(plan->tw675), reinterpret_cast<const float2*>(plan->twNc), q0);
-        TT_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_fft49_cols<0>, dim3(NTILES, nq), dim3(256), 0, sx, s.A, s.X,
-                           reinterpret_cast<const float2*>(plan->tw49), reinterpret_cast<const float2*>(plan->twN),
-                           (unsigned*)nullptr, q0);
-        TT_LAUNCH_CHECK();
-        return 0;
-    };
-    auto band_stage = [&](hipStream_t sx, int q0, int nq) -> int {
-        dim3 grid((F + 3) / 4, nq);
-        if (out_complex)
-            hipLaunchKernelGGL(k_band_fwd<true>, grid, dim3(256), 0, sx, s.X, out,
-                               reinterpret_cast<const int4*>(plan->bin_tab), plan->window,
-                               reinterpret_cast<const float2*>(plan->tw1024), F, n_blocks, q0);
-        else
-            hipLaunchKernelGGL(k_band_fwd<false>, grid, dim3(256), 0, sx, s.X, out,
-                               reinterpret_cast<const int4*>(plan->bin_tab), plan->window,
-                               reinterpret_cast<const float2*>(plan->tw1024), F, n_blocks, q0);
-        TT_LAUNCH_CHECK();
-        return 0;
-    };
-    const int nsplit = cqt_split(Q, n_blocks, st);
-    if (nsplit > 1) {
-        pthread_mutex_lock(&g_pipe_mu);
-        CqtPipe* p = cqt_pipe();
-        rc = p ? 0 : TT_E_UNSUPPORTED;
-        if (!rc) rc = (int)hipEventRecord(p->fork, st);
-        if (!rc) rc = (int)hipStreamWaitEvent(p->side, p->fork, 0);
-        for (int c = 0; c < nsplit && !rc; ++c) {
-            int q0, nq;
-            chunk_range(c, nsplit, Q, n_blocks, q0, nq);
-            rc = fft_stage(p->side, q0, nq);
-            if (!rc) rc = (int)hipEventRecord(p->ev[c], p->side);
-        }
-        for (int c = 0; c < nsplit && !rc; ++c) {
-            int q0, nq;
-            chunk_range(c, nsplit, Q, n_blocks, q0, nq);
-            rc = (int)hipStreamWaitEvent(st, p->ev[c], 0);
-            if (!rc) rc = band_stage(st, q0, nq);
-        }
-        pthread_mutex_unlock(&g_pipe_mu);
-        return rc;
-    }
-    if ((rc = fft_stage(st, 0, Q))) return rc;
-    return band_stage(st, 0, Q);
+    hipLaunchKernelGGL(k_fft675_rows, dim3(N2 / ROWS, Q), dim3(FFT_ROWS_THREADS), LDS_ROWS, st,
+                       reinterpret_cast<const float2*>(audio), s.A,
+                       reinterpret_cast<const float2*>(plan->tw675), reinterpret_cast<const float2*>(plan->twNc));
+    TT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_fft49_cols<0>, dim3(NTILES, Q), dim3(256), 0, st, s.A, s.X,
+                       reinterpret_cast<const float2*>(plan->tw49), reinterpret_cast<const float2*>(plan->twN),
+                       (unsigned*)nullptr);
+    TT_LAUNCH_CHECK();
+    dim3 grid((F + 3) / 4, Q);
+    if (out_complex)
+        hipLaunchKernelGGL(k_band_fwd<true>, grid, dim3(256), 0, st, s.X, out,
+                           reinterpret_cast<const int4*>(plan->bin_tab), plan->window,
+                           reinterpret_cast<const float2*>(plan->tw1024), F, n_blocks);
+    else
+        hipLaunchKernelGGL(k_band_fwd<false>, grid, dim3(256), 0, st, s.X, out,
+                           reinterpret_cast<const int4*>(plan->bin_tab), plan->window,
+                           reinterpret_cast<const float2*>(plan->tw1024), F, n_blocks);
+    TT_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int tt_cqt_inverse(const tt_cqt_plan* plan, const float* coeffs, float* audio, void* scratch,
@@ -686,55 +604,28 @@ extern "C" int tt_cqt_inverse(const tt_cqt_plan* plan, const float* coeffs, floa
     hipStream_t st = tt_stream(stream);
     const int Q = B * n_blocks, F = plan->n_bins;
     Scratch s = carve(scratch, Q, plan->sum_len);
+    dim3 grid((F + 3) / 4, Q);
+    if (in_complex)
+        hipLaunchKernelGGL(k_band_inv<true>, grid, dim3(256), 0, st, coeffs, s.S,
+                           reinterpret_cast<const int4*>(plan->bin_tab), plan->dual,
+                           reinterpret_cast<const float2*>(plan->tw1024), F, n_blocks, plan->sum_len);
+    else
+        hipLaunchKernelGGL(k_band_inv<false>, grid, dim3(256), 0, st, coeffs, s.S,
+                           reinterpret_cast<const int4*>(plan->bin_tab), plan->dual,
+                           reinterpret_cast<const float2*>(plan->tw1024), F, n_blocks, plan->sum_len);
+    TT_LAUNCH_CHECK();
     float2* Zc = s.X;   // reuse: [Q][NC]
-    auto band_stage = [&](hipStream_t sx, int q0, int nq) -> int {
-        dim3 grid((F + 3) / 4, nq);
-        if (in_complex)
-            hipLaunchKernelGGL(k_band_inv<true>, grid, dim3(256), 0, sx, coeffs, s.S,
-                               reinterpret_cast<const int4*>(plan->bin_tab), plan->dual,
-                               reinterpret_cast<const float2*>(plan->tw1024), F, n_blocks, plan->sum_len, q0);
-        else
-            hipLaunchKernelGGL(k_band_inv<false>, grid, dim3(256), 0, sx, coeffs, s.S,
-                               reinterpret_cast<const int4*>(plan->bin_tab), plan->dual,
-                               reinterpret_cast<const float2*>(plan->tw1024), F, n_blocks, plan->sum_len, q0);
-        TT_LAUNCH_CHECK();
-        return 0;
-    };
-    auto fft_stage = [&](hipStream_t sx, int q0, int nq) -> int {
-        hipLaunchKernelGGL(k_spec_gather, dim3((NC + 255) / 256, nq), dim3(256), 0, sx, s.S, Zc, plan->gat_off,
-                           plan->gat_idx, reinterpret_cast<const float2*>(plan->twN), plan->sum_len, q0);
-        TT_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_fft675_rows, dim3(N2 / ROWS, nq), dim3(FFT_ROWS_THREADS), LDS_ROWS, sx, Zc, s.A,
-                           reinterpret_cast<const float2*>(plan->tw675), reinterpret_cast<const float2*>(plan->twNc), q0);
-        TT_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_fft49_cols<1>, dim3(NTILES, nq), dim3(256), 0, sx, s.A, reinterpret_cast<float2*>(audio),
-                           reinterpret_cast<const float2*>(plan->tw49), reinterpret_cast<const float2*>(plan->twN),
-                           normalize ? s.mx : (unsigned*)nullptr, q0);
-        TT_LAUNCH_CHECK();
-        return 0;
-    };
-    if (normalize) TT_HIP(hipMemsetAsync(s.mx, 0, 4, st));      // before every chunk's last stage (ordered through the events)
-    const int nsplit = cqt_split(Q, n_blocks, st);
-    if (nsplit > 1) {
-        pthread_mutex_lock(&g_pipe_mu);
-        CqtPipe* p = cqt_pipe();
-        rc = p ? 0 : TT_E_UNSUPPORTED;
-        for (int c = 0; c < nsplit && !rc; ++c) {
-            int q0, nq;
-            chunk_range(c, nsplit, Q, n_blocks, q0, nq);
-            rc = band_stage(st, q0, nq);
-            if (!rc) rc = (int)hipEventRecord(p->ev[c], st);
-            if (!rc) rc = (int)hipStreamWaitEvent(p->side, p->ev[c], 0);
-            if (!rc) rc = fft_stage(p->side, q0, nq);
-        }
-        if (!rc) rc = (int)hipEventRecord(p->join, p->side);
-        if (!rc) rc = (int)hipStreamWaitEvent(st, p->join, 0);
-        pthread_mutex_unlock(&g_pipe_mu);
-        if (rc) return rc;
-    } else {
-        if ((rc = band_stage(st, 0, Q))) return rc;
-        if ((rc = fft_stage(st, 0, Q))) return rc;
-    }
+    hipLaunchKernelGGL(k_spec_gather, dim3((NC + 255) / 256, Q), dim3(256), 0, st, s.S, Zc, plan->gat_off,
+                       plan->gat_idx, reinterpret_cast<const float2*>(plan->twN), plan->sum_len);
+    TT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_fft675_rows, dim3(N2 / ROWS, Q), dim3(FFT_ROWS_THREADS), LDS_ROWS, st, Zc, s.A,
+                       reinterpret_cast<const float2*>(plan->tw675), reinterpret_cast<const float2*>(plan->twNc));
+    TT_LAUNCH_CHECK();
+    if (normalize) TT_HIP(hipMemsetAsync(s.mx, 0, 4, st));
+    hipLaunchKernelGGL(k_fft49_cols<1>, dim3(NTILES, Q), dim3(256), 0, st, s.A, reinterpret_cast<float2*>(audio),
+                       reinterpret_cast<const float2*>(plan->tw49), reinterpret_cast<const float2*>(plan->twN),
+                       normalize ? s.mx : (unsigned*)nullptr);
+    TT_LAUNCH_CHECK();
     if (normalize) {
         const long n = (long)Q * 2 * NC;
         hipLaunchKernelGGL(k_scale_by_max, dim3(2048), dim3(256), 0, st, audio, s.mx, n);

@@ -1,14 +1,16 @@
 #!/bin/bash
-# A/B of the one-pass wide backward (k_wrb_bwd1) against the per-stage kernels at the bench shape; env switches are read once per process
+# A/B of the one-pass wide backward (strip form k_wrb_bwds; TTRAP_BWD1_FORM=1: tile form k_wrb_bwd1) against the per-stage kernels at the
+# bench shape; env switches are read once per process
 cd "$(dirname "$0")/.."
 out=gpurun_out/r04_bwd1_ab.txt
 : > $out
 for C in 32 16; do
   echo "== C=$C per-stage" >> $out
-  TTRAP_WBWD1=0 KB_C=$C KB_D=1,2,3 KB_WHAT=bwd KB_N=20 python tools/kb_level.py >> $out 2>&1
-  for tile in 0 1; do for per in 2 3; do
-    echo "== C=$C one-pass TILE=$tile PER_CU=$per" >> $out
-    TTRAP_BWD1_TILE=$tile TTRAP_BWD1_PER_CU=$per KB_C=$C KB_D=1,2,3 KB_WHAT=bwd1 KB_N=20 python tools/kb_level.py >> $out 2>&1
+  TTRAP_WBWD1=0 KB_C=$C KB_D=1,2,3 KB_WHAT=bwd KB_N=20 python tools/kb_level.py 2>&1 | grep bwd >> $out
+  for tile in 0 1 2; do for per in 2 3 4; do
+    if [ $C = 32 ] && [ $per = 4 ]; then continue; fi
+    echo "== C=$C strips TILE=$tile PER_CU=$per" >> $out
+    TTRAP_BWDS_TILE=$tile TTRAP_BWDS_PER_CU=$per KB_C=$C KB_D=1,2,3 KB_WHAT=bwd1 KB_N=20 python tools/kb_level.py 2>&1 | grep bwd >> $out
   done; done
 done
 cat $out

@@ -345,6 +345,55 @@ int tt_peak_pick(const float* x, float* out, int64_t n_outer, int F, int T, doub
 int tt_target_activations(const int* bins, const int* frames, int n, const double* weights, int radius, int F, int T,
                           double* work, double* out, void* stream);
 
+/* ---- fp16 twins ---------------------------------------------------------------------------------------------------------------
+ * Every entry point of the 16-bit channels-last path above exists a second time with the suffix _h: the same kernels compiled with
+ * fp16 elements (csrc/bf16_common.h, -DTT_F16: v_mfma_f32_*_f16, same layouts, same scratch sizes, same argument meaning; `void*`
+ * activation pointers then hold IEEE half instead of bf16).  fp16 is the dtype the reference's own train step runs in
+ * (experiments/train.py:415: torch.autocast('cuda') defaults to torch.float16): 11 significant bits per stored activation instead of
+ * 8, at the price of fp16's range (normal numbers 6.1e-5 .. 65504; the reference uses no GradScaler, and neither does this path).
+ * The Python layer picks the set by the autocast dtype. */
+int64_t tt_wide_scratch_bytes_h(int B, int C, int H, int T);
+int tt_wide_pack_h(const float* x, void* out, int B, int C, int H, int T, void* stream);
+int tt_wide_unpack_h(const void* in, float* y, int B, int C, int H, int T, void* stream);
+int tt_wide_rb_fwd_h(const void* x, const float* w1, const float* b1, const float* w2, const float* b2, void* y, void* h1,
+                   int B, int C, int H, int T, int dilation, void* stream);
+int tt_wide_rb_bwd_h(const void* x, const void* h1, const void* dy, const float* w1, const float* w2, const float* b2,
+                   void* dx, float* dw1, float* db1, float* dw2, float* db2, void* ws, int B, int C, int H, int T,
+                   int dilation, void* stream);
+int64_t tt_wide_fused_scratch_bytes_h(int C);
+int tt_wide_rb_bwd_fused_h(const void* x, const void* dy, const float* w1, const float* b1, const float* w2, const float* b2,
+                         void* dx, float* dw1, float* db1, float* dw2, float* db2, void* ws, int B, int C, int H, int T,
+                         int dilation, void* stream);
+int64_t tt_wide_onepass_scratch_bytes_h(int C);
+int tt_wide_rb_bwd_onepass_h(const void* x, const void* h1, const void* dy, const float* w1, const float* w2, const float* b2,
+                           void* dx, float* dw1, float* db1, float* dw2, float* db2, void* ws, int B, int C, int H, int T,
+                           int dilation, void* stream);
+int tt_wide_rb_bwd_is_onepass_h(int C, int dilation);
+int64_t tt_stride16_scratch_bytes_h(int C);
+int tt_sconv16_fwd_h(const void* x, const float* w, const float* b, void* y, int B, int C, int H, int T, void* stream);
+int tt_sconv16_bwd_h(const void* x, const void* y, const void* dy, const float* w, void* dx, float* dw, float* db, void* ws,
+                   int B, int C, int H, int T, void* stream);
+int tt_tconv16_fwd_h(const void* x, const float* w, const float* b, void* y, int B, int C, int H, int T, int out_pad,
+                   void* stream);
+int tt_tconv16_bwd_h(const void* x, const void* y, const void* dy, const float* w, void* dx, float* dw, float* db, void* ws,
+                   int B, int C, int H, int T, int out_pad, void* stream);
+int64_t tt_latent16_scratch_bytes_h(int B, int CT, int D, int E, int T);
+int tt_latent16_contract_h(const void* in, const void* gy, const float* w, const float* bias, float* out, void* ws, int B, int CT,
+                         int D, int Dout, int E, int T, void* stream);
+int tt_latent16_expand_h(const float* z, int Dz, float fill, const float* w, const float* bias, void* out, void* ws, int B, int CT,
+                       int D, int E, int T, void* stream);
+int tt_latent16_wgrad_h(const float* z, int Dz, float fill, const void* g, const void* gy, float* dw, float* db, void* ws, int B,
+                      int CT, int D, int E, int T, void* stream);
+int64_t tt_edge16_scratch_bytes_h(void);
+int tt_convin16_fwd_h(const float* x, const float* w, const float* b, void* y, int B, int H, int T, void* stream);
+int tt_convin16_bwd_h(const float* x, const void* y, const void* dy, const float* w, float* dx, float* dw, float* db, void* ws,
+                    int B, int H, int T, void* stream);
+int tt_convout16_fwd_h(const void* x, const float* w, const float* b, float* y, int B, int H, int T, void* stream);
+int tt_convout16_bwd_h(const void* x, const float* dy, const float* w, void* dx, float* dw, float* db, void* ws, int B, int H,
+                     int T, void* stream);
+int tt_scaled_add16_h(const void* a, const void* b, const float* s, int idx, void* y, int64_t n, void* stream);
+int tt_dot16_h(const void* a, const void* b, float* out, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

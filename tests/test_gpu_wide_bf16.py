@@ -21,7 +21,26 @@ from oracle import autoencoder as oae
 
 pytestmark = pytest.mark.gpu
 
-BF16_REL = 2.0 ** -8
+# Element type of the 16-bit channels-last tensors under test: bf16 (default), or fp16 with TT_TEST_ELT=fp16 -- the same kernels
+# compiled with fp16 elements (the _h entry points of include/ttrap.h); test_fp16_build_passes_the_same_stagewise_tests re-runs the
+# stage-wise tests of this file that way in a child process.
+FP16 = os.environ.get('TT_TEST_ELT', 'bf16') == 'fp16'
+ELT = torch.float16 if FP16 else torch.bfloat16
+BF16_REL = 2.0 ** -11 if FP16 else 2.0 ** -8            # one rounding of a stored element
+ABS16 = 2.5e-4 if FP16 else 2e-3                        # absolute slack, relative to the tensor's scale
+
+
+@pytest.fixture(autouse=True)
+def _element_type(monkeypatch):
+    if FP16:
+        from timbre_trap.framework import ops
+        monkeypatch.setattr(ops, 'PRECISION', 'fp16')       # forwards that create 16-bit tensors from fp32 inputs follow the mode
+    yield
+
+
+def _lib():
+    from timbre_trap.framework import ops
+    return ops.lib16(ELT)
 
 
 def _rand(*shape, seed=0, scale=1.0):
@@ -30,8 +49,8 @@ def _rand(*shape, seed=0, scale=1.0):
 
 
 def _r16(t):
-    """round to bf16, return float64."""
-    return t.float().bfloat16().double()
+    """round to the element type under test, return float64."""
+    return t.float().to(ELT).double()
 
 
 def _planar(t_nhwc):
@@ -42,7 +61,7 @@ def _planar(t_nhwc):
 def _close16(got, want, name, abs_scale=None):
     """|got - want| within bf16 rounding of want (+ a small absolute term relative to the tensor's magnitude)."""
     scale = float(want.abs().max()) if abs_scale is None else abs_scale
-    tol = BF16_REL * want.abs() + 2e-3 * scale + 1e-30
+    tol = BF16_REL * want.abs() + ABS16 * scale + 1e-30
     bad = (got - want).abs() > tol
     assert not bool(bad.any()), '%s: %d of %d outside bf16 rounding, worst %.3e (scale %.3e)' % (
         name, int(bad.sum()), bad.numel(), float((got - want).abs().max()), scale)
@@ -66,9 +85,8 @@ def _elu_grad(a):
 
 
 def _stagewise(C, d, B, H, T):
-    from timbre_trap import _hip
     from timbre_trap._hip import check, ptr, stream_ptr
-    lib, st = _hip.lib(), stream_ptr()
+    lib, st = _lib(), stream_ptr()
     x = _rand(B, C, H, T, seed=1)
     w1 = _rand(C, C, 3, 3, seed=2, scale=1.0 / (3 * C ** 0.5))
     b1 = _rand(C, seed=3, scale=0.3)
@@ -79,16 +97,16 @@ def _stagewise(C, d, B, H, T):
     xd, w1d, b1d, w2d, b2d, gyd = (dev(t) for t in (x, w1, b1, w2, b2, gy))
 
     def nhwc():
-        return torch.empty((B, H, T, C), dtype=torch.bfloat16, device='cuda')
+        return torch.empty((B, H, T, C), dtype=ELT, device='cuda')
 
     # layout change: exact bf16 rounding, and its inverse
     xb, gb = nhwc(), nhwc()
     check(lib.tt_wide_pack(ptr(xd), ptr(xb), B, C, H, T, st), 'pack')
     check(lib.tt_wide_pack(ptr(gyd), ptr(gb), B, C, H, T, st), 'pack')
-    assert torch.equal(xb.cpu(), x.bfloat16().permute(0, 2, 3, 1).contiguous())
+    assert torch.equal(xb.cpu(), x.to(ELT).permute(0, 2, 3, 1).contiguous())
     back = torch.empty_like(xd)
     check(lib.tt_wide_unpack(ptr(xb), ptr(back), B, C, H, T, st), 'unpack')
-    assert torch.equal(back.cpu(), x.bfloat16().float())
+    assert torch.equal(back.cpu(), x.to(ELT).float())
 
     # forward
     yb, hb = nhwc(), nhwc()
@@ -118,7 +136,7 @@ def _stagewise(C, d, B, H, T):
     dA1 = dh1 * torch.where(h_k > 0, torch.ones_like(h_k), h_k + 1)
     fused = {'0': False, '2': True}.get(os.environ.get('TTRAP_NARROW_FUSED16', '1'), d <= 2 if C == 8 else True)
     if (C >= 16 and not lib.tt_wide_rb_bwd_is_onepass(C, d)) or (C < 16 and not fused):
-        da1_k = _planar(ws[:B * H * T * C * 2].view(torch.bfloat16).view(B, H, T, C))
+        da1_k = _planar(ws[:B * H * T * C * 2].view(ELT).view(B, H, T, C))
         _close16(da1_k, dA1, 'dA1')
     else:
         da1_k = _r16(dA1)          # the fused narrow backward keeps dA1 in LDS: the restatement's own rounded dA1 stands in
@@ -235,9 +253,11 @@ def test_level_dispatch(monkeypatch):
     assert ops.wide_storage() == 'fp32'
 
 
-def test_autocast_selects_bf16_path(monkeypatch):
-    """ops.PRECISION == 'auto' (the default): bf16 storage inside torch.autocast('cuda') -- where the reference's train step runs
-    (experiments/train.py:415) -- and exact fp32 outside it."""
+@pytest.mark.parametrize('dtype', [None, torch.bfloat16, torch.float16], ids=['default-fp16', 'bf16', 'fp16'])
+def test_autocast_selects_the_16_bit_path_of_its_dtype(dtype, monkeypatch):
+    """ops.PRECISION == 'auto' (the default): 16-bit channels-last storage inside torch.autocast('cuda') -- where the reference's
+    train step runs (experiments/train.py:415) -- in the REGION'S dtype: the unmodified ``torch.autocast('cuda')`` of the reference
+    is float16 (torch's default), bench.py asks for bfloat16; exact fp32 outside the region."""
     from timbre_trap.framework import modules, ops
     monkeypatch.setattr(ops, 'PRECISION', 'auto')
     monkeypatch.setattr(ops, 'WIDE_STORAGE', '')
@@ -246,13 +266,15 @@ def test_autocast_selects_bf16_path(monkeypatch):
     x = _rand(1, 32, 6, 64, seed=3).cuda().requires_grad_(True)
     assert ops.precision() == 'fp32'
     y32 = blk(x)
-    with torch.autocast(device_type='cuda'):
-        assert ops.precision() == 'bf16' and ops.wide_storage() == 'bf16'
+    want = 'bf16' if dtype == torch.bfloat16 else 'fp16'
+    with (torch.autocast(device_type='cuda') if dtype is None else torch.autocast(device_type='cuda', dtype=dtype)):
+        assert ops.precision() == want and ops.wide_storage() == want and ops.cl16_mode()
         y16 = blk(x)
         y16.square().mean().backward()
     assert ops.precision() == 'fp32'
-    assert ops.is_cl16(y16) and y16.shape == y32.shape        # a bf16 channels-last tensor of the reference's logical shape
-    assert _rel(y16.detach().float().cpu().double(), y32.detach().cpu().double()) < 3e-2
+    assert ops.is_cl16(y16) and y16.shape == y32.shape        # a 16-bit channels-last tensor of the reference's logical shape
+    assert y16.dtype == (torch.bfloat16 if dtype == torch.bfloat16 else torch.float16)
+    assert _rel(y16.detach().float().cpu().double(), y32.detach().cpu().double()) < (3e-2 if dtype == torch.bfloat16 else 4e-3)
     assert x.grad is not None and x.grad.dtype == torch.float32 and torch.isfinite(x.grad).all()
 
 
@@ -261,7 +283,7 @@ def test_autocast_selects_bf16_path(monkeypatch):
 def _cl16(t):
     """fp32 (B,C,H,T) CPU tensor -> cl16 device tensor through the pack kernel."""
     from timbre_trap.framework import ops
-    return ops._pack(t.cuda().contiguous())
+    return ops._pack(t.cuda().contiguous(), ELT)
 
 
 def _f64(t16):
@@ -278,20 +300,20 @@ def test_sconv16_stagewise(C, shape):
     from timbre_trap import _hip
     from timbre_trap._hip import check, ptr, stream_ptr
     from timbre_trap.framework import ops
-    lib, st = _hip.lib(), stream_ptr()
+    lib, st = _lib(), stream_ptr()
     B, H, T = shape
     Ho = (H - 4) // 2 + 1
     x, dy = _rand(B, C, H, T, seed=1), _rand(B, 2 * C, Ho, T, seed=2)
     w, b = _rand(2 * C, C, 4, 1, seed=3, scale=1.0 / (2 * C ** 0.5)), _rand(2 * C, seed=4, scale=0.3)
     xb, gb = _cl16(x), _cl16(dy)
     wd, bd = w.cuda(), b.cuda()
-    y = ops.new_cl16(B, 2 * C, Ho, T, 'cuda')
+    y = ops.new_cl16(B, 2 * C, Ho, T, 'cuda', ELT)
     check(lib.tt_sconv16_fwd(ptr(xb), ptr(wd), ptr(bd), ptr(y), B, C, H, T, st), 'fwd')
     xr, gr, wr = _r16(x), _r16(dy), _r16(w)
     y_ref = F.elu(F.conv2d(xr, wr, b.double(), stride=(2, 1)))
     y_k = _f64(y)
     _close16(y_k, y_ref, 'y')
-    dx = ops.new_cl16(B, C, H, T, 'cuda')
+    dx = ops.new_cl16(B, C, H, T, 'cuda', ELT)
     dw, db = torch.full((2 * C, C, 4, 1), 0.25, device='cuda'), torch.full((2 * C,), 0.25, device='cuda')
     ws = torch.empty(lib.tt_stride16_scratch_bytes(C), dtype=torch.uint8, device='cuda')
     check(lib.tt_sconv16_bwd(ptr(xb), ptr(y), ptr(gb), ptr(wd), ptr(dx), ptr(dw), ptr(db), ptr(ws), B, C, H, T, st), 'bwd')
@@ -310,20 +332,20 @@ def test_tconv16_stagewise(C, shape, out_pad):
     from timbre_trap import _hip
     from timbre_trap._hip import check, ptr, stream_ptr
     from timbre_trap.framework import ops
-    lib, st = _hip.lib(), stream_ptr()
+    lib, st = _lib(), stream_ptr()
     B, H, T = shape
     Ho = 2 * H + 2 + out_pad
     x, dy = _rand(B, 2 * C, H, T, seed=1), _rand(B, C, Ho, T, seed=2)
     w, b = _rand(2 * C, C, 4, 1, seed=3, scale=1.0 / (2 * C ** 0.5)), _rand(C, seed=4, scale=0.3)
     xb, gb = _cl16(x), _cl16(dy)
     wd, bd = w.cuda(), b.cuda()
-    y = ops.new_cl16(B, C, Ho, T, 'cuda')
+    y = ops.new_cl16(B, C, Ho, T, 'cuda', ELT)
     check(lib.tt_tconv16_fwd(ptr(xb), ptr(wd), ptr(bd), ptr(y), B, C, H, T, out_pad, st), 'fwd')
     xr, gr, wr = _r16(x), _r16(dy), _r16(w)
     y_ref = F.elu(F.conv_transpose2d(xr, wr, b.double(), stride=(2, 1), output_padding=(out_pad, 0)))
     y_k = _f64(y)
     _close16(y_k, y_ref, 'y')
-    dx = ops.new_cl16(B, 2 * C, H, T, 'cuda')
+    dx = ops.new_cl16(B, 2 * C, H, T, 'cuda', ELT)
     dw, db = torch.full((2 * C, C, 4, 1), 0.25, device='cuda'), torch.full((C,), 0.25, device='cuda')
     ws = torch.empty(lib.tt_stride16_scratch_bytes(C), dtype=torch.uint8, device='cuda')
     check(lib.tt_tconv16_bwd(ptr(xb), ptr(y), ptr(gb), ptr(wd), ptr(dx), ptr(dw), ptr(db), ptr(ws), B, C, H, T, out_pad, st), 'bwd')
@@ -534,7 +556,7 @@ def test_skip_joins_on_the_device(shape):
     B, C, H, T = shape
     e32, y32, g32 = _rand(B, C, H, T, seed=1), _rand(B, C, H, T, seed=2), _rand(B, C, H, T, seed=3)
     w = torch.tensor([0.5, -1.25, 2.0, 0.75, 1.5])
-    cl = lambda t: t.cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    cl = lambda t: t.cuda().to(ELT).contiguous(memory_format=torch.channels_last)
     e, y = cl(e32).requires_grad_(True), cl(y32).requires_grad_(True)
     wd = w.cuda().requires_grad_(True)
     assert ops.is_cl16(e)
@@ -582,4 +604,16 @@ def test_recompute_path_at_model_level():
     out = _pytest_subprocess(dict(TTRAP_LEVEL_RECOMPUTE='1', TT_CHILD_PYTEST='1'),
                              ['tests/test_gpu_model.py', 'tests/test_gpu_wide_bf16.py', '-k',
                               'autocast_bf16_step_matches or wide_level_matches_oracle or reduced_precision_training'])
+    assert ' passed' in out
+
+
+@pytest.mark.skipif(os.environ.get('TT_CHILD_PYTEST') == '1', reason='already inside the child run')
+def test_fp16_build_passes_the_same_stagewise_tests():
+    """The fp16 twins (include/ttrap.h: suffix _h; the same sources compiled with fp16 elements -- the reference's own autocast dtype,
+    train.py:415) against the same float64 restatements with fp16 roundings at the kernels' rounding points: residual blocks of all
+    four widths (per-stage, one-pass and fused), strided / transposed layers, latent heads, boundary convolutions, skip joins, capped
+    grids, bench heights and T = 3072 -- at the fp16 bars (2^-11 relative + 2.5e-4 of the tensor's scale per stored element)."""
+    out = _pytest_subprocess(dict(TT_TEST_ELT='fp16', TT_CHILD_PYTEST='1'),
+                             ['tests/test_gpu_wide_bf16.py', '-k', 'stagewise or multitile or edge_convs or capped_grids or bench_launch_shapes '
+                              'or bench_heights or skip_joins or reference_training_length'])
     assert ' passed' in out

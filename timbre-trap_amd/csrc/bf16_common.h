@@ -1,5 +1,14 @@
-// Shared pieces of the bf16 channel-innermost kernels (conv_wide_bf16.hip, conv_stride_bf16.hip) for gfx950.
+// Shared pieces of the 16-bit channel-innermost kernels (conv_wide_bf16.hip, conv_level_bf16.hip, conv_stride_bf16.hip,
+// latent_bf16.hip, conv_edge_bf16.hip) for gfx950.
+//
+// ELEMENT TYPE.  These five sources are compiled TWICE (timbre_trap/_hip.py): as written with e16 = bf16 -- the "bf16 MFMA conv
+// path" of BASELINE config[2] -- and with -DTT_F16 with e16 = fp16, the dtype the reference's own train step runs in
+// (experiments/train.py:415: torch.autocast('cuda') defaults to float16): the same kernels, the same layouts (every operand is 16
+// bits), v_mfma_f32_*_f16 instead of *_bf16 at the same rate, 11 instead of 8 significant bits in every stored activation and
+// operand, a range of 6e-5 .. 65504 (normal) instead of fp32's.  The second build exports every entry point with the suffix _h
+// (e16_names.h); include/ttrap.h declares both sets.
 #pragma once
+#include "e16_names.h"
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -7,8 +16,13 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#if defined(TT_F16)
+typedef _Float16 e16;
+#else
+typedef __bf16 e16;
+#endif
+typedef e16 e16x8 __attribute__((ext_vector_type(8)));
+typedef e16 e16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int NT = 256;                        // threads per workgroup (4 waves)
@@ -20,9 +34,24 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 // A (16 x 32) . B (32 x 16): lane l holds row / column l & 15 and k = 8 (l >> 4) + j; D: column l & 15, rows 4 (l >> 4) + r
-__device__ __forceinline__ f32x4 mma32(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+#if defined(TT_F16)
+__device__ __forceinline__ f32x4 mma32(e16x8 a, e16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+#else
+__device__ __forceinline__ f32x4 mma32(e16x8 a, e16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+#endif
 // K = 16: lane l holds k = 4 (l >> 4) + j
+// and sixteen independent 4 x 4 x 4 products per wave (block = lane / 4): the lane-per-pixel form of the narrow levels
+#if defined(TT_F16)
+__device__ __forceinline__ f32x4 mma16(s16x4 a, s16x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(e16x4, a), __builtin_bit_cast(e16x4, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mma4(s16x4 a, s16x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(e16x4, a), __builtin_bit_cast(e16x4, b), c, 0, 0, 0);
+}
+#else
 __device__ __forceinline__ f32x4 mma16(s16x4 a, s16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mma4(s16x4 a, s16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a, b, c, 0, 0, 0); }
+#endif
 
 __device__ __forceinline__ int xcd_order(int v, int n) {          // see conv_mfma.hip: one contiguous eighth of the raster per XCD
     const int per = n >> 3;

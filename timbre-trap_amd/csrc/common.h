@@ -47,7 +47,7 @@ __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
 
-// ELU and its derivative through the output, exact fp32 path (every oracle parity test): compare + select like torch -- a > 0 gives a
+// ELU and its derivative through the output, exact fp32 path (the arithmetic every CPU-restatement parity test pins): compare + select like torch -- a > 0 gives a
 // itself (v_med3(a, exp(a) - 1, 0), tried in round 3, returns exp(a) - 1 for 0 < a < 3e-4 where the fp32 difference falls below a:
 // up to 1.2e-7 off) and a NaN stays a NaN (the median and v_min forms return 0 / 1 for a NaN operand, which would hide a diverged
 // weight from the loss).

@@ -105,7 +105,7 @@ struct StagePlanar {
 template <bool GATE>
 struct StageCl4 {
     static constexpr int NIT = (EPLANE + NT - 1) / NT;
-    bf16x4 q[NIT], yq[GATE ? NIT : 1];
+    e16x4 q[NIT], yq[GATE ? NIT : 1];
     unsigned rel[NIT];
     unsigned okm;
     __device__ __forceinline__ void init(int T, int tid) {
@@ -116,7 +116,7 @@ struct StageCl4 {
             rel[it] = i < EPLANE ? (unsigned)(row * T + col) * 8u : 0u;
         }
     }
-    __device__ __forceinline__ void load(const __bf16* src, const __bf16* ysrc, const TileCtx& c, int H, int T, int tid) {
+    __device__ __forceinline__ void load(const e16* src, const e16* ysrc, const TileCtx& c, int H, int T, int tid) {
         const ETile tl = c.tl;
         if (c.interior) {
             const long first = (((long)tl.b * H + (tl.h0 - 1)) * T + (tl.t0 - 1)) * 4;
@@ -125,8 +125,8 @@ struct StageCl4 {
             okm = 0xffffffffu;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                q[it] = *reinterpret_cast<const bf16x4*>(base + rel[it]);
-                if (GATE) yq[it] = *reinterpret_cast<const bf16x4*>(ybase + rel[it]);
+                q[it] = *reinterpret_cast<const e16x4*>(base + rel[it]);
+                if (GATE) yq[it] = *reinterpret_cast<const e16x4*>(ybase + rel[it]);
             }
             return;
         }
@@ -139,8 +139,8 @@ struct StageCl4 {
             const bool ok = i < EPLANE && (unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T;
             okm |= ok ? 1u << it : 0u;
             const long off = ok ? (((long)tl.b * H + h) * T + t) * 4 : 0;
-            q[it] = *reinterpret_cast<const bf16x4*>(src + off);
-            if (GATE) yq[it] = *reinterpret_cast<const bf16x4*>(ysrc + off);
+            q[it] = *reinterpret_cast<const e16x4*>(src + off);
+            if (GATE) yq[it] = *reinterpret_cast<const e16x4*>(ysrc + off);
         }
     }
     // LDS layout [pixel][4 channels] fp32: ONE 16-byte write per element here and one 16-byte read per tap pixel in the kernels (the
@@ -275,7 +275,7 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& 
 // ---- Encoder.convin ------------------------------------------------------------------------------------------------------------
 template <bool VEC>
 __global__ __launch_bounds__(NT) void k_cin_fwd(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                                 __bf16* __restrict__ y, int H, int T, int tiles_h, int tiles_t, int ntiles) {
+                                                 e16* __restrict__ y, int H, int T, int tiles_h, int tiles_t, int ntiles) {
     __shared__ __attribute__((aligned(16))) float xs[2 * PPLANE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float wa[18];                                                // [ci * 9 + k]: w[co = lane % 4][ci][k], the A operand of the 4x4x1 products
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(NT) void k_cin_fwd(const float* __restrict__ x, con
         const int t = tl.t0 + lane, r0 = wave * ERPW;
         Win<2> xw;
         xw.start(xs, r0, lane);
-        bf16x4 o[ERPW];                                          // stores after the rows: no branch between them (one basic block, so
+        e16x4 o[ERPW];                                          // stores after the rows: no branch between them (one basic block, so
 #pragma unroll                                                   // that every tap broadcast folds into the multiply-add's op_sel)
         for (int rr = 0; rr < ERPW; ++rr) {
             xw.advance(xs, r0 + rr, lane);
@@ -305,15 +305,15 @@ __global__ __launch_bounds__(NT) void k_cin_fwd(const float* __restrict__ x, con
                 a1 = mfma441(wa[9 + k], xw.template one<k>(1), a1);
             });
             const f32x4 a = a0 + a1;
-            o[rr][0] = (__bf16)elu_f(a[0]); o[rr][1] = (__bf16)elu_f(a[1]);
-            o[rr][2] = (__bf16)elu_f(a[2]); o[rr][3] = (__bf16)elu_f(a[3]);
+            o[rr][0] = (e16)elu_f(a[0]); o[rr][1] = (e16)elu_f(a[1]);
+            o[rr][2] = (e16)elu_f(a[2]); o[rr][3] = (e16)elu_f(a[3]);
             asm volatile("" :: "v"(o[rr]));
             row_fence();
         }
 #pragma unroll
         for (int rr = 0; rr < ERPW; ++rr) {
             const int h = tl.h0 + r0 + rr;
-            if (t < T && h < H) *reinterpret_cast<bf16x4*>(y + (((long)tl.b * H + h) * T + t) * 4) = o[rr];
+            if (t < T && h < H) *reinterpret_cast<e16x4*>(y + (((long)tl.b * H + h) * T + t) * 4) = o[rr];
         }
     }
 }
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(NT) void k_cin_fwd(const float* __restrict__ x, con
 // dW[co][ci][k] = sum g[co][p] x[ci][p + k];  db[co] = sum g[co];  dx[ci][p] = sum_{co,k} W[co][ci][k] g[co][p - k]
 // (g and x are zero outside the image in LDS, so only the stores are masked)
 template <bool DX, bool VEC>
-__global__ __launch_bounds__(NT, 2) void k_cin_bwd(const float* __restrict__ x, const __bf16* __restrict__ y, const __bf16* __restrict__ dy,
+__global__ __launch_bounds__(NT, 2) void k_cin_bwd(const float* __restrict__ x, const e16* __restrict__ y, const e16* __restrict__ dy,
                                                  const float* __restrict__ w, float* __restrict__ dx, float* __restrict__ part,
                                                  int H, int T, int tiles_h, int tiles_t, int ntiles) {
     __shared__ __attribute__((aligned(16))) float xs[2 * PPLANE];
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(NT, 2) void k_cin_bwd(const float* __restrict__ x, 
 }
 
 // ---- Decoder.convout -----------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void k_cout_fwd(const __bf16* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+__global__ __launch_bounds__(NT) void k_cout_fwd(const e16* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                   float* __restrict__ y, int H, int T, int tiles_h, int tiles_t, int ntiles) {
     __shared__ __attribute__((aligned(16))) float xs[4 * EPLANE + 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -476,8 +476,8 @@ __global__ __launch_bounds__(NT) void k_cout_fwd(const __bf16* __restrict__ x, c
 }
 
 template <bool VEC>
-__global__ __launch_bounds__(NT, 2) void k_cout_bwd(const __bf16* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ w,
-                                                  __bf16* __restrict__ dx, float* __restrict__ part, int H, int T, int tiles_h,
+__global__ __launch_bounds__(NT, 2) void k_cout_bwd(const e16* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ w,
+                                                  e16* __restrict__ dx, float* __restrict__ part, int H, int T, int tiles_h,
                                                   int tiles_t, int ntiles) {
     __shared__ __attribute__((aligned(16))) float xs[4 * EPLANE + 4];
     __shared__ __attribute__((aligned(16))) float gs[2 * PPLANE];
@@ -545,9 +545,9 @@ __global__ __launch_bounds__(NT, 2) void k_cout_bwd(const __bf16* __restrict__ x
 #pragma unroll
         for (int rr = 0; rr < ERPW; ++rr) {
             const int h = tl.h0 + r0 + rr;
-            bf16x4 o;
-            o[0] = (__bf16)d[rr][0]; o[1] = (__bf16)d[rr][1]; o[2] = (__bf16)d[rr][2]; o[3] = (__bf16)d[rr][3];
-            if (t < T && h < H) *reinterpret_cast<bf16x4*>(dx + (((long)tl.b * H + h) * T + t) * 4) = o;
+            e16x4 o;
+            o[0] = (e16)d[rr][0]; o[1] = (e16)d[rr][1]; o[2] = (e16)d[rr][2]; o[3] = (e16)d[rr][3];
+            if (t < T && h < H) *reinterpret_cast<e16x4*>(dx + (((long)tl.b * H + h) * T + t) * 4) = o;
         }
     }
     __syncthreads();
@@ -592,8 +592,8 @@ int64_t tt_edge16_scratch_bytes(void) { return (int64_t)EDGE_MAX_WG * NPARTW * 4
 int tt_convin16_fwd(const float* x, const float* w, const float* b, void* y, int B, int H, int T, void* stream) {
     if (!x || !w || !b || !y || !edge_ok(B, H, T)) return TT_E_BADARG;
     int th, tt, n; edge_tiles(B, H, T, th, tt, n);
-    if (T % 4 == 0) hipLaunchKernelGGL(k_cin_fwd<true>, dim3(edge_grid(n)), dim3(NT), 0, tt_stream(stream), x, w, b, (__bf16*)y, H, T, th, tt, n);
-    else hipLaunchKernelGGL(k_cin_fwd<false>, dim3(edge_grid(n)), dim3(NT), 0, tt_stream(stream), x, w, b, (__bf16*)y, H, T, th, tt, n);
+    if (T % 4 == 0) hipLaunchKernelGGL(k_cin_fwd<true>, dim3(edge_grid(n)), dim3(NT), 0, tt_stream(stream), x, w, b, (e16*)y, H, T, th, tt, n);
+    else hipLaunchKernelGGL(k_cin_fwd<false>, dim3(edge_grid(n)), dim3(NT), 0, tt_stream(stream), x, w, b, (e16*)y, H, T, th, tt, n);
     TT_LAUNCH_CHECK();
     return 0;
 }
@@ -605,7 +605,7 @@ int tt_convin16_bwd(const float* x, const void* y, const void* dy, const float* 
     const int grid = edge_grid(n);
     hipStream_t st = tt_stream(stream);
     const bool vec = T % 4 == 0;
-#define CIN_BWD(DX_, V_) hipLaunchKernelGGL((k_cin_bwd<DX_, V_>), dim3(grid), dim3(NT), 0, st, x, (const __bf16*)y, (const __bf16*)dy, w, dx, (float*)ws, H, T, th, tt, n)
+#define CIN_BWD(DX_, V_) hipLaunchKernelGGL((k_cin_bwd<DX_, V_>), dim3(grid), dim3(NT), 0, st, x, (const e16*)y, (const e16*)dy, w, dx, (float*)ws, H, T, th, tt, n)
     if (dx) { if (vec) CIN_BWD(true, true); else CIN_BWD(true, false); }
     else { if (vec) CIN_BWD(false, true); else CIN_BWD(false, false); }
 #undef CIN_BWD
@@ -618,7 +618,7 @@ int tt_convin16_bwd(const float* x, const void* y, const void* dy, const float* 
 int tt_convout16_fwd(const void* x, const float* w, const float* b, float* y, int B, int H, int T, void* stream) {
     if (!x || !w || !b || !y || !edge_ok(B, H, T)) return TT_E_BADARG;
     int th, tt, n; edge_tiles(B, H, T, th, tt, n);
-    hipLaunchKernelGGL(k_cout_fwd, dim3(edge_grid(n)), dim3(NT), 0, tt_stream(stream), (const __bf16*)x, w, b, y, H, T, th, tt, n);
+    hipLaunchKernelGGL(k_cout_fwd, dim3(edge_grid(n)), dim3(NT), 0, tt_stream(stream), (const e16*)x, w, b, y, H, T, th, tt, n);
     TT_LAUNCH_CHECK();
     return 0;
 }
@@ -629,8 +629,8 @@ int tt_convout16_bwd(const void* x, const float* dy, const float* w, void* dx, f
     int th, tt, n; edge_tiles(B, H, T, th, tt, n);
     const int grid = edge_grid(n);
     hipStream_t st = tt_stream(stream);
-    if (T % 4 == 0) hipLaunchKernelGGL(k_cout_bwd<true>, dim3(grid), dim3(NT), 0, st, (const __bf16*)x, dy, w, (__bf16*)dx, (float*)ws, H, T, th, tt, n);
-    else hipLaunchKernelGGL(k_cout_bwd<false>, dim3(grid), dim3(NT), 0, st, (const __bf16*)x, dy, w, (__bf16*)dx, (float*)ws, H, T, th, tt, n);
+    if (T % 4 == 0) hipLaunchKernelGGL(k_cout_bwd<true>, dim3(grid), dim3(NT), 0, st, (const e16*)x, dy, w, (e16*)dx, (float*)ws, H, T, th, tt, n);
+    else hipLaunchKernelGGL(k_cout_bwd<false>, dim3(grid), dim3(NT), 0, st, (const e16*)x, dy, w, (e16*)dx, (float*)ws, H, T, th, tt, n);
     TT_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_edge_reduce, dim3(2), dim3(1024), 0, st, (const float*)ws, grid, dw, db, 2);
     TT_LAUNCH_CHECK();

@@ -272,32 +272,35 @@ __global__ __launch_bounds__(256) void k_dot(const float* __restrict__ a, const 
     if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
 }
 
-// The same two on bf16 tensors (the skip joins of the bf16 channels-last path: elementwise, so the layout does not matter):
-// eight elements per thread as one 16-byte access, fp32 arithmetic, round-to-nearest-even on the store.
-typedef __bf16 bf16x8_g __attribute__((ext_vector_type(8)));
-__global__ __launch_bounds__(256) void k_scaled_add16(const __bf16* __restrict__ a, const __bf16* __restrict__ b,
-                                                      const float* __restrict__ s, int idx, __bf16* __restrict__ y, long n8, long n) {
+// The same two on 16-bit tensors (the skip joins of the channels-last path: elementwise, so the layout does not matter): E = bf16, or
+// fp16 for the _h entry points; eight elements per thread as one 16-byte access, fp32 arithmetic, round-to-nearest-even on the store.
+template <class E>
+__global__ __launch_bounds__(256) void k_scaled_add16(const E* __restrict__ a, const E* __restrict__ b,
+                                                      const float* __restrict__ s, int idx, E* __restrict__ y, long n8, long n) {
+    typedef E e8 __attribute__((ext_vector_type(8)));
     const float sc = s ? s[idx] : 1.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
-        const bf16x8_g bv = *reinterpret_cast<const bf16x8_g*>(b + 8 * i);
-        bf16x8_g av, o;
-        if (a) av = *reinterpret_cast<const bf16x8_g*>(a + 8 * i);
+        const e8 bv = *reinterpret_cast<const e8*>(b + 8 * i);
+        e8 av, o;
+        if (a) av = *reinterpret_cast<const e8*>(a + 8 * i);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (__bf16)fmaf(sc, (float)bv[j], a ? (float)av[j] : 0.f);
-        *reinterpret_cast<bf16x8_g*>(y + 8 * i) = o;
+        for (int j = 0; j < 8; ++j) o[j] = (E)fmaf(sc, (float)bv[j], a ? (float)av[j] : 0.f);
+        *reinterpret_cast<e8*>(y + 8 * i) = o;
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {              // tail of a length that is not a multiple of 8
         const long i = (n & ~7l) + threadIdx.x;
-        y[i] = (__bf16)fmaf(sc, (float)b[i], a ? (float)a[i] : 0.f);
+        y[i] = (E)fmaf(sc, (float)b[i], a ? (float)a[i] : 0.f);
     }
 }
 
-__global__ __launch_bounds__(256) void k_dot16(const __bf16* __restrict__ a, const __bf16* __restrict__ b, float* __restrict__ out,
+template <class E>
+__global__ __launch_bounds__(256) void k_dot16(const E* __restrict__ a, const E* __restrict__ b, float* __restrict__ out,
                                                long n8, long n) {
+    typedef E e8 __attribute__((ext_vector_type(8)));
     __shared__ float red[4];
     float acc = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
-        const bf16x8_g av = *reinterpret_cast<const bf16x8_g*>(a + 8 * i), bv = *reinterpret_cast<const bf16x8_g*>(b + 8 * i);
+        const e8 av = *reinterpret_cast<const e8*>(a + 8 * i), bv = *reinterpret_cast<const e8*>(b + 8 * i);
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc = fmaf((float)av[j], (float)bv[j], acc);
     }
@@ -605,25 +608,34 @@ extern "C" int tt_scaled_add(const float* a, const float* b, const float* s, int
     return 0;
 }
 
-extern "C" int tt_scaled_add16(const void* a, const void* b, const float* s, int idx, void* y, int64_t n, void* stream) {
+template <class E>
+static int scaled_add16(const void* a, const void* b, const float* s, int idx, void* y, int64_t n, void* stream) {
     if (!b || !y || n < 0) return TT_E_BADARG;
     if ((((uintptr_t)b | (uintptr_t)y | (uintptr_t)a) & 15) != 0) return TT_E_BADARG;        // 16-byte accesses
     if (n == 0) return 0;
-    hipLaunchKernelGGL(k_scaled_add16, dim3(grid1d((n + 7) / 8, 256, 4096)), dim3(256), 0, tt_stream(stream), (const __bf16*)a,
-                       (const __bf16*)b, s, idx, (__bf16*)y, (long)(n / 8), (long)n);
+    hipLaunchKernelGGL(k_scaled_add16<E>, dim3(grid1d((n + 7) / 8, 256, 4096)), dim3(256), 0, tt_stream(stream), (const E*)a,
+                       (const E*)b, s, idx, (E*)y, (long)(n / 8), (long)n);
     TT_LAUNCH_CHECK();
     return 0;
 }
-
-extern "C" int tt_dot16(const void* a, const void* b, float* out, int64_t n, void* stream) {
+template <class E>
+static int dot16(const void* a, const void* b, float* out, int64_t n, void* stream) {
     if (!a || !b || !out || n < 0) return TT_E_BADARG;
     if ((((uintptr_t)a | (uintptr_t)b) & 15) != 0) return TT_E_BADARG;
     if (n == 0) return 0;
-    hipLaunchKernelGGL(k_dot16, dim3(grid1d((n + 7) / 8, 256 * 4, 1024)), dim3(256), 0, tt_stream(stream), (const __bf16*)a,
-                       (const __bf16*)b, out, (long)(n / 8), (long)n);
+    hipLaunchKernelGGL(k_dot16<E>, dim3(grid1d((n + 7) / 8, 256 * 4, 1024)), dim3(256), 0, tt_stream(stream), (const E*)a,
+                       (const E*)b, out, (long)(n / 8), (long)n);
     TT_LAUNCH_CHECK();
     return 0;
 }
+extern "C" int tt_scaled_add16(const void* a, const void* b, const float* s, int idx, void* y, int64_t n, void* stream) {
+    return scaled_add16<__bf16>(a, b, s, idx, y, n, stream);
+}
+extern "C" int tt_dot16(const void* a, const void* b, float* out, int64_t n, void* stream) { return dot16<__bf16>(a, b, out, n, stream); }
+extern "C" int tt_scaled_add16_h(const void* a, const void* b, const float* s, int idx, void* y, int64_t n, void* stream) {
+    return scaled_add16<_Float16>(a, b, s, idx, y, n, stream);
+}
+extern "C" int tt_dot16_h(const void* a, const void* b, float* out, int64_t n, void* stream) { return dot16<_Float16>(a, b, out, n, stream); }
 
 // Windowed overlap-add of half-overlapping chunks (TimbreTrap.chunked_inference, reference modules.py:259-263):
 //   out[b][r][i * M/2 + m] += window[m] * chunks[i - c0][b][r][m]      for the chunks i = c0 .. c1-1 of this call, ascending i

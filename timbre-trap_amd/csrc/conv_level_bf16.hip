@@ -24,33 +24,33 @@
 namespace {
 
 template <int C>
-__global__ __launch_bounds__(64) void k_lvl_wprep(const float* __restrict__ w1, const float* __restrict__ w2, bf16x8* __restrict__ img) {
+__global__ __launch_bounds__(64) void k_lvl_wprep(const float* __restrict__ w1, const float* __restrict__ w2, e16x8* __restrict__ img) {
     using K = WK<C>;
     const int lane = threadIdx.x, n = lane & 15, g = lane >> 4, blk = blockIdx.x;
     if (blk < K::NK * K::NCT) {
         const int k = blk / K::NCT, ct = blk - k * K::NCT;
-        bf16x8 f, b;
+        e16x8 f, b;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             int tap, kc;                                         // tap and contraction channel of this lane's k = 8 g + j
             if (C == 32) { tap = k; kc = 8 * g + j; }
             else { tap = 2 * k + (g >> 1); kc = 8 * (g & 1) + j; }
             const int mo = chan_of<C>(ct, n);
-            f[j] = (__bf16)(tap < 9 ? w1[(mo * C + kc) * 9 + tap] : 0.f);
-            b[j] = (__bf16)(tap < 9 ? w1[(kc * C + mo) * 9 + (8 - tap)] : 0.f);
+            f[j] = (e16)(tap < 9 ? w1[(mo * C + kc) * 9 + tap] : 0.f);
+            b[j] = (e16)(tap < 9 ? w1[(kc * C + mo) * 9 + (8 - tap)] : 0.f);
         }
         img[blk * 64 + lane] = f;
         img[K::W3 + blk * 64 + lane] = b;
     } else {
 #pragma unroll
         for (int ct = 0; ct < K::NCT; ++ct) {
-            bf16x8 a, at;
+            e16x8 a, at;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float va = 0.f, vt = 0.f;
                 if (C == 32) { va = w2[chan_of<C>(ct, n) * C + 8 * g + j]; vt = w2[(8 * g + j) * C + chan_of<C>(ct, n)]; }
                 else if (j < 4) { va = w2[n * C + 4 * g + j]; vt = w2[(4 * g + j) * C + n]; }
-                a[j] = (__bf16)va; at[j] = (__bf16)vt;
+                a[j] = (e16)va; at[j] = (e16)vt;
             }
             img[2 * K::W3 + ct * 64 + lane] = a;
             img[2 * K::W3 + K::NCT * 64 + ct * 64 + lane] = at;
@@ -76,15 +76,15 @@ template <int C, int D, int TH, int TW, int NW> struct FB {
 };
 
 template <int C, int D, int TH, int TW, int NW>
-__global__ __launch_bounds__(NW * 64, C == 32 ? 2 : 3) void k_wrb_bwd_fused(const __bf16* __restrict__ x, const __bf16* __restrict__ dy,
-                                                              const bf16x8* __restrict__ wimg, const float* __restrict__ b1,
-                                                              const float* __restrict__ b2, __bf16* __restrict__ dx,
+__global__ __launch_bounds__(NW * 64, C == 32 ? 2 : 3) void k_wrb_bwd_fused(const e16* __restrict__ x, const e16* __restrict__ dy,
+                                                              const e16x8* __restrict__ wimg, const float* __restrict__ b1,
+                                                              const float* __restrict__ b2, e16* __restrict__ dx,
                                                               float* __restrict__ part_a, float* __restrict__ part_w, int B, int H,
                                                               int T, int tiles_h, int tiles_t, int ntiles) {
     using G = FB<C, D, TH, TW, NW>;
     using K = WK<C>;
     constexpr int NCT = K::NCT, NK = K::NK, NCH = K::NCH, PB = G::PB;
-    typedef typename std::conditional<C == 32, bf16x8, bf16x4>::type vec_t;     // a lane's channels of one pixel
+    typedef typename std::conditional<C == 32, e16x8, e16x4>::type vec_t;     // a lane's channels of one pixel
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char* xs = smem;
     unsigned char* gs = smem + G::X_BYTES;
@@ -117,16 +117,16 @@ __global__ __launch_bounds__(NW * 64, C == 32 ? 2 : 3) void k_wrb_bwd_fused(cons
     for (int j = 0; j < NCH; ++j) { db1a[j] = 0.f; db2a[j] = 0.f; }
     vec_t zero_v;
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) zero_v[j] = (__bf16)0.f;
+    for (int j = 0; j < NCH; ++j) zero_v[j] = (e16)0.f;
 
-    const __bf16* zero = reinterpret_cast<const __bf16*>(&g_wzero16);
+    const e16* zero = reinterpret_cast<const e16*>(&g_wzero16);
     for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
         int tile = xcd_order(v, ntiles);
         const int tt = tile % tiles_t; tile /= tiles_t;
         const int th = tile % tiles_h;
         const int b = tile / tiles_h, h0 = th * TH, t0 = tt * TW;
-        const __bf16* xb = x + (long)b * H * T * C;
-        const __bf16* gb = dy + (long)b * H * T * C;
+        const e16* xb = x + (long)b * H * T * C;
+        const e16* gb = dy + (long)b * H * T * C;
 
         __syncthreads();                                         // the previous tile has been consumed
         for (int i = wave * 64; i < G::XPR; i += G::NTH) {
@@ -148,19 +148,19 @@ __global__ __launch_bounds__(NW * 64, C == 32 ? 2 : 3) void k_wrb_bwd_fused(cons
 
         // The weights of each phase are (re)loaded per tile through laundered pointers so that their registers are free in
         // the other phase (72 VGPRs per orientation at C = 32 beside 72 of weight-gradient accumulators).
-        const bf16x8* wp = wimg;
+        const e16x8* wp = wimg;
         const float* b1p = b1;
         const float* b2p = b2;
         asm volatile("" : "+s"(wp), "+s"(b1p), "+s"(b2p));
 
         // ---- phase 1: h1 recomputed, pointwise chain, dA1 over dy in LDS; db2 / dW2 over the tile's own pixels ----
         {
-            bf16x8 A[NK][NCT];
+            e16x8 A[NK][NCT];
 #pragma unroll
             for (int k = 0; k < NK; ++k)
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct) A[k][ct] = wp[(k * NCT + ct) * 64 + lane];
-            bf16x8 A2[NCT], A2T[NCT];
+            e16x8 A2[NCT], A2T[NCT];
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
                 A2[ct] = wp[2 * K::W3 + ct * 64 + lane];
@@ -181,13 +181,13 @@ __global__ __launch_bounds__(NW * 64, C == 32 ? 2 : 3) void k_wrb_bwd_fused(cons
                 f32x4 acc[NCT];                                  // biases enter as the accumulators' initial values
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{b1r[4 * ct], b1r[4 * ct + 1], b1r[4 * ct + 2], b1r[4 * ct + 3]};
-                bf16x8 unused;
+                e16x8 unused;
                 conv_taps<C, D, G::XW>(xs, row, col, g, A, acc, unused);
                 unsigned char* gp = gs + (row * G::GW + col) * PB + 16 * (opiece ^ fswz<C>(col)) + obyte;
                 const vec_t dq = *reinterpret_cast<const vec_t*>(gp);
                 vec_t hq;
 #pragma unroll
-                for (int j = 0; j < NCH; ++j) hq[j] = (__bf16)elu_f(acc[j >> 2][j & 3]);
+                for (int j = 0; j < NCH; ++j) hq[j] = (e16)elu_f(acc[j >> 2][j & 3]);
                 float hv[NCH], gv[NCH];
                 vec_t gq, aq;
                 f32x4 z[NCT], u[NCT];
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(NW * 64, C == 32 ? 2 : 3) void k_wrb_bwd_fused(cons
                 for (int j = 0; j < NCH; ++j) {
                     const float a2 = z[j >> 2][j & 3];
                     gv[j] = (float)dq[j] * elu_dpre(a2);
-                    gq[j] = (__bf16)gv[j];
+                    gq[j] = (e16)gv[j];
                     hv[j] = (float)hq[j];
                 }
                 if constexpr (C == 32) {
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(NW * 64, C == 32 ? 2 : 3) void k_wrb_bwd_fused(cons
                     u[0] = mma16(A2Ts, __builtin_bit_cast(s16x4, gq), f32x4{0.f, 0.f, 0.f, 0.f});
                 }
 #pragma unroll
-                for (int j = 0; j < NCH; ++j) aq[j] = (__bf16)(u[j >> 2][j & 3] * elu_dout(hv[j]));
+                for (int j = 0; j < NCH; ++j) aq[j] = (e16)(u[j >> 2][j & 3] * elu_dout(hv[j]));
                 if (inq) *reinterpret_cast<vec_t*>(gp) = aq;
                 // sums over the tile's own pixels only (halo pixels belong to the neighbours; out-of-image ones are zero)
                 const vec_t gm = core ? gq : zero_v;
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(NW * 64, C == 32 ? 2 : 3) void k_wrb_bwd_fused(cons
 
         // ---- phase 2a: dx = dy + W1^T (*) dA1 over the tile's own pixels; db1 from the centre tap ----
         {
-            bf16x8 A[NK][NCT];
+            e16x8 A[NK][NCT];
 #pragma unroll
             for (int k = 0; k < NK; ++k)
 #pragma unroll
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(NW * 64, C == 32 ? 2 : 3) void k_wrb_bwd_fused(cons
                 f32x4 acc[NCT];
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-                bf16x8 centre;
+                e16x8 centre;
                 conv_taps<C, D, G::GW>(gs, r, c, g, A, acc, centre);
                 vec_t cen;
                 if constexpr (C == 32) cen = centre;
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(NW * 64, C == 32 ? 2 : 3) void k_wrb_bwd_fused(cons
 #pragma unroll
                 for (int j = 0; j < NCH; ++j) {
                     db1a[j] += (float)cen[j];                    // out-of-image pixels hold zeros
-                    o[j] = (__bf16)(acc[j >> 2][j & 3] + (float)rq[j]);
+                    o[j] = (e16)(acc[j >> 2][j & 3] + (float)rq[j]);
                 }
                 if (valid) *reinterpret_cast<vec_t*>(dx + pix * C + NCH * g) = o;
             }
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(NW * 64, C == 32 ? 2 : 3) void k_wrb_bwd_fused(cons
                                               16 * (((C == 32 ? 2 * aw : 0) + (trq >> 1)) ^ fswz<C>(cc)) + 8 * (trq & 1));
                     if (u == 0) lo = t4; else hi = t4;
                 }
-                const bf16x8 ga = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                const e16x8 ga = __builtin_bit_cast(e16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
                     const int kh = k / 3, kw = k - 3 * kh;
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(NW * 64, C == 32 ? 2 : 3) void k_wrb_bwd_fused(cons
                                                   16 * (((C == 32 ? 2 * cit : 0) + (trq >> 1)) ^ fswz<C>(xc)) + 8 * (trq & 1));
                         if (u == 0) lo = t4; else hi = t4;
                     }
-                    const bf16x8 xq = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                    const e16x8 xq = __builtin_bit_cast(e16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
                     wacc[k] = mma32(ga, xq, wacc[k]);
                 }
             }
@@ -350,12 +350,12 @@ template <int C> constexpr long fused_scratch_bytes() {
 }
 
 template <int C, int D, int TH, int TW>
-int launch_fused(const __bf16* x, const __bf16* dy, const float* w1, const float* b1, const float* w2, const float* b2, __bf16* dx,
+int launch_fused(const e16* x, const e16* dy, const float* w1, const float* b1, const float* w2, const float* b2, e16* dx,
                  float* dw1, float* db1, float* dw2, float* db2, unsigned char* ws, int B, int H, int T, hipStream_t st) {
     constexpr int NW = 4;
     using G = FB<C, D, TH, TW, NW>;
     using K = WK<C>;
-    bf16x8* wimg = reinterpret_cast<bf16x8*>(ws);
+    e16x8* wimg = reinterpret_cast<e16x8*>(ws);
     float* part_a = reinterpret_cast<float*>(ws + K::IMG_BYTES);
     float* part_w = part_a + (long)MAX_W_WG * G::ADUMP;
     hipLaunchKernelGGL(k_lvl_wprep<C>, dim3(K::NK * K::NCT + 1), dim3(64), 0, st, w1, w2, wimg);
@@ -380,7 +380,7 @@ int launch_fused(const __bf16* x, const __bf16* dy, const float* w1, const float
 // Tile shapes (TTRAP_FBWD_TILE = 0 / 1 selects the alternative set, for tuning):
 //   LDS per workgroup = x image (TH + 4D)(TW + 4D) + dy/dA1 image (TH + 2D)(TW + 2D) pixels of 2C bytes + transposition buffers.
 template <int C>
-int fused_c(const __bf16* x, const __bf16* dy, const float* w1, const float* b1, const float* w2, const float* b2, __bf16* dx,
+int fused_c(const e16* x, const e16* dy, const float* w1, const float* b1, const float* w2, const float* b2, e16* dx,
             float* dw1, float* db1, float* dw2, float* db2, unsigned char* ws, int B, int H, int T, int D, hipStream_t st) {
     static const int alt = env_int("TTRAP_FBWD_TILE", 0);
 #define TT_FB(DD, TH_, TW_) return launch_fused<C, DD, TH_, TW_>(x, dy, w1, b1, w2, b2, dx, dw1, db1, dw2, db2, ws, B, H, T, st)
@@ -434,14 +434,14 @@ template <int C, int D, int TH, int TW> struct OP {
 };
 
 template <int C, int D, int TH, int TW, int MINW>
-__global__ __launch_bounds__(NT, MINW) void k_wrb_bwd1(const __bf16* __restrict__ x, const __bf16* __restrict__ h1, const __bf16* __restrict__ dy,
-                                                     const bf16x8* __restrict__ wimg, const float* __restrict__ b2, __bf16* __restrict__ dx,
+__global__ __launch_bounds__(NT, MINW) void k_wrb_bwd1(const e16* __restrict__ x, const e16* __restrict__ h1, const e16* __restrict__ dy,
+                                                     const e16x8* __restrict__ wimg, const float* __restrict__ b2, e16* __restrict__ dx,
                                                      float* __restrict__ part_a, float* __restrict__ part_w, int B, int H, int T,
                                                      int tiles_h, int tiles_t, int ntiles) {
     using G = OP<C, D, TH, TW>;
     using K = WK<C>;
     constexpr int NCT = K::NCT, NK = K::NK, NCH = K::NCH, PB = G::PB;
-    typedef typename std::conditional<C == 32, bf16x8, bf16x4>::type vec_t;     // a lane's channels of one pixel
+    typedef typename std::conditional<C == 32, e16x8, e16x4>::type vec_t;     // a lane's channels of one pixel
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char* gs = smem;                                    // dA1, tile + D halo
     unsigned char* xs = smem + G::G_BYTES;                       // x, tile only
@@ -470,17 +470,17 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_bwd1(const __bf16* __restrict_
     for (int j = 0; j < NCH; ++j) { db1a[j] = 0.f; db2a[j] = 0.f; }
     vec_t zero_v;
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) zero_v[j] = (__bf16)0.f;
+    for (int j = 0; j < NCH; ++j) zero_v[j] = (e16)0.f;
 
-    const __bf16* zero = reinterpret_cast<const __bf16*>(&g_wzero16);
+    const e16* zero = reinterpret_cast<const e16*>(&g_wzero16);
     for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
         int tile = xcd_order(v, ntiles);
         const int tt = tile % tiles_t; tile /= tiles_t;
         const int th = tile % tiles_h;
         const int b = tile / tiles_h, h0 = th * TH, t0 = tt * TW;
         const long ib = (long)b * H * T * C;
-        const __bf16* hb_ = h1 + ib + NCH * g;                  // this lane's channels
-        const __bf16* gb_ = dy + ib + NCH * g;
+        const e16* hb_ = h1 + ib + NCH * g;                  // this lane's channels
+        const e16* gb_ = dy + ib + NCH * g;
 
         // image pixel of group `grp`, lane n: LDS byte offset of the lane's channels, in-image / tile-core flags, HBM element offset
         auto locate = [&](int grp, int& loff, bool& inq, bool& core, int& goff) {
@@ -511,13 +511,13 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_bwd1(const __bf16* __restrict_
 
         // the weights of each phase are (re)loaded per tile through laundered pointers so that their registers are free in the
         // other phase (72 VGPRs of data-gradient weights at C = 32 beside 36 + 16 + 16 of accumulators)
-        const bf16x8* wp = wimg;
+        const e16x8* wp = wimg;
         const float* b2p = b2;
         asm volatile("" : "+s"(wp), "+s"(b2p));
 
         // ---- phase 1: pointwise chain on tile + halo, dA1 into LDS; db1 / db2 / dW2 over the tile's own pixels ----
         {
-            bf16x8 A2[NCT], A2T[NCT];
+            e16x8 A2[NCT], A2T[NCT];
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
                 A2[ct] = wp[2 * K::W3 + ct * 64 + lane];
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_bwd1(const __bf16* __restrict_
                 for (int j = 0; j < NCH; ++j) {
                     const float a2 = z[j >> 2][j & 3];
                     gv[j] = (float)dq[j] * elu_dpre(a2);
-                    gq[j] = (__bf16)gv[j];
+                    gq[j] = (e16)gv[j];
                     hv[j] = (float)hq[j];
                 }
                 if constexpr (C == 32) {
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_bwd1(const __bf16* __restrict_
 #pragma unroll
                 for (int j = 0; j < NCH; ++j) {
                     a1g[j] = u[j >> 2][j & 3] * elu_dout(hv[j]);
-                    aq[j] = (__bf16)a1g[j];
+                    aq[j] = (e16)a1g[j];
                     db2a[j] += cm * gv[j]; db1a[j] += cm * a1g[j];
                 }
                 if (inq) *reinterpret_cast<vec_t*>(gs + loff) = aq;
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_bwd1(const __bf16* __restrict_
 
         // ---- phase 2a: dx = dy + W1^T (*) dA1 over the tile's own pixels ----
         {
-            bf16x8 A[NK][NCT];
+            e16x8 A[NK][NCT];
 #pragma unroll
             for (int k = 0; k < NK; ++k)
 #pragma unroll
@@ -621,11 +621,11 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_bwd1(const __bf16* __restrict_
                 f32x4 acc[NCT];
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-                bf16x8 unused;
+                e16x8 unused;
                 conv_taps<C, D, G::GW>(gs, r, c, g, A, acc, unused);
                 vec_t o;
 #pragma unroll
-                for (int j = 0; j < NCH; ++j) o[j] = (__bf16)(acc[j >> 2][j & 3] + (float)rq[j]);
+                for (int j = 0; j < NCH; ++j) o[j] = (e16)(acc[j >> 2][j & 3] + (float)rq[j]);
                 if (valid) *reinterpret_cast<vec_t*>(dx + pix * C + NCH * g) = o;
             }
         }
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_bwd1(const __bf16* __restrict_
                     const s16x4 t4 = lds_tr16(xs + (r * TW + xc) * PB + 16 * (((C == 32 ? 2 * cit : 0) + (trq >> 1)) ^ fswz<C>(xc)) + 8 * (trq & 1));
                     if (u == 0) lo = t4; else hi = t4;
                 }
-                const bf16x8 xq = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                const e16x8 xq = __builtin_bit_cast(e16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
                     const int kh = k / 3, kw = k - 3 * kh;
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_bwd1(const __bf16* __restrict_
                                                   16 * (((C == 32 ? 2 * aw : 0) + (trq >> 1)) ^ fswz<C>(cc)) + 8 * (trq & 1));
                         if (u == 0) lo = t4; else hi = t4;
                     }
-                    const bf16x8 ga = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                    const e16x8 ga = __builtin_bit_cast(e16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
                     wacc[k] = mma32(ga, xq, wacc[k]);
                 }
             }
@@ -689,11 +689,11 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_bwd1(const __bf16* __restrict_
 }
 
 template <int C, int D, int TH, int TW>
-int launch_bwd1(const __bf16* x, const __bf16* h1, const __bf16* dy, const float* w1, const float* w2, const float* b2, __bf16* dx,
+int launch_bwd1(const e16* x, const e16* h1, const e16* dy, const float* w1, const float* w2, const float* b2, e16* dx,
                 float* dw1, float* db1, float* dw2, float* db2, unsigned char* ws, int B, int H, int T, hipStream_t st) {
     using G = OP<C, D, TH, TW>;
     using K = WK<C>;
-    bf16x8* wimg = reinterpret_cast<bf16x8*>(ws);
+    e16x8* wimg = reinterpret_cast<e16x8*>(ws);
     float* part_a = reinterpret_cast<float*>(ws + K::IMG_BYTES);
     float* part_w = part_a + (long)MAX_W_WG * G::ADUMP;
     hipLaunchKernelGGL(k_lvl_wprep<C>, dim3(K::NK * K::NCT + 1), dim3(64), 0, st, w1, w2, wimg);
@@ -717,7 +717,7 @@ int launch_bwd1(const __bf16* x, const __bf16* h1, const __bf16* dy, const float
 }
 
 template <int C>
-int bwd1_c(const __bf16* x, const __bf16* h1, const __bf16* dy, const float* w1, const float* w2, const float* b2, __bf16* dx,
+int bwd1_c(const e16* x, const e16* h1, const e16* dy, const float* w1, const float* w2, const float* b2, e16* dx,
            float* dw1, float* db1, float* dw2, float* db2, unsigned char* ws, int B, int H, int T, int D, hipStream_t st) {
     static const int alt = env_int("TTRAP_BWD1_TILE", 0);
 #define TT_B1(DD, TH_, TW_) return launch_bwd1<C, DD, TH_, TW_>(x, h1, dy, w1, w2, b2, dx, dw1, db1, dw2, db2, ws, B, H, T, st)
@@ -769,7 +769,7 @@ template <int C, int D, int TH, int TW> struct OS {
 // 3x3 dilated product on one 16-pixel group out of the ring: `ro[kh]` = byte offset of the image row of tap row kh
 template <int C, int D, int IW>
 __device__ __forceinline__ void conv_taps_ring(const unsigned char* img, const int (&ro)[3], int col, int g,
-                                               const bf16x8 (&A)[WK<C>::NK][WK<C>::NCT], f32x4 (&acc)[WK<C>::NCT]) {
+                                               const e16x8 (&A)[WK<C>::NK][WK<C>::NCT], f32x4 (&acc)[WK<C>::NCT]) {
     constexpr int NK = WK<C>::NK, NCT = WK<C>::NCT, PB = C * 2;
     const int gsel = C == 32 ? g : (g & 1);
 #pragma unroll
@@ -779,21 +779,21 @@ __device__ __forceinline__ void conv_taps_ring(const unsigned char* img, const i
         const int kh = tap / 3, kw = tap - 3 * kh;
         const int xc = col + kw * D;
         const int rb = C == 32 ? ro[k / 3] : (kh == 0 ? ro[0] : (kh == 1 ? ro[1] : ro[2]));
-        const bf16x8 bq = *reinterpret_cast<const bf16x8*>(img + rb + xc * PB + 16 * (gsel ^ fswz<C>(xc)));
+        const e16x8 bq = *reinterpret_cast<const e16x8*>(img + rb + xc * PB + 16 * (gsel ^ fswz<C>(xc)));
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) acc[ct] = mma32(A[k][ct], bq, acc[ct]);
     }
 }
 
 template <int C, int D, int TH, int TW, int MINW>
-__global__ __launch_bounds__(NT, MINW) void k_wrb_bwds(const __bf16* __restrict__ x, const __bf16* __restrict__ h1, const __bf16* __restrict__ dy,
-                                                     const bf16x8* __restrict__ wimg, const float* __restrict__ b2, __bf16* __restrict__ dx,
+__global__ __launch_bounds__(NT, MINW) void k_wrb_bwds(const e16* __restrict__ x, const e16* __restrict__ h1, const e16* __restrict__ dy,
+                                                     const e16x8* __restrict__ wimg, const float* __restrict__ b2, e16* __restrict__ dx,
                                                      float* __restrict__ part_a, float* __restrict__ part_w, int B, int H, int T,
                                                      int tiles_t, int nstrips) {
     using G = OS<C, D, TH, TW>;
     using K = WK<C>;
     constexpr int NCT = K::NCT, NK = K::NK, NCH = K::NCH, PB = G::PB, GW = G::GW, RING = G::RING;
-    typedef typename std::conditional<C == 32, bf16x8, bf16x4>::type vec_t;     // a lane's channels of one pixel
+    typedef typename std::conditional<C == 32, e16x8, e16x4>::type vec_t;     // a lane's channels of one pixel
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char* ring = smem;                                  // dy, then dA1: RING image rows of GW pixels
     unsigned char* hst = smem + G::RING_BYTES;                   // h1 of the step's new rows, then the step's x rows
@@ -821,9 +821,9 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_bwds(const __bf16* __restrict_
     for (int j = 0; j < NCH; ++j) { db1a[j] = 0.f; db2a[j] = 0.f; }
     vec_t zero_v;
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) zero_v[j] = (__bf16)0.f;
+    for (int j = 0; j < NCH; ++j) zero_v[j] = (e16)0.f;
 
-    const __bf16* zero = reinterpret_cast<const __bf16*>(&g_wzero16);
+    const e16* zero = reinterpret_cast<const e16*>(&g_wzero16);
     const int nsteps = (H + TH - 1) / TH + 1;
     // ring slot of image row R (R >= -RING): (R + RING) mod RING, on the scalar unit where R is wave-uniform
     auto slot = [&](int R) -> int { return (R + RING) % RING; };
@@ -853,13 +853,13 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_bwds(const __bf16* __restrict_
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
 
-            const bf16x8* wp = wimg;
+            const e16x8* wp = wimg;
             const float* b2p = b2;
             asm volatile("" : "+s"(wp), "+s"(b2p));
 
             // ---- b. pointwise chain on the new rows, dA1 over dy in the ring; db1 / db2 / dW2 over the strip's own columns ----
             if (N0 < H) {                                        // rows below the image: dy = 0 staged, dA1 = 0 already
-                bf16x8 A2[NCT], A2T[NCT];
+                e16x8 A2[NCT], A2T[NCT];
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct) {
                     A2[ct] = wp[2 * K::W3 + ct * 64 + lane];
@@ -896,7 +896,7 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_bwds(const __bf16* __restrict_
                     for (int jj = 0; jj < NCH; ++jj) {
                         const float a2 = z[jj >> 2][jj & 3];
                         gv[jj] = (float)dq[jj] * elu_dpre(a2);
-                        gq[jj] = (__bf16)gv[jj];
+                        gq[jj] = (e16)gv[jj];
                         hv[jj] = (float)hq[jj];
                     }
                     if constexpr (C == 32) {
@@ -909,7 +909,7 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_bwds(const __bf16* __restrict_
 #pragma unroll
                     for (int jj = 0; jj < NCH; ++jj) {
                         a1g[jj] = u[jj >> 2][jj & 3] * elu_dout(hv[jj]);
-                        aq[jj] = (__bf16)a1g[jj];
+                        aq[jj] = (e16)a1g[jj];
                         db2a[jj] += cm * gv[jj]; db1a[jj] += cm * a1g[jj];
                     }
                     if (inq) *reinterpret_cast<vec_t*>(gp) = aq;
@@ -953,7 +953,7 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_bwds(const __bf16* __restrict_
 
             // ---- d. dx = dy + W1^T (*) dA1 over the step's rows ----
             {
-                bf16x8 A[NK][NCT];
+                e16x8 A[NK][NCT];
 #pragma unroll
                 for (int k = 0; k < NK; ++k)
 #pragma unroll
@@ -975,7 +975,7 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_bwds(const __bf16* __restrict_
                     conv_taps_ring<C, D, GW>(ring, ro, c, g, A, acc);
                     vec_t o;
 #pragma unroll
-                    for (int jj = 0; jj < NCH; ++jj) o[jj] = (__bf16)(acc[jj >> 2][jj & 3] + (float)rq[jj]);
+                    for (int jj = 0; jj < NCH; ++jj) o[jj] = (e16)(acc[jj >> 2][jj & 3] + (float)rq[jj]);
                     if (valid) *reinterpret_cast<vec_t*>(dx + pix * C + NCH * g) = o;
                 }
             }
@@ -996,7 +996,7 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_bwds(const __bf16* __restrict_
                         const s16x4 t4 = lds_tr16(hst + (r * TW + xc) * PB + 16 * (((C == 32 ? 2 * cit : 0) + (trq >> 1)) ^ fswz<C>(xc)) + 8 * (trq & 1));
                         if (u == 0) lo = t4; else hi = t4;
                     }
-                    const bf16x8 xq = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                    const e16x8 xq = __builtin_bit_cast(e16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
                     for (int k = 0; k < 9; ++k) {
                         const int kh = k / 3, kw = k - 3 * kh;
@@ -1007,7 +1007,7 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_bwds(const __bf16* __restrict_
                                                       16 * (((C == 32 ? 2 * aw : 0) + (trq >> 1)) ^ fswz<C>(cc)) + 8 * (trq & 1));
                             if (u == 0) lo = t4; else hi = t4;
                         }
-                        const bf16x8 ga = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                        const e16x8 ga = __builtin_bit_cast(e16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
                         wacc[k] = mma32(ga, xq, wacc[k]);
                     }
                 }
@@ -1043,17 +1043,17 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_bwds(const __bf16* __restrict_
 }
 
 template <int C, int D, int TH, int TW>
-int launch_bwds(const __bf16* x, const __bf16* h1, const __bf16* dy, const float* w1, const float* w2, const float* b2, __bf16* dx,
+int launch_bwds(const e16* x, const e16* h1, const e16* dy, const float* w1, const float* w2, const float* b2, e16* dx,
                 float* dw1, float* db1, float* dw2, float* db2, unsigned char* ws, int B, int H, int T, hipStream_t st) {
     using G = OS<C, D, TH, TW>;
     using K = WK<C>;
-    bf16x8* wimg = reinterpret_cast<bf16x8*>(ws);
+    e16x8* wimg = reinterpret_cast<e16x8*>(ws);
     float* part_a = reinterpret_cast<float*>(ws + K::IMG_BYTES);
     float* part_w = part_a + (long)MAX_W_WG * G::ADUMP;
     hipLaunchKernelGGL(k_lvl_wprep<C>, dim3(K::NK * K::NCT + 1), dim3(64), 0, st, w1, w2, wimg);
     TT_LAUNCH_CHECK();
     static AttrOnce once;
-    constexpr int MINW = C == 32 ? 2 : 3;
+    constexpr int MINW = C == 32 ? 2 : 4;          // registers: 192 (C = 32), 124 (C = 16)
     auto kern = k_wrb_bwds<C, D, TH, TW, MINW>;
     if (int rc = raise_lds(kern, G::LDS_BYTES, once)) return rc;
     const int tiles_t = (T + TW - 1) / TW, nstrips = B * tiles_t;
@@ -1070,7 +1070,7 @@ int launch_bwds(const __bf16* x, const __bf16* h1, const __bf16* dy, const float
 }
 
 template <int C>
-int bwds_c(const __bf16* x, const __bf16* h1, const __bf16* dy, const float* w1, const float* w2, const float* b2, __bf16* dx,
+int bwds_c(const e16* x, const e16* h1, const e16* dy, const float* w1, const float* w2, const float* b2, e16* dx,
            float* dw1, float* db1, float* dw2, float* db2, unsigned char* ws, int B, int H, int T, int D, hipStream_t st) {
     static const int alt = env_int("TTRAP_BWDS_TILE", 0);
 #define TT_BS(DD, TH_, TW_) return launch_bwds<C, DD, TH_, TW_>(x, h1, dy, w1, w2, b2, dx, dw1, db1, dw2, db2, ws, B, H, T, st)
@@ -1101,10 +1101,10 @@ int tt_wide_rb_bwd_fused(const void* x, const void* dy, const float* w1, const f
     if (!x || !dy || !w1 || !b1 || !w2 || !b2 || !dx || !dw1 || !db1 || !dw2 || !db2 || !ws) return TT_E_BADARG;
     if (C != 16 && C != 32) return TT_E_UNSUPPORTED;
     if (!fshape_ok(B, C, H, T)) return TT_E_BADARG;
-    const __bf16 *xi = (const __bf16*)x, *gi = (const __bf16*)dy;
+    const e16 *xi = (const e16*)x, *gi = (const e16*)dy;
     hipStream_t st = tt_stream(stream);
-    if (C == 16) return fused_c<16>(xi, gi, w1, b1, w2, b2, (__bf16*)dx, dw1, db1, dw2, db2, (unsigned char*)ws, B, H, T, dilation, st);
-    return fused_c<32>(xi, gi, w1, b1, w2, b2, (__bf16*)dx, dw1, db1, dw2, db2, (unsigned char*)ws, B, H, T, dilation, st);
+    if (C == 16) return fused_c<16>(xi, gi, w1, b1, w2, b2, (e16*)dx, dw1, db1, dw2, db2, (unsigned char*)ws, B, H, T, dilation, st);
+    return fused_c<32>(xi, gi, w1, b1, w2, b2, (e16*)dx, dw1, db1, dw2, db2, (unsigned char*)ws, B, H, T, dilation, st);
 }
 
 int64_t tt_wide_onepass_scratch_bytes(int C) { return tt_wide_fused_scratch_bytes(C); }
@@ -1115,15 +1115,15 @@ int tt_wide_rb_bwd_onepass(const void* x, const void* h1, const void* dy, const 
     if (!x || !h1 || !dy || !w1 || !w2 || !b2 || !dx || !dw1 || !db1 || !dw2 || !db2 || !ws) return TT_E_BADARG;
     if (C != 16 && C != 32) return TT_E_UNSUPPORTED;
     if (!fshape_ok(B, C, H, T)) return TT_E_BADARG;
-    const __bf16 *xi = (const __bf16*)x, *hi = (const __bf16*)h1, *gi = (const __bf16*)dy;
+    const e16 *xi = (const e16*)x, *hi = (const e16*)h1, *gi = (const e16*)dy;
     hipStream_t st = tt_stream(stream);
     static const int tile_form = env_int("TTRAP_BWD1_FORM", 0);        // 1: the tile form k_wrb_bwd1 (halo all round), kept for A/B
     if (tile_form) {
-        if (C == 16) return bwd1_c<16>(xi, hi, gi, w1, w2, b2, (__bf16*)dx, dw1, db1, dw2, db2, (unsigned char*)ws, B, H, T, dilation, st);
-        return bwd1_c<32>(xi, hi, gi, w1, w2, b2, (__bf16*)dx, dw1, db1, dw2, db2, (unsigned char*)ws, B, H, T, dilation, st);
+        if (C == 16) return bwd1_c<16>(xi, hi, gi, w1, w2, b2, (e16*)dx, dw1, db1, dw2, db2, (unsigned char*)ws, B, H, T, dilation, st);
+        return bwd1_c<32>(xi, hi, gi, w1, w2, b2, (e16*)dx, dw1, db1, dw2, db2, (unsigned char*)ws, B, H, T, dilation, st);
     }
-    if (C == 16) return bwds_c<16>(xi, hi, gi, w1, w2, b2, (__bf16*)dx, dw1, db1, dw2, db2, (unsigned char*)ws, B, H, T, dilation, st);
-    return bwds_c<32>(xi, hi, gi, w1, w2, b2, (__bf16*)dx, dw1, db1, dw2, db2, (unsigned char*)ws, B, H, T, dilation, st);
+    if (C == 16) return bwds_c<16>(xi, hi, gi, w1, w2, b2, (e16*)dx, dw1, db1, dw2, db2, (unsigned char*)ws, B, H, T, dilation, st);
+    return bwds_c<32>(xi, hi, gi, w1, w2, b2, (e16*)dx, dw1, db1, dw2, db2, (unsigned char*)ws, B, H, T, dilation, st);
 }
 
 }  // extern "C"

@@ -44,20 +44,20 @@ template <int C> struct S4 {
     __device__ static int c0(int g) { return C == 32 ? 8 * g : (C == 16 ? 8 * (g & 1) : 0); }
 };
 
-template <int CE> struct VecE { typedef typename std::conditional<CE == 8, bf16x8, bf16x4>::type type; };
+template <int CE> struct VecE { typedef typename std::conditional<CE == 8, e16x8, e16x4>::type type; };
 
 template <int CE>
-__device__ __forceinline__ typename VecE<CE>::type load_gated(const __bf16* in, const __bf16* gy, long off, bool ok, bool gate) {
+__device__ __forceinline__ typename VecE<CE>::type load_gated(const e16* in, const e16* gy, long off, bool ok, bool gate) {
     typedef typename VecE<CE>::type vec_t;
     vec_t v;
 #pragma unroll
-    for (int j = 0; j < CE; ++j) v[j] = (__bf16)0.f;
+    for (int j = 0; j < CE; ++j) v[j] = (e16)0.f;
     if (ok) {
         v = *reinterpret_cast<const vec_t*>(in + off);
         if (gate) {
             const vec_t yv = *reinterpret_cast<const vec_t*>(gy + off);
 #pragma unroll
-            for (int j = 0; j < CE; ++j) v[j] = (__bf16)gate_f((float)v[j], (float)yv[j]);
+            for (int j = 0; j < CE; ++j) v[j] = (e16)gate_f((float)v[j], (float)yv[j]);
         }
     }
     return v;
@@ -69,21 +69,21 @@ template <int CE> __device__ __forceinline__ f32x4 mma_e(typename VecE<CE>::type
 }
 
 template <int COUT, int NCH>
-__device__ __forceinline__ void store_lane(__bf16* out, long pix, int g, const float (&v)[NCH], bool ok) {
+__device__ __forceinline__ void store_lane(e16* out, long pix, int g, const float (&v)[NCH], bool ok) {
     if (!ok || NCH * g >= COUT) return;
-    __bf16* d = out + pix * COUT + NCH * g;
+    e16* d = out + pix * COUT + NCH * g;
     if constexpr (NCH == 4) {
-        bf16x4 o;
+        e16x4 o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (__bf16)v[j];
-        *reinterpret_cast<bf16x4*>(d) = o;
+        for (int j = 0; j < 4; ++j) o[j] = (e16)v[j];
+        *reinterpret_cast<e16x4*>(d) = o;
     } else {
 #pragma unroll
         for (int q = 0; q < NCH / 8; ++q) {
-            bf16x8 o;
+            e16x8 o;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (__bf16)v[8 * q + j];
-            *reinterpret_cast<bf16x8*>(d + 8 * q) = o;
+            for (int j = 0; j < 8; ++j) o[j] = (e16)v[8 * q + j];
+            *reinterpret_cast<e16x8*>(d + 8 * q) = o;
         }
     }
 }
@@ -93,9 +93,9 @@ __device__ __forceinline__ void store_lane(__bf16* out, long pix, int g, const f
 // set it is 160-208 and the waves cover each other instead (round 3, library A/B: tconv C = 32 forward 0.145 -> 0.120 ms, backward
 // 0.520 -> 0.487 ms, sconv backward 0.456 -> 0.426 ms).
 template <int C, bool GATE, bool ACT>
-__global__ __launch_bounds__(NT) void k_s4(const __bf16* __restrict__ in, const __bf16* __restrict__ gy,
+__global__ __launch_bounds__(NT) void k_s4(const e16* __restrict__ in, const e16* __restrict__ gy,
                                             const float* __restrict__ w, const float* __restrict__ bias,
-                                            __bf16* __restrict__ out, int B, int Hin, int Hout, int T, int tb, long ngroups) {
+                                            e16* __restrict__ out, int B, int Hin, int Hout, int T, int tb, long ngroups) {
     using S = S4<C>;
     constexpr int COUT = 2 * C, NCT = OutT<COUT>::NCT, NCH = OutT<COUT>::NCH;
     typedef typename VecE<S::CE>::type vec_t;
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(NT) void k_s4(const __bf16* __restrict__ in, const 
         for (int ct = 0; ct < NCT; ++ct) {
             const int co = och<COUT>(ct, n), kh = S::kh(j, g), c0 = S::c0(g);
 #pragma unroll
-            for (int e = 0; e < S::CE; ++e) A[j][ct][e] = (__bf16)(co < COUT ? w[(co * C + c0 + e) * 4 + kh] : 0.f);
+            for (int e = 0; e < S::CE; ++e) A[j][ct][e] = (e16)(co < COUT ? w[(co * C + c0 + e) * 4 + kh] : 0.f);
         }
     float br[NCH];
 #pragma unroll
@@ -183,9 +183,9 @@ template <int C> struct P2 {
 };
 
 template <int C, bool GATE, bool ACT>
-__global__ __launch_bounds__(NT) void k_p2(const __bf16* __restrict__ in, const __bf16* __restrict__ gy,
+__global__ __launch_bounds__(NT) void k_p2(const e16* __restrict__ in, const e16* __restrict__ gy,
                                             const float* __restrict__ w, const float* __restrict__ bias,
-                                            __bf16* __restrict__ out, int B, int Hin, int Hout, int T, int tb, long ngroups) {
+                                            e16* __restrict__ out, int B, int Hin, int Hout, int T, int tb, long ngroups) {
     using S = P2<C>;
     constexpr int CIN = 2 * C, NCT = OutT<C>::NCT, NCH = OutT<C>::NCH;
     typedef typename VecE<S::CE>::type vec_t;
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(NT) void k_p2(const __bf16* __restrict__ in, const 
             for (int ct = 0; ct < NCT; ++ct) {
                 const int co = och<C>(ct, n), kh = par + 2 * S::rs(j, g), c0 = S::c0(j, g);
 #pragma unroll
-                for (int e = 0; e < S::CE; ++e) A[par][j][ct][e] = (__bf16)(co < C ? w[((c0 + e) * C + co) * 4 + kh] : 0.f);
+                for (int e = 0; e < S::CE; ++e) A[par][j][ct][e] = (e16)(co < C ? w[((c0 + e) * C + co) * 4 + kh] : 0.f);
             }
     float br[NCH];
 #pragma unroll
@@ -262,47 +262,46 @@ __global__ __launch_bounds__(NT) void k_p2(const __bf16* __restrict__ in, const 
 // ---- C = 4, 8: a lane is a pixel (v_mfma_f32_4x4x4_16b_bf16, see conv_wide_bf16.hip) -------------------------------------
 // With 4 / 8 channels a 16-row tile is mostly padding and three quarters of the lanes would idle in the epilogue; here every
 // lane loads its own pixel's rows (8 / 16 bytes), owns all output channels of its pixel and stores 16 / 8 bytes.
-__device__ __forceinline__ f32x4 mma4(s16x4 a, s16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ s16x4 lo4(bf16x8 v) { return __builtin_bit_cast(s16x4, __builtin_shufflevector(v, v, 0, 1, 2, 3)); }
-__device__ __forceinline__ s16x4 hi4(bf16x8 v) { return __builtin_bit_cast(s16x4, __builtin_shufflevector(v, v, 4, 5, 6, 7)); }
+__device__ __forceinline__ s16x4 lo4(e16x8 v) { return __builtin_bit_cast(s16x4, __builtin_shufflevector(v, v, 0, 1, 2, 3)); }
+__device__ __forceinline__ s16x4 hi4(e16x8 v) { return __builtin_bit_cast(s16x4, __builtin_shufflevector(v, v, 4, 5, 6, 7)); }
 
 // all N channels of one pixel as N / 4 four-channel operands of the 4x4x4 product, optionally gated by the saved output
 template <int N, bool GATE>
-__device__ __forceinline__ void load_px(const __bf16* in, const __bf16* gy, long off, bool ok, s16x4 (&c)[N / 4]) {
+__device__ __forceinline__ void load_px(const e16* in, const e16* gy, long off, bool ok, s16x4 (&c)[N / 4]) {
     if constexpr (N == 4) {
         c[0] = __builtin_bit_cast(s16x4, load_gated<4>(in, gy, off, ok, GATE));
     } else {
 #pragma unroll
         for (int q = 0; q < N / 8; ++q) {
-            const bf16x8 v = load_gated<8>(in, gy, off + 8 * q, ok, GATE);
+            const e16x8 v = load_gated<8>(in, gy, off + 8 * q, ok, GATE);
             c[2 * q] = lo4(v); c[2 * q + 1] = hi4(v);
         }
     }
 }
 template <int N, bool ACT>
-__device__ __forceinline__ void store_px(__bf16* out, long off, const f32x4 (&acc)[N / 4], const float (&br)[N], bool ok) {
+__device__ __forceinline__ void store_px(e16* out, long off, const f32x4 (&acc)[N / 4], const float (&br)[N], bool ok) {
     if (!ok) return;
     if constexpr (N == 4) {
-        bf16x4 o;
+        e16x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const float a = acc[0][e] + br[e]; o[e] = (__bf16)(ACT ? elu_f(a) : a); }
-        *reinterpret_cast<bf16x4*>(out + off) = o;
+        for (int e = 0; e < 4; ++e) { const float a = acc[0][e] + br[e]; o[e] = (e16)(ACT ? elu_f(a) : a); }
+        *reinterpret_cast<e16x4*>(out + off) = o;
     } else {
 #pragma unroll
         for (int q = 0; q < N / 8; ++q) {
-            bf16x8 o;
+            e16x8 o;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { const float a = acc[2 * q + (e >> 2)][e & 3] + br[8 * q + e]; o[e] = (__bf16)(ACT ? elu_f(a) : a); }
-            *reinterpret_cast<bf16x8*>(out + off + 8 * q) = o;
+            for (int e = 0; e < 8; ++e) { const float a = acc[2 * q + (e >> 2)][e & 3] + br[8 * q + e]; o[e] = (e16)(ACT ? elu_f(a) : a); }
+            *reinterpret_cast<e16x8*>(out + off + 8 * q) = o;
         }
     }
 }
 
 // "gather four rows", C -> 2C (C = 4, 8); one group = 64 frames of the output-row pair 2m, 2m + 1: six input rows for two outputs
 template <int C, bool GATE, bool ACT>
-__global__ __launch_bounds__(NT) void k_s4n(const __bf16* __restrict__ in, const __bf16* __restrict__ gy,
+__global__ __launch_bounds__(NT) void k_s4n(const e16* __restrict__ in, const e16* __restrict__ gy,
                                              const float* __restrict__ w, const float* __restrict__ bias,
-                                             __bf16* __restrict__ out, int B, int Hin, int Hout, int T, int tb, long ngroups) {
+                                             e16* __restrict__ out, int B, int Hin, int Hout, int T, int tb, long ngroups) {
     constexpr int NBI = C / 4, NBO = C / 2, CO = 2 * C;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i4 = lane & 3;
     s16x4 A[4][NBO][NBI];                                        // [kh][output block][input block]
@@ -312,9 +311,9 @@ __global__ __launch_bounds__(NT) void k_s4n(const __bf16* __restrict__ in, const
         for (int ob = 0; ob < NBO; ++ob)
 #pragma unroll
             for (int kb = 0; kb < NBI; ++kb) {
-                bf16x4 t;
+                e16x4 t;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) t[k] = (__bf16)w[((4 * ob + i4) * C + 4 * kb + k) * 4 + kh];
+                for (int k = 0; k < 4; ++k) t[k] = (e16)w[((4 * ob + i4) * C + 4 * kb + k) * 4 + kh];
                 A[kh][ob][kb] = __builtin_bit_cast(s16x4, t);
             }
     float br[CO];
@@ -370,9 +369,9 @@ __global__ __launch_bounds__(NT) void k_s4n(const __bf16* __restrict__ in, const
 
 // "two rows by parity", 2C -> C (C = 4, 8); one group = 64 frames of the output-row pair 2m, 2m + 1 from input rows m, m - 1
 template <int C, bool GATE, bool ACT>
-__global__ __launch_bounds__(NT) void k_p2n(const __bf16* __restrict__ in, const __bf16* __restrict__ gy,
+__global__ __launch_bounds__(NT) void k_p2n(const e16* __restrict__ in, const e16* __restrict__ gy,
                                              const float* __restrict__ w, const float* __restrict__ bias,
-                                             __bf16* __restrict__ out, int B, int Hin, int Hout, int T, int tb, long ngroups) {
+                                             e16* __restrict__ out, int B, int Hin, int Hout, int T, int tb, long ngroups) {
     constexpr int CI = 2 * C, NBI = CI / 4, NBO = C / 4;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i4 = lane & 3;
     s16x4 A[2][2][NBO][NBI];                                     // [parity][row select][output block][input block]
@@ -384,9 +383,9 @@ __global__ __launch_bounds__(NT) void k_p2n(const __bf16* __restrict__ in, const
             for (int ob = 0; ob < NBO; ++ob)
 #pragma unroll
                 for (int kb = 0; kb < NBI; ++kb) {
-                    bf16x4 t;
+                    e16x4 t;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) t[k] = (__bf16)w[((4 * kb + k) * C + 4 * ob + i4) * 4 + par + 2 * rs];
+                    for (int k = 0; k < 4; ++k) t[k] = (e16)w[((4 * kb + k) * C + 4 * ob + i4) * 4 + par + 2 * rs];
                     A[par][rs][ob][kb] = __builtin_bit_cast(s16x4, t);
                 }
     float br[C];
@@ -468,12 +467,12 @@ template <int PB> __device__ __forceinline__ int tr_off(int p, int tile, int trq
 }
 
 template <int PB, int ROWS, bool GATED, int BATCH = 64>
-__device__ __forceinline__ void stage_tile(unsigned char* lds, const __bf16* src, const __bf16* ysrc, int row_h0, int Hs,
+__device__ __forceinline__ void stage_tile(unsigned char* lds, const e16* src, const e16* ysrc, int row_h0, int Hs,
                                            int t0, int T, int tid, float (&dbacc)[8], int db_rows, int db_row0 = 0) {
     // image [ROWS][TW][PB bytes]; piece = 16 bytes; GATED: through registers with dy * ELU'(y), else LDS-DMA
     constexpr int TWp = 64, PPP = PB >= 16 ? 1 : 16 / PB, CGn = PB >= 16 ? PB / 16 : 1;
     constexpr int NPC = ROWS * TWp * PB / 16, NIT = (NPC + NT - 1) / NT;
-    const __bf16* zero = reinterpret_cast<const __bf16*>(&g_wzero16);
+    const e16* zero = reinterpret_cast<const e16*>(&g_wzero16);
     const int lane = tid & 63, wave = tid >> 6;
     if constexpr (!GATED) {
 #pragma unroll
@@ -494,7 +493,7 @@ __device__ __forceinline__ void stage_tile(unsigned char* lds, const __bf16* src
         constexpr int NB_ = BATCH < NIT ? BATCH : NIT;
 #pragma unroll
         for (int it0 = 0; it0 < NIT; it0 += NB_) {
-            bf16x8 v[NB_], yv[NB_];
+            e16x8 v[NB_], yv[NB_];
 #pragma unroll
             for (int u = 0; u < NB_; ++u) {
                 const int it = it0 + u;
@@ -506,8 +505,8 @@ __device__ __forceinline__ void stage_tile(unsigned char* lds, const __bf16* src
                 const bool ok = it < NIT && p < NPC && (unsigned)h < (unsigned)Hs && t < T;
                 // clamped unconditional loads (no branch in front of the later requests); masked when used
                 const long o2 = ok ? ((long)h * T + t) * (PB / 2) + cg * 8 : 0;
-                v[u] = *reinterpret_cast<const bf16x8*>(src + o2);
-                yv[u] = *reinterpret_cast<const bf16x8*>(ysrc + o2);
+                v[u] = *reinterpret_cast<const e16x8*>(src + o2);
+                yv[u] = *reinterpret_cast<const e16x8*>(ysrc + o2);
             }
 #pragma unroll
             for (int u = 0; u < NB_; ++u) {
@@ -516,14 +515,14 @@ __device__ __forceinline__ void stage_tile(unsigned char* lds, const __bf16* src
                 const int q = (p / CGn) * PPP;
                 const int row = q / TWp, px = q - row * TWp;
                 const bool ok = it < NIT && p < NPC && (unsigned)(row_h0 + row) < (unsigned)Hs && t0 + px < T;
-                bf16x8 o;
+                e16x8 o;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float gq = ok ? gate_f((float)v[u][j], (float)yv[u][j]) : 0.f;
                     if (row >= db_row0 && row < db_rows) dbacc[j] += gq;    // rows shared with a neighbouring tile are counted once
-                    o[j] = (__bf16)gq;
+                    o[j] = (e16)gq;
                 }
-                if (it < NIT && p < NPC) *reinterpret_cast<bf16x8*>(lds + (long)p * 16) = o;
+                if (it < NIT && p < NPC) *reinterpret_cast<e16x8*>(lds + (long)p * 16) = o;
             }
         }
     }
@@ -544,9 +543,9 @@ template <int PB> __device__ __forceinline__ const unsigned char* px_piece(const
 }
 
 template <int C, bool GS, bool DX>
-__global__ __launch_bounds__(NT, C == 32 ? ((!DX && GS) ? 3 : 2) : W4_WAVES16) void k_w4(const __bf16* __restrict__ small, const __bf16* __restrict__ big,
-                                            const __bf16* __restrict__ ygate, float* __restrict__ part, float* __restrict__ dbpart,
-                                            const float* __restrict__ w, __bf16* __restrict__ dx,
+__global__ __launch_bounds__(NT, C == 32 ? ((!DX && GS) ? 3 : 2) : W4_WAVES16) void k_w4(const e16* __restrict__ small, const e16* __restrict__ big,
+                                            const e16* __restrict__ ygate, float* __restrict__ part, float* __restrict__ dbpart,
+                                            const float* __restrict__ w, e16* __restrict__ dx,
                                             int B, int Hs, int Hb, int T, int tiles_h, int tiles_t, int ntiles) {
     using G = W4<C>;
     constexpr int SROW0 = (DX && GS) ? 1 : 0;                    // image row of the tile's first small row
@@ -579,7 +578,7 @@ __global__ __launch_bounds__(NT, C == 32 ? ((!DX && GS) ? 3 : 2) : W4_WAVES16) v
             for (int ct = 0; ct < NCTS; ++ct) {
                 const int co = och<2 * C>(ct, n), kh = S::kh(j, g), c0 = S::c0(g);
 #pragma unroll
-                for (int e = 0; e < S::CE; ++e) AS[j][ct][e] = (__bf16)(co < 2 * C ? w[(co * C + c0 + e) * 4 + kh] : 0.f);
+                for (int e = 0; e < S::CE; ++e) AS[j][ct][e] = (e16)(co < 2 * C ? w[(co * C + c0 + e) * 4 + kh] : 0.f);
             }
     }
     if constexpr (DX && GS) {
@@ -591,7 +590,7 @@ __global__ __launch_bounds__(NT, C == 32 ? ((!DX && GS) ? 3 : 2) : W4_WAVES16) v
                 for (int ct = 0; ct < NCTP; ++ct) {
                     const int co = och<C>(ct, n), kh = par + 2 * P::rs(j, g), c0 = P::c0(j, g);
 #pragma unroll
-                    for (int e = 0; e < P::CE; ++e) AP[par][j][ct][e] = (__bf16)(co < C ? w[((c0 + e) * C + co) * 4 + kh] : 0.f);
+                    for (int e = 0; e < P::CE; ++e) AP[par][j][ct][e] = (e16)(co < C ? w[((c0 + e) * C + co) * 4 + kh] : 0.f);
                 }
     }
 
@@ -600,8 +599,8 @@ __global__ __launch_bounds__(NT, C == 32 ? ((!DX && GS) ? 3 : 2) : W4_WAVES16) v
         const int tt = tile % tiles_t; tile /= tiles_t;
         const int th = tile % tiles_h;
         const int b = tile / tiles_h, r0 = th * G::TR, t0 = tt * G::TW;
-        const __bf16* sb = small + (long)b * Hs * T * (2 * C);
-        const __bf16* bb = big + (long)b * Hb * T * C;
+        const e16* sb = small + (long)b * Hs * T * (2 * C);
+        const e16* bb = big + (long)b * Hb * T * C;
         __syncthreads();
         if constexpr (GS) {
             stage_tile<G::BB, G::BROWS, false>(bs, bb, nullptr, 2 * r0, Hb, t0, T, tid, dbacc, 0);
@@ -653,7 +652,7 @@ __global__ __launch_bounds__(NT, C == 32 ? ((!DX && GS) ? 3 : 2) : W4_WAVES16) v
                     const int q = (hi - r0 + SROW0) * G::TW + col;
                     dvec_t z;
 #pragma unroll
-                    for (int e = 0; e < P::CE; ++e) z[e] = (__bf16)0.f;
+                    for (int e = 0; e < P::CE; ++e) z[e] = (e16)0.f;
                     bq[j] = (hi >= 0 && hi < Hs) ? *reinterpret_cast<const dvec_t*>(px_piece<G::SB>(ss, q, P::c0(j, g))) : z;
                 }
 #pragma unroll
@@ -683,7 +682,7 @@ __global__ __launch_bounds__(NT, C == 32 ? ((!DX && GS) ? 3 : 2) : W4_WAVES16) v
 #pragma unroll
             for (int chh = 0; chh < (SPLIT ? 2 : 1); ++chh) {
                 const int colh = SPLIT ? chh : (wave & 1);
-                bf16x8 sa[NAW];
+                e16x8 sa[NAW];
 #pragma unroll
                 for (int a = 0; a < NAW; ++a) {
                     s16x4 h2[2];
@@ -692,7 +691,7 @@ __global__ __launch_bounds__(NT, C == 32 ? ((!DX && GS) ? 3 : 2) : W4_WAVES16) v
                         const int p = (r + SROW0) * G::TW + colh * 32 + 16 * u + 4 * g + trj;
                         h2[u] = lds_tr16(ss + (long)p * G::SB + tr_off<G::SB>(p, SPLIT ? wave : a, trq));
                     }
-                    sa[a] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(h2[0], h2[1], 0, 1, 2, 3, 4, 5, 6, 7));
+                    sa[a] = __builtin_bit_cast(e16x8, __builtin_shufflevector(h2[0], h2[1], 0, 1, 2, 3, 4, 5, 6, 7));
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
@@ -704,7 +703,7 @@ __global__ __launch_bounds__(NT, C == 32 ? ((!DX && GS) ? 3 : 2) : W4_WAVES16) v
                             const int p = (2 * r + k) * G::TW + colh * 32 + 16 * u + 4 * g + trj;
                             h2[u] = lds_tr16(bs + (long)p * G::BB + tr_off<G::BB>(p, c, trq));
                         }
-                        const bf16x8 bq = __builtin_bit_cast(bf16x8, __builtin_shufflevector(h2[0], h2[1], 0, 1, 2, 3, 4, 5, 6, 7));
+                        const e16x8 bq = __builtin_bit_cast(e16x8, __builtin_shufflevector(h2[0], h2[1], 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
                         for (int a = 0; a < NAW; ++a) acc[k][a][c] = mma32(sa[a], bq, acc[k][a][c]);
                     }
@@ -802,7 +801,7 @@ inline int flat_grid(long ngroups) {
 }
 
 template <int C, bool GATE, bool ACT>
-int launch_s4(const __bf16* in, const __bf16* gy, const float* w, const float* bias, __bf16* out, int B, int Hin, int Hout, int T,
+int launch_s4(const e16* in, const e16* gy, const float* w, const float* bias, e16* out, int B, int Hin, int Hout, int T,
               hipStream_t st) {
     if constexpr (C == 4 || (C == 8 && !GATE)) {              // gated C = 8 (tconv data gradient): the 16-row tile form is faster (0.21 vs 0.26 ms)
         const int tb = (T + 63) / 64;
@@ -820,7 +819,7 @@ int launch_s4(const __bf16* in, const __bf16* gy, const float* w, const float* b
     return 0;
 }
 template <int C, bool GATE, bool ACT>
-int launch_p2(const __bf16* in, const __bf16* gy, const float* w, const float* bias, __bf16* out, int B, int Hin, int Hout, int T,
+int launch_p2(const e16* in, const e16* gy, const float* w, const float* bias, e16* out, int B, int Hin, int Hout, int T,
               hipStream_t st) {
     if constexpr (C <= 8) {
         const int tb = (T + 63) / 64;
@@ -844,7 +843,7 @@ template <int C> inline bool w4x_enabled() {
 }
 
 template <int C, bool GS, bool DX>
-int launch_w4(const __bf16* small, const __bf16* big, const __bf16* ygate, float* dw, float* db, float* ws, const float* w, __bf16* dx,
+int launch_w4(const e16* small, const e16* big, const e16* ygate, float* dw, float* db, float* ws, const float* w, e16* dx,
               int B, int Hs, int Hb, int T, hipStream_t st) {
     using G = W4<C>;
     constexpr int LDS = ((DX && GS) ? G::SX_BYTES : G::S_BYTES) + G::B_BYTES;
@@ -897,7 +896,7 @@ int tt_sconv16_fwd(const void* x, const float* w, const float* b, void* y, int B
     if (!x || !w || !b || !y || !ok_shape(B, C, H, T)) return TT_E_BADARG;
     const int Ho = (H - 4) / 2 + 1;
     hipStream_t st = tt_stream(stream);
-    TT_BY_C(C, (launch_s4<CC, false, true>((const __bf16*)x, nullptr, w, b, (__bf16*)y, B, H, Ho, T, st)));
+    TT_BY_C(C, (launch_s4<CC, false, true>((const e16*)x, nullptr, w, b, (e16*)y, B, H, Ho, T, st)));
 }
 
 int tt_sconv16_bwd(const void* x, const void* y, const void* dy, const float* w, void* dx, float* dw, float* db, void* ws, int B,
@@ -907,22 +906,22 @@ int tt_sconv16_bwd(const void* x, const void* y, const void* dy, const float* w,
     hipStream_t st = tt_stream(stream);
     if (dx && C <= 16 && w4x_enabled<32>()) {                     // one pass: weight, bias and data gradient
         switch (C) {      // C = 32: the gated-small form spills with the data-gradient weights aboard (0.512 vs 0.400 ms in two kernels) -- not merged
-            case 4: return launch_w4<4, true, true>((const __bf16*)dy, (const __bf16*)x, (const __bf16*)y, dw, db, (float*)ws, w, (__bf16*)dx, B, Ho, H, T, st);
-            case 8: return launch_w4<8, true, true>((const __bf16*)dy, (const __bf16*)x, (const __bf16*)y, dw, db, (float*)ws, w, (__bf16*)dx, B, Ho, H, T, st);
-            case 16: return launch_w4<16, true, true>((const __bf16*)dy, (const __bf16*)x, (const __bf16*)y, dw, db, (float*)ws, w, (__bf16*)dx, B, Ho, H, T, st);
+            case 4: return launch_w4<4, true, true>((const e16*)dy, (const e16*)x, (const e16*)y, dw, db, (float*)ws, w, (e16*)dx, B, Ho, H, T, st);
+            case 8: return launch_w4<8, true, true>((const e16*)dy, (const e16*)x, (const e16*)y, dw, db, (float*)ws, w, (e16*)dx, B, Ho, H, T, st);
+            case 16: return launch_w4<16, true, true>((const e16*)dy, (const e16*)x, (const e16*)y, dw, db, (float*)ws, w, (e16*)dx, B, Ho, H, T, st);
         }
     }
     if (dx) {
         int rc = TT_E_UNSUPPORTED;
         switch (C) {
-            case 4: rc = launch_p2<4, true, false>((const __bf16*)dy, (const __bf16*)y, w, nullptr, (__bf16*)dx, B, Ho, H, T, st); break;
-            case 8: rc = launch_p2<8, true, false>((const __bf16*)dy, (const __bf16*)y, w, nullptr, (__bf16*)dx, B, Ho, H, T, st); break;
-            case 16: rc = launch_p2<16, true, false>((const __bf16*)dy, (const __bf16*)y, w, nullptr, (__bf16*)dx, B, Ho, H, T, st); break;
-            case 32: rc = launch_p2<32, true, false>((const __bf16*)dy, (const __bf16*)y, w, nullptr, (__bf16*)dx, B, Ho, H, T, st); break;
+            case 4: rc = launch_p2<4, true, false>((const e16*)dy, (const e16*)y, w, nullptr, (e16*)dx, B, Ho, H, T, st); break;
+            case 8: rc = launch_p2<8, true, false>((const e16*)dy, (const e16*)y, w, nullptr, (e16*)dx, B, Ho, H, T, st); break;
+            case 16: rc = launch_p2<16, true, false>((const e16*)dy, (const e16*)y, w, nullptr, (e16*)dx, B, Ho, H, T, st); break;
+            case 32: rc = launch_p2<32, true, false>((const e16*)dy, (const e16*)y, w, nullptr, (e16*)dx, B, Ho, H, T, st); break;
         }
         if (rc) return rc;
     }
-    TT_BY_C(C, (launch_w4<CC, true, false>((const __bf16*)dy, (const __bf16*)x, (const __bf16*)y, dw, db, (float*)ws, nullptr, nullptr, B, Ho, H, T, st)));
+    TT_BY_C(C, (launch_w4<CC, true, false>((const e16*)dy, (const e16*)x, (const e16*)y, dw, db, (float*)ws, nullptr, nullptr, B, Ho, H, T, st)));
 }
 
 int tt_tconv16_fwd(const void* x, const float* w, const float* b, void* y, int B, int C, int H, int T, int out_pad, void* stream) {
@@ -930,7 +929,7 @@ int tt_tconv16_fwd(const void* x, const float* w, const float* b, void* y, int B
     const int Ho = 2 * H + 2 + out_pad;
     if (!ok_shape(B, C, Ho, T)) return TT_E_BADARG;
     hipStream_t st = tt_stream(stream);
-    TT_BY_C(C, (launch_p2<CC, false, true>((const __bf16*)x, nullptr, w, b, (__bf16*)y, B, H, Ho, T, st)));
+    TT_BY_C(C, (launch_p2<CC, false, true>((const e16*)x, nullptr, w, b, (e16*)y, B, H, Ho, T, st)));
 }
 
 int tt_tconv16_bwd(const void* x, const void* y, const void* dy, const float* w, void* dx, float* dw, float* db, void* ws, int B,
@@ -941,23 +940,23 @@ int tt_tconv16_bwd(const void* x, const void* y, const void* dy, const float* w,
     hipStream_t st = tt_stream(stream);
     if (dx && w4x_enabled<32>()) {
         switch (C) {
-            case 32: return launch_w4<32, false, true>((const __bf16*)x, (const __bf16*)dy, (const __bf16*)y, dw, db, (float*)ws, w, (__bf16*)dx, B, H, Ho, T, st);
-            case 4: return launch_w4<4, false, true>((const __bf16*)x, (const __bf16*)dy, (const __bf16*)y, dw, db, (float*)ws, w, (__bf16*)dx, B, H, Ho, T, st);
-            case 8: return launch_w4<8, false, true>((const __bf16*)x, (const __bf16*)dy, (const __bf16*)y, dw, db, (float*)ws, w, (__bf16*)dx, B, H, Ho, T, st);
-            case 16: return launch_w4<16, false, true>((const __bf16*)x, (const __bf16*)dy, (const __bf16*)y, dw, db, (float*)ws, w, (__bf16*)dx, B, H, Ho, T, st);
+            case 32: return launch_w4<32, false, true>((const e16*)x, (const e16*)dy, (const e16*)y, dw, db, (float*)ws, w, (e16*)dx, B, H, Ho, T, st);
+            case 4: return launch_w4<4, false, true>((const e16*)x, (const e16*)dy, (const e16*)y, dw, db, (float*)ws, w, (e16*)dx, B, H, Ho, T, st);
+            case 8: return launch_w4<8, false, true>((const e16*)x, (const e16*)dy, (const e16*)y, dw, db, (float*)ws, w, (e16*)dx, B, H, Ho, T, st);
+            case 16: return launch_w4<16, false, true>((const e16*)x, (const e16*)dy, (const e16*)y, dw, db, (float*)ws, w, (e16*)dx, B, H, Ho, T, st);
         }
     }
     if (dx) {
         int rc = TT_E_UNSUPPORTED;
         switch (C) {
-            case 4: rc = launch_s4<4, true, false>((const __bf16*)dy, (const __bf16*)y, w, nullptr, (__bf16*)dx, B, Ho, H, T, st); break;
-            case 8: rc = launch_s4<8, true, false>((const __bf16*)dy, (const __bf16*)y, w, nullptr, (__bf16*)dx, B, Ho, H, T, st); break;
-            case 16: rc = launch_s4<16, true, false>((const __bf16*)dy, (const __bf16*)y, w, nullptr, (__bf16*)dx, B, Ho, H, T, st); break;
-            case 32: rc = launch_s4<32, true, false>((const __bf16*)dy, (const __bf16*)y, w, nullptr, (__bf16*)dx, B, Ho, H, T, st); break;
+            case 4: rc = launch_s4<4, true, false>((const e16*)dy, (const e16*)y, w, nullptr, (e16*)dx, B, Ho, H, T, st); break;
+            case 8: rc = launch_s4<8, true, false>((const e16*)dy, (const e16*)y, w, nullptr, (e16*)dx, B, Ho, H, T, st); break;
+            case 16: rc = launch_s4<16, true, false>((const e16*)dy, (const e16*)y, w, nullptr, (e16*)dx, B, Ho, H, T, st); break;
+            case 32: rc = launch_s4<32, true, false>((const e16*)dy, (const e16*)y, w, nullptr, (e16*)dx, B, Ho, H, T, st); break;
         }
         if (rc) return rc;
     }
-    TT_BY_C(C, (launch_w4<CC, false, false>((const __bf16*)x, (const __bf16*)dy, (const __bf16*)y, dw, db, (float*)ws, nullptr, nullptr, B, H, Ho, T, st)));
+    TT_BY_C(C, (launch_w4<CC, false, false>((const e16*)x, (const e16*)dy, (const e16*)y, dw, db, (float*)ws, nullptr, nullptr, B, H, Ho, T, st)));
 }
 
 }  // extern "C"

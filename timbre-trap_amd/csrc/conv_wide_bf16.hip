@@ -30,7 +30,7 @@ namespace {
 // One thread per 16-byte piece: eight channels of one pixel (C >= 8) or two whole pixels (C = 4; T even keeps a pair inside
 // one image row).
 template <int C>
-__global__ __launch_bounds__(NT) void k_wide_pack(const float* __restrict__ x, __bf16* __restrict__ out, int H, int T, long npix) {
+__global__ __launch_bounds__(NT) void k_wide_pack(const float* __restrict__ x, e16* __restrict__ out, int H, int T, long npix) {
     constexpr int CPP = C >= 8 ? 8 : C, PPP = 8 / CPP, CG = C / CPP;         // channels / pixels per piece, pieces per pixel
     const long i = (long)blockIdx.x * NT + threadIdx.x;
     const long pix = (i / CG) * PPP;
@@ -39,15 +39,15 @@ __global__ __launch_bounds__(NT) void k_wide_pack(const float* __restrict__ x, _
     const long plane = (long)H * T;
     const long b = pix / plane, o = pix - b * plane;
     const float* s = x + (b * C + cg * CPP) * plane + o;
-    bf16x8 q;
+    e16x8 q;
 #pragma unroll
     for (int p = 0; p < PPP; ++p)
 #pragma unroll
-        for (int j = 0; j < CPP; ++j) q[p * CPP + j] = (__bf16)s[j * plane + p];
-    *reinterpret_cast<bf16x8*>(out + pix * C + cg * CPP) = q;
+        for (int j = 0; j < CPP; ++j) q[p * CPP + j] = (e16)s[j * plane + p];
+    *reinterpret_cast<e16x8*>(out + pix * C + cg * CPP) = q;
 }
 template <int C>
-__global__ __launch_bounds__(NT) void k_wide_unpack(const __bf16* __restrict__ in, float* __restrict__ y, int H, int T, long npix) {
+__global__ __launch_bounds__(NT) void k_wide_unpack(const e16* __restrict__ in, float* __restrict__ y, int H, int T, long npix) {
     constexpr int CPP = C >= 8 ? 8 : C, PPP = 8 / CPP, CG = C / CPP;
     const long i = (long)blockIdx.x * NT + threadIdx.x;
     const long pix = (i / CG) * PPP;
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(NT) void k_wide_unpack(const __bf16* __restrict__ i
     const int cg = (int)(i % CG);
     const long plane = (long)H * T;
     const long b = pix / plane, o = pix - b * plane;
-    const bf16x8 q = *reinterpret_cast<const bf16x8*>(in + pix * C + cg * CPP);
+    const e16x8 q = *reinterpret_cast<const e16x8*>(in + pix * C + cg * CPP);
     float* d = y + (b * C + cg * CPP) * plane + o;
 #pragma unroll
     for (int p = 0; p < PPP; ++p)
@@ -88,10 +88,10 @@ template <int C, int D> struct WT {
 // MINW = waves per SIMD the register allocation must allow: at C = 32 the forward holds 72 + 8 VGPRs of weights and lands
 // at 172-176 registers -- two workgroups per CU -- unless capped at 168 (MINW = 3: four registers spill to scratch).
 template <int C, int D, int MODE, bool SAVE, int MINW>
-__global__ __launch_bounds__(NT, MINW) void k_wrb_conv(const __bf16* __restrict__ x, const float* __restrict__ w1,
+__global__ __launch_bounds__(NT, MINW) void k_wrb_conv(const e16* __restrict__ x, const float* __restrict__ w1,
                                                  const float* __restrict__ b1, const float* __restrict__ w2,
-                                                 const float* __restrict__ b2, const __bf16* __restrict__ res,
-                                                 __bf16* __restrict__ y, __bf16* __restrict__ h1, int B, int H, int T,
+                                                 const float* __restrict__ b2, const e16* __restrict__ res,
+                                                 e16* __restrict__ y, e16* __restrict__ h1, int B, int H, int T,
                                                  int tiles_h, int tiles_t, int ntiles) {
     using G = WT<C, D>;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_conv(const __bf16* __restrict_
     constexpr int NCH = C == 32 ? 8 : 4;                         // channels a lane ends up with
 
     // ---- weights to registers, rounded to bf16 ----
-    bf16x8 A[NK][NCT];
+    e16x8 A[NK][NCT];
 #pragma unroll
     for (int k = 0; k < NK; ++k)
 #pragma unroll
@@ -119,9 +119,9 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_conv(const __bf16* __restrict_
                 v[j] = wv;
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) A[k][ct][j] = (__bf16)v[j];
+            for (int j = 0; j < 8; ++j) A[k][ct][j] = (e16)v[j];
         }
-    bf16x8 A2[NCT];                                              // C = 32: W2 rows (K = 32)
+    e16x8 A2[NCT];                                              // C = 32: W2 rows (K = 32)
     s16x4 A2s;                                                   // C = 16: W2 rows (K = 16)
     float b1r[NCH], b2r[NCH];
     if constexpr (MODE == 0) {
@@ -129,24 +129,24 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_conv(const __bf16* __restrict_
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) A2[ct][j] = (__bf16)w2[chan_of<C>(ct, n) * C + 8 * g + j];
+                for (int j = 0; j < 8; ++j) A2[ct][j] = (e16)w2[chan_of<C>(ct, n) * C + 8 * g + j];
         } else {
-            bf16x4 t;
+            e16x4 t;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) t[j] = (__bf16)w2[n * C + 4 * g + j];
+            for (int j = 0; j < 4; ++j) t[j] = (e16)w2[n * C + 4 * g + j];
             A2s = __builtin_bit_cast(s16x4, t);
         }
 #pragma unroll
         for (int j = 0; j < NCH; ++j) { b1r[j] = b1[NCH * g + j]; b2r[j] = b2[NCH * g + j]; }
     }
 
-    const __bf16* zero = reinterpret_cast<const __bf16*>(&g_wzero16);
+    const e16* zero = reinterpret_cast<const e16*>(&g_wzero16);
     for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
         int tile = xcd_order(v, ntiles);
         const int tt = tile % tiles_t; tile /= tiles_t;
         const int th = tile % tiles_h;
         const int b = tile / tiles_h, h0 = th * G::TH, t0 = tt * G::TW;
-        const __bf16* xb = x + (long)b * H * T * C;
+        const e16* xb = x + (long)b * H * T * C;
 
         __syncthreads();                                         // the previous tile has been consumed
         for (int i = wave * 64; i < G::NPR; i += NT) {
@@ -173,10 +173,10 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_conv(const __bf16* __restrict_
                 if constexpr (MODE == 0) acc[ct] = f32x4{b1r[4 * ct], b1r[4 * ct + 1], b1r[4 * ct + 2], b1r[4 * ct + 3]};
                 else acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            typename std::conditional<C == 32, bf16x8, bf16x4>::type rq;      // MODE 1: dy of this pixel, requested early
+            typename std::conditional<C == 32, e16x8, e16x4>::type rq;      // MODE 1: dy of this pixel, requested early
             if constexpr (MODE == 1)            // unconditional (clamped) so that no branch pins a wait in front of the products
                 rq = *reinterpret_cast<const decltype(rq)*>(res + (valid ? pix : pix - (t - (T - 1))) * C + NCH * g);
-            bf16x8 centre;
+            e16x8 centre;
 #pragma unroll
             for (int k = 0; k < NK; ++k) {
                 int tap = C == 32 ? k : 2 * k + (g >> 1);
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_conv(const __bf16* __restrict_
                 const int kh = tap / 3, kw = tap - 3 * kh;
                 const int col = c0 + n + kw * D, pxi = (r + kh * D) * G::RW + col;
                 const int cho = 8 * ((C == 32 ? g : (g & 1)) ^ cswz<C>(col));
-                const bf16x8 bq = *reinterpret_cast<const bf16x8*>(smem + ((long)pxi * C + cho) * 2);
+                const e16x8 bq = *reinterpret_cast<const e16x8*>(smem + ((long)pxi * C + cho) * 2);
                 if (C == 32 && k == 4) centre = bq;
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct) acc[ct] = mma32(A[k][ct], bq, acc[ct]);
@@ -200,46 +200,46 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_conv(const __bf16* __restrict_
             if constexpr (MODE == 1) {
                 if (valid) {
                     if constexpr (C == 32) {
-                        bf16x8 o;
+                        e16x8 o;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) o[j] = (__bf16)(val[j] + (float)rq[j]);
-                        *reinterpret_cast<bf16x8*>(y + pix * C + 8 * g) = o;
+                        for (int j = 0; j < 8; ++j) o[j] = (e16)(val[j] + (float)rq[j]);
+                        *reinterpret_cast<e16x8*>(y + pix * C + 8 * g) = o;
                     } else {
-                        bf16x4 o;
+                        e16x4 o;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) o[j] = (__bf16)(val[j] + (float)rq[j]);
-                        *reinterpret_cast<bf16x4*>(y + pix * C + 4 * g) = o;
+                        for (int j = 0; j < 4; ++j) o[j] = (e16)(val[j] + (float)rq[j]);
+                        *reinterpret_cast<e16x4*>(y + pix * C + 4 * g) = o;
                     }
                 }
             } else {
 #pragma unroll
                 for (int j = 0; j < NCH; ++j) val[j] = elu_f(val[j]);
                 if constexpr (C == 32) {
-                    bf16x8 hq;
+                    e16x8 hq;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) hq[j] = (__bf16)val[j];
-                    if (SAVE && valid) *reinterpret_cast<bf16x8*>(h1 + pix * C + 8 * g) = hq;
+                    for (int j = 0; j < 8; ++j) hq[j] = (e16)val[j];
+                    if (SAVE && valid) *reinterpret_cast<e16x8*>(h1 + pix * C + 8 * g) = hq;
                     f32x4 z0 = mma32(A2[0], hq, f32x4{b2r[0], b2r[1], b2r[2], b2r[3]});
                     f32x4 z1 = mma32(A2[1], hq, f32x4{b2r[4], b2r[5], b2r[6], b2r[7]});
-                    bf16x8 o;
+                    e16x8 o;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        o[j] = (__bf16)(elu_f(z0[j]) + (float)centre[j]);
-                        o[4 + j] = (__bf16)(elu_f(z1[j]) + (float)centre[4 + j]);
+                        o[j] = (e16)(elu_f(z0[j]) + (float)centre[j]);
+                        o[4 + j] = (e16)(elu_f(z1[j]) + (float)centre[4 + j]);
                     }
-                    if (valid) *reinterpret_cast<bf16x8*>(y + pix * C + 8 * g) = o;
+                    if (valid) *reinterpret_cast<e16x8*>(y + pix * C + 8 * g) = o;
                 } else {
-                    bf16x4 hq;
+                    e16x4 hq;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) hq[j] = (__bf16)val[j];
-                    if (SAVE && valid) *reinterpret_cast<bf16x4*>(h1 + pix * C + 4 * g) = hq;
+                    for (int j = 0; j < 4; ++j) hq[j] = (e16)val[j];
+                    if (SAVE && valid) *reinterpret_cast<e16x4*>(h1 + pix * C + 4 * g) = hq;
                     const f32x4 z = mma16(A2s, __builtin_bit_cast(s16x4, hq), f32x4{b2r[0], b2r[1], b2r[2], b2r[3]});
                     const int colc = c0 + n + D, pxc = (r + D) * G::RW + colc;
-                    const bf16x4 xc = *reinterpret_cast<const bf16x4*>(smem + ((long)pxc * C + 8 * ((g >> 1) ^ cswz<C>(colc)) + 4 * (g & 1)) * 2);
-                    bf16x4 o;
+                    const e16x4 xc = *reinterpret_cast<const e16x4*>(smem + ((long)pxc * C + 8 * ((g >> 1) ^ cswz<C>(colc)) + 4 * (g & 1)) * 2);
+                    e16x4 o;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (__bf16)(elu_f(z[j]) + (float)xc[j]);
-                    if (valid) *reinterpret_cast<bf16x4*>(y + pix * C + 4 * g) = o;
+                    for (int j = 0; j < 4; ++j) o[j] = (e16)(elu_f(z[j]) + (float)xc[j]);
+                    if (valid) *reinterpret_cast<e16x4*>(y + pix * C + 4 * g) = o;
                 }
             }
         }
@@ -259,32 +259,32 @@ template <int C> struct WA {
 };
 
 template <int C>
-__global__ __launch_bounds__(NT) void k_wrb_bwd_a(const __bf16* __restrict__ h1, const __bf16* __restrict__ dy,
+__global__ __launch_bounds__(NT) void k_wrb_bwd_a(const e16* __restrict__ h1, const e16* __restrict__ dy,
                                                   const float* __restrict__ w2, const float* __restrict__ b2,
-                                                  __bf16* __restrict__ da1, float* __restrict__ part, long npix, long ngroups) {
+                                                  e16* __restrict__ da1, float* __restrict__ part, long npix, long ngroups) {
     using G = WA<C>;
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
     constexpr int NCT = C / 16;
     constexpr int NCH = C == 32 ? 8 : 4;
-    typedef typename std::conditional<C == 32, bf16x8, bf16x4>::type vec_t;     // a lane's channels of one pixel
+    typedef typename std::conditional<C == 32, e16x8, e16x4>::type vec_t;     // a lane's channels of one pixel
 
     // W2 (rows = output channel) and W2^T (rows = input channel), both with the row order of chan_of
-    bf16x8 A2[NCT], A2T[NCT];
+    e16x8 A2[NCT], A2T[NCT];
     s16x4 A2s, A2Ts;
     if constexpr (C == 32) {
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                A2[ct][j] = (__bf16)w2[chan_of<C>(ct, n) * C + 8 * g + j];
-                A2T[ct][j] = (__bf16)w2[(8 * g + j) * C + chan_of<C>(ct, n)];
+                A2[ct][j] = (e16)w2[chan_of<C>(ct, n) * C + 8 * g + j];
+                A2T[ct][j] = (e16)w2[(8 * g + j) * C + chan_of<C>(ct, n)];
             }
     } else {
-        bf16x4 a, at;
+        e16x4 a, at;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { a[j] = (__bf16)w2[n * C + 4 * g + j]; at[j] = (__bf16)w2[(4 * g + j) * C + n]; }
+        for (int j = 0; j < 4; ++j) { a[j] = (e16)w2[n * C + 4 * g + j]; at[j] = (e16)w2[(4 * g + j) * C + n]; }
         A2s = __builtin_bit_cast(s16x4, a); A2Ts = __builtin_bit_cast(s16x4, at);
     }
     float b2r[NCH], db1a[NCH], db2a[NCH];
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(NT) void k_wrb_bwd_a(const __bf16* __restrict__ h1,
 
     vec_t zero_v;
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) zero_v[j] = (__bf16)0.f;
+    for (int j = 0; j < NCH; ++j) zero_v[j] = (e16)0.f;
     const long gstride = (long)gridDim.x * 4;
     long grp = (long)blockIdx.x * 4 + wave;
     vec_t hq = zero_v, dq = zero_v;
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(NT) void k_wrb_bwd_a(const __bf16* __restrict__ h1,
         for (int j = 0; j < NCH; ++j) {
             const float a2 = z[j >> 2][j & 3];
             gv[j] = (float)dq[j] * elu_dpre(a2);
-            gq[j] = (__bf16)gv[j];
+            gq[j] = (e16)gv[j];
             hv[j] = (float)hq[j];
         }
         if constexpr (C == 32) {
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(NT) void k_wrb_bwd_a(const __bf16* __restrict__ h1,
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             a1g[j] = u[j >> 2][j & 3] * elu_dout(hv[j]);
-            aq[j] = (__bf16)a1g[j];
+            aq[j] = (e16)a1g[j];
             db2a[j] += gv[j]; db1a[j] += a1g[j];                  // invalid pixels contribute zeros
         }
         if (valid) *reinterpret_cast<vec_t*>(da1 + pix * C + NCH * g) = aq;
@@ -424,7 +424,7 @@ template <int C, int D> struct WG {
 template <int C> __device__ __forceinline__ int swz_piece(int q, int cg) { return C == 32 ? (cg ^ (((q >> 2) & 1) << 1)) : cg; }
 
 template <int C, int D>
-__global__ __launch_bounds__(NT) void k_wrb_wgrad(const __bf16* __restrict__ x, const __bf16* __restrict__ da1,
+__global__ __launch_bounds__(NT) void k_wrb_wgrad(const e16* __restrict__ x, const e16* __restrict__ da1,
                                                   float* __restrict__ part, int B, int H, int T, int tiles_h, int tiles_t,
                                                   int ntiles) {
     using G = WG<C, D>;
@@ -444,14 +444,14 @@ __global__ __launch_bounds__(NT) void k_wrb_wgrad(const __bf16* __restrict__ x, 
 #pragma unroll
         for (int a = 0; a < NA; ++a) acc[k][a] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const __bf16* zero = reinterpret_cast<const __bf16*>(&g_wzero16);
+    const e16* zero = reinterpret_cast<const e16*>(&g_wzero16);
     for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
         int tile = xcd_order(v, ntiles);
         const int tt = tile % tiles_t; tile /= tiles_t;
         const int th = tile % tiles_h;
         const int b = tile / tiles_h, h0 = th * G::TH, t0 = tt * G::TW;
-        const __bf16* xb = x + (long)b * H * T * C;
-        const __bf16* gb = da1 + (long)b * H * T * C;
+        const e16* xb = x + (long)b * H * T * C;
+        const e16* gb = da1 + (long)b * H * T * C;
         __syncthreads();
         for (int i = wave * 64; i < G::XPR; i += NT) {
             const int p = i + lane, q = p / G::CG, cg = swz_piece<C>(q, p - q * G::CG);
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(NT) void k_wrb_wgrad(const __bf16* __restrict__ x, 
         for (int r = row0; r < G::TH; r += rstep) {
             if (h0 + r >= H) break;
             // dA1 operand(s): co-tiles 0..NA-1
-            bf16x8 ga[NA];
+            e16x8 ga[NA];
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
                 s16x4 lo, hi;
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(NT) void k_wrb_wgrad(const __bf16* __restrict__ x, 
                     const s16x4 t4 = lds_tr16(gs + (long)q * (C * 2) + half + trq * 8);
                     if (u == 0) lo = t4; else hi = t4;
                 }
-                ga[a] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                ga[a] = __builtin_bit_cast(e16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
             }
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(NT) void k_wrb_wgrad(const __bf16* __restrict__ x, 
                     const s16x4 t4 = lds_tr16(xs + (long)q * (C * 2) + half + trq * 8);
                     if (u == 0) lo = t4; else hi = t4;
                 }
-                const bf16x8 xq = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                const e16x8 xq = __builtin_bit_cast(e16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
                 for (int a = 0; a < NA; ++a) acc[k][a] = mma32(ga[a], xq, acc[k][a]);
             }
@@ -533,13 +533,13 @@ template <int C, int D, int TH, int TW> struct DXW {
 };
 
 template <int C, int D, int TH, int TW>
-__global__ __launch_bounds__(NT, 2) void k_wrb_dxw(const __bf16* __restrict__ x, const __bf16* __restrict__ da1, const __bf16* __restrict__ dy,
-                                                   const float* __restrict__ w1, __bf16* __restrict__ dx, float* __restrict__ part_w, int B,
+__global__ __launch_bounds__(NT, 2) void k_wrb_dxw(const e16* __restrict__ x, const e16* __restrict__ da1, const e16* __restrict__ dy,
+                                                   const float* __restrict__ w1, e16* __restrict__ dx, float* __restrict__ part_w, int B,
                                                    int H, int T, int tiles_h, int tiles_t, int ntiles) {
     using G = DXW<C, D, TH, TW>;
     using K = WK<C>;
     constexpr int NCT = K::NCT, NK = K::NK, NCH = K::NCH, PB = G::PB;
-    typedef typename std::conditional<C == 32, bf16x8, bf16x4>::type vec_t;
+    typedef typename std::conditional<C == 32, e16x8, e16x4>::type vec_t;
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char* gs = smem;                                    // dA1
     unsigned char* xs = smem + G::IMG_BYTES;                     // x
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(NT, 2) void k_wrb_dxw(const __bf16* __restrict__ x,
     const int n = lane & 15, g = lane >> 4, trj = n >> 2, trq = n & 3;
 
     // data-gradient weights (transposed, taps reversed), bf16, in registers for the whole launch
-    bf16x8 A[NK][NCT];
+    e16x8 A[NK][NCT];
 #pragma unroll
     for (int k = 0; k < NK; ++k)
 #pragma unroll
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(NT, 2) void k_wrb_dxw(const __bf16* __restrict__ x,
                 v[j] = tap < 9 ? w1[(kc * C + chan_of<C>(ct, n)) * 9 + (8 - tap)] : 0.f;
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) A[k][ct][j] = (__bf16)v[j];
+            for (int j = 0; j < 8; ++j) A[k][ct][j] = (e16)v[j];
         }
     // weight-gradient roles (as in k_wrb_bwd_fused): C = 32: wave = (ci-tile wave & 1, co-tile wave >> 1), all rows and chunks;
     // C = 16: the waves split the 32-column chunks, then the rows
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(NT, 2) void k_wrb_dxw(const __bf16* __restrict__ x,
 #pragma unroll
     for (int k = 0; k < 9; ++k) wacc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const __bf16* zero = reinterpret_cast<const __bf16*>(&g_wzero16);
+    const e16* zero = reinterpret_cast<const e16*>(&g_wzero16);
     for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
         int tile = xcd_order(v, ntiles);
         const int tt = tile % tiles_t; tile /= tiles_t;
@@ -608,11 +608,11 @@ __global__ __launch_bounds__(NT, 2) void k_wrb_dxw(const __bf16* __restrict__ x,
             f32x4 acc[NCT];
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-            bf16x8 unused;
+            e16x8 unused;
             conv_taps<C, D, G::IW>(gs, r, c, g, A, acc, unused);
             vec_t o;
 #pragma unroll
-            for (int j = 0; j < NCH; ++j) o[j] = (__bf16)(acc[j >> 2][j & 3] + (float)rq[j]);
+            for (int j = 0; j < NCH; ++j) o[j] = (e16)(acc[j >> 2][j & 3] + (float)rq[j]);
             if (valid) *reinterpret_cast<vec_t*>(dx + pix * C + NCH * g) = o;
         }
 
@@ -629,7 +629,7 @@ __global__ __launch_bounds__(NT, 2) void k_wrb_dxw(const __bf16* __restrict__ x,
                                               16 * (((C == 32 ? 2 * aw : 0) + (trq >> 1)) ^ fswz<C>(cc)) + 8 * (trq & 1));
                     if (u == 0) lo = t4; else hi = t4;
                 }
-                const bf16x8 ga = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                const e16x8 ga = __builtin_bit_cast(e16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
                     const int kh = k / 3, kw = k - 3 * kh;
@@ -640,7 +640,7 @@ __global__ __launch_bounds__(NT, 2) void k_wrb_dxw(const __bf16* __restrict__ x,
                                                   16 * (((C == 32 ? 2 * cit : 0) + (trq >> 1)) ^ fswz<C>(xc)) + 8 * (trq & 1));
                         if (u == 0) lo = t4; else hi = t4;
                     }
-                    const bf16x8 xq = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                    const e16x8 xq = __builtin_bit_cast(e16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
                     wacc[k] = mma32(ga, xq, wacc[k]);
                 }
             }
@@ -669,8 +669,8 @@ __global__ __launch_bounds__(NT, 2) void k_wrb_dxw(const __bf16* __restrict__ x,
 
 // ---- launchers -------------------------------------------------------------------------------------------------------
 template <int C, int D, int MODE, bool SAVE>
-int launch_conv(const __bf16* x, const float* w1, const float* b1, const float* w2, const float* b2, const __bf16* res,
-                __bf16* y, __bf16* h1, int B, int H, int T, hipStream_t st) {
+int launch_conv(const e16* x, const float* w1, const float* b1, const float* w2, const float* b2, const e16* res,
+                e16* y, e16* h1, int B, int H, int T, hipStream_t st) {
     using G = WT<C, D>;
     const int tiles_h = (H + G::TH - 1) / G::TH, tiles_t = (T + G::TW - 1) / G::TW, ntiles = B * tiles_h * tiles_t;
     static const int per_cu = getenv("TTRAP_WIDE_PER_CU") ? atoi(getenv("TTRAP_WIDE_PER_CU")) : 4;
@@ -699,7 +699,7 @@ int launch_conv(const __bf16* x, const float* w1, const float* b1, const float* 
 template <int C> constexpr long dump_floats() { return (long)MAX_A_WG * WA<C>::DUMP + (long)MAX_W_WG * 4 * 9 * (C / 16) * 256; }
 
 template <int C, int D, int TH, int TW>
-int launch_dxw(const __bf16* x, const __bf16* da1, const __bf16* dy, const float* w1, __bf16* dx, float* part_w, float* part_a, int grid_a,
+int launch_dxw(const e16* x, const e16* da1, const e16* dy, const float* w1, e16* dx, float* part_w, float* part_a, int grid_a,
                float* dw1, float* db1, float* dw2, float* db2, int B, int H, int T, hipStream_t st) {
     using X = DXW<C, D, TH, TW>;
     static AttrOnce once_x;
@@ -718,22 +718,27 @@ int launch_dxw(const __bf16* x, const __bf16* da1, const __bf16* dy, const float
     return 0;
 }
 
-// One-pass backward (k_wrb_bwd1, conv_level_bf16.hip) or the per-stage kernels below: TTRAP_WBWD1 = 0 / 1 forces one of them for
-// every width and dilation, unset = the measured choice per (C, dilation).
+// One-pass backward (k_wrb_bwds, conv_level_bf16.hip: column strips, dA1 in a rolling LDS ring, 4 tensors of HBM traffic) or the
+// per-stage kernels below (7 tensors): TTRAP_WBWD1 = 0 / 1 forces one of them for every width and dilation, unset = the measured
+// choice per (C, dilation).  Round 4, per call at the bench shape (64 clips), per-stage -> one-pass:
+//   C = 16 (four workgroups per CU, 124 registers): 0.469 / 0.436 / 0.437 -> 0.420 / 0.379 / 0.372 ms (dilation 1 / 2 / 3): taken;
+//   C = 32 (192 registers = two workgroups per CU): 0.466 / 0.449 / 0.464 -> 0.509 / 0.458 / 0.453 ms: HBM traffic 2.16 -> 1.15 GB
+//   per call (PMC, profiles/r04_pmc_bwds.txt) but two waves per SIMD leave the vector ALUs 39 % and the matrix pipe 19 % busy with
+//   the waves parked 39 % of their life -- not taken.
 inline int onepass_choice(int C, int D) {
     static const int forced = env_int("TTRAP_WBWD1", -1);
     if (forced >= 0) return forced ? 1 : 0;
-    (void)C; (void)D;
-    return 0;
+    (void)D;
+    return C == 16 ? 1 : 0;
 }
 
 template <int C, int D>
-int launch_bwd(const __bf16* x, const __bf16* h1, const __bf16* dy, const float* w1, const float* w2, const float* b2,
-               __bf16* dx, float* dw1, float* db1, float* dw2, float* db2, unsigned char* ws, int B, int H, int T,
+int launch_bwd(const e16* x, const e16* h1, const e16* dy, const float* w1, const float* w2, const float* b2,
+               e16* dx, float* dw1, float* db1, float* dw2, float* db2, unsigned char* ws, int B, int H, int T,
                hipStream_t st) {
     if (onepass_choice(C, D)) return tt_wide_rb_bwd_onepass(x, h1, dy, w1, w2, b2, dx, dw1, db1, dw2, db2, ws, B, C, H, T, D, st);
     const long npix = (long)B * H * T;
-    __bf16* da1 = reinterpret_cast<__bf16*>(ws);
+    e16* da1 = reinterpret_cast<e16*>(ws);
     float* part_a = reinterpret_cast<float*>(ws + ((npix * C * 2 + 255) / 256) * 256);
     float* part_w = part_a + (long)MAX_A_WG * WA<C>::DUMP;
     // pointwise chain
@@ -780,7 +785,7 @@ int launch_bwd(const __bf16* x, const __bf16* h1, const __bf16* dy, const float*
 }
 
 template <int C>
-int fwd_c(const __bf16* x, const float* w1, const float* b1, const float* w2, const float* b2, __bf16* y, __bf16* h1, int B,
+int fwd_c(const e16* x, const float* w1, const float* b1, const float* w2, const float* b2, e16* y, e16* h1, int B,
           int H, int T, int D, hipStream_t st) {
 #define TT_WFWD(DD)                                                                                                  \
     return h1 ? launch_conv<C, DD, 0, true>(x, w1, b1, w2, b2, nullptr, y, h1, B, H, T, st)                           \
@@ -794,7 +799,7 @@ int fwd_c(const __bf16* x, const float* w1, const float* b1, const float* w2, co
     return TT_E_UNSUPPORTED;
 }
 template <int C>
-int bwd_c(const __bf16* x, const __bf16* h1, const __bf16* dy, const float* w1, const float* w2, const float* b2, __bf16* dx,
+int bwd_c(const e16* x, const e16* h1, const e16* dy, const float* w1, const float* w2, const float* b2, e16* dx,
           float* dw1, float* db1, float* dw2, float* db2, unsigned char* ws, int B, int H, int T, int D, hipStream_t st) {
     switch (D) {
         case 1: return launch_bwd<C, 1>(x, h1, dy, w1, w2, b2, dx, dw1, db1, dw2, db2, ws, B, H, T, st);
@@ -810,12 +815,11 @@ int bwd_c(const __bf16* x, const __bf16* h1, const __bf16* dy, const float* w1, 
 // A = a 4 x 4 slice of the weights (the same in every block) and B = four channels of the lane's own pixel, every lane
 // ends up with ALL output channels of its pixel: a 64-pixel row segment per wave instruction, 8- / 16-byte accesses
 // everywhere, nothing wasted on padding the channel count up to a 16-row tile.
-__device__ __forceinline__ f32x4 mma4(s16x4 a, s16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a, b, c, 0, 0, 0); }
 
-template <int C> struct VecOf { typedef typename std::conditional<C == 8, bf16x8, bf16x4>::type type; };
+template <int C> struct VecOf { typedef typename std::conditional<C == 8, e16x8, e16x4>::type type; };
 template <int C> __device__ __forceinline__ s16x4 chunk_of(const typename VecOf<C>::type& v, int kb) {
     if constexpr (C == 8) {
-        const bf16x4 h = kb == 0 ? __builtin_shufflevector(v, v, 0, 1, 2, 3) : __builtin_shufflevector(v, v, 4, 5, 6, 7);
+        const e16x4 h = kb == 0 ? __builtin_shufflevector(v, v, 0, 1, 2, 3) : __builtin_shufflevector(v, v, 4, 5, 6, 7);
         return __builtin_bit_cast(s16x4, h);
     } else {
         return __builtin_bit_cast(s16x4, v);
@@ -835,10 +839,10 @@ template <int C, int D> struct NTl {
 
 // C = 8 forward: capped at 168 VGPRs (three waves per SIMD; 208 otherwise): 0.194 / 0.190 / 0.195 -> 0.187 / 0.186 / 0.189 ms (library A/B, round 3)
 template <int C, int D, int MODE, bool SAVE>
-__global__ __launch_bounds__(NT, (C == 8 && MODE == 0) ? 3 : 1) void k_nrb_conv(const __bf16* __restrict__ x, const float* __restrict__ w1,
+__global__ __launch_bounds__(NT, (C == 8 && MODE == 0) ? 3 : 1) void k_nrb_conv(const e16* __restrict__ x, const float* __restrict__ w1,
                                                  const float* __restrict__ b1, const float* __restrict__ w2,
-                                                 const float* __restrict__ b2, const __bf16* __restrict__ res,
-                                                 __bf16* __restrict__ y, __bf16* __restrict__ h1, int B, int H, int T,
+                                                 const float* __restrict__ b2, const e16* __restrict__ res,
+                                                 e16* __restrict__ y, e16* __restrict__ h1, int B, int H, int T,
                                                  int tiles_h, int tiles_t, int ntiles) {
     using G = NTl<C, D>;
     typedef typename VecOf<C>::type vec_t;
@@ -854,11 +858,11 @@ __global__ __launch_bounds__(NT, (C == 8 && MODE == 0) ? 3 : 1) void k_nrb_conv(
         for (int ob = 0; ob < NB; ++ob)
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) {
-                bf16x4 t;
+                e16x4 t;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int mo = 4 * ob + i4, kc = 4 * kb + k;
-                    t[k] = (__bf16)(MODE == 0 ? w1[(mo * C + kc) * 9 + tap] : w1[(kc * C + mo) * 9 + (8 - tap)]);
+                    t[k] = (e16)(MODE == 0 ? w1[(mo * C + kc) * 9 + tap] : w1[(kc * C + mo) * 9 + (8 - tap)]);
                 }
                 A[tap][ob][kb] = __builtin_bit_cast(s16x4, t);
             }
@@ -868,22 +872,22 @@ __global__ __launch_bounds__(NT, (C == 8 && MODE == 0) ? 3 : 1) void k_nrb_conv(
         for (int ob = 0; ob < NB; ++ob)
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) {
-                bf16x4 t;
+                e16x4 t;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) t[k] = (__bf16)w2[(4 * ob + i4) * C + 4 * kb + k];
+                for (int k = 0; k < 4; ++k) t[k] = (e16)w2[(4 * ob + i4) * C + 4 * kb + k];
                 A2[ob][kb] = __builtin_bit_cast(s16x4, t);
             }
 #pragma unroll
         for (int c = 0; c < C; ++c) { b1r[c] = b1[c]; b2r[c] = b2[c]; }
     }
 
-    const __bf16* zero = reinterpret_cast<const __bf16*>(&g_wzero16);
+    const e16* zero = reinterpret_cast<const e16*>(&g_wzero16);
     for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
         int tile = xcd_order(v, ntiles);
         const int tt = tile % tiles_t; tile /= tiles_t;
         const int th = tile % tiles_h;
         const int b = tile / tiles_h, h0 = th * G::TH, t0 = tt * G::TW;
-        const __bf16* xb = x + (long)b * H * T * C;
+        const e16* xb = x + (long)b * H * T * C;
 
         __syncthreads();
         for (int i = wave * 64; i < G::NPR; i += NT) {
@@ -925,11 +929,11 @@ __global__ __launch_bounds__(NT, (C == 8 && MODE == 0) ? 3 : 1) void k_nrb_conv(
             vec_t o;
             if constexpr (MODE == 1) {
 #pragma unroll
-                for (int c = 0; c < C; ++c) o[c] = (__bf16)(acc[c >> 2][c & 3] + (float)rq[c]);
+                for (int c = 0; c < C; ++c) o[c] = (e16)(acc[c >> 2][c & 3] + (float)rq[c]);
             } else {
                 vec_t hq;
 #pragma unroll
-                for (int c = 0; c < C; ++c) hq[c] = (__bf16)elu_f(acc[c >> 2][c & 3]);
+                for (int c = 0; c < C; ++c) hq[c] = (e16)elu_f(acc[c >> 2][c & 3]);
                 if (SAVE && valid) *reinterpret_cast<vec_t*>(h1 + pix * C) = hq;
                 f32x4 z[NB];
 #pragma unroll
@@ -939,7 +943,7 @@ __global__ __launch_bounds__(NT, (C == 8 && MODE == 0) ? 3 : 1) void k_nrb_conv(
                     for (int kb = 0; kb < NB; ++kb) z[ob] = mma4(A2[ob][kb], chunk_of<C>(hq, kb), z[ob]);
                 }
 #pragma unroll
-                for (int c = 0; c < C; ++c) o[c] = (__bf16)(elu_f(z[c >> 2][c & 3]) + (float)centre[c]);
+                for (int c = 0; c < C; ++c) o[c] = (e16)(elu_f(z[c >> 2][c & 3]) + (float)centre[c]);
             }
             if (valid) *reinterpret_cast<vec_t*>(y + pix * C) = o;
         }
@@ -949,9 +953,9 @@ __global__ __launch_bounds__(NT, (C == 8 && MODE == 0) ? 3 : 1) void k_nrb_conv(
 // Pointwise chain of the backward, lane = pixel.  dW2 is a per-lane outer product (C^2 fused multiply-adds per pixel),
 // reduced over the wave by shuffles once at the end.  One dump [dW2 co*C+ci][db1][db2] per workgroup.
 template <int C>
-__global__ __launch_bounds__(NT) void k_nrb_bwd_a(const __bf16* __restrict__ h1, const __bf16* __restrict__ dy,
+__global__ __launch_bounds__(NT) void k_nrb_bwd_a(const e16* __restrict__ h1, const e16* __restrict__ dy,
                                                   const float* __restrict__ w2, const float* __restrict__ b2,
-                                                  __bf16* __restrict__ da1, float* __restrict__ part, long npix, long ngroups) {
+                                                  e16* __restrict__ da1, float* __restrict__ part, long npix, long ngroups) {
     typedef typename VecOf<C>::type vec_t;
     constexpr int NB = C / 4, DUMP = C * C + 2 * C;
     __shared__ float red[4][DUMP];
@@ -962,11 +966,11 @@ __global__ __launch_bounds__(NT) void k_nrb_bwd_a(const __bf16* __restrict__ h1,
     for (int ob = 0; ob < NB; ++ob)
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) {
-            bf16x4 a, at;
+            e16x4 a, at;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                a[k] = (__bf16)w2[(4 * ob + i4) * C + 4 * kb + k];
-                at[k] = (__bf16)w2[(4 * kb + k) * C + 4 * ob + i4];
+                a[k] = (e16)w2[(4 * ob + i4) * C + 4 * kb + k];
+                at[k] = (e16)w2[(4 * kb + k) * C + 4 * ob + i4];
             }
             A2[ob][kb] = __builtin_bit_cast(s16x4, a); A2T[ob][kb] = __builtin_bit_cast(s16x4, at);
         }
@@ -978,7 +982,7 @@ __global__ __launch_bounds__(NT) void k_nrb_bwd_a(const __bf16* __restrict__ h1,
 
     vec_t zero_v;
 #pragma unroll
-    for (int c = 0; c < C; ++c) zero_v[c] = (__bf16)0.f;
+    for (int c = 0; c < C; ++c) zero_v[c] = (e16)0.f;
     const long gstride = (long)gridDim.x * 4;
     long grp = (long)blockIdx.x * 4 + wave;
     vec_t hq = zero_v, dq = zero_v;
@@ -1006,7 +1010,7 @@ __global__ __launch_bounds__(NT) void k_nrb_bwd_a(const __bf16* __restrict__ h1,
         for (int c = 0; c < C; ++c) {
             const float a2 = z[c >> 2][c & 3];
             gv[c] = (float)dq[c] * elu_dpre(a2);
-            gq[c] = (__bf16)gv[c];
+            gq[c] = (e16)gv[c];
             gr[c] = (float)gq[c];
             hv[c] = (float)hq[c];
         }
@@ -1019,7 +1023,7 @@ __global__ __launch_bounds__(NT) void k_nrb_bwd_a(const __bf16* __restrict__ h1,
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const float a1 = u[c >> 2][c & 3] * elu_dout(hv[c]);
-            aq[c] = (__bf16)a1;
+            aq[c] = (e16)a1;
             acc[C * C + c] += a1; acc[C * C + C + c] += gv[c];       // invalid pixels contribute zeros
         }
         if (pix < npix) *reinterpret_cast<vec_t*>(da1 + pix * C) = aq;
@@ -1060,7 +1064,7 @@ template <int C, int D> struct NG {
 };
 
 template <int C, int D>
-__global__ __launch_bounds__(NT) void k_nrb_wgrad(const __bf16* __restrict__ x, const __bf16* __restrict__ da1,
+__global__ __launch_bounds__(NT) void k_nrb_wgrad(const e16* __restrict__ x, const e16* __restrict__ da1,
                                                   float* __restrict__ part, int B, int H, int T, int tiles_h, int tiles_t,
                                                   int ntiles) {
     using G = NG<C, D>;
@@ -1076,14 +1080,14 @@ __global__ __launch_bounds__(NT) void k_nrb_wgrad(const __bf16* __restrict__ x, 
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const __bf16* zero = reinterpret_cast<const __bf16*>(&g_wzero16);
+    const e16* zero = reinterpret_cast<const e16*>(&g_wzero16);
     for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
         int tile = xcd_order(v, ntiles);
         const int tt = tile % tiles_t; tile /= tiles_t;
         const int th = tile % tiles_h;
         const int b = tile / tiles_h, h0 = th * G::TH, t0 = tt * G::TW;
-        const __bf16* xb = x + (long)b * H * T * C;
-        const __bf16* gb = da1 + (long)b * H * T * C;
+        const e16* xb = x + (long)b * H * T * C;
+        const e16* gb = da1 + (long)b * H * T * C;
         __syncthreads();
         for (int i = wave * 64; i < G::XPR; i += NT) {
             const int p = i + lane, q = p * G::PPP;
@@ -1107,13 +1111,13 @@ __global__ __launch_bounds__(NT) void k_nrb_wgrad(const __bf16* __restrict__ x, 
             if (h0 + r >= H) break;
             const unsigned char* gp = gs + (long)r * (G::TW * G::PXB) + so;
             const s16x4 glo = lds_tr16(gp), ghi = lds_tr16(gp + 512);
-            const bf16x8 ga = __builtin_bit_cast(bf16x8, __builtin_shufflevector(glo, ghi, 0, 1, 2, 3, 4, 5, 6, 7));
+            const e16x8 ga = __builtin_bit_cast(e16x8, __builtin_shufflevector(glo, ghi, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
                 const int kh = k / 3, kw = k - 3 * kh;
                 const unsigned char* xp = xs + (long)(r + kh * D) * (G::RW * G::PXB) + (G::DP + (kw - 1) * D) * G::PXB + so;
                 const s16x4 lo = lds_tr16(xp), hi = lds_tr16(xp + 512);
-                acc[k] = mma32(ga, __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)), acc[k]);
+                acc[k] = mma32(ga, __builtin_bit_cast(e16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)), acc[k]);
             }
         }
     }
@@ -1131,10 +1135,10 @@ __global__ __launch_bounds__(NT) void k_nrb_wgrad(const __bf16* __restrict__ x, 
 // takes dx = dy + W1^T (*) dA1 and dW1 = sum dA1 (x) x(+tap) straight from the three LDS images.  dA1 never goes to HBM: 4 tensors
 // of traffic per block instead of 8 (h1, dy, x read; dx written), one launch instead of three.
 template <int C, int D>
-__global__ __launch_bounds__(NT, C == 8 ? 2 : 1) void k_nrb_bwd_fused(const __bf16* __restrict__ x, const __bf16* __restrict__ h1,
-                                                      const __bf16* __restrict__ dy, const float* __restrict__ w1,
+__global__ __launch_bounds__(NT, C == 8 ? 2 : 1) void k_nrb_bwd_fused(const e16* __restrict__ x, const e16* __restrict__ h1,
+                                                      const e16* __restrict__ dy, const float* __restrict__ w1,
                                                       const float* __restrict__ w2, const float* __restrict__ b2,
-                                                      __bf16* __restrict__ dx, float* __restrict__ part_a, float* __restrict__ part_w,
+                                                      e16* __restrict__ dx, float* __restrict__ part_a, float* __restrict__ part_w,
                                                       int B, int H, int T, int tiles_h, int tiles_t, int ntiles, int fastdma) {
     using G = NTl<C, D>;
     typedef typename VecOf<C>::type vec_t;
@@ -1155,7 +1159,7 @@ __global__ __launch_bounds__(NT, C == 8 ? 2 : 1) void k_nrb_bwd_fused(const __bf
 #pragma unroll
     for (int k = 0; k < 9; ++k) wacc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const __bf16* zero = reinterpret_cast<const __bf16*>(&g_wzero16);
+    const e16* zero = reinterpret_cast<const e16*>(&g_wzero16);
     // The A operands of every phase as a bf16 image in LDS, built once per workgroup: entry ((m * NB + ob) * NB + kb) * 4 + i4 holds the
     // four values lane i4 of a 4-lane group feeds to product (ob, kb) of matrix m (0: W2, 1: W2^T, 2 + tap: W1^T of tap 8 - tap).  The
     // phases fetch theirs per tile (8 / 36 eight-byte LDS reads at C = 8) so that the registers are free in the other phases (72 + 16
@@ -1164,12 +1168,12 @@ __global__ __launch_bounds__(NT, C == 8 ? 2 : 1) void k_nrb_bwd_fused(const __bf
     unsigned char* wimg = smem + 3 * IMG;
     for (int e = tid; e < (2 + 9) * NB * NB * 4; e += NT) {
         const int l4 = e & 3, kb = (e >> 2) % NB, ob = (e >> 2) / NB % NB, m = (e >> 2) / (NB * NB);
-        bf16x4 a;
+        e16x4 a;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            a[k] = (__bf16)(m == 0 ? w2[(4 * ob + l4) * C + 4 * kb + k] : m == 1 ? w2[(4 * kb + k) * C + 4 * ob + l4]
+            a[k] = (e16)(m == 0 ? w2[(4 * ob + l4) * C + 4 * kb + k] : m == 1 ? w2[(4 * kb + k) * C + 4 * ob + l4]
                                    : w1[((4 * kb + k) * C + 4 * ob + l4) * 9 + (8 - (m - 2))]);
-        *reinterpret_cast<bf16x4*>(wimg + e * 8) = a;
+        *reinterpret_cast<e16x4*>(wimg + e * 8) = a;
     }
     constexpr int NITD = G::NPR / NT;                            // 16-byte pieces per thread and image
     unsigned rel[NITD];                                          // their byte offsets from the tile's first halo pixel
@@ -1246,7 +1250,7 @@ __global__ __launch_bounds__(NT, C == 8 ? 2 : 1) void k_nrb_bwd_fused(const __bf
                 for (int c = 0; c < C; ++c) {
                     const float a2 = z[c >> 2][c & 3];
                     gv[c] = (float)dq[c] * elu_dpre(a2);
-                    gq[c] = (__bf16)gv[c];
+                    gq[c] = (e16)gv[c];
                     gr[c] = (float)gq[c];
                     hv[c] = (float)hq[c];
                 }
@@ -1260,7 +1264,7 @@ __global__ __launch_bounds__(NT, C == 8 ? 2 : 1) void k_nrb_bwd_fused(const __bf
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
                     const float a1 = u[c >> 2][c & 3] * elu_dout(hv[c]);
-                    aq[c] = (__bf16)a1;
+                    aq[c] = (e16)a1;
                     acc[C * C + c] += m * a1; acc[C * C + C + c] += m * gv[c];
                     gr[c] *= m;
                 }
@@ -1306,7 +1310,7 @@ __global__ __launch_bounds__(NT, C == 8 ? 2 : 1) void k_nrb_bwd_fused(const __bf
                 const vec_t rq = *reinterpret_cast<const vec_t*>(gs + (long)((r + D) * G::RW + G::DP + lane) * G::PXB);
                 vec_t o;
 #pragma unroll
-                for (int c = 0; c < C; ++c) o[c] = (__bf16)(a4[c >> 2][c & 3] + (float)rq[c]);
+                for (int c = 0; c < C; ++c) o[c] = (e16)(a4[c >> 2][c & 3] + (float)rq[c]);
                 if (t < T) *reinterpret_cast<vec_t*>(dx + ib + ((long)h * T + t) * C) = o;
             }
         }
@@ -1322,13 +1326,13 @@ __global__ __launch_bounds__(NT, C == 8 ? 2 : 1) void k_nrb_bwd_fused(const __bf
                 if (h0 + r >= H) break;
                 const unsigned char* gp = hs + (long)(r + D) * ROWB + G::DP * G::PXB + so;
                 const s16x4 glo = lds_tr16(gp), ghi = lds_tr16(gp + UOFF);
-                const bf16x8 ga = __builtin_bit_cast(bf16x8, __builtin_shufflevector(glo, ghi, 0, 1, 2, 3, 4, 5, 6, 7));
+                const e16x8 ga = __builtin_bit_cast(e16x8, __builtin_shufflevector(glo, ghi, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
                     const int kh = k / 3, kw = k - 3 * kh;
                     const unsigned char* xp = xs + (long)(r + kh * D) * ROWB + (G::DP + (kw - 1) * D) * G::PXB + so;
                     const s16x4 lo = lds_tr16(xp), hi = lds_tr16(xp + UOFF);
-                    wacc[k] = mma32(ga, __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)), wacc[k]);
+                    wacc[k] = mma32(ga, __builtin_bit_cast(e16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)), wacc[k]);
                 }
             }
         }
@@ -1358,8 +1362,8 @@ __global__ __launch_bounds__(NT, C == 8 ? 2 : 1) void k_nrb_bwd_fused(const __bf
 // and x tiles (16 x 64 pixels + halo) are staged once, dx = dy + W1^T (*) dA1 by lane-per-pixel 4x4x4 products, dW1 by transpose reads
 // of 32-byte slots (k_nrb_wgrad's scheme; the two K halves are the two halves of a row at C = 8, two consecutive rows at C = 4).
 template <int C, int D>
-__global__ __launch_bounds__(NT) void k_nrb_dxw(const __bf16* __restrict__ x, const __bf16* __restrict__ da1, const __bf16* __restrict__ dy,
-                                                const float* __restrict__ w1, __bf16* __restrict__ dx, float* __restrict__ part_w, int B,
+__global__ __launch_bounds__(NT) void k_nrb_dxw(const e16* __restrict__ x, const e16* __restrict__ da1, const e16* __restrict__ dy,
+                                                const float* __restrict__ w1, e16* __restrict__ dx, float* __restrict__ part_w, int B,
                                                 int H, int T, int tiles_h, int tiles_t, int ntiles) {
     using G = NTl<C, D>;
     typedef typename VecOf<C>::type vec_t;
@@ -1376,16 +1380,16 @@ __global__ __launch_bounds__(NT) void k_nrb_dxw(const __bf16* __restrict__ x, co
         for (int ob = 0; ob < NB; ++ob)
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) {
-                bf16x4 t4;
+                e16x4 t4;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) t4[k] = (__bf16)w1[((4 * kb + k) * C + 4 * ob + i4) * 9 + (8 - tap)];
+                for (int k = 0; k < 4; ++k) t4[k] = (e16)w1[((4 * kb + k) * C + 4 * ob + i4) * 9 + (8 - tap)];
                 A[tap][ob][kb] = __builtin_bit_cast(s16x4, t4);
             }
     f32x4 wacc[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) wacc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const __bf16* zero = reinterpret_cast<const __bf16*>(&g_wzero16);
+    const e16* zero = reinterpret_cast<const e16*>(&g_wzero16);
     for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
         int tile = xcd_order(v, ntiles);
         const int tt = tile % tiles_t; tile /= tiles_t;
@@ -1429,7 +1433,7 @@ __global__ __launch_bounds__(NT) void k_nrb_dxw(const __bf16* __restrict__ x, co
                 }
                 vec_t o;
 #pragma unroll
-                for (int c = 0; c < C; ++c) o[c] = (__bf16)(a4[c >> 2][c & 3] + (float)rq[c]);
+                for (int c = 0; c < C; ++c) o[c] = (e16)(a4[c >> 2][c & 3] + (float)rq[c]);
                 if (valid) *reinterpret_cast<vec_t*>(dx + pix * C) = o;
             }
         }
@@ -1443,13 +1447,13 @@ __global__ __launch_bounds__(NT) void k_nrb_dxw(const __bf16* __restrict__ x, co
                 if (h0 + r >= H) break;
                 const unsigned char* gp = hs + (long)(r + D) * ROWB + G::DP * G::PXB + so;
                 const s16x4 glo = lds_tr16(gp), ghi = lds_tr16(gp + UOFF);
-                const bf16x8 ga = __builtin_bit_cast(bf16x8, __builtin_shufflevector(glo, ghi, 0, 1, 2, 3, 4, 5, 6, 7));
+                const e16x8 ga = __builtin_bit_cast(e16x8, __builtin_shufflevector(glo, ghi, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
                     const int kh = k / 3, kw = k - 3 * kh;
                     const unsigned char* xp = xs + (long)(r + kh * D) * ROWB + (G::DP + (kw - 1) * D) * G::PXB + so;
                     const s16x4 lo = lds_tr16(xp), hi = lds_tr16(xp + UOFF);
-                    wacc[k] = mma32(ga, __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)), wacc[k]);
+                    wacc[k] = mma32(ga, __builtin_bit_cast(e16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)), wacc[k]);
                 }
             }
         }
@@ -1506,8 +1510,8 @@ __global__ __launch_bounds__(1024) void k_nrb_reduce(RedArgs ar) {
 }
 
 template <int C, int D, int MODE, bool SAVE>
-int launch_nconv(const __bf16* x, const float* w1, const float* b1, const float* w2, const float* b2, const __bf16* res,
-                 __bf16* y, __bf16* h1, int B, int H, int T, hipStream_t st) {
+int launch_nconv(const e16* x, const float* w1, const float* b1, const float* w2, const float* b2, const e16* res,
+                 e16* y, e16* h1, int B, int H, int T, hipStream_t st) {
     using G = NTl<C, D>;
     static AttrOnce once;
     auto kern = k_nrb_conv<C, D, MODE, SAVE>;
@@ -1524,11 +1528,11 @@ int launch_nconv(const __bf16* x, const float* w1, const float* b1, const float*
 template <int C> constexpr long ndump_floats() { return (long)MAX_A_WG * (C * C + 2 * C) + (long)MAX_W_WG * 4 * 9 * 256; }
 
 template <int C, int D>
-int launch_nbwd(const __bf16* x, const __bf16* h1, const __bf16* dy, const float* w1, const float* w2, const float* b2,
-                __bf16* dx, float* dw1, float* db1, float* dw2, float* db2, unsigned char* ws, int B, int H, int T,
+int launch_nbwd(const e16* x, const e16* h1, const e16* dy, const float* w1, const float* w2, const float* b2,
+                e16* dx, float* dw1, float* db1, float* dw2, float* db2, unsigned char* ws, int B, int H, int T,
                 hipStream_t st) {
     const long npix = (long)B * H * T;
-    __bf16* da1 = reinterpret_cast<__bf16*>(ws);
+    e16* da1 = reinterpret_cast<e16*>(ws);
     float* part_a = reinterpret_cast<float*>(ws + ((npix * C * 2 + 255) / 256) * 256);
     float* part_w = part_a + (long)MAX_A_WG * (C * C + 2 * C);
     // Measured per launch at the bench shapes, pointwise + merged gradient kernels -> fused (with the weight image in LDS):
@@ -1599,7 +1603,7 @@ int launch_nbwd(const __bf16* x, const __bf16* h1, const __bf16* dy, const float
 }
 
 template <int C>
-int nfwd_c(const __bf16* x, const float* w1, const float* b1, const float* w2, const float* b2, __bf16* y, __bf16* h1, int B,
+int nfwd_c(const e16* x, const float* w1, const float* b1, const float* w2, const float* b2, e16* y, e16* h1, int B,
            int H, int T, int D, hipStream_t st) {
 #define TT_NFWD(DD)                                                                                                  \
     return h1 ? launch_nconv<C, DD, 0, true>(x, w1, b1, w2, b2, nullptr, y, h1, B, H, T, st)                          \
@@ -1613,7 +1617,7 @@ int nfwd_c(const __bf16* x, const float* w1, const float* b1, const float* w2, c
     return TT_E_UNSUPPORTED;
 }
 template <int C>
-int nbwd_c(const __bf16* x, const __bf16* h1, const __bf16* dy, const float* w1, const float* w2, const float* b2, __bf16* dx,
+int nbwd_c(const e16* x, const e16* h1, const e16* dy, const float* w1, const float* w2, const float* b2, e16* dx,
            float* dw1, float* db1, float* dw2, float* db2, unsigned char* ws, int B, int H, int T, int D, hipStream_t st) {
     switch (D) {
         case 1: return launch_nbwd<C, 1>(x, h1, dy, w1, w2, b2, dx, dw1, db1, dw2, db2, ws, B, H, T, st);
@@ -1645,11 +1649,11 @@ int tt_wide_pack(const float* x, void* out, int B, int C, int H, int T, void* st
     const unsigned grid = (unsigned)((pieces + NT - 1) / NT);
     hipStream_t st = tt_stream(stream);
     switch (C) {
-        case 4: hipLaunchKernelGGL(k_wide_pack<4>, dim3(grid), dim3(NT), 0, st, x, (__bf16*)out, H, T, npix); break;
-        case 8: hipLaunchKernelGGL(k_wide_pack<8>, dim3(grid), dim3(NT), 0, st, x, (__bf16*)out, H, T, npix); break;
-        case 16: hipLaunchKernelGGL(k_wide_pack<16>, dim3(grid), dim3(NT), 0, st, x, (__bf16*)out, H, T, npix); break;
-        case 64: hipLaunchKernelGGL(k_wide_pack<64>, dim3(grid), dim3(NT), 0, st, x, (__bf16*)out, H, T, npix); break;
-        default: hipLaunchKernelGGL(k_wide_pack<32>, dim3(grid), dim3(NT), 0, st, x, (__bf16*)out, H, T, npix);
+        case 4: hipLaunchKernelGGL(k_wide_pack<4>, dim3(grid), dim3(NT), 0, st, x, (e16*)out, H, T, npix); break;
+        case 8: hipLaunchKernelGGL(k_wide_pack<8>, dim3(grid), dim3(NT), 0, st, x, (e16*)out, H, T, npix); break;
+        case 16: hipLaunchKernelGGL(k_wide_pack<16>, dim3(grid), dim3(NT), 0, st, x, (e16*)out, H, T, npix); break;
+        case 64: hipLaunchKernelGGL(k_wide_pack<64>, dim3(grid), dim3(NT), 0, st, x, (e16*)out, H, T, npix); break;
+        default: hipLaunchKernelGGL(k_wide_pack<32>, dim3(grid), dim3(NT), 0, st, x, (e16*)out, H, T, npix);
     }
     TT_LAUNCH_CHECK();
     return 0;
@@ -1661,11 +1665,11 @@ int tt_wide_unpack(const void* in, float* y, int B, int C, int H, int T, void* s
     const unsigned grid = (unsigned)((pieces + NT - 1) / NT);
     hipStream_t st = tt_stream(stream);
     switch (C) {
-        case 4: hipLaunchKernelGGL(k_wide_unpack<4>, dim3(grid), dim3(NT), 0, st, (const __bf16*)in, y, H, T, npix); break;
-        case 8: hipLaunchKernelGGL(k_wide_unpack<8>, dim3(grid), dim3(NT), 0, st, (const __bf16*)in, y, H, T, npix); break;
-        case 16: hipLaunchKernelGGL(k_wide_unpack<16>, dim3(grid), dim3(NT), 0, st, (const __bf16*)in, y, H, T, npix); break;
-        case 64: hipLaunchKernelGGL(k_wide_unpack<64>, dim3(grid), dim3(NT), 0, st, (const __bf16*)in, y, H, T, npix); break;
-        default: hipLaunchKernelGGL(k_wide_unpack<32>, dim3(grid), dim3(NT), 0, st, (const __bf16*)in, y, H, T, npix);
+        case 4: hipLaunchKernelGGL(k_wide_unpack<4>, dim3(grid), dim3(NT), 0, st, (const e16*)in, y, H, T, npix); break;
+        case 8: hipLaunchKernelGGL(k_wide_unpack<8>, dim3(grid), dim3(NT), 0, st, (const e16*)in, y, H, T, npix); break;
+        case 16: hipLaunchKernelGGL(k_wide_unpack<16>, dim3(grid), dim3(NT), 0, st, (const e16*)in, y, H, T, npix); break;
+        case 64: hipLaunchKernelGGL(k_wide_unpack<64>, dim3(grid), dim3(NT), 0, st, (const e16*)in, y, H, T, npix); break;
+        default: hipLaunchKernelGGL(k_wide_unpack<32>, dim3(grid), dim3(NT), 0, st, (const e16*)in, y, H, T, npix);
     }
     TT_LAUNCH_CHECK();
     return 0;
@@ -1674,8 +1678,8 @@ int tt_wide_unpack(const void* in, float* y, int B, int C, int H, int T, void* s
 int tt_wide_rb_fwd(const void* x, const float* w1, const float* b1, const float* w2, const float* b2, void* y, void* h1, int B,
                    int C, int H, int T, int dilation, void* stream) {
     if (!x || !w1 || !b1 || !w2 || !b2 || !y || !shape_ok(B, C, H, T)) return TT_E_BADARG;
-    const __bf16* xi = (const __bf16*)x;
-    __bf16 *yo = (__bf16*)y, *ho = (__bf16*)h1;
+    const e16* xi = (const e16*)x;
+    e16 *yo = (e16*)y, *ho = (e16*)h1;
     hipStream_t st = tt_stream(stream);
     switch (C) {
         case 4: return nfwd_c<4>(xi, w1, b1, w2, b2, yo, ho, B, H, T, dilation, st);
@@ -1694,8 +1698,8 @@ int tt_wide_rb_bwd(const void* x, const void* h1, const void* dy, const float* w
                    void* stream) {
     if (!x || !h1 || !dy || !w1 || !w2 || !b2 || !dx || !dw1 || !db1 || !dw2 || !db2 || !ws || !shape_ok(B, C, H, T))
         return TT_E_BADARG;
-    const __bf16 *xi = (const __bf16*)x, *hi = (const __bf16*)h1, *gi = (const __bf16*)dy;
-    __bf16* go = (__bf16*)dx;
+    const e16 *xi = (const e16*)x, *hi = (const e16*)h1, *gi = (const e16*)dy;
+    e16* go = (e16*)dx;
     unsigned char* w = (unsigned char*)ws;
     hipStream_t st = tt_stream(stream);
     switch (C) {

@@ -1,0 +1,30 @@
+// Names of the C entry points of the 16-bit channel-innermost kernels in the fp16 build (-DTT_F16, see bf16_common.h): every
+// function the five sources define gets the suffix _h, so that both builds link into one library.  Included before
+// include/ttrap.h, whose declarations of these names then declare the _h functions in this translation unit.
+#pragma once
+#if defined(TT_F16)
+#define tt_wide_scratch_bytes tt_wide_scratch_bytes_h
+#define tt_wide_pack tt_wide_pack_h
+#define tt_wide_unpack tt_wide_unpack_h
+#define tt_wide_rb_fwd tt_wide_rb_fwd_h
+#define tt_wide_rb_bwd_is_onepass tt_wide_rb_bwd_is_onepass_h
+#define tt_wide_rb_bwd tt_wide_rb_bwd_h
+#define tt_wide_fused_scratch_bytes tt_wide_fused_scratch_bytes_h
+#define tt_wide_rb_bwd_fused tt_wide_rb_bwd_fused_h
+#define tt_wide_onepass_scratch_bytes tt_wide_onepass_scratch_bytes_h
+#define tt_wide_rb_bwd_onepass tt_wide_rb_bwd_onepass_h
+#define tt_stride16_scratch_bytes tt_stride16_scratch_bytes_h
+#define tt_sconv16_fwd tt_sconv16_fwd_h
+#define tt_sconv16_bwd tt_sconv16_bwd_h
+#define tt_tconv16_fwd tt_tconv16_fwd_h
+#define tt_tconv16_bwd tt_tconv16_bwd_h
+#define tt_latent16_scratch_bytes tt_latent16_scratch_bytes_h
+#define tt_latent16_contract tt_latent16_contract_h
+#define tt_latent16_expand tt_latent16_expand_h
+#define tt_latent16_wgrad tt_latent16_wgrad_h
+#define tt_edge16_scratch_bytes tt_edge16_scratch_bytes_h
+#define tt_convin16_fwd tt_convin16_fwd_h
+#define tt_convin16_bwd tt_convin16_bwd_h
+#define tt_convout16_fwd tt_convout16_fwd_h
+#define tt_convout16_bwd tt_convout16_bwd_h
+#endif

@@ -32,35 +32,35 @@ template <int CT> __device__ __forceinline__ int ochc(int ct, int m) { return (C
 // ---- operand preparation -------------------------------------------------------------------------------------------------
 // Wp1[s][dt][lane][8]: step s = h * (CT/32) + half;  value W[d = 16 dt + (lane & 15)][c = 32 half + 8 (lane >> 4) + e][h]
 template <int CT, int DT>
-__global__ __launch_bounds__(NT) void k_lat_wprep1(const float* __restrict__ w, __bf16* __restrict__ wp, int D, int E) {
+__global__ __launch_bounds__(NT) void k_lat_wprep1(const float* __restrict__ w, e16* __restrict__ wp, int D, int E) {
     constexpr int SPH = CT / 32;
     const int i = blockIdx.x * NT + threadIdx.x;                 // one 16-byte piece
     if (i >= E * SPH * DT * 64) return;
     const int lane = i & 63, dt = (i >> 6) % DT, s = (i >> 6) / DT;
     const int h = s / SPH, half = s - h * SPH;
     const int d = 16 * dt + (lane & 15), c0 = 32 * half + 8 * (lane >> 4);
-    bf16x8 v;
+    e16x8 v;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (__bf16)(d < D ? w[((long)d * CT + c0 + e) * E + h] : 0.f);
-    reinterpret_cast<bf16x8*>(wp)[i] = v;
+    for (int e = 0; e < 8; ++e) v[e] = (e16)(d < D ? w[((long)d * CT + c0 + e) * E + h] : 0.f);
+    reinterpret_cast<e16x8*>(wp)[i] = v;
 }
 // Wp2[h][ct][s][lane][8]: value W[d = 32 s + 8 (lane >> 4) + e][c = ochc(ct, lane & 15)][h]
 template <int CT, int KS>
-__global__ __launch_bounds__(NT) void k_lat_wprep2(const float* __restrict__ w, __bf16* __restrict__ wp, int D, int E) {
+__global__ __launch_bounds__(NT) void k_lat_wprep2(const float* __restrict__ w, e16* __restrict__ wp, int D, int E) {
     constexpr int NC = CT / 16;
     const int i = blockIdx.x * NT + threadIdx.x;
     if (i >= E * NC * KS * 64) return;
     const int lane = i & 63, s = (i >> 6) % KS, ct = ((i >> 6) / KS) % NC, h = (i >> 6) / (KS * NC);
     const int c = ochc<CT>(ct, lane & 15), d0 = 32 * s + 8 * (lane >> 4);
-    bf16x8 v;
+    e16x8 v;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (__bf16)(d0 + e < D ? w[((long)(d0 + e) * CT + c) * E + h] : 0.f);
-    reinterpret_cast<bf16x8*>(wp)[i] = v;
+    for (int e = 0; e < 8; ++e) v[e] = (e16)(d0 + e < D ? w[((long)(d0 + e) * CT + c) * E + h] : 0.f);
+    reinterpret_cast<e16x8*>(wp)[i] = v;
 }
 // zt[b][t][ZS] (bf16) = z[b][d][t] (fp32, Dz rows), row Dz = the constant `fill` when Dz < D (the indicator channel of
 // TimbreTrap.decode, modules.py:139-142, without materialising the concatenation), zero beyond D
 template <int KS>
-__global__ __launch_bounds__(NT) void k_lat_zprep(const float* __restrict__ z, __bf16* __restrict__ zt, int D, int Dz, float fill, int T,
+__global__ __launch_bounds__(NT) void k_lat_zprep(const float* __restrict__ z, e16* __restrict__ zt, int D, int Dz, float fill, int T,
                                                    long npix) {
     constexpr int ZS = 32 * KS + 16, PCS = ZS / 8;
     // a wave = 64 consecutive frames x one 16-byte piece: the fp32 reads are coalesced, the bf16 writes 16 bytes per lane
@@ -69,10 +69,10 @@ __global__ __launch_bounds__(NT) void k_lat_zprep(const float* __restrict__ z, _
     if (pix >= npix) return;
     const int d0 = (int)((i >> 6) % PCS) * 8;
     const long b = pix / T, t = pix - b * T;
-    bf16x8 v;
+    e16x8 v;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (__bf16)(d0 + e < Dz ? z[(b * Dz + d0 + e) * T + t] : (d0 + e < D ? fill : 0.f));
-    *reinterpret_cast<bf16x8*>(zt + pix * ZS + d0) = v;
+    for (int e = 0; e < 8; ++e) v[e] = (e16)(d0 + e < Dz ? z[(b * Dz + d0 + e) * T + t] : (d0 + e < D ? fill : 0.f));
+    *reinterpret_cast<e16x8*>(zt + pix * ZS + d0) = v;
 }
 
 // ---- contract over (h, c) ----------------------------------------------------------------------------------------------------
@@ -80,8 +80,8 @@ __global__ __launch_bounds__(NT) void k_lat_zprep(const float* __restrict__ z, _
 // 62 barrier-separated K steps run with four waves per CU (452 VGPRs at CT = 64: 164 us for 0.52 GB); QN = 1 gives 1024 workgroups
 // of 64 frames, 36 accumulator registers per wave and several workgroups per CU (the weights are re-read from L2).
 template <int CT, int DT, bool GATE, int QN>
-__global__ __launch_bounds__(NT) void k_lat_contract(const __bf16* __restrict__ in, const __bf16* __restrict__ gy,
-                                                      const __bf16* __restrict__ wp, const float* __restrict__ bias,
+__global__ __launch_bounds__(NT) void k_lat_contract(const e16* __restrict__ in, const e16* __restrict__ gy,
+                                                      const e16* __restrict__ wp, const float* __restrict__ bias,
                                                       float* __restrict__ out, int D, int Dout, int E, int T, long npix) {
     constexpr int SPH = CT / 32;
     constexpr int CHUNK = DT * 64 * 16, ROUNDS = (DT * 64 + NT - 1) / NT;      // bytes of one step's weights
@@ -99,28 +99,28 @@ __global__ __launch_bounds__(NT) void k_lat_contract(const __bf16* __restrict__ 
         base[q] = (b * E * T + t) * CT + 8 * g;                  // element offset of row h = 0; + h T CT per row
     }
     auto stage = [&](int s, int buf) {
-        const __bf16* src = wp + (long)s * (DT * 64 * 8);
+        const e16* src = wp + (long)s * (DT * 64 * 8);
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
             const int i = r * NT + wave * 64, p = i + lane;
             glds16(src + (long)(p < DT * 64 ? p : DT * 64 - 1) * 8, smem + buf * (ROUNDS * NT * 16) + (long)i * 16);
         }
     };
-    auto fetch = [&](int s, bf16x8 (&q8)[QN]) {
+    auto fetch = [&](int s, e16x8 (&q8)[QN]) {
         const int h = s / SPH, half = s - h * SPH;
 #pragma unroll
         for (int q = 0; q < QN; ++q) {
             const long off = base[q] + (long)h * T * CT + 32 * half;
             const bool live = ok[q] && s < nsteps;
-            bf16x8 v = *reinterpret_cast<const bf16x8*>(in + (live ? off : 0));
+            e16x8 v = *reinterpret_cast<const e16x8*>(in + (live ? off : 0));
             if (GATE) {
-                const bf16x8 yv = *reinterpret_cast<const bf16x8*>(gy + (live ? off : 0));
+                const e16x8 yv = *reinterpret_cast<const e16x8*>(gy + (live ? off : 0));
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (__bf16)gate_f((float)v[e], (float)yv[e]);
+                for (int e = 0; e < 8; ++e) v[e] = (e16)gate_f((float)v[e], (float)yv[e]);
             }
             if (!live)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
+                for (int e = 0; e < 8; ++e) v[e] = (e16)0.f;
             q8[q] = v;
         }
     };
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(NT) void k_lat_contract(const __bf16* __restrict__ 
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int q = 0; q < QN; ++q) acc[dt][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 bq[QN], bn[QN];
+    e16x8 bq[QN], bn[QN];
     stage(0, 0);
     fetch(0, bq);
     for (int s = 0; s < nsteps; ++s) {
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(NT) void k_lat_contract(const __bf16* __restrict__ 
         const unsigned char* wb = smem + (s & 1) * (ROUNDS * NT * 16);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(wb + ((long)dt * 64 + lane) * 16);
+            const e16x8 a = *reinterpret_cast<const e16x8*>(wb + ((long)dt * 64 + lane) * 16);
 #pragma unroll
             for (int q = 0; q < QN; ++q) acc[dt][q] = mma32(a, bq[q], acc[dt][q]);
         }
@@ -166,8 +166,8 @@ __global__ __launch_bounds__(NT) void k_lat_contract(const __bf16* __restrict__ 
 // QE = 16-frame groups per wave: 4 (256 frames per workgroup) launches ONE workgroup per CU at the bench shape (81 us for 0.26 GB);
 // 2 gives 512 workgroups with half the accumulators.
 template <int CT, int KS, bool ACT, int QE>
-__global__ __launch_bounds__(NT) void k_lat_expand(const __bf16* __restrict__ zt, const __bf16* __restrict__ wp,
-                                                    const float* __restrict__ bias, __bf16* __restrict__ out, int E, int T,
+__global__ __launch_bounds__(NT) void k_lat_expand(const e16* __restrict__ zt, const e16* __restrict__ wp,
+                                                    const float* __restrict__ bias, e16* __restrict__ out, int E, int T,
                                                     long npix) {
     constexpr int NC = CT / 16, NCH = CT / 4, ZS = 32 * KS + 16;
     constexpr int PCS = NC * KS * 64, ROUNDS = (PCS + NT - 1) / NT;            // 16-byte pieces of one row's weights
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(NT) void k_lat_expand(const __bf16* __restrict__ zt
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
     const long p0 = (long)blockIdx.x * (64 * QE) + wave * (16 * QE);
-    bf16x8 bz[QE][KS];
+    e16x8 bz[QE][KS];
     long obase[QE]; bool ok[QE];
 #pragma unroll
     for (int q = 0; q < QE; ++q) {
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(NT) void k_lat_expand(const __bf16* __restrict__ zt
         ok[q] = pix < npix;
         const long pc = ok[q] ? pix : 0;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) bz[q][s] = *reinterpret_cast<const bf16x8*>(zt + pc * ZS + 32 * s + 8 * g);
+        for (int s = 0; s < KS; ++s) bz[q][s] = *reinterpret_cast<const e16x8*>(zt + pc * ZS + 32 * s + 8 * g);
         const long b = pc / T, t = pc - b * T;
         obase[q] = (b * E * T + t) * CT + NCH * g;
     }
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(NT) void k_lat_expand(const __bf16* __restrict__ zt
 #pragma unroll
     for (int e = 0; e < NCH; ++e) br[e] = ACT ? bias[NCH * g + e] : 0.f;
     auto stage = [&](int h, int buf) {
-        const __bf16* src = wp + (long)h * (PCS * 8);
+        const e16* src = wp + (long)h * (PCS * 8);
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
             const int i = r * NT + wave * 64, p = i + lane;
@@ -213,24 +213,24 @@ __global__ __launch_bounds__(NT) void k_lat_expand(const __bf16* __restrict__ zt
         for (int ct = 0; ct < NC; ++ct)
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(wb + (((long)ct * KS + s) * 64 + lane) * 16);
+                const e16x8 a = *reinterpret_cast<const e16x8*>(wb + (((long)ct * KS + s) * 64 + lane) * 16);
 #pragma unroll
                 for (int q = 0; q < QE; ++q) acc[ct][q] = mma32(a, bz[q][s], acc[ct][q]);
             }
 #pragma unroll
         for (int q = 0; q < QE; ++q) {
             if (!ok[q]) continue;
-            __bf16* d = out + obase[q] + (long)h * T * CT;
+            e16* d = out + obase[q] + (long)h * T * CT;
 #pragma unroll
             for (int c8 = 0; c8 < NCH / 8; ++c8) {
-                bf16x8 o;
+                e16x8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int ch = 8 * c8 + e;                   // lane channel NCH g + ch = tile ch / 4, row 4g + ch % 4
                     const float a = acc[ch >> 2][q][ch & 3] + br[ch];
-                    o[e] = (__bf16)(ACT ? elu_f(a) : a);
+                    o[e] = (e16)(ACT ? elu_f(a) : a);
                 }
-                *reinterpret_cast<bf16x8*>(d + 8 * c8) = o;
+                *reinterpret_cast<e16x8*>(d + 8 * c8) = o;
             }
         }
     }
@@ -240,8 +240,8 @@ __global__ __launch_bounds__(NT) void k_lat_expand(const __bf16* __restrict__ zt
 template <int CT> __device__ __forceinline__ int gswz(int p) { return CT == 64 ? ((p >> 1) & 3) : ((p >> 2) & 1); }
 
 template <int CT, int DT, int KS, bool GATE>
-__global__ __launch_bounds__(NT, LAT_WGRAD_WAVES) void k_lat_wgrad(const __bf16* __restrict__ zt, const __bf16* __restrict__ g_in,
-                                                   const __bf16* __restrict__ gy, float* __restrict__ part,
+__global__ __launch_bounds__(NT, LAT_WGRAD_WAVES) void k_lat_wgrad(const e16* __restrict__ zt, const e16* __restrict__ g_in,
+                                                   const e16* __restrict__ gy, float* __restrict__ part,
                                                    float* __restrict__ dbpart, int E, int T, long npix, int nsplit) {
     constexpr int NC = CT / 16, ZS = 32 * KS + 16, ZB = ZS * 2, GB = CT * 2;   // bytes per pixel of the two images
     constexpr int ZPC = 64 * ZB / 16, GPC = 64 * GB / 16;                      // pieces per 64-pixel chunk
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(NT, LAT_WGRAD_WAVES) void k_lat_wgrad(const __bf16*
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float dbacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const __bf16* zero = reinterpret_cast<const __bf16*>(&g_wzero16);
+    const e16* zero = reinterpret_cast<const e16*>(&g_wzero16);
     // A chunk is 64 consecutive (clip, frame) pixels: clip and frame of its first pixel are wave-uniform 32-bit scalars, a lane adds its
     // pixel's offset and wraps once (T >= 64) -- the per-piece 64-bit division pixel / T this replaces was most of the staging's
     // ~400 vector instructions per chunk, next to 18 matrix instructions of work (npix < 2^31: checked by the launcher).
@@ -268,14 +268,14 @@ __global__ __launch_bounds__(NT, LAT_WGRAD_WAVES) void k_lat_wgrad(const __bf16*
         const int b0 = px0 / T, t00 = px0 - b0 * T;
         __syncthreads();
         const bool full = px0 + 64 <= npx;                        // every chunk but possibly the last
-        const __bf16* zc = zt + (long)px0 * ZS;
+        const e16* zc = zt + (long)px0 * ZS;
 #pragma unroll
         for (int r = 0; r < ZR; ++r) {                           // zt rows of the chunk are one contiguous run
             const int i = r * NT + wave * 64, p = i + lane;
             const bool okp = p < ZPC && (full || px0 + p * 16 / ZB < npx);
             glds16(okp ? zc + p * 8 : zero, zs + (long)i * 16);
         }
-        bf16x8 v[GATE ? GR : 1], yv[GATE ? GR : 1];
+        e16x8 v[GATE ? GR : 1], yv[GATE ? GR : 1];
 #pragma unroll
         for (int r = 0; r < GR; ++r) {
             const int i = r * NT + wave * 64, p = i + lane;
@@ -287,21 +287,21 @@ __global__ __launch_bounds__(NT, LAT_WGRAD_WAVES) void k_lat_wgrad(const __bf16*
             else { const int e = t / T; b += e; t -= e * T; }
             const long off = okp ? (long)((b * E + h) * T + t) * CT + cg * 8 : 0;
             if constexpr (!GATE) glds16(okp ? g_in + off : zero, gs + (long)i * 16);
-            else { v[r] = *reinterpret_cast<const bf16x8*>(g_in + off); yv[r] = *reinterpret_cast<const bf16x8*>(gy + off); }
+            else { v[r] = *reinterpret_cast<const e16x8*>(g_in + off); yv[r] = *reinterpret_cast<const e16x8*>(gy + off); }
         }
         if constexpr (GATE) {
 #pragma unroll
             for (int r = 0; r < GR; ++r) {
                 const int p = r * NT + tid;
                 const bool okp = p < GPC && px0 + p / (GB / 16) < npx;
-                bf16x8 o;
+                e16x8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float gq = okp ? gate_f((float)v[r][e], (float)yv[r][e]) : 0.f;
                     dbacc[e] += gq;
-                    o[e] = (__bf16)gq;
+                    o[e] = (e16)gq;
                 }
-                if (p < GPC) *reinterpret_cast<bf16x8*>(gs + (long)p * 16) = o;
+                if (p < GPC) *reinterpret_cast<e16x8*>(gs + (long)p * 16) = o;
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -313,13 +313,13 @@ __global__ __launch_bounds__(NT, LAT_WGRAD_WAVES) void k_lat_wgrad(const __bf16*
                 lo = lds_tr16(gs + (long)p * GB + ((ct ^ gswz<CT>(p)) << 5) + 8 * trq);
                 hi = lds_tr16(gs + (long)(p + 16) * GB + ((ct ^ gswz<CT>(p + 16)) << 5) + 8 * trq);
             }
-            const bf16x8 bq = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            const e16x8 bq = __builtin_bit_cast(e16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 const int p = 32 * sub + 4 * g + trj;
                 const s16x4 alo = lds_tr16(zs + (long)p * ZB + dt * 32 + 8 * trq);
                 const s16x4 ahi = lds_tr16(zs + (long)(p + 16) * ZB + dt * 32 + 8 * trq);
-                acc[dt] = mma32(__builtin_bit_cast(bf16x8, __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7)), bq, acc[dt]);
+                acc[dt] = mma32(__builtin_bit_cast(e16x8, __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7)), bq, acc[dt]);
             }
         }
     }
@@ -382,11 +382,11 @@ template <int CT, int DT, int KS> struct LatSizes {
 };
 
 template <int CT, int DT, int KS, bool GATE>
-int run_contract(const __bf16* in, const __bf16* gy, const float* w, const float* bias, float* out, unsigned char* ws, int B, int D,
+int run_contract(const e16* in, const e16* gy, const float* w, const float* bias, float* out, unsigned char* ws, int B, int D,
                  int Dout, int E, int T, hipStream_t st) {
     using L = LatSizes<CT, DT, KS>;
     const long npix = (long)B * T;
-    __bf16* wp = reinterpret_cast<__bf16*>(ws);
+    e16* wp = reinterpret_cast<e16*>(ws);
     const int pieces = E * L::SPH * DT * 64;
     hipLaunchKernelGGL((k_lat_wprep1<CT, DT>), dim3((pieces + NT - 1) / NT), dim3(NT), 0, st, w, wp, D, E);
     TT_LAUNCH_CHECK();
@@ -401,12 +401,12 @@ int run_contract(const __bf16* in, const __bf16* gy, const float* w, const float
 }
 
 template <int CT, int DT, int KS, bool ACT>
-int run_expand(const float* z, int Dz, float fill, const float* w, const float* bias, __bf16* out, unsigned char* ws, int B, int D, int E,
+int run_expand(const float* z, int Dz, float fill, const float* w, const float* bias, e16* out, unsigned char* ws, int B, int D, int E,
                int T, hipStream_t st) {
     using L = LatSizes<CT, DT, KS>;
     const long npix = (long)B * T;
-    __bf16* wp = reinterpret_cast<__bf16*>(ws);
-    __bf16* zt = reinterpret_cast<__bf16*>(ws + ((L::wp2_bytes(E) + 255) / 256) * 256);
+    e16* wp = reinterpret_cast<e16*>(ws);
+    e16* zt = reinterpret_cast<e16*>(ws + ((L::wp2_bytes(E) + 255) / 256) * 256);
     const int pieces = E * L::NC * KS * 64;
     hipLaunchKernelGGL((k_lat_wprep2<CT, KS>), dim3((pieces + NT - 1) / NT), dim3(NT), 0, st, w, wp, D, E);
     TT_LAUNCH_CHECK();
@@ -424,12 +424,12 @@ int run_expand(const float* z, int Dz, float fill, const float* w, const float* 
 }
 
 template <int CT, int DT, int KS, bool GATE>
-int run_wgrad(const float* z, int Dz, float fill, const __bf16* g_in, const __bf16* gy, float* dw, float* db, unsigned char* ws, int B,
+int run_wgrad(const float* z, int Dz, float fill, const e16* g_in, const e16* gy, float* dw, float* db, unsigned char* ws, int B,
               int D, int E, int T, hipStream_t st) {
     using L = LatSizes<CT, DT, KS>;
     const long npix = (long)B * T;
     if (npix >= (1l << 30) || (long)B * E * T >= (1l << 31)) return TT_E_UNSUPPORTED;      // 32-bit pixel arithmetic in k_lat_wgrad
-    __bf16* zt = reinterpret_cast<__bf16*>(ws);
+    e16* zt = reinterpret_cast<e16*>(ws);
     float* part = reinterpret_cast<float*>(ws + ((L::zt_bytes(npix) + 255) / 256) * 256);
     float* dbpart = part + (long)NSPLIT * E * 4 * DT * 256;
     const long zp = ((npix + 63) / 64) * 64 * (L::ZS / 8);
@@ -474,7 +474,7 @@ int tt_latent16_contract(const void* in, const void* gy, const float* w, const f
                          int Dout, int E, int T, void* stream) {
     if (!in || !w || !out || !ws || B <= 0 || E <= 0 || T <= 0 || T % 16 || Dout < 1 || Dout > D) return TT_E_BADARG;
     hipStream_t st = tt_stream(stream);
-    const __bf16 *i = (const __bf16*)in, *y = (const __bf16*)gy;
+    const e16 *i = (const e16*)in, *y = (const e16*)gy;
     unsigned char* s = (unsigned char*)ws;
     switch (cfg_of(CT, D)) {
         case 1: return y ? run_contract<32, 3, 2, true>(i, y, w, bias, out, s, B, D, Dout, E, T, st) : run_contract<32, 3, 2, false>(i, y, w, bias, out, s, B, D, Dout, E, T, st);
@@ -489,7 +489,7 @@ int tt_latent16_expand(const float* z, int Dz, float fill, const float* w, const
                        int E, int T, void* stream) {
     if (!z || !w || !out || !ws || B <= 0 || E <= 0 || T <= 0 || T % 16 || (Dz != D && Dz != D - 1)) return TT_E_BADARG;
     hipStream_t st = tt_stream(stream);
-    __bf16* o = (__bf16*)out;
+    e16* o = (e16*)out;
     unsigned char* s = (unsigned char*)ws;
     switch (cfg_of(CT, D)) {
         case 1: return bias ? run_expand<32, 3, 2, true>(z, Dz, fill, w, bias, o, s, B, D, E, T, st) : run_expand<32, 3, 2, false>(z, Dz, fill, w, bias, o, s, B, D, E, T, st);
@@ -503,7 +503,7 @@ int tt_latent16_wgrad(const float* z, int Dz, float fill, const void* g, const v
                       int D, int E, int T, void* stream) {
     if (!z || !g || !dw || !ws || (gy && !db) || B <= 0 || E <= 0 || T <= 0 || T % 16 || (Dz != D && Dz != D - 1)) return TT_E_BADARG;
     hipStream_t st = tt_stream(stream);
-    const __bf16 *gi = (const __bf16*)g, *y = (const __bf16*)gy;
+    const e16 *gi = (const e16*)g, *y = (const e16*)gy;
     unsigned char* s = (unsigned char*)ws;
     switch (cfg_of(CT, D)) {
         case 1: return y ? run_wgrad<32, 3, 2, true>(z, Dz, fill, gi, y, dw, db, s, B, D, E, T, st) : run_wgrad<32, 3, 2, false>(z, Dz, fill, gi, y, dw, db, s, B, D, E, T, st);

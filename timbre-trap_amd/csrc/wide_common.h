@@ -33,7 +33,7 @@ template <int C> struct WK {
 // channel-innermost LDS image IW pixels wide in the fswz layout.
 template <int C, int D, int IW>
 __device__ __forceinline__ void conv_taps(const unsigned char* img, int row, int col, int g,
-                                          const bf16x8 (&A)[WK<C>::NK][WK<C>::NCT], f32x4 (&acc)[WK<C>::NCT], bf16x8& centre) {
+                                          const e16x8 (&A)[WK<C>::NK][WK<C>::NCT], f32x4 (&acc)[WK<C>::NCT], e16x8& centre) {
     constexpr int NK = WK<C>::NK, NCT = WK<C>::NCT, PB = C * 2;
     const int gsel = C == 32 ? g : (g & 1);
 #pragma unroll
@@ -42,7 +42,7 @@ __device__ __forceinline__ void conv_taps(const unsigned char* img, int row, int
         if (tap > 8) tap = 8;                                    // the weights of the missing tenth tap are zero
         const int kh = tap / 3, kw = tap - 3 * kh;
         const int xc = col + kw * D;
-        const bf16x8 bq = *reinterpret_cast<const bf16x8*>(img + ((row + kh * D) * IW + xc) * PB + 16 * (gsel ^ fswz<C>(xc)));
+        const e16x8 bq = *reinterpret_cast<const e16x8*>(img + ((row + kh * D) * IW + xc) * PB + 16 * (gsel ^ fswz<C>(xc)));
         if (C == 32 && k == 4) centre = bq;
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) acc[ct] = mma32(A[k][ct], bq, acc[ct]);

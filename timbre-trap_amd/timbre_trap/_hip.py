@@ -20,7 +20,10 @@ CSRC = os.path.join(PKG_ROOT, 'csrc')
 LIB_PATH = os.path.join(PKG_ROOT, 'lib', 'libttrap_hip.so')
 if os.environ.get('TTRAP_LIB'):                         # tuning: an alternative build of the same sources (tools/build_variant.sh)
     LIB_PATH = os.path.join(PKG_ROOT, 'lib', os.environ['TTRAP_LIB'])
-SOURCES = ['cqt.hip', 'conv_generic.hip', 'conv_mfma.hip', 'conv_small.hip', 'conv_wide_bf16.hip', 'conv_level_bf16.hip', 'conv_stride_bf16.hip', 'latent_bf16.hip', 'conv_edge_bf16.hip', 'gemm.hip', 'losses.hip']
+SOURCES = ['cqt.hip', 'conv_generic.hip', 'conv_mfma.hip', 'conv_small.hip', 'conv_wide_bf16.hip', 'conv_level_bf16.hip', 'conv_stride_bf16.hip',
+           'latent_bf16.hip', 'conv_edge_bf16.hip', 'gemm.hip', 'losses.hip',
+           # the 16-bit channels-last sources a second time with fp16 elements (two-line wrappers: #define TT_F16 + #include)
+           'conv_wide_f16.hip', 'conv_level_f16.hip', 'conv_stride_f16.hip', 'latent_f16.hip', 'conv_edge_f16.hip']
 
 _lib = None
 
@@ -97,6 +100,14 @@ _PROTOS = {
     'tt_l2norm': (c_int, [P, P, P, L, P]),
     'tt_adamw_step': (c_int, [P, P, P, P, P, L, F_, F_, F_, F_, F_, I, F_, I, P]),
 }
+# fp16 twins (include/ttrap.h: suffix _h): the 16-bit channels-last sources compiled a second time with -DTT_F16
+HALF_TWINS = ('tt_wide_scratch_bytes', 'tt_wide_pack', 'tt_wide_unpack', 'tt_wide_rb_fwd', 'tt_wide_rb_bwd', 'tt_wide_fused_scratch_bytes',
+              'tt_wide_rb_bwd_fused', 'tt_wide_onepass_scratch_bytes', 'tt_wide_rb_bwd_onepass', 'tt_wide_rb_bwd_is_onepass',
+              'tt_stride16_scratch_bytes', 'tt_sconv16_fwd', 'tt_sconv16_bwd', 'tt_tconv16_fwd', 'tt_tconv16_bwd', 'tt_latent16_scratch_bytes',
+              'tt_latent16_contract', 'tt_latent16_expand', 'tt_latent16_wgrad', 'tt_edge16_scratch_bytes', 'tt_convin16_fwd', 'tt_convin16_bwd',
+              'tt_convout16_fwd', 'tt_convout16_bwd', 'tt_scaled_add16', 'tt_dot16')
+for _n in HALF_TWINS:
+    _PROTOS[_n + '_h'] = _PROTOS[_n]
 EXPORTED_SYMBOLS = tuple(_PROTOS)
 # Per-source compiler flags.  cqt.hip: the SLP vectoriser turns the complex butterflies into v_pk_*_f32 plus the register moves that
 # form their aligned pairs; on gfx950 a packed fp32 op issues at about half the rate of a plain one (tools/probes/pkfma_probe.cpp:
@@ -109,24 +120,35 @@ def build(verbose=False, force=False):
     """Compile every HIP source for gfx950 into timbre-trap_amd/lib/libttrap_hip.so (in-tree)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     deps = srcs + [os.path.join(CSRC, 'common.h'), os.path.join(REPO_ROOT, 'include', 'ttrap.h')]
-    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')] + [os.path.abspath(__file__)]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     objs = []
-    procs = []
+    jobs = []
     for s in srcs:
-        o = os.path.join(PKG_ROOT, 'lib', os.path.basename(s).replace('.hip', '.o'))
+        base = os.path.basename(s)
+        o = os.path.join(PKG_ROOT, 'lib', base.replace('.hip', '.o'))
         objs.append(o)
-        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC'] + EXTRA_FLAGS.get(os.path.basename(s), []) + ['-c', s, '-o', o]
-        if verbose:
-            print(' '.join(cmd), file=sys.stderr)
-        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-    for cmd, pr in procs:
+        jobs.append([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC'] + EXTRA_FLAGS.get(base, []) + ['-c', s, '-o', o])
+    # at most as many compilers at once as there are cores (the largest sources take ~1 GB each)
+    width = max(1, min(len(jobs), os.cpu_count() or 1))
+    running, failed = [], None
+    pending = list(jobs)
+    while pending or running:
+        while pending and len(running) < width:
+            cmd = pending.pop(0)
+            if verbose:
+                print(' '.join(cmd), file=sys.stderr)
+            running.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        cmd, pr = running.pop(0)
         out, _ = pr.communicate()
-        if pr.returncode != 0:
-            raise RuntimeError('hipcc failed: %s\n%s' % (' '.join(cmd), out.decode()))
+        if pr.returncode != 0 and failed is None:
+            failed = 'hipcc failed: %s\n%s' % (' '.join(cmd), out.decode())
+            pending = []
+    if failed:
+        raise RuntimeError(failed)
     # objects of sources that no longer exist must not travel to the GPU box with the snapshot
     for f in os.listdir(os.path.dirname(LIB_PATH)):
         if f.endswith('.o') and os.path.join(os.path.dirname(LIB_PATH), f) not in objs:

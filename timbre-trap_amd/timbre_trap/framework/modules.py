@@ -213,8 +213,8 @@ class TimbreTrap(nn.Module):
     def decode(self, latents, embeddings=None, transcribe=False):
         """latents (B,D,T) -> logits (B,2,F,T); the extra latent channel is 1 for reconstruction, 0 for transcription."""
         value = 0.0 if transcribe else 1.0
-        if ops.wide_storage() == 'bf16':
-            # the bf16 latent head takes the indicator as a constant channel: no concatenated copy of the latents, and their
+        if ops.cl16_mode():
+            # the 16-bit latent head takes the indicator as a constant channel: no concatenated copy of the latents, and their
             # gradient comes back contiguous
             return self.decoder(latents, embeddings, indicator=value)
         indicator = torch.full_like(latents[..., :1, :], value)

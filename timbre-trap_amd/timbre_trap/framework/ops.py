@@ -28,14 +28,18 @@ SAVE_HIDDEN = os.environ.get('TTRAP_SAVE_HIDDEN', '1') != '0'
 #   'fp32'    v_mfma_f32_16x16x4_f32, exact fp32 -- what every parity test pins
 #   'bf16x3'  fp32 tensors, every operand fed as hi + lo bf16 (three products): fp32-class results at 16/3 of the fp32 rate
 #   'bf16'    operands rounded to bf16, fp32 accumulation (v_mfma_f32_16x16x32_bf16)
-#   'auto'    (default) 'bf16' inside a ``torch.autocast('cuda')`` region, 'fp32' outside -- the reference runs its train
-#             step under autocast (experiments/train.py:415: half-precision convolutions) and everything else in fp32
-#             (experiments/evaluate.py), so the unmodified scripts get the same split here.
+#   'fp16'    the same kernels with fp16 elements (v_mfma_f32_16x16x32_f16; the _h entry points of include/ttrap.h)
+#   'auto'    (default) inside a ``torch.autocast('cuda')`` region the region's own dtype -- 'fp16' for the reference's unmodified
+#             ``torch.autocast('cuda')`` (experiments/train.py:415 takes torch's default, float16, no GradScaler), 'bf16' for
+#             ``torch.autocast('cuda', dtype=torch.bfloat16)`` (bench.py, BASELINE config[2]) -- and 'fp32' outside: the reference
+#             runs its train step under autocast and everything else in fp32 (experiments/evaluate.py), so the unmodified scripts
+#             get the same split here.
 PRECISION = os.environ.get('TTRAP_PRECISION', 'auto')
 # Storage of the activations INSIDE the wide levels (C = 16, 32: the three residual blocks of an Encoder/DecoderBlock):
 #   'fp32'  channel-planar fp32 tensors, one ResBlockFn per block (any precision above)
 #   'bf16'  bf16 channel-innermost tensors in HBM, csrc/conv_wide_bf16.hip: the "bf16 MFMA conv path" of BASELINE config[2].
-# Default: follows the precision ('bf16' means bf16 operands AND bf16 storage); TTRAP_WIDE_STORAGE overrides.
+#   'fp16'  the same with fp16 elements.
+# Default: follows the precision ('bf16' / 'fp16' mean 16-bit operands AND 16-bit storage); TTRAP_WIDE_STORAGE overrides.
 WIDE_STORAGE = os.environ.get('TTRAP_WIDE_STORAGE', '')
 WIDE_CHANNELS = (4, 8, 16, 32)        # every level of the model (C = 4 needs an even number of frames)
 
@@ -43,21 +47,55 @@ WIDE_CHANNELS = (4, 8, 16, 32)        # every level of the model (C = 4 needs an
 def precision():
     """The arithmetic in force for the call being made: PRECISION with 'auto' resolved against the autocast state."""
     if PRECISION == 'auto':
-        return 'bf16' if torch.is_autocast_enabled('cuda') else 'fp32'
-    if PRECISION not in ('fp32', 'bf16', 'bf16x3'):
-        raise ValueError('TTRAP_PRECISION / ops.PRECISION must be auto, fp32, bf16x3 or bf16, got %r' % (PRECISION,))
+        if not torch.is_autocast_enabled('cuda'):
+            return 'fp32'
+        return 'fp16' if torch.get_autocast_dtype('cuda') == torch.float16 else 'bf16'
+    if PRECISION not in ('fp32', 'bf16', 'fp16', 'bf16x3'):
+        raise ValueError('TTRAP_PRECISION / ops.PRECISION must be auto, fp32, bf16x3, bf16 or fp16, got %r' % (PRECISION,))
     return PRECISION
 
 
 def wide_storage():
-    mode = WIDE_STORAGE or ('bf16' if precision() == 'bf16' else 'fp32')
-    if mode not in ('fp32', 'bf16'):
-        raise ValueError('TTRAP_WIDE_STORAGE / ops.WIDE_STORAGE must be fp32 or bf16, got %r' % (mode,))
+    p = precision()
+    mode = WIDE_STORAGE or (p if p in ('bf16', 'fp16') else 'fp32')
+    if mode not in ('fp32', 'bf16', 'fp16'):
+        raise ValueError('TTRAP_WIDE_STORAGE / ops.WIDE_STORAGE must be fp32, bf16 or fp16, got %r' % (mode,))
     return mode
 
 
+def cl16_mode():
+    """True where the layers run on 16-bit channels-last activations (either element type)."""
+    return wide_storage() in ('bf16', 'fp16')
+
+
+def cl16_dtype():
+    """Element type of the 16-bit channels-last activations a forward creates from fp32 inputs in the current mode."""
+    return torch.float16 if wide_storage() == 'fp16' else torch.bfloat16
+
+
+class _HalfLib:
+    """The fp16 twins of the 16-bit entry points (include/ttrap.h "fp16 twins"): attribute tt_x resolves to tt_x_h."""
+
+    def __init__(self, lib):
+        self._lib = lib
+
+    def __getattr__(self, name):
+        return getattr(self._lib, name + '_h' if name in _hip.HALF_TWINS else name)
+
+
+def lib16(t):
+    """The library as seen by a 16-bit channels-last tensor (or dtype) ``t``: bf16 -> the plain entry points, fp16 -> the _h twins."""
+    dtype = t if isinstance(t, torch.dtype) else t.dtype
+    if dtype == torch.float16:
+        return _HalfLib(_hip.lib())
+    if dtype != torch.bfloat16:
+        raise TypeError('16-bit channels-last kernels take bfloat16 or float16 tensors, got %s' % (dtype,))
+    return _hip.lib()
+
+
 def _flags():
-    return {'fp32': 0, 'bf16': 1, 'bf16x3': 2}[precision()]
+    # the fp32-tensor kernels (shapes without a 16-bit channels-last kernel) know bf16 operand rounding only: fp16 mode takes it too
+    return {'fp32': 0, 'bf16': 1, 'fp16': 1, 'bf16x3': 2}[precision()]
 
 
 @dataclass(frozen=True)
@@ -174,7 +212,7 @@ class ConvFn(torch.autograd.Function):
 def conv(x, w, b, cfg):
     same3 = (cfg.kind == 'conv' and (cfg.KH, cfg.KW, cfg.stride, cfg.dil, cfg.pad_h, cfg.pad_w) == (3, 3, 1, 1, 1, 1) and b is not None
              and x.dim() == 4 and x.size(3) % 2 == 0 and FUSED_RESBLOCK and x.size(2) * x.size(3) * 4 < 2 ** 31)
-    if same3 and cfg.act == ACT_ELU and w.shape == (4, 2, 3, 3) and not is_cl16(x) and wide_storage() == 'bf16':
+    if same3 and cfg.act == ACT_ELU and w.shape == (4, 2, 3, 3) and not is_cl16(x) and cl16_mode():
         return ConvIn16Fn.apply(x, w, b)                         # Encoder.convin feeding the bf16 channels-last interior
     if same3 and cfg.act == ACT_NONE and w.shape == (2, 4, 3, 3) and is_cl16(x):
         return ConvOut16Fn.apply(x, w, b)                        # Decoder.convout leaving it
@@ -342,7 +380,7 @@ def _stride16_ok(C, T, w, b):
 def strided_conv(x, w, b, win, hop):
     """Conv2d(C, Cout, (win,1), stride (hop,1)) + ELU."""
     C = x.size(1)
-    if (win == 4 and hop == 2 and x.size(2) >= 4 and _stride16_ok(C, x.size(-1), w, b) and (is_cl16(x) or wide_storage() == 'bf16')
+    if (win == 4 and hop == 2 and x.size(2) >= 4 and _stride16_ok(C, x.size(-1), w, b) and (is_cl16(x) or cl16_mode())
             and _i32_ok(x, 2 * C)):
         return SConv16Fn.apply(to_cl16(x), w, b)
     x = to_planar32(x)
@@ -355,7 +393,7 @@ def transposed_conv(x, w, b, win, hop, out_pad):
     """ConvTranspose2d(Cin, C, (win,1), stride (hop,1), output_padding (out_pad,0)) + ELU."""
     C = w.size(1)
     if (win == 4 and hop == 2 and x.size(1) == 2 * C and out_pad in (0, 1) and _stride16_ok(C, x.size(-1), w, b)
-            and (is_cl16(x) or wide_storage() == 'bf16') and (2 * x.size(2) + 2 + out_pad) * x.size(3) * 2 * C < 2 ** 31):
+            and (is_cl16(x) or cl16_mode()) and (2 * x.size(2) + 2 + out_pad) * x.size(3) * 2 * C < 2 ** 31):
         return TConv16Fn.apply(to_cl16(x), w, b, out_pad)
     x = to_planar32(x)
     if (FUSED_RESBLOCK and win == 4 and hop == 2 and C in FUSED_CHANNELS and w.shape == (2 * C, C, 4, 1)
@@ -387,25 +425,25 @@ CL16_CHANNELS = (4, 8, 16, 32, 64)
 
 
 def is_cl16(x):
-    return (x.dtype == torch.bfloat16 and x.dim() == 4 and x.stride(1) == 1 and x.stride(3) == x.size(1)
+    return (x.dtype in (torch.bfloat16, torch.float16) and x.dim() == 4 and x.stride(1) == 1 and x.stride(3) == x.size(1)
             and x.stride(2) == x.size(1) * x.size(3) and x.stride(0) == x.size(1) * x.size(2) * x.size(3))
 
 
-def new_cl16(B, C, H, T, device):
-    return torch.empty((B, H, T, C), dtype=torch.bfloat16, device=device).permute(0, 3, 1, 2)
+def new_cl16(B, C, H, T, device, dtype=torch.bfloat16):
+    return torch.empty((B, H, T, C), dtype=dtype, device=device).permute(0, 3, 1, 2)
 
 
-def _pack(x32):
+def _pack(x32, dtype=torch.bfloat16):
     B, C, H, T = x32.shape
-    out = new_cl16(B, C, H, T, x32.device)
-    check(_hip.lib().tt_wide_pack(ptr(x32), ptr(out), B, C, H, T, stream_ptr()), 'tt_wide_pack')
+    out = new_cl16(B, C, H, T, x32.device, dtype)
+    check(lib16(dtype).tt_wide_pack(ptr(x32), ptr(out), B, C, H, T, stream_ptr()), 'tt_wide_pack')
     return out
 
 
 def _unpack(x16):
     B, C, H, T = x16.shape
     out = torch.empty((B, C, H, T), dtype=torch.float32, device=x16.device)
-    check(_hip.lib().tt_wide_unpack(ptr(x16), ptr(out), B, C, H, T, stream_ptr()), 'tt_wide_unpack')
+    check(lib16(x16).tt_wide_unpack(ptr(x16), ptr(out), B, C, H, T, stream_ptr()), 'tt_wide_unpack')
     return out
 
 
@@ -419,13 +457,13 @@ def _i32_ok(x, channels=None):
     return x.size(2) * x.size(3) * (channels or x.size(1)) < 2 ** 31
 
 
-def _as_cl16(t):
-    """Any (B,C,H,T) tensor as cl16 (no autograd): used on incoming gradients."""
-    if is_cl16(t):
+def _as_cl16(t, dtype=torch.bfloat16):
+    """Any (B,C,H,T) tensor as cl16 of element type ``dtype`` (no autograd): used on incoming gradients."""
+    if is_cl16(t) and t.dtype == dtype:
         return t
     if t.dtype == torch.float32 and _cl16_ok(t.size(1), t.size(3)):
-        return _pack(t.contiguous())
-    return t.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        return _pack(t.contiguous(), dtype)
+    return t.to(dtype).contiguous(memory_format=torch.channels_last)
 
 
 class ToCL16Fn(torch.autograd.Function):
@@ -434,11 +472,12 @@ class ToCL16Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
         _hip.require_cuda(x)
-        return _pack(_f32c(x))
+        ctx.dtype = cl16_dtype()
+        return _pack(_f32c(x), ctx.dtype)
 
     @staticmethod
     def backward(ctx, g):
-        return _unpack(_as_cl16(g))
+        return _unpack(_as_cl16(g, ctx.dtype))
 
 
 class ToPlanar32Fn(torch.autograd.Function):
@@ -446,11 +485,12 @@ class ToPlanar32Fn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x):
+        ctx.dtype = x.dtype
         return _unpack(x)
 
     @staticmethod
     def backward(ctx, g):
-        return _pack(_f32c(g))
+        return _pack(_f32c(g), ctx.dtype)
 
 
 def to_cl16(x):
@@ -476,8 +516,8 @@ class ConvIn16Fn(torch.autograd.Function):
         _hip.require_cuda(x, w)
         x = _f32c(x)
         B, _, H, T = x.shape
-        y = new_cl16(B, 4, H, T, x.device)
-        check(_hip.lib().tt_convin16_fwd(ptr(x), ptr(w), ptr(b), ptr(y), B, H, T, stream_ptr()), 'tt_convin16_fwd')
+        y = new_cl16(B, 4, H, T, x.device, cl16_dtype())
+        check(lib16(y).tt_convin16_fwd(ptr(x), ptr(w), ptr(b), ptr(y), B, H, T, stream_ptr()), 'tt_convin16_fwd')
         ctx.params = (w, b)
         ctx.save_for_backward(x, w, y)
         return y
@@ -486,8 +526,8 @@ class ConvIn16Fn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w, y = ctx.saved_tensors
         B, _, H, T = x.shape
-        lib = _hip.lib()
-        g = _as_cl16(dy)
+        lib = lib16(y)
+        g = _as_cl16(dy, y.dtype)
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         (dw, r1), (db, r2) = (_grad_target(t) for t in ctx.params)
         ws = torch.empty(lib.tt_edge16_scratch_bytes(), dtype=torch.uint8, device=x.device)
@@ -503,7 +543,7 @@ class ConvOut16Fn(torch.autograd.Function):
     def forward(ctx, x, w, b):
         B, _, H, T = x.shape
         y = torch.empty((B, 2, H, T), dtype=torch.float32, device=x.device)
-        check(_hip.lib().tt_convout16_fwd(ptr(x), ptr(w), ptr(b), ptr(y), B, H, T, stream_ptr()), 'tt_convout16_fwd')
+        check(lib16(x).tt_convout16_fwd(ptr(x), ptr(w), ptr(b), ptr(y), B, H, T, stream_ptr()), 'tt_convout16_fwd')
         ctx.params = (w, b)
         ctx.save_for_backward(x, w)
         return y
@@ -512,9 +552,9 @@ class ConvOut16Fn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         B, _, H, T = x.shape
-        lib = _hip.lib()
+        lib = lib16(x)
         dy = _f32c(dy)
-        dx = new_cl16(B, 4, H, T, x.device)
+        dx = new_cl16(B, 4, H, T, x.device, x.dtype)
         (dw, r1), (db, r2) = (_grad_target(t) for t in ctx.params)
         ws = torch.empty(lib.tt_edge16_scratch_bytes(), dtype=torch.uint8, device=x.device)
         check(lib.tt_convout16_bwd(ptr(x), ptr(dy), ptr(w), ptr(dx), ptr(dw), ptr(db), ptr(ws), B, H, T, stream_ptr()),
@@ -550,12 +590,12 @@ class Level16Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, dilations, *params):
         B, C, H, T = x.shape
-        lib, st = _hip.lib(), stream_ptr()
+        lib, st = lib16(x), stream_ptr()
         needs_grad = any(ctx.needs_input_grad)
         recompute = C in RECOMPUTE_CHANNELS
         nb = len(dilations)
-        outs = [new_cl16(B, C, H, T, x.device) for _ in range(nb)]
-        hids = [new_cl16(B, C, H, T, x.device) if (needs_grad and not recompute) else None for _ in range(nb)]
+        outs = [new_cl16(B, C, H, T, x.device, x.dtype) for _ in range(nb)]
+        hids = [new_cl16(B, C, H, T, x.device, x.dtype) if (needs_grad and not recompute) else None for _ in range(nb)]
         for b0, b1 in _chunks(B):
             cur = x[b0:b1]
             for i, d in enumerate(dilations):
@@ -581,16 +621,17 @@ class Level16Fn(torch.autograd.Function):
         tensors = ctx.saved_tensors
         params, saved = tensors[:4 * nb], tensors[4 * nb:]
         B, C, H, T = saved[0].shape
-        lib, st = _hip.lib(), stream_ptr()
-        g_all = _as_cl16(dy)
+        dt = saved[0].dtype
+        lib, st = lib16(dt), stream_ptr()
+        g_all = _as_cl16(dy, dt)
         chunks = _chunks(B)
         cb = chunks[0][1] - chunks[0][0]
         recompute = ctx.recompute
         ws_bytes = lib.tt_wide_fused_scratch_bytes(C) if recompute else lib.tt_wide_scratch_bytes(cb, C, H, T)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=g_all.device)
         targets = [_grad_target(t) for t in ctx.params]
-        dx = new_cl16(B, C, H, T, g_all.device)
-        tmp = [new_cl16(cb, C, H, T, g_all.device) for _ in range(2)] if nb > 1 else []
+        dx = new_cl16(B, C, H, T, g_all.device, dt)
+        tmp = [new_cl16(cb, C, H, T, g_all.device, dt) for _ in range(2)] if nb > 1 else []
         for b0, b1 in chunks:
             g = g_all[b0:b1]
             for i in reversed(range(nb)):
@@ -617,8 +658,8 @@ class SConv16Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b):
         B, C, H, T = x.shape
-        y = new_cl16(B, 2 * C, (H - 4) // 2 + 1, T, x.device)
-        check(_hip.lib().tt_sconv16_fwd(ptr(x), ptr(w), ptr(b), ptr(y), B, C, H, T, stream_ptr()), 'tt_sconv16_fwd')
+        y = new_cl16(B, 2 * C, (H - 4) // 2 + 1, T, x.device, x.dtype)
+        check(lib16(x).tt_sconv16_fwd(ptr(x), ptr(w), ptr(b), ptr(y), B, C, H, T, stream_ptr()), 'tt_sconv16_fwd')
         ctx.params = (w, b)
         ctx.save_for_backward(x, w, y)
         return y
@@ -627,9 +668,9 @@ class SConv16Fn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w, y = ctx.saved_tensors
         B, C, H, T = x.shape
-        lib = _hip.lib()
-        g = _as_cl16(dy)
-        dx = new_cl16(B, C, H, T, x.device) if ctx.needs_input_grad[0] else None
+        lib = lib16(x)
+        g = _as_cl16(dy, x.dtype)
+        dx = new_cl16(B, C, H, T, x.device, x.dtype) if ctx.needs_input_grad[0] else None
         (dw, r1), (db, r2) = (_grad_target(t) for t in ctx.params)
         ws = torch.empty(lib.tt_stride16_scratch_bytes(C), dtype=torch.uint8, device=x.device)
         check(lib.tt_sconv16_bwd(ptr(x), ptr(y), ptr(g), ptr(w), ptr(dx), ptr(dw), ptr(db), ptr(ws), B, C, H, T, stream_ptr()),
@@ -644,8 +685,8 @@ class TConv16Fn(torch.autograd.Function):
     def forward(ctx, x, w, b, out_pad):
         B, C2, H, T = x.shape
         C = C2 // 2
-        y = new_cl16(B, C, 2 * H + 2 + out_pad, T, x.device)
-        check(_hip.lib().tt_tconv16_fwd(ptr(x), ptr(w), ptr(b), ptr(y), B, C, H, T, out_pad, stream_ptr()), 'tt_tconv16_fwd')
+        y = new_cl16(B, C, 2 * H + 2 + out_pad, T, x.device, x.dtype)
+        check(lib16(x).tt_tconv16_fwd(ptr(x), ptr(w), ptr(b), ptr(y), B, C, H, T, out_pad, stream_ptr()), 'tt_tconv16_fwd')
         ctx.params = (w, b)
         ctx.out_pad = out_pad
         ctx.save_for_backward(x, w, y)
@@ -656,9 +697,9 @@ class TConv16Fn(torch.autograd.Function):
         x, w, y = ctx.saved_tensors
         B, C2, H, T = x.shape
         C = C2 // 2
-        lib = _hip.lib()
-        g = _as_cl16(dy)
-        dx = new_cl16(B, C2, H, T, x.device) if ctx.needs_input_grad[0] else None
+        lib = lib16(x)
+        g = _as_cl16(dy, x.dtype)
+        dx = new_cl16(B, C2, H, T, x.device, x.dtype) if ctx.needs_input_grad[0] else None
         (dw, r1), (db, r2) = (_grad_target(t) for t in ctx.params)
         ws = torch.empty(lib.tt_stride16_scratch_bytes(C), dtype=torch.uint8, device=x.device)
         check(lib.tt_tconv16_bwd(ptr(x), ptr(y), ptr(g), ptr(w), ptr(dx), ptr(dw), ptr(db), ptr(ws), B, C, H, T, ctx.out_pad,
@@ -679,10 +720,11 @@ class WideLevelFn(torch.autograd.Function):
         _hip.require_cuda(x, params[0])
         x = _f32c(x)
         B, C, H, T = x.shape
-        lib, st = _hip.lib(), stream_ptr()
+        ctx.dtype = dt = cl16_dtype()
+        lib, st = lib16(dt), stream_ptr()
         nb = len(dilations)
         needs_grad = any(ctx.needs_input_grad)
-        cur = torch.empty((B, H, T, C), dtype=torch.bfloat16, device=x.device)
+        cur = torch.empty((B, H, T, C), dtype=dt, device=x.device)
         check(lib.tt_wide_pack(ptr(x), ptr(cur), B, C, H, T, st), 'tt_wide_pack')
         saved = []
         for i, d in enumerate(dilations):
@@ -709,9 +751,9 @@ class WideLevelFn(torch.autograd.Function):
         nb = len(ctx.dilations)
         tensors = ctx.saved_tensors
         params, saved = tensors[:4 * nb], tensors[4 * nb:]
-        lib, st = _hip.lib(), stream_ptr()
+        lib, st = lib16(ctx.dtype), stream_ptr()
         dy = _f32c(dy)
-        g = torch.empty((B, H, T, C), dtype=torch.bfloat16, device=dy.device)
+        g = torch.empty((B, H, T, C), dtype=ctx.dtype, device=dy.device)
         check(lib.tt_wide_pack(ptr(dy), ptr(g), B, C, H, T, st), 'tt_wide_pack')
         ws = torch.empty(lib.tt_wide_scratch_bytes(B, C, H, T), dtype=torch.uint8, device=dy.device)
         grads = [None] * (4 * nb)
@@ -736,13 +778,16 @@ class Add16Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
         B, C, H, T = a.shape
-        y = new_cl16(B, C, H, T, a.device)
-        check(_hip.lib().tt_scaled_add16(ptr(a), ptr(b), None, 0, ptr(y), a.numel(), stream_ptr()), 'tt_scaled_add16')
+        if b.dtype != a.dtype:
+            raise TypeError('skip join of %s and %s tensors' % (a.dtype, b.dtype))
+        y = new_cl16(B, C, H, T, a.device, a.dtype)
+        check(lib16(a).tt_scaled_add16(ptr(a), ptr(b), None, 0, ptr(y), a.numel(), stream_ptr()), 'tt_scaled_add16')
+        ctx.dtype = a.dtype
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        g = _as_cl16(dy)
+        g = _as_cl16(dy, ctx.dtype)
         return g, g
 
 
@@ -753,8 +798,8 @@ class Scale16Fn(torch.autograd.Function):
     def forward(ctx, e, s, idx):
         B, C, H, T = e.shape
         s = _f32c(s)
-        y = new_cl16(B, C, H, T, e.device)
-        check(_hip.lib().tt_scaled_add16(None, ptr(e), ptr(s), idx, ptr(y), e.numel(), stream_ptr()), 'tt_scaled_add16')
+        y = new_cl16(B, C, H, T, e.device, e.dtype)
+        check(lib16(e).tt_scaled_add16(None, ptr(e), ptr(s), idx, ptr(y), e.numel(), stream_ptr()), 'tt_scaled_add16')
         ctx.idx = idx
         ctx.save_for_backward(e, s)
         return y
@@ -762,12 +807,12 @@ class Scale16Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         e, s = ctx.saved_tensors
-        g = _as_cl16(dy)
-        lib, st = _hip.lib(), stream_ptr()
+        g = _as_cl16(dy, e.dtype)
+        lib, st = lib16(e), stream_ptr()
         de = ds = None
         if ctx.needs_input_grad[0]:
             B, C, H, T = e.shape
-            de = new_cl16(B, C, H, T, e.device)
+            de = new_cl16(B, C, H, T, e.device, e.dtype)
             check(lib.tt_scaled_add16(None, ptr(g), ptr(s), ctx.idx, ptr(de), e.numel(), st), 'tt_scaled_add16')
         if ctx.needs_input_grad[1]:
             ds = torch.zeros_like(s)
@@ -791,12 +836,12 @@ def scale(e, weights, i):
 
 def residual_level(x, blocks):
     """
-    block3(block2(block1(x))) for the ResidualConv2dBlock modules ``blocks``.  With ops.wide_storage() == 'bf16' the level runs
+    block3(block2(block1(x))) for the ResidualConv2dBlock modules ``blocks``.  With ops.cl16_mode() the level runs
     on cl16 tensors (Level16Fn) and RETURNS a cl16 tensor -- the next layer either has a bf16 kernel or converts with
     to_planar32; otherwise the per-block fp32 path.
     """
     C, T = x.size(1), x.size(-1)
-    if (wide_storage() == 'bf16' and C in WIDE_CHANNELS and FUSED_RESBLOCK and (C != 4 or T % 2 == 0) and _i32_ok(x)
+    if (cl16_mode() and C in WIDE_CHANNELS and FUSED_RESBLOCK and (C != 4 or T % 2 == 0) and _i32_ok(x)
             and all(b.conv1[0].weight.shape == (C, C, 3, 3) and 1 <= b.dilation <= 3 for b in blocks)):
         params = []
         for b in blocks:
@@ -899,7 +944,7 @@ class LatEnc16Fn(torch.autograd.Function):
     def forward(ctx, x, w, b):
         B, CT, E, T = x.shape
         D = w.size(0)
-        lib = _hip.lib()
+        lib = lib16(x)
         y = torch.empty((B, D, T), dtype=torch.float32, device=x.device)
         ws = torch.empty(lib.tt_latent16_scratch_bytes(B, CT, D, E, T), dtype=torch.uint8, device=x.device)
         check(lib.tt_latent16_contract(ptr(x), None, ptr(w), ptr(b), ptr(y), ptr(ws), B, CT, D, D, E, T, stream_ptr()),
@@ -913,12 +958,12 @@ class LatEnc16Fn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         B, CT, E, T = x.shape
         D = w.size(0)
-        lib, st = _hip.lib(), stream_ptr()
+        lib, st = lib16(x), stream_ptr()
         dy = _f32c(dy)
         ws = torch.empty(lib.tt_latent16_scratch_bytes(B, CT, D, E, T), dtype=torch.uint8, device=x.device)
         dx = rw = rb = None
         if ctx.needs_input_grad[0]:
-            dx = new_cl16(B, CT, E, T, x.device)
+            dx = new_cl16(B, CT, E, T, x.device, x.dtype)
             check(lib.tt_latent16_expand(ptr(dy), D, 0.0, ptr(w), None, ptr(dx), ptr(ws), B, CT, D, E, T, st), 'tt_latent16_expand')
         if ctx.needs_input_grad[1]:
             dw, rw = _grad_target(ctx.params[0])
@@ -940,8 +985,8 @@ class LatDec16Fn(torch.autograd.Function):
         z = _f32c(z)
         B, Dz, T = z.shape
         D, CT, E = w.size(0), w.size(1), w.size(2)
-        lib = _hip.lib()
-        y = new_cl16(B, CT, E, T, z.device)
+        y = new_cl16(B, CT, E, T, z.device, cl16_dtype())
+        lib = lib16(y)
         ws = torch.empty(lib.tt_latent16_scratch_bytes(B, CT, D, E, T), dtype=torch.uint8, device=z.device)
         ctx.fill = 0.0 if fill is None else float(fill)
         check(lib.tt_latent16_expand(ptr(z), Dz, ctx.fill, ptr(w), ptr(b), ptr(y), ptr(ws), B, CT, D, E, T, stream_ptr()),
@@ -955,8 +1000,8 @@ class LatDec16Fn(torch.autograd.Function):
         z, w, y = ctx.saved_tensors
         B, Dz, T = z.shape
         D, CT, E = w.size(0), w.size(1), w.size(2)
-        lib, st = _hip.lib(), stream_ptr()
-        g = _as_cl16(dy)
+        lib, st = lib16(y), stream_ptr()
+        g = _as_cl16(dy, y.dtype)
         ws = torch.empty(lib.tt_latent16_scratch_bytes(B, CT, D, E, T), dtype=torch.uint8, device=z.device)
         dz = rw = rb = None
         if ctx.needs_input_grad[0]:
@@ -982,7 +1027,7 @@ def latent_decode(z, w, b, fill=None):
     does not carry (see LatDec16Fn); on the fp32 path the channel is concatenated like the reference does.
     """
     Dz = z.size(1) + (fill is not None)
-    if (wide_storage() == 'bf16' and FUSED_RESBLOCK and _f32ok(w) and z.dim() == 3 and w.size(0) == Dz and w.size(3) == 1
+    if (cl16_mode() and FUSED_RESBLOCK and _f32ok(w) and z.dim() == 3 and w.size(0) == Dz and w.size(3) == 1
             and _lat16_ok(w.size(1), w.size(0), w.size(2), z.size(2), b)):
         return LatDec16Fn.apply(z, w, b, fill)
     if fill is not None:

@@ -174,13 +174,14 @@ int64_t tt_wide_fused_scratch_bytes(int C);
 int tt_wide_rb_bwd_fused(const void* x, const void* dy, const float* w1, const float* b1, const float* w2, const float* b2,
                          void* dx, float* dw1, float* db1, float* dw2, float* db2, void* ws, int B, int C, int H, int T,
                          int dilation, void* stream);
-/* The whole backward of one block in ONE pass from x, the SAVED h1 and dy (csrc/conv_level_bf16.hip k_wrb_bwd1; C = 16, 32, else
- * TT_E_UNSUPPORTED): the pointwise chain runs on tile + halo with h1 / dy read straight from HBM, dL/d(conv1 pre-activation) lives
- * in LDS only, and the 3x3 weight gradient is indexed by the pixel of x (dW1[tap] = sum_q x[q] (x) dA1[q - tap D]) so that x
- * needs no halo: h1, dy, x in and dx out -- 4 tensors of HBM traffic where tt_wide_rb_bwd's per-stage kernels move 7; nothing is
- * recomputed.  Same results as tt_wide_rb_bwd (dx and dA1 bit-identical; the fp32 weight / bias gradients differ by summation
- * order) (modules.py:755-777 differentiated).  ws = tt_wide_onepass_scratch_bytes(C) bytes (<= tt_wide_scratch_bytes).
- * tt_wide_rb_bwd itself takes this path where tt_wide_rb_bwd_is_onepass(C, dilation) says 1 (measured per width / dilation). */
+/* The whole backward of one block in ONE pass from x, the SAVED h1 and dy (csrc/conv_level_bf16.hip k_wrb_bwds; C = 16, 32, else
+ * TT_E_UNSUPPORTED): a workgroup walks a strip of 32 columns downwards, the pointwise chain runs once per image row (+ the column
+ * halo), dL/d(conv1 pre-activation) lives in a ring of LDS rows only, and the 3x3 weight gradient is indexed by the pixel of x
+ * (dW1[tap] = sum_q x[q] (x) dA1[q - tap D]) so that x needs no halo: h1, dy, x in and dx out -- 4 tensors of HBM traffic where
+ * tt_wide_rb_bwd's per-stage kernels move 7; nothing is recomputed.  Same results as the per-stage kernels: dx bit-identical, the
+ * fp32 weight / bias gradients equal up to summation order (modules.py:755-777 differentiated).
+ * ws = tt_wide_onepass_scratch_bytes(C) bytes (<= tt_wide_scratch_bytes).  tt_wide_rb_bwd itself takes this path where
+ * tt_wide_rb_bwd_is_onepass(C, dilation) says 1 (measured per width / dilation; TTRAP_WBWD1 = 0 / 1 forces a choice). */
 int64_t tt_wide_onepass_scratch_bytes(int C);
 int tt_wide_rb_bwd_onepass(const void* x, const void* h1, const void* dy, const float* w1, const float* w2, const float* b2,
                            void* dx, float* dw1, float* db1, float* dw2, float* db2, void* ws, int B, int C, int H, int T,

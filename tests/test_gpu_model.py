@@ -280,9 +280,10 @@ def _bench_style_targets(n, n_bins, T, seed=4321):
     return target
 
 
-def _autocast_step_vs_oracle(n_clips, n_blocks, n_mpe, record=None, bench_targets=False):
+def _autocast_step_vs_oracle(n_clips, n_blocks, n_mpe, record=None, bench_targets=False, dtype=torch.bfloat16, bars=(3e-2, 1e-2, 3e-2, 6e-2, 0.999)):
     """
-    One train step of mc 2 / latent 128 under torch.autocast (bf16 channels-last path) against the fp32 CPU oracle: the five
+    One train step of mc 2 / latent 128 under torch.autocast (16-bit channels-last path of element type ``dtype``; ``bars`` = outputs,
+    losses, gradient relative L2, the same for bias vectors, cosine) against the fp32 CPU oracle: the five
     outputs, the four losses and EVERY parameter gradient of the total loss.  ``n_clips`` items of ``n_blocks`` 3-s blocks each
     (T = n_blocks * 1024 frames per item); the first ``n_mpe`` items are annotated -- the `[:mpe_batch_size]` slices of
     reference experiments/train.py:429,439-441 are live when n_mpe < n_clips.
@@ -309,7 +310,8 @@ def _autocast_step_vs_oracle(n_clips, n_blocks, n_mpe, record=None, bench_target
     tot_ref.backward()
     # HIP path under autocast
     c, g = coeffs.cuda(), gt.cuda()
-    with torch.autocast(device_type='cuda', dtype=torch.bfloat16):
+    out_bar, loss_bar, grad_bar, bias_bar, cos_bar = bars
+    with torch.autocast(device_type='cuda', dtype=dtype):
         latents, emb, _ = model.encoder(c)
         rec, trn = model.decode(latents, None), model.decode(latents, None, True)
         lat2, _, _ = model.encoder(trn)
@@ -325,13 +327,13 @@ def _autocast_step_vs_oracle(n_clips, n_blocks, n_mpe, record=None, bench_target
                                (rec, latents, trn, trn_rec, trn_scr), ref):
         assert got.shape == want.shape, (name, got.shape, want.shape)
         err = float((got.detach().float().cpu() - want.detach()).abs().max() / want.detach().abs().max())
-        assert err < 3e-2, (name, err)
+        assert err < out_bar, (name, err)
     for name, got in (('reconstruction', l_rec), ('transcription', l_trn), ('consistency_spectral', l_sp), ('consistency_score', l_sc)):
         want = float(parts[name].detach())
         # relative to the loss itself, with a floor relative to the total: the consistency terms are squared differences of two
         # nearly equal tensors (3e-6 of the total here), so bf16 rounding noise -- which adds in quadrature -- is a visible part of them
-        assert abs(float(got) - want) <= 1e-2 * abs(want) + 1e-5 * abs(float(tot_ref.detach())), (name, float(got), want)
-    assert abs(float(total) - float(tot_ref.detach())) <= 1e-2 * abs(float(tot_ref.detach()))
+        assert abs(float(got) - want) <= loss_bar * abs(want) + 1e-5 * abs(float(tot_ref.detach())), (name, float(got), want)
+    assert abs(float(total) - float(tot_ref.detach())) <= loss_bar * abs(float(tot_ref.detach()))
     named = dict(model.named_parameters())
     assert set(named) == set(params)
     stats = []
@@ -345,8 +347,8 @@ def _autocast_step_vs_oracle(n_clips, n_blocks, n_mpe, record=None, bench_target
     stats.sort(reverse=True)
     n_checked = len(stats)
     rels = sorted(r for r, _, _ in stats)
-    print('bf16 autocast step vs oracle (%d items x %d blocks, %d annotated): %d parameter gradients; relative L2 median %.3e, '
-          'worst %.3e (%s); worst cosine %.6f' % (n_clips, n_blocks, n_mpe, n_checked, rels[n_checked // 2], stats[0][0], stats[0][2],
+    print('%s autocast step vs oracle (%d items x %d blocks, %d annotated): %d parameter gradients; relative L2 median %.3e, '
+          'worst %.3e (%s); worst cosine %.6f' % (str(dtype).split('.')[-1], n_clips, n_blocks, n_mpe, n_checked, rels[n_checked // 2], stats[0][0], stats[0][2],
                                                    min(c for _, c, _ in stats)))
     for rel, cos, k in stats[:8]:
         print('   %-44s rel L2 %.3e  cosine %.6f' % (k, rel, cos))
@@ -362,8 +364,8 @@ def _autocast_step_vs_oracle(n_clips, n_blocks, n_mpe, record=None, bench_target
     # blocks, against the oracle AND against the fp32 HIP path, with the one-pass and with the per-stage narrow kernels alike
     # (profiles/r04_diag_bias_T3072.txt) -- i.e. arithmetic noise of that sum, not an indexing error at T = 3072.
     for rel, cos, k in stats:
-        bar = 6e-2 if k.endswith('.bias') else 3e-2
-        assert rel <= bar and cos >= 0.999, (k, rel, cos)
+        bar = bias_bar if k.endswith('.bias') else grad_bar
+        assert rel <= bar and cos >= cos_bar, (k, rel, cos)
     assert n_checked == len(params) >= 120
 
 
@@ -377,6 +379,15 @@ def test_autocast_bf16_step_matches_oracle_outputs_losses_and_all_gradients():
     Measured on MI355X (round 3): median 7.9e-3, worst 1.2e-2 (encoder.convin.0.bias), worst cosine 0.99996.
     """
     _autocast_step_vs_oracle(2, 1, 2, record='bf16_grad_parity.txt')
+
+
+def test_autocast_fp16_step_matches_oracle_outputs_losses_and_all_gradients():
+    """The same step under the reference's OWN autocast dtype -- ``torch.autocast('cuda')`` is float16 (experiments/train.py:415), which
+    selects the fp16 twins of every 16-bit kernel (include/ttrap.h, suffix _h): 11 significant bits per stored element instead of
+    bf16's 8, so every bar is 4x tighter than the bf16 test's (outputs 8e-3, losses 2.5e-3, gradients 8e-3, bias vectors 1.6e-2).
+    Two clips x T = 1024: dL/dlogit ~ 1e-3 of the error, well inside fp16's normal range (profiles/r04_fp16_vs_bf16.txt has the
+    64-clip figures, where the reference's missing GradScaler starts to matter)."""
+    _autocast_step_vs_oracle(2, 1, 2, record='fp16_grad_parity.txt', dtype=torch.float16, bars=(8e-3, 2.5e-3, 8e-3, 1.6e-2, 0.9999))
 
 
 def test_autocast_bf16_step_at_reference_training_shape():
@@ -648,3 +659,23 @@ def test_frozen_parameter_gets_no_gradient_on_the_bf16_path():
     live = model.encoder.block3.block2.conv2[0].weight
     o, k = slots[id(live)]
     assert float(opt.flat_grad[o:o + k].abs().max()) > 0.0
+    # ... and the optimizer must leave it alone like torch.optim.AdamW does for a parameter without a gradient: residual momentum
+    # from the steps before it was frozen and the weight decay would otherwise keep moving it (round-3 advisor finding)
+    for p in frozen:                                        # give the frozen slots momentum, as after earlier live steps
+        o, k = slots[id(p)]
+        opt.exp_avg[o:o + k].fill_(0.3)
+        opt.exp_avg_sq[o:o + k].fill_(0.01)
+    before = {id(p): (p.detach().clone(), opt.exp_avg[slots[id(p)][0]:sum(slots[id(p)])].clone()) for p in frozen}
+    live_before = live.detach().clone()
+    opt.step()
+    torch.cuda.synchronize()
+    for p in frozen:
+        o, k = slots[id(p)]
+        assert torch.equal(p.detach(), before[id(p)][0]), 'a frozen parameter moved'
+        assert torch.equal(opt.exp_avg[o:o + k], before[id(p)][1]), 'the moments of a frozen parameter moved'
+    assert not torch.equal(live.detach(), live_before)
+    model.decoder.block1.tconv[0].bias.requires_grad_(True)          # thawed and given no gradient at all: still skipped
+    model.decoder.block1.tconv[0].bias.grad = None
+    b0 = model.decoder.block1.tconv[0].bias.detach().clone()
+    opt.step()
+    assert torch.equal(model.decoder.block1.tconv[0].bias.detach(), b0)

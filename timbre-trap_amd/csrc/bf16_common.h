@@ -68,6 +68,17 @@ __device__ __forceinline__ int xcd_order(int v, int n) {          // see conv_mf
 //     the min: by then the forward has already put the NaN into the loss and into dy.
 // ELU'(a) = min(exp(a), 1); expressed through the output h = ELU(a): min(h + 1, 1).
 __device__ __forceinline__ float elu_f(float a) { return __builtin_fmaf(a, 0.f, __builtin_amdgcn_fmed3f(a, __expf(a) - 1.f, 0.f)); }
+// The median alone (NaN -> 0), for the residual-block forward kernels, which do not need the per-element term: a non-finite INPUT
+// reaches their output through the residual add (y = ELU(..) + x), and non-finite PARAMETERS are found once per workgroup when the
+// weights are loaded (params_poisoned below) and turn the whole output into NaN.  Two full-rate instructions per element saved.
+__device__ __forceinline__ float elu_res(float a) { return __builtin_amdgcn_fmed3f(a, __expf(a) - 1.f, 0.f); }
+// v * 0 summed over the values a lane loads: +-0 for finite parameters, NaN as soon as one is NaN or inf
+__device__ __forceinline__ float poison_acc(float acc, float v) { return __builtin_fmaf(v, 0.f, acc); }
+__device__ __forceinline__ bool params_poisoned(float acc) {      // any lane of the wave (every wave loads all parameters)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    return !(acc == 0.f);
+}
 __device__ __forceinline__ float elu_dpre(float a) { return __builtin_fminf(__expf(a), 1.f); }
 __device__ __forceinline__ float elu_dout(float h) { return __builtin_fminf(h + 1.f, 1.f); }
 

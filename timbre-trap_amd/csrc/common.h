@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/ttrap.h"
 
 #define TT_LAUNCH_CHECK()                                   \
@@ -31,6 +32,19 @@ struct AttrOnce {
     }
     void mark(int dev) { __atomic_fetch_or(&done[dev >> 6], 1ull << (dev & 63), __ATOMIC_RELAXED); }
 };
+
+// Run-time switches (environment).  tt_switch: the documented ones, which the tests exercise -- always read.
+// tt_tune: knobs of the A/B scripts under tools/ (workgroups per CU, alternative tile shapes, ablations, measured-and-dropped
+// variants): compiled OUT of the shipped library, where they return their default; a library built with -DTTRAP_EXPERIMENTAL
+// (tools/build_variant.sh <name> -DTTRAP_EXPERIMENTAL, selected with TTRAP_LIB) reads them.
+static inline int tt_switch(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+#ifdef TTRAP_EXPERIMENTAL
+static inline int tt_tune(const char* name, int dflt) { return tt_switch(name, dflt); }
+static inline bool tt_tune_set(const char* name) { return getenv(name) != nullptr; }
+#else
+static inline int tt_tune(const char*, int dflt) { return dflt; }
+static inline bool tt_tune_set(const char*) { return false; }
+#endif
 
 // Persistent kernels launch min(work items, tt_cus() * workgroups per CU) workgroups.  256 CUs on MI355X;
 // tt_set_cu_limit (include/ttrap.h) lowers the figure so that small shapes run the multi-tile loops (tests, tuning).

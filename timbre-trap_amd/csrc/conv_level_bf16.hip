@@ -364,7 +364,7 @@ int launch_fused(const e16* x, const e16* dy, const float* w1, const float* b1, 
     auto kern = k_wrb_bwd_fused<C, D, TH, TW, NW>;
     if (int rc = raise_lds(kern, G::LDS_BYTES, once)) return rc;
     const int tiles_h = (H + TH - 1) / TH, tiles_t = (T + TW - 1) / TW, ntiles = B * tiles_h * tiles_t;
-    static const int per_cu = env_int("TTRAP_FBWD_PER_CU", C == 32 ? 2 : 3);        // registers: 2 waves per SIMD at C = 32, 3 at C = 16
+    static const int per_cu = tt_tune("TTRAP_FBWD_PER_CU", C == 32 ? 2 : 3);        // registers: 2 waves per SIMD at C = 32, 3 at C = 16
     int grid = grid_for(ntiles, G::LDS_BYTES, per_cu);
     if (grid > MAX_W_WG) grid = MAX_W_WG;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), G::LDS_BYTES, st, x, dy, wimg, b1, b2, dx, part_a, part_w, B, H, T, tiles_h,
@@ -382,7 +382,7 @@ int launch_fused(const e16* x, const e16* dy, const float* w1, const float* b1, 
 template <int C>
 int fused_c(const e16* x, const e16* dy, const float* w1, const float* b1, const float* w2, const float* b2, e16* dx,
             float* dw1, float* db1, float* dw2, float* db2, unsigned char* ws, int B, int H, int T, int D, hipStream_t st) {
-    static const int alt = env_int("TTRAP_FBWD_TILE", 0);
+    static const int alt = tt_tune("TTRAP_FBWD_TILE", 0);
 #define TT_FB(DD, TH_, TW_) return launch_fused<C, DD, TH_, TW_>(x, dy, w1, b1, w2, b2, dx, dw1, db1, dw2, db2, ws, B, H, T, st)
     if constexpr (C == 32) {
         switch (D) {
@@ -401,338 +401,13 @@ int fused_c(const e16* x, const e16* dy, const float* w1, const float* b1, const
     return TT_E_UNSUPPORTED;
 }
 
-// ==== one-pass backward with the hidden activation SAVED (round 4) ===========================================================
-//   k_wrb_bwd1<C,D,TH,TW>   the whole backward of a wide ResidualConv2dBlock from x, h1 and dy in ONE pass, nothing recomputed:
-//       phase 0  the x tile (NO halo) starts towards LDS by LDS-DMA;
-//       phase 1  on every pixel of the tile + D halo the pointwise chain a2 = W2 h1 + b2, dA2 = dy ELU'(a2), dh1 = W2^T dA2,
-//                dA1 = dh1 ELU'(a1) runs with h1 and dy read STRAIGHT FROM HBM in B-operand layout (a lane = 8 / 4 channels of a
-//                pixel, as in k_wrb_bwd_a; next group's loads in flight under this group's arithmetic) and dA1 (bf16) written into
-//                the one halo'd LDS image (fswz layout); an out-of-image pixel gets dy = 0 and therefore dA1 = 0 exactly -- the
-//                zero padding of the data gradient; db1 / db2 / dW2 over the tile's own pixels;
-//       phase 2  dx = dy + W1^T (*)_D dA1 over the tile (dy re-read: an L2 hit), and the weight gradient indexed by the pixel of
-//                x instead of the pixel of dA1:  dW1[tap] = sum_{q in tile} x[q] (x) dA1[q - tap D]  -- every image pixel q is in
-//                exactly one tile and dA1 outside the image is zero, so the halo is needed on dA1 only (it is there already) and
-//                not on x.
-//   dA1 never exists in HBM: the block's backward moves h1, dy, x in and dx out (4 tensors; the per-stage path: 7), with no 3x3
-//   recomputation (that is what made k_wrb_bwd_fused issue-bound) -- the only redundant work is the pointwise chain on the halo.
-//   LDS: one halo'd image + the x tile + the transposition buffers of dW2 (C = 32, 8 x 32 tile: 22 + 16 + 9 KB at dilation 1).
-template <int C, int D, int TH, int TW> struct OP {
-    static constexpr int CG = C / 8, PB = C * 2;
-    static constexpr int GR = TH + 2 * D, GW = TW + 2 * D, GPIX = GR * GW;
-    static constexpr int G_BYTES = (GPIX * PB + 255) / 256 * 256;
-    static constexpr int XP = TH * TW * CG;                      // 16-byte pieces of the x tile
-    static constexpr int XPR = (XP + NT - 1) / NT * NT;
-    static constexpr int X_BYTES = XPR * 16;
-    static constexpr int PS = C * 2 + 8;
-    static constexpr int T_BYTES = 4 * 2 * 16 * PS;
-    static constexpr int ADUMP = C * C + 2 * C;
-    static constexpr int WDUMP = 9 * (C / 16) * 256;
-    static constexpr int LDS_BYTES = G_BYTES + X_BYTES + T_BYTES;
-    static constexpr int NG1 = (GPIX + 15) / 16;
-    static_assert(4 * ADUMP * 4 <= G_BYTES + X_BYTES, "final dump reduction reuses the images");
-    static_assert(TW % 32 == 0, "the K = 32 pixels of a weight-gradient product are 32 consecutive columns");
-};
-
-template <int C, int D, int TH, int TW, int MINW>
-__global__ __launch_bounds__(NT, MINW) void k_wrb_bwd1(const e16* __restrict__ x, const e16* __restrict__ h1, const e16* __restrict__ dy,
-                                                     const e16x8* __restrict__ wimg, const float* __restrict__ b2, e16* __restrict__ dx,
-                                                     float* __restrict__ part_a, float* __restrict__ part_w, int B, int H, int T,
-                                                     int tiles_h, int tiles_t, int ntiles) {
-    using G = OP<C, D, TH, TW>;
-    using K = WK<C>;
-    constexpr int NCT = K::NCT, NK = K::NK, NCH = K::NCH, PB = G::PB;
-    typedef typename std::conditional<C == 32, e16x8, e16x4>::type vec_t;     // a lane's channels of one pixel
-    extern __shared__ __align__(16) unsigned char smem[];
-    unsigned char* gs = smem;                                    // dA1, tile + D halo
-    unsigned char* xs = smem + G::G_BYTES;                       // x, tile only
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = lane & 15, g = lane >> 4, trj = n >> 2, trq = n & 3;
-    unsigned char* tg = smem + G::G_BYTES + G::X_BYTES + wave * (2 * 16 * G::PS);   // this wave's dA2 tile, then its h1 tile
-    unsigned char* thh = tg + 16 * G::PS;
-    const int opiece = C == 32 ? g : (g >> 1), obyte = C == 32 ? 0 : 8 * (g & 1);
-
-    // weight-gradient roles as in k_wrb_dxw: C = 32: wave = (ci-tile wave & 1, co-tile wave >> 1); C = 16: chunks, then rows
-    constexpr int NCHK = TW / 32;
-    static_assert(C == 32 || (4 % NCHK == 0), "wave roles");
-    const int cit = C == 32 ? (wave & 1) : 0, aw = C == 32 ? (wave >> 1) : 0;
-    const int ch0 = C == 32 ? 0 : wave % NCHK, rpar = C == 32 ? 0 : wave / NCHK;
-    constexpr int CHSTEP = C == 32 ? 1 : NCHK, RSTEP = C == 32 ? 1 : 4 / NCHK;
-
-    f32x4 wacc[9], dw2[NCT][NCT];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) wacc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int a = 0; a < NCT; ++a)
-#pragma unroll
-        for (int c = 0; c < NCT; ++c) dw2[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float db1a[NCH], db2a[NCH];
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) { db1a[j] = 0.f; db2a[j] = 0.f; }
-    vec_t zero_v;
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) zero_v[j] = (e16)0.f;
-
-    const e16* zero = reinterpret_cast<const e16*>(&g_wzero16);
-    for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
-        int tile = xcd_order(v, ntiles);
-        const int tt = tile % tiles_t; tile /= tiles_t;
-        const int th = tile % tiles_h;
-        const int b = tile / tiles_h, h0 = th * TH, t0 = tt * TW;
-        const long ib = (long)b * H * T * C;
-        const e16* hb_ = h1 + ib + NCH * g;                  // this lane's channels
-        const e16* gb_ = dy + ib + NCH * g;
-
-        // image pixel of group `grp`, lane n: LDS byte offset of the lane's channels, in-image / tile-core flags, HBM element offset
-        auto locate = [&](int grp, int& loff, bool& inq, bool& core, int& goff) {
-            const int q = grp * 16 + n;
-            inq = q < G::GPIX;
-            const int qq = inq ? q : G::GPIX - 1;
-            const int row = qq / G::GW, col = qq - row * G::GW;
-            const int h = h0 - D + row, t = t0 - D + col;
-            const bool img = inq && (unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T;
-            core = img && row >= D && row < D + TH && col >= D && col < D + TW;
-            loff = (row * G::GW + col) * PB + 16 * (opiece ^ fswz<C>(col)) + obyte;
-            goff = img ? (h * T + t) * C : -1;
-        };
-
-        __syncthreads();                                         // the previous tile has been consumed
-        int loff, goff; bool inq, core;
-        locate(wave, loff, inq, core, goff);
-        vec_t hq = *reinterpret_cast<const vec_t*>(hb_ + (goff < 0 ? 0 : goff));
-        vec_t dq = *reinterpret_cast<const vec_t*>(gb_ + (goff < 0 ? 0 : goff));
-        // ---- phase 0: the x tile towards LDS (consumed in phase 2b only) ----
-        for (int i = wave * 64; i < G::XPR; i += NT) {
-            const int p = i + lane, q = p / G::CG, s = p - q * G::CG;
-            const int row = q / TW, px = q - row * TW;
-            const int h = h0 + row, t = t0 + px;
-            const bool ok = p < G::XP && h < H && t < T;
-            glds16(ok ? x + ib + ((long)h * T + t) * C + (s ^ fswz<C>(px)) * 8 : zero, xs + (long)i * 16);
-        }
-
-        // the weights of each phase are (re)loaded per tile through laundered pointers so that their registers are free in the
-        // other phase (72 VGPRs of data-gradient weights at C = 32 beside 36 + 16 + 16 of accumulators)
-        const e16x8* wp = wimg;
-        const float* b2p = b2;
-        asm volatile("" : "+s"(wp), "+s"(b2p));
-
-        // ---- phase 1: pointwise chain on tile + halo, dA1 into LDS; db1 / db2 / dW2 over the tile's own pixels ----
-        {
-            e16x8 A2[NCT], A2T[NCT];
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) {
-                A2[ct] = wp[2 * K::W3 + ct * 64 + lane];
-                A2T[ct] = wp[2 * K::W3 + NCT * 64 + ct * 64 + lane];
-            }
-            const s16x4 A2s = __builtin_bit_cast(s16x4, __builtin_shufflevector(A2[0], A2[0], 0, 1, 2, 3));      // C = 16: K = 16
-            const s16x4 A2Ts = __builtin_bit_cast(s16x4, __builtin_shufflevector(A2T[0], A2T[0], 0, 1, 2, 3));
-            float b2r[NCH];
-#pragma unroll
-            for (int j = 0; j < NCH; ++j) b2r[j] = b2p[NCH * g + j];
-
-            for (int grp = wave; grp < G::NG1; grp += 4) {
-                // next group's operands are on their way while this one is processed
-                int loff_n = 0, goff_n = -1; bool inq_n = false, core_n = false;
-                vec_t hq_n = zero_v, dq_n = zero_v;
-                if (grp + 4 < G::NG1) {
-                    locate(grp + 4, loff_n, inq_n, core_n, goff_n);
-                    hq_n = *reinterpret_cast<const vec_t*>(hb_ + (goff_n < 0 ? 0 : goff_n));
-                    dq_n = *reinterpret_cast<const vec_t*>(gb_ + (goff_n < 0 ? 0 : goff_n));
-                }
-                if (goff < 0) dq = zero_v;                       // outside the image: dy = 0 -> dA2 = dA1 = 0 (h1 is then irrelevant)
-                float hv[NCH], gv[NCH], a1g[NCH];
-                vec_t gq, aq;
-                f32x4 z[NCT], u[NCT];
-                if constexpr (C == 32) {
-                    z[0] = mma32(A2[0], hq, f32x4{b2r[0], b2r[1], b2r[2], b2r[3]});
-                    z[1] = mma32(A2[1], hq, f32x4{b2r[4], b2r[5], b2r[6], b2r[7]});
-                } else {
-                    z[0] = mma16(A2s, __builtin_bit_cast(s16x4, hq), f32x4{b2r[0], b2r[1], b2r[2], b2r[3]});
-                }
-#pragma unroll
-                for (int j = 0; j < NCH; ++j) {
-                    const float a2 = z[j >> 2][j & 3];
-                    gv[j] = (float)dq[j] * elu_dpre(a2);
-                    gq[j] = (e16)gv[j];
-                    hv[j] = (float)hq[j];
-                }
-                if constexpr (C == 32) {
-                    u[0] = mma32(A2T[0], gq, f32x4{0.f, 0.f, 0.f, 0.f});
-                    u[1] = mma32(A2T[1], gq, f32x4{0.f, 0.f, 0.f, 0.f});
-                } else {
-                    u[0] = mma16(A2Ts, __builtin_bit_cast(s16x4, gq), f32x4{0.f, 0.f, 0.f, 0.f});
-                }
-                const float cm = core ? 1.f : 0.f;               // sums over the tile's own pixels only (halo pixels belong to the neighbours)
-#pragma unroll
-                for (int j = 0; j < NCH; ++j) {
-                    a1g[j] = u[j >> 2][j & 3] * elu_dout(hv[j]);
-                    aq[j] = (e16)a1g[j];
-                    db2a[j] += cm * gv[j]; db1a[j] += cm * a1g[j];
-                }
-                if (inq) *reinterpret_cast<vec_t*>(gs + loff) = aq;
-                const vec_t gm = core ? gq : zero_v;
-                if constexpr (C == 32) {
-                    const uint2* s1 = reinterpret_cast<const uint2*>(&gm);
-                    const uint2* s2 = reinterpret_cast<const uint2*>(&hq);
-                    uint2* d1 = reinterpret_cast<uint2*>(tg + n * G::PS + 16 * g);
-                    uint2* d2 = reinterpret_cast<uint2*>(thh + n * G::PS + 16 * g);
-                    d1[0] = s1[0]; d1[1] = s1[1]; d2[0] = s2[0]; d2[1] = s2[1];
-                } else {
-                    *reinterpret_cast<uint2*>(tg + n * G::PS + 8 * g) = __builtin_bit_cast(uint2, gm);
-                    *reinterpret_cast<uint2*>(thh + n * G::PS + 8 * g) = __builtin_bit_cast(uint2, hq);
-                }
-                // dW2[co][ci] += sum over the 16 pixels dA2[co][p] h1[ci][p]: the tiles read back transposed (the same wave
-                // wrote them: LDS operations of one wave complete in order; the fences only stop the compiler)
-                __builtin_amdgcn_wave_barrier();
-                asm volatile("" ::: "memory");
-                s16x4 ga[NCT], hb[NCT];
-#pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) {
-                    ga[ct] = lds_tr16(tg + (4 * g + trj) * G::PS + (16 * ct + 4 * trq) * 2);
-                    hb[ct] = lds_tr16(thh + (4 * g + trj) * G::PS + (16 * ct + 4 * trq) * 2);
-                }
-#pragma unroll
-                for (int a = 0; a < NCT; ++a)
-#pragma unroll
-                    for (int c = 0; c < NCT; ++c) dw2[a][c] = mma16(ga[a], hb[c], dw2[a][c]);
-                asm volatile("" ::: "memory");
-                hq = hq_n; dq = dq_n; loff = loff_n; goff = goff_n; inq = inq_n; core = core_n;
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the x tile has landed
-        __syncthreads();
-
-        // ---- phase 2a: dx = dy + W1^T (*) dA1 over the tile's own pixels ----
-        {
-            e16x8 A[NK][NCT];
-#pragma unroll
-            for (int k = 0; k < NK; ++k)
-#pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) A[k][ct] = wp[K::W3 + (k * NCT + ct) * 64 + lane];
-            constexpr int GPRW = TW / 16;
-            for (int grp = wave; grp < TH * GPRW; grp += 4) {
-                const int r = grp / GPRW, c = (grp - r * GPRW) * 16 + n;
-                const int h = h0 + r;
-                if (h >= H) break;
-                const int t = t0 + c;
-                const bool valid = t < T;
-                const long pix = ((long)b * H + h) * T + t;
-                // unconditional (clamped) so that no branch pins a wait in front of the products
-                const vec_t rq = *reinterpret_cast<const vec_t*>(dy + (valid ? pix : pix - (t - (T - 1))) * C + NCH * g);
-                f32x4 acc[NCT];
-#pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-                e16x8 unused;
-                conv_taps<C, D, G::GW>(gs, r, c, g, A, acc, unused);
-                vec_t o;
-#pragma unroll
-                for (int j = 0; j < NCH; ++j) o[j] = (e16)(acc[j >> 2][j & 3] + (float)rq[j]);
-                if (valid) *reinterpret_cast<vec_t*>(dx + pix * C + NCH * g) = o;
-            }
-        }
-
-        // ---- phase 2b: dW1[tap] += x[q] (x) dA1[q - tap D] over the tile's pixels q, K = 32 consecutive columns of a row per
-        //      product, both operands by transpose reads; the x operand is read once per chunk, the dA1 operand once per tap ----
-        for (int r = rpar; r < TH; r += RSTEP) {
-            if (h0 + r >= H) break;
-#pragma unroll
-            for (int ch = ch0; ch < NCHK; ch += CHSTEP) {
-                s16x4 lo, hi;
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int xc = ch * 32 + 4 * g + trj + 16 * u;
-                    const s16x4 t4 = lds_tr16(xs + (r * TW + xc) * PB + 16 * (((C == 32 ? 2 * cit : 0) + (trq >> 1)) ^ fswz<C>(xc)) + 8 * (trq & 1));
-                    if (u == 0) lo = t4; else hi = t4;
-                }
-                const e16x8 xq = __builtin_bit_cast(e16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-#pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    const int kh = k / 3, kw = k - 3 * kh;
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int cc = (2 - kw) * D + ch * 32 + 4 * g + trj + 16 * u;
-                        const s16x4 t4 = lds_tr16(gs + ((r + (2 - kh) * D) * G::GW + cc) * PB +
-                                                  16 * (((C == 32 ? 2 * aw : 0) + (trq >> 1)) ^ fswz<C>(cc)) + 8 * (trq & 1));
-                        if (u == 0) lo = t4; else hi = t4;
-                    }
-                    const e16x8 ga = __builtin_bit_cast(e16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-                    wacc[k] = mma32(ga, xq, wacc[k]);
-                }
-            }
-        }
-    }
-
-    // ---- dumps: the weight-gradient accumulators per wave, everything else summed over the waves through LDS ----
-    float* pw = part_w + ((long)blockIdx.x * 4 + wave) * G::WDUMP;
-#pragma unroll
-    for (int k = 0; k < 9; ++k)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) pw[((k * NCT + aw) * 4 + r) * 64 + lane] = wacc[k][r];   // C = 32: only this wave's co-tile (RedArgs::split_a)
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(smem) + wave * G::ADUMP;
-#pragma unroll
-    for (int a = 0; a < NCT; ++a)
-#pragma unroll
-        for (int c = 0; c < NCT; ++c)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) red[((a * NCT + c) * 4 + r) * 64 + lane] = dw2[a][c][r];
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-        float s1 = db1a[j], s2 = db2a[j];
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-        if (n == 0) { red[C * C + NCH * g + j] = s1; red[C * C + C + NCH * g + j] = s2; }
-    }
-    __syncthreads();
-    const float* all = reinterpret_cast<const float*>(smem);
-    float* pa = part_a + (long)blockIdx.x * G::ADUMP;
-    for (int i = tid; i < G::ADUMP; i += NT) pa[i] = (all[i] + all[G::ADUMP + i]) + (all[2 * G::ADUMP + i] + all[3 * G::ADUMP + i]);
-}
-
-template <int C, int D, int TH, int TW>
-int launch_bwd1(const e16* x, const e16* h1, const e16* dy, const float* w1, const float* w2, const float* b2, e16* dx,
-                float* dw1, float* db1, float* dw2, float* db2, unsigned char* ws, int B, int H, int T, hipStream_t st) {
-    using G = OP<C, D, TH, TW>;
-    using K = WK<C>;
-    e16x8* wimg = reinterpret_cast<e16x8*>(ws);
-    float* part_a = reinterpret_cast<float*>(ws + K::IMG_BYTES);
-    float* part_w = part_a + (long)MAX_W_WG * G::ADUMP;
-    hipLaunchKernelGGL(k_lvl_wprep<C>, dim3(K::NK * K::NCT + 1), dim3(64), 0, st, w1, w2, wimg);
-    TT_LAUNCH_CHECK();
-    static AttrOnce once;
-    constexpr int MINW = 2;
-    auto kern = k_wrb_bwd1<C, D, TH, TW, MINW>;
-    if (int rc = raise_lds(kern, G::LDS_BYTES, once)) return rc;
-    const int tiles_h = (H + TH - 1) / TH, tiles_t = (T + TW - 1) / TW, ntiles = B * tiles_h * tiles_t;
-    static const int per_cu = env_int("TTRAP_BWD1_PER_CU", MINW);
-    int grid = grid_for(ntiles, G::LDS_BYTES, per_cu);
-    if (grid > MAX_W_WG) grid = MAX_W_WG;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), G::LDS_BYTES, st, x, h1, dy, wimg, b2, dx, part_a, part_w, B, H, T, tiles_h, tiles_t,
-                       ntiles);
-    TT_LAUNCH_CHECK();
-    RedArgs ra{part_w, grid, part_a, grid, dw1, db1, dw2, db2, C == 32 ? 1 : 0};
-    constexpr int total = 9 * C * C + C * C + 2 * C;
-    hipLaunchKernelGGL(k_wrb_reduce<C>, dim3((total + REL - 1) / REL), dim3(1024), 0, st, ra);
-    TT_LAUNCH_CHECK();
-    return 0;
-}
-
-template <int C>
-int bwd1_c(const e16* x, const e16* h1, const e16* dy, const float* w1, const float* w2, const float* b2, e16* dx,
-           float* dw1, float* db1, float* dw2, float* db2, unsigned char* ws, int B, int H, int T, int D, hipStream_t st) {
-    static const int alt = env_int("TTRAP_BWD1_TILE", 0);
-#define TT_B1(DD, TH_, TW_) return launch_bwd1<C, DD, TH_, TW_>(x, h1, dy, w1, w2, b2, dx, dw1, db1, dw2, db2, ws, B, H, T, st)
-    switch (D) {
-        case 1: if (alt == 1) TT_B1(1, 16, 32); TT_B1(1, 8, 32);
-        case 2: if (alt == 1) TT_B1(2, 16, 32); TT_B1(2, 8, 32);
-        case 3: if (alt == 1) TT_B1(3, 16, 32); TT_B1(3, 8, 32);
-    }
-#undef TT_B1
-    return TT_E_UNSUPPORTED;
-}
-
 // ==== one-pass backward, h1 saved, COLUMN STRIPS with a rolling ring of dA1 rows (round 4) ===================================
-//   k_wrb_bwds<C,D,TH,TW>   The tile form above (k_wrb_bwd1) redoes the pointwise chain on a D halo all round: 1.33x / 1.69x /
-//   2.08x the pixels at dilation 1 / 2 / 3 with 8 x 32 tiles, and it lost.  Here a workgroup owns a STRIP of TW columns over the
+//   k_wrb_bwds<C,D,TH,TW>   the whole backward of a wide ResidualConv2dBlock from x, the SAVED h1 and dy in ONE pass, nothing
+//   recomputed: dA1 = dL/d(conv1 pre-activation) exists in LDS only, and the 3x3 weight gradient is indexed by the pixel of x,
+//   dW1[tap] = sum_q x[q] (x) dA1[q - tap D] (every image pixel q is visited once and dA1 is zero outside the image), so that x
+//   needs no halo.  A first form with 8 x 32 TILES (k_wrb_bwd1, round 4, removed) redid the pointwise chain on a D halo all round
+//   -- 1.33x / 1.69x / 2.08x the pixels at dilation 1 / 2 / 3 -- and lost to the per-stage kernels (C = 32: 0.514 / 0.510 /
+//   0.554 ms against 0.469 / 0.442 / 0.477; C = 16: 0.473 / 0.473 / 0.508 against 0.470 / 0.435 / 0.443).  Here a workgroup owns a STRIP of TW columns over the
 //   whole height and walks it downwards TH rows at a time; dA1 lives in a ring of TH + 2D image rows in LDS, so the rows a step
 //   needs above it are the ones the previous steps computed -- every image row goes through the pointwise chain ONCE per strip and
 //   only the column halo is redone (1.06x / 1.13x / 1.19x).  Step j:
@@ -1057,7 +732,7 @@ int launch_bwds(const e16* x, const e16* h1, const e16* dy, const float* w1, con
     auto kern = k_wrb_bwds<C, D, TH, TW, MINW>;
     if (int rc = raise_lds(kern, G::LDS_BYTES, once)) return rc;
     const int tiles_t = (T + TW - 1) / TW, nstrips = B * tiles_t;
-    static const int per_cu = env_int("TTRAP_BWDS_PER_CU", MINW);
+    static const int per_cu = tt_tune("TTRAP_BWDS_PER_CU", MINW);
     int grid = grid_for(nstrips, G::LDS_BYTES, per_cu);
     if (grid > MAX_W_WG) grid = MAX_W_WG;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), G::LDS_BYTES, st, x, h1, dy, wimg, b2, dx, part_a, part_w, B, H, T, tiles_t, nstrips);
@@ -1072,7 +747,7 @@ int launch_bwds(const e16* x, const e16* h1, const e16* dy, const float* w1, con
 template <int C>
 int bwds_c(const e16* x, const e16* h1, const e16* dy, const float* w1, const float* w2, const float* b2, e16* dx,
            float* dw1, float* db1, float* dw2, float* db2, unsigned char* ws, int B, int H, int T, int D, hipStream_t st) {
-    static const int alt = env_int("TTRAP_BWDS_TILE", 0);
+    static const int alt = tt_tune("TTRAP_BWDS_TILE", 0);
 #define TT_BS(DD, TH_, TW_) return launch_bwds<C, DD, TH_, TW_>(x, h1, dy, w1, w2, b2, dx, dw1, db1, dw2, db2, ws, B, H, T, st)
     switch (D) {
         case 1: if (alt == 1) TT_BS(1, 16, 32); if (alt == 2) TT_BS(1, 4, 32); TT_BS(1, 8, 32);
@@ -1117,11 +792,6 @@ int tt_wide_rb_bwd_onepass(const void* x, const void* h1, const void* dy, const 
     if (!fshape_ok(B, C, H, T)) return TT_E_BADARG;
     const e16 *xi = (const e16*)x, *hi = (const e16*)h1, *gi = (const e16*)dy;
     hipStream_t st = tt_stream(stream);
-    static const int tile_form = env_int("TTRAP_BWD1_FORM", 0);        // 1: the tile form k_wrb_bwd1 (halo all round), kept for A/B
-    if (tile_form) {
-        if (C == 16) return bwd1_c<16>(xi, hi, gi, w1, w2, b2, (e16*)dx, dw1, db1, dw2, db2, (unsigned char*)ws, B, H, T, dilation, st);
-        return bwd1_c<32>(xi, hi, gi, w1, w2, b2, (e16*)dx, dw1, db1, dw2, db2, (unsigned char*)ws, B, H, T, dilation, st);
-    }
     if (C == 16) return bwds_c<16>(xi, hi, gi, w1, w2, b2, (e16*)dx, dw1, db1, dw2, db2, (unsigned char*)ws, B, H, T, dilation, st);
     return bwds_c<32>(xi, hi, gi, w1, w2, b2, (e16*)dx, dw1, db1, dw2, db2, (unsigned char*)ws, B, H, T, dilation, st);
 }

@@ -1575,7 +1575,7 @@ int launch_conv(const float* x, const float* gy, const float* w, WSpec ws, const
         if (dma_ok(x, T)) {
             // measured: the transposed geometry (2 taps) wins up to 16 -> 8 channels, the strided one (4 taps) only at 4 -> 8
             if constexpr ((P::NTAPS == 2 && CIN * COUT <= 128) || (P::NTAPS == 4 && CIN * COUT <= 32)) {
-                static const bool valu = getenv("TTRAP_STRIDED_MFMA") == nullptr;
+                static const bool valu = !tt_tune_set("TTRAP_STRIDED_MFMA");
                 if (valu && !res) return launch_conv_valu<CIN, COUT, P>(x, w, ws, bias, y, B, Hin, Hout, T, act, st);
             }
             if constexpr (P::NTAPS == 9 && CIN >= 4) {
@@ -1638,7 +1638,7 @@ int launch_wgrad(const float* Pt, const float* Pg, const float* Qt, const float*
             // 2.10-2.23 ms, C = 16 1.45-1.56 against 1.41-1.52 ms.  Several independent workgroups hide the DMA wait better than
             // one deeper pipeline.  TTRAP_WGRAD_NBUF=2 keeps the variant reachable for measurements.
             constexpr int NBUF = (CA >= 16 && 2 * SET_FLOATS * 4 <= 160 * 1024) ? 2 : 1;
-            static const bool dbuf_env = NBUF == 2 && getenv("TTRAP_WGRAD_NBUF") && atoi(getenv("TTRAP_WGRAD_NBUF")) == 2;
+            static const bool dbuf_env = NBUF == 2 && tt_tune("TTRAP_WGRAD_NBUF", 1) == 2;
             const bool dbuf = dbuf_env && !(CA >= 16 && WP::NTAPS == 9 && prec != 0);      // the bf16 modes keep the single set
             const int LDS = cmax((dbuf ? 2 : 1) * SET_FLOATS, K::RED_FLOATS) * 4;
             static AttrOnce attr;
@@ -2046,7 +2046,7 @@ extern "C" int tt_resblock_fwd(const float* x, const float* w1, const float* b1,
     // conversion and barrier costs are per PIXEL, and the narrow levels have 8-16x more pixels per channel -- C = 4: 0.68-0.79 ms
     // against 0.40 ms forward, 1.83-1.95 against 0.87-0.96 ms backward; C = 8: 0.54-0.65 against 0.55-0.62 ms forward.
     // TTRAP_NARROW_MFMA=1 keeps that route reachable for measurements.
-    if (C <= 8 && (bf16 == 0 || getenv("TTRAP_NARROW_MFMA") == nullptr))
+    if (C <= 8 && (bf16 == 0 || !tt_tune_set("TTRAP_NARROW_MFMA")))
         return tt_small_rb_fwd(x, w1, b1, w2, b2, y, h1, B, C, H, T, dilation, st);
     TT_DISPATCH_CD(launch_rb_fwd, x, w1, b1, w2, b2, y, h1, B, H, T, st, bf16)
 }
@@ -2059,7 +2059,7 @@ extern "C" int tt_resblock_bwd(const float* x, const float* h1, const float* dy,
     if (!clip_fits(C, H, T)) return TT_E_UNSUPPORTED;
     hipStream_t st = tt_stream(stream);
     const int bf16n = (flags & TT_FLAG_BF16_SPLIT) ? 2 : ((flags & TT_FLAG_BF16_OPERANDS) ? 1 : 0);
-    if (C <= 8 && (bf16n == 0 || getenv("TTRAP_NARROW_MFMA") == nullptr)) {
+    if (C <= 8 && (bf16n == 0 || !tt_tune_set("TTRAP_NARROW_MFMA"))) {
         int rc = tt_small_rb_bwd(x, h1, dy, w1, b1, w2, b2, dx, dw1, db1, dw2, db2, ws, ws + (long)B * C * H * T, B, C, H, T,
                                  dilation, st);
         if (rc == TT_SMALL_BWD_DID_DW1) return 0;           // fused narrow backward: nothing left to do

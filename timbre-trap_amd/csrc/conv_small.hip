@@ -746,7 +746,7 @@ int launch_small_bwd_fused(const float* x, const float* h1, const float* dy, con
     if (per_cu < 1) per_cu = 1;
     int grid = ntiles < tt_cus() * per_cu ? ntiles : tt_cus() * per_cu;
     if (grid > 512) grid = 512;                            // partial images in the caller's scratch (tt_wgrad_scratch_floats)
-    const char* ab = getenv("TTRAP_FUSED_ABLATE");          // measurement only: bit 0 / 1 / 2 / 3 = skip phase 1 / dW1 / dx / re-staging
+    const char* ab = tt_tune_set("TTRAP_FUSED_ABLATE") ? getenv("TTRAP_FUSED_ABLATE") : nullptr;          // measurement only: bit 0 / 1 / 2 / 3 = skip phase 1 / dW1 / dx / re-staging
     hipLaunchKernelGGL((k_small_bwd_fused<C, D, RPT, NW, NBUF>), dim3(grid), dim3(L::NT), L::LDS_BYTES, st, x, h1, dy, w1, w2, b2, dx, db1, dw2,
                        db2, scratch, B, H, T, ab ? atoi(ab) : 0);
     TT_LAUNCH_CHECK();
@@ -757,7 +757,7 @@ int launch_small_bwd_fused(const float* x, const float* h1, const float* dy, con
 
 // the LDS-tiled kernels need LDS-DMA-able rows (T % 4 == 0, 16-byte aligned input); TTRAP_SMALL_GLOBAL=1 forces the
 // thread-per-pixel kernels with global taps (kept for unaligned shapes and for A/B measurements)
-inline bool lds_variant() { static const bool v = getenv("TTRAP_SMALL_GLOBAL") == nullptr; return v; }
+inline bool lds_variant() { static const bool v = !tt_tune_set("TTRAP_SMALL_GLOBAL"); return v; }
 
 inline bool small_mfma_variant() { return getenv("TTRAP_SMALL_VALU_FMA") == nullptr; }   // read per call (tests A/B both forms)
 

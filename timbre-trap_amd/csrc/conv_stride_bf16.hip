@@ -838,7 +838,7 @@ int launch_p2(const e16* in, const e16* gy, const float* w, const float* bias, e
 }
 // the data gradient rides along in the weight-gradient pass where the registers allow it (TTRAP_W4X=0: always two kernels)
 template <int C> inline bool w4x_enabled() {
-    static const int on = getenv("TTRAP_W4X") ? atoi(getenv("TTRAP_W4X")) : 1;
+    static const int on = tt_switch("TTRAP_W4X", 1);
     return on && C <= 32;
 }
 

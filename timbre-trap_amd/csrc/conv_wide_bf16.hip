@@ -21,7 +21,9 @@
 //                                  dA1 = dh1 ELU'(a1); dW2, db1, db2 partials
 //   k_wrb_wgrad<C,D>               dW1[co][ci][tap] = sum_pix dA1[co][pix] x[ci][pix + tap]: K = pixels, both operands by
 //                                  LDS transpose reads (ds_read_b64_tr_b16) from channel-innermost images
-//   k_wrb_reduce<C>                sums the per-wave register dumps into the fp32 gradients (+=), no atomics anywhere
+//   k_wrb_reduce<C>                sums the per-wave register dumps into the fp32 gradients (+=) in a fixed order: no atomics at the
+//                                  wide levels (the narrow levels' k_nrb_reduce below meets the 16 / C diagonal contributions of a
+//                                  dW1 element in atomicAdd: run-to-run differences at fp32 rounding, tests/test_gpu_determinism.py)
 #include "wide_common.h"
 
 namespace {
@@ -103,6 +105,7 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_conv(const e16* __restrict__ x
 
     // ---- weights to registers, rounded to bf16 ----
     e16x8 A[NK][NCT];
+    float chk = 0.f;                                             // MODE 0: non-finite parameters (poison_acc, bf16_common.h)
 #pragma unroll
     for (int k = 0; k < NK; ++k)
 #pragma unroll
@@ -117,6 +120,7 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_conv(const e16* __restrict__ x
                 float wv = 0.f;
                 if (tap < 9) wv = MODE == 0 ? w1[(mo * C + kc) * 9 + tap] : w1[(kc * C + mo) * 9 + (8 - tap)];
                 v[j] = wv;
+                if (MODE == 0) chk = poison_acc(chk, wv);
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) A[k][ct][j] = (e16)v[j];
@@ -129,16 +133,23 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_conv(const e16* __restrict__ x
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) A2[ct][j] = (e16)w2[chan_of<C>(ct, n) * C + 8 * g + j];
+                for (int j = 0; j < 8; ++j) {
+                    const float wv = w2[chan_of<C>(ct, n) * C + 8 * g + j];
+                    chk = poison_acc(chk, wv);
+                    A2[ct][j] = (e16)wv;
+                }
         } else {
             e16x4 t;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) t[j] = (e16)w2[n * C + 4 * g + j];
+            for (int j = 0; j < 4; ++j) { const float wv = w2[n * C + 4 * g + j]; chk = poison_acc(chk, wv); t[j] = (e16)wv; }
             A2s = __builtin_bit_cast(s16x4, t);
         }
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) { b1r[j] = b1[NCH * g + j]; b2r[j] = b2[NCH * g + j]; }
+        for (int j = 0; j < NCH; ++j) { b1r[j] = b1[NCH * g + j]; b2r[j] = b2[NCH * g + j]; chk = poison_acc(poison_acc(chk, b1r[j]), b2r[j]); }
     }
+    // a NaN / inf weight or bias must reach the output like in torch (the ELU forms below return 0 for a NaN pre-activation): the
+    // workgroup then writes NaN to every output it owns
+    const bool poisoned = MODE == 0 && params_poisoned(chk);
 
     const e16* zero = reinterpret_cast<const e16*>(&g_wzero16);
     for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
@@ -167,6 +178,16 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_conv(const e16* __restrict__ x
             if (h >= H) break;
             const long pix = ((long)b * H + h) * T + t;
             const bool valid = t < T;
+            if (poisoned) {
+                if (valid) {
+                    typename std::conditional<C == 32, e16x8, e16x4>::type qn;
+#pragma unroll
+                    for (int j = 0; j < NCH; ++j) qn[j] = (e16)__builtin_nanf("");
+                    *reinterpret_cast<decltype(qn)*>(y + pix * C + NCH * g) = qn;
+                    if (SAVE) *reinterpret_cast<decltype(qn)*>(h1 + pix * C + NCH * g) = qn;
+                }
+                continue;
+            }
             f32x4 acc[NCT];                                      // the bias enters as the accumulator's initial value
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
@@ -213,7 +234,7 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_conv(const e16* __restrict__ x
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < NCH; ++j) val[j] = elu_f(val[j]);
+                for (int j = 0; j < NCH; ++j) val[j] = elu_res(val[j]);
                 if constexpr (C == 32) {
                     e16x8 hq;
 #pragma unroll
@@ -224,8 +245,8 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_conv(const e16* __restrict__ x
                     e16x8 o;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        o[j] = (e16)(elu_f(z0[j]) + (float)centre[j]);
-                        o[4 + j] = (e16)(elu_f(z1[j]) + (float)centre[4 + j]);
+                        o[j] = (e16)(elu_res(z0[j]) + (float)centre[j]);
+                        o[4 + j] = (e16)(elu_res(z1[j]) + (float)centre[4 + j]);
                     }
                     if (valid) *reinterpret_cast<e16x8*>(y + pix * C + 8 * g) = o;
                 } else {
@@ -238,7 +259,7 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_conv(const e16* __restrict__ x
                     const e16x4 xc = *reinterpret_cast<const e16x4*>(smem + ((long)pxc * C + 8 * ((g >> 1) ^ cswz<C>(colc)) + 4 * (g & 1)) * 2);
                     e16x4 o;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (e16)(elu_f(z[j]) + (float)xc[j]);
+                    for (int j = 0; j < 4; ++j) o[j] = (e16)(elu_res(z[j]) + (float)xc[j]);
                     if (valid) *reinterpret_cast<e16x4*>(y + pix * C + 4 * g) = o;
                 }
             }
@@ -249,7 +270,7 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_conv(const e16* __restrict__ x
 // ---- pointwise chain of the backward ---------------------------------------------------------------------------------
 // One wave per group of 16 consecutive pixels (the tensor is [npix][C]); operands straight from HBM in B-operand layout.
 // Every workgroup leaves its accumulators as a raw register dump [dW2: ((a NCT + c) 4 + r) 64 + lane][db1 C][db2 C]
-// (the four waves summed through LDS); k_wrb_reduce sums the dumps of all workgroups (no atomics anywhere).
+// (the four waves summed through LDS); k_wrb_reduce sums the dumps of all workgroups in a fixed order (no atomics).
 // The 16-pixel tiles are read back transposed (lds_tr16, bf16_common.h) as the K = pixels operands of the dW2 product.
 template <int C> struct WA {
     static constexpr int PS = C * 2 + 8;                         // bytes per pixel of the transposition buffers (bank spread)
@@ -673,8 +694,8 @@ int launch_conv(const e16* x, const float* w1, const float* b1, const float* w2,
                 e16* y, e16* h1, int B, int H, int T, hipStream_t st) {
     using G = WT<C, D>;
     const int tiles_h = (H + G::TH - 1) / G::TH, tiles_t = (T + G::TW - 1) / G::TW, ntiles = B * tiles_h * tiles_t;
-    static const int per_cu = getenv("TTRAP_WIDE_PER_CU") ? atoi(getenv("TTRAP_WIDE_PER_CU")) : 4;
-    static const int w3 = env_int("TTRAP_WCONV_W3", 0);
+    static const int per_cu = tt_tune("TTRAP_WIDE_PER_CU", 4);
+    static const int w3 = tt_tune("TTRAP_WCONV_W3", 0);
     if (C == 32 && MODE == 0 && w3) {
         static AttrOnce once3;
         auto kern = k_wrb_conv<C, D, MODE, SAVE, (C == 32 && MODE == 0) ? 3 : 2>;
@@ -706,7 +727,7 @@ int launch_dxw(const e16* x, const e16* da1, const e16* dy, const float* w1, e16
     auto kx = k_wrb_dxw<C, D, TH, TW>;
     if (int rc = raise_lds(kx, X::LDS_BYTES, once_x)) return rc;
     const int tiles_h = (H + TH - 1) / TH, tiles_t = (T + TW - 1) / TW, ntiles = B * tiles_h * tiles_t;
-    static const int x_per_cu = env_int("TTRAP_DXW_PER_CU", C == 32 ? 3 : 4);      // registers: 165 / 113 VGPRs
+    static const int x_per_cu = tt_tune("TTRAP_DXW_PER_CU", C == 32 ? 3 : 4);      // registers: 165 / 113 VGPRs
     int gx = grid_for(ntiles, X::LDS_BYTES, x_per_cu);
     if (gx > MAX_W_WG) gx = MAX_W_WG;
     hipLaunchKernelGGL(kx, dim3(gx), dim3(NT), X::LDS_BYTES, st, x, da1, dy, w1, dx, part_w, B, H, T, tiles_h, tiles_t, ntiles);
@@ -726,7 +747,7 @@ int launch_dxw(const e16* x, const e16* da1, const e16* dy, const float* w1, e16
 //   per call (PMC, profiles/r04_pmc_bwds.txt) but two waves per SIMD leave the vector ALUs 39 % and the matrix pipe 19 % busy with
 //   the waves parked 39 % of their life -- not taken.
 inline int onepass_choice(int C, int D) {
-    static const int forced = env_int("TTRAP_WBWD1", -1);
+    static const int forced = tt_switch("TTRAP_WBWD1", -1);
     if (forced >= 0) return forced ? 1 : 0;
     (void)D;
     return C == 16 ? 1 : 0;
@@ -748,13 +769,13 @@ int launch_bwd(const e16* x, const e16* h1, const e16* dy, const float* w1, cons
     if (int rc = raise_lds(kern, G::LDS_BYTES, once)) return rc;
     const long ngroups = (npix + 15) / 16;
     const long want = (ngroups + 3) / 4;
-    static const int a_per_cu = env_int("TTRAP_BWDA_PER_CU", 4);
+    static const int a_per_cu = tt_tune("TTRAP_BWDA_PER_CU", 4);
     int grid = (int)(want < (long)a_per_cu * tt_cus() ? want : (long)a_per_cu * tt_cus());
     if (grid > MAX_A_WG) grid = MAX_A_WG;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), G::LDS_BYTES, st, h1, dy, w2, b2, da1, part_a, npix, ngroups);
     TT_LAUNCH_CHECK();
     // data gradient + weight gradient in one pass (TTRAP_DXW=0: the two separate kernels)
-    static const int dxw = env_int("TTRAP_DXW", 1);
+    static const int dxw = tt_switch("TTRAP_DXW", 1);
     if (dxw) {
         // tiles 8 x 32 at both widths (round 3, per call at the bench shape, separate kernels -> merged: C = 32 0.486 / 0.485 / 0.521 ->
         // 0.413 / 0.443 / 0.454 ms; C = 16 0.469 / 0.469 / 0.474 -> 0.430 / 0.431 / 0.451 ms; 8 x 64 tiles at C = 16 lose at
@@ -772,7 +793,7 @@ int launch_bwd(const e16* x, const e16* h1, const e16* dy, const float* w1, cons
     auto kw = k_wrb_wgrad<C, D>;
     if (int rc = raise_lds(kw, W::LDS_BYTES, once_w)) return rc;
     const int tiles_h = (H + W::TH - 1) / W::TH, tiles_t = (T + W::TW - 1) / W::TW, ntiles = B * tiles_h * tiles_t;
-    static const int w_per_cu = env_int("TTRAP_WGRAD_PER_CU", 2);
+    static const int w_per_cu = tt_tune("TTRAP_WGRAD_PER_CU", 2);
     int gw = grid_for(ntiles, W::LDS_BYTES, w_per_cu);
     if (gw > MAX_W_WG) gw = MAX_W_WG;
     hipLaunchKernelGGL(kw, dim3(gw), dim3(NT), W::LDS_BYTES, st, x, da1, part_w, B, H, T, tiles_h, tiles_t, ntiles);
@@ -852,6 +873,7 @@ __global__ __launch_bounds__(NT, (C == 8 && MODE == 0) ? 3 : 1) void k_nrb_conv(
     constexpr int NB = C / 4;
 
     s16x4 A[9][NB][NB], A2[NB][NB];
+    float chk = 0.f;                                             // MODE 0: non-finite parameters (poison_acc, bf16_common.h)
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
@@ -862,7 +884,9 @@ __global__ __launch_bounds__(NT, (C == 8 && MODE == 0) ? 3 : 1) void k_nrb_conv(
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int mo = 4 * ob + i4, kc = 4 * kb + k;
-                    t[k] = (e16)(MODE == 0 ? w1[(mo * C + kc) * 9 + tap] : w1[(kc * C + mo) * 9 + (8 - tap)]);
+                    const float wv = MODE == 0 ? w1[(mo * C + kc) * 9 + tap] : w1[(kc * C + mo) * 9 + (8 - tap)];
+                    if (MODE == 0) chk = poison_acc(chk, wv);
+                    t[k] = (e16)wv;
                 }
                 A[tap][ob][kb] = __builtin_bit_cast(s16x4, t);
             }
@@ -874,12 +898,13 @@ __global__ __launch_bounds__(NT, (C == 8 && MODE == 0) ? 3 : 1) void k_nrb_conv(
             for (int kb = 0; kb < NB; ++kb) {
                 e16x4 t;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) t[k] = (e16)w2[(4 * ob + i4) * C + 4 * kb + k];
+                for (int k = 0; k < 4; ++k) { const float wv = w2[(4 * ob + i4) * C + 4 * kb + k]; chk = poison_acc(chk, wv); t[k] = (e16)wv; }
                 A2[ob][kb] = __builtin_bit_cast(s16x4, t);
             }
 #pragma unroll
-        for (int c = 0; c < C; ++c) { b1r[c] = b1[c]; b2r[c] = b2[c]; }
+        for (int c = 0; c < C; ++c) { b1r[c] = b1[c]; b2r[c] = b2[c]; chk = poison_acc(poison_acc(chk, b1r[c]), b2r[c]); }
     }
+    const bool poisoned = MODE == 0 && params_poisoned(chk);    // see k_wrb_conv
 
     const e16* zero = reinterpret_cast<const e16*>(&g_wzero16);
     for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
@@ -906,6 +931,16 @@ __global__ __launch_bounds__(NT, (C == 8 && MODE == 0) ? 3 : 1) void k_nrb_conv(
             const int h = h0 + r;
             if (h >= H) break;
             const long pix = ((long)b * H + h) * T + t;
+            if (poisoned) {
+                if (valid) {
+                    vec_t qn;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) qn[c] = (e16)__builtin_nanf("");
+                    *reinterpret_cast<vec_t*>(y + pix * C) = qn;
+                    if (SAVE) *reinterpret_cast<vec_t*>(h1 + pix * C) = qn;
+                }
+                continue;
+            }
             vec_t rq;
             if constexpr (MODE == 1) rq = *reinterpret_cast<const vec_t*>(res + (valid ? pix : pix - (t - (T - 1))) * C);
             f32x4 acc[NB];
@@ -933,7 +968,7 @@ __global__ __launch_bounds__(NT, (C == 8 && MODE == 0) ? 3 : 1) void k_nrb_conv(
             } else {
                 vec_t hq;
 #pragma unroll
-                for (int c = 0; c < C; ++c) hq[c] = (e16)elu_f(acc[c >> 2][c & 3]);
+                for (int c = 0; c < C; ++c) hq[c] = (e16)elu_res(acc[c >> 2][c & 3]);
                 if (SAVE && valid) *reinterpret_cast<vec_t*>(h1 + pix * C) = hq;
                 f32x4 z[NB];
 #pragma unroll
@@ -943,7 +978,7 @@ __global__ __launch_bounds__(NT, (C == 8 && MODE == 0) ? 3 : 1) void k_nrb_conv(
                     for (int kb = 0; kb < NB; ++kb) z[ob] = mma4(A2[ob][kb], chunk_of<C>(hq, kb), z[ob]);
                 }
 #pragma unroll
-                for (int c = 0; c < C; ++c) o[c] = (e16)(elu_f(z[c >> 2][c & 3]) + (float)centre[c]);
+                for (int c = 0; c < C; ++c) o[c] = (e16)(elu_res(z[c >> 2][c & 3]) + (float)centre[c]);
             }
             if (valid) *reinterpret_cast<vec_t*>(y + pix * C) = o;
         }
@@ -1518,7 +1553,7 @@ int launch_nconv(const e16* x, const float* w1, const float* b1, const float* w2
     if (int rc = raise_lds(kern, G::LDS_BYTES, once)) return rc;
     const int tiles_h = (H + G::TH - 1) / G::TH, tiles_t = (T + G::TW - 1) / G::TW, ntiles = B * tiles_h * tiles_t;
     // workgroups per CU (LDS allows 5-10): 2 / 4 / 6 / 8 -> data gradient of a C = 4 block 0.25 / 0.19 / 0.165 / 0.165 ms
-    static const int per_cu = getenv("TTRAP_NARROW_PER_CU") ? atoi(getenv("TTRAP_NARROW_PER_CU")) : 6;
+    static const int per_cu = tt_tune("TTRAP_NARROW_PER_CU", 6);
     hipLaunchKernelGGL(kern, dim3(grid_for(ntiles, G::LDS_BYTES, per_cu)), dim3(NT), G::LDS_BYTES, st, x, w1, b1, w2, b2, res, y, h1,
                        B, H, T, tiles_h, tiles_t, ntiles);
     TT_LAUNCH_CHECK();
@@ -1539,7 +1574,7 @@ int launch_nbwd(const e16* x, const e16* h1, const e16* dy, const float* w1, con
     // C = 8: 0.410 / 0.409 / 0.452 -> 0.394 / 0.411 / 0.563 ms for dilation 1 / 2 / 3, C = 4: 0.40 / 0.407 / 0.408 -> 0.338 / 0.344 / 0.383 ms.
     // Half the HBM traffic buys less than half the time because the pass is then bound by its own arithmetic (pointwise chain on the halo
     // as well; three LDS images = 2 workgroups per CU at C = 8): fused where it wins -- C = 4 always, C = 8 at dilation 1, 2.
-    static const int fused = getenv("TTRAP_NARROW_FUSED16") ? atoi(getenv("TTRAP_NARROW_FUSED16")) : 1;
+    static const int fused = tt_switch("TTRAP_NARROW_FUSED16", 1);
     if (fused == 2 || (fused == 1 && (C == 8 ? D <= 2 : true))) {
         using F = NTl<C, D>;
         constexpr int LDS = 3 * F::NPR * 16 + 11 * (C / 4) * (C / 4) * 32;        // three images + the bf16 weight image
@@ -1549,7 +1584,7 @@ int launch_nbwd(const e16* x, const e16* h1, const e16* dy, const float* w1, con
         const int tiles_h = (H + F::TH - 1) / F::TH, tiles_t = (T + F::TW - 1) / F::TW, ntiles = B * tiles_h * tiles_t;
         int gf = grid_for(ntiles, LDS, 4);
         if (gf > MAX_W_WG) gf = MAX_W_WG;
-        static const int fastdma = env_int("TTRAP_FAST_DMA", 1);
+        static const int fastdma = tt_tune("TTRAP_FAST_DMA", 1);
         hipLaunchKernelGGL(kf, dim3(gf), dim3(NT), LDS, st, x, h1, dy, w1, w2, b2, dx, part_a, part_w, B, H, T, tiles_h, tiles_t, ntiles, fastdma);
         TT_LAUNCH_CHECK();
         RedArgs ra{part_w, gf, part_a, gf, dw1, db1, dw2, db2};
@@ -1560,12 +1595,12 @@ int launch_nbwd(const e16* x, const e16* h1, const e16* dy, const float* w1, con
     }
     const long ngroups = (npix + 63) / 64;
     const long want = (ngroups + 3) / 4;
-    static const int a_per_cu = env_int("TTRAP_BWDA_PER_CU", 4);
+    static const int a_per_cu = tt_tune("TTRAP_BWDA_PER_CU", 4);
     int grid = (int)(want < (long)a_per_cu * tt_cus() ? want : (long)a_per_cu * tt_cus());
     if (grid > MAX_A_WG) grid = MAX_A_WG;
     hipLaunchKernelGGL(k_nrb_bwd_a<C>, dim3(grid), dim3(NT), 0, st, h1, dy, w2, b2, da1, part_a, npix, ngroups);
     TT_LAUNCH_CHECK();
-    static const int ndxw = env_int("TTRAP_NDXW", 1);
+    static const int ndxw = tt_switch("TTRAP_NDXW", 1);
     if (ndxw) {                                                  // data + weight gradient in one pass
         using F = NTl<C, D>;
         constexpr int LDS = 2 * F::NPR * 16 > 4 * 2304 * 4 ? 2 * F::NPR * 16 : 4 * 2304 * 4;   // images, then the four waves' accumulators
@@ -1573,7 +1608,7 @@ int launch_nbwd(const e16* x, const e16* h1, const e16* dy, const float* w1, con
         auto kx = k_nrb_dxw<C, D>;
         if (int rc = raise_lds(kx, LDS, once_x)) return rc;
         const int tiles_h = (H + F::TH - 1) / F::TH, tiles_t = (T + F::TW - 1) / F::TW, ntiles = B * tiles_h * tiles_t;
-        static const int x_per_cu = env_int("TTRAP_NDXW_PER_CU", 4);
+        static const int x_per_cu = tt_tune("TTRAP_NDXW_PER_CU", 4);
         int gx = grid_for(ntiles, LDS, x_per_cu);
         if (gx > MAX_W_WG) gx = MAX_W_WG;
         hipLaunchKernelGGL(kx, dim3(gx), dim3(NT), LDS, st, x, da1, dy, w1, dx, part_w, B, H, T, tiles_h, tiles_t, ntiles);
@@ -1590,7 +1625,7 @@ int launch_nbwd(const e16* x, const e16* h1, const e16* dy, const float* w1, con
     auto kw = k_nrb_wgrad<C, D>;
     if (int rc = raise_lds(kw, W::LDS_BYTES, once_w)) return rc;
     const int tiles_h = (H + W::TH - 1) / W::TH, tiles_t = (T + W::TW - 1) / W::TW, ntiles = B * tiles_h * tiles_t;
-    static const int w_per_cu = env_int("TTRAP_NWGRAD_PER_CU", 3);
+    static const int w_per_cu = tt_tune("TTRAP_NWGRAD_PER_CU", 3);
     int gw = grid_for(ntiles, W::LDS_BYTES, w_per_cu);
     if (gw > MAX_W_WG) gw = MAX_W_WG;
     hipLaunchKernelGGL(kw, dim3(gw), dim3(NT), W::LDS_BYTES, st, x, da1, part_w, B, H, T, tiles_h, tiles_t, ntiles);

@@ -277,7 +277,7 @@ extern "C" int tt_gemm(const float* A, const float* Bm, float* C, const float* b
     GemmP p{A, Bm, C, bias, M, N, K,
             transA ? 1 : (long)lda, transA ? (long)lda : 1, transB ? 1 : (long)ldb, transB ? (long)ldb : 1, (long)ldc,
             (long)sa, (long)sb, (long)sc, reduce_batch, batch, alpha, beta, bias_mode, bias_div > 0 ? bias_div : 1, act};
-    static const bool valu_only = getenv("TTRAP_GEMM_VALU") != nullptr;      // A/B switch for measurements
+    static const bool valu_only = tt_tune_set("TTRAP_GEMM_VALU");      // A/B switch for measurements
     if (!valu_only) {
         // 64 rows per workgroup; row tiles past M are skipped inside the kernel (M = 129: the third block does 1/4 of the MFMAs)
         // reduce_batch: up to 64 batch groups (measured: 64-way atomics per element cost less than longer per-workgroup loops)

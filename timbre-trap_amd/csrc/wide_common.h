@@ -1,5 +1,5 @@
-// Pieces shared by the bf16 channel-innermost residual-block kernels (conv_wide_bf16.hip: one kernel per stage;
-// conv_level_bf16.hip: fused backward with recomputed hidden activation, level-fused forward) for gfx950.
+// Pieces shared by the 16-bit channel-innermost residual-block kernels (conv_wide_bf16.hip: one kernel per stage;
+// conv_level_bf16.hip: the one-pass backward kernels -- hidden activation saved (column strips) or recomputed (tiles)) for gfx950.
 #pragma once
 #include "bf16_common.h"
 
@@ -50,7 +50,6 @@ __device__ __forceinline__ void conv_taps(const unsigned char* img, int row, int
 }
 
 constexpr int MAX_A_WG = 2048, MAX_W_WG = 1024;   // workgroups that leave dumps (bounds the scratch)
-inline int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 
 // Sum of the register dumps into the fp32 gradients (+=).  1024 threads = REL consecutive dump elements x RSL slices of the
 // contributing waves (bf16_common.h); the dump order keeps the loads coalesced, the scatter into dW1 / dW2 is the cheap side.

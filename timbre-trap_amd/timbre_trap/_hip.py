@@ -121,6 +121,12 @@ def build(verbose=False, force=False):
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     deps = srcs + [os.path.join(CSRC, 'common.h'), os.path.join(REPO_ROOT, 'include', 'ttrap.h')]
     deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')] + [os.path.abspath(__file__)]
+    if os.environ.get('TTRAP_LIB'):
+        # an alternative build selected for an A/B run (tools/build_variant.sh made it with ITS flags): never rebuilt from here --
+        # that would overwrite the variant with the default flags and compare default against default
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError('TTRAP_LIB=%s: %s does not exist (build it with tools/build_variant.sh)' % (os.environ['TTRAP_LIB'], LIB_PATH))
+        return LIB_PATH
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)

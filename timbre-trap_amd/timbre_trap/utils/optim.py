@@ -124,10 +124,21 @@ class FusedAdamW(torch.optim.Optimizer):
         if closure is not None:
             raise NotImplementedError
         g = self.param_groups[0]
+        # torch.optim.AdamW skips a parameter without a gradient (frozen after the optimizer was built, or ``p.grad = None``): neither
+        # its residual momentum nor the weight decay may move it.  The fused kernel walks the whole flat buffer, so the slots of such
+        # parameters (zero gradient: nothing in the clipping norm either) are put back, moments included, after the update.
+        frozen = [(o, k) for p, o, k in self._slots if p.grad is None or not p.requires_grad]
         self._reattach()
+        keep = [(o, k, self.flat_param[o:o + k].clone(), self.exp_avg[o:o + k].clone(), self.exp_avg_sq[o:o + k].clone()) for o, k in frozen]
+        for o, k in frozen:
+            self.flat_grad[o:o + k].zero_()
         self._step += 1
         with _hip.timed('clip_adamw'):
             norm = self._clip_and_update(g)
+        for o, k, p0, m0, v0 in keep:
+            self.flat_param[o:o + k].copy_(p0)
+            self.exp_avg[o:o + k].copy_(m0)
+            self.exp_avg_sq[o:o + k].copy_(v0)
         return norm
 
     def _clip_and_update(self, g):

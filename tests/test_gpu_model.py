@@ -280,10 +280,10 @@ def _bench_style_targets(n, n_bins, T, seed=4321):
     return target
 
 
-def _autocast_step_vs_oracle(n_clips, n_blocks, n_mpe, record=None, bench_targets=False, dtype=torch.bfloat16, bars=(3e-2, 1e-2, 3e-2, 6e-2, 0.999)):
+def _autocast_step_vs_oracle(n_clips, n_blocks, n_mpe, record=None, bench_targets=False, dtype=torch.bfloat16, bars=(3e-2, 1e-2, 3e-2, 6e-2, 0.999, 2e-2)):
     """
     One train step of mc 2 / latent 128 under torch.autocast (16-bit channels-last path of element type ``dtype``; ``bars`` = outputs,
-    losses, gradient relative L2, the same for bias vectors, cosine) against the fp32 CPU oracle: the five
+    losses, gradient relative L2, the same for bias vectors, cosine, median of the gradients' relative L2) against the fp32 CPU oracle: the five
     outputs, the four losses and EVERY parameter gradient of the total loss.  ``n_clips`` items of ``n_blocks`` 3-s blocks each
     (T = n_blocks * 1024 frames per item); the first ``n_mpe`` items are annotated -- the `[:mpe_batch_size]` slices of
     reference experiments/train.py:429,439-441 are live when n_mpe < n_clips.
@@ -310,7 +310,7 @@ def _autocast_step_vs_oracle(n_clips, n_blocks, n_mpe, record=None, bench_target
     tot_ref.backward()
     # HIP path under autocast
     c, g = coeffs.cuda(), gt.cuda()
-    out_bar, loss_bar, grad_bar, bias_bar, cos_bar = bars
+    out_bar, loss_bar, grad_bar, bias_bar, cos_bar, median_bar = bars
     with torch.autocast(device_type='cuda', dtype=dtype):
         latents, emb, _ = model.encoder(c)
         rec, trn = model.decode(latents, None), model.decode(latents, None, True)
@@ -366,6 +366,7 @@ def _autocast_step_vs_oracle(n_clips, n_blocks, n_mpe, record=None, bench_target
     for rel, cos, k in stats:
         bar = bias_bar if k.endswith('.bias') else grad_bar
         assert rel <= bar and cos >= cos_bar, (k, rel, cos)
+    assert rels[n_checked // 2] <= median_bar, rels[n_checked // 2]
     assert n_checked == len(params) >= 120
 
 
@@ -384,10 +385,16 @@ def test_autocast_bf16_step_matches_oracle_outputs_losses_and_all_gradients():
 def test_autocast_fp16_step_matches_oracle_outputs_losses_and_all_gradients():
     """The same step under the reference's OWN autocast dtype -- ``torch.autocast('cuda')`` is float16 (experiments/train.py:415), which
     selects the fp16 twins of every 16-bit kernel (include/ttrap.h, suffix _h): 11 significant bits per stored element instead of
-    bf16's 8, so every bar is 4x tighter than the bf16 test's (outputs 8e-3, losses 2.5e-3, gradients 8e-3, bias vectors 1.6e-2).
-    Two clips x T = 1024: dL/dlogit ~ 1e-3 of the error, well inside fp16's normal range (profiles/r04_fp16_vs_bf16.txt has the
-    64-clip figures, where the reference's missing GradScaler starts to matter)."""
-    _autocast_step_vs_oracle(2, 1, 2, record='fp16_grad_parity.txt', dtype=torch.float16, bars=(8e-3, 2.5e-3, 8e-3, 1.6e-2, 0.9999))
+    bf16's 8.  Measured on MI355X (round 4, profiles/r04_fp16_vs_bf16.txt, profiles/r04_fp16_grad_parity.txt):
+      * forward: the five outputs agree with fp32 to 1.1-1.4e-3 of their maximum (bf16: 0.8-1.1e-2) -- the expected 8x;
+      * backward: the MEDIAN gradient agrees to 1.3e-3 (bf16: 7.9e-3), but the first encoder levels read 2-4e-2, WORSE than bf16's
+        1.2e-2: their activation gradients are ~1e-7 and leave fp16's normal range (6.1e-5; 24 significant bits only down to there) --
+        the reference trains under this autocast without a GradScaler, and so does this path.  At the bench batch (64 clips: the
+        loss is a mean over B x T frames, dL/dlogit ~ 3e-5 of the error) the median falls to 3.4e-2 and single tensors to 0.5, where
+        bf16 stays at 7e-3 / 3.6e-2: fp16 is the tighter INFERENCE arithmetic, bf16 the better training arithmetic, which is why
+        bench.py's train step asks for bfloat16.
+    Bars: outputs 4e-3, losses 2.5e-3, gradient median 3e-3, every gradient 8e-2 with cosine >= 0.998."""
+    _autocast_step_vs_oracle(2, 1, 2, record='fp16_grad_parity.txt', dtype=torch.float16, bars=(4e-3, 2.5e-3, 8e-2, 8e-2, 0.998, 3e-3))
 
 
 def test_autocast_bf16_step_at_reference_training_shape():

@@ -728,7 +728,7 @@ int launch_bwds(const e16* x, const e16* h1, const e16* dy, const float* w1, con
     hipLaunchKernelGGL(k_lvl_wprep<C>, dim3(K::NK * K::NCT + 1), dim3(64), 0, st, w1, w2, wimg);
     TT_LAUNCH_CHECK();
     static AttrOnce once;
-    constexpr int MINW = C == 32 ? 2 : 4;          // registers: 192 (C = 32), 124 (C = 16)
+    constexpr int MINW = C == 32 ? 3 : 4;          // registers: 192 (C = 32), 124 (C = 16)
     auto kern = k_wrb_bwds<C, D, TH, TW, MINW>;
     if (int rc = raise_lds(kern, G::LDS_BYTES, once)) return rc;
     const int tiles_t = (T + TW - 1) / TW, nstrips = B * tiles_t;

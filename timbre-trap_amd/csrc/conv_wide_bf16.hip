@@ -1307,10 +1307,19 @@ __global__ __launch_bounds__(NT, C == 8 ? 2 : 1) void k_nrb_bwd_fused(const e16*
                 // crossed lane selects and register rotations, and ONE of the 64 accumulators then came out different from run to run
                 // (a single pixel product wrong in ~3 % of the workgroups; tools/probes/dbg_nrb.py; not reproduced by the standalone
                 // instruction probes, cause not found).  A packed fp32 op issues at half rate anyway.
+                // -DTTRAP_NRB_DW2_SLP rebuilds the failing form (the plain loop, left to the vectoriser) for the investigation:
+                // tools/build_variant.sh slpdw2 -DTTRAP_NRB_DW2_SLP; TTRAP_LIB=libttrap_slpdw2.so pytest tests/test_gpu_determinism.py;
+                // the two listings of this loop are profiles/r04_isa_nrb_dw2_{asm,slp}.txt.
 #pragma unroll
                 for (int co = 0; co < C; ++co)
 #pragma unroll
-                    for (int ci = 0; ci < C; ++ci) asm("v_fmac_f32 %0, %1, %2" : "+v"(acc[co * C + ci]) : "v"(gr[co]), "v"(hv[ci]));
+                    for (int ci = 0; ci < C; ++ci) {
+#ifdef TTRAP_NRB_DW2_SLP
+                        acc[co * C + ci] += gr[co] * hv[ci];
+#else
+                        asm("v_fmac_f32 %0, %1, %2" : "+v"(acc[co * C + ci]) : "v"(gr[co]), "v"(hv[ci]));
+#endif
+                    }
                 if (in_img) *reinterpret_cast<vec_t*>(hs + (long)q * G::PXB) = aq;
             }
         }

@@ -2,6 +2,8 @@
 # A/B of the one-pass wide backward (strip form k_wrb_bwds; TTRAP_BWD1_FORM=1: tile form k_wrb_bwd1) against the per-stage kernels at the
 # bench shape; env switches are read once per process
 cd "$(dirname "$0")/.."
+# the per-CU / tile knobs are tt_tune switches: compiled out of the shipped library, read by a -DTTRAP_EXPERIMENTAL build
+bash tools/build_variant.sh exp -DTTRAP_EXPERIMENTAL > /dev/null 2>&1 && export TTRAP_LIB=libttrap_exp.so
 out=gpurun_out/r04_bwd1_ab.txt
 : > $out
 for C in 32 16; do

@@ -27,6 +27,7 @@ Prints ONE JSON line on rank 0 with the driver's fields plus
                         rocprofv3 PMC passes of those kernels (`traffic_source` names the file -- not re-measured in this run)
   "roofline_fwd"      : the fused block forward k_wrb_conv<32,D,0> the same way (round 2's roofline kernel; fp32 path: k_rb_fwd<32,D>
                         against the fp32 matrix peak)
+  "roofline_onepass_bwd" : the same call one level down (C = 16), where it runs as the one-pass strip kernel k_wrb_bwds (round 4)
   "roofline_cqt"      : tt_cqt_forward, measured in the timed steps (HBM bound, 4,688,280 algorithmic bytes per clip)
   "roofline_cqt_inv"  : tt_cqt_inverse (CQT.decode) on the same batch, measured after the timed region (training never calls it)
   "families"          : per kernel family (narrow / wide residual blocks, strided, transposed, latent GEMMs, boundary convs,
@@ -341,10 +342,12 @@ def cpu_baseline(mc, latent, seconds_budget=15.0, config0=False):
                 s_per_step=step_s, legs_s={k: v / n for k, v in legs.items()})
 
 
-def bench_inference(model, args, rank, world, dev, steps=None, warmup=None, emit=True, autocast=False):
+def bench_inference(model, args, rank, world, dev, steps=None, warmup=None, emit=True, autocast=False, dtype=None):
     """BASELINE.json configs[1]: model.transcribe(audio) + model.reconstruct(audio), batch x 3 s clips (secondary line).
-    autocast=True: the same calls inside torch.autocast (bf16 channels-last path) -- what a user who evaluates under autocast gets;
-    the reference's evaluate.py does not, so the fp32 figure is the one that carries the 1e-4 output bar."""
+    autocast=True: the same calls inside torch.autocast (16-bit channels-last path of element type ``dtype``, default bfloat16) -- what a
+    user who evaluates under autocast gets; the reference's evaluate.py does not, so the fp32 figure is the one that carries the 1e-4
+    output bar."""
+    dtype = dtype or torch.bfloat16
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
     was_training = model.training
@@ -353,7 +356,7 @@ def bench_inference(model, args, rank, world, dev, steps=None, warmup=None, emit
     audio, _ = synthetic_batch(batch, rank, dev)
 
     def step():
-        with torch.no_grad(), torch.autocast(device_type='cuda', dtype=torch.bfloat16, enabled=autocast):
+        with torch.no_grad(), torch.autocast(device_type='cuda', dtype=dtype, enabled=autocast):
             act = model.transcribe(audio)
             rec = model.reconstruct(audio)
         return act, rec
@@ -370,7 +373,7 @@ def bench_inference(model, args, rank, world, dev, steps=None, warmup=None, emit
     line = dict(metric='audio-seconds/s inference throughput, transcribe()+reconstruct() (9oct x 60bpo, 3s@22.05kHz)',
                 value=world * batch * SECS_PER_CLIP / (elapsed / steps), unit='audio-seconds/s', n_gpus=world,
                 steps=steps, warmup=warmup, ms_per_step=ms, higher_is_better=True, scaling='weak',
-                vs_baseline=None, dtype='bf16' if autocast else args.infer_dtype, data='synthetic',
+                vs_baseline=None, dtype=('f16' if dtype == torch.float16 else 'bf16') if autocast else args.infer_dtype, data='synthetic',
                 config=dict(workload='transcribe() + reconstruct() (each: 3 half-overlapping chunks per clip through CQT + '
                                      'encoder + decoder, Hann cross-fade; reconstruct adds the inverse CQT), model_complexity=%d '
                                      'latent=%d, %d clips x 3 s' % (args.mc, args.latent, batch),
@@ -426,7 +429,7 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='clips per GPU')
     ap.add_argument('--mc', type=int, default=2)
     ap.add_argument('--latent', type=int, default=128)
-    ap.add_argument('--precision', choices=('auto', 'fp32', 'bf16x3', 'bf16'), default=os.environ.get('TTRAP_PRECISION', 'auto'),
+    ap.add_argument('--precision', choices=('auto', 'fp32', 'bf16x3', 'bf16', 'fp16'), default=os.environ.get('TTRAP_PRECISION', 'auto'),
                     help="auto (default) = like the reference: the train step runs under torch.autocast and takes the bf16 MFMA conv path "
                          "(BASELINE config[2]), inference runs in exact fp32; fp32 / bf16x3 / bf16 force one arithmetic everywhere")
     ap.add_argument('--mode', choices=('train', 'infer'), default='train',
@@ -445,8 +448,8 @@ def main():
     from timbre_trap.framework import ops
     from timbre_trap.utils import FusedAdamW, allreduce_gradients, init_process_group_from_env
     ops.PRECISION = args.precision
-    train_dtype = {'auto': 'bf16', 'fp32': 'f32', 'bf16x3': 'bf16x3', 'bf16': 'bf16'}[args.precision]
-    infer_dtype = {'auto': 'f32', 'fp32': 'f32', 'bf16x3': 'bf16x3', 'bf16': 'bf16'}[args.precision]
+    train_dtype = {'auto': 'bf16', 'fp32': 'f32', 'bf16x3': 'bf16x3', 'bf16': 'bf16', 'fp16': 'f16'}[args.precision]
+    infer_dtype = {'auto': 'f32', 'fp32': 'f32', 'bf16x3': 'bf16x3', 'bf16': 'bf16', 'fp16': 'f16'}[args.precision]
     args.infer_dtype = infer_dtype
     from timbre_trap.utils.distributed import broadcast_parameters
     import torch.distributed as dist
@@ -492,7 +495,8 @@ def main():
     torch.cuda.reset_peak_memory_stats()
     C = 16 * 2 ** (args.mc - 1)
     key, key16, keyb = 'resblock_fwd_C%d' % C, 'wide_rb_fwd_C%d' % C, 'wide_rb_bwd_C%d' % C
-    _hip.EVENT_KEYS = {key, key16, keyb, 'cqt_forward'}   # the timed region brackets only the roofline calls
+    keyb_half = 'wide_rb_bwd_C%d' % (C // 2)              # the level below: its backward runs as the one-pass strip kernel
+    _hip.EVENT_KEYS = {key, key16, keyb, keyb_half, 'cqt_forward'}   # the timed region brackets only the roofline calls
     _hip.EVENT_LOG = {}
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -621,6 +625,24 @@ def main():
                         launches=n_l, avg_ms=a_ms, ms_per_step=a_ms * n_l / args.steps, pmc=pmc_note,
                         note='algorithmic bytes = dy and x read, dx written once (bf16); the two passes also read the saved hidden '
                              'activation, write and re-read dL/d(conv1 pre-activation) and read dy twice -- see traffic')
+        roof_onepass = None
+        if events.get(keyb_half) and C == 32 and train_dtype in ('bf16', 'f16'):
+            a_ms, n_l = avg_ms(events[keyb_half])
+            Ch, Hh = C // 2, 133
+            nbytes = 3.0 * 2 * Ch * args.batch * Hh * M_FRAMES
+            gbs = nbytes / (a_ms * 1e-3) / 1e9
+            traffic = traffic_source = None
+            pmc = os.path.join(ROOT, 'profiles', 'r04_pmc_bwds_C16.json')
+            if args.batch == 64 and os.path.exists(pmc):
+                pj = json.load(open(pmc))
+                traffic, traffic_source = pj['traffic_bytes_corrected'], 'profiles/r04_pmc_bwds_C16.json (rocprofv3 --pmc passes at this shape: FETCH_SIZE x2 + WRITE_SIZE; not re-measured in this run)'
+            roof_onepass = dict(kernel='tt_wide_rb_bwd at C=%d, H=%d: k_wrb_bwds<%d,D,8,32> (one-pass strip backward: h1, dy, x in, dx out; dL/d(conv1 '
+                                       'pre-activation) in an LDS ring) + k_wrb_reduce<%d>' % (Ch, Hh, Ch, Ch),
+                                bound='hbm', achieved=gbs, peak=PEAK_HBM_GBS, unit='GB/s', frac=gbs / PEAK_HBM_GBS, traffic=traffic,
+                                traffic_source=traffic_source, algorithmic_bytes=nbytes, launches=n_l, avg_ms=a_ms,
+                                ms_per_step=a_ms * n_l / args.steps,
+                                note='algorithmic bytes = dy and x read, dx written once (the same definition as `roofline`); the kernel also reads '
+                                     'the saved hidden activation: 4 tensors of traffic where the per-stage kernels move 7')
         cqt = cqt_inv = None
         if events.get('cqt_forward'):
             a_ms, n_l = avg_ms(events['cqt_forward'])
@@ -648,6 +670,10 @@ def main():
             if args.precision == 'auto':
                 full16 = bench_inference(model, args, rank, world, dev, steps=10, warmup=2, emit=False, autocast=True)
                 infer['under_autocast'] = {k: full16[k] for k in ('value', 'unit', 'ms_per_step', 'dtype')}
+                # the reference's own autocast dtype (train.py:415 takes torch's default, float16): outputs within ~1.4e-3 of fp32
+                # (bf16: ~1e-2; profiles/r04_fp16_vs_bf16.txt)
+                fullh = bench_inference(model, args, rank, world, dev, steps=10, warmup=2, emit=False, autocast=True, dtype=torch.float16)
+                infer['under_autocast_fp16'] = {k: fullh[k] for k in ('value', 'unit', 'ms_per_step', 'dtype')}
         fp32_step = None
         if world == 1 and not args.timed_only and train_dtype != 'f32':
             # the exact-fp32 train step (every parity test's arithmetic), measured in the same run: secondary figure
@@ -697,7 +723,7 @@ def main():
                                             '(bf16 MFMA conv path of BASELINE config[2]; fp32 master weights, losses and optimizer)'
                                             if args.precision == 'auto' else ''),
                                 global_batch=world * args.batch, parallelism='dp%d' % world),
-                    roofline=roof, roofline_fwd=roof_fwd if roof_fwd is not roof else None, roofline_cqt=cqt, roofline_cqt_inv=cqt_inv, families=families, whole_step=whole,
+                    roofline=roof, roofline_fwd=roof_fwd if roof_fwd is not roof else None, roofline_onepass_bwd=roof_onepass, roofline_cqt=cqt, roofline_cqt_inv=cqt_inv, families=families, whole_step=whole,
                     peak_memory_gb=peak_gb, inference_config1=infer, fp32_train_step=fp32_step, skip_connections_step=skip_step, per_rank_ms=per_rank_ms, allreduce_ms=allreduce_ms, overlap=overlap_info, cpu_baseline=base, cpu_baseline_config0=base0,
                     final_loss=float(total.detach()))
         print(json.dumps(line))

@@ -499,6 +499,18 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_bwds(const e16* __restrict__ x
     for (int j = 0; j < NCH; ++j) zero_v[j] = (e16)0.f;
 
     const e16* zero = reinterpret_cast<const e16*>(&g_wzero16);
+    static_assert((TW * G::CG) % 64 == 0, "a DMA wave-instruction of the x rows stays inside one row");
+    int coff[G::IPR], xoff[G::XP / NT];                          // per-lane element offsets of the staged pieces inside their row
+#pragma unroll
+    for (int part = 0; part < G::IPR; ++part) {
+        const int p = part * 64 + lane, px = p / G::CG, sgrp = p - px * G::CG;
+        coff[part] = px * C + (sgrp ^ fswz<C>(px)) * 8;
+    }
+#pragma unroll
+    for (int it = 0; it < G::XP / NT; ++it) {
+        const int p = it * NT + wave * 64 + lane, q = p / G::CG, sgrp = p - q * G::CG, px = q % TW;
+        xoff[it] = px * C + (sgrp ^ fswz<C>(px)) * 8;
+    }
     const int nsteps = (H + TH - 1) / TH + 1;
     // ring slot of image row R (R >= -RING): (R + RING) mod RING, on the scalar unit where R is wave-uniform
     auto slot = [&](int R) -> int { return (R + RING) % RING; };
@@ -507,22 +519,41 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_bwds(const e16* __restrict__ x
         const int strip = xcd_order(v, nstrips);
         const int b = strip / tiles_t, t0 = (strip - b * tiles_t) * TW;
         const long ib = (long)b * H * T * C;
+        const bool edge = t0 - D < 0 || t0 + TW + D > T;         // the strip's halo crosses the left / right image border
 
         for (int j = 0; j < nsteps; ++j) {
             const int N0 = j * TH + D - TH;                      // first new dA1 row of this step
             const int X0 = (j - 1) * TH;                         // first row whose dx / dW1 this step produces
             __syncthreads();                                     // the previous step has been consumed
             // ---- a. dy -> ring slots of the new rows, h1 -> staging; one image row per IPR wave-instructions ----
-            for (int k = wave; k < TH * G::IPR; k += 4) {
-                const int rl = k / G::IPR, part = k - rl * G::IPR;
-                const int p = part * 64 + lane;                  // piece inside the row
-                const int px = p / G::CG, sgrp = p - px * G::CG;
-                const int h = N0 + rl, t = t0 - D + px;
-                const bool ok = (unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T;
-                const long off = ib + ((long)h * T + t) * C + (sgrp ^ fswz<C>(px)) * 8;
-                if (p < G::RPP) {
-                    glds16(ok ? dy + off : zero, ring + slot(N0 + rl) * G::ROWB + part * 1024);
-                    glds16(ok ? h1 + off : zero, hst + rl * G::ROWB + part * 1024);
+            // A wave stages whole rows (rl = wave, wave + 4, ..); the row is wave-uniform, so its in-image test and its base address
+            // are scalar, and away from the left / right image border the per-lane part of the address is the constant coff[]
+            // (one 32-bit add per piece instead of ~20 vector instructions of index arithmetic and bounds tests).
+            for (int rl = wave; rl < TH; rl += 4) {
+                const int h = N0 + rl;
+                unsigned char* rdst = ring + slot(h) * G::ROWB;
+                unsigned char* hdst = hst + rl * G::ROWB;
+                if ((unsigned)h >= (unsigned)H) {                // a row above / below the image: zero page (dy = 0 -> dA1 = 0)
+#pragma unroll
+                    for (int part = 0; part < G::IPR; ++part)
+                        if (part * 64 + lane < G::RPP) { glds16(zero, rdst + part * 1024); glds16(zero, hdst + part * 1024); }
+                } else if (!edge) {
+                    const long rowoff = ib + ((long)h * T + (t0 - D)) * C;
+                    const e16* gr_ = dy + rowoff;
+                    const e16* hr_ = h1 + rowoff;
+#pragma unroll
+                    for (int part = 0; part < G::IPR; ++part)
+                        if (part * 64 + lane < G::RPP) { glds16(gr_ + coff[part], rdst + part * 1024); glds16(hr_ + coff[part], hdst + part * 1024); }
+                } else {
+#pragma unroll
+                    for (int part = 0; part < G::IPR; ++part) {
+                        const int p = part * 64 + lane;
+                        const int px = p / G::CG;
+                        const int t = t0 - D + px;
+                        const bool ok = (unsigned)t < (unsigned)T;
+                        const long off = ib + ((long)h * T + (t0 - D)) * C + coff[part];
+                        if (p < G::RPP) { glds16(ok ? dy + off : zero, rdst + part * 1024); glds16(ok ? h1 + off : zero, hdst + part * 1024); }
+                    }
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -618,12 +649,15 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_bwds(const e16* __restrict__ x
             __syncthreads();                                     // dA1 rows complete, h1 staging dead
 
             // ---- c. the x rows of this step towards the staging image (consumed in e.) ----
-            for (int i = wave * 64; i < G::XP; i += NT) {
-                const int p = i + lane, q = p / G::CG, sgrp = p - q * G::CG;
-                const int row = q / TW, px = q - row * TW;
-                const int h = X0 + row, t = t0 + px;
-                const bool ok = h < H && t < T;
-                glds16(ok ? x + ib + ((long)h * T + t) * C + (sgrp ^ fswz<C>(px)) * 8 : zero, hst + (long)i * 16);
+            // (a wave instruction = 64 pieces of ONE row: TW * CG is a multiple of 64)
+#pragma unroll
+            for (int it = 0; it < G::XP / NT; ++it) {
+                const int i = it * NT + wave * 64;
+                const int row = i / (TW * G::CG);
+                const int h = X0 + row;
+                const int px = ((i + lane) / G::CG) % TW;
+                const bool ok = h < H && (!edge || t0 + px < T);
+                glds16(ok ? x + ib + ((long)h * T + t0) * C + xoff[it] : zero, hst + (long)i * 16);
             }
 
             // ---- d. dx = dy + W1^T (*) dA1 over the step's rows ----
@@ -728,7 +762,9 @@ int launch_bwds(const e16* x, const e16* h1, const e16* dy, const float* w1, con
     hipLaunchKernelGGL(k_lvl_wprep<C>, dim3(K::NK * K::NCT + 1), dim3(64), 0, st, w1, w2, wimg);
     TT_LAUNCH_CHECK();
     static AttrOnce once;
-    constexpr int MINW = C == 32 ? 3 : 4;          // registers: 192 (C = 32), 124 (C = 16)
+    // registers: 192 at C = 32 (capped at 168 for a third wave per SIMD it spills 22-45 registers and loses: 0.536 / 0.561 / 0.553 ms
+    // against 0.509 / 0.458 / 0.453), 128 at C = 16
+    constexpr int MINW = C == 32 ? 2 : 4;
     auto kern = k_wrb_bwds<C, D, TH, TW, MINW>;
     if (int rc = raise_lds(kern, G::LDS_BYTES, once)) return rc;
     const int tiles_t = (T + TW - 1) / TW, nstrips = B * tiles_t;

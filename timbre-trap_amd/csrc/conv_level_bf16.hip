@@ -661,7 +661,38 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_bwds(const e16* __restrict__ x
             }
 
             // ---- d. dx = dy + W1^T (*) dA1 over the step's rows ----
-            {
+            if constexpr (C == 32) {
+                // C = 32: a wave computes ONE co-tile (16 of the 32 output channels: for a lane the four consecutive channels
+                // 8 g + 4 ct ..) of twice as many pixel groups -- 36 registers of weights instead of 72, which is what brings the
+                // kernel under 168 registers (a third workgroup per CU); the B operands are read twice from LDS instead.
+                const int ctd = wave & 1;
+                e16x8 A1[NK];
+#pragma unroll
+                for (int k = 0; k < NK; ++k) A1[k] = wp[K::W3 + (k * NCT + ctd) * 64 + lane];
+                constexpr int GPRW = TW / 16;
+                for (int grp = wave >> 1; grp < TH * GPRW; grp += 2) {
+                    const int r = grp / GPRW, c = (grp - r * GPRW) * 16 + n;
+                    const int h = X0 + r;
+                    if (h >= H) break;
+                    const int t = t0 + c;
+                    const bool valid = t < T;
+                    const long pix = ((long)b * H + h) * T + t;
+                    const e16x4 rq = *reinterpret_cast<const e16x4*>(dy + (valid ? pix : pix - (t - (T - 1))) * C + 8 * g + 4 * ctd);
+                    const int ro[3] = {slot(h - D) * G::ROWB, slot(h) * G::ROWB, slot(h + D) * G::ROWB};
+                    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) {
+                        const int kh = k / 3, kw = k - 3 * kh;
+                        const int xc = c + kw * D;
+                        const e16x8 bq = *reinterpret_cast<const e16x8*>(ring + ro[kh] + xc * PB + 16 * (g ^ fswz<C>(xc)));
+                        acc = mma32(A1[k], bq, acc);
+                    }
+                    e16x4 o;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) o[jj] = (e16)(acc[jj] + (float)rq[jj]);
+                    if (valid) *reinterpret_cast<e16x4*>(dx + pix * C + 8 * g + 4 * ctd) = o;
+                }
+            } else {
                 e16x8 A[NK][NCT];
 #pragma unroll
                 for (int k = 0; k < NK; ++k)
@@ -762,9 +793,7 @@ int launch_bwds(const e16* x, const e16* h1, const e16* dy, const float* w1, con
     hipLaunchKernelGGL(k_lvl_wprep<C>, dim3(K::NK * K::NCT + 1), dim3(64), 0, st, w1, w2, wimg);
     TT_LAUNCH_CHECK();
     static AttrOnce once;
-    // registers: 192 at C = 32 (capped at 168 for a third wave per SIMD it spills 22-45 registers and loses: 0.536 / 0.561 / 0.553 ms
-    // against 0.509 / 0.458 / 0.453), 128 at C = 16
-    constexpr int MINW = C == 32 ? 2 : 4;
+    constexpr int MINW = C == 32 ? 3 : 4;
     auto kern = k_wrb_bwds<C, D, TH, TW, MINW>;
     if (int rc = raise_lds(kern, G::LDS_BYTES, once)) return rc;
     const int tiles_t = (T + TW - 1) / TW, nstrips = B * tiles_t;
@@ -783,12 +812,14 @@ int launch_bwds(const e16* x, const e16* h1, const e16* dy, const float* w1, con
 template <int C>
 int bwds_c(const e16* x, const e16* h1, const e16* dy, const float* w1, const float* w2, const float* b2, e16* dx,
            float* dw1, float* db1, float* dw2, float* db2, unsigned char* ws, int B, int H, int T, int D, hipStream_t st) {
-    static const int alt = tt_tune("TTRAP_BWDS_TILE", 0);
 #define TT_BS(DD, TH_, TW_) return launch_bwds<C, DD, TH_, TW_>(x, h1, dy, w1, w2, b2, dx, dw1, db1, dw2, db2, ws, B, H, T, st)
     switch (D) {
-        case 1: if (alt == 1) TT_BS(1, 16, 32); if (alt == 2) TT_BS(1, 4, 32); TT_BS(1, 8, 32);
-        case 2: if (alt == 1) TT_BS(2, 16, 32); if (alt == 2) TT_BS(2, 4, 32); TT_BS(2, 8, 32);
-        case 3: if (alt == 1) TT_BS(3, 16, 32); if (alt == 2) TT_BS(3, 4, 32); TT_BS(3, 8, 32);
+        // 8-row steps everywhere.  C = 32 (round 4): 6-row steps at dilation 2, 3 fit a third workgroup per CU (46.9 / 53.3 KB of LDS) and
+        // changed nothing at dilation 2 (0.458 ms either way) and lost at dilation 3 (0.637 vs 0.453 ms: the third workgroup does not
+        // become resident at 53.3 KB); 16- and 4-row steps lose at both widths (profiles/r04_bwds_ab.txt).
+        case 1: TT_BS(1, 8, 32);
+        case 2: TT_BS(2, 8, 32);
+        case 3: TT_BS(3, 8, 32);
     }
 #undef TT_BS
     return TT_E_UNSUPPORTED;

@@ -4,7 +4,7 @@ import re
 import sys
 
 GROUPS = [('bf16 block forward (k_wrb_conv / k_nrb_conv MODE 0)', r'k_[wn]rb_conv.*ELi0ELb'), ('bf16 block data gradient (MODE 1)', r'k_[wn]rb_conv.*ELi1ELb'),
-          ('bf16 block data + weight gradient in one pass (k_wrb_dxw / k_nrb_dxw)', r'k_[wn]rb_dxw'), ('bf16 one-pass backward with recomputed h1 (opt-in)', r'k_wrb_bwd_fused|k_lvl_wprep'),
+          ('bf16 block data + weight gradient in one pass (k_wrb_dxw / k_nrb_dxw)', r'k_[wn]rb_dxw'), ('bf16 one-pass strip backward, h1 saved (k_wrb_bwds + weight prep)', r'k_wrb_bwds|k_lvl_wprep'), ('bf16 one-pass backward with recomputed h1 (opt-in)', r'k_wrb_bwd_fused'),
           ('bf16 block pointwise backward (bwd_a)', r'k_[wn]rb_bwd_a'), ('bf16 block weight gradient', r'k_[wn]rb_wgrad'),
           ('bf16 narrow fused backward', r'k_nrb_bwd_fused'), ('bf16 partial-sum reduces', r'k_[wn]rb_reduce|k_w4_reduce|k_lat_wred|k_edge_reduce'),
           ('bf16 strided / transposed layers (k_s4 / k_p2)', r'k_s4|k_p2'), ('bf16 strided weight gradient (k_w4)', r'k_w4<'),

@@ -1201,6 +1201,23 @@ __global__ __launch_bounds__(NT, C == 8 ? 2 : 1) void k_nrb_bwd_fused(const e16*
     // registers of weights beside 116 of accumulators); converting them from the fp32 parameters per tile instead was 144 + 32 loads
     // and as many conversions per lane and tile -- a third of the kernel's vector instructions.
     unsigned char* wimg = smem + 3 * IMG;
+    // dW2 += dA2 (x) h1 over the tile's own pixels on the MATRIX pipe (round 4): the 64 pixels a wave handles per step are 32 (C = 8) /
+    // 16 (C = 4) consecutive 32-byte slots of the flat pixel-major images, i.e. exactly the K = 32 / K = 16 of one product whose 16
+    // rows / columns are the (pixel-in-slot, channel) pairs of a slot: A = the wave's masked dA2 (written to a 64-pixel buffer), B = h1
+    // straight from its image, both by transpose reads; the diagonal blocks (same pixel-in-slot on both sides) of the 16 x 16
+    // accumulator are the gradient.  One matrix instruction, two 16-byte LDS writes and two to four transpose reads replace the C^2
+    // multiply-adds per pixel (64 of the ~124 vector instructions a pixel of phase 1 cost at C = 8) and their C^2 accumulator registers.
+    // -DTTRAP_NRB_DW2_FMAC / -DTTRAP_NRB_DW2_SLP rebuild the vector forms (the second one is the run-to-run different one of round 3).
+#if defined(TTRAP_NRB_DW2_SLP) || defined(TTRAP_NRB_DW2_FMAC)
+    constexpr bool DW2_MFMA = false;
+#else
+    constexpr bool DW2_MFMA = true;
+#endif
+    unsigned char* abuf = wimg + 11 * NB * NB * 32 + wave * (64 * G::PXB);     // this wave's 64 pixels of masked dA2
+    f32x4 dw2m = f32x4{0.f, 0.f, 0.f, 0.f};
+    vec_t zero_px;
+#pragma unroll
+    for (int c = 0; c < C; ++c) zero_px[c] = (e16)0.f;
     for (int e = tid; e < (2 + 9) * NB * NB * 4; e += NT) {
         const int l4 = e & 3, kb = (e >> 2) % NB, ob = (e >> 2) / NB % NB, m = (e >> 2) / (NB * NB);
         e16x4 a;
@@ -1303,23 +1320,41 @@ __global__ __launch_bounds__(NT, C == 8 ? 2 : 1) void k_nrb_bwd_fused(const e16*
                     acc[C * C + c] += m * a1; acc[C * C + C + c] += m * gv[c];
                     gr[c] *= m;
                 }
-                // dW2 += dA2 (x) h1 as plain v_fmac_f32, spelled out: left to the SLP vectoriser this loop became packed multiply-adds with
-                // crossed lane selects and register rotations, and ONE of the 64 accumulators then came out different from run to run
-                // (a single pixel product wrong in ~3 % of the workgroups; tools/probes/dbg_nrb.py; not reproduced by the standalone
-                // instruction probes, cause not found).  A packed fp32 op issues at half rate anyway.
-                // -DTTRAP_NRB_DW2_SLP rebuilds the failing form (the plain loop, left to the vectoriser) for the investigation:
-                // tools/build_variant.sh slpdw2 -DTTRAP_NRB_DW2_SLP; TTRAP_LIB=libttrap_slpdw2.so pytest tests/test_gpu_determinism.py;
-                // the two listings of this loop are profiles/r04_isa_nrb_dw2_{asm,slp}.txt.
-#pragma unroll
-                for (int co = 0; co < C; ++co)
-#pragma unroll
-                    for (int ci = 0; ci < C; ++ci) {
-#ifdef TTRAP_NRB_DW2_SLP
-                        acc[co * C + ci] += gr[co] * hv[ci];
-#else
-                        asm("v_fmac_f32 %0, %1, %2" : "+v"(acc[co * C + ci]) : "v"(gr[co]), "v"(hv[ci]));
-#endif
+                if constexpr (DW2_MFMA) {
+                    *reinterpret_cast<vec_t*>(abuf + lane * G::PXB) = centre ? gq : zero_px;
+                    __builtin_amdgcn_wave_barrier();             // same wave: LDS operations complete in order; the fences stop the compiler
+                    asm volatile("" ::: "memory");
+                    const unsigned char* hb0 = hs + (long)c0 * G::PXB;               // the 64 pixels of this step, before dA1 replaces them
+                    const int so = 32 * (4 * g + trj) + 8 * trq;
+                    if constexpr (C == 8) {
+                        const s16x4 glo = lds_tr16(abuf + so), ghi = lds_tr16(abuf + so + 512);
+                        const s16x4 hlo = lds_tr16(hb0 + so), hhi = lds_tr16(hb0 + so + 512);
+                        dw2m = mma32(__builtin_bit_cast(e16x8, __builtin_shufflevector(glo, ghi, 0, 1, 2, 3, 4, 5, 6, 7)),
+                                     __builtin_bit_cast(e16x8, __builtin_shufflevector(hlo, hhi, 0, 1, 2, 3, 4, 5, 6, 7)), dw2m);
+                    } else {
+                        dw2m = mma16(lds_tr16(abuf + so), lds_tr16(hb0 + so), dw2m);
                     }
+                    asm volatile("" ::: "memory");
+                } else {
+                    // The vector forms.  Left to the SLP vectoriser (-DTTRAP_NRB_DW2_SLP) this loop became packed multiply-adds with crossed
+                    // lane selects and register rotations, and ONE of the 64 accumulators -- dW2[0][0], at C = 8 / dilation 1 only -- then
+                    // came out different from run to run (2-7 % off in some runs).  Round 4: still does (tests/test_gpu_determinism.py
+                    // catches it 12 runs out of 12), and extra wait states after every packed multiply-add, after the packed multiplies
+                    // that feed them, between the crossed-select multiply-add and the rotation that overwrites its source pair, or after
+                    // every matrix instruction -- patched into the assembly, tools/isa_patch/ -- change nothing: not an instruction
+                    // hazard; cause still unknown (profiles/r04_isa_patch_determinism.txt, r04_isa_nrb_dw2_{asm,slp}.txt).
+                    // -DTTRAP_NRB_DW2_FMAC: the same loop spelled out as C^2 v_fmac_f32 (bit-stable; the shipped form of round 3).
+#pragma unroll
+                    for (int co = 0; co < C; ++co)
+#pragma unroll
+                        for (int ci = 0; ci < C; ++ci) {
+#ifdef TTRAP_NRB_DW2_SLP
+                            acc[co * C + ci] += gr[co] * hv[ci];
+#else
+                            asm("v_fmac_f32 %0, %1, %2" : "+v"(acc[co * C + ci]) : "v"(gr[co]), "v"(hv[ci]));
+#endif
+                        }
+                }
                 if (in_img) *reinterpret_cast<vec_t*>(hs + (long)q * G::PXB) = aq;
             }
         }
@@ -1390,11 +1425,27 @@ __global__ __launch_bounds__(NT, C == 8 ? 2 : 1) void k_nrb_bwd_fused(const e16*
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
-    for (int e = 0; e < ADUMP; ++e) {
+    for (int e = DW2_MFMA ? C * C : 0; e < ADUMP; ++e) {
         float sv = acc[e];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) sv += __shfl_xor(sv, o, 64);
         if (lane == 0) red[wave * ADUMP + e] = sv;
+    }
+    if constexpr (DW2_MFMA) {
+        // the wave's 16 x 16 accumulator (row = (pixel-in-slot, co), column = (pixel-in-slot, ci)) through LDS; dW2[co][ci] = the sum of
+        // its diagonal blocks
+        float* sc = red + 4 * ADUMP + wave * 256;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sc[(4 * g + r) * 16 + n] = dw2m[r];
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+        if (lane < C * C) {
+            const int co = lane / C, ci = lane - co * C;
+            float sv = 0.f;
+#pragma unroll
+            for (int p_ = 0; p_ < 16 / C; ++p_) sv += sc[(p_ * C + co) * 16 + p_ * C + ci];
+            red[wave * ADUMP + lane] = sv;
+        }
     }
     __syncthreads();
     float* pa = part_a + (long)blockIdx.x * ADUMP;
@@ -1586,7 +1637,7 @@ int launch_nbwd(const e16* x, const e16* h1, const e16* dy, const float* w1, con
     static const int fused = tt_switch("TTRAP_NARROW_FUSED16", 1);
     if (fused == 2 || (fused == 1 && (C == 8 ? D <= 2 : true))) {
         using F = NTl<C, D>;
-        constexpr int LDS = 3 * F::NPR * 16 + 11 * (C / 4) * (C / 4) * 32;        // three images + the bf16 weight image
+        constexpr int LDS = 3 * F::NPR * 16 + 11 * (C / 4) * (C / 4) * 32 + 4 * 64 * F::PXB;   // three images + the bf16 weight image + the waves' dA2 buffers
         static AttrOnce once_f;
         auto kf = k_nrb_bwd_fused<C, D>;
         if (int rc = raise_lds(kf, LDS, once_f)) return rc;

@@ -21,8 +21,7 @@ GPU, 9 octaves x 60 bins/octave; weak scaling (per-GPU batch fixed).  The step r
 
 Prints ONE JSON line on rank 0 with the driver's fields plus
   "roofline"          : the by-time dominant call of the step -- the residual-block backward at the widest level
-                        (tt_wide_rb_bwd, C = 32, 18 calls per step: the one-pass strip kernel k_wrb_bwds at dilation 1 and 3,
-                        k_wrb_bwd_a + k_wrb_dxw at dilation 2, + k_wrb_reduce):
+                        (tt_wide_rb_bwd, C = 32: k_wrb_bwd_a + k_wrb_dxw + k_wrb_reduce, 18 calls per step):
                         algorithmic bytes (dy, x read, dx written once, bf16) / average call time measured with HIP events on the
                         launch stream over the timed steps, against the HBM peak; `traffic` is the HBM byte count of the committed
                         rocprofv3 PMC passes of those kernels (`traffic_source` names the file -- not re-measured in this run)
@@ -612,22 +611,21 @@ def main():
             flops = 2.0 * 2.0 * (9 * C * C + C * C) * args.batch * 65 * M_FRAMES
             gbs = nbytes / (a_ms * 1e-3) / 1e9
             traffic, traffic_source, pmc_note = None, None, None
-            pmc = os.path.join(ROOT, 'profiles', 'r04_pmc_wrb_bwd_C32.json')
+            pmc = os.path.join(ROOT, 'profiles', 'r03_pmc_wrb_bwd_C32.json')       # the per-stage kernels of this call are unchanged since round 3
             if C == 32 and args.batch == 64 and os.path.exists(pmc):
                 pj = json.load(open(pmc))
                 traffic = pj['traffic_bytes_corrected']
                 pmc_note = pj.get('summary')
-                traffic_source = 'profiles/r04_pmc_wrb_bwd_C32.json (rocprofv3 --pmc passes of the kernels of the call at this shape: FETCH_SIZE x2 + WRITE_SIZE, summed per call, mean of the three dilations; not re-measured in this run)'
-            roof = dict(kernel='tt_wide_rb_bwd at C=%d, H=65 (ResidualConv2dBlock backward, bf16 channel-innermost storage): dilation 1, 3 as the one-pass '
-                               'strip kernel k_wrb_bwds<%d,D,8,32> (h1, dy, x in, dx out), dilation 2 as k_wrb_bwd_a<%d> + k_wrb_dxw<%d,2,6,32>; + k_wrb_reduce<%d>; '
-                               'the by-time dominant call of the step' % (C, C, C, C, C),
+                traffic_source = 'profiles/r03_pmc_wrb_bwd_C32.json (rocprofv3 --pmc passes of the four kernels at this shape: FETCH_SIZE x2 + WRITE_SIZE, summed; round 4 re-measured dilation 2: 2188 MB, profiles/r04_pmc_C32.txt; not re-measured in this run)'
+            roof = dict(kernel='tt_wide_rb_bwd at C=%d, H=65 (ResidualConv2dBlock backward, bf16 channel-innermost storage): k_wrb_bwd_a<%d> + '
+                               'k_wrb_dxw<%d,D,8,32> (data + weight gradient in one pass) + k_wrb_reduce<%d>; the by-time dominant call of the step '
+                               '(the one-pass strip kernel, default one level down, loses here inside the step: roofline_onepass_bwd, DESIGN.md section 7)' % (C, C, C, C),
                         bound='hbm', achieved=gbs, peak=PEAK_HBM_GBS, unit='GB/s', frac=gbs / PEAK_HBM_GBS, traffic=traffic,
                         traffic_source=traffic_source, algorithmic_bytes=nbytes, algorithmic_flops=flops,
                         achieved_tflops=flops / (a_ms * 1e-3) / 1e12, frac_bf16_mfma_peak=flops / (a_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
                         launches=n_l, avg_ms=a_ms, ms_per_step=a_ms * n_l / args.steps, pmc=pmc_note,
-                        note='algorithmic bytes = dy and x read, dx written once (bf16); the one-pass kernel also reads the saved hidden '
-                             'activation (4 tensors), the per-stage kernels also write and re-read dL/d(conv1 pre-activation) and read dy twice '
-                             '(7 tensors) -- see traffic')
+                        note='algorithmic bytes = dy and x read, dx written once (bf16); the two passes also read the saved hidden '
+                             'activation, write and re-read dL/d(conv1 pre-activation) and read dy twice -- see traffic')
         roof_onepass = None
         if events.get(keyb_half) and C == 32 and train_dtype in ('bf16', 'f16'):
             a_ms, n_l = avg_ms(events[keyb_half])

@@ -740,17 +740,19 @@ int launch_dxw(const e16* x, const e16* da1, const e16* dy, const float* w1, e16
 }
 
 // One-pass backward (k_wrb_bwds, conv_level_bf16.hip: column strips, dA1 in a rolling LDS ring, 4 tensors of HBM traffic) or the
-// per-stage kernels below (7 tensors): TTRAP_WBWD1 = 0 / 1 forces one of them for every width and dilation, unset = the measured
-// choice per (C, dilation).  Round 4, per call at the bench shape (64 clips), per-stage -> one-pass:
-//   C = 16 (four workgroups per CU, 128 registers): 0.469 / 0.436 / 0.437 -> 0.420 / 0.379 / 0.372 ms (dilation 1 / 2 / 3): taken;
-//   C = 32 (168 registers with the data gradient split by co-tile over the waves: three workgroups per CU at dilation 1, two by LDS at
-//   dilation 2, 3): 0.465 / 0.430 / 0.464 -> 0.450 / 0.458 / 0.453 ms: taken at dilation 1 and 3.  HBM traffic 2.16 -> 1.15 GB
-//   per call either way (PMC, profiles/r04_pmc_bwds.txt); what holds the C = 32 kernel back is occupancy -- at two waves per SIMD
-//   the vector ALUs are 39 % and the matrix pipe 19 % busy with the waves parked 39 % of their life.
+// per-stage kernels below (7 tensors): TTRAP_WBWD1 = 0 / 1 forces one of them for every width and dilation, 16 / 32 the one-pass
+// kernel at that width only; unset = the measured choice.  Round 4, measured INSIDE the 64-clip train step (bench.py --timed-only, same
+// box, back to back; profiles/r04_wbwd1_step_ab.txt), average call: C = 16 0.418 -> 0.376 ms (taken: step 57.64 -> 56.75 ms);
+// C = 32 0.427 -> 0.495 ms (not taken).  The isolated micro-benchmark (tools/kb_level.py) had the C = 32 strips level with the
+// per-stage kernels (0.450 / 0.458 / 0.453 vs 0.465 / 0.430 / 0.464 ms): inside the step the per-stage path finds dy (just written by
+// the next block's backward) and its own dA1 in the 256 MB memory-side cache, so its extra passes cost less than their bytes, while
+// the one-pass kernel runs at two to three waves per SIMD (168 registers) with the vector ALUs 39 % and the matrix pipe 19 % busy.
 inline int onepass_choice(int C, int D) {
-    static const int forced = tt_switch("TTRAP_WBWD1", -1);
+    static const int forced = tt_switch("TTRAP_WBWD1", -1);       // 0 / 1: never / always; 16 / 32: at that width only
+    if (forced == 16 || forced == 32) return C == forced ? 1 : 0;
     if (forced >= 0) return forced ? 1 : 0;
-    return C == 16 || (C == 32 && D != 2) ? 1 : 0;
+    (void)D;
+    return C == 16 ? 1 : 0;
 }
 
 template <int C, int D>

@@ -607,6 +607,8 @@ def main():
         if events.get(keyb):
             # the by-time dominant call of the bf16 step: the residual-block backward at the widest level (18 calls per step)
             a_ms, n_l = avg_ms(events[keyb])
+            if ops.LEVEL_BWD:                                     # one event = tt_wide_level_bwd = the three blocks of a level (one reduce launch)
+                a_ms, n_l = a_ms / 3.0, n_l * 3
             nbytes = 3.0 * 2 * C * args.batch * 65 * M_FRAMES
             flops = 2.0 * 2.0 * (9 * C * C + C * C) * args.batch * 65 * M_FRAMES
             gbs = nbytes / (a_ms * 1e-3) / 1e9
@@ -629,6 +631,8 @@ def main():
         roof_onepass = None
         if events.get(keyb_half) and C == 32 and train_dtype in ('bf16', 'f16'):
             a_ms, n_l = avg_ms(events[keyb_half])
+            if ops.LEVEL_BWD:
+                a_ms, n_l = a_ms / 3.0, n_l * 3
             Ch, Hh = C // 2, 133
             nbytes = 3.0 * 2 * Ch * args.batch * Hh * M_FRAMES
             gbs = nbytes / (a_ms * 1e-3) / 1e9
@@ -642,7 +646,7 @@ def main():
                                 bound='hbm', achieved=gbs, peak=PEAK_HBM_GBS, unit='GB/s', frac=gbs / PEAK_HBM_GBS, traffic=traffic,
                                 traffic_source=traffic_source, algorithmic_bytes=nbytes, launches=n_l, avg_ms=a_ms,
                                 ms_per_step=a_ms * n_l / args.steps,
-                                note='algorithmic bytes = dy and x read, dx written once (the same definition as `roofline`); the kernel also reads '
+                                note='average per block (the event brackets tt_wide_level_bwd: three blocks + one reduce launch); algorithmic bytes = dy and x read, dx written once (the same definition as `roofline`); the kernel also reads '
                                      'the saved hidden activation: 4 tensors of traffic where the per-stage kernels move 7')
         cqt = cqt_inv = None
         if events.get('cqt_forward'):

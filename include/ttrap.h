@@ -166,6 +166,16 @@ int tt_wide_rb_fwd(const void* x, const float* w1, const float* b1, const float*
 int tt_wide_rb_bwd(const void* x, const void* h1, const void* dy, const float* w1, const float* w2, const float* b2,
                    void* dx, float* dw1, float* db1, float* dw2, float* db2, void* ws, int B, int C, int H, int T,
                    int dilation, void* stream);
+/* The backward of ALL residual blocks of one level in one call (modules.py:621-624 / 690-693 differentiated: block nblocks-1 first):
+ * tt_wide_rb_bwd for every block -- x[i], h1[i], w1[i], w2[i], b2[i], dilations[i]; dy enters the last block, dx leaves the first,
+ * tmp0 / tmp1 (nblocks > 1) are two (B,C,H,T) 16-bit buffers for the gradients between the blocks -- with the partial-sum reduces
+ * of all blocks DEFERRED into one launch at the end (two launches fewer per level; same sums in the same order, so every output is
+ * bit-identical to nblocks calls of tt_wide_rb_bwd).  ws = tt_wide_level_scratch_bytes(nblocks, B, C, H, T) bytes; nblocks <= 4. */
+int64_t tt_wide_level_scratch_bytes(int nblocks, int B, int C, int H, int T);
+int tt_wide_level_bwd(int nblocks, const void* const* x, const void* const* h1, const void* dy, const float* const* w1,
+                      const float* const* w2, const float* const* b2, void* dx, void* tmp0, void* tmp1, float* const* dw1,
+                      float* const* db1, float* const* dw2, float* const* db2, void* ws, int B, int C, int H, int T,
+                      const int* dilations, void* stream);
 /* The whole backward of one block in ONE pass from x and dy only (csrc/conv_level_bf16.hip; C = 16, 32, else
  * TT_E_UNSUPPORTED): the hidden activation is recomputed per tile (bit-identical to what tt_wide_rb_fwd would have stored),
  * dL/d(conv1 pre-activation) stays in LDS -- reads x and dy, writes dx.  The forward can then run with h1 = NULL.
@@ -353,6 +363,11 @@ int tt_target_activations(const int* bins, const int* frames, int n, const doubl
  * (experiments/train.py:415: torch.autocast('cuda') defaults to torch.float16): 11 significant bits per stored activation instead of
  * 8, at the price of fp16's range (normal numbers 6.1e-5 .. 65504; the reference uses no GradScaler, and neither does this path).
  * The Python layer picks the set by the autocast dtype. */
+int64_t tt_wide_level_scratch_bytes_h(int nblocks, int B, int C, int H, int T);
+int tt_wide_level_bwd_h(int nblocks, const void* const* x, const void* const* h1, const void* dy, const float* const* w1,
+                        const float* const* w2, const float* const* b2, void* dx, void* tmp0, void* tmp1, float* const* dw1,
+                        float* const* db1, float* const* dw2, float* const* db2, void* ws, int B, int C, int H, int T,
+                        const int* dilations, void* stream);
 int64_t tt_wide_scratch_bytes_h(int B, int C, int H, int T);
 int tt_wide_pack_h(const float* x, void* out, int B, int C, int H, int T, void* stream);
 int tt_wide_unpack_h(const void* in, float* y, int B, int C, int H, int T, void* stream);

@@ -206,6 +206,52 @@ def test_wide_block_multitile(C, d, shape, cus, cu_limit):
     _stagewise(C, d, *shape)
 
 
+@pytest.mark.parametrize('C,shape', [(4, (2, 37, 130)), (8, (1, 40, 200)), (16, (2, 21, 96)), (32, (1, 30, 160))])
+def test_level_backward_equals_block_by_block(C, shape):
+    """tt_wide_level_bwd (all blocks of a level, the partial-sum reduces deferred into ONE launch) against one tt_wide_rb_bwd call per
+    block: the same kernels and the same sums in the same order -- dx and every weight / bias gradient bit-identical (the narrow levels'
+    3x3 weight gradient, whose reduce adds with atomics, at fp32 rounding)."""
+    import ctypes
+    from timbre_trap._hip import check, ptr, stream_ptr
+    lib, st = _lib(), stream_ptr()
+    B, H, T = shape
+    nb, dil = 3, (1, 2, 3)
+    par = [[_rand(C, C, 3, 3, seed=20 + i, scale=1.0 / (3 * C ** 0.5)).cuda(), _rand(C, seed=30 + i, scale=0.3).cuda(),
+            _rand(C, C, 1, 1, seed=40 + i, scale=1.0 / C ** 0.5).cuda(), _rand(C, seed=50 + i, scale=0.3).cuda()] for i in range(nb)]
+    nhwc = lambda: torch.empty((B, H, T, C), dtype=ELT, device='cuda')
+    xs, hs = [nhwc() for _ in range(nb + 1)], [nhwc() for _ in range(nb)]
+    check(lib.tt_wide_pack(ptr(_rand(B, C, H, T, seed=1).cuda()), ptr(xs[0]), B, C, H, T, st), 'pack')
+    for i in range(nb):
+        check(lib.tt_wide_rb_fwd(ptr(xs[i]), ptr(par[i][0]), ptr(par[i][1]), ptr(par[i][2]), ptr(par[i][3]), ptr(xs[i + 1]), ptr(hs[i]), B, C, H, T, dil[i], st), 'fwd')
+    dy = nhwc()
+    check(lib.tt_wide_pack(ptr(_rand(B, C, H, T, seed=2).cuda()), ptr(dy), B, C, H, T, st), 'pack')
+    shapes = ((C, C, 3, 3), (C,), (C, C, 1, 1), (C,))
+    # block by block
+    ws = torch.zeros(lib.tt_wide_scratch_bytes(B, C, H, T), dtype=torch.uint8, device='cuda')
+    ga = [[torch.full(s_, 0.5, device='cuda') for s_ in shapes] for _ in range(nb)]
+    g, bufs = dy, [nhwc(), nhwc(), nhwc()]
+    for i in reversed(range(nb)):
+        check(lib.tt_wide_rb_bwd(ptr(xs[i]), ptr(hs[i]), ptr(g), ptr(par[i][0]), ptr(par[i][2]), ptr(par[i][3]), ptr(bufs[i]), ptr(ga[i][0]), ptr(ga[i][1]),
+                                 ptr(ga[i][2]), ptr(ga[i][3]), ptr(ws), B, C, H, T, dil[i], st), 'bwd')
+        g = bufs[i]
+    # the level entry
+    arr = lambda ts: (ctypes.c_void_p * nb)(*[t.data_ptr() for t in ts])
+    gb = [[torch.full(s_, 0.5, device='cuda') for s_ in shapes] for _ in range(nb)]
+    dx, t0, t1 = nhwc(), nhwc(), nhwc()
+    wsl = torch.zeros(lib.tt_wide_level_scratch_bytes(nb, B, C, H, T), dtype=torch.uint8, device='cuda')
+    check(lib.tt_wide_level_bwd(nb, arr(xs[:nb]), arr(hs), ptr(dy), arr([p_[0] for p_ in par]), arr([p_[2] for p_ in par]), arr([p_[3] for p_ in par]),
+                                ptr(dx), ptr(t0), ptr(t1), arr([g_[0] for g_ in gb]), arr([g_[1] for g_ in gb]), arr([g_[2] for g_ in gb]),
+                                arr([g_[3] for g_ in gb]), ptr(wsl), B, C, H, T, (ctypes.c_int * nb)(*dil), st), 'level bwd')
+    torch.cuda.synchronize()
+    assert torch.equal(dx, bufs[0])
+    for i in range(nb):
+        for j, name in enumerate(('dw1', 'db1', 'dw2', 'db2')):
+            if name == 'dw1' and C <= 8:
+                assert float((ga[i][j] - gb[i][j]).abs().max()) <= 1e-5 * float(ga[i][j].abs().max()), (i, name)
+            else:
+                assert torch.equal(ga[i][j], gb[i][j]), (i, name)
+
+
 @pytest.mark.parametrize('C', [4, 8, 16, 32])
 def test_wide_level_matches_oracle(C):
     """Three blocks (d = 1, 2, 3) through WideLevelFn against the fp64 oracle of the unrounded blocks, bf16 tolerance."""
@@ -616,5 +662,5 @@ def test_fp16_build_passes_the_same_stagewise_tests():
     grids, bench heights and T = 3072 -- at the fp16 bars (2^-11 relative + 2.5e-4 of the tensor's scale per stored element)."""
     out = _pytest_subprocess(dict(TT_TEST_ELT='fp16', TT_CHILD_PYTEST='1'),
                              ['tests/test_gpu_wide_bf16.py', '-k', 'stagewise or multitile or edge_convs or capped_grids or bench_launch_shapes '
-                              'or bench_heights or skip_joins or reference_training_length'])
+                              'or bench_heights or skip_joins or reference_training_length or level_backward_equals'])
     assert ' passed' in out

@@ -372,9 +372,7 @@ int launch_fused(const e16* x, const e16* dy, const float* w1, const float* b1, 
     TT_LAUNCH_CHECK();
     RedArgs ra{part_w, grid, part_a, grid, dw1, db1, dw2, db2, C == 32 ? 1 : 0};
     constexpr int total = 9 * C * C + C * C + 2 * C;
-    hipLaunchKernelGGL(k_wrb_reduce<C>, dim3((total + REL - 1) / REL), dim3(1024), 0, st, ra);
-    TT_LAUNCH_CHECK();
-    return 0;
+    return reduce_or_defer(k_wrb_reduce<C>, total, ra, st);
 }
 
 // Tile shapes (TTRAP_FBWD_TILE = 0 / 1 selects the alternative set, for tuning):
@@ -804,9 +802,7 @@ int launch_bwds(const e16* x, const e16* h1, const e16* dy, const float* w1, con
     TT_LAUNCH_CHECK();
     RedArgs ra{part_w, grid, part_a, grid, dw1, db1, dw2, db2, C == 32 ? 1 : 0};
     constexpr int total = 9 * C * C + C * C + 2 * C;
-    hipLaunchKernelGGL(k_wrb_reduce<C>, dim3((total + REL - 1) / REL), dim3(1024), 0, st, ra);
-    TT_LAUNCH_CHECK();
-    return 0;
+    return reduce_or_defer(k_wrb_reduce<C>, total, ra, st);
 }
 
 template <int C>

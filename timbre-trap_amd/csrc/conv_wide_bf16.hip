@@ -734,9 +734,7 @@ int launch_dxw(const e16* x, const e16* da1, const e16* dy, const float* w1, e16
     TT_LAUNCH_CHECK();
     RedArgs ra{part_w, gx, part_a, grid_a, dw1, db1, dw2, db2, C == 32 ? 1 : 0, C == 32 ? 0 : 1};
     constexpr int total = 9 * C * C + C * C + 2 * C;
-    hipLaunchKernelGGL(k_wrb_reduce<C>, dim3((total + REL - 1) / REL), dim3(1024), 0, st, ra);
-    TT_LAUNCH_CHECK();
-    return 0;
+    return reduce_or_defer(k_wrb_reduce<C>, total, ra, st);
 }
 
 // One-pass backward (k_wrb_bwds, conv_level_bf16.hip: column strips, dA1 in a rolling LDS ring, 4 tensors of HBM traffic) or the
@@ -802,9 +800,7 @@ int launch_bwd(const e16* x, const e16* h1, const e16* dy, const float* w1, cons
     TT_LAUNCH_CHECK();
     RedArgs ra{part_w, gw, part_a, grid, dw1, db1, dw2, db2};
     constexpr int total = 9 * C * C + C * C + 2 * C;
-    hipLaunchKernelGGL(k_wrb_reduce<C>, dim3((total + REL - 1) / REL), dim3(1024), 0, st, ra);
-    TT_LAUNCH_CHECK();
-    return 0;
+    return reduce_or_defer(k_wrb_reduce<C>, total, ra, st);
 }
 
 template <int C>
@@ -1568,7 +1564,8 @@ __global__ __launch_bounds__(NT) void k_nrb_dxw(const e16* __restrict__ x, const
 }
 
 template <int C>
-__global__ __launch_bounds__(1024) void k_nrb_reduce(RedArgs ar) {
+__global__ __launch_bounds__(1024) void k_nrb_reduce(RedBatch batch) {
+    const RedArgs& ar = batch.a[blockIdx.y];
     constexpr int WDUMP = 9 * 256, ADUMP = C * C + 2 * C;
     __shared__ float red[RSL][REL];
     const int el = threadIdx.x % REL, sl = threadIdx.x / REL;
@@ -1651,9 +1648,7 @@ int launch_nbwd(const e16* x, const e16* h1, const e16* dy, const float* w1, con
         TT_LAUNCH_CHECK();
         RedArgs ra{part_w, gf, part_a, gf, dw1, db1, dw2, db2};
         constexpr int total = 9 * 256 + C * C + 2 * C;
-        hipLaunchKernelGGL(k_nrb_reduce<C>, dim3((total + REL - 1) / REL), dim3(1024), 0, st, ra);
-        TT_LAUNCH_CHECK();
-        return 0;
+        return reduce_or_defer(k_nrb_reduce<C>, total, ra, st);
     }
     const long ngroups = (npix + 63) / 64;
     const long want = (ngroups + 3) / 4;
@@ -1677,9 +1672,7 @@ int launch_nbwd(const e16* x, const e16* h1, const e16* dy, const float* w1, con
         TT_LAUNCH_CHECK();
         RedArgs ra{part_w, gx, part_a, grid, dw1, db1, dw2, db2, 0, 1};
         constexpr int total = 9 * 256 + C * C + 2 * C;
-        hipLaunchKernelGGL(k_nrb_reduce<C>, dim3((total + REL - 1) / REL), dim3(1024), 0, st, ra);
-        TT_LAUNCH_CHECK();
-        return 0;
+        return reduce_or_defer(k_nrb_reduce<C>, total, ra, st);
     }
     if (int rc = launch_nconv<C, D, 1, false>(da1, w1, nullptr, nullptr, nullptr, dy, dx, nullptr, B, H, T, st)) return rc;
     using W = NG<C, D>;
@@ -1694,9 +1687,7 @@ int launch_nbwd(const e16* x, const e16* h1, const e16* dy, const float* w1, con
     TT_LAUNCH_CHECK();
     RedArgs ra{part_w, gw, part_a, grid, dw1, db1, dw2, db2};
     constexpr int total = 9 * 256 + C * C + 2 * C;
-    hipLaunchKernelGGL(k_nrb_reduce<C>, dim3((total + REL - 1) / REL), dim3(1024), 0, st, ra);
-    TT_LAUNCH_CHECK();
-    return 0;
+    return reduce_or_defer(k_nrb_reduce<C>, total, ra, st);
 }
 
 template <int C>
@@ -1730,6 +1721,8 @@ inline bool shape_ok(int B, int C, int H, int T) {
 }
 
 }  // namespace
+
+thread_local void* ttx_red_defer = nullptr;
 
 extern "C" {
 
@@ -1805,6 +1798,47 @@ int tt_wide_rb_bwd(const void* x, const void* h1, const void* dy, const float* w
         case 16: return bwd_c<16>(xi, hi, gi, w1, w2, b2, go, dw1, db1, dw2, db2, w, B, H, T, dilation, st);
     }
     return bwd_c<32>(xi, hi, gi, w1, w2, b2, go, dw1, db1, dw2, db2, w, B, H, T, dilation, st);
+}
+
+int64_t tt_wide_level_scratch_bytes(int nblocks, int B, int C, int H, int T) {
+    const int64_t one = tt_wide_scratch_bytes(B, C, H, T);
+    return one < 0 || nblocks < 1 || nblocks > 4 ? -1 : (int64_t)nblocks * ((one + 255) / 256 * 256);
+}
+
+int tt_wide_level_bwd(int nblocks, const void* const* x, const void* const* h1, const void* dy, const float* const* w1,
+                      const float* const* w2, const float* const* b2, void* dx, void* tmp0, void* tmp1, float* const* dw1,
+                      float* const* db1, float* const* dw2, float* const* db2, void* ws, int B, int C, int H, int T,
+                      const int* dilations, void* stream) {
+    if (nblocks < 1 || nblocks > 4 || !x || !h1 || !dy || !w1 || !w2 || !b2 || !dx || !dw1 || !db1 || !dw2 || !db2 || !ws || !dilations ||
+        (nblocks > 1 && (!tmp0 || !tmp1)) || !shape_ok(B, C, H, T))
+        return TT_E_BADARG;
+    if (ttx_red_defer) return TT_E_BADARG;                      // not re-entrant on one thread
+    const int64_t one = (tt_wide_scratch_bytes(B, C, H, T) + 255) / 256 * 256;
+    RedBatch batch;
+    ttx_red_defer = &batch;
+    const void* g = dy;
+    int rc = 0;
+    for (int i = nblocks - 1; i >= 0 && !rc; --i) {
+        void* gx = i == 0 ? dx : ((i & 1) ? tmp1 : tmp0);
+        rc = tt_wide_rb_bwd(x[i], h1[i], g, w1[i], w2[i], b2[i], gx, dw1[i], db1[i], dw2[i], db2[i], (unsigned char*)ws + (int64_t)i * one, B, C, H, T,
+                            dilations[i], stream);
+        g = gx;
+    }
+    ttx_red_defer = nullptr;
+    if (rc) return rc;
+    hipStream_t st = tt_stream(stream);
+    if (batch.n > 0) {
+        const int total = (C <= 8 ? 9 * 256 : 9 * C * C) + C * C + 2 * C;
+        const dim3 grid((total + REL - 1) / REL, batch.n);
+        switch (C) {
+            case 4: hipLaunchKernelGGL(k_nrb_reduce<4>, grid, dim3(1024), 0, st, batch); break;
+            case 8: hipLaunchKernelGGL(k_nrb_reduce<8>, grid, dim3(1024), 0, st, batch); break;
+            case 16: hipLaunchKernelGGL(k_wrb_reduce<16>, grid, dim3(1024), 0, st, batch); break;
+            default: hipLaunchKernelGGL(k_wrb_reduce<32>, grid, dim3(1024), 0, st, batch);
+        }
+        TT_LAUNCH_CHECK();
+    }
+    return 0;
 }
 
 }  // extern "C"

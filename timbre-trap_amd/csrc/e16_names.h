@@ -27,4 +27,7 @@
 #define tt_convin16_bwd tt_convin16_bwd_h
 #define tt_convout16_fwd tt_convout16_fwd_h
 #define tt_convout16_bwd tt_convout16_bwd_h
+#define ttx_red_defer ttx_red_defer_h
+#define tt_wide_level_bwd tt_wide_level_bwd_h
+#define tt_wide_level_scratch_bytes tt_wide_level_scratch_bytes_h
 #endif

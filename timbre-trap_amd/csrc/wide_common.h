@@ -60,8 +60,12 @@ struct RedArgs {
     int split_a = 0;                // C = 32 fused backward: wave = (ci-tile, co-tile), each wave dumps only its own co-tile
     int one_dump = 0;               // the producing kernel summed its four waves: only wave slot 0 of every workgroup holds data
 };
+// Up to four reduces in ONE launch (blockIdx.y): tt_wide_level_bwd defers the reduce of every block of a level and sums all their dumps
+// at the end -- two launches (and their dependent-launch gaps) fewer per level and pass, 48 per train step.
+struct RedBatch { RedArgs a[4]; int n = 0; };
 template <int C>
-__global__ __launch_bounds__(1024) void k_wrb_reduce(RedArgs ar) {
+__global__ __launch_bounds__(1024) void k_wrb_reduce(RedBatch batch) {
+    const RedArgs& ar = batch.a[blockIdx.y];
     constexpr int NCT = C / 16;
     constexpr int WDUMP = 9 * NCT * 256, NEW = NCT * WDUMP;      // wgrad: elements = (wave role) x dump
     constexpr int ADUMP = C * C + 2 * C;
@@ -116,6 +120,25 @@ __global__ __launch_bounds__(1024) void k_wrb_reduce(RedArgs ar) {
         for (int i = 0; i < RSL; ++i) s += red[i][el];
         *dst += s;
     }
+}
+
+// Where a launcher would start its reduce: now, or -- inside tt_wide_level_bwd -- into the level's batch (ttx_red_defer: the calling
+// thread's pending batch; conv_wide_bf16.hip defines it, conv_level_bf16.hip's launchers see it too).
+}  // namespace
+extern thread_local void* ttx_red_defer;
+namespace {
+template <class Kernel> inline int reduce_or_defer(Kernel kern, int total, const RedArgs& ra, hipStream_t st) {
+    if (ttx_red_defer) {
+        RedBatch* b = static_cast<RedBatch*>(ttx_red_defer);
+        if (b->n >= 4) return TT_E_BADARG;
+        b->a[b->n++] = ra;
+        return 0;
+    }
+    RedBatch one;
+    one.a[0] = ra; one.n = 1;
+    hipLaunchKernelGGL(kern, dim3((total + REL - 1) / REL, 1), dim3(1024), 0, st, one);
+    TT_LAUNCH_CHECK();
+    return 0;
 }
 
 }  // namespace

@@ -577,6 +577,10 @@ LEVEL_CHUNK = int(os.environ.get('TTRAP_LEVEL_CHUNK', '0'))
 RECOMPUTE_CHANNELS = (16, 32) if os.environ.get('TTRAP_LEVEL_RECOMPUTE', '0') == '1' else ()
 
 
+# TTRAP_LEVEL_BWD=0: one tt_wide_rb_bwd call (with its own reduce launch) per block instead of tt_wide_level_bwd (A/B switch)
+LEVEL_BWD = os.environ.get('TTRAP_LEVEL_BWD', '1') != '0'
+
+
 def _chunks(B):
     c = LEVEL_CHUNK if 0 < LEVEL_CHUNK < B else B
     return [(b0, min(B, b0 + c)) for b0 in range(0, B, c)]
@@ -632,6 +636,20 @@ class Level16Fn(torch.autograd.Function):
         targets = [_grad_target(t) for t in ctx.params]
         dx = new_cl16(B, C, H, T, g_all.device, dt)
         tmp = [new_cl16(cb, C, H, T, g_all.device, dt) for _ in range(2)] if nb > 1 else []
+        if LEVEL_BWD and not recompute and len(chunks) == 1 and nb <= 4:
+            # the whole level in one call: the partial-sum reduces of its blocks are one launch at the end (tt_wide_level_bwd)
+            def arr(ts):
+                return (ctypes.c_void_p * nb)(*[t.data_ptr() for t in ts])
+            ws = torch.empty(lib.tt_wide_level_scratch_bytes(nb, B, C, H, T), dtype=torch.uint8, device=g_all.device)
+            cols = list(zip(*[[targets[4 * i + j][0] for j in range(4)] for i in range(nb)]))      # dw1s, db1s, dw2s, db2s
+            dil = (ctypes.c_int * nb)(*ctx.dilations)
+            with _hip.timed('wide_rb_bwd_C%d' % C):
+                check(lib.tt_wide_level_bwd(nb, arr([saved[2 * i] for i in range(nb)]), arr([saved[2 * i + 1] for i in range(nb)]), ptr(g_all),
+                                            arr([params[4 * i] for i in range(nb)]), arr([params[4 * i + 2] for i in range(nb)]),
+                                            arr([params[4 * i + 3] for i in range(nb)]), ptr(dx), ptr(tmp[0]) if tmp else None,
+                                            ptr(tmp[1]) if tmp else None, arr(cols[0]), arr(cols[1]), arr(cols[2]), arr(cols[3]), ptr(ws),
+                                            B, C, H, T, dil, st), 'tt_wide_level_bwd')
+            return (dx, None, *[r for _, r in targets])
         for b0, b1 in chunks:
             g = g_all[b0:b1]
             for i in reversed(range(nb)):

@@ -23,9 +23,14 @@
 
 namespace {
 
+// blockIdx.y selects one of up to four (w1, w2, image) triples: tt_wide_level_bwd prepares the images of all blocks of a level in one launch
+struct WPrep { const float* w1[4]; const float* w2[4]; e16x8* img[4]; };
 template <int C>
-__global__ __launch_bounds__(64) void k_lvl_wprep(const float* __restrict__ w1, const float* __restrict__ w2, e16x8* __restrict__ img) {
+__global__ __launch_bounds__(64) void k_lvl_wprep(WPrep wp_) {
     using K = WK<C>;
+    const float* __restrict__ w1 = wp_.w1[blockIdx.y];
+    const float* __restrict__ w2 = wp_.w2[blockIdx.y];
+    e16x8* __restrict__ img = wp_.img[blockIdx.y];
     const int lane = threadIdx.x, n = lane & 15, g = lane >> 4, blk = blockIdx.x;
     if (blk < K::NK * K::NCT) {
         const int k = blk / K::NCT, ct = blk - k * K::NCT;
@@ -358,8 +363,11 @@ int launch_fused(const e16* x, const e16* dy, const float* w1, const float* b1, 
     e16x8* wimg = reinterpret_cast<e16x8*>(ws);
     float* part_a = reinterpret_cast<float*>(ws + K::IMG_BYTES);
     float* part_w = part_a + (long)MAX_W_WG * G::ADUMP;
-    hipLaunchKernelGGL(k_lvl_wprep<C>, dim3(K::NK * K::NCT + 1), dim3(64), 0, st, w1, w2, wimg);
-    TT_LAUNCH_CHECK();
+    if (!ttx_wprep_done) {                                       // inside tt_wide_level_bwd the images of all blocks were prepared in one launch
+        WPrep wp1{{w1}, {w2}, {wimg}};
+        hipLaunchKernelGGL(k_lvl_wprep<C>, dim3(K::NK * K::NCT + 1, 1), dim3(64), 0, st, wp1);
+        TT_LAUNCH_CHECK();
+    }
     static AttrOnce once;
     auto kern = k_wrb_bwd_fused<C, D, TH, TW, NW>;
     if (int rc = raise_lds(kern, G::LDS_BYTES, once)) return rc;
@@ -753,13 +761,38 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_bwds(const e16* __restrict__ x
         }
     }
 
-    // ---- dumps: the weight-gradient accumulators per wave, everything else summed over the waves through LDS ----
-    float* pw = part_w + ((long)blockIdx.x * 4 + wave) * G::WDUMP;
+    // ---- dumps: the weight-gradient accumulators (C = 32: per wave, each holds its own (ci-tile, co-tile); C = 16: the four waves hold
+    //      the same elements and are summed through LDS -- one dump per workgroup, the reduce reads a quarter of the bytes:
+    //      RedArgs::one_dump), everything else summed over the waves through LDS ----
+    if constexpr (C == 32) {
+        float* pw = part_w + ((long)blockIdx.x * 4 + wave) * G::WDUMP;
 #pragma unroll
-    for (int k = 0; k < 9; ++k)
+        for (int k = 0; k < 9; ++k)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pw[((k * NCT + aw) * 4 + r) * 64 + lane] = wacc[k][r];   // C = 32: only this wave's co-tile (RedArgs::split_a)
-    __syncthreads();
+            for (int r = 0; r < 4; ++r) pw[((k * NCT + aw) * 4 + r) * 64 + lane] = wacc[k][r];   // only this wave's co-tile (RedArgs::split_a)
+        __syncthreads();
+    } else {
+        static_assert(C == 32 || 2 * G::WDUMP * 4 <= G::LDS_BYTES, "two waves' accumulators fit the images");
+        __syncthreads();
+        float* wr = reinterpret_cast<float*>(smem);              // two slots: (wave 2 + wave 0), (wave 3 + wave 1), then their sum
+        if (wave >= 2) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) wr[(wave - 2) * G::WDUMP + (k * 4 + r) * 64 + lane] = wacc[k][r];
+        }
+        __syncthreads();
+        if (wave < 2) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) wr[wave * G::WDUMP + (k * 4 + r) * 64 + lane] += wacc[k][r];
+        }
+        __syncthreads();
+        float* pw = part_w + (long)blockIdx.x * 4 * G::WDUMP;
+        for (int i = tid; i < G::WDUMP; i += NT) pw[i] = wr[i] + wr[G::WDUMP + i];
+        __syncthreads();
+    }
     float* red = reinterpret_cast<float*>(smem) + wave * G::ADUMP;
 #pragma unroll
     for (int a = 0; a < NCT; ++a)
@@ -788,8 +821,11 @@ int launch_bwds(const e16* x, const e16* h1, const e16* dy, const float* w1, con
     e16x8* wimg = reinterpret_cast<e16x8*>(ws);
     float* part_a = reinterpret_cast<float*>(ws + K::IMG_BYTES);
     float* part_w = part_a + (long)MAX_W_WG * G::ADUMP;
-    hipLaunchKernelGGL(k_lvl_wprep<C>, dim3(K::NK * K::NCT + 1), dim3(64), 0, st, w1, w2, wimg);
-    TT_LAUNCH_CHECK();
+    if (!ttx_wprep_done) {                                       // inside tt_wide_level_bwd the images of all blocks were prepared in one launch
+        WPrep wp1{{w1}, {w2}, {wimg}};
+        hipLaunchKernelGGL(k_lvl_wprep<C>, dim3(K::NK * K::NCT + 1, 1), dim3(64), 0, st, wp1);
+        TT_LAUNCH_CHECK();
+    }
     static AttrOnce once;
     constexpr int MINW = C == 32 ? 3 : 4;
     auto kern = k_wrb_bwds<C, D, TH, TW, MINW>;
@@ -800,7 +836,7 @@ int launch_bwds(const e16* x, const e16* h1, const e16* dy, const float* w1, con
     if (grid > MAX_W_WG) grid = MAX_W_WG;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), G::LDS_BYTES, st, x, h1, dy, wimg, b2, dx, part_a, part_w, B, H, T, tiles_t, nstrips);
     TT_LAUNCH_CHECK();
-    RedArgs ra{part_w, grid, part_a, grid, dw1, db1, dw2, db2, C == 32 ? 1 : 0};
+    RedArgs ra{part_w, grid, part_a, grid, dw1, db1, dw2, db2, C == 32 ? 1 : 0, C == 32 ? 0 : 1};
     constexpr int total = 9 * C * C + C * C + 2 * C;
     return reduce_or_defer(k_wrb_reduce<C>, total, ra, st);
 }
@@ -826,6 +862,19 @@ inline bool fshape_ok(int B, int C, int H, int T) {
 }
 
 }  // namespace
+
+// called by tt_wide_level_bwd (conv_wide_bf16.hip): the bf16 weight images of n blocks (image i at ws_i, where the one-pass kernels expect
+// it) in ONE launch; not part of the C ABI
+int ttx_wide_wprep_batch(int C, int n, const float* const* w1, const float* const* w2, void* const* ws, hipStream_t st) {
+    if (n < 1 || n > 4) return TT_E_BADARG;
+    WPrep wp{};
+    for (int i = 0; i < n; ++i) { wp.w1[i] = w1[i]; wp.w2[i] = w2[i]; wp.img[i] = reinterpret_cast<e16x8*>(ws[i]); }
+    if (C == 16) hipLaunchKernelGGL(k_lvl_wprep<16>, dim3(WK<16>::NK * WK<16>::NCT + 1, n), dim3(64), 0, st, wp);
+    else if (C == 32) hipLaunchKernelGGL(k_lvl_wprep<32>, dim3(WK<32>::NK * WK<32>::NCT + 1, n), dim3(64), 0, st, wp);
+    else return TT_E_UNSUPPORTED;
+    TT_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" {
 

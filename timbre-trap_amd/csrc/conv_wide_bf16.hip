@@ -1414,12 +1414,19 @@ __global__ __launch_bounds__(NT, C == 8 ? 2 : 1) void k_nrb_bwd_fused(const e16*
             }
         }
     }
-    // ---- dumps ----
-    float* pw = part_w + ((long)blockIdx.x * 4 + wave) * (9 * 256);
+    // ---- dumps: the four waves hold the same weight-gradient elements -- summed through LDS, ONE dump per workgroup (wave slot 0;
+    //      RedArgs::one_dump: the reduce reads a quarter of the bytes) ----
+    __syncthreads();
+    {
+        float* wr = reinterpret_cast<float*>(smem);
 #pragma unroll
-    for (int k = 0; k < 9; ++k)
+        for (int k = 0; k < 9; ++k)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pw[(k * 4 + r) * 64 + lane] = wacc[k][r];
+            for (int r = 0; r < 4; ++r) wr[wave * 2304 + (k * 4 + r) * 64 + lane] = wacc[k][r];
+        __syncthreads();
+        float* pw = part_w + (long)blockIdx.x * 4 * 2304;
+        for (int i = tid; i < 2304; i += NT) pw[i] = (wr[i] + wr[2304 + i]) + (wr[2 * 2304 + i] + wr[3 * 2304 + i]);
+    }
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
@@ -1646,7 +1653,7 @@ int launch_nbwd(const e16* x, const e16* h1, const e16* dy, const float* w1, con
         static const int fastdma = tt_tune("TTRAP_FAST_DMA", 1);
         hipLaunchKernelGGL(kf, dim3(gf), dim3(NT), LDS, st, x, h1, dy, w1, w2, b2, dx, part_a, part_w, B, H, T, tiles_h, tiles_t, ntiles, fastdma);
         TT_LAUNCH_CHECK();
-        RedArgs ra{part_w, gf, part_a, gf, dw1, db1, dw2, db2};
+        RedArgs ra{part_w, gf, part_a, gf, dw1, db1, dw2, db2, 0, 1};
         constexpr int total = 9 * 256 + C * C + 2 * C;
         return reduce_or_defer(k_nrb_reduce<C>, total, ra, st);
     }
@@ -1723,6 +1730,7 @@ inline bool shape_ok(int B, int C, int H, int T) {
 }  // namespace
 
 thread_local void* ttx_red_defer = nullptr;
+thread_local bool ttx_wprep_done = false;
 
 extern "C" {
 
@@ -1815,9 +1823,21 @@ int tt_wide_level_bwd(int nblocks, const void* const* x, const void* const* h1, 
     if (ttx_red_defer) return TT_E_BADARG;                      // not re-entrant on one thread
     const int64_t one = (tt_wide_scratch_bytes(B, C, H, T) + 255) / 256 * 256;
     RedBatch batch;
+    int rc = 0;
+    // the weight images of the blocks that take the one-pass kernel: one launch for the level
+    {
+        const float *pw1[4], *pw2[4];
+        void* pws[4];
+        int np = 0;
+        for (int i = 0; i < nblocks; ++i)
+            if (tt_wide_rb_bwd_is_onepass(C, dilations[i])) { pw1[np] = w1[i]; pw2[np] = w2[i]; pws[np] = (unsigned char*)ws + (int64_t)i * one; ++np; }
+        if (np > 0) {
+            if ((rc = ttx_wide_wprep_batch(C, np, pw1, pw2, pws, tt_stream(stream)))) return rc;
+            ttx_wprep_done = true;
+        }
+    }
     ttx_red_defer = &batch;
     const void* g = dy;
-    int rc = 0;
     for (int i = nblocks - 1; i >= 0 && !rc; --i) {
         void* gx = i == 0 ? dx : ((i & 1) ? tmp1 : tmp0);
         rc = tt_wide_rb_bwd(x[i], h1[i], g, w1[i], w2[i], b2[i], gx, dw1[i], db1[i], dw2[i], db2[i], (unsigned char*)ws + (int64_t)i * one, B, C, H, T,
@@ -1825,6 +1845,7 @@ int tt_wide_level_bwd(int nblocks, const void* const* x, const void* const* h1, 
         g = gx;
     }
     ttx_red_defer = nullptr;
+    ttx_wprep_done = false;
     if (rc) return rc;
     hipStream_t st = tt_stream(stream);
     if (batch.n > 0) {

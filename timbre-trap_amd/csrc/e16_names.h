@@ -28,6 +28,8 @@
 #define tt_convout16_fwd tt_convout16_fwd_h
 #define tt_convout16_bwd tt_convout16_bwd_h
 #define ttx_red_defer ttx_red_defer_h
+#define ttx_wprep_done ttx_wprep_done_h
+#define ttx_wide_wprep_batch ttx_wide_wprep_batch_h
 #define tt_wide_level_bwd tt_wide_level_bwd_h
 #define tt_wide_level_scratch_bytes tt_wide_level_scratch_bytes_h
 #endif

@@ -710,16 +710,38 @@ __global__ __launch_bounds__(NT, C == 32 ? ((!DX && GS) ? 3 : 2) : W4_WAVES16) v
             }
         }
     }
-    float* pw = part + ((long)blockIdx.x * 4 + wave) * G::DUMP;
+    if constexpr (SPLIT) {
+        float* pw = part + ((long)blockIdx.x * 4 + wave) * G::DUMP;
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int a = 0; a < NAW; ++a)
+        for (int k = 0; k < 4; ++k)
 #pragma unroll
             for (int c = 0; c < G::NBT; ++c)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)      // SPLIT: only this wave's small-side tile (the reduce reads exactly those slots)
-                    pw[(((k * G::NA + (SPLIT ? wave : a)) * G::NBT + c) * 4 + r) * 64 + lane] = acc[k][a][c][r];
+                for (int r = 0; r < 4; ++r)      // only this wave's small-side tile (the reduce reads exactly those slots)
+                    pw[(((k * G::NA + wave) * G::NBT + c) * 4 + r) * 64 + lane] = acc[k][0][c][r];
+    } else {
+        // the four waves hold the same elements (they split columns and rows): summed through LDS in a fixed order -- (wave 2 + wave 0) +
+        // (wave 3 + wave 1) -- and ONE dump per workgroup (wave slot 0): k_w4_reduce reads a quarter of the bytes (round 4)
+        static_assert(2 * G::DUMP * 4 <= G::LDS_BYTES, "two waves' accumulators fit the images");
+        __syncthreads();
+        float* wr = reinterpret_cast<float*>(smem);
+        auto each = [&](auto&& f) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int a = 0; a < NAW; ++a)
+#pragma unroll
+                    for (int c = 0; c < G::NBT; ++c)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) f((((k * G::NA + a) * G::NBT + c) * 4 + r) * 64 + lane, acc[k][a][c][r]);
+        };
+        if (wave >= 2) each([&](int i, float v) { wr[(wave - 2) * G::DUMP + i] = v; });
+        __syncthreads();
+        if (wave < 2) each([&](int i, float v) { wr[wave * G::DUMP + i] += v; });
+        __syncthreads();
+        float* pw = part + (long)blockIdx.x * 4 * G::DUMP;
+        for (int i = tid; i < G::DUMP; i += NT) pw[i] = wr[i] + wr[G::DUMP + i];
+    }
     // bias gradient: a thread always stages the same physical 16-byte position of the gated operand's pixels (256 pieces per
     // round is a multiple of 8 pixels, which leaves the swizzle bits unchanged), hence one fixed logical channel group
     constexpr int GB = GS ? G::SB : G::BB, GC = GB / 2;
@@ -760,12 +782,11 @@ __global__ __launch_bounds__(1024) void k_w4_reduce(W4Red ar) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
                     if (j0 + RSL * u < ar.gw) p8[u] += ar.part[((long)(j0 + RSL * u) * 4 + wv) * G::DUMP + e];
-        } else {
-            const int nc = ar.gw * 4;
-            for (int j0 = sl; j0 < nc; j0 += 8 * RSL)
+        } else {                                                // one dump per workgroup, in wave slot 0
+            for (int j0 = sl; j0 < ar.gw; j0 += 8 * RSL)
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
-                    if (j0 + RSL * u < nc) p8[u] += ar.part[(long)(j0 + RSL * u) * G::DUMP + e];
+                    if (j0 + RSL * u < ar.gw) p8[u] += ar.part[(long)(j0 + RSL * u) * 4 * G::DUMP + e];
         }
     } else if (e < G::DUMP + GC) {
         for (int j = sl; j < ar.gw; j += RSL) p8[0] += ar.dbpart[(long)j * 64 + (e - G::DUMP)];

@@ -207,8 +207,9 @@ def test_wide_block_multitile(C, d, shape, cus, cu_limit):
     _stagewise(C, d, *shape)
 
 
-@pytest.mark.parametrize('C,shape', [(4, (2, 37, 130)), (8, (1, 40, 200)), (16, (2, 21, 96)), (32, (1, 30, 160))])
-def test_level_backward_equals_block_by_block(C, shape):
+@pytest.mark.parametrize('C,shape,dil', [(4, (2, 37, 130), (1, 2, 3)), (8, (1, 40, 200), (1, 2, 3)), (16, (2, 21, 96), (1, 2, 3)), (32, (1, 30, 160), (1, 2, 3)),
+                                         (16, (1, 21, 96), (2,)), (8, (1, 24, 64), (3, 1)), (32, (1, 12, 64), (1, 2, 3, 1))])
+def test_level_backward_equals_block_by_block(C, shape, dil):
     """tt_wide_level_bwd (all blocks of a level, the partial-sum reduces deferred into ONE launch) against one tt_wide_rb_bwd call per
     block: the same kernels and the same sums in the same order -- dx and every weight / bias gradient bit-identical (the narrow levels'
     3x3 weight gradient, whose reduce adds with atomics, at fp32 rounding)."""
@@ -216,7 +217,7 @@ def test_level_backward_equals_block_by_block(C, shape):
     from timbre_trap._hip import check, ptr, stream_ptr
     lib, st = _lib(), stream_ptr()
     B, H, T = shape
-    nb, dil = 3, (1, 2, 3)
+    nb = len(dil)                                            # 1 .. 4 blocks: the two gradient buffers between the blocks alternate
     par = [[_rand(C, C, 3, 3, seed=20 + i, scale=1.0 / (3 * C ** 0.5)).cuda(), _rand(C, seed=30 + i, scale=0.3).cuda(),
             _rand(C, C, 1, 1, seed=40 + i, scale=1.0 / C ** 0.5).cuda(), _rand(C, seed=50 + i, scale=0.3).cuda()] for i in range(nb)]
     nhwc = lambda: torch.empty((B, H, T, C), dtype=ELT, device='cuda')
@@ -230,7 +231,7 @@ def test_level_backward_equals_block_by_block(C, shape):
     # block by block
     ws = torch.zeros(lib.tt_wide_scratch_bytes(B, C, H, T), dtype=torch.uint8, device='cuda')
     ga = [[torch.full(s_, 0.5, device='cuda') for s_ in shapes] for _ in range(nb)]
-    g, bufs = dy, [nhwc(), nhwc(), nhwc()]
+    g, bufs = dy, [nhwc() for _ in range(nb)]
     for i in reversed(range(nb)):
         check(lib.tt_wide_rb_bwd(ptr(xs[i]), ptr(hs[i]), ptr(g), ptr(par[i][0]), ptr(par[i][2]), ptr(par[i][3]), ptr(bufs[i]), ptr(ga[i][0]), ptr(ga[i][1]),
                                  ptr(ga[i][2]), ptr(ga[i][3]), ptr(ws), B, C, H, T, dil[i], st), 'bwd')

@@ -672,6 +672,14 @@ def main():
             full = bench_inference(model, args, rank, world, dev, steps=10, warmup=2, emit=False)
             infer = {k: full[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype')}
             infer['workload'] = full['config']['workload']
+            if args.precision == 'auto' and ops.X3_INFER:
+                # no autocast, no grad: the wide levels (C = 16, 32) run on split fp16 operands (csrc/conv_x3.hip: fp32-class results,
+                # tests/test_gpu_x3.py; model-level bar 1e-4 in tests/test_gpu_model.py), the rest on the fp32 kernels
+                infer['dtype'] = 'f32 (wide levels: f16 hi/lo pairs, three f16 MFMA products, f32 accumulate)'
+                ops.X3_INFER = False
+                plain = bench_inference(model, args, rank, world, dev, steps=10, warmup=2, emit=False)
+                ops.X3_INFER = True
+                infer['fp32_kernels_only'] = {k: plain[k] for k in ('value', 'unit', 'ms_per_step', 'dtype')}
             if args.precision == 'auto':
                 full16 = bench_inference(model, args, rank, world, dev, steps=10, warmup=2, emit=False, autocast=True)
                 infer['under_autocast'] = {k: full16[k] for k in ('value', 'unit', 'ms_per_step', 'dtype')}

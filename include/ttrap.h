@@ -356,6 +356,28 @@ int tt_peak_pick(const float* x, float* out, int64_t n_outer, int F, int T, doub
 int tt_target_activations(const int* bins, const int* frames, int n, const double* weights, int radius, int F, int T,
                           double* work, double* out, void* stream);
 
+/* ---- fp32-class residual blocks on the 16-bit matrix pipe ("x3": split operands), inference ----------------------------------------
+ * csrc/conv_x3.hip.  The three ResidualConv2dBlocks of one wide EncoderBlock / DecoderBlock (modules.py:621-624, 690-693; C = 16, 32,
+ * dilation 1..3, else TT_E_BADARG / TT_E_UNSUPPORTED) evaluated to fp32 accuracy without the fp32 matrix instructions: every fp32
+ * value v (activations in HBM, weights in LDS) is the pair hi = fp16(v), lo = fp16((v - hi) 2^11) and a product is
+ * Whi xhi + 2^-11 (Whi xlo + Wlo xhi) on v_mfma_f32_16x16x32_f16 with fp32 accumulators; bias, ELU, residual add in fp32.  Results agree
+ * with the fp32 kernels (tt_resblock_fwd) to a few 1e-7 relative; values beyond fp16's range (|v| > 65504) come out non-finite.
+ * Forward only (no hidden activation is saved): the no-grad path of ops.residual_level in fp32 mode.
+ *   tt_x3_bytes      bytes of one activation tensor in the x3 layout [B][H][T][2][C] halves (= B C H T 4)
+ *   tt_x3_pack       x (B,C,H,T) fp32 planar -> x3              tt_x3_unpack   the inverse (exact to 2^-23 relative)
+ *   tt_x3_rb_fwd     y = ELU(W2 . ELU(W1 (*)_dil x + b1) + b2) + x; x is an x3 tensor, y an x3 tensor (planar_out = 0; x != y) or an
+ *                    fp32 planar (B,C,H,T) tensor (planar_out = 1); weights fp32 (C,C,3,3) / (C,C,1,1)
+ *   tt_x3_level_fwd  pack, nblocks blocks (w1[i], b1[i], w2[i], b2[i], dilations[i]; the last one planar_out): fp32 planar in and out;
+ *                    ws = tt_x3_level_scratch_bytes bytes */
+int64_t tt_x3_bytes(int B, int C, int H, int T);
+int64_t tt_x3_level_scratch_bytes(int B, int C, int H, int T);
+int tt_x3_pack(const float* x, void* out, int B, int C, int H, int T, void* stream);
+int tt_x3_unpack(const void* in, float* y, int B, int C, int H, int T, void* stream);
+int tt_x3_rb_fwd(const void* x, const float* w1, const float* b1, const float* w2, const float* b2, void* y, int planar_out, int B,
+                 int C, int H, int T, int dilation, void* stream);
+int tt_x3_level_fwd(int nblocks, const float* x, float* y, const float* const* w1, const float* const* b1, const float* const* w2,
+                    const float* const* b2, const int* dilations, void* ws, int B, int C, int H, int T, void* stream);
+
 /* ---- fp16 twins ---------------------------------------------------------------------------------------------------------------
  * Every entry point of the 16-bit channels-last path above exists a second time with the suffix _h: the same kernels compiled with
  * fp16 elements (csrc/bf16_common.h, -DTT_F16: v_mfma_f32_*_f16, same layouts, same scratch sizes, same argument meaning; `void*`

@@ -239,6 +239,44 @@ def test_train_steps_match_oracle_mc2_full_block():
     assert worst < 2e-4, worst
 
 
+def test_config1_split_operand_wide_levels_agree_with_fp32_kernels():
+    """
+    Without autocast and without grad the wide levels (C = 16, 32) of transcribe() / reconstruct() run on split fp16 operands
+    (csrc/conv_x3.hip, ops.X3_INFER): the outputs must agree with the all-fp32-kernel forward far inside the 1e-4 bar (the oracle
+    comparison of the next test runs WITH the split path, being the default), for mc 2 (both wide levels) and with skip connections.
+    """
+    from timbre_trap.framework import ops
+    g = torch.Generator().manual_seed(5)
+    audio = (torch.rand(2, 1, N, generator=g) * 2 - 1).cuda()
+    for kw in (KW['mc2'], dict(KW['mc2'], skip_connections=True)):
+        sd = oae.closed_form_state_dict(oae.state_dict_shapes(540, **kw), amplitude=0.06)
+        model = _model(kw, sd).eval()
+        calls = []
+        orig = ops.x3_level
+        ops.x3_level = lambda x, blocks: (calls.append(x.shape[1]), orig(x, blocks))[1]
+        try:
+            with torch.no_grad():
+                t3, r3 = model.chunked_inference(audio, True), model.chunked_inference(audio, False)
+                assert sorted(set(calls)) == [16, 32] and len(calls) == 8, calls      # 2 passes x (encoder + decoder) x 2 wide levels
+                ops.X3_INFER = False
+                t32, r32 = model.chunked_inference(audio, True), model.chunked_inference(audio, False)
+                assert len(calls) == 8
+        finally:
+            ops.X3_INFER = True
+            ops.x3_level = orig
+        for a, b in ((t3, t32), (r3, r32)):
+            assert float((a - b).abs().max() / b.abs().max()) < 5e-6
+    # a forward that records a graph keeps the fp32 kernels (their hidden activations feed the fp32 backward)
+    calls = []
+    ops.x3_level = lambda x, blocks: (calls.append(1), orig(x, blocks))[1]
+    try:
+        model.train()
+        model(audio[:1])
+    finally:
+        ops.x3_level = orig
+    assert not calls
+
+
 def test_transcribe_reconstruct_config1_mc2_batch():
     """
     BASELINE configs[1]: model_complexity 2 / latent 128, a BATCH of clips through transcribe() + reconstruct()

@@ -1,0 +1,219 @@
+"""
+GPU parity of the fp32-class residual blocks on split fp16 operands (csrc/conv_x3.hip; reference modules.py:721-777 -- the no-grad
+path of the wide levels in fp32 mode, i.e. what evaluate.py / transcribe() / reconstruct() run without autocast).
+
+Every value is a pair of halves (hi + 2^-11 lo, 22 significant bits) and a product is three fp16 MFMAs with fp32 accumulation, so
+the results must agree with a float64 evaluation of the same block at fp32-arithmetic level: the bar here is 2e-6 of the tensor's
+scale (the fp32 kernels of conv_mfma.hip are held to 2e-5 by tests/test_gpu_conv.py; north_star's bar is 1e-4).  An indexing error of
+any kind (tap, channel permutation, plane, swizzle, halo, tile edge) shows at O(1); a lost cross term at 2^-11 = 5e-4.
+Shapes cover ragged tile edges, both tile geometries (C = 32: 6 x 32, C = 16: 8 x 64), multi-tile persistent loops
+(tt_set_cu_limit), the bench's own plane sizes, values across fp16's subnormal boundary, and non-finite propagation.
+"""
+
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BAR = 2e-6
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def _params(C, seed=0):
+    w1 = _rand(C, C, 3, 3, seed=seed + 2, scale=1.0 / (3 * C ** 0.5))
+    b1 = _rand(C, seed=seed + 3, scale=0.3)
+    w2 = _rand(C, C, 1, 1, seed=seed + 4, scale=1.0 / C ** 0.5)
+    b2 = _rand(C, seed=seed + 5, scale=0.3)
+    return w1, b1, w2, b2
+
+
+def _block64(x, w1, b1, w2, b2, d):
+    x = x.double()
+    h = F.elu(F.conv2d(x, w1.double(), b1.double(), padding=d, dilation=d))
+    return F.elu(F.conv2d(h, w2.double(), b2.double())) + x
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
+
+
+@pytest.fixture
+def cu_limit():
+    from timbre_trap import _hip
+    lib = _hip.lib()
+    prev = lib.tt_set_cu_limit(0)
+    yield lib.tt_set_cu_limit
+    lib.tt_set_cu_limit(prev)
+
+
+def _x3_buf(B, C, H, T):
+    return torch.empty((B, H, T, 2, C), dtype=torch.float16, device='cuda')
+
+
+def _run_block(x, params, d):
+    from timbre_trap._hip import check, lib, ptr, stream_ptr
+    L, st = lib(), stream_ptr()
+    B, C, H, T = x.shape
+    xd = x.cuda().contiguous()
+    pd = [p.cuda().contiguous() for p in params]
+    a, b = _x3_buf(B, C, H, T), _x3_buf(B, C, H, T)
+    assert L.tt_x3_bytes(B, C, H, T) == a.numel() * 2
+    check(L.tt_x3_pack(ptr(xd), ptr(a), B, C, H, T, st), 'tt_x3_pack')
+    check(L.tt_x3_rb_fwd(ptr(a), ptr(pd[0]), ptr(pd[1]), ptr(pd[2]), ptr(pd[3]), ptr(b), 0, B, C, H, T, d, st), 'tt_x3_rb_fwd')
+    y = torch.empty_like(xd)
+    check(L.tt_x3_unpack(ptr(b), ptr(y), B, C, H, T, st), 'tt_x3_unpack')
+    # the same block with the fp32 planar epilogue (the last block of a level): the very same values
+    yp = torch.empty_like(xd)
+    check(L.tt_x3_rb_fwd(ptr(a), ptr(pd[0]), ptr(pd[1]), ptr(pd[2]), ptr(pd[3]), ptr(yp), 1, B, C, H, T, d, st), 'tt_x3_rb_fwd')
+    torch.cuda.synchronize()
+    fin = torch.isfinite(y)
+    assert torch.equal(fin, torch.isfinite(yp))
+    assert bool(((yp - y).abs() <= y.abs() * 2.0 ** -22 + 2.0 ** -35)[fin].all()), 'planar epilogue = x3 epilogue before the split'
+    return yp.cpu(), a, b
+
+
+@pytest.mark.parametrize('C', [16, 32])
+def test_pack_is_a_22_bit_split_and_unpack_its_inverse(C):
+    from timbre_trap._hip import check, lib, ptr, stream_ptr
+    L, st = lib(), stream_ptr()
+    B, H, T = 2, 5, 37
+    x = _rand(B, C, H, T, seed=11)
+    # magnitudes from far below fp16's normal range to near its top
+    x = x * (10.0 ** (_rand(B, C, H, T, seed=12) * 6 - 2))
+    x[0, 0, 0, :8] = torch.tensor([0.0, -0.0, 6.1e-5, -6.0e-5, 1e-7, 3e-8, 60000.0, -2 ** -14])
+    xd = x.cuda()
+    buf = _x3_buf(B, C, H, T)
+    check(L.tt_x3_pack(ptr(xd), ptr(buf), B, C, H, T, st), 'tt_x3_pack')
+    back = torch.empty_like(xd)
+    check(L.tt_x3_unpack(ptr(buf), ptr(back), B, C, H, T, st), 'tt_x3_unpack')
+    torch.cuda.synchronize()
+    hi, lo = buf[..., 0, :].float().cpu(), buf[..., 1, :].float().cpu()            # (B,H,T,C)
+    xp = x.permute(0, 2, 3, 1)
+    # the planes are what the header says: hi = fp16(v) (subnormal halves included), lo = fp16((v - hi) 2^11)
+    want_hi = xp.half().float()
+    assert torch.equal(hi, want_hi)
+    assert torch.equal(lo, ((xp - want_hi) * 2048.0).half().float())
+    err = (back.cpu() - x).abs()
+    assert bool((err <= x.abs() * 2.0 ** -22 + 2.0 ** -35).all()), float((err / (x.abs() + 1e-30)).max())
+
+
+@pytest.mark.parametrize('C', [16, 32])
+@pytest.mark.parametrize('d', [1, 2, 3])
+@pytest.mark.parametrize('shape', [(2, 13, 70), (1, 37, 33), (3, 16, 64)])
+def test_block_matches_float64(C, d, shape):
+    B, H, T = shape
+    x = _rand(B, C, H, T, seed=1)
+    params = _params(C)
+    y, _, _ = _run_block(x, params, d)
+    assert _rel(y, _block64(x, *params, d)) < BAR
+
+
+@pytest.mark.parametrize('C', [16, 32])
+def test_block_agrees_with_the_fp32_kernels(C):
+    """Same block through tt_resblock_fwd (conv_mfma.hip, fp32 matrix instructions): the two product paths differ by fp32 rounding only."""
+    from timbre_trap.framework import ops
+    B, H, T, d = 2, 21, 100, 2
+    x = _rand(B, C, H, T, seed=4)
+    params = _params(C, seed=20)
+    y, _, _ = _run_block(x, params, d)
+    with torch.no_grad():
+        ref = ops.ResBlockFn.apply(x.cuda(), *[p.cuda() for p in params], d).cpu()
+    assert _rel(y, ref) < BAR
+
+
+@pytest.mark.parametrize('C,H,T', [(32, 65, 1024), (16, 133, 1088)])
+def test_block_at_bench_plane_sizes_with_capped_grid(C, H, T, cu_limit):
+    """The bench's planes (multi-tile persistent loops: 3 CUs' worth of workgroups walk hundreds of tiles)."""
+    x = _rand(1, C, H, T, seed=7)
+    params = _params(C, seed=30)
+    want = _block64(x, *params, 3)
+    y_full, _, _ = _run_block(x, params, 3)
+    assert _rel(y_full, want) < BAR
+    cu_limit(3)
+    y_cap, _, _ = _run_block(x, params, 3)
+    assert torch.equal(y_cap, y_full), 'the result must not depend on the number of workgroups'
+
+
+@pytest.mark.parametrize('C', [16, 32])
+def test_small_and_large_magnitudes(C):
+    """Activations spanning 1e-6 .. 1e3 (fp16 alone would flush / lose them): relative to the output's scale the bar holds."""
+    B, H, T, d = 1, 9, 50, 1
+    x = _rand(B, C, H, T, seed=8) * (10.0 ** (_rand(B, C, H, T, seed=9) * 4.5 - 1.5))
+    params = _params(C, seed=40)
+    y, _, _ = _run_block(x, params, d)
+    want = _block64(x, *params, d)
+    assert _rel(y, want) < BAR
+    # and for a uniformly tiny input the output is bias-dominated, the input's contribution must still be exact to fp32 level
+    xs = _rand(B, C, H, T, seed=10) * 1e-5
+    ys, _, _ = _run_block(xs, params, d)
+    zero, _, _ = _run_block(torch.zeros_like(xs), params, d)
+    contrib = (ys - zero).double()
+    want_c = _block64(xs, *params, d) - _block64(torch.zeros_like(xs), *params, d)
+    assert float((contrib - want_c).abs().max()) < 1e-7 * float(want.abs().max())
+
+
+@pytest.mark.parametrize('C', [16, 32])
+def test_level_entry_is_three_blocks(C):
+    from timbre_trap._hip import check, lib, ptr, stream_ptr
+    L, st = lib(), stream_ptr()
+    B, H, T = 2, 19, 90
+    x = _rand(B, C, H, T, seed=2)
+    blocks = [_params(C, seed=50 + 10 * i) for i in range(3)]
+    dil = (1, 2, 3)
+    want = x
+    for p, d in zip(blocks, dil):
+        want = _block64(want, *p, d)
+    xd = x.cuda()
+    dev = [[t.cuda().contiguous() for t in p] for p in blocks]
+    arr = lambda j: (ctypes.c_void_p * 3)(*[dev[i][j].data_ptr() for i in range(3)])
+    ws = torch.empty(L.tt_x3_level_scratch_bytes(B, C, H, T), dtype=torch.uint8, device='cuda')
+    y = torch.empty_like(xd)
+    check(L.tt_x3_level_fwd(3, ptr(xd), ptr(y), arr(0), arr(1), arr(2), arr(3), (ctypes.c_int * 3)(*dil), ptr(ws), B, C, H, T, st),
+          'tt_x3_level_fwd')
+    torch.cuda.synchronize()
+    assert _rel(y.cpu(), want) < 2 * BAR
+    # the Python dispatch: ops.residual_level without grad in fp32 mode takes this path and returns the same tensor
+    from timbre_trap.framework import modules, ops
+    mods = [modules.ResidualConv2dBlock(C, C, 3, d) for d in dil]
+    for m, p in zip(mods, blocks):
+        m.conv1[0].weight.data, m.conv1[0].bias.data = p[0].clone(), p[1].clone()
+        m.conv2[0].weight.data, m.conv2[0].bias.data = p[2].clone(), p[3].clone()
+        m.cuda()
+    with torch.no_grad():
+        assert ops.x3_inference()
+        y_ops = ops.residual_level(xd, mods)
+    assert torch.equal(y_ops, y)
+    y_grad = ops.residual_level(xd.clone().requires_grad_(True), mods)            # with grad: the fp32 kernels (hidden activations saved)
+    assert y_grad.requires_grad and _rel(y_grad.detach().cpu(), want) < 1e-5
+
+
+def test_non_finite_values_surface():
+    C, B, H, T, d = 32, 1, 8, 40, 1
+    x = _rand(B, C, H, T, seed=3)
+    params = list(_params(C, seed=60))
+    bad = [p.clone() for p in params]
+    bad[0][3, 5, 1, 1] = float('nan')
+    y, _, _ = _run_block(x, bad, d)
+    assert bool(torch.isnan(y).any())
+    big = x.clone()
+    big[0, 2, 3, 7] = 1e5                                                         # beyond fp16: must not come out as a finite wrong number
+    y, _, _ = _run_block(big, params, d)
+    assert not bool(torch.isfinite(y[0, 2, 3, 7]))
+
+
+def test_argument_errors():
+    from timbre_trap._hip import lib, ptr, stream_ptr
+    L, st = lib(), stream_ptr()
+    t = torch.zeros(1, device='cuda')
+    assert L.tt_x3_bytes(1, 8, 4, 4) < 0
+    assert L.tt_x3_pack(ptr(t), ptr(t), 1, 8, 4, 4, st) < 0                       # C = 8 has no x3 kernel
+    assert L.tt_x3_rb_fwd(ptr(t), ptr(t), ptr(t), ptr(t), ptr(t), ptr(t), 0, 1, 16, 4, 4, 1, st) < 0     # in place
+    u = torch.zeros(1, device='cuda')
+    assert L.tt_x3_rb_fwd(ptr(t), ptr(t), ptr(t), ptr(t), ptr(t), ptr(u), 0, 1, 16, 4, 4, 4, st) < 0     # dilation 4

@@ -1,0 +1,395 @@
+// fp32-CLASS residual blocks of the wide levels (C = 16, 32; reference modules.py:721-777) on the 16-bit matrix pipe, for gfx950:
+// the inference path that carries the 1e-4 output bar of BASELINE's north_star at more than the fp32 matrix rate.
+//
+// The fp32 kernels of conv_mfma.hip are bound by v_mfma_f32_16x16x4_f32 (a sixteenth of the 16-bit rate); the 16-bit kernels of
+// conv_wide_bf16.hip keep 8 / 11 significant bits per stored activation.  Here every fp32 value v -- activations in HBM and weights in
+// LDS -- is held as a PAIR of IEEE halves
+//       hi = fp16(v),      lo = fp16((v - hi) * 2^11)                       v = hi + lo * 2^-11  to 2^-23 relative
+// (below |v| = 2^-14 hi is a subnormal half -- v_mfma_f32_*_f16 takes subnormal inputs at full value on gfx950,
+// tools/diag/mfma_denorm.hip -- and the pair is exact to 2^-36 absolute; |v| > 65504 does not fit: hi = inf and the result is
+// non-finite, never silently wrong), and a product is three
+// v_mfma_f32_16x16x32_f16 with fp32 accumulation:
+//       W x  =  Whi xhi  +  2^-11 (Whi xlo + Wlo xhi)          (the dropped Wlo xlo term is 2^-22 relative)
+// with the cross terms in their own accumulators.  Bias, ELU and the residual add are fp32, exactly like conv_mfma.hip.
+//
+// Layout "x3" of an activation tensor: [B][H][T][2][C] halves -- the hi and lo planes of one pixel are adjacent, 4 C bytes per pixel
+// (as many bytes as fp32), so that a tile row with its halo is one contiguous run and goes to LDS by LDS-DMA like in the 16-bit
+// kernels, and the K = channels slice of either plane is one 16-byte LDS read in B-operand order: no conversion on the read side.
+// The split is done ONCE per element, by the producer's epilogue.
+//
+// Kernels: k_x3_pack / k_x3_unpack (fp32 planar <-> x3 at the two ends of a level), k_x3_conv<C, D> (one residual block:
+// y = ELU(W2 . ELU(W1 (*)_D x + b1) + b2) + x; persistent, XCD-ordered tile walk; weights of both planes in LDS in operand order,
+// written by every workgroup for itself).  Forward only: training saves fp32 activations for the fp32 backward.
+#define TT_F16 1
+#include "wide_common.h"
+
+namespace {
+
+constexpr float LO_SCALE = 2048.f, LO_INV = 1.f / 2048.f;
+
+__device__ __forceinline__ void split(float v, e16& hi, e16& lo) {
+    hi = (e16)v;
+    lo = (e16)__builtin_fmaf((float)hi, -LO_SCALE, v * LO_SCALE);      // = (v - hi) 2^11 exactly (every step is exact), one fma_mix
+}
+__device__ __forceinline__ float join(e16 hi, e16 lo) { return __builtin_fmaf((float)lo, LO_INV, (float)hi); }
+
+template <int C> struct XL {
+    static constexpr int PB = 4 * C;                             // bytes per pixel: [hi C][lo C]
+    static constexpr int PP = PB / 16;                           // 16-byte pieces per pixel (C = 32: 8, C = 16: 4)
+    static constexpr int CG = C / 8;                             // pieces per plane
+    static constexpr int CPR = 256 / PB;                         // pixels per 256 bytes (all 64 banks)
+};
+// The piece `q` of the pixel in image column `col` sits at position q ^ xswz(col): the sixteen consecutive columns a k-group reads
+// as B operand then cover all sixteen bank quads (same rule as cswz of conv_wide_bf16.hip at twice the pixel size).
+template <int C> __device__ __forceinline__ int xswz(int col) { return (col / XL<C>::CPR) & (XL<C>::PP - 1); }
+
+// ---- layout change at the ends of a level: one thread per eight channels of one pixel ----------------------------------------
+template <int C>
+__global__ __launch_bounds__(NT) void k_x3_pack(const float* __restrict__ x, e16* __restrict__ out, int H, int T, long npix) {
+    constexpr int CG = C / 8;
+    const long i = (long)blockIdx.x * NT + threadIdx.x;
+    const long pix = i / CG;
+    if (pix >= npix) return;
+    const int cg = (int)(i % CG);
+    const long plane = (long)H * T;
+    const long b = pix / plane, o = pix - b * plane;
+    const float* s = x + (b * C + cg * 8) * plane + o;
+    e16x8 qh, ql;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { e16 h, l; split(s[j * plane], h, l); qh[j] = h; ql[j] = l; }
+    *reinterpret_cast<e16x8*>(out + pix * 2 * C + cg * 8) = qh;
+    *reinterpret_cast<e16x8*>(out + pix * 2 * C + C + cg * 8) = ql;
+}
+template <int C>
+__global__ __launch_bounds__(NT) void k_x3_unpack(const e16* __restrict__ in, float* __restrict__ y, int H, int T, long npix) {
+    constexpr int CG = C / 8;
+    const long i = (long)blockIdx.x * NT + threadIdx.x;
+    const long pix = i / CG;
+    if (pix >= npix) return;
+    const int cg = (int)(i % CG);
+    const long plane = (long)H * T;
+    const long b = pix / plane, o = pix - b * plane;
+    const e16x8 qh = *reinterpret_cast<const e16x8*>(in + pix * 2 * C + cg * 8);
+    const e16x8 ql = *reinterpret_cast<const e16x8*>(in + pix * 2 * C + C + cg * 8);
+    float* d = y + (b * C + cg * 8) * plane + o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d[j * plane] = join(qh[j], ql[j]);
+}
+
+// ---- one residual block ---------------------------------------------------------------------------------------------------------
+// A wave owns a 16-pixel column group of the tile and walks R rows of it at a time, so that the weight operands of a tap that live
+// in LDS are read once per R rows.  Measured first (bench plane, profiles/r04_x3_ablation.txt): staging and products + epilogue of
+// one workgroup do not overlap (0.13 + 0.30 ms at C = 32 on 16 x 32 tiles with one workgroup per CU), and the products' side is
+// issue-bound (60 matrix + ~250 vector instructions per 16-pixel row) -- so the shapes are chosen for overlap and occupancy:
+//   C = 32: TWO workgroups of four waves per CU on 6 x 32 tiles (R = 3: with R = 4 the registers spill): 36-61 KB of tile + 18 KB for the lo planes of W1
+//           in LDS; the hi planes of W1 and both planes of W2 sit in registers (88 of the 256 a lane has at two waves per SIMD);
+//   C = 16: two workgroups of EIGHT waves per CU on 8 x 64 tiles (64 KB + 11 KB of weights, both planes in LDS): four waves per
+//           SIMD at <= 128 registers.
+template <int C, int D> struct XT {
+    using L = XL<C>;
+    static constexpr bool WREG = C == 32;
+    static constexpr int TW = C == 32 ? 32 : 64;
+    static constexpr int TH = C == 32 ? 6 : 8;
+    static constexpr int NTH = C == 32 ? 256 : 512;
+    static constexpr int MINW = C == 32 ? 2 : 4;
+    static constexpr int NCG = TW / 16, NRG = (NTH / 64) / NCG;  // column groups x row groups of waves
+    static constexpr int R = TH / NRG;
+    static constexpr int RW = TW + 2 * D, ROWS = TH + 2 * D;
+    static constexpr int NP = ROWS * RW * L::PP;                 // 16-byte pieces of the tile with its halo
+    static constexpr int NPR = (NP + NTH - 1) / NTH * NTH;       // whole DMA instructions for every wave
+    static constexpr int TILE_BYTES = NPR * 16;
+    static constexpr int NCT = C / 16;
+    static constexpr int NK = C == 32 ? 9 : 5;                   // products per co-tile: one tap (C = 32) / two taps (C = 16)
+    static constexpr int NPL = WREG ? 1 : 2;                     // planes of W1 kept in LDS (lo only / hi and lo)
+    static constexpr int W1_BYTES = NK * NCT * NPL * 64 * 16;    // [k][ct][plane][lane] x 16 bytes
+    static constexpr int W2_BYTES = WREG ? 0 : 2 * 64 * 8;       // C = 16: [plane][lane] x 8 bytes
+    static constexpr int LDS_BYTES = TILE_BYTES + W1_BYTES + W2_BYTES;
+    static_assert(R * NRG == TH, "rows per wave");
+};
+
+// PLANAR: the output goes out as fp32 (B,C,H,T) instead of x3 -- the last block of a level (saves the unpack pass).
+template <int C, int D, bool PLANAR>
+__global__ __launch_bounds__((XT<C, D>::NTH), (XT<C, D>::MINW)) void k_x3_conv(const e16* __restrict__ x, const float* __restrict__ w1,
+                                                                               const float* __restrict__ b1, const float* __restrict__ w2,
+                                                                               const float* __restrict__ b2, void* __restrict__ yout,
+                                                                               int B, int H, int T, int tiles_h, int tiles_t, int ntiles) {
+    using G = XT<C, D>;
+    using L = XL<C>;
+    constexpr int NTH = G::NTH, NCT = G::NCT, NK = G::NK, R = G::R, PB = L::PB, CG = L::CG, NPL = G::NPL;
+    constexpr bool WREG = G::WREG;
+    constexpr int NCH = C == 32 ? 8 : 4;                         // channels a lane ends up with
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char* w1img = smem + G::TILE_BYTES;
+    unsigned char* w2img = w1img + G::W1_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+
+    // ---- weights in operand order, split into the two planes: to LDS, and (WREG) the hi planes to registers ----
+    for (int e = tid; e < NK * NCT * 64; e += NTH) {
+        const int l = e & 63, ct = (e >> 6) % NCT, k = e / (64 * NCT);
+        const int ln = l & 15, lg = l >> 4;
+        e16x8 qh, ql;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int tap, kc;                                         // tap and contraction channel of this lane's k = 8 g + j
+            if (C == 32) { tap = k; kc = 8 * lg + j; }
+            else { tap = 2 * k + (lg >> 1); kc = 8 * (lg & 1) + j; }
+            const int mo = chan_of<C>(ct, ln);                   // output channel of row n
+            const float wv = tap < 9 ? w1[(mo * C + kc) * 9 + tap] : 0.f;
+            e16 h, lo_; split(wv, h, lo_); qh[j] = h; ql[j] = lo_;
+        }
+        if constexpr (!WREG) *reinterpret_cast<e16x8*>(w1img + ((long)((k * NCT + ct) * NPL + 0) * 64 + l) * 16) = qh;
+        *reinterpret_cast<e16x8*>(w1img + ((long)((k * NCT + ct) * NPL + NPL - 1) * 64 + l) * 16) = ql;
+    }
+    e16x8 WH[WREG ? NK : 1][NCT], A2H[NCT], A2L[NCT];           // WREG: hi planes of W1, both planes of W2
+    if constexpr (WREG) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) WH[k][ct][j] = (e16)w1[(chan_of<C>(ct, n) * C + 8 * g + j) * 9 + k];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                e16 h, lo_; split(w2[chan_of<C>(ct, n) * C + 8 * g + j], h, lo_); A2H[ct][j] = h; A2L[ct][j] = lo_;
+            }
+    } else {
+        for (int e = tid; e < 64; e += NTH) {
+            e16x4 qh, ql;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { e16 h, lo_; split(w2[(e & 15) * C + 4 * (e >> 4) + j], h, lo_); qh[j] = h; ql[j] = lo_; }
+            *reinterpret_cast<e16x4*>(w2img + (long)e * 8) = qh;
+            *reinterpret_cast<e16x4*>(w2img + (long)(64 + e) * 8) = ql;
+        }
+    }
+    float b1r[NCH], b2r[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) { b1r[j] = b1[NCH * g + j]; b2r[j] = b2[NCH * g + j]; }
+
+    const int c0 = (wave % G::NCG) * 16, r0 = (wave / G::NCG) * R;
+    const e16* zero = reinterpret_cast<const e16*>(&g_wzero16);
+
+    for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
+        int tile = xcd_order(v, ntiles);
+        const int tt = tile % tiles_t; tile /= tiles_t;
+        const int th = tile % tiles_h;
+        const int b = tile / tiles_h, h0 = th * G::TH, t0 = tt * G::TW;
+        const unsigned char* xb = reinterpret_cast<const unsigned char*>(x) + (long)b * H * T * PB;
+
+        __syncthreads();                                         // the previous tile has been consumed (first pass: weights written)
+#ifdef X3_NOSTAGE
+        if (v == (int)blockIdx.x)
+#endif
+        for (int i = wave * 64; i < G::NPR; i += NTH) {
+            const int p = i + lane;
+            const int row = p / (G::RW * L::PP), rem = p - row * (G::RW * L::PP);
+            const int px = rem / L::PP, q = (rem - px * L::PP) ^ xswz<C>(px);       // 16-byte position -> piece held there
+            const int h = h0 - D + row, t = t0 - D + px;
+            const bool ok = p < G::NP && (unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T;
+            glds16(ok ? (const void*)(xb + ((long)h * T + t) * PB + q * 16) : (const void*)zero, smem + (long)i * 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        const int t = t0 + c0 + n;
+        const bool valid = t < T;
+#ifdef X3_NOCOMPUTE
+        if (v != (int)blockIdx.x) continue;
+#endif
+        if (h0 + r0 >= H) continue;
+        f32x4 am[R][NCT], al[R][NCT];                            // hi x hi (bias as initial value) and the two cross terms
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                am[rr][ct] = f32x4{b1r[4 * ct], b1r[4 * ct + 1], b1r[4 * ct + 2], b1r[4 * ct + 3]};
+                al[rr][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            int tap = C == 32 ? k : 2 * k + (g >> 1);
+            if (tap > 8) tap = 8;                                // the weights of the missing tenth tap are zero
+            const int kh = tap / 3, kw = tap - 3 * kh;
+            const int col = c0 + n + kw * D;
+            const int gsel = C == 32 ? g : (g & 1), sw = xswz<C>(col);
+            e16x8 wh[NCT], wl[NCT], bh[R], bl[R];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                if constexpr (WREG) wh[ct] = WH[k][ct];
+                else wh[ct] = *reinterpret_cast<const e16x8*>(w1img + ((long)((k * NCT + ct) * NPL + 0) * 64 + lane) * 16);
+                wl[ct] = *reinterpret_cast<const e16x8*>(w1img + ((long)((k * NCT + ct) * NPL + NPL - 1) * 64 + lane) * 16);
+            }
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+                const unsigned char* pxp = smem + ((long)(r0 + rr + kh * D) * G::RW + col) * PB;
+                bh[rr] = *reinterpret_cast<const e16x8*>(pxp + 16 * (gsel ^ sw));
+                bl[rr] = *reinterpret_cast<const e16x8*>(pxp + 16 * ((CG + gsel) ^ sw));
+            }
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    am[rr][ct] = mma32(wh[ct], bh[rr], am[rr][ct]);
+                    al[rr][ct] = mma32(wh[ct], bl[rr], al[rr][ct]);
+                }
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) al[rr][ct] = mma32(wl[ct], bh[rr], al[rr][ct]);
+        }
+        // ---- ELU, 1x1 product, ELU, residual add, split, store ----
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            const int h = h0 + r0 + rr;
+            if (h >= H) break;
+            const long pix = ((long)b * H + h) * T + t;
+            const int colc = c0 + n + D, swc = xswz<C>(colc);
+            const unsigned char* pxc = smem + ((long)(r0 + rr + D) * G::RW + colc) * PB;
+            float out[NCH];
+            if constexpr (C == 32) {
+                e16x8 hh, hl;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    e16 a_, b_;
+                    split(elu1(__builtin_fmaf(al[rr][0][j], LO_INV, am[rr][0][j])), a_, b_); hh[j] = a_; hl[j] = b_;
+                    split(elu1(__builtin_fmaf(al[rr][1][j], LO_INV, am[rr][1][j])), a_, b_); hh[4 + j] = a_; hl[4 + j] = b_;
+                }
+                f32x4 zm[2], zl[2];
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    zm[ct] = mma32(A2H[ct], hh, f32x4{b2r[4 * ct], b2r[4 * ct + 1], b2r[4 * ct + 2], b2r[4 * ct + 3]});
+                    zl[ct] = mma32(A2H[ct], hl, f32x4{0.f, 0.f, 0.f, 0.f});
+                }
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) zl[ct] = mma32(A2L[ct], hh, zl[ct]);
+                const e16x8 ch = *reinterpret_cast<const e16x8*>(pxc + 16 * (g ^ swc));
+                const e16x8 cl = *reinterpret_cast<const e16x8*>(pxc + 16 * ((CG + g) ^ swc));
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    out[j] = elu1(__builtin_fmaf(zl[j >> 2][j & 3], LO_INV, zm[j >> 2][j & 3])) + join(ch[j], cl[j]);
+            } else {
+                e16x4 hh, hl;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    e16 a_, b_;
+                    split(elu1(__builtin_fmaf(al[rr][0][j], LO_INV, am[rr][0][j])), a_, b_); hh[j] = a_; hl[j] = b_;
+                }
+                const s16x4 a2h = *reinterpret_cast<const s16x4*>(w2img + (long)lane * 8);
+                const s16x4 a2l = *reinterpret_cast<const s16x4*>(w2img + (long)(64 + lane) * 8);
+                const f32x4 zm = mma16(a2h, __builtin_bit_cast(s16x4, hh), f32x4{b2r[0], b2r[1], b2r[2], b2r[3]});
+                f32x4 zl = mma16(a2h, __builtin_bit_cast(s16x4, hl), f32x4{0.f, 0.f, 0.f, 0.f});
+                zl = mma16(a2l, __builtin_bit_cast(s16x4, hh), zl);
+                const e16x4 ch = *reinterpret_cast<const e16x4*>(pxc + 16 * ((g >> 1) ^ swc) + 8 * (g & 1));
+                const e16x4 cl = *reinterpret_cast<const e16x4*>(pxc + 16 * ((CG + (g >> 1)) ^ swc) + 8 * (g & 1));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) out[j] = elu1(__builtin_fmaf(zl[j], LO_INV, zm[j])) + join(ch[j], cl[j]);
+            }
+            if (!valid) continue;
+            if constexpr (PLANAR) {
+                float* yp = static_cast<float*>(yout) + (((long)b * C + NCH * g) * H + h) * T + t;
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) yp[(long)j * H * T] = out[j];
+            } else {
+                e16* y = static_cast<e16*>(yout);
+                typename std::conditional<C == 32, e16x8, e16x4>::type oh, ol;
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) { e16 a_, b_; split(out[j], a_, b_); oh[j] = a_; ol[j] = b_; }
+                *reinterpret_cast<decltype(oh)*>(y + pix * 2 * C + NCH * g) = oh;
+                *reinterpret_cast<decltype(ol)*>(y + pix * 2 * C + C + NCH * g) = ol;
+            }
+        }
+    }
+}
+
+template <int C, int D, bool PLANAR>
+int launch_x3(const e16* x, const float* w1, const float* b1, const float* w2, const float* b2, void* y, int B, int H, int T,
+              hipStream_t st) {
+    using G = XT<C, D>;
+    const int tiles_h = (H + G::TH - 1) / G::TH, tiles_t = (T + G::TW - 1) / G::TW, ntiles = B * tiles_h * tiles_t;
+    static AttrOnce once;
+    auto kern = k_x3_conv<C, D, PLANAR>;
+    if (int rc = raise_lds(kern, G::LDS_BYTES, once)) return rc;
+    hipLaunchKernelGGL(kern, dim3(grid_for(ntiles, G::LDS_BYTES, 2)), dim3(G::NTH), G::LDS_BYTES, st, x, w1, b1, w2, b2, y, B, H, T,
+                       tiles_h, tiles_t, ntiles);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+template <int C, bool PLANAR>
+int x3_d(const e16* x, const float* w1, const float* b1, const float* w2, const float* b2, void* y, int B, int H, int T, int d,
+         hipStream_t st) {
+    switch (d) {
+        case 1: return launch_x3<C, 1, PLANAR>(x, w1, b1, w2, b2, y, B, H, T, st);
+        case 2: return launch_x3<C, 2, PLANAR>(x, w1, b1, w2, b2, y, B, H, T, st);
+        case 3: return launch_x3<C, 3, PLANAR>(x, w1, b1, w2, b2, y, B, H, T, st);
+    }
+    return TT_E_UNSUPPORTED;
+}
+int x3_block(const e16* x, const float* w1, const float* b1, const float* w2, const float* b2, void* y, bool planar, int B, int C,
+             int H, int T, int d, hipStream_t st) {
+    if (C == 16) return planar ? x3_d<16, true>(x, w1, b1, w2, b2, y, B, H, T, d, st) : x3_d<16, false>(x, w1, b1, w2, b2, y, B, H, T, d, st);
+    return planar ? x3_d<32, true>(x, w1, b1, w2, b2, y, B, H, T, d, st) : x3_d<32, false>(x, w1, b1, w2, b2, y, B, H, T, d, st);
+}
+bool x3_shape_ok(int B, int C, int H, int T) { return B > 0 && H > 0 && T > 0 && (C == 16 || C == 32); }
+
+}  // namespace
+
+extern "C" {
+
+int64_t tt_x3_bytes(int B, int C, int H, int T) {
+    if (!x3_shape_ok(B, C, H, T)) return -1;
+    return (int64_t)B * H * T * C * 4;
+}
+
+int tt_x3_pack(const float* x, void* out, int B, int C, int H, int T, void* stream) {
+    if (!x || !out || !x3_shape_ok(B, C, H, T)) return TT_E_BADARG;
+    const long npix = (long)B * H * T, pieces = npix * C / 8;
+    const unsigned grid = (unsigned)((pieces + NT - 1) / NT);
+    hipStream_t st = tt_stream(stream);
+    if (C == 16) hipLaunchKernelGGL(k_x3_pack<16>, dim3(grid), dim3(NT), 0, st, x, (e16*)out, H, T, npix);
+    else hipLaunchKernelGGL(k_x3_pack<32>, dim3(grid), dim3(NT), 0, st, x, (e16*)out, H, T, npix);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
+int tt_x3_unpack(const void* in, float* y, int B, int C, int H, int T, void* stream) {
+    if (!in || !y || !x3_shape_ok(B, C, H, T)) return TT_E_BADARG;
+    const long npix = (long)B * H * T, pieces = npix * C / 8;
+    const unsigned grid = (unsigned)((pieces + NT - 1) / NT);
+    hipStream_t st = tt_stream(stream);
+    if (C == 16) hipLaunchKernelGGL(k_x3_unpack<16>, dim3(grid), dim3(NT), 0, st, (const e16*)in, y, H, T, npix);
+    else hipLaunchKernelGGL(k_x3_unpack<32>, dim3(grid), dim3(NT), 0, st, (const e16*)in, y, H, T, npix);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
+int tt_x3_rb_fwd(const void* x, const float* w1, const float* b1, const float* w2, const float* b2, void* y, int planar_out, int B,
+                 int C, int H, int T, int dilation, void* stream) {
+    if (!x || !w1 || !b1 || !w2 || !b2 || !y || x == y || !x3_shape_ok(B, C, H, T)) return TT_E_BADARG;
+    return x3_block((const e16*)x, w1, b1, w2, b2, y, planar_out != 0, B, C, H, T, dilation, tt_stream(stream));
+}
+
+int tt_x3_level_fwd(int nblocks, const float* x, float* y, const float* const* w1, const float* const* b1, const float* const* w2,
+                    const float* const* b2, const int* dilations, void* ws, int B, int C, int H, int T, void* stream) {
+    if (nblocks < 1 || !x || !y || !w1 || !b1 || !w2 || !b2 || !dilations || !ws || !x3_shape_ok(B, C, H, T)) return TT_E_BADARG;
+    for (int i = 0; i < nblocks; ++i)
+        if (!w1[i] || !b1[i] || !w2[i] || !b2[i] || dilations[i] < 1 || dilations[i] > 3) return TT_E_BADARG;
+    const int64_t bytes = tt_x3_bytes(B, C, H, T);
+    unsigned char* buf[2] = {static_cast<unsigned char*>(ws), static_cast<unsigned char*>(ws) + ((bytes + 255) / 256) * 256};
+    if (int rc = tt_x3_pack(x, buf[0], B, C, H, T, stream)) return rc;
+    for (int i = 0; i < nblocks; ++i) {                          // the last block writes fp32 planar straight into y
+        const bool last = i == nblocks - 1;
+        if (int rc = tt_x3_rb_fwd(buf[i & 1], w1[i], b1[i], w2[i], b2[i], last ? (void*)y : (void*)buf[(i + 1) & 1], last, B, C, H, T,
+                                  dilations[i], stream))
+            return rc;
+    }
+    return 0;
+}
+
+int64_t tt_x3_level_scratch_bytes(int B, int C, int H, int T) {
+    const int64_t bytes = tt_x3_bytes(B, C, H, T);
+    return bytes < 0 ? -1 : 2 * (((bytes + 255) / 256) * 256);
+}
+
+}  // extern "C"

@@ -23,7 +23,9 @@ if os.environ.get('TTRAP_LIB'):                         # tuning: an alternative
 SOURCES = ['cqt.hip', 'conv_generic.hip', 'conv_mfma.hip', 'conv_small.hip', 'conv_wide_bf16.hip', 'conv_level_bf16.hip', 'conv_stride_bf16.hip',
            'latent_bf16.hip', 'conv_edge_bf16.hip', 'gemm.hip', 'losses.hip',
            # the 16-bit channels-last sources a second time with fp16 elements (two-line wrappers: #define TT_F16 + #include)
-           'conv_wide_f16.hip', 'conv_level_f16.hip', 'conv_stride_f16.hip', 'latent_f16.hip', 'conv_edge_f16.hip']
+           'conv_wide_f16.hip', 'conv_level_f16.hip', 'conv_stride_f16.hip', 'latent_f16.hip', 'conv_edge_f16.hip',
+           # fp32-class inference blocks on split fp16 operands
+           'conv_x3.hip']
 
 _lib = None
 
@@ -59,6 +61,12 @@ _PROTOS = {
     'tt_wide_rb_bwd': (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
     'tt_wide_level_scratch_bytes': (c_int64, [I, I, I, I, I]),
     'tt_wide_level_bwd': (c_int, [I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P]),
+    'tt_x3_bytes': (c_int64, [I, I, I, I]),
+    'tt_x3_level_scratch_bytes': (c_int64, [I, I, I, I]),
+    'tt_x3_pack': (c_int, [P, P, I, I, I, I, P]),
+    'tt_x3_unpack': (c_int, [P, P, I, I, I, I, P]),
+    'tt_x3_rb_fwd': (c_int, [P, P, P, P, P, P, I, I, I, I, I, I, P]),
+    'tt_x3_level_fwd': (c_int, [I, P, P, P, P, P, P, P, P, I, I, I, I, P]),
     'tt_wide_fused_scratch_bytes': (c_int64, [I]),
     'tt_wide_rb_bwd_fused': (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
     'tt_wide_onepass_scratch_bytes': (c_int64, [I]),

@@ -866,9 +866,43 @@ def residual_level(x, blocks):
             params += [b.conv1[0].weight, b.conv1[0].bias, b.conv2[0].weight, b.conv2[0].bias]
         return Level16Fn.apply(to_cl16(x), tuple(b.dilation for b in blocks), *params)
     x = to_planar32(x)
+    if (x3_inference() and C in X3_CHANNELS and FUSED_RESBLOCK and x.is_cuda and 1 <= len(blocks) <= 8
+            and all(b.conv1[0].weight.shape == (C, C, 3, 3) and b.conv2[0].weight.shape == (C, C, 1, 1) and 1 <= b.dilation <= 3
+                    for b in blocks)):
+        return x3_level(x, blocks)
     for b in blocks:
         x = b(x)
     return x
+
+
+# ---- fp32-class inference on split fp16 operands ("x3", csrc/conv_x3.hip) -------------------------------------------------------
+# Without autocast and without grad (evaluate.py:94-95, transcribe() / reconstruct()) the wide levels do not need the hidden
+# activations the fp32 backward reads, and the fp32 matrix instructions are what bounds tt_resblock_fwd: the level then runs on
+# (hi, lo) fp16 pairs -- fp32-level results (tests/test_gpu_x3.py: 2e-6 of the tensor's scale against float64) at the 16-bit matrix
+# rate.  TTRAP_X3_INFER=0 / ops.X3_INFER = False keeps the fp32 kernels.
+X3_INFER = os.environ.get('TTRAP_X3_INFER', '1') != '0'
+X3_CHANNELS = (16, 32)
+
+
+def x3_inference():
+    return X3_INFER and not torch.is_grad_enabled() and precision() == 'fp32' and wide_storage() == 'fp32'
+
+
+def x3_level(x, blocks):
+    """block_n(...block1(x)) for fp32 planar x (B,C,H,T), C in X3_CHANNELS, no autograd graph: tt_x3_level_fwd."""
+    x = _f32c(x)
+    B, C, H, T = x.shape
+    lib, st = _hip.lib(), stream_ptr()
+    n = len(blocks)
+    params = [[_f32c(t.detach()) for t in (b.conv1[0].weight, b.conv1[0].bias, b.conv2[0].weight, b.conv2[0].bias)] for b in blocks]
+    _hip.require_cuda(x, params[0][0])
+    arr = lambda j: (ctypes.c_void_p * n)(*[p[j].data_ptr() for p in params])
+    ws = torch.empty(lib.tt_x3_level_scratch_bytes(B, C, H, T), dtype=torch.uint8, device=x.device)
+    y = torch.empty_like(x)
+    with _hip.timed('x3_level_fwd_C%d' % C):
+        check(lib.tt_x3_level_fwd(n, ptr(x), ptr(y), arr(0), arr(1), arr(2), arr(3), (ctypes.c_int * n)(*[b.dilation for b in blocks]),
+                                  ptr(ws), B, C, H, T, st), 'tt_x3_level_fwd')
+    return y
 
 
 class LatentEncodeFn(torch.autograd.Function):

@@ -1,0 +1,60 @@
+"""Kernel-level timing of the split-operand (x3) residual blocks next to the fp32 and bf16 kernels (bench shape, 64 clips).
+   KB_C=16,32 KB_D=1,2,3 KB_N=20 python tools/kb_x3.py"""
+import os
+import sys
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'timbre-trap_amd'))
+from timbre_trap import _hip
+from timbre_trap._hip import check, ptr, stream_ptr
+from timbre_trap.framework import ops
+
+SHAPES = {32: (64, 65, 1024), 16: (64, 133, 1024)}
+
+
+def timeit(fn, n):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def main():
+    lib, st = _hip.lib(), stream_ptr()
+    n = int(os.environ.get('KB_N', 20))
+    for C in [int(c) for c in os.environ.get('KB_C', '16,32').split(',')]:
+        B, H, T = SHAPES[C]
+        B = int(os.environ.get('KB_B', B))
+        x = torch.randn(B, C, H, T, device='cuda')
+        w1 = torch.randn(C, C, 3, 3, device='cuda') / (3 * C ** 0.5)
+        b1 = torch.randn(C, device='cuda') * 0.1
+        w2 = torch.randn(C, C, 1, 1, device='cuda') / C ** 0.5
+        b2 = torch.randn(C, device='cuda') * 0.1
+        a = torch.empty((B, H, T, 2, C), dtype=torch.float16, device='cuda')
+        b = torch.empty_like(a)
+        y = torch.empty_like(x)
+        gb = x.numel() * 4 / 1e9
+        ms = timeit(lambda: check(lib.tt_x3_pack(ptr(x), ptr(a), B, C, H, T, st), 'pack'), n)
+        print('C%d pack    %.3f ms  %.2f TB/s (read + write)' % (C, ms, 2 * gb / ms))
+        ms = timeit(lambda: check(lib.tt_x3_unpack(ptr(a), ptr(y), B, C, H, T, st), 'unpack'), n)
+        print('C%d unpack  %.3f ms  %.2f TB/s (read + write)' % (C, ms, 2 * gb / ms))
+        for d in [int(v) for v in os.environ.get('KB_D', '1,2,3').split(',')]:
+            ms = timeit(lambda: check(lib.tt_x3_rb_fwd(ptr(a), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(b), 0, B, C, H, T, d, st), 'x3'), n)
+            msp = timeit(lambda: check(lib.tt_x3_rb_fwd(ptr(a), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(y), 1, B, C, H, T, d, st), 'x3'), n)
+            with torch.no_grad():
+                ops.X3_INFER = False
+                ms32 = timeit(lambda: ops.ResBlockFn.apply(x, w1, b1, w2, b2, d), n)
+            xb = torch.empty((B, H, T, C), dtype=torch.bfloat16, device='cuda')
+            yb = torch.empty_like(xb)
+            ms16 = timeit(lambda: check(lib.tt_wide_rb_fwd(ptr(xb), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(yb), None, B, C, H, T, d, st), 'bf16'), n)
+            print('C%d d%d x3 %.3f ms  %.2f TB/s (x + y, 4 bytes per element) | planar out %.3f ms | fp32 kernel %.3f ms | bf16 kernel %.3f ms' % (C, d, ms, 2 * gb / ms, msp, ms32, ms16))
+
+
+if __name__ == '__main__':
+    main()

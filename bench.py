@@ -37,7 +37,9 @@ Prints ONE JSON line on rank 0 with the driver's fields plus
   "overlap"           : N > 1 only: event timestamps of one instrumented step -- how long the compute stream still had to wait for
                         the all-reduce AFTER it had finished the next batch's CQT (0 = the collective was hidden entirely)
   "skip_connections_step" : the same step with skip_connections=True (the model of BASELINE.json configs[4]), N = 1
-  "inference_config1" : BASELINE.json configs[1] (transcribe() + reconstruct(), 32 clips) timed in the same run, N = 1
+  "inference_config1" : BASELINE.json configs[1] (transcribe() + reconstruct(), 32 clips) timed in the same run, N = 1: fp32 semantics
+                        (no autocast; the wide levels on split fp16 operands, csrc/conv_x3.hip -- "fp32_kernels_only" is the same leg with
+                        ops.X3_INFER off, "roofline_x3_fwd" the split-operand block against the HBM peak), and under bf16 / fp16 autocast
   "cpu_baseline"      : the CPU oracle (kind "port") on a bounded sample of the SAME workload (model_complexity 2; rank 0, N = 1)
   "cpu_baseline_config0" : BASELINE.json configs[0] on the oracle: model_complexity 1, one clip, CQT forward + inverse + one step
 """
@@ -680,6 +682,32 @@ def main():
                 plain = bench_inference(model, args, rank, world, dev, steps=10, warmup=2, emit=False)
                 ops.X3_INFER = True
                 infer['fp32_kernels_only'] = {k: plain[k] for k in ('value', 'unit', 'ms_per_step', 'dtype')}
+                # its own roofline entry: the split-operand block at the widest level, HIP events around every launch of two more
+                # (untimed) inference steps
+                x3_events = {}
+                _hip.EVENT_KEYS = {'x3_rb_fwd_C%d' % (16 * args.mc)}
+                _hip.EVENT_LOG = x3_events
+                bench_inference(model, args, rank, world, dev, steps=2, warmup=0, emit=False)
+                _hip.EVENT_LOG = None
+                _hip.EVENT_KEYS = None
+                key = 'x3_rb_fwd_C%d' % (16 * args.mc)
+                if x3_events.get(key):
+                    a_ms, n_l = avg_ms(x3_events[key])
+                    Bx, Cx, Hx, Tx = ops.X3_SHAPES[key]
+                    nbytes = 2 * Bx * Cx * Hx * Tx * 4                  # x read + y written, 4 bytes per element (two halves)
+                    gbs = nbytes / (a_ms * 1e-3) / 1e9
+                    traffic, traffic_source = None, None
+                    pmc = os.path.join(ROOT, 'profiles', 'r04_pmc_x3_C32.json')
+                    if Cx == 32 and os.path.exists(pmc):
+                        pj = json.load(open(pmc))
+                        traffic = pj['traffic_bytes_corrected'] * (Bx * Hx * Tx) / pj['pixels']
+                        traffic_source = 'profiles/r04_pmc_x3_C32.json (rocprofv3 --pmc passes at B 64 x H 65 x T 1024, scaled by the pixel count; FETCH_SIZE x2 + WRITE_SIZE; not re-measured in this run)'
+                    infer['roofline_x3_fwd'] = dict(
+                        kernel='tt_x3_rb_fwd at C=%d, B=%d, H=%d, T=%d: k_x3_conv<%d,D> (fused ResidualConv2dBlock forward on fp16 hi/lo pairs, '
+                               'dilation 1 / 2 / 3 averaged)' % (Cx, Bx, Hx, Tx, Cx),
+                        bound='hbm', achieved=gbs, peak=PEAK_HBM_GBS, unit='GB/s', frac=gbs / PEAK_HBM_GBS, traffic=traffic,
+                        traffic_source=traffic_source, algorithmic_bytes=nbytes, launches=n_l, avg_ms=a_ms,
+                        note='algorithmic bytes = x read + y written at 4 bytes per element (the x3 layout is as wide as fp32)')
             if args.precision == 'auto':
                 full16 = bench_inference(model, args, rank, world, dev, steps=10, warmup=2, emit=False, autocast=True)
                 infer['under_autocast'] = {k: full16[k] for k in ('value', 'unit', 'ms_per_step', 'dtype')}

@@ -882,6 +882,7 @@ def residual_level(x, blocks):
 # rate.  TTRAP_X3_INFER=0 / ops.X3_INFER = False keeps the fp32 kernels.
 X3_INFER = os.environ.get('TTRAP_X3_INFER', '1') != '0'
 X3_CHANNELS = (16, 32)
+X3_SHAPES = {}                        # event key -> (B, C, H, T) of the last instrumented call (bench.py's roofline_x3_fwd)
 
 
 def x3_inference():
@@ -899,9 +900,20 @@ def x3_level(x, blocks):
     arr = lambda j: (ctypes.c_void_p * n)(*[p[j].data_ptr() for p in params])
     ws = torch.empty(lib.tt_x3_level_scratch_bytes(B, C, H, T), dtype=torch.uint8, device=x.device)
     y = torch.empty_like(x)
-    with _hip.timed('x3_level_fwd_C%d' % C):
-        check(lib.tt_x3_level_fwd(n, ptr(x), ptr(y), arr(0), arr(1), arr(2), arr(3), (ctypes.c_int * n)(*[b.dilation for b in blocks]),
-                                  ptr(ws), B, C, H, T, st), 'tt_x3_level_fwd')
+    if _hip.EVENT_LOG is not None:
+        # bench.py's instrumented steps: the same launches as tt_x3_level_fwd, one at a time, each block between its own pair of events
+        half = ws.numel() // 2
+        buf = (ws[:half], ws[half:])
+        check(lib.tt_x3_pack(ptr(x), ptr(buf[0]), B, C, H, T, st), 'tt_x3_pack')
+        for i, (b, p) in enumerate(zip(blocks, params)):
+            last = i == n - 1
+            with _hip.timed('x3_rb_fwd_C%d' % C):
+                check(lib.tt_x3_rb_fwd(ptr(buf[i & 1]), ptr(p[0]), ptr(p[1]), ptr(p[2]), ptr(p[3]), ptr(y if last else buf[(i + 1) & 1]),
+                                       int(last), B, C, H, T, b.dilation, st), 'tt_x3_rb_fwd')
+        X3_SHAPES['x3_rb_fwd_C%d' % C] = (B, C, H, T)
+        return y
+    check(lib.tt_x3_level_fwd(n, ptr(x), ptr(y), arr(0), arr(1), arr(2), arr(3), (ctypes.c_int * n)(*[b.dilation for b in blocks]),
+                              ptr(ws), B, C, H, T, st), 'tt_x3_level_fwd')
     return y
 
 

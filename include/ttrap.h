@@ -367,7 +367,8 @@ int tt_target_activations(const int* bins, const int* frames, int n, const doubl
  *   tt_x3_pack       x (B,C,H,T) fp32 planar -> x3              tt_x3_unpack   the inverse (exact to 2^-23 relative)
  *   tt_x3_rb_fwd     y = ELU(W2 . ELU(W1 (*)_dil x + b1) + b2) + x; x is an x3 tensor, y an x3 tensor (planar_out = 0; x != y) or an
  *                    fp32 planar (B,C,H,T) tensor (planar_out = 1); weights fp32 (C,C,3,3) / (C,C,1,1)
- *   tt_x3_level_fwd  pack, nblocks blocks (w1[i], b1[i], w2[i], b2[i], dilations[i]; the last one planar_out): fp32 planar in and out;
+ *   tt_x3_level_fwd  nblocks blocks (w1[i], b1[i], w2[i], b2[i], dilations[i]); x is fp32 planar (x3_in = 0: packed first) or an x3
+ *                    tensor, y fp32 planar (x3_out = 0: written by the last block directly) or an x3 tensor;
  *                    ws = tt_x3_level_scratch_bytes bytes */
 int64_t tt_x3_bytes(int B, int C, int H, int T);
 int64_t tt_x3_level_scratch_bytes(int B, int C, int H, int T);
@@ -375,8 +376,19 @@ int tt_x3_pack(const float* x, void* out, int B, int C, int H, int T, void* stre
 int tt_x3_unpack(const void* in, float* y, int B, int C, int H, int T, void* stream);
 int tt_x3_rb_fwd(const void* x, const float* w1, const float* b1, const float* w2, const float* b2, void* y, int planar_out, int B,
                  int C, int H, int T, int dilation, void* stream);
-int tt_x3_level_fwd(int nblocks, const float* x, float* y, const float* const* w1, const float* const* b1, const float* const* w2,
-                    const float* const* b2, const int* dilations, void* ws, int B, int C, int H, int T, void* stream);
+int tt_x3_level_fwd(int nblocks, const void* x, int x3_in, void* y, int x3_out, const float* const* w1, const float* const* b1,
+                    const float* const* w2, const float* const* b2, const int* dilations, void* ws, int B, int C, int H, int T,
+                    void* stream);
+/* The strided layers between and above the wide levels on x3 tensors, so that level -> strided layer -> level never leaves the layout:
+ *   tt_x3_sconv_fwd  EncoderBlock.sconv (modules.py:626-630): y = ELU(Conv2d(C, 2C, (4,1), stride (2,1))(x) + bias), C = 16 or 32,
+ *                    x an x3 tensor of H rows, y ((H - 4) / 2 + 1 rows, 2C channels) an x3 tensor or fp32 planar (planar_out)
+ *   tt_x3_tconv_fwd  DecoderBlock.tconv (modules.py:683-688): y = ELU(ConvTranspose2d(2C, C, (4,1), stride (2,1),
+ *                    output_padding (out_pad, 0))(x) + bias), C = 16 (else TT_E_UNSUPPORTED), x an x3 tensor with 2C channels,
+ *                    y (2H + 2 + out_pad rows) an x3 tensor or fp32 planar
+ * weights fp32 in torch's layouts ((2C, C, 4, 1) / (2C, C, 4, 1) for the transposed layer: (in, out, 4, 1)). */
+int tt_x3_sconv_fwd(const void* x, const float* w, const float* bias, void* y, int planar_out, int B, int C, int H, int T, void* stream);
+int tt_x3_tconv_fwd(const void* x, const float* w, const float* bias, void* y, int planar_out, int B, int C, int H, int T, int out_pad,
+                    void* stream);
 
 /* ---- fp16 twins ---------------------------------------------------------------------------------------------------------------
  * Every entry point of the 16-bit channels-last path above exists a second time with the suffix _h: the same kernels compiled with

@@ -175,7 +175,7 @@ def test_level_entry_is_three_blocks(C):
     arr = lambda j: (ctypes.c_void_p * 3)(*[dev[i][j].data_ptr() for i in range(3)])
     ws = torch.empty(L.tt_x3_level_scratch_bytes(B, C, H, T), dtype=torch.uint8, device='cuda')
     y = torch.empty_like(xd)
-    check(L.tt_x3_level_fwd(3, ptr(xd), ptr(y), arr(0), arr(1), arr(2), arr(3), (ctypes.c_int * 3)(*dil), ptr(ws), B, C, H, T, st),
+    check(L.tt_x3_level_fwd(3, ptr(xd), 0, ptr(y), 0, arr(0), arr(1), arr(2), arr(3), (ctypes.c_int * 3)(*dil), ptr(ws), B, C, H, T, st),
           'tt_x3_level_fwd')
     torch.cuda.synchronize()
     assert _rel(y.cpu(), want) < 2 * BAR
@@ -192,6 +192,103 @@ def test_level_entry_is_three_blocks(C):
     assert torch.equal(y_ops, y)
     y_grad = ops.residual_level(xd.clone().requires_grad_(True), mods)            # with grad: the fp32 kernels (hidden activations saved)
     assert y_grad.requires_grad and _rel(y_grad.detach().cpu(), want) < 1e-5
+
+
+def _sconv64(x, w, b):
+    return F.elu(F.conv2d(x.double(), w.double(), b.double(), stride=(2, 1)))
+
+
+def _tconv64(x, w, b, out_pad):
+    return F.elu(F.conv_transpose2d(x.double(), w.double(), b.double(), stride=(2, 1), output_padding=(out_pad, 0)))
+
+
+def _to_x3(x):
+    from timbre_trap._hip import check, lib, ptr, stream_ptr
+    B, C, H, T = x.shape
+    buf = _x3_buf(B, C, H, T)
+    check(lib().tt_x3_pack(ptr(x), ptr(buf), B, C, H, T, stream_ptr()), 'tt_x3_pack')
+    return buf
+
+
+@pytest.mark.parametrize('C', [16, 32])
+@pytest.mark.parametrize('shape', [(2, 13, 70), (1, 36, 33), (3, 133, 64), (1, 4, 16)])
+def test_strided_layer_matches_float64(C, shape):
+    """EncoderBlock.sconv on x3 tensors: x3 and fp32 planar outputs, ragged frame counts, odd and even heights, the minimum height."""
+    from timbre_trap._hip import check, lib, ptr, stream_ptr
+    from timbre_trap.framework import ops
+    L, st = lib(), stream_ptr()
+    B, H, T = shape
+    x = _rand(B, C, H, T, seed=21)
+    w = _rand(2 * C, C, 4, 1, seed=22, scale=1.0 / (2 * C ** 0.5))
+    b = _rand(2 * C, seed=23, scale=0.3)
+    want = _sconv64(x, w, b)
+    Ho = (H - 4) // 2 + 1
+    xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
+    x3 = _to_x3(xd)
+    yp = torch.empty((B, 2 * C, Ho, T), dtype=torch.float32, device='cuda')
+    check(L.tt_x3_sconv_fwd(ptr(x3), ptr(wd), ptr(bd), ptr(yp), 1, B, C, H, T, st), 'tt_x3_sconv_fwd')
+    y3 = torch.full((B, Ho, T, 2, 2 * C), 7.0, dtype=torch.float16, device='cuda')
+    check(L.tt_x3_sconv_fwd(ptr(x3), ptr(wd), ptr(bd), ptr(y3), 0, B, C, H, T, st), 'tt_x3_sconv_fwd')
+    torch.cuda.synchronize()
+    assert _rel(yp.cpu(), want) < BAR
+    assert ops.is_x3(y3)
+    assert _rel(ops.from_x3(y3).cpu(), want) < BAR
+    assert torch.equal(ops.strided_conv(x3, wd, bd, 4, 2, out_x3=False), yp)
+
+
+@pytest.mark.parametrize('out_pad', [0, 1])
+@pytest.mark.parametrize('shape', [(2, 6, 70), (1, 65, 33), (1, 1, 16)])
+def test_transposed_layer_matches_float64(out_pad, shape):
+    """DecoderBlock.tconv 32 -> 16 on x3 tensors, with and without output padding."""
+    from timbre_trap._hip import check, lib, ptr, stream_ptr
+    from timbre_trap.framework import ops
+    L, st = lib(), stream_ptr()
+    B, H, T = shape
+    C = 16
+    x = _rand(B, 2 * C, H, T, seed=31)
+    w = _rand(2 * C, C, 4, 1, seed=32, scale=1.0 / (2 * C ** 0.5))
+    b = _rand(C, seed=33, scale=0.3)
+    want = _tconv64(x, w, b, out_pad)
+    Ho = 2 * H + 2 + out_pad
+    assert want.shape == (B, C, Ho, T)
+    xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
+    x3 = _to_x3(xd)
+    yp = torch.empty((B, C, Ho, T), dtype=torch.float32, device='cuda')
+    check(L.tt_x3_tconv_fwd(ptr(x3), ptr(wd), ptr(bd), ptr(yp), 1, B, C, H, T, out_pad, st), 'tt_x3_tconv_fwd')
+    y3 = torch.full((B, Ho, T, 2, C), 7.0, dtype=torch.float16, device='cuda')
+    check(L.tt_x3_tconv_fwd(ptr(x3), ptr(wd), ptr(bd), ptr(y3), 0, B, C, H, T, out_pad, st), 'tt_x3_tconv_fwd')
+    torch.cuda.synchronize()
+    assert _rel(yp.cpu(), want) < BAR
+    assert _rel(ops.from_x3(y3).cpu(), want) < BAR
+    assert torch.equal(ops.transposed_conv(x3, wd, bd, 4, 2, out_pad, out_x3=True), y3)
+
+
+def test_chain_level_strided_level_stays_in_layout():
+    """level(16) -> sconv -> level(32) -> sconv (planar out) and level(32) -> tconv -> level(16) with x3 tensors in between: the same
+    values as the chain through fp32 planar tensors, to the split's 22 bits."""
+    from timbre_trap.framework import modules, ops
+    torch.manual_seed(0)
+    enc3, enc4 = modules.EncoderBlock(16, 32).cuda(), modules.EncoderBlock(32, 64).cuda()
+    dec1, dec2 = modules.DecoderBlock(64, 32, padding=1).cuda(), modules.DecoderBlock(32, 16, padding=1).cuda()
+    x = _rand(2, 16, 69, 80, seed=41).cuda()
+    with torch.no_grad():
+        ref_e = enc4(enc3(x))
+        ref_d = dec2(dec1(ref_e))
+        assert not ops.is_x3(enc3(x, out_x3=True)), 'outside the scope nothing changes'
+        with ops.x3_chain_scope(True):
+            mid = enc3(x, out_x3=True)
+            assert ops.is_x3(mid) and mid.shape == (2, 33, 80, 2, 32)
+            got_e = enc4(mid)
+            assert got_e.dtype == torch.float32 and got_e.shape == ref_e.shape
+            dmid = dec1(got_e, out_x3=True)
+            assert ops.is_x3(dmid)
+            got_d = dec2(dmid)
+            assert got_d.dtype == torch.float32 and got_d.shape == ref_d.shape
+    assert _rel(got_e, ref_e) < 2 * BAR
+    assert _rel(got_d, ref_d) < 4 * BAR
+    with ops.x3_chain_scope(True):                                # with grad the scope is inert
+        assert not ops.x3_chain()
+        assert enc3(x, out_x3=True).dtype == torch.float32
 
 
 def test_non_finite_values_surface():

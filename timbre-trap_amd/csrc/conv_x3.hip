@@ -326,39 +326,221 @@ int x3_d(const e16* x, const float* w1, const float* b1, const float* w2, const 
     }
     return TT_E_UNSUPPORTED;
 }
+// ---- strided layers between and above the wide levels ------------------------------------------------------------------------------
+// EncoderBlock.sconv = ELU(Conv2d(C, 2C, (4,1), stride (2,1))) (reference modules.py:626-630) and DecoderBlock.tconv =
+// ELU(ConvTranspose2d(2C, C, (4,1), stride (2,1), output_padding)) (modules.py:683-688) on x3 tensors, so that a chain
+// level -> strided layer -> level never leaves the split layout (no pack / unpack passes, no fp32 matrix instructions).
+// These layers are pointwise in time: an output pixel (h, t) reads 4 (2) input pixels of the same frame.  No LDS: a wave owns 16
+// consecutive frames of one clip and a run of output rows, all weights of its co-tiles sit in registers as hi / lo pairs in operand
+// order, the K = 32 slices of the input rows come straight from HBM / L2 in B-operand order (16 bytes per lane and plane; the rows
+// shared by neighbouring output rows are re-read from the caches), the next row's operands are requested before this row's products.
+//   DOWN, C = 16: K = 4 x 16 = two slices of two rows each; 32 output channels = 2 co-tiles.
+//   DOWN, C = 32: K = 4 x 32 = four slices; 64 output channels = 4 co-tiles, two per wave (two waves share a pixel group).
+//   UP,  2C = 32: output rows 2m, 2m + 1 both read input rows m (tap = parity) and m - 1 (tap = parity + 2): two slices per parity;
+//                 16 output channels = 1 co-tile.
+template <int CIN, bool UP> struct XS {
+    static constexpr int COUT = UP ? CIN / 2 : 2 * CIN;
+    static constexpr int NCT = COUT / 16;                        // co-tiles in all
+    static constexpr int NCTW = NCT > 2 ? 2 : NCT;               // co-tiles per wave
+    static constexpr int NSPLIT = NCT / NCTW;                    // waves that share a pixel group
+    static constexpr int NKS = UP ? 2 : (4 * CIN) / 32;          // K = 32 slices per output row
+    static constexpr int NSET = UP ? 2 : 1;                      // weight sets (output row parity)
+    static constexpr int NCH = COUT == 16 ? 4 : 8;               // channels a lane ends up with
+};
+
+template <int CIN, bool UP, bool PLANAR>
+__global__ __launch_bounds__(NT, (CIN == 32 && !UP) ? 2 : 4) void k_x3_sconv(const e16* __restrict__ x, const float* __restrict__ w,
+                                                                             const float* __restrict__ bias, void* __restrict__ yout,
+                                                                             int B, int Hin, int Hout, int T, int nchunks, int rch) {
+    using S = XS<CIN, UP>;
+    constexpr int COUT = S::COUT, NCTW = S::NCTW, NKS = S::NKS, NSET = S::NSET, NCH = S::NCH;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+    // task of this workgroup: (clip, 64-frame group, co split, row chunk); the four waves take the four 16-frame groups
+    int task = blockIdx.x;
+    const int rc = task % nchunks; task /= nchunks;
+    const int sp = task % S::NSPLIT; task /= S::NSPLIT;
+    const int tgroups = (T + 63) / 64;
+    const int tg = task % tgroups, b = task / tgroups;
+    const int t = tg * 64 + wave * 16 + n;
+    const bool tv = t < T;
+    const int tc = tv ? t : T - 1;                               // clamped: loads stay inside the tensor, stores are masked
+
+    // ---- weights of this workgroup's co-tiles: split once by the four waves together (through LDS), then to registers ----
+    // channel of row m of co-tile ct (global index): a lane's rows 4g..4g+3 of its co-tiles are consecutive channels
+    auto cmap = [&](int ct, int m) { return COUT == 16 ? m : COUT == 32 ? 8 * (m >> 2) + 4 * ct + (m & 3) : 16 * (m >> 2) + 4 * ct + (m & 3); };
+    constexpr int NE = NSET * NKS * NCTW;
+    __shared__ __align__(16) unsigned char wimg[NE * 2 * 64 * 16];
+    for (int e = threadIdx.x; e < NE * 64; e += NT) {
+        const int l = e & 63, ent = e >> 6, ct = ent % NCTW, ks = (ent / NCTW) % NKS, st_ = ent / (NCTW * NKS);
+        const int ln = l & 15, lg = l >> 4;
+        const int co = cmap(sp * NCTW + ct, ln);
+        e16x8 qh, ql;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float wv;
+            if constexpr (UP) wv = w[((8 * lg + j) * COUT + co) * 4 + st_ + 2 * ks];            // (Cin, Cout, 4, 1): tap = parity + 2 ks
+            else if constexpr (CIN == 16) wv = w[(co * CIN + 8 * (lg & 1) + j) * 4 + 2 * ks + (lg >> 1)];
+            else wv = w[(co * CIN + 8 * lg + j) * 4 + ks];
+            e16 h, lo_; split(wv, h, lo_); qh[j] = h; ql[j] = lo_;
+        }
+        *reinterpret_cast<e16x8*>(wimg + ((long)(ent * 2 + 0) * 64 + l) * 16) = qh;
+        *reinterpret_cast<e16x8*>(wimg + ((long)(ent * 2 + 1) * 64 + l) * 16) = ql;
+    }
+    __syncthreads();
+    e16x8 AH[NSET][NKS][NCTW], AL[NSET][NKS][NCTW];
+#pragma unroll
+    for (int st_ = 0; st_ < NSET; ++st_)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int ct = 0; ct < NCTW; ++ct) {
+                const int ent = (st_ * NKS + ks) * NCTW + ct;
+                AH[st_][ks][ct] = *reinterpret_cast<const e16x8*>(wimg + ((long)(ent * 2 + 0) * 64 + lane) * 16);
+                AL[st_][ks][ct] = *reinterpret_cast<const e16x8*>(wimg + ((long)(ent * 2 + 1) * 64 + lane) * 16);
+            }
+    float br[NCTW][4];
+#pragma unroll
+    for (int ct = 0; ct < NCTW; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) br[ct][r] = bias[cmap(sp * NCTW + ct, 4 * g + r)];
+    const int chbase = COUT == 16 ? 4 * g : COUT == 32 ? 8 * g : 16 * g + 8 * sp;       // first of the lane's NCH consecutive channels
+
+    const e16* xb = x + (long)b * Hin * T * 2 * CIN;
+    // B operand of slice ks for output row `ho` (UP: for the pair m = ho): 16 bytes of one plane; rows outside the input read row 0
+    // and are zeroed
+    auto in_row = [&](int ho, int ks) { return UP ? ho - ks : (CIN == 16 ? 2 * ho + 2 * ks + (g >> 1) : 2 * ho + ks); };
+    auto ldb = [&](int ho, int ks, int plane) -> e16x8 {
+        const int row = in_row(ho, ks);
+        const bool ok = (unsigned)row < (unsigned)Hin;
+        const int piece = CIN == 16 ? (g & 1) : g;
+        e16x8 v = *reinterpret_cast<const e16x8*>(xb + ((long)(ok ? row : 0) * T + tc) * 2 * CIN + plane * CIN + 8 * piece);
+        if (!ok) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (e16)0.f;
+        }
+        return v;
+    };
+    const int npairs = UP ? (Hout + 1) / 2 : Hout;               // units the row loop walks: output rows, or pairs of them
+    const int u0 = rc * rch, u1 = u0 + rch < npairs ? u0 + rch : npairs;
+    if (u0 >= npairs) return;
+    // Sliding window: consecutive units share half of their slices (DOWN: the two lower input rows of one output row are the two upper
+    // ones of the next; UP: row m of one pair is row m - 1 of the next), so a unit loads only its NKS / 2 NEW slices -- requested one
+    // unit ahead -- and the window shifts in registers.
+    constexpr int NNEW = NKS / 2;
+    // slice index -> window position: DOWN keeps slices in ascending row order (new ones enter at the top end), UP has slice 0 = row m
+    // (new) and slice 1 = row m - 1 (the previous unit's slice 0)
+    e16x8 bh[NKS], bl[NKS], nh[NNEW], nl[NNEW];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) { bh[ks] = ldb(u0, ks, 0); bl[ks] = ldb(u0, ks, 1); }
+    for (int u = u0; u < u1; ++u) {
+        if (u + 1 < u1) {
+#pragma unroll
+            for (int i = 0; i < NNEW; ++i) {
+                const int ks = UP ? i : NNEW + i;                // the slices of unit u + 1 that unit u does not hold
+                nh[i] = ldb(u + 1, ks, 0); nl[i] = ldb(u + 1, ks, 1);
+            }
+        }
+#pragma unroll
+        for (int st_ = 0; st_ < NSET; ++st_) {
+            const int ho = UP ? 2 * u + st_ : u;
+            f32x4 am[NCTW], al[NCTW];
+#pragma unroll
+            for (int ct = 0; ct < NCTW; ++ct) { am[ct] = f32x4{br[ct][0], br[ct][1], br[ct][2], br[ct][3]}; al[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+                for (int ct = 0; ct < NCTW; ++ct) {
+                    am[ct] = mma32(AH[st_][ks][ct], bh[ks], am[ct]);
+                    al[ct] = mma32(AH[st_][ks][ct], bl[ks], al[ct]);
+                }
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+                for (int ct = 0; ct < NCTW; ++ct) al[ct] = mma32(AL[st_][ks][ct], bh[ks], al[ct]);
+            if (ho >= Hout || !tv) continue;
+            float out[NCH];
+#pragma unroll
+            for (int ct = 0; ct < NCTW; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[4 * ct + r] = elu1(__builtin_fmaf(al[ct][r], LO_INV, am[ct][r]));
+            if constexpr (PLANAR) {
+                float* yp = static_cast<float*>(yout) + (((long)b * COUT + chbase) * Hout + ho) * T + t;
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) yp[(long)j * Hout * T] = out[j];
+            } else {
+                e16* y = static_cast<e16*>(yout) + (((long)b * Hout + ho) * T + t) * 2 * COUT + chbase;
+                typename std::conditional<NCH == 8, e16x8, e16x4>::type oh, ol;
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) { e16 a_, b_; split(out[j], a_, b_); oh[j] = a_; ol[j] = b_; }
+                *reinterpret_cast<decltype(oh)*>(y) = oh;
+                *reinterpret_cast<decltype(ol)*>(y + COUT) = ol;
+            }
+        }
+        // shift the window
+        if constexpr (UP) {
+#pragma unroll
+            for (int i = 0; i < NNEW; ++i) { bh[NNEW + i] = bh[i]; bl[NNEW + i] = bl[i]; bh[i] = nh[i]; bl[i] = nl[i]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NNEW; ++i) { bh[i] = bh[NNEW + i]; bl[i] = bl[NNEW + i]; bh[NNEW + i] = nh[i]; bl[NNEW + i] = nl[i]; }
+        }
+    }
+}
+
+template <int CIN, bool UP, bool PLANAR>
+int launch_x3s(const e16* x, const float* w, const float* bias, void* y, int B, int Hin, int Hout, int T, hipStream_t st) {
+    using S = XS<CIN, UP>;
+    // a task = (clip, 64 frames, co split, run of output rows): runs as long as the grid still holds ~16 workgroups per CU (the weight
+    // split at the head of a workgroup is amortised over the run), never shorter than 8 rows
+    const int units = UP ? (Hout + 1) / 2 : Hout;
+    const long base = (long)B * ((T + 63) / 64) * S::NSPLIT;
+    long want = (16l * tt_cus() + base - 1) / base;
+    if (want < 1) want = 1;
+    if (want > (units + 7) / 8) want = (units + 7) / 8;
+    const int rch = (int)((units + want - 1) / want), nchunks = (units + rch - 1) / rch;
+    const long grid = base * nchunks;
+    if (grid > 0x7fffffffl) return TT_E_UNSUPPORTED;
+    hipLaunchKernelGGL((k_x3_sconv<CIN, UP, PLANAR>), dim3((unsigned)grid), dim3(NT), 0, st, x, w, bias, y, B, Hin, Hout, T, nchunks, rch);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
 int x3_block(const e16* x, const float* w1, const float* b1, const float* w2, const float* b2, void* y, bool planar, int B, int C,
              int H, int T, int d, hipStream_t st) {
     if (C == 16) return planar ? x3_d<16, true>(x, w1, b1, w2, b2, y, B, H, T, d, st) : x3_d<16, false>(x, w1, b1, w2, b2, y, B, H, T, d, st);
     return planar ? x3_d<32, true>(x, w1, b1, w2, b2, y, B, H, T, d, st) : x3_d<32, false>(x, w1, b1, w2, b2, y, B, H, T, d, st);
 }
-bool x3_shape_ok(int B, int C, int H, int T) { return B > 0 && H > 0 && T > 0 && (C == 16 || C == 32); }
+bool x3_shape_ok(int B, int C, int H, int T) { return B > 0 && H > 0 && T > 0 && (C == 16 || C == 32); }      // widths with block kernels
+bool x3_layout_ok(int B, int C, int H, int T) { return B > 0 && H > 0 && T > 0 && (C == 16 || C == 32 || C == 64); }   // + the strided layer's output
 
 }  // namespace
 
 extern "C" {
 
 int64_t tt_x3_bytes(int B, int C, int H, int T) {
-    if (!x3_shape_ok(B, C, H, T)) return -1;
+    if (!x3_layout_ok(B, C, H, T)) return -1;
     return (int64_t)B * H * T * C * 4;
 }
 
 int tt_x3_pack(const float* x, void* out, int B, int C, int H, int T, void* stream) {
-    if (!x || !out || !x3_shape_ok(B, C, H, T)) return TT_E_BADARG;
+    if (!x || !out || !x3_layout_ok(B, C, H, T)) return TT_E_BADARG;
     const long npix = (long)B * H * T, pieces = npix * C / 8;
     const unsigned grid = (unsigned)((pieces + NT - 1) / NT);
     hipStream_t st = tt_stream(stream);
     if (C == 16) hipLaunchKernelGGL(k_x3_pack<16>, dim3(grid), dim3(NT), 0, st, x, (e16*)out, H, T, npix);
+    else if (C == 64) hipLaunchKernelGGL(k_x3_pack<64>, dim3(grid), dim3(NT), 0, st, x, (e16*)out, H, T, npix);
     else hipLaunchKernelGGL(k_x3_pack<32>, dim3(grid), dim3(NT), 0, st, x, (e16*)out, H, T, npix);
     TT_LAUNCH_CHECK();
     return 0;
 }
 
 int tt_x3_unpack(const void* in, float* y, int B, int C, int H, int T, void* stream) {
-    if (!in || !y || !x3_shape_ok(B, C, H, T)) return TT_E_BADARG;
+    if (!in || !y || !x3_layout_ok(B, C, H, T)) return TT_E_BADARG;
     const long npix = (long)B * H * T, pieces = npix * C / 8;
     const unsigned grid = (unsigned)((pieces + NT - 1) / NT);
     hipStream_t st = tt_stream(stream);
     if (C == 16) hipLaunchKernelGGL(k_x3_unpack<16>, dim3(grid), dim3(NT), 0, st, (const e16*)in, y, H, T, npix);
+    else if (C == 64) hipLaunchKernelGGL(k_x3_unpack<64>, dim3(grid), dim3(NT), 0, st, (const e16*)in, y, H, T, npix);
     else hipLaunchKernelGGL(k_x3_unpack<32>, dim3(grid), dim3(NT), 0, st, (const e16*)in, y, H, T, npix);
     TT_LAUNCH_CHECK();
     return 0;
@@ -370,21 +552,46 @@ int tt_x3_rb_fwd(const void* x, const float* w1, const float* b1, const float* w
     return x3_block((const e16*)x, w1, b1, w2, b2, y, planar_out != 0, B, C, H, T, dilation, tt_stream(stream));
 }
 
-int tt_x3_level_fwd(int nblocks, const float* x, float* y, const float* const* w1, const float* const* b1, const float* const* w2,
-                    const float* const* b2, const int* dilations, void* ws, int B, int C, int H, int T, void* stream) {
+int tt_x3_level_fwd(int nblocks, const void* x, int x3_in, void* y, int x3_out, const float* const* w1, const float* const* b1,
+                    const float* const* w2, const float* const* b2, const int* dilations, void* ws, int B, int C, int H, int T,
+                    void* stream) {
     if (nblocks < 1 || !x || !y || !w1 || !b1 || !w2 || !b2 || !dilations || !ws || !x3_shape_ok(B, C, H, T)) return TT_E_BADARG;
     for (int i = 0; i < nblocks; ++i)
         if (!w1[i] || !b1[i] || !w2[i] || !b2[i] || dilations[i] < 1 || dilations[i] > 3) return TT_E_BADARG;
     const int64_t bytes = tt_x3_bytes(B, C, H, T);
     unsigned char* buf[2] = {static_cast<unsigned char*>(ws), static_cast<unsigned char*>(ws) + ((bytes + 255) / 256) * 256};
-    if (int rc = tt_x3_pack(x, buf[0], B, C, H, T, stream)) return rc;
-    for (int i = 0; i < nblocks; ++i) {                          // the last block writes fp32 planar straight into y
+    const void* cur = x;
+    if (!x3_in) {
+        if (int rc = tt_x3_pack(static_cast<const float*>(x), buf[0], B, C, H, T, stream)) return rc;
+        cur = buf[0];
+    }
+    for (int i = 0; i < nblocks; ++i) {                          // the last block writes into y: x3, or fp32 planar straight away
         const bool last = i == nblocks - 1;
-        if (int rc = tt_x3_rb_fwd(buf[i & 1], w1[i], b1[i], w2[i], b2[i], last ? (void*)y : (void*)buf[(i + 1) & 1], last, B, C, H, T,
-                                  dilations[i], stream))
-            return rc;
+        void* dst = last ? y : (cur == buf[0] ? buf[1] : buf[0]);
+        if (dst == cur) return TT_E_BADARG;                      // x3_in with y == x
+        if (int rc = tt_x3_rb_fwd(cur, w1[i], b1[i], w2[i], b2[i], dst, last && !x3_out, B, C, H, T, dilations[i], stream)) return rc;
+        cur = dst;
     }
     return 0;
+}
+
+int tt_x3_sconv_fwd(const void* x, const float* w, const float* bias, void* y, int planar_out, int B, int C, int H, int T, void* stream) {
+    if (!x || !w || !bias || !y || !x3_shape_ok(B, C, H, T) || H < 4) return TT_E_BADARG;
+    const int Hout = (H - 4) / 2 + 1;
+    hipStream_t st = tt_stream(stream);
+    const e16* xi = (const e16*)x;
+    if (C == 16) return planar_out ? launch_x3s<16, false, true>(xi, w, bias, y, B, H, Hout, T, st) : launch_x3s<16, false, false>(xi, w, bias, y, B, H, Hout, T, st);
+    return planar_out ? launch_x3s<32, false, true>(xi, w, bias, y, B, H, Hout, T, st) : launch_x3s<32, false, false>(xi, w, bias, y, B, H, Hout, T, st);
+}
+
+int tt_x3_tconv_fwd(const void* x, const float* w, const float* bias, void* y, int planar_out, int B, int C, int H, int T, int out_pad,
+                    void* stream) {
+    if (!x || !w || !bias || !y || B <= 0 || H <= 0 || T <= 0 || (out_pad != 0 && out_pad != 1)) return TT_E_BADARG;
+    if (C != 16) return TT_E_UNSUPPORTED;                        // C = output channels; input 2 C = 32
+    const int Hout = 2 * H + 2 + out_pad;
+    hipStream_t st = tt_stream(stream);
+    const e16* xi = (const e16*)x;
+    return planar_out ? launch_x3s<32, true, true>(xi, w, bias, y, B, H, Hout, T, st) : launch_x3s<32, true, false>(xi, w, bias, y, B, H, Hout, T, st);
 }
 
 int64_t tt_x3_level_scratch_bytes(int B, int C, int H, int T) {

@@ -66,7 +66,9 @@ _PROTOS = {
     'tt_x3_pack': (c_int, [P, P, I, I, I, I, P]),
     'tt_x3_unpack': (c_int, [P, P, I, I, I, I, P]),
     'tt_x3_rb_fwd': (c_int, [P, P, P, P, P, P, I, I, I, I, I, I, P]),
-    'tt_x3_level_fwd': (c_int, [I, P, P, P, P, P, P, P, P, I, I, I, I, P]),
+    'tt_x3_level_fwd': (c_int, [I, P, I, P, I, P, P, P, P, P, P, I, I, I, I, P]),
+    'tt_x3_sconv_fwd': (c_int, [P, P, P, P, I, I, I, I, I, P]),
+    'tt_x3_tconv_fwd': (c_int, [P, P, P, P, I, I, I, I, I, I, P]),
     'tt_wide_fused_scratch_bytes': (c_int64, [I]),
     'tt_wide_rb_bwd_fused': (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
     'tt_wide_onepass_scratch_bytes': (c_int64, [I]),

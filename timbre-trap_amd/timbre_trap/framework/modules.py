@@ -79,10 +79,11 @@ class EncoderBlock(nn.Module):
             nn.Conv2d(in_channels, out_channels, kernel_size=(self.win, 1), stride=(self.hop, 1)),
             nn.ELU(inplace=True))
 
-    def forward(self, x):
-        y = ops.residual_level(x, (self.block1, self.block2, self.block3))
+    def forward(self, x, out_x3=False):
+        """out_x3 (inside ops.x3_chain_scope only): the caller's next layer takes a split-operand tensor."""
+        y = ops.residual_level(x, (self.block1, self.block2, self.block3), out_x3=ops.x3_chain())
         s = self.sconv[0]
-        return ops.strided_conv(y, s.weight, s.bias, self.win, self.hop)
+        return ops.strided_conv(y, s.weight, s.bias, self.win, self.hop, out_x3=out_x3)
 
 
 class DecoderBlock(nn.Module):
@@ -104,10 +105,10 @@ class DecoderBlock(nn.Module):
         self.block2 = ResidualConv2dBlock(out_channels, out_channels, kernel_size=3, dilation=2)
         self.block3 = ResidualConv2dBlock(out_channels, out_channels, kernel_size=3, dilation=3)
 
-    def forward(self, x):
+    def forward(self, x, out_x3=False):
         t = self.tconv[0]
-        y = ops.transposed_conv(x, t.weight, t.bias, self.win, self.hop, self.out_pad)
-        return ops.residual_level(y, (self.block1, self.block2, self.block3))
+        y = ops.transposed_conv(x, t.weight, t.bias, self.win, self.hop, self.out_pad, out_x3=ops.x3_chain())
+        return ops.residual_level(y, (self.block1, self.block2, self.block3), out_x3=out_x3)
 
 
 class Encoder(nn.Module):
@@ -134,9 +135,13 @@ class Encoder(nn.Module):
         """returns (latents (B,D,T), [5 embeddings], {})."""
         c = self.convin[0]
         embeddings = [ops.conv(coefficients, c.weight, c.bias, ConvCfg(3, 3, 1, 1, 1, 1, 'conv', 0, ACT_ELU))]
-        for block in (self.block1, self.block2, self.block3, self.block4):
-            embeddings.append(block(embeddings[-1]))
-        top = embeddings[-1]
+        blocks = (self.block1, self.block2, self.block3, self.block4)
+        for i, block in enumerate(blocks):
+            # inside ops.x3_chain_scope (embeddings dropped by the caller): a block whose successor starts with a split-operand level
+            # hands its output over in that layout
+            nxt = blocks[i + 1].block1.conv1[0].in_channels if i + 1 < len(blocks) else 0
+            embeddings.append(block(embeddings[-1], out_x3=ops.x3_chain() and nxt in ops.X3_CHANNELS))
+        top = ops.to_planar32(embeddings[-1])
         if top.size(-2) != self.convlat.kernel_size[0]:
             raise ValueError('feature size %d does not match the latent head (%d)' % (top.size(-2), self.convlat.kernel_size[0]))
         latents = ops.latent_encode(top, self.convlat.weight, self.convlat.bias)
@@ -176,8 +181,11 @@ class Decoder(nn.Module):
         skips = None if encoder_embeddings is None else list(encoder_embeddings)[::-1]
         if skips is not None:
             y = ops.add(y, skips[0])
-        for i, block in enumerate((self.block1, self.block2, self.block3, self.block4)):
-            y = block(y)
+        blocks = (self.block1, self.block2, self.block3, self.block4)
+        for i, block in enumerate(blocks):
+            # the one transposed layer with a split-operand kernel is 32 -> 16 channels (tt_x3_tconv_fwd)
+            t = blocks[i + 1].tconv[0] if i + 1 < len(blocks) else None
+            y = block(y, out_x3=skips is None and ops.x3_chain() and t is not None and (t.in_channels, t.out_channels) == (32, 16))
             if skips is not None:
                 y = ops.add(y, skips[i + 1])
         o = self.convout
@@ -221,7 +229,9 @@ class TimbreTrap(nn.Module):
         return self.decoder(torch.cat((latents, indicator), dim=-2), embeddings)
 
     def _inference(self, audio, transcribe=False):
-        with torch.no_grad():
+        # without skip connections the embeddings are dropped right here: the layers may keep their activations in the split-operand
+        # layout between two wide levels (ops.x3_chain_scope; fp32 semantics, no autocast, no grad)
+        with torch.no_grad(), ops.x3_chain_scope(self.skip_weights is None):
             latents, embeddings, _ = self.encode(audio)
             return self.decode(latents, self.apply_skip_connections(embeddings), transcribe)
 

@@ -8,6 +8,7 @@ CPU path -- tensors must live on the GPU.
 
 import ctypes
 import os
+import threading
 from dataclasses import dataclass
 
 import torch
@@ -377,8 +378,13 @@ def _stride16_ok(C, T, w, b):
     return (FUSED_RESBLOCK and C in WIDE_CHANNELS and (C != 4 or T % 2 == 0) and w.shape == (2 * C, C, 4, 1) and b is not None)
 
 
-def strided_conv(x, w, b, win, hop):
-    """Conv2d(C, Cout, (win,1), stride (hop,1)) + ELU."""
+def strided_conv(x, w, b, win, hop, out_x3=False):
+    """Conv2d(C, Cout, (win,1), stride (hop,1)) + ELU.  x may be an x3 tensor (is_x3); out_x3: the next layer takes one."""
+    if is_x3(x):
+        C = x.size(4)
+        if win == 4 and hop == 2 and x.size(1) >= 4 and C in X3_CHANNELS and w.shape == (2 * C, C, 4, 1) and b is not None:
+            return x3_strided_conv(x, w, b, out_x3 and 2 * C in X3_CHANNELS)
+        x = from_x3(x)
     C = x.size(1)
     if (win == 4 and hop == 2 and x.size(2) >= 4 and _stride16_ok(C, x.size(-1), w, b) and (is_cl16(x) or cl16_mode())
             and _i32_ok(x, 2 * C)):
@@ -389,9 +395,13 @@ def strided_conv(x, w, b, win, hop):
     return conv(x, w, b, ConvCfg(win, 1, hop, 1, 0, 0, 'conv', 0, ACT_ELU))
 
 
-def transposed_conv(x, w, b, win, hop, out_pad):
-    """ConvTranspose2d(Cin, C, (win,1), stride (hop,1), output_padding (out_pad,0)) + ELU."""
+def transposed_conv(x, w, b, win, hop, out_pad, out_x3=False):
+    """ConvTranspose2d(Cin, C, (win,1), stride (hop,1), output_padding (out_pad,0)) + ELU.  x may be an x3 tensor."""
     C = w.size(1)
+    if is_x3(x):
+        if (win == 4 and hop == 2 and C == 16 and x.size(4) == 32 and w.shape == (32, 16, 4, 1) and b is not None and out_pad in (0, 1)):
+            return x3_transposed_conv(x, w, b, out_pad, out_x3)
+        x = from_x3(x)
     if (win == 4 and hop == 2 and x.size(1) == 2 * C and out_pad in (0, 1) and _stride16_ok(C, x.size(-1), w, b)
             and (is_cl16(x) or cl16_mode()) and (2 * x.size(2) + 2 + out_pad) * x.size(3) * 2 * C < 2 ** 31):
         return TConv16Fn.apply(to_cl16(x), w, b, out_pad)
@@ -505,6 +515,8 @@ def to_planar32(x):
     """What every fp32-only layer calls on its input: identity for fp32 tensors."""
     if is_cl16(x):
         return ToPlanar32Fn.apply(x)
+    if is_x3(x):
+        return from_x3(x)
     return x
 
 
@@ -852,12 +864,15 @@ def scale(e, weights, i):
     return ScaleFn.apply(e, weights, i)
 
 
-def residual_level(x, blocks):
+def residual_level(x, blocks, out_x3=False):
     """
     block3(block2(block1(x))) for the ResidualConv2dBlock modules ``blocks``.  With ops.cl16_mode() the level runs
     on cl16 tensors (Level16Fn) and RETURNS a cl16 tensor -- the next layer either has a bf16 kernel or converts with
-    to_planar32; otherwise the per-block fp32 path.
+    to_planar32; otherwise the per-block fp32 path.  ``out_x3``: the caller's next layer takes a split-operand tensor (is_x3):
+    honoured only where the level itself runs on them (x3_inference()).
     """
+    if is_x3(x):
+        return x3_level(x, blocks, out_x3)
     C, T = x.size(1), x.size(-1)
     if (cl16_mode() and C in WIDE_CHANNELS and FUSED_RESBLOCK and (C != 4 or T % 2 == 0) and _i32_ok(x)
             and all(b.conv1[0].weight.shape == (C, C, 3, 3) and 1 <= b.dilation <= 3 for b in blocks)):
@@ -866,10 +881,8 @@ def residual_level(x, blocks):
             params += [b.conv1[0].weight, b.conv1[0].bias, b.conv2[0].weight, b.conv2[0].bias]
         return Level16Fn.apply(to_cl16(x), tuple(b.dilation for b in blocks), *params)
     x = to_planar32(x)
-    if (x3_inference() and C in X3_CHANNELS and FUSED_RESBLOCK and x.is_cuda and 1 <= len(blocks) <= 8
-            and all(b.conv1[0].weight.shape == (C, C, 3, 3) and b.conv2[0].weight.shape == (C, C, 1, 1) and 1 <= b.dilation <= 3
-                    for b in blocks)):
-        return x3_level(x, blocks)
+    if x3_inference() and C in X3_CHANNELS and x.is_cuda and _x3_blocks_ok(C, blocks):
+        return x3_level(x, blocks, out_x3)
     for b in blocks:
         x = b(x)
     return x
@@ -883,37 +896,118 @@ def residual_level(x, blocks):
 X3_INFER = os.environ.get('TTRAP_X3_INFER', '1') != '0'
 X3_CHANNELS = (16, 32)
 X3_SHAPES = {}                        # event key -> (B, C, H, T) of the last instrumented call (bench.py's roofline_x3_fwd)
+_X3_LOCAL = threading.local()
 
 
 def x3_inference():
     return X3_INFER and not torch.is_grad_enabled() and precision() == 'fp32' and wide_storage() == 'fp32'
 
 
-def x3_level(x, blocks):
-    """block_n(...block1(x)) for fp32 planar x (B,C,H,T), C in X3_CHANNELS, no autograd graph: tt_x3_level_fwd."""
-    x = _f32c(x)
-    B, C, H, T = x.shape
+class x3_chain_scope:
+    """
+    Inside this scope (TimbreTrap._inference when there are no skip connections: the encoder's embeddings are dropped) the layers
+    between two split-operand levels hand x3 tensors to each other -- torch.float16 tensors of shape (B, H, T, 2, C), the layout of
+    csrc/conv_x3.hip -- instead of fp32 planar ones: no pack / unpack passes, strided layers on tt_x3_sconv_fwd / tt_x3_tconv_fwd.
+    Such tensors never leave the model: every consumer without an x3 kernel converts (to_planar32).
+    """
+
+    def __init__(self, enabled=True):
+        self.enabled = enabled
+
+    def __enter__(self):
+        self.prev = getattr(_X3_LOCAL, 'chain', False)
+        _X3_LOCAL.chain = bool(self.enabled)
+        return self
+
+    def __exit__(self, *exc):
+        _X3_LOCAL.chain = self.prev
+        return False
+
+
+def x3_chain():
+    return getattr(_X3_LOCAL, 'chain', False) and x3_inference()
+
+
+def is_x3(t):
+    return t.dtype == torch.float16 and t.dim() == 5 and t.size(3) == 2 and t.is_contiguous()
+
+
+def from_x3(t):
+    """x3 (B, H, T, 2, C) -> fp32 planar (B, C, H, T) (tt_x3_unpack: hi + lo 2^-11, exact)."""
+    B, H, T, _, C = t.shape
+    y = torch.empty((B, C, H, T), dtype=torch.float32, device=t.device)
+    check(_hip.lib().tt_x3_unpack(ptr(t), ptr(y), B, C, H, T, stream_ptr()), 'tt_x3_unpack')
+    return y
+
+
+def _x3_blocks_ok(C, blocks):
+    return (FUSED_RESBLOCK and 1 <= len(blocks) <= 8
+            and all(b.conv1[0].weight.shape == (C, C, 3, 3) and b.conv2[0].weight.shape == (C, C, 1, 1) and 1 <= b.dilation <= 3
+                    for b in blocks))
+
+
+def x3_level(x, blocks, out_x3=False):
+    """block_n(...block1(x)) without an autograd graph: tt_x3_level_fwd.  x: fp32 planar (B,C,H,T) or an x3 tensor; returns an x3
+    tensor if out_x3 (the caller's next layer takes one), else fp32 planar."""
+    in_x3 = is_x3(x)
+    if in_x3:
+        B, H, T, _, C = x.shape
+        if C not in X3_CHANNELS or not _x3_blocks_ok(C, blocks):
+            return residual_level(from_x3(x), blocks)
+    else:
+        x = _f32c(x)
+        B, C, H, T = x.shape
     lib, st = _hip.lib(), stream_ptr()
     n = len(blocks)
     params = [[_f32c(t.detach()) for t in (b.conv1[0].weight, b.conv1[0].bias, b.conv2[0].weight, b.conv2[0].bias)] for b in blocks]
     _hip.require_cuda(x, params[0][0])
     arr = lambda j: (ctypes.c_void_p * n)(*[p[j].data_ptr() for p in params])
     ws = torch.empty(lib.tt_x3_level_scratch_bytes(B, C, H, T), dtype=torch.uint8, device=x.device)
-    y = torch.empty_like(x)
+    y = (torch.empty((B, H, T, 2, C), dtype=torch.float16, device=x.device) if out_x3
+         else torch.empty((B, C, H, T), dtype=torch.float32, device=x.device))
     if _hip.EVENT_LOG is not None:
         # bench.py's instrumented steps: the same launches as tt_x3_level_fwd, one at a time, each block between its own pair of events
         half = ws.numel() // 2
         buf = (ws[:half], ws[half:])
-        check(lib.tt_x3_pack(ptr(x), ptr(buf[0]), B, C, H, T, st), 'tt_x3_pack')
+        cur = x
+        if not in_x3:
+            check(lib.tt_x3_pack(ptr(x), ptr(buf[0]), B, C, H, T, st), 'tt_x3_pack')
+            cur = buf[0]
         for i, (b, p) in enumerate(zip(blocks, params)):
             last = i == n - 1
+            dst = y if last else (buf[1] if cur is buf[0] else buf[0])
             with _hip.timed('x3_rb_fwd_C%d' % C):
-                check(lib.tt_x3_rb_fwd(ptr(buf[i & 1]), ptr(p[0]), ptr(p[1]), ptr(p[2]), ptr(p[3]), ptr(y if last else buf[(i + 1) & 1]),
-                                       int(last), B, C, H, T, b.dilation, st), 'tt_x3_rb_fwd')
+                check(lib.tt_x3_rb_fwd(ptr(cur), ptr(p[0]), ptr(p[1]), ptr(p[2]), ptr(p[3]), ptr(dst), int(last and not out_x3), B, C, H, T,
+                                       b.dilation, st), 'tt_x3_rb_fwd')
+            cur = dst
         X3_SHAPES['x3_rb_fwd_C%d' % C] = (B, C, H, T)
         return y
-    check(lib.tt_x3_level_fwd(n, ptr(x), ptr(y), arr(0), arr(1), arr(2), arr(3), (ctypes.c_int * n)(*[b.dilation for b in blocks]),
-                              ptr(ws), B, C, H, T, st), 'tt_x3_level_fwd')
+    check(lib.tt_x3_level_fwd(n, ptr(x), int(in_x3), ptr(y), int(out_x3), arr(0), arr(1), arr(2), arr(3),
+                              (ctypes.c_int * n)(*[b.dilation for b in blocks]), ptr(ws), B, C, H, T, st), 'tt_x3_level_fwd')
+    return y
+
+
+def x3_strided_conv(x, w, b, out_x3):
+    """EncoderBlock.sconv on an x3 tensor (tt_x3_sconv_fwd): returns x3 (B, Hout, T, 2, 2C) or fp32 planar (B, 2C, Hout, T)."""
+    B, H, T, _, C = x.shape
+    Ho = (H - 4) // 2 + 1
+    w, b = _f32c(w.detach()), _f32c(b.detach())
+    y = (torch.empty((B, Ho, T, 2, 2 * C), dtype=torch.float16, device=x.device) if out_x3
+         else torch.empty((B, 2 * C, Ho, T), dtype=torch.float32, device=x.device))
+    with _hip.timed('x3_sconv_C%d' % C):
+        check(_hip.lib().tt_x3_sconv_fwd(ptr(x), ptr(w), ptr(b), ptr(y), int(not out_x3), B, C, H, T, stream_ptr()), 'tt_x3_sconv_fwd')
+    return y
+
+
+def x3_transposed_conv(x, w, b, out_pad, out_x3):
+    """DecoderBlock.tconv on an x3 tensor with 2C = 32 channels (tt_x3_tconv_fwd): x3 (B, Hout, T, 2, C) or fp32 planar."""
+    B, H, T, _, C2 = x.shape
+    C, Ho = C2 // 2, 2 * H + 2 + out_pad
+    w, b = _f32c(w.detach()), _f32c(b.detach())
+    y = (torch.empty((B, Ho, T, 2, C), dtype=torch.float16, device=x.device) if out_x3
+         else torch.empty((B, C, Ho, T), dtype=torch.float32, device=x.device))
+    with _hip.timed('x3_tconv_C%d' % C):
+        check(_hip.lib().tt_x3_tconv_fwd(ptr(x), ptr(w), ptr(b), ptr(y), int(not out_x3), B, C, H, T, out_pad, stream_ptr()), 'tt_x3_tconv_fwd')
     return y
 
 

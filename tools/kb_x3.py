@@ -55,6 +55,29 @@ def main():
             ms16 = timeit(lambda: check(lib.tt_wide_rb_fwd(ptr(xb), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(yb), None, B, C, H, T, d, st), 'bf16'), n)
             print('C%d d%d x3 %.3f ms  %.2f TB/s (x + y, 4 bytes per element) | planar out %.3f ms | fp32 kernel %.3f ms | bf16 kernel %.3f ms' % (C, d, ms, 2 * gb / ms, msp, ms32, ms16))
 
+        # strided layers on x3 tensors next to the fp32 kernels
+        wS = torch.randn(2 * C, C, 4, 1, device='cuda') / (2 * C ** 0.5)
+        bS = torch.randn(2 * C, device='cuda') * 0.1
+        Ho = (H - 4) // 2 + 1
+        y3 = torch.empty((B, Ho, T, 2, 2 * C), dtype=torch.float16, device='cuda')
+        yp = torch.empty((B, 2 * C, Ho, T), device='cuda')
+        ms3 = timeit(lambda: check(lib.tt_x3_sconv_fwd(ptr(a), ptr(wS), ptr(bS), ptr(y3), 0, B, C, H, T, st), 's'), n)
+        msp = timeit(lambda: check(lib.tt_x3_sconv_fwd(ptr(a), ptr(wS), ptr(bS), ptr(yp), 1, B, C, H, T, st), 's'), n)
+        with torch.no_grad():
+            ms32 = timeit(lambda: ops.StridedConvFn.apply(x, wS, bS), n)
+        gbs = (x.numel() + yp.numel()) * 4 / 1e9
+        print('C%d sconv x3 -> x3 %.3f ms %.2f TB/s | x3 -> planar %.3f ms | fp32 kernel %.3f ms' % (C, ms3, gbs / ms3, msp, ms32))
+        if C == 32:
+            wT = torch.randn(32, 16, 4, 1, device='cuda') / 8
+            bT = torch.randn(16, device='cuda') * 0.1
+            Ht = 2 * H + 3
+            z3 = torch.empty((B, Ht, T, 2, 16), dtype=torch.float16, device='cuda')
+            mst = timeit(lambda: check(lib.tt_x3_tconv_fwd(ptr(a), ptr(wT), ptr(bT), ptr(z3), 0, B, 16, H, T, 1, st), 't'), n)
+            with torch.no_grad():
+                mst32 = timeit(lambda: ops.TransposedConvFn.apply(x, wT, bT, 1), n)
+            gbt = (x.numel() + z3.numel() // 2) * 4 / 1e9
+            print('C32 -> 16 tconv x3 -> x3 %.3f ms %.2f TB/s | fp32 kernel %.3f ms' % (mst, gbt / mst, mst32))
+
 
 if __name__ == '__main__':
     main()

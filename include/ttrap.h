@@ -379,16 +379,32 @@ int tt_x3_rb_fwd(const void* x, const float* w1, const float* b1, const float* w
 int tt_x3_level_fwd(int nblocks, const void* x, int x3_in, void* y, int x3_out, const float* const* w1, const float* const* b1,
                     const float* const* w2, const float* const* b2, const int* dilations, void* ws, int B, int C, int H, int T,
                     void* stream);
-/* The strided layers between and above the wide levels on x3 tensors, so that level -> strided layer -> level never leaves the layout:
- *   tt_x3_sconv_fwd  EncoderBlock.sconv (modules.py:626-630): y = ELU(Conv2d(C, 2C, (4,1), stride (2,1))(x) + bias), C = 16 or 32,
- *                    x an x3 tensor of H rows, y ((H - 4) / 2 + 1 rows, 2C channels) an x3 tensor or fp32 planar (planar_out)
+/* The strided layers between and above the wide levels with split operands, so that level -> strided layer -> level never leaves the
+ * x3 layout.  x is an x3 tensor (planar_in = 0) or -- the layer that ENTERS the split-operand part of the network -- an fp32 planar
+ * (B,C,H,T) tensor (planar_in = 1); y an x3 tensor (planar_out = 0) or fp32 planar (planar_out = 1):
+ *   tt_x3_sconv_fwd  EncoderBlock.sconv (modules.py:626-630): y = ELU(Conv2d(C, 2C, (4,1), stride (2,1))(x) + bias); x has C channels and
+ *                    H >= 4 rows, y 2C channels and (H - 4) / 2 + 1 rows; C = 16, 32 (x3 input) or C = 8 (planar input)
  *   tt_x3_tconv_fwd  DecoderBlock.tconv (modules.py:683-688): y = ELU(ConvTranspose2d(2C, C, (4,1), stride (2,1),
- *                    output_padding (out_pad, 0))(x) + bias), C = 16 (else TT_E_UNSUPPORTED), x an x3 tensor with 2C channels,
- *                    y (2H + 2 + out_pad rows) an x3 tensor or fp32 planar
- * weights fp32 in torch's layouts ((2C, C, 4, 1) / (2C, C, 4, 1) for the transposed layer: (in, out, 4, 1)). */
-int tt_x3_sconv_fwd(const void* x, const float* w, const float* bias, void* y, int planar_out, int B, int C, int H, int T, void* stream);
-int tt_x3_tconv_fwd(const void* x, const float* w, const float* bias, void* y, int planar_out, int B, int C, int H, int T, int out_pad,
+ *                    output_padding (out_pad, 0))(x) + bias); x has 2C channels and H rows, y C channels and 2H + 2 + out_pad rows;
+ *                    C = 16 or 32 (x3 input), C = 32 (planar input)
+ * other widths: TT_E_UNSUPPORTED.  Weights fp32 in torch's layouts: (2C, C, 4, 1) for both (the transposed layer's is (in, out, 4, 1)). */
+int tt_x3_sconv_fwd(const void* x, int planar_in, const float* w, const float* bias, void* y, int planar_out, int B, int C, int H, int T,
                     void* stream);
+int tt_x3_tconv_fwd(const void* x, int planar_in, const float* w, const float* bias, void* y, int planar_out, int B, int C, int H, int T,
+                    int out_pad, void* stream);
+
+/* The latent heads with split operands (csrc/conv_x3.hip), (C, D) = (64, 128) or (32, 32), else TT_E_UNSUPPORTED / -1:
+ *   tt_x3_latent_encode  Encoder.convlat (modules.py:446) = Conv2d(C, D, (E,1)): x an x3 tensor (B, E, T, 2, C), w (D, C, E, 1), bias (D) or
+ *                        NULL, z (B, D, T) fp32
+ *   tt_x3_latent_decode  Decoder.convin (modules.py:534) = ELU(ConvTranspose2d(D + 1, C, (E,1))): z (B, Dz, T) fp32 with Dz = D + 1, or
+ *                        Dz = D and the last input channel constant = fill; w (D + 1, C, E, 1), bias (C) or NULL; y an x3 tensor
+ *                        (B, E, T, 2, C) or fp32 planar (B, C, E, T) (planar_out)
+ *   ws = tt_x3_latent_scratch_bytes(C, E, D) bytes (the split weights in operand order, rewritten by every call). */
+int64_t tt_x3_latent_scratch_bytes(int C, int E, int D);
+int tt_x3_latent_encode(const void* x, const float* w, const float* bias, float* z, void* ws, int B, int C, int E, int D, int T,
+                        void* stream);
+int tt_x3_latent_decode(const float* z, int Dz, float fill, const float* w, const float* bias, void* y, int planar_out, void* ws, int B,
+                        int C, int E, int D, int T, void* stream);
 
 /* ---- fp16 twins ---------------------------------------------------------------------------------------------------------------
  * Every entry point of the 16-bit channels-last path above exists a second time with the suffix _h: the same kernels compiled with

@@ -256,19 +256,24 @@ def test_config1_split_operand_wide_levels_agree_with_fp32_kernels():
         ops.x3_level = lambda x, blocks, out_x3=False: (calls.append(x.shape[4] if ops.is_x3(x) else x.shape[1]), orig(x, blocks, out_x3))[1]
         ops.x3_strided_conv = lambda *a: (strided.append('s'), orig_s(*a))[1]
         ops.x3_transposed_conv = lambda *a: (strided.append('t'), orig_t(*a))[1]
+        orig_le, orig_ld = ops.x3_latent_encode, ops.x3_latent_decode
+        ops.x3_latent_encode = lambda *a: (strided.append('le'), orig_le(*a))[1]
+        ops.x3_latent_decode = lambda *a: (strided.append('ld'), orig_ld(*a))[1]
         try:
             with torch.no_grad():
                 t3, r3 = model.chunked_inference(audio, True), model.chunked_inference(audio, False)
                 assert sorted(set(calls)) == [16, 32] and len(calls) == 8, calls      # 2 passes x (encoder + decoder) x 2 wide levels
                 # without skip connections the embeddings are dropped and the strided layers between / above the wide levels stay in the
-                # split layout (2 passes x (16 -> 32, 32 -> 64, 32 -> 16)); with them every level converts at its ends
-                assert sorted(strided) == (['s'] * 4 + ['t'] * 2 if not kw['skip_connections'] else []), strided
+                # split layout (2 passes x (8 -> 16 entering, 16 -> 32, 32 -> 64, latent heads, 64 -> 32, 32 -> 16)); with them every
+                # level converts at its ends
+                assert sorted(strided) == (['ld'] * 2 + ['le'] * 2 + ['s'] * 6 + ['t'] * 4 if not kw['skip_connections'] else []), strided
                 ops.X3_INFER = False
                 t32, r32 = model.chunked_inference(audio, True), model.chunked_inference(audio, False)
                 assert len(calls) == 8
         finally:
             ops.X3_INFER = True
             ops.x3_level, ops.x3_strided_conv, ops.x3_transposed_conv = orig, orig_s, orig_t
+            ops.x3_latent_encode, ops.x3_latent_decode = orig_le, orig_ld
         for a, b in ((t3, t32), (r3, r32)):
             assert float((a - b).abs().max() / b.abs().max()) < 5e-6
     # a forward that records a graph keeps the fp32 kernels (their hidden activations feed the fp32 backward)

@@ -226,9 +226,9 @@ def test_strided_layer_matches_float64(C, shape):
     xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
     x3 = _to_x3(xd)
     yp = torch.empty((B, 2 * C, Ho, T), dtype=torch.float32, device='cuda')
-    check(L.tt_x3_sconv_fwd(ptr(x3), ptr(wd), ptr(bd), ptr(yp), 1, B, C, H, T, st), 'tt_x3_sconv_fwd')
+    check(L.tt_x3_sconv_fwd(ptr(x3), 0, ptr(wd), ptr(bd), ptr(yp), 1, B, C, H, T, st), 'tt_x3_sconv_fwd')
     y3 = torch.full((B, Ho, T, 2, 2 * C), 7.0, dtype=torch.float16, device='cuda')
-    check(L.tt_x3_sconv_fwd(ptr(x3), ptr(wd), ptr(bd), ptr(y3), 0, B, C, H, T, st), 'tt_x3_sconv_fwd')
+    check(L.tt_x3_sconv_fwd(ptr(x3), 0, ptr(wd), ptr(bd), ptr(y3), 0, B, C, H, T, st), 'tt_x3_sconv_fwd')
     torch.cuda.synchronize()
     assert _rel(yp.cpu(), want) < BAR
     assert ops.is_x3(y3)
@@ -254,13 +254,100 @@ def test_transposed_layer_matches_float64(out_pad, shape):
     xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
     x3 = _to_x3(xd)
     yp = torch.empty((B, C, Ho, T), dtype=torch.float32, device='cuda')
-    check(L.tt_x3_tconv_fwd(ptr(x3), ptr(wd), ptr(bd), ptr(yp), 1, B, C, H, T, out_pad, st), 'tt_x3_tconv_fwd')
+    check(L.tt_x3_tconv_fwd(ptr(x3), 0, ptr(wd), ptr(bd), ptr(yp), 1, B, C, H, T, out_pad, st), 'tt_x3_tconv_fwd')
     y3 = torch.full((B, Ho, T, 2, C), 7.0, dtype=torch.float16, device='cuda')
-    check(L.tt_x3_tconv_fwd(ptr(x3), ptr(wd), ptr(bd), ptr(y3), 0, B, C, H, T, out_pad, st), 'tt_x3_tconv_fwd')
+    check(L.tt_x3_tconv_fwd(ptr(x3), 0, ptr(wd), ptr(bd), ptr(y3), 0, B, C, H, T, out_pad, st), 'tt_x3_tconv_fwd')
     torch.cuda.synchronize()
     assert _rel(yp.cpu(), want) < BAR
     assert _rel(ops.from_x3(y3).cpu(), want) < BAR
     assert torch.equal(ops.transposed_conv(x3, wd, bd, 4, 2, out_pad, out_x3=True), y3)
+
+
+@pytest.mark.parametrize('shape', [(2, 13, 70), (1, 269, 33), (1, 4, 16)])
+def test_entering_strided_layer_from_planar_matches_float64(shape):
+    """EncoderBlock.sconv 8 -> 16 from an fp32 planar tensor straight into the split layout (the layer in front of the first wide level)."""
+    from timbre_trap._hip import check, lib, ptr, stream_ptr
+    from timbre_trap.framework import ops
+    L, st = lib(), stream_ptr()
+    B, H, T = shape
+    C = 8
+    x = _rand(B, C, H, T, seed=51) * (10.0 ** (_rand(B, C, H, T, seed=52) * 2 - 1))
+    w = _rand(2 * C, C, 4, 1, seed=53, scale=1.0 / (2 * C ** 0.5))
+    b = _rand(2 * C, seed=54, scale=0.3)
+    want = _sconv64(x, w, b)
+    Ho = (H - 4) // 2 + 1
+    xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
+    y3 = torch.full((B, Ho, T, 2, 2 * C), 7.0, dtype=torch.float16, device='cuda')
+    check(L.tt_x3_sconv_fwd(ptr(xd), 1, ptr(wd), ptr(bd), ptr(y3), 0, B, C, H, T, st), 'tt_x3_sconv_fwd')
+    yp = torch.empty((B, 2 * C, Ho, T), dtype=torch.float32, device='cuda')
+    check(L.tt_x3_sconv_fwd(ptr(xd), 1, ptr(wd), ptr(bd), ptr(yp), 1, B, C, H, T, st), 'tt_x3_sconv_fwd')
+    torch.cuda.synchronize()
+    assert _rel(ops.from_x3(y3).cpu(), want) < BAR and _rel(yp.cpu(), want) < BAR
+    assert L.tt_x3_sconv_fwd(ptr(xd), 1, ptr(wd), ptr(bd), ptr(yp), 1, B, 16, H, T, st) == -2       # planar input: C = 8 only
+    assert L.tt_x3_sconv_fwd(ptr(xd), 0, ptr(wd), ptr(bd), ptr(yp), 1, B, 8, H, T, st) == -2        # x3 input: C = 16, 32 only
+
+
+@pytest.mark.parametrize('out_pad', [0, 1])
+@pytest.mark.parametrize('shape', [(2, 6, 70), (1, 31, 33), (1, 1, 16)])
+def test_entering_transposed_layer_from_planar_matches_float64(out_pad, shape):
+    """DecoderBlock.tconv 64 -> 32 from an fp32 planar tensor into the split layout (the layer in front of the decoder's first wide level)."""
+    from timbre_trap._hip import check, lib, ptr, stream_ptr
+    from timbre_trap.framework import ops
+    L, st = lib(), stream_ptr()
+    B, H, T = shape
+    C = 32
+    x = _rand(B, 2 * C, H, T, seed=61)
+    w = _rand(2 * C, C, 4, 1, seed=62, scale=1.0 / (2 * C ** 0.5))
+    b = _rand(C, seed=63, scale=0.3)
+    want = _tconv64(x, w, b, out_pad)
+    Ho = 2 * H + 2 + out_pad
+    xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
+    y3 = torch.full((B, Ho, T, 2, C), 7.0, dtype=torch.float16, device='cuda')
+    check(L.tt_x3_tconv_fwd(ptr(xd), 1, ptr(wd), ptr(bd), ptr(y3), 0, B, C, H, T, out_pad, st), 'tt_x3_tconv_fwd')
+    yp = torch.empty((B, C, Ho, T), dtype=torch.float32, device='cuda')
+    check(L.tt_x3_tconv_fwd(ptr(xd), 1, ptr(wd), ptr(bd), ptr(yp), 1, B, C, H, T, out_pad, st), 'tt_x3_tconv_fwd')
+    torch.cuda.synchronize()
+    assert _rel(ops.from_x3(y3).cpu(), want) < BAR and _rel(yp.cpu(), want) < BAR
+    assert L.tt_x3_tconv_fwd(ptr(xd), 1, ptr(wd), ptr(bd), ptr(yp), 1, B, 16, H, T, out_pad, st) == -2
+
+
+@pytest.mark.parametrize('C,D,E', [(64, 128, 31), (32, 32, 7), (64, 128, 3)])
+@pytest.mark.parametrize('BT', [(2, 200), (1, 37), (3, 128)])
+def test_latent_heads_match_float64(C, D, E, BT):
+    """Encoder.convlat on an x3 embedding and Decoder.convin (+ ELU) into one, both model sizes, ragged frame counts (a workgroup = 128
+    frames), the switch channel carried by z (D + 1 rows) or given as a constant."""
+    from timbre_trap._hip import check, lib, ptr, stream_ptr
+    from timbre_trap.framework import ops
+    L, st = lib(), stream_ptr()
+    B, T = BT
+    x = _rand(B, C, E, T, seed=71)
+    we = _rand(D, C, E, 1, seed=72, scale=1.0 / (C * E) ** 0.5)
+    be = _rand(D, seed=73, scale=0.3)
+    want_z = F.conv2d(x.double(), we.double(), be.double()).squeeze(2)                  # (B, D, T)
+    xd, wed, bed = x.cuda(), we.cuda(), be.cuda()
+    ws = torch.empty(L.tt_x3_latent_scratch_bytes(C, E, D), dtype=torch.uint8, device='cuda')
+    z = torch.empty((B, D, T), dtype=torch.float32, device='cuda')
+    check(L.tt_x3_latent_encode(ptr(_to_x3(xd)), ptr(wed), ptr(bed), ptr(z), ptr(ws), B, C, E, D, T, st), 'tt_x3_latent_encode')
+    torch.cuda.synchronize()
+    assert _rel(z.cpu(), want_z) < BAR
+    assert torch.equal(ops.latent_encode(_to_x3(xd), wed, bed), z)
+    # decode
+    zin = _rand(B, D + 1, T, seed=74)
+    zin[:, D] = 1.0
+    wd = _rand(D + 1, C, E, 1, seed=75, scale=1.0 / D ** 0.5)
+    bd = _rand(C, seed=76, scale=0.3)
+    want_y = F.elu(F.conv_transpose2d(zin.double().unsqueeze(2), wd.double(), bd.double()))     # (B, C, E, T)
+    zd, wdd, bdd = zin.cuda(), wd.cuda(), bd.cuda()
+    y3 = torch.full((B, E, T, 2, C), 7.0, dtype=torch.float16, device='cuda')
+    check(L.tt_x3_latent_decode(ptr(zd), D + 1, 0.0, ptr(wdd), ptr(bdd), ptr(y3), 0, ptr(ws), B, C, E, D, T, st), 'tt_x3_latent_decode')
+    yp = torch.empty((B, C, E, T), dtype=torch.float32, device='cuda')
+    check(L.tt_x3_latent_decode(ptr(zd[:, :D].contiguous()), D, 1.0, ptr(wdd), ptr(bdd), ptr(yp), 1, ptr(ws), B, C, E, D, T, st),
+          'tt_x3_latent_decode')
+    torch.cuda.synchronize()
+    assert _rel(ops.from_x3(y3).cpu(), want_y) < BAR
+    assert _rel(yp.cpu(), want_y) < BAR, 'constant switch channel = the same channel carried by z'
+    assert L.tt_x3_latent_scratch_bytes(48, E, D) < 0
+    assert L.tt_x3_latent_encode(ptr(y3), ptr(wed), ptr(bed), ptr(z), ptr(ws), B, 48, E, D, T, st) == -2
 
 
 def test_chain_level_strided_level_stays_in_layout():

@@ -328,32 +328,37 @@ int x3_d(const e16* x, const float* w1, const float* b1, const float* w2, const 
 }
 // ---- strided layers between and above the wide levels ------------------------------------------------------------------------------
 // EncoderBlock.sconv = ELU(Conv2d(C, 2C, (4,1), stride (2,1))) (reference modules.py:626-630) and DecoderBlock.tconv =
-// ELU(ConvTranspose2d(2C, C, (4,1), stride (2,1), output_padding)) (modules.py:683-688) on x3 tensors, so that a chain
-// level -> strided layer -> level never leaves the split layout (no pack / unpack passes, no fp32 matrix instructions).
-// These layers are pointwise in time: an output pixel (h, t) reads 4 (2) input pixels of the same frame.  No LDS: a wave owns 16
-// consecutive frames of one clip and a run of output rows, all weights of its co-tiles sit in registers as hi / lo pairs in operand
-// order, the K = 32 slices of the input rows come straight from HBM / L2 in B-operand order (16 bytes per lane and plane; the rows
-// shared by neighbouring output rows are re-read from the caches), the next row's operands are requested before this row's products.
-//   DOWN, C = 16: K = 4 x 16 = two slices of two rows each; 32 output channels = 2 co-tiles.
-//   DOWN, C = 32: K = 4 x 32 = four slices; 64 output channels = 4 co-tiles, two per wave (two waves share a pixel group).
-//   UP,  2C = 32: output rows 2m, 2m + 1 both read input rows m (tap = parity) and m - 1 (tap = parity + 2): two slices per parity;
-//                 16 output channels = 1 co-tile.
+// ELU(ConvTranspose2d(2C, C, (4,1), stride (2,1), output_padding)) (modules.py:683-688) with split operands, so that a chain
+// level -> strided layer -> level never leaves the x3 layout (no pack / unpack passes, no fp32 matrix instructions).
+// These layers are pointwise in time: an output pixel (h, t) reads 4 (2) input pixels of the same frame.  No LDS for the activations: a
+// wave owns 16 consecutive frames of one clip and a run of output rows, all weights of its co-tiles sit in registers as hi / lo pairs
+// in operand order (split once per workgroup, through LDS), the K = 32 slices of the input rows come straight from HBM / L2 in
+// B-operand order, the next unit's NEW slices are requested before this unit's products, and the slices two neighbouring units share
+// stay in registers (sliding window).  Input: an x3 tensor (16 bytes per lane, plane and slice) or -- PIN, the layer that ENTERS the
+// split-operand part of the network -- an fp32 planar tensor (eight 4-byte loads per slice, split in registers).
+//   DOWN  C = 8 (PIN): K = 4 x 8 = one slice (the four rows on the four lane groups: no window); 16 output channels.
+//   DOWN  C = 16: two slices of two rows each; 32 output channels = 2 co-tiles.
+//   DOWN  C = 32: four slices; 64 output channels = 4 co-tiles, two per wave (two waves share a pixel group).
+//   UP   2C = 32: output rows 2m, 2m + 1 both read input rows m (tap = parity) and m - 1 (tap = parity + 2): two slices per parity.
+//   UP   2C = 64 (PIN): the same with two slices per input row; 32 output channels = 2 co-tiles.
 template <int CIN, bool UP> struct XS {
     static constexpr int COUT = UP ? CIN / 2 : 2 * CIN;
     static constexpr int NCT = COUT / 16;                        // co-tiles in all
     static constexpr int NCTW = NCT > 2 ? 2 : NCT;               // co-tiles per wave
     static constexpr int NSPLIT = NCT / NCTW;                    // waves that share a pixel group
-    static constexpr int NKS = UP ? 2 : (4 * CIN) / 32;          // K = 32 slices per output row
+    static constexpr int SPR = CIN > 32 ? CIN / 32 : 1;          // slices per input row
+    static constexpr int NKS = UP ? 2 * SPR : (4 * CIN) / 32;    // K = 32 slices per unit
+    static constexpr int NNEW = NKS == 1 ? 1 : NKS / 2;          // slices a unit does not share with its predecessor
     static constexpr int NSET = UP ? 2 : 1;                      // weight sets (output row parity)
     static constexpr int NCH = COUT == 16 ? 4 : 8;               // channels a lane ends up with
 };
 
-template <int CIN, bool UP, bool PLANAR>
-__global__ __launch_bounds__(NT, (CIN == 32 && !UP) ? 2 : 4) void k_x3_sconv(const e16* __restrict__ x, const float* __restrict__ w,
-                                                                             const float* __restrict__ bias, void* __restrict__ yout,
-                                                                             int B, int Hin, int Hout, int T, int nchunks, int rch) {
+template <int CIN, bool UP, bool PIN, bool PLANAR>
+__global__ __launch_bounds__(NT, (CIN >= 64 || (CIN == 32 && !UP)) ? 2 : 4) void k_x3_sconv(const void* __restrict__ xin, const float* __restrict__ w,
+                                                                                      const float* __restrict__ bias, void* __restrict__ yout,
+                                                                                      int B, int Hin, int Hout, int T, int nchunks, int rch) {
     using S = XS<CIN, UP>;
-    constexpr int COUT = S::COUT, NCTW = S::NCTW, NKS = S::NKS, NSET = S::NSET, NCH = S::NCH;
+    constexpr int COUT = S::COUT, NCTW = S::NCTW, NKS = S::NKS, NSET = S::NSET, NCH = S::NCH, NNEW = S::NNEW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
     // task of this workgroup: (clip, 64-frame group, co split, row chunk); the four waves take the four 16-frame groups
     int task = blockIdx.x;
@@ -365,9 +370,14 @@ __global__ __launch_bounds__(NT, (CIN == 32 && !UP) ? 2 : 4) void k_x3_sconv(con
     const bool tv = t < T;
     const int tc = tv ? t : T - 1;                               // clamped: loads stay inside the tensor, stores are masked
 
+    // slice ks as seen by lane group lg: input row relative to the unit's first row (DOWN: 2u, UP: u), tap, first of its 8 channels
+    auto row_off = [](int ks, int lg) { return UP ? -(ks / S::SPR) : CIN == 8 ? lg : CIN == 16 ? 2 * ks + (lg >> 1) : ks; };
+    auto chan0 = [](int ks, int lg) { return CIN == 8 ? 0 : CIN == 16 ? 8 * (lg & 1) : CIN == 32 ? 8 * lg : 32 * (ks % S::SPR) + 8 * lg; };
+
     // ---- weights of this workgroup's co-tiles: split once by the four waves together (through LDS), then to registers ----
     // channel of row m of co-tile ct (global index): a lane's rows 4g..4g+3 of its co-tiles are consecutive channels
-    auto cmap = [&](int ct, int m) { return COUT == 16 ? m : COUT == 32 ? 8 * (m >> 2) + 4 * ct + (m & 3) : 16 * (m >> 2) + 4 * ct + (m & 3); };
+    // (COUT = 64: the two co-tiles of a wave cover 32 CONSECUTIVE channels, 8 per lane group: whole 64-byte runs per pixel and plane)
+    auto cmap = [&](int ct, int m) { return COUT == 16 ? m : COUT == 32 ? 8 * (m >> 2) + 4 * ct + (m & 3) : 32 * (ct >> 1) + 8 * (m >> 2) + 4 * (ct & 1) + (m & 3); };
     constexpr int NE = NSET * NKS * NCTW;
     __shared__ __align__(16) unsigned char wimg[NE * 2 * 64 * 16];
     for (int e = threadIdx.x; e < NE * 64; e += NT) {
@@ -377,10 +387,9 @@ __global__ __launch_bounds__(NT, (CIN == 32 && !UP) ? 2 : 4) void k_x3_sconv(con
         e16x8 qh, ql;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float wv;
-            if constexpr (UP) wv = w[((8 * lg + j) * COUT + co) * 4 + st_ + 2 * ks];            // (Cin, Cout, 4, 1): tap = parity + 2 ks
-            else if constexpr (CIN == 16) wv = w[(co * CIN + 8 * (lg & 1) + j) * 4 + 2 * ks + (lg >> 1)];
-            else wv = w[(co * CIN + 8 * lg + j) * 4 + ks];
+            const int ci = chan0(ks, lg) + j;
+            const float wv = UP ? w[(ci * COUT + co) * 4 + st_ - 2 * row_off(ks, lg)]           // (Cin, Cout, 4, 1): tap = parity + 2 (m - row)
+                                : w[(co * CIN + ci) * 4 + row_off(ks, lg)];                      // (Cout, Cin, 4, 1): tap = row - 2 ho
             e16 h, lo_; split(wv, h, lo_); qh[j] = h; ql[j] = lo_;
         }
         *reinterpret_cast<e16x8*>(wimg + ((long)(ent * 2 + 0) * 64 + l) * 16) = qh;
@@ -403,42 +412,42 @@ __global__ __launch_bounds__(NT, (CIN == 32 && !UP) ? 2 : 4) void k_x3_sconv(con
     for (int ct = 0; ct < NCTW; ++ct)
 #pragma unroll
         for (int r = 0; r < 4; ++r) br[ct][r] = bias[cmap(sp * NCTW + ct, 4 * g + r)];
-    const int chbase = COUT == 16 ? 4 * g : COUT == 32 ? 8 * g : 16 * g + 8 * sp;       // first of the lane's NCH consecutive channels
+    const int chbase = COUT == 16 ? 4 * g : COUT == 32 ? 8 * g : 32 * sp + 8 * g;       // first of the lane's NCH consecutive channels
 
-    const e16* xb = x + (long)b * Hin * T * 2 * CIN;
-    // B operand of slice ks for output row `ho` (UP: for the pair m = ho): 16 bytes of one plane; rows outside the input read row 0
-    // and are zeroed
-    auto in_row = [&](int ho, int ks) { return UP ? ho - ks : (CIN == 16 ? 2 * ho + 2 * ks + (g >> 1) : 2 * ho + ks); };
-    auto ldb = [&](int ho, int ks, int plane) -> e16x8 {
-        const int row = in_row(ho, ks);
+    // B operand (both planes) of slice ks for unit u; rows outside the input read row 0 and are zeroed
+    auto ldb = [&](int u, int ks, e16x8& vh, e16x8& vl) {
+        const int row = (UP ? u : 2 * u) + row_off(ks, g);
         const bool ok = (unsigned)row < (unsigned)Hin;
-        const int piece = CIN == 16 ? (g & 1) : g;
-        e16x8 v = *reinterpret_cast<const e16x8*>(xb + ((long)(ok ? row : 0) * T + tc) * 2 * CIN + plane * CIN + 8 * piece);
-        if (!ok) {
+        const int rw = ok ? row : 0, c0_ = chan0(ks, g);
+        if constexpr (PIN) {
+            const float* xp = static_cast<const float*>(xin) + (((long)b * CIN + c0_) * Hin + rw) * T + tc;
+            float f[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (e16)0.f;
+            for (int j = 0; j < 8; ++j) f[j] = xp[(long)j * Hin * T];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { e16 h, l; split(ok ? f[j] : 0.f, h, l); vh[j] = h; vl[j] = l; }
+        } else {
+            const e16* xp = static_cast<const e16*>(xin) + (((long)b * Hin + rw) * T + tc) * 2 * CIN + c0_;
+            vh = *reinterpret_cast<const e16x8*>(xp);
+            vl = *reinterpret_cast<const e16x8*>(xp + CIN);
+            if (!ok) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { vh[j] = (e16)0.f; vl[j] = (e16)0.f; }
+            }
         }
-        return v;
     };
     const int npairs = UP ? (Hout + 1) / 2 : Hout;               // units the row loop walks: output rows, or pairs of them
     const int u0 = rc * rch, u1 = u0 + rch < npairs ? u0 + rch : npairs;
     if (u0 >= npairs) return;
-    // Sliding window: consecutive units share half of their slices (DOWN: the two lower input rows of one output row are the two upper
-    // ones of the next; UP: row m of one pair is row m - 1 of the next), so a unit loads only its NKS / 2 NEW slices -- requested one
-    // unit ahead -- and the window shifts in registers.
-    constexpr int NNEW = NKS / 2;
-    // slice index -> window position: DOWN keeps slices in ascending row order (new ones enter at the top end), UP has slice 0 = row m
-    // (new) and slice 1 = row m - 1 (the previous unit's slice 0)
+    // window positions: DOWN keeps the slices in ascending row order (new ones enter at the top end); UP has the slices of row m first
+    // (new), then those of row m - 1 (the previous unit's first half)
     e16x8 bh[NKS], bl[NKS], nh[NNEW], nl[NNEW];
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) { bh[ks] = ldb(u0, ks, 0); bl[ks] = ldb(u0, ks, 1); }
+    for (int ks = 0; ks < NKS; ++ks) ldb(u0, ks, bh[ks], bl[ks]);
     for (int u = u0; u < u1; ++u) {
         if (u + 1 < u1) {
 #pragma unroll
-            for (int i = 0; i < NNEW; ++i) {
-                const int ks = UP ? i : NNEW + i;                // the slices of unit u + 1 that unit u does not hold
-                nh[i] = ldb(u + 1, ks, 0); nl[i] = ldb(u + 1, ks, 1);
-            }
+            for (int i = 0; i < NNEW; ++i) ldb(u + 1, UP ? i : NKS - NNEW + i, nh[i], nl[i]);   // the slices unit u does not hold
         }
 #pragma unroll
         for (int st_ = 0; st_ < NSET; ++st_) {
@@ -477,7 +486,10 @@ __global__ __launch_bounds__(NT, (CIN == 32 && !UP) ? 2 : 4) void k_x3_sconv(con
             }
         }
         // shift the window
-        if constexpr (UP) {
+        if constexpr (NNEW == NKS) {
+#pragma unroll
+            for (int i = 0; i < NKS; ++i) { bh[i] = nh[i]; bl[i] = nl[i]; }
+        } else if constexpr (UP) {
 #pragma unroll
             for (int i = 0; i < NNEW; ++i) { bh[NNEW + i] = bh[i]; bl[NNEW + i] = bl[i]; bh[i] = nh[i]; bl[i] = nl[i]; }
         } else {
@@ -487,8 +499,8 @@ __global__ __launch_bounds__(NT, (CIN == 32 && !UP) ? 2 : 4) void k_x3_sconv(con
     }
 }
 
-template <int CIN, bool UP, bool PLANAR>
-int launch_x3s(const e16* x, const float* w, const float* bias, void* y, int B, int Hin, int Hout, int T, hipStream_t st) {
+template <int CIN, bool UP, bool PIN>
+int launch_x3s(const void* x, const float* w, const float* bias, void* y, bool planar_out, int B, int Hin, int Hout, int T, hipStream_t st) {
     using S = XS<CIN, UP>;
     // a task = (clip, 64 frames, co split, run of output rows): runs as long as the grid still holds ~16 workgroups per CU (the weight
     // split at the head of a workgroup is amortised over the run), never shorter than 8 rows
@@ -500,7 +512,231 @@ int launch_x3s(const e16* x, const float* w, const float* bias, void* y, int B, 
     const int rch = (int)((units + want - 1) / want), nchunks = (units + rch - 1) / rch;
     const long grid = base * nchunks;
     if (grid > 0x7fffffffl) return TT_E_UNSUPPORTED;
-    hipLaunchKernelGGL((k_x3_sconv<CIN, UP, PLANAR>), dim3((unsigned)grid), dim3(NT), 0, st, x, w, bias, y, B, Hin, Hout, T, nchunks, rch);
+    if (planar_out)
+        hipLaunchKernelGGL((k_x3_sconv<CIN, UP, PIN, true>), dim3((unsigned)grid), dim3(NT), 0, st, x, w, bias, y, B, Hin, Hout, T, nchunks, rch);
+    else
+        hipLaunchKernelGGL((k_x3_sconv<CIN, UP, PIN, false>), dim3((unsigned)grid), dim3(NT), 0, st, x, w, bias, y, B, Hin, Hout, T, nchunks, rch);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- latent heads ---------------------------------------------------------------------------------------------------------------------
+// Encoder.convlat = Conv2d(C, D, (E,1)) (reference modules.py:446): z[d][t] = b[d] + sum_{e,c} W[d][c][e] x[c][e][t], and Decoder.convin =
+// ELU(ConvTranspose2d(D + 1, C, (E,1))) (modules.py:534): y[co][e][t] = ELU(b[co] + sum_d W[d][co][e] z[d][t]) -- per frame a
+// (D x C E) and a (C E x D + 1) matrix-vector product; the fp32 GEMM runs them at 46 % of the fp32 matrix peak (0.69 ms each at the
+// inference batch).  With split operands they are memory-bound: the x3 embedding (E rows of C channels) is read / written once.
+// The weights are split ONCE per call into an operand-order image (k_x3_lat_wprep: [step][slice][co-tile][plane][lane] x 16 bytes; a
+// step = one frequency row e) which every workgroup streams through LDS by LDS-DMA, double-buffered, one step ahead; a workgroup =
+// eight waves = 128 consecutive frames of one clip.
+//   encode: the K loop runs over the E rows (B operands straight from the x3 tensor, one row ahead), all D outputs accumulate in
+//           registers (D / 16 co-tiles x two accumulator sets);
+//   decode: the latent vector of the wave's 16 frames is split once into registers (K = D), the loop runs over the E OUTPUT rows; the
+//           extra input channel (the transcription switch, D + 1) enters as a rank-1 term on the vector pipe.
+template <int C, int D> struct XLat {
+    static constexpr int SPR = C / 32;                           // K = 32 slices per frequency row (encode)
+    static constexpr int KS = D / 32;                            // K = 32 slices of the latent vector (decode)
+    static constexpr int NCT_E = D / 16, NCT_D = C / 16;         // co-tiles: encode (latent channels), decode (embedding channels)
+    static constexpr int ENT_E = SPR * NCT_E, ENT_D = KS * NCT_D;     // 2-KB image entries (hi + lo plane of one operand) per step
+};
+constexpr int XLAT_NT = 512;
+
+// MODE 0: encode image from w (D, C, E, 1); MODE 1: decode image from w (D + 1, C, E, 1) (rows d < D)
+template <int C, int D, int MODE>
+__global__ __launch_bounds__(256) void k_x3_lat_wprep(const float* __restrict__ w, unsigned char* __restrict__ img, int E) {
+    using L = XLat<C, D>;
+    constexpr int ENT = MODE == 0 ? L::ENT_E : L::ENT_D, NCT = MODE == 0 ? L::NCT_E : L::NCT_D;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= E * ENT * 64) return;
+    const int l = i & 63, ent = (i >> 6) % ENT, e = i / (64 * ENT);
+    const int ct = ent % NCT, ks = ent / NCT, ln = l & 15, lg = l >> 4;
+    e16x8 qh, ql;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float wv;
+        if (MODE == 0) wv = w[((long)(16 * ct + ln) * C + 32 * ks + 8 * lg + j) * E + e];
+        else {
+            const int co = C == 32 ? 8 * (ln >> 2) + 4 * ct + (ln & 3) : 16 * (ln >> 2) + 4 * ct + (ln & 3);
+            wv = w[((long)(32 * ks + 8 * lg + j) * C + co) * E + e];
+        }
+        e16 h, lo_; split(wv, h, lo_); qh[j] = h; ql[j] = lo_;
+    }
+    unsigned char* dst = img + ((long)(e * ENT + ent) * 2) * 1024 + l * 16;
+    *reinterpret_cast<e16x8*>(dst) = qh;
+    *reinterpret_cast<e16x8*>(dst + 1024) = ql;
+}
+
+template <int C, int D>
+__global__ __launch_bounds__(XLAT_NT, 2) void k_x3_latenc(const e16* __restrict__ x, const unsigned char* __restrict__ img,
+                                                          const float* __restrict__ bias, float* __restrict__ z, int B, int E, int T) {
+    using L = XLat<C, D>;
+    constexpr int SPR = L::SPR, NCT = L::NCT_E, STEP = L::ENT_E * 2048;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+    const int tgroups = (T + 127) / 128;
+    const int tg = blockIdx.x % tgroups, b = blockIdx.x / tgroups;
+    const int t = tg * 128 + wave * 16 + n;
+    const bool tv = t < T;
+    const int tc = tv ? t : T - 1;
+    auto stage = [&](int e, int buf) {
+        for (int i = wave * 1024; i < STEP; i += XLAT_NT * 16) glds16(img + (long)e * STEP + i + lane * 16, smem + buf * STEP + i);
+    };
+    f32x4 am[NCT], al[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        am[ct] = bias ? f32x4{bias[16 * ct + 4 * g], bias[16 * ct + 4 * g + 1], bias[16 * ct + 4 * g + 2], bias[16 * ct + 4 * g + 3]}
+                      : f32x4{0.f, 0.f, 0.f, 0.f};
+        al[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const e16* xb = x + ((long)b * E * T + tc) * 2 * C + 8 * g;
+    e16x8 bh[SPR], bl[SPR], nh[SPR], nl[SPR];
+#pragma unroll
+    for (int s_ = 0; s_ < SPR; ++s_) { bh[s_] = *reinterpret_cast<const e16x8*>(xb + 32 * s_); bl[s_] = *reinterpret_cast<const e16x8*>(xb + C + 32 * s_); }
+    stage(0, 0);
+    for (int e = 0; e < E; ++e) {
+        const int buf = e & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                         // step e has landed; everyone has left step e - 1 (buffer buf ^ 1)
+        if (e + 1 < E) {
+            stage(e + 1, buf ^ 1);
+            const e16* xn = xb + (long)(e + 1) * T * 2 * C;
+#pragma unroll
+            for (int s_ = 0; s_ < SPR; ++s_) { nh[s_] = *reinterpret_cast<const e16x8*>(xn + 32 * s_); nl[s_] = *reinterpret_cast<const e16x8*>(xn + C + 32 * s_); }
+        }
+        const unsigned char* A = smem + buf * STEP;
+#pragma unroll
+        for (int s_ = 0; s_ < SPR; ++s_)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const e16x8 wh = *reinterpret_cast<const e16x8*>(A + ((s_ * NCT + ct) * 2) * 1024 + lane * 16);
+                const e16x8 wl = *reinterpret_cast<const e16x8*>(A + ((s_ * NCT + ct) * 2 + 1) * 1024 + lane * 16);
+                am[ct] = mma32(wh, bh[s_], am[ct]);
+                al[ct] = mma32(wh, bl[s_], al[ct]);
+                al[ct] = mma32(wl, bh[s_], al[ct]);
+            }
+#pragma unroll
+        for (int s_ = 0; s_ < SPR; ++s_) { bh[s_] = nh[s_]; bl[s_] = nl[s_]; }
+    }
+    if (!tv) return;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z[((long)b * D + 16 * ct + 4 * g + r) * T + t] = __builtin_fmaf(al[ct][r], LO_INV, am[ct][r]);
+}
+
+template <int C, int D, bool PLANAR>
+__global__ __launch_bounds__(XLAT_NT, 2) void k_x3_latdec(const float* __restrict__ z, int Dz, float fill, const float* __restrict__ w,
+                                                          const unsigned char* __restrict__ img, const float* __restrict__ bias,
+                                                          void* __restrict__ yout, int B, int E, int T) {
+    using L = XLat<C, D>;
+    constexpr int KS = L::KS, NCT = L::NCT_D, STEP = L::ENT_D * 2048, NCH = C == 32 ? 8 : 16;
+    extern __shared__ __align__(16) unsigned char smem[];
+    float* wx = reinterpret_cast<float*>(smem + 2 * STEP);       // [E][C]: the weights of the extra input channel
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+    const int tgroups = (T + 127) / 128;
+    const int tg = blockIdx.x % tgroups, b = blockIdx.x / tgroups;
+    const int t = tg * 128 + wave * 16 + n;
+    const bool tv = t < T;
+    const int tc = tv ? t : T - 1;
+    auto stage = [&](int e, int buf) {
+        for (int i = wave * 1024; i < STEP; i += XLAT_NT * 16) glds16(img + (long)e * STEP + i + lane * 16, smem + buf * STEP + i);
+    };
+    stage(0, 0);
+    for (int i = threadIdx.x; i < E * C; i += XLAT_NT) { const int e = i / C, co = i - e * C; wx[i] = w[((long)D * C + co) * E + e]; }
+    // the latent vector of this wave's frames, split once
+    e16x8 bh[KS], bl[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = z[((long)b * Dz + 32 * ks + 8 * g + j) * T + tc];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { e16 h, l; split(f[j], h, l); bh[ks][j] = h; bl[ks][j] = l; }
+    }
+    const float zx = Dz > D ? z[((long)b * Dz + D) * T + tc] : fill;
+    auto cmap = [&](int ct, int m) { return C == 32 ? 8 * (m >> 2) + 4 * ct + (m & 3) : 16 * (m >> 2) + 4 * ct + (m & 3); };
+    float br[NCT][4];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) br[ct][r] = bias ? bias[cmap(ct, 4 * g + r)] : 0.f;
+    const int chbase = NCH * g;                                  // the lane's NCH consecutive channels: cmap(ct, 4 g + r) = chbase + 4 ct + r
+    for (int e = 0; e < E; ++e) {
+        const int buf = e & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (e + 1 < E) stage(e + 1, buf ^ 1);
+        const unsigned char* A = smem + buf * STEP;
+        f32x4 am[NCT], al[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) { am[ct] = f32x4{br[ct][0], br[ct][1], br[ct][2], br[ct][3]}; al[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const e16x8 wh = *reinterpret_cast<const e16x8*>(A + ((ks * NCT + ct) * 2) * 1024 + lane * 16);
+                const e16x8 wl = *reinterpret_cast<const e16x8*>(A + ((ks * NCT + ct) * 2 + 1) * 1024 + lane * 16);
+                am[ct] = mma32(wh, bh[ks], am[ct]);
+                al[ct] = mma32(wh, bl[ks], al[ct]);
+                al[ct] = mma32(wl, bh[ks], al[ct]);
+            }
+        if (!tv) continue;
+        float out[NCH];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                out[4 * ct + r] = elu1(__builtin_fmaf(wx[e * C + chbase + 4 * ct + r], zx, __builtin_fmaf(al[ct][r], LO_INV, am[ct][r])));
+        if constexpr (PLANAR) {
+            float* yp = static_cast<float*>(yout) + (((long)b * C + chbase) * E + e) * T + t;
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) yp[(long)j * E * T] = out[j];
+        } else {
+            e16* y = static_cast<e16*>(yout) + (((long)b * E + e) * T + t) * 2 * C + chbase;
+#pragma unroll
+            for (int q = 0; q < NCH / 8; ++q) {
+                e16x8 oh, ol;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { e16 a_, b_; split(out[8 * q + j], a_, b_); oh[j] = a_; ol[j] = b_; }
+                *reinterpret_cast<e16x8*>(y + 8 * q) = oh;
+                *reinterpret_cast<e16x8*>(y + C + 8 * q) = ol;
+            }
+        }
+    }
+}
+
+template <int C, int D>
+int launch_latenc(const e16* x, const float* w, const float* bias, float* z, unsigned char* ws, int B, int E, int T, hipStream_t st) {
+    using L = XLat<C, D>;
+    const int n = E * L::ENT_E * 64;
+    hipLaunchKernelGGL((k_x3_lat_wprep<C, D, 0>), dim3((n + 255) / 256), dim3(256), 0, st, w, ws, E);
+    TT_LAUNCH_CHECK();
+    static AttrOnce once;
+    auto kern = k_x3_latenc<C, D>;
+    constexpr int LDS = 2 * L::ENT_E * 2048;
+    if (int rc = raise_lds(kern, LDS, once)) return rc;
+    hipLaunchKernelGGL(kern, dim3(B * ((T + 127) / 128)), dim3(XLAT_NT), LDS, st, x, (const unsigned char*)ws, bias, z, B, E, T);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+template <int C, int D>
+int launch_latdec(const float* z, int Dz, float fill, const float* w, const float* bias, void* y, bool planar, unsigned char* ws, int B,
+                  int E, int T, hipStream_t st) {
+    using L = XLat<C, D>;
+    const int n = E * L::ENT_D * 64;
+    hipLaunchKernelGGL((k_x3_lat_wprep<C, D, 1>), dim3((n + 255) / 256), dim3(256), 0, st, w, ws, E);
+    TT_LAUNCH_CHECK();
+    const int LDS = 2 * L::ENT_D * 2048 + E * C * 4;
+    static AttrOnce once_p, once_x;
+    const dim3 grid(B * ((T + 127) / 128));
+    if (planar) {
+        auto kern = k_x3_latdec<C, D, true>;
+        if (int rc = raise_lds(kern, 160 * 1024, once_p)) return rc;
+        hipLaunchKernelGGL(kern, grid, dim3(XLAT_NT), LDS, st, z, Dz, fill, w, (const unsigned char*)ws, bias, y, B, E, T);
+    } else {
+        auto kern = k_x3_latdec<C, D, false>;
+        if (int rc = raise_lds(kern, 160 * 1024, once_x)) return rc;
+        hipLaunchKernelGGL(kern, grid, dim3(XLAT_NT), LDS, st, z, Dz, fill, w, (const unsigned char*)ws, bias, y, B, E, T);
+    }
     TT_LAUNCH_CHECK();
     return 0;
 }
@@ -575,23 +811,50 @@ int tt_x3_level_fwd(int nblocks, const void* x, int x3_in, void* y, int x3_out, 
     return 0;
 }
 
-int tt_x3_sconv_fwd(const void* x, const float* w, const float* bias, void* y, int planar_out, int B, int C, int H, int T, void* stream) {
-    if (!x || !w || !bias || !y || !x3_shape_ok(B, C, H, T) || H < 4) return TT_E_BADARG;
+int tt_x3_sconv_fwd(const void* x, int planar_in, const float* w, const float* bias, void* y, int planar_out, int B, int C, int H, int T,
+                    void* stream) {
+    if (!x || !w || !bias || !y || B <= 0 || T <= 0 || H < 4) return TT_E_BADARG;
     const int Hout = (H - 4) / 2 + 1;
     hipStream_t st = tt_stream(stream);
-    const e16* xi = (const e16*)x;
-    if (C == 16) return planar_out ? launch_x3s<16, false, true>(xi, w, bias, y, B, H, Hout, T, st) : launch_x3s<16, false, false>(xi, w, bias, y, B, H, Hout, T, st);
-    return planar_out ? launch_x3s<32, false, true>(xi, w, bias, y, B, H, Hout, T, st) : launch_x3s<32, false, false>(xi, w, bias, y, B, H, Hout, T, st);
+    if (planar_in) return C == 8 ? launch_x3s<8, false, true>(x, w, bias, y, planar_out, B, H, Hout, T, st) : TT_E_UNSUPPORTED;
+    if (C == 16) return launch_x3s<16, false, false>(x, w, bias, y, planar_out, B, H, Hout, T, st);
+    if (C == 32) return launch_x3s<32, false, false>(x, w, bias, y, planar_out, B, H, Hout, T, st);
+    return TT_E_UNSUPPORTED;
 }
 
-int tt_x3_tconv_fwd(const void* x, const float* w, const float* bias, void* y, int planar_out, int B, int C, int H, int T, int out_pad,
-                    void* stream) {
+int tt_x3_tconv_fwd(const void* x, int planar_in, const float* w, const float* bias, void* y, int planar_out, int B, int C, int H, int T,
+                    int out_pad, void* stream) {
     if (!x || !w || !bias || !y || B <= 0 || H <= 0 || T <= 0 || (out_pad != 0 && out_pad != 1)) return TT_E_BADARG;
-    if (C != 16) return TT_E_UNSUPPORTED;                        // C = output channels; input 2 C = 32
-    const int Hout = 2 * H + 2 + out_pad;
+    const int Hout = 2 * H + 2 + out_pad;                        // C = output channels; the input has 2 C
     hipStream_t st = tt_stream(stream);
-    const e16* xi = (const e16*)x;
-    return planar_out ? launch_x3s<32, true, true>(xi, w, bias, y, B, H, Hout, T, st) : launch_x3s<32, true, false>(xi, w, bias, y, B, H, Hout, T, st);
+    if (planar_in) return C == 32 ? launch_x3s<64, true, true>(x, w, bias, y, planar_out, B, H, Hout, T, st) : TT_E_UNSUPPORTED;
+    if (C == 32) return launch_x3s<64, true, false>(x, w, bias, y, planar_out, B, H, Hout, T, st);
+    return C == 16 ? launch_x3s<32, true, false>(x, w, bias, y, planar_out, B, H, Hout, T, st) : TT_E_UNSUPPORTED;
+}
+
+int64_t tt_x3_latent_scratch_bytes(int C, int E, int D) {
+    if (!((C == 64 && D == 128) || (C == 32 && D == 32)) || E < 1) return -1;
+    const int64_t enc = (int64_t)E * (C / 32) * (D / 16) * 2048, dec = (int64_t)E * (D / 32) * (C / 16) * 2048;
+    return enc > dec ? enc : dec;
+}
+
+int tt_x3_latent_encode(const void* x, const float* w, const float* bias, float* z, void* ws, int B, int C, int E, int D, int T,
+                        void* stream) {
+    if (!x || !w || !z || !ws || B <= 0 || E <= 0 || T <= 0) return TT_E_BADARG;
+    hipStream_t st = tt_stream(stream);
+    if (C == 64 && D == 128) return launch_latenc<64, 128>((const e16*)x, w, bias, z, (unsigned char*)ws, B, E, T, st);
+    if (C == 32 && D == 32) return launch_latenc<32, 32>((const e16*)x, w, bias, z, (unsigned char*)ws, B, E, T, st);
+    return TT_E_UNSUPPORTED;
+}
+
+int tt_x3_latent_decode(const float* z, int Dz, float fill, const float* w, const float* bias, void* y, int planar_out, void* ws, int B,
+                        int C, int E, int D, int T, void* stream) {
+    if (!z || !w || !y || !ws || B <= 0 || E <= 0 || T <= 0 || (Dz != D && Dz != D + 1)) return TT_E_BADARG;
+    if ((int64_t)E * C * 4 + 2 * (int64_t)(D / 32) * (C / 16) * 2048 > 160 * 1024) return TT_E_UNSUPPORTED;
+    hipStream_t st = tt_stream(stream);
+    if (C == 64 && D == 128) return launch_latdec<64, 128>(z, Dz, fill, w, bias, y, planar_out != 0, (unsigned char*)ws, B, E, T, st);
+    if (C == 32 && D == 32) return launch_latdec<32, 32>(z, Dz, fill, w, bias, y, planar_out != 0, (unsigned char*)ws, B, E, T, st);
+    return TT_E_UNSUPPORTED;
 }
 
 int64_t tt_x3_level_scratch_bytes(int B, int C, int H, int T) {

@@ -67,8 +67,11 @@ _PROTOS = {
     'tt_x3_unpack': (c_int, [P, P, I, I, I, I, P]),
     'tt_x3_rb_fwd': (c_int, [P, P, P, P, P, P, I, I, I, I, I, I, P]),
     'tt_x3_level_fwd': (c_int, [I, P, I, P, I, P, P, P, P, P, P, I, I, I, I, P]),
-    'tt_x3_sconv_fwd': (c_int, [P, P, P, P, I, I, I, I, I, P]),
-    'tt_x3_tconv_fwd': (c_int, [P, P, P, P, I, I, I, I, I, I, P]),
+    'tt_x3_latent_scratch_bytes': (c_int64, [I, I, I]),
+    'tt_x3_latent_encode': (c_int, [P, P, P, P, P, I, I, I, I, I, P]),
+    'tt_x3_latent_decode': (c_int, [P, I, c_float, P, P, P, I, P, I, I, I, I, I, P]),
+    'tt_x3_sconv_fwd': (c_int, [P, I, P, P, P, I, I, I, I, I, P]),
+    'tt_x3_tconv_fwd': (c_int, [P, I, P, P, P, I, I, I, I, I, I, P]),
     'tt_wide_fused_scratch_bytes': (c_int64, [I]),
     'tt_wide_rb_bwd_fused': (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
     'tt_wide_onepass_scratch_bytes': (c_int64, [I]),

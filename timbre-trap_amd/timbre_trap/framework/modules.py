@@ -139,11 +139,15 @@ class Encoder(nn.Module):
         for i, block in enumerate(blocks):
             # inside ops.x3_chain_scope (embeddings dropped by the caller): a block whose successor starts with a split-operand level
             # hands its output over in that layout
-            nxt = blocks[i + 1].block1.conv1[0].in_channels if i + 1 < len(blocks) else 0
-            embeddings.append(block(embeddings[-1], out_x3=ops.x3_chain() and nxt in ops.X3_CHANNELS))
-        top = ops.to_planar32(embeddings[-1])
-        if top.size(-2) != self.convlat.kernel_size[0]:
-            raise ValueError('feature size %d does not match the latent head (%d)' % (top.size(-2), self.convlat.kernel_size[0]))
+            if i + 1 < len(blocks):
+                takes_x3 = blocks[i + 1].block1.conv1[0].in_channels in ops.X3_CHANNELS
+            else:                                                # the latent head
+                takes_x3 = ops.x3_latent_ok(block.sconv[0].out_channels, self.convlat.out_channels, w_enc=self.convlat.weight)
+            embeddings.append(block(embeddings[-1], out_x3=ops.x3_chain() and takes_x3))
+        top = embeddings[-1]
+        E = top.size(1) if ops.is_x3(top) else top.size(-2)
+        if E != self.convlat.kernel_size[0]:
+            raise ValueError('feature size %d does not match the latent head (%d)' % (E, self.convlat.kernel_size[0]))
         latents = ops.latent_encode(top, self.convlat.weight, self.convlat.bias)
         return latents, embeddings, dict()
 
@@ -177,15 +181,17 @@ class Decoder(nn.Module):
         """``indicator``: None (latents carry the switch channel, the reference's call) or its constant value (then latents have
         one channel less and ops.latent_decode supplies it)."""
         c = self.convin[0]
-        y = ops.latent_decode(latents, c.weight, c.bias, indicator)
         skips = None if encoder_embeddings is None else list(encoder_embeddings)[::-1]
+        # (inside ops.x3_chain_scope, no skip connections: the head hands a split-operand tensor to block1's transposed layer)
+        y = ops.latent_decode(latents, c.weight, c.bias, indicator,
+                              out_x3=skips is None and ops.x3_chain() and self.block1.tconv[0].out_channels in ops.X3_CHANNELS)
         if skips is not None:
             y = ops.add(y, skips[0])
         blocks = (self.block1, self.block2, self.block3, self.block4)
         for i, block in enumerate(blocks):
-            # the one transposed layer with a split-operand kernel is 32 -> 16 channels (tt_x3_tconv_fwd)
+            # transposed layers with a split-operand kernel: 64 -> 32 and 32 -> 16 channels (tt_x3_tconv_fwd)
             t = blocks[i + 1].tconv[0] if i + 1 < len(blocks) else None
-            y = block(y, out_x3=skips is None and ops.x3_chain() and t is not None and (t.in_channels, t.out_channels) == (32, 16))
+            y = block(y, out_x3=skips is None and ops.x3_chain() and t is not None and (t.in_channels, t.out_channels) in ((64, 32), (32, 16)))
             if skips is not None:
                 y = ops.add(y, skips[i + 1])
         o = self.convout

@@ -383,13 +383,16 @@ def strided_conv(x, w, b, win, hop, out_x3=False):
     if is_x3(x):
         C = x.size(4)
         if win == 4 and hop == 2 and x.size(1) >= 4 and C in X3_CHANNELS and w.shape == (2 * C, C, 4, 1) and b is not None:
-            return x3_strided_conv(x, w, b, out_x3 and 2 * C in X3_CHANNELS)
+            return x3_strided_conv(x, w, b, out_x3)
         x = from_x3(x)
     C = x.size(1)
     if (win == 4 and hop == 2 and x.size(2) >= 4 and _stride16_ok(C, x.size(-1), w, b) and (is_cl16(x) or cl16_mode())
             and _i32_ok(x, 2 * C)):
         return SConv16Fn.apply(to_cl16(x), w, b)
     x = to_planar32(x)
+    if (out_x3 and x3_chain() and C == 8 and 2 * C in X3_CHANNELS and win == 4 and hop == 2 and x.size(2) >= 4 and x.is_cuda
+            and w.shape == (2 * C, C, 4, 1) and b is not None):
+        return x3_strided_conv(x, w, b, True)                    # the layer that enters the split-operand part of the encoder
     if FUSED_RESBLOCK and win == 4 and hop == 2 and C in FUSED_CHANNELS and w.shape == (2 * C, C, 4, 1) and b is not None:
         return StridedConvFn.apply(x, w, b)
     return conv(x, w, b, ConvCfg(win, 1, hop, 1, 0, 0, 'conv', 0, ACT_ELU))
@@ -399,13 +402,17 @@ def transposed_conv(x, w, b, win, hop, out_pad, out_x3=False):
     """ConvTranspose2d(Cin, C, (win,1), stride (hop,1), output_padding (out_pad,0)) + ELU.  x may be an x3 tensor."""
     C = w.size(1)
     if is_x3(x):
-        if (win == 4 and hop == 2 and C == 16 and x.size(4) == 32 and w.shape == (32, 16, 4, 1) and b is not None and out_pad in (0, 1)):
+        if (win == 4 and hop == 2 and C in (16, 32) and x.size(4) == 2 * C and w.shape == (2 * C, C, 4, 1) and b is not None
+                and out_pad in (0, 1)):
             return x3_transposed_conv(x, w, b, out_pad, out_x3)
         x = from_x3(x)
     if (win == 4 and hop == 2 and x.size(1) == 2 * C and out_pad in (0, 1) and _stride16_ok(C, x.size(-1), w, b)
             and (is_cl16(x) or cl16_mode()) and (2 * x.size(2) + 2 + out_pad) * x.size(3) * 2 * C < 2 ** 31):
         return TConv16Fn.apply(to_cl16(x), w, b, out_pad)
     x = to_planar32(x)
+    if (out_x3 and x3_chain() and C == 32 and x.size(1) == 64 and win == 4 and hop == 2 and x.is_cuda and w.shape == (64, 32, 4, 1)
+            and b is not None and out_pad in (0, 1)):
+        return x3_transposed_conv(x, w, b, out_pad, True)        # the layer that enters the split-operand part of the decoder
     if (FUSED_RESBLOCK and win == 4 and hop == 2 and C in FUSED_CHANNELS and w.shape == (2 * C, C, 4, 1)
             and x.size(1) == 2 * C and b is not None and out_pad in (0, 1)):
         return TransposedConvFn.apply(x, w, b, out_pad)
@@ -988,26 +995,42 @@ def x3_level(x, blocks, out_x3=False):
 
 
 def x3_strided_conv(x, w, b, out_x3):
-    """EncoderBlock.sconv on an x3 tensor (tt_x3_sconv_fwd): returns x3 (B, Hout, T, 2, 2C) or fp32 planar (B, 2C, Hout, T)."""
-    B, H, T, _, C = x.shape
+    """EncoderBlock.sconv with split operands (tt_x3_sconv_fwd).  x: an x3 tensor (C = 16, 32) or fp32 planar (C = 8: the layer that
+    enters the split-operand part); returns x3 (B, Hout, T, 2, 2C) or fp32 planar (B, 2C, Hout, T)."""
+    pin = not is_x3(x)
+    if pin:
+        x = _f32c(x)
+        B, C, H, T = x.shape
+    else:
+        B, H, T, _, C = x.shape
     Ho = (H - 4) // 2 + 1
     w, b = _f32c(w.detach()), _f32c(b.detach())
+    _hip.require_cuda(x, w)
     y = (torch.empty((B, Ho, T, 2, 2 * C), dtype=torch.float16, device=x.device) if out_x3
          else torch.empty((B, 2 * C, Ho, T), dtype=torch.float32, device=x.device))
     with _hip.timed('x3_sconv_C%d' % C):
-        check(_hip.lib().tt_x3_sconv_fwd(ptr(x), ptr(w), ptr(b), ptr(y), int(not out_x3), B, C, H, T, stream_ptr()), 'tt_x3_sconv_fwd')
+        check(_hip.lib().tt_x3_sconv_fwd(ptr(x), int(pin), ptr(w), ptr(b), ptr(y), int(not out_x3), B, C, H, T, stream_ptr()),
+              'tt_x3_sconv_fwd')
     return y
 
 
 def x3_transposed_conv(x, w, b, out_pad, out_x3):
-    """DecoderBlock.tconv on an x3 tensor with 2C = 32 channels (tt_x3_tconv_fwd): x3 (B, Hout, T, 2, C) or fp32 planar."""
-    B, H, T, _, C2 = x.shape
+    """DecoderBlock.tconv with split operands (tt_x3_tconv_fwd).  x: an x3 tensor with 2C = 32 channels or fp32 planar with 2C = 64;
+    returns x3 (B, Hout, T, 2, C) or fp32 planar (B, C, Hout, T)."""
+    pin = not is_x3(x)
+    if pin:
+        x = _f32c(x)
+        B, C2, H, T = x.shape
+    else:
+        B, H, T, _, C2 = x.shape
     C, Ho = C2 // 2, 2 * H + 2 + out_pad
     w, b = _f32c(w.detach()), _f32c(b.detach())
+    _hip.require_cuda(x, w)
     y = (torch.empty((B, Ho, T, 2, C), dtype=torch.float16, device=x.device) if out_x3
          else torch.empty((B, C, Ho, T), dtype=torch.float32, device=x.device))
     with _hip.timed('x3_tconv_C%d' % C):
-        check(_hip.lib().tt_x3_tconv_fwd(ptr(x), ptr(w), ptr(b), ptr(y), int(not out_x3), B, C, H, T, out_pad, stream_ptr()), 'tt_x3_tconv_fwd')
+        check(_hip.lib().tt_x3_tconv_fwd(ptr(x), int(pin), ptr(w), ptr(b), ptr(y), int(not out_x3), B, C, H, T, out_pad, stream_ptr()),
+              'tt_x3_tconv_fwd')
     return y
 
 
@@ -1172,19 +1195,66 @@ class LatDec16Fn(torch.autograd.Function):
         return dz, rw, rb, None
 
 
+X3_LATENT_SHAPES = ((64, 128), (32, 32))          # (channels of the top embedding, latent size) with split-operand latent heads
+
+
+def x3_latent_ok(C, D, w_enc=None, w_dec=None):
+    return ((C, D) in X3_LATENT_SHAPES and (w_enc is None or (w_enc.dim() == 4 and w_enc.shape[:2] == (D, C) and w_enc.size(3) == 1))
+            and (w_dec is None or (w_dec.dim() == 4 and w_dec.shape[:2] == (D + 1, C) and w_dec.size(3) == 1)))
+
+
+def x3_latent_encode(top, w, b):
+    """Encoder.convlat on an x3 embedding (B, E, T, 2, C) -> latents (B, D, T) fp32 (tt_x3_latent_encode)."""
+    B, E, T, _, C = top.shape
+    D = w.size(0)
+    lib = _hip.lib()
+    w = _f32c(w.detach())
+    b = None if b is None else _f32c(b.detach())
+    ws = torch.empty(lib.tt_x3_latent_scratch_bytes(C, E, D), dtype=torch.uint8, device=top.device)
+    z = torch.empty((B, D, T), dtype=torch.float32, device=top.device)
+    with _hip.timed('x3_latent_encode'):
+        check(lib.tt_x3_latent_encode(ptr(top), ptr(w), ptr(b), ptr(z), ptr(ws), B, C, E, D, T, stream_ptr()), 'tt_x3_latent_encode')
+    return z
+
+
+def x3_latent_decode(z, w, b, fill, out_x3):
+    """Decoder.convin + ELU with split operands: latents (B, D or D + 1, T) fp32 -> x3 (B, E, T, 2, C) or fp32 planar (tt_x3_latent_decode)."""
+    z = _f32c(z)
+    B, Dz, T = z.shape
+    D, C, E = w.size(0) - 1, w.size(1), w.size(2)
+    lib = _hip.lib()
+    w = _f32c(w.detach())
+    b = None if b is None else _f32c(b.detach())
+    ws = torch.empty(lib.tt_x3_latent_scratch_bytes(C, E, D), dtype=torch.uint8, device=z.device)
+    y = (torch.empty((B, E, T, 2, C), dtype=torch.float16, device=z.device) if out_x3
+         else torch.empty((B, C, E, T), dtype=torch.float32, device=z.device))
+    with _hip.timed('x3_latent_decode'):
+        check(lib.tt_x3_latent_decode(ptr(z), Dz, float(fill) if fill is not None else 0.0, ptr(w), ptr(b), ptr(y), int(not out_x3), ptr(ws),
+                                      B, C, E, D, T, stream_ptr()), 'tt_x3_latent_decode')
+    return y
+
+
 def latent_encode(top, w, b):
     """Encoder.convlat (modules.py:446)."""
+    if is_x3(top):
+        if x3_latent_ok(top.size(4), w.size(0), w_enc=w) and w.size(2) == top.size(1):
+            return x3_latent_encode(top, w, b)
+        top = from_x3(top)
     if is_cl16(top) and _f32ok(w) and _lat16_ok(top.size(1), w.size(0), top.size(2), top.size(3), b) and w.shape[1:] == (top.size(1), top.size(2), 1):
         return LatEnc16Fn.apply(top, w, b)
     return LatentEncodeFn.apply(to_planar32(top), w, b)
 
 
-def latent_decode(z, w, b, fill=None):
+def latent_decode(z, w, b, fill=None, out_x3=False):
     """
     Decoder.convin (modules.py:534) + ELU; cl16 output in the bf16 mode.  ``fill``: value of a constant last input channel that z
-    does not carry (see LatDec16Fn); on the fp32 path the channel is concatenated like the reference does.
+    does not carry (see LatDec16Fn); on the fp32 path the channel is concatenated like the reference does.  ``out_x3`` (inside
+    ops.x3_chain_scope): the next layer takes a split-operand tensor.
     """
     Dz = z.size(1) + (fill is not None)
+    if (out_x3 and x3_chain() and z.dim() == 3 and z.is_cuda and w.size(0) == Dz and x3_latent_ok(w.size(1), Dz - 1, w_dec=w)
+            and w.size(2) * w.size(1) * 4 + 2 * ((Dz - 1) // 32) * (w.size(1) // 16) * 2048 <= 160 * 1024):
+        return x3_latent_decode(z, w, b, fill, True)
     if (cl16_mode() and FUSED_RESBLOCK and _f32ok(w) and z.dim() == 3 and w.size(0) == Dz and w.size(3) == 1
             and _lat16_ok(w.size(1), w.size(0), w.size(2), z.size(2), b)):
         return LatDec16Fn.apply(z, w, b, fill)

@@ -61,8 +61,8 @@ def main():
         Ho = (H - 4) // 2 + 1
         y3 = torch.empty((B, Ho, T, 2, 2 * C), dtype=torch.float16, device='cuda')
         yp = torch.empty((B, 2 * C, Ho, T), device='cuda')
-        ms3 = timeit(lambda: check(lib.tt_x3_sconv_fwd(ptr(a), ptr(wS), ptr(bS), ptr(y3), 0, B, C, H, T, st), 's'), n)
-        msp = timeit(lambda: check(lib.tt_x3_sconv_fwd(ptr(a), ptr(wS), ptr(bS), ptr(yp), 1, B, C, H, T, st), 's'), n)
+        ms3 = timeit(lambda: check(lib.tt_x3_sconv_fwd(ptr(a), 0, ptr(wS), ptr(bS), ptr(y3), 0, B, C, H, T, st), 's'), n)
+        msp = timeit(lambda: check(lib.tt_x3_sconv_fwd(ptr(a), 0, ptr(wS), ptr(bS), ptr(yp), 1, B, C, H, T, st), 's'), n)
         with torch.no_grad():
             ms32 = timeit(lambda: ops.StridedConvFn.apply(x, wS, bS), n)
         gbs = (x.numel() + yp.numel()) * 4 / 1e9
@@ -72,11 +72,30 @@ def main():
             bT = torch.randn(16, device='cuda') * 0.1
             Ht = 2 * H + 3
             z3 = torch.empty((B, Ht, T, 2, 16), dtype=torch.float16, device='cuda')
-            mst = timeit(lambda: check(lib.tt_x3_tconv_fwd(ptr(a), ptr(wT), ptr(bT), ptr(z3), 0, B, 16, H, T, 1, st), 't'), n)
+            mst = timeit(lambda: check(lib.tt_x3_tconv_fwd(ptr(a), 0, ptr(wT), ptr(bT), ptr(z3), 0, B, 16, H, T, 1, st), 't'), n)
             with torch.no_grad():
                 mst32 = timeit(lambda: ops.TransposedConvFn.apply(x, wT, bT, 1), n)
             gbt = (x.numel() + z3.numel() // 2) * 4 / 1e9
             print('C32 -> 16 tconv x3 -> x3 %.3f ms %.2f TB/s | fp32 kernel %.3f ms' % (mst, gbt / mst, mst32))
+
+    # the two layers that ENTER the split-operand part from fp32 planar tensors
+    B = int(os.environ.get('KB_B', 64))
+    x8 = torch.randn(B, 8, 269, 1024, device='cuda')
+    w8 = torch.randn(16, 8, 4, 1, device='cuda') / 4
+    b8 = torch.randn(16, device='cuda') * 0.1
+    y16 = torch.empty((B, 133, 1024, 2, 16), dtype=torch.float16, device='cuda')
+    ms = timeit(lambda: check(lib.tt_x3_sconv_fwd(ptr(x8), 1, ptr(w8), ptr(b8), ptr(y16), 0, B, 8, 269, 1024, st), 's8'), n)
+    with torch.no_grad():
+        ms32 = timeit(lambda: ops.StridedConvFn.apply(x8, w8, b8), n)
+    print('C8 -> 16 sconv planar -> x3 %.3f ms %.2f TB/s | fp32 kernel %.3f ms (+ pack of its output)' % (ms, (x8.numel() * 4 + y16.numel() * 2) / 1e9 / ms, ms32))
+    x64 = torch.randn(B, 64, 31, 1024, device='cuda')
+    w64 = torch.randn(64, 32, 4, 1, device='cuda') / 11
+    b32 = torch.randn(32, device='cuda') * 0.1
+    y32 = torch.empty((B, 65, 1024, 2, 32), dtype=torch.float16, device='cuda')
+    ms = timeit(lambda: check(lib.tt_x3_tconv_fwd(ptr(x64), 1, ptr(w64), ptr(b32), ptr(y32), 0, B, 32, 31, 1024, 1, st), 't64'), n)
+    with torch.no_grad():
+        ms32 = timeit(lambda: ops.TransposedConvFn.apply(x64, w64, b32, 1), n)
+    print('C64 -> 32 tconv planar -> x3 %.3f ms %.2f TB/s | fp32 kernel %.3f ms (+ pack of its output)' % (ms, (x64.numel() * 4 + y32.numel() * 2) / 1e9 / ms, ms32))
 
 
 if __name__ == '__main__':

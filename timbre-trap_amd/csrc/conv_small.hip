@@ -338,6 +338,131 @@ __global__ __launch_bounds__(512, (C == 8 && MODE == 0 && MF ? SMALL_LB8 : 1)) v
     }
 }
 
+// ---- forward, four pixels per lane -------------------------------------------------------------------------------------------------
+// k_small_lds (MODE 0) is bound by LDS INSTRUCTIONS (profiles/r02_pmc_narrow_levels.txt: SQ_LDS_CMD_FIFO_FULL for a third of its busy
+// time): one 4-byte tap read per pixel, input channel and tap, one weight read per tap and group of four output channels, 4-byte
+// stores.  Here a lane owns FOUR consecutive frames of one row: the taps of a (channel, kernel row) come from three aligned 16-byte
+// reads of the tile row (columns 4q - 4 .. 4q + 7 cover 4q - D .. 4q + 3 + D) and are picked out of registers, a weight read serves
+// four pixels, the residual and every store are 16 bytes.  Same products in the same order on the same matrix instruction (mfma4:
+// one FMA per product), so y and h1 are BIT-IDENTICAL to k_small_lds -- tests/test_gpu_conv.py pins that.
+// Tile 16 rows x 64 frames, 256 threads (16 rows x 16 quads), one LDS buffer: three (C = 8) / four (C = 4) workgroups per CU cover each
+// other's staging.
+template <int C, int D>
+struct SL4 {
+    static constexpr int TR = 16, XR = TR + 2 * D, XCP = 72, PLANE = XR * XCP;
+    static constexpr int NQ = C * PLANE / 4, NP = (NQ + 63) / 64;
+    static constexpr int BUF = NP * 256;
+    static constexpr int LDS_BYTES = (BUF + SW<C>::FLOATS) * 4;
+};
+
+template <int C, int D>
+__global__ __launch_bounds__(256, 3) void k_small_fwd4(const float* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                       const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ y,
+                                                       float* __restrict__ h1out, int B, int H, int T) {
+    using S = SW<C>;
+    using L = SL4<C, D>;
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+    float* xs = lds_dyn;
+    float* wimg = lds_dyn + L::BUF;
+    build_images<C>(wimg, w1, b1, w2, b2, false);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = threadIdx.x & 15, row = threadIdx.x >> 4, l4 = lane & 3;
+    const int tiles_h = (H + L::TR - 1) / L::TR, tiles_t = (T + 63) / 64;
+    const int ntiles = B * tiles_h * tiles_t;
+    const long plane = (long)H * T;
+    const float* zero = reinterpret_cast<const float*>(&g_zero16_small);
+    constexpr int NG = C / 4;
+
+    for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
+        int tt = xcd_tile_s(v, ntiles);
+        const int tx = tt % tiles_t; tt /= tiles_t;
+        const int ty = tt % tiles_h;
+        const int b = tt / tiles_h, row0 = ty * L::TR - D, col0 = tx * 64 - 4;
+        const float* xb = x + (long)b * C * plane;
+        __syncthreads();                                         // everyone is done with the previous tile
+#pragma unroll
+        for (int jj = 0; jj < (L::NP + 3) / 4; ++jj) {
+            const int j = wave + 4 * jj;
+            if (j < L::NP) {
+                const int p = j * 64 + lane;
+                const int ci = p / (L::PLANE / 4);
+                const int rem = p - ci * (L::PLANE / 4);
+                const int r = rem / 18, c4 = rem - r * 18;
+                const int h = row0 + r, t = col0 + 4 * c4;
+                const bool ok = p < L::NQ && h >= 0 && h < H && t >= 0 && t < T;
+                glds16s(ok ? xb + (ci * (int)plane + h * T + t) : zero, xs + j * 256);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        const int h = ty * L::TR + row, t4 = tx * 64 + 4 * q;
+        // window of tile row (row + kh D), columns 4q .. 4q + 11 of the tile = frames t4 - 4 .. t4 + 7
+        const float* xt = xs + row * L::XCP + 4 * q;
+        f32x4s av[4][NG];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int gq = 0; gq < NG; ++gq)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) av[p][gq][c] = wimg[S::B1 + 4 * gq + c];
+#pragma unroll 1
+        for (int ci = 0; ci < C; ++ci) {
+            const float* xc = xt + ci * L::PLANE;
+            const float* wc = wimg + S::W1 + ci * 9 * C + l4;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                asm volatile("" ::: "memory");
+                const float4 q0 = *reinterpret_cast<const float4*>(xc + kh * D * L::XCP);
+                const float4 q1 = *reinterpret_cast<const float4*>(xc + kh * D * L::XCP + 4);
+                const float4 q2 = *reinterpret_cast<const float4*>(xc + kh * D * L::XCP + 8);
+                const float win[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    float w[NG];
+#pragma unroll
+                    for (int gq = 0; gq < NG; ++gq) w[gq] = wc[(kh * 3 + kw) * C + 4 * gq];
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const float xv = win[4 + p + (kw - 1) * D];
+#pragma unroll
+                        for (int gq = 0; gq < NG; ++gq) av[p][gq] = mfma4(w[gq], xv, av[p][gq]);
+                    }
+                }
+            }
+        }
+        if (h < H && t4 < T) {
+            const long o = (long)b * C * plane + (long)h * T + t4;
+            float a2[4][C];
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int co = 0; co < C; ++co) a2[p][co] = wimg[S::B2 + co];
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                float hv[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) hv[p] = elu1(av[p][c >> 2][c & 3]);
+                if (h1out) *reinterpret_cast<float4*>(h1out + o + c * plane) = float4{hv[0], hv[1], hv[2], hv[3]};
+                const float* wl = wimg + S::W2 + c * C;
+#pragma unroll
+                for (int co = 0; co < C; ++co) {
+                    const float wv = wl[co];
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) a2[p][co] = fmaf(hv[p], wv, a2[p][co]);
+                }
+            }
+#pragma unroll
+            for (int co = 0; co < C; ++co) {
+                const float4 xr = *reinterpret_cast<const float4*>(xt + co * L::PLANE + D * L::XCP + 4);
+                *reinterpret_cast<float4*>(y + o + co * plane) =
+                    float4{elu1(a2[0][co]) + xr.x, elu1(a2[1][co]) + xr.y, elu1(a2[2][co]) + xr.z, elu1(a2[3][co]) + xr.w};
+            }
+        }
+    }
+}
+
 // recompute + pointwise chain; persistent workgroups accumulate db1, db2, dW2 in registers
 template <int C, int D, bool RECOMP>
 __global__ __launch_bounds__(256) void k_small_bwd_a(const float* __restrict__ x, const float* __restrict__ h1in,
@@ -792,7 +917,30 @@ int launch_small_lds(const float* x, const float* w1, const float* b1, const flo
 template <int C, int D>
 int fwd_t(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y, float* h1, int B, int H,
           int T, hipStream_t st) {
-    if (lds_variant() && T % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) return launch_small_lds<C, D, 0>(x, w1, b1, w2, b2, nullptr, y, h1, B, H, T, st);
+    if (lds_variant() && T % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        // four pixels per lane (k_small_fwd4; TTRAP_SMALL_FWD4=0: the one-pixel form, bit-identical) needs 16-byte aligned outputs too
+        static const bool four = tt_switch("TTRAP_SMALL_FWD4", 1) != 0;
+        // taken where it wins (B 96 planes, ms per launch, one / four pixels per lane): C = 8 0.743 / 0.649, 0.658 / 0.571 at dilation 1, 2;
+        // dilation 3 0.649 / 0.918 (its 22-row tile leaves room for two workgroups per CU only); C = 4 0.436 / 0.423, 0.433 / 0.417,
+        // 0.440 / 0.507 -- the kernel is the SUM of staging, products and epilogue at three waves per SIMD, not bound by one of them
+        if (four && C == 8 && D <= 2 && small_mfma_variant() && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(h1)) & 15) == 0) {
+            using L = SL4<C, D>;
+            static AttrOnce attr4;
+            auto kern = k_small_fwd4<C, D>;
+            if (const int dev_ = attr4.pending(); dev_ >= 0) {
+                TT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES));
+                attr4.mark(dev_);
+            }
+            const int ntiles = B * ((H + L::TR - 1) / L::TR) * ((T + 63) / 64);
+            int per_cu = (160 * 1024) / L::LDS_BYTES;
+            if (per_cu > 4) per_cu = 4;
+            const int grid = ntiles < tt_cus() * per_cu ? ntiles : tt_cus() * per_cu;
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), L::LDS_BYTES, st, x, w1, b1, w2, b2, y, h1, B, H, T);
+            TT_LAUNCH_CHECK();
+            return 0;
+        }
+        return launch_small_lds<C, D, 0>(x, w1, b1, w2, b2, nullptr, y, h1, B, H, T, st);
+    }
     dim3 grid((T + 63) / 64, (H + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, B);
     hipLaunchKernelGGL((k_small<C, D, 0>), grid, dim3(256), 0, st, x, w1, b1, w2, b2, (const float*)nullptr, y, h1, B, H, T);
     TT_LAUNCH_CHECK();

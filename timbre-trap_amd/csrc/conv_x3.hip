@@ -336,21 +336,22 @@ int x3_d(const e16* x, const float* w1, const float* b1, const float* w2, const 
 // B-operand order, the next unit's NEW slices are requested before this unit's products, and the slices two neighbouring units share
 // stay in registers (sliding window).  Input: an x3 tensor (16 bytes per lane, plane and slice) or -- PIN, the layer that ENTERS the
 // split-operand part of the network -- an fp32 planar tensor (eight 4-byte loads per slice, split in registers).
-//   DOWN  C = 8 (PIN): K = 4 x 8 = one slice (the four rows on the four lane groups: no window); 16 output channels.
+//   DOWN  C = 8 (PIN): its own kernel below (k_x3_sconv8: K = 16 half-slices of two rows, so that the window works).
 //   DOWN  C = 16: two slices of two rows each; 32 output channels = 2 co-tiles.
-//   DOWN  C = 32: four slices; 64 output channels = 4 co-tiles, two per wave (two waves share a pixel group).
+//   DOWN  C = 32: four slices; 64 output channels = 4 co-tiles.
 //   UP   2C = 32: output rows 2m, 2m + 1 both read input rows m (tap = parity) and m - 1 (tap = parity + 2): two slices per parity.
 //   UP   2C = 64 (PIN): the same with two slices per input row; 32 output channels = 2 co-tiles.
 template <int CIN, bool UP> struct XS {
     static constexpr int COUT = UP ? CIN / 2 : 2 * CIN;
     static constexpr int NCT = COUT / 16;                        // co-tiles in all
-    static constexpr int NCTW = NCT > 2 ? 2 : NCT;               // co-tiles per wave
-    static constexpr int NSPLIT = NCT / NCTW;                    // waves that share a pixel group
+    static constexpr int NCTW = NCT;                             // co-tiles per wave: all of them (two waves with two co-tiles each on the
+                                                                 // same frames loaded every operand twice: 32 -> 64 0.48 -> 0.35 ms)
+    static constexpr int NSPLIT = NCT / NCTW;
     static constexpr int SPR = CIN > 32 ? CIN / 32 : 1;          // slices per input row
     static constexpr int NKS = UP ? 2 * SPR : (4 * CIN) / 32;    // K = 32 slices per unit
     static constexpr int NNEW = NKS == 1 ? 1 : NKS / 2;          // slices a unit does not share with its predecessor
     static constexpr int NSET = UP ? 2 : 1;                      // weight sets (output row parity)
-    static constexpr int NCH = COUT == 16 ? 4 : 8;               // channels a lane ends up with
+    static constexpr int NCH = 4 * NCTW;                         // channels a lane ends up with
 };
 
 template <int CIN, bool UP, bool PIN, bool PLANAR>
@@ -412,7 +413,6 @@ __global__ __launch_bounds__(NT, (CIN >= 64 || (CIN == 32 && !UP)) ? 2 : 4) void
     for (int ct = 0; ct < NCTW; ++ct)
 #pragma unroll
         for (int r = 0; r < 4; ++r) br[ct][r] = bias[cmap(sp * NCTW + ct, 4 * g + r)];
-    const int chbase = COUT == 16 ? 4 * g : COUT == 32 ? 8 * g : 32 * sp + 8 * g;       // first of the lane's NCH consecutive channels
 
     // B operand (both planes) of slice ks for unit u; rows outside the input read row 0 and are zeroed
     auto ldb = [&](int u, int ks, e16x8& vh, e16x8& vl) {
@@ -472,17 +472,23 @@ __global__ __launch_bounds__(NT, (CIN >= 64 || (CIN == 32 && !UP)) ? 2 : 4) void
             for (int ct = 0; ct < NCTW; ++ct)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) out[4 * ct + r] = elu1(__builtin_fmaf(al[ct][r], LO_INV, am[ct][r]));
-            if constexpr (PLANAR) {
-                float* yp = static_cast<float*>(yout) + (((long)b * COUT + chbase) * Hout + ho) * T + t;
+            // a lane's rows 4g..4g+3 of two neighbouring co-tiles are eight consecutive channels (cmap): one 16-byte piece per plane
+            constexpr int PW = NCTW >= 2 ? 2 : 1;
 #pragma unroll
-                for (int j = 0; j < NCH; ++j) yp[(long)j * Hout * T] = out[j];
-            } else {
-                e16* y = static_cast<e16*>(yout) + (((long)b * Hout + ho) * T + t) * 2 * COUT + chbase;
-                typename std::conditional<NCH == 8, e16x8, e16x4>::type oh, ol;
+            for (int q = 0; q < NCTW / PW; ++q) {
+                const int cb = cmap(sp * NCTW + PW * q, 4 * g);
+                if constexpr (PLANAR) {
+                    float* yp = static_cast<float*>(yout) + (((long)b * COUT + cb) * Hout + ho) * T + t;
 #pragma unroll
-                for (int j = 0; j < NCH; ++j) { e16 a_, b_; split(out[j], a_, b_); oh[j] = a_; ol[j] = b_; }
-                *reinterpret_cast<decltype(oh)*>(y) = oh;
-                *reinterpret_cast<decltype(ol)*>(y + COUT) = ol;
+                    for (int j = 0; j < 4 * PW; ++j) yp[(long)j * Hout * T] = out[4 * PW * q + j];
+                } else {
+                    e16* y = static_cast<e16*>(yout) + (((long)b * Hout + ho) * T + t) * 2 * COUT + cb;
+                    typename std::conditional<PW == 2, e16x8, e16x4>::type oh, ol;
+#pragma unroll
+                    for (int j = 0; j < 4 * PW; ++j) { e16 a_, b_; split(out[4 * PW * q + j], a_, b_); oh[j] = a_; ol[j] = b_; }
+                    *reinterpret_cast<decltype(oh)*>(y) = oh;
+                    *reinterpret_cast<decltype(ol)*>(y + COUT) = ol;
+                }
             }
         }
         // shift the window
@@ -499,6 +505,76 @@ __global__ __launch_bounds__(NT, (CIN >= 64 || (CIN == 32 && !UP)) ? 2 : 4) void
     }
 }
 
+// EncoderBlock.sconv 8 -> 16 from an fp32 planar tensor (the layer that enters the split-operand part of the encoder).  K = 4 rows x 8
+// channels = 32 would be ONE slice with the four rows on the four lane groups -- no two units could share registers and every input row
+// would be fetched twice, four bytes per lane at a time (0.49 ms).  Two K = 16 half-slices of two rows each (v_mfma_f32_16x16x16_f16)
+// restore the sliding window: the lower half-slice of one output row is the upper one of the next.
+template <bool PLANAR>
+__global__ __launch_bounds__(NT, 4) void k_x3_sconv8(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                     void* __restrict__ yout, int B, int Hin, int Hout, int T, int nchunks, int rch) {
+    constexpr int CIN = 8, COUT = 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+    int task = blockIdx.x;
+    const int rc = task % nchunks; task /= nchunks;
+    const int tgroups = (T + 63) / 64;
+    const int tg = task % tgroups, b = task / tgroups;
+    const int t = tg * 64 + wave * 16 + n;
+    const bool tv = t < T;
+    const int tc = tv ? t : T - 1;
+    // A operands: row n = output channel, k = 4 g + j  ->  input row (g >> 1) of the half-slice, channel 4 (g & 1) + j
+    s16x4 AH[2], AL[2];
+#pragma unroll
+    for (int hs = 0; hs < 2; ++hs) {
+        e16x4 qh, ql;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { e16 h, l; split(w[(n * CIN + 4 * (g & 1) + j) * 4 + 2 * hs + (g >> 1)], h, l); qh[j] = h; ql[j] = l; }
+        AH[hs] = __builtin_bit_cast(s16x4, qh); AL[hs] = __builtin_bit_cast(s16x4, ql);
+    }
+    const float br[4] = {bias[4 * g], bias[4 * g + 1], bias[4 * g + 2], bias[4 * g + 3]};
+    auto ldb = [&](int u, int hs, s16x4& vh, s16x4& vl) {
+        const int row = 2 * u + 2 * hs + (g >> 1);
+        const bool ok = row < Hin;
+        const float* xp = x + (((long)b * CIN + 4 * (g & 1)) * Hin + (ok ? row : 0)) * T + tc;
+        float f[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[j] = xp[(long)j * Hin * T];
+        e16x4 qh, ql;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { e16 h, l; split(ok ? f[j] : 0.f, h, l); qh[j] = h; ql[j] = l; }
+        vh = __builtin_bit_cast(s16x4, qh); vl = __builtin_bit_cast(s16x4, ql);
+    };
+    const int u0 = rc * rch, u1 = u0 + rch < Hout ? u0 + rch : Hout;
+    if (u0 >= Hout) return;
+    s16x4 bh[2], bl[2], nh, nl;
+    ldb(u0, 0, bh[0], bl[0]); ldb(u0, 1, bh[1], bl[1]);
+    for (int u = u0; u < u1; ++u) {
+        if (u + 1 < u1) ldb(u + 1, 1, nh, nl);
+        f32x4 am = f32x4{br[0], br[1], br[2], br[3]}, al = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int hs = 0; hs < 2; ++hs) { am = mma16(AH[hs], bh[hs], am); al = mma16(AH[hs], bl[hs], al); }
+#pragma unroll
+        for (int hs = 0; hs < 2; ++hs) al = mma16(AL[hs], bh[hs], al);
+        if (tv) {
+            float out[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[r] = elu1(__builtin_fmaf(al[r], LO_INV, am[r]));
+            if constexpr (PLANAR) {
+                float* yp = static_cast<float*>(yout) + (((long)b * COUT + 4 * g) * Hout + u) * T + t;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) yp[(long)j * Hout * T] = out[j];
+            } else {
+                e16* y = static_cast<e16*>(yout) + (((long)b * Hout + u) * T + t) * 2 * COUT + 4 * g;
+                e16x4 oh, ol;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { e16 a_, b_; split(out[j], a_, b_); oh[j] = a_; ol[j] = b_; }
+                *reinterpret_cast<e16x4*>(y) = oh;
+                *reinterpret_cast<e16x4*>(y + COUT) = ol;
+            }
+        }
+        bh[0] = bh[1]; bl[0] = bl[1]; bh[1] = nh; bl[1] = nl;
+    }
+}
+
 template <int CIN, bool UP, bool PIN>
 int launch_x3s(const void* x, const float* w, const float* bias, void* y, bool planar_out, int B, int Hin, int Hout, int T, hipStream_t st) {
     using S = XS<CIN, UP>;
@@ -512,7 +588,10 @@ int launch_x3s(const void* x, const float* w, const float* bias, void* y, bool p
     const int rch = (int)((units + want - 1) / want), nchunks = (units + rch - 1) / rch;
     const long grid = base * nchunks;
     if (grid > 0x7fffffffl) return TT_E_UNSUPPORTED;
-    if (planar_out)
+    if constexpr (CIN == 8) {
+        if (planar_out) hipLaunchKernelGGL(k_x3_sconv8<true>, dim3((unsigned)grid), dim3(NT), 0, st, (const float*)x, w, bias, y, B, Hin, Hout, T, nchunks, rch);
+        else hipLaunchKernelGGL(k_x3_sconv8<false>, dim3((unsigned)grid), dim3(NT), 0, st, (const float*)x, w, bias, y, B, Hin, Hout, T, nchunks, rch);
+    } else if (planar_out)
         hipLaunchKernelGGL((k_x3_sconv<CIN, UP, PIN, true>), dim3((unsigned)grid), dim3(NT), 0, st, x, w, bias, y, B, Hin, Hout, T, nchunks, rch);
     else
         hipLaunchKernelGGL((k_x3_sconv<CIN, UP, PIN, false>), dim3((unsigned)grid), dim3(NT), 0, st, x, w, bias, y, B, Hin, Hout, T, nchunks, rch);

@@ -281,3 +281,26 @@ def test_bias_gradient_with_frozen_weight():
         y = ops.conv(xd, wd, bd, cfg)
         y.backward(gy.cuda())
         assert wd.grad is None and _rel(bd.grad, br.grad) < 1e-4
+
+
+def test_four_pixel_narrow_forward_is_bit_identical(tmp_path):
+    """
+    k_small_fwd4 (csrc/conv_small.hip: four frames per lane, 16-byte tap reads and stores) performs the same products in the same order
+    on the same instruction as k_small_lds: y and the saved hidden activation must be BIT-identical for C = 4, 8 x three dilations x
+    ragged and bench-sized planes.  The switch is read once per process, so each setting runs in its own child
+    (TTRAP_SMALL_FWD4 = 0: never, 2: every shape; the default takes it where it wins).
+    """
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, 'tools', 'diag', 'small_fwd_check.py')
+    outs = []
+    for setting in ('0', '2'):
+        out = str(tmp_path / ('fwd4_%s.pt' % setting))
+        env = dict(os.environ, TTRAP_SMALL_FWD4=setting)
+        r = subprocess.run([sys.executable, tool, out], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(out)
+    r = subprocess.run([sys.executable, tool, 'cmp'] + outs, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and '0 differ' in r.stdout, r.stdout[-2000:]

@@ -183,6 +183,9 @@ struct SL {
     static constexpr int LDS_BYTES = (NBUF * BUF + SW<C>::FLOATS) * 4;
 };
 
+#ifndef SMALL_FWD4_TR
+#define SMALL_FWD4_TR 16  // rows of the four-pixels-per-lane forward tile
+#endif
 #ifndef SMALL_LB8
 #define SMALL_LB8 1      // waves per SIMD the C = 8 forward kernel is compiled for.  Measured: 6 (80 registers, a handful spilled,
                          // three workgroups per CU) 0.75-1.05 ms and 5 0.73-0.78 ms against 0.49-0.54 ms uncapped -- the spills cost
@@ -347,20 +350,21 @@ __global__ __launch_bounds__(512, (C == 8 && MODE == 0 && MF ? SMALL_LB8 : 1)) v
 // one FMA per product), so y and h1 are BIT-IDENTICAL to k_small_lds -- tests/test_gpu_conv.py pins that.
 // Tile 16 rows x 64 frames, 256 threads (16 rows x 16 quads), one LDS buffer: three (C = 8) / four (C = 4) workgroups per CU cover each
 // other's staging.
-template <int C, int D>
+template <int C, int D, int TR_>
 struct SL4 {
-    static constexpr int TR = 16, XR = TR + 2 * D, XCP = 72, PLANE = XR * XCP;
+    static constexpr int TR = TR_, XR = TR + 2 * D, XCP = 72, PLANE = XR * XCP;
+    static constexpr int NTH = TR * 16, NW = NTH / 64;
     static constexpr int NQ = C * PLANE / 4, NP = (NQ + 63) / 64;
     static constexpr int BUF = NP * 256;
     static constexpr int LDS_BYTES = (BUF + SW<C>::FLOATS) * 4;
 };
 
-template <int C, int D>
-__global__ __launch_bounds__(256, 3) void k_small_fwd4(const float* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ b1,
+template <int C, int D, int TR>
+__global__ __launch_bounds__((TR * 16), 3) void k_small_fwd4(const float* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ b1,
                                                        const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ y,
                                                        float* __restrict__ h1out, int B, int H, int T) {
     using S = SW<C>;
-    using L = SL4<C, D>;
+    using L = SL4<C, D, TR>;
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
     float* xs = lds_dyn;
     float* wimg = lds_dyn + L::BUF;
@@ -381,8 +385,8 @@ __global__ __launch_bounds__(256, 3) void k_small_fwd4(const float* __restrict__
         const float* xb = x + (long)b * C * plane;
         __syncthreads();                                         // everyone is done with the previous tile
 #pragma unroll
-        for (int jj = 0; jj < (L::NP + 3) / 4; ++jj) {
-            const int j = wave + 4 * jj;
+        for (int jj = 0; jj < (L::NP + L::NW - 1) / L::NW; ++jj) {
+            const int j = wave + L::NW * jj;
             if (j < L::NP) {
                 const int p = j * 64 + lane;
                 const int ci = p / (L::PLANE / 4);
@@ -919,23 +923,24 @@ int fwd_t(const float* x, const float* w1, const float* b1, const float* w2, con
           int T, hipStream_t st) {
     if (lds_variant() && T % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
         // four pixels per lane (k_small_fwd4; TTRAP_SMALL_FWD4=0: the one-pixel form, bit-identical) needs 16-byte aligned outputs too
-        static const bool four = tt_switch("TTRAP_SMALL_FWD4", 1) != 0;
+        static const int four = tt_switch("TTRAP_SMALL_FWD4", 1);      // 0: never, 1: where it wins, 2: every shape (A/B)
         // taken where it wins (B 96 planes, ms per launch, one / four pixels per lane): C = 8 0.743 / 0.649, 0.658 / 0.571 at dilation 1, 2;
         // dilation 3 0.649 / 0.918 (its 22-row tile leaves room for two workgroups per CU only); C = 4 0.436 / 0.423, 0.433 / 0.417,
         // 0.440 / 0.507 -- the kernel is the SUM of staging, products and epilogue at three waves per SIMD, not bound by one of them
-        if (four && C == 8 && D <= 2 && small_mfma_variant() && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(h1)) & 15) == 0) {
-            using L = SL4<C, D>;
+        if (four && (four == 2 || (C == 8 && D <= 2)) && small_mfma_variant() && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(h1)) & 15) == 0) {
+            constexpr int TR4 = SMALL_FWD4_TR;
+            using L = SL4<C, D, TR4>;
             static AttrOnce attr4;
-            auto kern = k_small_fwd4<C, D>;
+            auto kern = k_small_fwd4<C, D, TR4>;
             if (const int dev_ = attr4.pending(); dev_ >= 0) {
                 TT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES));
                 attr4.mark(dev_);
             }
             const int ntiles = B * ((H + L::TR - 1) / L::TR) * ((T + 63) / 64);
             int per_cu = (160 * 1024) / L::LDS_BYTES;
-            if (per_cu > 4) per_cu = 4;
+            if (per_cu > 8) per_cu = 8;
             const int grid = ntiles < tt_cus() * per_cu ? ntiles : tt_cus() * per_cu;
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), L::LDS_BYTES, st, x, w1, b1, w2, b2, y, h1, B, H, T);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(L::NTH), L::LDS_BYTES, st, x, w1, b1, w2, b2, y, h1, B, H, T);
             TT_LAUNCH_CHECK();
             return 0;
         }

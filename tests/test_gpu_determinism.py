@@ -210,3 +210,37 @@ def test_one_pass_wide_backward_is_reproducible(C, d, entry, runs=6, B=2, T=1024
         torch.cuda.synchronize()
         out.append([t.clone() for t in gr] + [dxb.clone()])
     _same(out, ('dw1', 'db1', 'dw2', 'db2', 'dx'))
+
+
+def test_split_operand_inference_chain_is_reproducible(runs=5, B=4, T=1024):
+    """
+    The split-operand forward kernels (csrc/conv_x3.hip) have no reduction across workgroups, but they accumulate with packed
+    multiply-adds next to matrix instructions like the loop this file was written for -- so the same encoder-top / decoder-top chain
+    (level 16 -> 16 -> 32 -> level 32 -> 32 -> 64 -> latent heads -> 64 -> 32 -> level 32 -> 32 -> 16 -> level 16) at the bench heights
+    must return the same bits run after run.
+    """
+    import torch.nn as nn
+    from timbre_trap.framework import modules, ops
+    torch.manual_seed(3)
+    enc3, enc4 = modules.EncoderBlock(16, 32).cuda(), modules.EncoderBlock(32, 64).cuda()
+    dec1, dec2 = modules.DecoderBlock(64, 32, padding=1).cuda(), modules.DecoderBlock(32, 16, padding=1).cuda()
+    convlat = nn.Conv2d(64, 128, (31, 1)).cuda()
+    convin = nn.ConvTranspose2d(129, 64, (31, 1)).cuda()
+    g = torch.Generator(device='cuda').manual_seed(5)
+    x = torch.randn(B, 16, HEIGHTS[16], T, device='cuda', generator=g)
+    outs = []
+    with torch.no_grad(), ops.x3_chain_scope(True):
+        for _ in range(runs):
+            top = enc4(enc3(x, out_x3=True), out_x3=True)
+            assert ops.is_x3(top) and top.shape == (B, 31, T, 2, 64)
+            z = ops.latent_encode(top, convlat.weight, convlat.bias)
+            y = ops.latent_decode(z, convin.weight, convin.bias, fill=1.0, out_x3=True)
+            assert ops.is_x3(y)
+            out = dec2(dec1(y, out_x3=True))
+            assert out.dtype == torch.float32 and out.shape == x.shape
+            outs.append((top.clone(), z.clone(), out.clone()))
+    torch.cuda.synchronize()
+    for r in outs[1:]:
+        for a, b in zip(outs[0], r):
+            assert torch.equal(a, b)
+    assert bool(torch.isfinite(outs[0][2]).all())

@@ -308,6 +308,11 @@ int tt_sqdiff_sum(const float* a, const float* b, float* loss, double* partials,
 /* da = 2*(a-b)*gscale[0]*scale ; db = -da   (either may be NULL) */
 int tt_sqdiff_bwd(const float* a, const float* b, const float* gscale, float scale, float* da,
                   float* db, int64_t n, void* stream);
+/* Both consistency terms at once (objectives.py:77-104: two squared errors against the same, non-detached, second operand):
+ * da1 = 2 scale g1[0] (a1 - b), da2 = 2 scale g2[0] (a2 - b), db = -(da1 + da2); g1 / g2 device scalars (NULL = 0), da1 / da2 / db may be
+ * NULL; all pointers 16-byte aligned. */
+int tt_sqdiff2_bwd(const float* a1, const float* a2, const float* b, const float* g1, const float* g2, float scale, float* da1,
+                   float* da2, float* db, int64_t n, void* stream);
 
 /* act = tanh(sqrt(re^2 + im^2)) for coeffs (B,2,F,T) -> (B,F,T) */
 int tt_activations_fwd(const float* coeffs, float* act, int B, int F, int T, void* stream);

@@ -734,3 +734,33 @@ def test_frozen_parameter_gets_no_gradient_on_the_bf16_path():
     b0 = model.decoder.block1.tconv[0].bias.detach().clone()
     opt.step()
     assert torch.equal(model.decoder.block1.tconv[0].bias.detach(), b0)
+
+
+def test_fused_consistency_backward_equals_two_squared_error_terms():
+    """
+    compute_consistency_loss = two squared errors against the same non-detached target (reference objectives.py:77-104).  ops.SqDiff2Fn
+    computes both in one Function whose backward writes the target's gradient once (tt_sqdiff2_bwd): losses and all three gradients must
+    be BITWISE what two SqDiffLossFn + autograd's sum give, also when only one of the two terms is used.
+    """
+    from timbre_trap.framework import compute_consistency_loss, compute_reconstruction_loss
+    g = torch.Generator().manual_seed(9)
+    shape = (3, 2, 37, 52)
+    base = [torch.randn(shape, generator=g).cuda() for _ in range(3)]
+    for use in ((1.0, 1.0), (1.0, 0.0), (0.3, 2.0)):
+        a1, a2, b = (t.clone().requires_grad_(True) for t in base)
+        l1, l2 = compute_consistency_loss(a1, a2, b)
+        (use[0] * l1 + use[1] * l2).backward()
+        r1, r2, rb = (t.clone().requires_grad_(True) for t in base)
+        m1, m2 = compute_reconstruction_loss(r1, rb), compute_reconstruction_loss(r2, rb)
+        (use[0] * m1 + use[1] * m2).backward()
+        assert torch.equal(l1, m1) and torch.equal(l2, m2)
+        assert torch.equal(a1.grad, r1.grad) and torch.equal(a2.grad, r2.grad) and torch.equal(b.grad, rb.grad)
+    # a detached target (no gradient wanted) and a length that is not a multiple of four take the two-term path
+    a1, a2 = (t.clone().requires_grad_(True) for t in base[:2])
+    l1, l2 = compute_consistency_loss(a1, a2, base[2])
+    (l1 + l2).backward()
+    assert a1.grad is not None and a2.grad is not None
+    odd = [torch.randn(1, 1, 3, 5, generator=g).cuda().requires_grad_(True) for _ in range(3)]
+    o1, o2 = compute_consistency_loss(*odd)
+    (o1 + o2).backward()
+    assert all(t.grad is not None for t in odd)

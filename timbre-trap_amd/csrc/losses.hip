@@ -167,6 +167,46 @@ extern "C" int tt_sqdiff_sum(const float* a, const float* b, float* loss, double
     return 0;
 }
 
+// Two squared-error terms against the SAME second operand (the consistency losses, reference objectives.py:77-104: both reconstruct
+// the non-detached transcription coefficients): da1 = 2 s g1 (a1 - b), da2 = 2 s g2 (a2 - b), db = -(da1 + da2) in one pass -- the two
+// tt_sqdiff_bwd calls wrote db twice and left the sum to a third elementwise kernel (11 tensor passes instead of 6).
+__global__ __launch_bounds__(256) void k_sqdiff2_bwd(const float4* __restrict__ a1, const float4* __restrict__ a2, const float4* __restrict__ b,
+                                                     const float* __restrict__ g1, const float* __restrict__ g2, float scale,
+                                                     float4* __restrict__ da1, float4* __restrict__ da2, float4* __restrict__ db, long n4,
+                                                     long n) {
+    const float s1 = g1 ? 2.f * scale * g1[0] : 0.f, s2 = g2 ? 2.f * scale * g2[0] : 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 x1 = a1[i], x2 = a2[i], y = b[i];
+        const float4 u = float4{s1 * (x1.x - y.x), s1 * (x1.y - y.y), s1 * (x1.z - y.z), s1 * (x1.w - y.w)};
+        const float4 v = float4{s2 * (x2.x - y.x), s2 * (x2.y - y.y), s2 * (x2.z - y.z), s2 * (x2.w - y.w)};
+        if (da1) da1[i] = u;
+        if (da2) da2[i] = v;
+        if (db) db[i] = float4{-u.x - v.x, -u.y - v.y, -u.z - v.z, -u.w - v.w};
+    }
+    if (blockIdx.x == 0) {                                       // tail of a length that is not a multiple of four
+        const long i = (n4 << 2) + threadIdx.x;
+        if (i < n) {
+            const float* p1 = reinterpret_cast<const float*>(a1); const float* p2 = reinterpret_cast<const float*>(a2);
+            const float* pb = reinterpret_cast<const float*>(b);
+            const float u = s1 * (p1[i] - pb[i]), v = s2 * (p2[i] - pb[i]);
+            if (da1) reinterpret_cast<float*>(da1)[i] = u;
+            if (da2) reinterpret_cast<float*>(da2)[i] = v;
+            if (db) reinterpret_cast<float*>(db)[i] = -u - v;
+        }
+    }
+}
+
+extern "C" int tt_sqdiff2_bwd(const float* a1, const float* a2, const float* b, const float* g1, const float* g2, float scale, float* da1,
+                              float* da2, float* db, int64_t n, void* stream) {
+    if (!a1 || !a2 || !b || n <= 0) return TT_E_BADARG;
+    const uintptr_t al = (uintptr_t)a1 | (uintptr_t)a2 | (uintptr_t)b | (uintptr_t)da1 | (uintptr_t)da2 | (uintptr_t)db;
+    if (al & 15) return TT_E_BADARG;                             // 16-byte accesses (torch allocations are 256-byte aligned)
+    hipLaunchKernelGGL(k_sqdiff2_bwd, dim3(nblocks(n >> 2, 4) * 4), dim3(256), 0, tt_stream(stream), (const float4*)a1, (const float4*)a2,
+                       (const float4*)b, g1, g2, scale, (float4*)da1, (float4*)da2, (float4*)db, (long)(n >> 2), (long)n);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int tt_sqdiff_bwd(const float* a, const float* b, const float* gscale, float scale, float* da,
                              float* db, int64_t n, void* stream) {
     if (!a || !b || !gscale || n <= 0 || (!da && !db)) return TT_E_BADARG;

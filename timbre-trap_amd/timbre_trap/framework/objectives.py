@@ -43,5 +43,12 @@ def compute_consistency_loss(spectral_coefficients, transcription_coefficients, 
     Spectral- and score-consistency terms: two reconstruction losses against the (non-detached)
     transcription coefficients (reference objectives.py:77-104).
     """
+    if spectral_coefficients.shape != target.shape or transcription_coefficients.shape != target.shape:
+        raise ValueError('shape mismatch: %s, %s vs %s' % (tuple(spectral_coefficients.shape), tuple(transcription_coefficients.shape),
+                                                           tuple(target.shape)))
+    averaged = target.numel() // (target.size(-3) * target.size(-2))
+    if target.numel() % 4 == 0 and all(t.dtype == target.dtype for t in (spectral_coefficients, transcription_coefficients)):
+        # both terms share the target: one backward pass writes its gradient once (ops.SqDiff2Fn)
+        return ops.SqDiff2Fn.apply(spectral_coefficients, transcription_coefficients, target, 1.0 / averaged)
     return (compute_reconstruction_loss(spectral_coefficients, target),
             compute_reconstruction_loss(transcription_coefficients, target))

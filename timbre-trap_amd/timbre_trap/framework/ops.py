@@ -1299,6 +1299,40 @@ class SqDiffLossFn(torch.autograd.Function):
         return da, db, None
 
 
+class SqDiff2Fn(torch.autograd.Function):
+    """
+    (scale * sum((a1 - b)^2), scale * sum((a2 - b)^2)): the two consistency terms (reference objectives.py:77-104), which share their
+    non-detached second operand.  Same sums as two SqDiffLossFn; the backward is ONE pass (tt_sqdiff2_bwd) that writes the gradient
+    of b once, as the sum of both terms -- two SqDiffLossFn left that sum to autograd (an extra elementwise pass over the logits).
+    """
+
+    @staticmethod
+    def forward(ctx, a1, a2, b, scale):
+        _hip.require_cuda(a1, b)
+        a1, a2, b = _f32c(a1), _f32c(a2), _f32c(b)
+        lib, st = _hip.lib(), stream_ptr()
+        l1 = torch.empty((), dtype=torch.float32, device=b.device)
+        l2 = torch.empty((), dtype=torch.float32, device=b.device)
+        check(lib.tt_sqdiff_sum(ptr(a1), ptr(b), ptr(l1), ptr(_partials(b.device)), b.numel(), scale, st), 'tt_sqdiff_sum')
+        check(lib.tt_sqdiff_sum(ptr(a2), ptr(b), ptr(l2), ptr(_partials(b.device)), b.numel(), scale, st), 'tt_sqdiff_sum')
+        ctx.scale = scale
+        ctx.save_for_backward(a1, a2, b)
+        return l1, l2
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        a1, a2, b = ctx.saved_tensors
+        g1 = None if g1 is None else _f32c(g1)
+        g2 = None if g2 is None else _f32c(g2)
+        da1 = torch.empty_like(a1) if ctx.needs_input_grad[0] else None
+        da2 = torch.empty_like(a2) if ctx.needs_input_grad[1] else None
+        db = torch.empty_like(b) if ctx.needs_input_grad[2] else None
+        if da1 is not None or da2 is not None or db is not None:
+            check(_hip.lib().tt_sqdiff2_bwd(ptr(a1), ptr(a2), ptr(b), ptr(g1), ptr(g2), ctx.scale, ptr(da1), ptr(da2), ptr(db), b.numel(),
+                                            stream_ptr()), 'tt_sqdiff2_bwd')
+        return da1, da2, db, None
+
+
 class ActivationsFn(torch.autograd.Function):
     """tanh(|re + i im|) over the channel pair (TimbreTrap.to_activations, modules.py:287)."""
 

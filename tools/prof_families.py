@@ -9,7 +9,7 @@ GROUPS = [('bf16 block forward (k_wrb_conv / k_nrb_conv MODE 0)', r'k_[wn]rb_con
           ('bf16 narrow fused backward', r'k_nrb_bwd_fused'), ('bf16 partial-sum reduces', r'k_[wn]rb_reduce|k_w4_reduce|k_lat_wred|k_edge_reduce'),
           ('bf16 strided / transposed layers (k_s4 / k_p2)', r'k_s4|k_p2'), ('bf16 strided weight gradient (k_w4)', r'k_w4<'),
           ('bf16 latent heads', r'k_lat_'), ('bf16 boundary convs', r'k_cin_|k_cout_'), ('fp32 <-> bf16 layout changes', r'k_wide_(un)?pack'),
-          ('narrow fused backward (k_small_bwd_fused)', r'k_small_bwd_fused|k_small_wgrad_reduce'), ('narrow resblocks fwd/dgrad (k_small)', r'k_small<|k_small_lds'), ('narrow pointwise backward (k_small_bwd_a)', r'k_small_bwd_a'),
+          ('narrow fused backward (k_small_bwd_fused)', r'k_small_bwd_fused|k_small_wgrad_reduce'), ('narrow resblocks fwd/dgrad (k_small)', r'k_small<|k_small_lds|k_small_fwd4'), ('narrow pointwise backward (k_small_bwd_a)', r'k_small_bwd_a'),
           ('weight grad 3x3 C>=16', r'k_wgrad_dma<(16|32), (16|32), 16, .*WRes'), ('weight grad other', r'k_wgrad3_pack_reduce'), ('weight grad 3x3 C<=8', r'k_wgrad_dma<(4|8), (4|8), .*WRes|k_wgrad3_pack<'),
           ('weight grad strided', r'k_wgrad_dma<.*WStr'), ('weight grad other', r'k_wgrad_reduce|k_wgrad_generic|k_wgrad3x3|k_wgrad_mfma|k_wgrad3_pack_reduce'),
           ('wide resblocks forward (k_rb_fwd)', r'k_rb_fwd'), ('wide 3x3 data gradient', r'k_conv_mfma<(16|32), (16|32), .*Res3x3'),

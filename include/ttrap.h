@@ -97,6 +97,40 @@ int tt_cqt_forward(const tt_cqt_plan* plan, const float* audio, float* out, void
 int tt_cqt_inverse(const tt_cqt_plan* plan, const float* coeffs, float* audio, void* scratch,
                    int B, int n_blocks, int in_complex, int normalize, void* stream);
 
+/* The same transform for ANY block length N and frame count M = 2^m (csrc/cqt_generic.hip): the reference constructor takes
+ * arbitrary secs_per_block / sample_rate (timbre_trap/framework/cqtwrapper.py:15-48, cqt_pytorch.CQT(block_length=...,
+ * power_of_2_length=True) at :31-35); the two entry points above cover N = 66150 / M = 1024 only.  Slow path by design: the
+ * length-N DFT as a Bluestein convolution over P = 2^p >= 2N - 1 points, global-memory Stockham passes, one launch per pass.
+ * Tables (host-built, timbre_trap/framework/nsgt_plan.py; bin_tab / window / dual / gat_* as above):
+ *   chirp   [N]    float2  exp(-i pi n^2 / N)
+ *   bfilt   [P]    float2  DFT_P of the wrapped conjugate chirp, divided by P
+ *   twP     [P/2]  float2  exp(-2 pi i q / P)          twM [M/2] float2  exp(-2 pi i q / M)
+ *   pos_bin [sumL] int32   bin of every ragged window position
+ * Same layouts, flags and normalisation rule as tt_cqt_forward / tt_cqt_inverse. */
+typedef struct {
+    const float*   chirp;
+    const float*   bfilt;
+    const float*   twP;
+    const float*   twM;
+    const int32_t* bin_tab;
+    const float*   window;
+    const float*   dual;
+    const int32_t* gat_off;    /* [N/2 + 2] */
+    const int32_t* gat_idx;
+    const int32_t* pos_bin;
+    int32_t        n_bins;
+    int32_t        sum_len;
+    int32_t        N;
+    int32_t        M;
+    int32_t        P;
+} tt_cqt_gplan;
+
+int64_t tt_cqt_generic_scratch_bytes(const tt_cqt_gplan* plan, int n_clips);
+int tt_cqt_generic_forward(const tt_cqt_gplan* plan, const float* audio, float* out, void* scratch,
+                           int B, int n_blocks, int out_complex, void* stream);
+int tt_cqt_generic_inverse(const tt_cqt_gplan* plan, const float* coeffs, float* audio, void* scratch,
+                           int B, int n_blocks, int in_complex, int normalize, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Convolution stack.  Replaces torch.nn.Conv2d / ConvTranspose2d / ELU as used by
  * timbre_trap/framework/modules.py (ResidualConv2dBlock :721-777, EncoderBlock :597-655,

@@ -41,7 +41,8 @@ import math
 import numpy as np
 
 
-FRAME_FLOOR = 1e-3
+FRAME_FLOOR = 1e-3      # the opt-in 'floored' dual (rounds 1-4 default)
+DUAL_EPS = 1e-8         # the default 'additive' dual: g / (D + eps), the recalled dense one-liner of cqt_pytorch (unverified)
 
 
 def _round_half_even(x):
@@ -49,9 +50,10 @@ def _round_half_even(x):
     return np.round(np.asarray(x, dtype=np.float64))
 
 
-def nsgt_tables(n_octaves, bins_per_octave, sample_rate, block_length, power_of_2_length=True):
+def nsgt_tables(n_octaves, bins_per_octave, sample_rate, block_length, power_of_2_length=True, dual='additive'):
     """
-    All conventions of the transform, as plain tables.
+    All conventions of the transform, as plain tables.  ``dual``: 'additive' (default, g / (D + 1e-8) wherever a window reaches) |
+    'floored' (g / D where D > 1e-3, else 0) | 'canonical' (g / D wherever D > 0).
 
     Returns a dict with
       n_bins, block_length (N), max_window_length (M)
@@ -108,12 +110,19 @@ def nsgt_tables(n_octaves, bins_per_octave, sample_rate, block_length, power_of_
     # diagonal of the frame operator on the positive half-spectrum
     D = np.zeros(N // 2 + 1, dtype=np.float64)
     np.add.at(D, spec_index, window ** 2)
-    # Spectral indices whose total window energy is below FRAME_FLOOR are treated as not represented:
-    # at the two band edges (and two sub-43 Hz gaps) only the extreme tail of ONE window reaches them, the
-    # canonical dual there would be 1/w ~ 6e4 and turn 1e-4 coefficient noise into audible sinusoids.
-    covered = D > FRAME_FLOOR
-    Dsafe = np.where(covered, D, 1.0)
-    dual = np.where(covered[spec_index], window / Dsafe[spec_index], 0.0)
+    # 'floored': spectral indices whose total window energy is below FRAME_FLOOR are treated as not represented: at the two
+    # band edges (and two sub-43 Hz gaps) only the extreme tail of ONE window reaches them, the canonical dual there would be
+    # 1/w ~ 6e4 and turn 1e-4 coefficient noise into audible sinusoids.  'additive' (default since round 5: the builder's best
+    # recollection of cqt_pytorch) regularises with an epsilon in the denominator instead.
+    if dual == 'additive':
+        covered = D > 0.0
+        dual = np.where(covered[spec_index], window / (D[spec_index] + DUAL_EPS), 0.0)
+    elif dual in ('floored', 'canonical'):
+        covered = D > (FRAME_FLOOR if dual == 'floored' else 0.0)
+        Dsafe = np.where(covered, D, 1.0)
+        dual = np.where(covered[spec_index], window / Dsafe[spec_index], 0.0)
+    else:
+        raise ValueError('unknown dual rule %r' % (dual,))
 
     return dict(n_bins=n_bins, block_length=N, max_window_length=M, freqs=freqs,
                 lengths=lengths, positions=positions, start=start, pad=pad,

@@ -26,6 +26,34 @@ def test_pin_tool_is_a_clean_no_op_without_cqt_pytorch():
     assert out.returncode == 0 and 'parity-unpinned' in out.stdout and not os.path.exists(PIN)
 
 
+@pytest.mark.parametrize('planted', [dict(crop_alignment='centre_minus_M', dual='canonical', diagonal='mirrored'),
+                                     dict(bandwidth_bin=1, dual='additive', dual_eps=1e-6, diagonal='positive'),
+                                     dict(window='hann_symmetric', dual='floored', frame_floor=1e-3, diagonal='positive')])
+def test_search_recovers_a_planted_convention(planted, capsys):
+    """The search of tools/pin_cqt.py, run against coefficients PRODUCED by one point of its own hypothesis space (standing in for the
+    absent package): it must rank that point first with ~0 error on the analysis side and name its dual rule on the synthesis side --
+    incl. the round-4 review's hypotheses (crop start c_k - M, bandwidth from bin k + 1, mirrored diagonal), two of which only
+    the wrapped full-spectrum oracle can evaluate."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import pin_cqt
+    from oracle.nsgt_dense import WrappedNSGT
+    x = pin_cqt.pin_audio()[..., :pin_cqt.N].astype(np.float64)
+    truth = WrappedNSGT(9, 60, 22050, 66150, conventions=planted)
+    c = truth.encode(x)
+    back = 3.7 * truth.decode(c)[0, 0]                      # an arbitrary scale: decode()'s normalisation is not part of the search
+    analysis = {k: v for k, v in planted.items() if k in ('window', 'crop_alignment', 'bandwidth_bin')}
+    space = [dict(window='hann_periodic', length_rounding='round', centre_rounding='round', crop_alignment='centred', bandwidth_bin=0),
+             dict(window='hann_periodic', length_rounding='round', centre_rounding='round', crop_alignment='window_start', bandwidth_bin=0)]
+    space.insert(1, dict(space[0], **analysis))
+    results, duals = pin_cqt.search(x, c, back, space=space)
+    assert results[0][0] < 1e-12 and all(results[0][1][k] == v for k, v in analysis.items())
+    assert results[1][0] > 1e-3                             # ... and the runner-up is clearly off
+    want_dual = {k: v for k, v in planted.items() if k in ('dual', 'dual_eps', 'frame_floor')}
+    assert duals[0][0] < 1e-9 and all(duals[0][1][k] == v for k, v in want_dual.items())
+    if planted.get('crop_alignment') == 'centre_minus_M':
+        assert duals[0][1]['diagonal'] == 'mirrored' and 'NOT expressible' in duals[0][2]      # windows wrap: the mirrored sum differs
+
+
 @needs_pin
 def test_oracle_matches_cqt_pytorch_fixture():
     sys.path.insert(0, os.path.join(ROOT, 'tools'))

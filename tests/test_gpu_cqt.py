@@ -99,7 +99,7 @@ def test_round_trip_on_covered_band(cqt, tab):
     rng = np.random.default_rng(2)
     x = rng.uniform(-1, 1, (3, 1, N))
     X = np.fft.rfft(x, axis=-1)
-    X[..., ~tab['covered']] = 0
+    X[..., tab['frame_diag'] <= 1e-3] = 0        # the well-covered band (the default additive dual inverts it to 1e-8 / D per index)
     xb = np.fft.irfft(X, n=N, axis=-1)
     xb = xb / np.abs(xb).max()
     a = torch.from_numpy(xb).float().cuda()
@@ -119,6 +119,7 @@ def test_zeros_and_errors(cqt):
 
 
 CONVENTION_SETS = {
+    'floored_dual': dict(dual='floored'),
     'symmetric_canonical': dict(window='hann_symmetric', dual='canonical'),
     'floor_ceil': dict(length_rounding='floor', centre_rounding='ceil', min_length=2),
     'window_start': dict(crop_alignment='window_start', length_rounding='ceil'),
@@ -170,3 +171,64 @@ def test_batch_is_bit_identical_to_single_clips(cqt, B, nblk):
     assert torch.equal(back, cqt.decode(c))                      # the abs-max is an atomicMax over the batch: order-free
     for b in range(B):
         assert torch.equal(raw[b:b + 1], cqt._decode_raw(c[b:b + 1])), b
+
+
+# ---- any block length (csrc/cqt_generic.hip; reference cqtwrapper.py:15-48 takes arbitrary secs_per_block / sample_rate) ------------
+
+def _generic_cqt(monkeypatch, secs):
+    from timbre_trap.framework import CQT, cqtwrapper
+    monkeypatch.setattr(cqtwrapper, 'FORCE_GENERIC', True)
+    return CQT(9, 60, SR, secs).to('cuda')
+
+
+def test_generic_path_equals_specialised_path_at_the_reference_configuration(cqt, tab, monkeypatch):
+    """N = 66150 / M = 1024 forced onto the any-length kernels (Bluestein + global Stockham passes): the same tables, so the same
+    transform as the specialised kernels -- forward against the oracle at the north-star bar and against the fast path at fp32
+    level, inverse likewise, complex in / out, batch-wide normalisation, the zero guard."""
+    g = _generic_cqt(monkeypatch, 3)
+    assert not g._fast and cqt._fast and g.block_length == N and g.max_window_length == M
+    a = _audio(3, 2, seed=31)
+    ref = nsgt.wrapper_forward(a.numpy(), tab)
+    fast, slow = cqt(a.cuda()), g(a.cuda())
+    scale = np.abs(ref).max()
+    assert slow.shape == fast.shape and slow.is_contiguous()
+    assert np.abs(slow.cpu().numpy() - ref).max() / scale < REL
+    assert float((slow - fast).abs().max()) / scale < 2e-5
+    ce = g.encode(a.cuda())
+    assert ce.is_complex() and ce.shape == (3, 1, 540, 2 * M)
+    assert torch.equal(g.to_real(ce).contiguous(), slow)
+    back_f, back_s = cqt.decode(fast), g.decode(fast)
+    want = nsgt.wrapper_decode(fast.cpu().numpy().astype(np.float64), tab)
+    assert np.abs(back_s.cpu().numpy() - want).max() < REL and float((back_s - back_f).abs().max()) < REL
+    assert abs(float(back_s.abs().max()) - 1.0) < 1e-6
+    assert torch.allclose(g.decode(torch.complex(fast[:, 0], fast[:, 1]).unsqueeze(1)), back_s, atol=1e-6)
+    raw = g._decode_raw(fast)
+    assert torch.equal(raw[1:2], g._decode_raw(fast[1:2]))                   # clips independent before the normalisation
+    z = g.decode(torch.zeros(1, 2, 540, M, device='cuda'))
+    assert z.shape == (1, 1, N) and float(z.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('secs', [2, 4, 2.9, 0.5])
+def test_other_block_lengths(secs):
+    """CQT(9, 60, 22050, secs_per_block != 3): 44100 (M = 512), 88200 (M = 1024), 63945 = 3^2 5 7^2 29 (a prime factor no
+    mixed-radix plan would cover) and 11025 samples (M = 128) -- constructor attributes as the reference computes them
+    (cqtwrapper.py:40-48), forward / inverse against the float64 oracle built for that block length, block independence."""
+    from timbre_trap.framework import CQT
+    n = int(secs * SR)
+    t = nsgt.nsgt_tables(9, 60, SR, n)
+    m = t['max_window_length']
+    cq = CQT(9, 60, SR, secs).to('cuda')
+    assert cq.block_length == n and cq.max_window_length == m and cq.hop_length == n / m and cq.n_bins == 540
+    assert cq.get_expected_frames(2 * n) == 2 * m
+    g = torch.Generator().manual_seed(int(secs * 10))
+    a = torch.rand(2, 1, 2 * n, generator=g) * 2 - 1
+    out = cq(a.cuda())
+    assert out.shape == (2, 2, 540, 2 * m)
+    ref = nsgt.wrapper_forward(a.numpy(), t)
+    assert np.abs(out.cpu().numpy() - ref).max() / np.abs(ref).max() < REL
+    assert torch.equal(out[..., :m], cq(a[..., :n].cuda())) and torch.equal(out[1:2], cq(a[1:2].cuda()))
+    back = cq.decode(out)
+    want = nsgt.wrapper_decode(out.cpu().numpy().astype(np.float64), t)
+    assert back.shape == (2, 1, 2 * n) and np.abs(back.cpu().numpy() - want).max() < REL
+    with pytest.raises(ValueError):
+        cq(torch.zeros(1, 1, n + 1, device='cuda'))

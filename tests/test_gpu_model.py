@@ -737,6 +737,23 @@ def test_frozen_parameter_gets_no_gradient_on_the_bf16_path():
     b0 = model.decoder.block1.tconv[0].bias.detach().clone()
     opt.step()
     assert torch.equal(model.decoder.block1.tconv[0].bias.detach(), b0)
+    # round-4 advisor finding: the views are re-attached BEFORE step() in normal use (grad_norm() for logging, sync_views() /
+    # GradientSync.start(opt) before the all-reduce), which replaces a None gradient by a zero view -- the parameter must still be skipped
+    for touch in (opt.grad_norm, opt.sync_views):
+        bias = model.decoder.block1.tconv[0].bias
+        o, k = slots[id(bias)]
+        opt.exp_avg[o:o + k].fill_(0.3)
+        opt.exp_avg_sq[o:o + k].fill_(0.01)
+        bias.grad = None
+        touch()
+        assert bias.grad is not None and float(bias.grad.abs().max()) == 0.0       # re-attached as a zero view ...
+        b0, m0 = bias.detach().clone(), opt.exp_avg[o:o + k].clone()
+        opt.step()
+        assert torch.equal(bias.detach(), b0) and torch.equal(opt.exp_avg[o:o + k], m0), '... and still skipped by the update'
+    # the record is consumed by step(): with a gradient again, the parameter moves again
+    bias.grad.fill_(1e-3)
+    opt.step()
+    assert not torch.equal(bias.detach(), b0)
 
 
 def test_fused_consistency_backward_equals_two_squared_error_terms():
@@ -767,3 +784,18 @@ def test_fused_consistency_backward_equals_two_squared_error_terms():
     o1, o2 = compute_consistency_loss(*odd)
     (o1 + o2).backward()
     assert all(t.grad is not None for t in odd)
+    # contiguous views at a storage offset that is not 16-byte aligned (round-4 advisor finding: tt_sqdiff2_bwd wants aligned
+    # pointers; such inputs must take the two-term path instead of raising in backward): bitwise the aligned result
+    big = [torch.zeros(shape[0] * shape[1] * shape[2] * shape[3] + 3).cuda() for _ in range(3)]
+    mis = []
+    for buf, t in zip(big, base):
+        buf[3:].copy_(t.reshape(-1))
+        mis.append(buf[3:].view(shape).requires_grad_(True))
+    assert all(t.is_contiguous() and t.data_ptr() % 16 != 0 for t in mis)
+    l1, l2 = compute_consistency_loss(*mis)
+    g1, g2, gb = torch.autograd.grad(l1 + l2, mis)
+    a1, a2, b = (t.clone().requires_grad_(True) for t in base)
+    r1, r2 = compute_consistency_loss(a1, a2, b)
+    (r1 + r2).backward()
+    assert torch.equal(l1, r1) and torch.equal(l2, r2)
+    assert torch.equal(g1, a1.grad) and torch.equal(g2, a2.grad) and torch.equal(gb, b.grad)

@@ -198,6 +198,41 @@ def test_wide_block_stagewise(C, d, shape):
     _stagewise(C, d, *shape)
 
 
+@pytest.mark.parametrize('C', [4, 8, 16, 32])
+@pytest.mark.parametrize('w2sign', ['negative', 'mixed'])
+def test_fp16_hidden_overflow_surfaces(C, w2sign):
+    """
+    Round-4 advisor finding.  In the fp16 build a FINITE hidden pre-activation above 65504 becomes inf once it is an fp16 operand;
+    the 1x1 product then holds -inf (all-negative W2) or inf - inf = NaN (mixed signs), which a NaN-dropping ELU (v_med3) would turn
+    into -1 / 0: a finite, silently wrong y.  torch under fp16 autocast shows inf / NaN there, and so must the kernel.  The bf16
+    build has fp32's range: the same inputs give the finite, correct answer.
+    """
+    from timbre_trap._hip import check, ptr, stream_ptr
+    from timbre_trap.framework import ops
+    B, H, T, d = 1, 9, 64, 1
+    x = torch.full((B, C, H, T), 100.0)
+    w1 = torch.full((C, C, 3, 3), 100.0)                              # interior pre-activation 9 C 1e4 >= 3.6e5
+    w2 = -torch.ones(C, C, 1, 1)
+    if w2sign == 'mixed':
+        w2[:, ::2] = 1.0
+    b = torch.zeros(C)
+    for elt in (torch.float16, torch.bfloat16):
+        lib, st = ops.lib16(elt), stream_ptr()
+        xd = x.cuda()
+        xb = torch.empty((B, H, T, C), dtype=elt, device='cuda')
+        check(lib.tt_wide_pack(ptr(xd), ptr(xb), B, C, H, T, st), 'pack')
+        yb, hb = torch.empty_like(xb), torch.empty_like(xb)
+        check(lib.tt_wide_rb_fwd(ptr(xb), ptr(w1.cuda()), ptr(b.cuda()), ptr(w2.cuda()), ptr(b.cuda()), ptr(yb), ptr(hb), B, C, H, T, d, st), 'fwd')
+        torch.cuda.synchronize()
+        inner = yb[:, 2:-2, 2:-2].float()
+        if elt == torch.float16:
+            assert bool(torch.isinf(hb[:, 2:-2, 2:-2].float()).all())
+            assert not bool(torch.isfinite(inner).any()), 'fp16: the overflow of the hidden activation was hidden (%s W2)' % w2sign
+        else:
+            want = (-1.0 if w2sign == 'negative' else 0.0) + 100.0     # ELU(-C a1) = -1, ELU(0) = 0, plus the residual
+            assert bool(torch.isfinite(inner).all()) and float((inner - want).abs().max()) <= 0.5
+
+
 @pytest.mark.parametrize('C,d,shape,cus', [(32, 3, (1, 65, 256), 1), (16, 2, (2, 37, 320), 1), (32, 1, (3, 20, 200), 2),
                                            (16, 3, (1, 133, 128), 3), (8, 3, (1, 269, 192), 1), (4, 2, (2, 100, 384), 1),
                                            (8, 1, (2, 40, 300), 2), (4, 3, (1, 540, 128), 2)])

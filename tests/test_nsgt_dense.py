@@ -78,8 +78,15 @@ def test_default_oracle_tables_are_the_default_conventions():
 
 
 def test_canonical_dual_inverts_exactly_on_the_covered_band_and_floor_is_the_only_difference():
-    """What the 'floored' deviation changes: only spectral indices with frame-operator diagonal <= 1e-3 (a handful)."""
-    floored, canon = DenseNSGT(9, 60, SR, N), DenseNSGT(9, 60, SR, N, conventions=dict(dual='canonical'))
+    """What the opt-in 'floored' rule changes: only spectral indices with frame-operator diagonal <= 1e-3 (a handful); and what the
+    default 'additive' rule (g / (D + 1e-8)) changes against the canonical dual: a relative 1e-8 / D per index, i.e. nothing on
+    the covered band and a bounded gain (<= 5e3 instead of ~6e4) where only a window tail reaches."""
+    floored, canon = DenseNSGT(9, 60, SR, N, conventions=dict(dual='floored')), DenseNSGT(9, 60, SR, N, conventions=dict(dual='canonical'))
+    additive = DenseNSGT(9, 60, SR, N)
+    assert additive.geo['cv']['dual'] == 'additive' and np.array_equal(additive.kept, canon.kept)
+    assert np.abs(additive.Wd).max() <= 0.5 / np.sqrt(1e-8) and np.abs(canon.Wd).max() > 1e4
+    strong = canon.D > 1e-3
+    assert np.abs(additive.Wd[:, strong] - canon.Wd[:, strong]).max() <= 1.01e-5 * np.abs(canon.Wd[:, strong]).max()
     differ = np.flatnonzero(floored.kept != canon.kept)
     assert 0 < len(differ) <= 64          # the upper tail of the top window (33030..33071) and a few sub-43 Hz indices
     assert canon.D[differ].max() <= 1e-3
@@ -90,6 +97,32 @@ def test_canonical_dual_inverts_exactly_on_the_covered_band_and_floor_is_the_onl
     band = band[(band > 200) & (band < 30000)]
     X[band] = rng.normal(size=len(band)) + 1j * rng.normal(size=len(band))
     x = np.fft.irfft(X, n=N)[None, None]
-    for t in (floored, canon):
+    for t, tol in ((floored, 1e-9), (canon, 1e-9), (additive, 1e-6)):
         back = t.decode(t.encode(x))
-        assert np.abs(back - x).max() < 1e-9 * np.abs(x).max()
+        assert np.abs(back - x).max() < tol * np.abs(x).max()
+
+
+@pytest.mark.parametrize('n,m,p', [(44100, 512, 131072), (88200, 1024, 262144), (66150, 1024, 262144), (63945, 1024, 131072)])
+def test_any_block_length_plan(n, m, p):
+    """The tables of the any-length device path (csrc/cqt_generic.hip) for N in {66150, 44100, 88200} and a block length with a large
+    prime factor: geometry against the dense derivation at that N, and the Bluestein tables as KNOWN-ANSWER data -- the length-N DFT
+    computed from them exactly as the kernels do (chirp, two length-P FFTs around the filter table, chirp), in float32 tables,
+    against numpy's FFT."""
+    plan = nsgt_plan.build_plan(9, 60, SR, n, generic=True)
+    assert not plan['fast'] and plan['M'] == m and plan['P'] == p and p >= 2 * n - 1
+    d = DenseNSGT(9, 60, SR, n)
+    np.testing.assert_array_equal(plan['lengths'], d.geo['L'])
+    np.testing.assert_array_equal(plan['start'] + plan['pad'], d.geo['a'])
+    np.testing.assert_allclose(plan['frame_diag'], d.D, rtol=1e-13, atol=1e-300)
+    assert plan['pos_bin'].shape == (plan['sum_len'],) and plan['pos_bin'][plan['win_off'][7]] == 7
+    c = lambda a: a[:, 0].astype(np.float32).astype(np.float64) + 1j * a[:, 1].astype(np.float32).astype(np.float64)
+    chirp, bfilt = c(plan['chirp']), c(plan['bfilt'])
+    x = np.random.default_rng(n).uniform(-1, 1, n)
+    a = np.zeros(p, dtype=np.complex128)
+    a[:n] = x * chirp
+    w = np.fft.fft(np.conj(np.fft.fft(a) * bfilt))              # the inverse transform as conj(FFT(conj .)); 1 / P is in the table
+    X = chirp * np.conj(w[:n])
+    want = np.fft.fft(x)
+    assert np.abs(X - want).max() < 2e-6 * np.abs(want).max()
+    tw = c(plan['twM'])
+    np.testing.assert_allclose(tw, np.exp(-2j * np.pi * np.arange(m // 2) / m), atol=1e-7)

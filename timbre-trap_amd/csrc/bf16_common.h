@@ -72,6 +72,16 @@ __device__ __forceinline__ float elu_f(float a) { return __builtin_fmaf(a, 0.f, 
 // reaches their output through the residual add (y = ELU(..) + x), and non-finite PARAMETERS are found once per workgroup when the
 // weights are loaded (params_poisoned below) and turn the whole output into NaN.  Two full-rate instructions per element saved.
 __device__ __forceinline__ float elu_res(float a) { return __builtin_amdgcn_fmed3f(a, __expf(a) - 1.f, 0.f); }
+// The OUTPUT activation of the residual-block forward (after the 1x1 product).  In the fp16 build a third source of non-finite values
+// exists that neither the residual add nor the parameter check covers: a FINITE hidden activation above 65504 becomes inf when it is
+// stored / fed to the 1x1 product as fp16, the product then holds -inf or inf - inf = NaN, and the median would turn those into -1 / 0:
+// a silently wrong finite y where torch under fp16 autocast shows inf / NaN in the loss.  The fp16 build therefore keeps the
+// NaN-propagating form here (one v_fma per element); bf16 has fp32's range and keeps the median.
+#if defined(TT_F16)
+__device__ __forceinline__ float elu_out(float a) { return elu_f(a); }
+#else
+__device__ __forceinline__ float elu_out(float a) { return elu_res(a); }
+#endif
 // v * 0 summed over the values a lane loads: +-0 for finite parameters, NaN as soon as one is NaN or inf
 __device__ __forceinline__ float poison_acc(float acc, float v) { return __builtin_fmaf(v, 0.f, acc); }
 __device__ __forceinline__ bool params_poisoned(float acc) {      // any lane of the wave (every wave loads all parameters)

@@ -245,8 +245,8 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_conv(const e16* __restrict__ x
                     e16x8 o;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        o[j] = (e16)(elu_res(z0[j]) + (float)centre[j]);
-                        o[4 + j] = (e16)(elu_res(z1[j]) + (float)centre[4 + j]);
+                        o[j] = (e16)(elu_out(z0[j]) + (float)centre[j]);
+                        o[4 + j] = (e16)(elu_out(z1[j]) + (float)centre[4 + j]);
                     }
                     if (valid) *reinterpret_cast<e16x8*>(y + pix * C + 8 * g) = o;
                 } else {
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_conv(const e16* __restrict__ x
                     const e16x4 xc = *reinterpret_cast<const e16x4*>(smem + ((long)pxc * C + 8 * ((g >> 1) ^ cswz<C>(colc)) + 4 * (g & 1)) * 2);
                     e16x4 o;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (e16)(elu_res(z[j]) + (float)xc[j]);
+                    for (int j = 0; j < 4; ++j) o[j] = (e16)(elu_out(z[j]) + (float)xc[j]);
                     if (valid) *reinterpret_cast<e16x4*>(y + pix * C + 4 * g) = o;
                 }
             }
@@ -976,7 +976,7 @@ __global__ __launch_bounds__(NT, (C == 8 && MODE == 0) ? 3 : 1) void k_nrb_conv(
                     for (int kb = 0; kb < NB; ++kb) z[ob] = mma4(A2[ob][kb], chunk_of<C>(hq, kb), z[ob]);
                 }
 #pragma unroll
-                for (int c = 0; c < C; ++c) o[c] = (e16)(elu_res(z[c >> 2][c & 3]) + (float)centre[c]);
+                for (int c = 0; c < C; ++c) o[c] = (e16)(elu_out(z[c >> 2][c & 3]) + (float)centre[c]);
             }
             if (valid) *reinterpret_cast<vec_t*>(y + pix * C) = o;
         }

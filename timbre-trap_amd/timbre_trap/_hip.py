@@ -20,7 +20,7 @@ CSRC = os.path.join(PKG_ROOT, 'csrc')
 LIB_PATH = os.path.join(PKG_ROOT, 'lib', 'libttrap_hip.so')
 if os.environ.get('TTRAP_LIB'):                         # tuning: an alternative build of the same sources (tools/build_variant.sh)
     LIB_PATH = os.path.join(PKG_ROOT, 'lib', os.environ['TTRAP_LIB'])
-SOURCES = ['cqt.hip', 'conv_generic.hip', 'conv_mfma.hip', 'conv_small.hip', 'conv_wide_bf16.hip', 'conv_level_bf16.hip', 'conv_stride_bf16.hip',
+SOURCES = ['cqt.hip', 'cqt_generic.hip', 'conv_generic.hip', 'conv_mfma.hip', 'conv_small.hip', 'conv_wide_bf16.hip', 'conv_level_bf16.hip', 'conv_stride_bf16.hip',
            'latent_bf16.hip', 'conv_edge_bf16.hip', 'gemm.hip', 'losses.hip',
            # the 16-bit channels-last sources a second time with fp16 elements (two-line wrappers: #define TT_F16 + #include)
            'conv_wide_f16.hip', 'conv_level_f16.hip', 'conv_stride_f16.hip', 'latent_f16.hip', 'conv_edge_f16.hip',
@@ -40,6 +40,13 @@ class CqtPlan(ctypes.Structure):
                 ('sum_len', ctypes.c_int32)]
 
 
+class CqtGenericPlan(ctypes.Structure):
+    """struct tt_cqt_gplan (include/ttrap.h): the any-block-length transform of csrc/cqt_generic.hip."""
+    _fields_ = [('chirp', c_void_p), ('bfilt', c_void_p), ('twP', c_void_p), ('twM', c_void_p), ('bin_tab', c_void_p), ('window', c_void_p),
+                ('dual', c_void_p), ('gat_off', c_void_p), ('gat_idx', c_void_p), ('pos_bin', c_void_p), ('n_bins', ctypes.c_int32),
+                ('sum_len', ctypes.c_int32), ('N', ctypes.c_int32), ('M', ctypes.c_int32), ('P', ctypes.c_int32)]
+
+
 P, I, L, F_ = c_void_p, c_int, c_int64, c_float
 _PROTOS = {
     'tt_version': (c_int, []),
@@ -49,6 +56,9 @@ _PROTOS = {
     'tt_cqt_scratch_bytes': (c_int64, [I, I, I]),
     'tt_cqt_forward': (c_int, [ctypes.POINTER(CqtPlan), P, P, P, I, I, I, P]),
     'tt_cqt_inverse': (c_int, [ctypes.POINTER(CqtPlan), P, P, P, I, I, I, I, P]),
+    'tt_cqt_generic_scratch_bytes': (c_int64, [ctypes.POINTER(CqtGenericPlan), I]),
+    'tt_cqt_generic_forward': (c_int, [ctypes.POINTER(CqtGenericPlan), P, P, P, I, I, I, P]),
+    'tt_cqt_generic_inverse': (c_int, [ctypes.POINTER(CqtGenericPlan), P, P, P, I, I, I, I, P]),
     'tt_conv2d': (c_int, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, L, L, L, L, I, P]),
     'tt_conv2d_wgrad': (c_int, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, L, L, L, L, P]),
     'tt_elu_bwd': (c_int, [P, P, P, L, P]),

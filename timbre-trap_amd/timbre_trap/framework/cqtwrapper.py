@@ -20,6 +20,10 @@ from .. import _hip
 from . import nsgt_plan
 
 _TABLES = ('tw675', 'tw49', 'twNc', 'twN', 'tw1024', 'bin_tab', 'window', 'dual', 'gat_off', 'gat_idx')
+_GENERIC_TABLES = ('chirp', 'bfilt', 'twP', 'twM', 'bin_tab', 'window', 'dual', 'gat_off', 'gat_idx', 'pos_bin')
+# True: also the reference configuration (3 s @ 22.05 kHz) runs on the any-block-length kernels (csrc/cqt_generic.hip) -- for tests
+# that hold the two paths against each other; read when a CQT is constructed
+FORCE_GENERIC = False
 
 
 class CQT(nn.Module):
@@ -46,17 +50,21 @@ class CQT(nn.Module):
 
         self.conventions = nsgt_plan.DEFAULT_CONVENTIONS if conventions is None else conventions
         plan = nsgt_plan.build_plan(n_octaves, bins_per_octave, sample_rate,
-                                    int(secs_per_block * sample_rate), power_of_2_length=True, conventions=self.conventions)
+                                    int(secs_per_block * sample_rate), power_of_2_length=True, conventions=self.conventions,
+                                    generic=FORCE_GENERIC)
         self.block_length = plan['N']
         self.max_window_length = plan['M']
         self._sum_len = plan['sum_len']
-        self._fast = 'tw675' in plan
+        # the reference configuration (N = 66150, M = 1024) runs on the specialised kernels of csrc/cqt.hip, every other block
+        # length on the any-length path of csrc/cqt_generic.hip (same tables, same conventions; reference cqtwrapper.py:15-48
+        # accepts any secs_per_block / sample_rate)
+        self._fast = plan['fast']
+        self._P = int(plan.get('P', 0))
 
-        if self._fast:
-            for name in _TABLES:
-                a = plan[name]
-                t = torch.from_numpy(np.ascontiguousarray(a)).to(torch.int32 if a.dtype.kind == 'i' else torch.float32)
-                self.register_buffer('_t_' + name, t.contiguous(), persistent=False)
+        for name in (_TABLES if self._fast else _GENERIC_TABLES):
+            a = plan[name]
+            t = torch.from_numpy(np.ascontiguousarray(a)).to(torch.int32 if a.dtype.kind == 'i' else torch.float32)
+            self.register_buffer('_t_' + name, t.contiguous(), persistent=False)
 
         self.sample_rate = sample_rate
         # reference cqtwrapper.py:40-48
@@ -68,20 +76,25 @@ class CQT(nn.Module):
     # ---- device side -------------------------------------------------------------------------
 
     def _plan_struct(self, device):
-        if not self._fast:
-            raise NotImplementedError(
-                'the HIP constant-Q transform is specialised for block_length 66150 / 1024 frames '
-                '(3 s @ 22.05 kHz); got block_length=%d, max_window_length=%d'
-                % (self.block_length, self.max_window_length))
         if self._t_window.device != device:
             raise RuntimeError('CQT tables are on %s but the input is on %s; call .to(device) on the module'
                                % (self._t_window.device, device))
-        ps = _hip.CqtPlan()
-        for name in _TABLES:
+        ps = _hip.CqtPlan() if self._fast else _hip.CqtGenericPlan()
+        for name in (_TABLES if self._fast else _GENERIC_TABLES):
             setattr(ps, name, getattr(self, '_t_' + name).data_ptr())
         ps.n_bins = self.n_bins
         ps.sum_len = self._sum_len
+        if not self._fast:
+            ps.N, ps.M, ps.P = self.block_length, self.max_window_length, self._P
         return ps
+
+    def _scratch(self, lib, ps, n_clips, device):
+        nbytes = (lib.tt_cqt_scratch_bytes(n_clips, self.n_bins, self._sum_len) if self._fast
+                  else lib.tt_cqt_generic_scratch_bytes(ctypes.byref(ps), n_clips))
+        if nbytes <= 0:
+            raise RuntimeError('the constant-Q transform plan was rejected by the library (block_length=%d, max_window_length=%d)'
+                               % (self.block_length, self.max_window_length))
+        return torch.empty(nbytes, dtype=torch.uint8, device=device)
 
     def _prepare_audio(self, audio):
         _hip.require_cuda(audio)
@@ -98,15 +111,15 @@ class CQT(nn.Module):
         T = n_blocks * self.max_window_length
         lib = _hip.lib()
         ps = self._plan_struct(a.device)
-        scratch = torch.empty(lib.tt_cqt_scratch_bytes(B * n_blocks, self.n_bins, self._sum_len),
-                              dtype=torch.uint8, device=a.device)
+        scratch = self._scratch(lib, ps, B * n_blocks, a.device)
+        forward = lib.tt_cqt_forward if self._fast else lib.tt_cqt_generic_forward
         if complex_out:
             out = torch.empty((B, 1, self.n_bins, T, 2), dtype=torch.float32, device=a.device)
         else:
             out = torch.empty((B, 2, self.n_bins, T), dtype=torch.float32, device=a.device)
         with _hip.timed('cqt_forward'):
-            _hip.check(lib.tt_cqt_forward(ctypes.byref(ps), _hip.ptr(a), _hip.ptr(out), _hip.ptr(scratch),
-                                          B, n_blocks, int(complex_out), _hip.stream_ptr()), 'tt_cqt_forward')
+            _hip.check(forward(ctypes.byref(ps), _hip.ptr(a), _hip.ptr(out), _hip.ptr(scratch),
+                               B, n_blocks, int(complex_out), _hip.stream_ptr()), 'tt_cqt_forward')
         if complex_out:
             out = torch.view_as_complex(out)
         # (B,1,N) input -> lead == (B,1): the channel dim of the reference output replaces it
@@ -159,12 +172,12 @@ class CQT(nn.Module):
             n_blocks = T // self.max_window_length
             lib = _hip.lib()
             ps = self._plan_struct(c.device)
-            scratch = torch.empty(lib.tt_cqt_scratch_bytes(B * n_blocks, self.n_bins, self._sum_len),
-                                  dtype=torch.uint8, device=c.device)
+            scratch = self._scratch(lib, ps, B * n_blocks, c.device)
+            inverse = lib.tt_cqt_inverse if self._fast else lib.tt_cqt_generic_inverse
             audio = torch.empty((B, 1, n_blocks * self.block_length), dtype=torch.float32, device=c.device)
             with _hip.timed('cqt_inverse'):
-                _hip.check(lib.tt_cqt_inverse(ctypes.byref(ps), _hip.ptr(c), _hip.ptr(audio), _hip.ptr(scratch),
-                                              B, n_blocks, int(is_complex), int(bool(normalize)), _hip.stream_ptr()), 'tt_cqt_inverse')
+                _hip.check(inverse(ctypes.byref(ps), _hip.ptr(c), _hip.ptr(audio), _hip.ptr(scratch),
+                                   B, n_blocks, int(is_complex), int(bool(normalize)), _hip.stream_ptr()), 'tt_cqt_inverse')
         return audio
 
     # ---- layout helpers (reference cqtwrapper.py:74-182), stock tensor views ----------------------

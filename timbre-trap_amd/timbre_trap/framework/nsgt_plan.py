@@ -24,8 +24,9 @@ FRAME_FLOOR = 1e-3   # minimum frame-operator diagonal for a spectral index to b
 class NSGTConventions:
     """
     Every free choice of the transform that the reference leaves to ``cqt_pytorch`` (absent here, so UNPINNED -- see
-    DESIGN.md section 2).  All of them are table-level: switching one changes the plan, never a kernel.  The defaults are the
-    recalled ``cqt_pytorch`` behaviour plus ONE deliberate deviation (``dual='floored'``, documented in INTEGRATION.md);
+    DESIGN.md section 2).  All of them are table-level: switching one changes the plan, never a kernel.  The DEFAULTS are the
+    builder's best recollection of ``cqt_pytorch`` (round 5: that includes the dual -- ``'additive'``, the one-line dense form
+    ``windows / (overlap[indices] + 1e-8)``; the noise-robust ``'floored'`` rule of rounds 1-4 is now the opt-in);
     ``tools/pin_cqt.py`` searches this space for the combination that reproduces ``cqt_pytorch`` when that package is available.
 
       window           'hann_periodic' (torch.hann_window default: 0.5 - 0.5 cos(2 pi n / L)) | 'hann_symmetric' (... / (L - 1))
@@ -33,25 +34,38 @@ class NSGTConventions:
       centre_rounding  how  f_k N / sr      becomes the centre index c_k:    'round' (half to even) | 'floor' | 'ceil'
       crop_alignment   where the M-sample crop sits: 'centred' (crop starts at c_k - M/2, window at floor(M/2 - L_k/2) inside it)
                        | 'window_start' (crop starts at the window's first sample, c_k - floor(L_k/2); a per-bin linear phase)
-      dual             'floored'   canonical dual g_k / D where the frame-operator diagonal D > frame_floor, 0 elsewhere
-                       | 'canonical'  g_k / D wherever D > 0 (exact inverse on the covered band; amplifies coefficient noise by up
-                         to ~6e4 at the few indices only the tail of one window reaches)
-                       | 'additive'  g_k / (D + dual_eps) wherever any window reaches -- the regularised inverse some NSGT
-                         implementations use instead of a floor (a plausible cqt_pytorch form, unverified)
+                       | 'centre_minus_M'  HYPOTHESIS (round-4 review): the crop starts at c_k - M with the window still centred
+                         inside it, i.e. every window sits M/2 spectral samples BELOW its nominal centre.  For the reference
+                         configuration the low bins then reach negative (wrapped) frequencies, which the device tables cannot
+                         express: build_plan raises, only the float64 search of tools/pin_cqt.py (its wrapped full-spectrum transform)
+                         evaluates it
+      bandwidth_bin    0 (default): Omega_k = f_k (2^(1/B) - 2^(-1/B)), the constant-Q bandwidth of bin k itself
+                       | 1  HYPOTHESIS (round-4 review): taken from the NEXT bin's frequency, Omega_k = f_(k+1) (2^(1/B) - 2^(-1/B))
+                         (an off-by-one slice of a frequency list that also carries DC / Nyquist entries would do this)
+      dual             'additive' (default)  g_k / (D + dual_eps) wherever any window reaches -- what a dense torch one-liner
+                         ``windows / (overlap[indices] + eps)`` computes (the epsilon is what keeps the zero-padded part of every
+                         crop from dividing 0 by 0); gains of up to 1 / (2 sqrt(dual_eps)) = 5e3 where only a window tail reaches
+                       | 'canonical'  g_k / D wherever D > 0 (exact inverse on the covered band; gains up to ~6e4 at those indices)
+                       | 'floored'   g_k / D where the frame-operator diagonal D > frame_floor, 0 elsewhere: the rounds 1-4
+                         default, robust against coefficient noise (network outputs) at the band edges -- opt in with
+                         ``CQT(..., conventions=NSGTConventions(dual='floored'))``
+      diagonal         'positive' (default): D summed over the positive-frequency windows | 'mirrored'  HYPOTHESIS (round-4 review):
+                       over those AND their mirror images at N - j.  With every window inside the OPEN positive half-spectrum
+                       (build_plan raises otherwise) the mirrored windows never reach an index of that half, so both give the same
+                       table -- build_plan computes the mirrored sum explicitly when asked and tests assert the equality
       min_length       lower bound of L_k (1: the lowest bins keep a one-sample window)
 
-    The frame-operator diagonal D is taken over the positive-frequency windows only: with every window inside the OPEN positive
-    half-spectrum (build_plan raises otherwise) the mirrored negative-frequency windows of a real signal never reach an index
-    of that half, so a diagonal that includes them is the same table -- that candidate form needs no switch here.
     """
     window: str = 'hann_periodic'
     length_rounding: str = 'round'
     centre_rounding: str = 'round'
     crop_alignment: str = 'centred'
-    dual: str = 'floored'
+    dual: str = 'additive'
     frame_floor: float = FRAME_FLOOR
     min_length: int = 1
     dual_eps: float = 1e-8
+    bandwidth_bin: int = 0
+    diagonal: str = 'positive'
 
     def replace(self, **kw):
         return replace(self, **kw)
@@ -79,7 +93,10 @@ def bin_geometry(n_octaves, bins_per_octave, sample_rate, block_length, power_of
     N = int(block_length)
     f_min = (sample_rate / 2) / (2 ** n_octaves)
     freqs = f_min * 2.0 ** (np.arange(n_bins, dtype=np.float64) / bins_per_octave)
-    bandwidths = freqs * (2.0 ** (1.0 / bins_per_octave) - 2.0 ** (-1.0 / bins_per_octave))
+    if cv.bandwidth_bin not in (0, 1):
+        raise ValueError('bandwidth_bin must be 0 or 1, got %r' % (cv.bandwidth_bin,))
+    bandwidths = (f_min * 2.0 ** ((np.arange(n_bins, dtype=np.float64) + cv.bandwidth_bin) / bins_per_octave)
+                  * (2.0 ** (1.0 / bins_per_octave) - 2.0 ** (-1.0 / bins_per_octave)))
     lengths = np.maximum(_ROUND[cv.length_rounding](bandwidths * N / sample_rate), cv.min_length).astype(np.int64)
     M = int(lengths.max())
     if power_of_2_length:
@@ -91,13 +108,19 @@ def bin_geometry(n_octaves, bins_per_octave, sample_rate, block_length, power_of
     elif cv.crop_alignment == 'window_start':
         pad = np.zeros(n_bins, dtype=np.int64)
         start = positions - lengths // 2
+    elif cv.crop_alignment == 'centre_minus_M':
+        pad = np.floor(M / 2 - lengths / 2).astype(np.int64)
+        start = positions - M
     else:
         raise ValueError('unknown crop alignment %r' % (cv.crop_alignment,))
     return dict(n_bins=n_bins, N=N, M=M, freqs=freqs, lengths=lengths, positions=positions, pad=pad, start=start)
 
 
-def build_plan(n_octaves, bins_per_octave, sample_rate, block_length, power_of_2_length=True, conventions=DEFAULT_CONVENTIONS):
-    """numpy tables (host); see CQT._device_plan for the device copies."""
+def build_plan(n_octaves, bins_per_octave, sample_rate, block_length, power_of_2_length=True, conventions=DEFAULT_CONVENTIONS,
+               generic=False):
+    """numpy tables (host); see CQT._plan_struct for the device copies.  The reference configuration (N = 66150, M = 1024) gets the
+    tables of the specialised kernels (csrc/cqt.hip); every other block length -- or ``generic=True`` -- those of the
+    any-length path (csrc/cqt_generic.hip: Bluestein chirp / filter, power-of-two twiddles)."""
     cv = conventions
     g = bin_geometry(n_octaves, bins_per_octave, sample_rate, block_length, power_of_2_length, cv)
     N, M, F = g['N'], g['M'], g['n_bins']
@@ -112,9 +135,17 @@ def build_plan(n_octaves, bins_per_octave, sample_rate, block_length, power_of_2
         window[win_off[k]:win_off[k + 1]] = hann(L, cv.window)
         spec_index[win_off[k]:win_off[k + 1]] = g['start'][k] + g['pad'][k] + np.arange(L)
     if spec_index.min() <= 0 or spec_index.max() >= N // 2:
-        raise ValueError('NSGT window leaves the open positive half-spectrum')
+        raise ValueError('NSGT window leaves the open positive half-spectrum (spectral indices %d .. %d of a half-spectrum 1 .. %d): the '
+                         'device tables hold windows on positive frequencies only' % (spec_index.min(), spec_index.max(), N // 2 - 1))
     diag = np.zeros(N // 2 + 1)
     np.add.at(diag, spec_index, window ** 2)
+    if cv.diagonal == 'mirrored':
+        full = np.zeros(N)
+        np.add.at(full, spec_index, window ** 2)
+        np.add.at(full, N - spec_index, window ** 2)             # the mirror images: indices N/2 + 1 .. N - 1 only
+        diag = full[:N // 2 + 1]
+    elif cv.diagonal != 'positive':
+        raise ValueError('unknown frame-operator diagonal %r' % (cv.diagonal,))
     # 'floored' (default): indices whose total window energy is below the floor are not synthesised (band edges: the
     # canonical dual 1/w would reach ~6e4 there and amplify coefficient noise into audible sinusoids); 'canonical': every
     # index any window reaches is inverted exactly
@@ -141,10 +172,26 @@ def build_plan(n_octaves, bins_per_octave, sample_rate, block_length, power_of_2
     plan.update(conventions=cv, frame_diag=diag, sum_len=total, win_off=win_off, window=window, dual=dual, spec_index=spec_index,
                 bin_tab=bin_tab.astype(np.int32), gat_off=gat_off.astype(np.int32),
                 gat_idx=order.astype(np.int32), covered=covered)
-    if N == N_FAST and M == M_FAST:
+    plan['fast'] = bool(N == N_FAST and M == M_FAST and not generic)
+    if plan['fast']:
         # four-step twiddles W_Nc^(n2 k1) laid out [n2][k1] (49 x 675) so the row kernel reads them coalesced
         n2k1 = np.outer(np.arange(49, dtype=np.float64), np.arange(675, dtype=np.float64)).reshape(-1)
         ang = -2.0 * np.pi * n2k1 / (N // 2)
         plan.update(tw675=tw(675), tw49=tw(49), twNc=np.stack([np.cos(ang), np.sin(ang)], axis=1),
                     twN=tw(N, N // 2 + 1), tw1024=tw(1024))
+    else:
+        if M & (M - 1):
+            raise ValueError('the device transform needs a power-of-two frame count per block (power_of_2_length=True), got M = %d' % M)
+        # Bluestein: X[k] = c[k] sum_n (x[n] c[n]) conj(c[k - n]),  c[n] = exp(-i pi n^2 / N)  (n^2 reduced mod 2N: exact phases)
+        P = 1 << int(2 * N - 2).bit_length()
+        n = np.arange(N, dtype=np.int64)
+        ph = -np.pi * ((n * n) % (2 * N)).astype(np.float64) / N
+        chirp = np.cos(ph) + 1j * np.sin(ph)
+        wrapped = np.zeros(P, dtype=np.complex128)
+        wrapped[:N] = np.conj(chirp)
+        wrapped[P - n[1:]] = np.conj(chirp[1:])
+        bfilt = np.fft.fft(wrapped) / P
+        pos_bin = np.repeat(np.arange(F, dtype=np.int64), lengths)
+        c2 = lambda z: np.stack([z.real, z.imag], axis=1)
+        plan.update(P=P, chirp=c2(chirp), bfilt=c2(bfilt), twP=tw(P, P // 2), twM=tw(M, M // 2), pos_bin=pos_bin.astype(np.int32))
     return plan

@@ -1309,7 +1309,9 @@ class SqDiff2Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a1, a2, b, scale):
         _hip.require_cuda(a1, b)
-        a1, a2, b = _f32c(a1), _f32c(a2), _f32c(b)
+        # tt_sqdiff2_bwd reads 16 bytes per lane: a contiguous view at an odd storage offset (a batch slice ``x[k:]`` whose offset is
+        # not a multiple of four floats) is copied once here rather than failing in backward after the forward has succeeded
+        a1, a2, b = (t if t.data_ptr() % 16 == 0 else t.clone() for t in (_f32c(a1), _f32c(a2), _f32c(b)))
         lib, st = _hip.lib(), stream_ptr()
         l1 = torch.empty((), dtype=torch.float32, device=b.device)
         l2 = torch.empty((), dtype=torch.float32, device=b.device)

@@ -22,6 +22,7 @@ class FusedAdamW(torch.optim.Optimizer):
         if len(self.param_groups) != 1:
             raise ValueError('FusedAdamW keeps one flat buffer: a single param group only')
         self.max_norm = max_norm
+        self._nograd = set()              # slots whose .grad was None when _reattach() last met them; consumed by step()
         self._flatten(params)
         self._step = 0
 
@@ -55,6 +56,10 @@ class FusedAdamW(torch.optim.Optimizer):
         that makes autograd install a fresh ``.grad`` tensor detaches a view: the fresh gradient is then copied into its slot
         and the view restored (a parameter without a gradient contributes zeros).  A re-allocated ``p.data`` on the same
         device is adopted the same way; one on another device is an error (build a new optimizer after moving the model).
+
+        A slot found with ``p.grad is None`` is REMEMBERED (``self._nograd``) until ``step()`` consumes it: re-attaching replaces the
+        None by a zero view, and ``sync_views()`` / ``grad_norm()`` / ``GradientSync.start(opt)`` all re-attach before ``step()``
+        runs -- without the record such a parameter would take weight decay and residual momentum, which ``torch.optim.AdamW`` skips.
         """
         gbase, pbase = self.flat_grad.data_ptr(), self.flat_param.data_ptr()
         for p, o, k in self._slots:
@@ -63,6 +68,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 slot = self.flat_grad[o:o + k]
                 if g is None:
                     slot.zero_()
+                    self._nograd.add(o)
                 else:
                     if g.device != slot.device:
                         raise RuntimeError('FusedAdamW: a gradient moved to %s (optimizer state is on %s)' % (g.device, slot.device))
@@ -127,8 +133,9 @@ class FusedAdamW(torch.optim.Optimizer):
         # torch.optim.AdamW skips a parameter without a gradient (frozen after the optimizer was built, or ``p.grad = None``): neither
         # its residual momentum nor the weight decay may move it.  The fused kernel walks the whole flat buffer, so the slots of such
         # parameters (zero gradient: nothing in the clipping norm either) are put back, moments included, after the update.
-        frozen = [(o, k) for p, o, k in self._slots if p.grad is None or not p.requires_grad]
-        self._reattach()
+        self._reattach()                   # records the slots whose gradient is None (now, or at an earlier re-attachment of this step)
+        frozen = [(o, k) for p, o, k in self._slots if o in self._nograd or not p.requires_grad]
+        self._nograd.clear()
         keep = [(o, k, self.flat_param[o:o + k].clone(), self.exp_avg[o:o + k].clone(), self.exp_avg_sq[o:o + k].clone()) for o, k in frozen]
         for o, k in frozen:
             self.flat_grad[o:o + k].zero_()

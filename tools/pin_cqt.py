@@ -14,8 +14,12 @@ It then
      strided subset of (bin, frame) positions, the decode(encode()) round trip, the package version and its registered
      buffers' shapes -> tests/golden/cqt_pytorch_pin.npz (inputs/outputs only; no source);
   2. searches the convention space of timbre_trap.framework.nsgt_plan.NSGTConventions (window family x length rounding x
-     centre rounding x crop alignment x dual rule) with the float64 oracle and prints the combination(s) that reproduce the
-     recorded coefficients to 1e-6, or the closest one with its error -- the default to set in nsgt_plan.DEFAULT_CONVENTIONS.
+     centre rounding x crop alignment -- incl. the HYPOTHESIS 'centre_minus_M' -- x bandwidth from bin k / k + 1 (HYPOTHESIS),
+     then dual rule x frame-operator diagonal 'positive' / 'mirrored' (HYPOTHESIS)) with the float64 oracle and prints the
+     combination(s) that reproduce the recorded coefficients to 1e-6, or the closest one with its error -- the default to set
+     in nsgt_plan.DEFAULT_CONVENTIONS.  Conventions whose windows leave the positive half-spectrum are evaluated on the full
+     spectrum with wrapped indices (oracle/nsgt_dense.WrappedNSGT); the device tables cannot express those yet, and the report
+     says so when one of them is the match.
 tests/test_cqt_pin.py compares the oracle (CPU) and the HIP transform (GPU) with the fixture whenever the file exists.
 """
 
@@ -67,21 +71,39 @@ def main():
                         max_window_length=np.array(getattr(ref, 'max_window_length', -1)), block_length=np.array(getattr(ref, 'block_length', -1)),
                         version=np.array(str(getattr(cqt_pytorch, '__version__', 'unknown'))), **buffers)
     print('recorded', OUT, os.path.getsize(OUT), 'bytes')
+    return search(x, c, back.numpy().astype(np.float64)[0, 0])
 
-    from oracle.nsgt_dense import DenseNSGT
-    want = c[0, 0, ::BIN_STRIDE, ::FRAME_STRIDE]
+
+def analysis_space():
+    for window, lr, cr, crop, bw in itertools.product(('hann_periodic', 'hann_symmetric'), ('round', 'floor', 'ceil'), ('round', 'floor', 'ceil'),
+                                                      ('centred', 'window_start', 'centre_minus_M'), (0, 1)):
+        yield dict(window=window, length_rounding=lr, centre_rounding=cr, crop_alignment=crop, bandwidth_bin=bw)
+
+
+def transform_for(kw):
+    """(transform, note): the dense oracle where the windows stay inside the positive half-spectrum (what the device tables can hold),
+    the wrapped full-spectrum one otherwise."""
+    from oracle.nsgt_dense import DenseNSGT, WrappedNSGT
+    try:
+        return DenseNSGT(9, 60, SR, N, conventions=kw), ''
+    except ValueError:
+        return WrappedNSGT(9, 60, SR, N, conventions=kw), 'windows wrap: NOT expressible by the device tables yet'
+
+
+def search(x, c, wantb, stride=(BIN_STRIDE, FRAME_STRIDE), space=None):
+    """Rank the convention space (``space``: an iterable of convention dicts, default the whole analysis space) against recorded
+    coefficients ``c`` (1, 1, F, T) and the recorded round trip ``wantb`` (samples)."""
+    want = c[0, 0, ::stride[0], ::stride[1]]
     scale = np.abs(c).max()
     results = []
-    space = itertools.product(('hann_periodic', 'hann_symmetric'), ('round', 'floor', 'ceil'), ('round', 'floor', 'ceil'),
-                              ('centred', 'window_start'))
-    for window, lr, cr, crop in space:
-        kw = dict(window=window, length_rounding=lr, centre_rounding=cr, crop_alignment=crop)
+    for kw in (analysis_space() if space is None else space):
         try:
-            got = DenseNSGT(9, 60, SR, N, conventions=kw).encode(x.astype(np.float64))[0, 0, ::BIN_STRIDE, ::FRAME_STRIDE]
+            t, note = transform_for(kw)
+            got = t.encode(x.astype(np.float64))[0, 0, ::stride[0], ::stride[1]]
         except ValueError as e:
             results.append((np.inf, kw, str(e)))
             continue
-        results.append((float(np.abs(got - want).max() / scale), kw, ''))
+        results.append((float(np.abs(got - want).max() / scale), kw, note))
     results.sort(key=lambda r: r[0])
     print('analysis conventions ranked by max |oracle - cqt_pytorch| / max |cqt_pytorch|:')
     for err, kw, note in results[:6]:
@@ -92,23 +114,27 @@ def main():
         print('no combination reproduces cqt_pytorch to 1e-6: the convention space needs another switch (closest above).')
     # synthesis side: with the best analysis conventions, which dual-window rule reproduces decode(encode(x))?
     best = results[0][1]
-    wantb = back.numpy().astype(np.float64)[0, 0]
     duals = []
-    for rule in (dict(dual='canonical'), dict(dual='floored', frame_floor=1e-3), dict(dual='additive', dual_eps=1e-8),
-                 dict(dual='additive', dual_eps=1e-6), dict(dual='additive', dual_eps=1e-12)):
+    rules = [dict(dual='additive', dual_eps=1e-8), dict(dual='canonical'), dict(dual='floored', frame_floor=1e-3),
+             dict(dual='additive', dual_eps=1e-6), dict(dual='additive', dual_eps=1e-12)]
+    for rule, diag in itertools.product(rules, ('positive', 'mirrored')):
+        rule = dict(rule, diagonal=diag)
         try:
-            t = DenseNSGT(9, 60, SR, N, conventions=dict(best, **rule))
+            t, note = transform_for(dict(best, **rule))
             gotb = t.decode(c.astype(np.complex128))[0, 0]
         except (ValueError, AttributeError) as e:
             duals.append((np.inf, rule, str(e)))
             continue
-        duals.append((float(np.abs(gotb - wantb).max() / (np.abs(wantb).max() + 1e-30)), rule, ''))
+        # the scale of decode() is a convention of its own (one-sided vs hermitian-extended spectrum): compare peak-normalised
+        gn, wn = gotb / (np.abs(gotb).max() + 1e-30), wantb / (np.abs(wantb).max() + 1e-30)
+        duals.append((float(np.abs(gn - wn).max()), rule, note))
     duals.sort(key=lambda r: r[0])
-    print('dual-window rules ranked by max |oracle decode - cqt_pytorch decode| / max:')
+    print('dual-window rules ranked by max |oracle decode - cqt_pytorch decode| (both peak-normalised):')
     for err, rule, note in duals:
         print('  %.3e  %s %s' % (err, rule, note))
-    return 0
+    return results, duals
 
 
 if __name__ == '__main__':
-    sys.exit(main())
+    main()
+    sys.exit(0)

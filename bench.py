@@ -104,7 +104,8 @@ def make_train_step(model, opt, world, overlap=True, autocast=True):
     """
     from timbre_trap.framework import compute_consistency_loss, compute_reconstruction_loss, compute_transcription_loss
     from timbre_trap.utils import GradientSync
-    sync = GradientSync(world) if world > 1 else None
+    from timbre_trap.utils.distributed import dist_active
+    sync = GradientSync(world) if (world > 1 or dist_active()) else None        # dist_active at world 1: TTRAP_FORCE_DIST=1 (RCCL on a 1-GPU box)
     state = dict(coeffs=None, src=None)
 
     def step(audio, target, next_audio=None):
@@ -453,7 +454,7 @@ def main():
     train_dtype = {'auto': 'bf16', 'fp32': 'f32', 'bf16x3': 'bf16x3', 'bf16': 'bf16', 'fp16': 'f16'}[args.precision]
     infer_dtype = {'auto': 'f32', 'fp32': 'f32', 'bf16x3': 'bf16x3', 'bf16': 'bf16', 'fp16': 'f16'}[args.precision]
     args.infer_dtype = infer_dtype
-    from timbre_trap.utils.distributed import broadcast_parameters
+    from timbre_trap.utils.distributed import broadcast_parameters, dist_active
     import torch.distributed as dist
 
     # Build decision BEFORE anything initialises the GPU or the process group (init_process_group_from_env selects the device
@@ -465,7 +466,11 @@ def main():
     rank, world, local_rank = init_process_group_from_env()
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
-    if world > 1:
+    # the data-parallel exchange is live with more than one rank -- or with ONE rank under TTRAP_FORCE_DIST=1 (how RCCL is exercised on
+    # a 1-GPU box: same process group, broadcast, asynchronous all-reduce and stream wait; the figures of `overlap` / `allreduce_ms`
+    # are then those of a one-rank communicator)
+    multi = world > 1 or dist_active()
+    if multi:
         dist.barrier()
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (there is no CPU fallback for the HIP path)')
@@ -481,13 +486,13 @@ def main():
     if args.mode == 'infer':
         return bench_inference(model, args, rank, world, dev)
     opt = FusedAdamW(model.parameters(), lr=1e-3, max_norm=10.0)
-    if world > 1:
+    if multi:
         broadcast_parameters(opt.flat_param)
     audio, target = synthetic_batch(args.batch, rank, dev)
     step_fn = make_train_step(model, opt, world, overlap=not args.no_overlap, autocast=args.precision == 'auto')
 
     def sync():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -510,7 +515,7 @@ def main():
     _hip.EVENT_LOG = None
     rank_ms = 1000.0 * elapsed / args.steps
     per_rank_ms = [rank_ms]
-    if world > 1:
+    if multi:
         # RCCL moves device tensors, gloo (functional tests of the N > 1 path on one GPU) host tensors
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
         gathered = [torch.zeros_like(t) for _ in range(world)]
@@ -529,7 +534,7 @@ def main():
     torch.cuda.synchronize()
     _hip.EVENT_LOG = None
     allreduce_ms = overlap_info = None
-    if world > 1 and not args.no_overlap:
+    if multi and not args.no_overlap:
         # did the next batch's CQT really run beside the all-reduce?  Compute-stream timestamps of two instrumented steps:
         # [start of the exchange] -> [CQT enqueued and finished] -> [the stream's wait for the collective released]
         step_fn.state['probe'] = []
@@ -542,7 +547,7 @@ def main():
         overlap_info = dict(cqt_on_compute_stream_ms=cq, wait_for_collective_after_cqt_ms=wt, backend=dist.get_backend(),
                             note='RCCL runs the collective on its own stream; wait << allreduce_ms means it was hidden behind the CQT '
                                  '(gloo blocks the host instead: the figures are then host-side)')
-    if world > 1:
+    if multi:
         a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         a0.record()
@@ -768,7 +773,7 @@ def main():
                     peak_memory_gb=peak_gb, inference_config1=infer, fp32_train_step=fp32_step, skip_connections_step=skip_step, per_rank_ms=per_rank_ms, allreduce_ms=allreduce_ms, overlap=overlap_info, cpu_baseline=base, cpu_baseline_config0=base0,
                     final_loss=float(total.detach()))
         print(json.dumps(line))
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

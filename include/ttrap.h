@@ -372,7 +372,25 @@ int tt_l2norm(const float* x, float* norm_out, double* partials, int64_t n, void
  * written back when write_clipped != 0, to match clip_grad_norm_'s in-place semantics). */
 int tt_adamw_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, const float* norm,
                   int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
-                  int step, float max_norm, int write_clipped, void* stream);
+                  int step, float max_norm, int write_clipped, int32_t* skipped, void* stream);
+/* `skipped` (device, may be NULL): overflow guard of the loss-scaled fp16 backward, the part of torch.amp.GradScaler the reference
+ * does without (experiments/train.py:415 has autocast but no scaler).  With norm and skipped given, a NON-FINITE norm[0] makes the
+ * call a no-op that adds 1 to skipped[0]; the bias corrections use step - skipped[0], the number of updates actually applied. */
+
+/* Static loss scale of the 16-bit backward, per calling thread (default 1; returns the previous value).  While S != 1 the backward
+ * entry points of the 16-bit channels-last layers treat every 16-bit activation gradient they are handed as carrying the factor S
+ * and every fp32 gradient as unscaled:
+ *   tt_convout16_bwd                      dx (16-bit) = S * (...)            -- the gradient ENTERS the 16-bit region; dw, db unscaled
+ *   tt_latent16_expand   (bias == NULL)   out (16-bit) = S * (...)           -- likewise (data gradient of Encoder.convlat)
+ *   tt_latent16_wgrad    (gy == NULL)     z (fp32 gradient) is scaled by S on its way to 16 bits; dw *= 1/S
+ *   tt_latent16_wgrad    (gy != NULL), tt_latent16_contract (gy != NULL), tt_convin16_bwd, tt_wide_rb_bwd*, tt_wide_level_bwd,
+ *   tt_sconv16_bwd, tt_tconv16_bwd, tt_dot16
+ *                                         every fp32 output (dw, db, dz, dx) *= 1/S; 16-bit data gradients stay scaled
+ * With S a power of two this is an exact identity in real arithmetic; in fp16 it lifts activation gradients of ~1e-7 (the loss is a
+ * mean over B x T frames) out of the subnormal range.  The value is read on the host when a kernel is launched and passed by value:
+ * stream-ordered like any argument, and invisible to other threads.  Forward entry points must be called with S = 1
+ * (timbre_trap/framework/ops.py sets it only around its backward calls). */
+float tt_set_loss_scale(float scale);
 
 /* ------------------------------------------------------------------------------------------------
  * Helpers on either side of the path.

@@ -129,6 +129,44 @@ def test_rccl_allreduce_smoke_when_two_gpus_present():
     assert out.stdout.count('NCCL_OK') == n
 
 
+@pytest.mark.gpu
+def test_rccl_single_rank_next_to_the_hip_library():
+    """
+    RCCL on the 1-GPU box (round-4 verdict item 5): `bench.py` under `torch.distributed.run --nproc-per-node 1` with backend 'nccl' and
+    TTRAP_FORCE_DIST=1, which keeps the whole N > 1 path alive at world size 1 -- process group, broadcast of the flat parameters,
+    GradientSync's asynchronous all-reduce on RCCL's own stream with the next batch's CQT issued meanwhile, the stream wait, the
+    stand-alone all-reduce timing.  Proves that ProcessGroupNCCL initialises beside the ctypes-loaded libttrap_hip.so and torch's
+    bundled HIP runtime (three users of one runtime), that the communicator comes up with HSA_ENABLE_IPC_MODE_LEGACY=0, and that
+    `work.wait()` orders the optimizer step after the collective: the loss after the same steps must equal the plain one-process run.
+    """
+    import json
+    import socket
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', TTRAP_FORCE_DIST='1')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'TTRAP_DIST_BACKEND'):
+        env.pop(k, None)
+    with socket.socket() as s_:
+        s_.bind(('127.0.0.1', 0))
+        port = s_.getsockname()[1]
+    argv = ['--gpus', '1', '--steps', '3', '--warmup', '1', '--batch', '2', '--no-cpu-baseline']
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+                          '--master-port', str(port), os.path.join(ROOT, 'bench.py')] + argv, env=env, capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 1 and line['config']['parallelism'] == 'dp1'
+    assert line['overlap'] is not None and line['overlap']['backend'] == 'nccl', line['overlap']
+    assert line['allreduce_ms'] is not None and 0.0 < line['allreduce_ms'] < 50.0
+    # RCCL does not block the host: the compute stream's wait after the CQT is a stream wait of (at most) the collective's length
+    assert line['overlap']['wait_for_collective_after_cqt_ms'] < 50.0
+    plain = _bench(*argv)
+    assert plain.returncode == 0, plain.stdout[-2000:] + plain.stderr[-3000:]
+    ref = json.loads([l for l in plain.stdout.splitlines() if l.startswith('{')][0])
+    assert ref['overlap'] is None and ref['allreduce_ms'] is None
+    assert abs(line['final_loss'] - ref['final_loss']) <= 1e-4 * abs(ref['final_loss']), (line['final_loss'], ref['final_loss'])
+
+
 def _bench(*argv, **env_over):
     env = dict(os.environ)
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'TTRAP_DIST_BACKEND'):

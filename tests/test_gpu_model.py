@@ -448,6 +448,104 @@ def test_autocast_fp16_step_matches_oracle_outputs_losses_and_all_gradients():
     _autocast_step_vs_oracle(2, 1, 2, record='fp16_grad_parity.txt', dtype=torch.float16, bars=(4e-3, 2.5e-3, 8e-2, 8e-2, 0.998, 3e-3))
 
 
+def _grads_of_step(model, c, target, dtype):
+    from timbre_trap.framework import compute_consistency_loss, compute_reconstruction_loss, compute_transcription_loss
+    with torch.autocast(device_type='cuda', dtype=dtype or torch.bfloat16, enabled=dtype is not None):
+        latents, emb, _ = model.encoder(c)
+        emb = model.apply_skip_connections(emb)
+        rec, trn = model.decode(latents, emb), model.decode(latents, emb, True)
+        lat2, emb2, _ = model.encoder(trn)
+        emb2 = model.apply_skip_connections(emb2)
+        trn_rec, trn_scr = model.decode(lat2, emb2), model.decode(lat2, emb2, True)
+        l_sp, l_sc = compute_consistency_loss(trn_rec, trn_scr, trn)
+        total = compute_reconstruction_loss(rec, c) + compute_transcription_loss(model.to_activations(trn), target, True) + (l_sp + l_sc)
+        model.zero_grad()
+        total.backward()
+    torch.cuda.synchronize()
+    outs = [t.detach().float().clone() for t in (rec, latents, trn, trn_rec, trn_scr)]
+    return outs, {k: p.grad.detach().double().clone() for k, p in model.named_parameters()}
+
+
+@pytest.mark.parametrize('tag,clips', [('mc2', 64), ('mc2skip', 4)], ids=['bench-batch', 'skip-connections'])
+def test_fp16_loss_scale_repairs_the_gradients_at_the_bench_batch(tag, clips, monkeypatch):
+    """
+    Round-4 verdict item 4: the reference's own autocast dtype (float16, train.py:415, no GradScaler) at the BENCH batch, 64 clips --
+    dL/dlogit ~ 3e-5 of the error, activation gradients of the first encoder levels ~1e-7, below fp16's normal range: round 4
+    measured parameter gradients 3.4e-2 median / 0.53 worst off the fp32 path.  With the static loss scale (ops.FP16_LOSS_SCALE, 2^12,
+    applied where a gradient enters the 16-bit region and removed inside the kernels' fp32 epilogues -- exact in real arithmetic) the
+    same step must read: median <= 3e-3, every tensor <= 5e-2, outputs unchanged (the forward never sees the scale), every ``.grad``
+    the TRUE gradient (no factor left anywhere: compared against the fp32 HIP path, itself pinned to the CPU restatement at small
+    batch).  And with the scale switched off the old defect is still there -- the comparison is the repair, not a loosened bar.
+    """
+    import bench
+    from timbre_trap.framework import ops
+    torch.manual_seed(2)
+    model = _model(KW[tag])
+    audio, target = bench.synthetic_batch(clips, 0, 'cuda')
+    with torch.no_grad():
+        c = model.sliCQ(audio)
+    del audio
+    ref_outs, ref = _grads_of_step(model, c, target, None)
+    ref_outs = [t.cpu() for t in ref_outs]
+    torch.cuda.empty_cache()
+
+    def rel(g):
+        return sorted(float((g[k] - ref[k]).norm() / (ref[k].norm() + 1e-300)) for k in ref)
+    assert ops.FP16_LOSS_SCALE == 4096.0
+    outs, g = _grads_of_step(model, c, target, torch.float16)
+    r = rel(g)
+    out_err = [float((a.cpu() - b).abs().max() / b.abs().max()) for a, b in zip(outs, ref_outs)]
+    assert max(out_err) < 4e-3, out_err
+    assert all(bool(torch.isfinite(v).all()) for v in g.values())
+    assert r[len(r) // 2] <= 3e-3 and r[-1] <= 5e-2, (r[len(r) // 2], r[-1])
+    del outs, g
+    torch.cuda.empty_cache()
+    if clips < 64:
+        return          # skip connections on (their joins and the five skip weights' gradients -- tt_dot16 -- sit inside the scaled region)
+    monkeypatch.setattr(ops, 'FP16_LOSS_SCALE', 1.0)
+    _, g1 = _grads_of_step(model, c, target, torch.float16)
+    r1 = rel(g1)
+    assert r1[len(r1) // 2] > 1e-2 and r1[-1] > 1e-1, 'unscaled fp16 at 64 clips no longer underflows? (%g, %g)' % (r1[len(r1) // 2], r1[-1])
+
+
+def test_fp16_overflow_skips_the_step_like_a_grad_scaler():
+    """The other half of a loss scale: a backward that overflows fp16 (here: provoked with a scale of 2^24 on ordinary gradients)
+    yields inf / NaN parameter gradients; FusedAdamW must then leave parameters, moments and the effective step count alone
+    (tt_adamw_step: non-finite norm -> no-op, skipped += 1), and the next clean step must be the FIRST update (bias corrections
+    at t = 1) -- what torch.amp.GradScaler does, and what the reference, which has no scaler, cannot."""
+    from timbre_trap.framework import compute_reconstruction_loss, ops
+    from timbre_trap.utils import FusedAdamW
+    torch.manual_seed(5)
+    model = _model(KW['mc2'])
+    twin = _model(KW['mc2'])
+    twin.load_state_dict(model.state_dict())
+    c = stub_cqt.closed_form_coefficients(1, 540, 64).cuda() * 50.0
+
+    def step(m, o, scale):
+        prev, ops.FP16_LOSS_SCALE = ops.FP16_LOSS_SCALE, scale
+        try:
+            with torch.autocast(device_type='cuda'):
+                latents, _, _ = m.encoder(c)
+                loss = compute_reconstruction_loss(m.decode(latents, None), c)
+                o.zero_grad()
+                loss.backward()
+            return o.step()
+        finally:
+            ops.FP16_LOSS_SCALE = prev
+    opt, opt2 = FusedAdamW(model.parameters(), lr=1e-3, max_norm=10.0), FusedAdamW(twin.parameters(), lr=1e-3, max_norm=10.0)
+    before = opt.flat_param.clone()
+    norm = step(model, opt, 2.0 ** 24)
+    torch.cuda.synchronize()
+    assert not bool(torch.isfinite(norm).all()), 'the provoked overflow did not happen (norm %g)' % float(norm)
+    assert int(opt.skipped) == 1 and torch.equal(opt.flat_param, before)
+    assert float(opt.exp_avg.abs().max()) == 0.0 and float(opt.exp_avg_sq.abs().max()) == 0.0
+    n1, n2 = step(model, opt, 4096.0), step(twin, opt2, 4096.0)          # the next clean step == the first step of an undisturbed twin
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(n1).all()) and int(opt.skipped) == 1 and int(opt2.skipped) == 0
+    assert not torch.equal(opt.flat_param, before)
+    assert torch.allclose(opt.flat_param, opt2.flat_param, rtol=0, atol=2e-6), float((opt.flat_param - opt2.flat_param).abs().max())
+
+
 def test_autocast_bf16_step_at_reference_training_shape():
     """
     The same comparison at the reference's OWN training shape (round-3 verdict, weak #3): experiments/train.py:45,48 default to

@@ -51,6 +51,14 @@ static inline bool tt_tune_set(const char*) { return false; }
 extern int g_tt_cu_limit;                       // defined in losses.hip
 static inline int tt_cus() { return g_tt_cu_limit; }
 
+// Static loss scale of the fp16 backward (tt_set_loss_scale, include/ttrap.h): the factor S carried by every 16-bit activation
+// gradient the CALLING THREAD hands to the backward entry points from now on.  Read on the host at launch time and passed to the
+// kernels by value, so it is ordered with the stream like any other argument; thread-local, so concurrent callers (autograd worker
+// threads of different devices) do not see each other's setting.  1 (the default) is the plain path.
+extern thread_local float g_tt_loss_scale;      // defined in losses.hip
+static inline float tt_loss_scale() { return g_tt_loss_scale; }
+static inline float tt_loss_unscale() { return 1.0f / g_tt_loss_scale; }
+
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }

@@ -323,13 +323,15 @@ __global__ __launch_bounds__(NT) void k_cin_fwd(const float* __restrict__ x, con
 template <bool DX, bool VEC>
 __global__ __launch_bounds__(NT, 2) void k_cin_bwd(const float* __restrict__ x, const e16* __restrict__ y, const e16* __restrict__ dy,
                                                  const float* __restrict__ w, float* __restrict__ dx, float* __restrict__ part,
-                                                 int H, int T, int tiles_h, int tiles_t, int ntiles) {
+                                                 int H, int T, int tiles_h, int tiles_t, int ntiles, float unscale) {
     __shared__ __attribute__((aligned(16))) float xs[2 * PPLANE];
     __shared__ __attribute__((aligned(16))) float gs[4 * EPLANE + 4];
     __shared__ float red[4 * 76];
     __shared__ __attribute__((aligned(16))) float wl[72];       // [(co * 9 + k) * 2 + ci]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (DX && tid < 72) { const int ci = tid & 1, q = tid >> 1; wl[tid] = w[((q / 9) * 2 + ci) * 9 + q % 9]; }
+    // dy carries the calling thread's loss scale S (a power of two): the fp32 data gradient leaves the scaled region through weights
+    // multiplied by 1 / S (exact), the weight / bias sums through k_edge_reduce
+    if (DX && tid < 72) { const int ci = tid & 1, q = tid >> 1; wl[tid] = unscale * w[((q / 9) * 2 + ci) * 9 + q % 9]; }
     f32x2 acc[2][18];                                            // [co pair][ci * 9 + k]: dW of co = 2p (lane 0) and 2p + 1 (lane 1)
     f32x2 accb[2];
 #pragma unroll
@@ -478,14 +480,14 @@ __global__ __launch_bounds__(NT) void k_cout_fwd(const e16* __restrict__ x, cons
 template <bool VEC>
 __global__ __launch_bounds__(NT, 2) void k_cout_bwd(const e16* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ w,
                                                   e16* __restrict__ dx, float* __restrict__ part, int H, int T, int tiles_h,
-                                                  int tiles_t, int ntiles) {
+                                                  int tiles_t, int ntiles, float scale) {
     __shared__ __attribute__((aligned(16))) float xs[4 * EPLANE + 4];
     __shared__ __attribute__((aligned(16))) float gs[2 * PPLANE];
     __shared__ float red[4 * 74];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float wa[18];                                                // [co * 9 + k]: w[co][ci = lane % 4][k], the A operand of the data gradient
 #pragma unroll
-    for (int i = 0; i < 18; ++i) wa[i] = w[((i / 9) * 4 + (lane & 3)) * 9 + i % 9];
+    for (int i = 0; i < 18; ++i) wa[i] = scale * w[((i / 9) * 4 + (lane & 3)) * 9 + i % 9];    // dx ENTERS the loss-scaled 16-bit region: x S (exact)
     f32x2 acc[36], accb = splat2(0.f);                           // [ci * 9 + k]: dW of co 0 (lane 0) and co 1 (lane 1)
 #pragma unroll
     for (int i = 0; i < 36; ++i) acc[i] = splat2(0.f);
@@ -561,7 +563,7 @@ __global__ __launch_bounds__(NT, 2) void k_cout_bwd(const e16* __restrict__ x, c
 
 // dw[e] += sum over workgroups (e < 72), db[e - 72] likewise; 1024 threads = 64 elements x 16 slices
 __global__ __launch_bounds__(1024) void k_edge_reduce(const float* __restrict__ part, int nwg, float* __restrict__ dw, float* __restrict__ db,
-                                                       int nb) {
+                                                       int nb, float scale) {
     __shared__ float red[16][64];
     const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + el;
@@ -574,7 +576,7 @@ __global__ __launch_bounds__(1024) void k_edge_reduce(const float* __restrict__ 
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) sum += red[i][el];
-    if (e < 72) dw[e] += sum; else db[e - 72] += sum;
+    if (e < 72) dw[e] += sum * scale; else db[e - 72] += sum * scale;
 }
 
 constexpr int EDGE_MAX_WG = 1024;
@@ -605,12 +607,12 @@ int tt_convin16_bwd(const float* x, const void* y, const void* dy, const float* 
     const int grid = edge_grid(n);
     hipStream_t st = tt_stream(stream);
     const bool vec = T % 4 == 0;
-#define CIN_BWD(DX_, V_) hipLaunchKernelGGL((k_cin_bwd<DX_, V_>), dim3(grid), dim3(NT), 0, st, x, (const e16*)y, (const e16*)dy, w, dx, (float*)ws, H, T, th, tt, n)
+#define CIN_BWD(DX_, V_) hipLaunchKernelGGL((k_cin_bwd<DX_, V_>), dim3(grid), dim3(NT), 0, st, x, (const e16*)y, (const e16*)dy, w, dx, (float*)ws, H, T, th, tt, n, tt_loss_unscale())
     if (dx) { if (vec) CIN_BWD(true, true); else CIN_BWD(true, false); }
     else { if (vec) CIN_BWD(false, true); else CIN_BWD(false, false); }
 #undef CIN_BWD
     TT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_edge_reduce, dim3(2), dim3(1024), 0, st, (const float*)ws, grid, dw, db, 4);
+    hipLaunchKernelGGL(k_edge_reduce, dim3(2), dim3(1024), 0, st, (const float*)ws, grid, dw, db, 4, tt_loss_unscale());
     TT_LAUNCH_CHECK();
     return 0;
 }
@@ -629,10 +631,10 @@ int tt_convout16_bwd(const void* x, const float* dy, const float* w, void* dx, f
     int th, tt, n; edge_tiles(B, H, T, th, tt, n);
     const int grid = edge_grid(n);
     hipStream_t st = tt_stream(stream);
-    if (T % 4 == 0) hipLaunchKernelGGL(k_cout_bwd<true>, dim3(grid), dim3(NT), 0, st, (const e16*)x, dy, w, (e16*)dx, (float*)ws, H, T, th, tt, n);
-    else hipLaunchKernelGGL(k_cout_bwd<false>, dim3(grid), dim3(NT), 0, st, (const e16*)x, dy, w, (e16*)dx, (float*)ws, H, T, th, tt, n);
+    if (T % 4 == 0) hipLaunchKernelGGL(k_cout_bwd<true>, dim3(grid), dim3(NT), 0, st, (const e16*)x, dy, w, (e16*)dx, (float*)ws, H, T, th, tt, n, tt_loss_scale());
+    else hipLaunchKernelGGL(k_cout_bwd<false>, dim3(grid), dim3(NT), 0, st, (const e16*)x, dy, w, (e16*)dx, (float*)ws, H, T, th, tt, n, tt_loss_scale());
     TT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_edge_reduce, dim3(2), dim3(1024), 0, st, (const float*)ws, grid, dw, db, 2);
+    hipLaunchKernelGGL(k_edge_reduce, dim3(2), dim3(1024), 0, st, (const float*)ws, grid, dw, db, 2, 1.f);   // dW, db from the fp32 dy itself
     TT_LAUNCH_CHECK();
     return 0;
 }

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void k_scaled_add16(const E* __restrict__ a, c
 
 template <class E>
 __global__ __launch_bounds__(256) void k_dot16(const E* __restrict__ a, const E* __restrict__ b, float* __restrict__ out,
-                                               long n8, long n) {
+                                               long n8, long n, float scale) {
     typedef E e8 __attribute__((ext_vector_type(8)));
     __shared__ float red[4];
     float acc = 0.f;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void k_dot16(const E* __restrict__ a, const E*
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1] + red[2] + red[3]) * scale);
 }
 
 // ---- LDS-tiled 3x3 boundary convs (2 <-> 4 channels, stride 1, pad 1) ------------------------------------------------
@@ -624,7 +624,7 @@ static int dot16(const void* a, const void* b, float* out, int64_t n, void* stre
     if ((((uintptr_t)a | (uintptr_t)b) & 15) != 0) return TT_E_BADARG;
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_dot16<E>, dim3(grid1d((n + 7) / 8, 256 * 4, 1024)), dim3(256), 0, tt_stream(stream), (const E*)a,
-                       (const E*)b, out, (long)(n / 8), (long)n);
+                       (const E*)b, out, (long)(n / 8), (long)n, tt_loss_unscale());   // a = the S-scaled gradient (backward of the skip weights)
     TT_LAUNCH_CHECK();
     return 0;
 }

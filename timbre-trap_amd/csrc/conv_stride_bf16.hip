@@ -763,7 +763,7 @@ __global__ __launch_bounds__(NT, C == 32 ? ((!DX && GS) ? 3 : 2) : W4_WAVES16) v
     }
 }
 
-struct W4Red { const float* part; const float* dbpart; int gw; float* dw; float* db; };
+struct W4Red { const float* part; const float* dbpart; int gw; float* dw; float* db; float scale = tt_loss_unscale(); };
 
 // 1024 threads = REL consecutive dump elements x RSL slices of the contributing waves (dumps) / workgroups (bias partials)
 template <int C, bool GS>
@@ -801,9 +801,9 @@ __global__ __launch_bounds__(1024) void k_w4_reduce(W4Red ar) {
         const int lane = e & 63, r = (e >> 6) & 3, t3 = e >> 8;
         const int c = t3 % G::NBT, a = (t3 / G::NBT) % G::NA, k = t3 / (G::NBT * G::NA);
         const int ach = 16 * a + 4 * (lane >> 4) + r, bch = 16 * c + (lane & 15);
-        if (ach < 2 * C && bch < C) ar.dw[(ach * C + bch) * 4 + k] += sum;
+        if (ach < 2 * C && bch < C) ar.dw[(ach * C + bch) * 4 + k] += sum * ar.scale;
     } else if (e < G::DUMP + GC) {
-        ar.db[e - G::DUMP] += sum;
+        ar.db[e - G::DUMP] += sum * ar.scale;
     }
 }
 

@@ -1602,11 +1602,11 @@ __global__ __launch_bounds__(1024) void k_nrb_reduce(RedBatch batch) {
         const int k = e >> 8, r = (e >> 6) & 3, lane = e & 63, g = lane >> 4, n = lane & 15;
         // D row 4g + r = (pixel-in-slot s, channel c), column n = (s', c'): keep s == s'
         const int m = 4 * g + r, s = m / C, c = m - s * C, s2 = n / C, c2 = n - s2 * C;
-        if (s == s2) atomicAdd(ar.dw1 + (c * C + c2) * 9 + k, sum);      // 16 / C contributions per element
+        if (s == s2) atomicAdd(ar.dw1 + (c * C + c2) * 9 + k, sum * ar.scale);   // 16 / C contributions per element
     } else if (e < WDUMP + ADUMP) {
         const int q = e - WDUMP;
         float* dst = q < C * C ? ar.dw2 + q : (q < C * C + C ? ar.db1 + (q - C * C) : ar.db2 + (q - C * C - C));
-        *dst += sum;
+        *dst += sum * ar.scale;
     }
 }
 

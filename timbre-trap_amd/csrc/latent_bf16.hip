@@ -61,7 +61,7 @@ __global__ __launch_bounds__(NT) void k_lat_wprep2(const float* __restrict__ w, 
 // TimbreTrap.decode, modules.py:139-142, without materialising the concatenation), zero beyond D
 template <int KS>
 __global__ __launch_bounds__(NT) void k_lat_zprep(const float* __restrict__ z, e16* __restrict__ zt, int D, int Dz, float fill, int T,
-                                                   long npix) {
+                                                   long npix, float zscale) {
     constexpr int ZS = 32 * KS + 16, PCS = ZS / 8;
     // a wave = 64 consecutive frames x one 16-byte piece: the fp32 reads are coalesced, the bf16 writes 16 bytes per lane
     const long i = (long)blockIdx.x * NT + threadIdx.x;
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(NT) void k_lat_zprep(const float* __restrict__ z, e
     const long b = pix / T, t = pix - b * T;
     e16x8 v;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (e16)(d0 + e < Dz ? z[(b * Dz + d0 + e) * T + t] : (d0 + e < D ? fill : 0.f));
+    for (int e = 0; e < 8; ++e) v[e] = (e16)(zscale * (d0 + e < Dz ? z[(b * Dz + d0 + e) * T + t] : (d0 + e < D ? fill : 0.f)));
     *reinterpret_cast<e16x8*>(zt + pix * ZS + d0) = v;
 }
 
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(NT) void k_lat_zprep(const float* __restrict__ z, e
 template <int CT, int DT, bool GATE, int QN>
 __global__ __launch_bounds__(NT) void k_lat_contract(const e16* __restrict__ in, const e16* __restrict__ gy,
                                                       const e16* __restrict__ wp, const float* __restrict__ bias,
-                                                      float* __restrict__ out, int D, int Dout, int E, int T, long npix) {
+                                                      float* __restrict__ out, int D, int Dout, int E, int T, long npix, float oscale) {
     constexpr int SPH = CT / 32;
     constexpr int CHUNK = DT * 64 * 16, ROUNDS = (DT * 64 + NT - 1) / NT;      // bytes of one step's weights
     extern __shared__ __align__(16) unsigned char smem[];       // two buffers of ROUNDS * NT * 16 bytes
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(NT) void k_lat_contract(const e16* __restrict__ in,
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int d = 16 * dt + 4 * g + r;
-                if (d < Dout) out[(b * Dout + d) * T + t] = acc[dt][q][r] + (bias ? bias[d] : 0.f);
+                if (d < Dout) out[(b * Dout + d) * T + t] = acc[dt][q][r] * oscale + (bias ? bias[d] : 0.f);
             }
     }
     (void)CHUNK;
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(NT, LAT_WGRAD_WAVES) void k_lat_wgrad(const e16* __
 
 template <int CT, int DT>
 __global__ __launch_bounds__(NT) void k_lat_wred(const float* __restrict__ part, const float* __restrict__ dbpart, float* __restrict__ dw,
-                                                  float* __restrict__ db, int D, int E, int nsplit) {
+                                                  float* __restrict__ db, int D, int E, int nsplit, float scale) {
     constexpr int NC = CT / 16, WPS = 4 / NC, WD = DT * 256;
     const int i = blockIdx.x * NT + threadIdx.x;                 // (h, ct, dump element)
     const int total = E * NC * WD;
@@ -361,12 +361,12 @@ __global__ __launch_bounds__(NT) void k_lat_wred(const float* __restrict__ part,
             for (int w2 = 0; w2 < WPS; ++w2) sum += part[(((long)ps * E + h) * 4 + ct + NC * w2) * WD + e];
         const int lane = e & 63, r = (e >> 6) & 3, dt = e >> 8;
         const int d = 16 * dt + 4 * (lane >> 4) + r, c = 16 * ct + (lane & 15);
-        if (d < D) dw[((long)d * CT + c) * E + h] += sum;
+        if (d < D) dw[((long)d * CT + c) * E + h] += sum * scale;
     } else if (db && i < total + CT * 16) {                     // sixteen slices of the workgroups per channel, joined by atomics
         const int c = (i - total) % CT, sl = (i - total) / CT;
         float sum = 0.f;
         for (int wg = sl; wg < nsplit * E; wg += 16) sum += dbpart[(long)wg * 64 + c];
-        atomicAdd(db + c, sum);
+        atomicAdd(db + c, sum * scale);
     }
 }
 
@@ -395,7 +395,9 @@ int run_contract(const e16* in, const e16* gy, const float* w, const float* bias
     constexpr int QN = CT == 64 ? 1 : 4;
     auto kern = k_lat_contract<CT, DT, GATE, QN>;
     if (int rc = raise_lds(kern, LDS, once)) return rc;
-    hipLaunchKernelGGL(kern, dim3((unsigned)((npix + 64 * QN - 1) / (64 * QN))), dim3(NT), LDS, st, in, gy, wp, bias, out, D, Dout, E, T, npix);
+    // GATE = the backward use (dz of Decoder.convin from the S-scaled gradient of its output): the fp32 result leaves the scaled region
+    const float oscale = GATE ? tt_loss_unscale() : 1.f;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((npix + 64 * QN - 1) / (64 * QN))), dim3(NT), LDS, st, in, gy, wp, bias, out, D, Dout, E, T, npix, oscale);
     TT_LAUNCH_CHECK();
     return 0;
 }
@@ -411,7 +413,9 @@ int run_expand(const float* z, int Dz, float fill, const float* w, const float* 
     hipLaunchKernelGGL((k_lat_wprep2<CT, KS>), dim3((pieces + NT - 1) / NT), dim3(NT), 0, st, w, wp, D, E);
     TT_LAUNCH_CHECK();
     const long zp = ((npix + 63) / 64) * 64 * (L::ZS / 8);
-    hipLaunchKernelGGL((k_lat_zprep<KS>), dim3((unsigned)((zp + NT - 1) / NT)), dim3(NT), 0, st, z, zt, D, Dz, fill, T, npix);
+    // !ACT = the backward use (dx of Encoder.convlat from the fp32 gradient of the latents): the 16-bit result ENTERS the scaled region
+    hipLaunchKernelGGL((k_lat_zprep<KS>), dim3((unsigned)((zp + NT - 1) / NT)), dim3(NT), 0, st, z, zt, D, Dz, fill, T, npix,
+                       ACT ? 1.f : tt_loss_scale());
     TT_LAUNCH_CHECK();
     constexpr int PCS = L::NC * KS * 64, ROUNDS = (PCS + NT - 1) / NT, LDS = 2 * ROUNDS * NT * 16;
     static AttrOnce once;
@@ -433,7 +437,10 @@ int run_wgrad(const float* z, int Dz, float fill, const e16* g_in, const e16* gy
     float* part = reinterpret_cast<float*>(ws + ((L::zt_bytes(npix) + 255) / 256) * 256);
     float* dbpart = part + (long)NSPLIT * E * 4 * DT * 256;
     const long zp = ((npix + 63) / 64) * 64 * (L::ZS / 8);
-    hipLaunchKernelGGL((k_lat_zprep<KS>), dim3((unsigned)((zp + NT - 1) / NT)), dim3(NT), 0, st, z, zt, D, Dz, fill, T, npix);
+    // GATE: z holds activations (the latents) and g the S-scaled gradient; !GATE (Encoder.convlat): z IS the gradient, fp32 and unscaled --
+    // it takes the factor S on its way to 16 bits.  Either way the dumps carry exactly one S, removed by the reduce.
+    hipLaunchKernelGGL((k_lat_zprep<KS>), dim3((unsigned)((zp + NT - 1) / NT)), dim3(NT), 0, st, z, zt, D, Dz, fill, T, npix,
+                       GATE ? 1.f : tt_loss_scale());
     TT_LAUNCH_CHECK();
     constexpr int ZB = L::ZS * 2, GBY = CT * 2;
     constexpr int ZR = (64 * ZB / 16 + NT - 1) / NT, GR = (64 * GBY / 16 + NT - 1) / NT;
@@ -444,7 +451,8 @@ int run_wgrad(const float* z, int Dz, float fill, const e16* g_in, const e16* gy
     hipLaunchKernelGGL(kern, dim3(E * NSPLIT), dim3(NT), LDS, st, zt, g_in, gy, part, dbpart, E, T, npix, NSPLIT);
     TT_LAUNCH_CHECK();
     const int total = E * (CT / 16) * DT * 256 + CT * 16;
-    hipLaunchKernelGGL((k_lat_wred<CT, DT>), dim3((total + NT - 1) / NT), dim3(NT), 0, st, part, dbpart, dw, GATE ? db : nullptr, D, E, NSPLIT);
+    hipLaunchKernelGGL((k_lat_wred<CT, DT>), dim3((total + NT - 1) / NT), dim3(NT), 0, st, part, dbpart, dw, GATE ? db : nullptr, D, E, NSPLIT,
+                       tt_loss_unscale());
     TT_LAUNCH_CHECK();
     return 0;
 }

@@ -269,13 +269,24 @@ __global__ __launch_bounds__(256) void k_sumsq_partial(const float* __restrict__
 
 __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                float* __restrict__ v, const float* __restrict__ norm, long n, float lr,
-                                               float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt,
+                                               float beta1, float beta2, float eps, float wd, int step, int* __restrict__ skipped,
                                                float max_norm, int write_clipped) {
     float clip = 1.f;
-    if (max_norm > 0.f && norm) {
-        clip = max_norm / (norm[0] + 1e-6f);
-        clip = clip > 1.f ? 1.f : clip;
+    if (norm) {
+        const float nv = norm[0];
+        if (skipped && !(fabsf(nv) <= 3.4e38f)) {                // inf / NaN gradient norm (an overflowed fp16 backward): skip the update,
+            if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(skipped, 1);   // as torch.amp.GradScaler would; nobody READS the count on this path
+            return;
+        }
+        if (max_norm > 0.f) {
+            clip = max_norm / (nv + 1e-6f);
+            clip = clip > 1.f ? 1.f : clip;
+        }
     }
+    // bias corrections at the number of APPLIED updates: the host's call count minus the skipped ones
+    // (in double: 1 - beta2^t cancels to ~1e-3 at t = 1, where a one-ulp error of a float pow would be 6e-5 of the result)
+    const double tstep = (double)(step - (skipped ? skipped[0] : 0));
+    const float bc1 = (float)(1.0 - pow((double)beta1, tstep)), bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, tstep));
     const float step_size = lr / bc1;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const float gi = g[i] * clip;
@@ -304,13 +315,11 @@ extern "C" int tt_l2norm(const float* x, float* norm_out, double* partials, int6
 
 extern "C" int tt_adamw_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, const float* norm,
                              int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
-                             int step, float max_norm, int write_clipped, void* stream) {
+                             int step, float max_norm, int write_clipped, int32_t* skipped, void* stream) {
     if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || step <= 0) return TT_E_BADARG;
-    const float bc1 = 1.f - powf(beta1, (float)step);
-    const float bc2 = 1.f - powf(beta2, (float)step);
     hipLaunchKernelGGL(k_adamw, dim3(nblocks(n, 4) * 4 > 2048 ? 2048 : nblocks(n, 4) * 4), dim3(256), 0, tt_stream(stream),
-                       param, grad, exp_avg, exp_avg_sq, norm, (long)n, lr, beta1, beta2, eps, weight_decay, bc1,
-                       sqrtf(bc2), max_norm, write_clipped);
+                       param, grad, exp_avg, exp_avg_sq, norm, (long)n, lr, beta1, beta2, eps, weight_decay, step, skipped,
+                       max_norm, write_clipped);
     TT_LAUNCH_CHECK();
     return 0;
 }
@@ -451,6 +460,13 @@ extern "C" int tt_peak_pick(const float* x, float* out, int64_t n_outer, int F, 
     return 0;
 }
 
+thread_local float g_tt_loss_scale = 1.0f;
+extern "C" float tt_set_loss_scale(float scale) {
+    const float prev = g_tt_loss_scale;
+    if (scale > 0.f && scale <= 16777216.f) g_tt_loss_scale = scale;
+    return prev;
+}
+
 int g_tt_cu_limit = 256;
 extern "C" int tt_set_cu_limit(int cus) {
     const int prev = g_tt_cu_limit;
@@ -458,7 +474,7 @@ extern "C" int tt_set_cu_limit(int cus) {
     return prev;
 }
 
-extern "C" int tt_version(void) { return 3; }   // 3: bf16 channels-last entry points (tt_wide_*, tt_sconv16_*, tt_tconv16_*, tt_latent16_*, tt_conv{in,out}16_*)
+extern "C" int tt_version(void) { return 4; }   // 4: any-block-length CQT, tt_set_loss_scale, tt_adamw_step(skipped)   // 3: bf16 channels-last entry points (tt_wide_*, tt_sconv16_*, tt_tconv16_*, tt_latent16_*, tt_conv{in,out}16_*)
 extern "C" const char* tt_arch(void) { return "gfx950"; }
 extern "C" const char* tt_error_string(int code) {
     if (code == 0) return "ok";

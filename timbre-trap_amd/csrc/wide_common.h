@@ -59,6 +59,7 @@ struct RedArgs {
     float *dw1, *db1, *dw2, *db2;
     int split_a = 0;                // C = 32 fused backward: wave = (ci-tile, co-tile), each wave dumps only its own co-tile
     int one_dump = 0;               // the producing kernel summed its four waves: only wave slot 0 of every workgroup holds data
+    float scale = tt_loss_unscale();  // 1 / S of the calling thread's loss scale (common.h): the dumps were formed from S-scaled gradients
 };
 // Up to four reduces in ONE launch (blockIdx.y): tt_wide_level_bwd defers the reduce of every block of a level and sums all their dumps
 // at the end -- two launches (and their dependent-launch gaps) fewer per level and pass, 48 per train step.
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(1024) void k_wrb_reduce(RedBatch batch) {
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < RSL; ++i) s += red[i][el];
-        *dst += s;
+        *dst += s * ar.scale;
     }
 }
 

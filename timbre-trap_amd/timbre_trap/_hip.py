@@ -124,7 +124,8 @@ _PROTOS = {
     'tt_peak_pick': (c_int, [P, P, L, I, I, ctypes.c_double, I, I, P]),
     'tt_target_activations': (c_int, [P, P, I, P, I, I, I, P, P, P]),
     'tt_l2norm': (c_int, [P, P, P, L, P]),
-    'tt_adamw_step': (c_int, [P, P, P, P, P, L, F_, F_, F_, F_, F_, I, F_, I, P]),
+    'tt_adamw_step': (c_int, [P, P, P, P, P, L, F_, F_, F_, F_, F_, I, F_, I, P, P]),
+    'tt_set_loss_scale': (c_float, [F_]),
 }
 # fp16 twins (include/ttrap.h: suffix _h): the 16-bit channels-last sources compiled a second time with -DTT_F16
 HALF_TWINS = ('tt_wide_level_scratch_bytes', 'tt_wide_level_bwd', 'tt_wide_scratch_bytes', 'tt_wide_pack', 'tt_wide_unpack', 'tt_wide_rb_fwd', 'tt_wide_rb_bwd', 'tt_wide_fused_scratch_bytes',

@@ -7,6 +7,7 @@ CPU path -- tensors must live on the GPU.
 """
 
 import ctypes
+import math
 import os
 import threading
 from dataclasses import dataclass
@@ -92,6 +93,48 @@ def lib16(t):
     if dtype != torch.bfloat16:
         raise TypeError('16-bit channels-last kernels take bfloat16 or float16 tensors, got %s' % (dtype,))
     return _hip.lib()
+
+
+# Static loss scale of the fp16 channels-last backward (power of two; 1 = off).  The reference runs its train step under
+# ``torch.autocast('cuda')`` = float16 WITHOUT a GradScaler (experiments/train.py:415): the loss is a mean over B x T frames, so the
+# activation gradients of the first encoder levels are ~1e-7 at training batch sizes -- below fp16's normal range (6.1e-5), where every
+# halving costs a bit (round 4 measured parameter gradients 3.4e-2 median / 0.53 worst off the fp32 path at 64 clips).  Here every
+# activation gradient that ENTERS the fp16 region (the backward of Decoder.convout, of Encoder.convlat, an fp32 gradient arriving at a
+# 16-bit layer) is multiplied by S, and everything that LEAVES it (weight / bias gradients, the gradient of the latents, of the
+# encoder's input coefficients, of the skip weights) by 1 / S inside the kernels' own fp32 epilogues (include/ttrap.h:
+# tt_set_loss_scale) -- an exact identity in real arithmetic, invisible to the caller: ``.grad`` holds the true gradient, no scaler
+# object, the unmodified train.py benefits.  An overflow (inf / NaN gradient norm) makes FusedAdamW skip the step, as GradScaler would.
+# bf16 has fp32's exponent range and is never scaled.
+FP16_LOSS_SCALE = float(os.environ.get('TTRAP_FP16_LOSS_SCALE', '4096'))
+
+
+def loss_scale(dtype):
+    """The factor carried by the 16-bit activation gradients of element type ``dtype`` during backward."""
+    if dtype != torch.float16 or FP16_LOSS_SCALE == 1.0:
+        return 1.0
+    s = float(FP16_LOSS_SCALE)
+    if not (1.0 <= s <= 2.0 ** 24) or math.frexp(s)[0] != 0.5:
+        raise ValueError('TTRAP_FP16_LOSS_SCALE / ops.FP16_LOSS_SCALE must be a power of two in [1, 2^24], got %r' % (FP16_LOSS_SCALE,))
+    return s
+
+
+class loss_scaled:
+    """``with loss_scaled(dtype):`` around the BACKWARD calls of the 16-bit layers: sets the calling thread's loss scale in the library
+    (thread-local there: autograd runs backward on its own threads) and restores the previous value."""
+
+    def __init__(self, dtype):
+        self.s = loss_scale(dtype)
+        self.prev = None
+
+    def __enter__(self):
+        if self.s != 1.0:
+            self.prev = _hip.lib().tt_set_loss_scale(self.s)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            _hip.lib().tt_set_loss_scale(self.prev)
+        return False
 
 
 def _flags():
@@ -478,8 +521,12 @@ def _as_cl16(t, dtype=torch.bfloat16):
     """Any (B,C,H,T) tensor as cl16 of element type ``dtype`` (no autograd): used on incoming gradients."""
     if is_cl16(t) and t.dtype == dtype:
         return t
-    if t.dtype == torch.float32 and _cl16_ok(t.size(1), t.size(3)):
-        return _pack(t.contiguous(), dtype)
+    if t.dtype == torch.float32:
+        # an fp32 gradient ENTERS the 16-bit region here: it takes the loss scale of the region (1 for bf16) before it is rounded
+        s = loss_scale(dtype)
+        t = t if s == 1.0 else t * s
+        if _cl16_ok(t.size(1), t.size(3)):
+            return _pack(t.contiguous(), dtype)
     return t.to(dtype).contiguous(memory_format=torch.channels_last)
 
 
@@ -494,7 +541,9 @@ class ToCL16Fn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return _unpack(_as_cl16(g, ctx.dtype))
+        out = _unpack(_as_cl16(g, ctx.dtype))
+        s = loss_scale(ctx.dtype)                    # the gradient LEAVES the 16-bit region: the loss scale comes off
+        return out if s == 1.0 else out.mul_(1.0 / s)
 
 
 class ToPlanar32Fn(torch.autograd.Function):
@@ -507,7 +556,8 @@ class ToPlanar32Fn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return _pack(_f32c(g), ctx.dtype)
+        s = loss_scale(ctx.dtype)                    # the gradient ENTERS the 16-bit region
+        return _pack(_f32c(g) if s == 1.0 else _f32c(g) * s, ctx.dtype)
 
 
 def to_cl16(x):
@@ -550,8 +600,9 @@ class ConvIn16Fn(torch.autograd.Function):
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         (dw, r1), (db, r2) = (_grad_target(t) for t in ctx.params)
         ws = torch.empty(lib.tt_edge16_scratch_bytes(), dtype=torch.uint8, device=x.device)
-        check(lib.tt_convin16_bwd(ptr(x), ptr(y), ptr(g), ptr(w), ptr(dx), ptr(dw), ptr(db), ptr(ws), B, H, T, stream_ptr()),
-              'tt_convin16_bwd')
+        with loss_scaled(y.dtype):
+            check(lib.tt_convin16_bwd(ptr(x), ptr(y), ptr(g), ptr(w), ptr(dx), ptr(dw), ptr(db), ptr(ws), B, H, T, stream_ptr()),
+                  'tt_convin16_bwd')
         return dx, r1, r2
 
 
@@ -576,8 +627,9 @@ class ConvOut16Fn(torch.autograd.Function):
         dx = new_cl16(B, 4, H, T, x.device, x.dtype)
         (dw, r1), (db, r2) = (_grad_target(t) for t in ctx.params)
         ws = torch.empty(lib.tt_edge16_scratch_bytes(), dtype=torch.uint8, device=x.device)
-        check(lib.tt_convout16_bwd(ptr(x), ptr(dy), ptr(w), ptr(dx), ptr(dw), ptr(db), ptr(ws), B, H, T, stream_ptr()),
-              'tt_convout16_bwd')
+        with loss_scaled(x.dtype):                      # dx enters the 16-bit region scaled; dw, db come from the fp32 dy itself
+            check(lib.tt_convout16_bwd(ptr(x), ptr(dy), ptr(w), ptr(dx), ptr(dw), ptr(db), ptr(ws), B, H, T, stream_ptr()),
+                  'tt_convout16_bwd')
         return dx, r1, r2
 
 
@@ -790,6 +842,9 @@ class WideLevelFn(torch.autograd.Function):
         params, saved = tensors[:4 * nb], tensors[4 * nb:]
         lib, st = lib16(ctx.dtype), stream_ptr()
         dy = _f32c(dy)
+        ls = loss_scale(ctx.dtype)                                # fp32 outside, 16-bit inside: the loss scale goes on here and comes off at the end
+        if ls != 1.0:
+            dy = dy * ls
         g = torch.empty((B, H, T, C), dtype=ctx.dtype, device=dy.device)
         check(lib.tt_wide_pack(ptr(dy), ptr(g), B, C, H, T, st), 'tt_wide_pack')
         ws = torch.empty(lib.tt_wide_scratch_bytes(B, C, H, T), dtype=torch.uint8, device=dy.device)
@@ -806,6 +861,8 @@ class WideLevelFn(torch.autograd.Function):
             g = gx
         dx = torch.empty((B, C, H, T), dtype=torch.float32, device=dy.device)
         check(lib.tt_wide_unpack(ptr(g), ptr(dx), B, C, H, T, st), 'tt_wide_unpack')
+        if ls != 1.0:
+            dx.mul_(1.0 / ls)
         return (dx, None, *grads)
 
 
@@ -1382,6 +1439,28 @@ class TranscriptionLossFn(torch.autograd.Function):
         check(_hip.lib().tt_transcription_loss_bwd(ptr(e), ptr(t), ptr(fs), ptr(_f32c(g)), ptr(de), B, F, T,
                                                    int(ctx.weighted), stream_ptr()), 'tt_transcription_loss_bwd')
         return de, None, None
+
+
+# ---- loss-scaled backward of the 16-bit layers (FP16_LOSS_SCALE above) -----------------------------------------------------------
+
+def _scale_backward(cls, dtype_of):
+    """Run cls.backward inside ``loss_scaled(<element type of the layer's 16-bit tensors>)``: its kernels then treat incoming 16-bit
+    gradients as scaled and unscale every fp32 result (ConvIn16Fn / ConvOut16Fn do it around their single call)."""
+    bwd = cls.backward
+
+    def backward(ctx, *grads):
+        with loss_scaled(dtype_of(ctx)):
+            return bwd(ctx, *grads)
+    cls.backward = staticmethod(backward)
+
+
+_scale_backward(Level16Fn, lambda ctx: ctx.saved_tensors[-1].dtype)
+_scale_backward(WideLevelFn, lambda ctx: ctx.dtype)
+_scale_backward(SConv16Fn, lambda ctx: ctx.saved_tensors[0].dtype)
+_scale_backward(TConv16Fn, lambda ctx: ctx.saved_tensors[0].dtype)
+_scale_backward(LatEnc16Fn, lambda ctx: ctx.saved_tensors[0].dtype)
+_scale_backward(LatDec16Fn, lambda ctx: ctx.saved_tensors[2].dtype)
+_scale_backward(Scale16Fn, lambda ctx: ctx.saved_tensors[0].dtype)
 
 
 # ---- instrumentation (bench.py): bracket every forward / backward of the Functions above with HIP events ------------------------

@@ -14,10 +14,25 @@ import torch
 import torch.distributed as dist
 
 
+def force_dist():
+    """TTRAP_FORCE_DIST=1 keeps the N > 1 code path alive at world size 1 (process group, broadcast of the parameters, the
+    asynchronous gradient all-reduce and its stream wait): how RCCL -- its coexistence with libttrap_hip.so and torch's bundled HIP
+    runtime in one process, communicator setup under HSA_ENABLE_IPC_MODE_LEGACY=0, ``work.wait()`` as a stream wait -- is exercised
+    on a 1-GPU box (tests/test_gpu_distributed.py)."""
+    return os.environ.get('TTRAP_FORCE_DIST') == '1'
+
+
+def dist_active():
+    """True where the data-parallel exchange runs: an initialised process group of more than one rank, or of ONE rank under
+    TTRAP_FORCE_DIST=1."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force_dist())
+
+
 def init_process_group_from_env(backend=None):
-    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun); no-op for one process."""
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun); no-op for one process (unless TTRAP_FORCE_DIST=1
+    and the launcher's rendezvous variables are present)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world <= 1:
+    if world <= 1 and not (force_dist() and 'RANK' in os.environ and 'MASTER_PORT' in os.environ):
         return 0, 1, 0
     rank = int(os.environ['RANK'])
     local_rank = int(os.environ.get('LOCAL_RANK', rank))
@@ -34,11 +49,9 @@ def init_process_group_from_env(backend=None):
 
 def allreduce_gradients(flat_grad, world_size=None, async_op=False):
     """Average one flat gradient buffer over all ranks with a single collective."""
-    if not (dist.is_available() and dist.is_initialized()):
+    if not dist_active():
         return None
     world_size = world_size or dist.get_world_size()
-    if world_size == 1:
-        return None
     flat_grad.div_(world_size)
     return dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, async_op=async_op)
 
@@ -78,7 +91,7 @@ class GradientSync:
 
 
 def broadcast_parameters(flat_param, src=0):
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist_active():
         dist.broadcast(flat_param, src=src)
 
 
@@ -115,7 +128,7 @@ class DataParallel(torch.nn.DataParallel):
             return getattr(self.module, name)
 
     def sync_gradients(self):
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not dist_active():
             return
         grads = [p.grad for p in self.module.parameters() if p.grad is not None]
         if not grads:

@@ -35,6 +35,10 @@ class FusedAdamW(torch.optim.Optimizer):
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self.norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        # steps skipped because the gradient norm was not finite (device counter, no host sync): the overflow guard that goes with the
+        # static loss scale of the fp16 path (ops.FP16_LOSS_SCALE) -- what torch.amp.GradScaler does on inf / NaN gradients, and what
+        # the reference, which has autocast without a scaler (train.py:415), lacks.  Needs max_norm (the norm is the detector).
+        self.skipped = torch.zeros(1, dtype=torch.int32, device=dev)
         self._partials = torch.empty(1024, dtype=torch.float64, device=dev)
         o = 0
         self._slots = []
@@ -96,7 +100,7 @@ class FusedAdamW(torch.optim.Optimizer):
         """Moments and step count included (they live in flat buffers, outside ``Optimizer.state``)."""
         sd = super().state_dict()
         sd['ttrap_flat'] = dict(step=self._step, exp_avg=self.exp_avg.detach().clone(), exp_avg_sq=self.exp_avg_sq.detach().clone(),
-                                max_norm=self.max_norm, n=self.n)
+                                max_norm=self.max_norm, n=self.n, skipped=int(self.skipped.item()))
         return sd
 
     def load_state_dict(self, state_dict):
@@ -108,6 +112,7 @@ class FusedAdamW(torch.optim.Optimizer):
         if int(flat['n']) != self.n:
             raise ValueError('FusedAdamW state has %d elements, this optimizer %d' % (int(flat['n']), self.n))
         self._step = int(flat['step'])
+        self.skipped.fill_(int(flat.get('skipped', 0)))
         self.exp_avg.copy_(flat['exp_avg'].to(self.exp_avg.device))
         self.exp_avg_sq.copy_(flat['exp_avg_sq'].to(self.exp_avg_sq.device))
 
@@ -154,6 +159,7 @@ class FusedAdamW(torch.optim.Optimizer):
                                             _hip.ptr(self.exp_avg_sq), _hip.ptr(norm), self.n, float(g['lr']),
                                             float(g['betas'][0]), float(g['betas'][1]), float(g['eps']),
                                             float(g['weight_decay']), self._step,
-                                            float(self.max_norm) if self.max_norm else 0.0, 1, _hip.stream_ptr()),
+                                            float(self.max_norm) if self.max_norm else 0.0, 1,
+                                            _hip.ptr(self.skipped) if self.max_norm else None, _hip.stream_ptr()),
                    'tt_adamw_step')
         return self.norm if self.max_norm else None

@@ -18,7 +18,11 @@ for B in [int(v) for v in os.environ.get('DIAG_B', '2,64').split(',')]:
     with torch.no_grad():
         c = model.sliCQ(audio)
     res = {}
-    for name, dt in (('fp32', None), ('bf16', torch.bfloat16), ('fp16', torch.float16)):
+    from timbre_trap.framework import ops
+    scales = [float(v) for v in os.environ.get('DIAG_SCALES', '1,4096,65536').split(',')]
+    runs = [('fp32', None, 1.0), ('bf16', torch.bfloat16, 1.0)] + [('fp16 S=%g' % sc, torch.float16, sc) for sc in scales]
+    for name, dt, sc in runs:
+        ops.FP16_LOSS_SCALE = sc                    # static loss scale of the fp16 backward (round 5; 1 = the reference's own arithmetic)
         with torch.autocast(device_type='cuda', dtype=dt or torch.bfloat16, enabled=dt is not None):
             latents, emb, _ = model.encoder(c)
             rec, trn = model.decode(latents, None), model.decode(latents, None, True)
@@ -36,7 +40,7 @@ for B in [int(v) for v in os.environ.get('DIAG_B', '2,64').split(',')]:
         del latents, emb, rec, trn, lat2, trn_rec, trn_scr, act, total
     ref = res['fp32']
     print('== %d clips x 3 s (T = 1024), mc 2 / latent 128, default init; reference = fp32 HIP path; |logits| max %.1f, |latents| max %.1f' % (B, ref['amax'][0], ref['amax'][1]))
-    for name in ('bf16', 'fp16'):
+    for name in [n for n, _, _ in runs[1:]]:
         r = res[name]
         out_err = [float((a - b).abs().max() / b.abs().max()) for a, b in zip(r['outs'], ref['outs'])]
         loss_err = [abs(a - b) / abs(b) for a, b in zip(r['losses'], ref['losses'])]

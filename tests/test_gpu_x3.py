@@ -392,6 +392,40 @@ def test_non_finite_values_surface():
     assert not bool(torch.isfinite(y[0, 2, 3, 7]))
 
 
+def test_out_of_range_values_fall_back_to_the_fp32_kernels():
+    """Round-4 advisor finding: |v| > 65504 cannot be held by the split representation, and csrc/conv_x3.hip then returns non-finite
+    values where the reference's fp32 evaluation stays finite.  The Python dispatch must notice and repeat on the fp32 kernels:
+    (i) a level entered from fp32 planar outside TimbreTrap._inference, (ii) a whole no-grad inference call (chain scope) with an
+    out-of-range coefficient -- both against the fp32-kernel result; (iii) a genuinely non-finite result (NaN weight) stays non-finite."""
+    from timbre_trap.framework import TimbreTrap, modules, ops
+    C, dil = 32, (1, 2, 3)
+    mods = [modules.ResidualConv2dBlock(C, C, 3, d).cuda() for d in dil]
+    x = _rand(1, C, 12, 64, seed=8).cuda()
+    x[0, 3, 5, 9] = 1.0e5
+    with torch.no_grad():
+        y = ops.residual_level(x, mods)
+        with ops.x3_disabled():
+            want = ops.residual_level(x, mods)
+    assert bool(torch.isfinite(y).all()) and torch.equal(y, want)
+    torch.manual_seed(3)
+    model = TimbreTrap(22050, 9, 60, 3, latent_size=128, model_complexity=2).cuda()
+    audio = _rand(2, 1, 66150, seed=4).cuda()
+    with torch.no_grad():
+        ok = model._inference(audio)
+        with ops.x3_disabled():
+            ok32 = model._inference(audio)
+        assert _rel(ok, ok32) < 5e-6                                                # in range: the split path, fp32-level agreement
+        big = model.encoder.block3.sconv[0].bias                                  # the layer in front of the first wide level
+        big.data[2] = 3.0e5                                                        # -> an activation far beyond fp16 inside the split part
+        out = model._inference(audio)
+        with ops.x3_disabled():
+            want = model._inference(audio)
+        assert bool(torch.isfinite(want).all()), 'the fp32 kernels themselves must stay finite here'
+        assert bool(torch.isfinite(out).all()) and torch.equal(out, want)
+        model.decoder.block1.block2.conv1[0].weight.data[1, 2, 1, 1] = float('nan')
+        assert not bool(torch.isfinite(model._inference(audio)).all())
+
+
 def test_argument_errors():
     from timbre_trap._hip import lib, ptr, stream_ptr
     L, st = lib(), stream_ptr()

@@ -237,9 +237,18 @@ class TimbreTrap(nn.Module):
     def _inference(self, audio, transcribe=False):
         # without skip connections the embeddings are dropped right here: the layers may keep their activations in the split-operand
         # layout between two wide levels (ops.x3_chain_scope; fp32 semantics, no autocast, no grad)
-        with torch.no_grad(), ops.x3_chain_scope(self.skip_weights is None):
-            latents, embeddings, _ = self.encode(audio)
-            return self.decode(latents, self.apply_skip_connections(embeddings), transcribe)
+        with torch.no_grad():
+            took_x3 = ops.x3_inference()
+            with ops.x3_chain_scope(self.skip_weights is None):
+                latents, embeddings, _ = self.encode(audio)
+                out = self.decode(latents, self.apply_skip_connections(embeddings), transcribe)
+            if took_x3 and not ops.x3_range_ok(out):
+                # an activation or weight beyond the split representation's range (|v| > 65504) comes out of csrc/conv_x3.hip
+                # non-finite: the reference's fp32 evaluation stays finite there -- repeat on the fp32 kernels (ops.x3_range_ok)
+                with ops.x3_disabled():
+                    latents, embeddings, _ = self.encode(audio)
+                    out = self.decode(latents, self.apply_skip_connections(embeddings), transcribe)
+            return out
 
     def inference(self, audio, transcribe=False):
         """Full-length inference after zero-padding to a whole number of blocks."""

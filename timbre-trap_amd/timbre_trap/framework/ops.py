@@ -425,7 +425,8 @@ def strided_conv(x, w, b, win, hop, out_x3=False):
     """Conv2d(C, Cout, (win,1), stride (hop,1)) + ELU.  x may be an x3 tensor (is_x3); out_x3: the next layer takes one."""
     if is_x3(x):
         C = x.size(4)
-        if win == 4 and hop == 2 and x.size(1) >= 4 and C in X3_CHANNELS and w.shape == (2 * C, C, 4, 1) and b is not None:
+        if (win == 4 and hop == 2 and x.size(1) >= 4 and C in X3_CHANNELS and w.shape == (2 * C, C, 4, 1) and b is not None
+                and _x3_size_ok(x.size(0), x.size(1), x.size(2))):
             return x3_strided_conv(x, w, b, out_x3)
         x = from_x3(x)
     C = x.size(1)
@@ -434,7 +435,7 @@ def strided_conv(x, w, b, win, hop, out_x3=False):
         return SConv16Fn.apply(to_cl16(x), w, b)
     x = to_planar32(x)
     if (out_x3 and x3_chain() and C == 8 and 2 * C in X3_CHANNELS and win == 4 and hop == 2 and x.size(2) >= 4 and x.is_cuda
-            and w.shape == (2 * C, C, 4, 1) and b is not None):
+            and w.shape == (2 * C, C, 4, 1) and b is not None and _x3_size_ok(x.size(0), x.size(2), x.size(3))):
         return x3_strided_conv(x, w, b, True)                    # the layer that enters the split-operand part of the encoder
     if FUSED_RESBLOCK and win == 4 and hop == 2 and C in FUSED_CHANNELS and w.shape == (2 * C, C, 4, 1) and b is not None:
         return StridedConvFn.apply(x, w, b)
@@ -446,7 +447,7 @@ def transposed_conv(x, w, b, win, hop, out_pad, out_x3=False):
     C = w.size(1)
     if is_x3(x):
         if (win == 4 and hop == 2 and C in (16, 32) and x.size(4) == 2 * C and w.shape == (2 * C, C, 4, 1) and b is not None
-                and out_pad in (0, 1)):
+                and out_pad in (0, 1) and _x3_size_ok(x.size(0), 2 * x.size(1) + 3, x.size(2))):
             return x3_transposed_conv(x, w, b, out_pad, out_x3)
         x = from_x3(x)
     if (win == 4 and hop == 2 and x.size(1) == 2 * C and out_pad in (0, 1) and _stride16_ok(C, x.size(-1), w, b)
@@ -454,7 +455,7 @@ def transposed_conv(x, w, b, win, hop, out_pad, out_x3=False):
         return TConv16Fn.apply(to_cl16(x), w, b, out_pad)
     x = to_planar32(x)
     if (out_x3 and x3_chain() and C == 32 and x.size(1) == 64 and win == 4 and hop == 2 and x.is_cuda and w.shape == (64, 32, 4, 1)
-            and b is not None and out_pad in (0, 1)):
+            and b is not None and out_pad in (0, 1) and _x3_size_ok(x.size(0), 2 * x.size(2) + 3, x.size(3))):
         return x3_transposed_conv(x, w, b, out_pad, True)        # the layer that enters the split-operand part of the decoder
     if (FUSED_RESBLOCK and win == 4 and hop == 2 and C in FUSED_CHANNELS and w.shape == (2 * C, C, 4, 1)
             and x.size(1) == 2 * C and b is not None and out_pad in (0, 1)):
@@ -946,7 +947,13 @@ def residual_level(x, blocks, out_x3=False):
         return Level16Fn.apply(to_cl16(x), tuple(b.dilation for b in blocks), *params)
     x = to_planar32(x)
     if x3_inference() and C in X3_CHANNELS and x.is_cuda and _x3_blocks_ok(C, blocks):
-        return x3_level(x, blocks, out_x3)
+        y = x3_level(x, blocks, out_x3)
+        # outside TimbreTrap._inference (which checks its final result once) a level that went fp32 -> split -> fp32 vouches for
+        # its own range: beyond +-65504 the split form is non-finite and the level is repeated on the fp32 kernels
+        if x3_chain() or is_x3(y) or x3_range_ok(y):
+            return y
+        with x3_disabled():
+            return residual_level(x, blocks)
     for b in blocks:
         x = b(x)
     return x
@@ -964,7 +971,37 @@ _X3_LOCAL = threading.local()
 
 
 def x3_inference():
-    return X3_INFER and not torch.is_grad_enabled() and precision() == 'fp32' and wide_storage() == 'fp32'
+    return (X3_INFER and not getattr(_X3_LOCAL, 'off', False) and not torch.is_grad_enabled() and precision() == 'fp32'
+            and wide_storage() == 'fp32')
+
+
+class x3_disabled:
+    """Inside this scope the calling thread's no-grad fp32 forwards stay on the fp32 kernels (the range fallback below)."""
+
+    def __enter__(self):
+        self.prev = getattr(_X3_LOCAL, 'off', False)
+        _X3_LOCAL.off = True
+        return self
+
+    def __exit__(self, *exc):
+        _X3_LOCAL.off = self.prev
+        return False
+
+
+def x3_range_ok(out):
+    """
+    The split representation holds |v| <= 65504 (hi = fp16(v)); beyond that -- activations or weights -- csrc/conv_x3.hip returns
+    NON-FINITE values, never a finite wrong number, where the reference's fp32 evaluation stays finite.  Callers that took the
+    split-operand path check their result with this (one read-only pass and one host sync per inference call) and, when it is not
+    finite, repeat the computation inside ``x3_disabled()`` on the fp32 kernels: a genuinely non-finite result (NaN weights) comes
+    out non-finite again, an out-of-range one finite -- the reference's answer either way (round-4 advisor finding).
+    """
+    return bool(torch.isfinite(out.float().sum()))
+
+
+def _x3_size_ok(B, H, T):
+    """The launchers of csrc/conv_x3.hip count tiles in 32-bit integers (64-bit element offsets): B * H * T / 16 stays far below 2^31."""
+    return B * H * T < 2 ** 34
 
 
 class x3_chain_scope:
@@ -1016,11 +1053,15 @@ def x3_level(x, blocks, out_x3=False):
     in_x3 = is_x3(x)
     if in_x3:
         B, H, T, _, C = x.shape
-        if C not in X3_CHANNELS or not _x3_blocks_ok(C, blocks):
-            return residual_level(from_x3(x), blocks)
+        if C not in X3_CHANNELS or not _x3_blocks_ok(C, blocks) or not _x3_size_ok(B, H, T):
+            with x3_disabled():
+                return residual_level(from_x3(x), blocks)
     else:
         x = _f32c(x)
         B, C, H, T = x.shape
+        if not _x3_size_ok(B, H, T):
+            with x3_disabled():
+                return residual_level(x, blocks)
     lib, st = _hip.lib(), stream_ptr()
     n = len(blocks)
     params = [[_f32c(t.detach()) for t in (b.conv1[0].weight, b.conv1[0].bias, b.conv2[0].weight, b.conv2[0].bias)] for b in blocks]

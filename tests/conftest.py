@@ -12,6 +12,8 @@ for p in (ROOT, PKG, os.path.join(ROOT, 'tests', 'golden')):
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'slow: re-runs of already covered entry points on opt-in / A-B code paths (child pytest runs); '
+                                       'skipped unless TT_RUN_SLOW=1 -- the default GPU selection has a wall-clock limit')
 
 
 def _have_gpu():
@@ -23,6 +25,11 @@ def _have_gpu():
 
 
 def pytest_collection_modifyitems(config, items):
+    if os.environ.get('TT_RUN_SLOW') != '1':
+        slow = pytest.mark.skip(reason='slow re-run of an opt-in / A-B path (TT_RUN_SLOW=1 runs it); its entry points are covered by the default selection')
+        for item in items:
+            if 'slow' in item.keywords:
+                item.add_marker(slow)
     if _have_gpu():
         return
     skip = pytest.mark.skip(reason='no GPU in this container')

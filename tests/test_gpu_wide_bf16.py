@@ -35,6 +35,9 @@ def _element_type(monkeypatch):
     if FP16:
         from timbre_trap.framework import ops
         monkeypatch.setattr(ops, 'PRECISION', 'fp16')       # forwards that create 16-bit tensors from fp32 inputs follow the mode
+        # the stage-wise tests drive single layers: a 16-bit gradient they read back would carry the static loss scale of the fp16
+        # backward (ops.FP16_LOSS_SCALE; exact, but not what the float64 restatements hold) -- it is tested on its own below
+        monkeypatch.setattr(ops, 'FP16_LOSS_SCALE', 1.0)
     yield
 
 
@@ -216,13 +219,13 @@ def test_fp16_hidden_overflow_surfaces(C, w2sign):
     if w2sign == 'mixed':
         w2[:, ::2] = 1.0
     b = torch.zeros(C)
+    xd, w1d, w2d, b1d, b2d = (t.cuda() for t in (x, w1, w2, b, b))      # named: a temporary would be recycled before the launch reads it
     for elt in (torch.float16, torch.bfloat16):
         lib, st = ops.lib16(elt), stream_ptr()
-        xd = x.cuda()
         xb = torch.empty((B, H, T, C), dtype=elt, device='cuda')
         check(lib.tt_wide_pack(ptr(xd), ptr(xb), B, C, H, T, st), 'pack')
         yb, hb = torch.empty_like(xb), torch.empty_like(xb)
-        check(lib.tt_wide_rb_fwd(ptr(xb), ptr(w1.cuda()), ptr(b.cuda()), ptr(w2.cuda()), ptr(b.cuda()), ptr(yb), ptr(hb), B, C, H, T, d, st), 'fwd')
+        check(lib.tt_wide_rb_fwd(ptr(xb), ptr(w1d), ptr(b1d), ptr(w2d), ptr(b2d), ptr(yb), ptr(hb), B, C, H, T, d, st), 'fwd')
         torch.cuda.synchronize()
         inner = yb[:, 2:-2, 2:-2].float()
         if elt == torch.float16:
@@ -231,6 +234,80 @@ def test_fp16_hidden_overflow_surfaces(C, w2sign):
         else:
             want = (-1.0 if w2sign == 'negative' else 0.0) + 100.0     # ELU(-C a1) = -1, ELU(0) = 0, plus the residual
             assert bool(torch.isfinite(inner).all()) and float((inner - want).abs().max()) <= 0.5
+
+
+def _layer_cases():
+    """(name, build) for every 16-bit layer Function of ops.py: build() -> (fn, 16-bit or fp32 inputs, fp32 parameters, output gradient)."""
+    from timbre_trap.framework import modules, ops
+    h = torch.float16
+
+    def cl(t):
+        return t.cuda().to(h).contiguous(memory_format=torch.channels_last)
+    cases = []
+    for C in (4, 8, 16, 32):
+        def level(C=C):
+            ps = []
+            for i in range(3):
+                ps += [_rand(C, C, 3, 3, seed=10 + i, scale=1.0 / (3 * C ** 0.5)), _rand(C, seed=20 + i, scale=0.3),
+                       _rand(C, C, 1, 1, seed=30 + i, scale=1.0 / C ** 0.5), _rand(C, seed=40 + i, scale=0.3)]
+            return (lambda x, *p: ops.Level16Fn.apply(x, (1, 2, 3), *p)), [cl(_rand(2, C, 21, 96, seed=1))], ps, cl(_rand(2, C, 21, 96, seed=2, scale=0.05))
+        cases.append(('level C=%d' % C, level))
+
+        def sconv(C=C):
+            return ops.SConv16Fn.apply, [cl(_rand(2, C, 14, 64, seed=3))], [_rand(2 * C, C, 4, 1, seed=4, scale=0.3), _rand(2 * C, seed=5, scale=0.2)], \
+                cl(_rand(2, 2 * C, 6, 64, seed=6, scale=0.05))
+        cases.append(('sconv C=%d' % C, sconv))
+
+        def tconv(C=C):
+            return (lambda x, w, b: ops.TConv16Fn.apply(x, w, b, 1)), [cl(_rand(2, 2 * C, 6, 64, seed=7))], \
+                [_rand(2 * C, C, 4, 1, seed=8, scale=0.3), _rand(C, seed=9, scale=0.2)], cl(_rand(2, C, 15, 64, seed=11, scale=0.05))
+        cases.append(('tconv C=%d' % C, tconv))
+    cases.append(('convin', lambda: (ops.ConvIn16Fn.apply, [_rand(2, 2, 21, 80, seed=12).cuda()], [_rand(4, 2, 3, 3, seed=13, scale=0.3), _rand(4, seed=14, scale=0.2)],
+                                     cl(_rand(2, 4, 21, 80, seed=15, scale=0.05)))))
+    cases.append(('convout', lambda: (ops.ConvOut16Fn.apply, [cl(_rand(2, 4, 21, 80, seed=16))], [_rand(2, 4, 3, 3, seed=17, scale=0.3), _rand(2, seed=18, scale=0.2)],
+                                      _rand(2, 2, 21, 80, seed=19, scale=0.05).cuda())))
+    cases.append(('latenc', lambda: (ops.LatEnc16Fn.apply, [cl(_rand(2, 64, 31, 48, seed=21))], [_rand(128, 64, 31, 1, seed=22, scale=0.02), _rand(128, seed=23, scale=0.2)],
+                                     _rand(2, 128, 48, seed=24, scale=0.05).cuda())))
+    cases.append(('latdec', lambda: ((lambda z, w, b: ops.LatDec16Fn.apply(z, w, b, 0.625)), [_rand(2, 128, 48, seed=25).cuda()],
+                                     [_rand(129, 64, 31, 1, seed=26, scale=0.05), _rand(64, seed=27, scale=0.2)], cl(_rand(2, 64, 31, 48, seed=28, scale=0.05)))))
+    cases.append(('skip scale', lambda: ((lambda e, sw: ops.Scale16Fn.apply(e, sw, 3)), [cl(_rand(2, 16, 9, 64, seed=29))], [torch.ones(5) * 0.75],
+                                         cl(_rand(2, 16, 9, 64, seed=31, scale=0.05)))))
+    return cases
+
+
+def test_fp16_loss_scale_is_an_exact_identity_per_layer(monkeypatch):
+    """
+    ops.FP16_LOSS_SCALE (the static loss scale of the fp16 backward) layer by layer, S = 4096 against S = 1 on gradients that sit in fp16's
+    normal range either way: every fp32 result -- weight / bias gradients, the fp32 data gradients that LEAVE the 16-bit region
+    (Encoder.convin's input, the latents) -- must be unchanged (to the order of the fp32 sums: 1e-5), and every 16-bit data gradient
+    exactly S times the unscaled one: the scale goes on where a gradient enters the region (Decoder.convout, Encoder.convlat), comes
+    off in the kernels' fp32 epilogues, and is carried in between.  A missing or doubled factor anywhere shows as 4096x.
+    """
+    from timbre_trap.framework import ops
+    if FP16:
+        monkeypatch.setattr(ops, 'PRECISION', 'fp16')
+    S = 4096.0
+    for name, build in _layer_cases():
+        res = {}
+        for scale in (1.0, S):
+            monkeypatch.setattr(ops, 'FP16_LOSS_SCALE', scale)
+            fn, ins, ps, gy = build()
+            ins = [t.detach().clone().requires_grad_(True) for t in ins]
+            ps = [t.cuda().requires_grad_(True) for t in ps]
+            with torch.autocast(device_type='cuda', dtype=torch.float16):
+                y = fn(*ins, *ps)
+            enters = y.dtype == torch.float32                     # fp32 output: its gradient is unscaled and the layer applies S itself
+            y.backward(gy if enters or scale == 1.0 else gy * scale)
+            torch.cuda.synchronize()
+            res[scale] = ([t.grad for t in ins], [t.grad for t in ps])
+        for a, b in zip(res[1.0][1], res[S][1]):
+            assert _rel(b.double(), a.double()) < 1e-5, '%s: a parameter gradient changed under the loss scale' % name
+        for a, b in zip(res[1.0][0], res[S][0]):
+            if a.dtype == torch.float32:
+                assert _rel(b.double(), a.double()) < 1e-5, '%s: an fp32 data gradient changed under the loss scale' % name
+            else:
+                assert bool(torch.isfinite(b.float()).all())
+                assert torch.equal(b.float(), a.float() * S), '%s: the 16-bit data gradient is not S times the unscaled one' % name
 
 
 @pytest.mark.parametrize('C,d,shape,cus', [(32, 3, (1, 65, 256), 1), (16, 2, (2, 37, 320), 1), (32, 1, (3, 20, 200), 2),
@@ -672,6 +749,7 @@ def _pytest_subprocess(env_extra, selection):
     return r.stdout
 
 
+@pytest.mark.slow          # the entry points of this opt-in / A-B path run stage-wise in the default selection (test_wide_block_stagewise, tests/test_gpu_determinism.py)
 @pytest.mark.skipif(os.environ.get('TT_CHILD_PYTEST') == '1', reason='already inside the child run')
 def test_separate_kernel_paths_still_agree():
     """TTRAP_DXW=0 / TTRAP_NDXW=0 / TTRAP_W4X=0: data gradient and weight gradient as separate kernels (the round-2 structure, kept
@@ -681,6 +759,7 @@ def test_separate_kernel_paths_still_agree():
     assert ' passed' in out
 
 
+@pytest.mark.slow          # the entry points of this opt-in / A-B path run stage-wise in the default selection (test_wide_block_stagewise, tests/test_gpu_determinism.py)
 @pytest.mark.skipif(os.environ.get('TT_CHILD_PYTEST') == '1', reason='already inside the child run')
 def test_recompute_path_at_model_level():
     """TTRAP_LEVEL_RECOMPUTE=1: wide levels through tt_wide_rb_bwd_fused (no h1 saved) -- the model-level oracle parity of the

@@ -99,6 +99,11 @@ __device__ __forceinline__ s16x4 lds_tr16(const unsigned char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
 }
 
+// 32-bit LDS address of a pointer into shared memory (operand of hand-written ds_* instructions)
+__device__ __forceinline__ unsigned lds_addr(const unsigned char* p) {
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)(p);
+}
+
 // shape of the partial-sum reduce kernels: a block of 1024 threads = REL consecutive dump elements x RSL slices of the contributors
 // (each thread keeps eight loads in flight; 16 x 64 puts 600+ blocks on the chip where 64 x 16 left a third of the CUs idle)
 constexpr int REL = 16, RSL = 64;

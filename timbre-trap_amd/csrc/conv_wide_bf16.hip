@@ -1457,6 +1457,297 @@ __global__ __launch_bounds__(NT, C == 8 ? 2 : 1) void k_nrb_bwd_fused(const e16*
     for (int e = tid; e < ADUMP; e += NT) pa[e] = (red[e] + red[ADUMP + e]) + (red[2 * ADUMP + e] + red[3 * ADUMP + e]);
 }
 
+// ---- round 5: the same one-pass backward, re-cut where its counters said the time goes ----------------------------------------
+// (i)   the x tile is staged WITHOUT halo: dW1[tap] = sum_q x[q] (x) dA1[q - off(tap)] indexes the weight gradient by the pixel of x
+//       (the strip kernel's identity, conv_level_bf16.hip), and dA1 has its halo anyway -- a third of the LDS image bytes and DMA
+//       instructions less, and C = 8 / dilation 3 fits two workgroups per CU (86 -> 78 KB), which the old cut did not;
+// (ii)  x is not needed before phase 2b: its DMA is issued last and waited for only behind phase 1 (s_waitcnt vmcnt(NITX) in front);
+// (iii) phase 1's per-step index arithmetic (flat pixel -> row / column by division, six compares for "this tile's own pixel") is
+//       tile-independent: LDS offset and a packed (row, column) key are computed once per kernel, the tile contributes two scalars;
+// (iv)  one conversion of dA2 to 16 bits serves the matrix operand and the dW2 staging buffer (the compiler emitted both forms).
+template <int C, int D>
+__global__ __launch_bounds__(NT, C == 8 ? 2 : 1) void k_nrb_bwd_fused2(const e16* __restrict__ x, const e16* __restrict__ h1,
+                                                       const e16* __restrict__ dy, const float* __restrict__ w1,
+                                                       const float* __restrict__ w2, const float* __restrict__ b2,
+                                                       e16* __restrict__ dx, float* __restrict__ part_a, float* __restrict__ part_w,
+                                                       int B, int H, int T, int tiles_h, int tiles_t, int ntiles) {
+    using G = NTl<C, D>;
+    typedef typename VecOf<C>::type vec_t;
+    constexpr int NB = C / 4, ADUMP = C * C + 2 * C, IMG = G::NPR * 16, NPX = G::ROWS * G::RW;
+    constexpr int XIMG = G::TH * G::TW * G::PXB, NITX = XIMG / 16 / NT, XROWB = G::TW * G::PXB;
+    constexpr int NS1 = (NPX + NT - 1) / NT;                     // phase-1 steps of 64 pixels per wave
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char* hs = smem;                                    // h1, then dA1   (halo'd)
+    unsigned char* gs = smem + IMG;                              // dy             (halo'd)
+    unsigned char* xs = smem + 2 * IMG;                          // x              (the tile's own pixels)
+    unsigned char* wimg = xs + XIMG;                             // A operands of every phase, 16-bit (see k_nrb_bwd_fused)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i4 = lane & 3;
+    const int n = lane & 15, g = lane >> 4, trj = n >> 2, trq = n & 3;
+
+    float b2r[C], acc[2 * C];                                    // db1 | db2
+#pragma unroll
+    for (int c = 0; c < C; ++c) b2r[c] = b2[c];
+#pragma unroll
+    for (int e = 0; e < 2 * C; ++e) acc[e] = 0.f;
+    f32x4 wacc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wacc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 dw2m = f32x4{0.f, 0.f, 0.f, 0.f};
+    const e16* zero = reinterpret_cast<const e16*>(&g_wzero16);
+    unsigned char* abuf = wimg + 11 * NB * NB * 32 + wave * (64 * G::PXB);      // this wave's 64 pixels of masked dA2
+    vec_t zero_px;
+#pragma unroll
+    for (int c = 0; c < C; ++c) zero_px[c] = (e16)0.f;
+    for (int e = tid; e < (2 + 9) * NB * NB * 4; e += NT) {
+        const int l4 = e & 3, kb = (e >> 2) % NB, ob = (e >> 2) / NB % NB, m = (e >> 2) / (NB * NB);
+        e16x4 a;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            a[k] = (e16)(m == 0 ? w2[(4 * ob + l4) * C + 4 * kb + k] : m == 1 ? w2[(4 * kb + k) * C + 4 * ob + l4]
+                                   : w1[((4 * kb + k) * C + 4 * ob + l4) * 9 + (8 - (m - 2))]);
+        *reinterpret_cast<e16x4*>(wimg + e * 8) = a;
+    }
+    constexpr int NITD = G::NPR / NT;                            // 16-byte pieces per thread and halo'd image
+    unsigned rel[NITD], relx[NITX];                              // byte offsets from the tile's first halo pixel / first own pixel
+#pragma unroll
+    for (int it = 0; it < NITD; ++it) {
+        const int p = wave * 64 + it * NT + lane, q = (p < G::NP ? p : 0) * G::PPP;
+        const int row = q / G::RW, px = q - row * G::RW;
+        rel[it] = (unsigned)(row * T + px) * (unsigned)(C * 2);
+    }
+#pragma unroll
+    for (int it = 0; it < NITX; ++it) {
+        const int q = (wave * 64 + it * NT + lane) * G::PPP;
+        const int row = q / G::TW, px = q - row * G::TW;
+        relx[it] = (unsigned)(row * T + px) * (unsigned)(C * 2);
+    }
+    // phase 1, per step s: LDS offset of the lane's pixel (clamped into the image) and key = row | column << 16 of a pixel of the
+    // tile proper, ~0 for a halo pixel: "one of this tile's own in-image pixels" is then (key & 0xffff) < hlim && (key >> 16) < tlim
+    unsigned poff[NS1], pkey[NS1];
+#pragma unroll
+    for (int s1 = 0; s1 < NS1; ++s1) {
+        const int q = wave * 64 + s1 * NT + lane, qq = q < NPX ? q : NPX - 1;
+        const int row = qq / G::RW, col = qq - row * G::RW;
+        poff[s1] = (unsigned)qq * G::PXB;
+        pkey[s1] = (q < NPX && row >= D && row < D + G::TH && col >= G::DP && col < G::DP + G::TW) ? (unsigned)row | ((unsigned)col << 16) : 0xffffffffu;
+    }
+    auto wfrag = [&](int m, int ob, int kb) { return *reinterpret_cast<const s16x4*>(wimg + ((((m * NB + ob) * NB + kb) << 2) + i4) * 8); };
+    for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
+        int tile = xcd_order(v, ntiles);
+        const int tt = tile % tiles_t; tile /= tiles_t;
+        const int th = tile % tiles_h;
+        const int b = tile / tiles_h, h0 = th * G::TH, t0 = tt * G::TW;
+        const long ib = (long)b * H * T * C;
+        // every wave is done READING the three images of the previous tile (its dx stores may still be in flight: they touch no LDS)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const bool fast = h0 >= D && h0 + G::TH + D <= H && t0 >= G::DP && t0 + G::TW + G::DP <= T;
+        if (fast) {
+            const long first = ib + ((long)(h0 - D) * T + (t0 - G::DP)) * C;
+            const char* hb = reinterpret_cast<const char*>(h1 + first);
+            const char* gb = reinterpret_cast<const char*>(dy + first);
+            const char* xb = reinterpret_cast<const char*>(x + ib + ((long)h0 * T + t0) * C);
+#pragma unroll
+            for (int it = 0; it < NITD; ++it) {
+                const int i = wave * 64 + it * NT;
+                glds16(hb + rel[it], hs + (long)i * 16);
+                glds16(gb + rel[it], gs + (long)i * 16);
+            }
+#pragma unroll
+            for (int it = 0; it < NITX; ++it) glds16(xb + relx[it], xs + (long)(wave * 64 + it * NT) * 16);
+        } else {
+            for (int i = wave * 64; i < G::NPR; i += NT) {
+                const int p = i + lane, q = p * G::PPP;
+                const int row = q / G::RW, px = q - row * G::RW;
+                const int h = h0 - D + row, t = t0 - G::DP + px;
+                const bool ok = p < G::NP && (unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T;
+                const long off = ib + ((long)h * T + t) * C;
+                glds16(ok ? h1 + off : zero, hs + (long)i * 16);
+                glds16(ok ? dy + off : zero, gs + (long)i * 16);
+            }
+#pragma unroll
+            for (int it = 0; it < NITX; ++it) {
+                const int q = (wave * 64 + it * NT + lane) * G::PPP;
+                const int row = q / G::TW, px = q - row * G::TW;
+                const bool ok = h0 + row < H && t0 + px < T;
+                glds16(ok ? x + ib + ((long)(h0 + row) * T + t0 + px) * C : zero, xs + (long)(wave * 64 + it * NT) * 16);
+            }
+        }
+        // h1 and dy complete (this wave's pieces; the barrier collects the others'), the NITX pieces of x still in flight.  A bare
+        // s_barrier: __syncthreads() carries a workgroup fence that the compiler lowers to s_waitcnt vmcnt(0) first, which would wait
+        // for x after all (LDS-DMA stays in flight across s_barrier; what orders an LDS read behind a DMA piece is the ISSUING wave's
+        // vmcnt plus a barrier for the other waves -- /opt/skills/guides/MI355X_MICROARCH.md, "Two waves per SIMD", item 7)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NITX) : "memory");
+
+        // ---- phase 1: pointwise chain on every pixel of the halo'd image; dA1 over h1 ----
+        {
+            s16x4 A2[NB][NB], A2T[NB][NB];
+#pragma unroll
+            for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+                for (int kb = 0; kb < NB; ++kb) { A2[ob][kb] = wfrag(0, ob, kb); A2T[ob][kb] = wfrag(1, ob, kb); }
+            const unsigned hlim = (unsigned)(H - h0 + D), tlim = (unsigned)(T - t0 + G::DP);
+#pragma unroll
+            for (int s1 = 0; s1 < NS1; ++s1) {
+                const int c0 = wave * 64 + s1 * NT;
+                if (c0 >= NPX) break;
+                const bool centre = (pkey[s1] & 0xffffu) < hlim && (pkey[s1] >> 16) < tlim;
+                const vec_t hq = *reinterpret_cast<const vec_t*>(hs + poff[s1]);
+                const vec_t dq = *reinterpret_cast<const vec_t*>(gs + poff[s1]);
+                f32x4 z[NB], u[NB], gv[NB];
+                e16x4 gq4[NB];
+#pragma unroll
+                for (int ob = 0; ob < NB; ++ob) {
+                    z[ob] = f32x4{b2r[4 * ob], b2r[4 * ob + 1], b2r[4 * ob + 2], b2r[4 * ob + 3]};
+#pragma unroll
+                    for (int kb = 0; kb < NB; ++kb) z[ob] = mma4(A2[ob][kb], chunk_of<C>(hq, kb), z[ob]);
+                }
+#pragma unroll
+                for (int ob = 0; ob < NB; ++ob) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) gv[ob][r] = (float)dq[4 * ob + r] * elu_dpre(z[ob][r]);
+                    gq4[ob] = __builtin_convertvector(gv[ob], e16x4);
+                }
+#pragma unroll
+                for (int ob = 0; ob < NB; ++ob) {
+                    u[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kb = 0; kb < NB; ++kb) u[ob] = mma4(A2T[ob][kb], __builtin_bit_cast(s16x4, gq4[kb]), u[ob]);
+                }
+                const float m = centre ? 1.f : 0.f;              // sums only over this tile's own pixels
+                vec_t aq, gq;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const float a1 = u[c >> 2][c & 3] * elu_dout((float)hq[c]);
+                    aq[c] = (e16)a1;
+                    gq[c] = gq4[c >> 2][c & 3];
+                    acc[c] = __builtin_fmaf(m, a1, acc[c]);
+                    acc[C + c] = __builtin_fmaf(m, gv[c >> 2][c & 3], acc[C + c]);
+                }
+                // dW2 += dA2 (x) h1 over the tile's own pixels as ONE matrix product per 64 pixels (see k_nrb_bwd_fused)
+                *reinterpret_cast<vec_t*>(abuf + lane * G::PXB) = centre ? gq : zero_px;
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("" ::: "memory");
+                const unsigned char* hb0 = hs + (long)c0 * G::PXB;                   // the 64 pixels of this step, before dA1 replaces them
+                const int so = 32 * (4 * g + trj) + 8 * trq;
+                // transpose reads spelled out: in front of the builtin form the compiler places s_waitcnt vmcnt(0) (an LDS read it cannot
+                // prove disjoint from the x pieces still arriving by LDS-DMA), which is exactly the wait this kernel defers
+                const unsigned ga_ = lds_addr(abuf + so), ha_ = lds_addr(hb0 + so);
+                if constexpr (C == 8) {
+                    s16x4 glo, ghi, hlo, hhi;
+                    asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:512\n\tds_read_b64_tr_b16 %2, %5\n\t"
+                                 "ds_read_b64_tr_b16 %3, %5 offset:512\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(glo), "=&v"(ghi), "=&v"(hlo), "=&v"(hhi) : "v"(ga_), "v"(ha_) : "memory");
+                    dw2m = mma32(__builtin_bit_cast(e16x8, __builtin_shufflevector(glo, ghi, 0, 1, 2, 3, 4, 5, 6, 7)),
+                                 __builtin_bit_cast(e16x8, __builtin_shufflevector(hlo, hhi, 0, 1, 2, 3, 4, 5, 6, 7)), dw2m);
+                } else {
+                    s16x4 gt_, ht_;
+                    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(gt_), "=&v"(ht_) : "v"(ga_), "v"(ha_) : "memory");
+                    dw2m = mma16(gt_, ht_, dw2m);
+                }
+                if (c0 + 64 <= NPX || lane < NPX - c0) *reinterpret_cast<vec_t*>(hs + poff[s1]) = aq;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // x has had all of phase 1 to arrive
+        __syncthreads();
+
+        // ---- phase 2a: dx = dy + W1^T (*) dA1 (k_nrb_conv, MODE 1, operands from LDS) ----
+        {
+            s16x4 A[9][NB][NB];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+                    for (int kb = 0; kb < NB; ++kb) A[tap][ob][kb] = wfrag(2 + tap, ob, kb);
+            const int t = t0 + lane;
+            for (int r = wave; r < G::TH; r += 4) {
+                const int h = h0 + r;
+                if (h >= H) break;
+                f32x4 a4[NB];
+#pragma unroll
+                for (int ob = 0; ob < NB; ++ob) a4[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int kh = tap / 3, kw = tap - 3 * kh;
+                    const int pxi = (r + kh * D) * G::RW + G::DP + lane + (kw - 1) * D;
+                    const vec_t bq = *reinterpret_cast<const vec_t*>(hs + (long)pxi * G::PXB);
+#pragma unroll
+                    for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+                        for (int kb = 0; kb < NB; ++kb) a4[ob] = mma4(A[tap][ob][kb], chunk_of<C>(bq, kb), a4[ob]);
+                }
+                const vec_t rq = *reinterpret_cast<const vec_t*>(gs + (long)((r + D) * G::RW + G::DP + lane) * G::PXB);
+                vec_t o;
+#pragma unroll
+                for (int c = 0; c < C; ++c) o[c] = (e16)(a4[c >> 2][c & 3] + (float)rq[c]);
+                if (t < T) *reinterpret_cast<vec_t*>(dx + ib + ((long)h * T + t) * C) = o;
+            }
+        }
+
+        // ---- phase 2b: dW1[tap] = sum over the tile's own pixels q of x[q] (x) dA1[q - off(tap)]: x from its halo-free image, dA1 at
+        //      row r + (2 - kh) D, column DP - (kw - 1) D of the halo'd one; 32-byte slots by transpose reads as in k_nrb_wgrad (the two
+        //      K halves are the two halves of a row at C = 8, two consecutive rows at C = 4) ----
+        {
+            constexpr int ROWB = G::RW * G::PXB;                 // bytes of a row of the halo'd images
+            constexpr int RPS = C == 8 ? 1 : 2;                  // rows per product step
+            constexpr int UOFF = C == 8 ? 512 : ROWB, UOFFX = C == 8 ? 512 : XROWB;    // byte distance of the second K half
+            const int so = 32 * (4 * g + trj) + 8 * trq;
+            for (int r = wave * RPS; r < G::TH; r += 4 * RPS) {
+                if (h0 + r >= H) break;
+                const unsigned char* xp = xs + (long)r * XROWB + so;
+                const s16x4 xlo = lds_tr16(xp), xhi = lds_tr16(xp + UOFFX);
+                const e16x8 xb8 = __builtin_bit_cast(e16x8, __builtin_shufflevector(xlo, xhi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const int kh = k / 3, kw = k - 3 * kh;
+                    const unsigned char* gp = hs + (long)(r + (2 - kh) * D) * ROWB + (G::DP - (kw - 1) * D) * G::PXB + so;
+                    const s16x4 lo = lds_tr16(gp), hi = lds_tr16(gp + UOFF);
+                    wacc[k] = mma32(__builtin_bit_cast(e16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)), xb8, wacc[k]);
+                }
+            }
+        }
+    }
+    // ---- dumps: as k_nrb_bwd_fused (ONE dump per workgroup, RedArgs::one_dump) ----
+    __syncthreads();
+    {
+        float* wr = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wr[wave * 2304 + (k * 4 + r) * 64 + lane] = wacc[k][r];
+        __syncthreads();
+        float* pw = part_w + (long)blockIdx.x * 4 * 2304;
+        for (int i = tid; i < 2304; i += NT) pw[i] = (wr[i] + wr[2304 + i]) + (wr[2 * 2304 + i] + wr[3 * 2304 + i]);
+    }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int e = 0; e < 2 * C; ++e) {
+        float sv = acc[e];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sv += __shfl_xor(sv, o, 64);
+        if (lane == 0) red[wave * ADUMP + C * C + e] = sv;
+    }
+    {
+        float* sc = red + 4 * ADUMP + wave * 256;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sc[(4 * g + r) * 16 + n] = dw2m[r];
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+        if (lane < C * C) {
+            const int co = lane / C, ci = lane - co * C;
+            float sv = 0.f;
+#pragma unroll
+            for (int p_ = 0; p_ < 16 / C; ++p_) sv += sc[(p_ * C + co) * 16 + p_ * C + ci];
+            red[wave * ADUMP + lane] = sv;
+        }
+    }
+    __syncthreads();
+    float* pa = part_a + (long)blockIdx.x * ADUMP;
+    for (int e = tid; e < ADUMP; e += NT) pa[e] = (red[e] + red[ADUMP + e]) + (red[2 * ADUMP + e] + red[3 * ADUMP + e]);
+}
+
 // ---- data gradient and weight gradient of a narrow block in one pass (the narrow counterpart of k_wrb_dxw) --------------------
 // Phases 2a / 2b of k_nrb_bwd_fused with dA1 coming from HBM (written by k_nrb_bwd_a) instead of being computed in place: the dA1
 // and x tiles (16 x 64 pixels + halo) are staged once, dx = dy + W1^T (*) dA1 by lane-per-pixel 4x4x4 products, dW1 by transpose reads
@@ -1641,6 +1932,23 @@ int launch_nbwd(const e16* x, const e16* h1, const e16* dy, const float* w1, con
     // Half the HBM traffic buys less than half the time because the pass is then bound by its own arithmetic (pointwise chain on the halo
     // as well; three LDS images = 2 workgroups per CU at C = 8): fused where it wins -- C = 4 always, C = 8 at dilation 1, 2.
     static const int fused = tt_switch("TTRAP_NARROW_FUSED16", 1);
+    static const int fused_v2 = tt_tune("TTRAP_NBF2", 1);       // round 5: k_nrb_bwd_fused2 (every width and dilation); 0 = the round-4 kernel and dispatch
+    if (fused && fused_v2) {
+        using F = NTl<C, D>;
+        constexpr int LAYOUT = 2 * F::NPR * 16 + F::TH * F::TW * F::PXB + 11 * (C / 4) * (C / 4) * 32 + 4 * 64 * F::PXB;
+        constexpr int LDS = LAYOUT > 4 * 2304 * 4 ? LAYOUT : 4 * 2304 * 4;       // the epilogue sums the four waves' dW1 accumulators through LDS
+        static AttrOnce once_f2;
+        auto kf = k_nrb_bwd_fused2<C, D>;
+        if (int rc = raise_lds(kf, LDS, once_f2)) return rc;
+        const int tiles_h = (H + F::TH - 1) / F::TH, tiles_t = (T + F::TW - 1) / F::TW, ntiles = B * tiles_h * tiles_t;
+        int gf = grid_for(ntiles, LDS, 4);
+        if (gf > MAX_W_WG) gf = MAX_W_WG;
+        hipLaunchKernelGGL(kf, dim3(gf), dim3(NT), LDS, st, x, h1, dy, w1, w2, b2, dx, part_a, part_w, B, H, T, tiles_h, tiles_t, ntiles);
+        TT_LAUNCH_CHECK();
+        RedArgs ra{part_w, gf, part_a, gf, dw1, db1, dw2, db2, 0, 1};
+        constexpr int total = 9 * 256 + C * C + 2 * C;
+        return reduce_or_defer(k_nrb_reduce<C>, total, ra, st);
+    }
     if (fused == 2 || (fused == 1 && (C == 8 ? D <= 2 : true))) {
         using F = NTl<C, D>;
         constexpr int LDS = 3 * F::NPR * 16 + 11 * (C / 4) * (C / 4) * 32 + 4 * 64 * F::PXB;   // three images + the bf16 weight image + the waves' dA2 buffers

@@ -429,6 +429,17 @@ int tt_target_activations(const int* bins, const int* frames, int n, const doubl
  *                    ws = tt_x3_level_scratch_bytes bytes */
 int64_t tt_x3_bytes(int B, int C, int H, int T);
 int64_t tt_x3_level_scratch_bytes(int B, int C, int H, int T);
+
+/* The NARROW levels (C = 4, 8) of the same no-grad fp32 forward with split operands (csrc/conv_x3.hip, k_x3n_conv: lane = pixel,
+ * v_mfma_f32_4x4x4_16b_f16; ResidualConv2dBlock, reference modules.py:721-777, as called from TimbreTrap._inference / evaluate.py:94-95).
+ * Between the blocks of a level the activations are "x3n" tensors [B][H][T][2][C] halves (hi plane, lo 2^11 plane); the first block
+ * reads the fp32 planar (B,C,H,T) tensor of the layer in front (planar_in), the last one stores fp32 planar (planar_out): no pack /
+ * unpack passes.  ws: tt_x3n_level_scratch_bytes.  Same value range as tt_x3_*: |v| <= 65504, non-finite beyond. */
+int64_t tt_x3n_level_scratch_bytes(int B, int C, int H, int T);
+int tt_x3n_rb_fwd(const void* x, int planar_in, const float* w1, const float* b1, const float* w2, const float* b2, void* y,
+                  int planar_out, int B, int C, int H, int T, int dilation, void* stream);
+int tt_x3n_level_fwd(int nblocks, const float* x, float* y, const float* const* w1, const float* const* b1, const float* const* w2,
+                     const float* const* b2, const int* dilations, void* ws, int B, int C, int H, int T, void* stream);
 int tt_x3_pack(const float* x, void* out, int B, int C, int H, int T, void* stream);
 int tt_x3_unpack(const void* in, float* y, int B, int C, int H, int T, void* stream);
 int tt_x3_rb_fwd(const void* x, const float* w1, const float* b1, const float* w2, const float* b2, void* y, int planar_out, int B,

@@ -194,6 +194,98 @@ def test_level_entry_is_three_blocks(C):
     assert y_grad.requires_grad and _rel(y_grad.detach().cpu(), want) < 1e-5
 
 
+# ---- narrow levels (C = 4, 8): lane-per-pixel split-operand blocks (k_x3n_conv; tt_x3n_rb_fwd / tt_x3n_level_fwd) -----------------------
+
+def _x3n_pack(x):
+    """fp32 (B,C,H,T) -> x3n (B,H,T,2,C) halves on the host: hi = fp16(v), lo = fp16((v - hi) 2^11)."""
+    xp = x.permute(0, 2, 3, 1).contiguous()
+    hi = xp.half()
+    lo = ((xp - hi.float()) * 2048.0).half()
+    return torch.stack([hi, lo], dim=3).contiguous()
+
+
+def _x3n_unpack(t):
+    return (t[:, :, :, 0].float() + t[:, :, :, 1].float() / 2048.0).permute(0, 3, 1, 2).contiguous()
+
+
+def _run_x3n(x, params, d, pin, pout):
+    from timbre_trap._hip import check, lib, ptr, stream_ptr
+    L, st = lib(), stream_ptr()
+    B, C, H, T = x.shape
+    xin = x.cuda().contiguous() if pin else _x3n_pack(x).cuda()
+    y = torch.empty((B, C, H, T), dtype=torch.float32, device='cuda') if pout else torch.empty((B, H, T, 2, C), dtype=torch.float16, device='cuda')
+    dev = [p.cuda().contiguous() for p in params]
+    check(L.tt_x3n_rb_fwd(ptr(xin), int(pin), ptr(dev[0]), ptr(dev[1]), ptr(dev[2]), ptr(dev[3]), ptr(y), int(pout), B, C, H, T, d, st), 'tt_x3n_rb_fwd')
+    torch.cuda.synchronize()
+    return y.cpu() if pout else _x3n_unpack(y.cpu())
+
+
+@pytest.mark.parametrize('C', [4, 8])
+@pytest.mark.parametrize('d', [1, 2, 3])
+@pytest.mark.parametrize('shape', [(2, 13, 70), (1, 37, 33), (3, 16, 64), (1, 40, 200)])
+def test_narrow_block_matches_float64(C, d, shape):
+    """Every (input, output) layout combination of the narrow split-operand block against float64 at the x3 bar (2e-6 of the output's
+    scale): ragged tile edges in both directions, one and several tiles, all dilations."""
+    B, H, T = shape
+    x = _rand(B, C, H, T, seed=1)
+    params = _params(C)
+    want = _block64(x, *params, d)
+    for pin, pout in ((True, True), (True, False), (False, False), (False, True)):
+        got = _run_x3n(x, params, d, pin, pout)
+        assert _rel(got, want) < BAR, (pin, pout, _rel(got, want))
+
+
+@pytest.mark.parametrize('C,H', [(4, 540), (8, 269)])
+def test_narrow_block_at_bench_plane_sizes_with_capped_grid(C, H, cu_limit):
+    x = _rand(1, C, H, 1024, seed=7)
+    params = _params(C, seed=30)
+    want = _block64(x, *params, 3)
+    full = _run_x3n(x, params, 3, True, True)
+    assert _rel(full, want) < BAR
+    cu_limit(3)
+    assert torch.equal(_run_x3n(x, params, 3, True, True), full), 'the result must not depend on the number of workgroups'
+    assert torch.equal(_run_x3n(x, params, 3, False, True), full), 'fp32 planar and split input hold the same values'
+
+
+@pytest.mark.parametrize('C', [4, 8])
+def test_narrow_level_dispatch_magnitudes_and_non_finite(C):
+    """tt_x3n_level_fwd = three blocks (planar in, split in between, planar out); ops.residual_level without grad takes it and agrees
+    with the exact-fp32 kernels of conv_small.hip at fp32 rounding; values across fp16's subnormal boundary keep fp32-level accuracy;
+    NaN weights surface; an out-of-range activation falls back to the fp32 kernels (finite, identical to them)."""
+    from timbre_trap.framework import modules, ops
+    B, H, T = 2, 19, 90
+    x = _rand(B, C, H, T, seed=2) * (10.0 ** (_rand(B, C, H, T, seed=9) * 4.0 - 2.0))
+    blocks = [_params(C, seed=50 + 10 * i) for i in range(3)]
+    dil = (1, 2, 3)
+    want = x
+    for p, d in zip(blocks, dil):
+        want = _block64(want, *p, d)
+    mods = [modules.ResidualConv2dBlock(C, C, 3, d) for d in dil]
+    for m, p in zip(mods, blocks):
+        m.conv1[0].weight.data, m.conv1[0].bias.data = p[0].clone(), p[1].clone()
+        m.conv2[0].weight.data, m.conv2[0].bias.data = p[2].clone(), p[3].clone()
+        m.cuda()
+    xd = x.cuda()
+    with torch.no_grad():
+        assert ops.x3_inference()
+        y = ops.residual_level(xd, mods)
+        with ops.x3_disabled():
+            y32 = ops.residual_level(xd, mods)
+    assert _rel(y.cpu(), want) < 2 * BAR and _rel(y32.cpu(), want) < 1e-5 and not torch.equal(y, y32)
+    y_grad = ops.residual_level(xd.clone().requires_grad_(True), mods)            # with grad: the fp32 kernels
+    assert y_grad.requires_grad and torch.equal(y_grad.detach(), y32)
+    big = xd.clone()
+    big[0, 1, 3, 7] = 2.0e5                                                       # beyond the split representation
+    with torch.no_grad():
+        yb = ops.residual_level(big, mods)
+        with ops.x3_disabled():
+            yb32 = ops.residual_level(big, mods)
+    assert bool(torch.isfinite(yb).all()) and torch.equal(yb, yb32)
+    mods[1].conv2[0].weight.data[1, 2, 0, 0] = float('nan')
+    with torch.no_grad():
+        assert bool(torch.isnan(ops.residual_level(xd, mods)).any())
+
+
 def _sconv64(x, w, b):
     return F.elu(F.conv2d(x.double(), w.double(), b.double(), stride=(2, 1)))
 

@@ -1465,8 +1465,11 @@ __global__ __launch_bounds__(NT, C == 8 ? 2 : 1) void k_nrb_bwd_fused(const e16*
 // (iii) phase 1's per-step index arithmetic (flat pixel -> row / column by division, six compares for "this tile's own pixel") is
 //       tile-independent: LDS offset and a packed (row, column) key are computed once per kernel, the tile contributes two scalars;
 // (iv)  one conversion of dA2 to 16 bits serves the matrix operand and the dW2 staging buffer (the compiler emitted both forms).
+#ifndef TT_NBF2_MINW4
+#define TT_NBF2_MINW4 4          // C = 4: registers capped for four workgroups per CU (the LDS limit); 1 lets the compiler take 156 (three)
+#endif
 template <int C, int D>
-__global__ __launch_bounds__(NT, C == 8 ? 2 : 1) void k_nrb_bwd_fused2(const e16* __restrict__ x, const e16* __restrict__ h1,
+__global__ __launch_bounds__(NT, C == 8 ? 2 : TT_NBF2_MINW4) void k_nrb_bwd_fused2(const e16* __restrict__ x, const e16* __restrict__ h1,
                                                        const e16* __restrict__ dy, const float* __restrict__ w1,
                                                        const float* __restrict__ w2, const float* __restrict__ b2,
                                                        e16* __restrict__ dx, float* __restrict__ part_a, float* __restrict__ part_w,

@@ -326,6 +326,273 @@ int x3_d(const e16* x, const float* w1, const float* b1, const float* w2, const 
     }
     return TT_E_UNSUPPORTED;
 }
+// ---- narrow levels (C = 4, 8) with split operands: a LANE is a pixel (round 5) -----------------------------------------------------
+// The narrow levels of the no-grad fp32 forward ran on the exact-fp32 kernels of conv_small.hip (k_small_lds / k_small_fwd4:
+// v_mfma_f32_4x4x1 at a sixteenth of the 16-bit matrix rate, 570-750 us per block at the 96 chunks of BASELINE configs[1] against a
+// 270 us memory floor: 15 of its 37 ms).  Same arithmetic as k_x3_conv above -- every value a (hi, lo 2^11) pair of halves, three
+// products with the cross terms in their own accumulators, bias / ELU / residual in fp32 -- in the lane-per-pixel form of the 16-bit
+// narrow kernels (k_nrb_conv, conv_wide_bf16.hip): v_mfma_f32_4x4x4_16b_f16 runs sixteen independent 4 x 4 x 4 products per wave, A = a
+// 4 x 4 slice of the weights, B = four channels of the lane's own pixel, so every lane ends up with all output channels of its pixel.
+//
+// Layout "x3n" between the blocks of a level: [B][H][T][2][C] halves like x3 -- C = 4: one 16-byte piece per pixel [hi 4][lo 4];
+// C = 8: two pieces [hi 8][lo 8].  The level's first block reads the fp32 planar tensor of the layer in front of it (PIN: C coalesced
+// 4-byte loads per pixel, split in registers on the way to LDS) and its last block stores fp32 planar (POUT): no pack / unpack pass,
+// the strided and boundary layers around the narrow levels stay as they are.
+// LDS tile (16 x 64 pixels + D halo): C = 4 pixel-major; C = 8 [row][plane][column] so that the 64 lanes of a B-operand read touch
+// 64 consecutive 16-byte pieces (pixel-major, 32 bytes apart, would be a two-way bank conflict) -- the DMA source addresses are
+// permuted instead.  A wave owns rows {2 w, 2 w + 1, 2 w + 8, 2 w + 9} and walks them two at a time (the LDS-resident weight
+// operands of C = 8 are read once per two rows; two independent accumulator chains per matrix instruction stream).
+template <int C, int D> struct XN {
+    static constexpr int TH = 16, TW = 64, NTH = 256, R = 2;
+    static constexpr int PXB = 4 * C, PPX = PXB / 16;            // bytes / 16-byte pieces per pixel
+    static constexpr int RW = TW + 2 * D, ROWS = TH + 2 * D, NPIX = ROWS * RW;
+    static constexpr int NP = NPIX * PPX;                        // pieces of the halo'd tile, [row][piece of the pixel][column]
+    static constexpr int NPR = (NP + NTH - 1) / NTH * NTH;
+    static constexpr int TILE_BYTES = NPR * 16;
+    static constexpr int NB = C / 4;
+    static constexpr bool WLDS = C == 8;                         // C = 8: both planes of W1 in LDS (144 VGPRs otherwise: one wave per SIMD less)
+    static constexpr int WL_BYTES = WLDS ? 2 * 9 * NB * NB * 4 * 8 : 0;  // [plane][tap][ob][kb][lane % 4] x 8 bytes
+    static constexpr int LDS_BYTES = TILE_BYTES + WL_BYTES;
+    static constexpr int NITP = (NPIX + NTH - 1) / NTH;          // PIN: pixels per thread
+};
+
+template <int C, int D, bool PIN, bool POUT>
+__global__ __launch_bounds__(256, 3) void k_x3n_conv(const void* __restrict__ xin, const float* __restrict__ w1,
+                                                                  const float* __restrict__ b1, const float* __restrict__ w2,
+                                                                  const float* __restrict__ b2, void* __restrict__ yout, int B, int H, int T,
+                                                                  int tiles_h, int tiles_t, int ntiles) {
+    using G = XN<C, D>;
+    constexpr int NB = G::NB, R = G::R, RW = G::RW, PPX = G::PPX, NTH = G::NTH;
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char* wl = smem + G::TILE_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i4 = lane & 3;
+
+    // ---- weights: the lane's rows of every 4 x 4 slice, split into the two planes ----
+    s16x4 AH[G::WLDS ? 1 : 9][NB][NB], AL[G::WLDS ? 1 : 9][NB][NB], A2H[NB][NB], A2L[NB][NB];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) {
+                e16x4 qh, ql;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { e16 h_, l_; split(w1[((4 * ob + i4) * C + 4 * kb + k) * 9 + tap], h_, l_); qh[k] = h_; ql[k] = l_; }
+                if constexpr (G::WLDS) {
+                    if (lane < 4) {                              // every wave writes the same bytes
+                        *reinterpret_cast<e16x4*>(wl + ((((tap * NB + ob) * NB + kb) << 2) + i4) * 8) = qh;
+                        *reinterpret_cast<e16x4*>(wl + 9 * NB * NB * 32 + ((((tap * NB + ob) * NB + kb) << 2) + i4) * 8) = ql;
+                    }
+                } else {
+                    AH[tap][ob][kb] = __builtin_bit_cast(s16x4, qh);
+                    AL[tap][ob][kb] = __builtin_bit_cast(s16x4, ql);
+                }
+            }
+#pragma unroll
+    for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) {
+            e16x4 qh, ql;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { e16 h_, l_; split(w2[(4 * ob + i4) * C + 4 * kb + k], h_, l_); qh[k] = h_; ql[k] = l_; }
+            A2H[ob][kb] = __builtin_bit_cast(s16x4, qh);
+            A2L[ob][kb] = __builtin_bit_cast(s16x4, ql);
+        }
+    float b1r[C], b2r[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) { b1r[c] = b1[c]; b2r[c] = b2[c]; }
+    auto whi = [&](int tap, int ob, int kb) {
+        if constexpr (G::WLDS) return *reinterpret_cast<const s16x4*>(wl + ((((tap * NB + ob) * NB + kb) << 2) + i4) * 8);
+        else return AH[tap][ob][kb];
+    };
+    auto wlo = [&](int tap, int ob, int kb) {
+        if constexpr (G::WLDS) return *reinterpret_cast<const s16x4*>(wl + 9 * NB * NB * 32 + ((((tap * NB + ob) * NB + kb) << 2) + i4) * 8);
+        else return AL[tap][ob][kb];
+    };
+    // the two planes of pixel (row, col) of the tile image as 4-channel chunks: hi[kb], lo[kb]
+    auto ldpx = [&](int row, int col, s16x4 (&hi)[NB], s16x4 (&lo)[NB]) {
+        if constexpr (C == 4) {
+            const e16x8 v = *reinterpret_cast<const e16x8*>(smem + ((long)row * RW + col) * 16);
+            hi[0] = __builtin_bit_cast(s16x4, __builtin_shufflevector(v, v, 0, 1, 2, 3));
+            lo[0] = __builtin_bit_cast(s16x4, __builtin_shufflevector(v, v, 4, 5, 6, 7));
+        } else {
+            const e16x8 vh = *reinterpret_cast<const e16x8*>(smem + ((long)(row * 2 + 0) * RW + col) * 16);
+            const e16x8 vl = *reinterpret_cast<const e16x8*>(smem + ((long)(row * 2 + 1) * RW + col) * 16);
+            hi[0] = __builtin_bit_cast(s16x4, __builtin_shufflevector(vh, vh, 0, 1, 2, 3));
+            hi[1] = __builtin_bit_cast(s16x4, __builtin_shufflevector(vh, vh, 4, 5, 6, 7));
+            lo[0] = __builtin_bit_cast(s16x4, __builtin_shufflevector(vl, vl, 0, 1, 2, 3));
+            lo[1] = __builtin_bit_cast(s16x4, __builtin_shufflevector(vl, vl, 4, 5, 6, 7));
+        }
+    };
+    const e16* zero = reinterpret_cast<const e16*>(&g_wzero16);
+
+    for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
+        int tile = xcd_order(v, ntiles);
+        const int tt = tile % tiles_t; tile /= tiles_t;
+        const int th = tile % tiles_h;
+        const int b = tile / tiles_h, h0 = th * G::TH, t0 = tt * G::TW;
+        __syncthreads();                                         // the previous tile has been consumed (first pass: lo weights written)
+        if constexpr (PIN) {
+            // fp32 planar -> split halves in LDS: C coalesced loads per pixel, all of a thread's pixels requested first
+            const float* xp = static_cast<const float*>(xin) + (long)b * C * H * T;
+            float f[G::NITP][C];
+#pragma unroll
+            for (int it = 0; it < G::NITP; ++it) {
+                const int i = it * NTH + tid, row = i / RW, col = i - row * RW;
+                const int h = h0 - D + row, t = t0 - D + col;
+                const bool ok = i < G::NPIX && (unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T;
+                const long o = ok ? (long)h * T + t : 0;
+#pragma unroll
+                for (int c = 0; c < C; ++c) { const float q = xp[(long)c * H * T + o]; f[it][c] = ok ? q : 0.f; }
+            }
+#pragma unroll
+            for (int it = 0; it < G::NITP; ++it) {
+                const int i = it * NTH + tid, row = i / RW, col = i - row * RW;
+                if (i >= G::NPIX) continue;
+                e16x8 ph, pl;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    e16 h_, l_; split(f[it][c], h_, l_);
+                    if constexpr (C == 4) { ph[c] = h_; ph[4 + c] = l_; } else { ph[c] = h_; pl[c] = l_; }
+                }
+                if constexpr (C == 4) {
+                    *reinterpret_cast<e16x8*>(smem + ((long)row * RW + col) * 16) = ph;
+                } else {
+                    *reinterpret_cast<e16x8*>(smem + ((long)(row * 2 + 0) * RW + col) * 16) = ph;
+                    *reinterpret_cast<e16x8*>(smem + ((long)(row * 2 + 1) * RW + col) * 16) = pl;
+                }
+            }
+        } else {
+            const unsigned char* xb = static_cast<const unsigned char*>(xin) + (long)b * H * T * G::PXB;
+            for (int i = wave * 64; i < G::NPR; i += NTH) {
+                const int p = i + lane;
+                const int rp = p / RW, col = p - rp * RW, row = rp / PPX, pc = rp - row * PPX;
+                const int h = h0 - D + row, t = t0 - D + col;
+                const bool ok = p < G::NP && (unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T;
+                glds16(ok ? (const void*)(xb + ((long)h * T + t) * G::PXB + pc * 16) : (const void*)zero, smem + (long)i * 16);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+
+        const int t = t0 + lane;
+        const bool valid = t < T;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int r0 = 2 * wave + 8 * half;                  // rows r0, r0 + 1 of the tile
+            if (h0 + r0 >= H) break;
+            f32x4 am[R][NB], al[R][NB];                          // hi x hi (bias as initial value) and the two cross terms
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+                for (int ob = 0; ob < NB; ++ob) {
+                    am[rr][ob] = f32x4{b1r[4 * ob], b1r[4 * ob + 1], b1r[4 * ob + 2], b1r[4 * ob + 3]};
+                    al[rr][ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int kh = tap / 3, kw = tap - 3 * kh;
+                s16x4 xh[R][NB], xl[R][NB];
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr) ldpx(r0 + rr + kh * D, lane + kw * D, xh[rr], xl[rr]);
+#pragma unroll
+                for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+                    for (int kb = 0; kb < NB; ++kb) {
+                        const s16x4 whv = whi(tap, ob, kb), wlv = wlo(tap, ob, kb);
+#pragma unroll
+                        for (int rr = 0; rr < R; ++rr) {
+                            am[rr][ob] = mma4(whv, xh[rr][kb], am[rr][ob]);
+                            al[rr][ob] = mma4(whv, xl[rr][kb], al[rr][ob]);
+                        }
+#pragma unroll
+                        for (int rr = 0; rr < R; ++rr) al[rr][ob] = mma4(wlv, xh[rr][kb], al[rr][ob]);
+                    }
+            }
+            // ---- ELU, 1x1 product, ELU, residual add, store ----
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+                const int h = h0 + r0 + rr;
+                if (h >= H) break;
+                e16x4 hh[NB], hl[NB];
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    e16 a_, b_;
+                    split(elu1(__builtin_fmaf(al[rr][c >> 2][c & 3], LO_INV, am[rr][c >> 2][c & 3])), a_, b_);
+                    hh[c >> 2][c & 3] = a_; hl[c >> 2][c & 3] = b_;
+                }
+                f32x4 zm[NB], zl[NB];
+#pragma unroll
+                for (int ob = 0; ob < NB; ++ob) {
+                    zm[ob] = f32x4{b2r[4 * ob], b2r[4 * ob + 1], b2r[4 * ob + 2], b2r[4 * ob + 3]};
+                    zl[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kb = 0; kb < NB; ++kb) {
+                        zm[ob] = mma4(A2H[ob][kb], __builtin_bit_cast(s16x4, hh[kb]), zm[ob]);
+                        zl[ob] = mma4(A2H[ob][kb], __builtin_bit_cast(s16x4, hl[kb]), zl[ob]);
+                        zl[ob] = mma4(A2L[ob][kb], __builtin_bit_cast(s16x4, hh[kb]), zl[ob]);
+                    }
+                }
+                s16x4 ch[NB], cl[NB];
+                ldpx(r0 + rr + D, lane + D, ch, cl);
+                float out[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const e16x4 c_h = __builtin_bit_cast(e16x4, ch[c >> 2]), c_l = __builtin_bit_cast(e16x4, cl[c >> 2]);
+                    out[c] = elu1(__builtin_fmaf(zl[c >> 2][c & 3], LO_INV, zm[c >> 2][c & 3])) + join(c_h[c & 3], c_l[c & 3]);
+                }
+                if (!valid) continue;
+                if constexpr (POUT) {
+                    float* yp = static_cast<float*>(yout) + ((long)b * C * H + h) * T + t;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) yp[(long)c * H * T] = out[c];
+                } else {
+                    e16* y = static_cast<e16*>(yout) + (((long)b * H + h) * T + t) * 2 * C;
+                    e16x8 oh, ol;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        e16 a_, b_; split(out[c], a_, b_);
+                        if constexpr (C == 4) { oh[c] = a_; oh[4 + c] = b_; } else { oh[c] = a_; ol[c] = b_; }
+                    }
+                    *reinterpret_cast<e16x8*>(y) = oh;
+                    if constexpr (C == 8) *reinterpret_cast<e16x8*>(y + 8) = ol;
+                }
+            }
+        }
+    }
+}
+
+template <int C, int D, bool PIN, bool POUT>
+int launch_x3n(const void* x, const float* w1, const float* b1, const float* w2, const float* b2, void* y, int B, int H, int T, hipStream_t st) {
+    using G = XN<C, D>;
+    const int tiles_h = (H + G::TH - 1) / G::TH, tiles_t = (T + G::TW - 1) / G::TW, ntiles = B * tiles_h * tiles_t;
+    static AttrOnce once;
+    auto kern = k_x3n_conv<C, D, PIN, POUT>;
+    if (int rc = raise_lds(kern, G::LDS_BYTES, once)) return rc;
+    static const int per_cu = tt_tune("TTRAP_X3N_PER_CU", C == 8 ? 3 : 4);
+    hipLaunchKernelGGL(kern, dim3(grid_for(ntiles, G::LDS_BYTES, per_cu)), dim3(G::NTH), G::LDS_BYTES, st, x, w1, b1, w2, b2, y, B, H, T,
+                       tiles_h, tiles_t, ntiles);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+template <int C, int D>
+int x3n_io(const void* x, bool pin, const float* w1, const float* b1, const float* w2, const float* b2, void* y, bool pout, int B, int H,
+           int T, hipStream_t st) {
+    if (pin) return pout ? launch_x3n<C, D, true, true>(x, w1, b1, w2, b2, y, B, H, T, st) : launch_x3n<C, D, true, false>(x, w1, b1, w2, b2, y, B, H, T, st);
+    return pout ? launch_x3n<C, D, false, true>(x, w1, b1, w2, b2, y, B, H, T, st) : launch_x3n<C, D, false, false>(x, w1, b1, w2, b2, y, B, H, T, st);
+}
+template <int C>
+int x3n_d(const void* x, bool pin, const float* w1, const float* b1, const float* w2, const float* b2, void* y, bool pout, int B, int H, int T,
+          int d, hipStream_t st) {
+    switch (d) {
+        case 1: return x3n_io<C, 1>(x, pin, w1, b1, w2, b2, y, pout, B, H, T, st);
+        case 2: return x3n_io<C, 2>(x, pin, w1, b1, w2, b2, y, pout, B, H, T, st);
+        case 3: return x3n_io<C, 3>(x, pin, w1, b1, w2, b2, y, pout, B, H, T, st);
+    }
+    return TT_E_UNSUPPORTED;
+}
+inline bool x3n_shape_ok(int B, int C, int H, int T) { return B > 0 && H > 0 && T > 0 && (C == 4 || C == 8) && (long)B * H * T < (1l << 34); }
+
 // ---- strided layers between and above the wide levels ------------------------------------------------------------------------------
 // EncoderBlock.sconv = ELU(Conv2d(C, 2C, (4,1), stride (2,1))) (reference modules.py:626-630) and DecoderBlock.tconv =
 // ELU(ConvTranspose2d(2C, C, (4,1), stride (2,1), output_padding)) (modules.py:683-688) with split operands, so that a chain
@@ -939,6 +1206,38 @@ int tt_x3_latent_decode(const float* z, int Dz, float fill, const float* w, cons
 int64_t tt_x3_level_scratch_bytes(int B, int C, int H, int T) {
     const int64_t bytes = tt_x3_bytes(B, C, H, T);
     return bytes < 0 ? -1 : 2 * (((bytes + 255) / 256) * 256);
+}
+
+int64_t tt_x3n_level_scratch_bytes(int B, int C, int H, int T) {
+    if (!x3n_shape_ok(B, C, H, T)) return -1;
+    const int64_t bytes = (int64_t)B * H * T * C * 4;
+    return 2 * (((bytes + 255) / 256) * 256);
+}
+
+int tt_x3n_rb_fwd(const void* x, int planar_in, const float* w1, const float* b1, const float* w2, const float* b2, void* y, int planar_out,
+                  int B, int C, int H, int T, int dilation, void* stream) {
+    if (!x || !w1 || !b1 || !w2 || !b2 || !y || x == y || !x3n_shape_ok(B, C, H, T)) return TT_E_BADARG;
+    hipStream_t st = tt_stream(stream);
+    return C == 4 ? x3n_d<4>(x, planar_in != 0, w1, b1, w2, b2, y, planar_out != 0, B, H, T, dilation, st)
+                  : x3n_d<8>(x, planar_in != 0, w1, b1, w2, b2, y, planar_out != 0, B, H, T, dilation, st);
+}
+
+int tt_x3n_level_fwd(int nblocks, const float* x, float* y, const float* const* w1, const float* const* b1, const float* const* w2,
+                     const float* const* b2, const int* dilations, void* ws, int B, int C, int H, int T, void* stream) {
+    if (nblocks < 1 || !x || !y || !w1 || !b1 || !w2 || !b2 || !dilations || !ws || !x3n_shape_ok(B, C, H, T)) return TT_E_BADARG;
+    for (int i = 0; i < nblocks; ++i)
+        if (!w1[i] || !b1[i] || !w2[i] || !b2[i] || dilations[i] < 1 || dilations[i] > 3) return TT_E_BADARG;
+    const int64_t bytes = (int64_t)B * H * T * C * 4;
+    unsigned char* buf[2] = {static_cast<unsigned char*>(ws), static_cast<unsigned char*>(ws) + ((bytes + 255) / 256) * 256};
+    const void* cur = x;
+    for (int i = 0; i < nblocks; ++i) {                          // first block: fp32 planar in; last block: fp32 planar out
+        const bool first = i == 0, last = i == nblocks - 1;
+        void* dst = last ? static_cast<void*>(y) : static_cast<void*>(buf[i & 1]);
+        if (dst == cur) return TT_E_BADARG;
+        if (int rc = tt_x3n_rb_fwd(cur, first, w1[i], b1[i], w2[i], b2[i], dst, last, B, C, H, T, dilations[i], stream)) return rc;
+        cur = dst;
+    }
+    return 0;
 }
 
 }  // extern "C"

@@ -77,6 +77,9 @@ _PROTOS = {
     'tt_x3_unpack': (c_int, [P, P, I, I, I, I, P]),
     'tt_x3_rb_fwd': (c_int, [P, P, P, P, P, P, I, I, I, I, I, I, P]),
     'tt_x3_level_fwd': (c_int, [I, P, I, P, I, P, P, P, P, P, P, I, I, I, I, P]),
+    'tt_x3n_level_scratch_bytes': (c_int64, [I, I, I, I]),
+    'tt_x3n_rb_fwd': (c_int, [P, I, P, P, P, P, P, I, I, I, I, I, I, P]),
+    'tt_x3n_level_fwd': (c_int, [I, P, P, P, P, P, P, P, P, I, I, I, I, P]),
     'tt_x3_latent_scratch_bytes': (c_int64, [I, I, I]),
     'tt_x3_latent_encode': (c_int, [P, P, P, P, P, I, I, I, I, I, P]),
     'tt_x3_latent_decode': (c_int, [P, I, c_float, P, P, P, I, P, I, I, I, I, I, P]),

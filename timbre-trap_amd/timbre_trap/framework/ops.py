@@ -946,6 +946,13 @@ def residual_level(x, blocks, out_x3=False):
             params += [b.conv1[0].weight, b.conv1[0].bias, b.conv2[0].weight, b.conv2[0].bias]
         return Level16Fn.apply(to_cl16(x), tuple(b.dilation for b in blocks), *params)
     x = to_planar32(x)
+    if (x3_inference() and X3N_INFER and C in X3N_CHANNELS and x.is_cuda and _x3_blocks_ok(C, blocks)
+            and _x3_size_ok(x.size(0), x.size(2), x.size(3))):
+        y = x3n_level(x, blocks)
+        if x3_chain() or x3_range_ok(y):                          # same range rule as the wide levels below
+            return y
+        with x3_disabled():
+            return residual_level(x, blocks)
     if x3_inference() and C in X3_CHANNELS and x.is_cuda and _x3_blocks_ok(C, blocks):
         y = x3_level(x, blocks, out_x3)
         # outside TimbreTrap._inference (which checks its final result once) a level that went fp32 -> split -> fp32 vouches for
@@ -966,6 +973,8 @@ def residual_level(x, blocks, out_x3=False):
 # rate.  TTRAP_X3_INFER=0 / ops.X3_INFER = False keeps the fp32 kernels.
 X3_INFER = os.environ.get('TTRAP_X3_INFER', '1') != '0'
 X3_CHANNELS = (16, 32)
+X3N_CHANNELS = (4, 8)                 # the narrow levels: lane-per-pixel split-operand blocks (tt_x3n_level_fwd), fp32 planar in and out
+X3N_INFER = os.environ.get('TTRAP_X3N_INFER', '1') != '0'        # 0: the narrow levels stay on the exact-fp32 kernels (A/B, bench.py)
 X3_SHAPES = {}                        # event key -> (B, C, H, T) of the last instrumented call (bench.py's roofline_x3_fwd)
 _X3_LOCAL = threading.local()
 
@@ -1089,6 +1098,37 @@ def x3_level(x, blocks, out_x3=False):
         return y
     check(lib.tt_x3_level_fwd(n, ptr(x), int(in_x3), ptr(y), int(out_x3), arr(0), arr(1), arr(2), arr(3),
                               (ctypes.c_int * n)(*[b.dilation for b in blocks]), ptr(ws), B, C, H, T, st), 'tt_x3_level_fwd')
+    return y
+
+
+def x3n_level(x, blocks):
+    """block_n(...block1(x)) of a NARROW level (C = 4, 8) without an autograd graph: tt_x3n_level_fwd, fp32 planar (B,C,H,T) in and
+    out, split-operand tensors between the blocks."""
+    x = _f32c(x)
+    B, C, H, T = x.shape
+    lib, st = _hip.lib(), stream_ptr()
+    n = len(blocks)
+    params = [[_f32c(t.detach()) for t in (b.conv1[0].weight, b.conv1[0].bias, b.conv2[0].weight, b.conv2[0].bias)] for b in blocks]
+    _hip.require_cuda(x, params[0][0])
+    arr = lambda j: (ctypes.c_void_p * n)(*[p[j].data_ptr() for p in params])
+    ws = torch.empty(lib.tt_x3n_level_scratch_bytes(B, C, H, T), dtype=torch.uint8, device=x.device)
+    y = torch.empty((B, C, H, T), dtype=torch.float32, device=x.device)
+    if _hip.EVENT_LOG is not None:
+        # bench.py's instrumented steps: the same launches, each block between its own pair of events
+        half = ws.numel() // 2
+        buf = (ws[:half], ws[half:])
+        cur = x
+        for i, (b, p) in enumerate(zip(blocks, params)):
+            last = i == n - 1
+            dst = y if last else buf[i & 1]
+            with _hip.timed('x3n_rb_fwd_C%d' % C):
+                check(lib.tt_x3n_rb_fwd(ptr(cur), int(i == 0), ptr(p[0]), ptr(p[1]), ptr(p[2]), ptr(p[3]), ptr(dst), int(last), B, C, H, T,
+                                        b.dilation, st), 'tt_x3n_rb_fwd')
+            cur = dst
+        X3_SHAPES['x3n_rb_fwd_C%d' % C] = (B, C, H, T)
+        return y
+    check(lib.tt_x3n_level_fwd(n, ptr(x), ptr(y), arr(0), arr(1), arr(2), arr(3), (ctypes.c_int * n)(*[b.dilation for b in blocks]), ptr(ws),
+                               B, C, H, T, st), 'tt_x3n_level_fwd')
     return y
 
 

@@ -340,10 +340,19 @@ int x3_d(const e16* x, const float* w1, const float* b1, const float* w2, const 
 // the strided and boundary layers around the narrow levels stay as they are.
 // LDS tile (16 x 64 pixels + D halo): C = 4 pixel-major; C = 8 [row][plane][column] so that the 64 lanes of a B-operand read touch
 // 64 consecutive 16-byte pieces (pixel-major, 32 bytes apart, would be a two-way bank conflict) -- the DMA source addresses are
-// permuted instead.  A wave owns rows {2 w, 2 w + 1, 2 w + 8, 2 w + 9} and walks them two at a time (the LDS-resident weight
-// operands of C = 8 are read once per two rows; two independent accumulator chains per matrix instruction stream).
+// permuted instead.  A wave owns rows 4 w .. 4 w + 3 and walks them R at a time (XN::R).
+#ifndef TT_X3N_R8
+#define TT_X3N_R8 4              // rows per step at C = 8 (2 | 4)
+#endif
+#ifndef TT_X3N_MINW8
+#define TT_X3N_MINW8 2           // workgroups per CU the C = 8 kernel's registers are capped for (3: 168 VGPRs, spills; 2: 256)
+#endif
 template <int C, int D> struct XN {
-    static constexpr int TH = 16, TW = 64, NTH = 256, R = 2;
+    static constexpr int TH = 16, TW = 64, NTH = 256;
+    // rows a wave walks at a time (of its four): C = 8 takes all four -- its weight operands come from LDS, and with two rows the 36
+    // reads per step sat in front of 120 matrix instructions each with its own wait (62 s_waitcnt per step in the listing); with four
+    // the eight fragments of a tap feed 96 matrix instructions
+    static constexpr int R = C == 8 ? TT_X3N_R8 : 2;
     static constexpr int PXB = 4 * C, PPX = PXB / 16;            // bytes / 16-byte pieces per pixel
     static constexpr int RW = TW + 2 * D, ROWS = TH + 2 * D, NPIX = ROWS * RW;
     static constexpr int NP = NPIX * PPX;                        // pieces of the halo'd tile, [row][piece of the pixel][column]
@@ -357,7 +366,7 @@ template <int C, int D> struct XN {
 };
 
 template <int C, int D, bool PIN, bool POUT>
-__global__ __launch_bounds__(256, 3) void k_x3n_conv(const void* __restrict__ xin, const float* __restrict__ w1,
+__global__ __launch_bounds__(256, C == 8 ? TT_X3N_MINW8 : 3) void k_x3n_conv(const void* __restrict__ xin, const float* __restrict__ w1,
                                                                   const float* __restrict__ b1, const float* __restrict__ w2,
                                                                   const float* __restrict__ b2, void* __restrict__ yout, int B, int H, int T,
                                                                   int tiles_h, int tiles_t, int ntiles) {
@@ -478,8 +487,8 @@ __global__ __launch_bounds__(256, 3) void k_x3n_conv(const void* __restrict__ xi
         const int t = t0 + lane;
         const bool valid = t < T;
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int r0 = 2 * wave + 8 * half;                  // rows r0, r0 + 1 of the tile
+        for (int part = 0; part < 4 / R; ++part) {
+            const int r0 = 4 * wave + R * part;                  // rows r0 .. r0 + R - 1 of the tile
             if (h0 + r0 >= H) break;
             f32x4 am[R][NB], al[R][NB];                          // hi x hi (bias as initial value) and the two cross terms
 #pragma unroll
@@ -569,7 +578,7 @@ int launch_x3n(const void* x, const float* w1, const float* b1, const float* w2,
     static AttrOnce once;
     auto kern = k_x3n_conv<C, D, PIN, POUT>;
     if (int rc = raise_lds(kern, G::LDS_BYTES, once)) return rc;
-    static const int per_cu = tt_tune("TTRAP_X3N_PER_CU", C == 8 ? 3 : 4);
+    static const int per_cu = tt_tune("TTRAP_X3N_PER_CU", C == 8 ? TT_X3N_MINW8 : 4);
     hipLaunchKernelGGL(kern, dim3(grid_for(ntiles, G::LDS_BYTES, per_cu)), dim3(G::NTH), G::LDS_BYTES, st, x, w1, b1, w2, b2, y, B, H, T,
                        tiles_h, tiles_t, ntiles);
     TT_LAUNCH_CHECK();

@@ -37,9 +37,12 @@ Prints ONE JSON line on rank 0 with the driver's fields plus
   "overlap"           : N > 1 only: event timestamps of one instrumented step -- how long the compute stream still had to wait for
                         the all-reduce AFTER it had finished the next batch's CQT (0 = the collective was hidden entirely)
   "skip_connections_step" : the same step with skip_connections=True (the model of BASELINE.json configs[4]), N = 1
+  "fp16_train_step"   : the same step under torch.autocast(dtype=float16) -- the unmodified train.py's dtype (train.py:415) -- with the static
+                        loss scale of the fp16 backward (ops.FP16_LOSS_SCALE, round 5), N = 1
   "inference_config1" : BASELINE.json configs[1] (transcribe() + reconstruct(), 32 clips) timed in the same run, N = 1: fp32 semantics
-                        (no autocast; the wide levels on split fp16 operands, csrc/conv_x3.hip -- "fp32_kernels_only" is the same leg with
-                        ops.X3_INFER off, "roofline_x3_fwd" the split-operand block against the HBM peak), and under bf16 / fp16 autocast
+                        (no autocast; the residual levels on split fp16 operands, csrc/conv_x3.hip -- "fp32_kernels_only" is the same leg with
+                        ops.X3_INFER off, "roofline_x3_fwd" / "roofline_x3n_fwd" the wide / narrow split-operand blocks against the HBM
+                        peak), and under bf16 / fp16 autocast
   "cpu_baseline"      : the CPU oracle (kind "port") on a bounded sample of the SAME workload (model_complexity 2; rank 0, N = 1)
   "cpu_baseline_config0" : BASELINE.json configs[0] on the oracle: model_complexity 1, one clip, CQT forward + inverse + one step
 """
@@ -92,7 +95,7 @@ def build_model(mc, latent, device, seed=2, skip=False):
                       latent_size=latent, model_complexity=mc, skip_connections=skip).to(device)
 
 
-def make_train_step(model, opt, world, overlap=True, autocast=True):
+def make_train_step(model, opt, world, overlap=True, autocast=True, autocast_dtype=torch.bfloat16):
     """
     Returns step(audio, target, next_audio=None) -> total loss: exactly the body of reference experiments/train.py:404-496.
 
@@ -117,7 +120,7 @@ def make_train_step(model, opt, world, overlap=True, autocast=True):
         state['coeffs'] = state['src'] = None
         # the reference runs forward, losses and backward of the step under autocast (experiments/train.py:415); with
         # ops.PRECISION == 'auto' that region is what selects the bf16 MFMA conv path (BASELINE config[2])
-        with torch.autocast(device_type='cuda', dtype=torch.bfloat16, enabled=autocast):
+        with torch.autocast(device_type='cuda', dtype=autocast_dtype, enabled=autocast):
             reconstruction, latents, trn_coeffs, trn_rec, trn_scr, _ = model(audio, True)
             transcription = model.to_activations(trn_coeffs)
             n = target.size(0)
@@ -682,7 +685,7 @@ def main():
             if args.precision == 'auto' and ops.X3_INFER:
                 # no autocast, no grad: the wide levels (C = 16, 32) run on split fp16 operands (csrc/conv_x3.hip: fp32-class results,
                 # tests/test_gpu_x3.py; model-level bar 1e-4 in tests/test_gpu_model.py), the rest on the fp32 kernels
-                infer['dtype'] = 'f32 (wide levels: f16 hi/lo pairs, three f16 MFMA products, f32 accumulate)'
+                infer['dtype'] = 'f32 (residual levels of all four widths: f16 hi/lo pairs, three f16 MFMA products, f32 accumulate)'
                 ops.X3_INFER = False
                 plain = bench_inference(model, args, rank, world, dev, steps=10, warmup=2, emit=False)
                 ops.X3_INFER = True
@@ -690,7 +693,8 @@ def main():
                 # its own roofline entry: the split-operand block at the widest level, HIP events around every launch of two more
                 # (untimed) inference steps
                 x3_events = {}
-                _hip.EVENT_KEYS = {'x3_rb_fwd_C%d' % (16 * args.mc)}
+                nkeys = ['x3n_rb_fwd_C%d' % c for c in (2 * args.mc, 4 * args.mc) if c in ops.X3N_CHANNELS]
+                _hip.EVENT_KEYS = {'x3_rb_fwd_C%d' % (16 * args.mc), *nkeys}
                 _hip.EVENT_LOG = x3_events
                 bench_inference(model, args, rank, world, dev, steps=2, warmup=0, emit=False)
                 _hip.EVENT_LOG = None
@@ -713,6 +717,18 @@ def main():
                         bound='hbm', achieved=gbs, peak=PEAK_HBM_GBS, unit='GB/s', frac=gbs / PEAK_HBM_GBS, traffic=traffic,
                         traffic_source=traffic_source, algorithmic_bytes=nbytes, launches=n_l, avg_ms=a_ms,
                         note='algorithmic bytes = x read + y written at 4 bytes per element (the x3 layout is as wide as fp32)')
+                # round 5: the narrow levels on the same arithmetic, lane = pixel (k_x3n_conv); fp32 planar or split tensors, 4 bytes per element either way
+                narrow = []
+                for nk in nkeys:
+                    if x3_events.get(nk):
+                        a_ms, n_l = avg_ms(x3_events[nk])
+                        Bx, Cx, Hx, Tx = ops.X3_SHAPES[nk]
+                        nbytes = 2 * Bx * Cx * Hx * Tx * 4
+                        gbs = nbytes / (a_ms * 1e-3) / 1e9
+                        narrow.append(dict(kernel='tt_x3n_rb_fwd at C=%d, B=%d, H=%d, T=%d: k_x3n_conv<%d,D,..> (dilation 1 / 2 / 3 averaged)' % (Cx, Bx, Hx, Tx, Cx),
+                                           bound='hbm', achieved=gbs, peak=PEAK_HBM_GBS, unit='GB/s', frac=gbs / PEAK_HBM_GBS, traffic=None,
+                                           algorithmic_bytes=nbytes, launches=n_l, avg_ms=a_ms))
+                infer['roofline_x3n_fwd'] = narrow or None
             if args.precision == 'auto':
                 full16 = bench_inference(model, args, rank, world, dev, steps=10, warmup=2, emit=False, autocast=True)
                 infer['under_autocast'] = {k: full16[k] for k in ('value', 'unit', 'ms_per_step', 'dtype')}
@@ -738,6 +754,23 @@ def main():
             ops.PRECISION = prev
             fp32_step = dict(ms_per_step=f_ms, value=args.batch * SECS_PER_CLIP / (f_ms * 1e-3), unit='audio-seconds/s', dtype='f32',
                              steps=4, warmup=2, peak_memory_gb=torch.cuda.max_memory_allocated() / 1e9, note='same step with ops.PRECISION = fp32 (no autocast): bit-exact fp32 MFMA path')
+        fp16_step = None
+        if world == 1 and not args.timed_only and args.precision == 'auto':
+            # the reference's OWN autocast dtype (train.py:415: torch.autocast('cuda') = float16) with the static loss scale of round 5
+            # (ops.FP16_LOSS_SCALE): same kernels compiled with fp16 elements; gradients 7x closer to fp32 than bf16's at this batch
+            # (profiles/r05_fp16_vs_bf16.txt) -- secondary figure, the headline keeps the bf16 path BASELINE configs[2] names
+            h_step = make_train_step(model, opt, world, overlap=False, autocast=True, autocast_dtype=torch.float16)
+            for _ in range(2):
+                h_step(audio, target)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(6):
+                h_step(audio, target)
+            torch.cuda.synchronize()
+            h_ms = 1000.0 * (time.perf_counter() - t1) / 6
+            fp16_step = dict(ms_per_step=h_ms, value=args.batch * SECS_PER_CLIP / (h_ms * 1e-3), unit='audio-seconds/s', dtype='f16', steps=6, warmup=2,
+                             loss_scale=ops.FP16_LOSS_SCALE, skipped_steps=int(opt.skipped),
+                             note='the same train step under torch.autocast(dtype=float16) -- the unmodified train.py\'s dtype -- with the static loss scale')
         skip_step = None
         if world == 1 and not args.timed_only and args.precision == 'auto':
             # BASELINE configs[4] trains with skip_connections=True: the same step with the five weighted skip joins (cl16 joins on the
@@ -770,7 +803,7 @@ def main():
                                             if args.precision == 'auto' else ''),
                                 global_batch=world * args.batch, parallelism='dp%d' % world),
                     roofline=roof, roofline_fwd=roof_fwd if roof_fwd is not roof else None, roofline_onepass_bwd=roof_onepass, roofline_cqt=cqt, roofline_cqt_inv=cqt_inv, families=families, whole_step=whole,
-                    peak_memory_gb=peak_gb, inference_config1=infer, fp32_train_step=fp32_step, skip_connections_step=skip_step, per_rank_ms=per_rank_ms, allreduce_ms=allreduce_ms, overlap=overlap_info, cpu_baseline=base, cpu_baseline_config0=base0,
+                    peak_memory_gb=peak_gb, inference_config1=infer, fp32_train_step=fp32_step, fp16_train_step=fp16_step, skip_connections_step=skip_step, per_rank_ms=per_rank_ms, allreduce_ms=allreduce_ms, overlap=overlap_info, cpu_baseline=base, cpu_baseline_config0=base0,
                     final_loss=float(total.detach()))
         print(json.dumps(line))
     if multi:

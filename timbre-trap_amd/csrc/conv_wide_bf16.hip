@@ -159,7 +159,7 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_conv(const e16* __restrict__ x
         const int b = tile / tiles_h, h0 = th * G::TH, t0 = tt * G::TW;
         const e16* xb = x + (long)b * H * T * C;
 
-        __syncthreads();                                         // the previous tile has been consumed
+        tile_top_barrier();                                      // the previous tile has been consumed
         for (int i = wave * 64; i < G::NPR; i += NT) {
             const int p = i + lane;
             const int row = p / (G::RW * G::CG), rem = p - row * (G::RW * G::CG);
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(NT) void k_wrb_wgrad(const e16* __restrict__ x, con
 // four tensor passes (dA1, dy, x | dx) for what took five, and one launch less.  No halo beyond D, no recomputation -- the vector
 // work is the sum of the two kernels minus one staging loop (PMC, round 3: both were parked on memory 40-67 % of their life).
 // Round 5 (XH = false): the x tile WITHOUT halo.  dW1[tap] = sum_q x[q] (x) dA1[q - off(tap)] indexes the weight gradient by the pixel
-// of x (the identity the strip kernel and k_nrb_bwd_fused2 use), and dA1 has its D halo anyway: the x image shrinks from
+// of x (the identity the strip kernel and k_nrb_bwd_fused use), and dA1 has its D halo anyway: the x image shrinks from
 // (TH + 2 D) x (TW + 2 D) to TH x TW pixels -- 25 / 41 / 52 % fewer staged bytes and DMA instructions at dilation 1 / 2 / 3, and at
 // C = 32 a third workgroup per CU at dilation 3 (68 -> 50 KB) and 8-row tiles instead of 6 at dilation 2 (55 -> 44 KB).
 template <int C, int D, int TH, int TW, bool XH> struct DXW {
@@ -610,7 +610,7 @@ __global__ __launch_bounds__(NT, 2) void k_wrb_dxw(const e16* __restrict__ x, co
         const int th = tile % tiles_h;
         const int b = tile / tiles_h, h0 = th * TH, t0 = tt * TW;
         const long ib = (long)b * H * T * C;
-        __syncthreads();                                         // the previous tile has been consumed
+        tile_top_barrier();                                      // the previous tile has been consumed
         for (int i = wave * 64; i < G::NPR; i += NT) {
             const int p = i + lane, q = p / G::CG, s = p - q * G::CG;
             const int row = q / G::IW, px = q - row * G::IW;
@@ -948,6 +948,19 @@ __global__ __launch_bounds__(NT, (C == 8 && MODE == 0) ? 3 : 1) void k_nrb_conv(
     const bool poisoned = MODE == 0 && params_poisoned(chk);    // see k_wrb_conv
 
     const e16* zero = reinterpret_cast<const e16*>(&g_wzero16);
+    // C = 4 only: at C = 8 the forward sits at its 168-register cap (three waves per SIMD) and the offsets would spill
+#ifndef TT_NCONV_FASTP
+#define TT_NCONV_FASTP 1
+#endif
+    constexpr bool FASTP = C == 4 && TT_NCONV_FASTP;
+    constexpr int NITD = FASTP ? G::NPR / NT : 1;                // 16-byte pieces per thread
+    unsigned rel[NITD];                                          // their byte offsets from the tile's first halo pixel (border-free tiles)
+#pragma unroll
+    for (int it = 0; it < NITD; ++it) {
+        const int p = wave * 64 + it * NT + lane, q = (p < G::NP ? p : 0) * G::PPP;
+        const int row = q / G::RW, px = q - row * G::RW;
+        rel[it] = (unsigned)(row * T + px) * (unsigned)(C * 2);
+    }
     for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
         int tile = xcd_order(v, ntiles);
         const int tt = tile % tiles_t; tile /= tiles_t;
@@ -955,13 +968,22 @@ __global__ __launch_bounds__(NT, (C == 8 && MODE == 0) ? 3 : 1) void k_nrb_conv(
         const int b = tile / tiles_h, h0 = th * G::TH, t0 = tt * G::TW;
         const e16* xb = x + (long)b * H * T * C;
 
-        __syncthreads();
-        for (int i = wave * 64; i < G::NPR; i += NT) {
-            const int p = i + lane, q = p * G::PPP;
-            const int row = q / G::RW, px = q - row * G::RW;
-            const int h = h0 - D + row, t = t0 - G::DP + px;
-            const bool ok = p < G::NP && (unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T;
-            glds16(ok ? xb + ((long)h * T + t) * C : zero, smem + (long)i * 16);
+        tile_top_barrier();                                      // the previous tile has been consumed
+        if (FASTP && h0 >= D && h0 + G::TH + D <= H && t0 >= G::DP && t0 + G::TW + G::DP <= T) {
+            // no piece of the halo'd tile is outside the image (most tiles at the bench shapes): a scalar base plus the thread's
+            // tile-independent byte offsets (round 5, as in k_nrb_bwd_fused: the general loop below spends ~25 vector instructions
+            // per piece on divisions, bounds and 64-bit selects -- a fifth of this kernel's vector instructions)
+            const char* fb = reinterpret_cast<const char*>(xb + ((long)(h0 - D) * T + (t0 - G::DP)) * C);
+#pragma unroll
+            for (int it = 0; it < NITD; ++it) glds16(fb + rel[it], smem + (long)(wave * 64 + it * NT) * 16);
+        } else {
+            for (int i = wave * 64; i < G::NPR; i += NT) {
+                const int p = i + lane, q = p * G::PPP;
+                const int row = q / G::RW, px = q - row * G::RW;
+                const int h = h0 - D + row, t = t0 - G::DP + px;
+                const bool ok = p < G::NP && (unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T;
+                glds16(ok ? xb + ((long)h * T + t) * C : zero, smem + (long)i * 16);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1106,7 +1128,7 @@ __global__ __launch_bounds__(NT) void k_nrb_bwd_a(const e16* __restrict__ h1, co
 #pragma unroll
         for (int co = 0; co < C; ++co)
 #pragma unroll
-            for (int ci = 0; ci < C; ++ci)     // plain v_fmac_f32, spelled out: see the same loop in k_nrb_bwd_fused
+            for (int ci = 0; ci < C; ++ci)     // plain v_fmac_f32, spelled out (the SLP-vectorised form of this pattern was the run-to-run different one of round 3: profiles/r04_isa_*)
                 asm("v_fmac_f32 %0, %1, %2" : "+v"(acc[co * C + ci]) : "v"(gr[co]), "v"(hv[ci]));
         hq = hq_n; dq = dq_n;
     }
@@ -1205,302 +1227,17 @@ __global__ __launch_bounds__(NT) void k_nrb_wgrad(const e16* __restrict__ x, con
 }
 
 // ---- the whole backward of a narrow block in ONE pass ---------------------------------------------------------------------
-// h1, dy and x tiles (16 x 64 pixels + halo) arrive by LDS-DMA; phase 1 runs the pointwise chain on EVERY pixel of the halo'd
-// tile (a lane = a pixel) and writes dA1 over h1 in LDS -- out-of-image pixels have h1 = dy = 0 and give dA1 = 0, which is the
-// zero padding of the data gradient; db1 / db2 / dW2 are accumulated over the tile's own (centre, in-image) pixels only.  Phase 2
-// takes dx = dy + W1^T (*) dA1 and dW1 = sum dA1 (x) x(+tap) straight from the three LDS images.  dA1 never goes to HBM: 4 tensors
-// of traffic per block instead of 8 (h1, dy, x read; dx written), one launch instead of three.
-template <int C, int D>
-__global__ __launch_bounds__(NT, C == 8 ? 2 : 1) void k_nrb_bwd_fused(const e16* __restrict__ x, const e16* __restrict__ h1,
-                                                      const e16* __restrict__ dy, const float* __restrict__ w1,
-                                                      const float* __restrict__ w2, const float* __restrict__ b2,
-                                                      e16* __restrict__ dx, float* __restrict__ part_a, float* __restrict__ part_w,
-                                                      int B, int H, int T, int tiles_h, int tiles_t, int ntiles, int fastdma) {
-    using G = NTl<C, D>;
-    typedef typename VecOf<C>::type vec_t;
-    constexpr int NB = C / 4, ADUMP = C * C + 2 * C, IMG = G::NPR * 16, NPX = G::ROWS * G::RW;
-    extern __shared__ __align__(16) unsigned char smem[];
-    unsigned char* hs = smem;                                    // h1, then dA1
-    unsigned char* gs = smem + IMG;                              // dy
-    unsigned char* xs = smem + 2 * IMG;                          // x
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i4 = lane & 3;
-    const int n = lane & 15, g = lane >> 4, trj = n >> 2, trq = n & 3;
-
-    float b2r[C], acc[ADUMP];
-#pragma unroll
-    for (int c = 0; c < C; ++c) b2r[c] = b2[c];
-#pragma unroll
-    for (int e = 0; e < ADUMP; ++e) acc[e] = 0.f;
-    f32x4 wacc[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) wacc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const e16* zero = reinterpret_cast<const e16*>(&g_wzero16);
-    // The A operands of every phase as a bf16 image in LDS, built once per workgroup: entry ((m * NB + ob) * NB + kb) * 4 + i4 holds the
-    // four values lane i4 of a 4-lane group feeds to product (ob, kb) of matrix m (0: W2, 1: W2^T, 2 + tap: W1^T of tap 8 - tap).  The
-    // phases fetch theirs per tile (8 / 36 eight-byte LDS reads at C = 8) so that the registers are free in the other phases (72 + 16
-    // registers of weights beside 116 of accumulators); converting them from the fp32 parameters per tile instead was 144 + 32 loads
-    // and as many conversions per lane and tile -- a third of the kernel's vector instructions.
-    unsigned char* wimg = smem + 3 * IMG;
-    // dW2 += dA2 (x) h1 over the tile's own pixels on the MATRIX pipe (round 4): the 64 pixels a wave handles per step are 32 (C = 8) /
-    // 16 (C = 4) consecutive 32-byte slots of the flat pixel-major images, i.e. exactly the K = 32 / K = 16 of one product whose 16
-    // rows / columns are the (pixel-in-slot, channel) pairs of a slot: A = the wave's masked dA2 (written to a 64-pixel buffer), B = h1
-    // straight from its image, both by transpose reads; the diagonal blocks (same pixel-in-slot on both sides) of the 16 x 16
-    // accumulator are the gradient.  One matrix instruction, two 16-byte LDS writes and two to four transpose reads replace the C^2
-    // multiply-adds per pixel (64 of the ~124 vector instructions a pixel of phase 1 cost at C = 8) and their C^2 accumulator registers.
-    // -DTTRAP_NRB_DW2_FMAC / -DTTRAP_NRB_DW2_SLP rebuild the vector forms (the second one is the run-to-run different one of round 3).
-#if defined(TTRAP_NRB_DW2_SLP) || defined(TTRAP_NRB_DW2_FMAC)
-    constexpr bool DW2_MFMA = false;
-#else
-    constexpr bool DW2_MFMA = true;
-#endif
-    unsigned char* abuf = wimg + 11 * NB * NB * 32 + wave * (64 * G::PXB);     // this wave's 64 pixels of masked dA2
-    f32x4 dw2m = f32x4{0.f, 0.f, 0.f, 0.f};
-    vec_t zero_px;
-#pragma unroll
-    for (int c = 0; c < C; ++c) zero_px[c] = (e16)0.f;
-    for (int e = tid; e < (2 + 9) * NB * NB * 4; e += NT) {
-        const int l4 = e & 3, kb = (e >> 2) % NB, ob = (e >> 2) / NB % NB, m = (e >> 2) / (NB * NB);
-        e16x4 a;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            a[k] = (e16)(m == 0 ? w2[(4 * ob + l4) * C + 4 * kb + k] : m == 1 ? w2[(4 * kb + k) * C + 4 * ob + l4]
-                                   : w1[((4 * kb + k) * C + 4 * ob + l4) * 9 + (8 - (m - 2))]);
-        *reinterpret_cast<e16x4*>(wimg + e * 8) = a;
-    }
-    constexpr int NITD = G::NPR / NT;                            // 16-byte pieces per thread and image
-    unsigned rel[NITD];                                          // their byte offsets from the tile's first halo pixel
-#pragma unroll
-    for (int it = 0; it < NITD; ++it) {
-        const int p = wave * 64 + it * NT + lane, q = (p < G::NP ? p : 0) * G::PPP;
-        const int row = q / G::RW, px = q - row * G::RW;
-        rel[it] = (unsigned)(row * T + px) * (unsigned)(C * 2);
-    }
-    auto wfrag = [&](int m, int ob, int kb) { return *reinterpret_cast<const s16x4*>(wimg + ((((m * NB + ob) * NB + kb) << 2) + i4) * 8); };
-    for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
-        int tile = xcd_order(v, ntiles);
-        const int tt = tile % tiles_t; tile /= tiles_t;
-        const int th = tile % tiles_h;
-        const int b = tile / tiles_h, h0 = th * G::TH, t0 = tt * G::TW;
-        const long ib = (long)b * H * T * C;
-        __syncthreads();
-        if (fastdma && h0 >= D && h0 + G::TH + D <= H && t0 >= G::DP && t0 + G::TW + G::DP <= T) {
-            // no piece of the halo'd tile is outside the image (77-82 % of the tiles at the bench shapes): scalar base + the thread's
-            // tile-independent byte offsets, no per-piece arithmetic (the general path below spends ~90 vector instructions per 256
-            // pieces on divisions, bounds and 64-bit selects -- a third of this kernel's vector instructions)
-            const long first = ib + ((long)(h0 - D) * T + (t0 - G::DP)) * C;
-            const char* hb = reinterpret_cast<const char*>(h1 + first);
-            const char* gb = reinterpret_cast<const char*>(dy + first);
-            const char* xb = reinterpret_cast<const char*>(x + first);
-#pragma unroll
-            for (int it = 0; it < NITD; ++it) {
-                const int i = wave * 64 + it * NT;
-                glds16(hb + rel[it], hs + (long)i * 16);
-                glds16(gb + rel[it], gs + (long)i * 16);
-                glds16(xb + rel[it], xs + (long)i * 16);
-            }
-        } else {
-            for (int i = wave * 64; i < G::NPR; i += NT) {
-                const int p = i + lane, q = p * G::PPP;
-                const int row = q / G::RW, px = q - row * G::RW;
-                const int h = h0 - D + row, t = t0 - G::DP + px;
-                const bool ok = p < G::NP && (unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T;
-                const long off = ib + ((long)h * T + t) * C;
-                glds16(ok ? h1 + off : zero, hs + (long)i * 16);
-                glds16(ok ? dy + off : zero, gs + (long)i * 16);
-                glds16(ok ? x + off : zero, xs + (long)i * 16);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-
-        // ---- phase 1: pointwise chain on every pixel of the image; dA1 over h1 ----
-        {
-            s16x4 A2[NB][NB], A2T[NB][NB];
-#pragma unroll
-            for (int ob = 0; ob < NB; ++ob)
-#pragma unroll
-                for (int kb = 0; kb < NB; ++kb) { A2[ob][kb] = wfrag(0, ob, kb); A2T[ob][kb] = wfrag(1, ob, kb); }
-            for (int c0 = wave * 64; c0 < NPX; c0 += NT) {
-                const int q = c0 + lane;
-                const bool in_img = q < NPX;
-                const int qq = in_img ? q : NPX - 1;
-                const int row = qq / G::RW, col = qq - row * G::RW;
-                const bool centre = in_img && row >= D && row < D + G::TH && col >= G::DP && col < G::DP + G::TW &&
-                                    h0 + row - D < H && t0 + col - G::DP < T;
-                const vec_t hq = *reinterpret_cast<const vec_t*>(hs + (long)qq * G::PXB);
-                const vec_t dq = *reinterpret_cast<const vec_t*>(gs + (long)qq * G::PXB);
-                f32x4 z[NB], u[NB];
-#pragma unroll
-                for (int ob = 0; ob < NB; ++ob) {
-                    z[ob] = f32x4{b2r[4 * ob], b2r[4 * ob + 1], b2r[4 * ob + 2], b2r[4 * ob + 3]};
-#pragma unroll
-                    for (int kb = 0; kb < NB; ++kb) z[ob] = mma4(A2[ob][kb], chunk_of<C>(hq, kb), z[ob]);
-                }
-                float gv[C], hv[C], gr[C];
-                vec_t gq, aq;
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    const float a2 = z[c >> 2][c & 3];
-                    gv[c] = (float)dq[c] * elu_dpre(a2);
-                    gq[c] = (e16)gv[c];
-                    gr[c] = (float)gq[c];
-                    hv[c] = (float)hq[c];
-                }
-#pragma unroll
-                for (int ob = 0; ob < NB; ++ob) {
-                    u[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int kb = 0; kb < NB; ++kb) u[ob] = mma4(A2T[ob][kb], chunk_of<C>(gq, kb), u[ob]);
-                }
-                const float m = centre ? 1.f : 0.f;              // sums only over this tile's own pixels
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    const float a1 = u[c >> 2][c & 3] * elu_dout(hv[c]);
-                    aq[c] = (e16)a1;
-                    acc[C * C + c] += m * a1; acc[C * C + C + c] += m * gv[c];
-                    gr[c] *= m;
-                }
-                if constexpr (DW2_MFMA) {
-                    *reinterpret_cast<vec_t*>(abuf + lane * G::PXB) = centre ? gq : zero_px;
-                    __builtin_amdgcn_wave_barrier();             // same wave: LDS operations complete in order; the fences stop the compiler
-                    asm volatile("" ::: "memory");
-                    const unsigned char* hb0 = hs + (long)c0 * G::PXB;               // the 64 pixels of this step, before dA1 replaces them
-                    const int so = 32 * (4 * g + trj) + 8 * trq;
-                    if constexpr (C == 8) {
-                        const s16x4 glo = lds_tr16(abuf + so), ghi = lds_tr16(abuf + so + 512);
-                        const s16x4 hlo = lds_tr16(hb0 + so), hhi = lds_tr16(hb0 + so + 512);
-                        dw2m = mma32(__builtin_bit_cast(e16x8, __builtin_shufflevector(glo, ghi, 0, 1, 2, 3, 4, 5, 6, 7)),
-                                     __builtin_bit_cast(e16x8, __builtin_shufflevector(hlo, hhi, 0, 1, 2, 3, 4, 5, 6, 7)), dw2m);
-                    } else {
-                        dw2m = mma16(lds_tr16(abuf + so), lds_tr16(hb0 + so), dw2m);
-                    }
-                    asm volatile("" ::: "memory");
-                } else {
-                    // The vector forms.  Left to the SLP vectoriser (-DTTRAP_NRB_DW2_SLP) this loop became packed multiply-adds with crossed
-                    // lane selects and register rotations, and ONE of the 64 accumulators -- dW2[0][0], at C = 8 / dilation 1 only -- then
-                    // came out different from run to run (2-7 % off in some runs).  Round 4: still does (tests/test_gpu_determinism.py
-                    // catches it 12 runs out of 12), and extra wait states after every packed multiply-add, after the packed multiplies
-                    // that feed them, between the crossed-select multiply-add and the rotation that overwrites its source pair, or after
-                    // every matrix instruction -- patched into the assembly, tools/isa_patch/ -- change nothing: not an instruction
-                    // hazard; cause still unknown (profiles/r04_isa_patch_determinism.txt, r04_isa_nrb_dw2_{asm,slp}.txt).
-                    // -DTTRAP_NRB_DW2_FMAC: the same loop spelled out as C^2 v_fmac_f32 (bit-stable; the shipped form of round 3).
-#pragma unroll
-                    for (int co = 0; co < C; ++co)
-#pragma unroll
-                        for (int ci = 0; ci < C; ++ci) {
-#ifdef TTRAP_NRB_DW2_SLP
-                            acc[co * C + ci] += gr[co] * hv[ci];
-#else
-                            asm("v_fmac_f32 %0, %1, %2" : "+v"(acc[co * C + ci]) : "v"(gr[co]), "v"(hv[ci]));
-#endif
-                        }
-                }
-                if (in_img) *reinterpret_cast<vec_t*>(hs + (long)q * G::PXB) = aq;
-            }
-        }
-        __syncthreads();
-
-        // ---- phase 2a: dx = dy + W1^T (*) dA1 (k_nrb_conv, MODE 1, operands from LDS) ----
-        {
-            s16x4 A[9][NB][NB];
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-                for (int ob = 0; ob < NB; ++ob)
-#pragma unroll
-                    for (int kb = 0; kb < NB; ++kb) A[tap][ob][kb] = wfrag(2 + tap, ob, kb);
-            const int t = t0 + lane;
-            for (int r = wave; r < G::TH; r += 4) {
-                const int h = h0 + r;
-                if (h >= H) break;
-                f32x4 a4[NB];
-#pragma unroll
-                for (int ob = 0; ob < NB; ++ob) a4[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    const int kh = tap / 3, kw = tap - 3 * kh;
-                    const int pxi = (r + kh * D) * G::RW + G::DP + lane + (kw - 1) * D;
-                    const vec_t bq = *reinterpret_cast<const vec_t*>(hs + (long)pxi * G::PXB);
-#pragma unroll
-                    for (int ob = 0; ob < NB; ++ob)
-#pragma unroll
-                        for (int kb = 0; kb < NB; ++kb) a4[ob] = mma4(A[tap][ob][kb], chunk_of<C>(bq, kb), a4[ob]);
-                }
-                const vec_t rq = *reinterpret_cast<const vec_t*>(gs + (long)((r + D) * G::RW + G::DP + lane) * G::PXB);
-                vec_t o;
-#pragma unroll
-                for (int c = 0; c < C; ++c) o[c] = (e16)(a4[c >> 2][c & 3] + (float)rq[c]);
-                if (t < T) *reinterpret_cast<vec_t*>(dx + ib + ((long)h * T + t) * C) = o;
-            }
-        }
-
-        // ---- phase 2b: dW1 (k_nrb_wgrad: 32-byte slots, transpose reads; the two K halves are the two halves of a row at
-        //      C = 8 and two consecutive rows at C = 4) ----
-        {
-            constexpr int ROWB = G::RW * G::PXB;                 // bytes of an image row
-            constexpr int RPS = C == 8 ? 1 : 2;                  // rows per product step
-            constexpr int UOFF = C == 8 ? 512 : ROWB;            // byte distance of the second K half
-            const int so = 32 * (4 * g + trj) + 8 * trq;
-            for (int r = wave * RPS; r < G::TH; r += 4 * RPS) {
-                if (h0 + r >= H) break;
-                const unsigned char* gp = hs + (long)(r + D) * ROWB + G::DP * G::PXB + so;
-                const s16x4 glo = lds_tr16(gp), ghi = lds_tr16(gp + UOFF);
-                const e16x8 ga = __builtin_bit_cast(e16x8, __builtin_shufflevector(glo, ghi, 0, 1, 2, 3, 4, 5, 6, 7));
-#pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    const int kh = k / 3, kw = k - 3 * kh;
-                    const unsigned char* xp = xs + (long)(r + kh * D) * ROWB + (G::DP + (kw - 1) * D) * G::PXB + so;
-                    const s16x4 lo = lds_tr16(xp), hi = lds_tr16(xp + UOFF);
-                    wacc[k] = mma32(ga, __builtin_bit_cast(e16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)), wacc[k]);
-                }
-            }
-        }
-    }
-    // ---- dumps: the four waves hold the same weight-gradient elements -- summed through LDS, ONE dump per workgroup (wave slot 0;
-    //      RedArgs::one_dump: the reduce reads a quarter of the bytes) ----
-    __syncthreads();
-    {
-        float* wr = reinterpret_cast<float*>(smem);
-#pragma unroll
-        for (int k = 0; k < 9; ++k)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) wr[wave * 2304 + (k * 4 + r) * 64 + lane] = wacc[k][r];
-        __syncthreads();
-        float* pw = part_w + (long)blockIdx.x * 4 * 2304;
-        for (int i = tid; i < 2304; i += NT) pw[i] = (wr[i] + wr[2304 + i]) + (wr[2 * 2304 + i] + wr[3 * 2304 + i]);
-    }
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int e = DW2_MFMA ? C * C : 0; e < ADUMP; ++e) {
-        float sv = acc[e];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sv += __shfl_xor(sv, o, 64);
-        if (lane == 0) red[wave * ADUMP + e] = sv;
-    }
-    if constexpr (DW2_MFMA) {
-        // the wave's 16 x 16 accumulator (row = (pixel-in-slot, co), column = (pixel-in-slot, ci)) through LDS; dW2[co][ci] = the sum of
-        // its diagonal blocks
-        float* sc = red + 4 * ADUMP + wave * 256;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sc[(4 * g + r) * 16 + n] = dw2m[r];
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("" ::: "memory");
-        if (lane < C * C) {
-            const int co = lane / C, ci = lane - co * C;
-            float sv = 0.f;
-#pragma unroll
-            for (int p_ = 0; p_ < 16 / C; ++p_) sv += sc[(p_ * C + co) * 16 + p_ * C + ci];
-            red[wave * ADUMP + lane] = sv;
-        }
-    }
-    __syncthreads();
-    float* pa = part_a + (long)blockIdx.x * ADUMP;
-    for (int e = tid; e < ADUMP; e += NT) pa[e] = (red[e] + red[ADUMP + e]) + (red[2 * ADUMP + e] + red[3 * ADUMP + e]);
-}
-
-// ---- round 5: the same one-pass backward, re-cut where its counters said the time goes ----------------------------------------
+// h1 and dy tiles (16 x 64 pixels + halo) and the x tile arrive by LDS-DMA; phase 1 runs the pointwise chain on EVERY pixel of the
+// halo'd tile (a lane = a pixel) and writes dA1 over h1 in LDS -- out-of-image pixels have h1 = dy = 0 and give dA1 = 0, which is the
+// zero padding of the data gradient; db1 / db2 / dW2 are accumulated over the tile's own (centre, in-image) pixels only -- dW2 as ONE
+// K = pixels matrix product per 64 pixels (the 32-byte slots of the flat images are the operand rows; the masked dA2 goes through a
+// 64-pixel buffer per wave, both operands by transpose reads, the diagonal blocks of the 16 x 16 accumulator are the gradient).
+// Phase 2 takes dx = dy + W1^T (*) dA1 and dW1 straight from the LDS images.  dA1 never goes to HBM: 4 tensors of traffic per block
+// instead of 8 (h1, dy, x read; dx written), one launch instead of three.  The A operands of every phase sit in a 16-bit weight
+// image in LDS built once per workgroup: entry ((m * NB + ob) * NB + kb) * 4 + i4 holds the four values lane i4 of a 4-lane group feeds
+// to product (ob, kb) of matrix m (0: W2, 1: W2^T, 2 + tap: W1^T of tap 8 - tap).
+// Round 5 (against the round-4 cut of this kernel, A/B in profiles/r05_nbf2_ab.txt: 55.4 -> 54.5 ms per step; C = 8 / dilation 3 0.457 ->
+// 0.323 ms per call, where the old cut had to fall back to the per-stage kernels), re-cut where its counters said the time goes:
 // (i)   the x tile is staged WITHOUT halo: dW1[tap] = sum_q x[q] (x) dA1[q - off(tap)] indexes the weight gradient by the pixel of x
 //       (the strip kernel's identity, conv_level_bf16.hip), and dA1 has its halo anyway -- a third of the LDS image bytes and DMA
 //       instructions less, and C = 8 / dilation 3 fits two workgroups per CU (86 -> 78 KB), which the old cut did not;
@@ -1512,7 +1249,7 @@ __global__ __launch_bounds__(NT, C == 8 ? 2 : 1) void k_nrb_bwd_fused(const e16*
 #define TT_NBF2_MINW4 4          // C = 4: registers capped for four workgroups per CU (the LDS limit); 1 lets the compiler take 156 (three)
 #endif
 template <int C, int D>
-__global__ __launch_bounds__(NT, C == 8 ? 2 : TT_NBF2_MINW4) void k_nrb_bwd_fused2(const e16* __restrict__ x, const e16* __restrict__ h1,
+__global__ __launch_bounds__(NT, C == 8 ? 2 : TT_NBF2_MINW4) void k_nrb_bwd_fused(const e16* __restrict__ x, const e16* __restrict__ h1,
                                                        const e16* __restrict__ dy, const float* __restrict__ w1,
                                                        const float* __restrict__ w2, const float* __restrict__ b2,
                                                        e16* __restrict__ dx, float* __restrict__ part_a, float* __restrict__ part_w,
@@ -1526,7 +1263,7 @@ __global__ __launch_bounds__(NT, C == 8 ? 2 : TT_NBF2_MINW4) void k_nrb_bwd_fuse
     unsigned char* hs = smem;                                    // h1, then dA1   (halo'd)
     unsigned char* gs = smem + IMG;                              // dy             (halo'd)
     unsigned char* xs = smem + 2 * IMG;                          // x              (the tile's own pixels)
-    unsigned char* wimg = xs + XIMG;                             // A operands of every phase, 16-bit (see k_nrb_bwd_fused)
+    unsigned char* wimg = xs + XIMG;                             // A operands of every phase, 16-bit
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i4 = lane & 3;
     const int n = lane & 15, g = lane >> 4, trj = n >> 2, trq = n & 3;
 
@@ -1669,7 +1406,7 @@ __global__ __launch_bounds__(NT, C == 8 ? 2 : TT_NBF2_MINW4) void k_nrb_bwd_fuse
                     acc[c] = __builtin_fmaf(m, a1, acc[c]);
                     acc[C + c] = __builtin_fmaf(m, gv[c >> 2][c & 3], acc[C + c]);
                 }
-                // dW2 += dA2 (x) h1 over the tile's own pixels as ONE matrix product per 64 pixels (see k_nrb_bwd_fused)
+                // dW2 += dA2 (x) h1 over the tile's own pixels as ONE matrix product per 64 pixels
                 *reinterpret_cast<vec_t*>(abuf + lane * G::PXB) = centre ? gq : zero_px;
                 __builtin_amdgcn_wave_barrier();
                 asm volatile("" ::: "memory");
@@ -1754,7 +1491,8 @@ __global__ __launch_bounds__(NT, C == 8 ? 2 : TT_NBF2_MINW4) void k_nrb_bwd_fuse
             }
         }
     }
-    // ---- dumps: as k_nrb_bwd_fused (ONE dump per workgroup, RedArgs::one_dump) ----
+    // ---- dumps: the four waves hold the same weight-gradient elements -- summed through LDS, ONE dump per workgroup (wave slot 0;
+    //      RedArgs::one_dump: the reduce reads a quarter of the bytes) ----
     __syncthreads();
     {
         float* wr = reinterpret_cast<float*>(smem);
@@ -1978,34 +1716,17 @@ int launch_nbwd(const e16* x, const e16* h1, const e16* dy, const float* w1, con
     // Half the HBM traffic buys less than half the time because the pass is then bound by its own arithmetic (pointwise chain on the halo
     // as well; three LDS images = 2 workgroups per CU at C = 8): fused where it wins -- C = 4 always, C = 8 at dilation 1, 2.
     static const int fused = tt_switch("TTRAP_NARROW_FUSED16", 1);
-    static const int fused_v2 = tt_tune("TTRAP_NBF2", 1);       // round 5: k_nrb_bwd_fused2 (every width and dilation); 0 = the round-4 kernel and dispatch
-    if (fused && fused_v2) {
+    if (fused) {
         using F = NTl<C, D>;
         constexpr int LAYOUT = 2 * F::NPR * 16 + F::TH * F::TW * F::PXB + 11 * (C / 4) * (C / 4) * 32 + 4 * 64 * F::PXB;
         constexpr int LDS = LAYOUT > 4 * 2304 * 4 ? LAYOUT : 4 * 2304 * 4;       // the epilogue sums the four waves' dW1 accumulators through LDS
-        static AttrOnce once_f2;
-        auto kf = k_nrb_bwd_fused2<C, D>;
-        if (int rc = raise_lds(kf, LDS, once_f2)) return rc;
-        const int tiles_h = (H + F::TH - 1) / F::TH, tiles_t = (T + F::TW - 1) / F::TW, ntiles = B * tiles_h * tiles_t;
-        int gf = grid_for(ntiles, LDS, 4);
-        if (gf > MAX_W_WG) gf = MAX_W_WG;
-        hipLaunchKernelGGL(kf, dim3(gf), dim3(NT), LDS, st, x, h1, dy, w1, w2, b2, dx, part_a, part_w, B, H, T, tiles_h, tiles_t, ntiles);
-        TT_LAUNCH_CHECK();
-        RedArgs ra{part_w, gf, part_a, gf, dw1, db1, dw2, db2, 0, 1};
-        constexpr int total = 9 * 256 + C * C + 2 * C;
-        return reduce_or_defer(k_nrb_reduce<C>, total, ra, st);
-    }
-    if (fused == 2 || (fused == 1 && (C == 8 ? D <= 2 : true))) {
-        using F = NTl<C, D>;
-        constexpr int LDS = 3 * F::NPR * 16 + 11 * (C / 4) * (C / 4) * 32 + 4 * 64 * F::PXB;   // three images + the bf16 weight image + the waves' dA2 buffers
         static AttrOnce once_f;
         auto kf = k_nrb_bwd_fused<C, D>;
         if (int rc = raise_lds(kf, LDS, once_f)) return rc;
         const int tiles_h = (H + F::TH - 1) / F::TH, tiles_t = (T + F::TW - 1) / F::TW, ntiles = B * tiles_h * tiles_t;
         int gf = grid_for(ntiles, LDS, 4);
         if (gf > MAX_W_WG) gf = MAX_W_WG;
-        static const int fastdma = tt_tune("TTRAP_FAST_DMA", 1);
-        hipLaunchKernelGGL(kf, dim3(gf), dim3(NT), LDS, st, x, h1, dy, w1, w2, b2, dx, part_a, part_w, B, H, T, tiles_h, tiles_t, ntiles, fastdma);
+        hipLaunchKernelGGL(kf, dim3(gf), dim3(NT), LDS, st, x, h1, dy, w1, w2, b2, dx, part_a, part_w, B, H, T, tiles_h, tiles_t, ntiles);
         TT_LAUNCH_CHECK();
         RedArgs ra{part_w, gf, part_a, gf, dw1, db1, dw2, db2, 0, 1};
         constexpr int total = 9 * 256 + C * C + 2 * C;

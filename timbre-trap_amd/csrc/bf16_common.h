@@ -104,21 +104,10 @@ __device__ __forceinline__ unsigned lds_addr(const unsigned char* p) {
     return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)(p);
 }
 
-// Barrier at the TOP of a persistent kernel's tile loop: every wave is done READING the LDS images of the previous tile, the next
-// tile's LDS-DMA may overwrite them.  __syncthreads() would do, but it carries a workgroup-scope fence that the compiler lowers to
-// s_waitcnt vmcnt(0) in front of the s_barrier -- i.e. it also waits for the previous tile's global STORES to drain before the next
-// tile's loads may even be issued.  Those stores touch no LDS: a bare barrier behind lgkmcnt(0) (LDS reads returned) is enough, and
-// the stores drain under the next tile's DMA flight (round 5; -DTT_RAW_TOP_BARRIER=0 restores __syncthreads()).
-#ifndef TT_RAW_TOP_BARRIER
-#define TT_RAW_TOP_BARRIER 1
-#endif
-__device__ __forceinline__ void tile_top_barrier() {
-#if TT_RAW_TOP_BARRIER
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#else
-    __syncthreads();
-#endif
-}
+// (Round 5 tried a bare s_barrier behind lgkmcnt(0) at the top of the persistent tile loops instead of __syncthreads(), whose fence the
+// compiler lowers to s_waitcnt vmcnt(0) -- a wait for the previous tile's global stores -- in front of the barrier: no effect on the
+// train step (53.42 vs 53.43 ms), slightly worse on inference (33.2 vs 32.8 ms); profiles/r05_barrier_fastp_ab.txt.  k_nrb_bwd_fused
+// keeps its own bare barriers, where they carry the deferred wait for the x tile.)
 
 // shape of the partial-sum reduce kernels: a block of 1024 threads = REL consecutive dump elements x RSL slices of the contributors
 // (each thread keeps eight loads in flight; 16 x 64 puts 600+ blocks on the chip where 64 x 16 left a third of the CUs idle)

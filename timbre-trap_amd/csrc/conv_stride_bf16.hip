@@ -601,7 +601,7 @@ __global__ __launch_bounds__(NT, C == 32 ? ((!DX && GS) ? 3 : 2) : W4_WAVES16) v
         const int b = tile / tiles_h, r0 = th * G::TR, t0 = tt * G::TW;
         const e16* sb = small + (long)b * Hs * T * (2 * C);
         const e16* bb = big + (long)b * Hb * T * C;
-        tile_top_barrier();                                      // the previous tile has been consumed (its dx stores may still be draining)
+        __syncthreads();
         if constexpr (GS) {
             stage_tile<G::BB, G::BROWS, false>(bs, bb, nullptr, 2 * r0, Hb, t0, T, tid, dbacc, 0);
             stage_tile<G::SB, G::TR + SROW0, true, SBATCH>(ss, sb, ygate + (long)b * Hs * T * (2 * C), r0 - SROW0, Hs, t0, T, tid, dbacc,

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_conv(const e16* __restrict__ x
         const int b = tile / tiles_h, h0 = th * G::TH, t0 = tt * G::TW;
         const e16* xb = x + (long)b * H * T * C;
 
-        tile_top_barrier();                                      // the previous tile has been consumed
+        __syncthreads();                                         // the previous tile has been consumed
         for (int i = wave * 64; i < G::NPR; i += NT) {
             const int p = i + lane;
             const int row = p / (G::RW * G::CG), rem = p - row * (G::RW * G::CG);
@@ -610,7 +610,7 @@ __global__ __launch_bounds__(NT, 2) void k_wrb_dxw(const e16* __restrict__ x, co
         const int th = tile % tiles_h;
         const int b = tile / tiles_h, h0 = th * TH, t0 = tt * TW;
         const long ib = (long)b * H * T * C;
-        tile_top_barrier();                                      // the previous tile has been consumed
+        __syncthreads();                                         // the previous tile has been consumed
         for (int i = wave * 64; i < G::NPR; i += NT) {
             const int p = i + lane, q = p / G::CG, s = p - q * G::CG;
             const int row = q / G::IW, px = q - row * G::IW;
@@ -948,19 +948,6 @@ __global__ __launch_bounds__(NT, (C == 8 && MODE == 0) ? 3 : 1) void k_nrb_conv(
     const bool poisoned = MODE == 0 && params_poisoned(chk);    // see k_wrb_conv
 
     const e16* zero = reinterpret_cast<const e16*>(&g_wzero16);
-    // C = 4 only: at C = 8 the forward sits at its 168-register cap (three waves per SIMD) and the offsets would spill
-#ifndef TT_NCONV_FASTP
-#define TT_NCONV_FASTP 1
-#endif
-    constexpr bool FASTP = C == 4 && TT_NCONV_FASTP;
-    constexpr int NITD = FASTP ? G::NPR / NT : 1;                // 16-byte pieces per thread
-    unsigned rel[NITD];                                          // their byte offsets from the tile's first halo pixel (border-free tiles)
-#pragma unroll
-    for (int it = 0; it < NITD; ++it) {
-        const int p = wave * 64 + it * NT + lane, q = (p < G::NP ? p : 0) * G::PPP;
-        const int row = q / G::RW, px = q - row * G::RW;
-        rel[it] = (unsigned)(row * T + px) * (unsigned)(C * 2);
-    }
     for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
         int tile = xcd_order(v, ntiles);
         const int tt = tile % tiles_t; tile /= tiles_t;
@@ -968,22 +955,15 @@ __global__ __launch_bounds__(NT, (C == 8 && MODE == 0) ? 3 : 1) void k_nrb_conv(
         const int b = tile / tiles_h, h0 = th * G::TH, t0 = tt * G::TW;
         const e16* xb = x + (long)b * H * T * C;
 
-        tile_top_barrier();                                      // the previous tile has been consumed
-        if (FASTP && h0 >= D && h0 + G::TH + D <= H && t0 >= G::DP && t0 + G::TW + G::DP <= T) {
-            // no piece of the halo'd tile is outside the image (most tiles at the bench shapes): a scalar base plus the thread's
-            // tile-independent byte offsets (round 5, as in k_nrb_bwd_fused: the general loop below spends ~25 vector instructions
-            // per piece on divisions, bounds and 64-bit selects -- a fifth of this kernel's vector instructions)
-            const char* fb = reinterpret_cast<const char*>(xb + ((long)(h0 - D) * T + (t0 - G::DP)) * C);
-#pragma unroll
-            for (int it = 0; it < NITD; ++it) glds16(fb + rel[it], smem + (long)(wave * 64 + it * NT) * 16);
-        } else {
-            for (int i = wave * 64; i < G::NPR; i += NT) {
-                const int p = i + lane, q = p * G::PPP;
-                const int row = q / G::RW, px = q - row * G::RW;
-                const int h = h0 - D + row, t = t0 - G::DP + px;
-                const bool ok = p < G::NP && (unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T;
-                glds16(ok ? xb + ((long)h * T + t) * C : zero, smem + (long)i * 16);
-            }
+        __syncthreads();                                         // the previous tile has been consumed
+        // (a border-free fast path with per-thread precomputed offsets, as in k_nrb_bwd_fused, bought nothing here: 53.42 vs 53.47 ms per
+        // step, profiles/r05_barrier_fastp_ab.txt -- the forward is not bound by its staging arithmetic)
+        for (int i = wave * 64; i < G::NPR; i += NT) {
+            const int p = i + lane, q = p * G::PPP;
+            const int row = q / G::RW, px = q - row * G::RW;
+            const int h = h0 - D + row, t = t0 - G::DP + px;
+            const bool ok = p < G::NP && (unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T;
+            glds16(ok ? xb + ((long)h * T + t) * C : zero, smem + (long)i * 16);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();

@@ -178,7 +178,7 @@ __global__ __launch_bounds__((XT<C, D>::NTH), (XT<C, D>::MINW)) void k_x3_conv(c
         const int b = tile / tiles_h, h0 = th * G::TH, t0 = tt * G::TW;
         const unsigned char* xb = reinterpret_cast<const unsigned char*>(x) + (long)b * H * T * PB;
 
-        tile_top_barrier();                                      // the previous tile has been consumed (first pass: weights written)
+        __syncthreads();                                         // the previous tile has been consumed (first pass: weights written)
 #ifdef X3_NOSTAGE
         if (v == (int)blockIdx.x)
 #endif
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256, C == 8 ? TT_X3N_MINW8 : 3) void k_x3n_conv(con
         const int tt = tile % tiles_t; tile /= tiles_t;
         const int th = tile % tiles_h;
         const int b = tile / tiles_h, h0 = th * G::TH, t0 = tt * G::TW;
-        tile_top_barrier();                                      // the previous tile has been consumed (first pass: weights written)
+        __syncthreads();                                         // the previous tile has been consumed (first pass: weights written)
         if constexpr (PIN) {
             // fp32 planar -> split halves in LDS: C coalesced loads per pixel, all of a thread's pixels requested first
             const float* xp = static_cast<const float*>(xin) + (long)b * C * H * T;

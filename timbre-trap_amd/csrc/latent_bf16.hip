@@ -392,7 +392,10 @@ int run_contract(const e16* in, const e16* gy, const float* w, const float* bias
     TT_LAUNCH_CHECK();
     constexpr int ROUNDS = (DT * 64 + NT - 1) / NT, LDS = 2 * ROUNDS * NT * 16;
     static AttrOnce once;
-    constexpr int QN = CT == 64 ? 1 : 4;
+#ifndef TT_LAT_QN64
+#define TT_LAT_QN64 1
+#endif
+    constexpr int QN = CT == 64 ? TT_LAT_QN64 : 4;
     auto kern = k_lat_contract<CT, DT, GATE, QN>;
     if (int rc = raise_lds(kern, LDS, once)) return rc;
     // GATE = the backward use (dz of Decoder.convin from the S-scaled gradient of its output): the fp32 result leaves the scaled region

@@ -326,111 +326,100 @@ int x3_d(const e16* x, const float* w1, const float* b1, const float* w2, const 
     }
     return TT_E_UNSUPPORTED;
 }
-// ---- narrow levels (C = 4, 8) with split operands: a LANE is a pixel (round 5) -----------------------------------------------------
+// ---- narrow levels (C = 4, 8) with split operands (round 5) ---------------------------------------------------------------------
 // The narrow levels of the no-grad fp32 forward ran on the exact-fp32 kernels of conv_small.hip (k_small_lds / k_small_fwd4:
 // v_mfma_f32_4x4x1 at a sixteenth of the 16-bit matrix rate, 570-750 us per block at the 96 chunks of BASELINE configs[1] against a
 // 270 us memory floor: 15 of its 37 ms).  Same arithmetic as k_x3_conv above -- every value a (hi, lo 2^11) pair of halves, three
-// products with the cross terms in their own accumulators, bias / ELU / residual in fp32 -- in the lane-per-pixel form of the 16-bit
-// narrow kernels (k_nrb_conv, conv_wide_bf16.hip): v_mfma_f32_4x4x4_16b_f16 runs sixteen independent 4 x 4 x 4 products per wave, A = a
-// 4 x 4 slice of the weights, B = four channels of the lane's own pixel, so every lane ends up with all output channels of its pixel.
+// products with the cross terms in their own accumulators, bias / ELU / residual in fp32.
+//
+// Matrix shape.  A first cut used the lane-per-pixel form of the 16-bit narrow kernels (v_mfma_f32_4x4x4_16b_f16, sixteen independent
+// 4 x 4 x 4 products per wave): 120 matrix instructions per 64 pixels at C = 8, and that instruction issues at ~16 cycles -- the
+// kernel was bound by the matrix pipe's ISSUE rate at a quarter of its arithmetic (0.56-0.66 ms per block at C = 8, no better than the
+// fp32 kernels; profiles/r05_x3n_*).  This cut feeds v_mfma_f32_16x16x16_f16 instead: the 16 rows / 16 k are S = 16 / C PIXELS x C
+// channels with the weights as the block-diagonal matrix W (x) I_S (lane n, group g holds A[m = n][k = 4 g ..]: W[co][ci] where the
+// pixel slots of m and k agree, 0 elsewhere), the 16 columns are 16 pixels per slot: one instruction = 16 S pixels x C x C of one tap
+// and plane pair -- 60 (C = 8) / 30 (C = 4) instructions per 64 pixels instead of 120 / 30 of the slow shape, half / three quarters of
+// each one's multiplies spent on the zero blocks, which the matrix pipe has to spare.  Pixel of (column n, slot s) = n + 16 s of the
+// span: consecutive lanes read consecutive pixels (conflict-free 8- / 16-byte LDS reads), and the D rows a lane gets (4 g .. 4 g + 3
+// = slot s, channels 4 (g & 1) ..) are exactly the k it supplies as B operand: the hidden activation goes from the accumulators of the
+// 3x3 product into the 1x1 product without leaving the lane, like in the wide kernels.
 //
 // Layout "x3n" between the blocks of a level: [B][H][T][2][C] halves like x3 -- C = 4: one 16-byte piece per pixel [hi 4][lo 4];
 // C = 8: two pieces [hi 8][lo 8].  The level's first block reads the fp32 planar tensor of the layer in front of it (PIN: C coalesced
 // 4-byte loads per pixel, split in registers on the way to LDS) and its last block stores fp32 planar (POUT): no pack / unpack pass,
 // the strided and boundary layers around the narrow levels stay as they are.
-// LDS tile (16 x 64 pixels + D halo): C = 4 pixel-major; C = 8 [row][plane][column] so that the 64 lanes of a B-operand read touch
-// 64 consecutive 16-byte pieces (pixel-major, 32 bytes apart, would be a two-way bank conflict) -- the DMA source addresses are
-// permuted instead.  A wave owns rows 4 w .. 4 w + 3 and walks them R at a time (XN::R).
+// LDS tile (16 x 64 pixels + D halo): C = 4 pixel-major; C = 8 [row][plane][column] (the DMA source addresses are permuted).  A wave owns
+// rows 4 w .. 4 w + 3 and walks them R at a time.
 #ifndef TT_X3N_R8
-#define TT_X3N_R8 4              // rows per step at C = 8 (2 | 4)
+#define TT_X3N_R8 2              // rows a wave walks at a time at C = 8 (1 | 2 | 4)
+#endif
+#ifndef TT_X3N_R4
+#define TT_X3N_R4 2              // ... at C = 4 (one span per row)
 #endif
 #ifndef TT_X3N_MINW8
-#define TT_X3N_MINW8 2           // workgroups per CU the C = 8 kernel's registers are capped for (3: 168 VGPRs, spills; 2: 256)
+#define TT_X3N_MINW8 3           // workgroups per CU the C = 8 kernel's registers are capped for
 #endif
 template <int C, int D> struct XN {
     static constexpr int TH = 16, TW = 64, NTH = 256;
-    // rows a wave walks at a time (of its four): C = 8 takes all four -- its weight operands come from LDS, and with two rows the 36
-    // reads per step sat in front of 120 matrix instructions each with its own wait (62 s_waitcnt per step in the listing); with four
-    // the eight fragments of a tap feed 96 matrix instructions
-    static constexpr int R = C == 8 ? TT_X3N_R8 : 2;
+    static constexpr int R = C == 8 ? TT_X3N_R8 : TT_X3N_R4;
+    static constexpr int S = 16 / C;                             // pixel slots of a matrix column: 2 (C = 8), 4 (C = 4)
+    static constexpr int SPAN = 16 * S, NSPAN = TW / SPAN;       // pixels per matrix instruction; instructions per 64-pixel row
     static constexpr int PXB = 4 * C, PPX = PXB / 16;            // bytes / 16-byte pieces per pixel
     static constexpr int RW = TW + 2 * D, ROWS = TH + 2 * D, NPIX = ROWS * RW;
     static constexpr int NP = NPIX * PPX;                        // pieces of the halo'd tile, [row][piece of the pixel][column]
     static constexpr int NPR = (NP + NTH - 1) / NTH * NTH;
     static constexpr int TILE_BYTES = NPR * 16;
-    static constexpr int NB = C / 4;
-    static constexpr bool WLDS = C == 8;                         // C = 8: both planes of W1 in LDS (144 VGPRs otherwise: one wave per SIMD less)
-    static constexpr int WL_BYTES = WLDS ? 2 * 9 * NB * NB * 4 * 8 : 0;  // [plane][tap][ob][kb][lane % 4] x 8 bytes
-    static constexpr int LDS_BYTES = TILE_BYTES + WL_BYTES;
+    static constexpr int LDS_BYTES = TILE_BYTES;
     static constexpr int NITP = (NPIX + NTH - 1) / NTH;          // PIN: pixels per thread
 };
 
 template <int C, int D, bool PIN, bool POUT>
 __global__ __launch_bounds__(256, C == 8 ? TT_X3N_MINW8 : 3) void k_x3n_conv(const void* __restrict__ xin, const float* __restrict__ w1,
-                                                                  const float* __restrict__ b1, const float* __restrict__ w2,
-                                                                  const float* __restrict__ b2, void* __restrict__ yout, int B, int H, int T,
-                                                                  int tiles_h, int tiles_t, int ntiles) {
+                                                      const float* __restrict__ b1, const float* __restrict__ w2,
+                                                      const float* __restrict__ b2, void* __restrict__ yout, int B, int H, int T,
+                                                      int tiles_h, int tiles_t, int ntiles) {
     using G = XN<C, D>;
-    constexpr int NB = G::NB, R = G::R, RW = G::RW, PPX = G::PPX, NTH = G::NTH;
+    constexpr int R = G::R, RW = G::RW, PPX = G::PPX, NTH = G::NTH, NSPAN = G::NSPAN, SPAN = G::SPAN;
     extern __shared__ __align__(16) unsigned char smem[];
-    unsigned char* wl = smem + G::TILE_BYTES;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i4 = lane & 3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    // this lane as B operand / D rows: pixel slot and first of its four channels;  as A operand: row n = (slot, output channel)
+    const int slot = C == 8 ? (g >> 1) : g, c0 = C == 8 ? 4 * (g & 1) : 0;
+    const int a_slot = n / C, a_co = n % C;
 
-    // ---- weights: the lane's rows of every 4 x 4 slice, split into the two planes ----
-    s16x4 AH[G::WLDS ? 1 : 9][NB][NB], AL[G::WLDS ? 1 : 9][NB][NB], A2H[NB][NB], A2L[NB][NB];
+    // ---- weights: block-diagonal W (x) I_S, this lane's four k of row n, both planes, in registers (9 + 1 taps x 2 planes x 2 VGPRs) ----
+    s16x4 AH[9], AL[9], A2H, A2L;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
+    for (int tap = 0; tap < 9; ++tap) {
+        e16x4 qh, ql;
 #pragma unroll
-        for (int ob = 0; ob < NB; ++ob)
-#pragma unroll
-            for (int kb = 0; kb < NB; ++kb) {
-                e16x4 qh, ql;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { e16 h_, l_; split(w1[((4 * ob + i4) * C + 4 * kb + k) * 9 + tap], h_, l_); qh[k] = h_; ql[k] = l_; }
-                if constexpr (G::WLDS) {
-                    if (lane < 4) {                              // every wave writes the same bytes
-                        *reinterpret_cast<e16x4*>(wl + ((((tap * NB + ob) * NB + kb) << 2) + i4) * 8) = qh;
-                        *reinterpret_cast<e16x4*>(wl + 9 * NB * NB * 32 + ((((tap * NB + ob) * NB + kb) << 2) + i4) * 8) = ql;
-                    }
-                } else {
-                    AH[tap][ob][kb] = __builtin_bit_cast(s16x4, qh);
-                    AL[tap][ob][kb] = __builtin_bit_cast(s16x4, ql);
-                }
-            }
-#pragma unroll
-    for (int ob = 0; ob < NB; ++ob)
-#pragma unroll
-        for (int kb = 0; kb < NB; ++kb) {
-            e16x4 qh, ql;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { e16 h_, l_; split(w2[(4 * ob + i4) * C + 4 * kb + k], h_, l_); qh[k] = h_; ql[k] = l_; }
-            A2H[ob][kb] = __builtin_bit_cast(s16x4, qh);
-            A2L[ob][kb] = __builtin_bit_cast(s16x4, ql);
+        for (int k = 0; k < 4; ++k) {
+            e16 h_, l_;
+            split(a_slot == slot ? w1[(a_co * C + c0 + k) * 9 + tap] : 0.f, h_, l_);
+            qh[k] = h_; ql[k] = l_;
         }
-    float b1r[C], b2r[C];
+        AH[tap] = __builtin_bit_cast(s16x4, qh);
+        AL[tap] = __builtin_bit_cast(s16x4, ql);
+    }
+    {
+        e16x4 qh, ql;
 #pragma unroll
-    for (int c = 0; c < C; ++c) { b1r[c] = b1[c]; b2r[c] = b2[c]; }
-    auto whi = [&](int tap, int ob, int kb) {
-        if constexpr (G::WLDS) return *reinterpret_cast<const s16x4*>(wl + ((((tap * NB + ob) * NB + kb) << 2) + i4) * 8);
-        else return AH[tap][ob][kb];
-    };
-    auto wlo = [&](int tap, int ob, int kb) {
-        if constexpr (G::WLDS) return *reinterpret_cast<const s16x4*>(wl + 9 * NB * NB * 32 + ((((tap * NB + ob) * NB + kb) << 2) + i4) * 8);
-        else return AL[tap][ob][kb];
-    };
-    // the two planes of pixel (row, col) of the tile image as 4-channel chunks: hi[kb], lo[kb]
-    auto ldpx = [&](int row, int col, s16x4 (&hi)[NB], s16x4 (&lo)[NB]) {
+        for (int k = 0; k < 4; ++k) { e16 h_, l_; split(a_slot == slot ? w2[a_co * C + c0 + k] : 0.f, h_, l_); qh[k] = h_; ql[k] = l_; }
+        A2H = __builtin_bit_cast(s16x4, qh);
+        A2L = __builtin_bit_cast(s16x4, ql);
+    }
+    float b1r[4], b2r[4];                                        // biases of the four channels this lane ends up with
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { b1r[r] = b1[c0 + r]; b2r[r] = b2[c0 + r]; }
+    // the lane's four channels (both planes) of the pixel in image (row, col)
+    auto ldpx = [&](int row, int col, s16x4& hi, s16x4& lo) {
         if constexpr (C == 4) {
             const e16x8 v = *reinterpret_cast<const e16x8*>(smem + ((long)row * RW + col) * 16);
-            hi[0] = __builtin_bit_cast(s16x4, __builtin_shufflevector(v, v, 0, 1, 2, 3));
-            lo[0] = __builtin_bit_cast(s16x4, __builtin_shufflevector(v, v, 4, 5, 6, 7));
+            hi = __builtin_bit_cast(s16x4, __builtin_shufflevector(v, v, 0, 1, 2, 3));
+            lo = __builtin_bit_cast(s16x4, __builtin_shufflevector(v, v, 4, 5, 6, 7));
         } else {
-            const e16x8 vh = *reinterpret_cast<const e16x8*>(smem + ((long)(row * 2 + 0) * RW + col) * 16);
-            const e16x8 vl = *reinterpret_cast<const e16x8*>(smem + ((long)(row * 2 + 1) * RW + col) * 16);
-            hi[0] = __builtin_bit_cast(s16x4, __builtin_shufflevector(vh, vh, 0, 1, 2, 3));
-            hi[1] = __builtin_bit_cast(s16x4, __builtin_shufflevector(vh, vh, 4, 5, 6, 7));
-            lo[0] = __builtin_bit_cast(s16x4, __builtin_shufflevector(vl, vl, 0, 1, 2, 3));
-            lo[1] = __builtin_bit_cast(s16x4, __builtin_shufflevector(vl, vl, 4, 5, 6, 7));
+            hi = *reinterpret_cast<const s16x4*>(smem + ((long)(row * 2 + 0) * RW + col) * 16 + 2 * c0);
+            lo = *reinterpret_cast<const s16x4*>(smem + ((long)(row * 2 + 1) * RW + col) * 16 + 2 * c0);
         }
     };
     const e16* zero = reinterpret_cast<const e16*>(&g_wzero16);
@@ -440,7 +429,7 @@ __global__ __launch_bounds__(256, C == 8 ? TT_X3N_MINW8 : 3) void k_x3n_conv(con
         const int tt = tile % tiles_t; tile /= tiles_t;
         const int th = tile % tiles_h;
         const int b = tile / tiles_h, h0 = th * G::TH, t0 = tt * G::TW;
-        __syncthreads();                                         // the previous tile has been consumed (first pass: weights written)
+        __syncthreads();                                         // the previous tile has been consumed
         if constexpr (PIN) {
             // fp32 planar -> split halves in LDS: C coalesced loads per pixel, all of a thread's pixels requested first
             const float* xp = static_cast<const float*>(xin) + (long)b * C * H * T;
@@ -484,87 +473,92 @@ __global__ __launch_bounds__(256, C == 8 ? TT_X3N_MINW8 : 3) void k_x3n_conv(con
         }
         __syncthreads();
 
-        const int t = t0 + lane;
-        const bool valid = t < T;
-#pragma unroll
+#pragma unroll 1
         for (int part = 0; part < 4 / R; ++part) {
             const int r0 = 4 * wave + R * part;                  // rows r0 .. r0 + R - 1 of the tile
             if (h0 + r0 >= H) break;
-            f32x4 am[R][NB], al[R][NB];                          // hi x hi (bias as initial value) and the two cross terms
+            f32x4 am[R][NSPAN], al[R][NSPAN];                    // hi x hi (bias as initial value) and the two cross terms
 #pragma unroll
             for (int rr = 0; rr < R; ++rr)
 #pragma unroll
-                for (int ob = 0; ob < NB; ++ob) {
-                    am[rr][ob] = f32x4{b1r[4 * ob], b1r[4 * ob + 1], b1r[4 * ob + 2], b1r[4 * ob + 3]};
-                    al[rr][ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int sp = 0; sp < NSPAN; ++sp) {
+                    am[rr][sp] = f32x4{b1r[0], b1r[1], b1r[2], b1r[3]};
+                    al[rr][sp] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
+            // operands one tap ahead; the empty asm statements pin that order (left alone, the compiler hoists the LDS reads of all nine
+            // taps to the top of the loop and spills 300 bytes per lane at C = 8 to hold them)
+            s16x4 xh[R][NSPAN], xl[R][NSPAN], nh[R][NSPAN], nl[R][NSPAN];
+            auto ldtap = [&](int tap, s16x4 (&qh)[R][NSPAN], s16x4 (&ql)[R][NSPAN]) {
+                const int kh = tap / 3, kw = tap - 3 * kh;
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+                    for (int sp = 0; sp < NSPAN; ++sp) ldpx(r0 + rr + kh * D, sp * SPAN + n + 16 * slot + kw * D, qh[rr][sp], ql[rr][sp]);
+            };
+            ldtap(0, xh, xl);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
-                const int kh = tap / 3, kw = tap - 3 * kh;
-                s16x4 xh[R][NB], xl[R][NB];
+                asm volatile("" ::: "memory");
+                if (tap + 1 < 9) ldtap(tap + 1, nh, nl);
+                asm volatile("" ::: "memory");
 #pragma unroll
-                for (int rr = 0; rr < R; ++rr) ldpx(r0 + rr + kh * D, lane + kw * D, xh[rr], xl[rr]);
+                for (int rr = 0; rr < R; ++rr)
 #pragma unroll
-                for (int ob = 0; ob < NB; ++ob)
-#pragma unroll
-                    for (int kb = 0; kb < NB; ++kb) {
-                        const s16x4 whv = whi(tap, ob, kb), wlv = wlo(tap, ob, kb);
-#pragma unroll
-                        for (int rr = 0; rr < R; ++rr) {
-                            am[rr][ob] = mma4(whv, xh[rr][kb], am[rr][ob]);
-                            al[rr][ob] = mma4(whv, xl[rr][kb], al[rr][ob]);
-                        }
-#pragma unroll
-                        for (int rr = 0; rr < R; ++rr) al[rr][ob] = mma4(wlv, xh[rr][kb], al[rr][ob]);
+                    for (int sp = 0; sp < NSPAN; ++sp) {
+                        am[rr][sp] = mma16(AH[tap], xh[rr][sp], am[rr][sp]);
+                        al[rr][sp] = mma16(AH[tap], xl[rr][sp], al[rr][sp]);
                     }
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+                    for (int sp = 0; sp < NSPAN; ++sp) al[rr][sp] = mma16(AL[tap], xh[rr][sp], al[rr][sp]);
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+                    for (int sp = 0; sp < NSPAN; ++sp) { xh[rr][sp] = nh[rr][sp]; xl[rr][sp] = nl[rr][sp]; }
             }
-            // ---- ELU, 1x1 product, ELU, residual add, store ----
+            // ---- ELU, 1x1 product (the accumulators of the 3x3 product ARE its B operand), ELU, residual add, store ----
 #pragma unroll
             for (int rr = 0; rr < R; ++rr) {
                 const int h = h0 + r0 + rr;
                 if (h >= H) break;
-                e16x4 hh[NB], hl[NB];
 #pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    e16 a_, b_;
-                    split(elu1(__builtin_fmaf(al[rr][c >> 2][c & 3], LO_INV, am[rr][c >> 2][c & 3])), a_, b_);
-                    hh[c >> 2][c & 3] = a_; hl[c >> 2][c & 3] = b_;
-                }
-                f32x4 zm[NB], zl[NB];
+                for (int sp = 0; sp < NSPAN; ++sp) {
+                    const int col = sp * SPAN + n + 16 * slot;   // this lane's pixel of the row
+                    const int t = t0 + col;
+                    e16x4 hh, hl;
 #pragma unroll
-                for (int ob = 0; ob < NB; ++ob) {
-                    zm[ob] = f32x4{b2r[4 * ob], b2r[4 * ob + 1], b2r[4 * ob + 2], b2r[4 * ob + 3]};
-                    zl[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int kb = 0; kb < NB; ++kb) {
-                        zm[ob] = mma4(A2H[ob][kb], __builtin_bit_cast(s16x4, hh[kb]), zm[ob]);
-                        zl[ob] = mma4(A2H[ob][kb], __builtin_bit_cast(s16x4, hl[kb]), zl[ob]);
-                        zl[ob] = mma4(A2L[ob][kb], __builtin_bit_cast(s16x4, hh[kb]), zl[ob]);
+                    for (int r = 0; r < 4; ++r) {
+                        e16 a_, b_;
+                        split(elu1(__builtin_fmaf(al[rr][sp][r], LO_INV, am[rr][sp][r])), a_, b_);
+                        hh[r] = a_; hl[r] = b_;
                     }
-                }
-                s16x4 ch[NB], cl[NB];
-                ldpx(r0 + rr + D, lane + D, ch, cl);
-                float out[C];
+                    const f32x4 zm = mma16(A2H, __builtin_bit_cast(s16x4, hh), f32x4{b2r[0], b2r[1], b2r[2], b2r[3]});
+                    f32x4 zl = mma16(A2H, __builtin_bit_cast(s16x4, hl), f32x4{0.f, 0.f, 0.f, 0.f});
+                    zl = mma16(A2L, __builtin_bit_cast(s16x4, hh), zl);
+                    s16x4 ch_, cl_;
+                    ldpx(r0 + rr + D, col + D, ch_, cl_);
+                    const e16x4 c_h = __builtin_bit_cast(e16x4, ch_), c_l = __builtin_bit_cast(e16x4, cl_);
+                    float out[4];
 #pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    const e16x4 c_h = __builtin_bit_cast(e16x4, ch[c >> 2]), c_l = __builtin_bit_cast(e16x4, cl[c >> 2]);
-                    out[c] = elu1(__builtin_fmaf(zl[c >> 2][c & 3], LO_INV, zm[c >> 2][c & 3])) + join(c_h[c & 3], c_l[c & 3]);
-                }
-                if (!valid) continue;
-                if constexpr (POUT) {
-                    float* yp = static_cast<float*>(yout) + ((long)b * C * H + h) * T + t;
+                    for (int r = 0; r < 4; ++r) out[r] = elu1(__builtin_fmaf(zl[r], LO_INV, zm[r])) + join(c_h[r], c_l[r]);
+                    if (t >= T) continue;
+                    if constexpr (POUT) {
+                        float* yp = static_cast<float*>(yout) + (((long)b * C + c0) * H + h) * T + t;
 #pragma unroll
-                    for (int c = 0; c < C; ++c) yp[(long)c * H * T] = out[c];
-                } else {
-                    e16* y = static_cast<e16*>(yout) + (((long)b * H + h) * T + t) * 2 * C;
-                    e16x8 oh, ol;
+                        for (int r = 0; r < 4; ++r) yp[(long)r * H * T] = out[r];
+                    } else {
+                        e16* y = static_cast<e16*>(yout) + (((long)b * H + h) * T + t) * 2 * C;
+                        e16x4 oh, ol;
 #pragma unroll
-                    for (int c = 0; c < C; ++c) {
-                        e16 a_, b_; split(out[c], a_, b_);
-                        if constexpr (C == 4) { oh[c] = a_; oh[4 + c] = b_; } else { oh[c] = a_; ol[c] = b_; }
+                        for (int r = 0; r < 4; ++r) { e16 a_, b_; split(out[r], a_, b_); oh[r] = a_; ol[r] = b_; }
+                        if constexpr (C == 4) {
+                            *reinterpret_cast<e16x8*>(y) = __builtin_shufflevector(oh, ol, 0, 1, 2, 3, 4, 5, 6, 7);
+                        } else {
+                            *reinterpret_cast<e16x4*>(y + c0) = oh;
+                            *reinterpret_cast<e16x4*>(y + C + c0) = ol;
+                        }
                     }
-                    *reinterpret_cast<e16x8*>(y) = oh;
-                    if constexpr (C == 8) *reinterpret_cast<e16x8*>(y + 8) = ol;
                 }
             }
         }
@@ -578,7 +572,7 @@ int launch_x3n(const void* x, const float* w1, const float* b1, const float* w2,
     static AttrOnce once;
     auto kern = k_x3n_conv<C, D, PIN, POUT>;
     if (int rc = raise_lds(kern, G::LDS_BYTES, once)) return rc;
-    static const int per_cu = tt_tune("TTRAP_X3N_PER_CU", C == 8 ? TT_X3N_MINW8 : 4);
+    static const int per_cu = tt_tune("TTRAP_X3N_PER_CU", C == 8 ? 3 : 4);     // registers: <= 152 (C = 8) / <= 99 (C = 4) VGPRs
     hipLaunchKernelGGL(kern, dim3(grid_for(ntiles, G::LDS_BYTES, per_cu)), dim3(G::NTH), G::LDS_BYTES, st, x, w1, b1, w2, b2, y, B, H, T,
                        tiles_h, tiles_t, ntiles);
     TT_LAUNCH_CHECK();

@@ -1236,7 +1236,10 @@ __global__ __launch_bounds__(NT, C == 8 ? 2 : TT_NBF2_MINW4) void k_nrb_bwd_fuse
                                                        int B, int H, int T, int tiles_h, int tiles_t, int ntiles) {
     using G = NTl<C, D>;
     typedef typename VecOf<C>::type vec_t;
-    constexpr int NB = C / 4, ADUMP = C * C + 2 * C, IMG = G::NPR * 16, NPX = G::ROWS * G::RW;
+    // the halo'd images hold exactly their NP pieces (the DMA instructions' tail lanes are masked off, not written as zeros behind the
+    // image): at C = 4 / dilation 3 the whole-instruction rounding (770 -> 1024 pieces, twice) was the difference between three and
+    // four workgroups per CU
+    constexpr int NB = C / 4, ADUMP = C * C + 2 * C, IMG = (G::NP * 16 + 63) / 64 * 64, NPX = G::ROWS * G::RW;
     constexpr int XIMG = G::TH * G::TW * G::PXB, NITX = XIMG / 16 / NT, XROWB = G::TW * G::PXB;
     constexpr int NS1 = (NPX + NT - 1) / NT;                     // phase-1 steps of 64 pixels per wave
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1312,8 +1315,10 @@ __global__ __launch_bounds__(NT, C == 8 ? 2 : TT_NBF2_MINW4) void k_nrb_bwd_fuse
 #pragma unroll
             for (int it = 0; it < NITD; ++it) {
                 const int i = wave * 64 + it * NT;
-                glds16(hb + rel[it], hs + (long)i * 16);
-                glds16(gb + rel[it], gs + (long)i * 16);
+                if (it + 1 < NITD || i + lane < G::NP) {         // (only the last round has lanes past the image)
+                    glds16(hb + rel[it], hs + (long)i * 16);
+                    glds16(gb + rel[it], gs + (long)i * 16);
+                }
             }
 #pragma unroll
             for (int it = 0; it < NITX; ++it) glds16(xb + relx[it], xs + (long)(wave * 64 + it * NT) * 16);
@@ -1322,10 +1327,12 @@ __global__ __launch_bounds__(NT, C == 8 ? 2 : TT_NBF2_MINW4) void k_nrb_bwd_fuse
                 const int p = i + lane, q = p * G::PPP;
                 const int row = q / G::RW, px = q - row * G::RW;
                 const int h = h0 - D + row, t = t0 - G::DP + px;
-                const bool ok = p < G::NP && (unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T;
+                const bool ok = (unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T;
                 const long off = ib + ((long)h * T + t) * C;
-                glds16(ok ? h1 + off : zero, hs + (long)i * 16);
-                glds16(ok ? dy + off : zero, gs + (long)i * 16);
+                if (p < G::NP) {
+                    glds16(ok ? h1 + off : zero, hs + (long)i * 16);
+                    glds16(ok ? dy + off : zero, gs + (long)i * 16);
+                }
             }
 #pragma unroll
             for (int it = 0; it < NITX; ++it) {
@@ -1698,7 +1705,7 @@ int launch_nbwd(const e16* x, const e16* h1, const e16* dy, const float* w1, con
     static const int fused = tt_switch("TTRAP_NARROW_FUSED16", 1);
     if (fused) {
         using F = NTl<C, D>;
-        constexpr int LAYOUT = 2 * F::NPR * 16 + F::TH * F::TW * F::PXB + 11 * (C / 4) * (C / 4) * 32 + 4 * 64 * F::PXB;
+        constexpr int LAYOUT = 2 * ((F::NP * 16 + 63) / 64 * 64) + F::TH * F::TW * F::PXB + 11 * (C / 4) * (C / 4) * 32 + 4 * 64 * F::PXB;
         constexpr int LDS = LAYOUT > 4 * 2304 * 4 ? LAYOUT : 4 * 2304 * 4;       // the epilogue sums the four waves' dW1 accumulators through LDS
         static AttrOnce once_f;
         auto kf = k_nrb_bwd_fused<C, D>;

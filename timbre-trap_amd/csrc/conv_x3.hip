@@ -387,7 +387,10 @@ __global__ __launch_bounds__(256, C == 8 ? TT_X3N_MINW8 : 3) void k_x3n_conv(con
     const int slot = C == 8 ? (g >> 1) : g, c0 = C == 8 ? 4 * (g & 1) : 0;
     const int a_slot = n / C, a_co = n % C;
 
-    // ---- weights: block-diagonal W (x) I_S, this lane's four k of row n, both planes, in registers (9 + 1 taps x 2 planes x 2 VGPRs) ----
+    // ---- weights, both planes, in registers.  C = 8: block-diagonal W (x) I_2, this lane's four k of row n (per tap; the 3x3 product
+    // takes two taps per K = 32 instruction).  C = 4: the plain 4 x 4 matrix, row lane % 4 (the sixteen-block instruction). ----
+    auto wsel = [&](int co_blockdiag, int ci) -> bool { (void)co_blockdiag; (void)ci; return C == 4 || a_slot == slot; };
+    const int w_row = C == 4 ? (lane & 3) : a_co;
     s16x4 AH[9], AL[9], A2H, A2L;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -395,7 +398,7 @@ __global__ __launch_bounds__(256, C == 8 ? TT_X3N_MINW8 : 3) void k_x3n_conv(con
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             e16 h_, l_;
-            split(a_slot == slot ? w1[(a_co * C + c0 + k) * 9 + tap] : 0.f, h_, l_);
+            split(wsel(0, 0) ? w1[(w_row * C + c0 + k) * 9 + tap] : 0.f, h_, l_);
             qh[k] = h_; ql[k] = l_;
         }
         AH[tap] = __builtin_bit_cast(s16x4, qh);
@@ -404,9 +407,21 @@ __global__ __launch_bounds__(256, C == 8 ? TT_X3N_MINW8 : 3) void k_x3n_conv(con
     {
         e16x4 qh, ql;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { e16 h_, l_; split(a_slot == slot ? w2[a_co * C + c0 + k] : 0.f, h_, l_); qh[k] = h_; ql[k] = l_; }
+        for (int k = 0; k < 4; ++k) { e16 h_, l_; split(wsel(0, 0) ? w2[w_row * C + c0 + k] : 0.f, h_, l_); qh[k] = h_; ql[k] = l_; }
         A2H = __builtin_bit_cast(s16x4, qh);
         A2L = __builtin_bit_cast(s16x4, ql);
+    }
+    // one K = 16 / K = 4-per-block product of the shape this width uses
+    auto mm = [&](s16x4 a, s16x4 b, f32x4 c) { if constexpr (C == 4) return mma4(a, b, c); else return mma16(a, b, c); };
+    auto cat8 = [&](s16x4 lo4, s16x4 hi4) { return __builtin_bit_cast(e16x8, __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7)); };
+    // C = 8: BOTH cross terms of a tap in one K = 32 instruction -- A = [Wlo | Whi] against B = [xhi ; xlo], the two planes of the lane's
+    // channels exactly as one 16-byte LDS read pair returns them (no register shuffling); the main term Whi xhi stays a K = 16 product
+    // on B's first half.  Two matrix instructions per tap and span instead of three.
+    e16x8 AX8[C == 8 ? 9 : 1], A2X8;
+    if constexpr (C == 8) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) AX8[tap] = cat8(AL[tap], AH[tap]);
+        A2X8 = cat8(A2L, A2H);
     }
     float b1r[4], b2r[4];                                        // biases of the four channels this lane ends up with
 #pragma unroll
@@ -485,33 +500,44 @@ __global__ __launch_bounds__(256, C == 8 ? TT_X3N_MINW8 : 3) void k_x3n_conv(con
                     am[rr][sp] = f32x4{b1r[0], b1r[1], b1r[2], b1r[3]};
                     al[rr][sp] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-            // operands one tap ahead; the empty asm statements pin that order (left alone, the compiler hoists the LDS reads of all nine
-            // taps to the top of the loop and spills 300 bytes per lane at C = 8 to hold them)
-            s16x4 xh[R][NSPAN], xl[R][NSPAN], nh[R][NSPAN], nl[R][NSPAN];
-            auto ldtap = [&](int tap, s16x4 (&qh)[R][NSPAN], s16x4 (&ql)[R][NSPAN]) {
+            // operands one step ahead; the empty asm statements pin that order (left alone, the compiler hoists the LDS reads of all nine
+            // taps to the top of the loop and spills 300 bytes per lane at C = 8 to hold them).  A step = one tap (C = 4) or two (C = 8:
+            // v_mfma_f32_16x16x32_f16 takes K = 32 = two taps x (2 slots x 8 channels) at the issue cost of one K = 16 instruction)
+            typedef typename std::conditional<C == 8, e16x8, s16x4>::type bop_t;       // C = 8: [hi 4 | lo 4] of the lane's channels in one operand
+            bop_t xh[R][NSPAN], nh[R][NSPAN];
+            s16x4 xl[R][NSPAN], nl[R][NSPAN];                      // C = 4: the lo plane separately
+            auto ldstep = [&](int tap, bop_t (&qh)[R][NSPAN], s16x4 (&ql)[R][NSPAN]) {
                 const int kh = tap / 3, kw = tap - 3 * kh;
 #pragma unroll
                 for (int rr = 0; rr < R; ++rr)
 #pragma unroll
-                    for (int sp = 0; sp < NSPAN; ++sp) ldpx(r0 + rr + kh * D, sp * SPAN + n + 16 * slot + kw * D, qh[rr][sp], ql[rr][sp]);
+                    for (int sp = 0; sp < NSPAN; ++sp) {
+                        s16x4 h4, l4;
+                        ldpx(r0 + rr + kh * D, sp * SPAN + n + 16 * slot + kw * D, h4, l4);
+                        if constexpr (C == 8) { qh[rr][sp] = cat8(h4, l4); ql[rr][sp] = l4; }
+                        else { qh[rr][sp] = h4; ql[rr][sp] = l4; }
+                    }
             };
-            ldtap(0, xh, xl);
+            ldstep(0, xh, xl);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 asm volatile("" ::: "memory");
-                if (tap + 1 < 9) ldtap(tap + 1, nh, nl);
+                if (tap + 1 < 9) ldstep(tap + 1, nh, nl);
                 asm volatile("" ::: "memory");
 #pragma unroll
                 for (int rr = 0; rr < R; ++rr)
 #pragma unroll
                     for (int sp = 0; sp < NSPAN; ++sp) {
-                        am[rr][sp] = mma16(AH[tap], xh[rr][sp], am[rr][sp]);
-                        al[rr][sp] = mma16(AH[tap], xl[rr][sp], al[rr][sp]);
+                        if constexpr (C == 8) {
+                            const s16x4 bh = __builtin_bit_cast(s16x4, __builtin_shufflevector(xh[rr][sp], xh[rr][sp], 0, 1, 2, 3));
+                            am[rr][sp] = mma16(AH[tap], bh, am[rr][sp]);
+                            al[rr][sp] = mma32(AX8[tap], xh[rr][sp], al[rr][sp]);
+                        } else {
+                            am[rr][sp] = mm(AH[tap], xh[rr][sp], am[rr][sp]);
+                            al[rr][sp] = mm(AH[tap], xl[rr][sp], al[rr][sp]);
+                            al[rr][sp] = mm(AL[tap], xh[rr][sp], al[rr][sp]);
+                        }
                     }
-#pragma unroll
-                for (int rr = 0; rr < R; ++rr)
-#pragma unroll
-                    for (int sp = 0; sp < NSPAN; ++sp) al[rr][sp] = mma16(AL[tap], xh[rr][sp], al[rr][sp]);
 #pragma unroll
                 for (int rr = 0; rr < R; ++rr)
 #pragma unroll
@@ -533,9 +559,14 @@ __global__ __launch_bounds__(256, C == 8 ? TT_X3N_MINW8 : 3) void k_x3n_conv(con
                         split(elu1(__builtin_fmaf(al[rr][sp][r], LO_INV, am[rr][sp][r])), a_, b_);
                         hh[r] = a_; hl[r] = b_;
                     }
-                    const f32x4 zm = mma16(A2H, __builtin_bit_cast(s16x4, hh), f32x4{b2r[0], b2r[1], b2r[2], b2r[3]});
-                    f32x4 zl = mma16(A2H, __builtin_bit_cast(s16x4, hl), f32x4{0.f, 0.f, 0.f, 0.f});
-                    zl = mma16(A2L, __builtin_bit_cast(s16x4, hh), zl);
+                    const f32x4 zm = mm(A2H, __builtin_bit_cast(s16x4, hh), f32x4{b2r[0], b2r[1], b2r[2], b2r[3]});
+                    f32x4 zl;
+                    if constexpr (C == 8) {
+                        zl = mma32(A2X8, __builtin_shufflevector(hh, hl, 0, 1, 2, 3, 4, 5, 6, 7), f32x4{0.f, 0.f, 0.f, 0.f});
+                    } else {
+                        zl = mm(A2H, __builtin_bit_cast(s16x4, hl), f32x4{0.f, 0.f, 0.f, 0.f});
+                        zl = mm(A2L, __builtin_bit_cast(s16x4, hh), zl);
+                    }
                     s16x4 ch_, cl_;
                     ldpx(r0 + rr + D, col + D, ch_, cl_);
                     const e16x4 c_h = __builtin_bit_cast(e16x4, ch_), c_l = __builtin_bit_cast(e16x4, cl_);

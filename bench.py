@@ -623,14 +623,14 @@ def main():
             flops = 2.0 * 2.0 * (9 * C * C + C * C) * args.batch * 65 * M_FRAMES
             gbs = nbytes / (a_ms * 1e-3) / 1e9
             traffic, traffic_source, pmc_note = None, None, None
-            pmc = os.path.join(ROOT, 'profiles', 'r03_pmc_wrb_bwd_C32.json')       # the per-stage kernels of this call are unchanged since round 3
+            pmc = os.path.join(ROOT, 'profiles', 'r05_pmc_wrb_bwd_C32.json')       # round 5: k_wrb_dxw with the halo-free x tile
             if C == 32 and args.batch == 64 and os.path.exists(pmc):
                 pj = json.load(open(pmc))
                 traffic = pj['traffic_bytes_corrected']
                 pmc_note = pj.get('summary')
-                traffic_source = 'profiles/r03_pmc_wrb_bwd_C32.json (rocprofv3 --pmc passes of the four kernels at this shape: FETCH_SIZE x2 + WRITE_SIZE, summed; round 4 re-measured dilation 2: 2188 MB, profiles/r04_pmc_C32.txt; not re-measured in this run)'
+                traffic_source = 'profiles/r05_pmc_wrb_bwd_C32.json (rocprofv3 --pmc passes of the kernels of this call at this shape, round 5: FETCH_SIZE x2 + WRITE_SIZE, summed, mean of the three dilations; round 3 / 4: 2160-2190 MB; not re-measured in this run)'
             roof = dict(kernel='tt_wide_rb_bwd at C=%d, H=65 (ResidualConv2dBlock backward, bf16 channel-innermost storage): k_wrb_bwd_a<%d> + '
-                               'k_wrb_dxw<%d,D,8,32> (data + weight gradient in one pass) + k_wrb_reduce<%d>; the by-time dominant call of the step '
+                               'k_wrb_dxw<%d,D,8,32,false> (data + weight gradient in one pass, halo-free x tile) + k_wrb_reduce<%d>; the by-time dominant call of the step '
                                '(the one-pass strip kernel, default one level down, loses here inside the step: roofline_onepass_bwd, DESIGN.md section 7)' % (C, C, C, C),
                         bound='hbm', achieved=gbs, peak=PEAK_HBM_GBS, unit='GB/s', frac=gbs / PEAK_HBM_GBS, traffic=traffic,
                         traffic_source=traffic_source, algorithmic_bytes=nbytes, algorithmic_flops=flops,

@@ -210,6 +210,16 @@ int tt_wide_level_bwd(int nblocks, const void* const* x, const void* const* h1, 
                       const float* const* w2, const float* const* b2, void* dx, void* tmp0, void* tmp1, float* const* dw1,
                       float* const* db1, float* const* dw2, float* const* db2, void* ws, int B, int C, int H, int T,
                       const int* dilations, void* stream);
+/* The same with the gradient leaving the level ALREADY GATED for the layer in front of it: dx = (d loss / d x[0]) * ELU'(x[0]).  In the
+ * reference every residual level but the encoder's first sits behind a layer that ends in an ELU (modules.py:626-630 sconv + ELU ->
+ * the next EncoderBlock's block1; :683-693 tconv + ELU -> block1), so x[0] IS that layer's saved output and the product is the first
+ * thing its backward computes; done here, in the epilogue of the first block's data gradient where x[0] is at hand, that layer's
+ * backward (tt_sconv16_bwd_pregated / tt_tconv16_bwd_pregated below) reads one tensor less and stages nothing through registers.
+ * All other outputs as tt_wide_level_bwd. */
+int tt_wide_level_bwd_gated(int nblocks, const void* const* x, const void* const* h1, const void* dy, const float* const* w1,
+                            const float* const* w2, const float* const* b2, void* dx, void* tmp0, void* tmp1, float* const* dw1,
+                            float* const* db1, float* const* dw2, float* const* db2, void* ws, int B, int C, int H, int T,
+                            const int* dilations, void* stream);
 /* The whole backward of one block in ONE pass from x and dy only (csrc/conv_level_bf16.hip; C = 16, 32, else
  * TT_E_UNSUPPORTED): the hidden activation is recomputed per tile (bit-identical to what tt_wide_rb_fwd would have stored),
  * dL/d(conv1 pre-activation) stays in LDS -- reads x and dy, writes dx.  The forward can then run with h1 = NULL.
@@ -248,6 +258,11 @@ int tt_tconv16_fwd(const void* x, const float* w, const float* b, void* y, int B
                    void* stream);
 int tt_tconv16_bwd(const void* x, const void* y, const void* dy, const float* w, void* dx, float* dw, float* db, void* ws,
                    int B, int C, int H, int T, int out_pad, void* stream);
+/* *_bwd_pregated: the same from x and g = dy * ELU'(y) (what tt_wide_level_bwd_gated leaves): the saved output is not needed. */
+int tt_sconv16_bwd_pregated(const void* x, const void* g, const float* w, void* dx, float* dw, float* db, void* ws, int B, int C,
+                            int H, int T, void* stream);
+int tt_tconv16_bwd_pregated(const void* x, const void* g, const float* w, void* dx, float* dw, float* db, void* ws, int B, int C,
+                            int H, int T, int out_pad, void* stream);
 
 /* The (31,1) latent heads on bf16 channels-last embeddings (csrc/latent_bf16.hip; modules.py:446 Encoder.convlat and :534
  * Decoder.convin).  w is the (D', CT, E, 1) weight of either layer (index (d CT + c) E + h); (CT, D') = (32, <= 48) or (64, <= 144);
@@ -509,6 +524,14 @@ int tt_sconv16_bwd_h(const void* x, const void* y, const void* dy, const float* 
                    int B, int C, int H, int T, void* stream);
 int tt_tconv16_fwd_h(const void* x, const float* w, const float* b, void* y, int B, int C, int H, int T, int out_pad,
                    void* stream);
+int tt_sconv16_bwd_pregated_h(const void* x, const void* g, const float* w, void* dx, float* dw, float* db, void* ws, int B, int C,
+                              int H, int T, void* stream);
+int tt_tconv16_bwd_pregated_h(const void* x, const void* g, const float* w, void* dx, float* dw, float* db, void* ws, int B, int C,
+                              int H, int T, int out_pad, void* stream);
+int tt_wide_level_bwd_gated_h(int nblocks, const void* const* x, const void* const* h1, const void* dy, const float* const* w1,
+                              const float* const* w2, const float* const* b2, void* dx, void* tmp0, void* tmp1, float* const* dw1,
+                              float* const* db1, float* const* dw2, float* const* db2, void* ws, int B, int C, int H, int T,
+                              const int* dilations, void* stream);
 int tt_tconv16_bwd_h(const void* x, const void* y, const void* dy, const float* w, void* dx, float* dw, float* db, void* ws,
                    int B, int C, int H, int T, int out_pad, void* stream);
 int64_t tt_latent16_scratch_bytes_h(int B, int CT, int D, int E, int T);

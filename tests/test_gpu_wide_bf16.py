@@ -250,7 +250,7 @@ def _layer_cases():
             for i in range(3):
                 ps += [_rand(C, C, 3, 3, seed=10 + i, scale=1.0 / (3 * C ** 0.5)), _rand(C, seed=20 + i, scale=0.3),
                        _rand(C, C, 1, 1, seed=30 + i, scale=1.0 / C ** 0.5), _rand(C, seed=40 + i, scale=0.3)]
-            return (lambda x, *p: ops.Level16Fn.apply(x, (1, 2, 3), *p)), [cl(_rand(2, C, 21, 96, seed=1))], ps, cl(_rand(2, C, 21, 96, seed=2, scale=0.05))
+            return (lambda x, *p: ops.Level16Fn.apply(x, (1, 2, 3), None, *p)), [cl(_rand(2, C, 21, 96, seed=1))], ps, cl(_rand(2, C, 21, 96, seed=2, scale=0.05))
         cases.append(('level C=%d' % C, level))
 
         def sconv(C=C):
@@ -487,6 +487,18 @@ def test_sconv16_stagewise(C, shape):
     dw_ref = torch.nn.grad.conv2d_weight(xr, w.shape, g_r, stride=(2, 1))
     assert _rel(dw.cpu().double() - 0.25, dw_ref) < 2e-4, 'dw'
     assert _rel(db.cpu().double() - 0.25, g.sum((0, 2, 3))) < 2e-3, 'db'
+    # the same from the gradient already gated (what tt_wide_level_bwd_gated leaves): y is not an argument; with and without dx
+    gpre = _cl16(g.float())
+    g_p = _f64(gpre)
+    for with_dx in (True, False):
+        dx2 = ops.new_cl16(B, C, H, T, 'cuda', ELT)
+        dw2, db2 = torch.full((2 * C, C, 4, 1), 0.25, device='cuda'), torch.full((2 * C,), 0.25, device='cuda')
+        check(lib.tt_sconv16_bwd_pregated(ptr(xb), ptr(gpre), ptr(wd), ptr(dx2) if with_dx else None, ptr(dw2), ptr(db2), ptr(ws), B, C, H, T, st),
+              'bwd pregated')
+        if with_dx:
+            _close16(_f64(dx2), F.conv_transpose2d(g_p, wr, stride=(2, 1), output_padding=(H - (2 * Ho + 2), 0)), 'dx pregated')
+        assert _rel(dw2.cpu().double() - 0.25, torch.nn.grad.conv2d_weight(xr, w.shape, g_p, stride=(2, 1))) < 2e-4, 'dw pregated'
+        assert _rel(db2.cpu().double() - 0.25, g_p.sum((0, 2, 3))) < 2e-4, 'db pregated'
 
 
 @pytest.mark.parametrize('C', [4, 8, 16, 32])
@@ -519,6 +531,73 @@ def test_tconv16_stagewise(C, shape, out_pad):
     dw_ref = torch.nn.grad.conv2d_weight(g_r, w.shape, xr, stride=(2, 1))
     assert _rel(dw.cpu().double() - 0.25, dw_ref) < 2e-4, 'dw'
     assert _rel(db.cpu().double() - 0.25, g.sum((0, 2, 3))) < 2e-3, 'db'
+    # the same from the gradient already gated (what tt_wide_level_bwd_gated leaves): y is not an argument; with and without dx
+    gpre = _cl16(g.float())
+    g_p = _f64(gpre)
+    for with_dx in (True, False):
+        dx2 = ops.new_cl16(B, 2 * C, H, T, 'cuda', ELT)
+        dw2, db2 = torch.full((2 * C, C, 4, 1), 0.25, device='cuda'), torch.full((C,), 0.25, device='cuda')
+        check(lib.tt_tconv16_bwd_pregated(ptr(xb), ptr(gpre), ptr(wd), ptr(dx2) if with_dx else None, ptr(dw2), ptr(db2), ptr(ws), B, C, H, T,
+                                          out_pad, st), 'bwd pregated')
+        if with_dx:
+            _close16(_f64(dx2), F.conv2d(g_p, wr, stride=(2, 1)), 'dx pregated')
+        assert _rel(dw2.cpu().double() - 0.25, torch.nn.grad.conv2d_weight(g_p, w.shape, xr, stride=(2, 1))) < 2e-4, 'dw pregated'
+        assert _rel(db2.cpu().double() - 0.25, g_p.sum((0, 2, 3))) < 2e-4, 'db pregated'
+
+
+@pytest.mark.parametrize('C', [4, 8, 16, 32])
+@pytest.mark.parametrize('kind', ['tconv', 'sconv'])
+@pytest.mark.parametrize('dilations', [(1, 2, 3), (2, 1)])
+def test_level_hands_the_layer_in_front_its_gradient_already_gated(C, kind, dilations, monkeypatch):
+    """(transposed / strided layer + ELU) -> residual level, with and without ops.GateLink: the level's own parameter gradients are
+    bit-identical (nothing about them changes), the gradient the level hands back equals the ungated one times ELU'(y) to one 16-bit
+    rounding, and the layer's dx / dw / db agree with the unlinked path to 16-bit rounding of the gated operand (rounded once instead of
+    twice).  Dilations (2, 1): the first block has no gated kernel -- the library gates in a pass of its own."""
+    from timbre_trap.framework import ops
+    B, T = 2, 96
+    nb = len(dilations)
+    params = []
+    for i in range(nb):
+        params += [_rand(C, C, 3, 3, seed=10 + i, scale=1.0 / (3 * C ** 0.5)), _rand(C, seed=20 + i, scale=0.2),
+                   _rand(C, C, 1, 1, seed=30 + i, scale=1.0 / C ** 0.5), _rand(C, seed=40 + i, scale=0.2)]
+    if kind == 'tconv':
+        x0 = _rand(B, 2 * C, 7, T, seed=1)
+        w, b = _rand(2 * C, C, 4, 1, seed=3, scale=1.0 / (2 * C ** 0.5)), _rand(C, seed=4, scale=0.3)
+    else:
+        if C == 4:
+            pytest.skip('no 2 -> 4 strided layer in the network')
+        x0 = _rand(B, C // 2, 37, T, seed=1)
+        w, b = _rand(C, C // 2, 4, 1, seed=3, scale=1.0 / C ** 0.5), _rand(C, seed=4, scale=0.3)
+
+    def run(linked):
+        monkeypatch.setattr(ops, 'PREGATE', linked)
+        xs = _cl16(x0).requires_grad_(True)
+        ps = [p.cuda().requires_grad_(True) for p in [w, b] + params]
+        link = ops.gate_link()
+        assert (link is not None) == linked
+        if kind == 'tconv':
+            y = ops.TConv16Fn.apply(xs, ps[0], ps[1], 1, link)
+        else:
+            y = ops.SConv16Fn.apply(xs, ps[0], ps[1], link)
+        seen = []
+        y.register_hook(lambda g_: seen.append(g_.detach().clone()))
+        out = ops.Level16Fn.apply(y, tuple(dilations), link, *ps[2:])
+        gout = _cl16(_rand(*out.shape, seed=7, scale=0.05))
+        out.backward(gout)
+        torch.cuda.synchronize()
+        return y.detach(), seen[0], xs.grad, [p.grad for p in ps]
+
+    y0, gy0, dx0, g0 = run(False)
+    y1, gy1, dx1, g1 = run(True)
+    assert torch.equal(y0, y1)
+    for a, c in zip(g0[2:], g1[2:]):                              # the level's own gradients: the same kernels' sums (run-to-run: a few fp32
+        assert _rel(a.cpu().double(), c.cpu().double()) < 2e-5    # atomics at the narrow levels, DESIGN.md "Reproducibility")
+    want = (_f64(gy0) * _gate(_f64(y0)))
+    tol = 2 * BF16_REL                                           # two roundings: the ungated run's dx, this run's product
+    assert float((_f64(gy1) - want).abs().max()) <= tol * float(want.abs().max()) + 1e-12
+    assert _rel(_f64(dx1), _f64(dx0)) < (8e-3 if ELT == torch.bfloat16 else 1e-3)
+    assert _rel(g1[0].cpu().double(), g0[0].cpu().double()) < (4e-3 if ELT == torch.bfloat16 else 5e-4)
+    assert _rel(g1[1].cpu().double(), g0[1].cpu().double()) < (6e-3 if ELT == torch.bfloat16 else 8e-4)   # db: sums of rounded vs unrounded products
 
 
 @pytest.mark.parametrize('skip', [False, True])

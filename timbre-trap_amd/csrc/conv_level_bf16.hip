@@ -466,7 +466,9 @@ __device__ __forceinline__ void conv_taps_ring(const unsigned char* img, const i
     }
 }
 
-template <int C, int D, int TH, int TW, int MINW>
+// GOUT: dx leaves as dx * ELU'(x) for the layer in front of the level (k_nrb_bwd_fused, conv_wide_bf16.hip); the x rows of the step are
+// still on their way into LDS at that point, so the lane's channels of x come from memory like its dy (the same lines the DMA is fetching).
+template <int C, int D, int TH, int TW, int MINW, bool GOUT = false>
 __global__ __launch_bounds__(NT, MINW) void k_wrb_bwds(const e16* __restrict__ x, const e16* __restrict__ h1, const e16* __restrict__ dy,
                                                      const e16x8* __restrict__ wimg, const float* __restrict__ b2, e16* __restrict__ dx,
                                                      float* __restrict__ part_a, float* __restrict__ part_w, int B, int H, int T,
@@ -684,6 +686,8 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_bwds(const e16* __restrict__ x
                     const bool valid = t < T;
                     const long pix = ((long)b * H + h) * T + t;
                     const e16x4 rq = *reinterpret_cast<const e16x4*>(dy + (valid ? pix : pix - (t - (T - 1))) * C + 8 * g + 4 * ctd);
+                    e16x4 xg;
+                    if constexpr (GOUT) xg = *reinterpret_cast<const e16x4*>(x + (valid ? pix : pix - (t - (T - 1))) * C + 8 * g + 4 * ctd);
                     const int ro[3] = {slot(h - D) * G::ROWB, slot(h) * G::ROWB, slot(h + D) * G::ROWB};
                     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -695,7 +699,7 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_bwds(const e16* __restrict__ x
                     }
                     e16x4 o;
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) o[jj] = (e16)(acc[jj] + (float)rq[jj]);
+                    for (int jj = 0; jj < 4; ++jj) o[jj] = GOUT ? (e16)((acc[jj] + (float)rq[jj]) * elu_dout((float)xg[jj])) : (e16)(acc[jj] + (float)rq[jj]);
                     if (valid) *reinterpret_cast<e16x4*>(dx + pix * C + 8 * g + 4 * ctd) = o;
                 }
             } else {
@@ -714,6 +718,8 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_bwds(const e16* __restrict__ x
                     const long pix = ((long)b * H + h) * T + t;
                     // unconditional (clamped) so that no branch pins a wait in front of the products
                     const vec_t rq = *reinterpret_cast<const vec_t*>(dy + (valid ? pix : pix - (t - (T - 1))) * C + NCH * g);
+                    vec_t xg;
+                    if constexpr (GOUT) xg = *reinterpret_cast<const vec_t*>(x + (valid ? pix : pix - (t - (T - 1))) * C + NCH * g);
                     const int ro[3] = {slot(h - D) * G::ROWB, slot(h) * G::ROWB, slot(h + D) * G::ROWB};
                     f32x4 acc[NCT];
 #pragma unroll
@@ -721,7 +727,8 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_bwds(const e16* __restrict__ x
                     conv_taps_ring<C, D, GW>(ring, ro, c, g, A, acc);
                     vec_t o;
 #pragma unroll
-                    for (int jj = 0; jj < NCH; ++jj) o[jj] = (e16)(acc[jj >> 2][jj & 3] + (float)rq[jj]);
+                    for (int jj = 0; jj < NCH; ++jj)
+                        o[jj] = GOUT ? (e16)((acc[jj >> 2][jj & 3] + (float)rq[jj]) * elu_dout((float)xg[jj])) : (e16)(acc[jj >> 2][jj & 3] + (float)rq[jj]);
                     if (valid) *reinterpret_cast<vec_t*>(dx + pix * C + NCH * g) = o;
                 }
             }
@@ -826,15 +833,27 @@ int launch_bwds(const e16* x, const e16* h1, const e16* dy, const float* w1, con
         hipLaunchKernelGGL(k_lvl_wprep<C>, dim3(K::NK * K::NCT + 1, 1), dim3(64), 0, st, wp1);
         TT_LAUNCH_CHECK();
     }
-    static AttrOnce once;
     constexpr int MINW = C == 32 ? 3 : 4;
-    auto kern = k_wrb_bwds<C, D, TH, TW, MINW>;
-    if (int rc = raise_lds(kern, G::LDS_BYTES, once)) return rc;
     const int tiles_t = (T + TW - 1) / TW, nstrips = B * tiles_t;
     static const int per_cu = tt_tune("TTRAP_BWDS_PER_CU", MINW);
     int grid = grid_for(nstrips, G::LDS_BYTES, per_cu);
     if (grid > MAX_W_WG) grid = MAX_W_WG;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), G::LDS_BYTES, st, x, h1, dy, wimg, b2, dx, part_a, part_w, B, H, T, tiles_t, nstrips);
+    bool gated = false;
+    if constexpr (D == 1) gated = ttx_gate_dx == 1;              // a level's first block: dx leaves gated
+    if (gated) {
+        if constexpr (D == 1) {
+            static AttrOnce once_g;
+            auto kg = k_wrb_bwds<C, D, TH, TW, MINW, true>;
+            if (int rc = raise_lds(kg, G::LDS_BYTES, once_g)) return rc;
+            hipLaunchKernelGGL(kg, dim3(grid), dim3(NT), G::LDS_BYTES, st, x, h1, dy, wimg, b2, dx, part_a, part_w, B, H, T, tiles_t, nstrips);
+            ttx_gate_dx = 2;
+        }
+    } else {
+        static AttrOnce once;
+        auto kern = k_wrb_bwds<C, D, TH, TW, MINW, false>;
+        if (int rc = raise_lds(kern, G::LDS_BYTES, once)) return rc;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), G::LDS_BYTES, st, x, h1, dy, wimg, b2, dx, part_a, part_w, B, H, T, tiles_t, nstrips);
+    }
     TT_LAUNCH_CHECK();
     RedArgs ra{part_w, grid, part_a, grid, dw1, db1, dw2, db2, C == 32 ? 1 : 0, C == 32 ? 0 : 1};
     constexpr int total = 9 * C * C + C * C + 2 * C;

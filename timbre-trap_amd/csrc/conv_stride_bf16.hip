@@ -542,7 +542,11 @@ template <int PB> __device__ __forceinline__ const unsigned char* px_piece(const
     return img + (long)q * PB + ch0 * 2;
 }
 
-template <int C, bool GS, bool DX>
+// PRE (round 5): the gated operand arrives ALREADY gated -- the backward of the residual level behind this layer left dx * ELU'(x), and its
+// x is this layer's output (tt_wide_level_bwd_gated) -- so the saved output is not read at all (one tensor pass less per layer backward),
+// both operands come in by LDS-DMA (nothing is staged through registers: no dependent load -> gate -> write batches), and the bias
+// gradient, which the register staging summed on the side, is one more matrix product per visit of a gated pixel group: ones (x) operand.
+template <int C, bool GS, bool DX, bool PRE = false>
 __global__ __launch_bounds__(NT, C == 32 ? ((!DX && GS) ? 3 : 2) : W4_WAVES16) void k_w4(const e16* __restrict__ small, const e16* __restrict__ big,
                                             const e16* __restrict__ ygate, float* __restrict__ part, float* __restrict__ dbpart,
                                             const float* __restrict__ w, e16* __restrict__ dx,
@@ -552,7 +556,9 @@ __global__ __launch_bounds__(NT, C == 32 ? ((!DX && GS) ? 3 : 2) : W4_WAVES16) v
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char* ss = smem;
     unsigned char* bs = smem + ((DX && GS) ? G::SX_BYTES : G::S_BYTES);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // PRE: the wave index on the scalar unit -- the bias-gradient products are taken by one wave each, and with a vector `wave` the compiler
+    // predicates them through EXEC (which matrix instructions ignore) and merges the accumulators with masked moves: wrong sums, measured
+    const int tid = threadIdx.x, lane = tid & 63, wave = PRE ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
     const int n = lane & 15, g = lane >> 4, trj = n >> 2, trq = n & 3;
     constexpr bool SPLIT = C == 32;                              // accumulators split over the waves by small-side tile (NA = 4 = waves)
     constexpr int NAW = SPLIT ? 1 : G::NA;
@@ -565,6 +571,16 @@ __global__ __launch_bounds__(NT, C == 32 ? ((!DX && GS) ? 3 : 2) : W4_WAVES16) v
 #pragma unroll
             for (int c = 0; c < G::NBT; ++c) acc[k][a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     float dbacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // PRE: bias-gradient accumulators, one per 16-channel tile of the gated operand this wave visits
+    // (GS = false: ONE per wave -- C <= 16 has one big-side tile; C = 32: wave w owns tile w & 1 and the rows of parity w >> 1)
+    static_assert(!(PRE && !GS) || SPLIT || G::NBT == 1, "one big-side tile per wave");
+    constexpr int NDB = (PRE && GS) ? NAW : 1;
+    f32x4 dbm[NDB];
+#pragma unroll
+    for (int i = 0; i < NDB; ++i) dbm[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    e16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (e16)1.f;
     // data-gradient weights in registers (the A operands of k_s4 / k_p2)
     using S = S4<C>;
     using P = P2<C>;
@@ -602,7 +618,10 @@ __global__ __launch_bounds__(NT, C == 32 ? ((!DX && GS) ? 3 : 2) : W4_WAVES16) v
         const e16* sb = small + (long)b * Hs * T * (2 * C);
         const e16* bb = big + (long)b * Hb * T * C;
         __syncthreads();
-        if constexpr (GS) {
+        if constexpr (PRE) {
+            stage_tile<G::BB, G::BROWS, false>(bs, bb, nullptr, 2 * r0, Hb, t0, T, tid, dbacc, 0);
+            stage_tile<G::SB, G::TR + SROW0, false>(ss, sb, nullptr, r0 - SROW0, Hs, t0, T, tid, dbacc, 0);
+        } else if constexpr (GS) {
             stage_tile<G::BB, G::BROWS, false>(bs, bb, nullptr, 2 * r0, Hb, t0, T, tid, dbacc, 0);
             stage_tile<G::SB, G::TR + SROW0, true, SBATCH>(ss, sb, ygate + (long)b * Hs * T * (2 * C), r0 - SROW0, Hs, t0, T, tid, dbacc,
                                                            G::TR + SROW0, SROW0);
@@ -692,6 +711,7 @@ __global__ __launch_bounds__(NT, C == 32 ? ((!DX && GS) ? 3 : 2) : W4_WAVES16) v
                         h2[u] = lds_tr16(ss + (long)p * G::SB + tr_off<G::SB>(p, SPLIT ? wave : a, trq));
                     }
                     sa[a] = __builtin_bit_cast(e16x8, __builtin_shufflevector(h2[0], h2[1], 0, 1, 2, 3, 4, 5, 6, 7));
+                    if constexpr (PRE && GS) dbm[a] = mma32(sa[a], ones, dbm[a]);      // every small pixel is visited once, by one wave per tile a
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
@@ -706,7 +726,34 @@ __global__ __launch_bounds__(NT, C == 32 ? ((!DX && GS) ? 3 : 2) : W4_WAVES16) v
                         const e16x8 bq = __builtin_bit_cast(e16x8, __builtin_shufflevector(h2[0], h2[1], 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
                         for (int a = 0; a < NAW; ++a) acc[k][a][c] = mma32(sa[a], bq, acc[k][a][c]);
+                        if constexpr (PRE && !GS) {
+                            // big rows 2 r + k, k = 0, 1 meet every big row of the tile once; SPLIT: all four waves read the same pixels,
+                            // wave (k, c) takes the product
+                            if (k < 2 && (!SPLIT || (k == (wave >> 1) && c == (wave & 1)))) dbm[0] = mma32(ones, bq, dbm[0]);
+                        }
                     }
+            }
+        }
+        if constexpr (PRE && !GS) {
+            // the big rows behind the last row pair the loop above visited: the two rows only taps 2, 3 of the last small row reach and the
+            // output_padding row -- in the last tile of the column only (elsewhere they are the next tile's first rows)
+            if (th == tiles_h - 1) {
+                const int nvalid = Hs - r0 < G::TR ? Hs - r0 : G::TR;
+                // C = 32: tile c = wave & 1, the (row, column half) pairs alternate between the two waves of a tile; else the four waves
+                // share the pairs of the one tile
+                const int c = SPLIT ? (wave & 1) : 0;
+                const int nx = (G::BROWS - 2 * nvalid) * 2;
+                for (int i = SPLIT ? (wave >> 1) : wave; i < nx; i += SPLIT ? 2 : 4) {
+                    const int colh = i & 1, row = 2 * nvalid + (i >> 1);
+                    s16x4 h2[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int p = row * G::TW + colh * 32 + 16 * u + 4 * g + trj;
+                        h2[u] = lds_tr16(bs + (long)p * G::BB + tr_off<G::BB>(p, c, trq));
+                    }
+                    const e16x8 bq = __builtin_bit_cast(e16x8, __builtin_shufflevector(h2[0], h2[1], 0, 1, 2, 3, 4, 5, 6, 7));
+                    dbm[0] = mma32(ones, bq, dbm[0]);
+                }
             }
         }
     }
@@ -748,6 +795,22 @@ __global__ __launch_bounds__(NT, C == 32 ? ((!DX && GS) ? 3 : 2) : W4_WAVES16) v
     constexpr int CGn = GB >= 16 ? GB / 16 : 1, PPP = GB >= 16 ? 1 : 16 / GB;
     __syncthreads();
     float* dl = reinterpret_cast<float*>(smem);
+    if constexpr (PRE) {
+        // a wave's share of channel ch sits in tile ch / 16: GS = false (A = ones): every row of D is the column sum -- row 0, lanes g == 0;
+        // GS = true (B = ones): every column is the row sum -- column 0, lanes n == 0
+        constexpr int NTL = GS ? G::NA : G::NBT;
+        for (int i = tid; i < 4 * NTL * 16; i += NT) dl[i] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NDB; ++i) {
+            const int tl = SPLIT ? (GS ? wave : (wave & 1)) : i;
+            if (GS) { if (n == 0) for (int r = 0; r < 4; ++r) dl[(wave * NTL + tl) * 16 + 4 * g + r] = dbm[i][r]; }
+            else { if (g == 0) dl[(wave * NTL + tl) * 16 + n] = dbm[i][0]; }
+        }
+        __syncthreads();
+        if (tid < GC) dbpart[(long)blockIdx.x * 64 + tid] = (dl[tid] + dl[NTL * 16 + tid]) + (dl[2 * NTL * 16 + tid] + dl[3 * NTL * 16 + tid]);
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) dl[tid * 8 + j] = dbacc[j];
     __syncthreads();
@@ -863,13 +926,13 @@ template <int C> inline bool w4x_enabled() {
     return on && C <= 32;
 }
 
-template <int C, bool GS, bool DX>
+template <int C, bool GS, bool DX, bool PRE = false>
 int launch_w4(const e16* small, const e16* big, const e16* ygate, float* dw, float* db, float* ws, const float* w, e16* dx,
               int B, int Hs, int Hb, int T, hipStream_t st) {
     using G = W4<C>;
     constexpr int LDS = ((DX && GS) ? G::SX_BYTES : G::S_BYTES) + G::B_BYTES;
     static AttrOnce once;
-    auto kern = k_w4<C, GS, DX>;
+    auto kern = k_w4<C, GS, DX, PRE>;
     if (int rc = raise_lds(kern, LDS, once)) return rc;
     const int tiles_h = (Hs + G::TR - 1) / G::TR, tiles_t = (T + G::TW - 1) / G::TW, ntiles = B * tiles_h * tiles_t;
     int gw = grid_for(ntiles, LDS, 3);
@@ -978,6 +1041,26 @@ int tt_tconv16_bwd(const void* x, const void* y, const void* dy, const float* w,
         if (rc) return rc;
     }
     TT_BY_C(C, (launch_w4<CC, false, false>((const e16*)x, (const e16*)dy, (const e16*)y, dw, db, (float*)ws, nullptr, nullptr, B, H, Ho, T, st)));
+}
+
+// The same two backward passes with dy ALREADY gated (g = dy * ELU'(y), as tt_wide_level_bwd_gated leaves it): y is not read.
+int tt_sconv16_bwd_pregated(const void* x, const void* g, const float* w, void* dx, float* dw, float* db, void* ws, int B, int C, int H,
+                            int T, void* stream) {
+    if (!x || !g || !w || !dw || !db || !ws || !ok_shape(B, C, H, T)) return TT_E_BADARG;
+    const int Ho = (H - 4) / 2 + 1;
+    hipStream_t st = tt_stream(stream);
+    if (dx) { TT_BY_C(C, (launch_w4<CC, true, true, true>((const e16*)g, (const e16*)x, nullptr, dw, db, (float*)ws, w, (e16*)dx, B, Ho, H, T, st))); }
+    TT_BY_C(C, (launch_w4<CC, true, false, true>((const e16*)g, (const e16*)x, nullptr, dw, db, (float*)ws, nullptr, nullptr, B, Ho, H, T, st)));
+}
+
+int tt_tconv16_bwd_pregated(const void* x, const void* g, const float* w, void* dx, float* dw, float* db, void* ws, int B, int C, int H,
+                            int T, int out_pad, void* stream) {
+    if (!x || !g || !w || !dw || !db || !ws || B <= 0 || H <= 0 || T <= 0 || out_pad < 0 || out_pad > 1) return TT_E_BADARG;
+    const int Ho = 2 * H + 2 + out_pad;
+    if (!ok_shape(B, C, Ho, T)) return TT_E_BADARG;
+    hipStream_t st = tt_stream(stream);
+    if (dx) { TT_BY_C(C, (launch_w4<CC, false, true, true>((const e16*)x, (const e16*)g, nullptr, dw, db, (float*)ws, w, (e16*)dx, B, H, Ho, T, st))); }
+    TT_BY_C(C, (launch_w4<CC, false, false, true>((const e16*)x, (const e16*)g, nullptr, dw, db, (float*)ws, nullptr, nullptr, B, H, Ho, T, st)));
 }
 
 }  // extern "C"

@@ -561,7 +561,7 @@ template <int C, int D, int TH, int TW, bool XH> struct DXW {
     static_assert(TW % 32 == 0, "the K = 32 pixels of a weight-gradient product are 32 consecutive columns");
 };
 
-template <int C, int D, int TH, int TW, bool XH>
+template <int C, int D, int TH, int TW, bool XH, bool GOUT = false>
 __global__ __launch_bounds__(NT, 2) void k_wrb_dxw(const e16* __restrict__ x, const e16* __restrict__ da1, const e16* __restrict__ dy,
                                                    const float* __restrict__ w1, e16* __restrict__ dx, float* __restrict__ part_w, int B,
                                                    int H, int T, int tiles_h, int tiles_t, int ntiles) {
@@ -649,8 +649,17 @@ __global__ __launch_bounds__(NT, 2) void k_wrb_dxw(const e16* __restrict__ x, co
             e16x8 unused;
             conv_taps<C, D, G::IW>(gs, r, c, g, A, acc, unused);
             vec_t o;
+            if constexpr (GOUT) {
+                // dx * ELU'(x) for the layer in front of the level (see k_nrb_bwd_fused): the lane's channels of x from the halo-free image
+                static_assert(!GOUT || !XH, "the gated form reads the halo-free x image");
+                const vec_t xq = *reinterpret_cast<const vec_t*>(xs + (r * TW + c) * PB + 16 * ((C == 32 ? g : (g >> 1)) ^ fswz<C>(c)) +
+                                                                 (C == 32 ? 0 : 8 * (g & 1)));
 #pragma unroll
-            for (int j = 0; j < NCH; ++j) o[j] = (e16)(acc[j >> 2][j & 3] + (float)rq[j]);
+                for (int j = 0; j < NCH; ++j) o[j] = (e16)((acc[j >> 2][j & 3] + (float)rq[j]) * elu_dout((float)xq[j]));
+            } else {
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) o[j] = (e16)(acc[j >> 2][j & 3] + (float)rq[j]);
+            }
             if (valid) *reinterpret_cast<vec_t*>(dx + pix * C + NCH * g) = o;
         }
 
@@ -763,14 +772,26 @@ template <int C, int D, int TH, int TW, bool XH>
 int launch_dxw(const e16* x, const e16* da1, const e16* dy, const float* w1, e16* dx, float* part_w, float* part_a, int grid_a,
                float* dw1, float* db1, float* dw2, float* db2, int B, int H, int T, hipStream_t st) {
     using X = DXW<C, D, TH, TW, XH>;
-    static AttrOnce once_x;
-    auto kx = k_wrb_dxw<C, D, TH, TW, XH>;
-    if (int rc = raise_lds(kx, X::LDS_BYTES, once_x)) return rc;
     const int tiles_h = (H + TH - 1) / TH, tiles_t = (T + TW - 1) / TW, ntiles = B * tiles_h * tiles_t;
     static const int x_per_cu = tt_tune("TTRAP_DXW_PER_CU", C == 32 ? 3 : 4);      // registers: 165 / 113 VGPRs
     int gx = grid_for(ntiles, X::LDS_BYTES, x_per_cu);
     if (gx > MAX_W_WG) gx = MAX_W_WG;
-    hipLaunchKernelGGL(kx, dim3(gx), dim3(NT), X::LDS_BYTES, st, x, da1, dy, w1, dx, part_w, B, H, T, tiles_h, tiles_t, ntiles);
+    bool gated = false;
+    if constexpr (D == 1 && !XH) gated = ttx_gate_dx == 1;       // a level's first block: dx leaves gated (k_nrb_bwd_fused, GOUT)
+    if (gated) {
+        if constexpr (D == 1 && !XH) {
+            static AttrOnce once_g;
+            auto kg = k_wrb_dxw<C, D, TH, TW, XH, true>;
+            if (int rc = raise_lds(kg, X::LDS_BYTES, once_g)) return rc;
+            hipLaunchKernelGGL(kg, dim3(gx), dim3(NT), X::LDS_BYTES, st, x, da1, dy, w1, dx, part_w, B, H, T, tiles_h, tiles_t, ntiles);
+            ttx_gate_dx = 2;
+        }
+    } else {
+        static AttrOnce once_x;
+        auto kx = k_wrb_dxw<C, D, TH, TW, XH, false>;
+        if (int rc = raise_lds(kx, X::LDS_BYTES, once_x)) return rc;
+        hipLaunchKernelGGL(kx, dim3(gx), dim3(NT), X::LDS_BYTES, st, x, da1, dy, w1, dx, part_w, B, H, T, tiles_h, tiles_t, ntiles);
+    }
     TT_LAUNCH_CHECK();
     RedArgs ra{part_w, gx, part_a, grid_a, dw1, db1, dw2, db2, C == 32 ? 1 : 0, C == 32 ? 0 : 1};
     constexpr int total = 9 * C * C + C * C + 2 * C;
@@ -1228,7 +1249,10 @@ __global__ __launch_bounds__(NT) void k_nrb_wgrad(const e16* __restrict__ x, con
 #ifndef TT_NBF2_MINW4
 #define TT_NBF2_MINW4 4          // C = 4: registers capped for four workgroups per CU (the LDS limit); 1 lets the compiler take 156 (three)
 #endif
-template <int C, int D>
+// GOUT: the block is the first of its level and the layer in front of it ends in an ELU whose output IS this block's x (the transposed /
+// strided layer of a DecoderBlock / EncoderBlock): dx leaves as dx * ELU'(x) -- the gated gradient that layer's backward needs, so that it
+// reads neither its saved output nor stages anything through registers (tt_wide_level_bwd_gated, conv_stride_bf16.hip).
+template <int C, int D, bool GOUT>
 __global__ __launch_bounds__(NT, C == 8 ? 2 : TT_NBF2_MINW4) void k_nrb_bwd_fused(const e16* __restrict__ x, const e16* __restrict__ h1,
                                                        const e16* __restrict__ dy, const float* __restrict__ w1,
                                                        const float* __restrict__ w2, const float* __restrict__ b2,
@@ -1449,8 +1473,14 @@ __global__ __launch_bounds__(NT, C == 8 ? 2 : TT_NBF2_MINW4) void k_nrb_bwd_fuse
                 }
                 const vec_t rq = *reinterpret_cast<const vec_t*>(gs + (long)((r + D) * G::RW + G::DP + lane) * G::PXB);
                 vec_t o;
+                if constexpr (GOUT) {
+                    const vec_t xq = *reinterpret_cast<const vec_t*>(xs + (long)r * XROWB + lane * G::PXB);
 #pragma unroll
-                for (int c = 0; c < C; ++c) o[c] = (e16)(a4[c >> 2][c & 3] + (float)rq[c]);
+                    for (int c = 0; c < C; ++c) o[c] = (e16)((a4[c >> 2][c & 3] + (float)rq[c]) * elu_dout((float)xq[c]));
+                } else {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) o[c] = (e16)(a4[c >> 2][c & 3] + (float)rq[c]);
+                }
                 if (t < T) *reinterpret_cast<vec_t*>(dx + ib + ((long)h * T + t) * C) = o;
             }
         }
@@ -1707,13 +1737,25 @@ int launch_nbwd(const e16* x, const e16* h1, const e16* dy, const float* w1, con
         using F = NTl<C, D>;
         constexpr int LAYOUT = 2 * ((F::NP * 16 + 63) / 64 * 64) + F::TH * F::TW * F::PXB + 11 * (C / 4) * (C / 4) * 32 + 4 * 64 * F::PXB;
         constexpr int LDS = LAYOUT > 4 * 2304 * 4 ? LAYOUT : 4 * 2304 * 4;       // the epilogue sums the four waves' dW1 accumulators through LDS
-        static AttrOnce once_f;
-        auto kf = k_nrb_bwd_fused<C, D>;
-        if (int rc = raise_lds(kf, LDS, once_f)) return rc;
         const int tiles_h = (H + F::TH - 1) / F::TH, tiles_t = (T + F::TW - 1) / F::TW, ntiles = B * tiles_h * tiles_t;
         int gf = grid_for(ntiles, LDS, 4);
         if (gf > MAX_W_WG) gf = MAX_W_WG;
-        hipLaunchKernelGGL(kf, dim3(gf), dim3(NT), LDS, st, x, h1, dy, w1, w2, b2, dx, part_a, part_w, B, H, T, tiles_h, tiles_t, ntiles);
+        bool gated = false;
+        if constexpr (D == 1) gated = ttx_gate_dx == 1;          // a level's first block (the reference's levels start at dilation 1)
+        if (gated) {
+            if constexpr (D == 1) {
+                static AttrOnce once_g;
+                auto kg = k_nrb_bwd_fused<C, D, true>;
+                if (int rc = raise_lds(kg, LDS, once_g)) return rc;
+                hipLaunchKernelGGL(kg, dim3(gf), dim3(NT), LDS, st, x, h1, dy, w1, w2, b2, dx, part_a, part_w, B, H, T, tiles_h, tiles_t, ntiles);
+                ttx_gate_dx = 2;
+            }
+        } else {
+            static AttrOnce once_f;
+            auto kf = k_nrb_bwd_fused<C, D, false>;
+            if (int rc = raise_lds(kf, LDS, once_f)) return rc;
+            hipLaunchKernelGGL(kf, dim3(gf), dim3(NT), LDS, st, x, h1, dy, w1, w2, b2, dx, part_a, part_w, B, H, T, tiles_h, tiles_t, ntiles);
+        }
         TT_LAUNCH_CHECK();
         RedArgs ra{part_w, gf, part_a, gf, dw1, db1, dw2, db2, 0, 1};
         constexpr int total = 9 * 256 + C * C + 2 * C;
@@ -1789,10 +1831,23 @@ inline bool shape_ok(int B, int C, int H, int T) {
            (long)H * T * C < (1l << 31);
 }
 
+// dx *= ELU'(x) in place, 8 elements per thread step: what tt_wide_level_bwd_gated runs behind a first block whose backward kernel has no
+// gated form (a dilation other than 1, the A/B paths behind TTRAP_DXW / TTRAP_NARROW_FUSED16 / TTRAP_WBWD1)
+__global__ __launch_bounds__(256) void k_gate_dx(e16* __restrict__ dx, const e16* __restrict__ x, long n8) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        e16x8 d = reinterpret_cast<const e16x8*>(dx)[i];
+        const e16x8 v = reinterpret_cast<const e16x8*>(x)[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d[j] = (e16)((float)d[j] * elu_dout((float)v[j]));
+        reinterpret_cast<e16x8*>(dx)[i] = d;
+    }
+}
+
 }  // namespace
 
 thread_local void* ttx_red_defer = nullptr;
 thread_local bool ttx_wprep_done = false;
+thread_local int ttx_gate_dx = 0;             // 1: the next block backward should leave dx * ELU'(x); 2: its kernel did (wide_common.h)
 
 extern "C" {
 
@@ -1875,10 +1930,10 @@ int64_t tt_wide_level_scratch_bytes(int nblocks, int B, int C, int H, int T) {
     return one < 0 || nblocks < 1 || nblocks > 4 ? -1 : (int64_t)nblocks * ((one + 255) / 256 * 256);
 }
 
-int tt_wide_level_bwd(int nblocks, const void* const* x, const void* const* h1, const void* dy, const float* const* w1,
-                      const float* const* w2, const float* const* b2, void* dx, void* tmp0, void* tmp1, float* const* dw1,
-                      float* const* db1, float* const* dw2, float* const* db2, void* ws, int B, int C, int H, int T,
-                      const int* dilations, void* stream) {
+static int level_bwd(int gate, int nblocks, const void* const* x, const void* const* h1, const void* dy, const float* const* w1,
+                     const float* const* w2, const float* const* b2, void* dx, void* tmp0, void* tmp1, float* const* dw1,
+                     float* const* db1, float* const* dw2, float* const* db2, void* ws, int B, int C, int H, int T,
+                     const int* dilations, void* stream) {
     if (nblocks < 1 || nblocks > 4 || !x || !h1 || !dy || !w1 || !w2 || !b2 || !dx || !dw1 || !db1 || !dw2 || !db2 || !ws || !dilations ||
         (nblocks > 1 && (!tmp0 || !tmp1)) || !shape_ok(B, C, H, T))
         return TT_E_BADARG;
@@ -1902,14 +1957,23 @@ int tt_wide_level_bwd(int nblocks, const void* const* x, const void* const* h1, 
     const void* g = dy;
     for (int i = nblocks - 1; i >= 0 && !rc; --i) {
         void* gx = i == 0 ? dx : ((i & 1) ? tmp1 : tmp0);
+        ttx_gate_dx = (i == 0 && gate) ? 1 : 0;
         rc = tt_wide_rb_bwd(x[i], h1[i], g, w1[i], w2[i], b2[i], gx, dw1[i], db1[i], dw2[i], db2[i], (unsigned char*)ws + (int64_t)i * one, B, C, H, T,
                             dilations[i], stream);
         g = gx;
     }
+    const bool gate_left = ttx_gate_dx == 1;                    // asked for and not done by the first block's kernel
+    ttx_gate_dx = 0;
     ttx_red_defer = nullptr;
     ttx_wprep_done = false;
     if (rc) return rc;
     hipStream_t st = tt_stream(stream);
+    if (gate_left) {
+        const long n8 = (long)B * H * T * C / 8;                 // C * T is a multiple of 8 (shape_ok)
+        const long want = (n8 + 255) / 256, cap = (long)8 * tt_cus();
+        hipLaunchKernelGGL(k_gate_dx, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, st, (e16*)dx, (const e16*)x[0], n8);
+        TT_LAUNCH_CHECK();
+    }
     if (batch.n > 0) {
         const int total = (C <= 8 ? 9 * 256 : 9 * C * C) + C * C + 2 * C;
         const dim3 grid((total + REL - 1) / REL, batch.n);
@@ -1922,6 +1986,20 @@ int tt_wide_level_bwd(int nblocks, const void* const* x, const void* const* h1, 
         TT_LAUNCH_CHECK();
     }
     return 0;
+}
+
+int tt_wide_level_bwd(int nblocks, const void* const* x, const void* const* h1, const void* dy, const float* const* w1,
+                      const float* const* w2, const float* const* b2, void* dx, void* tmp0, void* tmp1, float* const* dw1,
+                      float* const* db1, float* const* dw2, float* const* db2, void* ws, int B, int C, int H, int T,
+                      const int* dilations, void* stream) {
+    return level_bwd(0, nblocks, x, h1, dy, w1, w2, b2, dx, tmp0, tmp1, dw1, db1, dw2, db2, ws, B, C, H, T, dilations, stream);
+}
+
+int tt_wide_level_bwd_gated(int nblocks, const void* const* x, const void* const* h1, const void* dy, const float* const* w1,
+                            const float* const* w2, const float* const* b2, void* dx, void* tmp0, void* tmp1, float* const* dw1,
+                            float* const* db1, float* const* dw2, float* const* db2, void* ws, int B, int C, int H, int T,
+                            const int* dilations, void* stream) {
+    return level_bwd(1, nblocks, x, h1, dy, w1, w2, b2, dx, tmp0, tmp1, dw1, db1, dw2, db2, ws, B, C, H, T, dilations, stream);
 }
 
 }  // extern "C"

@@ -29,7 +29,11 @@
 #define tt_convout16_bwd tt_convout16_bwd_h
 #define ttx_red_defer ttx_red_defer_h
 #define ttx_wprep_done ttx_wprep_done_h
+#define ttx_gate_dx ttx_gate_dx_h
 #define ttx_wide_wprep_batch ttx_wide_wprep_batch_h
 #define tt_wide_level_bwd tt_wide_level_bwd_h
+#define tt_wide_level_bwd_gated tt_wide_level_bwd_gated_h
+#define tt_sconv16_bwd_pregated tt_sconv16_bwd_pregated_h
+#define tt_tconv16_bwd_pregated tt_tconv16_bwd_pregated_h
 #define tt_wide_level_scratch_bytes tt_wide_level_scratch_bytes_h
 #endif

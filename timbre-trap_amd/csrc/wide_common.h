@@ -127,6 +127,7 @@ __global__ __launch_bounds__(1024) void k_wrb_reduce(RedBatch batch) {
 // thread's pending batch; conv_wide_bf16.hip defines it, conv_level_bf16.hip's launchers see it too).
 }  // namespace
 extern thread_local void* ttx_red_defer;
+extern thread_local int ttx_gate_dx;        // set by tt_wide_level_bwd_gated around its first block: 1 = asked for, 2 = the block's kernel gated dx
 extern thread_local bool ttx_wprep_done;     // set by tt_wide_level_bwd while the weight images of its blocks are already prepared
 int ttx_wide_wprep_batch(int C, int n, const float* const* w1, const float* const* w2, void* const* ws, hipStream_t st);
 namespace {

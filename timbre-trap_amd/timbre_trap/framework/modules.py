@@ -107,8 +107,10 @@ class DecoderBlock(nn.Module):
 
     def forward(self, x, out_x3=False):
         t = self.tconv[0]
-        y = ops.transposed_conv(x, t.weight, t.bias, self.win, self.hop, self.out_pad, out_x3=ops.x3_chain())
-        return ops.residual_level(y, (self.block1, self.block2, self.block3), out_x3=out_x3)
+        # y has no consumer but the level: the level's backward may hand the transposed layer its gradient already gated (ops.GateLink)
+        link = ops.gate_link() if torch.is_grad_enabled() else None
+        y = ops.transposed_conv(x, t.weight, t.bias, self.win, self.hop, self.out_pad, out_x3=ops.x3_chain(), link=link)
+        return ops.residual_level(y, (self.block1, self.block2, self.block3), out_x3=out_x3, link=link)
 
 
 class Encoder(nn.Module):

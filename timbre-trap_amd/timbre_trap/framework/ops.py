@@ -421,7 +421,7 @@ def _stride16_ok(C, T, w, b):
     return (FUSED_RESBLOCK and C in WIDE_CHANNELS and (C != 4 or T % 2 == 0) and w.shape == (2 * C, C, 4, 1) and b is not None)
 
 
-def strided_conv(x, w, b, win, hop, out_x3=False):
+def strided_conv(x, w, b, win, hop, out_x3=False, link=None):
     """Conv2d(C, Cout, (win,1), stride (hop,1)) + ELU.  x may be an x3 tensor (is_x3); out_x3: the next layer takes one."""
     if is_x3(x):
         C = x.size(4)
@@ -432,7 +432,7 @@ def strided_conv(x, w, b, win, hop, out_x3=False):
     C = x.size(1)
     if (win == 4 and hop == 2 and x.size(2) >= 4 and _stride16_ok(C, x.size(-1), w, b) and (is_cl16(x) or cl16_mode())
             and _i32_ok(x, 2 * C)):
-        return SConv16Fn.apply(to_cl16(x), w, b)
+        return SConv16Fn.apply(to_cl16(x), w, b, link)
     x = to_planar32(x)
     if (out_x3 and x3_chain() and C == 8 and 2 * C in X3_CHANNELS and win == 4 and hop == 2 and x.size(2) >= 4 and x.is_cuda
             and w.shape == (2 * C, C, 4, 1) and b is not None and _x3_size_ok(x.size(0), x.size(2), x.size(3))):
@@ -442,7 +442,7 @@ def strided_conv(x, w, b, win, hop, out_x3=False):
     return conv(x, w, b, ConvCfg(win, 1, hop, 1, 0, 0, 'conv', 0, ACT_ELU))
 
 
-def transposed_conv(x, w, b, win, hop, out_pad, out_x3=False):
+def transposed_conv(x, w, b, win, hop, out_pad, out_x3=False, link=None):
     """ConvTranspose2d(Cin, C, (win,1), stride (hop,1), output_padding (out_pad,0)) + ELU.  x may be an x3 tensor."""
     C = w.size(1)
     if is_x3(x):
@@ -452,7 +452,7 @@ def transposed_conv(x, w, b, win, hop, out_pad, out_x3=False):
         x = from_x3(x)
     if (win == 4 and hop == 2 and x.size(1) == 2 * C and out_pad in (0, 1) and _stride16_ok(C, x.size(-1), w, b)
             and (is_cl16(x) or cl16_mode()) and (2 * x.size(2) + 2 + out_pad) * x.size(3) * 2 * C < 2 ** 31):
-        return TConv16Fn.apply(to_cl16(x), w, b, out_pad)
+        return TConv16Fn.apply(to_cl16(x), w, b, out_pad, link)
     x = to_planar32(x)
     if (out_x3 and x3_chain() and C == 32 and x.size(1) == 64 and win == 4 and hop == 2 and x.is_cuda and w.shape == (64, 32, 4, 1)
             and b is not None and out_pad in (0, 1) and _x3_size_ok(x.size(0), 2 * x.size(2) + 3, x.size(3))):
@@ -658,17 +658,41 @@ def _chunks(B):
     return [(b0, min(B, b0 + c)) for b0 in range(0, B, c)]
 
 
+# A residual level's backward can hand the layer in front of it its gradient ALREADY multiplied by that layer's ELU derivative: the
+# level's input IS that layer's output (modules.py:683-693: tconv + ELU -> block1), and the first block's data-gradient kernel has it in
+# LDS when it writes dx (tt_wide_level_bwd_gated).  The layer's backward then skips reading its saved output and stages nothing through
+# registers (tt_tconv16_bwd_pregated / tt_sconv16_bwd_pregated).  Both sides must agree, and the product must reach nobody else: a
+# GateLink is created by the module that owns BOTH calls and knows the intermediate tensor has no other consumer (DecoderBlock); the
+# producer marks it when it took the 16-bit path, the level gates only then and says so, the producer's backward reads the flag.
+# TTRAP_PREGATE=0 / ops.PREGATE = False: never (A/B).
+PREGATE = os.environ.get('TTRAP_PREGATE', '1') != '0'
+
+
+class GateLink:
+    __slots__ = ('producer', 'gated')
+
+    def __init__(self):
+        self.producer = False        # set by SConv16Fn / TConv16Fn.forward: the producing layer is a 16-bit one and will look at `gated`
+        self.gated = False           # set by Level16Fn.backward: the gradient it returned carries the producer's ELU'
+
+
+def gate_link():
+    """A GateLink for a (strided / transposed layer -> residual level) pair whose intermediate tensor nobody else consumes, or None."""
+    return GateLink() if PREGATE else None
+
+
 class Level16Fn(torch.autograd.Function):
     """The residual blocks of one level on cl16 tensors (csrc/conv_wide_bf16.hip, csrc/conv_level_bf16.hip); see WideLevelFn for
     the fp32-facing form.  Saved for backward: the input of every block, plus its hidden activation at the widths whose
     backward does not recompute it (RECOMPUTE_CHANNELS)."""
 
     @staticmethod
-    def forward(ctx, x, dilations, *params):
+    def forward(ctx, x, dilations, link, *params):
         B, C, H, T = x.shape
         lib, st = lib16(x), stream_ptr()
         needs_grad = any(ctx.needs_input_grad)
         recompute = C in RECOMPUTE_CHANNELS
+        ctx.link = link if (link is not None and link.producer) else None
         nb = len(dilations)
         outs = [new_cl16(B, C, H, T, x.device, x.dtype) for _ in range(nb)]
         hids = [new_cl16(B, C, H, T, x.device, x.dtype) if (needs_grad and not recompute) else None for _ in range(nb)]
@@ -715,13 +739,17 @@ class Level16Fn(torch.autograd.Function):
             ws = torch.empty(lib.tt_wide_level_scratch_bytes(nb, B, C, H, T), dtype=torch.uint8, device=g_all.device)
             cols = list(zip(*[[targets[4 * i + j][0] for j in range(4)] for i in range(nb)]))      # dw1s, db1s, dw2s, db2s
             dil = (ctypes.c_int * nb)(*ctx.dilations)
+            gate = ctx.link is not None and ctx.needs_input_grad[0]
+            fn = lib.tt_wide_level_bwd_gated if gate else lib.tt_wide_level_bwd
             with _hip.timed('wide_rb_bwd_C%d' % C):
-                check(lib.tt_wide_level_bwd(nb, arr([saved[2 * i] for i in range(nb)]), arr([saved[2 * i + 1] for i in range(nb)]), ptr(g_all),
-                                            arr([params[4 * i] for i in range(nb)]), arr([params[4 * i + 2] for i in range(nb)]),
-                                            arr([params[4 * i + 3] for i in range(nb)]), ptr(dx), ptr(tmp[0]) if tmp else None,
-                                            ptr(tmp[1]) if tmp else None, arr(cols[0]), arr(cols[1]), arr(cols[2]), arr(cols[3]), ptr(ws),
-                                            B, C, H, T, dil, st), 'tt_wide_level_bwd')
-            return (dx, None, *[r for _, r in targets])
+                check(fn(nb, arr([saved[2 * i] for i in range(nb)]), arr([saved[2 * i + 1] for i in range(nb)]), ptr(g_all),
+                         arr([params[4 * i] for i in range(nb)]), arr([params[4 * i + 2] for i in range(nb)]),
+                         arr([params[4 * i + 3] for i in range(nb)]), ptr(dx), ptr(tmp[0]) if tmp else None,
+                         ptr(tmp[1]) if tmp else None, arr(cols[0]), arr(cols[1]), arr(cols[2]), arr(cols[3]), ptr(ws),
+                         B, C, H, T, dil, st), 'tt_wide_level_bwd')
+            if gate:
+                ctx.link.gated = True
+            return (dx, None, None, *[r for _, r in targets])
         for b0, b1 in chunks:
             g = g_all[b0:b1]
             for i in reversed(range(nb)):
@@ -739,18 +767,21 @@ class Level16Fn(torch.autograd.Function):
                         check(lib.tt_wide_rb_bwd(ptr(xin), ptr(h1), ptr(g), ptr(w1), ptr(w2), ptr(b2), ptr(gx), ptr(dw1), ptr(db1),
                                                  ptr(dw2), ptr(db2), ptr(ws), b1 - b0, C, H, T, ctx.dilations[i], st), 'tt_wide_rb_bwd')
                 g = gx
-        return (dx, None, *[r for _, r in targets])
+        return (dx, None, None, *[r for _, r in targets])
 
 
 class SConv16Fn(torch.autograd.Function):
     """EncoderBlock.sconv on cl16 tensors: (B,C,H,T) -> (B,2C,(H-4)/2+1,T) (csrc/conv_stride_bf16.hip)."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, link=None):
         B, C, H, T = x.shape
         y = new_cl16(B, 2 * C, (H - 4) // 2 + 1, T, x.device, x.dtype)
         check(lib16(x).tt_sconv16_fwd(ptr(x), ptr(w), ptr(b), ptr(y), B, C, H, T, stream_ptr()), 'tt_sconv16_fwd')
         ctx.params = (w, b)
+        ctx.link = link
+        if link is not None:
+            link.producer = True
         ctx.save_for_backward(x, w, y)
         return y
 
@@ -763,22 +794,30 @@ class SConv16Fn(torch.autograd.Function):
         dx = new_cl16(B, C, H, T, x.device, x.dtype) if ctx.needs_input_grad[0] else None
         (dw, r1), (db, r2) = (_grad_target(t) for t in ctx.params)
         ws = torch.empty(lib.tt_stride16_scratch_bytes(C), dtype=torch.uint8, device=x.device)
+        if ctx.link is not None and ctx.link.gated:              # the level behind this layer left dy * ELU'(y)
+            ctx.link.gated = False
+            check(lib.tt_sconv16_bwd_pregated(ptr(x), ptr(g), ptr(w), ptr(dx), ptr(dw), ptr(db), ptr(ws), B, C, H, T, stream_ptr()),
+                  'tt_sconv16_bwd_pregated')
+            return dx, r1, r2, None
         check(lib.tt_sconv16_bwd(ptr(x), ptr(y), ptr(g), ptr(w), ptr(dx), ptr(dw), ptr(db), ptr(ws), B, C, H, T, stream_ptr()),
               'tt_sconv16_bwd')
-        return dx, r1, r2
+        return dx, r1, r2, None
 
 
 class TConv16Fn(torch.autograd.Function):
     """DecoderBlock.tconv on cl16 tensors: (B,2C,H,T) -> (B,C,2H+2+out_pad,T)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, out_pad):
+    def forward(ctx, x, w, b, out_pad, link=None):
         B, C2, H, T = x.shape
         C = C2 // 2
         y = new_cl16(B, C, 2 * H + 2 + out_pad, T, x.device, x.dtype)
         check(lib16(x).tt_tconv16_fwd(ptr(x), ptr(w), ptr(b), ptr(y), B, C, H, T, out_pad, stream_ptr()), 'tt_tconv16_fwd')
         ctx.params = (w, b)
         ctx.out_pad = out_pad
+        ctx.link = link
+        if link is not None:
+            link.producer = True
         ctx.save_for_backward(x, w, y)
         return y
 
@@ -792,9 +831,14 @@ class TConv16Fn(torch.autograd.Function):
         dx = new_cl16(B, C2, H, T, x.device, x.dtype) if ctx.needs_input_grad[0] else None
         (dw, r1), (db, r2) = (_grad_target(t) for t in ctx.params)
         ws = torch.empty(lib.tt_stride16_scratch_bytes(C), dtype=torch.uint8, device=x.device)
+        if ctx.link is not None and ctx.link.gated:              # the level behind this layer left dy * ELU'(y)
+            ctx.link.gated = False
+            check(lib.tt_tconv16_bwd_pregated(ptr(x), ptr(g), ptr(w), ptr(dx), ptr(dw), ptr(db), ptr(ws), B, C, H, T, ctx.out_pad,
+                                              stream_ptr()), 'tt_tconv16_bwd_pregated')
+            return dx, r1, r2, None, None
         check(lib.tt_tconv16_bwd(ptr(x), ptr(y), ptr(g), ptr(w), ptr(dx), ptr(dw), ptr(db), ptr(ws), B, C, H, T, ctx.out_pad,
                                  stream_ptr()), 'tt_tconv16_bwd')
-        return dx, r1, r2, None
+        return dx, r1, r2, None, None
 
 
 class WideLevelFn(torch.autograd.Function):
@@ -929,7 +973,7 @@ def scale(e, weights, i):
     return ScaleFn.apply(e, weights, i)
 
 
-def residual_level(x, blocks, out_x3=False):
+def residual_level(x, blocks, out_x3=False, link=None):
     """
     block3(block2(block1(x))) for the ResidualConv2dBlock modules ``blocks``.  With ops.cl16_mode() the level runs
     on cl16 tensors (Level16Fn) and RETURNS a cl16 tensor -- the next layer either has a bf16 kernel or converts with
@@ -944,7 +988,8 @@ def residual_level(x, blocks, out_x3=False):
         params = []
         for b in blocks:
             params += [b.conv1[0].weight, b.conv1[0].bias, b.conv2[0].weight, b.conv2[0].bias]
-        return Level16Fn.apply(to_cl16(x), tuple(b.dilation for b in blocks), *params)
+        # link: only when x is the producing layer's own output tensor (to_cl16 is the identity on it)
+        return Level16Fn.apply(to_cl16(x), tuple(b.dilation for b in blocks), link if is_cl16(x) else None, *params)
     x = to_planar32(x)
     if (x3_inference() and X3N_INFER and C in X3N_CHANNELS and x.is_cuda and _x3_blocks_ok(C, blocks)
             and _x3_size_ok(x.size(0), x.size(2), x.size(3))):

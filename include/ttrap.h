@@ -220,6 +220,9 @@ int tt_wide_level_bwd_gated(int nblocks, const void* const* x, const void* const
                             const float* const* w2, const float* const* b2, void* dx, void* tmp0, void* tmp1, float* const* dw1,
                             float* const* db1, float* const* dw2, float* const* db2, void* ws, int B, int C, int H, int T,
                             const int* dilations, void* stream);
+/* g *= ELU'(y) in place on n 16-bit elements (n % 8 == 0): the same factor for a gradient that reaches such a layer by another way
+ * (a skip connection, a caller's own use of an encoder embedding; ops.GateTapFn). */
+int tt_gate16(void* g, const void* y, int64_t n, void* stream);
 /* The whole backward of one block in ONE pass from x and dy only (csrc/conv_level_bf16.hip; C = 16, 32, else
  * TT_E_UNSUPPORTED): the hidden activation is recomputed per tile (bit-identical to what tt_wide_rb_fwd would have stored),
  * dL/d(conv1 pre-activation) stays in LDS -- reads x and dy, writes dx.  The forward can then run with h1 = NULL.
@@ -526,6 +529,7 @@ int tt_tconv16_fwd_h(const void* x, const float* w, const float* b, void* y, int
                    void* stream);
 int tt_sconv16_bwd_pregated_h(const void* x, const void* g, const float* w, void* dx, float* dw, float* db, void* ws, int B, int C,
                               int H, int T, void* stream);
+int tt_gate16_h(void* g, const void* y, int64_t n, void* stream);
 int tt_tconv16_bwd_pregated_h(const void* x, const void* g, const float* w, void* dx, float* dw, float* db, void* ws, int B, int C,
                               int H, int T, int out_pad, void* stream);
 int tt_wide_level_bwd_gated_h(int nblocks, const void* const* x, const void* const* h1, const void* dy, const float* const* w1,

@@ -600,6 +600,33 @@ def test_level_hands_the_layer_in_front_its_gradient_already_gated(C, kind, dila
     assert _rel(g1[1].cpu().double(), g0[1].cpu().double()) < (6e-3 if ELT == torch.bfloat16 else 8e-4)   # db: sums of rounded vs unrounded products
 
 
+def test_encoder_embeddings_stay_usable_next_to_the_gated_levels(monkeypatch):
+    """The output of an EncoderBlock's strided layer feeds the next block's level (which hands its gradient back gated, ops.GateLink) AND
+    leaves the encoder as an embedding: whatever a caller does with that copy -- here a loss of its own on every embedding, next to the
+    latents -- must reach the strided layer with the same factor (ops.GateTapFn).  Gradients with and without the links agree to the
+    16-bit rounding of the activation gradients."""
+    from timbre_trap.framework import TimbreTrap, ops
+    torch.manual_seed(5)
+    model = TimbreTrap(sample_rate=22050, n_octaves=9, bins_per_octave=60, secs_per_block=3, latent_size=32, model_complexity=2).cuda()
+    coeffs = _rand(2, 2, 540, 64, seed=6).cuda()
+    monkeypatch.setattr(ops, 'PRECISION', 'bf16' if ELT == torch.bfloat16 else 'fp16')
+
+    def run(linked):
+        monkeypatch.setattr(ops, 'PREGATE', linked)
+        model.zero_grad(set_to_none=True)
+        lat, emb, _ = model.encoder(coeffs)
+        loss = lat.square().mean() + sum((0.5 + 0.1 * i) * ops.to_planar32(e).square().mean() for i, e in enumerate(emb))
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss), {k: p.grad.detach().double().cpu() for k, p in model.encoder.named_parameters()}
+
+    l0, g0 = run(False)
+    l1, g1 = run(True)
+    assert l0 == l1
+    worst = max((float((g1[k] - g0[k]).norm() / (g0[k].norm() + 1e-30)), k) for k in g0)
+    assert worst[0] < (2e-2 if ELT == torch.bfloat16 else 3e-3), worst
+
+
 @pytest.mark.parametrize('skip', [False, True])
 def test_bf16_model_is_channels_last_end_to_end(skip, monkeypatch):
     """In the bf16 mode every tensor between convin and convout is cl16 (no fp32 round trips inside the autoencoder), the

@@ -1988,6 +1988,15 @@ static int level_bwd(int gate, int nblocks, const void* const* x, const void* co
     return 0;
 }
 
+int tt_gate16(void* g, const void* y, int64_t n, void* stream) {
+    if (!g || !y || n < 0 || n % 8) return TT_E_BADARG;
+    if (n == 0) return 0;
+    const long n8 = n / 8, want = (n8 + 255) / 256, cap = (long)8 * tt_cus();
+    hipLaunchKernelGGL(k_gate_dx, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, tt_stream(stream), (e16*)g, (const e16*)y, n8);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
 int tt_wide_level_bwd(int nblocks, const void* const* x, const void* const* h1, const void* dy, const float* const* w1,
                       const float* const* w2, const float* const* b2, void* dx, void* tmp0, void* tmp1, float* const* dw1,
                       float* const* db1, float* const* dw2, float* const* db2, void* ws, int B, int C, int H, int T,

@@ -79,11 +79,13 @@ class EncoderBlock(nn.Module):
             nn.Conv2d(in_channels, out_channels, kernel_size=(self.win, 1), stride=(self.hop, 1)),
             nn.ELU(inplace=True))
 
-    def forward(self, x, out_x3=False):
-        """out_x3 (inside ops.x3_chain_scope only): the caller's next layer takes a split-operand tensor."""
-        y = ops.residual_level(x, (self.block1, self.block2, self.block3), out_x3=ops.x3_chain())
+    def forward(self, x, out_x3=False, link_in=None, link_out=None):
+        """out_x3 (inside ops.x3_chain_scope only): the caller's next layer takes a split-operand tensor.  link_in / link_out
+        (Encoder.forward): ops.GateLink with the strided layer in front of this block's level / between this block's strided layer and
+        the next block's level."""
+        y = ops.residual_level(x, (self.block1, self.block2, self.block3), out_x3=ops.x3_chain(), link=link_in)
         s = self.sconv[0]
-        return ops.strided_conv(y, s.weight, s.bias, self.win, self.hop, out_x3=out_x3)
+        return ops.strided_conv(y, s.weight, s.bias, self.win, self.hop, out_x3=out_x3, link=link_out)
 
 
 class DecoderBlock(nn.Module):
@@ -138,6 +140,10 @@ class Encoder(nn.Module):
         c = self.convin[0]
         embeddings = [ops.conv(coefficients, c.weight, c.bias, ConvCfg(3, 3, 1, 1, 1, 1, 'conv', 0, ACT_ELU))]
         blocks = (self.block1, self.block2, self.block3, self.block4)
+        # the output of a block's strided layer is the next block's level input AND an embedding handed to the caller: the level's backward
+        # hands the strided layer its gradient already gated (ops.GateLink), the caller's copy goes through ops.gate_tap
+        links = [None] + [ops.gate_link() if torch.is_grad_enabled() else None for _ in blocks[:-1]] + [None]
+        raw = embeddings[0]
         for i, block in enumerate(blocks):
             # inside ops.x3_chain_scope (embeddings dropped by the caller): a block whose successor starts with a split-operand level
             # hands its output over in that layout
@@ -145,8 +151,9 @@ class Encoder(nn.Module):
                 takes_x3 = blocks[i + 1].block1.conv1[0].in_channels in ops.X3_CHANNELS
             else:                                                # the latent head
                 takes_x3 = ops.x3_latent_ok(block.sconv[0].out_channels, self.convlat.out_channels, w_enc=self.convlat.weight)
-            embeddings.append(block(embeddings[-1], out_x3=ops.x3_chain() and takes_x3))
-        top = embeddings[-1]
+            raw = block(raw, out_x3=ops.x3_chain() and takes_x3, link_in=links[i], link_out=links[i + 1])
+            embeddings.append(ops.gate_tap(raw, links[i + 1]))
+        top = raw
         E = top.size(1) if ops.is_x3(top) else top.size(-2)
         if E != self.convlat.kernel_size[0]:
             raise ValueError('feature size %d does not match the latent head (%d)' % (E, self.convlat.kernel_size[0]))

@@ -661,10 +661,12 @@ def _chunks(B):
 # A residual level's backward can hand the layer in front of it its gradient ALREADY multiplied by that layer's ELU derivative: the
 # level's input IS that layer's output (modules.py:683-693: tconv + ELU -> block1), and the first block's data-gradient kernel has it in
 # LDS when it writes dx (tt_wide_level_bwd_gated).  The layer's backward then skips reading its saved output and stages nothing through
-# registers (tt_tconv16_bwd_pregated / tt_sconv16_bwd_pregated).  Both sides must agree, and the product must reach nobody else: a
-# GateLink is created by the module that owns BOTH calls and knows the intermediate tensor has no other consumer (DecoderBlock); the
-# producer marks it when it took the 16-bit path, the level gates only then and says so, the producer's backward reads the flag.
-# TTRAP_PREGATE=0 / ops.PREGATE = False: never (A/B).
+# registers (tt_tconv16_bwd_pregated / tt_sconv16_bwd_pregated).  Both sides must agree, and EVERY gradient that reaches the producing
+# layer must carry the factor: a GateLink is created by the module that owns both calls (DecoderBlock: the intermediate tensor has no
+# other consumer; Encoder: the strided layer's output is also an embedding handed to the caller -- that copy goes through gate_tap,
+# whose backward applies the factor to whatever gradient comes back through it, skip connections included).  The producer marks the
+# link in its forward when it took the 16-bit path; the level, in ITS forward, promises to gate when it will run tt_wide_level_bwd
+# (link.gated); the producer's backward and the tap's read the promise.  TTRAP_PREGATE=0 / ops.PREGATE = False: never (A/B).
 PREGATE = os.environ.get('TTRAP_PREGATE', '1') != '0'
 
 
@@ -673,7 +675,7 @@ class GateLink:
 
     def __init__(self):
         self.producer = False        # set by SConv16Fn / TConv16Fn.forward: the producing layer is a 16-bit one and will look at `gated`
-        self.gated = False           # set by Level16Fn.backward: the gradient it returned carries the producer's ELU'
+        self.gated = False           # set by Level16Fn.forward: the gradient its backward returns will carry the producer's ELU'
 
 
 def gate_link():
@@ -692,7 +694,11 @@ class Level16Fn(torch.autograd.Function):
         lib, st = lib16(x), stream_ptr()
         needs_grad = any(ctx.needs_input_grad)
         recompute = C in RECOMPUTE_CHANNELS
-        ctx.link = link if (link is not None and link.producer) else None
+        # the promise to gate: only where backward will take the one-call path below (all of it known now)
+        ctx.gate = bool(link is not None and link.producer and ctx.needs_input_grad[0] and LEVEL_BWD and not recompute
+                        and len(_chunks(B)) == 1 and len(dilations) <= 4)
+        if ctx.gate:
+            link.gated = True
         nb = len(dilations)
         outs = [new_cl16(B, C, H, T, x.device, x.dtype) for _ in range(nb)]
         hids = [new_cl16(B, C, H, T, x.device, x.dtype) if (needs_grad and not recompute) else None for _ in range(nb)]
@@ -739,17 +745,16 @@ class Level16Fn(torch.autograd.Function):
             ws = torch.empty(lib.tt_wide_level_scratch_bytes(nb, B, C, H, T), dtype=torch.uint8, device=g_all.device)
             cols = list(zip(*[[targets[4 * i + j][0] for j in range(4)] for i in range(nb)]))      # dw1s, db1s, dw2s, db2s
             dil = (ctypes.c_int * nb)(*ctx.dilations)
-            gate = ctx.link is not None and ctx.needs_input_grad[0]
-            fn = lib.tt_wide_level_bwd_gated if gate else lib.tt_wide_level_bwd
+            fn = lib.tt_wide_level_bwd_gated if ctx.gate else lib.tt_wide_level_bwd
             with _hip.timed('wide_rb_bwd_C%d' % C):
                 check(fn(nb, arr([saved[2 * i] for i in range(nb)]), arr([saved[2 * i + 1] for i in range(nb)]), ptr(g_all),
                          arr([params[4 * i] for i in range(nb)]), arr([params[4 * i + 2] for i in range(nb)]),
                          arr([params[4 * i + 3] for i in range(nb)]), ptr(dx), ptr(tmp[0]) if tmp else None,
                          ptr(tmp[1]) if tmp else None, arr(cols[0]), arr(cols[1]), arr(cols[2]), arr(cols[3]), ptr(ws),
                          B, C, H, T, dil, st), 'tt_wide_level_bwd')
-            if gate:
-                ctx.link.gated = True
             return (dx, None, None, *[r for _, r in targets])
+        if ctx.gate:
+            raise RuntimeError('ops.LEVEL_BWD / LEVEL_CHUNK / RECOMPUTE_CHANNELS changed between the forward and the backward of a level')
         for b0, b1 in chunks:
             g = g_all[b0:b1]
             for i in reversed(range(nb)):
@@ -795,7 +800,6 @@ class SConv16Fn(torch.autograd.Function):
         (dw, r1), (db, r2) = (_grad_target(t) for t in ctx.params)
         ws = torch.empty(lib.tt_stride16_scratch_bytes(C), dtype=torch.uint8, device=x.device)
         if ctx.link is not None and ctx.link.gated:              # the level behind this layer left dy * ELU'(y)
-            ctx.link.gated = False
             check(lib.tt_sconv16_bwd_pregated(ptr(x), ptr(g), ptr(w), ptr(dx), ptr(dw), ptr(db), ptr(ws), B, C, H, T, stream_ptr()),
                   'tt_sconv16_bwd_pregated')
             return dx, r1, r2, None
@@ -832,13 +836,40 @@ class TConv16Fn(torch.autograd.Function):
         (dw, r1), (db, r2) = (_grad_target(t) for t in ctx.params)
         ws = torch.empty(lib.tt_stride16_scratch_bytes(C), dtype=torch.uint8, device=x.device)
         if ctx.link is not None and ctx.link.gated:              # the level behind this layer left dy * ELU'(y)
-            ctx.link.gated = False
             check(lib.tt_tconv16_bwd_pregated(ptr(x), ptr(g), ptr(w), ptr(dx), ptr(dw), ptr(db), ptr(ws), B, C, H, T, ctx.out_pad,
                                               stream_ptr()), 'tt_tconv16_bwd_pregated')
             return dx, r1, r2, None, None
         check(lib.tt_tconv16_bwd(ptr(x), ptr(y), ptr(g), ptr(w), ptr(dx), ptr(dw), ptr(db), ptr(ws), B, C, H, T, ctx.out_pad,
                                  stream_ptr()), 'tt_tconv16_bwd')
         return dx, r1, r2, None, None
+
+
+class GateTapFn(torch.autograd.Function):
+    """Identity on the output y of a 16-bit strided layer whose OTHER consumer is a level that gates (GateLink): what comes back through
+    this copy (skip connections, a caller's own use of the embedding) gets the factor ELU'(y) here, so that every contribution to the
+    layer's incoming gradient carries it."""
+
+    @staticmethod
+    def forward(ctx, y, link):
+        ctx.link = link
+        ctx.save_for_backward(y)
+        return y.as_strided(y.size(), y.stride(), y.storage_offset())     # (view_as renumbers the stride of a size-1 batch dimension)
+
+    @staticmethod
+    def backward(ctx, g):
+        if not ctx.link.gated:
+            return g, None
+        y, = ctx.saved_tensors
+        g16 = _as_cl16(g, y.dtype).clone()
+        check(lib16(y).tt_gate16(ptr(g16), ptr(y), y.numel(), stream_ptr()), 'tt_gate16')
+        return g16, None
+
+
+def gate_tap(y, link):
+    """The copy of a linked layer's output that leaves the module (see GateLink); y itself when there is nothing to do."""
+    if link is None or not link.producer or not torch.is_grad_enabled() or not y.requires_grad:
+        return y
+    return GateTapFn.apply(y, link)
 
 
 class WideLevelFn(torch.autograd.Function):
@@ -1587,6 +1618,7 @@ _scale_backward(TConv16Fn, lambda ctx: ctx.saved_tensors[0].dtype)
 _scale_backward(LatEnc16Fn, lambda ctx: ctx.saved_tensors[0].dtype)
 _scale_backward(LatDec16Fn, lambda ctx: ctx.saved_tensors[2].dtype)
 _scale_backward(Scale16Fn, lambda ctx: ctx.saved_tensors[0].dtype)
+_scale_backward(GateTapFn, lambda ctx: ctx.saved_tensors[0].dtype)
 
 
 # ---- instrumentation (bench.py): bracket every forward / backward of the Functions above with HIP events ------------------------

@@ -562,7 +562,7 @@ template <int C, int D, int TH, int TW, bool XH> struct DXW {
 };
 
 template <int C, int D, int TH, int TW, bool XH, bool GOUT = false>
-__global__ __launch_bounds__(NT, 2) void k_wrb_dxw(const e16* __restrict__ x, const e16* __restrict__ da1, const e16* __restrict__ dy,
+__global__ __launch_bounds__(NT, (GOUT && C == 32) ? 3 : 2) void k_wrb_dxw(const e16* __restrict__ x, const e16* __restrict__ da1, const e16* __restrict__ dy,
                                                    const float* __restrict__ w1, e16* __restrict__ dx, float* __restrict__ part_w, int B,
                                                    int H, int T, int tiles_h, int tiles_t, int ntiles) {
     using G = DXW<C, D, TH, TW, XH>;
@@ -652,10 +652,16 @@ __global__ __launch_bounds__(NT, 2) void k_wrb_dxw(const e16* __restrict__ x, co
             if constexpr (GOUT) {
                 // dx * ELU'(x) for the layer in front of the level (see k_nrb_bwd_fused): the lane's channels of x from the halo-free image
                 static_assert(!GOUT || !XH, "the gated form reads the halo-free x image");
+                // (the x read stays BEHIND the products and the residual: its registers on top of the live dy piece were 176 instead of 168,
+                // i.e. two workgroups per CU instead of three -- 0.343 instead of 0.236 ms per call)
+                float sum[NCH];
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) sum[j] = acc[j >> 2][j & 3] + (float)rq[j];
+                asm volatile("" ::: "memory");
                 const vec_t xq = *reinterpret_cast<const vec_t*>(xs + (r * TW + c) * PB + 16 * ((C == 32 ? g : (g >> 1)) ^ fswz<C>(c)) +
                                                                  (C == 32 ? 0 : 8 * (g & 1)));
 #pragma unroll
-                for (int j = 0; j < NCH; ++j) o[j] = (e16)((acc[j >> 2][j & 3] + (float)rq[j]) * elu_dout((float)xq[j]));
+                for (int j = 0; j < NCH; ++j) o[j] = (e16)(sum[j] * elu_dout((float)xq[j]));
             } else {
 #pragma unroll
                 for (int j = 0; j < NCH; ++j) o[j] = (e16)(acc[j >> 2][j & 3] + (float)rq[j]);

@@ -261,11 +261,13 @@ int tt_tconv16_fwd(const void* x, const float* w, const float* b, void* y, int B
                    void* stream);
 int tt_tconv16_bwd(const void* x, const void* y, const void* dy, const float* w, void* dx, float* dw, float* db, void* ws,
                    int B, int C, int H, int T, int out_pad, void* stream);
-/* *_bwd_pregated: the same from x and g = dy * ELU'(y) (what tt_wide_level_bwd_gated leaves): the saved output is not needed. */
+/* *_bwd_pregated: the same from x and g = dy * ELU'(y) (what tt_wide_level_bwd_gated / tt_latent16_expand_gated leave): the saved
+ * output is not needed.  tt_tconv16_bwd_pregated with gate_dx = 1 (C = 16, 32; else TT_E_UNSUPPORTED) passes the favour on: dx leaves
+ * as dx * ELU'(x) for the layer in front of the first DecoderBlock (Decoder.convin + ELU, modules.py:534-537 -> tt_latent16_*_pregated). */
 int tt_sconv16_bwd_pregated(const void* x, const void* g, const float* w, void* dx, float* dw, float* db, void* ws, int B, int C,
                             int H, int T, void* stream);
 int tt_tconv16_bwd_pregated(const void* x, const void* g, const float* w, void* dx, float* dw, float* db, void* ws, int B, int C,
-                            int H, int T, int out_pad, void* stream);
+                            int H, int T, int out_pad, int gate_dx, void* stream);
 
 /* The (31,1) latent heads on bf16 channels-last embeddings (csrc/latent_bf16.hip; modules.py:446 Encoder.convlat and :534
  * Decoder.convin).  w is the (D', CT, E, 1) weight of either layer (index (d CT + c) E + h); (CT, D') = (32, <= 48) or (64, <= 144);
@@ -282,6 +284,19 @@ int tt_latent16_contract(const void* in, const void* gy, const float* w, const f
                          int D, int Dout, int E, int T, void* stream);
 int tt_latent16_expand(const float* z, int Dz, float fill, const float* w, const float* bias, void* out, void* ws, int B, int CT,
                        int D, int E, int T, void* stream);
+/* The backward uses with a neighbouring layer's ELU gate moved across the layer boundary (tt_wide_level_bwd_gated for the idea):
+ *   tt_latent16_expand_gated      data gradient of Encoder.convlat leaving as (.) * ELU'(gy), gy = the saved output of the strided layer
+ *                                 in front (its backward: tt_sconv16_bwd_pregated)
+ *   tt_latent16_contract_pregated, tt_latent16_wgrad_pregated   backward of Decoder.convin from g = dy * ELU'(y), as
+ *                                 tt_tconv16_bwd_pregated(gate_dx = 1) leaves it; y is not read.  The bias gradient rides as the weight
+ *                                 gradient's row of a constant-1 input row: needs D < 48 (CT = 32) / D < 144 (CT = 64), else
+ *                                 TT_E_UNSUPPORTED. */
+int tt_latent16_expand_gated(const float* z, const float* w, const void* gy, void* out, void* ws, int B, int CT, int D, int E, int T,
+                             void* stream);
+int tt_latent16_contract_pregated(const void* g, const float* w, float* out, void* ws, int B, int CT, int D, int Dout, int E, int T,
+                                  void* stream);
+int tt_latent16_wgrad_pregated(const float* z, int Dz, float fill, const void* g, float* dw, float* db, void* ws, int B, int CT, int D,
+                               int E, int T, void* stream);
 int tt_latent16_wgrad(const float* z, int Dz, float fill, const void* g, const void* gy, float* dw, float* db, void* ws, int B,
                       int CT, int D, int E, int T, void* stream);
 
@@ -531,7 +546,13 @@ int tt_sconv16_bwd_pregated_h(const void* x, const void* g, const float* w, void
                               int H, int T, void* stream);
 int tt_gate16_h(void* g, const void* y, int64_t n, void* stream);
 int tt_tconv16_bwd_pregated_h(const void* x, const void* g, const float* w, void* dx, float* dw, float* db, void* ws, int B, int C,
-                              int H, int T, int out_pad, void* stream);
+                              int H, int T, int out_pad, int gate_dx, void* stream);
+int tt_latent16_expand_gated_h(const float* z, const float* w, const void* gy, void* out, void* ws, int B, int CT, int D, int E, int T,
+                               void* stream);
+int tt_latent16_contract_pregated_h(const void* g, const float* w, float* out, void* ws, int B, int CT, int D, int Dout, int E, int T,
+                                    void* stream);
+int tt_latent16_wgrad_pregated_h(const float* z, int Dz, float fill, const void* g, float* dw, float* db, void* ws, int B, int CT, int D,
+                                 int E, int T, void* stream);
 int tt_wide_level_bwd_gated_h(int nblocks, const void* const* x, const void* const* h1, const void* dy, const float* const* w1,
                               const float* const* w2, const float* const* b2, void* dx, void* tmp0, void* tmp1, float* const* dw1,
                               float* const* db1, float* const* dw2, float* const* db2, void* ws, int B, int C, int H, int T,

@@ -538,9 +538,17 @@ def test_tconv16_stagewise(C, shape, out_pad):
         dx2 = ops.new_cl16(B, 2 * C, H, T, 'cuda', ELT)
         dw2, db2 = torch.full((2 * C, C, 4, 1), 0.25, device='cuda'), torch.full((C,), 0.25, device='cuda')
         check(lib.tt_tconv16_bwd_pregated(ptr(xb), ptr(gpre), ptr(wd), ptr(dx2) if with_dx else None, ptr(dw2), ptr(db2), ptr(ws), B, C, H, T,
-                                          out_pad, st), 'bwd pregated')
+                                          out_pad, 0, st), 'bwd pregated')
         if with_dx:
             _close16(_f64(dx2), F.conv2d(g_p, wr, stride=(2, 1)), 'dx pregated')
+            # ... and with dx leaving gated by the layer's own input (the ELU output of the latent head in front of the first DecoderBlock)
+            dx3 = ops.new_cl16(B, 2 * C, H, T, 'cuda', ELT)
+            dw3, db3 = torch.zeros_like(dw2), torch.zeros_like(db2)
+            rc = lib.tt_tconv16_bwd_pregated(ptr(xb), ptr(gpre), ptr(wd), ptr(dx3), ptr(dw3), ptr(db3), ptr(ws), B, C, H, T, out_pad, 1, st)
+            assert rc == (0 if C in (16, 32) else -2)
+            if rc == 0:
+                _close16(_f64(dx3), F.conv2d(g_p, wr, stride=(2, 1)) * _gate(xr), 'dx pregated and gated')
+                assert _rel(dw3.cpu().double(), dw2.cpu().double() - 0.25) < 1e-5
         assert _rel(dw2.cpu().double() - 0.25, torch.nn.grad.conv2d_weight(g_p, w.shape, xr, stride=(2, 1))) < 2e-4, 'dw pregated'
         assert _rel(db2.cpu().double() - 0.25, g_p.sum((0, 2, 3))) < 2e-4, 'db pregated'
 
@@ -693,6 +701,29 @@ def test_latent_heads_stagewise(CT, D, B, T):
     assert _rel(zd.grad.cpu().double(), torch.einsum('dk,bkt->bdt', W2, g_r.view(B, CT * E, T))) < 2e-4
     assert _rel(wd2.grad.cpu().double().view(D, CT * E), torch.einsum('bdt,bkt->dk', zr, g_r.view(B, CT * E, T))) < 2e-4
     assert _rel(bd2.grad.cpu().double(), g.sum((0, 2, 3))) < 2e-3
+
+    # the same two heads with the ELU gates moved across the layer boundaries (ops.GateLink): convlat's data gradient leaves gated by the
+    # layer in front's saved output (= its input), convin's backward takes its gradient already gated and does not read its own output
+    class _Link:
+        producer, gated = True, True
+    x16b = _cl16(top).requires_grad_(True)
+    wdb, bdb = w.cuda().requires_grad_(True), be.cuda().requires_grad_(True)
+    ops.LatEnc16Fn.apply(x16b, wdb, bdb, _Link()).backward(dlat.cuda())
+    _close16(_f64(x16b.grad), torch.einsum('dk,bdt->bkt', W2, dlr).view(B, CT, E, T) * _gate(_f64(x16b.detach())), 'dtop gated')
+    assert torch.equal(wdb.grad, wd.grad) and _rel(bdb.grad.double(), bdv.grad.double()) < 1e-6       # (tt_channel_sum ends in fp32 atomics)
+    if D < (48 if CT == 32 else 144):
+        link = ops.GateLink()
+        zd3 = z.cuda().requires_grad_(True)
+        wd3, bd3 = w.cuda().requires_grad_(True), bd.cuda().requires_grad_(True)
+        y3 = ops.LatDec16Fn.apply(zd3, wd3, bd3, None, link)
+        assert link.producer and torch.equal(y3.detach(), y.detach())
+        link.gated = True
+        gpre = _cl16(g.float())
+        g_p = _f64(gpre)
+        y3.backward(gpre)
+        assert _rel(zd3.grad.cpu().double(), torch.einsum('dk,bkt->bdt', W2, g_p.view(B, CT * E, T))) < 2e-4
+        assert _rel(wd3.grad.cpu().double().view(D, CT * E), torch.einsum('bdt,bkt->dk', zr, g_p.view(B, CT * E, T))) < 2e-4
+        assert _rel(bd3.grad.cpu().double(), g_p.sum((0, 2, 3))) < 2e-4
 
     # the last input channel as a constant (TimbreTrap.decode's indicator) instead of a row of z: same output, same gradients
     zc = z.clone()

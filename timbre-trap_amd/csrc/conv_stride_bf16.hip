@@ -546,7 +546,9 @@ template <int PB> __device__ __forceinline__ const unsigned char* px_piece(const
 // x is this layer's output (tt_wide_level_bwd_gated) -- so the saved output is not read at all (one tensor pass less per layer backward),
 // both operands come in by LDS-DMA (nothing is staged through registers: no dependent load -> gate -> write batches), and the bias
 // gradient, which the register staging summed on the side, is one more matrix product per visit of a gated pixel group: ones (x) operand.
-template <int C, bool GS, bool DX, bool PRE = false>
+// GDX (transposed layer, DX): dx leaves as dx * ELU'(x) -- x, the layer's input, is the ELU output of Decoder.convin in the first
+// DecoderBlock, whose backward then takes its gradient gated (tt_latent16_*_pregated); x is the small image already in LDS.
+template <int C, bool GS, bool DX, bool PRE = false, bool GDX = false>
 __global__ __launch_bounds__(NT, C == 32 ? ((!DX && GS) ? 3 : 2) : W4_WAVES16) void k_w4(const e16* __restrict__ small, const e16* __restrict__ big,
                                             const e16* __restrict__ ygate, float* __restrict__ part, float* __restrict__ dbpart,
                                             const float* __restrict__ w, e16* __restrict__ dx,
@@ -654,6 +656,17 @@ __global__ __launch_bounds__(NT, C == 32 ? ((!DX && GS) ? 3 : 2) : W4_WAVES16) v
                 for (int ct = 0; ct < NCTS; ++ct)
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) vv[4 * ct + rr] = acc[ct][rr];
+                if constexpr (GDX) {
+                    static_assert(!GDX || NCHS % 8 == 0, "whole 16-byte pieces of the small image per lane");
+                    if (NCHS * g < 2 * C) {
+#pragma unroll
+                        for (int q8 = 0; q8 < NCHS / 8; ++q8) {
+                            const e16x8 xv = *reinterpret_cast<const e16x8*>(px_piece<G::SB>(ss, r * G::TW + col, NCHS * g + 8 * q8));
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) vv[8 * q8 + j] *= elu_dout((float)xv[j]);
+                        }
+                    }
+                }
                 store_lane<2 * C, NCHS>(dx, ((long)b * Hs + r0 + r) * T + t, g, vv, t < T);
             }
         }
@@ -926,13 +939,13 @@ template <int C> inline bool w4x_enabled() {
     return on && C <= 32;
 }
 
-template <int C, bool GS, bool DX, bool PRE = false>
+template <int C, bool GS, bool DX, bool PRE = false, bool GDX = false>
 int launch_w4(const e16* small, const e16* big, const e16* ygate, float* dw, float* db, float* ws, const float* w, e16* dx,
               int B, int Hs, int Hb, int T, hipStream_t st) {
     using G = W4<C>;
     constexpr int LDS = ((DX && GS) ? G::SX_BYTES : G::S_BYTES) + G::B_BYTES;
     static AttrOnce once;
-    auto kern = k_w4<C, GS, DX, PRE>;
+    auto kern = k_w4<C, GS, DX, PRE, GDX>;
     if (int rc = raise_lds(kern, LDS, once)) return rc;
     const int tiles_h = (Hs + G::TR - 1) / G::TR, tiles_t = (T + G::TW - 1) / G::TW, ntiles = B * tiles_h * tiles_t;
     int gw = grid_for(ntiles, LDS, 3);
@@ -1054,11 +1067,16 @@ int tt_sconv16_bwd_pregated(const void* x, const void* g, const float* w, void* 
 }
 
 int tt_tconv16_bwd_pregated(const void* x, const void* g, const float* w, void* dx, float* dw, float* db, void* ws, int B, int C, int H,
-                            int T, int out_pad, void* stream) {
-    if (!x || !g || !w || !dw || !db || !ws || B <= 0 || H <= 0 || T <= 0 || out_pad < 0 || out_pad > 1) return TT_E_BADARG;
+                            int T, int out_pad, int gate_dx, void* stream) {
+    if (!x || !g || !w || !dw || !db || !ws || B <= 0 || H <= 0 || T <= 0 || out_pad < 0 || out_pad > 1 || (gate_dx && !dx)) return TT_E_BADARG;
     const int Ho = 2 * H + 2 + out_pad;
     if (!ok_shape(B, C, Ho, T)) return TT_E_BADARG;
     hipStream_t st = tt_stream(stream);
+    if (gate_dx) {                                               // dx * ELU'(x): the widths a latent head can sit in front of (tt_latent16_*)
+        if (C == 32) return launch_w4<32, false, true, true, true>((const e16*)x, (const e16*)g, nullptr, dw, db, (float*)ws, w, (e16*)dx, B, H, Ho, T, st);
+        if (C == 16) return launch_w4<16, false, true, true, true>((const e16*)x, (const e16*)g, nullptr, dw, db, (float*)ws, w, (e16*)dx, B, H, Ho, T, st);
+        return TT_E_UNSUPPORTED;
+    }
     if (dx) { TT_BY_C(C, (launch_w4<CC, false, true, true>((const e16*)x, (const e16*)g, nullptr, dw, db, (float*)ws, w, (e16*)dx, B, H, Ho, T, st))); }
     TT_BY_C(C, (launch_w4<CC, false, false, true>((const e16*)x, (const e16*)g, nullptr, dw, db, (float*)ws, nullptr, nullptr, B, H, Ho, T, st)));
 }

@@ -60,8 +60,10 @@ __global__ __launch_bounds__(NT) void k_lat_wprep2(const float* __restrict__ w, 
 // zt[b][t][ZS] (bf16) = z[b][d][t] (fp32, Dz rows), row Dz = the constant `fill` when Dz < D (the indicator channel of
 // TimbreTrap.decode, modules.py:139-142, without materialising the concatenation), zero beyond D
 template <int KS>
+// `one_row` >= 0: that row (a padding row, >= D) holds the constant 1 -- the weight gradient's row of it is then sum_{b,t} g = the bias
+// gradient, which the pregated form has no register staging to sum on the side (tt_latent16_wgrad_pregated)
 __global__ __launch_bounds__(NT) void k_lat_zprep(const float* __restrict__ z, e16* __restrict__ zt, int D, int Dz, float fill, int T,
-                                                   long npix, float zscale) {
+                                                   long npix, float zscale, int one_row = -1) {
     constexpr int ZS = 32 * KS + 16, PCS = ZS / 8;
     // a wave = 64 consecutive frames x one 16-byte piece: the fp32 reads are coalesced, the bf16 writes 16 bytes per lane
     const long i = (long)blockIdx.x * NT + threadIdx.x;
@@ -71,7 +73,8 @@ __global__ __launch_bounds__(NT) void k_lat_zprep(const float* __restrict__ z, e
     const long b = pix / T, t = pix - b * T;
     e16x8 v;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (e16)(zscale * (d0 + e < Dz ? z[(b * Dz + d0 + e) * T + t] : (d0 + e < D ? fill : 0.f)));
+    for (int e = 0; e < 8; ++e)
+        v[e] = (e16)(zscale * (d0 + e < Dz ? z[(b * Dz + d0 + e) * T + t] : (d0 + e < D ? fill : (d0 + e == one_row ? 1.f : 0.f))));
     *reinterpret_cast<e16x8*>(zt + pix * ZS + d0) = v;
 }
 
@@ -165,10 +168,12 @@ __global__ __launch_bounds__(NT) void k_lat_contract(const e16* __restrict__ in,
 // ---- expand to (h, c) ----------------------------------------------------------------------------------------------------------
 // QE = 16-frame groups per wave: 4 (256 frames per workgroup) launches ONE workgroup per CU at the bench shape (81 us for 0.26 GB);
 // 2 gives 512 workgroups with half the accumulators.
-template <int CT, int KS, bool ACT, int QE>
+// GOUT (backward use, !ACT): out = (.) * ELU'(gy) with gy the saved output of the layer in front (Encoder's last strided layer), whose
+// backward then takes the gradient already gated (tt_sconv16_bwd_pregated)
+template <int CT, int KS, bool ACT, int QE, bool GOUT = false>
 __global__ __launch_bounds__(NT) void k_lat_expand(const e16* __restrict__ zt, const e16* __restrict__ wp,
                                                     const float* __restrict__ bias, e16* __restrict__ out, int E, int T,
-                                                    long npix) {
+                                                    long npix, const e16* __restrict__ gy = nullptr) {
     constexpr int NC = CT / 16, NCH = CT / 4, ZS = 32 * KS + 16;
     constexpr int PCS = NC * KS * 64, ROUNDS = (PCS + NT - 1) / NT;            // 16-byte pieces of one row's weights
     extern __shared__ __align__(16) unsigned char smem[];
@@ -223,12 +228,13 @@ __global__ __launch_bounds__(NT) void k_lat_expand(const e16* __restrict__ zt, c
             e16* d = out + obase[q] + (long)h * T * CT;
 #pragma unroll
             for (int c8 = 0; c8 < NCH / 8; ++c8) {
-                e16x8 o;
+                e16x8 o, yv;
+                if constexpr (GOUT) yv = *reinterpret_cast<const e16x8*>(gy + obase[q] + (long)h * T * CT + 8 * c8);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int ch = 8 * c8 + e;                   // lane channel NCH g + ch = tile ch / 4, row 4g + ch % 4
                     const float a = acc[ch >> 2][q][ch & 3] + br[ch];
-                    o[e] = (e16)(ACT ? elu_f(a) : a);
+                    o[e] = (e16)(ACT ? elu_f(a) : (GOUT ? a * elu_dout((float)yv[e]) : a));
                 }
                 *reinterpret_cast<e16x8*>(d + 8 * c8) = o;
             }
@@ -349,7 +355,7 @@ __global__ __launch_bounds__(NT, LAT_WGRAD_WAVES) void k_lat_wgrad(const e16* __
 
 template <int CT, int DT>
 __global__ __launch_bounds__(NT) void k_lat_wred(const float* __restrict__ part, const float* __restrict__ dbpart, float* __restrict__ dw,
-                                                  float* __restrict__ db, int D, int E, int nsplit, float scale) {
+                                                  float* __restrict__ db, int D, int E, int nsplit, float scale, int db_row = -1) {
     constexpr int NC = CT / 16, WPS = 4 / NC, WD = DT * 256;
     const int i = blockIdx.x * NT + threadIdx.x;                 // (h, ct, dump element)
     const int total = E * NC * WD;
@@ -362,7 +368,8 @@ __global__ __launch_bounds__(NT) void k_lat_wred(const float* __restrict__ part,
         const int lane = e & 63, r = (e >> 6) & 3, dt = e >> 8;
         const int d = 16 * dt + 4 * (lane >> 4) + r, c = 16 * ct + (lane & 15);
         if (d < D) dw[((long)d * CT + c) * E + h] += sum * scale;
-    } else if (db && i < total + CT * 16) {                     // sixteen slices of the workgroups per channel, joined by atomics
+        else if (d == db_row) atomicAdd(db + c, sum * scale);   // the row of ones (k_lat_zprep): sum of g over this row h of the embedding
+    } else if (db && db_row < 0 && i < total + CT * 16) {       // sixteen slices of the workgroups per channel, joined by atomics
         const int c = (i - total) % CT, sl = (i - total) / CT;
         float sum = 0.f;
         for (int wg = sl; wg < nsplit * E; wg += 16) sum += dbpart[(long)wg * 64 + c];
@@ -383,7 +390,7 @@ template <int CT, int DT, int KS> struct LatSizes {
 
 template <int CT, int DT, int KS, bool GATE>
 int run_contract(const e16* in, const e16* gy, const float* w, const float* bias, float* out, unsigned char* ws, int B, int D,
-                 int Dout, int E, int T, hipStream_t st) {
+                 int Dout, int E, int T, hipStream_t st, bool pregated = false) {
     using L = LatSizes<CT, DT, KS>;
     const long npix = (long)B * T;
     e16* wp = reinterpret_cast<e16*>(ws);
@@ -399,15 +406,15 @@ int run_contract(const e16* in, const e16* gy, const float* w, const float* bias
     auto kern = k_lat_contract<CT, DT, GATE, QN>;
     if (int rc = raise_lds(kern, LDS, once)) return rc;
     // GATE = the backward use (dz of Decoder.convin from the S-scaled gradient of its output): the fp32 result leaves the scaled region
-    const float oscale = GATE ? tt_loss_unscale() : 1.f;
+    const float oscale = (GATE || pregated) ? tt_loss_unscale() : 1.f;
     hipLaunchKernelGGL(kern, dim3((unsigned)((npix + 64 * QN - 1) / (64 * QN))), dim3(NT), LDS, st, in, gy, wp, bias, out, D, Dout, E, T, npix, oscale);
     TT_LAUNCH_CHECK();
     return 0;
 }
 
-template <int CT, int DT, int KS, bool ACT>
+template <int CT, int DT, int KS, bool ACT, bool GOUT = false>
 int run_expand(const float* z, int Dz, float fill, const float* w, const float* bias, e16* out, unsigned char* ws, int B, int D, int E,
-               int T, hipStream_t st) {
+               int T, hipStream_t st, const e16* gy = nullptr) {
     using L = LatSizes<CT, DT, KS>;
     const long npix = (long)B * T;
     e16* wp = reinterpret_cast<e16*>(ws);
@@ -423,16 +430,16 @@ int run_expand(const float* z, int Dz, float fill, const float* w, const float* 
     constexpr int PCS = L::NC * KS * 64, ROUNDS = (PCS + NT - 1) / NT, LDS = 2 * ROUNDS * NT * 16;
     static AttrOnce once;
     constexpr int QE = LAT_EXPAND_Q;
-    auto kern = k_lat_expand<CT, KS, ACT, QE>;
+    auto kern = k_lat_expand<CT, KS, ACT, QE, GOUT>;
     if (int rc = raise_lds(kern, LDS, once)) return rc;
-    hipLaunchKernelGGL(kern, dim3((unsigned)((npix + 64 * QE - 1) / (64 * QE))), dim3(NT), LDS, st, zt, wp, bias, out, E, T, npix);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((npix + 64 * QE - 1) / (64 * QE))), dim3(NT), LDS, st, zt, wp, bias, out, E, T, npix, gy);
     TT_LAUNCH_CHECK();
     return 0;
 }
 
 template <int CT, int DT, int KS, bool GATE>
 int run_wgrad(const float* z, int Dz, float fill, const e16* g_in, const e16* gy, float* dw, float* db, unsigned char* ws, int B,
-              int D, int E, int T, hipStream_t st) {
+              int D, int E, int T, hipStream_t st, bool pregated = false) {
     using L = LatSizes<CT, DT, KS>;
     const long npix = (long)B * T;
     if (npix >= (1l << 30) || (long)B * E * T >= (1l << 31)) return TT_E_UNSUPPORTED;      // 32-bit pixel arithmetic in k_lat_wgrad
@@ -442,8 +449,12 @@ int run_wgrad(const float* z, int Dz, float fill, const e16* g_in, const e16* gy
     const long zp = ((npix + 63) / 64) * 64 * (L::ZS / 8);
     // GATE: z holds activations (the latents) and g the S-scaled gradient; !GATE (Encoder.convlat): z IS the gradient, fp32 and unscaled --
     // it takes the factor S on its way to 16 bits.  Either way the dumps carry exactly one S, removed by the reduce.
+    // pregated (!GATE kernels, the gated form's meaning): z holds activations, g arrives gated and S-scaled; the bias gradient is the weight
+    // gradient's row of a constant-1 input row (needs a padding row: D < 16 DT)
+    if (pregated && (GATE || D >= 16 * DT || !db)) return TT_E_UNSUPPORTED;
+    const int one_row = pregated ? D : -1;
     hipLaunchKernelGGL((k_lat_zprep<KS>), dim3((unsigned)((zp + NT - 1) / NT)), dim3(NT), 0, st, z, zt, D, Dz, fill, T, npix,
-                       GATE ? 1.f : tt_loss_scale());
+                       (GATE || pregated) ? 1.f : tt_loss_scale(), one_row);
     TT_LAUNCH_CHECK();
     constexpr int ZB = L::ZS * 2, GBY = CT * 2;
     constexpr int ZR = (64 * ZB / 16 + NT - 1) / NT, GR = (64 * GBY / 16 + NT - 1) / NT;
@@ -454,8 +465,8 @@ int run_wgrad(const float* z, int Dz, float fill, const e16* g_in, const e16* gy
     hipLaunchKernelGGL(kern, dim3(E * NSPLIT), dim3(NT), LDS, st, zt, g_in, gy, part, dbpart, E, T, npix, NSPLIT);
     TT_LAUNCH_CHECK();
     const int total = E * (CT / 16) * DT * 256 + CT * 16;
-    hipLaunchKernelGGL((k_lat_wred<CT, DT>), dim3((total + NT - 1) / NT), dim3(NT), 0, st, part, dbpart, dw, GATE ? db : nullptr, D, E, NSPLIT,
-                       tt_loss_unscale());
+    hipLaunchKernelGGL((k_lat_wred<CT, DT>), dim3((total + NT - 1) / NT), dim3(NT), 0, st, part, dbpart, dw, (GATE || pregated) ? db : nullptr, D, E,
+                       NSPLIT, tt_loss_unscale(), one_row);
     TT_LAUNCH_CHECK();
     return 0;
 }
@@ -519,6 +530,45 @@ int tt_latent16_wgrad(const float* z, int Dz, float fill, const void* g, const v
     switch (cfg_of(CT, D)) {
         case 1: return y ? run_wgrad<32, 3, 2, true>(z, Dz, fill, gi, y, dw, db, s, B, D, E, T, st) : run_wgrad<32, 3, 2, false>(z, Dz, fill, gi, y, dw, db, s, B, D, E, T, st);
         case 2: return y ? run_wgrad<64, 9, 5, true>(z, Dz, fill, gi, y, dw, db, s, B, D, E, T, st) : run_wgrad<64, 9, 5, false>(z, Dz, fill, gi, y, dw, db, s, B, D, E, T, st);
+    }
+    return TT_E_UNSUPPORTED;
+}
+
+/* The three backward uses with the ELU gate of a neighbouring layer moved (ops.GateLink; tt_wide_level_bwd_gated for the idea):
+ *   tt_latent16_expand_gated     data gradient of Encoder.convlat, leaving as (.) * ELU'(gy): gy = the saved output of the strided layer
+ *                                in front, whose backward is then tt_sconv16_bwd_pregated
+ *   tt_latent16_contract_pregated / tt_latent16_wgrad_pregated   backward of Decoder.convin from g = dy * ELU'(y) as the transposed layer
+ *                                behind it leaves it (tt_tconv16_bwd_pregated, gate_dx = 1): y is not read; needs D < 16 * ceil(D / 16)
+ *                                rounded up to the kernel's tile count (a free input row carries the bias gradient): TT_E_UNSUPPORTED else */
+int tt_latent16_expand_gated(const float* z, const float* w, const void* gy, void* out, void* ws, int B, int CT, int D, int E, int T,
+                             void* stream) {
+    if (!z || !w || !gy || !out || !ws || B <= 0 || E <= 0 || T <= 0 || T % 16) return TT_E_BADARG;
+    hipStream_t st = tt_stream(stream);
+    switch (cfg_of(CT, D)) {
+        case 1: return run_expand<32, 3, 2, false, true>(z, D, 0.f, w, nullptr, (e16*)out, (unsigned char*)ws, B, D, E, T, st, (const e16*)gy);
+        case 2: return run_expand<64, 9, 5, false, true>(z, D, 0.f, w, nullptr, (e16*)out, (unsigned char*)ws, B, D, E, T, st, (const e16*)gy);
+    }
+    return TT_E_UNSUPPORTED;
+}
+
+int tt_latent16_contract_pregated(const void* g, const float* w, float* out, void* ws, int B, int CT, int D, int Dout, int E, int T,
+                                  void* stream) {
+    if (!g || !w || !out || !ws || B <= 0 || E <= 0 || T <= 0 || T % 16 || Dout < 1 || Dout > D) return TT_E_BADARG;
+    hipStream_t st = tt_stream(stream);
+    switch (cfg_of(CT, D)) {
+        case 1: return run_contract<32, 3, 2, false>((const e16*)g, nullptr, w, nullptr, out, (unsigned char*)ws, B, D, Dout, E, T, st, true);
+        case 2: return run_contract<64, 9, 5, false>((const e16*)g, nullptr, w, nullptr, out, (unsigned char*)ws, B, D, Dout, E, T, st, true);
+    }
+    return TT_E_UNSUPPORTED;
+}
+
+int tt_latent16_wgrad_pregated(const float* z, int Dz, float fill, const void* g, float* dw, float* db, void* ws, int B, int CT, int D,
+                               int E, int T, void* stream) {
+    if (!z || !g || !dw || !db || !ws || B <= 0 || E <= 0 || T <= 0 || T % 16 || (Dz != D && Dz != D - 1)) return TT_E_BADARG;
+    hipStream_t st = tt_stream(stream);
+    switch (cfg_of(CT, D)) {
+        case 1: return run_wgrad<32, 3, 2, false>(z, Dz, fill, (const e16*)g, nullptr, dw, db, (unsigned char*)ws, B, D, E, T, st, true);
+        case 2: return run_wgrad<64, 9, 5, false>(z, Dz, fill, (const e16*)g, nullptr, dw, db, (unsigned char*)ws, B, D, E, T, st, true);
     }
     return TT_E_UNSUPPORTED;
 }

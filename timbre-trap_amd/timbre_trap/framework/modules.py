@@ -107,11 +107,11 @@ class DecoderBlock(nn.Module):
         self.block2 = ResidualConv2dBlock(out_channels, out_channels, kernel_size=3, dilation=2)
         self.block3 = ResidualConv2dBlock(out_channels, out_channels, kernel_size=3, dilation=3)
 
-    def forward(self, x, out_x3=False):
+    def forward(self, x, out_x3=False, uplink=None):
         t = self.tconv[0]
         # y has no consumer but the level: the level's backward may hand the transposed layer its gradient already gated (ops.GateLink)
         link = ops.gate_link() if torch.is_grad_enabled() else None
-        y = ops.transposed_conv(x, t.weight, t.bias, self.win, self.hop, self.out_pad, out_x3=ops.x3_chain(), link=link)
+        y = ops.transposed_conv(x, t.weight, t.bias, self.win, self.hop, self.out_pad, out_x3=ops.x3_chain(), link=link, uplink=uplink)
         return ops.residual_level(y, (self.block1, self.block2, self.block3), out_x3=out_x3, link=link)
 
 
@@ -142,7 +142,8 @@ class Encoder(nn.Module):
         blocks = (self.block1, self.block2, self.block3, self.block4)
         # the output of a block's strided layer is the next block's level input AND an embedding handed to the caller: the level's backward
         # hands the strided layer its gradient already gated (ops.GateLink), the caller's copy goes through ops.gate_tap
-        links = [None] + [ops.gate_link() if torch.is_grad_enabled() else None for _ in blocks[:-1]] + [None]
+        # (the last one: between the last strided layer and the latent head)
+        links = [None] + [ops.gate_link() if torch.is_grad_enabled() else None for _ in blocks]
         raw = embeddings[0]
         for i, block in enumerate(blocks):
             # inside ops.x3_chain_scope (embeddings dropped by the caller): a block whose successor starts with a split-operand level
@@ -157,7 +158,7 @@ class Encoder(nn.Module):
         E = top.size(1) if ops.is_x3(top) else top.size(-2)
         if E != self.convlat.kernel_size[0]:
             raise ValueError('feature size %d does not match the latent head (%d)' % (E, self.convlat.kernel_size[0]))
-        latents = ops.latent_encode(top, self.convlat.weight, self.convlat.bias)
+        latents = ops.latent_encode(top, self.convlat.weight, self.convlat.bias, link=links[-1])
         return latents, embeddings, dict()
 
 
@@ -192,15 +193,19 @@ class Decoder(nn.Module):
         c = self.convin[0]
         skips = None if encoder_embeddings is None else list(encoder_embeddings)[::-1]
         # (inside ops.x3_chain_scope, no skip connections: the head hands a split-operand tensor to block1's transposed layer)
+        # without skip connections the head's output goes straight (and only) into block1's transposed layer: that layer's backward may
+        # hand the head its gradient already gated (ops.GateLink)
+        uplink = ops.gate_link() if (skips is None and torch.is_grad_enabled()) else None
         y = ops.latent_decode(latents, c.weight, c.bias, indicator,
-                              out_x3=skips is None and ops.x3_chain() and self.block1.tconv[0].out_channels in ops.X3_CHANNELS)
+                              out_x3=skips is None and ops.x3_chain() and self.block1.tconv[0].out_channels in ops.X3_CHANNELS, link=uplink)
         if skips is not None:
             y = ops.add(y, skips[0])
         blocks = (self.block1, self.block2, self.block3, self.block4)
         for i, block in enumerate(blocks):
             # transposed layers with a split-operand kernel: 64 -> 32 and 32 -> 16 channels (tt_x3_tconv_fwd)
             t = blocks[i + 1].tconv[0] if i + 1 < len(blocks) else None
-            y = block(y, out_x3=skips is None and ops.x3_chain() and t is not None and (t.in_channels, t.out_channels) in ((64, 32), (32, 16)))
+            y = block(y, out_x3=skips is None and ops.x3_chain() and t is not None and (t.in_channels, t.out_channels) in ((64, 32), (32, 16)),
+                      uplink=uplink if i == 0 else None)
             if skips is not None:
                 y = ops.add(y, skips[i + 1])
         o = self.convout

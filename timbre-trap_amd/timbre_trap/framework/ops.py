@@ -442,7 +442,7 @@ def strided_conv(x, w, b, win, hop, out_x3=False, link=None):
     return conv(x, w, b, ConvCfg(win, 1, hop, 1, 0, 0, 'conv', 0, ACT_ELU))
 
 
-def transposed_conv(x, w, b, win, hop, out_pad, out_x3=False, link=None):
+def transposed_conv(x, w, b, win, hop, out_pad, out_x3=False, link=None, uplink=None):
     """ConvTranspose2d(Cin, C, (win,1), stride (hop,1), output_padding (out_pad,0)) + ELU.  x may be an x3 tensor."""
     C = w.size(1)
     if is_x3(x):
@@ -452,7 +452,7 @@ def transposed_conv(x, w, b, win, hop, out_pad, out_x3=False, link=None):
         x = from_x3(x)
     if (win == 4 and hop == 2 and x.size(1) == 2 * C and out_pad in (0, 1) and _stride16_ok(C, x.size(-1), w, b)
             and (is_cl16(x) or cl16_mode()) and (2 * x.size(2) + 2 + out_pad) * x.size(3) * 2 * C < 2 ** 31):
-        return TConv16Fn.apply(to_cl16(x), w, b, out_pad, link)
+        return TConv16Fn.apply(to_cl16(x), w, b, out_pad, link, uplink if is_cl16(x) else None)
     x = to_planar32(x)
     if (out_x3 and x3_chain() and C == 32 and x.size(1) == 64 and win == 4 and hop == 2 and x.is_cuda and w.shape == (64, 32, 4, 1)
             and b is not None and out_pad in (0, 1) and _x3_size_ok(x.size(0), 2 * x.size(2) + 3, x.size(3))):
@@ -670,12 +670,26 @@ def _chunks(B):
 PREGATE = os.environ.get('TTRAP_PREGATE', '1') != '0'
 
 
+# The same between the latent heads and their neighbours: Encoder.convlat's data gradient leaves gated for the last strided layer
+# (tt_latent16_expand_gated), and the first DecoderBlock's transposed layer gates ITS dx for Decoder.convin -- which it can only do in its
+# pregated form, i.e. when the level behind it gates in turn: that promise `depends` on the other link's, read at backward time.
 class GateLink:
-    __slots__ = ('producer', 'gated')
+    __slots__ = ('producer', '_gated', 'depends')
 
     def __init__(self):
-        self.producer = False        # set by SConv16Fn / TConv16Fn.forward: the producing layer is a 16-bit one and will look at `gated`
-        self.gated = False           # set by Level16Fn.forward: the gradient its backward returns will carry the producer's ELU'
+        self.producer = False        # set by the producing layer's forward (SConv16Fn / TConv16Fn / LatDec16Fn): it is a 16-bit one and
+                                     # its backward will look at `gated`
+        self._gated = False          # set by the consumer's forward (Level16Fn / LatEnc16Fn / TConv16Fn): the gradient its backward
+                                     # returns will carry the producer's ELU'
+        self.depends = None          # ... provided this other link's consumer gates too
+
+    @property
+    def gated(self):
+        return self._gated and (self.depends is None or self.depends.gated)
+
+    @gated.setter
+    def gated(self, v):
+        self._gated = bool(v)
 
 
 def gate_link():
@@ -812,9 +826,15 @@ class TConv16Fn(torch.autograd.Function):
     """DecoderBlock.tconv on cl16 tensors: (B,2C,H,T) -> (B,C,2H+2+out_pad,T)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, out_pad, link=None):
+    def forward(ctx, x, w, b, out_pad, link=None, uplink=None):
         B, C2, H, T = x.shape
         C = C2 // 2
+        # uplink: x is the ELU output of a 16-bit layer that takes its gradient gated (LatDec16Fn); this layer's pregated backward can do it
+        ctx.uplink = uplink if (uplink is not None and uplink.producer and link is not None and C in (16, 32)
+                                and ctx.needs_input_grad[0]) else None
+        if ctx.uplink is not None:
+            uplink.depends = link
+            uplink.gated = True
         y = new_cl16(B, C, 2 * H + 2 + out_pad, T, x.device, x.dtype)
         check(lib16(x).tt_tconv16_fwd(ptr(x), ptr(w), ptr(b), ptr(y), B, C, H, T, out_pad, stream_ptr()), 'tt_tconv16_fwd')
         ctx.params = (w, b)
@@ -837,11 +857,11 @@ class TConv16Fn(torch.autograd.Function):
         ws = torch.empty(lib.tt_stride16_scratch_bytes(C), dtype=torch.uint8, device=x.device)
         if ctx.link is not None and ctx.link.gated:              # the level behind this layer left dy * ELU'(y)
             check(lib.tt_tconv16_bwd_pregated(ptr(x), ptr(g), ptr(w), ptr(dx), ptr(dw), ptr(db), ptr(ws), B, C, H, T, ctx.out_pad,
-                                              stream_ptr()), 'tt_tconv16_bwd_pregated')
-            return dx, r1, r2, None, None
+                                              1 if ctx.uplink is not None else 0, stream_ptr()), 'tt_tconv16_bwd_pregated')
+            return dx, r1, r2, None, None, None
         check(lib.tt_tconv16_bwd(ptr(x), ptr(y), ptr(g), ptr(w), ptr(dx), ptr(dw), ptr(db), ptr(ws), B, C, H, T, ctx.out_pad,
                                  stream_ptr()), 'tt_tconv16_bwd')
-        return dx, r1, r2, None, None
+        return dx, r1, r2, None, None, None
 
 
 class GateTapFn(torch.autograd.Function):
@@ -1336,7 +1356,7 @@ class LatEnc16Fn(torch.autograd.Function):
     """Encoder.convlat on the cl16 top embedding (csrc/latent_bf16.hip): (B,CT,E,T) cl16 -> latents (B,D,T) fp32."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, link=None):
         B, CT, E, T = x.shape
         D = w.size(0)
         lib = lib16(x)
@@ -1344,6 +1364,10 @@ class LatEnc16Fn(torch.autograd.Function):
         ws = torch.empty(lib.tt_latent16_scratch_bytes(B, CT, D, E, T), dtype=torch.uint8, device=x.device)
         check(lib.tt_latent16_contract(ptr(x), None, ptr(w), ptr(b), ptr(y), ptr(ws), B, CT, D, D, E, T, stream_ptr()),
               'tt_latent16_contract')
+        # x is the output of the encoder's last strided layer (+ ELU): its gradient goes back gated (GateLink)
+        ctx.gate = bool(link is not None and link.producer and ctx.needs_input_grad[0])
+        if ctx.gate:
+            link.gated = True
         ctx.params = (w, b)
         ctx.save_for_backward(x, w)
         return y
@@ -1359,13 +1383,16 @@ class LatEnc16Fn(torch.autograd.Function):
         dx = rw = rb = None
         if ctx.needs_input_grad[0]:
             dx = new_cl16(B, CT, E, T, x.device, x.dtype)
-            check(lib.tt_latent16_expand(ptr(dy), D, 0.0, ptr(w), None, ptr(dx), ptr(ws), B, CT, D, E, T, st), 'tt_latent16_expand')
+            if ctx.gate:
+                check(lib.tt_latent16_expand_gated(ptr(dy), ptr(w), ptr(x), ptr(dx), ptr(ws), B, CT, D, E, T, st), 'tt_latent16_expand_gated')
+            else:
+                check(lib.tt_latent16_expand(ptr(dy), D, 0.0, ptr(w), None, ptr(dx), ptr(ws), B, CT, D, E, T, st), 'tt_latent16_expand')
         if ctx.needs_input_grad[1]:
             dw, rw = _grad_target(ctx.params[0])
             check(lib.tt_latent16_wgrad(ptr(dy), D, 0.0, ptr(x), None, ptr(dw), None, ptr(ws), B, CT, D, E, T, st), 'tt_latent16_wgrad')
             db, rb = _grad_target(ctx.params[1])
             check(lib.tt_channel_sum(ptr(dy), ptr(db), B, D, T, st), 'tt_channel_sum')
-        return dx, rw, rb
+        return dx, rw, rb, None
 
 
 class LatDec16Fn(torch.autograd.Function):
@@ -1376,10 +1403,14 @@ class LatDec16Fn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, z, w, b, fill):
+    def forward(ctx, z, w, b, fill, link=None):
         z = _f32c(z)
         B, Dz, T = z.shape
         D, CT, E = w.size(0), w.size(1), w.size(2)
+        # the pregated backward carries the bias gradient in a free input row of the weight gradient: D < 48 / 144 (include/ttrap.h)
+        ctx.link = link if (link is not None and D < (48 if CT == 32 else 144)) else None
+        if ctx.link is not None:
+            ctx.link.producer = True
         y = new_cl16(B, CT, E, T, z.device, cl16_dtype())
         lib = lib16(y)
         ws = torch.empty(lib.tt_latent16_scratch_bytes(B, CT, D, E, T), dtype=torch.uint8, device=z.device)
@@ -1399,14 +1430,22 @@ class LatDec16Fn(torch.autograd.Function):
         g = _as_cl16(dy, y.dtype)
         ws = torch.empty(lib.tt_latent16_scratch_bytes(B, CT, D, E, T), dtype=torch.uint8, device=z.device)
         dz = rw = rb = None
+        pre = ctx.link is not None and ctx.link.gated           # the transposed layer behind left dy * ELU'(y)
         if ctx.needs_input_grad[0]:
             dz = torch.empty_like(z)
-            check(lib.tt_latent16_contract(ptr(g), ptr(y), ptr(w), None, ptr(dz), ptr(ws), B, CT, D, Dz, E, T, st), 'tt_latent16_contract')
+            if pre:
+                check(lib.tt_latent16_contract_pregated(ptr(g), ptr(w), ptr(dz), ptr(ws), B, CT, D, Dz, E, T, st), 'tt_latent16_contract_pregated')
+            else:
+                check(lib.tt_latent16_contract(ptr(g), ptr(y), ptr(w), None, ptr(dz), ptr(ws), B, CT, D, Dz, E, T, st), 'tt_latent16_contract')
         if ctx.needs_input_grad[1]:
             dw, rw = _grad_target(ctx.params[0])
             db, rb = _grad_target(ctx.params[1])
-            check(lib.tt_latent16_wgrad(ptr(z), Dz, ctx.fill, ptr(g), ptr(y), ptr(dw), ptr(db), ptr(ws), B, CT, D, E, T, st), 'tt_latent16_wgrad')
-        return dz, rw, rb, None
+            if pre:
+                check(lib.tt_latent16_wgrad_pregated(ptr(z), Dz, ctx.fill, ptr(g), ptr(dw), ptr(db), ptr(ws), B, CT, D, E, T, st),
+                      'tt_latent16_wgrad_pregated')
+            else:
+                check(lib.tt_latent16_wgrad(ptr(z), Dz, ctx.fill, ptr(g), ptr(y), ptr(dw), ptr(db), ptr(ws), B, CT, D, E, T, st), 'tt_latent16_wgrad')
+        return dz, rw, rb, None, None
 
 
 X3_LATENT_SHAPES = ((64, 128), (32, 32))          # (channels of the top embedding, latent size) with split-operand latent heads
@@ -1448,18 +1487,18 @@ def x3_latent_decode(z, w, b, fill, out_x3):
     return y
 
 
-def latent_encode(top, w, b):
+def latent_encode(top, w, b, link=None):
     """Encoder.convlat (modules.py:446)."""
     if is_x3(top):
         if x3_latent_ok(top.size(4), w.size(0), w_enc=w) and w.size(2) == top.size(1):
             return x3_latent_encode(top, w, b)
         top = from_x3(top)
     if is_cl16(top) and _f32ok(w) and _lat16_ok(top.size(1), w.size(0), top.size(2), top.size(3), b) and w.shape[1:] == (top.size(1), top.size(2), 1):
-        return LatEnc16Fn.apply(top, w, b)
+        return LatEnc16Fn.apply(top, w, b, link)
     return LatentEncodeFn.apply(to_planar32(top), w, b)
 
 
-def latent_decode(z, w, b, fill=None, out_x3=False):
+def latent_decode(z, w, b, fill=None, out_x3=False, link=None):
     """
     Decoder.convin (modules.py:534) + ELU; cl16 output in the bf16 mode.  ``fill``: value of a constant last input channel that z
     does not carry (see LatDec16Fn); on the fp32 path the channel is concatenated like the reference does.  ``out_x3`` (inside
@@ -1471,7 +1510,7 @@ def latent_decode(z, w, b, fill=None, out_x3=False):
         return x3_latent_decode(z, w, b, fill, True)
     if (cl16_mode() and FUSED_RESBLOCK and _f32ok(w) and z.dim() == 3 and w.size(0) == Dz and w.size(3) == 1
             and _lat16_ok(w.size(1), w.size(0), w.size(2), z.size(2), b)):
-        return LatDec16Fn.apply(z, w, b, fill)
+        return LatDec16Fn.apply(z, w, b, fill, link)
     if fill is not None:
         z = torch.cat((z, torch.full_like(z[..., :1, :], float(fill))), dim=-2)
     return LatentDecodeFn.apply(z, w, b)

@@ -13,6 +13,8 @@ How it differs from the reference inside (the public behaviour does not):
     unchanged and bit-identical in summation order).
 """
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -187,9 +189,10 @@ class Decoder(nn.Module):
         self.block4 = DecoderBlock(channels[3], channels[4], stride=2, padding=padding[3])
         self.convout = nn.Conv2d(channels[4], 2, kernel_size=3, padding='same')
 
-    def forward(self, latents, encoder_embeddings=None, indicator=None):
+    def forward(self, latents, encoder_embeddings=None, indicator=None, pair=False):
         """``indicator``: None (latents carry the switch channel, the reference's call) or its constant value (then latents have
-        one channel less and ops.latent_decode supplies it)."""
+        one channel less and ops.latent_decode supplies it).  ``pair`` (TimbreTrap.decode_pair): the batch is two batches back to
+        back; returns their two logits tensors."""
         c = self.convin[0]
         skips = None if encoder_embeddings is None else list(encoder_embeddings)[::-1]
         # (inside ops.x3_chain_scope, no skip connections: the head hands a split-operand tensor to block1's transposed layer)
@@ -209,6 +212,8 @@ class Decoder(nn.Module):
             if skips is not None:
                 y = ops.add(y, skips[i + 1])
         o = self.convout
+        if pair:
+            return ops.conv_out_pair(y, o.weight, o.bias)
         return ops.conv(y, o.weight, o.bias, ConvCfg(3, 3, 1, 1, 1, 1, 'conv', 0, ACT_NONE))
 
 
@@ -218,6 +223,8 @@ class TimbreTrap(nn.Module):
     (``sliCQ``, ``encoder``, ``decoder``, ``skip_weights``) follow the reference because every
     script of the reference reaches into them.
     """
+
+    PAIR_DECODE = os.environ.get('TTRAP_PAIR_DECODE', '1') != '0'
 
     def __init__(self, sample_rate, n_octaves, bins_per_octave, secs_per_block=3,
                  latent_size=None, model_complexity=1, skip_connections=False):
@@ -247,6 +254,17 @@ class TimbreTrap(nn.Module):
             return self.decoder(latents, embeddings, indicator=value)
         indicator = torch.full_like(latents[..., :1, :], value)
         return self.decoder(torch.cat((latents, indicator), dim=-2), embeddings)
+
+    def decode_pair(self, latents, embeddings=None):
+        """(decode(latents, embeddings), decode(latents, embeddings, True)) -- the reconstruction and the transcription of the same
+        latents (reference modules.py:365-371 calls decode twice).  On the 16-bit training path without skip connections the two are
+        ONE pass of the decoder over a batch of 2 B (clips are independent: the same values; half the launches, weight-gradient
+        reduces and kernel tails of the decoder).  TTRAP_PAIR_DECODE=0 / TimbreTrap.PAIR_DECODE = False: two passes."""
+        if self.PAIR_DECODE and embeddings is None and ops.cl16_mode() and torch.is_grad_enabled() and latents.dim() == 3:
+            ones = torch.ones_like(latents[..., :1, :])
+            z = torch.cat((torch.cat((latents, ones), dim=-2), torch.cat((latents, torch.zeros_like(ones)), dim=-2)), dim=0)
+            return self.decoder(z, None, pair=True)
+        return self.decode(latents, embeddings), self.decode(latents, embeddings, True)
 
     def _inference(self, audio, transcribe=False):
         # without skip connections the embeddings are dropped right here: the layers may keep their activations in the split-operand
@@ -322,14 +340,12 @@ class TimbreTrap(nn.Module):
         """
         latents, embeddings, losses = self.encode(audio)
         embeddings = self.apply_skip_connections(embeddings)
-        reconstruction = self.decode(latents, embeddings)
-        transcription = self.decode(latents, embeddings, True)
+        reconstruction, transcription = self.decode_pair(latents, embeddings)
         transcription_rec = transcription_scr = None
         if consistency:
             latents_trn, embeddings_trn, _ = self.encoder(transcription)
             embeddings_trn = self.apply_skip_connections(embeddings_trn)
-            transcription_rec = self.decode(latents_trn, embeddings_trn)
-            transcription_scr = self.decode(latents_trn, embeddings_trn, True)
+            transcription_rec, transcription_scr = self.decode_pair(latents_trn, embeddings_trn)
         return reconstruction, latents, transcription, transcription_rec, transcription_scr, losses
 
 

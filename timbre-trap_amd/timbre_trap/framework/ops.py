@@ -634,6 +634,53 @@ class ConvOut16Fn(torch.autograd.Function):
         return dx, r1, r2
 
 
+class ConvOut16PairFn(torch.autograd.Function):
+    """Decoder.convout on a batch that is two batches back to back (TimbreTrap.decode_pair: the reconstruction and the transcription
+    decode of the same latents in ONE pass through the decoder): returns the two halves as two tensors of their own, so that the losses'
+    gradients come back as two tensors as well -- a sliced single output would cost autograd a zero-filled full-size gradient and an
+    add per slice (0.55 ms per step measured for such slices, bench.py)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        B, _, H, T = x.shape
+        h = B // 2
+        lib, st = lib16(x), stream_ptr()
+        ys = [torch.empty((h, 2, H, T), dtype=torch.float32, device=x.device) for _ in range(2)]
+        for i, y in enumerate(ys):
+            check(lib.tt_convout16_fwd(ptr(x[i * h:(i + 1) * h]), ptr(w), ptr(b), ptr(y), h, H, T, st), 'tt_convout16_fwd')
+        ctx.params = (w, b)
+        ctx.save_for_backward(x, w)
+        return ys[0], ys[1]
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        x, w = ctx.saved_tensors
+        B, _, H, T = x.shape
+        h = B // 2
+        lib, st = lib16(x), stream_ptr()
+        dx = new_cl16(B, 4, H, T, x.device, x.dtype)
+        (dw, r1), (db, r2) = (_grad_target(t) for t in ctx.params)
+        ws = torch.empty(lib.tt_edge16_scratch_bytes(), dtype=torch.uint8, device=x.device)
+        with loss_scaled(x.dtype):
+            for i, g in enumerate((g0, g1)):
+                if g is None:
+                    dx[i * h:(i + 1) * h].zero_()
+                    continue
+                check(lib.tt_convout16_bwd(ptr(x[i * h:(i + 1) * h]), ptr(_f32c(g)), ptr(w), ptr(dx[i * h:(i + 1) * h]), ptr(dw), ptr(db), ptr(ws),
+                                           h, H, T, st), 'tt_convout16_bwd')
+        return dx, r1, r2
+
+
+def conv_out_pair(x, w, b):
+    """Conv2d(4, 2, 3, padding 'same') on a batch of two halves -> (first half, second half) (ConvOut16PairFn; else conv + slices)."""
+    if (x.dim() == 4 and x.size(0) % 2 == 0 and is_cl16(x) and w.shape == (2, 4, 3, 3) and b is not None and x.size(3) % 2 == 0
+            and FUSED_RESBLOCK and x.size(2) * x.size(3) * 4 < 2 ** 31):
+        return ConvOut16PairFn.apply(x, w, b)
+    y = conv(x, w, b, ConvCfg(3, 3, 1, 1, 1, 1, 'conv', 0, ACT_NONE))
+    h = y.size(0) // 2
+    return y[:h], y[h:]
+
+
 # Clips per pass of a level (0 = the whole batch at once, the default): with a chunk, the three blocks run back to back on a few clips
 # at a time, so a block reads what the previous one just wrote while it may still be in the 256 MB memory-side cache.  Measured at 64
 # clips: 69.9 ms per step unchunked, 74.1 / 79.8 / 93.6 ms with chunks of 32 / 16 / 8 -- smaller launches cost more than the cache gives.
@@ -1688,6 +1735,7 @@ _instrument(ResBlockFn, 'rb', lambda x, *a: 'C%d' % x.size(1))
 _instrument(WideLevelFn, 'widelevel', lambda x, *a: 'C%d' % x.size(1))
 _instrument(ConvIn16Fn, 'edge16', lambda x, *a: 'in')
 _instrument(ConvOut16Fn, 'edge16', lambda x, *a: 'out')
+_instrument(ConvOut16PairFn, 'edge16', lambda x, *a: 'out')
 _instrument(Level16Fn, 'widelevel', lambda x, *a: 'C%d' % x.size(1))
 _instrument(SConv16Fn, 'sconv16', lambda x, *a: 'C%d' % x.size(1))
 _instrument(TConv16Fn, 'tconv16', lambda x, w, *a: 'C%d' % w.size(1))

@@ -14,7 +14,7 @@ def main(db_path, steps):
     fam = collections.defaultdict(lambda: [0.0, 0])
     for name, n, ms, _ in rows:
         m = re.search(r'(k_\w+)(<[^>]*>)?', name)
-        key = (m.group(1) + (m.group(2) or '')) if m else name[:60]
+        key = (m.group(1) + (m.group(2) or '')) if m else re.sub(r'\s+', ' ', name)[:200]     # (torch's own kernels: enough of the name to tell them apart)
         fam[key][0] += ms
         fam[key][1] += n
     print('\n## by kernel (ms per step, %% of kernel time, launches per step, avg us)')

@@ -219,8 +219,10 @@ def _train_step(model, opt, c, gt):
 
 def test_train_steps_match_oracle_mc2_full_block():
     """
-    BASELINE configs[2] at reduced batch: model_complexity 2 / latent 128, two clips x one full 3-s block (T = 1024, the
-    bench's tile counts per clip), two steps of losses -> backward -> clip 10 -> AdamW against the CPU oracle trainer.
+    BASELINE configs[2] at reduced batch: model_complexity 2 / latent 128, one clip x one full 3-s block (T = 1024, the
+    bench's tile counts per clip), two steps of losses -> backward -> clip 10 -> AdamW against the CPU oracle trainer.  (One clip: the
+    CPU oracle is what this test's minute goes into, and the batch dimension at this length is the autocast test's below; round 5,
+    the GPU selection's wall-clock budget.)
     """
     from timbre_trap.utils import FusedAdamW
     kw = KW['mc2']
@@ -229,8 +231,8 @@ def test_train_steps_match_oracle_mc2_full_block():
     opt = FusedAdamW(model.parameters(), lr=1e-3, max_norm=10.0)
     oracle = OracleTrainer(sd, lr=1e-3)
     for step in range(2):
-        coeffs = stub_cqt.closed_form_coefficients(2, 540, M) * (1.0 + 0.1 * step)
-        gt = stub_cqt.closed_form_targets(2, 540, M)
+        coeffs = stub_cqt.closed_form_coefficients(1, 540, M) * (1.0 + 0.1 * step)
+        gt = stub_cqt.closed_form_targets(1, 540, M)
         ref = oracle.step(coeffs, gt)
         total, norm = _train_step(model, opt, coeffs.cuda(), gt.cuda())
         np.testing.assert_allclose(float(total), ref['total'], rtol=2e-4)
@@ -619,7 +621,7 @@ def test_model_level_reduced_precision_modes(precision, logit_tol, loss_tol, mon
 
 # ---- evaluate()-scale inputs: one long track, batch 1, one-shot forward (reference experiments/evaluate.py:81-113) ----------
 
-@pytest.mark.parametrize('tag,n_blocks', [('mc1', 20), ('mc2', 6)])
+@pytest.mark.parametrize('tag,n_blocks', [('mc1', 12), ('mc2', 6)])
 def test_full_track_one_shot_forward(tag, n_blocks):
     """
     evaluate() pads a whole track to a multiple of the block length and runs ONE forward over it (batch 1, T = n * 1024

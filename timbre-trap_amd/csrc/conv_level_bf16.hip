@@ -468,6 +468,8 @@ __device__ __forceinline__ void conv_taps_ring(const unsigned char* img, const i
 
 // GOUT: dx leaves as dx * ELU'(x) for the layer in front of the level (k_nrb_bwd_fused, conv_wide_bf16.hip); the x rows of the step are
 // still on their way into LDS at that point, so the lane's channels of x come from memory like its dy (the same lines the DMA is fetching).
+// (Round 5, measured and dropped: h1 straight from memory into the lanes of step b. -- no staging image for it, the x rows into the freed
+// image already in step a., three barriers per step instead of four: 53.18 / 52.62 ms per step against 51.96 / 52.06, profiles/r05_bwds_hd_ab.txt.)
 template <int C, int D, int TH, int TW, int MINW, bool GOUT = false>
 __global__ __launch_bounds__(NT, MINW) void k_wrb_bwds(const e16* __restrict__ x, const e16* __restrict__ h1, const e16* __restrict__ dy,
                                                      const e16x8* __restrict__ wimg, const float* __restrict__ b2, e16* __restrict__ dx,

@@ -425,6 +425,9 @@ int fused_c(const e16* x, const e16* dy, const float* w1, const float* b1, const
 //       d. dx of those rows = dy + W1^T (*)_D dA1 from the ring, then
 //       e. dW1[tap] += x[q] (x) dA1[q - tap D] over those rows (x needs no halo).
 //   HBM traffic per block: h1, dy, x in, dx out, plus the column halo of h1 / dy (2D / TW).
+#ifndef TT_BWDS_XE
+#define TT_BWDS_XE 1
+#endif
 template <int C, int D, int TH, int TW> struct OS {
     static constexpr int CG = C / 8, PB = C * 2;
     static constexpr int GW = TW + 2 * D, RING = TH + 2 * D;
@@ -439,7 +442,11 @@ template <int C, int D, int TH, int TW> struct OS {
     static constexpr int T_BYTES = 4 * 2 * 16 * PS;
     static constexpr int ADUMP = C * C + 2 * C;
     static constexpr int WDUMP = 9 * (C / 16) * 256;
-    static constexpr int LDS_BYTES = RING_BYTES + HS_BYTES + T_BYTES;
+    // TT_BWDS_XE (C = 16): the x rows in an image of their own, staged in step a. with dy and h1 (they used to wait for h1 to die, step c.):
+    // steps d. and e. then run back to back without the wait and the barrier between them, and the gated form reads its x from LDS
+    static constexpr bool XE = TT_BWDS_XE != 0 && C == 16 && D <= 2;             // (dilation 3: 41 KB with it = three workgroups per CU instead of four)
+    static constexpr int XS_BYTES = XE ? XP * 16 : 0;
+    static constexpr int LDS_BYTES = RING_BYTES + HS_BYTES + XS_BYTES + T_BYTES;
     static constexpr int NG1 = (TH * GW + 15) / 16;
     static_assert(XP % NT == 0, "whole DMA instructions for the x rows");
     static_assert(4 * ADUMP * 4 <= RING_BYTES + HS_BYTES, "final dump reduction reuses the images");
@@ -484,7 +491,9 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_bwds(const e16* __restrict__ x
     unsigned char* hst = smem + G::RING_BYTES;                   // h1 of the step's new rows, then the step's x rows
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, g = lane >> 4, trj = n >> 2, trq = n & 3;
-    unsigned char* tg = smem + G::RING_BYTES + G::HS_BYTES + wave * (2 * 16 * G::PS);   // this wave's dA2 tile, then its h1 tile
+    constexpr bool XE = G::XE;
+    unsigned char* xst = XE ? smem + G::RING_BYTES + G::HS_BYTES : hst;          // the step's x rows (XE: an image of their own)
+    unsigned char* tg = smem + G::RING_BYTES + G::HS_BYTES + G::XS_BYTES + wave * (2 * 16 * G::PS);   // this wave's dA2 tile, then its h1 tile
     unsigned char* thh = tg + 16 * G::PS;
     const int opiece = C == 32 ? g : (g >> 1), obyte = C == 32 ? 0 : 8 * (g & 1);
 
@@ -566,6 +575,19 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_bwds(const e16* __restrict__ x
                     }
                 }
             }
+            // the x rows of this step's dx / dW1 (a wave instruction = 64 pieces of ONE row: TW * CG is a multiple of 64)
+            auto stage_x = [&]() {
+#pragma unroll
+                for (int it = 0; it < G::XP / NT; ++it) {
+                    const int i = it * NT + wave * 64;
+                    const int row = i / (TW * G::CG);
+                    const int h = X0 + row;
+                    const int px = ((i + lane) / G::CG) % TW;
+                    const bool ok = h < H && (!edge || t0 + px < T);
+                    glds16(ok ? x + ib + ((long)h * T + t0) * C + xoff[it] : zero, xst + (long)i * 16);
+                }
+            };
+            if constexpr (XE) { if (j > 0) stage_x(); }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
 
@@ -658,17 +680,8 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_bwds(const e16* __restrict__ x
             if (j == 0) continue;                                // nothing above the image to produce
             __syncthreads();                                     // dA1 rows complete, h1 staging dead
 
-            // ---- c. the x rows of this step towards the staging image (consumed in e.) ----
-            // (a wave instruction = 64 pieces of ONE row: TW * CG is a multiple of 64)
-#pragma unroll
-            for (int it = 0; it < G::XP / NT; ++it) {
-                const int i = it * NT + wave * 64;
-                const int row = i / (TW * G::CG);
-                const int h = X0 + row;
-                const int px = ((i + lane) / G::CG) % TW;
-                const bool ok = h < H && (!edge || t0 + px < T);
-                glds16(ok ? x + ib + ((long)h * T + t0) * C + xoff[it] : zero, hst + (long)i * 16);
-            }
+            // ---- c. (!XE) the x rows of this step towards the staging image (consumed in e.) ----
+            if constexpr (!XE) stage_x();
 
             // ---- d. dx = dy + W1^T (*) dA1 over the step's rows ----
             if constexpr (C == 32) {
@@ -689,7 +702,8 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_bwds(const e16* __restrict__ x
                     const long pix = ((long)b * H + h) * T + t;
                     const e16x4 rq = *reinterpret_cast<const e16x4*>(dy + (valid ? pix : pix - (t - (T - 1))) * C + 8 * g + 4 * ctd);
                     e16x4 xg;
-                    if constexpr (GOUT) xg = *reinterpret_cast<const e16x4*>(x + (valid ? pix : pix - (t - (T - 1))) * C + 8 * g + 4 * ctd);
+                    if constexpr (GOUT && XE) xg = *reinterpret_cast<const e16x4*>(xst + (r * TW + c) * PB + 16 * (g ^ fswz<C>(c)) + 8 * ctd);
+                    else if constexpr (GOUT) xg = *reinterpret_cast<const e16x4*>(x + (valid ? pix : pix - (t - (T - 1))) * C + 8 * g + 4 * ctd);
                     const int ro[3] = {slot(h - D) * G::ROWB, slot(h) * G::ROWB, slot(h + D) * G::ROWB};
                     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -721,7 +735,8 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_bwds(const e16* __restrict__ x
                     // unconditional (clamped) so that no branch pins a wait in front of the products
                     const vec_t rq = *reinterpret_cast<const vec_t*>(dy + (valid ? pix : pix - (t - (T - 1))) * C + NCH * g);
                     vec_t xg;
-                    if constexpr (GOUT) xg = *reinterpret_cast<const vec_t*>(x + (valid ? pix : pix - (t - (T - 1))) * C + NCH * g);
+                    if constexpr (GOUT && XE) xg = *reinterpret_cast<const vec_t*>(xst + (r * TW + c) * PB + 16 * (opiece ^ fswz<C>(c)) + obyte);
+                    else if constexpr (GOUT) xg = *reinterpret_cast<const vec_t*>(x + (valid ? pix : pix - (t - (T - 1))) * C + NCH * g);
                     const int ro[3] = {slot(h - D) * G::ROWB, slot(h) * G::ROWB, slot(h + D) * G::ROWB};
                     f32x4 acc[NCT];
 #pragma unroll
@@ -734,8 +749,10 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_bwds(const e16* __restrict__ x
                     if (valid) *reinterpret_cast<vec_t*>(dx + pix * C + NCH * g) = o;
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the x rows have landed
-            __syncthreads();
+            if constexpr (!XE) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the x rows have landed
+                __syncthreads();
+            }
 
             // ---- e. dW1[tap] += x[q] (x) dA1[q - tap D] over the step's rows, K = 32 consecutive columns per product ----
             for (int r = rpar; r < TH; r += RSTEP) {
@@ -748,7 +765,7 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_bwds(const e16* __restrict__ x
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         const int xc = ch * 32 + 4 * g + trj + 16 * u;
-                        const s16x4 t4 = lds_tr16(hst + (r * TW + xc) * PB + 16 * (((C == 32 ? 2 * cit : 0) + (trq >> 1)) ^ fswz<C>(xc)) + 8 * (trq & 1));
+                        const s16x4 t4 = lds_tr16(xst + (r * TW + xc) * PB + 16 * (((C == 32 ? 2 * cit : 0) + (trq >> 1)) ^ fswz<C>(xc)) + 8 * (trq & 1));
                         if (u == 0) lo = t4; else hi = t4;
                     }
                     const e16x8 xq = __builtin_bit_cast(e16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));

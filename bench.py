@@ -183,8 +183,9 @@ def family_table(events, n_steps, batch, mc, latent, bf16=False):
         f['gbyte_per_step'] += nbytes / 1e9
 
     for key, ev in events.items():
-        times = [s_.elapsed_time(e_) for s_, e_ in ev]
-        ms, calls = sum(times) / n_steps, len(times) / n_steps
+        times = [e_[0].elapsed_time(e_[1]) for e_ in ev]
+        # a call over 2 B clips (TimbreTrap.decode_pair runs the decoder that way) counts as two calls of the per-call work below
+        ms, calls = sum(times) / n_steps, sum((e_[2] / float(batch)) if (len(e_) > 2 and e_[2]) else 1.0 for e_ in ev) / n_steps
         parts = key.split('_')
         kind, direction, tag = parts[0], parts[1] if len(parts) > 1 else '', parts[-1]
         bwd = direction == 'bwd'
@@ -575,8 +576,10 @@ def main():
 
     if rank == 0:
         def avg_ms(ev):
-            times = [s_.elapsed_time(e_) for s_, e_ in ev]
-            return sum(times) / len(times), len(times)
+            # average duration of a call over args.batch clips: a call over 2 B clips (TimbreTrap.decode_pair: the decoder) counts as two
+            times = [e_[0].elapsed_time(e_[1]) for e_ in ev]
+            units = sum((e_[2] / float(args.batch)) if (len(e_) > 2 and e_[2]) else 1.0 for e_ in ev)
+            return sum(times) / units, int(round(units))
         # the fused residual block at the widest level (C = 16*mc channels, H = 65 rows)
         roof = None
         if events.get(key):

@@ -237,10 +237,13 @@ EVENT_KEYS = None
 
 
 class timed:
-    """with timed(key): <C-ABI call>  -- records a (start, end) event pair when EVENT_LOG is a dict."""
+    """with timed(key): <C-ABI call>  -- records a (start, end, clips) event triple when EVENT_LOG is a dict; ``clips`` = the batch of
+    that call (None: unknown) -- the train step runs its decoder over 2 B clips per call and its encoder over B, and bench.py prices a call
+    per clip."""
 
-    def __init__(self, key):
+    def __init__(self, key, clips=None):
         self.key = key
+        self.clips = clips
         self.start = None
 
     def __enter__(self):
@@ -255,7 +258,7 @@ class timed:
             import torch
             end = torch.cuda.Event(enable_timing=True)
             end.record()
-            EVENT_LOG.setdefault(self.key, []).append((self.start, end))
+            EVENT_LOG.setdefault(self.key, []).append((self.start, end, self.clips))
         return False
 
 

@@ -768,7 +768,7 @@ class Level16Fn(torch.autograd.Function):
             for i, d in enumerate(dilations):
                 w1, b1_, w2, b2 = params[4 * i: 4 * i + 4]
                 h1 = hids[i][b0:b1] if hids[i] is not None else None
-                with _hip.timed('wide_rb_fwd_C%d' % C):
+                with _hip.timed('wide_rb_fwd_C%d' % C, clips=b1 - b0):
                     check(lib.tt_wide_rb_fwd(ptr(cur), ptr(w1), ptr(b1_), ptr(w2), ptr(b2), ptr(outs[i][b0:b1]), ptr(h1), b1 - b0, C, H, T,
                                              d, st), 'tt_wide_rb_fwd')
                 cur = outs[i][b0:b1]
@@ -807,7 +807,7 @@ class Level16Fn(torch.autograd.Function):
             cols = list(zip(*[[targets[4 * i + j][0] for j in range(4)] for i in range(nb)]))      # dw1s, db1s, dw2s, db2s
             dil = (ctypes.c_int * nb)(*ctx.dilations)
             fn = lib.tt_wide_level_bwd_gated if ctx.gate else lib.tt_wide_level_bwd
-            with _hip.timed('wide_rb_bwd_C%d' % C):
+            with _hip.timed('wide_rb_bwd_C%d' % C, clips=B):
                 check(fn(nb, arr([saved[2 * i] for i in range(nb)]), arr([saved[2 * i + 1] for i in range(nb)]), ptr(g_all),
                          arr([params[4 * i] for i in range(nb)]), arr([params[4 * i + 2] for i in range(nb)]),
                          arr([params[4 * i + 3] for i in range(nb)]), ptr(dx), ptr(tmp[0]) if tmp else None,
@@ -822,7 +822,7 @@ class Level16Fn(torch.autograd.Function):
                 w1, b1_, w2, b2 = params[4 * i: 4 * i + 4]
                 (dw1, _), (db1, _), (dw2, _), (db2, _) = targets[4 * i: 4 * i + 4]
                 gx = dx[b0:b1] if i == 0 else tmp[i & 1][:b1 - b0]
-                with _hip.timed('wide_rb_bwd_C%d' % C):
+                with _hip.timed('wide_rb_bwd_C%d' % C, clips=b1 - b0):
                     if recompute:
                         xin = saved[i][b0:b1]
                         check(lib.tt_wide_rb_bwd_fused(ptr(xin), ptr(g), ptr(w1), ptr(b1_), ptr(w2), ptr(b2), ptr(gx), ptr(dw1), ptr(db1),
@@ -1718,13 +1718,14 @@ def _instrument(cls, name, keyfn):
         if _hip.EVENT_LOG is None:
             return fwd(ctx, *args)
         ctx._tt_key = keyfn(*args)
-        with _hip.timed('%s_fwd_%s' % (name, ctx._tt_key)):
+        ctx._tt_clips = args[0].size(0) if (torch.is_tensor(args[0]) and args[0].dim() >= 3) else None
+        with _hip.timed('%s_fwd_%s' % (name, ctx._tt_key), clips=ctx._tt_clips):
             return fwd(ctx, *args)
 
     def backward(ctx, *grads):
         if _hip.EVENT_LOG is None:
             return bwd(ctx, *grads)
-        with _hip.timed('%s_bwd_%s' % (name, getattr(ctx, '_tt_key', '?'))):
+        with _hip.timed('%s_bwd_%s' % (name, getattr(ctx, '_tt_key', '?')), clips=getattr(ctx, '_tt_clips', None)):
             return bwd(ctx, *grads)
     cls.forward = staticmethod(forward)
     cls.backward = staticmethod(backward)

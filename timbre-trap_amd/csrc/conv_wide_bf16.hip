@@ -1252,6 +1252,9 @@ __global__ __launch_bounds__(NT) void k_nrb_wgrad(const e16* __restrict__ x, con
 // (iii) phase 1's per-step index arithmetic (flat pixel -> row / column by division, six compares for "this tile's own pixel") is
 //       tile-independent: LDS offset and a packed (row, column) key are computed once per kernel, the tile contributes two scalars;
 // (iv)  one conversion of dA2 to 16 bits serves the matrix operand and the dW2 staging buffer (the compiler emitted both forms).
+// (Round 5, measured and dropped at C = 8: three workgroups per CU instead of two -- data-gradient weights read per tap from the LDS image instead
+// of held in 72 registers (142-157 registers), tiles of 12 / 12 / 8 rows so that three sets of images fit: 51.59 / 51.39 ms per step against
+// 51.64 / 51.21; 8-row tiles throughout: 52.16 / 51.94.  profiles/r05_nbf2_c8_occupancy_ab.txt)
 #ifndef TT_NBF2_MINW4
 #define TT_NBF2_MINW4 4          // C = 4: registers capped for four workgroups per CU (the LDS limit); 1 lets the compiler take 156 (three)
 #endif

@@ -541,17 +541,17 @@ __global__ __launch_bounds__(NT) void k_wrb_wgrad(const e16* __restrict__ x, con
 // dW1[co][ci][tap] += dA1 (x) x(+tap) by transpose reads of the same two images.  dA1 is read from HBM once instead of twice:
 // four tensor passes (dA1, dy, x | dx) for what took five, and one launch less.  No halo beyond D, no recomputation -- the vector
 // work is the sum of the two kernels minus one staging loop (PMC, round 3: both were parked on memory 40-67 % of their life).
-// Round 5 (XH = false): the x tile WITHOUT halo.  dW1[tap] = sum_q x[q] (x) dA1[q - off(tap)] indexes the weight gradient by the pixel
+// Round 5: the x tile WITHOUT halo (the halo.d form of rounds 3 / 4 is gone).  dW1[tap] = sum_q x[q] (x) dA1[q - off(tap)] indexes the weight gradient by the pixel
 // of x (the identity the strip kernel and k_nrb_bwd_fused use), and dA1 has its D halo anyway: the x image shrinks from
 // (TH + 2 D) x (TW + 2 D) to TH x TW pixels -- 25 / 41 / 52 % fewer staged bytes and DMA instructions at dilation 1 / 2 / 3, and at
 // C = 32 a third workgroup per CU at dilation 3 (68 -> 50 KB) and 8-row tiles instead of 6 at dilation 2 (55 -> 44 KB).
-template <int C, int D, int TH, int TW, bool XH> struct DXW {
+template <int C, int D, int TH, int TW> struct DXW {
     static constexpr int CG = C / 8, PB = C * 2;
     static constexpr int IR = TH + 2 * D, IW = TW + 2 * D;       // dA1 image: tile + D halo
     static constexpr int NP = IR * IW * CG;
     static constexpr int NPR = (NP + NT - 1) / NT * NT;
     static constexpr int IMG_BYTES = NPR * 16;
-    static constexpr int XR = XH ? IR : TH, XW = XH ? IW : TW;   // x image
+    static constexpr int XR = TH, XW = TW;                       // x image: the tile's own pixels
     static constexpr int XNP = XR * XW * CG;
     static constexpr int XNPR = (XNP + NT - 1) / NT * NT;
     static constexpr int X_BYTES = XNPR * 16;
@@ -561,17 +561,17 @@ template <int C, int D, int TH, int TW, bool XH> struct DXW {
     static_assert(TW % 32 == 0, "the K = 32 pixels of a weight-gradient product are 32 consecutive columns");
 };
 
-template <int C, int D, int TH, int TW, bool XH, bool GOUT = false>
+template <int C, int D, int TH, int TW, bool GOUT = false>
 __global__ __launch_bounds__(NT, (GOUT && C == 32) ? 3 : 2) void k_wrb_dxw(const e16* __restrict__ x, const e16* __restrict__ da1, const e16* __restrict__ dy,
                                                    const float* __restrict__ w1, e16* __restrict__ dx, float* __restrict__ part_w, int B,
                                                    int H, int T, int tiles_h, int tiles_t, int ntiles) {
-    using G = DXW<C, D, TH, TW, XH>;
+    using G = DXW<C, D, TH, TW>;
     using K = WK<C>;
     constexpr int NCT = K::NCT, NK = K::NK, NCH = K::NCH, PB = G::PB;
     typedef typename std::conditional<C == 32, e16x8, e16x4>::type vec_t;
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char* gs = smem;                                    // dA1 (with halo)
-    unsigned char* xs = smem + G::IMG_BYTES;                     // x   (XH: with halo; else the tile's own pixels)
+    unsigned char* xs = smem + G::IMG_BYTES;                     // x   (the tile's own pixels)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4, trj = n >> 2, trq = n & 3;
 
@@ -618,16 +618,13 @@ __global__ __launch_bounds__(NT, (GOUT && C == 32) ? 3 : 2) void k_wrb_dxw(const
             const bool ok = p < G::NP && (unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T;
             const long off = ib + ((long)h * T + t) * C + (s ^ fswz<C>(px)) * 8;
             glds16(ok ? da1 + off : zero, gs + (long)i * 16);
-            if constexpr (XH) glds16(ok ? x + off : zero, xs + (long)i * 16);
         }
-        if constexpr (!XH) {
-            for (int i = wave * 64; i < G::XNPR; i += NT) {
-                const int p = i + lane, q = p / G::CG, s = p - q * G::CG;
-                const int row = q / TW, px = q - row * TW;
-                const int h = h0 + row, t = t0 + px;
-                const bool ok = p < G::XNP && h < H && t < T;
-                glds16(ok ? x + ib + ((long)h * T + t) * C + (s ^ fswz<C>(px)) * 8 : zero, xs + (long)i * 16);
-            }
+        for (int i = wave * 64; i < G::XNPR; i += NT) {
+            const int p = i + lane, q = p / G::CG, s = p - q * G::CG;
+            const int row = q / TW, px = q - row * TW;
+            const int h = h0 + row, t = t0 + px;
+            const bool ok = p < G::XNP && h < H && t < T;
+            glds16(ok ? x + ib + ((long)h * T + t) * C + (s ^ fswz<C>(px)) * 8 : zero, xs + (long)i * 16);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -651,7 +648,6 @@ __global__ __launch_bounds__(NT, (GOUT && C == 32) ? 3 : 2) void k_wrb_dxw(const
             vec_t o;
             if constexpr (GOUT) {
                 // dx * ELU'(x) for the layer in front of the level (see k_nrb_bwd_fused): the lane's channels of x from the halo-free image
-                static_assert(!GOUT || !XH, "the gated form reads the halo-free x image");
                 // (the x read stays BEHIND the products and the residual: its registers on top of the live dy piece were 176 instead of 168,
                 // i.e. two workgroups per CU instead of three -- 0.343 instead of 0.236 ms per call)
                 float sum[NCH];
@@ -675,49 +671,25 @@ __global__ __launch_bounds__(NT, (GOUT && C == 32) ? 3 : 2) void k_wrb_dxw(const
 #pragma unroll
             for (int ch = ch0; ch < NCHK; ch += CHSTEP) {
                 s16x4 lo, hi;
-                if constexpr (!XH) {
-                    // indexed by the pixel of x: B = x at (r, 32 ch ..) of its halo-free image, A = dA1 at row r + (2 - kh) D, column (2 - kw) D + ..
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int xc = ch * 32 + 4 * g + trj + 16 * u;
-                        const s16x4 t4 = lds_tr16(xs + (r * TW + xc) * PB + 16 * (((C == 32 ? 2 * cit : 0) + (trq >> 1)) ^ fswz<C>(xc)) + 8 * (trq & 1));
-                        if (u == 0) lo = t4; else hi = t4;
-                    }
-                    const e16x8 xq = __builtin_bit_cast(e16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) {
-                        const int kh = k / 3, kw = k - 3 * kh;
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            const int cc = (2 - kw) * D + ch * 32 + 4 * g + trj + 16 * u;
-                            const s16x4 t4 = lds_tr16(gs + ((r + (2 - kh) * D) * G::IW + cc) * PB +
-                                                      16 * (((C == 32 ? 2 * aw : 0) + (trq >> 1)) ^ fswz<C>(cc)) + 8 * (trq & 1));
-                            if (u == 0) lo = t4; else hi = t4;
-                        }
-                        wacc[k] = mma32(__builtin_bit_cast(e16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)), xq, wacc[k]);
-                    }
-                    continue;
-                }
+                // indexed by the pixel of x: B = x at (r, 32 ch ..) of its halo-free image, A = dA1 at row r + (2 - kh) D, column (2 - kw) D + ..
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const int cc = D + ch * 32 + 4 * g + trj + 16 * u;
-                    const s16x4 t4 = lds_tr16(gs + ((r + D) * G::IW + cc) * PB +
-                                              16 * (((C == 32 ? 2 * aw : 0) + (trq >> 1)) ^ fswz<C>(cc)) + 8 * (trq & 1));
+                    const int xc = ch * 32 + 4 * g + trj + 16 * u;
+                    const s16x4 t4 = lds_tr16(xs + (r * TW + xc) * PB + 16 * (((C == 32 ? 2 * cit : 0) + (trq >> 1)) ^ fswz<C>(xc)) + 8 * (trq & 1));
                     if (u == 0) lo = t4; else hi = t4;
                 }
-                const e16x8 ga = __builtin_bit_cast(e16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                const e16x8 xq = __builtin_bit_cast(e16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
                     const int kh = k / 3, kw = k - 3 * kh;
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
-                        const int xc = kw * D + ch * 32 + 4 * g + trj + 16 * u;
-                        const s16x4 t4 = lds_tr16(xs + ((r + kh * D) * G::IW + xc) * PB +
-                                                  16 * (((C == 32 ? 2 * cit : 0) + (trq >> 1)) ^ fswz<C>(xc)) + 8 * (trq & 1));
+                        const int cc = (2 - kw) * D + ch * 32 + 4 * g + trj + 16 * u;
+                        const s16x4 t4 = lds_tr16(gs + ((r + (2 - kh) * D) * G::IW + cc) * PB +
+                                                  16 * (((C == 32 ? 2 * aw : 0) + (trq >> 1)) ^ fswz<C>(cc)) + 8 * (trq & 1));
                         if (u == 0) lo = t4; else hi = t4;
                     }
-                    const e16x8 xq = __builtin_bit_cast(e16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-                    wacc[k] = mma32(ga, xq, wacc[k]);
+                    wacc[k] = mma32(__builtin_bit_cast(e16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)), xq, wacc[k]);
                 }
             }
         }
@@ -750,16 +722,7 @@ int launch_conv(const e16* x, const float* w1, const float* b1, const float* w2,
     using G = WT<C, D>;
     const int tiles_h = (H + G::TH - 1) / G::TH, tiles_t = (T + G::TW - 1) / G::TW, ntiles = B * tiles_h * tiles_t;
     static const int per_cu = tt_tune("TTRAP_WIDE_PER_CU", 4);
-    static const int w3 = tt_tune("TTRAP_WCONV_W3", 0);
-    if (C == 32 && MODE == 0 && w3) {
-        static AttrOnce once3;
-        auto kern = k_wrb_conv<C, D, MODE, SAVE, (C == 32 && MODE == 0) ? 3 : 2>;
-        if (int rc = raise_lds(kern, G::LDS_BYTES, once3)) return rc;
-        hipLaunchKernelGGL(kern, dim3(grid_for(ntiles, G::LDS_BYTES, per_cu)), dim3(NT), G::LDS_BYTES, st, x, w1, b1, w2, b2, res, y,
-                           h1, B, H, T, tiles_h, tiles_t, ntiles);
-        TT_LAUNCH_CHECK();
-        return 0;
-    }
+    // (a forward kernel capped at 168 registers for a third workgroup per CU at C = 32 was measured in round 3 and bought nothing: DESIGN.md 7b)
     static AttrOnce once;
     auto kern = k_wrb_conv<C, D, MODE, SAVE, 2>;
     if (int rc = raise_lds(kern, G::LDS_BYTES, once)) return rc;
@@ -774,27 +737,27 @@ int launch_conv(const e16* x, const float* w1, const float* b1, const float* w2,
 
 template <int C> constexpr long dump_floats() { return (long)MAX_A_WG * WA<C>::DUMP + (long)MAX_W_WG * 4 * 9 * (C / 16) * 256; }
 
-template <int C, int D, int TH, int TW, bool XH>
+template <int C, int D, int TH, int TW>
 int launch_dxw(const e16* x, const e16* da1, const e16* dy, const float* w1, e16* dx, float* part_w, float* part_a, int grid_a,
                float* dw1, float* db1, float* dw2, float* db2, int B, int H, int T, hipStream_t st) {
-    using X = DXW<C, D, TH, TW, XH>;
+    using X = DXW<C, D, TH, TW>;
     const int tiles_h = (H + TH - 1) / TH, tiles_t = (T + TW - 1) / TW, ntiles = B * tiles_h * tiles_t;
     static const int x_per_cu = tt_tune("TTRAP_DXW_PER_CU", C == 32 ? 3 : 4);      // registers: 165 / 113 VGPRs
     int gx = grid_for(ntiles, X::LDS_BYTES, x_per_cu);
     if (gx > MAX_W_WG) gx = MAX_W_WG;
     bool gated = false;
-    if constexpr (D == 1 && !XH) gated = ttx_gate_dx == 1;       // a level's first block: dx leaves gated (k_nrb_bwd_fused, GOUT)
+    if constexpr (D == 1) gated = ttx_gate_dx == 1;              // a level's first block: dx leaves gated (k_nrb_bwd_fused, GOUT)
     if (gated) {
-        if constexpr (D == 1 && !XH) {
+        if constexpr (D == 1) {
             static AttrOnce once_g;
-            auto kg = k_wrb_dxw<C, D, TH, TW, XH, true>;
+            auto kg = k_wrb_dxw<C, D, TH, TW, true>;
             if (int rc = raise_lds(kg, X::LDS_BYTES, once_g)) return rc;
             hipLaunchKernelGGL(kg, dim3(gx), dim3(NT), X::LDS_BYTES, st, x, da1, dy, w1, dx, part_w, B, H, T, tiles_h, tiles_t, ntiles);
             ttx_gate_dx = 2;
         }
     } else {
         static AttrOnce once_x;
-        auto kx = k_wrb_dxw<C, D, TH, TW, XH, false>;
+        auto kx = k_wrb_dxw<C, D, TH, TW, false>;
         if (int rc = raise_lds(kx, X::LDS_BYTES, once_x)) return rc;
         hipLaunchKernelGGL(kx, dim3(gx), dim3(NT), X::LDS_BYTES, st, x, da1, dy, w1, dx, part_w, B, H, T, tiles_h, tiles_t, ntiles);
     }
@@ -849,11 +812,9 @@ int launch_bwd(const e16* x, const e16* h1, const e16* dy, const float* w1, cons
         // dilation 2, 3 (0.50 ms: two workgroups per CU); 16 x 32 tiles at C = 16: 0.431 / 0.439 / 0.496 ms)
         // C = 32, dilation 2: two images of 12 x 36 pixels are 55 KB = two workgroups per CU; 6-row tiles (49 KB) admit the third:
         // 0.456 -> 0.427 ms per call.  Dilation 3 (68 KB; 4-row tiles 49 KB): no change, 0.467 ms either way -- 8 rows kept.
-        // Round 5: the x tile without halo (DXW, XH = false): 8-row tiles fit three workgroups per CU at every dilation
-        static const int xh = tt_tune("TTRAP_DXW_XH", 0);       // 1: the round-3 / 4 form (x with halo, 6-row tiles at C = 32 / dilation 2)
-        if (!xh) return launch_dxw<C, D, 8, 32, false>(x, da1, dy, w1, dx, part_w, part_a, grid, dw1, db1, dw2, db2, B, H, T, st);
-        if (C == 32 && D == 2) return launch_dxw<C, D, 6, 32, true>(x, da1, dy, w1, dx, part_w, part_a, grid, dw1, db1, dw2, db2, B, H, T, st);
-        return launch_dxw<C, D, 8, 32, true>(x, da1, dy, w1, dx, part_w, part_a, grid, dw1, db1, dw2, db2, B, H, T, st);
+        // Round 5: the x tile without halo: 8-row tiles fit three workgroups per CU at every dilation
+        // (the round-3 / 4 form -- x with halo, 6-row tiles at C = 32 / dilation 2 -- is gone: profiles/r05_dxw_xh_x3n_shapes_ab.txt)
+        return launch_dxw<C, D, 8, 32>(x, da1, dy, w1, dx, part_w, part_a, grid, dw1, db1, dw2, db2, B, H, T, st);
     }
     // data gradient
     if (int rc = launch_conv<C, D, 1, false>(da1, w1, nullptr, nullptr, nullptr, dy, dx, nullptr, B, H, T, st)) return rc;

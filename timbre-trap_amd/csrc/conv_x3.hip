@@ -33,6 +33,96 @@ __device__ __forceinline__ void split(float v, e16& hi, e16& lo) {
 }
 __device__ __forceinline__ float join(e16 hi, e16 lo) { return __builtin_fmaf((float)lo, LO_INV, (float)hi); }
 
+// The same two steps on PAIRS, with the mixed-precision fma spelled out (round 5).  The kernels below are bound by vector issue, and the
+// vectoriser turns the scalar forms above into packed fp32 arithmetic around explicit conversions -- hi back to fp32 (one instruction per
+// element), packed fma, packed conversion of lo: three instructions per split element, and two conversions + an fma per joined element.
+// v_fma_mix* takes the f16 halves as they are: split = packed conversion of hi (1/2) + packed v * 2^11 (1/2) + one v_fma_mix{lo,hi}_f16 per
+// element = 2; join = ONE v_fma_mix_f32 per element.  The arithmetic is the scalar forms' (an fp32 fma, then one rounding to f16).
+#ifndef TT_X3_MIX
+#define TT_X3_MIX 1
+#endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef e16 e16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// TOMM: the halves go straight into a matrix instruction as an operand.  The compiler's hazard recogniser does not see an asm block as a vector
+// instruction, so the two wait states a matrix instruction needs behind a vector write of one of its sources are spelled out too (without
+// them the C = 16 and C = 4 kernels, whose products follow the split most closely, read stale registers: tests/test_gpu_x3.py caught it).
+template <bool TOMM>
+__device__ __forceinline__ void split2(float v0, float v1, unsigned& hi2, unsigned& lo2) {
+    const f32x2 v = f32x2{v0, v1};
+    hi2 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, e16x2));
+    const f32x2 sc = v * LO_SCALE;
+    const float nk = -LO_SCALE;
+    unsigned d;
+    if constexpr (TOMM)
+        asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixhi_f16 %0, %1, %2, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "s_nop 1"
+            : "=&v"(d) : "v"(hi2), "v"(nk), "v"(sc.x), "v"(sc.y));
+    else
+        asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixhi_f16 %0, %1, %2, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+            : "=&v"(d) : "v"(hi2), "v"(nk), "v"(sc.x), "v"(sc.y));
+    lo2 = d;
+}
+__device__ __forceinline__ void join2(unsigned hi2, unsigned lo2, float& o0, float& o1) {
+    const float k = LO_INV;
+    asm("v_fma_mix_f32 %0, %2, %4, %3 op_sel_hi:[1,0,1]\n\t"
+        "v_fma_mix_f32 %1, %2, %4, %3 op_sel:[1,0,1] op_sel_hi:[1,0,1]"
+        : "=&v"(o0), "=&v"(o1) : "v"(lo2), "v"(hi2), "v"(k));
+}
+template <bool TOMM = false>
+__device__ __forceinline__ void split_v(const float (&v)[4], e16x4& hi, e16x4& lo) {
+#if TT_X3_MIX
+    u32x2 h, l;
+    unsigned a, b;
+    split2<TOMM>(v[0], v[1], a, b); h.x = a; l.x = b;
+    split2<TOMM>(v[2], v[3], a, b); h.y = a; l.y = b;
+    hi = __builtin_bit_cast(e16x4, h); lo = __builtin_bit_cast(e16x4, l);
+#else
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { e16 a_, b_; split(v[j], a_, b_); hi[j] = a_; lo[j] = b_; }
+#endif
+}
+template <bool TOMM = false>
+__device__ __forceinline__ void split_v(const float (&v)[8], e16x8& hi, e16x8& lo) {
+#if TT_X3_MIX
+    u32x4 h, l;
+    unsigned a, b;
+    split2<TOMM>(v[0], v[1], a, b); h.x = a; l.x = b;
+    split2<TOMM>(v[2], v[3], a, b); h.y = a; l.y = b;
+    split2<TOMM>(v[4], v[5], a, b); h.z = a; l.z = b;
+    split2<TOMM>(v[6], v[7], a, b); h.w = a; l.w = b;
+    hi = __builtin_bit_cast(e16x8, h); lo = __builtin_bit_cast(e16x8, l);
+#else
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { e16 a_, b_; split(v[j], a_, b_); hi[j] = a_; lo[j] = b_; }
+#endif
+}
+__device__ __forceinline__ void join_v(e16x4 hi, e16x4 lo, float (&o)[4]) {
+#if TT_X3_MIX
+    const u32x2 h = __builtin_bit_cast(u32x2, hi), l = __builtin_bit_cast(u32x2, lo);
+    join2(h.x, l.x, o[0], o[1]);
+    join2(h.y, l.y, o[2], o[3]);
+#else
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = join(hi[j], lo[j]);
+#endif
+}
+__device__ __forceinline__ void join_v(e16x8 hi, e16x8 lo, float (&o)[8]) {
+#if TT_X3_MIX
+    const u32x4 h = __builtin_bit_cast(u32x4, hi), l = __builtin_bit_cast(u32x4, lo);
+    join2(h.x, l.x, o[0], o[1]);
+    join2(h.y, l.y, o[2], o[3]);
+    join2(h.z, l.z, o[4], o[5]);
+    join2(h.w, l.w, o[6], o[7]);
+#else
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = join(hi[j], lo[j]);
+#endif
+}
+
 template <int C> struct XL {
     static constexpr int PB = 4 * C;                             // bytes per pixel: [hi C][lo C]
     static constexpr int PP = PB / 16;                           // 16-byte pieces per pixel (C = 32: 8, C = 16: 4)
@@ -250,12 +340,13 @@ __global__ __launch_bounds__((XT<C, D>::NTH), (XT<C, D>::MINW)) void k_x3_conv(c
             float out[NCH];
             if constexpr (C == 32) {
                 e16x8 hh, hl;
+                float hv[8];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    e16 a_, b_;
-                    split(elu1(__builtin_fmaf(al[rr][0][j], LO_INV, am[rr][0][j])), a_, b_); hh[j] = a_; hl[j] = b_;
-                    split(elu1(__builtin_fmaf(al[rr][1][j], LO_INV, am[rr][1][j])), a_, b_); hh[4 + j] = a_; hl[4 + j] = b_;
+                    hv[j] = elu1(__builtin_fmaf(al[rr][0][j], LO_INV, am[rr][0][j]));
+                    hv[4 + j] = elu1(__builtin_fmaf(al[rr][1][j], LO_INV, am[rr][1][j]));
                 }
+                split_v<true>(hv, hh, hl);
                 f32x4 zm[2], zl[2];
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
@@ -266,16 +357,16 @@ __global__ __launch_bounds__((XT<C, D>::NTH), (XT<C, D>::MINW)) void k_x3_conv(c
                 for (int ct = 0; ct < 2; ++ct) zl[ct] = mma32(A2L[ct], hh, zl[ct]);
                 const e16x8 ch = *reinterpret_cast<const e16x8*>(pxc + 16 * (g ^ swc));
                 const e16x8 cl = *reinterpret_cast<const e16x8*>(pxc + 16 * ((CG + g) ^ swc));
+                float res[8];
+                join_v(ch, cl, res);
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    out[j] = elu1(__builtin_fmaf(zl[j >> 2][j & 3], LO_INV, zm[j >> 2][j & 3])) + join(ch[j], cl[j]);
+                for (int j = 0; j < 8; ++j) out[j] = elu1(__builtin_fmaf(zl[j >> 2][j & 3], LO_INV, zm[j >> 2][j & 3])) + res[j];
             } else {
                 e16x4 hh, hl;
+                float hv[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    e16 a_, b_;
-                    split(elu1(__builtin_fmaf(al[rr][0][j], LO_INV, am[rr][0][j])), a_, b_); hh[j] = a_; hl[j] = b_;
-                }
+                for (int j = 0; j < 4; ++j) hv[j] = elu1(__builtin_fmaf(al[rr][0][j], LO_INV, am[rr][0][j]));
+                split_v<true>(hv, hh, hl);
                 const s16x4 a2h = *reinterpret_cast<const s16x4*>(w2img + (long)lane * 8);
                 const s16x4 a2l = *reinterpret_cast<const s16x4*>(w2img + (long)(64 + lane) * 8);
                 const f32x4 zm = mma16(a2h, __builtin_bit_cast(s16x4, hh), f32x4{b2r[0], b2r[1], b2r[2], b2r[3]});
@@ -283,8 +374,10 @@ __global__ __launch_bounds__((XT<C, D>::NTH), (XT<C, D>::MINW)) void k_x3_conv(c
                 zl = mma16(a2l, __builtin_bit_cast(s16x4, hh), zl);
                 const e16x4 ch = *reinterpret_cast<const e16x4*>(pxc + 16 * ((g >> 1) ^ swc) + 8 * (g & 1));
                 const e16x4 cl = *reinterpret_cast<const e16x4*>(pxc + 16 * ((CG + (g >> 1)) ^ swc) + 8 * (g & 1));
+                float res[4];
+                join_v(ch, cl, res);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) out[j] = elu1(__builtin_fmaf(zl[j], LO_INV, zm[j])) + join(ch[j], cl[j]);
+                for (int j = 0; j < 4; ++j) out[j] = elu1(__builtin_fmaf(zl[j], LO_INV, zm[j])) + res[j];
             }
             if (!valid) continue;
             if constexpr (PLANAR) {
@@ -294,8 +387,7 @@ __global__ __launch_bounds__((XT<C, D>::NTH), (XT<C, D>::MINW)) void k_x3_conv(c
             } else {
                 e16* y = static_cast<e16*>(yout);
                 typename std::conditional<C == 32, e16x8, e16x4>::type oh, ol;
-#pragma unroll
-                for (int j = 0; j < NCH; ++j) { e16 a_, b_; split(out[j], a_, b_); oh[j] = a_; ol[j] = b_; }
+                split_v(out, oh, ol);
                 *reinterpret_cast<decltype(oh)*>(y + pix * 2 * C + NCH * g) = oh;
                 *reinterpret_cast<decltype(ol)*>(y + pix * 2 * C + C + NCH * g) = ol;
             }
@@ -553,12 +645,10 @@ __global__ __launch_bounds__(256, C == 8 ? TT_X3N_MINW8 : 3) void k_x3n_conv(con
                     const int col = sp * SPAN + n + 16 * slot;   // this lane's pixel of the row
                     const int t = t0 + col;
                     e16x4 hh, hl;
+                    float hv[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        e16 a_, b_;
-                        split(elu1(__builtin_fmaf(al[rr][sp][r], LO_INV, am[rr][sp][r])), a_, b_);
-                        hh[r] = a_; hl[r] = b_;
-                    }
+                    for (int r = 0; r < 4; ++r) hv[r] = elu1(__builtin_fmaf(al[rr][sp][r], LO_INV, am[rr][sp][r]));
+                    split_v<true>(hv, hh, hl);
                     const f32x4 zm = mm(A2H, __builtin_bit_cast(s16x4, hh), f32x4{b2r[0], b2r[1], b2r[2], b2r[3]});
                     f32x4 zl;
                     if constexpr (C == 8) {
@@ -570,9 +660,10 @@ __global__ __launch_bounds__(256, C == 8 ? TT_X3N_MINW8 : 3) void k_x3n_conv(con
                     s16x4 ch_, cl_;
                     ldpx(r0 + rr + D, col + D, ch_, cl_);
                     const e16x4 c_h = __builtin_bit_cast(e16x4, ch_), c_l = __builtin_bit_cast(e16x4, cl_);
-                    float out[4];
+                    float out[4], res[4];
+                    join_v(c_h, c_l, res);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) out[r] = elu1(__builtin_fmaf(zl[r], LO_INV, zm[r])) + join(c_h[r], c_l[r]);
+                    for (int r = 0; r < 4; ++r) out[r] = elu1(__builtin_fmaf(zl[r], LO_INV, zm[r])) + res[r];
                     if (t >= T) continue;
                     if constexpr (POUT) {
                         float* yp = static_cast<float*>(yout) + (((long)b * C + c0) * H + h) * T + t;
@@ -581,8 +672,7 @@ __global__ __launch_bounds__(256, C == 8 ? TT_X3N_MINW8 : 3) void k_x3n_conv(con
                     } else {
                         e16* y = static_cast<e16*>(yout) + (((long)b * H + h) * T + t) * 2 * C;
                         e16x4 oh, ol;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) { e16 a_, b_; split(out[r], a_, b_); oh[r] = a_; ol[r] = b_; }
+                        split_v(out, oh, ol);
                         if constexpr (C == 4) {
                             *reinterpret_cast<e16x8*>(y) = __builtin_shufflevector(oh, ol, 0, 1, 2, 3, 4, 5, 6, 7);
                         } else {

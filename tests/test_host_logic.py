@@ -104,3 +104,32 @@ def test_cqt_pickles_and_forks_without_touching_hip():
     model = TimbreTrap(22050, 9, 60, 3)
     m2 = pickle.loads(pickle.dumps(model))
     assert m2.sliCQ.n_bins == 540
+
+
+def test_gate_link_promises():
+    """ops.GateLink (the forward-time handshake that lets a layer's backward take its gradient already multiplied by its ELU derivative):
+    nothing is gated until a consumer promises; a promise that depends on another link's (the first transposed layer gates its dx only in
+    its pregated form, i.e. when the level behind it gates in turn) follows that link at the time it is READ; ops.PREGATE = False hands
+    out no links; a tap on an unlinked tensor is the tensor itself."""
+    from timbre_trap.framework import ops
+    link = ops.GateLink()
+    assert not link.producer and not link.gated
+    link.gated = True
+    assert link.gated
+    down = ops.GateLink()
+    link.depends = down
+    assert not link.gated                                    # the level behind has not promised
+    down.gated = True
+    assert link.gated
+    down.gated = False
+    assert not link.gated
+    saved = ops.PREGATE
+    try:
+        ops.PREGATE = False
+        assert ops.gate_link() is None
+        ops.PREGATE = True
+        assert isinstance(ops.gate_link(), ops.GateLink)
+    finally:
+        ops.PREGATE = saved
+    y = torch.zeros(1, 4, 3, 8, requires_grad=True)
+    assert ops.gate_tap(y, None) is y and ops.gate_tap(y, ops.GateLink()) is y      # no producer marked: nothing to do

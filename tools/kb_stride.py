@@ -40,6 +40,12 @@ def main():
         print('tconv C%-2d fwd %.3f ms  %.2f TB/s' % (C, t, gb / t))
         t = timeit(lambda: check(lib.tt_tconv16_bwd(ptr(y), ptr(x), ptr(dx), ptr(w), ptr(dy), ptr(dw), ptr(dbt), ptr(ws), B, C, Ho, T, p, st), 'b'))
         print('tconv C%-2d bwd %.3f ms' % (C, t))
+        # round 5: the same two backward passes from a gradient that arrives already gated (no read of the saved output)
+        t = timeit(lambda: check(lib.tt_sconv16_bwd_pregated(ptr(x), ptr(dy), ptr(w), ptr(dx), ptr(dw), ptr(db), ptr(ws), B, C, H, T, st), 'b'))
+        print('sconv C%-2d bwd pregated %.3f ms' % (C, t))
+        t = timeit(lambda: check(lib.tt_tconv16_bwd_pregated(ptr(y), ptr(dx), ptr(w), ptr(dy), ptr(dw), ptr(dbt), ptr(ws), B, C, Ho, T, p,
+                                                              1 if C in (16, 32) else 0, st), 'b'))
+        print('tconv C%-2d bwd pregated %.3f ms' % (C, t))
 
 
 if __name__ == '__main__':

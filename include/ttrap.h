@@ -303,7 +303,8 @@ int tt_latent16_wgrad(const float* z, int Dz, float fill, const void* g, const v
 /* The 3x3 boundary convolutions where fp32 planar tensors meet the bf16 channels-last interior (csrc/conv_edge_bf16.hip), for
  * C0 = 4 first-level channels (model_complexity 2):
  *   tt_convin16_fwd   Encoder.convin (modules.py:433): x (B,2,H,T) fp32 -> y = ELU(conv3x3 + b) as cl16 (B,4,H,T); w (4,2,3,3)
- *   tt_convin16_bwd   from x, the saved output y and dy (cl16): dw, db (+=), dx (B,2,H,T) fp32 (written; may be NULL)
+ *   tt_convin16_bwd   from x, the saved output y and dy (cl16): dw, db (+=), dx (B,2,H,T) fp32 (written; may be NULL); y == NULL: dy is
+ *                     already dy * ELU'(y), as tt_wide_level_bwd_gated of the first level leaves it -- the saved output is not read
  *   tt_convout16_fwd  Decoder.convout (modules.py:560): x cl16 (B,4,H,T) -> y (B,2,H,T) fp32 = conv3x3 + b; w (2,4,3,3)
  *   tt_convout16_bwd  from x and dy (B,2,H,T) fp32: dx cl16 (written), dw, db (+=)
  * ws: tt_edge16_scratch_bytes() bytes (per-workgroup partial gradients).  fp32 arithmetic; only the cl16 tensors are bf16. */

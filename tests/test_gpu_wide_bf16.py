@@ -762,6 +762,18 @@ def test_edge_convs(shape):
     assert _rel(xd.grad.cpu().double(), F.conv_transpose2d(g, w.double(), padding=1)) < 1e-5
     assert _rel(wd.grad.cpu().double(), torch.nn.grad.conv2d_weight(x.double(), w.shape, g, padding=1)) < 1e-5
     assert _rel(bd.grad.cpu().double(), g.sum((0, 2, 3))) < 1e-5
+    # the same backward from a gradient that arrives already gated (ops.GateLink with the first level): the saved output is not read
+    link = ops.GateLink()
+    xd2, wd2, bd2 = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    y2 = ops.ConvIn16Fn.apply(xd2, wd2, bd2, link)
+    assert link.producer and torch.equal(y2.detach(), y.detach())
+    link.gated = True
+    gpre = _cl16(g.float())
+    g_p = _f64(gpre)
+    y2.backward(gpre)
+    assert _rel(xd2.grad.cpu().double(), F.conv_transpose2d(g_p, w.double(), padding=1)) < 1e-5
+    assert _rel(wd2.grad.cpu().double(), torch.nn.grad.conv2d_weight(x.double(), w.shape, g_p, padding=1)) < 1e-5
+    assert _rel(bd2.grad.cpu().double(), g_p.sum((0, 2, 3))) < 1e-5
 
     x4 = _rand(B, 4, H, T, seed=5)
     w2, b2 = _rand(2, 4, 3, 3, seed=6, scale=0.3), _rand(2, seed=7, scale=0.2)

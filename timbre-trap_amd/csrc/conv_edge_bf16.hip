@@ -320,7 +320,8 @@ __global__ __launch_bounds__(NT) void k_cin_fwd(const float* __restrict__ x, con
 
 // dW[co][ci][k] = sum g[co][p] x[ci][p + k];  db[co] = sum g[co];  dx[ci][p] = sum_{co,k} W[co][ci][k] g[co][p - k]
 // (g and x are zero outside the image in LDS, so only the stores are masked)
-template <bool DX, bool VEC>
+// PRE: dy arrives already gated (the first level's backward left dy * ELU'(y): tt_wide_level_bwd_gated) -- y is not read
+template <bool DX, bool VEC, bool PRE = false>
 __global__ __launch_bounds__(NT, 2) void k_cin_bwd(const float* __restrict__ x, const e16* __restrict__ y, const e16* __restrict__ dy,
                                                  const float* __restrict__ w, float* __restrict__ dx, float* __restrict__ part,
                                                  int H, int T, int tiles_h, int tiles_t, int ntiles, float unscale) {
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(NT, 2) void k_cin_bwd(const float* __restrict__ x, 
         accb[p] = splat2(0.f);
     }
     StagePlanar<2, VEC> sx;
-    StageCl4<true> sg;
+    StageCl4<!PRE> sg;
     sx.init(H, T, tid); sg.init(T, tid);
     if (blockIdx.x < ntiles) {
         const TileCtx t0 = tile_ctx(blockIdx.x, tiles_h, tiles_t, ntiles, H, T);
@@ -602,14 +603,19 @@ int tt_convin16_fwd(const float* x, const float* w, const float* b, void* y, int
 
 int tt_convin16_bwd(const float* x, const void* y, const void* dy, const float* w, float* dx, float* dw, float* db, void* ws, int B,
                     int H, int T, void* stream) {
-    if (!x || !y || !dy || !w || !dw || !db || !ws || !edge_ok(B, H, T)) return TT_E_BADARG;
+    if (!x || !dy || !w || !dw || !db || !ws || !edge_ok(B, H, T)) return TT_E_BADARG;       // y == NULL: dy is already gated
     int th, tt, n; edge_tiles(B, H, T, th, tt, n);
     const int grid = edge_grid(n);
     hipStream_t st = tt_stream(stream);
     const bool vec = T % 4 == 0;
-#define CIN_BWD(DX_, V_) hipLaunchKernelGGL((k_cin_bwd<DX_, V_>), dim3(grid), dim3(NT), 0, st, x, (const e16*)y, (const e16*)dy, w, dx, (float*)ws, H, T, th, tt, n, tt_loss_unscale())
-    if (dx) { if (vec) CIN_BWD(true, true); else CIN_BWD(true, false); }
-    else { if (vec) CIN_BWD(false, true); else CIN_BWD(false, false); }
+#define CIN_BWD(DX_, V_, P_) hipLaunchKernelGGL((k_cin_bwd<DX_, V_, P_>), dim3(grid), dim3(NT), 0, st, x, (const e16*)y, (const e16*)dy, w, dx, (float*)ws, H, T, th, tt, n, tt_loss_unscale())
+    if (y) {
+        if (dx) { if (vec) CIN_BWD(true, true, false); else CIN_BWD(true, false, false); }
+        else { if (vec) CIN_BWD(false, true, false); else CIN_BWD(false, false, false); }
+    } else {
+        if (dx) { if (vec) CIN_BWD(true, true, true); else CIN_BWD(true, false, true); }
+        else { if (vec) CIN_BWD(false, true, true); else CIN_BWD(false, false, true); }
+    }
 #undef CIN_BWD
     TT_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_edge_reduce, dim3(2), dim3(1024), 0, st, (const float*)ws, grid, dw, db, 4, tt_loss_unscale());

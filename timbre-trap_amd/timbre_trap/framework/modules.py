@@ -140,13 +140,13 @@ class Encoder(nn.Module):
     def forward(self, coefficients):
         """returns (latents (B,D,T), [5 embeddings], {})."""
         c = self.convin[0]
-        embeddings = [ops.conv(coefficients, c.weight, c.bias, ConvCfg(3, 3, 1, 1, 1, 1, 'conv', 0, ACT_ELU))]
         blocks = (self.block1, self.block2, self.block3, self.block4)
         # the output of a block's strided layer is the next block's level input AND an embedding handed to the caller: the level's backward
         # hands the strided layer its gradient already gated (ops.GateLink), the caller's copy goes through ops.gate_tap
-        # (the last one: between the last strided layer and the latent head)
-        links = [None] + [ops.gate_link() if torch.is_grad_enabled() else None for _ in blocks]
-        raw = embeddings[0]
+        # (the first one: between convin and the first level; the last one: between the last strided layer and the latent head)
+        links = [ops.gate_link() if torch.is_grad_enabled() else None for _ in range(len(blocks) + 1)]
+        raw = ops.conv(coefficients, c.weight, c.bias, ConvCfg(3, 3, 1, 1, 1, 1, 'conv', 0, ACT_ELU), link=links[0])
+        embeddings = [ops.gate_tap(raw, links[0])]
         for i, block in enumerate(blocks):
             # inside ops.x3_chain_scope (embeddings dropped by the caller): a block whose successor starts with a split-operand level
             # hands its output over in that layout

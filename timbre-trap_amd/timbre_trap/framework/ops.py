@@ -253,11 +253,11 @@ class ConvFn(torch.autograd.Function):
         return dx, rw, rb, None
 
 
-def conv(x, w, b, cfg):
+def conv(x, w, b, cfg, link=None):
     same3 = (cfg.kind == 'conv' and (cfg.KH, cfg.KW, cfg.stride, cfg.dil, cfg.pad_h, cfg.pad_w) == (3, 3, 1, 1, 1, 1) and b is not None
              and x.dim() == 4 and x.size(3) % 2 == 0 and FUSED_RESBLOCK and x.size(2) * x.size(3) * 4 < 2 ** 31)
     if same3 and cfg.act == ACT_ELU and w.shape == (4, 2, 3, 3) and not is_cl16(x) and cl16_mode():
-        return ConvIn16Fn.apply(x, w, b)                         # Encoder.convin feeding the bf16 channels-last interior
+        return ConvIn16Fn.apply(x, w, b, link)                   # Encoder.convin feeding the bf16 channels-last interior
     if same3 and cfg.act == ACT_NONE and w.shape == (2, 4, 3, 3) and is_cl16(x):
         return ConvOut16Fn.apply(x, w, b)                        # Decoder.convout leaving it
     x = to_planar32(x)
@@ -582,13 +582,16 @@ class ConvIn16Fn(torch.autograd.Function):
     """Encoder.convin (3x3, 2 -> 4, ELU): fp32 planar coefficients -> cl16 (csrc/conv_edge_bf16.hip)."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, link=None):
         _hip.require_cuda(x, w)
         x = _f32c(x)
         B, _, H, T = x.shape
         y = new_cl16(B, 4, H, T, x.device, cl16_dtype())
         check(lib16(y).tt_convin16_fwd(ptr(x), ptr(w), ptr(b), ptr(y), B, H, T, stream_ptr()), 'tt_convin16_fwd')
         ctx.params = (w, b)
+        ctx.link = link                                          # GateLink with the first level (its backward may hand dy back gated)
+        if link is not None:
+            link.producer = True
         ctx.save_for_backward(x, w, y)
         return y
 
@@ -601,10 +604,11 @@ class ConvIn16Fn(torch.autograd.Function):
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         (dw, r1), (db, r2) = (_grad_target(t) for t in ctx.params)
         ws = torch.empty(lib.tt_edge16_scratch_bytes(), dtype=torch.uint8, device=x.device)
+        pre = ctx.link is not None and ctx.link.gated           # dy arrives as dy * ELU'(y): y is not read
         with loss_scaled(y.dtype):
-            check(lib.tt_convin16_bwd(ptr(x), ptr(y), ptr(g), ptr(w), ptr(dx), ptr(dw), ptr(db), ptr(ws), B, H, T, stream_ptr()),
+            check(lib.tt_convin16_bwd(ptr(x), None if pre else ptr(y), ptr(g), ptr(w), ptr(dx), ptr(dw), ptr(db), ptr(ws), B, H, T, stream_ptr()),
                   'tt_convin16_bwd')
-        return dx, r1, r2
+        return dx, r1, r2, None
 
 
 class ConvOut16Fn(torch.autograd.Function):

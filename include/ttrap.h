@@ -381,6 +381,18 @@ int tt_sqdiff_bwd(const float* a, const float* b, const float* gscale, float sca
  * NULL; all pointers 16-byte aligned. */
 int tt_sqdiff2_bwd(const float* a1, const float* a2, const float* b, const float* g1, const float* g2, float scale, float* da1,
                    float* da2, float* db, int64_t n, void* stream);
+/* The loss(es) AND the gradient(s) in one pass (round 5): the same sums as tt_sqdiff_sum (bit-identical values), and, where a pointer is
+ * given, da = 2 scale (a - b), db = -da [tt_sqdiff2_sum_grad: da1, da2 for the two terms against the same b, db = -(da1 + da2);
+ * partials: 2048 doubles] -- the gradient for an incoming scalar of 1.  The backward pass is then tt_sqdiff_rescale /
+ * tt_sqdiff2_rescale with the incoming scalar(s) on the device: every workgroup reads them and returns when they are 1 (the loss enters
+ * the total as it is, train.py:453-466), otherwise the stored gradients are multiplied in place (tt_sqdiff2_rescale recomputes db from
+ * da1, da2, which it therefore needs; a NULL scalar counts as 0).  All tensor pointers 16-byte aligned. */
+int tt_sqdiff_sum_grad(const float* a, const float* b, float* loss, double* partials, int64_t n, float scale, float* da, float* db,
+                       void* stream);
+int tt_sqdiff2_sum_grad(const float* a1, const float* a2, const float* b, float* l1, float* l2, double* partials, int64_t n, float scale,
+                        float* da1, float* da2, float* db, void* stream);
+int tt_sqdiff_rescale(float* da, float* db, const float* g, int64_t n, void* stream);
+int tt_sqdiff2_rescale(float* da1, float* da2, float* db, const float* g1, const float* g2, int64_t n, void* stream);
 
 /* act = tanh(sqrt(re^2 + im^2)) for coeffs (B,2,F,T) -> (B,F,T) */
 int tt_activations_fwd(const float* coeffs, float* act, int B, int F, int T, void* stream);

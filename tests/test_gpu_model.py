@@ -935,3 +935,46 @@ def test_fused_consistency_backward_equals_two_squared_error_terms():
     (r1 + r2).backward()
     assert torch.equal(l1, r1) and torch.equal(l2, r2)
     assert torch.equal(g1, a1.grad) and torch.equal(g2, a2.grad) and torch.equal(gb, b.grad)
+
+
+@pytest.mark.gpu
+def test_losses_with_the_gradient_written_in_the_forward_pass(monkeypatch):
+    """ops.LOSS_FUSED (round 5): the squared-error losses write their gradient for an incoming scalar of 1 in the forward pass and only
+    rescale in backward.  Against the two-pass form (gradient recomputed from the operands in backward): loss values bitwise, gradients
+    bitwise for an incoming 1 and to one rounding otherwise (2 s (a - b) g is associated differently); a second backward through the same
+    graph (retain_graph) and a forward under no_grad take the two-pass kernels and give the same."""
+    from timbre_trap.framework import compute_consistency_loss, compute_reconstruction_loss, ops
+    g = torch.Generator().manual_seed(11)
+    shape = (2, 2, 41, 36)
+    base = [torch.randn(shape, generator=g).cuda() for _ in range(3)]
+
+    def run(fused, k1, k2, k3):
+        monkeypatch.setattr(ops, 'LOSS_FUSED', fused)
+        a1, a2, b = (t.clone().requires_grad_(True) for t in base)
+        lr = compute_reconstruction_loss(a1, b)
+        l1, l2 = compute_consistency_loss(a1, a2, b)
+        (k1 * lr + k2 * l1 + k3 * l2).backward()
+        return [float(lr), float(l1), float(l2)], [a1.grad.clone(), a2.grad.clone(), b.grad.clone()]
+
+    for ks in ((1.0, 1.0, 1.0), (0.5, 2.0, 0.25)):                # incoming scalars that are powers of two: exact either way
+        l_f, g_f = run(True, *ks)
+        l_t, g_t = run(False, *ks)
+        assert l_f == l_t
+        for x, y in zip(g_f, g_t):
+            assert torch.equal(x, y)
+    l_f, g_f = run(True, 0.3, 1.7, 1.1)
+    l_t, g_t = run(False, 0.3, 1.7, 1.1)
+    assert l_f == l_t
+    for x, y in zip(g_f, g_t):
+        assert float((x - y).abs().max()) <= 4e-7 * float(y.abs().max())
+    # retain_graph: the second backward recomputes from the operands
+    monkeypatch.setattr(ops, 'LOSS_FUSED', True)
+    a, b = (t.clone().requires_grad_(True) for t in base[:2])
+    loss = compute_reconstruction_loss(a, b)
+    loss.backward(retain_graph=True)
+    first = a.grad.clone()
+    a.grad = None
+    loss.backward()
+    assert torch.equal(a.grad, first)
+    with torch.no_grad():
+        assert float(compute_reconstruction_loss(a, b)) == float(loss)

@@ -52,6 +52,73 @@ __global__ __launch_bounds__(256) void k_sqdiff_partial(const float* __restrict_
     block_partial(acc, partials);
 }
 
+// Round 5: the loss and its gradient in ONE pass.  The gradient of scale * sum((a - b)^2) is 2 scale (a - b) times the incoming scalar,
+// which is 1 whenever the loss goes into the total as it is (train.py:453-466): the forward pass, which reads a and b anyway, writes
+// 2 scale (a - b) [and its negative / the second term's], and the backward pass is k_rescale* -- a launch whose every workgroup reads
+// the incoming scalar(s) and returns when they are 1 -- instead of a second read of both operands.  Same loops and partial sums as
+// k_sqdiff_partial: the loss values are bit-identical to tt_sqdiff_sum's.  TWO: both consistency terms against the same b.
+template <bool TWO>
+__global__ __launch_bounds__(256) void k_sqdiff_fused(const float* __restrict__ a1, const float* __restrict__ a2, const float* __restrict__ b,
+                                                      double* __restrict__ partials, float s2, float* __restrict__ da1,
+                                                      float* __restrict__ da2, float* __restrict__ db, long n) {
+    const long n4 = n >> 2;
+    const float4* p1 = reinterpret_cast<const float4*>(a1);
+    const float4* p2 = reinterpret_cast<const float4*>(a2);
+    const float4* pb = reinterpret_cast<const float4*>(b);
+    double acc1 = 0.0, acc2 = 0.0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 y = pb[i], x = p1[i];
+        const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
+        acc1 += (double)(d0 * d0 + d1 * d1) + (double)(d2 * d2 + d3 * d3);
+        const float4 u = float4{s2 * d0, s2 * d1, s2 * d2, s2 * d3};
+        float4 v = float4{0.f, 0.f, 0.f, 0.f};
+        if (TWO) {
+            const float4 z = p2[i];
+            const float e0 = z.x - y.x, e1 = z.y - y.y, e2 = z.z - y.z, e3 = z.w - y.w;
+            acc2 += (double)(e0 * e0 + e1 * e1) + (double)(e2 * e2 + e3 * e3);
+            v = float4{s2 * e0, s2 * e1, s2 * e2, s2 * e3};
+            if (da2) reinterpret_cast<float4*>(da2)[i] = v;
+        }
+        if (da1) reinterpret_cast<float4*>(da1)[i] = u;
+        if (db) reinterpret_cast<float4*>(db)[i] = float4{-u.x - v.x, -u.y - v.y, -u.z - v.z, -u.w - v.w};
+    }
+    if (blockIdx.x == 0) {
+        const long i = (n4 << 2) + threadIdx.x;
+        if (i < n) {
+            const float d = a1[i] - b[i];
+            acc1 += (double)(d * d);
+            float v = 0.f;
+            if (TWO) { const float e = a2[i] - b[i]; acc2 += (double)(e * e); v = s2 * e; if (da2) da2[i] = v; }
+            if (da1) da1[i] = s2 * d;
+            if (db) db[i] = -(s2 * d) - v;
+        }
+    }
+    block_partial(acc1, partials);
+    if (TWO) { __syncthreads(); block_partial(acc2, partials + MAXP); }
+}
+
+// t *= g (and tneg, the stored negative); nothing when g == 1 (every workgroup reads the scalar and returns)
+__global__ __launch_bounds__(256) void k_rescale1(float* __restrict__ t, float* __restrict__ tneg, const float* __restrict__ g, long n) {
+    const float gv = g[0];
+    if (gv == 1.f) return;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        if (t) t[i] *= gv;
+        if (tneg) tneg[i] *= gv;
+    }
+}
+// da1 *= g1, da2 *= g2, db = -(g1 u + g2 v) from the stored unit-scale gradients u, v (db alone cannot be rescaled: it is their sum); a
+// missing incoming gradient counts as 0.  Needs da1 and da2 (the caller keeps them even when only db is wanted).
+__global__ __launch_bounds__(256) void k_rescale2(float* __restrict__ da1, float* __restrict__ da2, float* __restrict__ db,
+                                                  const float* __restrict__ g1, const float* __restrict__ g2, long n) {
+    const float s1 = g1 ? g1[0] : 0.f, s2 = g2 ? g2[0] : 0.f;
+    if (s1 == 1.f && s2 == 1.f) return;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float u = s1 * da1[i], v = s2 * da2[i];
+        da1[i] = u; da2[i] = v;
+        if (db) db[i] = -u - v;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_sqdiff_bwd(const float* __restrict__ a, const float* __restrict__ b,
                                                     const float* __restrict__ gscale, float scale,
                                                     float* __restrict__ da, float* __restrict__ db, long n) {
@@ -163,6 +230,47 @@ extern "C" int tt_sqdiff_sum(const float* a, const float* b, float* loss, double
     hipLaunchKernelGGL(k_sqdiff_partial, dim3(g), dim3(256), 0, tt_stream(stream), a, b, partials, (long)n);
     TT_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, tt_stream(stream), partials, g, (double)scale, loss, 0);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tt_sqdiff_sum_grad(const float* a, const float* b, float* loss, double* partials, int64_t n, float scale, float* da,
+                                  float* db, void* stream) {
+    if (!a || !b || !loss || !partials || n <= 0) return TT_E_BADARG;
+    if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)da | (uintptr_t)db) & 15) return TT_E_BADARG;
+    const int g = nblocks(n, 16);
+    hipLaunchKernelGGL(k_sqdiff_fused<false>, dim3(g), dim3(256), 0, tt_stream(stream), a, (const float*)nullptr, b, partials, 2.f * scale, da,
+                       (float*)nullptr, db, (long)n);
+    TT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, tt_stream(stream), partials, g, (double)scale, loss, 0);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tt_sqdiff2_sum_grad(const float* a1, const float* a2, const float* b, float* l1, float* l2, double* partials, int64_t n,
+                                   float scale, float* da1, float* da2, float* db, void* stream) {
+    if (!a1 || !a2 || !b || !l1 || !l2 || !partials || n <= 0) return TT_E_BADARG;
+    if (((uintptr_t)a1 | (uintptr_t)a2 | (uintptr_t)b | (uintptr_t)da1 | (uintptr_t)da2 | (uintptr_t)db) & 15) return TT_E_BADARG;
+    const int g = nblocks(n, 16);
+    hipLaunchKernelGGL(k_sqdiff_fused<true>, dim3(g), dim3(256), 0, tt_stream(stream), a1, a2, b, partials, 2.f * scale, da1, da2, db, (long)n);
+    TT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, tt_stream(stream), partials, g, (double)scale, l1, 0);
+    TT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, tt_stream(stream), partials + MAXP, g, (double)scale, l2, 0);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tt_sqdiff_rescale(float* da, float* db, const float* g, int64_t n, void* stream) {
+    if ((!da && !db) || !g || n <= 0) return TT_E_BADARG;
+    hipLaunchKernelGGL(k_rescale1, dim3(nblocks(n, 4) * 4), dim3(256), 0, tt_stream(stream), da, db, g, (long)n);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tt_sqdiff2_rescale(float* da1, float* da2, float* db, const float* g1, const float* g2, int64_t n, void* stream) {
+    if (!da1 || !da2 || n <= 0) return TT_E_BADARG;
+    hipLaunchKernelGGL(k_rescale2, dim3(nblocks(n, 4) * 4), dim3(256), 0, tt_stream(stream), da1, da2, db, g1, g2, (long)n);
     TT_LAUNCH_CHECK();
     return 0;
 }

@@ -126,6 +126,10 @@ _PROTOS = {
     'tt_sqdiff_sum': (c_int, [P, P, P, P, L, F_, P]),
     'tt_sqdiff_bwd': (c_int, [P, P, P, F_, P, P, L, P]),
     'tt_sqdiff2_bwd': (c_int, [P, P, P, P, P, F_, P, P, P, L, P]),
+    'tt_sqdiff_sum_grad': (c_int, [P, P, P, P, L, F_, P, P, P]),
+    'tt_sqdiff2_sum_grad': (c_int, [P, P, P, P, P, P, L, F_, P, P, P, P]),
+    'tt_sqdiff_rescale': (c_int, [P, P, P, L, P]),
+    'tt_sqdiff2_rescale': (c_int, [P, P, P, P, P, L, P]),
     'tt_activations_fwd': (c_int, [P, P, I, I, I, P]),
     'tt_activations_bwd': (c_int, [P, P, P, P, I, I, I, P]),
     'tt_transcription_loss_fwd': (c_int, [P, P, P, P, P, I, I, I, I, P]),

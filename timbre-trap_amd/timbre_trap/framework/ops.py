@@ -1577,16 +1577,32 @@ def _partials(device):
     return torch.empty(1024, dtype=torch.float64, device=device)
 
 
+# TTRAP_LOSS_FUSED=0 / ops.LOSS_FUSED = False: the squared-error losses compute their gradients in backward from the saved operands (A/B)
+LOSS_FUSED = os.environ.get('TTRAP_LOSS_FUSED', '1') != '0'
+
+
 class SqDiffLossFn(torch.autograd.Function):
-    """loss = scale * sum((a - b)^2); gradients flow into both arguments."""
+    """loss = scale * sum((a - b)^2); gradients flow into both arguments.  With grad enabled the forward pass, which reads both operands
+    anyway, also writes the gradient for an incoming scalar of 1 (tt_sqdiff_sum_grad); backward is a launch that checks the incoming scalar
+    on the device and multiplies only if it is not 1 (tt_sqdiff_rescale) -- no second read of the operands.  A second backward through the
+    same node (retain_graph) recomputes from the operands (tt_sqdiff_bwd)."""
 
     @staticmethod
     def forward(ctx, a, b, scale):
         _hip.require_cuda(a, b)
         a, b = _f32c(a), _f32c(b)
         loss = torch.empty((), dtype=torch.float32, device=a.device)
-        check(_hip.lib().tt_sqdiff_sum(ptr(a), ptr(b), ptr(loss), ptr(_partials(a.device)), a.numel(), scale,
-                                       stream_ptr()), 'tt_sqdiff_sum')
+        need = (ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        ctx.grads = None
+        if LOSS_FUSED and any(need) and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0:
+            da = torch.empty_like(a) if need[0] else None
+            db = torch.empty_like(b) if need[1] else None
+            check(_hip.lib().tt_sqdiff_sum_grad(ptr(a), ptr(b), ptr(loss), ptr(_partials(a.device)), a.numel(), scale, ptr(da), ptr(db),
+                                                stream_ptr()), 'tt_sqdiff_sum_grad')
+            ctx.grads = (da, db)
+        else:
+            check(_hip.lib().tt_sqdiff_sum(ptr(a), ptr(b), ptr(loss), ptr(_partials(a.device)), a.numel(), scale,
+                                           stream_ptr()), 'tt_sqdiff_sum')
         ctx.scale = scale
         ctx.save_for_backward(a, b)
         return loss
@@ -1595,6 +1611,11 @@ class SqDiffLossFn(torch.autograd.Function):
     def backward(ctx, g):
         a, b = ctx.saved_tensors
         g = _f32c(g)
+        if ctx.grads is not None:
+            da, db = ctx.grads
+            ctx.grads = None                                     # single use: autograd may accumulate into these buffers in place
+            check(_hip.lib().tt_sqdiff_rescale(ptr(da), ptr(db), ptr(g), a.numel(), stream_ptr()), 'tt_sqdiff_rescale')
+            return da, db, None
         da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
         db = torch.empty_like(b) if ctx.needs_input_grad[1] else None
         if da is not None or db is not None:
@@ -1619,8 +1640,17 @@ class SqDiff2Fn(torch.autograd.Function):
         lib, st = _hip.lib(), stream_ptr()
         l1 = torch.empty((), dtype=torch.float32, device=b.device)
         l2 = torch.empty((), dtype=torch.float32, device=b.device)
-        check(lib.tt_sqdiff_sum(ptr(a1), ptr(b), ptr(l1), ptr(_partials(b.device)), b.numel(), scale, st), 'tt_sqdiff_sum')
-        check(lib.tt_sqdiff_sum(ptr(a2), ptr(b), ptr(l2), ptr(_partials(b.device)), b.numel(), scale, st), 'tt_sqdiff_sum')
+        ctx.grads = None
+        if LOSS_FUSED and any(ctx.needs_input_grad[:3]):
+            # one pass over a1, a2, b for both sums and the three gradients at unit incoming scale (tt_sqdiff2_sum_grad; see SqDiffLossFn)
+            da1, da2 = torch.empty_like(a1), torch.empty_like(a2)
+            db = torch.empty_like(b) if ctx.needs_input_grad[2] else None
+            check(lib.tt_sqdiff2_sum_grad(ptr(a1), ptr(a2), ptr(b), ptr(l1), ptr(l2), ptr(torch.empty(2048, dtype=torch.float64, device=b.device)),
+                                          b.numel(), scale, ptr(da1), ptr(da2), ptr(db), st), 'tt_sqdiff2_sum_grad')
+            ctx.grads = (da1, da2, db)
+        else:
+            check(lib.tt_sqdiff_sum(ptr(a1), ptr(b), ptr(l1), ptr(_partials(b.device)), b.numel(), scale, st), 'tt_sqdiff_sum')
+            check(lib.tt_sqdiff_sum(ptr(a2), ptr(b), ptr(l2), ptr(_partials(b.device)), b.numel(), scale, st), 'tt_sqdiff_sum')
         ctx.scale = scale
         ctx.save_for_backward(a1, a2, b)
         return l1, l2
@@ -1630,6 +1660,11 @@ class SqDiff2Fn(torch.autograd.Function):
         a1, a2, b = ctx.saved_tensors
         g1 = None if g1 is None else _f32c(g1)
         g2 = None if g2 is None else _f32c(g2)
+        if ctx.grads is not None:
+            da1, da2, db = ctx.grads
+            ctx.grads = None
+            check(_hip.lib().tt_sqdiff2_rescale(ptr(da1), ptr(da2), ptr(db), ptr(g1), ptr(g2), b.numel(), stream_ptr()), 'tt_sqdiff2_rescale')
+            return (da1 if ctx.needs_input_grad[0] else None, da2 if ctx.needs_input_grad[1] else None, db, None)
         da1 = torch.empty_like(a1) if ctx.needs_input_grad[0] else None
         da2 = torch.empty_like(a2) if ctx.needs_input_grad[1] else None
         db = torch.empty_like(b) if ctx.needs_input_grad[2] else None

@@ -404,6 +404,10 @@ int tt_activations_bwd(const float* coeffs, const float* act, const float* dact,
  * for the backward pass; weighted = weight_positive_class. */
 int tt_transcription_loss_fwd(const float* est, const float* tgt, float* loss, float* frame_scale,
                               double* partials, int B, int F, int T, int weighted, void* stream);
+/* tt_transcription_loss_fwd that also writes dest = the gradient w.r.t. est for an incoming scalar of 1 (round 5; backward is then
+ * tt_sqdiff_rescale(dest, NULL, g, B F T): a device-side check of the incoming scalar) */
+int tt_transcription_loss_fwd_grad(const float* est, const float* tgt, float* loss, float* frame_scale, double* partials, float* dest,
+                                   int B, int F, int T, int weighted, void* stream);
 int tt_transcription_loss_bwd(const float* est, const float* tgt, const float* frame_scale,
                               const float* gscale, float* dest, int B, int F, int T, int weighted,
                               void* stream);

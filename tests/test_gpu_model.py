@@ -978,3 +978,17 @@ def test_losses_with_the_gradient_written_in_the_forward_pass(monkeypatch):
     assert torch.equal(a.grad, first)
     with torch.no_grad():
         assert float(compute_reconstruction_loss(a, b)) == float(loss)
+    # the transcription loss (weighted and not): the same, with the target carrying exact ones (the weighted branch) and a frame of zeros
+    from timbre_trap.framework import compute_transcription_loss
+    est = torch.rand(3, 37, 50, generator=g).cuda()
+    tgt = (torch.rand(3, 37, 50, generator=g) > 0.8).float().cuda()
+    tgt[1, :, 7] = 0.0
+    for weighted in (True, False):
+        res = []
+        for fused in (True, False):
+            monkeypatch.setattr(ops, 'LOSS_FUSED', fused)
+            e = est.clone().requires_grad_(True)
+            l = compute_transcription_loss(e, tgt, weighted)
+            (2.0 * l).backward()
+            res.append((float(l), e.grad.clone()))
+        assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])

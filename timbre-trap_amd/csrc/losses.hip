@@ -157,9 +157,11 @@ __global__ __launch_bounds__(256) void k_act_bwd(const float* __restrict__ c, co
 // A workgroup = 64 consecutive frames x 4 quarters of the F bins (wave = quarter, so every load is 256 contiguous bytes); the
 // quarters meet in LDS in a fixed order.  (One thread per frame looping all 540 bins twice left the launch at 65,536 threads of
 // dependent loads: 0.43 ms for 0.42 GB; round 3.)
+// dest != NULL (round 5, like k_sqdiff_fused): the gradient w.r.t. the estimate for an incoming scalar of 1, s1 w (est - tgt) with
+// s1 = 2 / (B T), written in the same pass (k_trn_bwd's expression); backward is then k_rescale1
 __global__ __launch_bounds__(256) void k_trn_fwd(const float* __restrict__ est, const float* __restrict__ tgt,
                                                  float* __restrict__ frame_scale, double* __restrict__ partials,
-                                                 int B, int F, int T, int weighted) {
+                                                 int B, int F, int T, int weighted, float* __restrict__ dest = nullptr, float s1 = 0.f) {
     __shared__ float sp[4][64], sn[4][64], ss[4][64];
     const long total = (long)B * T;
     const int tl = threadIdx.x & 63, fq = threadIdx.x >> 6;
@@ -191,6 +193,7 @@ __global__ __launch_bounds__(256) void k_trn_fwd(const float* __restrict__ est, 
             float w = 1.f;
             if (weighted && tv == 1.f && scale != 0.f) w = scale;
             s = fmaf(d * d, w, s);
+            if (dest && valid) dest[b * F * (long)T + t + (long)f * T] = s1 * w * d;
         }
         ss[fq][tl] = s;
         __syncthreads();
@@ -346,6 +349,19 @@ extern "C" int tt_transcription_loss_fwd(const float* est, const float* tgt, flo
     if (weighted && !frame_scale) return TT_E_BADARG;
     const int g = nblocks((long)B * T, 1) * 4 > MAXP ? MAXP : nblocks((long)B * T, 1) * 4;     // 64 frames per workgroup
     hipLaunchKernelGGL(k_trn_fwd, dim3(g), dim3(256), 0, tt_stream(stream), est, tgt, frame_scale, partials, B, F, T, weighted);
+    TT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, tt_stream(stream), partials, g, 1.0 / ((double)B * T), loss, 0);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tt_transcription_loss_fwd_grad(const float* est, const float* tgt, float* loss, float* frame_scale, double* partials,
+                                              float* dest, int B, int F, int T, int weighted, void* stream) {
+    if (!est || !tgt || !loss || !partials || !dest || B <= 0 || F <= 0 || T <= 0) return TT_E_BADARG;
+    if (weighted && !frame_scale) return TT_E_BADARG;
+    const int g = nblocks((long)B * T, 1) * 4 > MAXP ? MAXP : nblocks((long)B * T, 1) * 4;
+    hipLaunchKernelGGL(k_trn_fwd, dim3(g), dim3(256), 0, tt_stream(stream), est, tgt, frame_scale, partials, B, F, T, weighted, dest,
+                       2.f / (float)((long)B * T));
     TT_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, tt_stream(stream), partials, g, 1.0 / ((double)B * T), loss, 0);
     TT_LAUNCH_CHECK();

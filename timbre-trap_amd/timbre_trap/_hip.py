@@ -133,6 +133,7 @@ _PROTOS = {
     'tt_activations_fwd': (c_int, [P, P, I, I, I, P]),
     'tt_activations_bwd': (c_int, [P, P, P, P, I, I, I, P]),
     'tt_transcription_loss_fwd': (c_int, [P, P, P, P, P, I, I, I, I, P]),
+    'tt_transcription_loss_fwd_grad': (c_int, [P, P, P, P, P, P, I, I, I, I, P]),
     'tt_transcription_loss_bwd': (c_int, [P, P, P, P, P, I, I, I, I, P]),
     'tt_segment_stats': (c_int, [P, P, I, P, P]),
     'tt_peak_pick': (c_int, [P, P, L, I, I, ctypes.c_double, I, I, P]),

@@ -1707,8 +1707,15 @@ class TranscriptionLossFn(torch.autograd.Function):
         B, F, T = e.shape
         loss = torch.empty((), dtype=torch.float32, device=e.device)
         fs = torch.empty((B, T), dtype=torch.float32, device=e.device) if weighted else None
-        check(_hip.lib().tt_transcription_loss_fwd(ptr(e), ptr(t), ptr(loss), ptr(fs), ptr(_partials(e.device)),
-                                                   B, F, T, int(weighted), stream_ptr()), 'tt_transcription_loss_fwd')
+        ctx.grad = None
+        if LOSS_FUSED and ctx.needs_input_grad[0]:               # the gradient for an incoming scalar of 1 in the same pass (see SqDiffLossFn)
+            de = torch.empty_like(e)
+            check(_hip.lib().tt_transcription_loss_fwd_grad(ptr(e), ptr(t), ptr(loss), ptr(fs), ptr(_partials(e.device)), ptr(de),
+                                                            B, F, T, int(weighted), stream_ptr()), 'tt_transcription_loss_fwd_grad')
+            ctx.grad = de
+        else:
+            check(_hip.lib().tt_transcription_loss_fwd(ptr(e), ptr(t), ptr(loss), ptr(fs), ptr(_partials(e.device)),
+                                                       B, F, T, int(weighted), stream_ptr()), 'tt_transcription_loss_fwd')
         ctx.weighted = weighted
         ctx.save_for_backward(e, t, fs)
         return loss
@@ -1717,6 +1724,10 @@ class TranscriptionLossFn(torch.autograd.Function):
     def backward(ctx, g):
         e, t, fs = ctx.saved_tensors
         B, F, T = e.shape
+        if ctx.grad is not None:
+            de, ctx.grad = ctx.grad, None
+            check(_hip.lib().tt_sqdiff_rescale(ptr(de), None, ptr(_f32c(g)), de.numel(), stream_ptr()), 'tt_sqdiff_rescale')
+            return de, None, None
         de = torch.empty_like(e)
         check(_hip.lib().tt_transcription_loss_bwd(ptr(e), ptr(t), ptr(fs), ptr(_f32c(g)), ptr(de), B, F, T,
                                                    int(ctx.weighted), stream_ptr()), 'tt_transcription_loss_bwd')

@@ -79,7 +79,7 @@ def main():
     d32 = parse('r05_C32')
     lines, j32 = rows(d32, bf16_alg())
     open(os.path.join(ROOT, 'profiles', 'r05_pmc_bwd_C32.txt'), 'w').write(
-        '\n'.join(['# tt_wide_rb_bwd at C = 32, default dispatch: k_wrb_bwd_a<32> + k_wrb_dxw<32,D,8,32,false> (halo-free x tile, round 5) + k_wrb_reduce<32>'] + head + lines) + '\n')
+        '\n'.join(['# tt_wide_rb_bwd at C = 32, default dispatch: k_wrb_bwd_a<32> + k_wrb_dxw<32,D,8,32> (halo-free x tile, round 5) + k_wrb_reduce<32>'] + head + lines) + '\n')
     per_d = {}
     for dd in (1, 2, 3):
         dxw = [k for k in j32 if k.startswith('k_wrb_dxw<32, %d,' % dd)]
@@ -87,7 +87,7 @@ def main():
         red = d32.get('k_wrb_reduce<32>', {})
         per_d[dd] = (j32['k_wrb_bwd_a<32>']['traffic_mb'] + j32[dxw[0]]['traffic_mb'] + 2 * red.get('F', 0) + red.get('W', 0)) * 1e6
     mean = sum(per_d.values()) / 3
-    json.dump(dict(call='tt_wide_rb_bwd at C = 32 (k_wrb_bwd_a<32> + k_wrb_dxw<32,D,8,32,false> + k_wrb_reduce<32>), round 5',
+    json.dump(dict(call='tt_wide_rb_bwd at C = 32 (k_wrb_bwd_a<32> + k_wrb_dxw<32,D,8,32> + k_wrb_reduce<32>), round 5',
                    shape=dict(B=64, C=32, H=65, T=1024), traffic_bytes_corrected_per_dilation={str(k): v for k, v in per_d.items()},
                    traffic_bytes_corrected=mean, algorithmic_bytes=dict(dy_x_dx=817889280), kernels=j32,
                    summary='traffic %.2f GB per call against 0.818 GB algorithmic (%.2fx): h1 read, dA1 written and read once, dy read twice; the '

@@ -633,7 +633,7 @@ def main():
                 pmc_note = pj.get('summary')
                 traffic_source = 'profiles/r05_pmc_wrb_bwd_C32.json (rocprofv3 --pmc passes of the kernels of this call at this shape, round 5: FETCH_SIZE x2 + WRITE_SIZE, summed, mean of the three dilations; round 3 / 4: 2160-2190 MB; not re-measured in this run)'
             roof = dict(kernel='tt_wide_rb_bwd at C=%d, H=65 (ResidualConv2dBlock backward, bf16 channel-innermost storage): k_wrb_bwd_a<%d> + '
-                               'k_wrb_dxw<%d,D,8,32> (data + weight gradient in one pass, halo-free x tile; the level's first block leaves dx gated for the layer in front) + k_wrb_reduce<%d>; the by-time dominant call of the step '
+                               'k_wrb_dxw<%d,D,8,32> (data + weight gradient in one pass, halo-free x tile; the first block of a level leaves dx gated for the layer in front) + k_wrb_reduce<%d>; the by-time dominant call of the step '
                                '(the one-pass strip kernel, default one level down, loses here inside the step: roofline_onepass_bwd, DESIGN.md section 7)' % (C, C, C, C),
                         bound='hbm', achieved=gbs, peak=PEAK_HBM_GBS, unit='GB/s', frac=gbs / PEAK_HBM_GBS, traffic=traffic,
                         traffic_source=traffic_source, algorithmic_bytes=nbytes, algorithmic_flops=flops,

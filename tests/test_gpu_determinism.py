@@ -101,7 +101,7 @@ def _same(runs, names, atomic=()):
 
 
 @pytest.mark.parametrize('C', [4, 8, 16, 32])
-@pytest.mark.parametrize('kind', ['sconv', 'tconv'])
+@pytest.mark.parametrize('kind', ['sconv', 'tconv', 'sconv-pregated', 'tconv-pregated'])
 def test_strided_backward_is_reproducible(C, kind, runs=6, B=2, T=1024):
     from timbre_trap import _hip
     from timbre_trap._hip import check, ptr, stream_ptr
@@ -116,15 +116,22 @@ def test_strided_backward_is_reproducible(C, kind, runs=6, B=2, T=1024):
     ws = torch.empty(lib.tt_stride16_scratch_bytes(C), dtype=torch.uint8, device='cuda')
     out = []
     for _ in range(runs):
-        if kind == 'sconv':      # x = big, y / dy = small
+        if kind.startswith('sconv'):      # x = big, y / dy = small
             dx, dw, db = ops.new_cl16(B, C, H, T, 'cuda'), torch.zeros_like(w), torch.zeros(2 * C, device='cuda')
             y = small.clone()
             dy = ops.new_cl16(B, 2 * C, Ho, T, 'cuda').copy_(small.flip(0))
-            check(lib.tt_sconv16_bwd(ptr(big), ptr(y), ptr(dy), ptr(w), ptr(dx), ptr(dw), ptr(db), ptr(ws), B, C, H, T, st), 'sconv bwd')
+            if kind == 'sconv':
+                check(lib.tt_sconv16_bwd(ptr(big), ptr(y), ptr(dy), ptr(w), ptr(dx), ptr(dw), ptr(db), ptr(ws), B, C, H, T, st), 'sconv bwd')
+            else:                # round 5: dy taken as already gated (both operands by LDS-DMA, db as a matrix product)
+                check(lib.tt_sconv16_bwd_pregated(ptr(big), ptr(dy), ptr(w), ptr(dx), ptr(dw), ptr(db), ptr(ws), B, C, H, T, st), 'sconv bwd pregated')
         else:                    # x = small, y / dy = big
             dx, dw, db = ops.new_cl16(B, 2 * C, Ho, T, 'cuda'), torch.zeros_like(w), torch.zeros(C, device='cuda')
             dy = ops.new_cl16(B, C, H, T, 'cuda').copy_(big.flip(0))
-            check(lib.tt_tconv16_bwd(ptr(small), ptr(big), ptr(dy), ptr(w), ptr(dx), ptr(dw), ptr(db), ptr(ws), B, C, Ho, T, pad, st), 'tconv bwd')
+            if kind == 'tconv':
+                check(lib.tt_tconv16_bwd(ptr(small), ptr(big), ptr(dy), ptr(w), ptr(dx), ptr(dw), ptr(db), ptr(ws), B, C, Ho, T, pad, st), 'tconv bwd')
+            else:                # ... and, where the kernel has the form, with dx leaving gated for the latent head in front
+                check(lib.tt_tconv16_bwd_pregated(ptr(small), ptr(dy), ptr(w), ptr(dx), ptr(dw), ptr(db), ptr(ws), B, C, Ho, T, pad,
+                                                  1 if C in (16, 32) else 0, st), 'tconv bwd pregated')
         torch.cuda.synchronize()
         out.append([dx.clone(), dw.clone(), db.clone()])
     _same(out, ('dx', 'dw', 'db'))
@@ -147,6 +154,16 @@ def test_latent_heads_backward_is_reproducible(head, runs=6, B=2, T=1024):
             torch.cuda.synchronize()
             out.append([x16.grad.clone(), wd.grad.clone(), bd.grad.clone()])
         _same(out, ('dtop', 'dw', 'db'), atomic=('db',))
+        out = []                                                 # round 5: the data gradient leaving gated (tt_latent16_expand_gated)
+        for _ in range(runs):
+            link = ops.GateLink()
+            link.producer = True
+            x16, wd, bd = top.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            ops.LatEnc16Fn.apply(x16, wd, bd, link).backward(dlat)
+            torch.cuda.synchronize()
+            assert link.gated
+            out.append([x16.grad.clone(), wd.grad.clone()])
+        _same(out, ('dtop gated', 'dw'))
     else:
         w, b, z = rnd(D + 1, CT, E, 1, scale=0.02), rnd(CT, scale=0.1), rnd(B, D, T)
         for _ in range(runs):
@@ -156,6 +173,16 @@ def test_latent_heads_backward_is_reproducible(head, runs=6, B=2, T=1024):
             torch.cuda.synchronize()
             out.append([y.detach().clone(), zd.grad.clone(), wd.grad.clone(), bd.grad.clone()])
         _same(out, ('y', 'dz', 'dw', 'db'), atomic=('db',))
+        out = []                                                 # round 5: from a gradient that arrives gated (tt_latent16_*_pregated)
+        for _ in range(runs):
+            link = ops.GateLink()
+            zd, wd, bd = z.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            y = ops.LatDec16Fn.apply(zd, wd, bd, 1.0, link)
+            link.gated = True
+            y.backward(dtop)
+            torch.cuda.synchronize()
+            out.append([zd.grad.clone(), wd.grad.clone(), bd.grad.clone()])
+        _same(out, ('dz', 'dw', 'db'), atomic=('db',))
 
 
 @pytest.mark.parametrize('which', ['convin', 'convout'])

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (round 5, session 23: the narrow fp32 strided layers with 2 columns per thread against 1 -- profiles/r05_valu4_ab.txt)
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 out=gpurun_out/r05_run23.txt

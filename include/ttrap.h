@@ -363,6 +363,18 @@ int tt_dot(const float* a, const float* b, float* out, int64_t n, void* stream);
  * round-to-nearest-even stores. */
 int tt_scaled_add16(const void* a, const void* b, const float* s, int idx, void* y, int64_t n, void* stream);
 int tt_dot16(const void* a, const void* b, float* out, int64_t n, void* stream);
+/* The weighted skip join as ONE pass each way (round 6; reference modules.py:112 `skip_weights[i] * embedding` and :569-589
+ * `y = y + skip`), 16-bit channels-last tensors, n = elements of ONE embedding (n % 8 == 0, 16-byte aligned pointers):
+ *   fwd:  out[r*n + i] = y[r*n + i] + s[idx] * e[i]              r < reps (1 or 2)
+ *   bwd:  t = sum_r g[r*n + i];   de[i] = s[idx] * t  (* ELU'(e[i]) if gate);   ds[idx] += sum_i t * e[i]      (dy = g: not written)
+ * reps = 2: the decoder runs the reconstruction and the transcription decode of the same latents as one batch of 2 B clips
+ * (TimbreTrap.decode_pair) and both halves take the same encoder embedding -- read once, never duplicated.  gate: e is the output of a
+ * strided layer + ELU whose backward takes its gradient already multiplied by ELU'(e) (tt_sconv16_bwd_pregated): this contribution
+ * then carries the factor as well (what tt_gate16 did in a pass of its own).  s may be NULL (scale 1), de or ds may be NULL.
+ * Loss scale (tt_set_loss_scale): g and de are 16-bit gradients and stay scaled, ds *= 1/S. */
+int tt_skip_join16_fwd(const void* y, const void* e, const float* s, int idx, void* out, int64_t n, int reps, void* stream);
+int tt_skip_join16_bwd(const void* g, const void* e, const float* s, int idx, void* de, float* ds, int64_t n, int reps, int gate,
+                       void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Objectives.  Replace timbre_trap/framework/objectives.py and TimbreTrap.to_activations
@@ -434,7 +446,7 @@ int tt_adamw_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, 
  *   tt_latent16_expand   (bias == NULL)   out (16-bit) = S * (...)           -- likewise (data gradient of Encoder.convlat)
  *   tt_latent16_wgrad    (gy == NULL)     z (fp32 gradient) is scaled by S on its way to 16 bits; dw *= 1/S
  *   tt_latent16_wgrad    (gy != NULL), tt_latent16_contract (gy != NULL), tt_convin16_bwd, tt_wide_rb_bwd*, tt_wide_level_bwd,
- *   tt_sconv16_bwd, tt_tconv16_bwd, tt_dot16
+ *   tt_sconv16_bwd, tt_tconv16_bwd, tt_dot16, tt_skip_join16_bwd (ds)
  *                                         every fp32 output (dw, db, dz, dx) *= 1/S; 16-bit data gradients stay scaled
  * With S a power of two this is an exact identity in real arithmetic; in fp16 it lifts activation gradients of ~1e-7 (the loss is a
  * mean over B x T frames) out of the subnormal range.  The value is read on the host when a kernel is launched and passed by value:
@@ -592,6 +604,9 @@ int tt_convout16_bwd_h(const void* x, const float* dy, const float* w, void* dx,
                      int T, void* stream);
 int tt_scaled_add16_h(const void* a, const void* b, const float* s, int idx, void* y, int64_t n, void* stream);
 int tt_dot16_h(const void* a, const void* b, float* out, int64_t n, void* stream);
+int tt_skip_join16_fwd_h(const void* y, const void* e, const float* s, int idx, void* out, int64_t n, int reps, void* stream);
+int tt_skip_join16_bwd_h(const void* g, const void* e, const float* s, int idx, void* de, float* ds, int64_t n, int reps, int gate,
+                         void* stream);
 
 #ifdef __cplusplus
 }

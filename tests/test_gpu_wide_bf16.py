@@ -888,6 +888,88 @@ def test_skip_joins_on_the_device(shape):
     assert torch.allclose(wd.grad.cpu().double(), dw, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize('shape', [(2, 64, 31, 48), (1, 4, 540, 6), (3, 32, 5, 8)])
+@pytest.mark.parametrize('reps', [1, 2])
+@pytest.mark.parametrize('gate', [False, True])
+def test_fused_skip_joins_stagewise(shape, reps, gate):
+    """tt_skip_join16_fwd / _bwd through the C ABI (round 6): out[r] = y[r] + w_i * e for one or two batches that share the embedding,
+    and in ONE backward pass de = w_i * (sum of the halves' gradients) [* ELU'(e)], dw_i += <sum of the halves, e> -- against float64 on
+    the 16-bit-rounded inputs: one rounding per stored element (bit-exact), the weight gradient to fp32 summation round-off; other
+    entries of the weight gradient untouched; NULL scale (plain shared add), NULL de / NULL ds."""
+    from timbre_trap import _hip
+    from timbre_trap._hip import check, ptr, stream_ptr
+    from timbre_trap.framework import ops
+    lib = _lib()
+    B, C, H, T = shape
+    e32, y32, g32 = _rand(B, C, H, T, seed=1, scale=1.5), _rand(reps * B, C, H, T, seed=2), _rand(reps * B, C, H, T, seed=3)
+    cl = lambda t: t.cuda().to(ELT).contiguous(memory_format=torch.channels_last)
+    e, y, g = cl(e32), cl(y32), cl(g32)
+    w = torch.tensor([0.5, -1.25, 2.0, 0.75, 1.5]).cuda()
+    n = e.numel()
+    out = ops.new_cl16(reps * B, C, H, T, e.device, ELT)
+    check(lib.tt_skip_join16_fwd(ptr(y), ptr(e), ptr(w), 3, ptr(out), n, reps, stream_ptr()), 'tt_skip_join16_fwd')
+    er, yr, gr = _r16(e32), _r16(y32), _r16(g32)
+    want = torch.cat([_r16((yr[r * B:(r + 1) * B] + 0.75 * er).float()) for r in range(reps)])
+    # (fp32 fma of exactly representable operands, then one rounding: the float64 sum rounded once agrees except at double-rounding ties)
+    got = out.float().cpu().double()
+    assert float((got - want).abs().max()) <= BF16_REL * float(want.abs().max())
+    assert float((got != want).double().mean()) < 1e-3
+    de = ops.new_cl16(B, C, H, T, e.device, ELT)
+    ds = torch.full((5,), 7.0, device='cuda')
+    check(lib.tt_skip_join16_bwd(ptr(g), ptr(e), ptr(w), 3, ptr(de), ptr(ds), n, reps, int(gate), stream_ptr()), 'tt_skip_join16_bwd')
+    torch.cuda.synchronize()
+    t = sum(gr[r * B:(r + 1) * B] for r in range(reps))
+    want_de = 0.75 * t * (torch.clamp(er + 1.0, max=1.0) if gate else 1.0)
+    _close16(de.float().cpu().double(), want_de, 'de')
+    want_ds = torch.full((5,), 7.0, dtype=torch.float64)
+    want_ds[3] += float((t * er).sum())
+    assert torch.allclose(ds.cpu().double(), want_ds, rtol=1e-4, atol=1e-4 * float((t * er).abs().sum()) ** 0.5)
+    # NULL scale = a plain shared add; de alone; ds alone (accumulating)
+    check(lib.tt_skip_join16_fwd(ptr(y), ptr(e), None, 0, ptr(out), n, reps, stream_ptr()), 'tt_skip_join16_fwd')
+    got = out.float().cpu().double()
+    want = torch.cat([_r16((yr[r * B:(r + 1) * B] + er).float()) for r in range(reps)])
+    assert float((got - want).abs().max()) <= BF16_REL * float(want.abs().max())
+    de2 = ops.new_cl16(B, C, H, T, e.device, ELT)
+    check(lib.tt_skip_join16_bwd(ptr(g), ptr(e), ptr(w), 3, ptr(de2), None, n, reps, int(gate), stream_ptr()), 'tt_skip_join16_bwd')
+    assert torch.equal(de2, de)
+    check(lib.tt_skip_join16_bwd(ptr(g), ptr(e), ptr(w), 3, None, ptr(ds), n, reps, int(gate), stream_ptr()), 'tt_skip_join16_bwd')
+    want_ds[3] += float((t * er).sum())
+    assert torch.allclose(ds.cpu().double(), want_ds, rtol=1e-4, atol=1e-4 * float((t * er).abs().sum()) ** 0.5)
+    # bad arguments are refused, not launched
+    assert lib.tt_skip_join16_fwd(ptr(y), ptr(e), ptr(w), 3, ptr(out), n, 3, stream_ptr()) != 0
+    assert lib.tt_skip_join16_bwd(ptr(g), ptr(e), ptr(w), 3, None, None, n, reps, 0, stream_ptr()) != 0
+    assert _hip.lib().tt_skip_join16_fwd(ptr(y), ptr(e), ptr(w), 3, ptr(out), n + 4, reps, stream_ptr()) != 0
+
+
+def test_fused_skip_joins_autograd_route_equals_the_two_step_route(monkeypatch):
+    """ops.skip_join with a SkipJoin descriptor (what TimbreTrap.forward hands the decoder) against scale + add + gate tap on the same
+    tensors, one and two batches: same output to one rounding, same three gradients (y's bit for bit: it is the incoming gradient)."""
+    from timbre_trap.framework import ops
+    B, C, H, T = 2, 16, 9, 24
+    cl = lambda t: t.cuda().to(ELT).contiguous(memory_format=torch.channels_last)
+    for reps in (1, 2):
+        for gated in (False, True):
+            res = []
+            for fused in (True, False):
+                e = cl(_rand(B, C, H, T, seed=5)).requires_grad_(True)
+                y = cl(_rand(reps * B, C, H, T, seed=6)).requires_grad_(True)
+                w = torch.tensor([1.0, 0.6, 1.0, 1.0, 1.0]).cuda().requires_grad_(True)
+                link = ops.GateLink()
+                link.producer, link.gated = True, gated
+                if fused:
+                    out = ops.skip_join(y, ops.SkipJoin(e, w, 1, link))
+                else:
+                    s = ops.scale(ops.gate_tap(e, link), w, 1)
+                    out = torch.cat([ops.add(y[r * B:(r + 1) * B], s) for r in range(reps)])
+                out.backward(cl(_rand(reps * B, C, H, T, seed=7)))
+                res.append((out.detach().float(), y.grad.float(), e.grad.float(), w.grad.clone()))
+            (o1, gy1, ge1, gw1), (o2, gy2, ge2, gw2) = res
+            assert float((o1 - o2).abs().max()) <= 2 * BF16_REL * float(o2.abs().max())
+            assert torch.equal(gy1, gy2)
+            assert float((ge1 - ge2).abs().max()) <= 4 * BF16_REL * float(ge2.abs().max()), (reps, gated)
+            assert torch.allclose(gw1, gw2, rtol=2e-2, atol=1e-3)
+
+
 def _pytest_subprocess(env_extra, selection):
     """The kernel switches are read once per process: the non-default paths run in a child pytest."""
     import subprocess

@@ -314,6 +314,69 @@ __global__ __launch_bounds__(256) void k_dot16(const E* __restrict__ a, const E*
     if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1] + red[2] + red[3]) * scale);
 }
 
+// The weighted skip join of the 16-bit training path as ONE pass each way (round 6; reference modules.py:112 `w_i * e_i` and
+// :569-589 `y + skip`): out[r][i] = y[r][i] + s[idx] * e[i] for r < reps -- reps = 2 when the decoder runs the reconstruction and the
+// transcription decode of the same latents as one batch of 2 B clips (TimbreTrap.decode_pair): both halves take the SAME encoder embedding,
+// which is read once per element here and never duplicated in memory.  Eight elements per thread step as one 16-byte access, fp32
+// arithmetic, one rounding per stored element.
+template <class E, int REPS>
+__global__ __launch_bounds__(256) void k_skip_join_fwd(const E* __restrict__ y, const E* __restrict__ e, const float* __restrict__ s, int idx,
+                                                       E* __restrict__ out, long n8) {
+    typedef E e8 __attribute__((ext_vector_type(8)));
+    const float sc = s ? s[idx] : 1.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const e8 ev = reinterpret_cast<const e8*>(e)[i];
+        e8 yv[REPS];
+#pragma unroll
+        for (int r = 0; r < REPS; ++r) yv[r] = reinterpret_cast<const e8*>(y)[r * n8 + i];
+#pragma unroll
+        for (int r = 0; r < REPS; ++r) {
+            e8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (E)fmaf(sc, (float)ev[j], (float)yv[r][j]);
+            reinterpret_cast<e8*>(out)[r * n8 + i] = o;
+        }
+    }
+}
+
+// Its backward: t = sum_r g[r][i] (fp32);  de[i] = s[idx] * t, times ELU'(e[i]) when GATE (e is the output of a strided layer + ELU whose
+// backward takes its gradient already gated -- ops.GateLink: the factor every OTHER contribution to that gradient carries);
+// ds[idx] += unscale * sum_i t * e[i] (the gradient of the skip weight: leaves the 16-bit region, the fp16 loss scale comes off).
+// dy = g is not written: the caller hands g itself on.
+template <class E, int REPS, bool GATE>
+__global__ __launch_bounds__(256) void k_skip_join_bwd(const E* __restrict__ g, const E* __restrict__ e, const float* __restrict__ s, int idx,
+                                                       E* __restrict__ de, float* __restrict__ ds, long n8, float unscale) {
+    typedef E e8 __attribute__((ext_vector_type(8)));
+    __shared__ float red[4];
+    const float sc = s ? s[idx] : 1.f;
+    float acc = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const e8 ev = reinterpret_cast<const e8*>(e)[i];
+        e8 gv[REPS];
+#pragma unroll
+        for (int r = 0; r < REPS; ++r) gv[r] = reinterpret_cast<const e8*>(g)[r * n8 + i];
+        e8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float t = (float)gv[0][j];
+#pragma unroll
+            for (int r = 1; r < REPS; ++r) t += (float)gv[r][j];
+            const float x = (float)ev[j];
+            acc = fmaf(t, x, acc);
+            float d = sc * t;
+            if (GATE) d *= __builtin_fminf(x + 1.f, 1.f);             // ELU'(pre-activation) from the ELU's output (bf16_common.h: elu_dout)
+            o[j] = (E)d;
+        }
+        if (de) reinterpret_cast<e8*>(de)[i] = o;
+    }
+    if (ds) {
+        acc = wave_sum(acc);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(ds + idx, (red[0] + red[1] + red[2] + red[3]) * unscale);
+    }
+}
+
 // ---- LDS-tiled 3x3 boundary convs (2 <-> 4 channels, stride 1, pad 1) ------------------------------------------------
 // Same scheme as k_small_lds (conv_small.hip): the CI-channel input tile (16 rows + 2, 64 columns + 8) arrives by
 // LDS-DMA, double buffered; a thread computes two output pixels (rows r, r + 8) for all CO channels from LDS taps with
@@ -627,6 +690,49 @@ static int dot16(const void* a, const void* b, float* out, int64_t n, void* stre
                        (const E*)b, out, (long)(n / 8), (long)n, tt_loss_unscale());   // a = the S-scaled gradient (backward of the skip weights)
     TT_LAUNCH_CHECK();
     return 0;
+}
+template <class E>
+static int skip_join16_fwd(const void* y, const void* e, const float* s, int idx, void* out, int64_t n, int reps, void* stream) {
+    if (!y || !e || !out || n < 0 || n % 8 || (reps != 1 && reps != 2) || idx < 0) return TT_E_BADARG;
+    if ((((uintptr_t)y | (uintptr_t)e | (uintptr_t)out) & 15) != 0) return TT_E_BADARG;        // 16-byte accesses
+    if (n == 0) return 0;
+    const long n8 = n / 8;
+    const dim3 grid(grid1d(n8, 256, 8 * 256));
+    if (reps == 1) hipLaunchKernelGGL((k_skip_join_fwd<E, 1>), grid, dim3(256), 0, tt_stream(stream), (const E*)y, (const E*)e, s, idx, (E*)out, n8);
+    else hipLaunchKernelGGL((k_skip_join_fwd<E, 2>), grid, dim3(256), 0, tt_stream(stream), (const E*)y, (const E*)e, s, idx, (E*)out, n8);
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+template <class E>
+static int skip_join16_bwd(const void* g, const void* e, const float* s, int idx, void* de, float* ds, int64_t n, int reps, int gate,
+                           void* stream) {
+    if (!g || !e || n < 0 || n % 8 || (reps != 1 && reps != 2) || idx < 0 || (!de && !ds)) return TT_E_BADARG;
+    if ((((uintptr_t)g | (uintptr_t)e | (uintptr_t)de) & 15) != 0) return TT_E_BADARG;
+    if (n == 0) return 0;
+    const long n8 = n / 8;
+    const dim3 grid(grid1d(n8, 256, 8 * 256));
+    const float un = tt_loss_unscale();
+    hipStream_t st = tt_stream(stream);
+#define TT_SJB(R, G) hipLaunchKernelGGL((k_skip_join_bwd<E, R, G>), grid, dim3(256), 0, st, (const E*)g, (const E*)e, s, idx, (E*)de, ds, n8, un)
+    if (reps == 1) { if (gate) TT_SJB(1, true); else TT_SJB(1, false); }
+    else           { if (gate) TT_SJB(2, true); else TT_SJB(2, false); }
+#undef TT_SJB
+    TT_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int tt_skip_join16_fwd(const void* y, const void* e, const float* s, int idx, void* out, int64_t n, int reps, void* stream) {
+    return skip_join16_fwd<__bf16>(y, e, s, idx, out, n, reps, stream);
+}
+extern "C" int tt_skip_join16_fwd_h(const void* y, const void* e, const float* s, int idx, void* out, int64_t n, int reps, void* stream) {
+    return skip_join16_fwd<_Float16>(y, e, s, idx, out, n, reps, stream);
+}
+extern "C" int tt_skip_join16_bwd(const void* g, const void* e, const float* s, int idx, void* de, float* ds, int64_t n, int reps, int gate,
+                                  void* stream) {
+    return skip_join16_bwd<__bf16>(g, e, s, idx, de, ds, n, reps, gate, stream);
+}
+extern "C" int tt_skip_join16_bwd_h(const void* g, const void* e, const float* s, int idx, void* de, float* ds, int64_t n, int reps, int gate,
+                                    void* stream) {
+    return skip_join16_bwd<_Float16>(g, e, s, idx, de, ds, n, reps, gate, stream);
 }
 extern "C" int tt_scaled_add16(const void* a, const void* b, const float* s, int idx, void* y, int64_t n, void* stream) {
     return scaled_add16<__bf16>(a, b, s, idx, y, n, stream);

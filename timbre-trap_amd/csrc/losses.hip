@@ -598,7 +598,7 @@ extern "C" int tt_set_cu_limit(int cus) {
     return prev;
 }
 
-extern "C" int tt_version(void) { return 5; }   // 5: gate links (tt_wide_level_bwd_gated, tt_*_bwd_pregated, tt_latent16_*_{gated,pregated}, tt_gate16)   // 4: any-block-length CQT, tt_set_loss_scale, tt_adamw_step(skipped)   // 3: bf16 channels-last entry points (tt_wide_*, tt_sconv16_*, tt_tconv16_*, tt_latent16_*, tt_conv{in,out}16_*)
+extern "C" int tt_version(void) { return 6; }   // 6: tt_skip_join16_{fwd,bwd} (the skip joins of the 16-bit path in one pass each way)   // 5: gate links (tt_wide_level_bwd_gated, tt_*_bwd_pregated, tt_latent16_*_{gated,pregated}, tt_gate16)   // 4: any-block-length CQT, tt_set_loss_scale, tt_adamw_step(skipped)   // 3: bf16 channels-last entry points (tt_wide_*, tt_sconv16_*, tt_tconv16_*, tt_latent16_*, tt_conv{in,out}16_*)
 extern "C" const char* tt_arch(void) { return "gfx950"; }
 extern "C" const char* tt_error_string(int code) {
     if (code == 0) return "ok";

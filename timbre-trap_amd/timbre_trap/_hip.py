@@ -123,6 +123,8 @@ _PROTOS = {
     'tt_dot': (c_int, [P, P, P, L, P]),
     'tt_scaled_add16': (c_int, [P, P, P, I, P, L, P]),
     'tt_dot16': (c_int, [P, P, P, L, P]),
+    'tt_skip_join16_fwd': (c_int, [P, P, P, I, P, L, I, P]),
+    'tt_skip_join16_bwd': (c_int, [P, P, P, I, P, P, L, I, I, P]),
     'tt_sqdiff_sum': (c_int, [P, P, P, P, L, F_, P]),
     'tt_sqdiff_bwd': (c_int, [P, P, P, F_, P, P, L, P]),
     'tt_sqdiff2_bwd': (c_int, [P, P, P, P, P, F_, P, P, P, L, P]),
@@ -147,7 +149,7 @@ HALF_TWINS = ('tt_wide_level_scratch_bytes', 'tt_wide_level_bwd', 'tt_wide_level
               'tt_wide_rb_bwd_fused', 'tt_wide_onepass_scratch_bytes', 'tt_wide_rb_bwd_onepass', 'tt_wide_rb_bwd_is_onepass',
               'tt_stride16_scratch_bytes', 'tt_sconv16_fwd', 'tt_sconv16_bwd', 'tt_tconv16_fwd', 'tt_tconv16_bwd', 'tt_latent16_scratch_bytes',
               'tt_latent16_contract', 'tt_latent16_expand', 'tt_latent16_wgrad', 'tt_edge16_scratch_bytes', 'tt_convin16_fwd', 'tt_convin16_bwd',
-              'tt_convout16_fwd', 'tt_convout16_bwd', 'tt_scaled_add16', 'tt_dot16')
+              'tt_convout16_fwd', 'tt_convout16_bwd', 'tt_scaled_add16', 'tt_dot16', 'tt_skip_join16_fwd', 'tt_skip_join16_bwd')
 for _n in HALF_TWINS:
     _PROTOS[_n + '_h'] = _PROTOS[_n]
 EXPORTED_SYMBOLS = tuple(_PROTOS)

@@ -117,6 +117,16 @@ class DecoderBlock(nn.Module):
         return ops.residual_level(y, (self.block1, self.block2, self.block3), out_x3=out_x3, link=link)
 
 
+class EmbeddingList(list):
+    """The encoder's five embeddings as the reference returns them (a list of tensors: modules.py:470-483), plus what the fused skip joins
+    of the 16-bit path need (ops.SkipJoin): ``raw[i]`` -- the layer's own output tensor where ``self[i]`` is its gate tap (ops.gate_tap) --
+    and ``links[i]``, the ops.GateLink of that layer (None without one)."""
+
+    def __init__(self, tensors, raw, links):
+        list.__init__(self, tensors)
+        self.raw, self.links = list(raw), list(links)
+
+
 class Encoder(nn.Module):
     """2-D convolutional encoder: coefficients (B,2,F,T) -> latents (B,D,T) (reference modules.py:396-483)."""
 
@@ -146,7 +156,7 @@ class Encoder(nn.Module):
         # (the first one: between convin and the first level; the last one: between the last strided layer and the latent head)
         links = [ops.gate_link() if torch.is_grad_enabled() else None for _ in range(len(blocks) + 1)]
         raw = ops.conv(coefficients, c.weight, c.bias, ConvCfg(3, 3, 1, 1, 1, 1, 'conv', 0, ACT_ELU), link=links[0])
-        embeddings = [ops.gate_tap(raw, links[0])]
+        embeddings, raws = [ops.gate_tap(raw, links[0])], [raw]
         for i, block in enumerate(blocks):
             # inside ops.x3_chain_scope (embeddings dropped by the caller): a block whose successor starts with a split-operand level
             # hands its output over in that layout
@@ -156,12 +166,13 @@ class Encoder(nn.Module):
                 takes_x3 = ops.x3_latent_ok(block.sconv[0].out_channels, self.convlat.out_channels, w_enc=self.convlat.weight)
             raw = block(raw, out_x3=ops.x3_chain() and takes_x3, link_in=links[i], link_out=links[i + 1])
             embeddings.append(ops.gate_tap(raw, links[i + 1]))
+            raws.append(raw)
         top = raw
         E = top.size(1) if ops.is_x3(top) else top.size(-2)
         if E != self.convlat.kernel_size[0]:
             raise ValueError('feature size %d does not match the latent head (%d)' % (E, self.convlat.kernel_size[0]))
         latents = ops.latent_encode(top, self.convlat.weight, self.convlat.bias, link=links[-1])
-        return latents, embeddings, dict()
+        return latents, EmbeddingList(embeddings, raws, links), dict()
 
 
 class Decoder(nn.Module):
@@ -192,7 +203,8 @@ class Decoder(nn.Module):
     def forward(self, latents, encoder_embeddings=None, indicator=None, pair=False):
         """``indicator``: None (latents carry the switch channel, the reference's call) or its constant value (then latents have
         one channel less and ops.latent_decode supplies it).  ``pair`` (TimbreTrap.decode_pair): the batch is two batches back to
-        back; returns their two logits tensors."""
+        back; returns their two logits tensors.  ``encoder_embeddings``: the scaled embeddings (reference modules.py:569-589) or
+        ops.SkipJoin descriptors (TimbreTrap.skip_joins: weight and join in one pass; with ``pair`` each serves both halves)."""
         c = self.convin[0]
         skips = None if encoder_embeddings is None else list(encoder_embeddings)[::-1]
         # (inside ops.x3_chain_scope, no skip connections: the head hands a split-operand tensor to block1's transposed layer)
@@ -202,7 +214,7 @@ class Decoder(nn.Module):
         y = ops.latent_decode(latents, c.weight, c.bias, indicator,
                               out_x3=skips is None and ops.x3_chain() and self.block1.tconv[0].out_channels in ops.X3_CHANNELS, link=uplink)
         if skips is not None:
-            y = ops.add(y, skips[0])
+            y = ops.skip_join(y, skips[0])
         blocks = (self.block1, self.block2, self.block3, self.block4)
         for i, block in enumerate(blocks):
             # transposed layers with a split-operand kernel: 64 -> 32 and 32 -> 16 channels (tt_x3_tconv_fwd)
@@ -210,7 +222,7 @@ class Decoder(nn.Module):
             y = block(y, out_x3=skips is None and ops.x3_chain() and t is not None and (t.in_channels, t.out_channels) in ((64, 32), (32, 16)),
                       uplink=uplink if i == 0 else None)
             if skips is not None:
-                y = ops.add(y, skips[i + 1])
+                y = ops.skip_join(y, skips[i + 1])
         o = self.convout
         if pair:
             return ops.conv_out_pair(y, o.weight, o.bias)
@@ -245,6 +257,16 @@ class TimbreTrap(nn.Module):
             return None
         return [ops.scale(e, self.skip_weights, i) for i, e in enumerate(embeddings)]
 
+    def skip_joins(self, embeddings):
+        """What ``forward`` hands the decoder instead of ``apply_skip_connections(embeddings)`` on the 16-bit channels-last path: one
+        ops.SkipJoin per embedding -- ``skip_weights[i] * e_i`` and the decoder's ``y + skip`` (reference modules.py:112, :569-589) are
+        then ONE pass each way, on the encoder's own output tensors.  None where that does not apply (no skip connections, fp32 path,
+        embeddings that did not come from this encoder as 16-bit tensors, ops.SKIP_FUSED off)."""
+        if (self.skip_weights is None or not ops.SKIP_FUSED or not ops.cl16_mode() or not isinstance(embeddings, EmbeddingList)
+                or not all(ops.is_cl16(e) and e.numel() % 8 == 0 for e in embeddings.raw)):
+            return None
+        return [ops.SkipJoin(e, self.skip_weights, i, link) for i, (e, link) in enumerate(zip(embeddings.raw, embeddings.links))]
+
     def decode(self, latents, embeddings=None, transcribe=False):
         """latents (B,D,T) -> logits (B,2,F,T); the extra latent channel is 1 for reconstruction, 0 for transcription."""
         value = 0.0 if transcribe else 1.0
@@ -257,13 +279,16 @@ class TimbreTrap(nn.Module):
 
     def decode_pair(self, latents, embeddings=None):
         """(decode(latents, embeddings), decode(latents, embeddings, True)) -- the reconstruction and the transcription of the same
-        latents (reference modules.py:365-371 calls decode twice).  On the 16-bit training path without skip connections the two are
-        ONE pass of the decoder over a batch of 2 B (clips are independent: the same values; half the launches, weight-gradient
-        reduces and kernel tails of the decoder).  TTRAP_PAIR_DECODE=0 / TimbreTrap.PAIR_DECODE = False: two passes."""
-        if self.PAIR_DECODE and embeddings is None and ops.cl16_mode() and torch.is_grad_enabled() and latents.dim() == 3:
+        latents (reference modules.py:365-371 calls decode twice).  On the 16-bit training path the two are ONE pass of the decoder
+        over a batch of 2 B (clips are independent: the same values; half the launches, weight-gradient reduces and kernel tails of
+        the decoder) -- without skip connections, or with them as ops.SkipJoin descriptors (``skip_joins``: each embedding then serves
+        both halves, round 6); already scaled embedding TENSORS would have to be duplicated: two passes.
+        TTRAP_PAIR_DECODE=0 / TimbreTrap.PAIR_DECODE = False: two passes."""
+        joins = embeddings is not None and all(isinstance(e, ops.SkipJoin) and ops.is_cl16(e.e) for e in embeddings)
+        if self.PAIR_DECODE and (embeddings is None or joins) and ops.cl16_mode() and torch.is_grad_enabled() and latents.dim() == 3:
             ones = torch.ones_like(latents[..., :1, :])
             z = torch.cat((torch.cat((latents, ones), dim=-2), torch.cat((latents, torch.zeros_like(ones)), dim=-2)), dim=0)
-            return self.decoder(z, None, pair=True)
+            return self.decoder(z, embeddings, pair=True)
         return self.decode(latents, embeddings), self.decode(latents, embeddings, True)
 
     def _inference(self, audio, transcribe=False):
@@ -339,12 +364,12 @@ class TimbreTrap(nn.Module):
         (reconstruction, latents, transcription, transcription_rec, transcription_scr, losses).
         """
         latents, embeddings, losses = self.encode(audio)
-        embeddings = self.apply_skip_connections(embeddings)
+        embeddings = self.skip_joins(embeddings) or self.apply_skip_connections(embeddings)
         reconstruction, transcription = self.decode_pair(latents, embeddings)
         transcription_rec = transcription_scr = None
         if consistency:
             latents_trn, embeddings_trn, _ = self.encoder(transcription)
-            embeddings_trn = self.apply_skip_connections(embeddings_trn)
+            embeddings_trn = self.skip_joins(embeddings_trn) or self.apply_skip_connections(embeddings_trn)
             transcription_rec, transcription_scr = self.decode_pair(latents_trn, embeddings_trn)
         return reconstruction, latents, transcription, transcription_rec, transcription_scr, losses
 

@@ -320,6 +320,7 @@ def _grad_target(p):
         return torch.zeros(p.shape, dtype=torch.float32, device=p.device), None
     g = p.grad if getattr(p, '_ttrap_accumulate', False) else None
     if g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.shape == p.shape and g.device == p.device:
+        p._ttrap_touched = True           # FusedAdamW: this slot has a gradient of the current step (utils/optim.py, _nograd)
         return g, None
     z = torch.zeros(p.shape, dtype=torch.float32, device=p.device)
     return z, z
@@ -1061,6 +1062,70 @@ class Scale16Fn(torch.autograd.Function):
         return de, ds, None
 
 
+class SkipJoin:
+    """A skip connection that has not been applied yet: (encoder embedding, the skip weights, which one, the embedding's GateLink).
+    TimbreTrap.forward hands these to the decoder on the 16-bit path instead of the scaled tensors of apply_skip_connections: the
+    product and the join are then ONE pass (SkipJoin16Fn) and the embedding serves both halves of a pair decode."""
+    __slots__ = ('e', 'weights', 'idx', 'link')
+
+    def __init__(self, e, weights, idx, link=None):
+        self.e, self.weights, self.idx, self.link = e, weights, idx, link
+
+
+# TTRAP_SKIP_FUSED=0 / ops.SKIP_FUSED = False: scale and join as two passes per decode, decodes one by one (the round 2-5 route; A/B)
+SKIP_FUSED = os.environ.get('TTRAP_SKIP_FUSED', '1') != '0'
+
+
+class SkipJoin16Fn(torch.autograd.Function):
+    """out = y + weights[idx] * e on cl16 tensors in one pass (tt_skip_join16_fwd; reference modules.py:112 and :569-589).  y may hold
+    ``reps`` = 2 batches back to back (TimbreTrap.decode_pair) that both take e.  Backward, one pass (tt_skip_join16_bwd): dy is the
+    incoming gradient itself, de = weights[idx] * (sum over the halves), d weights[idx] += <sum over the halves, e>.  ``link``: e is the RAW
+    output of a 16-bit strided layer whose backward may take its gradient already gated (GateLink, read at backward time): de then
+    carries ELU'(e) -- what GateTapFn + tt_gate16 did in two more passes."""
+
+    @staticmethod
+    def forward(ctx, y, e, weights, idx, link):
+        B, C, H, T = e.shape
+        reps = y.size(0) // B
+        if y.dtype != e.dtype or y.shape[1:] != e.shape[1:] or reps * B != y.size(0) or reps not in (1, 2):
+            raise ValueError('skip join of %s %s and %s %s tensors' % (tuple(y.shape), y.dtype, tuple(e.shape), e.dtype))
+        out = new_cl16(reps * B, C, H, T, y.device, y.dtype)
+        check(lib16(y).tt_skip_join16_fwd(ptr(y), ptr(e), ptr(weights), idx, ptr(out), e.numel(), reps, stream_ptr()), 'tt_skip_join16_fwd')
+        ctx.idx, ctx.reps, ctx.link, ctx.param = idx, reps, link, weights
+        ctx.save_for_backward(e, weights)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        e, weights = ctx.saved_tensors
+        B, C, H, T = e.shape
+        g = _as_cl16(g, e.dtype)
+        de = new_cl16(B, C, H, T, e.device, e.dtype) if ctx.needs_input_grad[1] else None
+        ds = rs = None
+        if ctx.needs_input_grad[2]:
+            ds, rs = _grad_target(ctx.param)
+        if de is not None or ds is not None:
+            gate = ctx.link is not None and ctx.link.gated
+            check(lib16(e).tt_skip_join16_bwd(ptr(g), ptr(e), ptr(weights), ctx.idx, ptr(de), ptr(ds), e.numel(), ctx.reps, int(gate), stream_ptr()),
+                  'tt_skip_join16_bwd')
+        return g, de, rs, None, None
+
+
+def skip_join(y, skip):
+    """y + skip for the decoder's joins: ``skip`` is a tensor (already scaled: apply_skip_connections) or a SkipJoin."""
+    if not isinstance(skip, SkipJoin):
+        return add(y, skip)
+    e, w = skip.e, skip.weights
+    if (is_cl16(y) and is_cl16(e) and y.dtype == e.dtype and e.numel() % 8 == 0 and w.dtype == torch.float32 and w.is_contiguous()
+            and y.shape[1:] == e.shape[1:] and y.size(0) in (e.size(0), 2 * e.size(0))):
+        return SkipJoin16Fn.apply(y, e, w, skip.idx, skip.link)
+    # any other layout: the two-step form on whatever the tensors are (the tap carries the gate of a linked embedding)
+    scaled = scale(gate_tap(e, skip.link), w, skip.idx)
+    if y.size(0) == 2 * e.size(0):
+        scaled = torch.cat((scaled, scaled), dim=0)
+    return add(y, scaled)
+
+
 def add(a, b):
     """a + b for the skip joins: on cl16 tensors when either side is one (Add16Fn), AddFn otherwise."""
     if is_cl16(a) or is_cl16(b):
@@ -1755,6 +1820,7 @@ _scale_backward(LatEnc16Fn, lambda ctx: ctx.saved_tensors[0].dtype)
 _scale_backward(LatDec16Fn, lambda ctx: ctx.saved_tensors[2].dtype)
 _scale_backward(Scale16Fn, lambda ctx: ctx.saved_tensors[0].dtype)
 _scale_backward(GateTapFn, lambda ctx: ctx.saved_tensors[0].dtype)
+_scale_backward(SkipJoin16Fn, lambda ctx: ctx.saved_tensors[0].dtype)
 
 
 # ---- instrumentation (bench.py): bracket every forward / backward of the Functions above with HIP events ------------------------
@@ -1794,6 +1860,7 @@ _instrument(ToCL16Fn, 'tocl16', lambda x: 'C%d' % x.size(1))
 _instrument(ToPlanar32Fn, 'toplanar', lambda x: 'C%d' % x.size(1))
 _instrument(StridedConvFn, 'sconv', lambda x, *a: 'C%d' % x.size(1))
 _instrument(TransposedConvFn, 'tconv', lambda x, w, *a: 'C%d' % w.size(1))
+_instrument(SkipJoin16Fn, 'skipjoin16', lambda y, e, *a: 'C%d' % e.size(1))
 _instrument(LatEnc16Fn, 'latenc16', lambda x, *a: 'C%d' % x.size(1))
 _instrument(LatDec16Fn, 'latdec16', lambda z, w, *a: 'C%d' % w.size(1))
 _instrument(LatentEncodeFn, 'latenc', lambda x, *a: 'C%d' % x.size(1))

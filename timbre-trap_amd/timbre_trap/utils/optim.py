@@ -14,6 +14,10 @@ import torch
 from .. import _hip
 
 
+def _mark_touched(p):
+    p._ttrap_touched = True
+
+
 class FusedAdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_norm=None):
         params = [p for p in params if p.requires_grad]
@@ -22,7 +26,10 @@ class FusedAdamW(torch.optim.Optimizer):
         if len(self.param_groups) != 1:
             raise ValueError('FusedAdamW keeps one flat buffer: a single param group only')
         self.max_norm = max_norm
-        self._nograd = set()              # slots whose .grad was None when _reattach() last met them; consumed by step()
+        # slots whose .grad was None when _reattach() last met them; consumed by step(), cleared by zero_grad(), and overruled by a
+        # gradient that arrives afterwards (``_ttrap_touched``: set where a backward kernel is handed the view, ops._grad_target, and by
+        # autograd's own accumulation, the hook below)
+        self._nograd = set()
         self._flatten(params)
         self._step = 0
 
@@ -49,6 +56,8 @@ class FusedAdamW(torch.optim.Optimizer):
                 p.data = self.flat_param[o:o + k].view_as(p)
                 p.grad = self.flat_grad[o:o + k].view_as(p)
                 p._ttrap_accumulate = True        # backward kernels add into this view directly (framework/ops.py:_grad_target)
+                p._ttrap_touched = False
+                p.register_post_accumulate_grad_hook(_mark_touched)       # gradients that autograd itself adds into the view
                 self._slots.append((p, o, k))
                 o += k
         self.n = n
@@ -64,6 +73,10 @@ class FusedAdamW(torch.optim.Optimizer):
         A slot found with ``p.grad is None`` is REMEMBERED (``self._nograd``) until ``step()`` consumes it: re-attaching replaces the
         None by a zero view, and ``sync_views()`` / ``grad_norm()`` / ``GradientSync.start(opt)`` all re-attach before ``step()``
         runs -- without the record such a parameter would take weight decay and residual momentum, which ``torch.optim.AdamW`` skips.
+        The record only says "no gradient SO FAR": a re-attachment between ``model.zero_grad()`` (gradients set to None) and the
+        backward pass -- ``grad_norm()`` logged at the end of the previous iteration, ``sync_views()`` -- would otherwise mark EVERY
+        slot, and the backward that follows accumulates straight into the restored views: a gradient that arrives after the record
+        was made (``p._ttrap_touched``) takes the slot out of it again (round-5 advisor finding), and so does ``zero_grad()``.
         """
         gbase, pbase = self.flat_grad.data_ptr(), self.flat_param.data_ptr()
         for p, o, k in self._slots:
@@ -73,10 +86,12 @@ class FusedAdamW(torch.optim.Optimizer):
                 if g is None:
                     slot.zero_()
                     self._nograd.add(o)
+                    p._ttrap_touched = False          # whatever arrives from here on is a gradient of this step
                 else:
                     if g.device != slot.device:
                         raise RuntimeError('FusedAdamW: a gradient moved to %s (optimizer state is on %s)' % (g.device, slot.device))
                     slot.copy_(g.detach().reshape(-1))
+                    self._nograd.discard(o)           # a fresh gradient installed by autograd since the record was made
                 p.grad = slot.view_as(p)
             if p.data_ptr() != pbase + 4 * o:
                 if p.device != self.flat_param.device or p.dtype != torch.float32:
@@ -119,6 +134,7 @@ class FusedAdamW(torch.optim.Optimizer):
     def zero_grad(self, set_to_none=False):
         # gradients must stay views of the flat buffer: zero in place, never drop them (and restore dropped ones)
         self.flat_grad.zero_()
+        self._nograd.clear()               # every slot is a (zero) view again: "had no gradient" starts over with this step
         for p, o, k in self._slots:
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
                 p.grad = self.flat_grad[o:o + k].view_as(p)
@@ -139,7 +155,7 @@ class FusedAdamW(torch.optim.Optimizer):
         # its residual momentum nor the weight decay may move it.  The fused kernel walks the whole flat buffer, so the slots of such
         # parameters (zero gradient: nothing in the clipping norm either) are put back, moments included, after the update.
         self._reattach()                   # records the slots whose gradient is None (now, or at an earlier re-attachment of this step)
-        frozen = [(o, k) for p, o, k in self._slots if o in self._nograd or not p.requires_grad]
+        frozen = [(o, k) for p, o, k in self._slots if (o in self._nograd and not getattr(p, '_ttrap_touched', False)) or not p.requires_grad]
         self._nograd.clear()
         keep = [(o, k, self.flat_param[o:o + k].clone(), self.exp_avg[o:o + k].clone(), self.exp_avg_sq[o:o + k].clone()) for o, k in frozen]
         for o, k in frozen:

@@ -28,6 +28,11 @@ Prints ONE JSON line on rank 0 with the driver's fields plus
   "roofline_fwd"      : the fused block forward k_wrb_conv<32,D,0> the same way (round 2's roofline kernel; fp32 path: k_rb_fwd<32,D>
                         against the fp32 matrix peak)
   "roofline_onepass_bwd" : the same call one level down (C = 16), where it runs as the one-pass strip kernel k_wrb_bwds (round 4)
+  "roofline_narrow_bwd" : the same call at the narrow levels (C = 4, 8: k_nrb_bwd_fused, by time the largest family of the step), one entry each
+  "host"              : host_enqueue_ms -- wall time Python + autograd need to enqueue a step with no sync inside -- next to the synced time
+                        of the same steps (host_over_gpu), and the cores this process may use
+  "core_capped_run"   : N = 1: the timed loop again in a child process restricted to TWO host cores (`--cores 2`, affinity set before torch is
+                        imported): what a rank of an 8-rank job gets on a 16-core host; vs_uncapped = its ms_per_step / this run's
   "roofline_cqt"      : tt_cqt_forward, measured in the timed steps (HBM bound, 4,688,280 algorithmic bytes per clip)
   "roofline_cqt_inv"  : tt_cqt_inverse (CQT.decode) on the same batch, measured after the timed region (training never calls it)
   "families"          : per kernel family (narrow / wide residual blocks, strided, transposed, latent GEMMs, boundary convs,
@@ -58,6 +63,27 @@ for p in (ROOT, os.path.join(ROOT, 'timbre-trap_amd')):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+
+def _apply_core_cap(argv):
+    """`--cores K`: restrict THIS process to K cores of its current affinity set before torch (and its thread pools) is imported and
+    long before anything touches the GPU -- the one-GPU proxy for what a rank of an 8-rank job on this host gets (SURVEY.md section 8e:
+    ">= 6.5x hinges on ... per-step host syncs"; round-5 verdict, weak #12).  Affects the host side only."""
+    for i, a in enumerate(argv):
+        k = None
+        if a == '--cores' and i + 1 < len(argv):
+            k = int(argv[i + 1])
+        elif a.startswith('--cores='):
+            k = int(a.split('=', 1)[1])
+        if k:
+            cores = sorted(os.sched_getaffinity(0))[:k]
+            os.sched_setaffinity(0, cores)
+            os.environ['OMP_NUM_THREADS'] = str(len(cores))
+            return len(cores)
+    return None
+
+
+CORE_CAP = _apply_core_cap(sys.argv[1:])
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -66,6 +92,7 @@ SECS_PER_CLIP = 3.0
 PEAK_FP32_MATRIX_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0       # same guide: dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0
+MEASURED_COPY_GBS = 6290.0           # same guide: what a device-to-device copy reaches on this chip
 CQT_BYTES_PER_CLIP = 4688280         # 264,600 B of audio + 4,423,680 B of coefficients
 
 
@@ -165,9 +192,14 @@ def family_table(events, n_steps, batch, mc, latent, bf16=False):
     timbre_trap/framework/ops.py, recorded on the launch stream during `n_steps` untimed instrumented steps), the ALGORITHMIC
     work of those calls and the achieved rates.  Algorithmic bytes count each tensor a layer must read or write once:
     residual block forward 2 tensors (x, y), backward 3 (dy, x, dx; the saved hidden activation is an implementation choice);
-    (4,1) strided / transposed layers forward in + out, backward 2 in + 2 out (the ELU gate needs y).  FLOPs are 2 MAC,
-    backward = 2 x forward.
+    (4,1) strided / transposed layers forward in + out, backward THREE tensors when the gradient arrives already gated (x and dy read,
+    dx written: ops.PREGATE, round 5 -- the ELU gate no longer needs y) and four otherwise; the losses as the passes they make:
+    with ops.LOSS_FUSED the forward reads its operands and writes the gradients, the backward moves nothing (round-5 verdict, weak #8:
+    both were still counted by their round-4 definitions, which put one family above what the chip can copy at).  FLOPs are 2 MAC,
+    backward = 2 x forward.  A family whose fraction of HBM peak exceeds the measured copy ceiling (6.29 of 8.0
+    TB/s) is flagged ``exceeds_copy_ceiling`` -- a byte definition gone stale, not a fast kernel.
     """
+    from timbre_trap.framework import ops
     ch = [round(c * 2 ** (mc - 1)) for c in (2, 4, 8, 16, 32)]
     hs = [540, 269, 133, 65, 31]
     T = M_FRAMES
@@ -205,9 +237,18 @@ def family_table(events, n_steps, batch, mc, latent, bf16=False):
             C = int(tag[1:]); l = level[C]
             big, small = C * hs[l] * T * batch, 2 * C * hs[l + 1] * T * batch          # elements at the C side / the 2C side
             fl = 2.0 * 4 * C * 2 * C * hs[l + 1] * T * batch * (2 if bwd else 1)
-            by = 2.0 * (big + small) * (2 if bwd else 1)
+            x_el, y_el = (big, small) if kind == 'sconv16' else (small, big)            # the layer's input / output
+            if not bwd:
+                by = 2.0 * (x_el + y_el)
+            else:                                                 # x, dy in, dx out (+ the saved output y for the gate when it is not pregated)
+                by = 2.0 * (2 * x_el + y_el + (0 if ops.PREGATE else y_el))
             add('strided + transposed (4,1) layers, bf16 channels-last ' + ('backward' if bwd else 'forward'), ms, calls, fl * calls,
                 by * calls, 'hbm')
+        elif kind == 'skipjoin16':
+            # out = y + w * e for both halves of a pair decode (5 tensor-halves forward: 2 y, e, 2 out); backward 2 g + e in, de out
+            C = int(tag[1:])
+            n_el = (C * hs[level[C]] if C in level else 64 * 31) * T * batch
+            add('skip joins (weight x embedding + join, one pass each way)', ms, calls, 0.0, 2.0 * n_el * (2.0 if bwd else 2.5) * calls, 'hbm')
         elif kind in ('tocl16', 'toplanar'):
             C = int(tag[1:])
             n_el = C * hs[level[C]] * T * batch if C in level else 64 * 31 * T * batch
@@ -239,9 +280,14 @@ def family_table(events, n_steps, batch, mc, latent, bf16=False):
             fl = 2.0 * 9 * ci * co * px * (2 if bwd else 1)
             by = 4.0 * (ci + co) * px * (1.5 if bwd else 1)
             add('boundary 3x3 convs (2<->%d)' % ch[0], ms, calls, fl * calls, by * calls, 'hbm')
-        elif kind in ('sqdiff', 'act', 'trn'):
-            px = hs[0] * T * batch
-            by = 4.0 * px * {'sqdiff': 4, 'act': 3, 'trn': 2}[kind] * (1.5 if bwd else 1)
+        elif kind in ('sqdiff', 'sqdiff2', 'act', 'trn'):
+            px = hs[0] * T * batch                                # fp32 planes of F x T per clip: logits 2 planes, activations / targets 1
+            if ops.LOSS_FUSED:
+                # forward: operands in, gradient(s) out; backward: a launch that returns when the incoming scalar is 1 (no tensor pass)
+                planes = {'sqdiff': (6, 0), 'sqdiff2': (12, 0), 'act': (3, 6), 'trn': (3, 0)}[kind]
+            else:
+                planes = {'sqdiff': (4, 6), 'sqdiff2': (8, 12), 'act': (3, 6), 'trn': (2, 3)}[kind]
+            by = 4.0 * px * planes[1 if bwd else 0]
             add('losses + to_activations', ms, calls, 0.0, by * calls, 'hbm')
         elif key == 'clip_adamw':
             add('clip + AdamW (flat buffer)', ms, calls, 0.0, 0.0, 'hbm')
@@ -253,6 +299,10 @@ def family_table(events, n_steps, batch, mc, latent, bf16=False):
         tf, tb = f['gflop_per_step'] / 1e3 / sec, f['gbyte_per_step'] / 1e3 / sec
         out[name] = dict(ms_per_step=round(f['ms_per_step'], 3), calls_per_step=f['calls_per_step'], bound=f['bound'],
                          achieved_tflops=round(tf, 2), achieved_tbs=round(tb, 3), frac_hbm_peak=round(tb * 1e3 / PEAK_HBM_GBS, 4))
+        if tb * 1e3 > MEASURED_COPY_GBS:
+            out[name]['exceeds_copy_ceiling'] = True
+            print('bench.py: family %r reads %.2f TB/s on its algorithmic bytes -- above the %.2f TB/s this chip copies at: its byte '
+                  'definition is stale' % (name, tb, MEASURED_COPY_GBS / 1e3), file=sys.stderr)
         # the matrix peak of the arithmetic the step actually runs in
         if bf16:
             out[name]['frac_bf16_mfma_peak'] = round(tf / PEAK_BF16_MFMA_TFLOPS, 4)
@@ -445,6 +495,10 @@ def main():
     ap.add_argument('--timed-only', action='store_true',
                     help='skip the untimed legs (instrumented family steps, inverse CQT, inference config, CPU baselines): for rocprofv3 runs whose '
                          'kernel totals should divide by warmup + steps')
+    ap.add_argument('--cores', type=int, default=None,
+                    help='restrict this process to K host cores (applied at import, before torch; see _apply_core_cap)')
+    ap.add_argument('--capped-run', choices=('auto', 'on', 'off'), default='auto',
+                    help='N = 1: repeat the timed loop in a child process on two host cores ("core_capped_run"); auto = with the CPU baselines')
     ap.add_argument('--no-overlap', action='store_true',
                     help='N > 1: blocking all-reduce on the compute stream instead of the side-stream all-reduce overlapped with the next CQT')
     args = ap.parse_args()
@@ -507,7 +561,8 @@ def main():
     C = 16 * 2 ** (args.mc - 1)
     key, key16, keyb = 'resblock_fwd_C%d' % C, 'wide_rb_fwd_C%d' % C, 'wide_rb_bwd_C%d' % C
     keyb_half = 'wide_rb_bwd_C%d' % (C // 2)              # the level below: its backward runs as the one-pass strip kernel
-    _hip.EVENT_KEYS = {key, key16, keyb, keyb_half, 'cqt_forward'}   # the timed region brackets only the roofline calls
+    keyb_narrow = ['wide_rb_bwd_C%d' % c for c in (C // 8, C // 4)]      # the narrow levels: k_nrb_bwd_fused (the largest family of the step)
+    _hip.EVENT_KEYS = {key, key16, keyb, keyb_half, *keyb_narrow, 'cqt_forward'}   # the timed region brackets only the roofline calls
     _hip.EVENT_LOG = {}
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -528,6 +583,23 @@ def main():
         elapsed = max(float(g.item()) for g in gathered)
     ms = 1000.0 * elapsed / args.steps
     value = world * args.batch * SECS_PER_CLIP / (elapsed / args.steps)
+
+    # ---- the host side of a step (round-5 verdict, weak #12): how long Python + autograd need to ENQUEUE a step, with no sync inside --
+    # wall time until the last launch of `n_enq` steps has returned, next to the synced wall time of the same steps.  host_over_gpu << 1:
+    # the host stays ahead of the device (the launch queue absorbs the difference); -> 1: the step is host-bound.  Every rank runs it.
+    n_enq = 4
+    sync()
+    t_e0 = time.perf_counter()
+    for _ in range(n_enq):
+        step_fn(audio, target)
+    t_e1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t_e2 = time.perf_counter()
+    host_enqueue_ms = 1000.0 * (t_e1 - t_e0) / n_enq
+    host_info = dict(host_enqueue_ms=host_enqueue_ms, synced_ms=1000.0 * (t_e2 - t_e0) / n_enq, host_over_gpu=(t_e1 - t_e0) / (t_e2 - t_e0),
+                     steps=n_enq, host_cores=available_cores(),
+                     note='wall time until the last launch of the steps returned (no sync inside) / the same steps synced; a ratio near 1 '
+                          'would mean the host, not the GPU, paces the step')
 
     # ---- untimed, instrumented legs (every rank runs them so collectives stay matched; rank 0 reports) ----
     fam_events, n_inst = {}, (0 if args.timed_only else 2)
@@ -661,6 +733,38 @@ def main():
                                 ms_per_step=a_ms * n_l / args.steps,
                                 note='average per block (the event brackets tt_wide_level_bwd: three blocks + one reduce launch); algorithmic bytes = dy and x read, dx written once (the same definition as `roofline`); the kernel also reads '
                                      'the saved hidden activation: 4 tensors of traffic where the per-stage kernels move 7')
+        roof_narrow = []
+        if train_dtype in ('bf16', 'f16'):
+            pmc_txt = os.path.join(ROOT, 'profiles', 'r05_pmc_bwd_narrow.txt')
+            pmc_rows = {}
+            if os.path.exists(pmc_txt):
+                import re
+                for ln in open(pmc_txt):
+                    m_ = re.match(r'k_nrb_bwd_fused<(\d+), (\d+), \w+>\s+traffic\s+([0-9.]+) MB', ln)
+                    if m_:
+                        pmc_rows.setdefault(int(m_.group(1)), []).append(float(m_.group(3)) * 1e6)
+            for kn in keyb_narrow:
+                if not events.get(kn):
+                    continue
+                Cn = int(kn.rsplit('C', 1)[1])
+                Hn = {C // 8: 540, C // 4: 269}[Cn]
+                a_ms, n_l = avg_ms(events[kn])
+                if ops.LEVEL_BWD:
+                    a_ms, n_l = a_ms / 3.0, n_l * 3
+                nbytes = 3.0 * 2 * Cn * args.batch * Hn * M_FRAMES
+                gbs = nbytes / (a_ms * 1e-3) / 1e9
+                traffic = traffic_source = None
+                if args.batch == 64 and args.mc == 2 and pmc_rows.get(Cn):
+                    traffic = sum(pmc_rows[Cn]) / len(pmc_rows[Cn])
+                    traffic_source = ('profiles/r05_pmc_bwd_narrow.txt (rocprofv3 --pmc passes of k_nrb_bwd_fused<%d,D> at this shape: FETCH_SIZE x2 + WRITE_SIZE, '
+                                      'mean of the three dilations; not re-measured in this run)' % Cn)
+                roof_narrow.append(dict(kernel='tt_wide_rb_bwd at C=%d, H=%d: k_nrb_bwd_fused<%d,D> (the whole backward of a narrow block in one pass: h1, dy, x in, dx out) '
+                                               '+ k_nrb_reduce<%d>' % (Cn, Hn, Cn, Cn),
+                                        bound='hbm', achieved=gbs, peak=PEAK_HBM_GBS, unit='GB/s', frac=gbs / PEAK_HBM_GBS, traffic=traffic,
+                                        traffic_source=traffic_source, algorithmic_bytes=nbytes, launches=n_l, avg_ms=a_ms,
+                                        ms_per_step=a_ms * n_l / args.steps,
+                                        note='average per block (the event brackets tt_wide_level_bwd: three blocks + one reduce launch); algorithmic bytes = dy and x read, '
+                                             'dx written once (the definition of `roofline`); the kernel also reads the saved hidden activation: 4 tensors'))
         cqt = cqt_inv = None
         if events.get('cqt_forward'):
             a_ms, n_l = avg_ms(events['cqt_forward'])
@@ -792,6 +896,24 @@ def main():
             skip_step = dict(ms_per_step=s_ms, value=args.batch * SECS_PER_CLIP / (s_ms * 1e-3), unit='audio-seconds/s', dtype='bf16', steps=6,
                              warmup=2, note='the same train step with skip_connections=True (BASELINE configs[4] model)')
             del s_model, s_opt, s_step
+        capped = None
+        want_capped = args.capped_run == 'on' or (args.capped_run == 'auto' and not args.no_cpu_baseline)
+        if world == 1 and not args.timed_only and want_capped and CORE_CAP is None and args.precision == 'auto' and available_cores() > 2:
+            # the same timed loop in a CHILD process restricted to two host cores from its first instruction (`--cores 2`: affinity set
+            # before torch is imported; this parent only waits) -- what a rank gets when eight of them share this box's cores
+            import subprocess
+            cmd = [sys.executable, os.path.abspath(__file__), '--cores', '2', '--timed-only', '--steps', str(max(args.steps, 10)), '--warmup', '3',
+                   '--batch', str(args.batch), '--mc', str(args.mc), '--latent', str(args.latent)]
+            try:
+                r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+                child = next((json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith('{')), None)
+            except (subprocess.TimeoutExpired, ValueError):
+                child = None
+            if child:
+                capped = dict(cores=child['host']['host_cores'], ms_per_step=child['ms_per_step'], vs_uncapped=child['ms_per_step'] / ms,
+                              host_enqueue_ms=child['host']['host_enqueue_ms'], host_over_gpu=child['host']['host_over_gpu'],
+                              steps=child['steps'], warmup=child['warmup'],
+                              note='python bench.py --cores 2 --timed-only as a child process: the whole train step with the host side on two cores')
         base = base0 = None
         if not args.no_cpu_baseline and not args.timed_only and world == 1:
             base = cpu_baseline(args.mc, args.latent)
@@ -805,7 +927,8 @@ def main():
                                             '(bf16 MFMA conv path of BASELINE config[2]; fp32 master weights, losses and optimizer)'
                                             if args.precision == 'auto' else ''),
                                 global_batch=world * args.batch, parallelism='dp%d' % world),
-                    roofline=roof, roofline_fwd=roof_fwd if roof_fwd is not roof else None, roofline_onepass_bwd=roof_onepass, roofline_cqt=cqt, roofline_cqt_inv=cqt_inv, families=families, whole_step=whole,
+                    roofline=roof, roofline_fwd=roof_fwd if roof_fwd is not roof else None, roofline_onepass_bwd=roof_onepass,
+                    roofline_narrow_bwd=roof_narrow or None, host=host_info, core_capped_run=capped, roofline_cqt=cqt, roofline_cqt_inv=cqt_inv, families=families, whole_step=whole,
                     peak_memory_gb=peak_gb, inference_config1=infer, fp32_train_step=fp32_step, fp16_train_step=fp16_step, skip_connections_step=skip_step, per_rank_ms=per_rank_ms, allreduce_ms=allreduce_ms, overlap=overlap_info, cpu_baseline=base, cpu_baseline_config0=base0,
                     final_loss=float(total.detach()))
         print(json.dumps(line))

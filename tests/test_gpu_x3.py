@@ -514,6 +514,29 @@ def test_out_of_range_values_fall_back_to_the_fp32_kernels():
             want = model._inference(audio)
         assert bool(torch.isfinite(want).all()), 'the fp32 kernels themselves must stay finite here'
         assert bool(torch.isfinite(out).all()) and torch.equal(out, want)
+        # (iv) round 6: transcribe() / reconstruct() check ONCE, on the cross-faded result of all passes (one reduction + one host sync
+        # per call instead of one per pass and, for a skip-connection model, one per level), and fall back as a whole
+        checks = []
+        orig = ops.x3_range_ok
+        ops.x3_range_ok = lambda t: (checks.append(1), orig(t))[1]
+        try:
+            got = model.chunked_inference(audio, True)
+            assert len(checks) == 1, len(checks)
+            with ops.x3_disabled():
+                want = model.chunked_inference(audio, True)
+            assert bool(torch.isfinite(got).all()) and torch.equal(got, want)
+            big.data[2] = 0.01
+            del checks[:]
+            model.chunked_inference(audio, True)
+            assert len(checks) == 1
+            torch.manual_seed(3)
+            skip_model = TimbreTrap(22050, 9, 60, 3, latent_size=128, model_complexity=2, skip_connections=True).cuda()
+            del checks[:]
+            skip_model._inference(audio)
+            assert len(checks) == 1, 'a skip-connection forward checked its range %d times' % len(checks)
+        finally:
+            ops.x3_range_ok = orig
+        big.data[2] = 3.0e5
         model.decoder.block1.block2.conv1[0].weight.data[1, 2, 1, 1] = float('nan')
         assert not bool(torch.isfinite(model._inference(audio)).all())
 

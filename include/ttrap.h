@@ -197,6 +197,14 @@ int tt_wide_pack(const float* x, void* out, int B, int C, int H, int T, void* st
 int tt_wide_unpack(const void* in, float* y, int B, int C, int H, int T, void* stream);
 int tt_wide_rb_fwd(const void* x, const float* w1, const float* b1, const float* w2, const float* b2, void* y, void* h1,
                    int B, int C, int H, int T, int dilation, void* stream);
+/* The same block with a weighted skip join in its epilogue (round 6): y = block(x) + skip_weights[skip_idx] * skip[b mod skip_B] --
+ * the join behind a DecoderBlock (reference modules.py:112 `skip_weights[i] * embedding`, :569-589 `y = y + skip`) without a pass of
+ * its own: skip = an encoder embedding of skip_B clips, same C / H / T and element type (B % skip_B == 0; B = 2 skip_B when the decoder
+ * runs the reconstruction and the transcription decode as one batch).  skip_weights may be NULL (scale 1).  One rounding of the joined
+ * value.  Backward: the block's own backward on the incoming gradient (tt_wide_rb_bwd / tt_wide_level_bwd) + tt_skip_join16_bwd. */
+int tt_wide_rb_fwd_join(const void* x, const float* w1, const float* b1, const float* w2, const float* b2, void* y, void* h1,
+                        const void* skip, const float* skip_weights, int skip_idx, int skip_B, int B, int C, int H, int T, int dilation,
+                        void* stream);
 int tt_wide_rb_bwd(const void* x, const void* h1, const void* dy, const float* w1, const float* w2, const float* b2,
                    void* dx, float* dw1, float* db1, float* dw2, float* db2, void* ws, int B, int C, int H, int T,
                    int dilation, void* stream);
@@ -553,6 +561,9 @@ int tt_wide_pack_h(const float* x, void* out, int B, int C, int H, int T, void* 
 int tt_wide_unpack_h(const void* in, float* y, int B, int C, int H, int T, void* stream);
 int tt_wide_rb_fwd_h(const void* x, const float* w1, const float* b1, const float* w2, const float* b2, void* y, void* h1,
                    int B, int C, int H, int T, int dilation, void* stream);
+int tt_wide_rb_fwd_join_h(const void* x, const float* w1, const float* b1, const float* w2, const float* b2, void* y, void* h1,
+                          const void* skip, const float* skip_weights, int skip_idx, int skip_B, int B, int C, int H, int T, int dilation,
+                          void* stream);
 int tt_wide_rb_bwd_h(const void* x, const void* h1, const void* dy, const float* w1, const float* w2, const float* b2,
                    void* dx, float* dw1, float* db1, float* dw2, float* db2, void* ws, int B, int C, int H, int T,
                    int dilation, void* stream);

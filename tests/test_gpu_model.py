@@ -468,6 +468,7 @@ def _autocast_step_vs_oracle(n_clips, n_blocks, n_mpe, record=None, bench_target
     c, g = run['coeffs'].cuda(), run['gt'].cuda()
     pair_calls = _count_calls(monkeypatch, ops.ConvOut16PairFn) if monkeypatch is not None else None
     join_calls = _count_calls(monkeypatch, ops.SkipJoin16Fn) if monkeypatch is not None else None
+    fold_calls = _count_calls(monkeypatch, ops.Level16JoinFn) if monkeypatch is not None else None
     if monkeypatch is not None:
         monkeypatch.setattr(TimbreTrap, 'PAIR_DECODE', pair)
     with torch.autocast(device_type='cuda', dtype=dtype):
@@ -490,8 +491,10 @@ def _autocast_step_vs_oracle(n_clips, n_blocks, n_mpe, record=None, bench_target
         total.backward()
     if pair_calls is not None:
         assert len(pair_calls) == (2 if (route == 'forward' and pair) else 0), (route, pair, len(pair_calls))
-        # with skip connections model.forward joins through ops.SkipJoin16Fn (five joins per decoder pass; one pass per pair)
-        assert len(join_calls) == ((10 if pair else 20) if (skips and route == 'forward') else 0), (route, pair, len(join_calls))
+        # with skip connections model.forward joins through ops.SkipJoin16Fn (the join behind the latent head) and ops.Level16JoinFn (the
+        # four behind the DecoderBlocks, in the epilogue of the level's last block): 1 + 4 per decoder pass, one pass per pair
+        passes = (2 if pair else 4) if (skips and route == 'forward') else 0
+        assert (len(join_calls), len(fold_calls)) == (passes, 4 * passes), (route, pair, len(join_calls), len(fold_calls))
     what = '%s autocast step%s, route %s%s (%d items x %d blocks, %d annotated)' % (str(dtype).split('.')[-1], ' with skip connections' if skips else '', route,
                                                                                   '' if pair else ' (pair decode off)', n_clips, n_blocks, n_mpe)
     stats = _compare_step_with_oracle(what, ref, (rec, latents, trn, trn_rec, trn_scr), (l_rec, l_trn, l_sp, l_sc), total,
@@ -610,8 +613,8 @@ def test_every_combination_of_the_route_switches_gives_the_same_gradients(monkey
     combinations no test enumerated): all 16 settings of ``model(audio, True)`` + losses + backward under bf16 autocast at two clips
     must give the same five outputs (the forward values do not depend on any of them beyond one 16-bit rounding) and the same 120
     parameter gradients -- each set within bf16 distance of the exact-fp32 HIP path's (relative L2 5e-2 / biases 8e-2, cosine 0.998: white
-    noise coefficients at T = 256 read up to 3.3e-2 where the CQT of audio reads 1.2e-2 in the oracle tests above), and within 2e-2 of the
-    default setting's.  mc 2 / latent 128 with the default initialisation.
+    noise coefficients at T = 256 read up to 3.3e-2 where the CQT of audio reads 1.2e-2 in the oracle tests above), and within 4e-2 of the
+    default setting's (two bf16 roundings of a gradient in different places: LEVEL_BWD off gates in a pass of its own, 2.0e-2 measured).  mc 2 / latent 128 with the default initialisation.
     """
     import itertools
     from timbre_trap.framework import TimbreTrap, compute_consistency_loss, compute_reconstruction_loss, compute_transcription_loss, ops
@@ -658,7 +661,7 @@ def test_every_combination_of_the_route_switches_gives_the_same_gradients(monkey
             for a, b in zip(outs, base[0]):
                 assert float((a - b).abs().max() / b.abs().max()) < 1e-2, tag
             for k in ref:
-                assert rel(grads[k], base[1][k]) <= 2e-2, (tag, k, rel(grads[k], base[1][k]))
+                assert rel(grads[k], base[1][k]) <= 4e-2, (tag, k, rel(grads[k], base[1][k]))
         print('%s: worst gradient rel L2 vs fp32 %.3e' % (tag, worst))
 
 

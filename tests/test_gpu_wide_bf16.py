@@ -1017,6 +1017,81 @@ def test_fused_skip_joins_autograd_route_equals_the_two_step_route(monkeypatch):
             assert torch.allclose(gw1, gw2, rtol=2e-2, atol=1e-3)
 
 
+@pytest.mark.parametrize('C,shape', [(4, (2, 37, 130)), (8, (1, 40, 200)), (16, (2, 21, 96)), (32, (1, 30, 160))])
+@pytest.mark.parametrize('d', [1, 2, 3])
+@pytest.mark.parametrize('reps', [1, 2])
+def test_block_forward_with_the_skip_join_in_its_epilogue_stagewise(C, shape, d, reps):
+    """tt_wide_rb_fwd_join (round 6) against tt_wide_rb_fwd followed by the join in float64: the saved hidden activation bit-identical,
+    the joined output one rounding of (block output before ITS rounding + w * e[b mod Be]) -- compared against the separately rounded
+    sum within two roundings; ragged tile edges; the embedding shared by the two halves of the batch; NULL weights = scale 1."""
+    from timbre_trap._hip import check, ptr, stream_ptr
+    lib, st = _lib(), stream_ptr()
+    Be, H, T = shape
+    B = reps * Be
+    par = [_rand(C, C, 3, 3, seed=20, scale=1.0 / (3 * C ** 0.5)).cuda(), _rand(C, seed=30, scale=0.3).cuda(),
+           _rand(C, C, 1, 1, seed=40, scale=1.0 / C ** 0.5).cuda(), _rand(C, seed=50, scale=0.3).cuda()]
+    nhwc = lambda b: torch.empty((b, H, T, C), dtype=ELT, device='cuda')
+    x, e = nhwc(B), nhwc(Be)
+    check(lib.tt_wide_pack(ptr(_rand(B, C, H, T, seed=1).cuda()), ptr(x), B, C, H, T, st), 'pack')
+    check(lib.tt_wide_pack(ptr(_rand(Be, C, H, T, seed=2, scale=1.5).cuda()), ptr(e), Be, C, H, T, st), 'pack')
+    w = torch.tensor([0.5, -1.25, 2.0, 0.75, 1.5]).cuda()
+    y0, h0, y1, h1 = nhwc(B), nhwc(B), nhwc(B), nhwc(B)
+    check(lib.tt_wide_rb_fwd(ptr(x), *[ptr(p_) for p_ in par], ptr(y0), ptr(h0), B, C, H, T, d, st), 'fwd')
+    check(lib.tt_wide_rb_fwd_join(ptr(x), *[ptr(p_) for p_ in par], ptr(y1), ptr(h1), ptr(e), ptr(w), 1, Be, B, C, H, T, d, st), 'fwd_join')
+    torch.cuda.synchronize()
+    assert torch.equal(h0, h1)
+    want = y0.double() + (-1.25) * torch.cat([e.double()] * reps)
+    got = y1.double()
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 2.5 * BF16_REL * scale, float((got - want).abs().max()) / scale
+    # no hidden activation wanted (a forward without grad), no weights (scale 1)
+    y2 = nhwc(B)
+    check(lib.tt_wide_rb_fwd_join(ptr(x), *[ptr(p_) for p_ in par], ptr(y2), None, ptr(e), None, 0, Be, B, C, H, T, d, st), 'fwd_join')
+    want = y0.double() + torch.cat([e.double()] * reps)
+    assert float((y2.double() - want).abs().max()) <= 2.5 * BF16_REL * float(want.abs().max())
+    # refused: a batch that is not a multiple of the embedding's, in place on the embedding
+    assert lib.tt_wide_rb_fwd_join(ptr(x), *[ptr(p_) for p_ in par], ptr(y2), None, ptr(e), ptr(w), 1, B + 1, B, C, H, T, d, st) != 0
+    assert lib.tt_wide_rb_fwd_join(ptr(x), *[ptr(p_) for p_ in par], ptr(e), None, ptr(e), ptr(w), 1, Be, B, C, H, T, d, st) != 0
+
+
+@pytest.mark.parametrize('C', [4, 8, 16, 32])
+@pytest.mark.parametrize('reps', [1, 2])
+def test_skip_join_folded_into_the_level_equals_the_join_behind_it(C, reps, monkeypatch):
+    """ops.residual_level(x, blocks, join=SkipJoin) with the join in the epilogue of the level's last block (ops.SKIP_FOLD, Level16JoinFn)
+    against the same level followed by SkipJoin16Fn: output within two roundings, and EVERY gradient -- x, the embedding (gated and not),
+    the skip weight, the twelve block parameters -- the same (the blocks' own bit for bit: they see the same incoming gradient)."""
+    from timbre_trap.framework import modules, ops
+    torch.manual_seed(C)
+    blocks = [modules.ResidualConv2dBlock(C, C, 3, dd).cuda() for dd in (1, 2, 3)]
+    Be, H, T = 2, 19, 96
+    cl = lambda t: t.cuda().to(ELT).contiguous(memory_format=torch.channels_last)
+    res = []
+    for fold in (True, False):
+        monkeypatch.setattr(ops, 'SKIP_FOLD', fold)
+        x = cl(_rand(reps * Be, C, H, T, seed=3)).requires_grad_(True)
+        e = cl(_rand(Be, C, H, T, seed=4)).requires_grad_(True)
+        w = torch.tensor([1.0, 1.0, 0.7, 1.0, 1.0]).cuda().requires_grad_(True)
+        link = ops.GateLink()
+        link.producer, link.gated = True, True
+        for b_ in blocks:
+            b_.zero_grad()
+        calls = []
+        orig = ops.Level16JoinFn.apply
+        monkeypatch.setattr(ops.Level16JoinFn, 'apply', staticmethod(lambda *a: (calls.append(1), orig(*a))[1]))
+        with torch.autocast(device_type='cuda', dtype=ELT):
+            out = ops.residual_level(x, blocks, join=ops.SkipJoin(e, w, 2, link))
+        monkeypatch.setattr(ops.Level16JoinFn, 'apply', staticmethod(orig))
+        assert len(calls) == int(fold)
+        out.backward(cl(_rand(reps * Be, C, H, T, seed=5, scale=0.1)))
+        res.append((out.detach().float(), x.grad.float(), e.grad.float(), w.grad.clone(), [p_.grad.clone() for b_ in blocks for p_ in b_.parameters()]))
+    (o1, gx1, ge1, gw1, gp1), (o2, gx2, ge2, gw2, gp2) = res
+    assert float((o1 - o2).abs().max()) <= 2.5 * BF16_REL * float(o2.abs().max())
+    assert torch.equal(gx1, gx2) and torch.equal(ge1, ge2)
+    assert torch.allclose(gw1, gw2, rtol=1e-4, atol=1e-5)
+    for a, b_ in zip(gp1, gp2):
+        assert float((a - b_).abs().max()) <= 2e-5 * float(b_.abs().max() + 1e-30)
+
+
 def _pytest_subprocess(env_extra, selection):
     """The kernel switches are read once per process: the non-default paths run in a child pytest."""
     import subprocess
@@ -1058,5 +1133,5 @@ def test_fp16_build_passes_the_same_stagewise_tests():
     grids, bench heights, the gate links -- at the fp16 bars (2^-11 relative + 2.5e-4 of the tensor's scale per stored element)."""
     out = _pytest_subprocess(dict(TT_TEST_ELT='fp16', TT_CHILD_PYTEST='1'),
                              ['tests/test_gpu_wide_bf16.py', '-k', 'stagewise or multitile or edge_convs or capped_grids or bench_launch_shapes '
-                              'or bench_heights or skip_joins or level_backward_equals or hands_the_layer'])
+                              'or bench_heights or skip_joins or skip_join or level_backward_equals or hands_the_layer'])
     assert ' passed' in out

@@ -87,6 +87,9 @@ template <int C, int D> struct WT {
 };
 
 // MODE 0: x -> y (and h1 if SAVE).  MODE 1: x = dA1, res = dy, y = dx; b1 / w2 / b2 unused.
+// MODE 2 (round 6): MODE 0 with a weighted skip join in the epilogue -- y = block(x) + jw[0] * res[b mod jB], res = an encoder embedding of
+// jB clips (reference modules.py:112, :569-589: the join behind a DecoderBlock; b mod jB: both halves of a pair decode take the same
+// embedding).  One more 16- / 8-byte load per lane, requested before the products like MODE 1's dy; one rounding of the joined value.
 // MINW = waves per SIMD the register allocation must allow: at C = 32 the forward holds 72 + 8 VGPRs of weights and lands
 // at 172-176 registers -- two workgroups per CU -- unless capped at 168 (MINW = 3: four registers spill to scratch).
 template <int C, int D, int MODE, bool SAVE, int MINW>
@@ -94,8 +97,11 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_conv(const e16* __restrict__ x
                                                  const float* __restrict__ b1, const float* __restrict__ w2,
                                                  const float* __restrict__ b2, const e16* __restrict__ res,
                                                  e16* __restrict__ y, e16* __restrict__ h1, int B, int H, int T,
-                                                 int tiles_h, int tiles_t, int ntiles) {
+                                                 int tiles_h, int tiles_t, int ntiles, const float* __restrict__ jw, int jB) {
     using G = WT<C, D>;
+    constexpr bool FWD = MODE != 1, JOIN = MODE == 2;
+    float jsc = 0.f;
+    if constexpr (JOIN) jsc = jw ? jw[0] : 1.f;
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
@@ -105,7 +111,7 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_conv(const e16* __restrict__ x
 
     // ---- weights to registers, rounded to bf16 ----
     e16x8 A[NK][NCT];
-    float chk = 0.f;                                             // MODE 0: non-finite parameters (poison_acc, bf16_common.h)
+    float chk = 0.f;                                             // forward: non-finite parameters (poison_acc, bf16_common.h)
 #pragma unroll
     for (int k = 0; k < NK; ++k)
 #pragma unroll
@@ -118,9 +124,9 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_conv(const e16* __restrict__ x
                 else { tap = 2 * k + (g >> 1); kc = 8 * (g & 1) + j; }
                 const int mo = chan_of<C>(ct, n);                // output channel of row n
                 float wv = 0.f;
-                if (tap < 9) wv = MODE == 0 ? w1[(mo * C + kc) * 9 + tap] : w1[(kc * C + mo) * 9 + (8 - tap)];
+                if (tap < 9) wv = FWD ? w1[(mo * C + kc) * 9 + tap] : w1[(kc * C + mo) * 9 + (8 - tap)];
                 v[j] = wv;
-                if (MODE == 0) chk = poison_acc(chk, wv);
+                if (FWD) chk = poison_acc(chk, wv);
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) A[k][ct][j] = (e16)v[j];
@@ -128,7 +134,7 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_conv(const e16* __restrict__ x
     e16x8 A2[NCT];                                              // C = 32: W2 rows (K = 32)
     s16x4 A2s;                                                   // C = 16: W2 rows (K = 16)
     float b1r[NCH], b2r[NCH];
-    if constexpr (MODE == 0) {
+    if constexpr (FWD) {
         if constexpr (C == 32) {
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct)
@@ -149,7 +155,7 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_conv(const e16* __restrict__ x
     }
     // a NaN / inf weight or bias must reach the output like in torch (the ELU forms below return 0 for a NaN pre-activation): the
     // workgroup then writes NaN to every output it owns
-    const bool poisoned = MODE == 0 && params_poisoned(chk);
+    const bool poisoned = FWD && params_poisoned(chk);          // (a non-finite join weight propagates through the fma by itself)
 
     const e16* zero = reinterpret_cast<const e16*>(&g_wzero16);
     for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
@@ -191,12 +197,16 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_conv(const e16* __restrict__ x
             f32x4 acc[NCT];                                      // the bias enters as the accumulator's initial value
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
-                if constexpr (MODE == 0) acc[ct] = f32x4{b1r[4 * ct], b1r[4 * ct + 1], b1r[4 * ct + 2], b1r[4 * ct + 3]};
+                if constexpr (FWD) acc[ct] = f32x4{b1r[4 * ct], b1r[4 * ct + 1], b1r[4 * ct + 2], b1r[4 * ct + 3]};
                 else acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             typename std::conditional<C == 32, e16x8, e16x4>::type rq;      // MODE 1: dy of this pixel, requested early
             if constexpr (MODE == 1)            // unconditional (clamped) so that no branch pins a wait in front of the products
                 rq = *reinterpret_cast<const decltype(rq)*>(res + (valid ? pix : pix - (t - (T - 1))) * C + NCH * g);
+            if constexpr (JOIN) {               // the embedding's pixel of clip b mod jB, the same way
+                const long pe = ((long)(b % jB) * H + h) * T + (valid ? t : T - 1);
+                rq = *reinterpret_cast<const decltype(rq)*>(res + pe * C + NCH * g);
+            }
             e16x8 centre;
 #pragma unroll
             for (int k = 0; k < NK; ++k) {
@@ -245,8 +255,13 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_conv(const e16* __restrict__ x
                     e16x8 o;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        o[j] = (e16)(elu_out(z0[j]) + (float)centre[j]);
-                        o[4 + j] = (e16)(elu_out(z1[j]) + (float)centre[4 + j]);
+                        if constexpr (JOIN) {
+                            o[j] = (e16)__builtin_fmaf(jsc, (float)rq[j], elu_out(z0[j]) + (float)centre[j]);
+                            o[4 + j] = (e16)__builtin_fmaf(jsc, (float)rq[4 + j], elu_out(z1[j]) + (float)centre[4 + j]);
+                        } else {
+                            o[j] = (e16)(elu_out(z0[j]) + (float)centre[j]);
+                            o[4 + j] = (e16)(elu_out(z1[j]) + (float)centre[4 + j]);
+                        }
                     }
                     if (valid) *reinterpret_cast<e16x8*>(y + pix * C + 8 * g) = o;
                 } else {
@@ -259,7 +274,7 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_conv(const e16* __restrict__ x
                     const e16x4 xc = *reinterpret_cast<const e16x4*>(smem + ((long)pxc * C + 8 * ((g >> 1) ^ cswz<C>(colc)) + 4 * (g & 1)) * 2);
                     e16x4 o;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (e16)(elu_out(z[j]) + (float)xc[j]);
+                    for (int j = 0; j < 4; ++j) o[j] = JOIN ? (e16)__builtin_fmaf(jsc, (float)rq[j], elu_out(z[j]) + (float)xc[j]) : (e16)(elu_out(z[j]) + (float)xc[j]);
                     if (valid) *reinterpret_cast<e16x4*>(y + pix * C + 4 * g) = o;
                 }
             }
@@ -718,7 +733,7 @@ __global__ __launch_bounds__(NT, (GOUT && C == 32) ? 3 : 2) void k_wrb_dxw(const
 // ---- launchers -------------------------------------------------------------------------------------------------------
 template <int C, int D, int MODE, bool SAVE>
 int launch_conv(const e16* x, const float* w1, const float* b1, const float* w2, const float* b2, const e16* res,
-                e16* y, e16* h1, int B, int H, int T, hipStream_t st) {
+                e16* y, e16* h1, int B, int H, int T, hipStream_t st, const float* jw = nullptr, int jB = 1) {
     using G = WT<C, D>;
     const int tiles_h = (H + G::TH - 1) / G::TH, tiles_t = (T + G::TW - 1) / G::TW, ntiles = B * tiles_h * tiles_t;
     static const int per_cu = tt_tune("TTRAP_WIDE_PER_CU", 4);
@@ -728,9 +743,9 @@ int launch_conv(const e16* x, const float* w1, const float* b1, const float* w2,
     if (int rc = raise_lds(kern, G::LDS_BYTES, once)) return rc;
     // registers admit two workgroups per CU at C = 32 (forward) whatever the LDS would hold: do not launch a third that only runs
     // after the first two have finished (a tail on a third of the chip)
-    const int cap = (C == 32 && MODE == 0 && per_cu > 2) ? 2 : per_cu;
+    const int cap = (C == 32 && MODE != 1 && per_cu > 2) ? 2 : per_cu;
     hipLaunchKernelGGL(kern, dim3(grid_for(ntiles, G::LDS_BYTES, cap)), dim3(NT), G::LDS_BYTES, st, x, w1, b1, w2, b2, res, y, h1,
-                       B, H, T, tiles_h, tiles_t, ntiles);
+                       B, H, T, tiles_h, tiles_t, ntiles, jw, jB);
     TT_LAUNCH_CHECK();
     return 0;
 }
@@ -836,8 +851,10 @@ int launch_bwd(const e16* x, const e16* h1, const e16* dy, const float* w1, cons
 
 template <int C>
 int fwd_c(const e16* x, const float* w1, const float* b1, const float* w2, const float* b2, e16* y, e16* h1, int B,
-          int H, int T, int D, hipStream_t st) {
+          int H, int T, int D, hipStream_t st, const e16* je = nullptr, const float* jw = nullptr, int jB = 1) {
 #define TT_WFWD(DD)                                                                                                  \
+    if (je) return h1 ? launch_conv<C, DD, 2, true>(x, w1, b1, w2, b2, je, y, h1, B, H, T, st, jw, jB)                \
+                      : launch_conv<C, DD, 2, false>(x, w1, b1, w2, b2, je, y, nullptr, B, H, T, st, jw, jB);         \
     return h1 ? launch_conv<C, DD, 0, true>(x, w1, b1, w2, b2, nullptr, y, h1, B, H, T, st)                           \
               : launch_conv<C, DD, 0, false>(x, w1, b1, w2, b2, nullptr, y, nullptr, B, H, T, st)
     switch (D) {
@@ -889,12 +906,15 @@ template <int C, int D> struct NTl {
 
 // C = 8 forward: capped at 168 VGPRs (three waves per SIMD; 208 otherwise): 0.194 / 0.190 / 0.195 -> 0.187 / 0.186 / 0.189 ms (library A/B, round 3)
 template <int C, int D, int MODE, bool SAVE>
-__global__ __launch_bounds__(NT, (C == 8 && MODE == 0) ? 3 : 1) void k_nrb_conv(const e16* __restrict__ x, const float* __restrict__ w1,
+__global__ __launch_bounds__(NT, (C == 8 && MODE != 1) ? 3 : 1) void k_nrb_conv(const e16* __restrict__ x, const float* __restrict__ w1,
                                                  const float* __restrict__ b1, const float* __restrict__ w2,
                                                  const float* __restrict__ b2, const e16* __restrict__ res,
                                                  e16* __restrict__ y, e16* __restrict__ h1, int B, int H, int T,
-                                                 int tiles_h, int tiles_t, int ntiles) {
+                                                 int tiles_h, int tiles_t, int ntiles, const float* __restrict__ jw, int jB) {
     using G = NTl<C, D>;
+    constexpr bool FWD = MODE != 1, JOIN = MODE == 2;            // MODE 2: the forward with a skip join in its epilogue (see k_wrb_conv)
+    float jsc = 0.f;
+    if constexpr (JOIN) jsc = jw ? jw[0] : 1.f;
     typedef typename VecOf<C>::type vec_t;
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -902,7 +922,7 @@ __global__ __launch_bounds__(NT, (C == 8 && MODE == 0) ? 3 : 1) void k_nrb_conv(
     constexpr int NB = C / 4;
 
     s16x4 A[9][NB][NB], A2[NB][NB];
-    float chk = 0.f;                                             // MODE 0: non-finite parameters (poison_acc, bf16_common.h)
+    float chk = 0.f;                                             // forward: non-finite parameters (poison_acc, bf16_common.h)
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
@@ -913,14 +933,14 @@ __global__ __launch_bounds__(NT, (C == 8 && MODE == 0) ? 3 : 1) void k_nrb_conv(
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int mo = 4 * ob + i4, kc = 4 * kb + k;
-                    const float wv = MODE == 0 ? w1[(mo * C + kc) * 9 + tap] : w1[(kc * C + mo) * 9 + (8 - tap)];
-                    if (MODE == 0) chk = poison_acc(chk, wv);
+                    const float wv = FWD ? w1[(mo * C + kc) * 9 + tap] : w1[(kc * C + mo) * 9 + (8 - tap)];
+                    if (FWD) chk = poison_acc(chk, wv);
                     t[k] = (e16)wv;
                 }
                 A[tap][ob][kb] = __builtin_bit_cast(s16x4, t);
             }
     float b1r[C], b2r[C];
-    if constexpr (MODE == 0) {
+    if constexpr (FWD) {
 #pragma unroll
         for (int ob = 0; ob < NB; ++ob)
 #pragma unroll
@@ -933,7 +953,7 @@ __global__ __launch_bounds__(NT, (C == 8 && MODE == 0) ? 3 : 1) void k_nrb_conv(
 #pragma unroll
         for (int c = 0; c < C; ++c) { b1r[c] = b1[c]; b2r[c] = b2[c]; chk = poison_acc(poison_acc(chk, b1r[c]), b2r[c]); }
     }
-    const bool poisoned = MODE == 0 && params_poisoned(chk);    // see k_wrb_conv
+    const bool poisoned = FWD && params_poisoned(chk);          // see k_wrb_conv (a non-finite join weight propagates through the fma by itself)
 
     const e16* zero = reinterpret_cast<const e16*>(&g_wzero16);
     for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
@@ -977,7 +997,7 @@ __global__ __launch_bounds__(NT, (C == 8 && MODE == 0) ? 3 : 1) void k_nrb_conv(
             f32x4 acc[NB];
 #pragma unroll
             for (int ob = 0; ob < NB; ++ob) {
-                if constexpr (MODE == 0) acc[ob] = f32x4{b1r[4 * ob], b1r[4 * ob + 1], b1r[4 * ob + 2], b1r[4 * ob + 3]};
+                if constexpr (FWD) acc[ob] = f32x4{b1r[4 * ob], b1r[4 * ob + 1], b1r[4 * ob + 2], b1r[4 * ob + 3]};
                 else acc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             vec_t centre;
@@ -992,6 +1012,8 @@ __global__ __launch_bounds__(NT, (C == 8 && MODE == 0) ? 3 : 1) void k_nrb_conv(
 #pragma unroll
                     for (int kb = 0; kb < NB; ++kb) acc[ob] = mma4(A[tap][ob][kb], chunk_of<C>(bq, kb), acc[ob]);
             }
+            // (the embedding's pixel is requested here, behind the 3x3 products: requested in front of them it costs C = 8 its 168-register cap)
+            if constexpr (JOIN) rq = *reinterpret_cast<const vec_t*>(res + (((long)(b % jB) * H + h) * T + (valid ? t : T - 1)) * C);
             vec_t o;
             if constexpr (MODE == 1) {
 #pragma unroll
@@ -1009,7 +1031,8 @@ __global__ __launch_bounds__(NT, (C == 8 && MODE == 0) ? 3 : 1) void k_nrb_conv(
                     for (int kb = 0; kb < NB; ++kb) z[ob] = mma4(A2[ob][kb], chunk_of<C>(hq, kb), z[ob]);
                 }
 #pragma unroll
-                for (int c = 0; c < C; ++c) o[c] = (e16)(elu_out(z[c >> 2][c & 3]) + (float)centre[c]);
+                for (int c = 0; c < C; ++c)
+                    o[c] = JOIN ? (e16)__builtin_fmaf(jsc, (float)rq[c], elu_out(z[c >> 2][c & 3]) + (float)centre[c]) : (e16)(elu_out(z[c >> 2][c & 3]) + (float)centre[c]);
             }
             if (valid) *reinterpret_cast<vec_t*>(y + pix * C) = o;
         }
@@ -1674,7 +1697,7 @@ __global__ __launch_bounds__(1024) void k_nrb_reduce(RedBatch batch) {
 
 template <int C, int D, int MODE, bool SAVE>
 int launch_nconv(const e16* x, const float* w1, const float* b1, const float* w2, const float* b2, const e16* res,
-                 e16* y, e16* h1, int B, int H, int T, hipStream_t st) {
+                 e16* y, e16* h1, int B, int H, int T, hipStream_t st, const float* jw = nullptr, int jB = 1) {
     using G = NTl<C, D>;
     static AttrOnce once;
     auto kern = k_nrb_conv<C, D, MODE, SAVE>;
@@ -1683,7 +1706,7 @@ int launch_nconv(const e16* x, const float* w1, const float* b1, const float* w2
     // workgroups per CU (LDS allows 5-10): 2 / 4 / 6 / 8 -> data gradient of a C = 4 block 0.25 / 0.19 / 0.165 / 0.165 ms
     static const int per_cu = tt_tune("TTRAP_NARROW_PER_CU", 6);
     hipLaunchKernelGGL(kern, dim3(grid_for(ntiles, G::LDS_BYTES, per_cu)), dim3(NT), G::LDS_BYTES, st, x, w1, b1, w2, b2, res, y, h1,
-                       B, H, T, tiles_h, tiles_t, ntiles);
+                       B, H, T, tiles_h, tiles_t, ntiles, jw, jB);
     TT_LAUNCH_CHECK();
     return 0;
 }
@@ -1773,8 +1796,10 @@ int launch_nbwd(const e16* x, const e16* h1, const e16* dy, const float* w1, con
 
 template <int C>
 int nfwd_c(const e16* x, const float* w1, const float* b1, const float* w2, const float* b2, e16* y, e16* h1, int B,
-           int H, int T, int D, hipStream_t st) {
+           int H, int T, int D, hipStream_t st, const e16* je = nullptr, const float* jw = nullptr, int jB = 1) {
 #define TT_NFWD(DD)                                                                                                  \
+    if (je) return h1 ? launch_nconv<C, DD, 2, true>(x, w1, b1, w2, b2, je, y, h1, B, H, T, st, jw, jB)               \
+                      : launch_nconv<C, DD, 2, false>(x, w1, b1, w2, b2, je, y, nullptr, B, H, T, st, jw, jB);        \
     return h1 ? launch_nconv<C, DD, 0, true>(x, w1, b1, w2, b2, nullptr, y, h1, B, H, T, st)                          \
               : launch_nconv<C, DD, 0, false>(x, w1, b1, w2, b2, nullptr, y, nullptr, B, H, T, st)
     switch (D) {
@@ -1872,6 +1897,23 @@ int tt_wide_rb_fwd(const void* x, const float* w1, const float* b1, const float*
         case 16: return fwd_c<16>(xi, w1, b1, w2, b2, yo, ho, B, H, T, dilation, st);
     }
     return fwd_c<32>(xi, w1, b1, w2, b2, yo, ho, B, H, T, dilation, st);
+}
+
+int tt_wide_rb_fwd_join(const void* x, const float* w1, const float* b1, const float* w2, const float* b2, void* y, void* h1,
+                        const void* skip, const float* skip_weights, int skip_idx, int skip_B, int B, int C, int H, int T, int dilation,
+                        void* stream) {
+    if (!x || !w1 || !b1 || !w2 || !b2 || !y || !skip || skip_idx < 0 || skip_B < 1 || B % skip_B || !shape_ok(B, C, H, T)) return TT_E_BADARG;
+    if (y == skip || y == x) return TT_E_BADARG;
+    const e16 *xi = (const e16*)x, *je = (const e16*)skip;
+    const float* jw = skip_weights ? skip_weights + skip_idx : nullptr;
+    e16 *yo = (e16*)y, *ho = (e16*)h1;
+    hipStream_t st = tt_stream(stream);
+    switch (C) {
+        case 4: return nfwd_c<4>(xi, w1, b1, w2, b2, yo, ho, B, H, T, dilation, st, je, jw, skip_B);
+        case 8: return nfwd_c<8>(xi, w1, b1, w2, b2, yo, ho, B, H, T, dilation, st, je, jw, skip_B);
+        case 16: return fwd_c<16>(xi, w1, b1, w2, b2, yo, ho, B, H, T, dilation, st, je, jw, skip_B);
+    }
+    return fwd_c<32>(xi, w1, b1, w2, b2, yo, ho, B, H, T, dilation, st, je, jw, skip_B);
 }
 
 int tt_wide_rb_bwd_is_onepass(int C, int dilation) {

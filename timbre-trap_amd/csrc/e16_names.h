@@ -7,6 +7,7 @@
 #define tt_wide_pack tt_wide_pack_h
 #define tt_wide_unpack tt_wide_unpack_h
 #define tt_wide_rb_fwd tt_wide_rb_fwd_h
+#define tt_wide_rb_fwd_join tt_wide_rb_fwd_join_h
 #define tt_wide_rb_bwd_is_onepass tt_wide_rb_bwd_is_onepass_h
 #define tt_wide_rb_bwd tt_wide_rb_bwd_h
 #define tt_wide_fused_scratch_bytes tt_wide_fused_scratch_bytes_h

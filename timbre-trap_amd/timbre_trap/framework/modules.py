@@ -109,12 +109,14 @@ class DecoderBlock(nn.Module):
         self.block2 = ResidualConv2dBlock(out_channels, out_channels, kernel_size=3, dilation=2)
         self.block3 = ResidualConv2dBlock(out_channels, out_channels, kernel_size=3, dilation=3)
 
-    def forward(self, x, out_x3=False, uplink=None):
+    def forward(self, x, out_x3=False, uplink=None, join=None):
+        """``join`` (ops.SkipJoin): the skip connection behind this block (reference modules.py:569-589 `y = block(y) + skip`), applied here so
+        that the level's last kernel can take it in its epilogue."""
         t = self.tconv[0]
         # y has no consumer but the level: the level's backward may hand the transposed layer its gradient already gated (ops.GateLink)
         link = ops.gate_link() if torch.is_grad_enabled() else None
         y = ops.transposed_conv(x, t.weight, t.bias, self.win, self.hop, self.out_pad, out_x3=ops.x3_chain(), link=link, uplink=uplink)
-        return ops.residual_level(y, (self.block1, self.block2, self.block3), out_x3=out_x3, link=link)
+        return ops.residual_level(y, (self.block1, self.block2, self.block3), out_x3=out_x3, link=link, join=join)
 
 
 class EmbeddingList(list):
@@ -219,9 +221,10 @@ class Decoder(nn.Module):
         for i, block in enumerate(blocks):
             # transposed layers with a split-operand kernel: 64 -> 32 and 32 -> 16 channels (tt_x3_tconv_fwd)
             t = blocks[i + 1].tconv[0] if i + 1 < len(blocks) else None
+            fold = skips is not None and isinstance(skips[i + 1], ops.SkipJoin)
             y = block(y, out_x3=skips is None and ops.x3_chain() and t is not None and (t.in_channels, t.out_channels) in ((64, 32), (32, 16)),
-                      uplink=uplink if i == 0 else None)
-            if skips is not None:
+                      uplink=uplink if i == 0 else None, join=skips[i + 1] if fold else None)
+            if skips is not None and not fold:
                 y = ops.skip_join(y, skips[i + 1])
         o = self.convout
         if pair:

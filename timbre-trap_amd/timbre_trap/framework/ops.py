@@ -749,6 +749,117 @@ def gate_link():
     return GateLink() if PREGATE else None
 
 
+def _level16_forward(ctx, x, dilations, link, join, params):
+    """Level16Fn / Level16JoinFn forward.  ``join`` = None or (e, weights, idx, link of e): the level's LAST block adds weights[idx] * e[b mod Be]
+    in its epilogue (tt_wide_rb_fwd_join)."""
+    B, C, H, T = x.shape
+    lib, st = lib16(x), stream_ptr()
+    needs_grad = any(ctx.needs_input_grad)
+    recompute = C in RECOMPUTE_CHANNELS
+    # the promise to gate: only where backward will take the one-call path below (all of it known now)
+    ctx.gate = bool(link is not None and link.producer and ctx.needs_input_grad[0] and LEVEL_BWD and not recompute
+                    and len(_chunks(B)) == 1 and len(dilations) <= 4)
+    if ctx.gate:
+        link.gated = True
+    nb = len(dilations)
+    outs = [new_cl16(B, C, H, T, x.device, x.dtype) for _ in range(nb)]
+    hids = [new_cl16(B, C, H, T, x.device, x.dtype) if (needs_grad and not recompute) else None for _ in range(nb)]
+    if join is not None and len(_chunks(B)) != 1:
+        raise RuntimeError('a level with a folded skip join runs unchunked (ops.residual_level decides)')
+    for b0, b1 in _chunks(B):
+        cur = x[b0:b1]
+        for i, d in enumerate(dilations):
+            w1, b1_, w2, b2 = params[4 * i: 4 * i + 4]
+            h1 = hids[i][b0:b1] if hids[i] is not None else None
+            with _hip.timed('wide_rb_fwd_C%d' % C, clips=b1 - b0):
+                if join is not None and i == nb - 1:
+                    je, jw, jidx = join[:3]
+                    check(lib.tt_wide_rb_fwd_join(ptr(cur), ptr(w1), ptr(b1_), ptr(w2), ptr(b2), ptr(outs[i][b0:b1]), ptr(h1), ptr(je), ptr(jw), jidx,
+                                                  je.size(0), b1 - b0, C, H, T, d, st), 'tt_wide_rb_fwd_join')
+                else:
+                    check(lib.tt_wide_rb_fwd(ptr(cur), ptr(w1), ptr(b1_), ptr(w2), ptr(b2), ptr(outs[i][b0:b1]), ptr(h1), b1 - b0, C, H, T,
+                                             d, st), 'tt_wide_rb_fwd')
+            cur = outs[i][b0:b1]
+    ctx.dilations = tuple(dilations)
+    ctx.params = params
+    ctx.recompute = recompute
+    ctx.join = None if join is None else (join[2], join[3], join[1])        # idx, link, the weights parameter object
+    if needs_grad:
+        saved = []
+        for i in range(nb):
+            saved += [x if i == 0 else outs[i - 1]] + ([] if recompute else [hids[i]])
+        ctx.save_for_backward(*params, *(() if join is None else join[:2]), *saved)
+    return outs[-1]
+
+
+def _level16_backward(ctx, dy):
+    """-> (dx, [values returned to autograd for the parameters], de, value returned for the skip weights)."""
+    nb = len(ctx.dilations)
+    tensors = ctx.saved_tensors
+    nj = 0 if ctx.join is None else 2
+    params, saved = tensors[:4 * nb], tensors[4 * nb + nj:]
+    B, C, H, T = saved[0].shape
+    dt = saved[0].dtype
+    lib, st = lib16(dt), stream_ptr()
+    g_all = _as_cl16(dy, dt)
+    de = rs = None
+    if ctx.join is not None:
+        # the folded join's backward: de = w * (sum over the halves of dy) [* ELU'(e)], dw += <sum, e> -- dy itself goes on into the blocks
+        je, jw = tensors[4 * nb: 4 * nb + 2]
+        jidx, jlink, jparam = ctx.join
+        want_e, want_w = ctx.needs_input_grad[3], ctx.needs_input_grad[4]
+        de = new_cl16(*je.shape, je.device, je.dtype) if want_e else None
+        ds = None
+        if want_w:
+            ds, rs = _grad_target(jparam)
+        if de is not None or ds is not None:
+            check(lib.tt_skip_join16_bwd(ptr(g_all), ptr(je), ptr(jw), jidx, ptr(de), ptr(ds), je.numel(), B // je.size(0),
+                                         int(jlink is not None and jlink.gated), st), 'tt_skip_join16_bwd')
+    chunks = _chunks(B)
+    cb = chunks[0][1] - chunks[0][0]
+    recompute = ctx.recompute
+    ws_bytes = lib.tt_wide_fused_scratch_bytes(C) if recompute else lib.tt_wide_scratch_bytes(cb, C, H, T)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=g_all.device)
+    targets = [_grad_target(t) for t in ctx.params]
+    dx = new_cl16(B, C, H, T, g_all.device, dt)
+    tmp = [new_cl16(cb, C, H, T, g_all.device, dt) for _ in range(2)] if nb > 1 else []
+    if LEVEL_BWD and not recompute and len(chunks) == 1 and nb <= 4:
+        # the whole level in one call: the partial-sum reduces of its blocks are one launch at the end (tt_wide_level_bwd)
+        def arr(ts):
+            return (ctypes.c_void_p * nb)(*[t.data_ptr() for t in ts])
+        ws = torch.empty(lib.tt_wide_level_scratch_bytes(nb, B, C, H, T), dtype=torch.uint8, device=g_all.device)
+        cols = list(zip(*[[targets[4 * i + j][0] for j in range(4)] for i in range(nb)]))      # dw1s, db1s, dw2s, db2s
+        dil = (ctypes.c_int * nb)(*ctx.dilations)
+        fn = lib.tt_wide_level_bwd_gated if ctx.gate else lib.tt_wide_level_bwd
+        with _hip.timed('wide_rb_bwd_C%d' % C, clips=B):
+            check(fn(nb, arr([saved[2 * i] for i in range(nb)]), arr([saved[2 * i + 1] for i in range(nb)]), ptr(g_all),
+                     arr([params[4 * i] for i in range(nb)]), arr([params[4 * i + 2] for i in range(nb)]),
+                     arr([params[4 * i + 3] for i in range(nb)]), ptr(dx), ptr(tmp[0]) if tmp else None,
+                     ptr(tmp[1]) if tmp else None, arr(cols[0]), arr(cols[1]), arr(cols[2]), arr(cols[3]), ptr(ws),
+                     B, C, H, T, dil, st), 'tt_wide_level_bwd')
+        return dx, [r for _, r in targets], de, rs
+    if ctx.gate:
+        raise RuntimeError('ops.LEVEL_BWD / LEVEL_CHUNK / RECOMPUTE_CHANNELS changed between the forward and the backward of a level')
+    for b0, b1 in chunks:
+        g = g_all[b0:b1]
+        for i in reversed(range(nb)):
+            w1, b1_, w2, b2 = params[4 * i: 4 * i + 4]
+            (dw1, _), (db1, _), (dw2, _), (db2, _) = targets[4 * i: 4 * i + 4]
+            gx = dx[b0:b1] if i == 0 else tmp[i & 1][:b1 - b0]
+            with _hip.timed('wide_rb_bwd_C%d' % C, clips=b1 - b0):
+                if recompute:
+                    xin = saved[i][b0:b1]
+                    check(lib.tt_wide_rb_bwd_fused(ptr(xin), ptr(g), ptr(w1), ptr(b1_), ptr(w2), ptr(b2), ptr(gx), ptr(dw1), ptr(db1),
+                                                   ptr(dw2), ptr(db2), ptr(ws), b1 - b0, C, H, T, ctx.dilations[i], st),
+                          'tt_wide_rb_bwd_fused')
+                else:
+                    xin, h1 = saved[2 * i][b0:b1], saved[2 * i + 1][b0:b1]
+                    check(lib.tt_wide_rb_bwd(ptr(xin), ptr(h1), ptr(g), ptr(w1), ptr(w2), ptr(b2), ptr(gx), ptr(dw1), ptr(db1),
+                                             ptr(dw2), ptr(db2), ptr(ws), b1 - b0, C, H, T, ctx.dilations[i], st), 'tt_wide_rb_bwd')
+            g = gx
+    return dx, [r for _, r in targets], de, rs
+
+
 class Level16Fn(torch.autograd.Function):
     """The residual blocks of one level on cl16 tensors (csrc/conv_wide_bf16.hip, csrc/conv_level_bf16.hip); see WideLevelFn for
     the fp32-facing form.  Saved for backward: the input of every block, plus its hidden activation at the widths whose
@@ -756,89 +867,27 @@ class Level16Fn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, dilations, link, *params):
-        B, C, H, T = x.shape
-        lib, st = lib16(x), stream_ptr()
-        needs_grad = any(ctx.needs_input_grad)
-        recompute = C in RECOMPUTE_CHANNELS
-        # the promise to gate: only where backward will take the one-call path below (all of it known now)
-        ctx.gate = bool(link is not None and link.producer and ctx.needs_input_grad[0] and LEVEL_BWD and not recompute
-                        and len(_chunks(B)) == 1 and len(dilations) <= 4)
-        if ctx.gate:
-            link.gated = True
-        nb = len(dilations)
-        outs = [new_cl16(B, C, H, T, x.device, x.dtype) for _ in range(nb)]
-        hids = [new_cl16(B, C, H, T, x.device, x.dtype) if (needs_grad and not recompute) else None for _ in range(nb)]
-        for b0, b1 in _chunks(B):
-            cur = x[b0:b1]
-            for i, d in enumerate(dilations):
-                w1, b1_, w2, b2 = params[4 * i: 4 * i + 4]
-                h1 = hids[i][b0:b1] if hids[i] is not None else None
-                with _hip.timed('wide_rb_fwd_C%d' % C, clips=b1 - b0):
-                    check(lib.tt_wide_rb_fwd(ptr(cur), ptr(w1), ptr(b1_), ptr(w2), ptr(b2), ptr(outs[i][b0:b1]), ptr(h1), b1 - b0, C, H, T,
-                                             d, st), 'tt_wide_rb_fwd')
-                cur = outs[i][b0:b1]
-        ctx.dilations = tuple(dilations)
-        ctx.params = params
-        ctx.recompute = recompute
-        if needs_grad:
-            saved = []
-            for i in range(nb):
-                saved += [x if i == 0 else outs[i - 1]] + ([] if recompute else [hids[i]])
-            ctx.save_for_backward(*params, *saved)
-        return outs[-1]
+        return _level16_forward(ctx, x, dilations, link, None, params)
 
     @staticmethod
     def backward(ctx, dy):
-        nb = len(ctx.dilations)
-        tensors = ctx.saved_tensors
-        params, saved = tensors[:4 * nb], tensors[4 * nb:]
-        B, C, H, T = saved[0].shape
-        dt = saved[0].dtype
-        lib, st = lib16(dt), stream_ptr()
-        g_all = _as_cl16(dy, dt)
-        chunks = _chunks(B)
-        cb = chunks[0][1] - chunks[0][0]
-        recompute = ctx.recompute
-        ws_bytes = lib.tt_wide_fused_scratch_bytes(C) if recompute else lib.tt_wide_scratch_bytes(cb, C, H, T)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=g_all.device)
-        targets = [_grad_target(t) for t in ctx.params]
-        dx = new_cl16(B, C, H, T, g_all.device, dt)
-        tmp = [new_cl16(cb, C, H, T, g_all.device, dt) for _ in range(2)] if nb > 1 else []
-        if LEVEL_BWD and not recompute and len(chunks) == 1 and nb <= 4:
-            # the whole level in one call: the partial-sum reduces of its blocks are one launch at the end (tt_wide_level_bwd)
-            def arr(ts):
-                return (ctypes.c_void_p * nb)(*[t.data_ptr() for t in ts])
-            ws = torch.empty(lib.tt_wide_level_scratch_bytes(nb, B, C, H, T), dtype=torch.uint8, device=g_all.device)
-            cols = list(zip(*[[targets[4 * i + j][0] for j in range(4)] for i in range(nb)]))      # dw1s, db1s, dw2s, db2s
-            dil = (ctypes.c_int * nb)(*ctx.dilations)
-            fn = lib.tt_wide_level_bwd_gated if ctx.gate else lib.tt_wide_level_bwd
-            with _hip.timed('wide_rb_bwd_C%d' % C, clips=B):
-                check(fn(nb, arr([saved[2 * i] for i in range(nb)]), arr([saved[2 * i + 1] for i in range(nb)]), ptr(g_all),
-                         arr([params[4 * i] for i in range(nb)]), arr([params[4 * i + 2] for i in range(nb)]),
-                         arr([params[4 * i + 3] for i in range(nb)]), ptr(dx), ptr(tmp[0]) if tmp else None,
-                         ptr(tmp[1]) if tmp else None, arr(cols[0]), arr(cols[1]), arr(cols[2]), arr(cols[3]), ptr(ws),
-                         B, C, H, T, dil, st), 'tt_wide_level_bwd')
-            return (dx, None, None, *[r for _, r in targets])
-        if ctx.gate:
-            raise RuntimeError('ops.LEVEL_BWD / LEVEL_CHUNK / RECOMPUTE_CHANNELS changed between the forward and the backward of a level')
-        for b0, b1 in chunks:
-            g = g_all[b0:b1]
-            for i in reversed(range(nb)):
-                w1, b1_, w2, b2 = params[4 * i: 4 * i + 4]
-                (dw1, _), (db1, _), (dw2, _), (db2, _) = targets[4 * i: 4 * i + 4]
-                gx = dx[b0:b1] if i == 0 else tmp[i & 1][:b1 - b0]
-                with _hip.timed('wide_rb_bwd_C%d' % C, clips=b1 - b0):
-                    if recompute:
-                        xin = saved[i][b0:b1]
-                        check(lib.tt_wide_rb_bwd_fused(ptr(xin), ptr(g), ptr(w1), ptr(b1_), ptr(w2), ptr(b2), ptr(gx), ptr(dw1), ptr(db1),
-                                                       ptr(dw2), ptr(db2), ptr(ws), b1 - b0, C, H, T, ctx.dilations[i], st),
-                              'tt_wide_rb_bwd_fused')
-                    else:
-                        xin, h1 = saved[2 * i][b0:b1], saved[2 * i + 1][b0:b1]
-                        check(lib.tt_wide_rb_bwd(ptr(xin), ptr(h1), ptr(g), ptr(w1), ptr(w2), ptr(b2), ptr(gx), ptr(dw1), ptr(db1),
-                                                 ptr(dw2), ptr(db2), ptr(ws), b1 - b0, C, H, T, ctx.dilations[i], st), 'tt_wide_rb_bwd')
-                g = gx
-        return (dx, None, None, *[r for _, r in targets])
+        dx, rp, _, _ = _level16_backward(ctx, dy)
+        return (dx, None, None, *rp)
+
+
+class Level16JoinFn(torch.autograd.Function):
+    """Level16Fn whose LAST block adds the weighted skip in its epilogue: level(x) + weights[idx] * e[b mod Be] (round 6: the join behind a
+    DecoderBlock, reference modules.py:569-589, without a pass of its own -- tt_wide_rb_fwd_join; backward = the level's backward on the
+    incoming gradient + tt_skip_join16_bwd for e and the weight).  ``elink``: the GateLink of e (see SkipJoin16Fn)."""
+
+    @staticmethod
+    def forward(ctx, x, dilations, link, e, weights, idx, elink, *params):
+        return _level16_forward(ctx, x, dilations, link, (e, weights, idx, elink), params)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx, rp, de, rs = _level16_backward(ctx, dy)
+        return (dx, None, None, de, rs, None, None, *rp)
 
 
 class SConv16Fn(torch.autograd.Function):
@@ -1176,13 +1225,31 @@ def scale(e, weights, i):
     return ScaleFn.apply(e, weights, i)
 
 
-def residual_level(x, blocks, out_x3=False, link=None):
+# TTRAP_SKIP_FOLD=0 / ops.SKIP_FOLD = False: the join behind a DecoderBlock as a pass of its own (SkipJoin16Fn) instead of the epilogue of the
+# level's last block (A/B)
+SKIP_FOLD = os.environ.get('TTRAP_SKIP_FOLD', '1') != '0'
+
+
+def residual_level(x, blocks, out_x3=False, link=None, join=None):
     """
     block3(block2(block1(x))) for the ResidualConv2dBlock modules ``blocks``.  With ops.cl16_mode() the level runs
     on cl16 tensors (Level16Fn) and RETURNS a cl16 tensor -- the next layer either has a bf16 kernel or converts with
     to_planar32; otherwise the per-block fp32 path.  ``out_x3``: the caller's next layer takes a split-operand tensor (is_x3):
-    honoured only where the level itself runs on them (x3_inference()).
+    honoured only where the level itself runs on them (x3_inference()).  ``join`` (a SkipJoin): the result + the weighted skip -- in the
+    epilogue of the level's last block where the level runs on cl16 tensors (Level16JoinFn), else skip_join() behind it.
     """
+    if join is not None:
+        C, T = x.size(1), x.size(-1)
+        e = join.e
+        if (SKIP_FOLD and cl16_mode() and is_cl16(x) and is_cl16(e) and e.dtype == x.dtype and e.shape[1:] == x.shape[1:] and x.size(0) % e.size(0) == 0
+                and x.size(0) // e.size(0) in (1, 2) and e.numel() % 8 == 0 and C in WIDE_CHANNELS and FUSED_RESBLOCK and (C != 4 or T % 2 == 0)
+                and _i32_ok(x) and len(_chunks(x.size(0))) == 1 and join.weights.dtype == torch.float32 and join.weights.is_contiguous()
+                and all(b.conv1[0].weight.shape == (C, C, 3, 3) and 1 <= b.dilation <= 3 for b in blocks)):
+            params = []
+            for b in blocks:
+                params += [b.conv1[0].weight, b.conv1[0].bias, b.conv2[0].weight, b.conv2[0].bias]
+            return Level16JoinFn.apply(x, tuple(b.dilation for b in blocks), link, e, join.weights, join.idx, join.link, *params)
+        return skip_join(residual_level(x, blocks, False, link), join)
     if is_x3(x):
         return x3_level(x, blocks, out_x3)
     C, T = x.size(1), x.size(-1)
@@ -1870,6 +1937,7 @@ def _scale_backward(cls, dtype_of):
 
 
 _scale_backward(Level16Fn, lambda ctx: ctx.saved_tensors[-1].dtype)
+_scale_backward(Level16JoinFn, lambda ctx: ctx.saved_tensors[-1].dtype)
 _scale_backward(WideLevelFn, lambda ctx: ctx.dtype)
 _scale_backward(SConv16Fn, lambda ctx: ctx.saved_tensors[0].dtype)
 _scale_backward(TConv16Fn, lambda ctx: ctx.saved_tensors[0].dtype)
@@ -1909,6 +1977,7 @@ _instrument(ConvIn16Fn, 'edge16', lambda x, *a: 'in')
 _instrument(ConvOut16Fn, 'edge16', lambda x, *a: 'out')
 _instrument(ConvOut16PairFn, 'edge16', lambda x, *a: 'out')
 _instrument(Level16Fn, 'widelevel', lambda x, *a: 'C%d' % x.size(1))
+_instrument(Level16JoinFn, 'widelevel', lambda x, *a: 'C%d' % x.size(1))
 _instrument(SConv16Fn, 'sconv16', lambda x, *a: 'C%d' % x.size(1))
 _instrument(TConv16Fn, 'tconv16', lambda x, w, *a: 'C%d' % w.size(1))
 _instrument(ToCL16Fn, 'tocl16', lambda x: 'C%d' % x.size(1))

@@ -292,6 +292,26 @@ def test_config1_split_operand_wide_levels_agree_with_fp32_kernels():
     assert not calls
 
 
+def test_config1_split_operand_narrow_levels_agree_with_fp32_kernels(monkeypatch):
+    """ops.X3N_INFER (the narrow levels of the no-grad fp32 forward on split operands, tt_x3n_level_fwd): on against off -- the exact-fp32
+    kernels k_small_fwd4 / k_small_lds -- far inside the 1e-4 bar, and the switch really selects the route."""
+    from timbre_trap.framework import ops
+    g = torch.Generator().manual_seed(6)
+    audio = (torch.rand(2, 1, N, generator=g) * 2 - 1).cuda()
+    sd = oae.closed_form_state_dict(oae.state_dict_shapes(540, **KW['mc2']), amplitude=0.06)
+    model = _model(KW['mc2'], sd).eval()
+    calls = []
+    orig = ops.x3n_level
+    monkeypatch.setattr(ops, 'x3n_level', lambda x, blocks: (calls.append(x.size(1)), orig(x, blocks))[1])
+    with torch.no_grad():
+        on = model.chunked_inference(audio, True)
+        assert sorted(set(calls)) == [4, 8] and len(calls) == 4, calls           # encoder + decoder, two narrow levels each
+        monkeypatch.setattr(ops, 'X3N_INFER', False)
+        off = model.chunked_inference(audio, True)
+        assert len(calls) == 4
+    assert float((on - off).abs().max() / off.abs().max()) < 5e-6
+
+
 def test_transcribe_reconstruct_config1_mc2_batch():
     """
     BASELINE configs[1]: model_complexity 2 / latent 128, a BATCH of clips through transcribe() + reconstruct()
@@ -490,11 +510,14 @@ def _autocast_step_vs_oracle(n_clips, n_blocks, n_mpe, record=None, bench_target
         model.zero_grad()
         total.backward()
     if pair_calls is not None:
-        assert len(pair_calls) == (2 if (route == 'forward' and pair) else 0), (route, pair, len(pair_calls))
+        assert len(pair_calls) == (2 if (route == 'forward' and pair and (not skips or ops.SKIP_FUSED)) else 0), (route, pair, len(pair_calls))
         # with skip connections model.forward joins through ops.SkipJoin16Fn (the join behind the latent head) and ops.Level16JoinFn (the
         # four behind the DecoderBlocks, in the epilogue of the level's last block): 1 + 4 per decoder pass, one pass per pair
-        passes = (2 if pair else 4) if (skips and route == 'forward') else 0
+        fused = skips and route == 'forward' and ops.SKIP_FUSED
+        passes = (2 if pair else 4) if fused else 0
         assert (len(join_calls), len(fold_calls)) == (passes, 4 * passes), (route, pair, len(join_calls), len(fold_calls))
+        if skips and route == 'forward' and not fused:
+            assert len(pair_calls) == 0
     what = '%s autocast step%s, route %s%s (%d items x %d blocks, %d annotated)' % (str(dtype).split('.')[-1], ' with skip connections' if skips else '', route,
                                                                                   '' if pair else ' (pair decode off)', n_clips, n_blocks, n_mpe)
     stats = _compare_step_with_oracle(what, ref, (rec, latents, trn, trn_rec, trn_scr), (l_rec, l_trn, l_sp, l_sc), total,
@@ -545,8 +568,9 @@ def test_autocast_fp16_step_matches_oracle_outputs_losses_and_all_gradients(rout
 
 
 @pytest.mark.parametrize('dtype,route,pair', [(torch.bfloat16, 'forward', True), (torch.bfloat16, 'forward', False), (torch.bfloat16, 'twice', True),
-                                              (torch.float16, 'forward', True)],
-                         ids=['bf16-model.forward-pair-decode', 'bf16-model.forward-two-decodes', 'bf16-scaled-embeddings-decode-twice', 'fp16-model.forward-pair-decode'])
+                                              (torch.float16, 'forward', True), (torch.bfloat16, 'forward-unfused', True)],
+                         ids=['bf16-model.forward-pair-decode', 'bf16-model.forward-two-decodes', 'bf16-scaled-embeddings-decode-twice', 'fp16-model.forward-pair-decode',
+                              'bf16-model.forward-SKIP_FUSED-off'])
 def test_autocast_step_with_skip_connections_matches_oracle(dtype, route, pair, monkeypatch):
     """
     The model of BASELINE configs[4] (skip_connections=True, reference modules.py:61-63, 95-117, 569-589) on the 16-bit path against the
@@ -555,7 +579,11 @@ def test_autocast_step_with_skip_connections_matches_oracle(dtype, route, pair, 
     embedding + join in one pass each way, the embedding shared by both halves of the pair decode, its gradient gated in the same pass);
     'scaled embeddings' is the public apply_skip_connections + decode route (scale and join as two passes, gate tap).
     """
+    from timbre_trap.framework import ops
     bars = (3e-2, 1e-2, 3e-2, 6e-2, 0.999, 2e-2) if dtype == torch.bfloat16 else (4e-3, 2.5e-3, 8e-2, 8e-2, 0.998, 3e-3)
+    if route == 'forward-unfused':          # ops.SKIP_FUSED off: model.forward itself takes the scaled-embedding route (the A/B switch)
+        monkeypatch.setattr(ops, 'SKIP_FUSED', False)
+        route = 'forward'
     _autocast_step_vs_oracle(2, 1, 2, dtype=dtype, bars=bars, route=route, pair=pair, monkeypatch=monkeypatch, tag='mc2skip')
 
 
@@ -613,7 +641,7 @@ def test_every_combination_of_the_route_switches_gives_the_same_gradients(monkey
     combinations no test enumerated): all 16 settings of ``model(audio, True)`` + losses + backward under bf16 autocast at two clips
     must give the same five outputs (the forward values do not depend on any of them beyond one 16-bit rounding) and the same 120
     parameter gradients -- each set within bf16 distance of the exact-fp32 HIP path's (relative L2 5e-2 / biases 8e-2, cosine 0.998: white
-    noise coefficients at T = 256 read up to 3.3e-2 where the CQT of audio reads 1.2e-2 in the oracle tests above), and within 4e-2 of the
+    noise coefficients at T = 256 read up to 3.3e-2 where the CQT of audio reads 1.2e-2 in the oracle tests above), and within 4e-2 (biases 8e-2) of the
     default setting's (two bf16 roundings of a gradient in different places: LEVEL_BWD off gates in a pass of its own, 2.0e-2 measured).  mc 2 / latent 128 with the default initialisation.
     """
     import itertools
@@ -661,7 +689,7 @@ def test_every_combination_of_the_route_switches_gives_the_same_gradients(monkey
             for a, b in zip(outs, base[0]):
                 assert float((a - b).abs().max() / b.abs().max()) < 1e-2, tag
             for k in ref:
-                assert rel(grads[k], base[1][k]) <= 4e-2, (tag, k, rel(grads[k], base[1][k]))
+                assert rel(grads[k], base[1][k]) <= (8e-2 if k.endswith('.bias') else 4e-2), (tag, k, rel(grads[k], base[1][k]))
         print('%s: worst gradient rel L2 vs fp32 %.3e' % (tag, worst))
 
 

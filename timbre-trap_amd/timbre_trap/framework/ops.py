@@ -686,10 +686,9 @@ def conv_out_pair(x, w, b):
     return y[:h], y[h:]
 
 
-# Clips per pass of a level (0 = the whole batch at once, the default): with a chunk, the three blocks run back to back on a few clips
-# at a time, so a block reads what the previous one just wrote while it may still be in the 256 MB memory-side cache.  Measured at 64
-# clips: 69.9 ms per step unchunked, 74.1 / 79.8 / 93.6 ms with chunks of 32 / 16 / 8 -- smaller launches cost more than the cache gives.
-LEVEL_CHUNK = int(os.environ.get('TTRAP_LEVEL_CHUNK', '0'))
+# (Clips-per-pass chunking of a level -- three blocks back to back on a few clips so that a block finds its input in the 256 MB memory-side
+# cache -- was measured in rounds 2 and 4 and removed in round 6: 69.9 ms per step unchunked, 74.1 / 79.8 / 93.6 ms with chunks of 32 / 16 / 8
+# clips; smaller launches cost more than the cache gives.)
 
 
 # TTRAP_LEVEL_RECOMPUTE=1: the residual blocks of the wide levels (C = 16, 32) run their backward as ONE fused pass that
@@ -703,11 +702,6 @@ RECOMPUTE_CHANNELS = (16, 32) if os.environ.get('TTRAP_LEVEL_RECOMPUTE', '0') ==
 
 # TTRAP_LEVEL_BWD=0: one tt_wide_rb_bwd call (with its own reduce launch) per block instead of tt_wide_level_bwd (A/B switch)
 LEVEL_BWD = os.environ.get('TTRAP_LEVEL_BWD', '1') != '0'
-
-
-def _chunks(B):
-    c = LEVEL_CHUNK if 0 < LEVEL_CHUNK < B else B
-    return [(b0, min(B, b0 + c)) for b0 in range(0, B, c)]
 
 
 # A residual level's backward can hand the layer in front of it its gradient ALREADY multiplied by that layer's ELU derivative: the
@@ -757,29 +751,23 @@ def _level16_forward(ctx, x, dilations, link, join, params):
     needs_grad = any(ctx.needs_input_grad)
     recompute = C in RECOMPUTE_CHANNELS
     # the promise to gate: only where backward will take the one-call path below (all of it known now)
-    ctx.gate = bool(link is not None and link.producer and ctx.needs_input_grad[0] and LEVEL_BWD and not recompute
-                    and len(_chunks(B)) == 1 and len(dilations) <= 4)
+    ctx.gate = bool(link is not None and link.producer and ctx.needs_input_grad[0] and LEVEL_BWD and not recompute and len(dilations) <= 4)
     if ctx.gate:
         link.gated = True
     nb = len(dilations)
     outs = [new_cl16(B, C, H, T, x.device, x.dtype) for _ in range(nb)]
     hids = [new_cl16(B, C, H, T, x.device, x.dtype) if (needs_grad and not recompute) else None for _ in range(nb)]
-    if join is not None and len(_chunks(B)) != 1:
-        raise RuntimeError('a level with a folded skip join runs unchunked (ops.residual_level decides)')
-    for b0, b1 in _chunks(B):
-        cur = x[b0:b1]
-        for i, d in enumerate(dilations):
-            w1, b1_, w2, b2 = params[4 * i: 4 * i + 4]
-            h1 = hids[i][b0:b1] if hids[i] is not None else None
-            with _hip.timed('wide_rb_fwd_C%d' % C, clips=b1 - b0):
-                if join is not None and i == nb - 1:
-                    je, jw, jidx = join[:3]
-                    check(lib.tt_wide_rb_fwd_join(ptr(cur), ptr(w1), ptr(b1_), ptr(w2), ptr(b2), ptr(outs[i][b0:b1]), ptr(h1), ptr(je), ptr(jw), jidx,
-                                                  je.size(0), b1 - b0, C, H, T, d, st), 'tt_wide_rb_fwd_join')
-                else:
-                    check(lib.tt_wide_rb_fwd(ptr(cur), ptr(w1), ptr(b1_), ptr(w2), ptr(b2), ptr(outs[i][b0:b1]), ptr(h1), b1 - b0, C, H, T,
-                                             d, st), 'tt_wide_rb_fwd')
-            cur = outs[i][b0:b1]
+    cur = x
+    for i, d in enumerate(dilations):
+        w1, b1_, w2, b2 = params[4 * i: 4 * i + 4]
+        with _hip.timed('wide_rb_fwd_C%d' % C, clips=B):
+            if join is not None and i == nb - 1:
+                je, jw, jidx = join[:3]
+                check(lib.tt_wide_rb_fwd_join(ptr(cur), ptr(w1), ptr(b1_), ptr(w2), ptr(b2), ptr(outs[i]), ptr(hids[i]), ptr(je), ptr(jw), jidx,
+                                              je.size(0), B, C, H, T, d, st), 'tt_wide_rb_fwd_join')
+            else:
+                check(lib.tt_wide_rb_fwd(ptr(cur), ptr(w1), ptr(b1_), ptr(w2), ptr(b2), ptr(outs[i]), ptr(hids[i]), B, C, H, T, d, st), 'tt_wide_rb_fwd')
+        cur = outs[i]
     ctx.dilations = tuple(dilations)
     ctx.params = params
     ctx.recompute = recompute
@@ -815,15 +803,13 @@ def _level16_backward(ctx, dy):
         if de is not None or ds is not None:
             check(lib.tt_skip_join16_bwd(ptr(g_all), ptr(je), ptr(jw), jidx, ptr(de), ptr(ds), je.numel(), B // je.size(0),
                                          int(jlink is not None and jlink.gated), st), 'tt_skip_join16_bwd')
-    chunks = _chunks(B)
-    cb = chunks[0][1] - chunks[0][0]
     recompute = ctx.recompute
-    ws_bytes = lib.tt_wide_fused_scratch_bytes(C) if recompute else lib.tt_wide_scratch_bytes(cb, C, H, T)
+    ws_bytes = lib.tt_wide_fused_scratch_bytes(C) if recompute else lib.tt_wide_scratch_bytes(B, C, H, T)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=g_all.device)
     targets = [_grad_target(t) for t in ctx.params]
     dx = new_cl16(B, C, H, T, g_all.device, dt)
-    tmp = [new_cl16(cb, C, H, T, g_all.device, dt) for _ in range(2)] if nb > 1 else []
-    if LEVEL_BWD and not recompute and len(chunks) == 1 and nb <= 4:
+    tmp = [new_cl16(B, C, H, T, g_all.device, dt) for _ in range(2)] if nb > 1 else []
+    if LEVEL_BWD and not recompute and nb <= 4:
         # the whole level in one call: the partial-sum reduces of its blocks are one launch at the end (tt_wide_level_bwd)
         def arr(ts):
             return (ctypes.c_void_p * nb)(*[t.data_ptr() for t in ts])
@@ -839,24 +825,20 @@ def _level16_backward(ctx, dy):
                      B, C, H, T, dil, st), 'tt_wide_level_bwd')
         return dx, [r for _, r in targets], de, rs
     if ctx.gate:
-        raise RuntimeError('ops.LEVEL_BWD / LEVEL_CHUNK / RECOMPUTE_CHANNELS changed between the forward and the backward of a level')
-    for b0, b1 in chunks:
-        g = g_all[b0:b1]
-        for i in reversed(range(nb)):
-            w1, b1_, w2, b2 = params[4 * i: 4 * i + 4]
-            (dw1, _), (db1, _), (dw2, _), (db2, _) = targets[4 * i: 4 * i + 4]
-            gx = dx[b0:b1] if i == 0 else tmp[i & 1][:b1 - b0]
-            with _hip.timed('wide_rb_bwd_C%d' % C, clips=b1 - b0):
-                if recompute:
-                    xin = saved[i][b0:b1]
-                    check(lib.tt_wide_rb_bwd_fused(ptr(xin), ptr(g), ptr(w1), ptr(b1_), ptr(w2), ptr(b2), ptr(gx), ptr(dw1), ptr(db1),
-                                                   ptr(dw2), ptr(db2), ptr(ws), b1 - b0, C, H, T, ctx.dilations[i], st),
-                          'tt_wide_rb_bwd_fused')
-                else:
-                    xin, h1 = saved[2 * i][b0:b1], saved[2 * i + 1][b0:b1]
-                    check(lib.tt_wide_rb_bwd(ptr(xin), ptr(h1), ptr(g), ptr(w1), ptr(w2), ptr(b2), ptr(gx), ptr(dw1), ptr(db1),
-                                             ptr(dw2), ptr(db2), ptr(ws), b1 - b0, C, H, T, ctx.dilations[i], st), 'tt_wide_rb_bwd')
-            g = gx
+        raise RuntimeError('ops.LEVEL_BWD / RECOMPUTE_CHANNELS changed between the forward and the backward of a level')
+    g = g_all
+    for i in reversed(range(nb)):
+        w1, b1_, w2, b2 = params[4 * i: 4 * i + 4]
+        (dw1, _), (db1, _), (dw2, _), (db2, _) = targets[4 * i: 4 * i + 4]
+        gx = dx if i == 0 else tmp[i & 1]
+        with _hip.timed('wide_rb_bwd_C%d' % C, clips=B):
+            if recompute:
+                check(lib.tt_wide_rb_bwd_fused(ptr(saved[i]), ptr(g), ptr(w1), ptr(b1_), ptr(w2), ptr(b2), ptr(gx), ptr(dw1), ptr(db1),
+                                               ptr(dw2), ptr(db2), ptr(ws), B, C, H, T, ctx.dilations[i], st), 'tt_wide_rb_bwd_fused')
+            else:
+                check(lib.tt_wide_rb_bwd(ptr(saved[2 * i]), ptr(saved[2 * i + 1]), ptr(g), ptr(w1), ptr(w2), ptr(b2), ptr(gx), ptr(dw1), ptr(db1),
+                                         ptr(dw2), ptr(db2), ptr(ws), B, C, H, T, ctx.dilations[i], st), 'tt_wide_rb_bwd')
+        g = gx
     return dx, [r for _, r in targets], de, rs
 
 
@@ -1243,7 +1225,7 @@ def residual_level(x, blocks, out_x3=False, link=None, join=None):
         e = join.e
         if (SKIP_FOLD and cl16_mode() and is_cl16(x) and is_cl16(e) and e.dtype == x.dtype and e.shape[1:] == x.shape[1:] and x.size(0) % e.size(0) == 0
                 and x.size(0) // e.size(0) in (1, 2) and e.numel() % 8 == 0 and C in WIDE_CHANNELS and FUSED_RESBLOCK and (C != 4 or T % 2 == 0)
-                and _i32_ok(x) and len(_chunks(x.size(0))) == 1 and join.weights.dtype == torch.float32 and join.weights.is_contiguous()
+                and _i32_ok(x) and join.weights.dtype == torch.float32 and join.weights.is_contiguous()
                 and all(b.conv1[0].weight.shape == (C, C, 3, 3) and 1 <= b.dilation <= 3 for b in blocks)):
             params = []
             for b in blocks:

@@ -491,6 +491,9 @@ def main():
                          "(BASELINE config[2]), inference runs in exact fp32; fp32 / bf16x3 / bf16 force one arithmetic everywhere")
     ap.add_argument('--mode', choices=('train', 'infer'), default='train',
                     help="train = the headline metric; infer = BASELINE config[1]: transcribe() + reconstruct() on 32 clips x 3 s")
+    ap.add_argument('--skip-connections', action='store_true',
+                    help='time the skip_connections=True model (BASELINE configs[4]) as the main line (profiling; the default line reports it as '
+                         '"skip_connections_step")')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--timed-only', action='store_true',
                     help='skip the untimed legs (instrumented family steps, inverse CQT, inference config, CPU baselines): for rocprofv3 runs whose '
@@ -540,7 +543,7 @@ def main():
     dev = torch.device('cuda', local_rank)
     _hip.lib()
 
-    model = build_model(args.mc, args.latent, dev)
+    model = build_model(args.mc, args.latent, dev, skip=args.skip_connections)
     if args.mode == 'infer':
         return bench_inference(model, args, rank, world, dev)
     opt = FusedAdamW(model.parameters(), lr=1e-3, max_norm=10.0)
@@ -922,8 +925,8 @@ def main():
                     unit='audio-seconds/s', n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms,
                     higher_is_better=True, scaling='weak', vs_baseline=None, dtype=train_dtype, data='synthetic',
                     config=dict(workload='full train step (CQT x2 + AE fwd/bwd with consistency + 3 losses + clip + AdamW), '
-                                         'model_complexity=%d latent=%d, %d clips x 3 s per GPU%s'
-                                         % (args.mc, args.latent, args.batch, ', under torch.autocast like reference experiments/train.py:415 '
+                                         'model_complexity=%d latent=%d%s, %d clips x 3 s per GPU%s'
+                                         % (args.mc, args.latent, ' skip_connections=True' if args.skip_connections else '', args.batch, ', under torch.autocast like reference experiments/train.py:415 '
                                             '(bf16 MFMA conv path of BASELINE config[2]; fp32 master weights, losses and optimizer)'
                                             if args.precision == 'auto' else ''),
                                 global_batch=world * args.batch, parallelism='dp%d' % world),

@@ -374,7 +374,9 @@ int tt_dot16(const void* a, const void* b, float* out, int64_t n, void* stream);
 /* The weighted skip join as ONE pass each way (round 6; reference modules.py:112 `skip_weights[i] * embedding` and :569-589
  * `y = y + skip`), 16-bit channels-last tensors, n = elements of ONE embedding (n % 8 == 0, 16-byte aligned pointers):
  *   fwd:  out[r*n + i] = y[r*n + i] + s[idx] * e[i]              r < reps (1 or 2)
- *   bwd:  t = sum_r g[r*n + i];   de[i] = s[idx] * t  (* ELU'(e[i]) if gate);   ds[idx] += sum_i t * e[i]      (dy = g: not written)
+ *   bwd:  t = sum_r g[r*n + i];   de[i] = s[idx] * t  (* ELU'(e[i]) if gate & 1);   ds[idx] += sum_i t * e[i]      (dy = g: not written)
+ *         gate & 2: de[i] += instead of = -- de already holds the other contribution to the embedding's gradient (the data gradient of
+ *         the encoder level behind it), so that no separate add is left
  * reps = 2: the decoder runs the reconstruction and the transcription decode of the same latents as one batch of 2 B clips
  * (TimbreTrap.decode_pair) and both halves take the same encoder embedding -- read once, never duplicated.  gate: e is the output of a
  * strided layer + ELU whose backward takes its gradient already multiplied by ELU'(e) (tt_sconv16_bwd_pregated): this contribution

@@ -271,7 +271,7 @@ def _layer_cases():
     cases.append(('latdec', lambda: ((lambda z, w, b: ops.LatDec16Fn.apply(z, w, b, 0.625)), [_rand(2, 128, 48, seed=25).cuda()],
                                      [_rand(129, 64, 31, 1, seed=26, scale=0.05), _rand(64, seed=27, scale=0.2)], cl(_rand(2, 64, 31, 48, seed=28, scale=0.05)))))
     # (round 6: the skip join INSIDE the region; the public scale / add / tap route sees true gradients -- its own test below)
-    cases.append(('skip join', lambda: ((lambda y, e, sw: ops.SkipJoin16Fn.apply(y, e, sw, 3, None)), [cl(_rand(4, 16, 9, 64, seed=32)), cl(_rand(2, 16, 9, 64, seed=29))],
+    cases.append(('skip join', lambda: ((lambda y, e, sw: ops.SkipJoin16Fn.apply(y, e, sw, 3, None, False)), [cl(_rand(4, 16, 9, 64, seed=32)), cl(_rand(2, 16, 9, 64, seed=29))],
                                         [torch.ones(5) * 0.75], cl(_rand(4, 16, 9, 64, seed=31, scale=0.05)))))
     return cases
 

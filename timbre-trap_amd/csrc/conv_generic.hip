@@ -342,8 +342,9 @@ __global__ __launch_bounds__(256) void k_skip_join_fwd(const E* __restrict__ y, 
 // Its backward: t = sum_r g[r][i] (fp32);  de[i] = s[idx] * t, times ELU'(e[i]) when GATE (e is the output of a strided layer + ELU whose
 // backward takes its gradient already gated -- ops.GateLink: the factor every OTHER contribution to that gradient carries);
 // ds[idx] += unscale * sum_i t * e[i] (the gradient of the skip weight: leaves the 16-bit region, the fp16 loss scale comes off).
-// dy = g is not written: the caller hands g itself on.
-template <class E, int REPS, bool GATE>
+// dy = g is not written: the caller hands g itself on.  ACC: de += instead of = (de already holds the OTHER contribution to the embedding's
+// gradient -- the data gradient of the encoder level behind it, gated the same way -- so that autograd has nothing left to add).
+template <class E, int REPS, bool GATE, bool ACC>
 __global__ __launch_bounds__(256) void k_skip_join_bwd(const E* __restrict__ g, const E* __restrict__ e, const float* __restrict__ s, int idx,
                                                        E* __restrict__ de, float* __restrict__ ds, long n8, float unscale) {
     typedef E e8 __attribute__((ext_vector_type(8)));
@@ -356,6 +357,7 @@ __global__ __launch_bounds__(256) void k_skip_join_bwd(const E* __restrict__ g, 
 #pragma unroll
         for (int r = 0; r < REPS; ++r) gv[r] = reinterpret_cast<const e8*>(g)[r * n8 + i];
         e8 o;
+        if (ACC) o = reinterpret_cast<const e8*>(de)[i];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float t = (float)gv[0][j];
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(256) void k_skip_join_bwd(const E* __restrict__ g, 
             acc = fmaf(t, x, acc);
             float d = sc * t;
             if (GATE) d *= __builtin_fminf(x + 1.f, 1.f);             // ELU'(pre-activation) from the ELU's output (bf16_common.h: elu_dout)
-            o[j] = (E)d;
+            o[j] = ACC ? (E)((float)o[j] + d) : (E)d;
         }
         if (de) reinterpret_cast<e8*>(de)[i] = o;
     }
@@ -706,16 +708,20 @@ static int skip_join16_fwd(const void* y, const void* e, const float* s, int idx
 template <class E>
 static int skip_join16_bwd(const void* g, const void* e, const float* s, int idx, void* de, float* ds, int64_t n, int reps, int gate,
                            void* stream) {
-    if (!g || !e || n < 0 || n % 8 || (reps != 1 && reps != 2) || idx < 0 || (!de && !ds)) return TT_E_BADARG;
+    const int acc = (gate >> 1) & 1;
+    gate &= 1;
+    if (!g || !e || n < 0 || n % 8 || (reps != 1 && reps != 2) || idx < 0 || (!de && !ds) || (acc && !de)) return TT_E_BADARG;
     if ((((uintptr_t)g | (uintptr_t)e | (uintptr_t)de) & 15) != 0) return TT_E_BADARG;
     if (n == 0) return 0;
     const long n8 = n / 8;
     const dim3 grid(grid1d(n8, 256, 8 * 256));
     const float un = tt_loss_unscale();
     hipStream_t st = tt_stream(stream);
-#define TT_SJB(R, G) hipLaunchKernelGGL((k_skip_join_bwd<E, R, G>), grid, dim3(256), 0, st, (const E*)g, (const E*)e, s, idx, (E*)de, ds, n8, un)
-    if (reps == 1) { if (gate) TT_SJB(1, true); else TT_SJB(1, false); }
-    else           { if (gate) TT_SJB(2, true); else TT_SJB(2, false); }
+#define TT_SJB(R, G, A) hipLaunchKernelGGL((k_skip_join_bwd<E, R, G, A>), grid, dim3(256), 0, st, (const E*)g, (const E*)e, s, idx, (E*)de, ds, n8, un)
+#define TT_SJB2(R, G) do { if (acc) TT_SJB(R, G, true); else TT_SJB(R, G, false); } while (0)
+    if (reps == 1) { if (gate) TT_SJB2(1, true); else TT_SJB2(1, false); }
+    else           { if (gate) TT_SJB2(2, true); else TT_SJB2(2, false); }
+#undef TT_SJB2
 #undef TT_SJB
     TT_LAUNCH_CHECK();
     return 0;

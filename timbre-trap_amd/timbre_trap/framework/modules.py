@@ -260,7 +260,7 @@ class TimbreTrap(nn.Module):
             return None
         return [ops.scale(e, self.skip_weights, i) for i, e in enumerate(embeddings)]
 
-    def skip_joins(self, embeddings):
+    def skip_joins(self, embeddings, defer=False):
         """What ``forward`` hands the decoder instead of ``apply_skip_connections(embeddings)`` on the 16-bit channels-last path: one
         ops.SkipJoin per embedding -- ``skip_weights[i] * e_i`` and the decoder's ``y + skip`` (reference modules.py:112, :569-589) are
         then ONE pass each way, on the encoder's own output tensors.  None where that does not apply (no skip connections, fp32 path,
@@ -268,7 +268,7 @@ class TimbreTrap(nn.Module):
         if (self.skip_weights is None or not ops.SKIP_FUSED or not ops.cl16_mode() or not isinstance(embeddings, EmbeddingList)
                 or not all(ops.is_cl16(e) and e.numel() % 8 == 0 for e in embeddings.raw)):
             return None
-        return [ops.SkipJoin(e, self.skip_weights, i, link) for i, (e, link) in enumerate(zip(embeddings.raw, embeddings.links))]
+        return [ops.SkipJoin(e, self.skip_weights, i, link, defer) for i, (e, link) in enumerate(zip(embeddings.raw, embeddings.links))]
 
     def decode(self, latents, embeddings=None, transcribe=False):
         """latents (B,D,T) -> logits (B,2,F,T); the extra latent channel is 1 for reconstruction, 0 for transcription."""
@@ -377,12 +377,13 @@ class TimbreTrap(nn.Module):
         (reconstruction, latents, transcription, transcription_rec, transcription_scr, losses).
         """
         latents, embeddings, losses = self.encode(audio)
-        embeddings = self.skip_joins(embeddings) or self.apply_skip_connections(embeddings)
+        # (defer: encoder and decoder are one graph here, so the joins' backward may be folded into the encoder layers' -- ops._join_backward)
+        embeddings = self.skip_joins(embeddings, defer=True) or self.apply_skip_connections(embeddings)
         reconstruction, transcription = self.decode_pair(latents, embeddings)
         transcription_rec = transcription_scr = None
         if consistency:
             latents_trn, embeddings_trn, _ = self.encoder(transcription)
-            embeddings_trn = self.skip_joins(embeddings_trn) or self.apply_skip_connections(embeddings_trn)
+            embeddings_trn = self.skip_joins(embeddings_trn, defer=True) or self.apply_skip_connections(embeddings_trn)
             transcription_rec, transcription_scr = self.decode_pair(latents_trn, embeddings_trn)
         return reconstruction, latents, transcription, transcription_rec, transcription_scr, losses
 

@@ -720,9 +720,15 @@ PREGATE = os.environ.get('TTRAP_PREGATE', '1') != '0'
 # (tt_latent16_expand_gated), and the first DecoderBlock's transposed layer gates ITS dx for Decoder.convin -- which it can only do in its
 # pregated form, i.e. when the level behind it gates in turn: that promise `depends` on the other link's, read at backward time.
 class GateLink:
-    __slots__ = ('producer', '_gated', 'depends')
+    __slots__ = ('producer', '_gated', 'depends', 'accumulates', 'pending')
 
     def __init__(self):
+        # Deferred skip joins (round 6): `accumulates` -- set by the forward of the layer that CONSUMES the linked tensor inside the encoder
+        # (Level16Fn, LatEnc16Fn): its backward will fold whatever sits in `pending` into the data gradient it writes (flush_pending);
+        # `pending` -- the backward of a skip join on the same tensor (which runs earlier: the decoder comes after the encoder) parks its
+        # arguments there instead of writing a gradient tensor of its own that autograd would then have to add to that data gradient.
+        self.accumulates = False
+        self.pending = []
         self.producer = False        # set by the producing layer's forward (SConv16Fn / TConv16Fn / LatDec16Fn): it is a 16-bit one and
                                      # its backward will look at `gated`
         self._gated = False          # set by the consumer's forward (Level16Fn / LatEnc16Fn / TConv16Fn): the gradient its backward
@@ -754,6 +760,9 @@ def _level16_forward(ctx, x, dilations, link, join, params):
     ctx.gate = bool(link is not None and link.producer and ctx.needs_input_grad[0] and LEVEL_BWD and not recompute and len(dilations) <= 4)
     if ctx.gate:
         link.gated = True
+    ctx.link = link
+    if link is not None and ctx.needs_input_grad[0]:
+        link.accumulates = True             # this level's backward folds parked skip-join backwards into its dx (flush_pending)
     nb = len(dilations)
     outs = [new_cl16(B, C, H, T, x.device, x.dtype) for _ in range(nb)]
     hids = [new_cl16(B, C, H, T, x.device, x.dtype) if (needs_grad and not recompute) else None for _ in range(nb)]
@@ -771,7 +780,7 @@ def _level16_forward(ctx, x, dilations, link, join, params):
     ctx.dilations = tuple(dilations)
     ctx.params = params
     ctx.recompute = recompute
-    ctx.join = None if join is None else (join[2], join[3], join[1])        # idx, link, the weights parameter object
+    ctx.join = None if join is None else (join[2], join[3], join[1], join[4])        # idx, link, the weights parameter object, defer
     if needs_grad:
         saved = []
         for i in range(nb):
@@ -794,15 +803,8 @@ def _level16_backward(ctx, dy):
     if ctx.join is not None:
         # the folded join's backward: de = w * (sum over the halves of dy) [* ELU'(e)], dw += <sum, e> -- dy itself goes on into the blocks
         je, jw = tensors[4 * nb: 4 * nb + 2]
-        jidx, jlink, jparam = ctx.join
-        want_e, want_w = ctx.needs_input_grad[3], ctx.needs_input_grad[4]
-        de = new_cl16(*je.shape, je.device, je.dtype) if want_e else None
-        ds = None
-        if want_w:
-            ds, rs = _grad_target(jparam)
-        if de is not None or ds is not None:
-            check(lib.tt_skip_join16_bwd(ptr(g_all), ptr(je), ptr(jw), jidx, ptr(de), ptr(ds), je.numel(), B // je.size(0),
-                                         int(jlink is not None and jlink.gated), st), 'tt_skip_join16_bwd')
+        jidx, jlink, jparam, jdefer = ctx.join
+        de, rs = _join_backward(g_all, je, jw, jidx, B // je.size(0), jlink, jparam, ctx.needs_input_grad[3], ctx.needs_input_grad[4], jdefer)
     recompute = ctx.recompute
     ws_bytes = lib.tt_wide_fused_scratch_bytes(C) if recompute else lib.tt_wide_scratch_bytes(B, C, H, T)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=g_all.device)
@@ -823,6 +825,7 @@ def _level16_backward(ctx, dy):
                      arr([params[4 * i + 3] for i in range(nb)]), ptr(dx), ptr(tmp[0]) if tmp else None,
                      ptr(tmp[1]) if tmp else None, arr(cols[0]), arr(cols[1]), arr(cols[2]), arr(cols[3]), ptr(ws),
                      B, C, H, T, dil, st), 'tt_wide_level_bwd')
+        flush_pending(ctx.link, dx)
         return dx, [r for _, r in targets], de, rs
     if ctx.gate:
         raise RuntimeError('ops.LEVEL_BWD / RECOMPUTE_CHANNELS changed between the forward and the backward of a level')
@@ -839,6 +842,7 @@ def _level16_backward(ctx, dy):
                 check(lib.tt_wide_rb_bwd(ptr(saved[2 * i]), ptr(saved[2 * i + 1]), ptr(g), ptr(w1), ptr(w2), ptr(b2), ptr(gx), ptr(dw1), ptr(db1),
                                          ptr(dw2), ptr(db2), ptr(ws), B, C, H, T, ctx.dilations[i], st), 'tt_wide_rb_bwd')
         g = gx
+    flush_pending(ctx.link, dx)
     return dx, [r for _, r in targets], de, rs
 
 
@@ -863,13 +867,13 @@ class Level16JoinFn(torch.autograd.Function):
     incoming gradient + tt_skip_join16_bwd for e and the weight).  ``elink``: the GateLink of e (see SkipJoin16Fn)."""
 
     @staticmethod
-    def forward(ctx, x, dilations, link, e, weights, idx, elink, *params):
-        return _level16_forward(ctx, x, dilations, link, (e, weights, idx, elink), params)
+    def forward(ctx, x, dilations, link, e, weights, idx, elink, defer, *params):
+        return _level16_forward(ctx, x, dilations, link, (e, weights, idx, elink, defer), params)
 
     @staticmethod
     def backward(ctx, dy):
         dx, rp, de, rs = _level16_backward(ctx, dy)
-        return (dx, None, None, de, rs, None, None, *rp)
+        return (dx, None, None, de, rs, None, None, None, *rp)
 
 
 class SConv16Fn(torch.autograd.Function):
@@ -1133,14 +1137,60 @@ class SkipJoin:
     """A skip connection that has not been applied yet: (encoder embedding, the skip weights, which one, the embedding's GateLink).
     TimbreTrap.forward hands these to the decoder on the 16-bit path instead of the scaled tensors of apply_skip_connections: the
     product and the join are then ONE pass (SkipJoin16Fn) and the embedding serves both halves of a pair decode."""
-    __slots__ = ('e', 'weights', 'idx', 'link')
+    __slots__ = ('e', 'weights', 'idx', 'link', 'defer')
 
-    def __init__(self, e, weights, idx, link=None):
+    def __init__(self, e, weights, idx, link=None, defer=False):
         self.e, self.weights, self.idx, self.link = e, weights, idx, link
+        # defer (TimbreTrap.forward only, where encoder and decoder are one graph): the embedding's share of the join's backward may be left
+        # to the backward of the encoder layer behind the embedding (GateLink.pending) -- see _join_backward
+        self.defer = bool(defer)
 
 
 # TTRAP_SKIP_FUSED=0 / ops.SKIP_FUSED = False: scale and join as two passes per decode, decodes one by one (the round 2-5 route; A/B)
 SKIP_FUSED = os.environ.get('TTRAP_SKIP_FUSED', '1') != '0'
+
+
+# TTRAP_SKIP_DEFER=0 / ops.SKIP_DEFER = False: every skip join writes the embedding's gradient in its own backward and autograd adds it to the
+# encoder level's data gradient (A/B)
+SKIP_DEFER = os.environ.get('TTRAP_SKIP_DEFER', '1') != '0'
+
+
+def _join_backward(g, e, weights, idx, reps, link, param, want_e, want_w, defer):
+    """The backward of a weighted skip join, out[r] = y[r] + weights[idx] * e (r < reps), for e and the weight; g = the incoming 16-bit
+    gradient (it IS dy).  -> (de, value returned to autograd for the weights).
+    Deferred form: where the embedding's other consumer is an encoder layer that accumulates (GateLink.accumulates) and the weight's
+    gradient goes straight into the optimizer's flat buffer, NOTHING is computed here -- the arguments wait in link.pending until that
+    layer's backward has written its data gradient dx, and ONE pass then does dx += w * (sum of the halves of g) [* ELU'(e)] and the
+    weight's dot product (flush_pending): 2 g + e + dx read, dx written, where de written here + autograd's add moved 2 g + e read, de
+    written, de + dx read, sum written."""
+    if not want_e and not want_w:
+        return None, None
+    ds = rs = None
+    if want_w:
+        ds, rs = _grad_target(param)
+    if (defer and SKIP_DEFER and want_e and link is not None and link.accumulates and rs is None and not torch.is_grad_enabled()):
+        link.pending.append((g, e, weights, idx, reps, ds))
+        return None, None
+    de = new_cl16(*e.shape, e.device, e.dtype) if want_e else None
+    gate = link is not None and link.gated
+    check(lib16(e).tt_skip_join16_bwd(ptr(g), ptr(e), ptr(weights), idx, ptr(de), ptr(ds), e.numel(), reps, int(gate), stream_ptr()),
+          'tt_skip_join16_bwd')
+    return de, rs
+
+
+def flush_pending(link, dx):
+    """Called by the backward of an encoder layer that consumes a linked tensor, after it has written the data gradient ``dx`` of that tensor
+    (gated iff link.gated): fold the parked skip-join backwards into it (see _join_backward).  Inside the caller's loss_scaled scope."""
+    if link is None or not link.pending:
+        return
+    pend, link.pending = link.pending, []
+    for g, e, weights, idx, reps, ds in pend:
+        if dx is None:                      # the layer's input wanted no gradient: only the weight's share is left to do
+            if ds is not None:
+                check(lib16(e).tt_skip_join16_bwd(ptr(g), ptr(e), ptr(weights), idx, None, ptr(ds), e.numel(), reps, 0, stream_ptr()), 'tt_skip_join16_bwd')
+            continue
+        flags = (1 if link.gated else 0) | 2
+        check(lib16(e).tt_skip_join16_bwd(ptr(g), ptr(e), ptr(weights), idx, ptr(dx), ptr(ds), e.numel(), reps, flags, stream_ptr()), 'tt_skip_join16_bwd')
 
 
 class SkipJoin16Fn(torch.autograd.Function):
@@ -1151,9 +1201,10 @@ class SkipJoin16Fn(torch.autograd.Function):
     carries ELU'(e) -- what GateTapFn + tt_gate16 did in two more passes."""
 
     @staticmethod
-    def forward(ctx, y, e, weights, idx, link):
+    def forward(ctx, y, e, weights, idx, link, defer):
         B, C, H, T = e.shape
         reps = y.size(0) // B
+        ctx.defer = defer
         if y.dtype != e.dtype or y.shape[1:] != e.shape[1:] or reps * B != y.size(0) or reps not in (1, 2):
             raise ValueError('skip join of %s %s and %s %s tensors' % (tuple(y.shape), y.dtype, tuple(e.shape), e.dtype))
         out = new_cl16(reps * B, C, H, T, y.device, y.dtype)
@@ -1167,15 +1218,8 @@ class SkipJoin16Fn(torch.autograd.Function):
         e, weights = ctx.saved_tensors
         B, C, H, T = e.shape
         g = _as_cl16(g, e.dtype)
-        de = new_cl16(B, C, H, T, e.device, e.dtype) if ctx.needs_input_grad[1] else None
-        ds = rs = None
-        if ctx.needs_input_grad[2]:
-            ds, rs = _grad_target(ctx.param)
-        if de is not None or ds is not None:
-            gate = ctx.link is not None and ctx.link.gated
-            check(lib16(e).tt_skip_join16_bwd(ptr(g), ptr(e), ptr(weights), ctx.idx, ptr(de), ptr(ds), e.numel(), ctx.reps, int(gate), stream_ptr()),
-                  'tt_skip_join16_bwd')
-        return g, de, rs, None, None
+        de, rs = _join_backward(g, e, weights, ctx.idx, ctx.reps, ctx.link, ctx.param, ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.defer)
+        return g, de, rs, None, None, None
 
 
 def skip_join(y, skip):
@@ -1185,7 +1229,7 @@ def skip_join(y, skip):
     e, w = skip.e, skip.weights
     if (is_cl16(y) and is_cl16(e) and y.dtype == e.dtype and e.numel() % 8 == 0 and w.dtype == torch.float32 and w.is_contiguous()
             and y.shape[1:] == e.shape[1:] and y.size(0) in (e.size(0), 2 * e.size(0))):
-        return SkipJoin16Fn.apply(y, e, w, skip.idx, skip.link)
+        return SkipJoin16Fn.apply(y, e, w, skip.idx, skip.link, skip.defer)
     # any other layout: the two-step form on whatever the tensors are (the tap carries the gate of a linked embedding)
     scaled = scale(gate_tap(e, skip.link), w, skip.idx)
     if y.size(0) == 2 * e.size(0):
@@ -1230,7 +1274,7 @@ def residual_level(x, blocks, out_x3=False, link=None, join=None):
             params = []
             for b in blocks:
                 params += [b.conv1[0].weight, b.conv1[0].bias, b.conv2[0].weight, b.conv2[0].bias]
-            return Level16JoinFn.apply(x, tuple(b.dilation for b in blocks), link, e, join.weights, join.idx, join.link, *params)
+            return Level16JoinFn.apply(x, tuple(b.dilation for b in blocks), link, e, join.weights, join.idx, join.link, join.defer, *params)
         return skip_join(residual_level(x, blocks, False, link), join)
     if is_x3(x):
         return x3_level(x, blocks, out_x3)
@@ -1590,6 +1634,9 @@ class LatEnc16Fn(torch.autograd.Function):
         ctx.gate = bool(link is not None and link.producer and ctx.needs_input_grad[0])
         if ctx.gate:
             link.gated = True
+        ctx.link = link
+        if link is not None and ctx.needs_input_grad[0]:
+            link.accumulates = True         # flush_pending in backward
         ctx.params = (w, b)
         ctx.save_for_backward(x, w)
         return y
@@ -1609,6 +1656,7 @@ class LatEnc16Fn(torch.autograd.Function):
                 check(lib.tt_latent16_expand_gated(ptr(dy), ptr(w), ptr(x), ptr(dx), ptr(ws), B, CT, D, E, T, st), 'tt_latent16_expand_gated')
             else:
                 check(lib.tt_latent16_expand(ptr(dy), D, 0.0, ptr(w), None, ptr(dx), ptr(ws), B, CT, D, E, T, st), 'tt_latent16_expand')
+        flush_pending(ctx.link, dx)
         if ctx.needs_input_grad[1]:
             dw, rw = _grad_target(ctx.params[0])
             check(lib.tt_latent16_wgrad(ptr(dy), D, 0.0, ptr(x), None, ptr(dw), None, ptr(ws), B, CT, D, E, T, st), 'tt_latent16_wgrad')

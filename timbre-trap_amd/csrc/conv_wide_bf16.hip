@@ -160,9 +160,13 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_conv(const e16* __restrict__ x
     const e16* zero = reinterpret_cast<const e16*>(&g_wzero16);
     for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
         int tile = xcd_order(v, ntiles);
+        // JOIN over two batches that share the embedding (B = 2 jB): the two halves' tiles of the same (clip, rows, columns) are NEIGHBOURS in
+        // the walk, so that the second read of the embedding's pixels finds them in the XCD's L2 (the half is the fastest index)
+        int half = 0;
+        if (JOIN && B == 2 * jB) { half = tile & 1; tile >>= 1; }
         const int tt = tile % tiles_t; tile /= tiles_t;
         const int th = tile % tiles_h;
-        const int b = tile / tiles_h, h0 = th * G::TH, t0 = tt * G::TW;
+        const int b = tile / tiles_h + half * jB, h0 = th * G::TH, t0 = tt * G::TW;
         const e16* xb = x + (long)b * H * T * C;
 
         __syncthreads();                                         // the previous tile has been consumed
@@ -958,9 +962,11 @@ __global__ __launch_bounds__(NT, (C == 8 && MODE != 1) ? 3 : 1) void k_nrb_conv(
     const e16* zero = reinterpret_cast<const e16*>(&g_wzero16);
     for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
         int tile = xcd_order(v, ntiles);
+        int half = 0;                                            // JOIN over two batches: the halves' tiles side by side in the walk (see k_wrb_conv)
+        if (JOIN && B == 2 * jB) { half = tile & 1; tile >>= 1; }
         const int tt = tile % tiles_t; tile /= tiles_t;
         const int th = tile % tiles_h;
-        const int b = tile / tiles_h, h0 = th * G::TH, t0 = tt * G::TW;
+        const int b = tile / tiles_h + half * jB, h0 = th * G::TH, t0 = tt * G::TW;
         const e16* xb = x + (long)b * H * T * C;
 
         __syncthreads();                                         // the previous tile has been consumed

@@ -1181,7 +1181,7 @@ def _join_backward(g, e, weights, idx, reps, link, param, want_e, want_w, defer)
 def flush_pending(link, dx):
     """Called by the backward of an encoder layer that consumes a linked tensor, after it has written the data gradient ``dx`` of that tensor
     (gated iff link.gated): fold the parked skip-join backwards into it (see _join_backward).  Inside the caller's loss_scaled scope."""
-    if link is None or not link.pending:
+    if not getattr(link, 'pending', None):          # (None, nothing parked, or a link-like object of a stage-wise test)
         return
     pend, link.pending = link.pending, []
     for g, e, weights, idx, reps, ds in pend:

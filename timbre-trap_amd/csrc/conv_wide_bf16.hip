@@ -178,11 +178,19 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_conv(const e16* __restrict__ x
             const bool ok = p < G::NP && (unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T;
             glds16(ok ? xb + ((long)h * T + t) * C + cg * 8 : zero, smem + (long)i * 16);
         }
+        const int c0 = wave * 16;
+        const int t = t0 + c0 + n;
+        // JOIN: the embedding's pixels one row ahead of their use -- the first row's request rides on the staging wait below, row r + 1's is
+        // issued at the top of row r (requested inside the row that uses it, every row exposed a full memory latency: +130-160 us per launch)
+        typename std::conditional<C == 32, e16x8, e16x4>::type jq;
+        const e16* jrow = nullptr;
+        if constexpr (JOIN) {
+            jrow = res + (((long)(b % jB) * H) * T + (t < T ? t : T - 1)) * C + NCH * g;
+            jq = *reinterpret_cast<const decltype(jq)*>(jrow + (long)(h0 < H ? h0 : H - 1) * T * C);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 
-        const int c0 = wave * 16;
-        const int t = t0 + c0 + n;
         for (int r = 0; r < G::TH; ++r) {
             const int h = h0 + r;
             if (h >= H) break;
@@ -207,9 +215,10 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_conv(const e16* __restrict__ x
             typename std::conditional<C == 32, e16x8, e16x4>::type rq;      // MODE 1: dy of this pixel, requested early
             if constexpr (MODE == 1)            // unconditional (clamped) so that no branch pins a wait in front of the products
                 rq = *reinterpret_cast<const decltype(rq)*>(res + (valid ? pix : pix - (t - (T - 1))) * C + NCH * g);
-            if constexpr (JOIN) {               // the embedding's pixel of clip b mod jB, the same way
-                const long pe = ((long)(b % jB) * H + h) * T + (valid ? t : T - 1);
-                rq = *reinterpret_cast<const decltype(rq)*>(res + pe * C + NCH * g);
+            if constexpr (JOIN) {               // the embedding's pixel of clip b mod jB: this row's arrived a row ago, the next row's goes out
+                rq = jq;
+                const int hn = h + 1 < H ? h + 1 : H - 1;
+                jq = *reinterpret_cast<const decltype(jq)*>(jrow + (long)hn * T * C);
             }
             e16x8 centre;
 #pragma unroll
@@ -657,7 +666,9 @@ __global__ __launch_bounds__(NT, (GOUT && C == 32) ? 3 : 2) void k_wrb_dxw(const
             const int t = t0 + c;
             const bool valid = t < T;
             const long pix = ((long)b * H + h) * T + t;
-            // unconditional (clamped) so that no branch pins a wait in front of the products
+            // unconditional (clamped) so that no branch pins a wait in front of the products.  (Round 6, measured and dropped: dy requested one
+            // pixel group AHEAD of its products, here and in the C = 16 strips' data-gradient phase -- 49.72-49.86 / 49.80-49.86 / 49.85-49.96 ms
+            // per step without / strips only / both, profiles/r06_pf_ab.txt: this latency is already hidden by the CU's other waves.)
             const vec_t rq = *reinterpret_cast<const vec_t*>(dy + (valid ? pix : pix - (t - (T - 1))) * C + NCH * g);
             f32x4 acc[NCT];
 #pragma unroll
@@ -979,11 +990,17 @@ __global__ __launch_bounds__(NT, (C == 8 && MODE != 1) ? 3 : 1) void k_nrb_conv(
             const bool ok = p < G::NP && (unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T;
             glds16(ok ? xb + ((long)h * T + t) * C : zero, smem + (long)i * 16);
         }
+        const int t = t0 + lane;
+        const bool valid = t < T;
+        vec_t jq;                                                // JOIN: the embedding's pixels one row of this wave ahead (see k_wrb_conv)
+        const e16* jrow = nullptr;
+        if constexpr (JOIN) {
+            jrow = res + (((long)(b % jB) * H) * T + (valid ? t : T - 1)) * C;
+            jq = *reinterpret_cast<const vec_t*>(jrow + (long)(h0 + wave < H ? h0 + wave : H - 1) * T * C);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 
-        const int t = t0 + lane;
-        const bool valid = t < T;
         for (int r = wave; r < G::TH; r += 4) {
             const int h = h0 + r;
             if (h >= H) break;
@@ -1018,8 +1035,11 @@ __global__ __launch_bounds__(NT, (C == 8 && MODE != 1) ? 3 : 1) void k_nrb_conv(
 #pragma unroll
                     for (int kb = 0; kb < NB; ++kb) acc[ob] = mma4(A[tap][ob][kb], chunk_of<C>(bq, kb), acc[ob]);
             }
-            // (the embedding's pixel is requested here, behind the 3x3 products: requested in front of them it costs C = 8 its 168-register cap)
-            if constexpr (JOIN) rq = *reinterpret_cast<const vec_t*>(res + (((long)(b % jB) * H + h) * T + (valid ? t : T - 1)) * C);
+            if constexpr (JOIN) {
+                rq = jq;
+                const int hn = h + 4 < H ? h + 4 : H - 1;
+                jq = *reinterpret_cast<const vec_t*>(jrow + (long)hn * T * C);
+            }
             vec_t o;
             if constexpr (MODE == 1) {
 #pragma unroll

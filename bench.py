@@ -725,10 +725,10 @@ def main():
             nbytes = 3.0 * 2 * Ch * args.batch * Hh * M_FRAMES
             gbs = nbytes / (a_ms * 1e-3) / 1e9
             traffic = traffic_source = None
-            pmc = os.path.join(ROOT, 'profiles', 'r04_pmc_bwds_C16.json')
+            pmc = os.path.join(ROOT, 'profiles', 'r06_pmc_bwds_C16.json')         # round 6: re-measured on the round-5 strip kernel (x rows in their own image)
             if args.batch == 64 and os.path.exists(pmc):
                 pj = json.load(open(pmc))
-                traffic, traffic_source = pj['traffic_bytes_corrected'], 'profiles/r04_pmc_bwds_C16.json (rocprofv3 --pmc passes at this shape: FETCH_SIZE x2 + WRITE_SIZE; not re-measured in this run)'
+                traffic, traffic_source = pj['traffic_bytes_corrected'], 'profiles/r06_pmc_bwds_C16.json (rocprofv3 --pmc passes of this kernel at this shape, round 6: FETCH_SIZE x2 + WRITE_SIZE, mean of the three dilations; not re-measured in this run)'
             roof_onepass = dict(kernel='tt_wide_rb_bwd at C=%d, H=%d: k_wrb_bwds<%d,D,8,32> (one-pass strip backward: h1, dy, x in, dx out; dL/d(conv1 '
                                        'pre-activation) in an LDS ring) + k_wrb_reduce<%d>' % (Ch, Hh, Ch, Ch),
                                 bound='hbm', achieved=gbs, peak=PEAK_HBM_GBS, unit='GB/s', frac=gbs / PEAK_HBM_GBS, traffic=traffic,

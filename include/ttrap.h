@@ -26,6 +26,7 @@ extern "C" {
 #endif
 
 #define TT_E_BADARG      (-1)
+#define TT_W_JOIN_LEFT 1       /* tt_wide_level_bwd_gated_join only: the level's backward is done, the riding skip join is NOT (see there) */
 #define TT_E_UNSUPPORTED (-2)   /* shape outside the compiled set, or one clip of >= 2^31 elements (32-bit offsets) */
 
 /* flags of tt_resblock_fwd / tt_resblock_bwd: round the operands of the 3x3 convolutions and of dW1 to bf16 for the
@@ -228,6 +229,20 @@ int tt_wide_level_bwd_gated(int nblocks, const void* const* x, const void* const
                             const float* const* w2, const float* const* b2, void* dx, void* tmp0, void* tmp1, float* const* dw1,
                             float* const* db1, float* const* dw2, float* const* db2, void* ws, int B, int C, int H, int T,
                             const int* dilations, void* stream);
+/* tt_wide_level_bwd_gated with the backward of a weighted skip join riding on it (round 6).  x[0], the level's input, is at the same time
+ * the encoder embedding e of a skip connection (reference modules.py:112, :569-589: `y + skip_weights[i] * e` in the decoder); skip_g =
+ * the gradient that reached that join's output, skip_reps (1 or 2) batches of B clips back to back (2: the pair decode).  The first block's
+ * gated epilogue then writes  dx = (dy + W1^T (*) dA1 + skip_weights[skip_idx] * (g[0] + g[1])) * ELU'(x[0])  -- the embedding's two
+ * gradient contributions in one tensor, so that nothing is left to add -- and  skip_dw[skip_idx] += <g[0] + g[1], x[0]>  (times 1 / S under
+ * tt_set_loss_scale).  Two more loads per lane and pixel instead of tt_skip_join16_bwd's pass over five tensors.  dilations[0] must be 1
+ * (TT_E_UNSUPPORTED before anything is launched otherwise).  Returns TT_W_JOIN_LEFT (> 0) when the level's backward ran but the first
+ * block's kernel was one without the riding form (the A/B dispatches TTRAP_DXW=0 / TTRAP_WBWD1 / TTRAP_NARROW_FUSED16=0): the caller then
+ * applies the join with tt_skip_join16_bwd(gate | 2) on dx. */
+int tt_wide_level_bwd_gated_join(int nblocks, const void* const* x, const void* const* h1, const void* dy, const float* const* w1,
+                                 const float* const* w2, const float* const* b2, void* dx, void* tmp0, void* tmp1, float* const* dw1,
+                                 float* const* db1, float* const* dw2, float* const* db2, void* ws, int B, int C, int H, int T,
+                                 const int* dilations, const void* skip_g, int skip_reps, const float* skip_weights, int skip_idx,
+                                 float* skip_dw, void* stream);
 /* g *= ELU'(y) in place on n 16-bit elements (n % 8 == 0): the same factor for a gradient that reaches such a layer by another way
  * (a skip connection, a caller's own use of an encoder embedding; ops.GateTapFn). */
 int tt_gate16(void* g, const void* y, int64_t n, void* stream);
@@ -599,6 +614,11 @@ int tt_wide_level_bwd_gated_h(int nblocks, const void* const* x, const void* con
                               const float* const* w2, const float* const* b2, void* dx, void* tmp0, void* tmp1, float* const* dw1,
                               float* const* db1, float* const* dw2, float* const* db2, void* ws, int B, int C, int H, int T,
                               const int* dilations, void* stream);
+int tt_wide_level_bwd_gated_join_h(int nblocks, const void* const* x, const void* const* h1, const void* dy, const float* const* w1,
+                                   const float* const* w2, const float* const* b2, void* dx, void* tmp0, void* tmp1, float* const* dw1,
+                                   float* const* db1, float* const* dw2, float* const* db2, void* ws, int B, int C, int H, int T,
+                                   const int* dilations, const void* skip_g, int skip_reps, const float* skip_weights, int skip_idx,
+                                   float* skip_dw, void* stream);
 int tt_tconv16_bwd_h(const void* x, const void* y, const void* dy, const float* w, void* dx, float* dw, float* db, void* ws,
                    int B, int C, int H, int T, int out_pad, void* stream);
 int64_t tt_latent16_scratch_bytes_h(int B, int CT, int D, int E, int T);

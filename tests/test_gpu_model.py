@@ -496,7 +496,9 @@ def _autocast_step_vs_oracle(n_clips, n_blocks, n_mpe, record=None, bench_target
     flushed = []
     if monkeypatch is not None:
         orig_flush = ops.flush_pending
-        monkeypatch.setattr(ops, 'flush_pending', lambda link, dx: (flushed.append(len(link.pending) if link is not None else 0), orig_flush(link, dx))[1])
+        monkeypatch.setattr(ops, 'flush_pending', lambda link, dx: (flushed.append(len(getattr(link, 'pending', None) or ())), orig_flush(link, dx))[1])
+        rides, orig_ride = [], ops._riding_join
+        monkeypatch.setattr(ops, '_riding_join', lambda ctx_, x0: (lambda r: (rides.append(r is not None), r)[1])(orig_ride(ctx_, x0)))
     c, g = run['coeffs'].cuda(), run['gt'].cuda()
     pair_calls = _count_calls(monkeypatch, ops.ConvOut16PairFn) if monkeypatch is not None else None
     join_calls = _count_calls(monkeypatch, ops.SkipJoin16Fn) if monkeypatch is not None else None
@@ -527,8 +529,12 @@ def _autocast_step_vs_oracle(n_clips, n_blocks, n_mpe, record=None, bench_target
     if monkeypatch is not None and skips:
         # deferred join backwards (TimbreTrap.forward + tagged parameters): one parked join per embedding and encoder pass with the pair decode
         # (two without), folded into the data gradient of the encoder layer behind it; none on any other route
-        want = ([1 if pair else 2] * 10) if (route == 'forward' and optimizer and ops.SKIP_FUSED and ops.SKIP_DEFER) else []
-        assert sorted(n for n in flushed if n) == sorted(want), (flushed, want)
+        deferred = route == 'forward' and optimizer and ops.SKIP_FUSED and ops.SKIP_DEFER
+        # ... of which the four per encoder pass whose embedding is a residual level's input RIDE on that level's gated first block
+        # (tt_wide_level_bwd_gated_join; one parked join only, i.e. with the pair decode) and the rest take the accumulating pass
+        riding = 8 if (deferred and pair and ops.SKIP_RIDE and ops.PREGATE) else 0
+        want = ([1 if pair else 2] * (10 - riding)) if deferred else []
+        assert sum(rides) == riding and sorted(n for n in flushed if n) == sorted(want), (sum(rides), riding, flushed, want)
     if pair_calls is not None:
         assert len(pair_calls) == (2 if (route == 'forward' and pair and (not skips or ops.SKIP_FUSED)) else 0), (route, pair, len(pair_calls))
         # with skip connections model.forward joins through ops.SkipJoin16Fn (the join behind the latent head) and ops.Level16JoinFn (the
@@ -589,9 +595,9 @@ def test_autocast_fp16_step_matches_oracle_outputs_losses_and_all_gradients(rout
 
 @pytest.mark.parametrize('dtype,route,pair', [(torch.bfloat16, 'forward', True), (torch.bfloat16, 'forward', False), (torch.bfloat16, 'twice', True),
                                               (torch.float16, 'forward', True), (torch.bfloat16, 'forward-unfused', True), (torch.bfloat16, 'forward-plain-grads', True),
-                                              (torch.bfloat16, 'forward-undeferred', True)],
+                                              (torch.bfloat16, 'forward-undeferred', True), (torch.bfloat16, 'forward-unridden', True)],
                          ids=['bf16-model.forward-pair-decode', 'bf16-model.forward-two-decodes', 'bf16-scaled-embeddings-decode-twice', 'fp16-model.forward-pair-decode',
-                              'bf16-model.forward-SKIP_FUSED-off', 'bf16-model.forward-without-FusedAdamW', 'bf16-model.forward-SKIP_DEFER-off'])
+                              'bf16-model.forward-SKIP_FUSED-off', 'bf16-model.forward-without-FusedAdamW', 'bf16-model.forward-SKIP_DEFER-off', 'bf16-model.forward-SKIP_RIDE-off'])
 def test_autocast_step_with_skip_connections_matches_oracle(dtype, route, pair, monkeypatch):
     """
     The model of BASELINE configs[4] (skip_connections=True, reference modules.py:61-63, 95-117, 569-589) on the 16-bit path against the
@@ -607,6 +613,8 @@ def test_autocast_step_with_skip_connections_matches_oracle(dtype, route, pair, 
         monkeypatch.setattr(ops, 'SKIP_FUSED', False)
     elif route == 'forward-undeferred':     # ops.SKIP_DEFER off: every join writes the embedding's gradient itself
         monkeypatch.setattr(ops, 'SKIP_DEFER', False)
+    elif route == 'forward-unridden':       # ops.SKIP_RIDE off: the parked joins are applied by accumulating passes of their own
+        monkeypatch.setattr(ops, 'SKIP_RIDE', False)
     elif route == 'forward-plain-grads':    # a stock optimizer: the skip weights' gradient goes back through autograd, nothing is deferred
         optimizer = False
     if route.startswith('forward-'):

@@ -1092,6 +1092,61 @@ def test_skip_join_folded_into_the_level_equals_the_join_behind_it(C, reps, monk
         assert float((a - b_).abs().max()) <= 2e-5 * float(b_.abs().max() + 1e-30)
 
 
+@pytest.mark.parametrize('C,shape', [(4, (2, 37, 130)), (8, (1, 40, 200)), (16, (2, 21, 96)), (32, (1, 30, 160)), (16, (1, 133, 64)), (4, (1, 20, 66))])
+@pytest.mark.parametrize('reps', [1, 2])
+def test_skip_join_backward_riding_on_the_gated_level_stagewise(C, shape, reps):
+    """tt_wide_level_bwd_gated_join (round 6) against tt_wide_level_bwd_gated followed by tt_skip_join16_bwd(gate | 2) on its dx: the same
+    level backward (every weight / bias gradient bit for bit -- the riding form only touches the first block's dx epilogue), dx within two
+    roundings (one rounding less than the two-step form), the skip weight's gradient to fp32 summation round-off; dilations (1, 2, 3) and
+    a single block; ragged tile edges; a first block at another dilation is refused before anything is launched."""
+    import ctypes
+    from timbre_trap._hip import check, ptr, stream_ptr
+    lib, st = _lib(), stream_ptr()
+    B, H, T = shape
+    for dil in ((1, 2, 3), (1,)):
+        nb = len(dil)
+        par = [[_rand(C, C, 3, 3, seed=20 + i, scale=1.0 / (3 * C ** 0.5)).cuda(), _rand(C, seed=30 + i, scale=0.3).cuda(),
+                _rand(C, C, 1, 1, seed=40 + i, scale=1.0 / C ** 0.5).cuda(), _rand(C, seed=50 + i, scale=0.3).cuda()] for i in range(nb)]
+        nhwc = lambda b=B: torch.empty((b, H, T, C), dtype=ELT, device='cuda')
+        xs, hs = [nhwc() for _ in range(nb + 1)], [nhwc() for _ in range(nb)]
+        check(lib.tt_wide_pack(ptr(_rand(B, C, H, T, seed=1).cuda()), ptr(xs[0]), B, C, H, T, st), 'pack')
+        for i in range(nb):
+            check(lib.tt_wide_rb_fwd(ptr(xs[i]), ptr(par[i][0]), ptr(par[i][1]), ptr(par[i][2]), ptr(par[i][3]), ptr(xs[i + 1]), ptr(hs[i]), B, C, H, T, dil[i], st), 'fwd')
+        dy, sg = nhwc(), nhwc(reps * B)
+        check(lib.tt_wide_pack(ptr(_rand(B, C, H, T, seed=2).cuda()), ptr(dy), B, C, H, T, st), 'pack')
+        check(lib.tt_wide_pack(ptr(_rand(reps * B, C, H, T, seed=3, scale=0.7).cuda()), ptr(sg), reps * B, C, H, T, st), 'pack')
+        w = torch.tensor([0.5, -1.25, 2.0, 0.75, 1.5]).cuda()
+        shapes = ((C, C, 3, 3), (C,), (C, C, 1, 1), (C,))
+        arr = lambda ts: (ctypes.c_void_p * nb)(*[t.data_ptr() for t in ts])
+        dils = (ctypes.c_int * nb)(*dil)
+        res = []
+        for ride in (False, True):
+            ga = [[torch.full(s_, 0.5, device='cuda') for s_ in shapes] for _ in range(nb)]
+            dx, t0, t1 = nhwc(), nhwc(), nhwc()
+            ds = torch.full((5,), 3.0, device='cuda')
+            ws = torch.zeros(lib.tt_wide_level_scratch_bytes(nb, B, C, H, T), dtype=torch.uint8, device='cuda')
+            args = (nb, arr(xs[:nb]), arr(hs), ptr(dy), arr([p_[0] for p_ in par]), arr([p_[2] for p_ in par]), arr([p_[3] for p_ in par]), ptr(dx), ptr(t0), ptr(t1),
+                    arr([g_[0] for g_ in ga]), arr([g_[1] for g_ in ga]), arr([g_[2] for g_ in ga]), arr([g_[3] for g_ in ga]), ptr(ws), B, C, H, T, dils)
+            if ride:
+                rc = lib.tt_wide_level_bwd_gated_join(*args, ptr(sg), reps, ptr(w), 3, ptr(ds), st)
+                assert rc == 0, rc
+            else:
+                check(lib.tt_wide_level_bwd_gated(*args, st), 'level')
+                check(lib.tt_skip_join16_bwd(ptr(sg), ptr(xs[0]), ptr(w), 3, ptr(dx), ptr(ds), xs[0].numel(), reps, 3, st), 'join')
+            torch.cuda.synchronize()
+            res.append((dx.float(), ds.clone(), [t.clone() for g_ in ga for t in g_]))
+        (dx0, ds0, gp0), (dx1, ds1, gp1) = res
+        scale = float(dx0.abs().max())
+        assert float((dx1 - dx0).abs().max()) <= 2.5 * BF16_REL * scale, (dil, float((dx1 - dx0).abs().max()) / scale)
+        assert torch.equal(ds0[[0, 1, 2, 4]], ds1[[0, 1, 2, 4]]) and float(ds0[0]) == 3.0
+        assert abs(float(ds1[3] - ds0[3])) <= 1e-3 * abs(float(ds0[3] - 3.0)) + 1e-3, (float(ds0[3]), float(ds1[3]))
+        for a, b_ in zip(gp0, gp1):
+            assert float((a - b_).abs().max()) <= 2e-5 * float(b_.abs().max() + 1e-30)
+    bad = (ctypes.c_int * 1)(2)
+    assert lib.tt_wide_level_bwd_gated_join(1, arr(xs[:1]), arr(hs[:1]), ptr(dy), arr([par[0][0]]), arr([par[0][2]]), arr([par[0][3]]), ptr(dx), None, None,
+                                            arr([ga[0][0]]), arr([ga[0][1]]), arr([ga[0][2]]), arr([ga[0][3]]), ptr(ws), B, C, H, T, bad, ptr(sg), reps, ptr(w), 3, ptr(ds), st) < 0
+
+
 def _pytest_subprocess(env_extra, selection):
     """The kernel switches are read once per process: the non-default paths run in a child pytest."""
     import subprocess

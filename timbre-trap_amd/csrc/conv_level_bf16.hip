@@ -477,11 +477,17 @@ __device__ __forceinline__ void conv_taps_ring(const unsigned char* img, const i
 // still on their way into LDS at that point, so the lane's channels of x come from memory like its dy (the same lines the DMA is fetching).
 // (Round 5, measured and dropped: h1 straight from memory into the lanes of step b. -- no staging image for it, the x rows into the freed
 // image already in step a., three barriers per step instead of four: 53.18 / 52.62 ms per step against 51.96 / 52.06, profiles/r05_bwds_hd_ab.txt.)
-template <int C, int D, int TH, int TW, int MINW, bool GOUT = false>
-__global__ __launch_bounds__(NT, MINW) void k_wrb_bwds(const e16* __restrict__ x, const e16* __restrict__ h1, const e16* __restrict__ dy,
-                                                     const e16x8* __restrict__ wimg, const float* __restrict__ b2, e16* __restrict__ dx,
-                                                     float* __restrict__ part_a, float* __restrict__ part_w, int B, int H, int T,
-                                                     int tiles_t, int nstrips) {
+// SJ (C = 16, with GOUT): the backward of a skip join on this block's input rides on the gated epilogue of step d. (SkipJ, wide_common.h)
+// (The kernel's body is a device function so that the riding form is a kernel of its OWN signature, k_wrb_bwds_sj: one more -- unused --
+// kernel argument on k_wrb_bwds itself moved its register allocation from 127 registers / no spill to 128 / one spilled.)
+template <int C, int D, int TH, int TW, int MINW, bool GOUT, bool SJ>
+__device__ __forceinline__ void wrb_bwds_body(const e16* __restrict__ x, const e16* __restrict__ h1, const e16* __restrict__ dy,
+                                              const e16x8* __restrict__ wimg, const float* __restrict__ b2, e16* __restrict__ dx,
+                                              float* __restrict__ part_a, float* __restrict__ part_w, int B, int H, int T,
+                                              int tiles_t, int nstrips, const SkipJ& sj) {
+    static_assert(!SJ || (GOUT && C == 16), "a skip join rides on the gated epilogue of the C = 16 strips only");
+    float sjw = 0.f, sjdot = 0.f;
+    if constexpr (SJ) sjw = sj.w ? sj.w[0] : 1.f;
     using G = OS<C, D, TH, TW>;
     using K = WK<C>;
     constexpr int NCT = K::NCT, NK = K::NK, NCH = K::NCH, PB = G::PB, GW = G::GW, RING = G::RING;
@@ -734,18 +740,31 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_bwds(const e16* __restrict__ x
                     const long pix = ((long)b * H + h) * T + t;
                     // unconditional (clamped) so that no branch pins a wait in front of the products
                     const vec_t rq = *reinterpret_cast<const vec_t*>(dy + (valid ? pix : pix - (t - (T - 1))) * C + NCH * g);
-                    vec_t xg;
+                    vec_t xg, sg0, sg1;
                     if constexpr (GOUT && XE) xg = *reinterpret_cast<const vec_t*>(xst + (r * TW + c) * PB + 16 * (opiece ^ fswz<C>(c)) + obyte);
                     else if constexpr (GOUT) xg = *reinterpret_cast<const vec_t*>(x + (valid ? pix : pix - (t - (T - 1))) * C + NCH * g);
+                    if constexpr (SJ) {                          // the join's gradient at this pixel, both batches: requested with dy
+                        const e16* gp = sj.g + (valid ? pix : pix - (t - (T - 1))) * C + NCH * g;
+                        sg0 = *reinterpret_cast<const vec_t*>(gp);
+                        sg1 = *reinterpret_cast<const vec_t*>(gp + sj.half);
+                    }
                     const int ro[3] = {slot(h - D) * G::ROWB, slot(h) * G::ROWB, slot(h + D) * G::ROWB};
                     f32x4 acc[NCT];
 #pragma unroll
                     for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
                     conv_taps_ring<C, D, GW>(ring, ro, c, g, A, acc);
                     vec_t o;
+                    if constexpr (SJ) {
+                        float add[NCH], dot = 0.f;
+                        skipj_terms<vec_t, NCH>(sg0, sg1, sj.half != 0, xg, sjw, add, dot);
+                        if (valid) sjdot += dot;
 #pragma unroll
-                    for (int jj = 0; jj < NCH; ++jj)
-                        o[jj] = GOUT ? (e16)((acc[jj >> 2][jj & 3] + (float)rq[jj]) * elu_dout((float)xg[jj])) : (e16)(acc[jj >> 2][jj & 3] + (float)rq[jj]);
+                        for (int jj = 0; jj < NCH; ++jj) o[jj] = (e16)((acc[jj >> 2][jj & 3] + (float)rq[jj] + add[jj]) * elu_dout((float)xg[jj]));
+                    } else {
+#pragma unroll
+                        for (int jj = 0; jj < NCH; ++jj)
+                            o[jj] = GOUT ? (e16)((acc[jj >> 2][jj & 3] + (float)rq[jj]) * elu_dout((float)xg[jj])) : (e16)(acc[jj >> 2][jj & 3] + (float)rq[jj]);
+                    }
                     if (valid) *reinterpret_cast<vec_t*>(dx + pix * C + NCH * g) = o;
                 }
             }
@@ -787,6 +806,7 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_bwds(const e16* __restrict__ x
         }
     }
 
+    if constexpr (SJ) skipj_finish(sjdot, sj);
     // ---- dumps: the weight-gradient accumulators (C = 32: per wave, each holds its own (ci-tile, co-tile); C = 16: the four waves hold
     //      the same elements and are summed through LDS -- one dump per workgroup, the reduce reads a quarter of the bytes:
     //      RedArgs::one_dump), everything else summed over the waves through LDS ----
@@ -839,6 +859,21 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_bwds(const e16* __restrict__ x
     for (int i = tid; i < G::ADUMP; i += NT) pa[i] = (all[i] + all[G::ADUMP + i]) + (all[2 * G::ADUMP + i] + all[3 * G::ADUMP + i]);
 }
 
+template <int C, int D, int TH, int TW, int MINW, bool GOUT = false>
+__global__ __launch_bounds__(NT, MINW) void k_wrb_bwds(const e16* __restrict__ x, const e16* __restrict__ h1, const e16* __restrict__ dy,
+                                                     const e16x8* __restrict__ wimg, const float* __restrict__ b2, e16* __restrict__ dx,
+                                                     float* __restrict__ part_a, float* __restrict__ part_w, int B, int H, int T,
+                                                     int tiles_t, int nstrips) {
+    wrb_bwds_body<C, D, TH, TW, MINW, GOUT, false>(x, h1, dy, wimg, b2, dx, part_a, part_w, B, H, T, tiles_t, nstrips, SkipJ());
+}
+template <int C, int D, int TH, int TW, int MINW>
+__global__ __launch_bounds__(NT, MINW - 1) void k_wrb_bwds_sj(const e16* __restrict__ x, const e16* __restrict__ h1, const e16* __restrict__ dy,
+                                                            const e16x8* __restrict__ wimg, const float* __restrict__ b2, e16* __restrict__ dx,
+                                                            float* __restrict__ part_a, float* __restrict__ part_w, int B, int H, int T,
+                                                            int tiles_t, int nstrips, SkipJ sj) {
+    wrb_bwds_body<C, D, TH, TW, MINW, true, true>(x, h1, dy, wimg, b2, dx, part_a, part_w, B, H, T, tiles_t, nstrips, sj);
+}
+
 template <int C, int D, int TH, int TW>
 int launch_bwds(const e16* x, const e16* h1, const e16* dy, const float* w1, const float* w2, const float* b2, e16* dx,
                 float* dw1, float* db1, float* dw2, float* db2, unsigned char* ws, int B, int H, int T, hipStream_t st) {
@@ -861,10 +896,23 @@ int launch_bwds(const e16* x, const e16* h1, const e16* dy, const float* w1, con
     if constexpr (D == 1) gated = ttx_gate_dx == 1;              // a level's first block: dx leaves gated
     if (gated) {
         if constexpr (D == 1) {
-            static AttrOnce once_g;
-            auto kg = k_wrb_bwds<C, D, TH, TW, MINW, true>;
-            if (int rc = raise_lds(kg, G::LDS_BYTES, once_g)) return rc;
-            hipLaunchKernelGGL(kg, dim3(grid), dim3(NT), G::LDS_BYTES, st, x, h1, dy, wimg, b2, dx, part_a, part_w, B, H, T, tiles_t, nstrips);
+            bool took = false;
+            if constexpr (C == 16) {
+                if (ttx_skip.g) {
+                    static AttrOnce once_j;
+                    auto kj = k_wrb_bwds_sj<C, D, TH, TW, MINW>;
+                    if (int rc = raise_lds(kj, G::LDS_BYTES, once_j)) return rc;
+                    hipLaunchKernelGGL(kj, dim3(grid), dim3(NT), G::LDS_BYTES, st, x, h1, dy, wimg, b2, dx, part_a, part_w, B, H, T, tiles_t, nstrips, ttx_skip);
+                    ttx_skip.g = nullptr;
+                    took = true;
+                }
+            }
+            if (!took) {
+                static AttrOnce once_g;
+                auto kg = k_wrb_bwds<C, D, TH, TW, MINW, true>;
+                if (int rc = raise_lds(kg, G::LDS_BYTES, once_g)) return rc;
+                hipLaunchKernelGGL(kg, dim3(grid), dim3(NT), G::LDS_BYTES, st, x, h1, dy, wimg, b2, dx, part_a, part_w, B, H, T, tiles_t, nstrips);
+            }
             ttx_gate_dx = 2;
         }
     } else {

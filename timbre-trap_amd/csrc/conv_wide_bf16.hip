@@ -589,10 +589,14 @@ template <int C, int D, int TH, int TW> struct DXW {
     static_assert(TW % 32 == 0, "the K = 32 pixels of a weight-gradient product are 32 consecutive columns");
 };
 
-template <int C, int D, int TH, int TW, bool GOUT = false>
-__global__ __launch_bounds__(NT, (GOUT && C == 32) ? 3 : 2) void k_wrb_dxw(const e16* __restrict__ x, const e16* __restrict__ da1, const e16* __restrict__ dy,
+// SJ (with GOUT): the backward of a skip join on this block's input rides on the epilogue (SkipJ, wide_common.h)
+template <int C, int D, int TH, int TW, bool GOUT = false, bool SJ = false>
+__global__ __launch_bounds__(NT, (GOUT && C == 32 && !SJ) ? 3 : 2) void k_wrb_dxw(const e16* __restrict__ x, const e16* __restrict__ da1, const e16* __restrict__ dy,
                                                    const float* __restrict__ w1, e16* __restrict__ dx, float* __restrict__ part_w, int B,
-                                                   int H, int T, int tiles_h, int tiles_t, int ntiles) {
+                                                   int H, int T, int tiles_h, int tiles_t, int ntiles, SkipJ sj = SkipJ()) {
+    static_assert(!SJ || GOUT, "a skip join rides on the gated epilogue only");
+    float sjw = 0.f, sjdot = 0.f;
+    if constexpr (SJ) sjw = sj.w ? sj.w[0] : 1.f;
     using G = DXW<C, D, TH, TW>;
     using K = WK<C>;
     constexpr int NCT = K::NCT, NK = K::NK, NCH = K::NCH, PB = G::PB;
@@ -666,6 +670,12 @@ __global__ __launch_bounds__(NT, (GOUT && C == 32) ? 3 : 2) void k_wrb_dxw(const
             const int t = t0 + c;
             const bool valid = t < T;
             const long pix = ((long)b * H + h) * T + t;
+            vec_t sg0, sg1;
+            if constexpr (SJ) {                                  // the join's gradient at this pixel, both batches: requested with dy
+                const e16* gp = sj.g + (valid ? pix : pix - (t - (T - 1))) * C + NCH * g;
+                sg0 = *reinterpret_cast<const vec_t*>(gp);
+                sg1 = *reinterpret_cast<const vec_t*>(gp + sj.half);
+            }
             // unconditional (clamped) so that no branch pins a wait in front of the products.  (Round 6, measured and dropped: dy requested one
             // pixel group AHEAD of its products, here and in the C = 16 strips' data-gradient phase -- 49.72-49.86 / 49.80-49.86 / 49.85-49.96 ms
             // per step without / strips only / both, profiles/r06_pf_ab.txt: this latency is already hidden by the CU's other waves.)
@@ -686,6 +696,13 @@ __global__ __launch_bounds__(NT, (GOUT && C == 32) ? 3 : 2) void k_wrb_dxw(const
                 asm volatile("" ::: "memory");
                 const vec_t xq = *reinterpret_cast<const vec_t*>(xs + (r * TW + c) * PB + 16 * ((C == 32 ? g : (g >> 1)) ^ fswz<C>(c)) +
                                                                  (C == 32 ? 0 : 8 * (g & 1)));
+                if constexpr (SJ) {
+                    float add[NCH], dot = 0.f;
+                    skipj_terms<vec_t, NCH>(sg0, sg1, sj.half != 0, xq, sjw, add, dot);
+                    if (valid) sjdot += dot;
+#pragma unroll
+                    for (int j = 0; j < NCH; ++j) sum[j] += add[j];
+                }
 #pragma unroll
                 for (int j = 0; j < NCH; ++j) o[j] = (e16)(sum[j] * elu_dout((float)xq[j]));
             } else {
@@ -724,6 +741,7 @@ __global__ __launch_bounds__(NT, (GOUT && C == 32) ? 3 : 2) void k_wrb_dxw(const
             }
         }
     }
+    if constexpr (SJ) skipj_finish(sjdot, sj);
     if constexpr (C == 32) {
         float* pw = part_w + ((long)blockIdx.x * 4 + wave) * G::WDUMP;
 #pragma unroll
@@ -779,17 +797,25 @@ int launch_dxw(const e16* x, const e16* da1, const e16* dy, const float* w1, e16
     if constexpr (D == 1) gated = ttx_gate_dx == 1;              // a level's first block: dx leaves gated (k_nrb_bwd_fused, GOUT)
     if (gated) {
         if constexpr (D == 1) {
-            static AttrOnce once_g;
-            auto kg = k_wrb_dxw<C, D, TH, TW, true>;
-            if (int rc = raise_lds(kg, X::LDS_BYTES, once_g)) return rc;
-            hipLaunchKernelGGL(kg, dim3(gx), dim3(NT), X::LDS_BYTES, st, x, da1, dy, w1, dx, part_w, B, H, T, tiles_h, tiles_t, ntiles);
+            if (ttx_skip.g) {
+                static AttrOnce once_j;
+                auto kj = k_wrb_dxw<C, D, TH, TW, true, true>;
+                if (int rc = raise_lds(kj, X::LDS_BYTES, once_j)) return rc;
+                hipLaunchKernelGGL(kj, dim3(gx), dim3(NT), X::LDS_BYTES, st, x, da1, dy, w1, dx, part_w, B, H, T, tiles_h, tiles_t, ntiles, ttx_skip);
+                ttx_skip.g = nullptr;
+            } else {
+                static AttrOnce once_g;
+                auto kg = k_wrb_dxw<C, D, TH, TW, true>;
+                if (int rc = raise_lds(kg, X::LDS_BYTES, once_g)) return rc;
+                hipLaunchKernelGGL(kg, dim3(gx), dim3(NT), X::LDS_BYTES, st, x, da1, dy, w1, dx, part_w, B, H, T, tiles_h, tiles_t, ntiles, SkipJ());
+            }
             ttx_gate_dx = 2;
         }
     } else {
         static AttrOnce once_x;
         auto kx = k_wrb_dxw<C, D, TH, TW, false>;
         if (int rc = raise_lds(kx, X::LDS_BYTES, once_x)) return rc;
-        hipLaunchKernelGGL(kx, dim3(gx), dim3(NT), X::LDS_BYTES, st, x, da1, dy, w1, dx, part_w, B, H, T, tiles_h, tiles_t, ntiles);
+        hipLaunchKernelGGL(kx, dim3(gx), dim3(NT), X::LDS_BYTES, st, x, da1, dy, w1, dx, part_w, B, H, T, tiles_h, tiles_t, ntiles, SkipJ());
     }
     TT_LAUNCH_CHECK();
     RedArgs ra{part_w, gx, part_a, grid_a, dw1, db1, dw2, db2, C == 32 ? 1 : 0, C == 32 ? 0 : 1};
@@ -1271,14 +1297,18 @@ __global__ __launch_bounds__(NT) void k_nrb_wgrad(const e16* __restrict__ x, con
 // GOUT: the block is the first of its level and the layer in front of it ends in an ELU whose output IS this block's x (the transposed /
 // strided layer of a DecoderBlock / EncoderBlock): dx leaves as dx * ELU'(x) -- the gated gradient that layer's backward needs, so that it
 // reads neither its saved output nor stages anything through registers (tt_wide_level_bwd_gated, conv_stride_bf16.hip).
-template <int C, int D, bool GOUT>
-__global__ __launch_bounds__(NT, C == 8 ? 2 : TT_NBF2_MINW4) void k_nrb_bwd_fused(const e16* __restrict__ x, const e16* __restrict__ h1,
+// SJ (with GOUT): the backward of a skip join on this block's input rides on the gated epilogue (SkipJ, wide_common.h)
+template <int C, int D, bool GOUT, bool SJ = false>
+__global__ __launch_bounds__(NT, C == 8 ? 2 : (SJ ? 3 : TT_NBF2_MINW4)) void k_nrb_bwd_fused(const e16* __restrict__ x, const e16* __restrict__ h1,
                                                        const e16* __restrict__ dy, const float* __restrict__ w1,
                                                        const float* __restrict__ w2, const float* __restrict__ b2,
                                                        e16* __restrict__ dx, float* __restrict__ part_a, float* __restrict__ part_w,
-                                                       int B, int H, int T, int tiles_h, int tiles_t, int ntiles) {
+                                                       int B, int H, int T, int tiles_h, int tiles_t, int ntiles, SkipJ sj = SkipJ()) {
+    static_assert(!SJ || GOUT, "a skip join rides on the gated epilogue only");
     using G = NTl<C, D>;
     typedef typename VecOf<C>::type vec_t;
+    float sjw = 0.f, sjdot = 0.f;
+    if constexpr (SJ) sjw = sj.w ? sj.w[0] : 1.f;
     // the halo'd images hold exactly their NP pieces (the DMA instructions' tail lanes are masked off, not written as zeros behind the
     // image): at C = 4 / dilation 3 the whole-instruction rounding (770 -> 1024 pieces, twice) was the difference between three and
     // four workgroups per CU
@@ -1477,6 +1507,12 @@ __global__ __launch_bounds__(NT, C == 8 ? 2 : TT_NBF2_MINW4) void k_nrb_bwd_fuse
             for (int r = wave; r < G::TH; r += 4) {
                 const int h = h0 + r;
                 if (h >= H) break;
+                vec_t sg0, sg1;
+                if constexpr (SJ) {                              // the join's gradient at this pixel, both batches: requested in front of the products
+                    const e16* gp = sj.g + ib + ((long)h * T + (t < T ? t : T - 1)) * C;
+                    sg0 = *reinterpret_cast<const vec_t*>(gp);
+                    sg1 = *reinterpret_cast<const vec_t*>(gp + sj.half);
+                }
                 f32x4 a4[NB];
 #pragma unroll
                 for (int ob = 0; ob < NB; ++ob) a4[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1494,8 +1530,16 @@ __global__ __launch_bounds__(NT, C == 8 ? 2 : TT_NBF2_MINW4) void k_nrb_bwd_fuse
                 vec_t o;
                 if constexpr (GOUT) {
                     const vec_t xq = *reinterpret_cast<const vec_t*>(xs + (long)r * XROWB + lane * G::PXB);
+                    if constexpr (SJ) {
+                        float add[C], dot = 0.f;
+                        skipj_terms<vec_t, C>(sg0, sg1, sj.half != 0, xq, sjw, add, dot);
+                        if (t < T) sjdot += dot;
 #pragma unroll
-                    for (int c = 0; c < C; ++c) o[c] = (e16)((a4[c >> 2][c & 3] + (float)rq[c]) * elu_dout((float)xq[c]));
+                        for (int c = 0; c < C; ++c) o[c] = (e16)((a4[c >> 2][c & 3] + (float)rq[c] + add[c]) * elu_dout((float)xq[c]));
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < C; ++c) o[c] = (e16)((a4[c >> 2][c & 3] + (float)rq[c]) * elu_dout((float)xq[c]));
+                    }
                 } else {
 #pragma unroll
                     for (int c = 0; c < C; ++c) o[c] = (e16)(a4[c >> 2][c & 3] + (float)rq[c]);
@@ -1527,6 +1571,7 @@ __global__ __launch_bounds__(NT, C == 8 ? 2 : TT_NBF2_MINW4) void k_nrb_bwd_fuse
             }
         }
     }
+    if constexpr (SJ) skipj_finish(sjdot, sj);
     // ---- dumps: the four waves hold the same weight-gradient elements -- summed through LDS, ONE dump per workgroup (wave slot 0;
     //      RedArgs::one_dump: the reduce reads a quarter of the bytes) ----
     __syncthreads();
@@ -1763,17 +1808,25 @@ int launch_nbwd(const e16* x, const e16* h1, const e16* dy, const float* w1, con
         if constexpr (D == 1) gated = ttx_gate_dx == 1;          // a level's first block (the reference's levels start at dilation 1)
         if (gated) {
             if constexpr (D == 1) {
-                static AttrOnce once_g;
-                auto kg = k_nrb_bwd_fused<C, D, true>;
-                if (int rc = raise_lds(kg, LDS, once_g)) return rc;
-                hipLaunchKernelGGL(kg, dim3(gf), dim3(NT), LDS, st, x, h1, dy, w1, w2, b2, dx, part_a, part_w, B, H, T, tiles_h, tiles_t, ntiles);
+                if (ttx_skip.g) {
+                    static AttrOnce once_j;
+                    auto kj = k_nrb_bwd_fused<C, D, true, true>;
+                    if (int rc = raise_lds(kj, LDS, once_j)) return rc;
+                    hipLaunchKernelGGL(kj, dim3(gf), dim3(NT), LDS, st, x, h1, dy, w1, w2, b2, dx, part_a, part_w, B, H, T, tiles_h, tiles_t, ntiles, ttx_skip);
+                    ttx_skip.g = nullptr;
+                } else {
+                    static AttrOnce once_g;
+                    auto kg = k_nrb_bwd_fused<C, D, true>;
+                    if (int rc = raise_lds(kg, LDS, once_g)) return rc;
+                    hipLaunchKernelGGL(kg, dim3(gf), dim3(NT), LDS, st, x, h1, dy, w1, w2, b2, dx, part_a, part_w, B, H, T, tiles_h, tiles_t, ntiles, SkipJ());
+                }
                 ttx_gate_dx = 2;
             }
         } else {
             static AttrOnce once_f;
             auto kf = k_nrb_bwd_fused<C, D, false>;
             if (int rc = raise_lds(kf, LDS, once_f)) return rc;
-            hipLaunchKernelGGL(kf, dim3(gf), dim3(NT), LDS, st, x, h1, dy, w1, w2, b2, dx, part_a, part_w, B, H, T, tiles_h, tiles_t, ntiles);
+            hipLaunchKernelGGL(kf, dim3(gf), dim3(NT), LDS, st, x, h1, dy, w1, w2, b2, dx, part_a, part_w, B, H, T, tiles_h, tiles_t, ntiles, SkipJ());
         }
         TT_LAUNCH_CHECK();
         RedArgs ra{part_w, gf, part_a, gf, dw1, db1, dw2, db2, 0, 1};
@@ -1868,6 +1921,7 @@ __global__ __launch_bounds__(256) void k_gate_dx(e16* __restrict__ dx, const e16
 
 thread_local void* ttx_red_defer = nullptr;
 thread_local bool ttx_wprep_done = false;
+thread_local SkipJ ttx_skip;
 thread_local int ttx_gate_dx = 0;             // 1: the next block backward should leave dx * ELU'(x); 2: its kernel did (wide_common.h)
 
 extern "C" {
@@ -2047,6 +2101,25 @@ int tt_wide_level_bwd_gated(int nblocks, const void* const* x, const void* const
                             float* const* db1, float* const* dw2, float* const* db2, void* ws, int B, int C, int H, int T,
                             const int* dilations, void* stream) {
     return level_bwd(1, nblocks, x, h1, dy, w1, w2, b2, dx, tmp0, tmp1, dw1, db1, dw2, db2, ws, B, C, H, T, dilations, stream);
+}
+
+int tt_wide_level_bwd_gated_join(int nblocks, const void* const* x, const void* const* h1, const void* dy, const float* const* w1,
+                                 const float* const* w2, const float* const* b2, void* dx, void* tmp0, void* tmp1, float* const* dw1,
+                                 float* const* db1, float* const* dw2, float* const* db2, void* ws, int B, int C, int H, int T,
+                                 const int* dilations, const void* skip_g, int skip_reps, const float* skip_weights, int skip_idx,
+                                 float* skip_dw, void* stream) {
+    if (!skip_g || (skip_reps != 1 && skip_reps != 2) || skip_idx < 0 || !dilations || nblocks < 1) return TT_E_BADARG;
+    if (dilations[0] != 1) return TT_E_UNSUPPORTED;              // only a first block at dilation 1 has a gated epilogue (the reference's levels)
+    ttx_skip.g = (const e16*)skip_g;
+    ttx_skip.half = skip_reps == 2 ? (long)B * H * T * C : 0;
+    ttx_skip.w = skip_weights ? skip_weights + skip_idx : nullptr;
+    ttx_skip.dw = skip_dw ? skip_dw + skip_idx : nullptr;
+    ttx_skip.unscale = tt_loss_unscale();
+    const int rc = level_bwd(1, nblocks, x, h1, dy, w1, w2, b2, dx, tmp0, tmp1, dw1, db1, dw2, db2, ws, B, C, H, T, dilations, stream);
+    const bool left = ttx_skip.g != nullptr;                     // the first block took a kernel without the riding form (an A/B dispatch)
+    ttx_skip = SkipJ();
+    if (rc) return rc;
+    return left ? TT_W_JOIN_LEFT : 0;
 }
 
 }  // extern "C"

@@ -31,6 +31,8 @@
 #define ttx_red_defer ttx_red_defer_h
 #define ttx_wprep_done ttx_wprep_done_h
 #define ttx_gate_dx ttx_gate_dx_h
+#define ttx_skip ttx_skip_h
+#define tt_wide_level_bwd_gated_join tt_wide_level_bwd_gated_join_h
 #define ttx_wide_wprep_batch ttx_wide_wprep_batch_h
 #define tt_wide_level_bwd tt_wide_level_bwd_h
 #define tt_wide_level_bwd_gated tt_wide_level_bwd_gated_h

@@ -126,11 +126,41 @@ __global__ __launch_bounds__(1024) void k_wrb_reduce(RedBatch batch) {
 // Where a launcher would start its reduce: now, or -- inside tt_wide_level_bwd -- into the level's batch (ttx_red_defer: the calling
 // thread's pending batch; conv_wide_bf16.hip defines it, conv_level_bf16.hip's launchers see it too).
 }  // namespace
+// The backward of a weighted skip join riding on a level's gated first block (round 6; tt_wide_level_bwd_gated_join): the block's x IS the
+// encoder embedding e of the join, so its GOUT epilogue -- which has x at hand for ELU'(x) -- also takes the embedding's share of the join's
+// backward: dx = (dy + W1^T (*) dA1 + w * (g[0] + g[1])) * ELU'(x) with g = the gradient that reached the join's output (reps = 1 or 2 batches of
+// B clips back to back, `half` elements apart), and the skip weight's gradient dw += unscale * <g[0] + g[1], x>.  Two more loads per lane and
+// pixel instead of a five-tensor pass of its own (tt_skip_join16_bwd, gate & 2).
+struct SkipJ {
+    const e16* g = nullptr;        // nullptr: no join rides on this launch
+    long half = 0;                 // elements between the two batches of g (0: one batch)
+    const float* w = nullptr;      // &skip_weights[idx] (nullptr: 1)
+    float* dw = nullptr;           // &d skip_weights[idx] (nullptr: not wanted)
+    float unscale = 1.f;           // 1 / loss scale (dw leaves the 16-bit region)
+};
+extern thread_local SkipJ ttx_skip;         // set by tt_wide_level_bwd_gated_join; the launch that takes it resets .g
 extern thread_local void* ttx_red_defer;
 extern thread_local int ttx_gate_dx;        // set by tt_wide_level_bwd_gated around its first block: 1 = asked for, 2 = the block's kernel gated dx
 extern thread_local bool ttx_wprep_done;     // set by tt_wide_level_bwd while the weight images of its blocks are already prepared
 int ttx_wide_wprep_batch(int C, int n, const float* const* w1, const float* const* w2, void* const* ws, hipStream_t st);
 namespace {
+// the per-lane pieces of that epilogue: t[j] = g0[j] + g1[j]; acc += <t, x>; returns w * t[j] through `add`
+template <class V, int N>
+__device__ __forceinline__ void skipj_terms(const V& g0, const V& g1, bool two, const V& xq, float w, float (&add)[N], float& dot) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const float t = two ? (float)g0[j] + (float)g1[j] : (float)g0[j];
+        dot = __builtin_fmaf(t, (float)xq[j], dot);
+        add[j] = w * t;
+    }
+}
+__device__ __forceinline__ void skipj_finish(float dot, const SkipJ& sj) {
+    if (!sj.dw) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(sj.dw, dot * sj.unscale);
+}
+
 template <class Kernel> inline int reduce_or_defer(Kernel kern, int total, const RedArgs& ra, hipStream_t st) {
     if (ttx_red_defer) {
         RedBatch* b = static_cast<RedBatch*>(ttx_red_defer);

@@ -819,12 +819,23 @@ def _level16_backward(ctx, dy):
         cols = list(zip(*[[targets[4 * i + j][0] for j in range(4)] for i in range(nb)]))      # dw1s, db1s, dw2s, db2s
         dil = (ctypes.c_int * nb)(*ctx.dilations)
         fn = lib.tt_wide_level_bwd_gated if ctx.gate else lib.tt_wide_level_bwd
+        args = (nb, arr([saved[2 * i] for i in range(nb)]), arr([saved[2 * i + 1] for i in range(nb)]), ptr(g_all),
+                arr([params[4 * i] for i in range(nb)]), arr([params[4 * i + 2] for i in range(nb)]),
+                arr([params[4 * i + 3] for i in range(nb)]), ptr(dx), ptr(tmp[0]) if tmp else None,
+                ptr(tmp[1]) if tmp else None, arr(cols[0]), arr(cols[1]), arr(cols[2]), arr(cols[3]), ptr(ws),
+                B, C, H, T, dil)
+        ride = _riding_join(ctx, saved[0])
         with _hip.timed('wide_rb_bwd_C%d' % C, clips=B):
-            check(fn(nb, arr([saved[2 * i] for i in range(nb)]), arr([saved[2 * i + 1] for i in range(nb)]), ptr(g_all),
-                     arr([params[4 * i] for i in range(nb)]), arr([params[4 * i + 2] for i in range(nb)]),
-                     arr([params[4 * i + 3] for i in range(nb)]), ptr(dx), ptr(tmp[0]) if tmp else None,
-                     ptr(tmp[1]) if tmp else None, arr(cols[0]), arr(cols[1]), arr(cols[2]), arr(cols[3]), ptr(ws),
-                     B, C, H, T, dil, st), 'tt_wide_level_bwd')
+            if ride is not None:
+                # one parked skip-join backward on this level's input: it rides on the first block's gated epilogue (tt_wide_level_bwd_gated_join)
+                pg, pe, pw, pidx, preps, pds = ride
+                rc = lib.tt_wide_level_bwd_gated_join(*args, ptr(pg), preps, ptr(pw), pidx, ptr(pds), st)
+                if rc == 0:
+                    ctx.link.pending = []
+                elif rc != 1:                                    # 1 = TT_W_JOIN_LEFT: the level is done, the join is left to flush_pending below
+                    check(rc, 'tt_wide_level_bwd_gated_join')
+            else:
+                check(fn(*args, st), 'tt_wide_level_bwd')
         flush_pending(ctx.link, dx)
         return dx, [r for _, r in targets], de, rs
     if ctx.gate:
@@ -1176,6 +1187,24 @@ def _join_backward(g, e, weights, idx, reps, link, param, want_e, want_w, defer)
     check(lib16(e).tt_skip_join16_bwd(ptr(g), ptr(e), ptr(weights), idx, ptr(de), ptr(ds), e.numel(), reps, int(gate), stream_ptr()),
           'tt_skip_join16_bwd')
     return de, rs
+
+
+# TTRAP_SKIP_RIDE=0 / ops.SKIP_RIDE = False: a parked skip-join backward is applied by a pass of its own (flush_pending) instead of riding on the
+# gated epilogue of the encoder level's first block (A/B)
+SKIP_RIDE = os.environ.get('TTRAP_SKIP_RIDE', '1') != '0'
+
+
+def _riding_join(ctx, x0):
+    """The one parked skip-join backward of ``ctx.link`` if it can ride on the level's gated first block (tt_wide_level_bwd_gated_join): the
+    level gates, its first block has dilation 1, exactly one join is parked and its embedding IS the level's input; else None."""
+    link = ctx.link
+    pend = getattr(link, 'pending', None)
+    if not SKIP_RIDE or not ctx.gate or not pend or len(pend) != 1 or ctx.dilations[0] != 1:
+        return None
+    g, e, weights, idx, reps, ds = pend[0]
+    if e.data_ptr() != x0.data_ptr() or e.shape != x0.shape or g.dtype != x0.dtype or g.size(0) != reps * x0.size(0):
+        return None
+    return pend[0]
 
 
 def flush_pending(link, dx):

@@ -314,6 +314,9 @@ int tt_latent16_expand(const float* z, int Dz, float fill, const float* w, const
  *                                 tt_tconv16_bwd_pregated(gate_dx = 1) leaves it; y is not read.  The bias gradient rides as the weight
  *                                 gradient's row of a constant-1 input row: needs D < 48 (CT = 32) / D < 144 (CT = 64), else
  *                                 TT_E_UNSUPPORTED. */
+/* 1 where the two pregated entry points below take a head of CT channels and D input channels (they need a free input row of the weight
+ * gradient's tile for the bias gradient), else 0 -- what a caller asks before it promises the gate (ops.LatDec16Fn). */
+int tt_latent16_pregated_ok(int CT, int D);
 int tt_latent16_expand_gated(const float* z, const float* w, const void* gy, void* out, void* ws, int B, int CT, int D, int E, int T,
                              void* stream);
 int tt_latent16_contract_pregated(const void* g, const float* w, float* out, void* ws, int B, int CT, int D, int Dout, int E, int T,
@@ -604,6 +607,7 @@ int tt_sconv16_bwd_pregated_h(const void* x, const void* g, const float* w, void
 int tt_gate16_h(void* g, const void* y, int64_t n, void* stream);
 int tt_tconv16_bwd_pregated_h(const void* x, const void* g, const float* w, void* dx, float* dw, float* db, void* ws, int B, int C,
                               int H, int T, int out_pad, int gate_dx, void* stream);
+int tt_latent16_pregated_ok_h(int CT, int D);
 int tt_latent16_expand_gated_h(const float* z, const float* w, const void* gy, void* out, void* ws, int B, int CT, int D, int E, int T,
                                void* stream);
 int tt_latent16_contract_pregated_h(const void* g, const float* w, float* out, void* ws, int B, int CT, int D, int Dout, int E, int T,

@@ -182,7 +182,7 @@ def test_latent_heads_backward_is_reproducible(head, runs=6, B=2, T=1024):
             y.backward(dtop)
             torch.cuda.synchronize()
             out.append([zd.grad.clone(), wd.grad.clone(), bd.grad.clone()])
-        _same(out, ('dz', 'dw', 'db'), atomic=('db',))
+        _same(out, ('dz', 'dw', 'db'))           # round 6: the pregated bias gradient is summed over the rows in a fixed order (was E atomics per channel)
 
 
 @pytest.mark.parametrize('which', ['convin', 'convout'])

@@ -867,7 +867,7 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_bwds(const e16* __restrict__ x
     wrb_bwds_body<C, D, TH, TW, MINW, GOUT, false>(x, h1, dy, wimg, b2, dx, part_a, part_w, B, H, T, tiles_t, nstrips, SkipJ());
 }
 template <int C, int D, int TH, int TW, int MINW>
-__global__ __launch_bounds__(NT, MINW - 1) void k_wrb_bwds_sj(const e16* __restrict__ x, const e16* __restrict__ h1, const e16* __restrict__ dy,
+__global__ __launch_bounds__(NT, MINW) void k_wrb_bwds_sj(const e16* __restrict__ x, const e16* __restrict__ h1, const e16* __restrict__ dy,
                                                             const e16x8* __restrict__ wimg, const float* __restrict__ b2, e16* __restrict__ dx,
                                                             float* __restrict__ part_a, float* __restrict__ part_w, int B, int H, int T,
                                                             int tiles_t, int nstrips, SkipJ sj) {

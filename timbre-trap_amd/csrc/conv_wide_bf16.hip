@@ -591,7 +591,7 @@ template <int C, int D, int TH, int TW> struct DXW {
 
 // SJ (with GOUT): the backward of a skip join on this block's input rides on the epilogue (SkipJ, wide_common.h)
 template <int C, int D, int TH, int TW, bool GOUT = false, bool SJ = false>
-__global__ __launch_bounds__(NT, (GOUT && C == 32 && !SJ) ? 3 : 2) void k_wrb_dxw(const e16* __restrict__ x, const e16* __restrict__ da1, const e16* __restrict__ dy,
+__global__ __launch_bounds__(NT, (GOUT && C == 32) ? 3 : 2) void k_wrb_dxw(const e16* __restrict__ x, const e16* __restrict__ da1, const e16* __restrict__ dy,
                                                    const float* __restrict__ w1, e16* __restrict__ dx, float* __restrict__ part_w, int B,
                                                    int H, int T, int tiles_h, int tiles_t, int ntiles, SkipJ sj = SkipJ()) {
     static_assert(!SJ || GOUT, "a skip join rides on the gated epilogue only");
@@ -1299,7 +1299,7 @@ __global__ __launch_bounds__(NT) void k_nrb_wgrad(const e16* __restrict__ x, con
 // reads neither its saved output nor stages anything through registers (tt_wide_level_bwd_gated, conv_stride_bf16.hip).
 // SJ (with GOUT): the backward of a skip join on this block's input rides on the gated epilogue (SkipJ, wide_common.h)
 template <int C, int D, bool GOUT, bool SJ = false>
-__global__ __launch_bounds__(NT, C == 8 ? 2 : (SJ ? 3 : TT_NBF2_MINW4)) void k_nrb_bwd_fused(const e16* __restrict__ x, const e16* __restrict__ h1,
+__global__ __launch_bounds__(NT, C == 8 ? 2 : TT_NBF2_MINW4) void k_nrb_bwd_fused(const e16* __restrict__ x, const e16* __restrict__ h1,
                                                        const e16* __restrict__ dy, const float* __restrict__ w1,
                                                        const float* __restrict__ w2, const float* __restrict__ b2,
                                                        e16* __restrict__ dx, float* __restrict__ part_a, float* __restrict__ part_w,

@@ -40,6 +40,7 @@
 #define tt_latent16_expand_gated tt_latent16_expand_gated_h
 #define tt_latent16_contract_pregated tt_latent16_contract_pregated_h
 #define tt_latent16_wgrad_pregated tt_latent16_wgrad_pregated_h
+#define tt_latent16_pregated_ok tt_latent16_pregated_ok_h
 #define tt_sconv16_bwd_pregated tt_sconv16_bwd_pregated_h
 #define tt_tconv16_bwd_pregated tt_tconv16_bwd_pregated_h
 #define tt_wide_level_scratch_bytes tt_wide_level_scratch_bytes_h

@@ -368,7 +368,17 @@ __global__ __launch_bounds__(NT) void k_lat_wred(const float* __restrict__ part,
         const int lane = e & 63, r = (e >> 6) & 3, dt = e >> 8;
         const int d = 16 * dt + 4 * (lane >> 4) + r, c = 16 * ct + (lane & 15);
         if (d < D) dw[((long)d * CT + c) * E + h] += sum * scale;
-        else if (d == db_row) atomicAdd(db + c, sum * scale);   // the row of ones (k_lat_zprep): sum of g over this row h of the embedding
+        else if (d == db_row && h == 0) {
+            // the row of ones (k_lat_zprep): its entry of row h is the sum of g over that row of the embedding.  ONE thread per channel adds
+            // the E rows in a fixed order (round 5 joined them with one atomicAdd per row: E contributions per channel in arrival order --
+            // the low bits of the bias gradient varied from run to run; advisor)
+            float tot = sum;
+            for (int hh = 1; hh < E; ++hh)
+                for (int ps = 0; ps < nsplit; ++ps)
+#pragma unroll
+                    for (int w2 = 0; w2 < WPS; ++w2) tot += part[(((long)ps * E + hh) * 4 + ct + NC * w2) * WD + e];
+            db[c] += tot * scale;
+        }
     } else if (db && db_row < 0 && i < total + CT * 16) {       // sixteen slices of the workgroups per channel, joined by atomics
         const int c = (i - total) % CT, sl = (i - total) / CT;
         float sum = 0.f;
@@ -540,6 +550,16 @@ int tt_latent16_wgrad(const float* z, int Dz, float fill, const void* g, const v
  *   tt_latent16_contract_pregated / tt_latent16_wgrad_pregated   backward of Decoder.convin from g = dy * ELU'(y) as the transposed layer
  *                                behind it leaves it (tt_tconv16_bwd_pregated, gate_dx = 1): y is not read; needs D < 16 * ceil(D / 16)
  *                                rounded up to the kernel's tile count (a free input row carries the bias gradient): TT_E_UNSUPPORTED else */
+/* 1 if tt_latent16_contract_pregated / tt_latent16_wgrad_pregated take a head of CT channels and D input channels (a free input row
+ * must be left for the bias gradient: D < 16 * the kernel's row-tile count), else 0 */
+int tt_latent16_pregated_ok(int CT, int D) {
+    switch (cfg_of(CT, D)) {
+        case 1: return D < 16 * 3;
+        case 2: return D < 16 * 9;
+    }
+    return 0;
+}
+
 int tt_latent16_expand_gated(const float* z, const float* w, const void* gy, void* out, void* ws, int B, int CT, int D, int E, int T,
                              void* stream) {
     if (!z || !w || !gy || !out || !ws || B <= 0 || E <= 0 || T <= 0 || T % 16) return TT_E_BADARG;

@@ -130,7 +130,9 @@ __global__ __launch_bounds__(1024) void k_wrb_reduce(RedBatch batch) {
 // encoder embedding e of the join, so its GOUT epilogue -- which has x at hand for ELU'(x) -- also takes the embedding's share of the join's
 // backward: dx = (dy + W1^T (*) dA1 + w * (g[0] + g[1])) * ELU'(x) with g = the gradient that reached the join's output (reps = 1 or 2 batches of
 // B clips back to back, `half` elements apart), and the skip weight's gradient dw += unscale * <g[0] + g[1], x>.  Two more loads per lane and
-// pixel instead of a five-tensor pass of its own (tt_skip_join16_bwd, gate & 2).
+// pixel instead of a five-tensor pass of its own (tt_skip_join16_bwd, gate & 2).  The riding kernels keep the register cap (= the occupancy) of the
+// plain gated ones: left to the compiler they took 141-189 registers and a wave per SIMD less, and the skip step read 53.7-54.1 ms instead of
+// 53.2-53.4 (profiles/r06_skip_ab.txt: k_wrb_bwds_sj 616 -> 457 us, k_wrb_dxw<32, SJ> 507 -> 364 us).
 struct SkipJ {
     const e16* g = nullptr;        // nullptr: no join rides on this launch
     long half = 0;                 // elements between the two batches of g (0: one batch)

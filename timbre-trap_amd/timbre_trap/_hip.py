@@ -101,6 +101,7 @@ _PROTOS = {
     'tt_gate16': (c_int, [P, P, L, P]),
     'tt_sconv16_bwd_pregated': (c_int, [P, P, P, P, P, P, P, I, I, I, I, P]),
     'tt_tconv16_bwd_pregated': (c_int, [P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
+    'tt_latent16_pregated_ok': (c_int, [I, I]),
     'tt_latent16_expand_gated': (c_int, [P, P, P, P, P, I, I, I, I, I, P]),
     'tt_latent16_contract_pregated': (c_int, [P, P, P, P, I, I, I, I, I, I, P]),
     'tt_latent16_wgrad_pregated': (c_int, [P, I, F_, P, P, P, P, I, I, I, I, I, P]),
@@ -147,7 +148,7 @@ _PROTOS = {
     'tt_set_loss_scale': (c_float, [F_]),
 }
 # fp16 twins (include/ttrap.h: suffix _h): the 16-bit channels-last sources compiled a second time with -DTT_F16
-HALF_TWINS = ('tt_wide_level_scratch_bytes', 'tt_wide_level_bwd', 'tt_wide_level_bwd_gated', 'tt_wide_level_bwd_gated_join', 'tt_gate16', 'tt_latent16_expand_gated', 'tt_latent16_contract_pregated', 'tt_latent16_wgrad_pregated', 'tt_sconv16_bwd_pregated', 'tt_tconv16_bwd_pregated', 'tt_wide_scratch_bytes', 'tt_wide_pack', 'tt_wide_unpack', 'tt_wide_rb_fwd', 'tt_wide_rb_fwd_join', 'tt_wide_rb_bwd', 'tt_wide_fused_scratch_bytes',
+HALF_TWINS = ('tt_wide_level_scratch_bytes', 'tt_wide_level_bwd', 'tt_wide_level_bwd_gated', 'tt_wide_level_bwd_gated_join', 'tt_gate16', 'tt_latent16_pregated_ok', 'tt_latent16_expand_gated', 'tt_latent16_contract_pregated', 'tt_latent16_wgrad_pregated', 'tt_sconv16_bwd_pregated', 'tt_tconv16_bwd_pregated', 'tt_wide_scratch_bytes', 'tt_wide_pack', 'tt_wide_unpack', 'tt_wide_rb_fwd', 'tt_wide_rb_fwd_join', 'tt_wide_rb_bwd', 'tt_wide_fused_scratch_bytes',
               'tt_wide_rb_bwd_fused', 'tt_wide_onepass_scratch_bytes', 'tt_wide_rb_bwd_onepass', 'tt_wide_rb_bwd_is_onepass',
               'tt_stride16_scratch_bytes', 'tt_sconv16_fwd', 'tt_sconv16_bwd', 'tt_tconv16_fwd', 'tt_tconv16_bwd', 'tt_latent16_scratch_bytes',
               'tt_latent16_contract', 'tt_latent16_expand', 'tt_latent16_wgrad', 'tt_edge16_scratch_bytes', 'tt_convin16_fwd', 'tt_convin16_bwd',

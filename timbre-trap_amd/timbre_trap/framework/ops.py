@@ -1706,8 +1706,8 @@ class LatDec16Fn(torch.autograd.Function):
         z = _f32c(z)
         B, Dz, T = z.shape
         D, CT, E = w.size(0), w.size(1), w.size(2)
-        # the pregated backward carries the bias gradient in a free input row of the weight gradient: D < 48 / 144 (include/ttrap.h)
-        ctx.link = link if (link is not None and D < (48 if CT == 32 else 144)) else None
+        # the pregated backward carries the bias gradient in a free input row of the weight gradient: the library says where it can
+        ctx.link = link if (link is not None and lib16(cl16_dtype()).tt_latent16_pregated_ok(CT, D)) else None
         if ctx.link is not None:
             ctx.link.producer = True
         y = new_cl16(B, CT, E, T, z.device, cl16_dtype())

@@ -355,7 +355,8 @@ __global__ __launch_bounds__(NT, LAT_WGRAD_WAVES) void k_lat_wgrad(const e16* __
 
 template <int CT, int DT>
 __global__ __launch_bounds__(NT) void k_lat_wred(const float* __restrict__ part, const float* __restrict__ dbpart, float* __restrict__ dw,
-                                                  float* __restrict__ db, int D, int E, int nsplit, float scale, int db_row = -1) {
+                                                  float* __restrict__ db, int D, int E, int nsplit, float scale, int db_row = -1,
+                                                  float* __restrict__ dbrows = nullptr) {
     constexpr int NC = CT / 16, WPS = 4 / NC, WD = DT * 256;
     const int i = blockIdx.x * NT + threadIdx.x;                 // (h, ct, dump element)
     const int total = E * NC * WD;
@@ -368,23 +369,24 @@ __global__ __launch_bounds__(NT) void k_lat_wred(const float* __restrict__ part,
         const int lane = e & 63, r = (e >> 6) & 3, dt = e >> 8;
         const int d = 16 * dt + 4 * (lane >> 4) + r, c = 16 * ct + (lane & 15);
         if (d < D) dw[((long)d * CT + c) * E + h] += sum * scale;
-        else if (d == db_row && h == 0) {
-            // the row of ones (k_lat_zprep): its entry of row h is the sum of g over that row of the embedding.  ONE thread per channel adds
-            // the E rows in a fixed order (round 5 joined them with one atomicAdd per row: E contributions per channel in arrival order --
-            // the low bits of the bias gradient varied from run to run; advisor)
-            float tot = sum;
-            for (int hh = 1; hh < E; ++hh)
-                for (int ps = 0; ps < nsplit; ++ps)
-#pragma unroll
-                    for (int w2 = 0; w2 < WPS; ++w2) tot += part[(((long)ps * E + hh) * 4 + ct + NC * w2) * WD + e];
-            db[c] += tot * scale;
-        }
+        else if (d == db_row) dbrows[h * CT + c] = sum * scale;   // the row of ones (k_lat_zprep): the sum of g over row h of the embedding; k_lat_dbrows
+                                                                   // adds the E rows of a channel in a fixed order (round 5: one atomicAdd per row -- E
+                                                                   // contributions per channel in arrival order, low bits varying from run to run; advisor)
     } else if (db && db_row < 0 && i < total + CT * 16) {       // sixteen slices of the workgroups per channel, joined by atomics
         const int c = (i - total) % CT, sl = (i - total) / CT;
         float sum = 0.f;
         for (int wg = sl; wg < nsplit * E; wg += 16) sum += dbpart[(long)wg * 64 + c];
         atomicAdd(db + c, sum * scale);
     }
+}
+
+// db[c] += sum_h rows[h][c], one thread per channel, ascending h (the pregated bias gradient's second stage)
+__global__ __launch_bounds__(64) void k_lat_dbrows(const float* __restrict__ rows, float* __restrict__ db, int E, int CT) {
+    const int c = threadIdx.x;
+    if (c >= CT) return;
+    float t = 0.f;
+    for (int h = 0; h < E; ++h) t += rows[h * CT + c];
+    db[c] += t;
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------------------------
@@ -475,9 +477,15 @@ int run_wgrad(const float* z, int Dz, float fill, const e16* g_in, const e16* gy
     hipLaunchKernelGGL(kern, dim3(E * NSPLIT), dim3(NT), LDS, st, zt, g_in, gy, part, dbpart, E, T, npix, NSPLIT);
     TT_LAUNCH_CHECK();
     const int total = E * (CT / 16) * DT * 256 + CT * 16;
+    // (pregated: dbpart, unused by that form's weight-gradient kernel, holds the E x CT row sums between the two stages)
     hipLaunchKernelGGL((k_lat_wred<CT, DT>), dim3((total + NT - 1) / NT), dim3(NT), 0, st, part, dbpart, dw, (GATE || pregated) ? db : nullptr, D, E,
-                       NSPLIT, tt_loss_unscale(), one_row);
+                       NSPLIT, tt_loss_unscale(), one_row, dbpart);
     TT_LAUNCH_CHECK();
+    if (pregated) {
+        static_assert(CT <= 64, "one wave sums the channels");
+        hipLaunchKernelGGL(k_lat_dbrows, dim3(1), dim3(64), 0, st, dbpart, db, E, CT);
+        TT_LAUNCH_CHECK();
+    }
     return 0;
 }
 

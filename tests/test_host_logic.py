@@ -133,3 +133,20 @@ def test_gate_link_promises():
         ops.PREGATE = saved
     y = torch.zeros(1, 4, 3, 8, requires_grad=True)
     assert ops.gate_tap(y, None) is y and ops.gate_tap(y, ops.GateLink()) is y      # no producer marked: nothing to do
+
+
+def test_bench_core_cap_applies_before_torch_is_imported():
+    """`bench.py --cores K` (round 6: the one-GPU proxy for K host cores per rank) restricts the process's affinity when the module is imported --
+    before torch and its thread pools -- and tells OpenMP the same number."""
+    import os
+    import subprocess
+    import sys
+    import pytest
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if len(os.sched_getaffinity(0)) < 2:
+        pytest.skip('needs two cores to cap to one fewer')
+    code = ("import sys, os; sys.argv = ['bench.py', '--cores', '1']; sys.path.insert(0, %r); import bench; "
+            "print(len(os.sched_getaffinity(0)), bench.CORE_CAP, os.environ.get('OMP_NUM_THREADS'), bench.available_cores())" % root)
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split() == ['1', '1', '1', '1'], out.stdout

@@ -623,7 +623,9 @@ def main():
         pr = step_fn.state.pop('probe')
         cq = sum(e[0].elapsed_time(e[1]) for e in pr) / len(pr)
         wt = sum(e[1].elapsed_time(e[2]) for e in pr) / len(pr)
-        overlap_info = dict(cqt_on_compute_stream_ms=cq, wait_for_collective_after_cqt_ms=wt, backend=dist.get_backend(),
+        overlap_info = dict(cqt_on_compute_stream_ms=cq, wait_for_collective_after_cqt_ms=wt, backend=dist.get_backend(), world_size=world,
+                            communicator='one-rank communicator (TTRAP_FORCE_DIST=1): the collective is a no-op -- these figures show co-existence and stream '
+                                         'ordering, not bandwidth' if world == 1 else '%d ranks' % world,
                             note='RCCL runs the collective on its own stream; wait << allreduce_ms means it was hidden behind the CQT '
                                  '(gloo blocks the host instead: the figures are then host-side)')
     if multi:

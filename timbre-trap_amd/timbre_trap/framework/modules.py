@@ -264,7 +264,11 @@ class TimbreTrap(nn.Module):
         """What ``forward`` hands the decoder instead of ``apply_skip_connections(embeddings)`` on the 16-bit channels-last path: one
         ops.SkipJoin per embedding -- ``skip_weights[i] * e_i`` and the decoder's ``y + skip`` (reference modules.py:112, :569-589) are
         then ONE pass each way, on the encoder's own output tensors.  None where that does not apply (no skip connections, fp32 path,
-        embeddings that did not come from this encoder as 16-bit tensors, ops.SKIP_FUSED off)."""
+        embeddings that did not come from this encoder as 16-bit tensors, ops.SKIP_FUSED off).
+        ``defer`` (what ``forward`` passes): the embedding's share of a join's backward may be left to the backward of the encoder layer
+        behind the embedding (ops._join_backward) -- valid only where the decoder also takes the LATENTS of the same encoder pass, so that
+        every encoder layer's backward is certain to run after the joins': with detached latents those layers would never be reached and
+        the parked gradients would be lost.  Callers composing encode / decode themselves keep the default."""
         if (self.skip_weights is None or not ops.SKIP_FUSED or not ops.cl16_mode() or not isinstance(embeddings, EmbeddingList)
                 or not all(ops.is_cl16(e) and e.numel() % 8 == 0 for e in embeddings.raw)):
             return None

@@ -70,7 +70,18 @@ __global__ __launch_bounds__(NT) void k_wide_unpack(const e16* __restrict__ in, 
 // would put them on 4 / 8 different bank quads only.  The LDS image therefore stores channel group cg of column `col` at
 // position cg ^ cswz(col) of the pixel (a permutation of the DMA sources): any sixteen consecutive columns then cover all
 // sixteen bank quads (PMC before: SQ_LDS_BANK_CONFLICT = 4 x SQ_ACTIVE_INST_LDS).
-template <int C> __device__ __forceinline__ int cswz(int col) { return C == 32 ? ((col >> 2) & 3) : ((col >> 3) & 1); }
+#ifndef TT_CSWZ_NEW
+#define TT_CSWZ_NEW 1
+#endif
+// (round 6: ds_read_b128's lane groups are {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, + 32 -- not runs of sixteen lanes: with the round 2-5 placement
+//  ((col >> 2) & 3 / (col >> 3) & 1) a B-operand read took 7-8 LDS cycles instead of 4 (PMC: SQ_LDS_BANK_CONFLICT = 47-50 % of SQ_LDS_IDX_ACTIVE in
+//  k_wrb_conv).  TT_CSWZ_NEW (default) is the conflict-free placement for those groups, piece ^= 2 * bit 2 of the column (C = 32) / bit 2 (C = 16):
+//  conflicts 9.6 M -> 0 (C = 32), 10.9 M -> 1.1 M (C = 16) per launch, LDS-active cycles halved -- and the SAME time, isolated and in the step
+//  (profiles/r06_bwds_ablation.txt): the forward kernels were never bound by their LDS reads.  Shipped because it is right, not because it is faster.)
+template <int C> __device__ __forceinline__ int cswz(int col) {
+    if (TT_CSWZ_NEW) return C == 32 ? (((col >> 2) & 1) << 1) : ((col >> 2) & 1);
+    return C == 32 ? ((col >> 2) & 3) : ((col >> 3) & 1);
+}
 // Measured at the bench shape (B 64, C 32, H 65, T 1024; 0.20 ms per launch = 4.1 TB/s over x + y + h1):
 //   staging alone 0.066 ms, products + epilogue + stores alone 0.134 ms, and they add up -- but an explicit double-buffered tile
 //   ring (8 waves, next tile's DMA issued before this tile's products, exact-count vmcnt waits so the stores keep draining)

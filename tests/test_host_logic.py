@@ -150,3 +150,22 @@ def test_bench_core_cap_applies_before_torch_is_imported():
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.split() == ['1', '1', '1', '1'], out.stdout
+
+
+def test_default_dual_window_can_be_pinned_from_the_environment():
+    """TTRAP_CQT_DUAL (round-5 advisor finding): the reference's scripts build ``TimbreTrap(...)`` and never see ``conventions=``; the environment pins
+    the dual window they get -- additive (default) | canonical | floored -- and anything else is refused at import."""
+    import os
+    import subprocess
+    import sys
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'timbre-trap_amd')
+    code = "import sys; sys.path.insert(0, %r); from timbre_trap.framework import nsgt_plan as p; print(p.DEFAULT_CONVENTIONS.dual)" % pkg
+    for env, want in ((None, 'additive'), ('floored', 'floored'), ('canonical', 'canonical')):
+        e = dict(os.environ)
+        e.pop('TTRAP_CQT_DUAL', None)
+        if env:
+            e['TTRAP_CQT_DUAL'] = env
+        out = subprocess.run([sys.executable, '-c', code], env=e, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0 and out.stdout.strip() == want, (env, out.stdout, out.stderr[-500:])
+    bad = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, TTRAP_CQT_DUAL='flored'), capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and 'TTRAP_CQT_DUAL' in bad.stderr

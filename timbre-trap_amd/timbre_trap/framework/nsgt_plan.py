@@ -11,6 +11,7 @@ bin, and the canonical dual windows ("painless" case) for synthesis.
 """
 
 import math
+import os
 from dataclasses import dataclass, replace
 
 import numpy as np
@@ -71,7 +72,19 @@ class NSGTConventions:
         return replace(self, **kw)
 
 
-DEFAULT_CONVENTIONS = NSGTConventions()
+def _default_conventions():
+    """The conventions a ``CQT(...)`` built without the ``conventions`` argument gets -- i.e. what the reference's unmodified scripts get, which
+    construct ``TimbreTrap(...)`` and never see that argument.  TTRAP_CQT_DUAL = additive (default) | canonical | floored pins the dual window from
+    the environment: the default dual changed in round 5 (the recalled dense form instead of the noise-robust floor of rounds 1-4) on the strength
+    of a recollection, not of a fixture -- a user who sonifies network outputs and wants the band-edge indices silent sets ``floored`` without
+    touching any script (round-5 advisor finding)."""
+    dual = os.environ.get('TTRAP_CQT_DUAL', 'additive')
+    if dual not in ('additive', 'canonical', 'floored'):
+        raise ValueError('TTRAP_CQT_DUAL must be additive, canonical or floored, got %r' % (dual,))
+    return NSGTConventions(dual=dual)
+
+
+DEFAULT_CONVENTIONS = _default_conventions()
 _ROUND = {'round': np.round, 'floor': np.floor, 'ceil': np.ceil}
 
 

@@ -202,6 +202,8 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_conv(const e16* __restrict__ x
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 
+        // (Round 6, measured and dropped: the row loop unrolled by two at C = 16 -- two independent chains of five matrix products per body: isolated
+        //  0.208 / 0.208 / 0.206 -> 0.195 / 0.205 / 0.203 ms, train step 51.33 / 51.01 / 50.97 -> 51.16 / 51.03 / 51.00 ms: nothing.)
         for (int r = 0; r < G::TH; ++r) {
             const int h = h0 + r;
             if (h >= H) break;

@@ -33,6 +33,23 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+// The same with the non-temporal hint (cache-policy bit 1 = nt on gfx940+): for tensors a backward kernel reads for the LAST time -- the block input x and
+// the hidden activation h1, both written by the forward pass tens of milliseconds earlier -- so that they do not displace the gradients, which the previous
+// kernel wrote a moment ago and the next one reads at once, from the L2 / memory-side cache (round 6; TT_BWD_NT_X / TT_BWD_NT_H1).  Measured
+// (profiles/r06_cache_hints_ab.txt): x streamed 50.43 / 50.13 / 50.68 -> 50.13 / 49.99 / 50.17 ms per step; h1 streamed AS WELL 50.41 / 50.65 / 50.60 -- its
+// tiles carry a halo that the neighbouring tiles re-read, and a streamed line is gone by then: h1 stays an ordinary load.
+#ifndef TT_BWD_NT_X
+#define TT_BWD_NT_X 1
+#endif
+#ifndef TT_BWD_NT_H1
+#define TT_BWD_NT_H1 0
+#endif
+__device__ __forceinline__ void glds16_nt(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 2);
+}
+__device__ __forceinline__ void glds16_x(const void* gsrc, void* lds_wave_base) { if (TT_BWD_NT_X) glds16_nt(gsrc, lds_wave_base); else glds16(gsrc, lds_wave_base); }
+__device__ __forceinline__ void glds16_h1(const void* gsrc, void* lds_wave_base) { if (TT_BWD_NT_H1) glds16_nt(gsrc, lds_wave_base); else glds16(gsrc, lds_wave_base); }
 // A (16 x 32) . B (32 x 16): lane l holds row / column l & 15 and k = 8 (l >> 4) + j; D: column l & 15, rows 4 (l >> 4) + r
 #if defined(TT_F16)
 __device__ __forceinline__ f32x4 mma32(e16x8 a, e16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }

@@ -586,7 +586,7 @@ __device__ __forceinline__ void wrb_bwds_body(const e16* __restrict__ x, const e
                     const e16* hr_ = h1 + rowoff;
 #pragma unroll
                     for (int part = 0; part < G::IPR; ++part)
-                        if (part * 64 + lane < G::RPP) { glds16(gr_ + roff[part], rdst + part * 1024); glds16(hr_ + coff[part], hdst + part * 1024); }
+                        if (part * 64 + lane < G::RPP) { glds16(gr_ + roff[part], rdst + part * 1024); glds16_h1(hr_ + coff[part], hdst + part * 1024); }
                 } else {
 #pragma unroll
                     for (int part = 0; part < G::IPR; ++part) {
@@ -595,7 +595,7 @@ __device__ __forceinline__ void wrb_bwds_body(const e16* __restrict__ x, const e
                         const int t = t0 - D + px;
                         const bool ok = (unsigned)t < (unsigned)T;
                         const long off = ib + ((long)h * T + (t0 - D)) * C;
-                        if (p < G::RPP) { glds16(ok ? dy + off + roff[part] : zero, rdst + part * 1024); glds16(ok ? h1 + off + coff[part] : zero, hdst + part * 1024); }
+                        if (p < G::RPP) { glds16(ok ? dy + off + roff[part] : zero, rdst + part * 1024); glds16_h1(ok ? h1 + off + coff[part] : zero, hdst + part * 1024); }
                     }
                 }
             }
@@ -608,7 +608,7 @@ __device__ __forceinline__ void wrb_bwds_body(const e16* __restrict__ x, const e
                     const int h = X0 + row;
                     const int px = ((i + lane) / G::CG) % TW;
                     const bool ok = h < H && (!edge || t0 + px < T);
-                    glds16(ok ? x + ib + ((long)h * T + t0) * C + xoff[it] : zero, xst + (long)i * 16);
+                    glds16_x(ok ? x + ib + ((long)h * T + t0) * C + xoff[it] : zero, xst + (long)i * 16);
                 }
             };
             if constexpr (XE) { if (j > 0) stage_x(); }

@@ -70,6 +70,16 @@ __global__ __launch_bounds__(NT) void k_wide_unpack(const e16* __restrict__ in, 
 // would put them on 4 / 8 different bank quads only.  The LDS image therefore stores channel group cg of column `col` at
 // position cg ^ cswz(col) of the pixel (a permutation of the DMA sources): any sixteen consecutive columns then cover all
 // sixteen bank quads (PMC before: SQ_LDS_BANK_CONFLICT = 4 x SQ_ACTIVE_INST_LDS).
+#ifndef TT_H1_NT
+#define TT_H1_NT 1
+#endif
+// The hidden activation is written for the BACKWARD pass, tens of milliseconds away: a non-temporal store keeps it from displacing the block's
+// output -- which the next kernel reads at once -- in the L2 / memory-side cache (TT_H1_NT, round 6: 50.97 / 50.74 / 50.68 -> 50.45 / 50.39 / 50.37 ms
+// per step, same box, profiles/r06_cache_hints_ab.txt; the isolated call does not change -- it is a cache effect between kernels)
+template <class V> __device__ __forceinline__ void h1_store(V* p, const V& v) {
+    if (TT_H1_NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
 #ifndef TT_CSWZ_NEW
 #define TT_CSWZ_NEW 1
 #endif
@@ -275,7 +285,7 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_conv(const e16* __restrict__ x
                     e16x8 hq;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) hq[j] = (e16)val[j];
-                    if (SAVE && valid) *reinterpret_cast<e16x8*>(h1 + pix * C + 8 * g) = hq;
+                    if (SAVE && valid) h1_store(reinterpret_cast<e16x8*>(h1 + pix * C + 8 * g), hq);
                     f32x4 z0 = mma32(A2[0], hq, f32x4{b2r[0], b2r[1], b2r[2], b2r[3]});
                     f32x4 z1 = mma32(A2[1], hq, f32x4{b2r[4], b2r[5], b2r[6], b2r[7]});
                     e16x8 o;
@@ -294,7 +304,7 @@ __global__ __launch_bounds__(NT, MINW) void k_wrb_conv(const e16* __restrict__ x
                     e16x4 hq;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) hq[j] = (e16)val[j];
-                    if (SAVE && valid) *reinterpret_cast<e16x4*>(h1 + pix * C + 4 * g) = hq;
+                    if (SAVE && valid) h1_store(reinterpret_cast<e16x4*>(h1 + pix * C + 4 * g), hq);
                     const f32x4 z = mma16(A2s, __builtin_bit_cast(s16x4, hq), f32x4{b2r[0], b2r[1], b2r[2], b2r[3]});
                     const int colc = c0 + n + D, pxc = (r + D) * G::RW + colc;
                     const e16x4 xc = *reinterpret_cast<const e16x4*>(smem + ((long)pxc * C + 8 * ((g >> 1) ^ cswz<C>(colc)) + 4 * (g & 1)) * 2);
@@ -669,7 +679,7 @@ __global__ __launch_bounds__(NT, (GOUT && C == 32) ? 3 : 2) void k_wrb_dxw(const
             const int row = q / TW, px = q - row * TW;
             const int h = h0 + row, t = t0 + px;
             const bool ok = p < G::XNP && h < H && t < T;
-            glds16(ok ? x + ib + ((long)h * T + t) * C + (s ^ fswz<C>(px)) * 8 : zero, xs + (long)i * 16);
+            glds16_x(ok ? x + ib + ((long)h * T + t) * C + (s ^ fswz<C>(px)) * 8 : zero, xs + (long)i * 16);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1087,7 +1097,7 @@ __global__ __launch_bounds__(NT, (C == 8 && MODE != 1) ? 3 : 1) void k_nrb_conv(
                 vec_t hq;
 #pragma unroll
                 for (int c = 0; c < C; ++c) hq[c] = (e16)elu_res(acc[c >> 2][c & 3]);
-                if (SAVE && valid) *reinterpret_cast<vec_t*>(h1 + pix * C) = hq;
+                if (SAVE && valid) h1_store(reinterpret_cast<vec_t*>(h1 + pix * C), hq);
                 f32x4 z[NB];
 #pragma unroll
                 for (int ob = 0; ob < NB; ++ob) {
@@ -1402,12 +1412,12 @@ __global__ __launch_bounds__(NT, C == 8 ? 2 : TT_NBF2_MINW4) void k_nrb_bwd_fuse
             for (int it = 0; it < NITD; ++it) {
                 const int i = wave * 64 + it * NT;
                 if (it + 1 < NITD || i + lane < G::NP) {         // (only the last round has lanes past the image)
-                    glds16(hb + rel[it], hs + (long)i * 16);
+                    glds16_h1(hb + rel[it], hs + (long)i * 16);
                     glds16(gb + rel[it], gs + (long)i * 16);
                 }
             }
 #pragma unroll
-            for (int it = 0; it < NITX; ++it) glds16(xb + relx[it], xs + (long)(wave * 64 + it * NT) * 16);
+            for (int it = 0; it < NITX; ++it) glds16_x(xb + relx[it], xs + (long)(wave * 64 + it * NT) * 16);
         } else {
             for (int i = wave * 64; i < G::NPR; i += NT) {
                 const int p = i + lane, q = p * G::PPP;
@@ -1416,7 +1426,7 @@ __global__ __launch_bounds__(NT, C == 8 ? 2 : TT_NBF2_MINW4) void k_nrb_bwd_fuse
                 const bool ok = (unsigned)h < (unsigned)H && (unsigned)t < (unsigned)T;
                 const long off = ib + ((long)h * T + t) * C;
                 if (p < G::NP) {
-                    glds16(ok ? h1 + off : zero, hs + (long)i * 16);
+                    glds16_h1(ok ? h1 + off : zero, hs + (long)i * 16);
                     glds16(ok ? dy + off : zero, gs + (long)i * 16);
                 }
             }
@@ -1425,7 +1435,7 @@ __global__ __launch_bounds__(NT, C == 8 ? 2 : TT_NBF2_MINW4) void k_nrb_bwd_fuse
                 const int q = (wave * 64 + it * NT + lane) * G::PPP;
                 const int row = q / G::TW, px = q - row * G::TW;
                 const bool ok = h0 + row < H && t0 + px < T;
-                glds16(ok ? x + ib + ((long)(h0 + row) * T + t0 + px) * C : zero, xs + (long)(wave * 64 + it * NT) * 16);
+                glds16_x(ok ? x + ib + ((long)(h0 + row) * T + t0 + px) * C : zero, xs + (long)(wave * 64 + it * NT) * 16);
             }
         }
         // h1 and dy complete (this wave's pieces; the barrier collects the others'), the NITX pieces of x still in flight.  A bare

@@ -74,6 +74,10 @@ __device__ __forceinline__ int xcd_order(int v, int n) {          // see conv_mf
     const int per = n >> 3;
     return v < (per << 3) ? (v & 7) * per + (v >> 3) : v;
 }
+// (Round 6, measured and dropped: the persistent tile walks of CONSECUTIVE kernels in OPPOSITE directions -- the residual blocks of a level alternating by
+//  dilation, k_wrb_dxw against k_wrb_bwd_a -- so that a consumer starts with the tiles its producer wrote last and finds them in the 256 MB memory-side
+//  cache (a 64-clip tensor is 283 MB): 50.47 / 50.02 / 49.82 / 50.03 ms per step without, 50.07 / 49.80 / 49.98 / 50.35 with -- nothing;
+//  profiles/r06_cache_hints_ab.txt.)
 // ELU and its derivative with as few vector instructions as the values allow (the bf16 kernels are bound by VALU issue:
 // PMC of round 3, profiles/r03_*): with e = exp(a) - 1, ELU(a) = a for a > 0 (the smaller of a and e, above 0) and e for a <= 0
 // (the larger, at most 0) = the median of (a, e, 0): one v_med3_f32 instead of compare + select.  Two caveats, both handled here:

@@ -24,8 +24,9 @@ SCRIPT = textwrap.dedent('''
     torch.cuda.set_device(0)
     torch.manual_seed(7 + rank)                      # different initial weights per rank: the broadcast must fix that
     amp = os.environ.get('TT_TEST_AUTOCAST') == '1'   # the bench's configuration: bf16 channels-last path under autocast, mc 2
+    skip = os.environ.get('TT_TEST_SKIP') == '1'      # the configs[4] model: fused / riding skip joins, their weights' gradient in the flat buffer
     model = TimbreTrap(sample_rate=22050, n_octaves=9, bins_per_octave=60, latent_size=128 if amp else 32,
-                       model_complexity=2 if amp else 1).cuda()
+                       model_complexity=2 if amp else 1, skip_connections=skip).cuda()
     opt = FusedAdamW(model.parameters(), lr=1e-3, max_norm=10.0)
     broadcast_parameters(opt.flat_param)
     g = torch.Generator().manual_seed(123)
@@ -53,9 +54,10 @@ SCRIPT = textwrap.dedent('''
 ''') % (ROOT, ROOT)
 
 
-def _run(rank, world, port, amp=False, model_zero=False):
+def _run(rank, world, port, amp=False, model_zero=False, skip=False):
     env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
-               TTRAP_DIST_BACKEND='gloo', TT_TEST_AUTOCAST='1' if amp else '0', TT_TEST_MODEL_ZERO='1' if model_zero else '0')
+               TTRAP_DIST_BACKEND='gloo', TT_TEST_AUTOCAST='1' if amp else '0', TT_TEST_MODEL_ZERO='1' if model_zero else '0',
+               TT_TEST_SKIP='1' if skip else '0')
     return subprocess.Popen([sys.executable, '-c', SCRIPT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
 
 
@@ -67,12 +69,12 @@ def _result(proc):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('amp', [False, True], ids=['fp32', 'autocast-bf16'])
-def test_two_ranks_match_single_process_global_batch(amp):
-    procs = [_run(r, 2, 29541 + 4 * amp, amp) for r in range(2)]
+@pytest.mark.parametrize('amp,skip', [(False, False), (True, False), (True, True)], ids=['fp32', 'autocast-bf16', 'autocast-bf16-skip-connections'])
+def test_two_ranks_match_single_process_global_batch(amp, skip):
+    procs = [_run(r, 2, 29541 + 4 * amp + 8 * skip, amp, skip=skip) for r in range(2)]
     res = [_result(p) for p in procs]
     assert res[0] == res[1]                                       # ranks end with bit-identical parameters
-    single = _result(_run(0, 1, 29542 + 4 * amp, amp))
+    single = _result(_run(0, 1, 29542 + 4 * amp + 8 * skip, amp, skip=skip))
     tol = 1e-4 if amp else 1e-5                                   # bf16 step: the same products summed in another order, then Adam
     assert abs(res[0][0] - single[0]) <= tol * abs(single[1]) and abs(res[0][1] - single[1]) <= tol * abs(single[1])
 
